@@ -1,0 +1,367 @@
+// acc.hip -- a9: GroupsAccumulator (SUM / AVG / COUNT / MIN / MAX) for AggregateExec on gfx950.
+//
+// Reference: expr/src/groups_accumulator.rs:78-164; physical-expr/src/aggregate/{sum,average,count,min_max}.rs;
+// groups_accumulator/{prim_op,accumulate}.rs; aggregate/utils.rs:55-125 (DecimalAverager).
+//
+// State lives in HBM, one slot per group: value/sum (8 B, or 16 B lo|hi for Decimal128), count (AVG, COUNT),
+// seen byte (NullState).  Two update paths:
+//   * few groups (<= 8, e.g. TPC-H Q1's 4): every lane keeps all group partials in registers over a
+//     grid-stride loop (compare-select, no divergence, no atomics in the loop), then wave shuffle
+//     reduce -> LDS -> one global atomic per workgroup and group.
+//   * many groups (Q3: 1e6, Q18: 1.5e8): one device-scope atomic per row; Decimal128 wrapping add is two
+//     64-bit atomics with the carry taken from the value the low add returned (exact mod 2^128).
+// Float64 SUM is order dependent in the reference too (sequential add in row order, prim_op.rs:101-109):
+// the contract is <= 1e-9 relative.
+#include "int128.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace dfgpu {
+constexpr uint32_t GID_NONE = 0xFFFFFFFFu;
+enum { CLS_I64 = 0, CLS_U64 = 1, CLS_F64 = 2, CLS_I128 = 3 };
+}
+using namespace dfgpu;
+
+struct dfgpu_acc {
+  dfgpu_ctx* ctx = nullptr; int kind = 0;
+  int32_t in_type = 0, in_precision = 0, in_scale = 0;
+  int32_t state_type = 0, state_precision = 0, state_scale = 0;
+  int32_t out_type = 0, out_precision = 0, out_scale = 0;
+  int cls = 0; int width = 8;
+  int64_t n = 0, cap = 0;
+  BufferPtr vals, counts, seen;     // vals: width B/group; counts: 8 B/group (AVG u64, COUNT i64); seen: 1 B/group
+};
+
+namespace dfgpu {
+
+__device__ inline bool filter_pass(const uint64_t* fbits, const uint64_t* fvalid, int64_t i) {
+  return fbits == nullptr || (bit_get(fbits, i) && valid_at(fvalid, i));
+}
+__device__ inline i128 acc_cell_int(const ColView& c, int64_t r) {
+  switch (c.type) {
+    case DFGPU_INT8: return ((const int8_t*)c.values)[r]; case DFGPU_INT16: return ((const int16_t*)c.values)[r];
+    case DFGPU_INT32: case DFGPU_DATE32: return ((const int32_t*)c.values)[r]; case DFGPU_INT64: return ((const int64_t*)c.values)[r];
+    case DFGPU_UINT8: return ((const uint8_t*)c.values)[r]; case DFGPU_UINT16: return ((const uint16_t*)c.values)[r];
+    case DFGPU_UINT32: return ((const uint32_t*)c.values)[r]; case DFGPU_UINT64: return (i128)((const uint64_t*)c.values)[r];
+    case DFGPU_DECIMAL128: return load_i128(c.values, r);
+    default: return 0;
+  }
+}
+__device__ inline double acc_cell_f64(const ColView& c, int64_t r) { return c.type == DFGPU_FLOAT32 ? (double)((const float*)c.values)[r] : ((const double*)c.values)[r]; }
+
+__device__ inline void atomic_add_i128(uint64_t* slot, i128 v) {
+  uint64_t lo = (uint64_t)(u128)v, hi = (uint64_t)((u128)v >> 64);
+  uint64_t old = atomicAdd((unsigned long long*)&slot[0], (unsigned long long)lo);
+  uint64_t carry = (uint64_t)(old + lo < old);
+  if (hi + carry) atomicAdd((unsigned long long*)&slot[1], (unsigned long long)(hi + carry));
+}
+__device__ inline void atomic_min_f64(double* p, double x, bool is_min) {
+  unsigned long long* q = (unsigned long long*)p; unsigned long long old = *q;
+  for (;;) { double cur = __longlong_as_double((long long)old); bool repl = is_min ? (cur > x) : (cur < x); if (!repl) return;
+    unsigned long long prev = atomicCAS(q, old, (unsigned long long)__double_as_longlong(x)); if (prev == old) return; old = prev; }
+}
+
+// ------------------------------------------------------------ many groups: one atomic per row
+__global__ void __launch_bounds__(BLOCK) k_acc_update(int kind, int cls, ColView v, int has_values, const uint32_t* gids, const uint64_t* fbits, const uint64_t* fvalid,
+                                                      int64_t n, int64_t total, void* vals, uint64_t* counts, uint8_t* seen, int count_only_valid, uint32_t* flags) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    uint32_t g = gids[i];
+    if (g == GID_NONE || !filter_pass(fbits, fvalid, i)) continue;
+    if ((int64_t)g >= total) { atomicOr(flags, DFGPU_FLAG_OOB); continue; }
+    int64_t r = i; bool ok = !has_values || cell_resolve(v, i, &r);
+    if (kind == DFGPU_AGG_COUNT) { if (ok || !count_only_valid) atomicAdd((unsigned long long*)&counts[g], 1ull); continue; }
+    if (!ok) continue;
+    seen[g] = 1;
+    if (kind == DFGPU_AGG_AVG) atomicAdd((unsigned long long*)&counts[g], 1ull);
+    if (kind == DFGPU_AGG_SUM || kind == DFGPU_AGG_AVG) {
+      if (cls == CLS_F64) unsafeAtomicAdd((double*)vals + g, acc_cell_f64(v, r));
+      else if (cls == CLS_I128) atomic_add_i128((uint64_t*)vals + 2 * (int64_t)g, acc_cell_int(v, r));
+      else atomicAdd((unsigned long long*)vals + g, (unsigned long long)(uint64_t)acc_cell_int(v, r));     // wrapping i64 / u64
+    } else {
+      bool is_min = kind == DFGPU_AGG_MIN;
+      if (cls == CLS_F64) atomic_min_f64((double*)vals + g, acc_cell_f64(v, r), is_min);
+      else if (cls == CLS_U64) { unsigned long long x = (unsigned long long)(uint64_t)acc_cell_int(v, r); if (is_min) atomicMin((unsigned long long*)vals + g, x); else atomicMax((unsigned long long*)vals + g, x); }
+      else if (cls == CLS_I64) { long long x = (long long)acc_cell_int(v, r); if (is_min) atomicMin((long long*)vals + g, x); else atomicMax((long long*)vals + g, x); }
+      else { long long hi = (long long)(acc_cell_int(v, r) >> 64); if (is_min) atomicMin((long long*)vals + 2 * (int64_t)g + 1, hi); else atomicMax((long long*)vals + 2 * (int64_t)g + 1, hi); }   // i128 pass 1: high word
+    }
+  }
+}
+// Decimal128 MIN/MAX pass 2: among rows whose high word equals the group's extreme high word, extreme of the low word
+__global__ void __launch_bounds__(BLOCK) k_acc_minmax128_lo(int is_min, ColView v, const uint32_t* gids, const uint64_t* fbits, const uint64_t* fvalid, int64_t n, uint64_t* vals) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    uint32_t g = gids[i]; int64_t r;
+    if (g == GID_NONE || !filter_pass(fbits, fvalid, i) || !cell_resolve(v, i, &r)) continue;
+    i128 x = acc_cell_int(v, r);
+    if ((uint64_t)((u128)x >> 64) != vals[2 * (int64_t)g + 1]) continue;
+    unsigned long long lo = (unsigned long long)(uint64_t)(u128)x;
+    if (is_min) atomicMin((unsigned long long*)&vals[2 * (int64_t)g], lo); else atomicMax((unsigned long long*)&vals[2 * (int64_t)g], lo);
+  }
+}
+__global__ void k_minmax128_prepare(int is_min, uint64_t* vals, const uint64_t* old_hi, int64_t total) {   // reset low words whose high word moved
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < total && vals[2 * g + 1] != old_hi[g]) vals[2 * g] = is_min ? ~0ull : 0ull;
+}
+__global__ void k_copy_hi(const uint64_t* vals, uint64_t* hi, int64_t total) { int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (g < total) hi[g] = vals[2 * g + 1]; }
+
+// ------------------------------------------------------------ few groups: register partials
+template <typename T> __device__ inline T wave_sum_any(T v) { return wave_sum(v); }
+template <> __device__ inline i128 wave_sum_any<i128>(i128 v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    uint64_t lo = __shfl_xor((unsigned long long)(uint64_t)(u128)v, d, 64), hi = __shfl_xor((unsigned long long)(uint64_t)((u128)v >> 64), d, 64);
+    v = (i128)((u128)v + (((u128)hi << 64) | lo));
+  }
+  return v;
+}
+constexpr int SMALL_G = 8;
+template <typename T, int CLS>
+__global__ void __launch_bounds__(BLOCK) k_acc_small(int kind, ColView v, int has_values, const uint32_t* gids, const uint64_t* fbits, const uint64_t* fvalid,
+                                                     int64_t n, int G, void* vals, uint64_t* counts, uint8_t* seen, int count_only_valid) {
+  T acc[SMALL_G]; uint64_t cnt[SMALL_G];
+#pragma unroll
+  for (int k = 0; k < SMALL_G; k++) { acc[k] = 0; cnt[k] = 0; }
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    uint32_t g = gids[i];
+    if (g == GID_NONE || !filter_pass(fbits, fvalid, i)) continue;
+    int64_t r = i; bool ok = !has_values || cell_resolve(v, i, &r);
+    if (kind == DFGPU_AGG_COUNT) { if (!(ok || !count_only_valid)) continue; }
+    else if (!ok) continue;
+    T x = 0;
+    if (kind != DFGPU_AGG_COUNT) { if constexpr (CLS == CLS_F64) x = acc_cell_f64(v, r); else x = (T)acc_cell_int(v, r); }
+#pragma unroll
+    for (int k = 0; k < SMALL_G; k++) { bool m = g == (uint32_t)k; acc[k] += m ? x : (T)0; cnt[k] += m ? 1u : 0u; }
+  }
+  __shared__ T s_acc[BLOCK / WAVE][SMALL_G]; __shared__ uint64_t s_cnt[BLOCK / WAVE][SMALL_G];
+  int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < SMALL_G; k++) { T a = wave_sum_any<T>(acc[k]); uint64_t c = wave_sum(cnt[k]); if (lane_id() == 0) { s_acc[wave][k] = a; s_cnt[wave][k] = c; } }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    int k = threadIdx.x; T a = 0; uint64_t c = 0;
+    for (int w = 0; w < BLOCK / WAVE; w++) { a += s_acc[w][k]; c += s_cnt[w][k]; }
+    if (c) {
+      if (kind == DFGPU_AGG_COUNT) { atomicAdd((unsigned long long*)&counts[k], (unsigned long long)c); return; }
+      seen[k] = 1;
+      if (kind == DFGPU_AGG_AVG) atomicAdd((unsigned long long*)&counts[k], (unsigned long long)c);
+      if constexpr (CLS == CLS_F64) unsafeAtomicAdd((double*)vals + k, a);
+      else if constexpr (CLS == CLS_I128) atomic_add_i128((uint64_t*)vals + 2 * k, a);
+      else atomicAdd((unsigned long long*)vals + k, (unsigned long long)a);
+    }
+  }
+}
+
+// ------------------------------------------------------------ emit
+__global__ void __launch_bounds__(BLOCK) k_seen_to_bits(const uint8_t* seen, int64_t n, uint64_t* bits) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  uint64_t m = ballot64(i < n && seen[i]);
+  if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) bits[i >> 6] = m;
+}
+__global__ void k_narrow(const uint64_t* vals, int64_t n, int32_t type, void* out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  switch (type) {
+    case DFGPU_INT8: case DFGPU_UINT8: ((uint8_t*)out)[i] = (uint8_t)vals[i]; break;
+    case DFGPU_INT16: case DFGPU_UINT16: ((uint16_t*)out)[i] = (uint16_t)vals[i]; break;
+    case DFGPU_INT32: case DFGPU_UINT32: case DFGPU_DATE32: ((uint32_t*)out)[i] = (uint32_t)vals[i]; break;
+    case DFGPU_FLOAT32: ((float*)out)[i] = (float)__longlong_as_double((long long)vals[i]); break;
+    default: ((uint64_t*)out)[i] = vals[i];
+  }
+}
+__global__ void k_avg_f64(const double* sums, const uint64_t* counts, const uint8_t* seen, int64_t n, double* out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = seen[i] ? sums[i] / (double)counts[i] : 0.0;     // average.rs:166
+}
+// DecimalAverager::avg (aggregate/utils.rs:108-124)
+__global__ void k_avg_dec(const uint64_t* sums, const uint64_t* counts, const uint8_t* seen, int64_t n, i128 factor, int precision, uint64_t* out, uint32_t* flags) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  i128 v = 0;
+  if (seen[i]) {
+    i128 prod;
+    if (!mul128_checked(load_i128(sums, i), factor, &prod)) atomicOr(flags, DFGPU_FLAG_OVERFLOW);
+    else { v = sdiv128(prod, (i128)counts[i], nullptr); if (!decimal_fits(v, precision)) { atomicOr(flags, DFGPU_FLAG_OVERFLOW); v = 0; } }
+  }
+  store_i128(out, i, v);
+}
+__global__ void k_fill64(uint64_t* p, int64_t from, int64_t to, uint64_t v, int stride, int off) {
+  int64_t i = from + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < to) p[i * stride + off] = v;
+}
+
+static int imin(int a, int b) { return a < b ? a : b; }
+
+static void acc_resize(dfgpu_acc* a, int64_t total) {
+  dfgpu_ctx* ctx = a->ctx;
+  if (total <= a->n) return;
+  if (total > a->cap) {
+    int64_t nc = a->cap ? a->cap : 1024; while (nc < total) nc *= 2;
+    BufferPtr nv = alloc_buffer(ctx, (size_t)nc * a->width), ncnt = alloc_buffer(ctx, (size_t)nc * 8), ns = alloc_buffer(ctx, (size_t)nc);
+    if (a->n) { HIP_CHECK(hipMemcpyAsync(nv->ptr, a->vals->ptr, (size_t)a->n * a->width, hipMemcpyDeviceToDevice, ctx->stream));
+                HIP_CHECK(hipMemcpyAsync(ncnt->ptr, a->counts->ptr, (size_t)a->n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                HIP_CHECK(hipMemcpyAsync(ns->ptr, a->seen->ptr, (size_t)a->n, hipMemcpyDeviceToDevice, ctx->stream)); }
+    a->vals = nv; a->counts = ncnt; a->seen = ns; a->cap = nc;
+  }
+  int64_t add = total - a->n;
+  HIP_CHECK(hipMemsetAsync((char*)a->counts->ptr + a->n * 8, 0, (size_t)add * 8, ctx->stream));
+  HIP_CHECK(hipMemsetAsync((char*)a->seen->ptr + a->n, 0, (size_t)add, ctx->stream));
+  if (a->kind == DFGPU_AGG_MIN || a->kind == DFGPU_AGG_MAX) {
+    bool mn = a->kind == DFGPU_AGG_MIN; uint64_t init;
+    // starting values: NATIVE::MAX for MIN, NATIVE::MIN for MAX (min_max.rs:102-139); integer state is widened to 64 bit
+    if (a->cls == CLS_F64) { double d = a->state_type == DFGPU_FLOAT32 ? 3.40282346638528859812e+38 : 1.7976931348623157e308; if (!mn) d = -d; memcpy(&init, &d, 8); }
+    else if (a->cls == CLS_U64) { uint64_t mx = a->state_type == DFGPU_UINT8 ? 0xFFull : a->state_type == DFGPU_UINT16 ? 0xFFFFull : a->state_type == DFGPU_UINT32 ? 0xFFFFFFFFull : ~0ull; init = mn ? mx : 0; }
+    else { int bits = a->cls == CLS_I128 ? 64 : type_width(a->state_type) * 8; int64_t mx = bits == 64 ? INT64_MAX : ((1ll << (bits - 1)) - 1); int64_t mnv = bits == 64 ? INT64_MIN : -(1ll << (bits - 1)); init = (uint64_t)(mn ? mx : mnv); }
+    dim3 grid(grid_for(add, BLOCK)), block(BLOCK);
+    if (a->cls == CLS_I128) { hipLaunchKernelGGL(k_fill64, grid, block, 0, ctx->stream, (uint64_t*)a->vals->ptr, a->n, total, init, 2, 1);
+                              hipLaunchKernelGGL(k_fill64, grid, block, 0, ctx->stream, (uint64_t*)a->vals->ptr, a->n, total, mn ? ~0ull : 0ull, 2, 0); }
+    else hipLaunchKernelGGL(k_fill64, grid, block, 0, ctx->stream, (uint64_t*)a->vals->ptr, a->n, total, init, 1, 0);
+    KERNEL_CHECK();
+  } else HIP_CHECK(hipMemsetAsync((char*)a->vals->ptr + a->n * a->width, 0, (size_t)add * a->width, ctx->stream));
+  a->n = total;
+}
+
+static void launch_update(dfgpu_acc* a, int kind, int cls, const dfgpu_array* values, const dfgpu_array* gids, const dfgpu_array* filt, int64_t total, void* vals) {
+  dfgpu_ctx* ctx = a->ctx; int64_t n = gids->length;
+  if (gids->type != DFGPU_UINT32) fail(DFGPU_INVALID_ARGUMENT, "group ids must be a UINT32 array");
+  if (values && values->length != n) fail(DFGPU_INVALID_ARGUMENT, "values (%lld rows) and group ids (%lld rows) differ in length", (long long)values->length, (long long)n);
+  if (filt && (filt->type != DFGPU_BOOL || filt->length != n)) fail(DFGPU_INVALID_ARGUMENT, "opt_filter must be a Boolean array of the batch length");
+  if (!n) return;
+  ColView v{}; if (values) v = make_view(values);
+  const uint64_t* fb = filt ? (const uint64_t*)filt->values->ptr : nullptr; const uint64_t* fv = filt && filt->validity ? (const uint64_t*)filt->validity->ptr : nullptr;
+  const uint32_t* g = (const uint32_t*)gids->values->ptr;
+  int blocks = grid_for(n, BLOCK * 8, ctx->num_cus * 8);
+  bool sumlike = kind == DFGPU_AGG_SUM || kind == DFGPU_AGG_AVG || kind == DFGPU_AGG_COUNT;
+  if (sumlike && total <= SMALL_G) {
+#define SMALL(T, C) hipLaunchKernelGGL((k_acc_small<T, C>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, kind, v, values ? 1 : 0, g, fb, fv, n, (int)total, vals, (uint64_t*)a->counts->ptr, (uint8_t*)a->seen->ptr, 1)
+    if (cls == CLS_F64) SMALL(double, CLS_F64); else if (cls == CLS_I128) SMALL(i128, CLS_I128); else SMALL(uint64_t, CLS_U64);
+#undef SMALL
+  } else {
+    hipLaunchKernelGGL(k_acc_update, dim3(blocks), dim3(BLOCK), 0, ctx->stream, kind, cls, v, values ? 1 : 0, g, fb, fv, n, total, vals, (uint64_t*)a->counts->ptr, (uint8_t*)a->seen->ptr, 1, ctx->d_flags);
+  }
+  KERNEL_CHECK();
+}
+
+}  // namespace dfgpu
+
+extern "C" {
+
+dfgpu_status dfgpu_acc_new(dfgpu_ctx* ctx, int32_t kind, int32_t in_type, int32_t p, int32_t s, dfgpu_acc** out) {
+  return guard(ctx, [&] {
+    std::unique_ptr<dfgpu_acc> a(new dfgpu_acc()); a->ctx = ctx; a->kind = kind; a->in_type = in_type; a->in_precision = p; a->in_scale = s;
+    auto cls_of = [](int32_t t) { return t == DFGPU_DECIMAL128 ? CLS_I128 : is_float(t) ? CLS_F64 : is_unsigned_int(t) ? CLS_U64 : CLS_I64; };
+    switch (kind) {
+      case DFGPU_AGG_COUNT: a->state_type = a->out_type = DFGPU_INT64; a->cls = CLS_I64; break;
+      case DFGPU_AGG_SUM:       // sum_return_type, expr/src/type_coercion/aggregates.rs:397-416
+        if (is_signed_int(in_type)) a->state_type = DFGPU_INT64; else if (is_unsigned_int(in_type)) a->state_type = DFGPU_UINT64; else if (is_float(in_type)) a->state_type = DFGPU_FLOAT64;
+        else if (in_type == DFGPU_DECIMAL128) { a->state_type = DFGPU_DECIMAL128; a->state_precision = imin(38, p + 10); a->state_scale = s; }
+        else fail(DFGPU_NOT_IMPLEMENTED, "SUM over type %d", in_type);
+        a->out_type = a->state_type; a->out_precision = a->state_precision; a->out_scale = a->state_scale; a->cls = cls_of(a->state_type); break;
+      case DFGPU_AGG_AVG:       // avg_return_type / avg_sum_type, aggregates.rs:455-505
+        if (in_type == DFGPU_DECIMAL128) { a->state_type = DFGPU_DECIMAL128; a->state_precision = imin(38, p + 10); a->state_scale = s; a->out_type = DFGPU_DECIMAL128; a->out_precision = imin(38, p + 4); a->out_scale = imin(38, s + 4); }
+        else if (in_type == DFGPU_FLOAT64) a->state_type = a->out_type = DFGPU_FLOAT64;
+        else fail(DFGPU_INVALID_ARGUMENT, "AVG input must be coerced to Float64 or Decimal128 (got %d)", in_type);
+        a->cls = cls_of(a->state_type); break;
+      case DFGPU_AGG_MIN: case DFGPU_AGG_MAX:
+        if (!type_width(in_type)) fail(DFGPU_NOT_IMPLEMENTED, "MIN/MAX over type %d", in_type);
+        a->state_type = a->out_type = in_type; a->state_precision = a->out_precision = p; a->state_scale = a->out_scale = s; a->cls = cls_of(in_type); break;
+      default: fail(DFGPU_INVALID_ARGUMENT, "unknown aggregate kind %d", kind);
+    }
+    a->width = a->cls == CLS_I128 ? 16 : 8;
+    *out = a.release();
+  });
+}
+void dfgpu_acc_free(dfgpu_acc* a) { delete a; }
+int64_t dfgpu_acc_size(const dfgpu_acc* a) { return a ? a->cap * (a->width + 9) : 0; }
+
+dfgpu_status dfgpu_acc_update_batch(dfgpu_ctx* ctx, dfgpu_acc* a, const dfgpu_array* values, const dfgpu_array* gids, const dfgpu_array* filt, int64_t total) {
+  return guard(ctx, [&] {
+    if (!a || !gids) fail(DFGPU_INVALID_ARGUMENT, "acc_update_batch: null argument");
+    if (gids->length == 0) { acc_resize(a, total); return; }     // self.values.resize(total_num_groups, ..) with nothing to accumulate
+    if (a->kind != DFGPU_AGG_COUNT) {
+      if (!values) fail(DFGPU_INVALID_ARGUMENT, "acc_update_batch: values required");
+      int32_t lt = logical_type(values);
+      bool ok = (a->kind == DFGPU_AGG_MIN || a->kind == DFGPU_AGG_MAX) ? lt == a->in_type
+              : (a->cls == CLS_I128 ? lt == DFGPU_DECIMAL128 : a->cls == CLS_F64 ? is_float(lt) : a->cls == CLS_U64 ? is_unsigned_int(lt) : is_signed_int(lt));
+      if (!ok) fail(DFGPU_INVALID_ARGUMENT, "accumulator created for input type %d got values of type %d", a->in_type, lt);
+    }
+    acc_resize(a, total);
+    bool mm128 = (a->kind == DFGPU_AGG_MIN || a->kind == DFGPU_AGG_MAX) && a->cls == CLS_I128;
+    BufferPtr old_hi;
+    if (mm128 && total) { old_hi = alloc_buffer(ctx, (size_t)total * 8); hipLaunchKernelGGL(k_copy_hi, dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)a->vals->ptr, (uint64_t*)old_hi->ptr, total); }
+    launch_update(a, a->kind, a->cls, values, gids, filt, total, a->vals ? a->vals->ptr : nullptr);
+    if (mm128 && total && gids->length) {
+      hipLaunchKernelGGL(k_minmax128_prepare, dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, ctx->stream, a->kind == DFGPU_AGG_MIN ? 1 : 0, (uint64_t*)a->vals->ptr, (const uint64_t*)old_hi->ptr, total);
+      ColView v = make_view(values);
+      hipLaunchKernelGGL(k_acc_minmax128_lo, dim3(grid_for(gids->length, BLOCK * 8, ctx->num_cus * 8)), dim3(BLOCK), 0, ctx->stream, a->kind == DFGPU_AGG_MIN ? 1 : 0, v, (const uint32_t*)gids->values->ptr,
+                         filt ? (const uint64_t*)filt->values->ptr : nullptr, filt && filt->validity ? (const uint64_t*)filt->validity->ptr : nullptr, gids->length, (uint64_t*)a->vals->ptr);
+      KERNEL_CHECK();
+    }
+    check_flags(ctx, "acc_update_batch");
+  });
+}
+
+dfgpu_status dfgpu_acc_merge_batch(dfgpu_ctx* ctx, dfgpu_acc* a, const dfgpu_array* const* st, int32_t nst, const dfgpu_array* gids, const dfgpu_array* filt, int64_t total) {
+  if (!a || !st) return DFGPU_INVALID_ARGUMENT;
+  if (a->kind == DFGPU_AGG_COUNT) {         // count.rs:135-170: add the partial counts (never null)
+    return guard(ctx, [&] {
+      if (nst != 1 || st[0]->type != DFGPU_INT64) fail(DFGPU_INVALID_ARGUMENT, "COUNT merge expects one Int64 state");
+      acc_resize(a, total);
+      launch_update(a, DFGPU_AGG_SUM, CLS_I64, st[0], gids, filt, total, a->counts->ptr);     // sum into counts; `seen` is unused by COUNT
+      check_flags(ctx, "acc_merge_batch");
+    });
+  }
+  if (a->kind == DFGPU_AGG_AVG) {           // average.rs:472-509
+    return guard(ctx, [&] {
+      if (nst != 2 || st[0]->type != DFGPU_UINT64) fail(DFGPU_INVALID_ARGUMENT, "AVG merge expects (UInt64 counts, sums)");
+      acc_resize(a, total);
+      launch_update(a, DFGPU_AGG_SUM, CLS_U64, st[0], gids, filt, total, a->counts->ptr);
+      launch_update(a, DFGPU_AGG_SUM, a->cls, st[1], gids, filt, total, a->vals->ptr);
+      check_flags(ctx, "acc_merge_batch");
+    });
+  }
+  if (nst != 1) { if (ctx) ctx->err = "merge expects one state column"; return DFGPU_INVALID_ARGUMENT; }
+  return dfgpu_acc_update_batch(ctx, a, st[0], gids, filt, total);     // prim_op.rs:119-127: update / merge are the same
+}
+
+static dfgpu_array* emit_values(dfgpu_ctx* ctx, dfgpu_acc* a, int32_t type, int32_t p, int32_t s, const void* src, bool with_seen) {
+  ArrayHolder h(new_fixed(ctx, type, a->n, p, s, with_seen));
+  if (a->n) {
+    if (type_width(type) == a->width || a->cls == CLS_I128) HIP_CHECK(hipMemcpyAsync(h.get()->values->ptr, src, (size_t)a->n * type_width(type), hipMemcpyDeviceToDevice, ctx->stream));
+    else hipLaunchKernelGGL(k_narrow, dim3(grid_for(a->n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)src, a->n, type, h.get()->values->ptr);
+    if (with_seen) hipLaunchKernelGGL(k_seen_to_bits, dim3(grid_for(a->n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint8_t*)a->seen->ptr, a->n, (uint64_t*)h.get()->validity->ptr);
+    KERNEL_CHECK();
+  }
+  if (with_seen) h.get()->null_count = -1;
+  return h.release();
+}
+
+dfgpu_status dfgpu_acc_evaluate(dfgpu_ctx* ctx, dfgpu_acc* a, dfgpu_array** out) {
+  return guard(ctx, [&] {
+    if (!a || !out) fail(DFGPU_INVALID_ARGUMENT, "acc_evaluate: null argument");
+    if (a->kind == DFGPU_AGG_COUNT) { *out = emit_values(ctx, a, DFGPU_INT64, 0, 0, a->counts ? a->counts->ptr : nullptr, false); return; }
+    if (a->kind != DFGPU_AGG_AVG) { *out = emit_values(ctx, a, a->out_type, a->out_precision, a->out_scale, a->vals ? a->vals->ptr : nullptr, true); return; }
+    ArrayHolder h(new_fixed(ctx, a->out_type, a->n, a->out_precision, a->out_scale, true));
+    if (a->n) {
+      dim3 grid(grid_for(a->n, BLOCK)), block(BLOCK);
+      if (a->out_type == DFGPU_FLOAT64) hipLaunchKernelGGL(k_avg_f64, grid, block, 0, ctx->stream, (const double*)a->vals->ptr, (const uint64_t*)a->counts->ptr, (const uint8_t*)a->seen->ptr, a->n, (double*)h.get()->values->ptr);
+      else { i128 factor = pow10_i128(a->out_scale - a->state_scale);
+             hipLaunchKernelGGL(k_avg_dec, grid, block, 0, ctx->stream, (const uint64_t*)a->vals->ptr, (const uint64_t*)a->counts->ptr, (const uint8_t*)a->seen->ptr, a->n, factor, a->out_precision, (uint64_t*)h.get()->values->ptr, ctx->d_flags); }
+      hipLaunchKernelGGL(k_seen_to_bits, grid, block, 0, ctx->stream, (const uint8_t*)a->seen->ptr, a->n, (uint64_t*)h.get()->validity->ptr);
+      KERNEL_CHECK();
+      uint32_t f = 0; HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 63, ctx->d_flags, 4, hipMemcpyDeviceToHost, ctx->stream)); HIP_CHECK(hipStreamSynchronize(ctx->stream)); f = *(uint32_t*)(ctx->h_pinned + 63);
+      if (f) { HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, 4, ctx->stream)); fail(DFGPU_EXECUTION, "Arithmetic Overflow in AvgAccumulator"); }
+    }
+    h.get()->null_count = -1;
+    *out = h.release();
+  });
+}
+
+dfgpu_status dfgpu_acc_state(dfgpu_ctx* ctx, dfgpu_acc* a, dfgpu_array** out_states, int32_t* n_states) {
+  if (!a || !out_states || !n_states) return DFGPU_INVALID_ARGUMENT;
+  if (a->kind != DFGPU_AGG_AVG) { *n_states = 1; return dfgpu_acc_evaluate(ctx, a, &out_states[0]); }
+  return guard(ctx, [&] {
+    ArrayHolder c(emit_values(ctx, a, DFGPU_UINT64, 0, 0, a->counts ? a->counts->ptr : nullptr, true));
+    ArrayHolder s(emit_values(ctx, a, a->state_type, a->state_precision, a->state_scale, a->vals ? a->vals->ptr : nullptr, true));
+    out_states[0] = c.release(); out_states[1] = s.release(); *n_states = 2;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,374 @@
+// core.hip -- context, HBM-resident Arrow arrays, import/export, slice, concat.
+#include "device_utils.h"
+#include <mutex>
+
+namespace dfgpu {
+
+void fail(dfgpu_status code, const char* fmt, ...) {
+  char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  throw Error(code, buf);
+}
+
+// ctx lifetime: the handle given to the user holds one reference, every owned Buffer another, so
+// arrays may outlive dfgpu_ctx_destroy (Rust drops in arbitrary order).
+struct CtxRefs { std::atomic<int64_t> n{1}; };
+static std::mutex g_mu;
+static std::vector<std::pair<dfgpu_ctx*, CtxRefs*>> g_ctx;
+static CtxRefs* refs_of(dfgpu_ctx* c) { std::lock_guard<std::mutex> l(g_mu); for (auto& p : g_ctx) if (p.first == c) return p.second; return nullptr; }
+static void ctx_unref(dfgpu_ctx* c) {
+  CtxRefs* r = refs_of(c);
+  if (!r || r->n.fetch_sub(1) != 1) return;
+  { std::lock_guard<std::mutex> l(g_mu); for (size_t i = 0; i < g_ctx.size(); i++) if (g_ctx[i].first == c) { g_ctx.erase(g_ctx.begin() + i); break; } }
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->d_flags) (void)hipFree(c->d_flags);
+  if (c->d_scratch64) (void)hipFree(c->d_scratch64);
+  if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete r; delete c;
+}
+
+Buffer::~Buffer() {
+  if (owned && ptr && ctx) { (void)hipSetDevice(ctx->device); (void)hipFreeAsync(ptr, ctx->stream); ctx_unref(ctx); }
+}
+BufferPtr alloc_buffer(dfgpu_ctx* ctx, size_t bytes, bool zero) {
+  auto b = std::make_shared<Buffer>();
+  size_t n = bytes ? ((bytes + 255) & ~(size_t)255) : 256;      // 256 B granules keep every buffer 16 B aligned + padded
+  void* p = nullptr;
+  HIP_CHECK(hipMallocAsync(&p, n, ctx->stream));
+  b->ptr = p; b->bytes = n; b->ctx = ctx; b->owned = true;
+  CtxRefs* r = refs_of(ctx); if (r) r->n.fetch_add(1);
+  if (zero) HIP_CHECK(hipMemsetAsync(p, 0, n, ctx->stream));
+  return b;
+}
+BufferPtr borrow_buffer(const void* ptr, size_t bytes) {
+  auto b = std::make_shared<Buffer>(); b->ptr = const_cast<void*>(ptr); b->bytes = bytes; b->owned = false; return b;
+}
+
+dfgpu_array* new_array(dfgpu_ctx* ctx, int32_t type, int64_t length, int32_t precision, int32_t scale) {
+  auto* a = new dfgpu_array(); a->ctx = ctx; a->type = type; a->length = length; a->precision = precision; a->scale = scale; return a;
+}
+dfgpu_array* new_fixed(dfgpu_ctx* ctx, int32_t type, int64_t length, int32_t precision, int32_t scale, bool with_validity) {
+  ArrayHolder h(new_array(ctx, type, length, precision, scale));
+  size_t vb = type == DFGPU_BOOL ? bitmap_bytes(length) : (size_t)length * type_width(type);
+  h.get()->values = alloc_buffer(ctx, vb, type == DFGPU_BOOL);
+  if (with_validity) h.get()->validity = alloc_buffer(ctx, bitmap_bytes(length), true); else h.get()->null_count = 0;
+  return h.release();
+}
+
+void check_flags(dfgpu_ctx* ctx, const char* what) {
+  uint32_t f = 0;
+  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 63, ctx->d_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  f = *(uint32_t*)(ctx->h_pinned + 63);
+  if (!f) return;
+  HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, 4, ctx->stream));
+  if (f & DFGPU_FLAG_DIV_ZERO) fail(DFGPU_EXECUTION, "Arrow error: Divide by zero error (%s)", what);
+  if (f & DFGPU_FLAG_OVERFLOW) fail(DFGPU_EXECUTION, "Arrow error: Arithmetic overflow (%s)", what);
+  if (f & DFGPU_FLAG_CAST) fail(DFGPU_EXECUTION, "Arrow error: Cast error: value out of range (%s)", what);
+  if (f & DFGPU_FLAG_OOB) fail(DFGPU_EXECUTION, "Arrow error: index out of bounds (%s)", what);
+  fail(DFGPU_INTERNAL, "kernel raised flag %u (%s)", f, what);
+}
+uint64_t read_scratch(dfgpu_ctx* ctx, int slot) {
+  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + slot, ctx->d_scratch64 + slot, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ctx->h_pinned[slot];
+}
+void zero_scratch(dfgpu_ctx* ctx) { HIP_CHECK(hipMemsetAsync(ctx->d_scratch64, 0, 64 * 8, ctx->stream)); }
+
+ColView make_view(const dfgpu_array* a) {
+  ColView v{};
+  const dfgpu_array* d = a;
+  if (a->type == DFGPU_DICTIONARY) {
+    d = a->dictionary;
+    v.keys = a->values->ptr; v.key_validity = a->validity ? (const uint64_t*)a->validity->ptr : nullptr; v.key_type = a->key_type;
+  }
+  v.type = d->type; v.width = type_width(d->type);
+  v.values = d->values ? d->values->ptr : nullptr;
+  v.validity = d->validity ? (const uint64_t*)d->validity->ptr : nullptr;
+  v.offsets = d->offsets ? (const int32_t*)d->offsets->ptr : nullptr;
+  v.precision = d->precision; v.scale = d->scale;
+  return v;
+}
+KeySet make_keyset(const dfgpu_array* const* cols, int32_t n) {
+  if (n < 1 || n > MAX_KEYS) fail(DFGPU_NOT_IMPLEMENTED, "between 1 and %d key columns are supported, got %d", MAX_KEYS, n);
+  KeySet ks{}; ks.n = n;
+  for (int i = 0; i < n; i++) {
+    if (!cols[i]) fail(DFGPU_INVALID_ARGUMENT, "null key column");
+    if (cols[i]->length != cols[0]->length) fail(DFGPU_INVALID_ARGUMENT, "key columns differ in length");
+    ks.c[i] = make_view(cols[i]);
+  }
+  return ks;
+}
+
+__global__ void k_and_words(const uint64_t* a, const uint64_t* b, uint64_t* out, int64_t nw) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nw) out[i] = a[i] & b[i];
+}
+BufferPtr effective_mask(dfgpu_ctx* ctx, const dfgpu_array* mask, int64_t expect_len) {
+  if (!mask) return nullptr;
+  if (mask->type != DFGPU_BOOL) fail(DFGPU_INVALID_ARGUMENT, "mask must be a Boolean array");
+  if (mask->length != expect_len) fail(DFGPU_INVALID_ARGUMENT, "mask length %lld != %lld", (long long)mask->length, (long long)expect_len);
+  if (!mask->validity) return mask->values;
+  int64_t nw = (mask->length + 63) / 64;
+  BufferPtr out = alloc_buffer(ctx, (size_t)nw * 8);
+  if (nw) hipLaunchKernelGGL(k_and_words, dim3(grid_for(nw, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)mask->values->ptr, (const uint64_t*)mask->validity->ptr, (uint64_t*)out->ptr, nw);
+  KERNEL_CHECK();
+  return out;
+}
+
+// OR `n` bits of src (all ones if src == null), starting at src bit 0, into dst starting at bit dst_off.
+__global__ void k_or_bits(uint64_t* dst, int64_t dst_off, const uint64_t* src, int64_t n) {
+  int64_t first_w = dst_off >> 6, last_w = (dst_off + n - 1) >> 6;
+  int64_t w = first_w + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w > last_w) return;
+  int64_t lo = w * 64 > dst_off ? w * 64 : dst_off, hi = (w + 1) * 64 < dst_off + n ? (w + 1) * 64 : dst_off + n;   // dst bit range
+  int64_t s0 = lo - dst_off; int cnt = (int)(hi - lo);
+  uint64_t bits;
+  if (!src) bits = ~0ull;
+  else { int64_t sw = s0 >> 6; int sh = (int)(s0 & 63); bits = src[sw] >> sh; if (sh && (s0 + cnt - 1) >> 6 != sw) bits |= src[sw + 1] << (64 - sh); }
+  if (cnt < 64) bits &= (1ull << cnt) - 1ull;
+  bits <<= (lo & 63);
+  atomicOr((unsigned long long*)&dst[w], (unsigned long long)bits);
+}
+static void or_bits(dfgpu_ctx* ctx, uint64_t* dst, int64_t dst_off, const uint64_t* src, int64_t n) {
+  if (n <= 0) return;
+  int64_t words = ((dst_off + n - 1) >> 6) - (dst_off >> 6) + 1;
+  hipLaunchKernelGGL(k_or_bits, dim3(grid_for(words, BLOCK)), dim3(BLOCK), 0, ctx->stream, dst, dst_off, src, n);
+  KERNEL_CHECK();
+}
+__global__ void k_rebase_offsets(const int32_t* src, int32_t* dst, int64_t n, int32_t delta) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i] + delta;
+}
+__global__ void k_popcount(const uint64_t* bits, int64_t n, unsigned long long* total) {
+  int64_t nw = (n + 63) >> 6; unsigned long long c = 0;
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t x = bits[w];
+    if (w == nw - 1 && (n & 63)) x &= (1ull << (n & 63)) - 1ull;
+    c += __popcll(x);
+  }
+  c = wave_sum(c);
+  if (lane_id() == 0 && c) atomicAdd(total, c);
+}
+int64_t count_set_bits(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n) {
+  if (n == 0) return 0;
+  HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 62, 0, 8, ctx->stream));
+  hipLaunchKernelGGL(k_popcount, dim3(grid_for((n + 63) / 64, BLOCK, 1024)), dim3(BLOCK), 0, ctx->stream, bits, n, (unsigned long long*)(ctx->d_scratch64 + 62));
+  KERNEL_CHECK();
+  return (int64_t)read_scratch(ctx, 62);
+}
+
+static void validate_type(int32_t t) { if (t < DFGPU_BOOL || t > DFGPU_DICTIONARY) fail(DFGPU_INVALID_ARGUMENT, "unknown type id %d", t); }
+
+static dfgpu_array* import_desc(dfgpu_ctx* ctx, const dfgpu_array_desc* d, bool copy) {
+  validate_type(d->type);
+  if (d->length < 0) fail(DFGPU_INVALID_ARGUMENT, "negative length");
+  if (d->length > 0xFFFFFFF0ll) fail(DFGPU_NOT_IMPLEMENTED, "arrays above 2^32-16 rows are not supported (UInt32 row ids, joins/utils.rs probe indices)");
+  ArrayHolder h(new_array(ctx, d->type, d->length, d->precision, d->scale));
+  dfgpu_array* a = h.get();
+  a->null_count = d->validity ? d->null_count : 0; a->key_type = d->key_type;
+  int64_t n = d->length;
+  size_t vbytes;
+  int32_t vt = d->type == DFGPU_DICTIONARY ? d->key_type : d->type;
+  if (d->type == DFGPU_UTF8) vbytes = (size_t)d->values_bytes;
+  else if (vt == DFGPU_BOOL) vbytes = (size_t)(n + 7) / 8;
+  else { if (!type_width(vt)) fail(DFGPU_INVALID_ARGUMENT, "bad value type %d", vt); vbytes = (size_t)n * type_width(vt); }
+  auto put = [&](const void* src, size_t bytes, size_t padded) -> BufferPtr {
+    if (!copy) {
+      if (((uintptr_t)src & 7) != 0) fail(DFGPU_INVALID_ARGUMENT, "device buffers must be 8-byte aligned");
+      return borrow_buffer(src, bytes);
+    }
+    BufferPtr b = alloc_buffer(ctx, padded, true);
+    if (bytes) HIP_CHECK(hipMemcpyAsync(b->ptr, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return b;
+  };
+  if ((vbytes && !d->values)) fail(DFGPU_INVALID_ARGUMENT, "values buffer is null");
+  a->values = put(d->values, vbytes, vt == DFGPU_BOOL && d->type != DFGPU_UTF8 ? bitmap_bytes(n) : vbytes);
+  a->values_bytes = d->type == DFGPU_UTF8 ? d->values_bytes : 0;
+  if (d->validity) a->validity = put(d->validity, (size_t)(n + 7) / 8, bitmap_bytes(n));
+  if (d->type == DFGPU_UTF8) { if (!d->offsets) fail(DFGPU_INVALID_ARGUMENT, "utf8 needs offsets"); a->offsets = put(d->offsets, (size_t)(n + 1) * 4, (size_t)(n + 1) * 4); }
+  if (d->type == DFGPU_DICTIONARY) {
+    if (!d->dictionary) fail(DFGPU_INVALID_ARGUMENT, "dictionary array without dictionary");
+    if (d->dictionary->type == DFGPU_DICTIONARY) fail(DFGPU_NOT_IMPLEMENTED, "nested dictionaries");
+    if (!is_signed_int(d->key_type) && !is_unsigned_int(d->key_type)) fail(DFGPU_INVALID_ARGUMENT, "dictionary key type %d", d->key_type);
+    a->dictionary = import_desc(ctx, d->dictionary, copy);
+  }
+  if (copy) {
+    if (n == 1 && d->type != DFGPU_UTF8 && d->type != DFGPU_DICTIONARY) {      // scalar Datum mirror
+      a->has_host_scalar = true; memset(a->host_scalar, 0, 16); memcpy(a->host_scalar, d->values, vt == DFGPU_BOOL ? 1 : vbytes);
+      a->host_scalar_valid = !d->validity || (d->validity[0] & 1);
+    }
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));   // pageable host memory may be reused by the caller on return
+  }
+  return h.release();
+}
+
+}  // namespace dfgpu
+
+using namespace dfgpu;
+
+extern "C" {
+
+const char* dfgpu_version(void) { return "dfgpu 0.1 (gfx950)"; }
+
+dfgpu_status dfgpu_ctx_create(int32_t device_id, void* stream, dfgpu_ctx** out) {
+  if (!out) return DFGPU_INVALID_ARGUMENT;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) return DFGPU_EXECUTION;
+  auto* c = new dfgpu_ctx();
+  c->device = device_id;
+  dfgpu_status st = guard(c, [&] {
+    HIP_CHECK(hipSetDevice(device_id));
+    hipDeviceProp_t prop; HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    hipMemPool_t pool; HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, device_id));
+    uint64_t thr = UINT64_MAX; HIP_CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr));
+    HIP_CHECK(hipMalloc((void**)&c->d_flags, 256)); HIP_CHECK(hipMemset(c->d_flags, 0, 256));
+    HIP_CHECK(hipMalloc((void**)&c->d_scratch64, 64 * 8)); HIP_CHECK(hipMemset(c->d_scratch64, 0, 64 * 8));
+    HIP_CHECK(hipHostMalloc((void**)&c->h_pinned, 64 * 8, hipHostMallocDefault));
+  });
+  if (st != DFGPU_OK) { fprintf(stderr, "dfgpu_ctx_create: %s\n", c->err.c_str()); delete c; return st; }
+  { std::lock_guard<std::mutex> l(g_mu); g_ctx.emplace_back(c, new CtxRefs()); }
+  *out = c;
+  return DFGPU_OK;
+}
+void dfgpu_ctx_destroy(dfgpu_ctx* ctx) { if (ctx) ctx_unref(ctx); }
+const char* dfgpu_last_error(const dfgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+void* dfgpu_ctx_stream(dfgpu_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx* ctx) { return guard(ctx, [&] { HIP_CHECK(hipSetDevice(ctx->device)); HIP_CHECK(hipStreamSynchronize(ctx->stream)); }); }
+dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value) {
+  return guard(ctx, [&] {
+    std::string k = key ? key : "";
+    if (k == "force_hash_collisions") ctx->force_hash_collisions = value != 0;
+    else if (k == "first_seen_group_order") ctx->first_seen_group_order = value != 0;
+    else fail(DFGPU_INVALID_ARGUMENT, "unknown option '%s'", k.c_str());
+  });
+}
+
+dfgpu_status dfgpu_array_import_host(dfgpu_ctx* ctx, const dfgpu_array_desc* host, dfgpu_array** out) {
+  return guard(ctx, [&] { HIP_CHECK(hipSetDevice(ctx->device)); *out = import_desc(ctx, host, true); });
+}
+dfgpu_status dfgpu_array_wrap_device(dfgpu_ctx* ctx, const dfgpu_array_desc* dev, dfgpu_array** out) {
+  return guard(ctx, [&] { *out = import_desc(ctx, dev, false); });
+}
+dfgpu_status dfgpu_array_describe(const dfgpu_array* a, dfgpu_array_desc* o) {
+  if (!a || !o) return DFGPU_INVALID_ARGUMENT;
+  auto fill = [](const dfgpu_array* x, dfgpu_array_desc* d) {
+    memset(d, 0, sizeof *d);
+    d->type = x->type; d->precision = x->precision; d->scale = x->scale; d->key_type = x->key_type; d->length = x->length; d->null_count = x->null_count;
+    d->values = x->values ? x->values->ptr : nullptr; d->validity = x->validity ? (const uint8_t*)x->validity->ptr : nullptr;
+    d->offsets = x->offsets ? (const int32_t*)x->offsets->ptr : nullptr; d->values_bytes = x->values_bytes;
+  };
+  fill(a, o);
+  if (a->dictionary) { auto* m = const_cast<dfgpu_array*>(a); fill(a->dictionary, &m->dict_desc); o->dictionary = &m->dict_desc; }
+  return DFGPU_OK;
+}
+dfgpu_status dfgpu_array_export_host(dfgpu_ctx* ctx, const dfgpu_array* a, void* values, uint8_t* validity, int32_t* offsets) {
+  return guard(ctx, [&] {
+    HIP_CHECK(hipSetDevice(ctx->device));
+    int64_t n = a->length; int32_t vt = a->type == DFGPU_DICTIONARY ? a->key_type : a->type;
+    size_t vbytes = a->type == DFGPU_UTF8 ? (size_t)a->values_bytes : (vt == DFGPU_BOOL ? (size_t)(n + 7) / 8 : (size_t)n * type_width(vt));
+    if (values && vbytes) HIP_CHECK(hipMemcpyAsync(values, a->values->ptr, vbytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (validity && a->validity && n) HIP_CHECK(hipMemcpyAsync(validity, a->validity->ptr, (size_t)(n + 7) / 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (offsets && a->offsets) HIP_CHECK(hipMemcpyAsync(offsets, a->offsets->ptr, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  });
+}
+void dfgpu_array_retain(dfgpu_array* a) { if (a) a->refs.fetch_add(1); }
+void dfgpu_array_release(dfgpu_array* a) {
+  if (!a) return;
+  if (a->refs.fetch_sub(1) == 1) { if (a->dictionary) dfgpu_array_release(a->dictionary); delete a; }
+}
+int64_t dfgpu_array_length(const dfgpu_array* a) { return a ? a->length : 0; }
+int64_t dfgpu_array_null_count(dfgpu_ctx* ctx, const dfgpu_array* a) {
+  if (!a) return 0;
+  if (a->null_count >= 0) return a->null_count;
+  if (!a->validity) return 0;
+  int64_t nc = -1;
+  guard(ctx, [&] { nc = a->length - count_set_bits(ctx, (const uint64_t*)a->validity->ptr, a->length); const_cast<dfgpu_array*>(a)->null_count = nc; });
+  return nc;
+}
+
+dfgpu_status dfgpu_array_new_null(dfgpu_ctx* ctx, int32_t type, int32_t precision, int32_t scale, int64_t length, dfgpu_array** out) {
+  return guard(ctx, [&] {
+    validate_type(type);
+    if (type == DFGPU_DICTIONARY) fail(DFGPU_NOT_IMPLEMENTED, "new_null dictionary");
+    ArrayHolder h(new_array(ctx, type, length, precision, scale));
+    size_t vb = type == DFGPU_UTF8 ? 0 : (type == DFGPU_BOOL ? bitmap_bytes(length) : (size_t)length * type_width(type));
+    h.get()->values = alloc_buffer(ctx, vb, true);
+    h.get()->validity = alloc_buffer(ctx, bitmap_bytes(length), true);
+    if (type == DFGPU_UTF8) h.get()->offsets = alloc_buffer(ctx, (size_t)(length + 1) * 4, true);
+    h.get()->null_count = length;
+    *out = h.release();
+  });
+}
+
+dfgpu_status dfgpu_array_slice(dfgpu_ctx* ctx, const dfgpu_array* a, int64_t offset, int64_t length, dfgpu_array** out) {
+  return guard(ctx, [&] {
+    if (offset < 0 || length < 0 || offset + length > a->length) fail(DFGPU_INVALID_ARGUMENT, "slice [%lld, +%lld) outside array of %lld rows", (long long)offset, (long long)length, (long long)a->length);
+    int32_t vt0 = a->type == DFGPU_DICTIONARY ? a->key_type : a->type;
+    bool bit_aligned_needed = a->validity != nullptr || vt0 == DFGPU_BOOL;
+    if (offset % 64 != 0 && bit_aligned_needed) {     // bitmaps cannot be re-based at bit granularity: copy through take with an iota index
+      ArrayHolder idx(new_fixed(ctx, DFGPU_UINT32, length));
+      launch_iota_u32(ctx, (uint32_t*)idx.get()->values->ptr, length, (uint32_t)offset);
+      *out = take_impl(ctx, a, idx.get()->values->ptr, 4, nullptr, length);
+      return;
+    }
+    ArrayHolder h(new_array(ctx, a->type, length, a->precision, a->scale));
+    dfgpu_array* s = h.get(); s->key_type = a->key_type; s->values_bytes = a->values_bytes;
+    auto sub = [&](const BufferPtr& b, size_t byte_off) { auto r = std::make_shared<Buffer>(); r->ptr = (char*)b->ptr + byte_off; r->bytes = b->bytes - byte_off; r->owned = false; r->parent = b; return r; };
+    int32_t vt = a->type == DFGPU_DICTIONARY ? a->key_type : a->type;
+    if (a->type == DFGPU_UTF8) { s->values = a->values; s->offsets = sub(a->offsets, (size_t)offset * 4); }
+    else if (vt == DFGPU_BOOL) s->values = sub(a->values, (size_t)offset / 8);
+    else s->values = sub(a->values, (size_t)offset * type_width(vt));
+    if (a->validity) { s->validity = sub(a->validity, (size_t)offset / 8); s->null_count = -1; } else s->null_count = 0;
+    if (a->dictionary) { s->dictionary = a->dictionary; dfgpu_array_retain(a->dictionary); }
+    *out = h.release();
+  });
+}
+
+dfgpu_status dfgpu_concat(dfgpu_ctx* ctx, const dfgpu_array* const* arrays, int32_t n, dfgpu_array** out) {
+  return guard(ctx, [&] {
+    if (n < 1) fail(DFGPU_INVALID_ARGUMENT, "concat of zero arrays");
+    const dfgpu_array* f = arrays[0];
+    int64_t total = 0, total_bytes = 0; bool any_validity = false;
+    for (int i = 0; i < n; i++) {
+      const dfgpu_array* a = arrays[i];
+      if (a->type != f->type || a->precision != f->precision || a->scale != f->scale) fail(DFGPU_INVALID_ARGUMENT, "concat: column types differ");
+      if (a->type == DFGPU_DICTIONARY && (a->dictionary != f->dictionary || a->key_type != f->key_type)) fail(DFGPU_NOT_IMPLEMENTED, "concat of dictionary arrays with different dictionaries");
+      total += a->length; total_bytes += a->values_bytes; any_validity |= (a->validity != nullptr);
+    }
+    if (total > 0xFFFFFFF0ll) fail(DFGPU_NOT_IMPLEMENTED, "concat above 2^32-16 rows");
+    ArrayHolder h(new_array(ctx, f->type, total, f->precision, f->scale));
+    dfgpu_array* o = h.get(); o->key_type = f->key_type;
+    int32_t vt = f->type == DFGPU_DICTIONARY ? f->key_type : f->type;
+    int w = type_width(vt);
+    if (f->type == DFGPU_UTF8) { o->values = alloc_buffer(ctx, (size_t)total_bytes); o->offsets = alloc_buffer(ctx, (size_t)(total + 1) * 4, true); o->values_bytes = total_bytes; }
+    else if (vt == DFGPU_BOOL) o->values = alloc_buffer(ctx, bitmap_bytes(total), true);
+    else o->values = alloc_buffer(ctx, (size_t)total * w);
+    if (any_validity) o->validity = alloc_buffer(ctx, bitmap_bytes(total), true); else o->null_count = 0;
+    int64_t row = 0, byte = 0;
+    for (int i = 0; i < n; i++) {
+      const dfgpu_array* a = arrays[i];
+      if (a->length == 0) continue;
+      if (f->type == DFGPU_UTF8) {
+        if (a->values_bytes) HIP_CHECK(hipMemcpyAsync((char*)o->values->ptr + byte, a->values->ptr, (size_t)a->values_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        // offsets of a slice may not start at 0: rebase by (byte - first offset) on device
+        hipLaunchKernelGGL(k_rebase_offsets, dim3(grid_for(a->length + 1, BLOCK)), dim3(BLOCK), 0, ctx->stream,
+                           (const int32_t*)a->offsets->ptr, (int32_t*)o->offsets->ptr + row, a->length + 1, (int32_t)byte);
+        KERNEL_CHECK();
+      } else if (vt == DFGPU_BOOL) or_bits(ctx, (uint64_t*)o->values->ptr, row, (const uint64_t*)a->values->ptr, a->length);
+      else HIP_CHECK(hipMemcpyAsync((char*)o->values->ptr + (size_t)row * w, a->values->ptr, (size_t)a->length * w, hipMemcpyDeviceToDevice, ctx->stream));
+      if (any_validity) or_bits(ctx, (uint64_t*)o->validity->ptr, row, a->validity ? (const uint64_t*)a->validity->ptr : nullptr, a->length);
+      row += a->length; byte += a->values_bytes;
+    }
+    if (f->dictionary) { o->dictionary = f->dictionary; dfgpu_array_retain(f->dictionary); }
+    *out = h.release();
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+// dfgpu_internal.h -- host-side plumbing shared by the HIP translation units of libdfgpu.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/dfgpu.h"
+
+namespace dfgpu {
+
+struct Error : std::exception {
+  dfgpu_status code; std::string msg;
+  Error(dfgpu_status c, std::string m) : code(c), msg(std::move(m)) {}
+  const char* what() const noexcept override { return msg.c_str(); }
+};
+[[noreturn]] void fail(dfgpu_status code, const char* fmt, ...);
+
+#define HIP_CHECK(expr)                                                                         \
+  do { hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) ::dfgpu::fail(e_ == hipErrorOutOfMemory ? DFGPU_RESOURCES_EXHAUSTED : DFGPU_INTERNAL, \
+                                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define KERNEL_CHECK() HIP_CHECK(hipGetLastError())
+
+}  // namespace dfgpu
+
+// Device error flags raised by kernels (checked by the op that launched them).
+enum : uint32_t { DFGPU_FLAG_DIV_ZERO = 1, DFGPU_FLAG_OVERFLOW = 2, DFGPU_FLAG_CAST = 4, DFGPU_FLAG_OOB = 8, DFGPU_FLAG_TABLE_FULL = 16 };
+
+struct dfgpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  bool force_hash_collisions = false;
+  bool first_seen_group_order = true;
+  uint32_t* d_flags = nullptr;      // device word for kernel error flags
+  uint64_t* d_scratch64 = nullptr;  // 64 x u64 device scratch for counters / totals
+  uint64_t* h_pinned = nullptr;     // 64 x u64 pinned host mirror
+  int num_cus = 256;
+};
+
+namespace dfgpu {
+
+struct Buffer {
+  void* ptr = nullptr; size_t bytes = 0; dfgpu_ctx* ctx = nullptr; bool owned = true;
+  std::shared_ptr<Buffer> parent;   // keeps a sliced parent alive
+  ~Buffer();
+};
+using BufferPtr = std::shared_ptr<Buffer>;
+BufferPtr alloc_buffer(dfgpu_ctx* ctx, size_t bytes, bool zero = false);
+BufferPtr borrow_buffer(const void* ptr, size_t bytes);
+
+}  // namespace dfgpu
+
+struct dfgpu_array {
+  std::atomic<int64_t> refs{1};
+  dfgpu_ctx* ctx = nullptr;
+  int32_t type = 0, precision = 0, scale = 0, key_type = 0;
+  int64_t length = 0;
+  int64_t null_count = -1;
+  dfgpu::BufferPtr values, validity, offsets;
+  int64_t values_bytes = 0;
+  dfgpu_array* dictionary = nullptr;   // retained
+  // host mirror of a length-1 array (scalar Datum) so kernels can take it by value
+  bool has_host_scalar = false; unsigned char host_scalar[16] = {0}; bool host_scalar_valid = true;
+  dfgpu_array_desc dict_desc{};        // storage for describe()
+};
+
+namespace dfgpu {
+
+inline int type_width(int32_t t) {
+  switch (t) {
+    case DFGPU_INT8: case DFGPU_UINT8: return 1;
+    case DFGPU_INT16: case DFGPU_UINT16: return 2;
+    case DFGPU_INT32: case DFGPU_UINT32: case DFGPU_FLOAT32: case DFGPU_DATE32: return 4;
+    case DFGPU_INT64: case DFGPU_UINT64: case DFGPU_FLOAT64: return 8;
+    case DFGPU_DECIMAL128: return 16;
+    default: return 0;
+  }
+}
+inline bool is_signed_int(int32_t t) { return t == DFGPU_INT8 || t == DFGPU_INT16 || t == DFGPU_INT32 || t == DFGPU_INT64; }
+inline bool is_unsigned_int(int32_t t) { return t == DFGPU_UINT8 || t == DFGPU_UINT16 || t == DFGPU_UINT32 || t == DFGPU_UINT64; }
+inline bool is_float(int32_t t) { return t == DFGPU_FLOAT32 || t == DFGPU_FLOAT64; }
+inline size_t bitmap_bytes(int64_t n) { return (size_t)((n + 63) / 64) * 8; }   // always whole u64 words
+inline int32_t logical_type(const dfgpu_array* a) { return a->type == DFGPU_DICTIONARY ? a->dictionary->type : a->type; }
+
+dfgpu_array* new_array(dfgpu_ctx* ctx, int32_t type, int64_t length, int32_t precision = 0, int32_t scale = 0);
+dfgpu_array* new_fixed(dfgpu_ctx* ctx, int32_t type, int64_t length, int32_t precision = 0, int32_t scale = 0, bool with_validity = false);
+struct ArrayHolder {   // RAII release on exception paths
+  dfgpu_array* a = nullptr;
+  ArrayHolder() = default; explicit ArrayHolder(dfgpu_array* x) : a(x) {}
+  ~ArrayHolder() { if (a) dfgpu_array_release(a); }
+  dfgpu_array* release() { dfgpu_array* x = a; a = nullptr; return x; }
+  dfgpu_array* get() const { return a; }
+  ArrayHolder(const ArrayHolder&) = delete; ArrayHolder& operator=(const ArrayHolder&) = delete;
+};
+
+// Read back the kernel error flags (synchronises) and raise the matching DataFusionError analogue.
+void check_flags(dfgpu_ctx* ctx, const char* what);
+uint64_t read_scratch(dfgpu_ctx* ctx, int slot);          // sync + D2H of d_scratch64[slot]
+void zero_scratch(dfgpu_ctx* ctx);
+
+// Device view of a column passed to kernels by value.
+struct ColView {
+  int32_t type; int32_t width;          // logical type (dictionary resolved) and byte width
+  const void* values; const uint64_t* validity;   // validity as u64 words (may be null)
+  const int32_t* offsets;               // utf8
+  const void* keys; const uint64_t* key_validity; int32_t key_type;  // dictionary indirection (keys != null)
+  int32_t precision, scale;
+};
+ColView make_view(const dfgpu_array* a);
+
+constexpr int MAX_KEYS = 8;
+struct KeySet { int32_t n; ColView c[MAX_KEYS]; };
+KeySet make_keyset(const dfgpu_array* const* cols, int32_t n);
+
+// mask (BOOL array) -> effective selection bitmap words (values & validity), null if no mask
+BufferPtr effective_mask(dfgpu_ctx* ctx, const dfgpu_array* mask, int64_t expect_len);
+
+// primitives implemented in scan.hip
+void exclusive_scan_u32(dfgpu_ctx* ctx, const uint32_t* in, uint64_t* out, int64_t n, uint64_t* d_total /*device, may be null*/);
+void exclusive_scan_u32_inplace32(dfgpu_ctx* ctx, uint32_t* data, int64_t n, uint64_t* d_total);
+
+// select.hip helpers reused by other ops
+dfgpu_array* take_impl(dfgpu_ctx* ctx, const dfgpu_array* values, const void* idx, int idx_width, const uint64_t* idx_validity, int64_t n_out);
+dfgpu_array* mask_to_indices_impl(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n);
+int64_t count_set_bits(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n);
+
+void launch_iota_u32(dfgpu_ctx* ctx, uint32_t* out, int64_t n, uint32_t start);
+void launch_set_bits_prefix(dfgpu_ctx* ctx, uint64_t* bits, int64_t m);   // bits[0..m) = 1
+
+// hash.hip
+void hash_keys_device(dfgpu_ctx* ctx, const dfgpu_array* const* cols, int32_t k, uint64_t seed, uint64_t* out);
+
+// sort.hip: stable sort of (u32 key, u32 value) pairs on `bits` low bits of the key
+void radix_sort_pairs_u32(dfgpu_ctx* ctx, uint32_t* keys, uint32_t* vals, int64_t n, int bits);
+
+template <typename F>
+dfgpu_status guard(dfgpu_ctx* ctx, F&& f) {
+  try { f(); return DFGPU_OK; }
+  catch (const Error& e) { if (ctx) ctx->err = e.msg; return e.code; }
+  catch (const std::bad_alloc&) { if (ctx) ctx->err = "host allocation failed"; return DFGPU_RESOURCES_EXHAUSTED; }
+  catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return DFGPU_INTERNAL; }
+}
+
+inline int grid_for(int64_t n, int block, int max_blocks = 1 << 20) {
+  int64_t g = (n + block - 1) / block; if (g < 1) g = 1; if (g > max_blocks) g = max_blocks; return (int)g;
+}
+
+}  // namespace dfgpu

@@ -1,0 +1,207 @@
+// groups.hip -- a8: GroupValues (key interning) for AggregateExec on gfx950.
+//
+// Reference: physical-plan/src/aggregates/group_values/{mod,primitive,row,bytes}.rs.  One device
+// implementation serves all three reference variants: keys are compared column-wise in place (no
+// row-format copy as GroupValuesRows does, row.rs:97), strings by (length, bytes).
+//
+// Persistent table in HBM: open addressing, 8-byte slots (hash tag:32 | payload:32).  payload is a
+// group id, or NEW|batch-row while a key first seen in the current batch is still unnumbered.
+// Ids must come out in FIRST-SEEN order (primitive.rs:137-141): every new slot keeps
+// atomicMin(first row); rows that are "first of their group" are flagged in a bitmap, compacted in
+// row order (ballot + scan), and their rank is the new id -- O(rows) streaming work, no sort.
+#include "device_utils.h"
+
+namespace dfgpu {
+constexpr uint64_t G_EMPTY = ~0ull;
+constexpr uint32_t G_NEW = 0x80000000u;
+constexpr uint32_t G_NONE = 0xFFFFFFFFu;
+constexpr uint64_t GROUP_SEED = 0x5851f42d4c957f2dULL;
+}
+using namespace dfgpu;
+
+struct dfgpu_groups {
+  dfgpu_ctx* ctx = nullptr; int32_t nkeys = 0;
+  int64_t n_groups = 0;
+  std::vector<dfgpu_array*> keys;     // stored key columns, one row per group (null until first batch)
+  uint64_t capacity = 0;
+  BufferPtr slots, first_row;          // u64[capacity], u32[capacity]
+  BufferPtr ghash; int64_t ghash_cap = 0;   // u64 per group
+  ~dfgpu_groups() { for (auto* a : keys) if (a) dfgpu_array_release(a); }
+};
+
+namespace dfgpu {
+
+__global__ void __launch_bounds__(BLOCK) k_groups_find(KeySet bk, KeySet stored, int has_stored, int64_t n, const uint64_t* mask, int force_zero,
+                                                       uint64_t* slots, uint64_t cap_mask, uint32_t* first_row, uint32_t* tmp,
+                                                       unsigned long long* counters /* [0] new groups, [1] overflow */, unsigned long long limit) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t res = G_NONE;
+  if (mask == nullptr || bit_get(mask, i)) {
+    bool an; uint64_t h = keyset_hash(bk, i, GROUP_SEED, &an);
+    if (force_zero) h = 0;
+    uint64_t tag = h >> 32, s = h & cap_mask, mine = (tag << 32) | (uint64_t)(G_NEW | (uint32_t)i);
+    bool done = false;
+    for (uint64_t step = 0; step <= cap_mask && !done; step++) {
+      uint64_t cur = slots[s];
+      if (cur == G_EMPTY) {
+        if (counters[0] >= limit) { atomicMax(&counters[1], 1ull); break; }
+        cur = atomicCAS((unsigned long long*)&slots[s], (unsigned long long)G_EMPTY, (unsigned long long)mine);
+        if (cur == G_EMPTY) { if (atomicAdd(&counters[0], 1ull) + 1 > limit) atomicMax(&counters[1], 1ull); cur = mine; }
+      }
+      if ((cur >> 32) == tag) {
+        uint32_t pl = (uint32_t)cur;
+        if (pl & G_NEW) {
+          int64_t rep = pl & ~G_NEW;
+          if (rep == i || keyset_equal(bk, i, bk, rep, true)) { atomicMin(&first_row[s], (uint32_t)i); res = G_NEW | (uint32_t)s; done = true; }
+        } else if (has_stored && keyset_equal(bk, i, stored, (int64_t)pl, true)) { res = pl; done = true; }
+      }
+      s = (s + 1) & cap_mask;
+    }
+    if (!done) atomicMax(&counters[1], 1ull);      // table full
+  }
+  tmp[i] = res;
+}
+__global__ void __launch_bounds__(BLOCK) k_groups_mark_first(const uint32_t* tmp, const uint32_t* first_row, int64_t n, uint64_t* bits) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  bool f = false;
+  if (i < n) { uint32_t t = tmp[i]; f = t != G_NONE && (t & G_NEW) && first_row[t & ~G_NEW] == (uint32_t)i; }
+  uint64_t m = ballot64(f);
+  if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) bits[i >> 6] = m;
+}
+__global__ void __launch_bounds__(BLOCK) k_groups_assign(KeySet bk, const uint32_t* first_rows, int64_t n_new, const uint32_t* tmp, uint64_t* slots,
+                                                         uint32_t* first_row, uint32_t base, int force_zero, uint64_t* ghash) {
+  int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (k >= n_new) return;
+  uint32_t i = first_rows[k], s = tmp[i] & ~G_NEW;
+  slots[s] = (slots[s] & 0xFFFFFFFF00000000ull) | (uint64_t)(base + (uint32_t)k);
+  first_row[s] = G_NONE;
+  bool an; uint64_t h = keyset_hash(bk, i, GROUP_SEED, &an);
+  ghash[base + k] = force_zero ? 0 : h;
+}
+__global__ void __launch_bounds__(BLOCK) k_groups_finalize(const uint32_t* tmp, const uint64_t* slots, int64_t n, uint32_t* out) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t t = tmp[i];
+  out[i] = (t != G_NONE && (t & G_NEW)) ? (uint32_t)slots[t & ~G_NEW] : t;
+}
+// re-insert numbered groups into a fresh table (all keys distinct: no comparisons needed)
+__global__ void __launch_bounds__(BLOCK) k_groups_rehash(const uint64_t* ghash, int64_t n_groups, uint64_t* slots, uint64_t cap_mask) {
+  int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (g >= n_groups) return;
+  uint64_t h = ghash[g], s = h & cap_mask, mine = ((h >> 32) << 32) | (uint64_t)g;
+  for (uint64_t step = 0; step <= cap_mask; step++) {
+    if (slots[s] == G_EMPTY && atomicCAS((unsigned long long*)&slots[s], (unsigned long long)G_EMPTY, (unsigned long long)mine) == G_EMPTY) return;
+    s = (s + 1) & cap_mask;
+  }
+}
+
+static void groups_alloc_table(dfgpu_groups* g, uint64_t cap) {
+  dfgpu_ctx* ctx = g->ctx;
+  g->capacity = cap;
+  g->slots = alloc_buffer(ctx, cap * 8); HIP_CHECK(hipMemsetAsync(g->slots->ptr, 0xFF, cap * 8, ctx->stream));
+  g->first_row = alloc_buffer(ctx, cap * 4); HIP_CHECK(hipMemsetAsync(g->first_row->ptr, 0xFF, cap * 4, ctx->stream));
+  if (g->n_groups) hipLaunchKernelGGL(k_groups_rehash, dim3(grid_for(g->n_groups, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)g->ghash->ptr, g->n_groups, (uint64_t*)g->slots->ptr, cap - 1);
+  KERNEL_CHECK();
+}
+
+}  // namespace dfgpu
+
+extern "C" {
+
+dfgpu_status dfgpu_groups_new(dfgpu_ctx* ctx, int32_t nkeys, dfgpu_groups** out) {
+  return guard(ctx, [&] {
+    if (nkeys < 1 || nkeys > MAX_KEYS || !out) fail(DFGPU_INVALID_ARGUMENT, "groups_new: 1..%d key columns", MAX_KEYS);
+    auto* g = new dfgpu_groups(); g->ctx = ctx; g->nkeys = nkeys; g->keys.assign(nkeys, nullptr);
+    *out = g;
+  });
+}
+void dfgpu_groups_free(dfgpu_groups* g) { delete g; }
+int64_t dfgpu_groups_len(const dfgpu_groups* g) { return g ? g->n_groups : 0; }
+int64_t dfgpu_groups_size(const dfgpu_groups* g) {
+  if (!g) return 0;
+  int64_t b = (int64_t)g->capacity * 12 + g->ghash_cap * 8;
+  for (auto* a : g->keys) if (a) b += (a->values ? (int64_t)a->values->bytes : 0) + (a->validity ? (int64_t)a->validity->bytes : 0) + (a->offsets ? (int64_t)a->offsets->bytes : 0);
+  return b;
+}
+
+dfgpu_status dfgpu_groups_intern(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_array* const* cols, int32_t nkeys, const dfgpu_array* opt_mask, dfgpu_array** out_group_ids) {
+  return guard(ctx, [&] {
+    if (!g || !cols || !out_group_ids) fail(DFGPU_INVALID_ARGUMENT, "groups_intern: null argument");
+    if (nkeys != g->nkeys) fail(DFGPU_INVALID_ARGUMENT, "groups_intern: %d key columns given, %d expected", nkeys, g->nkeys);
+    KeySet bk = make_keyset(cols, nkeys);
+    int64_t n = cols[0]->length;
+    if (n >= (int64_t)G_NEW) fail(DFGPU_NOT_IMPLEMENTED, "intern batches above 2^31 rows; split the batch");
+    for (int c = 0; c < nkeys; c++) if (g->keys[c] && logical_type(cols[c]) != g->keys[c]->type) fail(DFGPU_INVALID_ARGUMENT, "groups_intern: key %d changed type", c);
+    KeySet stored{}; int has_stored = 0;
+    if (g->n_groups) { std::vector<const dfgpu_array*> sk(g->keys.begin(), g->keys.end()); stored = make_keyset(sk.data(), nkeys); has_stored = 1; }
+    BufferPtr mask = effective_mask(ctx, opt_mask, n);
+    ArrayHolder ids(new_fixed(ctx, DFGPU_UINT32, n));
+    if (n == 0) { *out_group_ids = ids.release(); return; }
+    BufferPtr tmp = alloc_buffer(ctx, (size_t)n * 4);
+    // optimistic table size: grow x16 and redo the batch when more than capacity/2 groups show up
+    uint64_t want = 1ull << 16; while (want < (uint64_t)g->n_groups * 4) want <<= 1;
+    if (g->capacity < want) groups_alloc_table(g, want);
+    int64_t n_new = 0;
+    for (;;) {
+      uint64_t limit = g->capacity / 2 > (uint64_t)g->n_groups ? g->capacity / 2 - (uint64_t)g->n_groups : 0;
+      zero_scratch(ctx);
+      hipLaunchKernelGGL(k_groups_find, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, bk, stored, has_stored, n, mask ? (const uint64_t*)mask->ptr : nullptr,
+                         ctx->force_hash_collisions ? 1 : 0, (uint64_t*)g->slots->ptr, g->capacity - 1, (uint32_t*)g->first_row->ptr, (uint32_t*)tmp->ptr,
+                         (unsigned long long*)ctx->d_scratch64, (unsigned long long)limit);
+      KERNEL_CHECK();
+      HIP_CHECK(hipMemcpyAsync(ctx->h_pinned, ctx->d_scratch64, 16, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      if (ctx->h_pinned[1] == 0) { n_new = (int64_t)ctx->h_pinned[0]; break; }
+      if (g->capacity >= (1ull << 31)) fail(DFGPU_RESOURCES_EXHAUSTED, "group table would exceed 2^31 slots");
+      uint64_t ncap = g->capacity << 4; if (ncap > (1ull << 31)) ncap = 1ull << 31;
+      groups_alloc_table(g, ncap);
+    }
+    if (g->n_groups + n_new >= (int64_t)G_NEW) fail(DFGPU_RESOURCES_EXHAUSTED, "more than 2^31 groups");
+    if (n_new) {
+      BufferPtr bits = alloc_buffer(ctx, bitmap_bytes(n));
+      hipLaunchKernelGGL(k_groups_mark_first, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)tmp->ptr, (const uint32_t*)g->first_row->ptr, n, (uint64_t*)bits->ptr);
+      KERNEL_CHECK();
+      ArrayHolder firsts(mask_to_indices_impl(ctx, (const uint64_t*)bits->ptr, n));
+      if (firsts.get()->length != n_new) fail(DFGPU_INTERNAL, "group interning: %lld first rows for %lld new groups", (long long)firsts.get()->length, (long long)n_new);
+      if (g->n_groups + n_new > g->ghash_cap) {
+        int64_t nc = g->ghash_cap ? g->ghash_cap : 1024; while (nc < g->n_groups + n_new) nc *= 2;
+        BufferPtr nh = alloc_buffer(ctx, (size_t)nc * 8);
+        if (g->n_groups) HIP_CHECK(hipMemcpyAsync(nh->ptr, g->ghash->ptr, (size_t)g->n_groups * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        g->ghash = nh; g->ghash_cap = nc;
+      }
+      hipLaunchKernelGGL(k_groups_assign, dim3(grid_for(n_new, BLOCK)), dim3(BLOCK), 0, ctx->stream, bk, (const uint32_t*)firsts.get()->values->ptr, n_new, (const uint32_t*)tmp->ptr,
+                         (uint64_t*)g->slots->ptr, (uint32_t*)g->first_row->ptr, (uint32_t)g->n_groups, ctx->force_hash_collisions ? 1 : 0, (uint64_t*)g->ghash->ptr);
+      KERNEL_CHECK();
+      // append the key values of the new groups (first-seen rows, in id order) to the stored key columns
+      for (int c = 0; c < nkeys; c++) {
+        ArrayHolder nk(take_impl(ctx, cols[c], firsts.get()->values->ptr, 4, nullptr, n_new));
+        if (nk.get()->type == DFGPU_DICTIONARY) {       // store plain values (GroupValues emits the value type)
+          dfgpu_array* k = nk.get(); int kw = type_width(k->key_type);
+          if (kw != 4 && kw != 8) { dfgpu_array* wide = nullptr; ArrayHolder keys_only(new_array(ctx, k->key_type, k->length)); keys_only.get()->values = k->values; keys_only.get()->validity = k->validity; keys_only.get()->null_count = k->null_count;
+            dfgpu_status st = dfgpu_cast(ctx, keys_only.get(), DFGPU_INT64, 0, 0, &wide); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str());
+            ArrayHolder w(wide); ArrayHolder dec(take_impl(ctx, k->dictionary, w.get()->values->ptr, 8, w.get()->validity ? (const uint64_t*)w.get()->validity->ptr : nullptr, k->length)); dfgpu_array_release(nk.release()); nk.a = dec.release(); }
+          else { ArrayHolder dec(take_impl(ctx, k->dictionary, k->values->ptr, kw, k->validity ? (const uint64_t*)k->validity->ptr : nullptr, k->length)); dfgpu_array_release(nk.release()); nk.a = dec.release(); }
+        }
+        if (!g->keys[c]) g->keys[c] = nk.release();
+        else { const dfgpu_array* parts[2] = { g->keys[c], nk.get() }; dfgpu_array* cat = nullptr; dfgpu_status st = dfgpu_concat(ctx, parts, 2, &cat); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str());
+               dfgpu_array_release(g->keys[c]); g->keys[c] = cat; }
+      }
+      check_flags(ctx, "groups_intern");
+    }
+    hipLaunchKernelGGL(k_groups_finalize, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)tmp->ptr, (const uint64_t*)g->slots->ptr, n, (uint32_t*)ids.get()->values->ptr);
+    KERNEL_CHECK();
+    g->n_groups += n_new;
+    *out_group_ids = ids.release();
+  });
+}
+
+dfgpu_status dfgpu_groups_emit(dfgpu_ctx* ctx, dfgpu_groups* g, dfgpu_array** out_cols) {
+  return guard(ctx, [&] {
+    if (!g || !out_cols) fail(DFGPU_INVALID_ARGUMENT, "groups_emit: null argument");
+    if (g->n_groups == 0) fail(DFGPU_INVALID_ARGUMENT, "groups_emit: no groups interned yet (key types unknown)");
+    for (int c = 0; c < g->nkeys; c++) { dfgpu_array_retain(g->keys[c]); out_cols[c] = g->keys[c]; }
+  });
+}
+
+}  // extern "C"

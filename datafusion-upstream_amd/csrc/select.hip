@@ -1,0 +1,195 @@
+// select.hip -- arrow-select on device: take (gather), filter (ordered stream compaction), selection vectors.
+//
+// take:   ≙ arrow::compute::take as used by build_batch_from_indices (joins/utils.rs:1180-1230),
+//         sort_batch (sorts/sort.rs:605) and BatchPartitioner (repartition/mod.rs:202).
+// filter: ≙ filter_record_batch (filter.rs:315-327): wave64 ballot + popcount prefix, order preserving.
+#include "device_utils.h"
+
+namespace dfgpu {
+
+struct U128 { uint64_t lo, hi; };
+template <int W> struct WT;
+template <> struct WT<1> { using T = uint8_t; };
+template <> struct WT<2> { using T = uint16_t; };
+template <> struct WT<4> { using T = uint32_t; };
+template <> struct WT<8> { using T = uint64_t; };
+template <> struct WT<16> { using T = U128; };
+
+__global__ void k_iota_u32(uint32_t* out, int64_t n, uint32_t start) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = start + (uint32_t)i;
+}
+void launch_iota_u32(dfgpu_ctx* ctx, uint32_t* out, int64_t n, uint32_t start) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, out, n, start);
+  KERNEL_CHECK();
+}
+
+__device__ inline int64_t load_index(const void* idx, int w, int64_t i) { return w == 4 ? (int64_t)((const uint32_t*)idx)[i] : (int64_t)((const uint64_t*)idx)[i]; }
+
+// One lane per output row; each wave owns 64 consecutive rows so the validity word is one ballot.
+template <int W>
+__global__ void __launch_bounds__(BLOCK) k_take_fixed(const typename WT<W>::T* src, const uint64_t* src_valid, int64_t src_len,
+                                                      const void* idx, int idx_w, const uint64_t* idx_valid, int64_t n,
+                                                      typename WT<W>::T* out, uint64_t* out_valid, uint32_t* flags) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  bool ok = false; typename WT<W>::T v{};
+  if (i < n && valid_at(idx_valid, i)) {
+    int64_t j = load_index(idx, idx_w, i);
+    if (j < 0 || j >= src_len) atomicOr(flags, DFGPU_FLAG_OOB);
+    else { ok = valid_at(src_valid, j); v = src[j]; }
+  }
+  if (i < n) out[i] = v;
+  if (out_valid) { uint64_t m = ballot64(ok); if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) out_valid[i >> 6] = m; }
+}
+__global__ void __launch_bounds__(BLOCK) k_take_bool(const uint64_t* src, const uint64_t* src_valid, int64_t src_len,
+                                                     const void* idx, int idx_w, const uint64_t* idx_valid, int64_t n,
+                                                     uint64_t* out, uint64_t* out_valid, uint32_t* flags) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  bool ok = false, v = false;
+  if (i < n && valid_at(idx_valid, i)) {
+    int64_t j = load_index(idx, idx_w, i);
+    if (j < 0 || j >= src_len) atomicOr(flags, DFGPU_FLAG_OOB);
+    else { ok = valid_at(src_valid, j); v = bit_get(src, j); }
+  }
+  uint64_t mv = ballot64(v), mo = ballot64(ok);
+  if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) { out[i >> 6] = mv; if (out_valid) out_valid[i >> 6] = mo; }
+}
+__global__ void __launch_bounds__(BLOCK) k_take_utf8_len(const int32_t* src_off, const uint64_t* src_valid, int64_t src_len,
+                                                         const void* idx, int idx_w, const uint64_t* idx_valid, int64_t n,
+                                                         uint32_t* out_len, uint64_t* out_valid, uint32_t* flags) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  bool ok = false; uint32_t len = 0;
+  if (i < n && valid_at(idx_valid, i)) {
+    int64_t j = load_index(idx, idx_w, i);
+    if (j < 0 || j >= src_len) atomicOr(flags, DFGPU_FLAG_OOB);
+    else { ok = valid_at(src_valid, j); if (ok) len = (uint32_t)(src_off[j + 1] - src_off[j]); }
+  }
+  if (i < n) out_len[i] = len;
+  if (out_valid) { uint64_t m = ballot64(ok); if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) out_valid[i >> 6] = m; }
+}
+__global__ void __launch_bounds__(BLOCK) k_take_utf8_copy(const uint8_t* src, const int32_t* src_off, const void* idx, int idx_w,
+                                                          const uint64_t* out_off64, int64_t n, int32_t* out_off, uint8_t* out, uint64_t total) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i > n) return;
+  if (i == n) { out_off[n] = (int32_t)total; return; }
+  uint64_t o = out_off64[i]; out_off[i] = (int32_t)o;
+  uint64_t next = i + 1 < n ? out_off64[i + 1] : total;
+  int64_t len = (int64_t)(next - o);
+  if (len > 0) { int64_t j = load_index(idx, idx_w, i); const uint8_t* p = src + src_off[j]; for (int64_t b = 0; b < len; b++) out[o + b] = p[b]; }
+}
+
+dfgpu_array* take_impl(dfgpu_ctx* ctx, const dfgpu_array* a, const void* idx, int idx_w, const uint64_t* idx_valid, int64_t n) {
+  if (n > 0xFFFFFFF0ll) fail(DFGPU_NOT_IMPLEMENTED, "take above 2^32-16 rows");
+  bool need_valid = idx_valid != nullptr || a->validity != nullptr;
+  int32_t vt = a->type == DFGPU_DICTIONARY ? a->key_type : a->type;
+  ArrayHolder h(new_array(ctx, a->type, n, a->precision, a->scale));
+  dfgpu_array* o = h.get(); o->key_type = a->key_type;
+  if (need_valid) o->validity = alloc_buffer(ctx, bitmap_bytes(n), n == 0); else o->null_count = 0;
+  uint64_t* ov = need_valid ? (uint64_t*)o->validity->ptr : nullptr;
+  const uint64_t* sv = a->validity ? (const uint64_t*)a->validity->ptr : nullptr;
+  dim3 grid(grid_for(n, BLOCK)), block(BLOCK);
+  if (a->type == DFGPU_UTF8) {
+    BufferPtr lens = alloc_buffer(ctx, (size_t)(n + 1) * 4), off64 = alloc_buffer(ctx, (size_t)(n + 1) * 8);
+    if (n) hipLaunchKernelGGL(k_take_utf8_len, grid, block, 0, ctx->stream, (const int32_t*)a->offsets->ptr, sv, a->length, idx, idx_w, idx_valid, n, (uint32_t*)lens->ptr, ov, ctx->d_flags);
+    exclusive_scan_u32(ctx, (const uint32_t*)lens->ptr, (uint64_t*)off64->ptr, n, ctx->d_scratch64 + 61);
+    uint64_t total = read_scratch(ctx, 61);
+    if (total > 0x7FFFFFFFull) fail(DFGPU_EXECUTION, "Arrow error: offset overflow: Utf8 output of %llu bytes exceeds i32 offsets", (unsigned long long)total);
+    o->values = alloc_buffer(ctx, (size_t)total); o->values_bytes = (int64_t)total; o->offsets = alloc_buffer(ctx, (size_t)(n + 1) * 4, true);
+    hipLaunchKernelGGL(k_take_utf8_copy, dim3(grid_for(n + 1, BLOCK)), block, 0, ctx->stream, (const uint8_t*)a->values->ptr, (const int32_t*)a->offsets->ptr, idx, idx_w,
+                       (const uint64_t*)off64->ptr, n, (int32_t*)o->offsets->ptr, (uint8_t*)o->values->ptr, total);
+    KERNEL_CHECK();
+  } else if (vt == DFGPU_BOOL) {
+    o->values = alloc_buffer(ctx, bitmap_bytes(n), n == 0);
+    if (n) hipLaunchKernelGGL(k_take_bool, grid, block, 0, ctx->stream, (const uint64_t*)a->values->ptr, sv, a->length, idx, idx_w, idx_valid, n, (uint64_t*)o->values->ptr, ov, ctx->d_flags);
+    KERNEL_CHECK();
+  } else {
+    int w = type_width(vt);
+    o->values = alloc_buffer(ctx, (size_t)n * w);
+    if (n) switch (w) {
+#define TAKE_CASE(W) case W: hipLaunchKernelGGL((k_take_fixed<W>), grid, block, 0, ctx->stream, (const WT<W>::T*)a->values->ptr, sv, a->length, idx, idx_w, idx_valid, n, (WT<W>::T*)o->values->ptr, ov, ctx->d_flags); break;
+      TAKE_CASE(1) TAKE_CASE(2) TAKE_CASE(4) TAKE_CASE(8) TAKE_CASE(16)
+#undef TAKE_CASE
+      default: fail(DFGPU_INTERNAL, "take: width %d", w);
+    }
+    KERNEL_CHECK();
+  }
+  if (a->dictionary) { o->dictionary = a->dictionary; dfgpu_array_retain(a->dictionary); }
+  if (need_valid) o->null_count = -1;
+  return h.release();
+}
+
+// ---------------------------------------------------------------- mask -> ascending selection vector
+constexpr int SEL_WORDS = 32;           // 64-bit mask words per workgroup = 2048 rows
+__device__ inline uint64_t mask_word(const uint64_t* bits, int64_t w, int64_t n) {
+  int64_t nw = (n + 63) >> 6; if (w >= nw) return 0;
+  uint64_t x = bits[w];
+  if (w == nw - 1 && (n & 63)) x &= (1ull << (n & 63)) - 1ull;
+  return x;
+}
+__global__ void __launch_bounds__(BLOCK) k_sel_count(const uint64_t* bits, int64_t n, uint32_t* counts) {
+  int64_t w0 = (int64_t)blockIdx.x * SEL_WORDS;
+  if (threadIdx.x < 64) {
+    uint32_t c = threadIdx.x < SEL_WORDS ? __popcll(mask_word(bits, w0 + threadIdx.x, n)) : 0;
+    c = wave_sum(c);
+    if (threadIdx.x == 0) counts[blockIdx.x] = c;
+  }
+}
+__global__ void __launch_bounds__(BLOCK) k_sel_write(const uint64_t* bits, int64_t n, const uint32_t* offsets, uint32_t* out) {
+  int64_t w0 = (int64_t)blockIdx.x * SEL_WORDS;
+  int lane = lane_id(), wave = threadIdx.x >> 6;
+  uint64_t word = lane < SEL_WORDS ? mask_word(bits, w0 + lane, n) : 0;
+  uint32_t pc = __popcll(word);
+  uint32_t ex = wave_inclusive_sum(pc) - pc;
+  uint32_t base = offsets[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SEL_WORDS / 4; k++) {
+    int wi = wave * (SEL_WORDS / 4) + k;
+    uint64_t m = __shfl(word, wi, 64); uint32_t p = __shfl(ex, wi, 64);
+    if ((m >> lane) & 1) out[base + p + __popcll(m & lanemask_lt())] = (uint32_t)((w0 + wi) * 64 + lane);
+  }
+}
+dfgpu_array* mask_to_indices_impl(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n) {
+  int64_t nw = (n + 63) / 64, nb = (nw + SEL_WORDS - 1) / SEL_WORDS;
+  if (n == 0) return new_fixed(ctx, DFGPU_UINT32, 0);
+  BufferPtr counts = alloc_buffer(ctx, (size_t)nb * 4);
+  hipLaunchKernelGGL(k_sel_count, dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream, bits, n, (uint32_t*)counts->ptr);
+  exclusive_scan_u32_inplace32(ctx, (uint32_t*)counts->ptr, nb, ctx->d_scratch64 + 60);
+  int64_t total = (int64_t)read_scratch(ctx, 60);
+  ArrayHolder h(new_fixed(ctx, DFGPU_UINT32, total));
+  if (total) hipLaunchKernelGGL(k_sel_write, dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream, bits, n, (const uint32_t*)counts->ptr, (uint32_t*)h.get()->values->ptr);
+  KERNEL_CHECK();
+  return h.release();
+}
+
+}  // namespace dfgpu
+
+using namespace dfgpu;
+extern "C" {
+
+dfgpu_status dfgpu_take(dfgpu_ctx* ctx, const dfgpu_array* values, const dfgpu_array* indices, dfgpu_array** out) {
+  return guard(ctx, [&] {
+    if (!values || !indices || !out) fail(DFGPU_INVALID_ARGUMENT, "take: null argument");
+    int w = indices->type == DFGPU_UINT32 || indices->type == DFGPU_INT32 ? 4 : (indices->type == DFGPU_UINT64 || indices->type == DFGPU_INT64 ? 8 : 0);
+    if (!w) fail(DFGPU_INVALID_ARGUMENT, "take: indices must be 32/64-bit integers");
+    *out = take_impl(ctx, values, indices->values->ptr, w, indices->validity ? (const uint64_t*)indices->validity->ptr : nullptr, indices->length);
+    check_flags(ctx, "take");
+  });
+}
+dfgpu_status dfgpu_mask_to_indices(dfgpu_ctx* ctx, const dfgpu_array* mask, dfgpu_array** out) {
+  return guard(ctx, [&] {
+    BufferPtr m = effective_mask(ctx, mask, mask ? mask->length : 0);
+    if (!m) fail(DFGPU_INVALID_ARGUMENT, "mask_to_indices: null mask");
+    *out = mask_to_indices_impl(ctx, (const uint64_t*)m->ptr, mask->length);
+  });
+}
+dfgpu_status dfgpu_filter(dfgpu_ctx* ctx, const dfgpu_array* values, const dfgpu_array* mask, dfgpu_array** out) {
+  return guard(ctx, [&] {
+    if (!values || !mask) fail(DFGPU_INVALID_ARGUMENT, "filter: null argument");
+    BufferPtr m = effective_mask(ctx, mask, values->length);
+    ArrayHolder sel(mask_to_indices_impl(ctx, (const uint64_t*)m->ptr, mask->length));
+    *out = take_impl(ctx, values, sel.get()->values->ptr, 4, nullptr, sel.get()->length);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+// sort.hip -- a13 SortExec / sort_batch (physical-plan/src/sorts/sort.rs:584-609) and the stable
+// multi-split used by the join CSR build and by RepartitionExec.
+//
+// lexsort_to_indices is done as: order-preserving byte encoding of the sort columns (one plane per
+// key byte, [byte][row] so a pass streams one n-byte plane) + stable LSD radix sort (8-bit digits)
+// of the UInt32 row ids.  Key bytes never move; passes whose byte is constant over all rows are
+// skipped using one up-front histogram of every plane.  Ranking inside a wave uses 64-wide ballots
+// (match-any over the 8 digit bits), across the 4 waves of a workgroup a small LDS table.
+// Stable => ties keep input order (the reference leaves tie order unspecified: sort_unstable_by,
+// sorts/sort.rs:641).
+#include "device_utils.h"
+#include <algorithm>
+
+namespace dfgpu {
+
+constexpr int RS_MAX_BLOCKS = 1024;
+
+struct DigitKeys { const uint32_t* keys; int shift; };                 // digit from a u32 key that moves with the value
+struct DigitPlane { const uint8_t* plane; };                           // digit = plane[row id], only row ids move
+__device__ inline uint32_t digit_of(const DigitKeys& d, uint32_t key, uint32_t) { return (key >> d.shift) & 0xFFu; }
+__device__ inline uint32_t digit_of(const DigitPlane& d, uint32_t, uint32_t val) { return d.plane[val]; }
+
+template <typename D>
+__global__ void __launch_bounds__(BLOCK) k_rs_hist(D dg, const uint32_t* keys, const uint32_t* vals, int64_t n, int64_t chunk, int nb, uint32_t* hist) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0; __syncthreads();
+  int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += BLOCK) atomicAdd(&h[digit_of(dg, keys ? keys[i] : 0u, vals[i])], 1u);
+  __syncthreads();
+  hist[(int64_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+
+template <typename D>
+__global__ void __launch_bounds__(BLOCK) k_rs_scatter(D dg, const uint32_t* keys, const uint32_t* vals, int64_t n, int64_t chunk, int nb,
+                                                      const uint32_t* offsets, uint32_t* out_keys, uint32_t* out_vals) {
+  __shared__ uint32_t running[256];
+  __shared__ uint32_t wave_cnt[BLOCK / WAVE][256];
+  running[threadIdx.x] = offsets[(int64_t)threadIdx.x * nb + blockIdx.x];
+#pragma unroll
+  for (int w = 0; w < BLOCK / WAVE; w++) wave_cnt[w][threadIdx.x] = 0;
+  __syncthreads();
+  int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  int lane = lane_id(), wave = threadIdx.x >> 6;
+  for (int64_t t0 = lo; t0 < hi; t0 += BLOCK) {
+    int64_t i = t0 + threadIdx.x;
+    bool active = i < hi;
+    uint32_t key = 0, val = 0, d = 0;
+    if (active) { val = vals[i]; key = keys ? keys[i] : 0u; d = digit_of(dg, key, val); }
+    // match-any: lanes of this wave holding the same digit
+    uint64_t peers = ballot64(active);
+#pragma unroll
+    for (int b = 0; b < 8; b++) { uint64_t m = ballot64((d >> b) & 1u); peers &= ((d >> b) & 1u) ? m : ~m; }
+    uint32_t rank = __popcll(peers & lanemask_lt());
+    if (active && rank == 0) wave_cnt[wave][d] = __popcll(peers);
+    __syncthreads();
+    if (active) {
+      uint32_t pos = running[d] + rank;
+      for (int w = 0; w < wave; w++) pos += wave_cnt[w][d];
+      out_vals[pos] = val; if (out_keys) out_keys[pos] = key;
+    }
+    __syncthreads();
+    uint32_t add = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / WAVE; w++) { add += wave_cnt[w][threadIdx.x]; wave_cnt[w][threadIdx.x] = 0; }
+    running[threadIdx.x] += add;
+    __syncthreads();
+  }
+}
+
+struct RadixPlan { int nb; int64_t chunk; };
+static RadixPlan plan_for(int64_t n) {
+  int64_t nb = (n + 4095) / 4096; if (nb < 1) nb = 1; if (nb > RS_MAX_BLOCKS) nb = RS_MAX_BLOCKS;
+  int64_t chunk = (n + nb - 1) / nb; chunk = (chunk + BLOCK - 1) / BLOCK * BLOCK;
+  nb = (n + chunk - 1) / chunk; if (nb < 1) nb = 1;
+  return { (int)nb, chunk };
+}
+
+template <typename D>
+static void radix_pass(dfgpu_ctx* ctx, D dg, const uint32_t* keys, const uint32_t* vals, uint32_t* out_keys, uint32_t* out_vals, int64_t n, uint32_t* hist, RadixPlan p) {
+  hipLaunchKernelGGL((k_rs_hist<D>), dim3(p.nb), dim3(BLOCK), 0, ctx->stream, dg, keys, vals, n, p.chunk, p.nb, hist);
+  exclusive_scan_u32_inplace32(ctx, hist, (int64_t)256 * p.nb, nullptr);
+  hipLaunchKernelGGL((k_rs_scatter<D>), dim3(p.nb), dim3(BLOCK), 0, ctx->stream, dg, keys, vals, n, p.chunk, p.nb, (const uint32_t*)hist, out_keys, out_vals);
+  KERNEL_CHECK();
+}
+
+void radix_sort_pairs_u32(dfgpu_ctx* ctx, uint32_t* keys, uint32_t* vals, int64_t n, int bits) {
+  if (n <= 1) return;
+  if (n > 0xFFFFFFF0ll) fail(DFGPU_NOT_IMPLEMENTED, "sort above 2^32-16 rows");
+  RadixPlan p = plan_for(n);
+  BufferPtr tk = alloc_buffer(ctx, (size_t)n * 4), tv = alloc_buffer(ctx, (size_t)n * 4), hist = alloc_buffer(ctx, (size_t)256 * p.nb * 4);
+  uint32_t *k0 = keys, *v0 = vals, *k1 = (uint32_t*)tk->ptr, *v1 = (uint32_t*)tv->ptr;
+  int passes = (bits + 7) / 8;
+  for (int ps = 0; ps < passes; ps++) {
+    radix_pass(ctx, DigitKeys{ k0, ps * 8 }, k0, v0, k1, v1, n, (uint32_t*)hist->ptr, p);
+    std::swap(k0, k1); std::swap(v0, v1);
+  }
+  if (k0 != keys) {
+    HIP_CHECK(hipMemcpyAsync(keys, k0, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(vals, v0, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+}
+
+// ---------------------------------------------------------------- order-preserving key encoding
+struct SortCol { ColView v; int32_t byte_off; int32_t has_null_byte; int32_t descending; int32_t nulls_first; };
+struct SortCols { int32_t n; SortCol c[MAX_KEYS]; };
+
+__device__ inline void put_be(uint8_t* planes, int64_t n, int64_t row, int off, uint64_t v, int width, uint8_t inv) {
+  for (int b = 0; b < width; b++) planes[(int64_t)(off + b) * n + row] = (uint8_t)(v >> (8 * (width - 1 - b))) ^ inv;
+}
+__global__ void __launch_bounds__(BLOCK) k_encode_sort_keys(SortCols sc, int64_t n, uint8_t* planes) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  for (int c = 0; c < sc.n; c++) {
+    const SortCol& s = sc.c[c]; const ColView& v = s.v;
+    int64_t r; bool ok = cell_resolve(v, i, &r);
+    int off = s.byte_off;
+    if (s.has_null_byte) { planes[(int64_t)off * n + i] = ok ? (s.nulls_first ? 1 : 0) : (s.nulls_first ? 0 : 1); off++; }
+    int w = v.type == DFGPU_BOOL ? 1 : v.width;
+    if (!ok) { for (int b = 0; b < w; b++) planes[(int64_t)(off + b) * n + i] = 0; continue; }
+    uint8_t inv = s.descending ? 0xFF : 0x00;
+    switch (v.type) {
+      case DFGPU_BOOL: put_be(planes, n, i, off, bit_get((const uint64_t*)v.values, r), 1, inv); break;
+      case DFGPU_INT8: put_be(planes, n, i, off, (uint8_t)(((const uint8_t*)v.values)[r] ^ 0x80u), 1, inv); break;
+      case DFGPU_INT16: put_be(planes, n, i, off, (uint16_t)(((const uint16_t*)v.values)[r] ^ 0x8000u), 2, inv); break;
+      case DFGPU_INT32: case DFGPU_DATE32: put_be(planes, n, i, off, ((const uint32_t*)v.values)[r] ^ 0x80000000u, 4, inv); break;
+      case DFGPU_INT64: put_be(planes, n, i, off, ((const uint64_t*)v.values)[r] ^ 0x8000000000000000ull, 8, inv); break;
+      case DFGPU_UINT8: put_be(planes, n, i, off, ((const uint8_t*)v.values)[r], 1, inv); break;
+      case DFGPU_UINT16: put_be(planes, n, i, off, ((const uint16_t*)v.values)[r], 2, inv); break;
+      case DFGPU_UINT32: put_be(planes, n, i, off, ((const uint32_t*)v.values)[r], 4, inv); break;
+      case DFGPU_UINT64: put_be(planes, n, i, off, ((const uint64_t*)v.values)[r], 8, inv); break;
+      case DFGPU_FLOAT32: { uint32_t b = ((const uint32_t*)v.values)[r]; b ^= (b >> 31) ? 0xFFFFFFFFu : 0x80000000u; put_be(planes, n, i, off, b, 4, inv); break; }   // IEEE totalOrder
+      case DFGPU_FLOAT64: { uint64_t b = ((const uint64_t*)v.values)[r]; b ^= (b >> 63) ? ~0ull : 0x8000000000000000ull; put_be(planes, n, i, off, b, 8, inv); break; }
+      case DFGPU_DECIMAL128: { const uint64_t* p = (const uint64_t*)v.values + 2 * r; put_be(planes, n, i, off, p[1] ^ 0x8000000000000000ull, 8, inv); put_be(planes, n, i, off + 8, p[0], 8, inv); break; }
+      default: break;
+    }
+  }
+}
+// per-plane digit totals: tot[plane * 256 + digit]
+__global__ void __launch_bounds__(BLOCK) k_plane_totals(const uint8_t* planes, int64_t n, uint32_t* tot) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0; __syncthreads();
+  const uint8_t* p = planes + (int64_t)blockIdx.y * n;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) atomicAdd(&h[p[i]], 1u);
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&tot[blockIdx.y * 256 + threadIdx.x], h[threadIdx.x]);
+}
+
+}  // namespace dfgpu
+
+using namespace dfgpu;
+extern "C" dfgpu_status dfgpu_sort_to_indices(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint8_t* descending, const uint8_t* nulls_first,
+                                              int32_t k, int64_t fetch, dfgpu_array** out) {
+  return guard(ctx, [&] {
+    if (!cols || k < 1 || !out) fail(DFGPU_INVALID_ARGUMENT, "Sort requires at least one column");
+    if (k > MAX_KEYS) fail(DFGPU_NOT_IMPLEMENTED, "more than %d sort columns", MAX_KEYS);
+    int64_t n = cols[0]->length;
+    SortCols sc{}; sc.n = k; int W = 0;
+    for (int c = 0; c < k; c++) {
+      if (cols[c]->length != n) fail(DFGPU_INVALID_ARGUMENT, "sort columns differ in length");
+      int32_t lt = logical_type(cols[c]);
+      if (lt == DFGPU_UTF8) fail(DFGPU_NOT_IMPLEMENTED, "Utf8 sort keys are not supported on device yet");
+      SortCol& s = sc.c[c]; s.v = make_view(cols[c]); s.byte_off = W;
+      s.has_null_byte = (s.v.validity || s.v.key_validity) ? 1 : 0; s.descending = descending && descending[c]; s.nulls_first = nulls_first ? nulls_first[c] : 1;
+      W += s.has_null_byte + (lt == DFGPU_BOOL ? 1 : type_width(lt));
+    }
+    ArrayHolder idx(new_fixed(ctx, DFGPU_UINT32, n));
+    launch_iota_u32(ctx, (uint32_t*)idx.get()->values->ptr, n, 0);
+    if (n > 1) {
+      BufferPtr planes = alloc_buffer(ctx, (size_t)W * n), tot = alloc_buffer(ctx, (size_t)W * 256 * 4, true);
+      hipLaunchKernelGGL(k_encode_sort_keys, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, sc, n, (uint8_t*)planes->ptr);
+      hipLaunchKernelGGL(k_plane_totals, dim3(grid_for(n, BLOCK * 16, 256), W), dim3(BLOCK), 0, ctx->stream, (const uint8_t*)planes->ptr, n, (uint32_t*)tot->ptr);
+      KERNEL_CHECK();
+      std::vector<uint32_t> h((size_t)W * 256);
+      HIP_CHECK(hipMemcpyAsync(h.data(), tot->ptr, h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      RadixPlan p = plan_for(n);
+      BufferPtr tmp = alloc_buffer(ctx, (size_t)n * 4), hist = alloc_buffer(ctx, (size_t)256 * p.nb * 4);
+      uint32_t *v0 = (uint32_t*)idx.get()->values->ptr, *v1 = (uint32_t*)tmp->ptr;
+      for (int b = W - 1; b >= 0; b--) {        // least significant plane first
+        bool constant = false;
+        for (int d = 0; d < 256; d++) if (h[(size_t)b * 256 + d] == (uint32_t)n) { constant = true; break; }
+        if (constant) continue;
+        radix_pass(ctx, DigitPlane{ (const uint8_t*)planes->ptr + (int64_t)b * n }, (const uint32_t*)nullptr, v0, (uint32_t*)nullptr, v1, n, (uint32_t*)hist->ptr, p);
+        std::swap(v0, v1);
+      }
+      if (v0 != (uint32_t*)idx.get()->values->ptr) HIP_CHECK(hipMemcpyAsync(idx.get()->values->ptr, v0, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));   // tmp / planes are released on return
+    }
+    if (fetch >= 0 && fetch < n) { dfgpu_array* s = nullptr; dfgpu_status st = dfgpu_array_slice(ctx, idx.get(), 0, fetch, &s); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str()); *out = s; }
+    else *out = idx.release();
+  });
+}

@@ -1,0 +1,338 @@
+"""Thin object wrappers over the C ABI: Context, Array (HBM-resident Arrow column), JoinTable,
+GroupValues, GroupsAccumulator.  Names follow the reference types they stand for."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+from . import capi
+from .capi import DfgpuError
+
+
+class Context:
+    """One device + one HIP stream (what ExecutionPlan::execute(partition, ..) runs on)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = capi.load_library()
+        h = C.c_void_p()
+        st = self.lib.dfgpu_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h))
+        if st != 0 or not h.value:
+            raise DfgpuError(st or 1, f"dfgpu_ctx_create(device={device}) failed: no usable HIP device (there is no CPU fallback)")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.dfgpu_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, status: int):
+        if status != 0:
+            msg = self.lib.dfgpu_last_error(self.h)
+            raise DfgpuError(status, msg.decode() if msg else "")
+
+    def synchronize(self):
+        self.check(self.lib.dfgpu_ctx_synchronize(self.h))
+
+    def set_option(self, key: str, value: int):
+        self.check(self.lib.dfgpu_ctx_set_option(self.h, key.encode(), int(value)))
+
+    @property
+    def stream(self) -> int:
+        return self.lib.dfgpu_ctx_stream(self.h) or 0
+
+    # ---- arrays
+    def _wrap(self, handle: C.c_void_p) -> "Array":
+        return Array(self, handle)
+
+    def from_arrow(self, arr) -> "Array":
+        """pyarrow.Array -> HBM (Arrow C Data Interface, PCIe copy)."""
+        import pyarrow as pa
+        if isinstance(arr, pa.ChunkedArray):
+            arr = arr.combine_chunks()
+        if arr.offset != 0:
+            arr = pa.concat_arrays([arr])       # materialise the slice so that offset == 0
+        ca, cs = capi.ArrowArray(), capi.ArrowSchema()
+        arr._export_to_c(C.addressof(ca), C.addressof(cs))
+        out = C.c_void_p()
+        try:
+            self.check(self.lib.dfgpu_array_import_arrow(self.h, C.byref(ca), C.byref(cs), C.byref(out)))
+        finally:
+            for s in (ca, cs):
+                if s.release:
+                    C.CFUNCTYPE(None, C.c_void_p)(s.release)(C.addressof(s))
+        return self._wrap(out)
+
+    def wrap_device(self, desc: capi.ArrayDesc, keepalive=None) -> "Array":
+        out = C.c_void_p()
+        self.check(self.lib.dfgpu_array_wrap_device(self.h, C.byref(desc), C.byref(out)))
+        a = self._wrap(out)
+        a._keepalive = keepalive
+        return a
+
+    def wrap_tensor(self, tensor, dtype: int, precision: int = 0, scale: int = 0) -> "Array":
+        """Zero-copy view of a contiguous torch CUDA tensor as a non-null fixed-width column."""
+        d = capi.ArrayDesc()
+        width = {capi.INT8: 1, capi.UINT8: 1, capi.INT16: 2, capi.UINT16: 2, capi.INT32: 4, capi.UINT32: 4, capi.FLOAT32: 4, capi.DATE32: 4,
+                 capi.INT64: 8, capi.UINT64: 8, capi.FLOAT64: 8, capi.DECIMAL128: 16}[dtype]
+        nbytes = tensor.numel() * tensor.element_size()
+        assert tensor.is_contiguous() and nbytes % width == 0
+        d.type, d.precision, d.scale, d.length, d.null_count = dtype, precision, scale, nbytes // width, 0
+        d.values = tensor.data_ptr()
+        return self.wrap_device(d, keepalive=tensor)
+
+    def concat(self, arrays: Sequence["Array"]) -> "Array":
+        hs, n = capi.handle_array([a.h.value for a in arrays])
+        out = C.c_void_p()
+        self.check(self.lib.dfgpu_concat(self.h, hs, n, C.byref(out)))
+        return self._wrap(out)
+
+    def new_null(self, dtype: int, length: int, precision: int = 0, scale: int = 0) -> "Array":
+        out = C.c_void_p()
+        self.check(self.lib.dfgpu_array_new_null(self.h, dtype, precision, scale, length, C.byref(out)))
+        return self._wrap(out)
+
+    # ---- a1
+    def hash_columns(self, cols: Sequence["Array"], seed: int = 0) -> "Array":
+        hs, n = capi.handle_array([a.h.value for a in cols])
+        out = C.c_void_p()
+        self.check(self.lib.dfgpu_hash_columns(self.h, hs, n, seed, C.byref(out)))
+        return self._wrap(out)
+
+    # ---- arrow-select
+    def take(self, values: "Array", indices: "Array") -> "Array":
+        out = C.c_void_p()
+        self.check(self.lib.dfgpu_take(self.h, values.h, indices.h, C.byref(out)))
+        return self._wrap(out)
+
+    def filter(self, values: "Array", mask: "Array") -> "Array":
+        out = C.c_void_p()
+        self.check(self.lib.dfgpu_filter(self.h, values.h, mask.h, C.byref(out)))
+        return self._wrap(out)
+
+    def mask_to_indices(self, mask: "Array") -> "Array":
+        out = C.c_void_p()
+        self.check(self.lib.dfgpu_mask_to_indices(self.h, mask.h, C.byref(out)))
+        return self._wrap(out)
+
+    # ---- a12
+    def binary(self, op: int, lhs: "Array", rhs: "Array", lhs_scalar: bool = False, rhs_scalar: bool = False) -> "Array":
+        out = C.c_void_p()
+        self.check(self.lib.dfgpu_binary(self.h, op, lhs.h, int(lhs_scalar), rhs.h, int(rhs_scalar), C.byref(out)))
+        return self._wrap(out)
+
+    def not_(self, a: "Array") -> "Array":
+        out = C.c_void_p()
+        self.check(self.lib.dfgpu_not(self.h, a.h, C.byref(out)))
+        return self._wrap(out)
+
+    def is_null(self, a: "Array", negate: bool = False) -> "Array":
+        out = C.c_void_p()
+        self.check(self.lib.dfgpu_is_null(self.h, a.h, int(negate), C.byref(out)))
+        return self._wrap(out)
+
+    def negative(self, a: "Array") -> "Array":
+        out = C.c_void_p()
+        self.check(self.lib.dfgpu_negative(self.h, a.h, C.byref(out)))
+        return self._wrap(out)
+
+    def cast(self, a: "Array", to_type: int, precision: int = 0, scale: int = 0) -> "Array":
+        out = C.c_void_p()
+        self.check(self.lib.dfgpu_cast(self.h, a.h, to_type, precision, scale, C.byref(out)))
+        return self._wrap(out)
+
+    def in_list(self, a: "Array", lst: "Array", negated: bool = False) -> "Array":
+        out = C.c_void_p()
+        self.check(self.lib.dfgpu_in_list(self.h, a.h, lst.h, int(negated), C.byref(out)))
+        return self._wrap(out)
+
+    # ---- a13 / a14
+    def sort_to_indices(self, cols: Sequence["Array"], descending: Sequence[bool], nulls_first: Sequence[bool], fetch: Optional[int] = None) -> "Array":
+        hs, n = capi.handle_array([a.h.value for a in cols])
+        out = C.c_void_p()
+        self.check(self.lib.dfgpu_sort_to_indices(self.h, hs, bytes(int(bool(x)) for x in descending), bytes(int(bool(x)) for x in nulls_first), n,
+                                                  -1 if fetch is None else int(fetch), C.byref(out)))
+        return self._wrap(out)
+
+    def hash_partition(self, keys: Sequence["Array"], num_partitions: int):
+        hs, n = capi.handle_array([a.h.value for a in keys])
+        out = C.c_void_p()
+        counts = (C.c_int64 * num_partitions)()
+        self.check(self.lib.dfgpu_hash_partition(self.h, hs, n, num_partitions, C.byref(out), counts))
+        return self._wrap(out), list(counts)
+
+
+class Array:
+    """Immutable Arrow column in HBM (dfgpu_array)."""
+
+    def __init__(self, ctx: Context, handle: C.c_void_p):
+        self.ctx = ctx
+        self.h = handle
+        self._keepalive = None
+
+    def __del__(self):
+        try:
+            if self.h is not None and self.h.value:
+                self.ctx.lib.dfgpu_array_release(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return self.ctx.lib.dfgpu_array_length(self.h)
+
+    def describe(self) -> capi.ArrayDesc:
+        d = capi.ArrayDesc()
+        self.ctx.check(self.ctx.lib.dfgpu_array_describe(self.h, C.byref(d)))
+        return d
+
+    @property
+    def type(self) -> int:
+        return self.describe().type
+
+    @property
+    def null_count(self) -> int:
+        return self.ctx.lib.dfgpu_array_null_count(self.ctx.h, self.h)
+
+    def slice(self, offset: int, length: int) -> "Array":
+        out = C.c_void_p()
+        self.ctx.check(self.ctx.lib.dfgpu_array_slice(self.ctx.h, self.h, offset, length, C.byref(out)))
+        return Array(self.ctx, out)
+
+    def to_arrow(self):
+        """HBM -> pyarrow.Array (Arrow C Data Interface)."""
+        import pyarrow as pa
+        ca, cs = capi.ArrowArray(), capi.ArrowSchema()
+        self.ctx.check(self.ctx.lib.dfgpu_array_export_arrow(self.ctx.h, self.h, C.byref(ca), C.byref(cs)))
+        return pa.Array._import_from_c(C.addressof(ca), C.addressof(cs))
+
+    def to_numpy(self):
+        return self.to_arrow().to_numpy(zero_copy_only=False)
+
+
+class JoinTable:
+    """≙ JoinLeftData { JoinHashMap, batch, visited bitmap } (joins/hash_join.rs:77-118)."""
+
+    def __init__(self, ctx: Context, keys: Sequence[Array], mask: Optional[Array] = None, null_equals_null: bool = False):
+        self.ctx = ctx
+        hs, n = capi.handle_array([a.h.value for a in keys])
+        h = C.c_void_p()
+        ctx.check(ctx.lib.dfgpu_join_build(ctx.h, hs, n, mask.h if mask is not None else None, int(null_equals_null), C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h is not None and self.h.value:
+                self.ctx.lib.dfgpu_join_table_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    @property
+    def num_rows(self) -> int:
+        return self.ctx.lib.dfgpu_join_table_num_rows(self.h)
+
+    @property
+    def memory(self) -> int:
+        return self.ctx.lib.dfgpu_join_table_memory(self.h)
+
+    def probe(self, keys: Sequence[Array], mask: Optional[Array] = None):
+        hs, n = capi.handle_array([a.h.value for a in keys])
+        ob, op = C.c_void_p(), C.c_void_p()
+        self.ctx.check(self.ctx.lib.dfgpu_join_probe(self.ctx.h, self.h, hs, n, mask.h if mask is not None else None, C.byref(ob), C.byref(op)))
+        return Array(self.ctx, ob), Array(self.ctx, op)
+
+    def mark_visited(self, build_idx: Array):
+        self.ctx.check(self.ctx.lib.dfgpu_join_mark_visited(self.ctx.h, self.h, build_idx.h))
+
+    def final_indices(self, join_type: int) -> Array:
+        out = C.c_void_p()
+        self.ctx.check(self.ctx.lib.dfgpu_join_final_indices(self.ctx.h, self.h, join_type, C.byref(out)))
+        return Array(self.ctx, out)
+
+
+def join_adjust_indices(ctx: Context, build_idx: Array, probe_idx: Array, range_start: int, range_end: int, join_type: int):
+    ob, op = C.c_void_p(), C.c_void_p()
+    ctx.check(ctx.lib.dfgpu_join_adjust_indices(ctx.h, build_idx.h, probe_idx.h, range_start, range_end, join_type, C.byref(ob), C.byref(op)))
+    return Array(ctx, ob), Array(ctx, op)
+
+
+class GroupValues:
+    """≙ trait GroupValues (aggregates/group_values/mod.rs:35-53)."""
+
+    def __init__(self, ctx: Context, nkeys: int):
+        self.ctx, self.nkeys = ctx, nkeys
+        h = C.c_void_p()
+        ctx.check(ctx.lib.dfgpu_groups_new(ctx.h, nkeys, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h is not None and self.h.value:
+                self.ctx.lib.dfgpu_groups_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def intern(self, cols: Sequence[Array], mask: Optional[Array] = None) -> Array:
+        hs, n = capi.handle_array([a.h.value for a in cols])
+        out = C.c_void_p()
+        self.ctx.check(self.ctx.lib.dfgpu_groups_intern(self.ctx.h, self.h, hs, n, mask.h if mask is not None else None, C.byref(out)))
+        return Array(self.ctx, out)
+
+    def __len__(self) -> int:
+        return self.ctx.lib.dfgpu_groups_len(self.h)
+
+    def size(self) -> int:
+        return self.ctx.lib.dfgpu_groups_size(self.h)
+
+    def emit(self) -> List[Array]:
+        outs = (C.c_void_p * self.nkeys)()
+        self.ctx.check(self.ctx.lib.dfgpu_groups_emit(self.ctx.h, self.h, outs))
+        return [Array(self.ctx, C.c_void_p(outs[i])) for i in range(self.nkeys)]
+
+
+class GroupsAccumulator:
+    """≙ trait GroupsAccumulator (expr/src/groups_accumulator.rs:78-164)."""
+
+    def __init__(self, ctx: Context, kind: int, in_type: int, precision: int = 0, scale: int = 0):
+        self.ctx, self.kind = ctx, kind
+        h = C.c_void_p()
+        ctx.check(ctx.lib.dfgpu_acc_new(ctx.h, kind, in_type, precision, scale, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h is not None and self.h.value:
+                self.ctx.lib.dfgpu_acc_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def update_batch(self, values: Optional[Array], group_ids: Array, opt_filter: Optional[Array], total_num_groups: int):
+        self.ctx.check(self.ctx.lib.dfgpu_acc_update_batch(self.ctx.h, self.h, values.h if values is not None else None, group_ids.h,
+                                                           opt_filter.h if opt_filter is not None else None, total_num_groups))
+
+    def merge_batch(self, states: Sequence[Array], group_ids: Array, opt_filter: Optional[Array], total_num_groups: int):
+        hs, n = capi.handle_array([a.h.value for a in states])
+        self.ctx.check(self.ctx.lib.dfgpu_acc_merge_batch(self.ctx.h, self.h, hs, n, group_ids.h, opt_filter.h if opt_filter is not None else None, total_num_groups))
+
+    def evaluate(self) -> Array:
+        out = C.c_void_p()
+        self.ctx.check(self.ctx.lib.dfgpu_acc_evaluate(self.ctx.h, self.h, C.byref(out)))
+        return Array(self.ctx, out)
+
+    def state(self) -> List[Array]:
+        outs = (C.c_void_p * 2)()
+        n = C.c_int32()
+        self.ctx.check(self.ctx.lib.dfgpu_acc_state(self.ctx.h, self.h, outs, C.byref(n)))
+        return [Array(self.ctx, C.c_void_p(outs[i])) for i in range(n.value)]
+
+    def size(self) -> int:
+        return self.ctx.lib.dfgpu_acc_size(self.h)

@@ -1,0 +1,234 @@
+/*
+ * dfgpu.h -- C ABI of the MI355X (gfx950) execution path for DataFusion 36's data-parallel
+ * physical operators.  This is the drop-in boundary: plain pointers and sizes, opaque handles,
+ * int32 status codes.  A Rust `impl ExecutionPlan` shim binds exactly these
+ * symbols; each one names the reference function it replaces (paths relative to
+ * /root/reference/datafusion/).
+ *
+ * Conventions
+ *  - Every call returns dfgpu_status; on failure dfgpu_last_error(ctx) holds the message.
+ *    The codes mirror DataFusionError variants (common/src/error.rs:52-122):
+ *    EXECUTION -> DataFusionError::Execution / ArrowError (e.g. "Divide by zero", decimal overflow),
+ *    INTERNAL -> Internal, RESOURCES_EXHAUSTED -> ResourcesExhausted, NOT_IMPLEMENTED ->
+ *    NotImplemented (the shim then keeps the CPU operator for that plan node).
+ *  - dfgpu_array is an immutable, reference counted Arrow-layout column resident in HBM
+ *    (Arrow columnar format: values buffer, LSB validity bitmap, int32 offsets for Utf8).
+ *    Callee never frees caller arrays; every `out` array is owned by the caller and released with
+ *    dfgpu_array_release (called from Rust Drop).
+ *  - A dfgpu_ctx is bound to one device + one HIP stream; calls on one ctx are stream ordered
+ *    and a ctx must be used by one thread at a time (ExecutionPlan::execute gives one ctx per
+ *    output partition, physical-plan/src/lib.rs:378-382).
+ *  - There is NO CPU fallback behind this ABI: if no HIP device is present ctx creation fails.
+ */
+#ifndef DFGPU_H
+#define DFGPU_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFGPU_API __attribute__((visibility("default")))
+
+typedef int32_t dfgpu_status;
+enum { DFGPU_OK = 0, DFGPU_EXECUTION = 1, DFGPU_INTERNAL = 2, DFGPU_RESOURCES_EXHAUSTED = 3,
+       DFGPU_NOT_IMPLEMENTED = 4, DFGPU_INVALID_ARGUMENT = 5 };
+
+/* Arrow data types supported on device (arrow-schema DataType) */
+enum { DFGPU_BOOL = 1, DFGPU_INT8 = 2, DFGPU_INT16 = 3, DFGPU_INT32 = 4, DFGPU_INT64 = 5,
+       DFGPU_UINT8 = 6, DFGPU_UINT16 = 7, DFGPU_UINT32 = 8, DFGPU_UINT64 = 9,
+       DFGPU_FLOAT32 = 10, DFGPU_FLOAT64 = 11, DFGPU_DATE32 = 12, DFGPU_DECIMAL128 = 13,
+       DFGPU_UTF8 = 14, DFGPU_DICTIONARY = 15 };
+
+/* Plain description of an Arrow column (host or device pointers, bit offset 0). */
+typedef struct dfgpu_array_desc {
+  int32_t type;
+  int32_t precision;             /* DECIMAL128 */
+  int32_t scale;                 /* DECIMAL128 */
+  int32_t key_type;              /* DICTIONARY: integer type of the keys in `values` */
+  int64_t length;
+  int64_t null_count;            /* -1 = unknown */
+  const void *values;            /* fixed width values | utf8 bytes | dictionary keys | bool bits */
+  const uint8_t *validity;       /* LSB-first bitmap or NULL */
+  const int32_t *offsets;        /* UTF8: length+1 */
+  int64_t values_bytes;          /* UTF8: bytes in `values` */
+  const struct dfgpu_array_desc *dictionary;  /* DICTIONARY: value column */
+} dfgpu_array_desc;
+
+typedef struct dfgpu_ctx dfgpu_ctx;
+typedef struct dfgpu_array dfgpu_array;
+typedef struct dfgpu_join_table dfgpu_join_table;
+typedef struct dfgpu_groups dfgpu_groups;
+typedef struct dfgpu_acc dfgpu_acc;
+
+/* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html); arrow-rs 50
+ * `arrow::ffi::{FFI_ArrowArray, FFI_ArrowSchema}` and pyarrow `_export_to_c` are layout compatible. */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+  const char *format; const char *name; const char *metadata; int64_t flags; int64_t n_children;
+  struct ArrowSchema **children; struct ArrowSchema *dictionary;
+  void (*release)(struct ArrowSchema *); void *private_data;
+};
+struct ArrowArray {
+  int64_t length; int64_t null_count; int64_t offset; int64_t n_buffers; int64_t n_children;
+  const void **buffers; struct ArrowArray **children; struct ArrowArray *dictionary;
+  void (*release)(struct ArrowArray *); void *private_data;
+};
+#endif
+
+/* ------------------------------------------------------------------ context */
+/* stream: a hipStream_t to enqueue on (e.g. the caller's / torch's current stream) or NULL to
+ * create a private non-blocking stream.  Fails (DFGPU_EXECUTION) when no gfx950 device is usable. */
+DFGPU_API dfgpu_status dfgpu_ctx_create(int32_t device_id, void *stream, dfgpu_ctx **out);
+DFGPU_API void dfgpu_ctx_destroy(dfgpu_ctx *ctx);
+DFGPU_API const char *dfgpu_last_error(const dfgpu_ctx *ctx);
+DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
+/* options: "force_hash_collisions" (0/1) == cargo feature of common/src/hash_utils.rs:306-318;
+ * "first_seen_group_order" (1/0) == group ids in first-seen order (group_values/primitive.rs:137-141). */
+DFGPU_API dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx *ctx, const char *key, int64_t value);
+DFGPU_API void *dfgpu_ctx_stream(dfgpu_ctx *ctx);
+DFGPU_API const char *dfgpu_version(void);
+
+/* ------------------------------------------------------------------ arrays */
+/* Copy a host column to HBM (PCIe).  ≙ a RecordBatch column entering the GPU operator. */
+DFGPU_API dfgpu_status dfgpu_array_import_host(dfgpu_ctx *ctx, const dfgpu_array_desc *host, dfgpu_array **out);
+/* Wrap device memory owned by the caller (zero copy; caller keeps it alive until release). */
+DFGPU_API dfgpu_status dfgpu_array_wrap_device(dfgpu_ctx *ctx, const dfgpu_array_desc *dev, dfgpu_array **out);
+/* Device pointers + metadata of an array (for RCCL / torch interop). `out->dictionary` points
+ * into storage owned by the array. */
+DFGPU_API dfgpu_status dfgpu_array_describe(const dfgpu_array *a, dfgpu_array_desc *out);
+/* Copy to caller-allocated host buffers sized from dfgpu_array_describe (values / validity /
+ * offsets may be NULL to skip).  Synchronises the ctx stream. */
+DFGPU_API dfgpu_status dfgpu_array_export_host(dfgpu_ctx *ctx, const dfgpu_array *a, void *values, uint8_t *validity, int32_t *offsets);
+DFGPU_API dfgpu_status dfgpu_array_import_arrow(dfgpu_ctx *ctx, struct ArrowArray *array, struct ArrowSchema *schema, dfgpu_array **out);
+DFGPU_API dfgpu_status dfgpu_array_export_arrow(dfgpu_ctx *ctx, const dfgpu_array *a, struct ArrowArray *out_array, struct ArrowSchema *out_schema);
+DFGPU_API void dfgpu_array_retain(dfgpu_array *a);
+DFGPU_API void dfgpu_array_release(dfgpu_array *a);
+DFGPU_API int64_t dfgpu_array_length(const dfgpu_array *a);
+DFGPU_API int64_t dfgpu_array_null_count(dfgpu_ctx *ctx, const dfgpu_array *a);   /* computes if unknown */
+/* RecordBatch::slice: zero copy when offset % 64 == 0 (batch_size 8192 chunks), otherwise a copy. */
+DFGPU_API dfgpu_status dfgpu_array_slice(dfgpu_ctx *ctx, const dfgpu_array *a, int64_t offset, int64_t length, dfgpu_array **out);
+/* concat_batches per column (hash_join.rs:764, coalesce_batches.rs:198-260, sorts/sort.rs:505). */
+DFGPU_API dfgpu_status dfgpu_concat(dfgpu_ctx *ctx, const dfgpu_array *const *arrays, int32_t n, dfgpu_array **out);
+/* new_null_array (joins/utils.rs:1214) */
+DFGPU_API dfgpu_status dfgpu_array_new_null(dfgpu_ctx *ctx, int32_t type, int32_t precision, int32_t scale, int64_t length, dfgpu_array **out);
+
+/* ------------------------------------------------------------------ a1: create_hashes */
+/* ≙ create_hashes (common/src/hash_utils.rs:357-417): per-row u64 of k key columns, first column
+ * assigns, later columns combine_hashes (:38-41); NULL leaves the running hash (0) unchanged;
+ * dictionaries hash their values (:182-213).  `seed`: 0 for join/repartition (fixed seeds,
+ * joins/hash_join.rs:329, repartition/mod.rs:115).  out: UINT64 array. */
+DFGPU_API dfgpu_status dfgpu_hash_columns(dfgpu_ctx *ctx, const dfgpu_array *const *cols, int32_t k, uint64_t seed, dfgpu_array **out);
+
+/* ------------------------------------------------------------------ arrow-select */
+/* ≙ arrow::compute::take (joins/utils.rs:1216,1224; sorts/sort.rs:605; repartition/mod.rs:202).
+ * indices: UINT32 / UINT64 / INT32 / INT64 array; a NULL index yields a NULL row. */
+DFGPU_API dfgpu_status dfgpu_take(dfgpu_ctx *ctx, const dfgpu_array *values, const dfgpu_array *indices, dfgpu_array **out);
+/* ≙ arrow::compute::filter with a BooleanArray mask (filter.rs:325): keeps rows whose mask is
+ * valid AND true, input order preserved. */
+DFGPU_API dfgpu_status dfgpu_filter(dfgpu_ctx *ctx, const dfgpu_array *values, const dfgpu_array *mask, dfgpu_array **out);
+/* Selection vector of a mask (ascending UINT32 row numbers) -- FilterBuilder::optimize analogue. */
+DFGPU_API dfgpu_status dfgpu_mask_to_indices(dfgpu_ctx *ctx, const dfgpu_array *mask, dfgpu_array **out);
+
+/* ------------------------------------------------------------------ a12: PhysicalExpr kernels */
+enum { DFGPU_OP_ADD = 0, DFGPU_OP_SUB = 1, DFGPU_OP_MUL = 2, DFGPU_OP_DIV = 3, DFGPU_OP_REM = 4,
+       DFGPU_OP_EQ = 10, DFGPU_OP_NEQ = 11, DFGPU_OP_LT = 12, DFGPU_OP_LTEQ = 13, DFGPU_OP_GT = 14,
+       DFGPU_OP_GTEQ = 15, DFGPU_OP_DISTINCT = 16, DFGPU_OP_NOT_DISTINCT = 17,
+       DFGPU_OP_AND = 20, DFGPU_OP_OR = 21 };
+/* ≙ BinaryExpr::evaluate (physical-expr/src/expressions/binary.rs:259-315) -> datum::apply /
+ * apply_cmp (datum.rs:28-58) -> and_kleene / or_kleene (binary.rs:563-586).  A scalar operand is a
+ * length-1 array with *_is_scalar = 1 (arrow Datum / ColumnarValue::Scalar). */
+DFGPU_API dfgpu_status dfgpu_binary(dfgpu_ctx *ctx, int32_t op, const dfgpu_array *lhs, int32_t lhs_is_scalar,
+                                    const dfgpu_array *rhs, int32_t rhs_is_scalar, dfgpu_array **out);
+DFGPU_API dfgpu_status dfgpu_not(dfgpu_ctx *ctx, const dfgpu_array *a, dfgpu_array **out);                 /* not.rs:71 */
+DFGPU_API dfgpu_status dfgpu_is_null(dfgpu_ctx *ctx, const dfgpu_array *a, int32_t negate, dfgpu_array **out); /* is_null.rs:74 / is_not_null.rs */
+DFGPU_API dfgpu_status dfgpu_negative(dfgpu_ctx *ctx, const dfgpu_array *a, dfgpu_array **out);            /* negative.rs:79 */
+DFGPU_API dfgpu_status dfgpu_cast(dfgpu_ctx *ctx, const dfgpu_array *a, int32_t to_type, int32_t precision, int32_t scale, dfgpu_array **out); /* cast.rs:121 */
+DFGPU_API dfgpu_status dfgpu_in_list(dfgpu_ctx *ctx, const dfgpu_array *a, const dfgpu_array *list, int32_t negated, dfgpu_array **out);      /* in_list.rs:349 */
+
+/* ------------------------------------------------------------------ a2-a6: HashJoinExec */
+enum { DFGPU_JOIN_INNER = 0, DFGPU_JOIN_LEFT = 1, DFGPU_JOIN_RIGHT = 2, DFGPU_JOIN_FULL = 3,
+       DFGPU_JOIN_LEFT_SEMI = 4, DFGPU_JOIN_RIGHT_SEMI = 5, DFGPU_JOIN_LEFT_ANTI = 6,
+       DFGPU_JOIN_RIGHT_ANTI = 7 };
+/* ≙ collect_left_input + update_hash + JoinHashMap (joins/hash_join.rs:678-815, joins/utils.rs:121-229).
+ * keys: the build key columns of the concatenated build batch, rows in ORIGINAL input order (the
+ * index space of the returned build indices; dfgpu_join_final_indices documents how the shim
+ * restores the reference's reversed-concat order).  opt_mask: optional BOOL array, rows not
+ * selected are not inserted (fused upstream FilterExec). */
+DFGPU_API dfgpu_status dfgpu_join_build(dfgpu_ctx *ctx, const dfgpu_array *const *keys, int32_t nkeys,
+                                        const dfgpu_array *opt_mask, int32_t null_equals_null, dfgpu_join_table **out);
+DFGPU_API void dfgpu_join_table_free(dfgpu_join_table *t);
+DFGPU_API int64_t dfgpu_join_table_num_rows(const dfgpu_join_table *t);
+DFGPU_API int64_t dfgpu_join_table_memory(const dfgpu_join_table *t);   /* bytes, for MemoryReservation::try_grow */
+/* ≙ lookup_join_hashmap = get_matched_indices_with_limit_offset (limit = whole batch) +
+ * equal_rows_arr (joins/hash_join.rs:1024-1118): all (build, probe) row pairs with equal keys,
+ * ordered by probe row, then by build input order (hash_join.rs:161-197, asserted :1593-1594).
+ * out_build_idx: UINT64, out_probe_idx: UINT32 (both without nulls). */
+DFGPU_API dfgpu_status dfgpu_join_probe(dfgpu_ctx *ctx, const dfgpu_join_table *t, const dfgpu_array *const *probe_keys,
+                                        int32_t nkeys, const dfgpu_array *opt_mask,
+                                        dfgpu_array **out_build_idx, dfgpu_array **out_probe_idx);
+/* ≙ visited_left_side.set_bit for every joined build index (hash_join.rs:1274-1278). */
+DFGPU_API dfgpu_status dfgpu_join_mark_visited(dfgpu_ctx *ctx, dfgpu_join_table *t, const dfgpu_array *build_idx);
+/* ≙ adjust_indices_by_join_type over the alignment range [range_start, range_end)
+ * (joins/utils.rs:1234-1364; hash_join.rs:1297-1316). */
+DFGPU_API dfgpu_status dfgpu_join_adjust_indices(dfgpu_ctx *ctx, const dfgpu_array *build_idx, const dfgpu_array *probe_idx,
+                                                 int64_t range_start, int64_t range_end, int32_t join_type,
+                                                 dfgpu_array **out_build_idx, dfgpu_array **out_probe_idx);
+/* ≙ get_final_indices_from_bit_map (joins/utils.rs:1119-1141): ascending build indices that are
+ * unmatched (Left/Full/LeftAnti) or matched (LeftSemi); probe side is all NULL. */
+DFGPU_API dfgpu_status dfgpu_join_final_indices(dfgpu_ctx *ctx, const dfgpu_join_table *t, int32_t join_type, dfgpu_array **out_build_idx);
+
+/* ------------------------------------------------------------------ a8: GroupValues */
+/* ≙ new_group_values (aggregates/group_values/mod.rs:55-85); one implementation covers
+ * GroupValuesPrimitive / GroupValuesRows / GroupValuesByes. */
+DFGPU_API dfgpu_status dfgpu_groups_new(dfgpu_ctx *ctx, int32_t nkeys, dfgpu_groups **out);
+DFGPU_API void dfgpu_groups_free(dfgpu_groups *g);
+/* ≙ GroupValues::intern (primitive.rs:112-149, row.rs:94-146, bytes.rs:44-73): out_group_ids is a
+ * UINT32 array, ids dense and (option first_seen_group_order) assigned in first-seen order; NULL keys
+ * form their own group.  opt_mask: rows not selected get id 0xFFFFFFFF and are skipped by accumulators. */
+DFGPU_API dfgpu_status dfgpu_groups_intern(dfgpu_ctx *ctx, dfgpu_groups *g, const dfgpu_array *const *cols, int32_t nkeys,
+                                           const dfgpu_array *opt_mask, dfgpu_array **out_group_ids);
+DFGPU_API int64_t dfgpu_groups_len(const dfgpu_groups *g);                   /* GroupValues::len */
+DFGPU_API int64_t dfgpu_groups_size(const dfgpu_groups *g);                  /* GroupValues::size (bytes) */
+/* ≙ GroupValues::emit(EmitTo::All) (primitive.rs:163-209): key columns in group id order. */
+DFGPU_API dfgpu_status dfgpu_groups_emit(dfgpu_ctx *ctx, dfgpu_groups *g, dfgpu_array **out_cols /* nkeys */);
+
+/* ------------------------------------------------------------------ a9: GroupsAccumulator */
+enum { DFGPU_AGG_SUM = 0, DFGPU_AGG_AVG = 1, DFGPU_AGG_COUNT = 2, DFGPU_AGG_MIN = 3, DFGPU_AGG_MAX = 4 };
+/* ≙ AggregateExpr::create_groups_accumulator (sum.rs, average.rs, count.rs, min_max.rs).
+ * Input dtype rules as the reference: SUM over Int64/UInt64/Float64/Decimal128 (sum.rs:75-86),
+ * AVG over Float64/Decimal128 (average.rs), MIN/MAX over primitive types. */
+DFGPU_API dfgpu_status dfgpu_acc_new(dfgpu_ctx *ctx, int32_t kind, int32_t in_type, int32_t in_precision, int32_t in_scale, dfgpu_acc **out);
+DFGPU_API void dfgpu_acc_free(dfgpu_acc *a);
+/* ≙ GroupsAccumulator::update_batch (expr/src/groups_accumulator.rs:98-104): values may be NULL for
+ * COUNT(*); group_ids UINT32 (0xFFFFFFFF = skip); opt_filter BOOL (NULL/false rows skipped). */
+DFGPU_API dfgpu_status dfgpu_acc_update_batch(dfgpu_ctx *ctx, dfgpu_acc *a, const dfgpu_array *values, const dfgpu_array *group_ids,
+                                              const dfgpu_array *opt_filter, int64_t total_num_groups);
+/* ≙ GroupsAccumulator::merge_batch (:136-142): states as produced by dfgpu_acc_state. */
+DFGPU_API dfgpu_status dfgpu_acc_merge_batch(dfgpu_ctx *ctx, dfgpu_acc *a, const dfgpu_array *const *states, int32_t nstates,
+                                             const dfgpu_array *group_ids, const dfgpu_array *opt_filter, int64_t total_num_groups);
+/* ≙ evaluate(EmitTo::All) / state(EmitTo::All) (:106-134).  out_states holds up to 2 arrays. */
+DFGPU_API dfgpu_status dfgpu_acc_evaluate(dfgpu_ctx *ctx, dfgpu_acc *a, dfgpu_array **out);
+DFGPU_API dfgpu_status dfgpu_acc_state(dfgpu_ctx *ctx, dfgpu_acc *a, dfgpu_array **out_states, int32_t *n_states);
+DFGPU_API int64_t dfgpu_acc_size(const dfgpu_acc *a);
+
+/* ------------------------------------------------------------------ a13: SortExec */
+/* ≙ lexsort_to_indices (sorts/sort.rs:599) with per column SortOptions (physical-expr/src/sort_expr.rs:34-74);
+ * fetch < 0 = none.  Stable (ties keep input order; the reference leaves tie order unspecified).
+ * out: UINT32 indices. */
+DFGPU_API dfgpu_status dfgpu_sort_to_indices(dfgpu_ctx *ctx, const dfgpu_array *const *cols, const uint8_t *descending,
+                                             const uint8_t *nulls_first, int32_t k, int64_t fetch, dfgpu_array **out);
+
+/* ------------------------------------------------------------------ a14: RepartitionExec */
+/* ≙ BatchPartitioner::partition_iter, Hash(exprs, n) (repartition/mod.rs:148-221): destination =
+ * create_hashes(keys) % n; out_indices (UINT32) lists the rows grouped by destination, input
+ * order kept inside each destination (:196-214); counts_host[n] receives rows per destination. */
+DFGPU_API dfgpu_status dfgpu_hash_partition(dfgpu_ctx *ctx, const dfgpu_array *const *keys, int32_t nkeys, int32_t num_partitions,
+                                            dfgpu_array **out_indices, int64_t *counts_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

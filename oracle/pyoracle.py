@@ -1,0 +1,408 @@
+"""ctypes binding of the CPU oracle (oracle/libdfo.so) for tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  TEST INFRASTRUCTURE ONLY: nothing under datafusion-upstream_amd/ imports this module."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import pyarrow as pa
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+BOOL, INT8, INT16, INT32, INT64, UINT8, UINT16, UINT32, UINT64 = 1, 2, 3, 4, 5, 6, 7, 8, 9
+FLOAT32, FLOAT64, DATE32, DECIMAL128, UTF8, DICTIONARY = 10, 11, 12, 13, 14, 15
+JOIN_TYPES = {"Inner": 0, "Left": 1, "Right": 2, "Full": 3, "LeftSemi": 4, "RightSemi": 5, "LeftAnti": 6, "RightAnti": 7}
+AGG = {"SUM": 0, "AVG": 1, "COUNT": 2, "MIN": 3, "MAX": 4}
+OPS = {"+": 0, "-": 1, "*": 2, "/": 3, "%": 4, "=": 10, "!=": 11, "<": 12, "<=": 13, ">": 14, ">=": 15,
+       "IS DISTINCT FROM": 16, "IS NOT DISTINCT FROM": 17, "AND": 20, "OR": 21}
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+class DfoArray(C.Structure):
+    pass
+
+
+DfoArray._fields_ = [("type", C.c_int32), ("precision", C.c_int32), ("scale", C.c_int32), ("key_type", C.c_int32),
+                     ("length", C.c_int64), ("null_count", C.c_int64), ("values", C.c_void_p), ("validity", C.c_void_p),
+                     ("offsets", C.c_void_p), ("values_bytes", C.c_int64), ("dictionary", C.POINTER(DfoArray))]
+
+
+class DfoBuilder(C.Structure):
+    _fields_ = [("arr", DfoArray), ("vals", C.c_void_p), ("vals_cap", C.c_int64), ("valid", C.c_void_p), ("valid_cap", C.c_int64),
+                ("offs", C.c_void_p), ("offs_cap", C.c_int64), ("nbytes", C.c_int64)]
+
+
+class DfoJoinResult(C.Structure):
+    _fields_ = [("n", C.c_int64), ("build_idx", C.POINTER(C.c_int64)), ("probe_idx", C.POINTER(C.c_int64)), ("probe_batch", C.POINTER(C.c_int32)),
+                ("n_batches", C.c_int64), ("batch_offsets", C.POINTER(C.c_int64))]
+
+
+class DfoQ3In(C.Structure):
+    _fields_ = [("n_customer", C.c_int64), ("c_custkey", C.c_void_p), ("c_mktsegment", C.c_void_p), ("segment_code", C.c_int8),
+                ("n_orders", C.c_int64), ("o_orderkey", C.c_void_p), ("o_custkey", C.c_void_p), ("o_orderdate", C.c_void_p),
+                ("o_shippriority", C.c_void_p), ("date_cut", C.c_int32),
+                ("n_lineitem", C.c_int64), ("l_orderkey", C.c_void_p), ("l_extendedprice", C.c_void_p), ("l_discount", C.c_void_p), ("l_shipdate", C.c_void_p)]
+
+
+class DfoQ3Out(C.Structure):
+    _fields_ = [("n", C.c_int64), ("l_orderkey", C.POINTER(C.c_int64)), ("revenue", C.c_void_p), ("o_orderdate", C.POINTER(C.c_int32)), ("o_shippriority", C.POINTER(C.c_int32))]
+
+
+FILTER_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_uint8))
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libdfo.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", _HERE])
+        L = C.CDLL(path)
+        L.dfo_last_error.restype = C.c_char_p
+        L.dfo_builder_free.argtypes = [C.c_void_p]
+        L.dfo_groups_new.restype = C.c_void_p
+        L.dfo_groups_len.restype = C.c_int64
+        L.dfo_groups_len.argtypes = [C.c_void_p]
+        L.dfo_groups_emit.restype = C.POINTER(DfoArray)
+        L.dfo_groups_emit.argtypes = [C.c_void_p, C.c_int]
+        L.dfo_groups_intern.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.dfo_groups_free.argtypes = [C.c_void_p]
+        L.dfo_acc_new.restype = C.c_void_p
+        L.dfo_acc_free.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _err() -> str:
+    return lib().dfo_last_error().decode()
+
+
+_PA_TYPE = {pa.bool_(): BOOL, pa.int8(): INT8, pa.int16(): INT16, pa.int32(): INT32, pa.int64(): INT64, pa.uint8(): UINT8, pa.uint16(): UINT16,
+            pa.uint32(): UINT32, pa.uint64(): UINT64, pa.float32(): FLOAT32, pa.float64(): FLOAT64, pa.date32(): DATE32, pa.utf8(): UTF8}
+
+
+class Col:
+    """Keeps a pyarrow array alive next to the dfo_array view of its buffers."""
+
+    def __init__(self, arr):
+        if isinstance(arr, pa.ChunkedArray):
+            arr = arr.combine_chunks()
+        if not isinstance(arr, pa.Array):
+            arr = pa.array(arr)
+        if arr.offset != 0:
+            arr = pa.concat_arrays([arr])
+        self.arr = arr
+        self.desc = DfoArray()
+        self._dict = None
+        d, t = self.desc, arr.type
+        d.length, d.null_count = len(arr), arr.null_count
+        bufs = arr.buffers()
+        d.validity = bufs[0].address if (bufs[0] is not None and arr.null_count) else None
+        if pa.types.is_dictionary(t):
+            d.type = DICTIONARY
+            d.key_type = _PA_TYPE[t.index_type]
+            d.values = bufs[1].address if bufs[1] is not None else None
+            self._dict = Col(arr.dictionary)
+            d.dictionary = C.pointer(self._dict.desc)
+        elif pa.types.is_decimal(t):
+            d.type, d.precision, d.scale = DECIMAL128, t.precision, t.scale
+            d.values = bufs[1].address if bufs[1] is not None else None
+        elif t == pa.utf8():
+            d.type = UTF8
+            d.offsets = bufs[1].address if bufs[1] is not None else None
+            d.values = bufs[2].address if (len(bufs) > 2 and bufs[2] is not None) else None
+            d.values_bytes = bufs[2].size if (len(bufs) > 2 and bufs[2] is not None) else 0
+            if d.offsets is None:
+                self._z = (C.c_int32 * 1)(0)
+                d.offsets = C.addressof(self._z)
+        else:
+            d.type = _PA_TYPE[t]
+            d.values = bufs[1].address if bufs[1] is not None else None
+        if d.values is None:
+            self._zv = (C.c_uint64 * 2)()
+            d.values = C.addressof(self._zv)
+
+
+def _cols(arrs: Sequence) -> List[Col]:
+    return [a if isinstance(a, Col) else Col(a) for a in arrs]
+
+
+def _ptr_array(cols: Sequence[Col]):
+    return (C.POINTER(DfoArray) * max(1, len(cols)))(*[C.pointer(c.desc) for c in cols])
+
+
+def _type_of_desc(d: DfoArray):
+    inv = {v: k for k, v in _PA_TYPE.items()}
+    if d.type == DECIMAL128:
+        return pa.decimal128(d.precision, d.scale)
+    return inv[d.type]
+
+
+def array_from_desc(d: DfoArray) -> pa.Array:
+    """Copy a dfo_array (oracle-owned memory) into a pyarrow array."""
+    n = d.length
+    t = _type_of_desc(d)
+    valid = None
+    if d.validity:
+        valid = pa.py_buffer(C.string_at(d.validity, (n + 7) // 8))
+    if d.type == UTF8:
+        offs = pa.py_buffer(C.string_at(d.offsets, (n + 1) * 4))
+        nbytes = np.frombuffer(offs, dtype=np.int32)[-1] if n else 0
+        data = pa.py_buffer(C.string_at(d.values, int(nbytes)) if nbytes else b"")
+        return pa.Array.from_buffers(t, n, [valid, offs, data])
+    if d.type == BOOL:
+        return pa.Array.from_buffers(t, n, [valid, pa.py_buffer(C.string_at(d.values, (n + 7) // 8))])
+    width = {INT8: 1, UINT8: 1, INT16: 2, UINT16: 2, INT32: 4, UINT32: 4, FLOAT32: 4, DATE32: 4, INT64: 8, UINT64: 8, FLOAT64: 8, DECIMAL128: 16}[d.type]
+    return pa.Array.from_buffers(t, n, [valid, pa.py_buffer(C.string_at(d.values, n * width) if n else b"")])
+
+
+def _take_builder(bp) -> pa.Array:
+    b = C.cast(bp, C.POINTER(DfoBuilder)).contents
+    out = array_from_desc(b.arr)
+    lib().dfo_builder_free(bp)
+    return out
+
+
+# ------------------------------------------------------------------ a1
+def create_hashes(cols: Sequence, seed: int = 0, force_collisions: bool = False) -> np.ndarray:
+    cs = _cols(cols)
+    n = len(cs[0].arr)
+    out = np.zeros(n, dtype=np.uint64)
+    lib().dfo_create_hashes(_ptr_array(cs), len(cs), C.c_int64(n), C.c_uint64(seed), int(force_collisions), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+# ------------------------------------------------------------------ a2-a6
+@dataclass
+class JoinResult:
+    build_idx: np.ndarray      # int64, -1 = NULL; index into the reference-order (reversed) concatenation of build batches
+    probe_idx: np.ndarray      # int64, -1 = NULL
+    probe_batch: np.ndarray    # int32, -1 for the final unmatched-build batch
+    batch_offsets: np.ndarray
+
+
+def hash_join(build_batches: Sequence[Sequence], probe_batches: Sequence[Sequence], join_type: str = "Inner", null_equals_null: bool = False,
+              batch_size: int = 8192, force_collisions: bool = False, filter_fn=None) -> JoinResult:
+    """build_batches[b] = list of key columns of build batch b (input order); likewise probe."""
+    nkeys = len(build_batches[0]) if build_batches else len(probe_batches[0])
+    bcols = [c for b in build_batches for c in _cols(b)]
+    pcols = [c for b in probe_batches for c in _cols(b)]
+    res = DfoJoinResult()
+    cb = None
+    if filter_fn is not None:
+        def _cb(ud, pb, bi, pi, n, keep):
+            k = filter_fn(int(pb), np.ctypeslib.as_array(bi, (n,)).copy(), np.ctypeslib.as_array(pi, (n,)).copy())
+            k = np.asarray(k, dtype=np.uint8)
+            C.memmove(keep, k.ctypes.data, n)
+        cb = FILTER_FN(_cb)
+    st = lib().dfo_hash_join(_ptr_array(bcols), len(build_batches), _ptr_array(pcols), len(probe_batches), nkeys, JOIN_TYPES[join_type],
+                             int(null_equals_null), C.c_int64(batch_size), int(force_collisions), cb if cb else C.cast(None, FILTER_FN), None, C.byref(res))
+    if st != 0:
+        raise OracleError(_err())
+    n = res.n
+    out = JoinResult(np.ctypeslib.as_array(res.build_idx, (n,)).copy() if n else np.zeros(0, np.int64),
+                     np.ctypeslib.as_array(res.probe_idx, (n,)).copy() if n else np.zeros(0, np.int64),
+                     np.ctypeslib.as_array(res.probe_batch, (n,)).copy() if n else np.zeros(0, np.int32),
+                     np.ctypeslib.as_array(res.batch_offsets, (res.n_batches + 1,)).copy())
+    lib().dfo_join_result_free(C.byref(res))
+    return out
+
+
+# ------------------------------------------------------------------ a8 / a9
+class Groups:
+    def __init__(self, types: Sequence[pa.DataType]):
+        ts, ps, ss = [], [], []
+        for t in types:
+            if pa.types.is_dictionary(t):
+                t = t.value_type
+            if pa.types.is_decimal(t):
+                ts.append(DECIMAL128); ps.append(t.precision); ss.append(t.scale)
+            else:
+                ts.append(_PA_TYPE[t]); ps.append(0); ss.append(0)
+        n = len(ts)
+        self.n = n
+        self.h = lib().dfo_groups_new(n, (C.c_int32 * n)(*ts), (C.c_int32 * n)(*ps), (C.c_int32 * n)(*ss))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().dfo_groups_free(self.h)
+            self.h = None
+
+    def intern(self, cols: Sequence) -> np.ndarray:
+        cs = _cols(cols)
+        n = len(cs[0].arr)
+        out = np.zeros(n, dtype=np.int64)
+        lib().dfo_groups_intern(self.h, _ptr_array(cs), C.c_int64(n), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def __len__(self):
+        return lib().dfo_groups_len(self.h)
+
+    def emit(self) -> List[pa.Array]:
+        return [array_from_desc(lib().dfo_groups_emit(self.h, c).contents) for c in range(self.n)]
+
+
+class Acc:
+    def __init__(self, kind: str, in_type: pa.DataType):
+        p = s = 0
+        if pa.types.is_decimal(in_type):
+            t, p, s = DECIMAL128, in_type.precision, in_type.scale
+        else:
+            t = _PA_TYPE[in_type]
+        self.h = lib().dfo_acc_new(AGG[kind], t, p, s)
+        if not self.h:
+            raise OracleError(_err())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().dfo_acc_free(self.h)
+            self.h = None
+
+    def update_batch(self, values, gids: np.ndarray, opt_filter, total: int):
+        v = Col(values) if values is not None else None
+        f = Col(opt_filter) if opt_filter is not None else None
+        g = np.ascontiguousarray(gids, dtype=np.int64)
+        st = lib().dfo_acc_update_batch(C.c_void_p(self.h), C.byref(v.desc) if v else None, g.ctypes.data_as(C.c_void_p), C.byref(f.desc) if f else None,
+                                        C.c_int64(len(g)), C.c_int64(total))
+        if st:
+            raise OracleError(_err())
+
+    def merge_batch(self, states: Sequence, gids: np.ndarray, opt_filter, total: int):
+        cs = _cols(states)
+        f = Col(opt_filter) if opt_filter is not None else None
+        g = np.ascontiguousarray(gids, dtype=np.int64)
+        st = lib().dfo_acc_merge_batch(C.c_void_p(self.h), _ptr_array(cs), len(cs), g.ctypes.data_as(C.c_void_p), C.byref(f.desc) if f else None,
+                                       C.c_int64(len(g)), C.c_int64(total))
+        if st:
+            raise OracleError(_err())
+
+    def evaluate(self) -> pa.Array:
+        out = C.POINTER(DfoArray)()
+        if lib().dfo_acc_evaluate(C.c_void_p(self.h), C.byref(out)):
+            raise OracleError(_err())
+        return array_from_desc(out.contents)
+
+    def state(self) -> List[pa.Array]:
+        o0, o1, n = C.POINTER(DfoArray)(), C.POINTER(DfoArray)(), C.c_int()
+        if lib().dfo_acc_state(C.c_void_p(self.h), C.byref(o0), C.byref(o1), C.byref(n)):
+            raise OracleError(_err())
+        return [array_from_desc(o0.contents)] + ([array_from_desc(o1.contents)] if n.value == 2 else [])
+
+
+# ------------------------------------------------------------------ a12
+def binary(op: str, l, r, l_scalar: bool = False, r_scalar: bool = False) -> pa.Array:
+    lc, rc = Col(l), Col(r)
+    out = C.c_void_p()
+    if lib().dfo_binary(OPS[op], C.byref(lc.desc), int(l_scalar), C.byref(rc.desc), int(r_scalar), C.byref(out)):
+        raise OracleError(_err())
+    return _take_builder(out)
+
+
+def _unary(fn, a, *args) -> pa.Array:
+    c = Col(a)
+    out = C.c_void_p()
+    if fn(C.byref(c.desc), *args, C.byref(out)):
+        raise OracleError(_err())
+    return _take_builder(out)
+
+
+def not_(a):
+    return _unary(lib().dfo_not, a)
+
+
+def is_null(a, negate=False):
+    return _unary(lib().dfo_is_null, a, int(negate))
+
+
+def negative(a):
+    return _unary(lib().dfo_negative, a)
+
+
+def cast(a, to: pa.DataType):
+    if pa.types.is_decimal(to):
+        return _unary(lib().dfo_cast, a, DECIMAL128, to.precision, to.scale)
+    return _unary(lib().dfo_cast, a, _PA_TYPE[to], 0, 0)
+
+
+def in_list(a, lst, negated=False):
+    c, l = Col(a), Col(lst)
+    out = C.c_void_p()
+    if lib().dfo_in_list(C.byref(c.desc), C.byref(l.desc), int(negated), C.byref(out)):
+        raise OracleError(_err())
+    return _take_builder(out)
+
+
+# ------------------------------------------------------------------ a13 / a14 / arrow-select
+def lexsort_to_indices(cols: Sequence, descending: Sequence[bool], nulls_first: Sequence[bool], fetch: Optional[int] = None) -> np.ndarray:
+    cs = _cols(cols)
+    n = len(cs[0].arr)
+    out = np.zeros(max(n, 1), dtype=np.uint32)
+    n_out = C.c_int64()
+    st = lib().dfo_lexsort_to_indices(_ptr_array(cs), len(cs), bytes(int(bool(x)) for x in descending), bytes(int(bool(x)) for x in nulls_first),
+                                      C.c_int64(n), C.c_int64(-1 if fetch is None else fetch), out.ctypes.data_as(C.c_void_p), C.byref(n_out))
+    if st:
+        raise OracleError(_err())
+    return out[:n_out.value].copy()
+
+
+def hash_partition(cols: Sequence, num_partitions: int, force_collisions: bool = False):
+    cs = _cols(cols)
+    n = len(cs[0].arr)
+    idx = np.zeros(max(n, 1), dtype=np.uint32)
+    counts = np.zeros(num_partitions, dtype=np.int64)
+    if lib().dfo_hash_partition(_ptr_array(cs), len(cs), C.c_int64(n), num_partitions, int(force_collisions), idx.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p)):
+        raise OracleError(_err())
+    return idx[:n].copy(), counts
+
+
+def take(a, indices: np.ndarray) -> pa.Array:
+    c = Col(a)
+    idx = np.ascontiguousarray(indices, dtype=np.int64)
+    out = C.c_void_p()
+    if lib().dfo_take(C.byref(c.desc), idx.ctypes.data_as(C.c_void_p), C.c_int64(len(idx)), C.byref(out)):
+        raise OracleError(_err())
+    return _take_builder(out)
+
+
+def filter_(a, mask) -> pa.Array:
+    c, m = Col(a), Col(mask)
+    out = C.c_void_p()
+    if lib().dfo_filter(C.byref(c.desc), C.byref(m.desc), C.byref(out)):
+        raise OracleError(_err())
+    return _take_builder(out)
+
+
+# ------------------------------------------------------------------ TPC-H Q3 restatement (cpu_baseline "port")
+def tpch_q3(t: dict, segment_code: int, date_cut: int, target_partitions: int = 1, batch_size: int = 8192):
+    """t: dict of contiguous numpy arrays (decimal columns as (n,2) uint64 little-endian lo/hi).  Returns dict of numpy arrays."""
+    inp = DfoQ3In()
+    keep = []
+
+    def p(a, dt):
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a.ctypes.data
+
+    inp.n_customer = len(t["c_custkey"]); inp.c_custkey = p(t["c_custkey"], np.int64); inp.c_mktsegment = p(t["c_mktsegment"], np.int8); inp.segment_code = segment_code
+    inp.n_orders = len(t["o_orderkey"]); inp.o_orderkey = p(t["o_orderkey"], np.int64); inp.o_custkey = p(t["o_custkey"], np.int64)
+    inp.o_orderdate = p(t["o_orderdate"], np.int32); inp.o_shippriority = p(t["o_shippriority"], np.int32); inp.date_cut = date_cut
+    inp.n_lineitem = len(t["l_orderkey"]); inp.l_orderkey = p(t["l_orderkey"], np.int64)
+    inp.l_extendedprice = p(t["l_extendedprice"], np.uint64); inp.l_discount = p(t["l_discount"], np.uint64); inp.l_shipdate = p(t["l_shipdate"], np.int32)
+    out = DfoQ3Out()
+    if lib().dfo_tpch_q3(C.byref(inp), target_partitions, C.c_int64(batch_size), C.byref(out)):
+        raise OracleError(_err())
+    n = out.n
+    res = {"l_orderkey": np.ctypeslib.as_array(out.l_orderkey, (n,)).copy() if n else np.zeros(0, np.int64),
+           "revenue": np.frombuffer(C.string_at(out.revenue, n * 16), dtype=np.uint64).reshape(n, 2).copy() if n else np.zeros((0, 2), np.uint64),
+           "o_orderdate": np.ctypeslib.as_array(out.o_orderdate, (n,)).copy() if n else np.zeros(0, np.int32),
+           "o_shippriority": np.ctypeslib.as_array(out.o_shippriority, (n,)).copy() if n else np.zeros(0, np.int32)}
+    lib().dfo_q3_output_free(C.byref(out))
+    return res
