@@ -1,0 +1,148 @@
+"""-m gpu: GroupValues + GroupsAccumulator on device vs the CPU oracle: group ids in first-seen order (bit-exact),
+integer / Decimal128 aggregates bit-exact, Float64 SUM/AVG within 1e-9 relative (north_star tolerance)."""
+import decimal
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from oracle import pyoracle as po
+from test_gpu_core import rand_array
+from test_gpu_join import keycols
+
+pytestmark = pytest.mark.gpu
+RNG = np.random.default_rng(5)
+FLOAT_RTOL = 1e-9          # BASELINE.json north_star: "within 1e-9 relative for floating-point SUM/AVG"
+KIND = {"SUM": 0, "AVG": 1, "COUNT": 2, "MIN": 3, "MAX": 4}
+
+
+@pytest.mark.parametrize("kinds,card", [(["int64"], 50), (["int64"], 100000), (["int32", "utf8"], 30), (["utf8"], 500), (["dict"], 40),
+                                        (["decimal", "int32", "float64"], 20), (["int64"], 3)])
+def test_intern_first_seen_ids_and_emit(ctx, kinds, card):
+    import dfgpu
+    gv, og = dfgpu.GroupValues(ctx, len(kinds)), None
+    for n in (5000, 1, 0, 20000, 777):          # several batches: ids keep growing in first-seen order (primitive.rs:137-141)
+        cols = keycols(kinds, n, 0.1, card)
+        if og is None:
+            og = po.Groups([c.type for c in cols])
+        ids = gv.intern([ctx.from_arrow(c) for c in cols]).to_numpy()
+        assert np.array_equal(ids.astype(np.int64), og.intern(cols))
+        assert len(gv) == len(og)
+    for got, want in zip(gv.emit(), og.emit()):
+        assert got.to_arrow().equals(want)
+    assert gv.size() > 0
+
+
+def test_intern_under_forced_collisions_and_mask(ctx):
+    import dfgpu
+    cols = keycols(["int64", "utf8"], 3000, 0.1, 12)
+    ctx.set_option("force_hash_collisions", 1)
+    try:
+        gv = dfgpu.GroupValues(ctx, 2)
+        ids = gv.intern([ctx.from_arrow(c) for c in cols]).to_numpy()
+    finally:
+        ctx.set_option("force_hash_collisions", 0)
+    og = po.Groups([c.type for c in cols])
+    assert np.array_equal(ids.astype(np.int64), og.intern(cols))
+    m = RNG.random(3000) < 0.5
+    gv2 = dfgpu.GroupValues(ctx, 2)
+    ids2 = gv2.intern([ctx.from_arrow(c) for c in cols], mask=ctx.from_arrow(pa.array(m))).to_numpy()
+    og2 = po.Groups([c.type for c in cols])
+    want = og2.intern([c.filter(pa.array(m)) for c in cols])
+    assert np.array_equal(ids2[m].astype(np.int64), want) and (ids2[~m] == 0xFFFFFFFF).all()
+
+
+def value_array(kind, n):
+    if kind == "decimal":
+        return pa.array([None if RNG.random() < 0.1 else decimal.Decimal(int(v)).scaleb(-2) for v in RNG.integers(-10**13, 10**13, n)], type=pa.decimal128(15, 2))
+    return rand_array(kind, n, 0.1, RNG)
+
+
+def check_equal(got, want, floats):
+    assert got.type == want.type, f"{got.type} vs {want.type}"
+    assert np.array_equal(np.asarray(got.is_null()), np.asarray(want.is_null()))
+    if floats:
+        g, w = np.asarray(got.fill_null(0), dtype=np.float64), np.asarray(want.fill_null(0), dtype=np.float64)
+        assert np.allclose(g, w, rtol=FLOAT_RTOL, atol=1e-9 * np.abs(w).max() if len(w) else 0)
+    else:
+        assert got.equals(want)
+
+
+AGG_CASES = [("SUM", "int64"), ("SUM", "int32"), ("SUM", "uint64"), ("SUM", "float64"), ("SUM", "decimal"), ("AVG", "float64"), ("AVG", "decimal"),
+             ("COUNT", "int64"), ("COUNT", "utf8"), ("MIN", "int32"), ("MAX", "int64"), ("MIN", "float64"), ("MAX", "float32"), ("MIN", "decimal"), ("MAX", "decimal"),
+             ("MIN", "uint8"), ("MAX", "date32")]
+
+
+@pytest.mark.parametrize("fun,kind", AGG_CASES, ids=[f"{f}-{k}" for f, k in AGG_CASES])
+@pytest.mark.parametrize("ngroups", [4, 8, 9, 5000])
+def test_accumulators_update_evaluate_state_merge(ctx, fun, kind, ngroups):
+    """Partial (update_batch over several batches, growing group count, opt_filter) -> state -> Final (merge_batch) -> evaluate."""
+    import dfgpu
+    first = value_array(kind, 10)
+    f = dfgpu.operators.field_of_array("v", ctx.from_arrow(first))
+    acc, oacc = dfgpu.GroupsAccumulator(ctx, KIND[fun], f.dtype, f.precision, f.scale), po.Acc(fun, first.type)
+    total = 0
+    for n, hi, use_filter in [(4000, ngroups // 2 + 1, False), (6000, ngroups, True), (10, ngroups, False)]:
+        v = value_array(kind, n)
+        g = RNG.integers(0, hi, n)
+        total = max(total, hi)
+        filt = pa.array(RNG.random(n) < 0.7, mask=RNG.random(n) < 0.05) if use_filter else None
+        acc.update_batch(ctx.from_arrow(v), ctx.from_arrow(pa.array(g.astype(np.uint32))), ctx.from_arrow(filt) if filt is not None else None, total)
+        oacc.update_batch(v, g, filt, total)
+    floats = kind.startswith("float") and fun in ("SUM", "AVG")
+    st, ost = acc.state(), oacc.state()
+    assert len(st) == len(ost)
+    for a, b in zip(st, ost):
+        check_equal(a.to_arrow(), b, floats)
+    check_equal(acc.evaluate().to_arrow(), oacc.evaluate(), floats)
+    # Final: merge the partial state twice (two "partitions") under a permutation of group ids
+    perm = RNG.permutation(total)
+    fin, ofin = dfgpu.GroupsAccumulator(ctx, KIND[fun], f.dtype, f.precision, f.scale), po.Acc(fun, first.type)
+    for _ in range(2):
+        fin.merge_batch(st, ctx.from_arrow(pa.array(perm.astype(np.uint32))), None, total)
+        ofin.merge_batch(ost, perm, None, total)
+    check_equal(fin.evaluate().to_arrow(), ofin.evaluate(), floats)
+    assert acc.size() > 0
+
+
+def test_count_star_and_resize_only_update(ctx):
+    import dfgpu
+    acc = dfgpu.GroupsAccumulator(ctx, KIND["COUNT"], dfgpu.capi.INT64)
+    g = RNG.integers(0, 6, 1000)
+    acc.update_batch(None, ctx.from_arrow(pa.array(g.astype(np.uint32))), None, 6)
+    acc.update_batch(None, ctx.from_arrow(pa.array([], type=pa.uint32())), None, 9)        # resize only
+    got = acc.evaluate().to_numpy()
+    assert np.array_equal(got, np.concatenate([np.bincount(g, minlength=6), [0, 0, 0]]))
+
+
+def test_avg_decimal_overflow_is_an_error(ctx):
+    import dfgpu
+    v = pa.array([decimal.Decimal(10**37)] * 4, type=pa.decimal128(38, 0))
+    acc = dfgpu.GroupsAccumulator(ctx, KIND["AVG"], dfgpu.capi.DECIMAL128, 38, 0)
+    acc.update_batch(ctx.from_arrow(v), ctx.from_arrow(pa.array([0, 0, 0, 0], type=pa.uint32())), None, 1)
+    with pytest.raises(dfgpu.DfgpuError) as e:
+        acc.evaluate()
+    assert "Arithmetic Overflow in AvgAccumulator" in str(e.value)
+
+
+def test_aggregate_exec_partial_final_matches_reference_vector(ctx, task_ctx):
+    """check_aggregates (physical-plan/src/aggregates/mod.rs:1256-1286 data, :1509-1613): AVG(b) GROUP BY a over two
+    batches: Partial state (count,sum) = a=2:(2,2.0) 3:(3,7.0) 4:(3,11.0) -- wait for the merged Final: 2->1.0, 3->2.3333333333333335, 4->3.6666666666666665."""
+    import dfgpu
+    from dfgpu import operators as ops
+    b1 = pa.table({"a": pa.array([2, 3, 4, 4], type=pa.uint32()), "b": pa.array([1.0, 2.0, 3.0, 4.0])})
+    b2 = pa.table({"a": pa.array([2, 3, 3, 4], type=pa.uint32()), "b": pa.array([1.0, 2.0, 3.0, 4.0])})
+    src = ops.MemoryExec([[ops.batch_from_arrow(ctx, b1), ops.batch_from_arrow(ctx, b2)]], ops.batch_from_arrow(ctx, b1).schema)
+    aggr = [ops.AggregateFunctionExpr("AVG", ops.Column("b", 1), "AVG(b)", input_field=ops.Field("b", dfgpu.capi.FLOAT64))]
+    partial = ops.AggregateExec("Partial", [(ops.Column("a", 0), "a")], aggr, src)
+    pb = ops.collect(partial, task_ctx)[0]
+    rows = sort_rows_local(pb)
+    assert rows == [[2, 2, 2.0], [3, 3, 7.0], [4, 3, 11.0]]          # aggregates/mod.rs:1555-1566
+    final = ops.AggregateExec("Final", [(ops.Column("a", 0), "a")], aggr, partial)
+    fb = ops.collect(final, task_ctx)[0]
+    assert sort_rows_local(fb) == [[2, 1.0], [3, 2.3333333333333335], [4, 3.6666666666666665]]      # :1592-1603
+
+
+def sort_rows_local(batch):
+    from helpers import rows_of, sort_rows
+    return sort_rows(rows_of([c.to_arrow() for c in batch.columns]))

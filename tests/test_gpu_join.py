@@ -1,0 +1,168 @@
+"""-m gpu: HashJoinExec on device vs (1) the reference's own known-answer tables (tests/golden/hash_join.json) and
+(2) the CPU oracle on seeded random inputs -- (build, probe) index pairs bit-exact INCLUDING ORDER."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from helpers import load_golden, pa_types_for, rows_of, side_batches, sort_rows
+from oracle import pyoracle as po
+from test_gpu_core import rand_array
+
+pytestmark = pytest.mark.gpu
+CASES = load_golden("hash_join.json")["cases"]
+RNG = np.random.default_rng(99)
+
+
+def device_join(ctx, case, batch_size):
+    import dfgpu
+    from dfgpu import operators as ops
+    tc = ops.TaskContext(ctx, batch_size=batch_size)
+
+    def side(name):
+        names = case[name]["names"]
+        batches = [ops.batch_from_arrow(ctx, pa.table(dict(zip([f"c{i}" for i in range(len(names))], cols)))) for cols in side_batches(case, name)]
+        ts = pa_types_for(case, len(names))
+        code = {pa.int32(): dfgpu.capi.INT32, pa.int64(): dfgpu.capi.INT64, pa.date32(): dfgpu.capi.DATE32}
+        schema = ops.Schema([ops.Field(n, code[t]) for n, t in zip(names, ts)])
+        for b in batches:
+            b.schema = schema
+        parts = [[b] for b in batches] if "two_parts" in case["name"] else [batches]
+        return ops.MemoryExec(parts, schema), schema
+
+    left, ls = side("left")
+    right, rs = side("right")
+    on = [(ops.Column.new_with_schema(l, ls), ops.Column.new_with_schema(r, rs)) for l, r in case["on"]]
+    filt = None
+    if case["filter"]:
+        spec = case["filter"]
+        rhs = ops.Column("c", spec["rhs_column"]) if "rhs_column" in spec else ops.Literal(spec["rhs_literal"], pa.int32())
+        filt = ops.JoinFilter(ops.BinaryExpr(ops.Column("x", 0), spec["op"], rhs), [tuple(ci) for ci in spec["column_indices"]],
+                              ops.Schema([ops.Field("x", dfgpu.capi.INT32)] * len(spec["column_indices"])))
+    join = ops.HashJoinExec(left, right, on, filt, case["join_type"], "CollectLeft", case["null_equals_null"])
+    per_partition = []
+    for p in range(join.output_partitioning().partition_count()):
+        rows = []
+        for b in join.execute(p, tc):
+            rows += rows_of([c.to_arrow() for c in b.materialize().columns])
+        per_partition.append(rows)
+    return per_partition, join
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_hash_join_reference_golden(ctx, case):
+    for bs in case["batch_sizes"][:3]:
+        parts, join = device_join(ctx, case, bs)
+        rows = [r for p in parts for r in p]
+        if case["ordered"]:
+            assert rows == case["expected"], f"batch_size={bs}"
+        else:
+            assert sort_rows(rows) == sort_rows(case["expected"]), f"batch_size={bs}"
+        if case["per_partition_expected"]:
+            assert parts == case["per_partition_expected"]
+        want_names = case["left"]["names"] + case["right"]["names"]
+        if case["join_type"] in ("LeftSemi", "LeftAnti"): want_names = case["left"]["names"]
+        if case["join_type"] in ("RightSemi", "RightAnti"): want_names = case["right"]["names"]
+        assert join.schema().names() == want_names
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if not c["name"].startswith("join_splitted")], ids=lambda c: c["name"])
+def test_hash_join_golden_under_forced_collisions(ctx, case):
+    """≙ CI job `cargo test --features force_hash_collisions` (.github/workflows/rust.yml:454-470)."""
+    ctx.set_option("force_hash_collisions", 1)
+    try:
+        parts, _ = device_join(ctx, case, 8192)
+        assert sort_rows([r for p in parts for r in p]) == sort_rows(case["expected"])
+    finally:
+        ctx.set_option("force_hash_collisions", 0)
+
+
+def keycols(kinds, n, null_frac, card):
+    cols = []
+    for k in kinds:
+        if k == "int64": cols.append(pa.array(RNG.integers(0, card, n).astype(np.int64), mask=RNG.random(n) < null_frac if null_frac else None))
+        elif k == "int32": cols.append(pa.array(RNG.integers(-card // 2, card // 2, n).astype(np.int32), mask=RNG.random(n) < null_frac if null_frac else None))
+        elif k == "utf8": cols.append(pa.array([None if RNG.random() < null_frac else f"k{v}" for v in RNG.integers(0, card, n)], type=pa.utf8()))
+        elif k == "dict": cols.append(pa.array([None if RNG.random() < null_frac else f"k{v}" for v in RNG.integers(0, card, n)], type=pa.utf8()).dictionary_encode())
+        elif k == "decimal":
+            import decimal
+            cols.append(pa.array([None if RNG.random() < null_frac else decimal.Decimal(int(v)).scaleb(-2) for v in RNG.integers(0, card, n)], type=pa.decimal128(15, 2)))
+        elif k == "float64": cols.append(pa.array(RNG.integers(0, card, n).astype(np.float64), mask=RNG.random(n) < null_frac if null_frac else None))
+    return cols
+
+
+FUZZ = [(["int64"], 20000, 50000, 0.0, 30000), (["int64"], 5000, 20000, 0.1, 500), (["int32", "utf8"], 3000, 9000, 0.1, 40),
+        (["decimal"], 4000, 8000, 0.05, 1000), (["dict", "int64"], 2000, 5000, 0.1, 30), (["float64"], 1000, 3000, 0.0, 100),
+        (["int64"], 1, 1000, 0.0, 5), (["int64"], 1000, 1, 0.0, 5), (["int64"], 0, 100, 0.0, 5), (["int64"], 100, 0, 0.0, 5),
+        (["int64"], 70000, 300000, 0.0, 10**9)]
+
+
+@pytest.mark.parametrize("kinds,nb,npr,nf,card", FUZZ, ids=[f"{'+'.join(f[0])}-{f[1]}x{f[2]}" for f in FUZZ])
+@pytest.mark.parametrize("nen", [False, True])
+def test_probe_pairs_match_oracle_exactly(ctx, kinds, nb, npr, nf, card, nen):
+    """≙ core/tests/fuzz_cases/join_fuzz.rs, but stricter: pair ORDER must equal the reference's (probe order, then build order)."""
+    import dfgpu
+    b, p = keycols(kinds, nb, nf, card), keycols(kinds, npr, nf, card)
+    table = dfgpu.JoinTable(ctx, [ctx.from_arrow(c) for c in b], null_equals_null=nen)
+    bi, pi = table.probe([ctx.from_arrow(c) for c in p])
+    want = po.hash_join([b], [p], "Inner", nen, batch_size=1 << 40)
+    assert np.array_equal(bi.to_numpy().astype(np.int64), want.build_idx)
+    assert np.array_equal(pi.to_numpy().astype(np.int64), want.probe_idx)
+    assert table.num_rows == nb and table.memory > 0
+
+
+def test_probe_with_fused_masks_equals_filtered_inputs(ctx):
+    """FilterExec fused into build and probe: same pairs as compacting first (indices mapped back)."""
+    import dfgpu
+    nb, npr = 8000, 30000
+    b, p = keycols(["int64"], nb, 0.0, 3000), keycols(["int64"], npr, 0.0, 3000)
+    bm, pm = RNG.random(nb) < 0.6, RNG.random(npr) < 0.4
+    table = dfgpu.JoinTable(ctx, [ctx.from_arrow(b[0])], mask=ctx.from_arrow(pa.array(bm)))
+    bi, pi = table.probe([ctx.from_arrow(p[0])], mask=ctx.from_arrow(pa.array(pm)))
+    want = po.hash_join([[b[0].filter(pa.array(bm))]], [[p[0].filter(pa.array(pm))]], "Inner", batch_size=1 << 40)
+    bmap, pmap = np.flatnonzero(bm), np.flatnonzero(pm)
+    assert np.array_equal(bi.to_numpy().astype(np.int64), bmap[want.build_idx])
+    assert np.array_equal(pi.to_numpy().astype(np.int64), pmap[want.probe_idx])
+    # unmatched build rows exclude rows dropped by the build-side filter
+    table.mark_visited(bi)
+    fin = table.final_indices(dfgpu.capi.JOIN_LEFT).to_numpy()
+    visited = np.zeros(nb, bool); visited[bmap[want.build_idx]] = True
+    assert np.array_equal(fin, np.flatnonzero(bm & ~visited))
+
+
+@pytest.mark.parametrize("jt", ["Inner", "Left", "Right", "Full", "LeftSemi", "RightSemi", "LeftAnti", "RightAnti"])
+def test_join_types_fuzz_vs_oracle(ctx, task_ctx, jt):
+    """All 8 join types over multi-batch inputs with NULL keys and duplicate keys; multiset of output rows equals the oracle's."""
+    import dfgpu
+    from dfgpu import operators as ops
+    lb = [pa.table({"k": keycols(["int64"], n, 0.1, 50)[0], "v": pa.array(RNG.integers(0, 10**6, n))}) for n in (300, 1, 500)]
+    rb = [pa.table({"k": keycols(["int64"], n, 0.1, 70)[0], "w": pa.array(RNG.integers(0, 10**6, n))}) for n in (700, 64, 200)]
+    mk = lambda tabs: ops.MemoryExec([[ops.batch_from_arrow(ctx, t) for t in tabs]], ops.batch_from_arrow(ctx, tabs[0]).schema)
+    left, right = mk(lb), mk(rb)
+    join = ops.HashJoinExec(left, right, [(ops.Column("k", 0), ops.Column("k", 0))], None, jt)
+    got = []
+    for b in ops.collect(join, task_ctx):
+        got += rows_of([c.to_arrow() for c in b.columns])
+    res = po.hash_join([[t["k"]] for t in lb], [[t["k"]] for t in rb], jt, batch_size=8192)
+    lcat = pa.concat_tables(lb[::-1]); want = []
+    for bi, pi, pb in zip(res.build_idx, res.probe_idx, res.probe_batch):
+        l = [None, None] if bi < 0 else [lcat["k"][int(bi)].as_py(), lcat["v"][int(bi)].as_py()]
+        r = [None, None] if pi < 0 else [rb[pb]["k"][int(pi)].as_py(), rb[pb]["w"][int(pi)].as_py()]
+        want.append(l if jt in ("LeftSemi", "LeftAnti") else r if jt in ("RightSemi", "RightAnti") else l + r)
+    assert sort_rows(got) == sort_rows(want)
+    if jt in ("Inner", "RightSemi", "RightAnti"):        # probe-order preserving join types: exact order
+        assert got == want
+
+
+def test_join_key_type_mismatch_is_rejected(ctx):
+    import dfgpu
+    t = dfgpu.JoinTable(ctx, [ctx.from_arrow(pa.array([1, 2, 3], type=pa.int64()))])
+    with pytest.raises(dfgpu.DfgpuError):
+        t.probe([ctx.from_arrow(pa.array([1, 2, 3], type=pa.int32()))])
+
+
+def test_join_requires_on_columns(ctx):
+    import dfgpu
+    from dfgpu import operators as ops
+    s = ops.Schema([ops.Field("a", dfgpu.capi.INT32)])
+    with pytest.raises(dfgpu.DfgpuError):     # hash_join.rs:303-305
+        ops.HashJoinExec(ops.MemoryExec([[]], s), ops.MemoryExec([[]], s), [], None, "Inner")

@@ -1,0 +1,76 @@
+"""-m gpu: SortExec (lexsort_to_indices) and RepartitionExec (hash partition) on device vs the CPU oracle -- index-exact."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from oracle import pyoracle as po
+from test_gpu_core import rand_array
+
+pytestmark = pytest.mark.gpu
+RNG = np.random.default_rng(11)
+
+SORT_KINDS = ["int8", "int16", "int32", "int64", "uint8", "uint32", "uint64", "float32", "float64", "date32", "bool", "decimal", "dict_int"]
+
+
+def sort_col(kind, n, nf):
+    if kind == "dict_int":
+        return pa.array(RNG.integers(0, 20, n).astype(np.int64), mask=RNG.random(n) < nf if nf else None).dictionary_encode()
+    if kind in ("int64", "float64"):     # few distinct values => many ties (stability matters)
+        a = rand_array(kind, n, nf, RNG)
+        return pa.array([None if v is None else (v if i % 2 else (1.5 if kind == "float64" else 7)) for i, v in enumerate(a.to_pylist())], type=a.type)
+    return rand_array(kind, n, nf, RNG)
+
+
+@pytest.mark.parametrize("kind", SORT_KINDS)
+@pytest.mark.parametrize("desc,nf_first", [(False, True), (True, True), (False, False), (True, False)])
+def test_single_column_sort(ctx, kind, desc, nf_first):
+    for n, nf in [(0, 0), (1, 0), (2, 0.5), (1000, 0.2), (5000, 0.0), (70000, 0.1)]:
+        a = sort_col(kind, n, nf)
+        got = ctx.sort_to_indices([ctx.from_arrow(a)], [desc], [nf_first]).to_numpy()
+        assert np.array_equal(got, po.lexsort_to_indices([a], [desc], [nf_first])), f"n={n}"
+
+
+def test_float_sort_nan_placement(ctx):
+    """test_lex_sort_by_float (sorts/sort.rs:1290-1392): NaN sorts above every number, NULLs by nulls_first."""
+    a = pa.array([float("nan"), None, None, float("nan"), 1.0, 2.0, 3.0, -0.0, 0.0, float("-inf"), float("inf")], type=pa.float32())
+    b = pa.array([10.0, 20.0, 10.0, 100.0, float("nan"), None, None, float("nan"), 1.0, 2.0, 3.0], type=pa.float64())
+    for da, na, db, nb in [(True, True, False, False), (False, False, True, True), (False, True, False, True)]:
+        got = ctx.sort_to_indices([ctx.from_arrow(a), ctx.from_arrow(b)], [da, db], [na, nb]).to_numpy()
+        assert np.array_equal(got, po.lexsort_to_indices([a, b], [da, db], [na, nb]))
+    asc = ctx.sort_to_indices([ctx.from_arrow(a)], [False], [False]).to_numpy()
+    vals = a.take(pa.array(asc)).to_pylist()
+    assert vals[-2:] == [None, None] and all(v != v for v in vals[-4:-2]) and vals[0] == float("-inf")
+
+
+def test_multi_column_sort_q3_shape_and_fetch(ctx):
+    """Q3 sort keys: revenue Decimal128(38,4) DESC NULLS FIRST, o_orderdate Date32 ASC NULLS LAST."""
+    import decimal
+    n = 50000
+    rev = pa.array([decimal.Decimal(int(v)).scaleb(-4) for v in RNG.integers(0, 3000, n) * 10**6], type=pa.decimal128(38, 4))
+    date = pa.array(RNG.integers(8035, 9204, n).astype(np.int32)).cast(pa.date32())
+    got = ctx.sort_to_indices([ctx.from_arrow(rev), ctx.from_arrow(date)], [True, False], [True, False]).to_numpy()
+    assert np.array_equal(got, po.lexsort_to_indices([rev, date], [True, False], [True, False]))
+    top = ctx.sort_to_indices([ctx.from_arrow(rev), ctx.from_arrow(date)], [True, False], [True, False], fetch=10).to_numpy()
+    assert np.array_equal(top, got[:10])
+    three = [rand_array("int8", 20000, 0.1, RNG), rand_array("bool", 20000, 0.1, RNG), rand_array("uint16", 20000, 0.0, RNG)]
+    got3 = ctx.sort_to_indices([ctx.from_arrow(c) for c in three], [False, True, False], [False, True, True]).to_numpy()
+    assert np.array_equal(got3, po.lexsort_to_indices(three, [False, True, False], [False, True, True]))
+
+
+def test_utf8_sort_key_reports_not_implemented(ctx):
+    import dfgpu
+    with pytest.raises(dfgpu.DfgpuError) as e:
+        ctx.sort_to_indices([ctx.from_arrow(pa.array(["b", "a"]))], [False], [True])
+    assert e.value.kind == "NotImplemented"
+
+
+@pytest.mark.parametrize("nparts", [1, 2, 3, 4, 8, 16, 200, 1000])
+def test_hash_partition_matches_oracle(ctx, nparts):
+    """BatchPartitioner::partition_iter (repartition/mod.rs:148-221): indices grouped by hash % n, input order kept; row conservation (:952-1031)."""
+    for kinds, n in [(["int64"], 100000), (["int32", "utf8"], 5000), (["decimal"], 3000), (["int64"], 0), (["int64"], 1)]:
+        from test_gpu_join import keycols
+        cols = keycols(kinds, n, 0.1, 1000)
+        idx, counts = ctx.hash_partition([ctx.from_arrow(c) for c in cols], nparts)
+        oidx, ocounts = po.hash_partition(cols, nparts)
+        assert counts == ocounts.tolist() and sum(counts) == n
+        assert np.array_equal(idx.to_numpy(), oidx)
