@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- TPC-H SF100 Q3 (hash-join + aggregate + sort) through the dfgpu operator layer on N MI355X.
+
+One "step" = one full pass of the Q3 physical plan (reference plan shape: sqllogictest/test_files/tpch/q3.slt.part)
+over synthetic TPC-H-shaped Arrow columns that are already resident in HBM when the clock starts (the analogue of
+the reference's `--mem-table` mode, benchmarks/src/tpch/run.rs:72-74).  value = input rows (customer + orders +
+lineitem) of the whole job / wall time, max over ranks.
+
+Extra objects in the JSON line:
+  roofline     dominant kernel by device time: algorithmic bytes per launch / average launch duration (HIP events
+               recorded on the stream the kernel runs on, through dfgpu_profile_*), against 8 TB/s HBM3E.
+  cpu_baseline the oracle's restatement of the same plan (oracle/dfo_tpch.c, "port") timed on this box's host cores
+               over a bounded SF sample of the same workload; reported, never the target.
+Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+Q3_BYTES_PER_ROW = 39.4         # 30.2 GB algorithmic bytes / 765,037,902 input rows at SF100
+
+# algorithmic bytes per row for the kernels that can dominate (DESIGN.md "kernels"): columns that must be read +
+# results that must be written once; hash tables and other intermediates are not counted.
+KERNEL_BYTES_PER_ROW = {
+    "k_join_probe_find": 8 + 0.125 + 4,       # probe key (Int64) + selection bit + matched-slot word
+    "k_join_probe_fill": 4 + 8 + 4,           # matched-slot word + (UInt64 build idx, UInt32 probe idx) per output pair (upper bound per probe row)
+    "k_join_build": 8 + 0.125 + 4,            # build key + selection bit + row->slot word
+    "k_compare": 4 + 0.125,                   # Date32 operand + result bit
+    "k_take_fixed": 4 + 8 + 8,                # index + gathered value + written value (8-byte column)
+    "k_groups_find": 16 + 4,                  # 3 key columns (8+4+4) + group-id word
+    "k_acc_update": 16 + 4,                   # Decimal128 value + group id
+    "k_arith": 32 + 16,                       # two Decimal128 operands + result
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--sf", type=float, default=100.0, help="TPC-H scale factor of the whole job")
+    ap.add_argument("--cpu-sf", type=float, default=10.0, help="scale factor of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    import dfgpu
+    from dfgpu import exchange, operators as ops, tpch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # one ctx on torch's current stream: dfgpu kernels, torch ops and RCCL collectives are stream ordered
+    ctx = dfgpu.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    tc = ops.TaskContext(ctx, batch_size=8192)
+    tables = tpch.gen_device(ctx, args.sf, rank=rank, world=world)
+    rows_local = sum(t.num_rows for t in tables.values())
+    rows_total = rows_local
+    if world > 1:
+        t = torch.tensor([rows_local], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t)
+        rows_total = int(t.item())
+    torch.cuda.synchronize()
+
+    result_rows = [0]
+
+    def step():
+        if world == 1:
+            plan = tpch.q3_plan(tables, batch_size=8192)
+            out = [b for b in plan.execute(0, tc)]
+        else:
+            plan = tpch.q3_distributed_plan(tables, batch_size=8192)
+            local = [b for b in plan.execute(0, tc)]
+            schema = local[0].schema if local else plan.schema()
+            mine = ops.concat_batches(schema, local) if local else None
+            gathered = exchange.gather_batches(ctx, schema, mine, 0)           # ≙ SortPreservingMergeExec gathering the sorted partitions
+            out = []
+            if rank == 0 and gathered.num_rows:
+                C = ops.Column
+                final = ops.SortExec([ops.PhysicalSortExpr(C("revenue", 1), True, True), ops.PhysicalSortExpr(C("o_orderdate", 2), False, False)],
+                                     ops.MemoryExec([[gathered]], gathered.schema))
+                out = [b for b in final.execute(0, tc)]
+        ctx.synchronize()
+        result_rows[0] = sum(b.num_rows for b in out)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile_enable(True)
+    ctx.profile_read()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = rows_total * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (rank 0's view; every rank runs the same kernels on its shard)
+    roofline = None
+    if prof:
+        name, (launches, total_ms) = max(prof.items(), key=lambda kv: kv[1][1])
+        per_step = launches / args.steps
+        avg_ms = total_ms / launches
+        # rows one launch of that kernel processes in this plan (its largest launch dominates the average)
+        line_rows = tables["lineitem"].num_rows
+        rows_per_launch = {"k_join_probe_find": (tables["orders"].num_rows + line_rows) / 2, "k_join_probe_fill": (tables["orders"].num_rows + line_rows) / 2,
+                           "k_compare": (tables["customer"].num_rows + tables["orders"].num_rows + line_rows) / 3}.get(name, None)
+        bpr = KERNEL_BYTES_PER_ROW.get(name)
+        if bpr is not None and rows_per_launch is not None:
+            achieved = bpr * rows_per_launch / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(name)
+            roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": traffic, "launches_per_step": per_step, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(bpr * rows_per_launch)}
+        else:
+            roofline = {"bound": "hbm", "kernel": name, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                        "launches_per_step": per_step, "avg_launch_ms": round(avg_ms, 4)}
+        roofline["kernel_ms_per_step"] = {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+        q_gbs = Q3_BYTES_PER_ROW * rows_total / (ms_per_step * 1e-3) / 1e9
+        roofline["query"] = {"achieved": round(q_gbs, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(q_gbs / (HBM_PEAK_GBS * world), 4),
+                             "algorithmic_bytes_per_step": int(Q3_BYTES_PER_ROW * rows_total)}
+
+    # ---- CPU baseline: the oracle's restatement of the same plan on a bounded sample (rank 0, N = 1 only)
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_sf > 0:
+        from oracle import pyoracle as po
+        import numpy as np
+        cpu_sf = min(args.cpu_sf, args.sf)
+        small = tpch.gen_device(ctx, cpu_sf, seed=tpch.SEED + 1)
+        host = {}
+        for tname, batch in small.items():
+            for f, col in zip(batch.schema.fields, batch.columns):
+                keep = col._keepalive[0] if isinstance(col._keepalive, tuple) else col._keepalive
+                a = keep.cpu().numpy()
+                host[f.name] = a.view(np.uint64) if a.ndim == 2 else a
+        del small
+        torch.cuda.empty_cache()
+        # a one-GPU box is given a 16-core share of the host (os.cpu_count() reports the whole machine)
+        cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+        n_in = tpch.total_input_rows(host)
+        seg, times = tpch.SEGMENTS.index(tpch.Q3_SEGMENT), []
+        po.tpch_q3(host, seg, tpch.Q3_DATE, cores, 8192)                  # warm-up (page faults)
+        for _ in range(3):
+            t1 = time.perf_counter()
+            res = po.tpch_q3(host, seg, tpch.Q3_DATE, cores, 8192)
+            times.append(time.perf_counter() - t1)
+        med = statistics.median(times)
+        cpu_baseline = {"value": round(n_in / med, 1), "unit": "rows/s", "cores": cores, "kind": "port",
+                        "sample": f"oracle/dfo_tpch.c restatement of DataFusion 36 CPU operators (Q3 plan, target_partitions={cores}, batch_size=8192) on synthetic SF{cpu_sf:g} "
+                                  f"({n_in} input rows, {len(res['l_orderkey'])} result rows); 1 warm-up + 3 runs, median {med:.3f}s, min {min(times):.3f}s",
+                        "min_value": round(n_in / min(times), 1)}
+
+    if rank == 0:
+        line = {"metric": "rows/sec hash-join+agg, TPC-H SF100 Q3", "value": round(value, 1), "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64 keys / i128 (Decimal128) sums",
+                "data": "synthetic", "config": {"workload": f"TPC-H SF{args.sf:g} Q3 (3-way hash join + group-by SUM + sort), int64 keys, Decimal128(15,2) money, resident in HBM",
+                                                "input_rows": rows_total, "result_rows": result_rows[0], "parallelism": f"{world} x (hash-partition + RCCL all-to-all)" if world > 1 else "1 GPU"},
+                "roofline": roofline, "cpu_baseline": cpu_baseline}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

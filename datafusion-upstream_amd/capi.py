@@ -79,6 +79,8 @@ PROTOTYPES = {
     "dfgpu_ctx_set_option": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
     "dfgpu_ctx_stream": (_P, [_P]),
     "dfgpu_version": (C.c_char_p, []),
+    "dfgpu_profile_enable": (C.c_int32, [_P, C.c_int32]),
+    "dfgpu_profile_read": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
     "dfgpu_array_import_host": (C.c_int32, [_P, C.POINTER(ArrayDesc), _PP]),
     "dfgpu_array_wrap_device": (C.c_int32, [_P, C.POINTER(ArrayDesc), _PP]),
     "dfgpu_array_describe": (C.c_int32, [_P, C.POINTER(ArrayDesc)]),
@@ -138,6 +140,13 @@ def load_library() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'); "
                           "there is no CPU fallback for the dfgpu operators")
+    # torch bundles its own ROCm runtime (libamdhip64): when torch is used in the same process (device memory,
+    # streams, RCCL plumbing) it must be loaded first so both sides share ONE HIP runtime; loading the system
+    # runtime first makes torch report "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol

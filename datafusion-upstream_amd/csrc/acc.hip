@@ -228,6 +228,7 @@ static void launch_update(dfgpu_acc* a, int kind, int cls, const dfgpu_array* va
   const uint64_t* fb = filt ? (const uint64_t*)filt->values->ptr : nullptr; const uint64_t* fv = filt && filt->validity ? (const uint64_t*)filt->validity->ptr : nullptr;
   const uint32_t* g = (const uint32_t*)gids->values->ptr;
   int blocks = grid_for(n, BLOCK * 8, ctx->num_cus * 8);
+  KernelTimer kt_(ctx, "k_acc_update");
   bool sumlike = kind == DFGPU_AGG_SUM || kind == DFGPU_AGG_AVG || kind == DFGPU_AGG_COUNT;
   if (sumlike && total <= SMALL_G) {
 #define SMALL(T, C) hipLaunchKernelGGL((k_acc_small<T, C>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, kind, v, values ? 1 : 0, g, fb, fv, n, (int)total, vals, (uint64_t*)a->counts->ptr, (uint8_t*)a->seen->ptr, 1)

@@ -21,6 +21,8 @@ static void ctx_unref(dfgpu_ctx* c) {
   { std::lock_guard<std::mutex> l(g_mu); for (size_t i = 0; i < g_ctx.size(); i++) if (g_ctx[i].first == c) { g_ctx.erase(g_ctx.begin() + i); break; } }
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->free_blocks) { for (auto& b : *c->free_blocks) (void)hipFree(b.second); delete c->free_blocks; }
+  delete c->alloc_mu;
   if (c->d_flags) (void)hipFree(c->d_flags);
   if (c->d_scratch64) (void)hipFree(c->d_scratch64);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -28,14 +30,38 @@ static void ctx_unref(dfgpu_ctx* c) {
   delete r; delete c;
 }
 
+static size_t size_class(size_t bytes) {
+  size_t n = 256;
+  while (n < bytes) { size_t m = n + n / 2; if (m >= bytes && n >= 512) return m; n <<= 1; }
+  return n;
+}
 Buffer::~Buffer() {
-  if (owned && ptr && ctx) { (void)hipSetDevice(ctx->device); (void)hipFreeAsync(ptr, ctx->stream); ctx_unref(ctx); }
+  if (owned && ptr && ctx) {
+    // stream-ordered reuse: every consumer of this block was enqueued on ctx->stream before the next owner's work
+    { std::lock_guard<std::mutex> l(*ctx->alloc_mu); ctx->free_blocks->emplace_back(bytes, ptr); ctx->cached_bytes += bytes; ctx->live_bytes -= bytes; }
+    ctx_unref(ctx);
+  }
 }
 BufferPtr alloc_buffer(dfgpu_ctx* ctx, size_t bytes, bool zero) {
   auto b = std::make_shared<Buffer>();
-  size_t n = bytes ? ((bytes + 255) & ~(size_t)255) : 256;      // 256 B granules keep every buffer 16 B aligned + padded
+  size_t n = size_class(bytes ? bytes : 1);      // >= 256 B granules keep every buffer 16 B aligned + padded
   void* p = nullptr;
-  HIP_CHECK(hipMallocAsync(&p, n, ctx->stream));
+  {
+    std::lock_guard<std::mutex> l(*ctx->alloc_mu);
+    auto& fb = *ctx->free_blocks;
+    for (size_t i = fb.size(); i-- > 0;) if (fb[i].first == n) { p = fb[i].second; fb[i] = fb.back(); fb.pop_back(); ctx->cached_bytes -= n; break; }
+  }
+  if (!p) {
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipErrorOutOfMemory) {          // give cached blocks back to the driver and retry once
+      (void)hipGetLastError();
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      { std::lock_guard<std::mutex> l(*ctx->alloc_mu); for (auto& x : *ctx->free_blocks) (void)hipFree(x.second); ctx->free_blocks->clear(); ctx->cached_bytes = 0; }
+      e = hipMalloc(&p, n);
+    }
+    if (e != hipSuccess) fail(e == hipErrorOutOfMemory ? DFGPU_RESOURCES_EXHAUSTED : DFGPU_INTERNAL, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+  }
+  { std::lock_guard<std::mutex> l(*ctx->alloc_mu); ctx->live_bytes += n; }
   b->ptr = p; b->bytes = n; b->ctx = ctx; b->owned = true;
   CtxRefs* r = refs_of(ctx); if (r) r->n.fetch_add(1);
   if (zero) HIP_CHECK(hipMemsetAsync(p, 0, n, ctx->stream));
@@ -225,8 +251,7 @@ dfgpu_status dfgpu_ctx_create(int32_t device_id, void* stream, dfgpu_ctx** out) 
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
-    hipMemPool_t pool; HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, device_id));
-    uint64_t thr = UINT64_MAX; HIP_CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr));
+    c->alloc_mu = new std::mutex(); c->free_blocks = new std::vector<std::pair<size_t, void*>>();
     HIP_CHECK(hipMalloc((void**)&c->d_flags, 256)); HIP_CHECK(hipMemset(c->d_flags, 0, 256));
     HIP_CHECK(hipMalloc((void**)&c->d_scratch64, 64 * 8)); HIP_CHECK(hipMemset(c->d_scratch64, 0, 64 * 8));
     HIP_CHECK(hipHostMalloc((void**)&c->h_pinned, 64 * 8, hipHostMallocDefault));
@@ -246,6 +271,30 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     if (k == "force_hash_collisions") ctx->force_hash_collisions = value != 0;
     else if (k == "first_seen_group_order") ctx->first_seen_group_order = value != 0;
     else fail(DFGPU_INVALID_ARGUMENT, "unknown option '%s'", k.c_str());
+  });
+}
+
+dfgpu_status dfgpu_profile_enable(dfgpu_ctx* ctx, int32_t on) {
+  if (!ctx) return DFGPU_INVALID_ARGUMENT;
+  ctx->profile = on != 0; return DFGPU_OK;
+}
+dfgpu_status dfgpu_profile_read(dfgpu_ctx* ctx, char* buf, int64_t capacity) {
+  return guard(ctx, [&] {
+    if (!buf || capacity < 1) fail(DFGPU_INVALID_ARGUMENT, "profile_read: no buffer");
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    std::vector<std::string> names; std::vector<double> ms; std::vector<int64_t> cnt;
+    for (auto& r : ctx->prof) {
+      float t = 0; if (hipEventElapsedTime(&t, r.start, r.stop) != hipSuccess) t = 0;
+      (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop);
+      size_t k = 0; for (; k < names.size(); k++) if (names[k] == r.name) break;
+      if (k == names.size()) { names.push_back(r.name); ms.push_back(0); cnt.push_back(0); }
+      ms[k] += t; cnt[k]++;
+    }
+    ctx->prof.clear();
+    std::string out;
+    for (size_t k = 0; k < names.size(); k++) { char line[256]; snprintf(line, sizeof line, "%s %lld %.6f\n", names[k].c_str(), (long long)cnt[k], ms[k]); out += line; }
+    if ((int64_t)out.size() + 1 > capacity) out.resize((size_t)capacity - 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
   });
 }
 

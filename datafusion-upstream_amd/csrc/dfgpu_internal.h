@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -43,6 +44,15 @@ struct dfgpu_ctx {
   uint64_t* d_scratch64 = nullptr;  // 64 x u64 device scratch for counters / totals
   uint64_t* h_pinned = nullptr;     // 64 x u64 pinned host mirror
   int num_cus = 256;
+  // optional per-kernel timing with HIP events on ctx->stream (bench.py roofline leg)
+  // stream-ordered caching allocator: freed blocks are reused by later work on the same stream without going
+  // back to the driver (hipMallocAsync pool growth cost ~200 ms per step at SF100); size classes 2^k and 1.5*2^k
+  std::mutex* alloc_mu = nullptr;
+  std::vector<std::pair<size_t, void*>>* free_blocks = nullptr;   // (class bytes, ptr)
+  size_t cached_bytes = 0, live_bytes = 0;
+  bool profile = false;
+  struct ProfRec { const char* name; hipEvent_t start, stop; };
+  std::vector<ProfRec> prof;
 };
 
 namespace dfgpu {
@@ -141,6 +151,18 @@ void hash_keys_device(dfgpu_ctx* ctx, const dfgpu_array* const* cols, int32_t k,
 // sort.hip: stable sort of (u32 key, u32 value) pairs on `bits` low bits of the key
 void radix_sort_pairs_u32(dfgpu_ctx* ctx, uint32_t* keys, uint32_t* vals, int64_t n, int bits);
 
+// RAII: brackets the kernel launches in its scope with HIP events when profiling is enabled
+struct KernelTimer {
+  dfgpu_ctx* c; int idx = -1;
+  KernelTimer(dfgpu_ctx* ctx, const char* name) : c(ctx) {
+    if (!c->profile) return;
+    dfgpu_ctx::ProfRec r{name, nullptr, nullptr};
+    if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+    (void)hipEventRecord(r.start, c->stream); c->prof.push_back(r); idx = (int)c->prof.size() - 1;
+  }
+  ~KernelTimer() { if (idx >= 0) (void)hipEventRecord(c->prof[idx].stop, c->stream); }
+};
+
 template <typename F>
 dfgpu_status guard(dfgpu_ctx* ctx, F&& f) {
   try { f(); return DFGPU_OK; }
@@ -149,8 +171,13 @@ dfgpu_status guard(dfgpu_ctx* ctx, F&& f) {
   catch (const std::exception& e) { if (ctx) ctx->err = e.what(); return DFGPU_INTERNAL; }
 }
 
-inline int grid_for(int64_t n, int block, int max_blocks = 1 << 20) {
-  int64_t g = (n + block - 1) / block; if (g < 1) g = 1; if (g > max_blocks) g = max_blocks; return (int)g;
+// One workgroup per `block` elements.  Kernels that index one element per lane pass no cap (gridDim.x may be
+// up to 2^31-1); only kernels written as grid-stride loops pass `max_blocks`.
+inline int grid_for(int64_t n, int block, int64_t max_blocks = 0x7FFFFFFF) {
+  int64_t g = (n + block - 1) / block; if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  if (g > 0x7FFFFFFFll) fail(DFGPU_NOT_IMPLEMENTED, "launch of %lld workgroups exceeds the grid limit", (long long)g);
+  return (int)g;
 }
 
 }  // namespace dfgpu

@@ -268,6 +268,7 @@ dfgpu_status dfgpu_binary(dfgpu_ctx* ctx, int32_t op, const dfgpu_array* l, int3
       if (lt == DFGPU_DECIMAL128 && lo.v.scale != ro.v.scale) fail(DFGPU_INVALID_ARGUMENT, "compare: decimal scales differ; the planner coerces first");
       bool need_valid = nulls && op != DFGPU_OP_DISTINCT && op != DFGPU_OP_NOT_DISTINCT;
       ArrayHolder h(new_fixed(ctx, DFGPU_BOOL, n, 0, 0, need_valid));
+      KernelTimer kt_(ctx, "k_compare");
       if (n) hipLaunchKernelGGL(k_compare, grid, block, 0, ctx->stream, op, lo, ro, n, (uint64_t*)h.get()->values->ptr, need_valid ? (uint64_t*)h.get()->validity->ptr : nullptr);
       KERNEL_CHECK(); if (need_valid) h.get()->null_count = -1;
       *out = h.release(); return;
@@ -286,6 +287,7 @@ dfgpu_status dfgpu_binary(dfgpu_ctx* ctx, int32_t op, const dfgpu_array* l, int3
     } else if (!(is_signed_int(lt) || is_unsigned_int(lt) || is_float(lt))) fail(DFGPU_NOT_IMPLEMENTED, "arithmetic on type %d", lt);
     ArrayHolder h(new_fixed(ctx, ot, n, rp, rsc, nulls));
     if (n) {
+      KernelTimer kt_(ctx, "k_arith");
       hipLaunchKernelGGL(k_arith, grid, block, 0, ctx->stream, op, lo, ro, n, ot, dr, h.get()->values->ptr, ctx->d_flags);
       if (nulls) hipLaunchKernelGGL(k_both_valid, grid, block, 0, ctx->stream, lo, ro, n, (uint64_t*)h.get()->validity->ptr);
       KERNEL_CHECK();

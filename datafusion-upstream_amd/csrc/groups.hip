@@ -33,7 +33,7 @@ namespace dfgpu {
 
 __global__ void __launch_bounds__(BLOCK) k_groups_find(KeySet bk, KeySet stored, int has_stored, int64_t n, const uint64_t* mask, int force_zero,
                                                        uint64_t* slots, uint64_t cap_mask, uint32_t* first_row, uint32_t* tmp,
-                                                       unsigned long long* counters /* [0] new groups, [1] overflow */, unsigned long long limit) {
+                                                       unsigned long long* counters /* [1] overflow */, uint64_t max_steps) {
   int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   uint32_t res = G_NONE;
@@ -42,12 +42,15 @@ __global__ void __launch_bounds__(BLOCK) k_groups_find(KeySet bk, KeySet stored,
     if (force_zero) h = 0;
     uint64_t tag = h >> 32, s = h & cap_mask, mine = (tag << 32) | (uint64_t)(G_NEW | (uint32_t)i);
     bool done = false;
-    for (uint64_t step = 0; step <= cap_mask && !done; step++) {
+    // No single-address group counter (1e6 atomics on one word cost 10+ ms): the number of new groups is the
+    // popcount of the first-row bitmap computed afterwards.  A table that fills up shows as a probe sequence longer
+    // than max_steps; the flag is polled so that the remaining workgroups drain quickly before the host retries.
+    for (uint64_t step = 0; step <= max_steps && !done; step++) {
+      if ((step & 63) == 63 && __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
       uint64_t cur = slots[s];
       if (cur == G_EMPTY) {
-        if (counters[0] >= limit) { atomicMax(&counters[1], 1ull); break; }
         cur = atomicCAS((unsigned long long*)&slots[s], (unsigned long long)G_EMPTY, (unsigned long long)mine);
-        if (cur == G_EMPTY) { if (atomicAdd(&counters[0], 1ull) + 1 > limit) atomicMax(&counters[1], 1ull); cur = mine; }
+        if (cur == G_EMPTY) cur = mine;
       }
       if ((cur >> 32) == tag) {
         uint32_t pl = (uint32_t)cur;
@@ -58,7 +61,7 @@ __global__ void __launch_bounds__(BLOCK) k_groups_find(KeySet bk, KeySet stored,
       }
       s = (s + 1) & cap_mask;
     }
-    if (!done) atomicMax(&counters[1], 1ull);      // table full
+    if (!done) counters[1] = 1ull;      // table (nearly) full: host grows it and redoes the batch
   }
   tmp[i] = res;
 }
@@ -139,31 +142,31 @@ dfgpu_status dfgpu_groups_intern(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_ar
     ArrayHolder ids(new_fixed(ctx, DFGPU_UINT32, n));
     if (n == 0) { *out_group_ids = ids.release(); return; }
     BufferPtr tmp = alloc_buffer(ctx, (size_t)n * 4);
-    // optimistic table size: grow x16 and redo the batch when more than capacity/2 groups show up
-    uint64_t want = 1ull << 16; while (want < (uint64_t)g->n_groups * 4) want <<= 1;
+    // optimistic table size (at most 2^23 slots up front); a batch that overfills it is redone on a table 8x larger
+    uint64_t guess = (uint64_t)g->n_groups * 4 + 2 * (uint64_t)(n < (1 << 22) ? n : (1 << 22));
+    uint64_t want = 1ull << 16; while (want < guess) want <<= 1;
     if (g->capacity < want) groups_alloc_table(g, want);
     int64_t n_new = 0;
     for (;;) {
-      uint64_t limit = g->capacity / 2 > (uint64_t)g->n_groups ? g->capacity / 2 - (uint64_t)g->n_groups : 0;
+      uint64_t max_steps = g->capacity - 1 < 4096 ? g->capacity - 1 : 4096;
       zero_scratch(ctx);
+      { KernelTimer kt_(ctx, "k_groups_find");
       hipLaunchKernelGGL(k_groups_find, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, bk, stored, has_stored, n, mask ? (const uint64_t*)mask->ptr : nullptr,
                          ctx->force_hash_collisions ? 1 : 0, (uint64_t*)g->slots->ptr, g->capacity - 1, (uint32_t*)g->first_row->ptr, (uint32_t*)tmp->ptr,
-                         (unsigned long long*)ctx->d_scratch64, (unsigned long long)limit);
+                         (unsigned long long*)ctx->d_scratch64, max_steps); }
       KERNEL_CHECK();
-      HIP_CHECK(hipMemcpyAsync(ctx->h_pinned, ctx->d_scratch64, 16, hipMemcpyDeviceToHost, ctx->stream));
-      HIP_CHECK(hipStreamSynchronize(ctx->stream));
-      if (ctx->h_pinned[1] == 0) { n_new = (int64_t)ctx->h_pinned[0]; break; }
+      if (read_scratch(ctx, 1) == 0) break;
       if (g->capacity >= (1ull << 31)) fail(DFGPU_RESOURCES_EXHAUSTED, "group table would exceed 2^31 slots");
-      uint64_t ncap = g->capacity << 4; if (ncap > (1ull << 31)) ncap = 1ull << 31;
+      uint64_t ncap = g->capacity << 3; if (ncap > (1ull << 31)) ncap = 1ull << 31;
       groups_alloc_table(g, ncap);
     }
+    BufferPtr bits = alloc_buffer(ctx, bitmap_bytes(n));
+    hipLaunchKernelGGL(k_groups_mark_first, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)tmp->ptr, (const uint32_t*)g->first_row->ptr, n, (uint64_t*)bits->ptr);
+    KERNEL_CHECK();
+    ArrayHolder firsts(mask_to_indices_impl(ctx, (const uint64_t*)bits->ptr, n));
+    n_new = firsts.get()->length;
     if (g->n_groups + n_new >= (int64_t)G_NEW) fail(DFGPU_RESOURCES_EXHAUSTED, "more than 2^31 groups");
     if (n_new) {
-      BufferPtr bits = alloc_buffer(ctx, bitmap_bytes(n));
-      hipLaunchKernelGGL(k_groups_mark_first, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)tmp->ptr, (const uint32_t*)g->first_row->ptr, n, (uint64_t*)bits->ptr);
-      KERNEL_CHECK();
-      ArrayHolder firsts(mask_to_indices_impl(ctx, (const uint64_t*)bits->ptr, n));
-      if (firsts.get()->length != n_new) fail(DFGPU_INTERNAL, "group interning: %lld first rows for %lld new groups", (long long)firsts.get()->length, (long long)n_new);
       if (g->n_groups + n_new > g->ghash_cap) {
         int64_t nc = g->ghash_cap ? g->ghash_cap : 1024; while (nc < g->n_groups + n_new) nc *= 2;
         BufferPtr nh = alloc_buffer(ctx, (size_t)nc * 8);
@@ -192,6 +195,8 @@ dfgpu_status dfgpu_groups_intern(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_ar
     hipLaunchKernelGGL(k_groups_finalize, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)tmp->ptr, (const uint64_t*)g->slots->ptr, n, (uint32_t*)ids.get()->values->ptr);
     KERNEL_CHECK();
     g->n_groups += n_new;
+    // keep the load factor <= 1/2 for the next batch (rehash of the numbered groups only: no key comparisons)
+    if ((uint64_t)g->n_groups * 2 > g->capacity) { uint64_t ncap = g->capacity; while (ncap < (uint64_t)g->n_groups * 4) ncap <<= 1; if (ncap > (1ull << 31)) ncap = 1ull << 31; groups_alloc_table(g, ncap); }
     *out_group_ids = ids.release();
   });
 }

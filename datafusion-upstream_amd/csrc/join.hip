@@ -40,7 +40,7 @@ __device__ inline bool row_selected(const uint64_t* mask, int64_t i) { return ma
 
 __global__ void __launch_bounds__(BLOCK) k_join_build(KeySet ks, int64_t n, const uint64_t* mask, int null_eq, int force_zero,
                                                       uint64_t* slots, uint32_t* slot_count, uint64_t cap_mask, uint32_t* row_slot,
-                                                      unsigned long long* counters /* [0]=inserted rows, [1]=groups */) {
+                                                      unsigned long long* counters /* [0]=1 when some key repeats */) {
   int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   uint32_t my_slot = NO_SLOT;
@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(BLOCK) k_join_build(KeySet ks, int64_t n, cons
         uint64_t cur = slots[s];
         if (cur == SLOT_EMPTY) {
           cur = atomicCAS((unsigned long long*)&slots[s], (unsigned long long)SLOT_EMPTY, (unsigned long long)mine);
-          if (cur == SLOT_EMPTY) { atomicAdd(&counters[1], 1ull); cur = mine; }
+          if (cur == SLOT_EMPTY) cur = mine;
         }
         if ((cur >> 32) == tag) {
           int64_t rep = (int64_t)(cur & 0xFFFFFFFFull);
@@ -61,7 +61,8 @@ __global__ void __launch_bounds__(BLOCK) k_join_build(KeySet ks, int64_t n, cons
         }
         s = (s + 1) & cap_mask;
       }
-      if (my_slot != NO_SLOT) { atomicAdd(&slot_count[my_slot], 1u); atomicAdd(&counters[0], 1ull); }
+      // no single-address counters here: 1e7 atomics on one word serialise (measured 10 ms per build at SF100)
+      if (my_slot != NO_SLOT && atomicAdd(&slot_count[my_slot], 1u) != 0u) counters[0] = 1ull;
     }
   }
   row_slot[i] = my_slot;
@@ -167,14 +168,11 @@ dfgpu_status dfgpu_join_build(dfgpu_ctx* ctx, const dfgpu_array* const* keys, in
     t->visited = alloc_buffer(ctx, bitmap_bytes(n), true);
     BufferPtr row_slot = alloc_buffer(ctx, (size_t)(n + 1) * 4);
     zero_scratch(ctx);
-    if (n) hipLaunchKernelGGL(k_join_build, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, t->ks, n,
+    if (n) { KernelTimer kt_(ctx, "k_join_build"); hipLaunchKernelGGL(k_join_build, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, t->ks, n,
                               t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr, null_equals_null ? 1 : 0, ctx->force_hash_collisions ? 1 : 0,
-                              (uint64_t*)t->slots->ptr, (uint32_t*)t->slot_count->ptr, cap - 1, (uint32_t*)row_slot->ptr, (unsigned long long*)ctx->d_scratch64);
+                              (uint64_t*)t->slots->ptr, (uint32_t*)t->slot_count->ptr, cap - 1, (uint32_t*)row_slot->ptr, (unsigned long long*)ctx->d_scratch64); }
     KERNEL_CHECK();
-    HIP_CHECK(hipMemcpyAsync(ctx->h_pinned, ctx->d_scratch64, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    t->n_inserted = (int64_t)ctx->h_pinned[0]; t->n_groups = (int64_t)ctx->h_pinned[1];
-    t->unique = t->n_inserted == t->n_groups;
+    t->unique = read_scratch(ctx, 0) == 0;
     t->mem = (int64_t)(cap * 12 + bitmap_bytes(n));
     if (!t->unique) {
       // CSR of build rows per key group: stable radix sort of (slot, row) then exclusive scan of group sizes
@@ -207,20 +205,21 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
     int64_t total = 0;
     BufferPtr match_slot = alloc_buffer(ctx, (size_t)(n + 1) * 4), bcounts = alloc_buffer(ctx, (size_t)(nb + 1) * 4), boffs = alloc_buffer(ctx, (size_t)(nb + 1) * 8);
     if (n) {
+      { KernelTimer kt_(ctx, "k_join_probe_find");
       hipLaunchKernelGGL(k_join_probe_find, dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream, t->ks, pks, n, mask ? (const uint64_t*)mask->ptr : nullptr,
                          t->null_equals_null ? 1 : 0, ctx->force_hash_collisions ? 1 : 0, (const uint64_t*)t->slots->ptr, (const uint32_t*)t->slot_count->ptr,
-                         t->capacity - 1, t->unique ? 1 : 0, (uint32_t*)match_slot->ptr, (uint32_t*)bcounts->ptr);
+                         t->capacity - 1, t->unique ? 1 : 0, (uint32_t*)match_slot->ptr, (uint32_t*)bcounts->ptr); }
       KERNEL_CHECK();
       exclusive_scan_u32(ctx, (const uint32_t*)bcounts->ptr, (uint64_t*)boffs->ptr, nb, ctx->d_scratch64 + 8);
       total = (int64_t)read_scratch(ctx, 8);
     }
     if (total > 0xFFFFFFF0ll) fail(DFGPU_RESOURCES_EXHAUSTED, "join output of %lld rows for one probe batch; split the probe batch", (long long)total);
     ArrayHolder ob(new_fixed(ctx, DFGPU_UINT64, total)), op(new_fixed(ctx, DFGPU_UINT32, total));
-    if (total)
+    if (total) { KernelTimer kt_(ctx, "k_join_probe_fill");
       hipLaunchKernelGGL(k_join_probe_fill, dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream, n, (const uint32_t*)match_slot->ptr, (const uint64_t*)t->slots->ptr,
                          (const uint32_t*)t->slot_count->ptr, t->slot_start ? (const uint32_t*)t->slot_start->ptr : nullptr,
                          t->csr_rows ? (const uint32_t*)t->csr_rows->ptr : nullptr, t->unique ? 1 : 0, (const uint64_t*)boffs->ptr,
-                         (uint64_t*)ob.get()->values->ptr, (uint32_t*)op.get()->values->ptr);
+                         (uint64_t*)ob.get()->values->ptr, (uint32_t*)op.get()->values->ptr); }
     KERNEL_CHECK();
     *out_build_idx = ob.release(); *out_probe_idx = op.release();
   });

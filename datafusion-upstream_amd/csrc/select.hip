@@ -106,6 +106,7 @@ dfgpu_array* take_impl(dfgpu_ctx* ctx, const dfgpu_array* a, const void* idx, in
   } else {
     int w = type_width(vt);
     o->values = alloc_buffer(ctx, (size_t)n * w);
+    KernelTimer kt_(ctx, "k_take_fixed");
     if (n) switch (w) {
 #define TAKE_CASE(W) case W: hipLaunchKernelGGL((k_take_fixed<W>), grid, block, 0, ctx->stream, (const WT<W>::T*)a->values->ptr, sv, a->length, idx, idx_w, idx_valid, n, (WT<W>::T*)o->values->ptr, ov, ctx->d_flags); break;
       TAKE_CASE(1) TAKE_CASE(2) TAKE_CASE(4) TAKE_CASE(8) TAKE_CASE(16)
@@ -153,6 +154,7 @@ dfgpu_array* mask_to_indices_impl(dfgpu_ctx* ctx, const uint64_t* bits, int64_t 
   int64_t nw = (n + 63) / 64, nb = (nw + SEL_WORDS - 1) / SEL_WORDS;
   if (n == 0) return new_fixed(ctx, DFGPU_UINT32, 0);
   BufferPtr counts = alloc_buffer(ctx, (size_t)nb * 4);
+  KernelTimer kt_(ctx, "k_sel_count+scan+write");
   hipLaunchKernelGGL(k_sel_count, dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream, bits, n, (uint32_t*)counts->ptr);
   exclusive_scan_u32_inplace32(ctx, (uint32_t*)counts->ptr, nb, ctx->d_scratch64 + 60);
   int64_t total = (int64_t)read_scratch(ctx, 60);

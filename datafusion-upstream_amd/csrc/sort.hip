@@ -77,6 +77,7 @@ static RadixPlan plan_for(int64_t n) {
 
 template <typename D>
 static void radix_pass(dfgpu_ctx* ctx, D dg, const uint32_t* keys, const uint32_t* vals, uint32_t* out_keys, uint32_t* out_vals, int64_t n, uint32_t* hist, RadixPlan p) {
+  KernelTimer kt_(ctx, "radix_pass");
   hipLaunchKernelGGL((k_rs_hist<D>), dim3(p.nb), dim3(BLOCK), 0, ctx->stream, dg, keys, vals, n, p.chunk, p.nb, hist);
   exclusive_scan_u32_inplace32(ctx, hist, (int64_t)256 * p.nb, nullptr);
   hipLaunchKernelGGL((k_rs_scatter<D>), dim3(p.nb), dim3(BLOCK), 0, ctx->stream, dg, keys, vals, n, p.chunk, p.nb, (const uint32_t*)hist, out_keys, out_vals);

@@ -43,6 +43,19 @@ class Context:
     def set_option(self, key: str, value: int):
         self.check(self.lib.dfgpu_ctx_set_option(self.h, key.encode(), int(value)))
 
+    def profile_enable(self, on: bool = True):
+        self.check(self.lib.dfgpu_profile_enable(self.h, int(on)))
+
+    def profile_read(self) -> dict:
+        """kernel name -> (launches, total_ms) since the last read; HIP events on this ctx's stream."""
+        buf = C.create_string_buffer(1 << 16)
+        self.check(self.lib.dfgpu_profile_read(self.h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.rsplit(" ", 2)
+            out[name] = (int(cnt), float(ms))
+        return out
+
     @property
     def stream(self) -> int:
         return self.lib.dfgpu_ctx_stream(self.h) or 0

@@ -1,0 +1,158 @@
+"""Multi-GPU shuffle: the RepartitionExec exchange as one RCCL all-to-all(v) per column buffer.
+
+The reference moves per-destination RecordBatch slices through in-process channels
+(physical-plan/src/repartition/mod.rs:442-580, :684-760).  With one process per GPU the same slices
+(produced by dfgpu_hash_partition + take) become the send segments of `torch.distributed.all_to_all_single`
+(backend "nccl" == RCCL over xGMI; "gloo" on CPU for the tests).  xGMI is point-to-point, so an all-to-all
+keeps all 7 links of a GPU busy at once; one collective per column buffer keeps messages large.
+
+`exchange_byte_columns` is device agnostic (CPU tensors under gloo -- tests/test_exchange.py runs it with
+world_size 2); `exchange_batches` / `ShuffleExec` adapt device RecordBatches to it.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+
+def all_to_all_counts(send_counts: Sequence[int], group=None) -> List[int]:
+    """Exchange the row-count matrix: returns recv_counts[src] (rows this rank receives from every rank)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    send = torch.tensor(list(send_counts), dtype=torch.int64, device=dev)
+    recv = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv, send, group=group)
+    return [int(x) for x in recv.cpu().tolist()]
+
+
+def all_to_all_buffers(send, send_elems: Sequence[int], recv_elems: Sequence[int], group=None):
+    """all-to-all(v) of one flat buffer: `send` holds the segments for rank 0..N-1 back to back
+    (send_elems[i] elements each); returns the received buffer (segments ordered by source rank)."""
+    import torch
+    import torch.distributed as dist
+    out = torch.empty(int(sum(recv_elems)), dtype=send.dtype, device=send.device)
+    dist.all_to_all_single(out, send.contiguous(), output_split_sizes=[int(x) for x in recv_elems],
+                           input_split_sizes=[int(x) for x in send_elems], group=group)
+    return out
+
+
+def exchange_byte_columns(parts: List[Optional[List]], counts: Sequence[int], widths: Sequence[int], group=None):
+    """parts[dest] = list (one per column) of 1-D uint8 tensors holding counts[dest] rows of widths[c] bytes,
+    or None when nothing goes to `dest`.  Returns (recv_counts, [uint8 tensor per column]) with the received
+    rows ordered by source rank -- row i of every column still belongs to the same logical row."""
+    import torch
+    recv_counts = all_to_all_counts(counts, group)
+    ref = next((p[0] for p in parts if p), None)
+    device = ref.device if ref is not None else ("cuda" if _is_nccl(group) else "cpu")
+    out = []
+    for c, w in enumerate(widths):
+        segs = [p[c] for p, n in zip(parts, counts) if p and n]
+        send = torch.cat(segs) if segs else torch.empty(0, dtype=torch.uint8, device=device)
+        assert send.numel() == sum(counts) * w, "segment sizes do not match the row counts"
+        out.append(all_to_all_buffers(send, [n * w for n in counts], [n * w for n in recv_counts], group))
+    return recv_counts, out
+
+
+def _is_nccl(group) -> bool:
+    import torch.distributed as dist
+    return dist.get_backend(group) == "nccl"
+
+
+class _DevicePtr:
+    """__cuda_array_interface__ view of raw device memory so torch can alias a dfgpu buffer without a copy."""
+
+    def __init__(self, ptr: int, nbytes: int, owner):
+        self.owner = owner
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+# byte width per dfgpu_type for the fixed-width types
+_WIDTH = {2: 1, 6: 1, 3: 2, 7: 2, 4: 4, 8: 4, 10: 4, 12: 4, 5: 8, 9: 8, 11: 8, 13: 16}
+
+
+def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=None):
+    """parts[dest] = the rows of this rank bound for rank `dest` (None/empty allowed; fixed-width, non-null
+    columns -- the TPC-H key/measure columns).  Returns one RecordBatch holding everything this rank
+    received, source ranks in order (≙ the batches a RepartitionExec output partition yields)."""
+    import torch
+    import torch.distributed as dist
+    from . import operators as ops
+    world = dist.get_world_size(group)
+    assert len(parts) == world
+    counts = [0 if p is None else p.num_rows for p in parts]
+    widths = []
+    for f in schema.fields:
+        if f.dtype not in _WIDTH:
+            raise ops.DfgpuError(4, f"exchange of column type {f.dtype} is not supported yet")
+        widths.append(_WIDTH[f.dtype])
+    ctx.synchronize()                      # producers ran on the ctx stream
+    tparts: List[Optional[List]] = []
+    for p, n in zip(parts, counts):
+        if p is None or n == 0:
+            tparts.append(None)
+            continue
+        cols = []
+        for c, col in enumerate(p.columns):
+            d = col.describe()
+            if d.validity:
+                raise ops.DfgpuError(4, "exchange of nullable columns is not supported yet")
+            cols.append(torch.as_tensor(_DevicePtr(d.values, d.length * widths[c], col), device="cuda"))
+        tparts.append(cols)
+    recv_counts, recv = exchange_byte_columns(tparts, counts, widths, group)
+    torch.cuda.current_stream().synchronize()      # consumers run on the ctx stream
+    cols = [ctx.wrap_tensor(t, f.dtype, f.precision, f.scale) for t, f in zip(recv, schema.fields)]
+    return ops.RecordBatch(schema, cols, num_rows=int(sum(recv_counts)))
+
+
+def gather_batches(ctx, schema, batch, dst: int = 0, group=None):
+    """≙ CoalescePartitionsExec / SortPreservingMergeExec input gathering: every rank's batch to rank `dst`."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    parts = [None] * world
+    parts[dst] = batch
+    return exchange_batches(ctx, schema, parts, group)
+
+
+class ShuffleExec:
+    """RepartitionExec(Partitioning::Hash(exprs, world_size)) across GPUs: this rank's input rows are
+    hash-partitioned on device (dfgpu_hash_partition, same create_hashes on every rank), exchanged with one
+    all-to-all per column, and the rows received form output partition `rank`
+    (≙ physical-plan/src/repartition/mod.rs:232-294 with the channels replaced by RCCL over xGMI)."""
+
+    def __init__(self, input, exprs, group=None):
+        import torch.distributed as dist
+        from . import operators as ops
+        self.input, self.exprs, self.group = input, list(exprs), group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self._ops = ops
+        self.bytes_sent = 0
+
+    def schema(self):
+        return self.input.schema()
+
+    def children(self):
+        return [self.input]
+
+    def output_partitioning(self):
+        return self._ops.Partitioning.Hash(self.exprs, 1)      # one local output partition per rank
+
+    def execute(self, partition, context):
+        ops = self._ops
+        parts = [[] for _ in range(self.world)]
+        schema = None
+        for p in range(self.input.output_partitioning().partition_count()):
+            for batch in self.input.execute(p, context):
+                schema = batch.schema
+                for dest, part in ops.partition_batch(batch, self.exprs, self.world):
+                    parts[dest].append(part)
+        if schema is None:
+            schema = self.input.schema()
+        merged = [ops.concat_batches(schema, ps) if ps else None for ps in parts]
+        for d, m in enumerate(merged):
+            if m is not None and d != self.rank:
+                self.bytes_sent += sum(_WIDTH.get(f.dtype, 0) for f in schema.fields) * m.num_rows
+        out = exchange_batches(context.ctx, schema, merged, self.group)
+        if out.num_rows:
+            yield out

@@ -520,10 +520,10 @@ class RepartitionExec(ExecutionPlan):
         rr = 0
         for p in range(self.input.output_partitioning().partition_count()):
             for batch in self.input.execute(p, context):
-                batch = batch.materialize()
-                if batch.num_rows == 0:
-                    continue
                 if self.partitioning.kind == "RoundRobinBatch":
+                    batch = batch.materialize()
+                    if batch.num_rows == 0:
+                        continue
                     outs[rr % n].append(batch)
                     rr += 1
                     continue
@@ -540,15 +540,28 @@ class RepartitionExec(ExecutionPlan):
 
 
 def partition_batch(batch: RecordBatch, exprs: Sequence[PhysicalExpr], n: int) -> List[Tuple[int, RecordBatch]]:
-    """≙ BatchPartitioner::partition_iter (repartition/mod.rs:148-221) for Partitioning::Hash."""
+    """≙ BatchPartitioner::partition_iter (repartition/mod.rs:148-221) for Partitioning::Hash.  A fused selection
+    mask is honoured without compacting the whole batch first: only the key columns are gathered for hashing and
+    every output column is gathered once, straight into its destination slice."""
     ctx = batch.ctx
-    keys = [e.evaluate(batch).into_array(ctx, batch.base_rows) for e in exprs]
+    sel = None
+    kb = batch
+    if batch.selection is not None:
+        sel = ctx.mask_to_indices(batch.selection)
+        needed = sorted(_columns_of(list(exprs)))
+        cols = [ctx.take(c, sel) if i in needed else None for i, c in enumerate(batch.columns)]
+        filler = ctx.new_null(capi.INT8, len(sel))
+        kb = RecordBatch(batch.schema, [c if c is not None else filler for c in cols], num_rows=len(sel))
+    if kb.base_rows == 0:
+        return []
+    keys = [e.evaluate(kb).into_array(ctx, kb.base_rows) for e in exprs]
     indices, counts = ctx.hash_partition(keys, n)
     out, off = [], 0
     for dest, cnt in enumerate(counts):
         if cnt:
             idx = indices.slice(off, cnt)
-            out.append((dest, RecordBatch(batch.schema, [ctx.take(c, idx) for c in batch.columns], num_rows=cnt)))
+            rows = ctx.take(sel, idx) if sel is not None else idx
+            out.append((dest, RecordBatch(batch.schema, [ctx.take(c, rows) for c in batch.columns], num_rows=cnt)))
         off += cnt
     return out
 

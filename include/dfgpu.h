@@ -90,6 +90,11 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
 DFGPU_API dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx *ctx, const char *key, int64_t value);
 DFGPU_API void *dfgpu_ctx_stream(dfgpu_ctx *ctx);
 DFGPU_API const char *dfgpu_version(void);
+/* Per-kernel device time measured with HIP events on the ctx stream (used by bench.py for the roofline
+ * figure; ≙ the BaselineMetrics elapsed_compute timers of physical-plan/src/metrics/baseline.rs:47-56).
+ * dfgpu_profile_read writes lines "kernel_name launches total_ms\n" into buf, then clears the records. */
+DFGPU_API dfgpu_status dfgpu_profile_enable(dfgpu_ctx *ctx, int32_t on);
+DFGPU_API dfgpu_status dfgpu_profile_read(dfgpu_ctx *ctx, char *buf, int64_t capacity);
 
 /* ------------------------------------------------------------------ arrays */
 /* Copy a host column to HBM (PCIe).  ≙ a RecordBatch column entering the GPU operator. */
