@@ -30,8 +30,9 @@ Q3_BYTES_PER_ROW = 39.4         # 30.2 GB algorithmic by
 # algorithmic bytes per row for the kernels that can dominate (DESIGN.md "kernels"): columns that must be read +
 # results that must be written once; hash tables and other intermediates are not counted.
 KERNEL_BYTES_PER_ROW = {
-    "k_join_probe_find": 8 + 0.125 + 4,       # probe key (Int64) + selection bit + matched-slot word
-    "k_join_probe_fill": 4 + 8 + 4,           # matched-slot word + (UInt64 build idx, UInt32 probe idx) per output pair (upper bound per probe row)
+    "k_probe_match_bitmap": 8 + 0.125 + 0.125,   # probe key (Int64) + selection bit + match bit
+    "k_probe_match_hash": 8 + 0.125 + 0.125,
+    "k_compare_scalar_fast": 4 + 0.125,
     "k_join_build": 8 + 0.125 + 4,            # build key + selection bit + row->slot word
     "k_compare": 4 + 0.125,                   # Date32 operand + result bit
     "k_take_fixed": 4 + 8 + 8,                # index + gathered value + written value (8-byte column)
@@ -135,7 +136,9 @@ def main():
         avg_ms = total_ms / launches
         # rows one launch of that kernel processes in this plan (its largest launch dominates the average)
         line_rows = tables["lineitem"].num_rows
-        rows_per_launch = {"k_join_probe_find": (tables["orders"].num_rows + line_rows) / 2, "k_join_probe_fill": (tables["orders"].num_rows + line_rows) / 2,
+        probe_rows = (tables["orders"].num_rows + line_rows) / 2          # two probe launches per step: orders, lineitem
+        rows_per_launch = {"k_probe_match_bitmap": probe_rows, "k_probe_match_hash": probe_rows,
+                           "k_compare_scalar_fast": (tables["orders"].num_rows + line_rows) / 2,
                            "k_compare": (tables["customer"].num_rows + tables["orders"].num_rows + line_rows) / 3}.get(name, None)
         bpr = KERNEL_BYTES_PER_ROW.get(name)
         if bpr is not None and rows_per_launch is not None:

@@ -78,6 +78,27 @@ __global__ void __launch_bounds__(BLOCK) k_compare(int op, Operand l, Operand r,
   if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) { out_bits[i >> 6] = mv; if (out_valid) out_valid[i >> 6] = mo; }
 }
 
+// Fast path of the FilterExec predicates that dominate TPC-H (`l_shipdate > date`, `o_orderdate < date`, `key = c`):
+// non-null fixed-width integer column vs scalar.  4 rows per lane (4 loads in flight), one 64-bit ballot per 64 rows.
+constexpr int CMP_ROWS = 4;
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_compare_scalar_fast(int op, const T* v, T s, int64_t n, uint64_t* out_bits) {
+  int64_t base = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * (WAVE * CMP_ROWS);
+  int lane = lane_id();
+  T x[CMP_ROWS];
+#pragma unroll
+  for (int r = 0; r < CMP_ROWS; r++) { int64_t j = base + r * WAVE + lane; x[r] = j < n ? v[j] : s; }
+#pragma unroll
+  for (int r = 0; r < CMP_ROWS; r++) {
+    int64_t j = base + r * WAVE + lane; bool b;
+    switch (op) { case DFGPU_OP_EQ: b = x[r] == s; break; case DFGPU_OP_NEQ: b = x[r] != s; break; case DFGPU_OP_LT: b = x[r] < s; break;
+      case DFGPU_OP_LTEQ: b = x[r] <= s; break; case DFGPU_OP_GT: b = x[r] > s; break; default: b = x[r] >= s; }
+    uint64_t m = ballot64(b && j < n);
+    if (lane == 0 && base + r * WAVE < n) out_bits[(base >> 6) + r] = m;
+  }
+}
+static int swap_cmp(int op) { switch (op) { case DFGPU_OP_LT: return DFGPU_OP_GT; case DFGPU_OP_LTEQ: return DFGPU_OP_GTEQ; case DFGPU_OP_GT: return DFGPU_OP_LT; case DFGPU_OP_GTEQ: return DFGPU_OP_LTEQ; default: return op; } }
+
 // ---------------------------------------------------------------- Kleene AND / OR on bitmap words
 __global__ void k_kleene(int is_and, const uint64_t* lv, const uint64_t* lok, int lscalar, const uint64_t* rv, const uint64_t* rok, int rscalar,
                          int64_t nw, uint64_t* out, uint64_t* out_ok) {
@@ -268,6 +289,19 @@ dfgpu_status dfgpu_binary(dfgpu_ctx* ctx, int32_t op, const dfgpu_array* l, int3
       if (lt == DFGPU_DECIMAL128 && lo.v.scale != ro.v.scale) fail(DFGPU_INVALID_ARGUMENT, "compare: decimal scales differ; the planner coerces first");
       bool need_valid = nulls && op != DFGPU_OP_DISTINCT && op != DFGPU_OP_NOT_DISTINCT;
       ArrayHolder h(new_fixed(ctx, DFGPU_BOOL, n, 0, 0, need_valid));
+      {   // fast path: non-null fixed-width integer column vs non-null scalar
+        const dfgpu_array* col = rs && !ls ? l : (ls && !rs ? r : nullptr); const dfgpu_array* sc = col == l ? r : l;
+        int fop = col == l ? op : swap_cmp(op);
+        if (col && n && !nulls && op <= DFGPU_OP_GTEQ && col->type != DFGPU_DICTIONARY && sc->type != DFGPU_DICTIONARY && sc->has_host_scalar && sc->host_scalar_valid &&
+            (lt == DFGPU_INT32 || lt == DFGPU_DATE32 || lt == DFGPU_INT64)) {
+          KernelTimer kt_(ctx, "k_compare_scalar_fast");
+          dim3 g(grid_for(n, BLOCK * CMP_ROWS));
+          if (lt == DFGPU_INT64) { int64_t sv; memcpy(&sv, sc->host_scalar, 8); hipLaunchKernelGGL((k_compare_scalar_fast<int64_t>), g, block, 0, ctx->stream, fop, (const int64_t*)col->values->ptr, sv, n, (uint64_t*)h.get()->values->ptr); }
+          else { int32_t sv; memcpy(&sv, sc->host_scalar, 4); hipLaunchKernelGGL((k_compare_scalar_fast<int32_t>), g, block, 0, ctx->stream, fop, (const int32_t*)col->values->ptr, sv, n, (uint64_t*)h.get()->values->ptr); }
+          KERNEL_CHECK();
+          *out = h.release(); return;
+        }
+      }
       KernelTimer kt_(ctx, "k_compare");
       if (n) hipLaunchKernelGGL(k_compare, grid, block, 0, ctx->stream, op, lo, ro, n, (uint64_t*)h.get()->values->ptr, need_valid ? (uint64_t*)h.get()->validity->ptr : nullptr);
       KERNEL_CHECK(); if (need_valid) h.get()->null_count = -1;

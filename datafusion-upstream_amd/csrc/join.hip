@@ -29,7 +29,10 @@ struct dfgpu_join_table {
   BufferPtr csr_rows;     // u32[n_inserted] build rows ordered by (slot, row) (non-unique only)
   BufferPtr build_mask;   // effective opt_mask words or null
   BufferPtr visited;      // u64 words over n_build
-  bool unique = true; int64_t n_inserted = 0, n_groups = 0;
+  bool unique = true;
+  // exact membership bitmap over [key_min, key_min + range) for single integer keys with a dense domain: the probe tests
+  // one bit (L2 / Infinity Cache resident, perfectly local for clustered keys) and touches the hash table for matches only
+  BufferPtr bitmap; int64_t key_min = 0; uint64_t range = 0;
   int64_t mem = 0;
   ~dfgpu_join_table() { for (auto* a : keys) dfgpu_array_release(a); }
 };
@@ -73,12 +76,11 @@ __global__ void __launch_bounds__(BLOCK) k_fix_unslotted(uint32_t* row_slot, int
   if (i < n && row_slot[i] == NO_SLOT) row_slot[i] = sentinel;
 }
 
-// pass A: locate the key group of every probe row; per-workgroup match totals
-__global__ void __launch_bounds__(BLOCK) k_join_probe_find(KeySet bks, KeySet pks, int64_t n, const uint64_t* mask, int null_eq, int force_zero,
-                                                           const uint64_t* slots, const uint32_t* slot_count, uint64_t cap_mask, int unique,
-                                                           uint32_t* match_slot, uint32_t* block_counts) {
+// ---- probe pass 1: one match bit per probe row (order-preserving compaction of the bitmap gives the probe indices)
+__global__ void __launch_bounds__(BLOCK) k_probe_match_hash(KeySet bks, KeySet pks, int64_t n, const uint64_t* mask, int null_eq, int force_zero,
+                                                            const uint64_t* slots, uint64_t cap_mask, uint64_t* match_bits) {
   int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  uint32_t found = NO_SLOT, cnt = 0;
+  bool hit = false;
   if (j < n && row_selected(mask, j)) {
     bool any_null; uint64_t h = keyset_hash(pks, j, 0, &any_null);
     if (force_zero) h = 0;
@@ -87,31 +89,85 @@ __global__ void __launch_bounds__(BLOCK) k_join_probe_find(KeySet bks, KeySet pk
       for (uint64_t step = 0; step <= cap_mask; step++) {
         uint64_t cur = slots[s];
         if (cur == SLOT_EMPTY) break;
-        if ((cur >> 32) == tag && keyset_equal(bks, (int64_t)(cur & 0xFFFFFFFFull), pks, j, null_eq != 0)) { found = (uint32_t)s; break; }
+        if ((cur >> 32) == tag && keyset_equal(bks, (int64_t)(cur & 0xFFFFFFFFull), pks, j, null_eq != 0)) { hit = true; break; }
         s = (s + 1) & cap_mask;
       }
-      if (found != NO_SLOT) cnt = unique ? 1u : slot_count[found];
     }
   }
-  if (j < n) match_slot[j] = found;
-  __shared__ uint32_t lds[4];
-  uint32_t tot; (void)block_exclusive_sum<uint32_t>(cnt, lds, &tot);
-  if (threadIdx.x == 0) block_counts[blockIdx.x] = tot;
+  uint64_t m = ballot64(hit);
+  if (lane_id() == 0 && (j >> 6) < ((n + 63) >> 6)) match_bits[j >> 6] = m;
 }
-// pass B: emit (build row, probe row) pairs at scanned offsets; order = probe row, then build row ascending
-__global__ void __launch_bounds__(BLOCK) k_join_probe_fill(int64_t n, const uint32_t* match_slot, const uint64_t* slots, const uint32_t* slot_count,
-                                                           const uint32_t* slot_start, const uint32_t* csr_rows, int unique,
-                                                           const uint64_t* block_offsets, uint64_t* out_build, uint32_t* out_probe) {
-  int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  uint32_t s = j < n ? match_slot[j] : NO_SLOT;
-  uint32_t cnt = s == NO_SLOT ? 0u : (unique ? 1u : slot_count[s]);
-  __shared__ uint32_t lds[4];
-  uint32_t tot; uint32_t ex = block_exclusive_sum<uint32_t>(cnt, lds, &tot);
-  if (!cnt) return;
-  uint64_t o = block_offsets[blockIdx.x] + ex;
-  if (unique) { out_build[o] = slots[s] & 0xFFFFFFFFull; out_probe[o] = (uint32_t)j; }
-  else { uint32_t st = slot_start[s]; for (uint32_t k = 0; k < cnt; k++) { out_build[o + k] = csr_rows[st + k]; out_probe[o + k] = (uint32_t)j; } }
+// dense integer key domain: stream the probe keys, test one bit each.  4 rows per lane, 4 loads in flight.
+constexpr int PM_ROWS = 4;
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_probe_match_bitmap(const T* keys, const uint64_t* key_valid, const uint64_t* mask, int64_t n, int64_t kmin, uint64_t range,
+                                                              const uint64_t* bitmap, uint64_t* match_bits) {
+  int64_t base = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * (WAVE * PM_ROWS);
+  int lane = lane_id();
+  T k[PM_ROWS]; bool sel[PM_ROWS];
+#pragma unroll
+  for (int r = 0; r < PM_ROWS; r++) { int64_t j = base + r * WAVE + lane; sel[r] = j < n; k[r] = sel[r] ? keys[j] : (T)0; }
+#pragma unroll
+  for (int r = 0; r < PM_ROWS; r++) {
+    int64_t j = base + r * WAVE + lane;
+    bool hit = false;
+    if (sel[r] && row_selected(mask, j) && valid_at(key_valid, j)) { uint64_t d = (uint64_t)((int64_t)k[r] - kmin); hit = d < range && bit_get(bitmap, (int64_t)d); }
+    uint64_t m = ballot64(hit);
+    if (lane == 0 && base + r * WAVE < n) match_bits[(base >> 6) + r] = m;
+  }
 }
+// ---- probe pass 2: the matched probe rows (ascending) look their key group up; unique builds emit the build row directly
+__global__ void __launch_bounds__(BLOCK) k_probe_lookup(KeySet bks, KeySet pks, const uint32_t* rows, int64_t m, int null_eq, int force_zero,
+                                                        const uint64_t* slots, const uint32_t* slot_count, uint64_t cap_mask, int unique,
+                                                        uint64_t* out_build, uint32_t* out_slot, uint32_t* out_cnt, uint32_t* flags) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= m) return;
+  int64_t j = rows[i];
+  bool any_null; uint64_t h = keyset_hash(pks, j, 0, &any_null);
+  if (force_zero) h = 0;
+  uint64_t tag = h >> 32, s = h & cap_mask; bool found = false;
+  for (uint64_t step = 0; step <= cap_mask; step++) {
+    uint64_t cur = slots[s];
+    if (cur == SLOT_EMPTY) break;
+    if ((cur >> 32) == tag && keyset_equal(bks, (int64_t)(cur & 0xFFFFFFFFull), pks, j, null_eq != 0)) { found = true; break; }
+    s = (s + 1) & cap_mask;
+  }
+  if (!found) { atomicOr(flags, DFGPU_FLAG_TABLE_FULL); s = 0; }       // cannot happen: pass 1 is exact
+  if (unique) out_build[i] = found ? (slots[s] & 0xFFFFFFFFull) : 0;
+  else { out_slot[i] = (uint32_t)s; out_cnt[i] = found ? slot_count[s] : 0; }
+}
+// ---- probe pass 3 (repeated build keys): every matched probe row emits its key group in build input order
+__global__ void __launch_bounds__(BLOCK) k_probe_expand(const uint32_t* rows, const uint32_t* slot_of, const uint32_t* cnt, const uint64_t* offsets, int64_t m,
+                                                        const uint32_t* slot_start, const uint32_t* csr_rows, uint64_t* out_build, uint32_t* out_probe) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= m) return;
+  uint32_t c = cnt[i], st = slot_start[slot_of[i]], j = rows[i]; uint64_t o = offsets[i];
+  for (uint32_t k = 0; k < c; k++) { out_build[o + k] = csr_rows[st + k]; out_probe[o + k] = j; }
+}
+// ---- membership bitmap of the build keys
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_key_minmax(const T* keys, const uint32_t* row_slot, int64_t n, long long* mn, long long* mx) {
+  long long lo = INT64_MAX, hi = INT64_MIN;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
+    if (row_slot[i] != NO_SLOT) { long long v = (long long)keys[i]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { long long a = __shfl_xor(lo, d, 64), b = __shfl_xor(hi, d, 64); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+  if (lane_id() == 0 && lo <= hi) { atomicMin(mn, lo); atomicMax(mx, hi); }
+}
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_key_setbits(const T* keys, const uint32_t* row_slot, int64_t n, int64_t kmin, uint64_t* bitmap) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n || row_slot[i] == NO_SLOT) return;
+  uint64_t d = (uint64_t)((int64_t)keys[i] - kmin);
+  atomicOr((unsigned long long*)&bitmap[d >> 6], 1ull << (d & 63));
+}
+#define DFGPU_INT_KEY_DISPATCH(TYPE, CALL)                                                                      \
+  switch (TYPE) {                                                                                               \
+    case DFGPU_INT8: { using T = int8_t; CALL; break; } case DFGPU_INT16: { using T = int16_t; CALL; break; }   \
+    case DFGPU_INT32: case DFGPU_DATE32: { using T = int32_t; CALL; break; } case DFGPU_INT64: { using T = int64_t; CALL; break; } \
+    case DFGPU_UINT8: { using T = uint8_t; CALL; break; } case DFGPU_UINT16: { using T = uint16_t; CALL; break; } \
+    case DFGPU_UINT32: { using T = uint32_t; CALL; break; } default: break; }
+static bool int_key_type(int32_t t) { return t == DFGPU_INT8 || t == DFGPU_INT16 || t == DFGPU_INT32 || t == DFGPU_INT64 || t == DFGPU_DATE32 || t == DFGPU_UINT8 || t == DFGPU_UINT16 || t == DFGPU_UINT32; }
 
 __global__ void k_mark_bits_u64idx(const uint64_t* idx, const uint64_t* idx_valid, int64_t n, uint64_t* bits, int64_t nbits, uint32_t* flags) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -174,6 +230,27 @@ dfgpu_status dfgpu_join_build(dfgpu_ctx* ctx, const dfgpu_array* const* keys, in
     KERNEL_CHECK();
     t->unique = read_scratch(ctx, 0) == 0;
     t->mem = (int64_t)(cap * 12 + bitmap_bytes(n));
+    if (n && nkeys == 1 && !null_equals_null && keys[0]->type != DFGPU_DICTIONARY && int_key_type(keys[0]->type)) {
+      KernelTimer kt_(ctx, "join_build_bitmap");
+      long long init[2] = { INT64_MAX, INT64_MIN };
+      HIP_CHECK(hipMemcpyAsync(ctx->d_scratch64 + 4, init, 16, hipMemcpyHostToDevice, ctx->stream));
+      const void* kv = keys[0]->values->ptr; const uint32_t* rs = (const uint32_t*)row_slot->ptr;
+      DFGPU_INT_KEY_DISPATCH(keys[0]->type, hipLaunchKernelGGL((k_key_minmax<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 8)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, rs, n,
+                                                               (long long*)(ctx->d_scratch64 + 4), (long long*)(ctx->d_scratch64 + 5)));
+      KERNEL_CHECK();
+      HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 4, ctx->d_scratch64 + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      long long lo = (long long)ctx->h_pinned[4], hi = (long long)ctx->h_pinned[5];
+      if (lo <= hi) {
+        uint64_t range = (uint64_t)hi - (uint64_t)lo + 1;
+        if (range != 0 && range <= (1ull << 32) && range <= (uint64_t)n * 4096 + 65536) {      // <= 512 MB and not absurdly sparse
+          t->bitmap = alloc_buffer(ctx, bitmap_bytes((int64_t)range), true); t->key_min = lo; t->range = range;
+          DFGPU_INT_KEY_DISPATCH(keys[0]->type, hipLaunchKernelGGL((k_key_setbits<T>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, rs, n, (int64_t)lo, (uint64_t*)t->bitmap->ptr));
+          KERNEL_CHECK();
+          t->mem += (int64_t)bitmap_bytes((int64_t)range);
+        }
+      }
+    }
     if (!t->unique) {
       // CSR of build rows per key group: stable radix sort of (slot, row) then exclusive scan of group sizes
       hipLaunchKernelGGL(k_fix_unslotted, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (uint32_t*)row_slot->ptr, n, (uint32_t)cap);
@@ -201,26 +278,56 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
     KeySet pks = make_keyset(probe_keys, nkeys);
     int64_t n = probe_keys[0]->length;
     BufferPtr mask = effective_mask(ctx, opt_mask, n);
-    int64_t nb = (n + BLOCK - 1) / BLOCK;
-    int64_t total = 0;
-    BufferPtr match_slot = alloc_buffer(ctx, (size_t)(n + 1) * 4), bcounts = alloc_buffer(ctx, (size_t)(nb + 1) * 4), boffs = alloc_buffer(ctx, (size_t)(nb + 1) * 8);
+    int64_t nw = (n + 63) / 64;
+    const uint64_t* mk = mask ? (const uint64_t*)mask->ptr : nullptr;
+    int nen = t->null_equals_null ? 1 : 0, fz = ctx->force_hash_collisions ? 1 : 0;
+    // pass 1: match bit per probe row
+    BufferPtr match_bits = alloc_buffer(ctx, bitmap_bytes(n), n == 0);
     if (n) {
-      { KernelTimer kt_(ctx, "k_join_probe_find");
-      hipLaunchKernelGGL(k_join_probe_find, dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream, t->ks, pks, n, mask ? (const uint64_t*)mask->ptr : nullptr,
-                         t->null_equals_null ? 1 : 0, ctx->force_hash_collisions ? 1 : 0, (const uint64_t*)t->slots->ptr, (const uint32_t*)t->slot_count->ptr,
-                         t->capacity - 1, t->unique ? 1 : 0, (uint32_t*)match_slot->ptr, (uint32_t*)bcounts->ptr); }
+      const dfgpu_array* pk = probe_keys[0];
+      bool use_bitmap = t->bitmap && pk->type == t->keys[0]->type;      // same physical integer type, no dictionary
+      if (use_bitmap) {
+        KernelTimer kt_(ctx, "k_probe_match_bitmap");
+        int64_t rows_per_block = (int64_t)BLOCK * PM_ROWS;
+        DFGPU_INT_KEY_DISPATCH(pk->type, hipLaunchKernelGGL((k_probe_match_bitmap<T>), dim3(grid_for(n, (int)rows_per_block)), dim3(BLOCK), 0, ctx->stream, (const T*)pk->values->ptr,
+                                                            pk->validity ? (const uint64_t*)pk->validity->ptr : nullptr, mk, n, t->key_min, t->range, (const uint64_t*)t->bitmap->ptr, (uint64_t*)match_bits->ptr));
+      } else {
+        KernelTimer kt_(ctx, "k_probe_match_hash");
+        hipLaunchKernelGGL(k_probe_match_hash, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, t->ks, pks, n, mk, nen, fz, (const uint64_t*)t->slots->ptr, t->capacity - 1, (uint64_t*)match_bits->ptr);
+      }
       KERNEL_CHECK();
-      exclusive_scan_u32(ctx, (const uint32_t*)bcounts->ptr, (uint64_t*)boffs->ptr, nb, ctx->d_scratch64 + 8);
-      total = (int64_t)read_scratch(ctx, 8);
     }
-    if (total > 0xFFFFFFF0ll) fail(DFGPU_RESOURCES_EXHAUSTED, "join output of %lld rows for one probe batch; split the probe batch", (long long)total);
-    ArrayHolder ob(new_fixed(ctx, DFGPU_UINT64, total)), op(new_fixed(ctx, DFGPU_UINT32, total));
-    if (total) { KernelTimer kt_(ctx, "k_join_probe_fill");
-      hipLaunchKernelGGL(k_join_probe_fill, dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream, n, (const uint32_t*)match_slot->ptr, (const uint64_t*)t->slots->ptr,
-                         (const uint32_t*)t->slot_count->ptr, t->slot_start ? (const uint32_t*)t->slot_start->ptr : nullptr,
-                         t->csr_rows ? (const uint32_t*)t->csr_rows->ptr : nullptr, t->unique ? 1 : 0, (const uint64_t*)boffs->ptr,
-                         (uint64_t*)ob.get()->values->ptr, (uint32_t*)op.get()->values->ptr); }
-    KERNEL_CHECK();
+    (void)nw;
+    ArrayHolder rows(mask_to_indices_impl(ctx, (const uint64_t*)match_bits->ptr, n));      // matched probe rows, ascending
+    int64_t m = rows.get()->length;
+    const uint32_t* rp = (const uint32_t*)rows.get()->values->ptr;
+    ArrayHolder ob, op;
+    if (t->unique) {
+      ob.a = new_fixed(ctx, DFGPU_UINT64, m);
+      if (m) { KernelTimer kt_(ctx, "k_probe_lookup");
+        hipLaunchKernelGGL(k_probe_lookup, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, t->ks, pks, rp, m, nen, fz, (const uint64_t*)t->slots->ptr, (const uint32_t*)t->slot_count->ptr,
+                           t->capacity - 1, 1, (uint64_t*)ob.get()->values->ptr, (uint32_t*)nullptr, (uint32_t*)nullptr, ctx->d_flags); }
+      KERNEL_CHECK();
+      op.a = rows.release();
+    } else {
+      BufferPtr slot_of = alloc_buffer(ctx, (size_t)(m + 1) * 4), cnt = alloc_buffer(ctx, (size_t)(m + 1) * 4), offs = alloc_buffer(ctx, (size_t)(m + 1) * 8);
+      int64_t total = 0;
+      if (m) {
+        { KernelTimer kt_(ctx, "k_probe_lookup");
+        hipLaunchKernelGGL(k_probe_lookup, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, t->ks, pks, rp, m, nen, fz, (const uint64_t*)t->slots->ptr, (const uint32_t*)t->slot_count->ptr,
+                           t->capacity - 1, 0, (uint64_t*)nullptr, (uint32_t*)slot_of->ptr, (uint32_t*)cnt->ptr, ctx->d_flags); }
+        KERNEL_CHECK();
+        exclusive_scan_u32(ctx, (const uint32_t*)cnt->ptr, (uint64_t*)offs->ptr, m, ctx->d_scratch64 + 8);
+        total = (int64_t)read_scratch(ctx, 8);
+      }
+      if (total > 0xFFFFFFF0ll) fail(DFGPU_RESOURCES_EXHAUSTED, "join output of %lld rows for one probe batch; split the probe batch", (long long)total);
+      ob.a = new_fixed(ctx, DFGPU_UINT64, total); op.a = new_fixed(ctx, DFGPU_UINT32, total);
+      if (total) { KernelTimer kt_(ctx, "k_probe_expand");
+        hipLaunchKernelGGL(k_probe_expand, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, rp, (const uint32_t*)slot_of->ptr, (const uint32_t*)cnt->ptr, (const uint64_t*)offs->ptr, m,
+                           (const uint32_t*)t->slot_start->ptr, (const uint32_t*)t->csr_rows->ptr, (uint64_t*)ob.get()->values->ptr, (uint32_t*)op.get()->values->ptr); }
+      KERNEL_CHECK();
+    }
+    check_flags(ctx, "join_probe");
     *out_build_idx = ob.release(); *out_probe_idx = op.release();
   });
 }
