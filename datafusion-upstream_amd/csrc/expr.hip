@@ -3,7 +3,9 @@
 //  cast.rs:121 with CastOptions{safe:false}; not.rs:71; is_null.rs:74; negative.rs:79; in_list.rs:349).
 // One lane per row, coalesced loads; a scalar Datum operand is a length-1 column read at index 0 (one
 // broadcast transaction per wave).  Boolean results are bit-packed with one 64-lane ballot per wave.
-// Semantics restated from arrow-arith/arrow-ord/arrow-cast 50.0.0 exactly as oracle/dfo_expr.c documents.
+// Semantics of arrow-arith / arrow-ord / arrow-cast 50.0.0 (third-party, pinned in datafusion-cli/Cargo.lock): integer
+// add/sub/mul wrap, div/rem are checked; Decimal128 result (precision, scale) rules and checked i128 payloads as listed in
+// DESIGN.md section 4; floats compare by IEEE totalOrder; NULL op x = NULL except IS [NOT] DISTINCT FROM.
 #include "int128.h"
 
 namespace dfgpu {

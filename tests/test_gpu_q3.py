@@ -50,3 +50,32 @@ def test_q3_oracle_partition_count_invariance():
         other = canon(po.tpch_q3(host, 1, tpch.Q3_DATE, p, batch_size=100))
         for k in base:
             assert np.array_equal(base[k], other[k])
+
+
+@gpu
+def test_q3_distributed_plan_world1_rccl_matches_single(ctx):
+    """The multi-GPU plan (ShuffleExec = device hash partition + RCCL all-to-all per column, Partial -> FinalPartitioned)
+    run with world_size 1 on the real nccl(RCCL) backend must equal the single-partition plan row for row."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from dfgpu import exchange, operators as ops, tpch
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        host = tpch.gen_host(0.05)
+        tables = tpch.upload(ctx, host)
+        tc = ops.TaskContext(ctx, batch_size=1 << 30)
+        single = tpch.q3_result_to_numpy(ops.collect(tpch.q3_plan(tables), tc))
+        plan = tpch.q3_distributed_plan(tables)
+        local = list(plan.execute(0, tc))
+        gathered = exchange.gather_batches(ctx, local[0].schema, ops.concat_batches(local[0].schema, local), 0)
+        multi = tpch.q3_result_to_numpy([gathered])
+        g, w = canon(multi), canon(single)
+        assert len(g["l_orderkey"]) == len(w["l_orderkey"]) > 0
+        for k in w:
+            assert np.array_equal(g[k], w[k]), k
+    finally:
+        dist.destroy_process_group()
