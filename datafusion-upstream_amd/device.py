@@ -100,6 +100,14 @@ class Context:
         d.values = tensor.data_ptr()
         return self.wrap_device(d, keepalive=tensor)
 
+    def wrap_tensor_bool(self, tensor, length: int) -> "Array":
+        """Zero-copy view of a uint8 CUDA tensor holding `length` bits (LSB first, padded to 8 bytes) as a Boolean column."""
+        d = capi.ArrayDesc()
+        assert tensor.is_contiguous() and tensor.numel() * tensor.element_size() >= ((length + 63) // 64) * 8
+        d.type, d.length, d.null_count = capi.BOOL, length, 0
+        d.values = tensor.data_ptr()
+        return self.wrap_device(d, keepalive=tensor)
+
     def concat(self, arrays: Sequence["Array"]) -> "Array":
         hs, n = capi.handle_array([a.h.value for a in arrays])
         out = C.c_void_p()

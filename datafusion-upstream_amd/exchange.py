@@ -72,12 +72,14 @@ _WIDTH = {2: 1, 6: 1, 3: 2, 7: 2, 4: 4, 8: 4, 10: 4, 12: 4, 5: 8, 9: 8, 11: 8, 1
 
 
 def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=None):
-    """parts[dest] = the rows of this rank bound for rank `dest` (None/empty allowed; fixed-width, non-null
-    columns -- the TPC-H key/measure columns).  Returns one RecordBatch holding everything this rank
-    received, source ranks in order (≙ the batches a RepartitionExec output partition yields)."""
+    """parts[dest] = the rows of this rank bound for rank `dest` (None/empty allowed; fixed-width columns, nullable
+    or not).  Returns one RecordBatch holding everything this rank received, source ranks in order (≙ the batches a
+    RepartitionExec output partition yields).  Values travel as one all-to-all per column; a column that carries a
+    validity bitmap on ANY rank (agreed with one all-reduce so every rank issues the same collectives) also sends
+    its bitmap words per destination, and the receiver splices the per-source bitmaps at bit granularity."""
     import torch
     import torch.distributed as dist
-    from . import operators as ops
+    from . import capi, operators as ops
     world = dist.get_world_size(group)
     assert len(parts) == world
     counts = [0 if p is None else p.num_rows for p in parts]
@@ -86,23 +88,64 @@ def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=No
         if f.dtype not in _WIDTH:
             raise ops.DfgpuError(4, f"exchange of column type {f.dtype} is not supported yet")
         widths.append(_WIDTH[f.dtype])
+    ncols = len(widths)
+    has_valid = torch.zeros(ncols, dtype=torch.int32, device="cuda")
+    for p, n in zip(parts, counts):
+        if p is not None and n:
+            for c, col in enumerate(p.columns):
+                if col.describe().validity:
+                    has_valid[c] = 1
+    if world > 1:
+        dist.all_reduce(has_valid, op=dist.ReduceOp.MAX, group=group)
+    nullable = [bool(x) for x in has_valid.cpu().tolist()]
     ctx.synchronize()                      # producers ran on the ctx stream
     tparts: List[Optional[List]] = []
+    vparts: List[Optional[List]] = []      # validity words of the nullable columns
+    keep = []
     for p, n in zip(parts, counts):
         if p is None or n == 0:
             tparts.append(None)
+            vparts.append(None)
             continue
-        cols = []
+        cols, vcols = [], []
         for c, col in enumerate(p.columns):
             d = col.describe()
-            if d.validity:
-                raise ops.DfgpuError(4, "exchange of nullable columns is not supported yet")
             cols.append(torch.as_tensor(_DevicePtr(d.values, d.length * widths[c], col), device="cuda"))
+            if nullable[c]:
+                bm = ctx.is_null(col, negate=True)           # validity as a Boolean column (all ones when there is no bitmap)
+                keep.append(bm)
+                vcols.append(torch.as_tensor(_DevicePtr(bm.describe().values, ((n + 63) // 64) * 8, bm), device="cuda"))
         tparts.append(cols)
+        vparts.append(vcols)
+    ctx.synchronize()
     recv_counts, recv = exchange_byte_columns(tparts, counts, widths, group)
+    total = int(sum(recv_counts))
+    out_cols = []
+    vi = 0
+    for c, f in enumerate(schema.fields):
+        if not nullable[c]:
+            out_cols.append(ctx.wrap_tensor(recv[c], f.dtype, f.precision, f.scale))
+            continue
+        segs = [vp[vi] for vp, n in zip(vparts, counts) if vp is not None and n]
+        send = torch.cat(segs) if segs else torch.empty(0, dtype=torch.uint8, device="cuda")
+        vrecv = all_to_all_buffers(send, [((n + 63) // 64) * 8 for n in counts], [((n + 63) // 64) * 8 for n in recv_counts], group)
+        torch.cuda.current_stream().synchronize()
+        pieces, off = [], 0
+        for n in recv_counts:
+            nb = ((n + 63) // 64) * 8
+            if n:
+                pieces.append(ctx.wrap_tensor_bool(vrecv[off:off + nb], n))
+            off += nb
+        validity = ctx.concat(pieces) if len(pieces) > 1 else (pieces[0] if pieces else None)
+        d = capi.ArrayDesc()
+        d.type, d.precision, d.scale, d.length, d.null_count = f.dtype, f.precision, f.scale, total, -1
+        d.values = recv[c].data_ptr() if total else 0
+        if validity is not None:
+            d.validity = validity.describe().values
+        out_cols.append(ctx.wrap_device(d, keepalive=(recv[c], validity, vrecv)) if total else ctx.wrap_tensor(recv[c], f.dtype, f.precision, f.scale))
+        vi += 1
     torch.cuda.current_stream().synchronize()      # consumers run on the ctx stream
-    cols = [ctx.wrap_tensor(t, f.dtype, f.precision, f.scale) for t, f in zip(recv, schema.fields)]
-    return ops.RecordBatch(schema, cols, num_rows=int(sum(recv_counts)))
+    return ops.RecordBatch(schema, out_cols, num_rows=total)
 
 
 def gather_batches(ctx, schema, batch, dst: int = 0, group=None):
