@@ -85,8 +85,9 @@ __global__ void __launch_bounds__(BLOCK) k_compare(int op, Operand l, Operand r,
 constexpr int CMP_ROWS = 4;
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_compare_scalar_fast(int op, const T* v, T s, int64_t n, uint64_t* out_bits) {
-  int64_t base = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * (WAVE * CMP_ROWS);
   int lane = lane_id();
+  for (int64_t base = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * (WAVE * CMP_ROWS); base < n;
+       base += (int64_t)gridDim.x * (BLOCK / WAVE) * (WAVE * CMP_ROWS)) {      // persistent grid-stride loop
   T x[CMP_ROWS];
 #pragma unroll
   for (int r = 0; r < CMP_ROWS; r++) { int64_t j = base + r * WAVE + lane; x[r] = j < n ? v[j] : s; }
@@ -97,6 +98,7 @@ __global__ void __launch_bounds__(BLOCK) k_compare_scalar_fast(int op, const T* 
       case DFGPU_OP_LTEQ: b = x[r] <= s; break; case DFGPU_OP_GT: b = x[r] > s; break; default: b = x[r] >= s; }
     uint64_t m = ballot64(b && j < n);
     if (lane == 0 && base + r * WAVE < n) out_bits[(base >> 6) + r] = m;
+  }
   }
 }
 static int swap_cmp(int op) { switch (op) { case DFGPU_OP_LT: return DFGPU_OP_GT; case DFGPU_OP_LTEQ: return DFGPU_OP_GTEQ; case DFGPU_OP_GT: return DFGPU_OP_LT; case DFGPU_OP_GTEQ: return DFGPU_OP_LTEQ; default: return op; } }
@@ -297,7 +299,7 @@ dfgpu_status dfgpu_binary(dfgpu_ctx* ctx, int32_t op, const dfgpu_array* l, int3
         if (col && n && !nulls && op <= DFGPU_OP_GTEQ && col->type != DFGPU_DICTIONARY && sc->type != DFGPU_DICTIONARY && sc->has_host_scalar && sc->host_scalar_valid &&
             (lt == DFGPU_INT32 || lt == DFGPU_DATE32 || lt == DFGPU_INT64)) {
           KernelTimer kt_(ctx, "k_compare_scalar_fast");
-          dim3 g(grid_for(n, BLOCK * CMP_ROWS));
+          dim3 g(grid_for(n, BLOCK * CMP_ROWS, ctx->num_cus * 8));
           if (lt == DFGPU_INT64) { int64_t sv; memcpy(&sv, sc->host_scalar, 8); hipLaunchKernelGGL((k_compare_scalar_fast<int64_t>), g, block, 0, ctx->stream, fop, (const int64_t*)col->values->ptr, sv, n, (uint64_t*)h.get()->values->ptr); }
           else { int32_t sv; memcpy(&sv, sc->host_scalar, 4); hipLaunchKernelGGL((k_compare_scalar_fast<int32_t>), g, block, 0, ctx->stream, fop, (const int32_t*)col->values->ptr, sv, n, (uint64_t*)h.get()->values->ptr); }
           KERNEL_CHECK();

@@ -60,17 +60,21 @@ __global__ void __launch_bounds__(BLOCK) k_join_build(KeySet ks, int64_t n, cons
         }
         if ((cur >> 32) == tag) {
           int64_t rep = (int64_t)(cur & 0xFFFFFFFFull);
-          if (rep == i || keyset_equal(ks, i, ks, rep, true)) { my_slot = (uint32_t)s; break; }
+          if (rep == i || keyset_equal(ks, i, ks, rep, true)) { my_slot = (uint32_t)s; if (rep != i) counters[0] = 1ull; break; }   // joined another row's group: key repeats
         }
         s = (s + 1) & cap_mask;
       }
       // no single-address counters here: 1e7 atomics on one word serialise (measured 10 ms per build at SF100)
-      if (my_slot != NO_SLOT && atomicAdd(&slot_count[my_slot], 1u) != 0u) counters[0] = 1ull;
+      // no per-row counters: group sizes are only counted (k_count_slots) when some key repeats (flag above)
     }
   }
   row_slot[i] = my_slot;
 }
 
+__global__ void __launch_bounds__(BLOCK) k_count_slots(const uint32_t* row_slot, int64_t n, uint32_t* slot_count) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n && row_slot[i] != NO_SLOT) atomicAdd(&slot_count[row_slot[i]], 1u);
+}
 __global__ void __launch_bounds__(BLOCK) k_fix_unslotted(uint32_t* row_slot, int64_t n, uint32_t sentinel) {
   int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i < n && row_slot[i] == NO_SLOT) row_slot[i] = sentinel;
@@ -98,22 +102,49 @@ __global__ void __launch_bounds__(BLOCK) k_probe_match_hash(KeySet bks, KeySet p
   if (lane_id() == 0 && (j >> 6) < ((n + 63) >> 6)) match_bits[j >> 6] = m;
 }
 // dense integer key domain: stream the probe keys, test one bit each.  4 rows per lane, 4 loads in flight.
-constexpr int PM_ROWS = 4;
+constexpr int PM_ROWS = 8;          // rows per lane: 4 iterations x 2 consecutive keys (one 16-B load for Int64 keys)
+__device__ inline uint64_t spread32(uint64_t x) {      // bit i -> bit 2i
+  x &= 0xFFFFFFFFull;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull; x = (x | (x << 8)) & 0x00FF00FF00FF00FFull; x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull; x = (x | (x << 1)) & 0x5555555555555555ull; return x;
+}
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_probe_match_bitmap(const T* keys, const uint64_t* key_valid, const uint64_t* mask, int64_t n, int64_t kmin, uint64_t range,
                                                               const uint64_t* bitmap, uint64_t* match_bits) {
-  int64_t base = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * (WAVE * PM_ROWS);
   int lane = lane_id();
-  T k[PM_ROWS]; bool sel[PM_ROWS];
+  // one 512-row chunk per wave when launched 1:1 (measured faster than a persistent grid: consecutive workgroups keep
+  // the key stream and the bitmap window local); the loop only matters if a caller caps the grid
+  for (int64_t base = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * (WAVE * PM_ROWS); base < n;
+       base += (int64_t)gridDim.x * (BLOCK / WAVE) * (WAVE * PM_ROWS)) {
+  T k[PM_ROWS / 2][2];
 #pragma unroll
-  for (int r = 0; r < PM_ROWS; r++) { int64_t j = base + r * WAVE + lane; sel[r] = j < n; k[r] = sel[r] ? keys[j] : (T)0; }
+  for (int r = 0; r < PM_ROWS / 2; r++) {                      // lane l owns rows base + 128 r + 2l, +1
+    int64_t j = base + r * 2 * WAVE + 2 * lane;
+    if (j + 1 < n) { struct alignas(2 * sizeof(T)) P { T a, b; }; P p = *(const P*)(keys + j); k[r][0] = p.a; k[r][1] = p.b; }
+    else { k[r][0] = j < n ? keys[j] : (T)0; k[r][1] = 0; }
+  }
+  // phase 2: all selection words, then all bitmap words (independent loads in flight together), then the ballots
+  uint64_t mw[PM_ROWS / 2];
 #pragma unroll
-  for (int r = 0; r < PM_ROWS; r++) {
-    int64_t j = base + r * WAVE + lane;
-    bool hit = false;
-    if (sel[r] && row_selected(mask, j) && valid_at(key_valid, j)) { uint64_t d = (uint64_t)((int64_t)k[r] - kmin); hit = d < range && bit_get(bitmap, (int64_t)d); }
-    uint64_t m = ballot64(hit);
-    if (lane == 0 && base + r * WAVE < n) match_bits[(base >> 6) + r] = m;
+  for (int r = 0; r < PM_ROWS / 2; r++) { int64_t j = base + r * 2 * WAVE + 2 * lane; mw[r] = (mask && j < n) ? mask[j >> 6] >> (j & 63) : 3ull; }
+  uint64_t bw[PM_ROWS / 2][2];
+#pragma unroll
+  for (int r = 0; r < PM_ROWS / 2; r++) {
+    int64_t j = base + r * 2 * WAVE + 2 * lane;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      uint64_t d = (uint64_t)((int64_t)k[r][e] - kmin);
+      bool go = j + e < n && ((mw[r] >> e) & 1) && valid_at(key_valid, j + e) && d < range;
+      bw[r][e] = go ? (bitmap[d >> 6] >> (d & 63)) & 1ull : 0ull;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < PM_ROWS / 2; r++) {
+    uint64_t be = ballot64(bw[r][0] != 0), bo = ballot64(bw[r][1] != 0);   // wave-uniform: the interleave below runs on the scalar unit
+    uint64_t w0 = spread32(be) | (spread32(bo) << 1), w1 = spread32(be >> 32) | (spread32(bo >> 32) << 1);
+    int64_t wbase = (base >> 6) + 2 * r;
+    if (lane == 0) { if (base + r * 2 * WAVE < n) match_bits[wbase] = w0; if (base + r * 2 * WAVE + WAVE < n) match_bits[wbase + 1] = w1; }
+  }
   }
 }
 // ---- probe pass 2: the matched probe rows (ascending) look their key group up; unique builds emit the build row directly
@@ -152,7 +183,13 @@ __global__ void __launch_bounds__(BLOCK) k_key_minmax(const T* keys, const uint3
     if (row_slot[i] != NO_SLOT) { long long v = (long long)keys[i]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { long long a = __shfl_xor(lo, d, 64), b = __shfl_xor(hi, d, 64); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
-  if (lane_id() == 0 && lo <= hi) { atomicMin(mn, lo); atomicMax(mx, hi); }
+  __shared__ long long slo[BLOCK / WAVE], shi[BLOCK / WAVE];
+  if (lane_id() == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {       // one atomic pair per workgroup (atomics on one word serialise)
+    for (int w = 1; w < BLOCK / WAVE; w++) { lo = slo[w] < lo ? slo[w] : lo; hi = shi[w] > hi ? shi[w] : hi; }
+    if (lo <= hi) { atomicMin(mn, lo); atomicMax(mx, hi); }
+  }
 }
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_key_setbits(const T* keys, const uint32_t* row_slot, int64_t n, int64_t kmin, uint64_t* bitmap) {
@@ -220,13 +257,12 @@ dfgpu_status dfgpu_join_build(dfgpu_ctx* ctx, const dfgpu_array* const* keys, in
     if (cap > (1ull << 31)) fail(DFGPU_RESOURCES_EXHAUSTED, "build side of %lld rows exceeds the 2^30-row hash table limit", (long long)n);
     t->capacity = cap; t->cap_bits = bits;
     t->slots = alloc_buffer(ctx, cap * 8); HIP_CHECK(hipMemsetAsync(t->slots->ptr, 0xFF, cap * 8, ctx->stream));
-    t->slot_count = alloc_buffer(ctx, cap * 4, true);
     t->visited = alloc_buffer(ctx, bitmap_bytes(n), true);
     BufferPtr row_slot = alloc_buffer(ctx, (size_t)(n + 1) * 4);
     zero_scratch(ctx);
     if (n) { KernelTimer kt_(ctx, "k_join_build"); hipLaunchKernelGGL(k_join_build, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, t->ks, n,
                               t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr, null_equals_null ? 1 : 0, ctx->force_hash_collisions ? 1 : 0,
-                              (uint64_t*)t->slots->ptr, (uint32_t*)t->slot_count->ptr, cap - 1, (uint32_t*)row_slot->ptr, (unsigned long long*)ctx->d_scratch64); }
+                              (uint64_t*)t->slots->ptr, (uint32_t*)nullptr, cap - 1, (uint32_t*)row_slot->ptr, (unsigned long long*)ctx->d_scratch64); }
     KERNEL_CHECK();
     t->unique = read_scratch(ctx, 0) == 0;
     t->mem = (int64_t)(cap * 12 + bitmap_bytes(n));
@@ -235,7 +271,7 @@ dfgpu_status dfgpu_join_build(dfgpu_ctx* ctx, const dfgpu_array* const* keys, in
       long long init[2] = { INT64_MAX, INT64_MIN };
       HIP_CHECK(hipMemcpyAsync(ctx->d_scratch64 + 4, init, 16, hipMemcpyHostToDevice, ctx->stream));
       const void* kv = keys[0]->values->ptr; const uint32_t* rs = (const uint32_t*)row_slot->ptr;
-      DFGPU_INT_KEY_DISPATCH(keys[0]->type, hipLaunchKernelGGL((k_key_minmax<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 8)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, rs, n,
+      DFGPU_INT_KEY_DISPATCH(keys[0]->type, hipLaunchKernelGGL((k_key_minmax<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 2)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, rs, n,
                                                                (long long*)(ctx->d_scratch64 + 4), (long long*)(ctx->d_scratch64 + 5)));
       KERNEL_CHECK();
       HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 4, ctx->d_scratch64 + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -252,6 +288,8 @@ dfgpu_status dfgpu_join_build(dfgpu_ctx* ctx, const dfgpu_array* const* keys, in
       }
     }
     if (!t->unique) {
+      t->slot_count = alloc_buffer(ctx, cap * 4, true);
+      hipLaunchKernelGGL(k_count_slots, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)row_slot->ptr, n, (uint32_t*)t->slot_count->ptr);
       // CSR of build rows per key group: stable radix sort of (slot, row) then exclusive scan of group sizes
       hipLaunchKernelGGL(k_fix_unslotted, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (uint32_t*)row_slot->ptr, n, (uint32_t)cap);
       BufferPtr rows = alloc_buffer(ctx, (size_t)n * 4);
@@ -305,7 +343,7 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
     if (t->unique) {
       ob.a = new_fixed(ctx, DFGPU_UINT64, m);
       if (m) { KernelTimer kt_(ctx, "k_probe_lookup");
-        hipLaunchKernelGGL(k_probe_lookup, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, t->ks, pks, rp, m, nen, fz, (const uint64_t*)t->slots->ptr, (const uint32_t*)t->slot_count->ptr,
+        hipLaunchKernelGGL(k_probe_lookup, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, t->ks, pks, rp, m, nen, fz, (const uint64_t*)t->slots->ptr, (const uint32_t*)nullptr,
                            t->capacity - 1, 1, (uint64_t*)ob.get()->values->ptr, (uint32_t*)nullptr, (uint32_t*)nullptr, ctx->d_flags); }
       KERNEL_CHECK();
       op.a = rows.release();

@@ -54,22 +54,57 @@ class Schema:
         return [f.name for f in self.fields]
 
 
-class RecordBatch:
-    """Columns in HBM + optional selection mask over their rows."""
+class LazyColumn:
+    """A join / gather output column that is not materialised yet: `take(source, indices)` runs on first use.
+    Columns that a downstream ProjectionExec drops are never gathered, and a gather of a gather is composed on
+    the (narrow) index arrays instead of moving the (wide) values twice (late materialisation)."""
 
-    def __init__(self, schema: Schema, columns: Sequence[Array], num_rows: Optional[int] = None, selection: Optional[Array] = None):
+    def __init__(self, source: Array, indices: Array):
+        self.source, self.indices, self._arr = source, indices, None
+        self.ctx = source.ctx
+
+    def __len__(self) -> int:
+        return len(self.indices)
+
+    def get(self) -> Array:
+        if self._arr is None:
+            self._arr = self.ctx.take(self.source, self.indices)
+        return self._arr
+
+    def take(self, idx: Array):
+        if self._arr is not None:
+            return LazyColumn(self._arr, idx)
+        return LazyColumn(self.source, self.ctx.take(self.indices, idx))
+
+
+def lazy_take(col, idx: Array):
+    """take(col, idx) without touching the values yet."""
+    return col.take(idx) if isinstance(col, LazyColumn) else LazyColumn(col, idx)
+
+
+class RecordBatch:
+    """Columns in HBM (materialised Arrays or LazyColumns) + optional selection mask over their rows."""
+
+    def __init__(self, schema: Schema, columns: Sequence, num_rows: Optional[int] = None, selection: Optional[Array] = None):
         self.schema = schema
-        self.columns = list(columns)
+        self.raw_columns = list(columns)
         self.base_rows = len(columns[0]) if columns else (num_rows or 0)
         self.selection = selection
         self._num_rows = num_rows
 
     @property
     def ctx(self) -> Context:
-        return self.columns[0].ctx
+        return self.raw_columns[0].ctx
 
     def column(self, i: int) -> Array:
-        return self.columns[i]
+        c = self.raw_columns[i]
+        if isinstance(c, LazyColumn):
+            c = self.raw_columns[i] = c.get()
+        return c
+
+    @property
+    def columns(self) -> List[Array]:
+        return [self.column(i) for i in range(len(self.raw_columns))]
 
     def materialize(self) -> "RecordBatch":
         """Apply the selection: ≙ filter_record_batch (filter.rs:325)."""
@@ -77,7 +112,7 @@ class RecordBatch:
             return self
         ctx = self.ctx
         sel = ctx.mask_to_indices(self.selection)
-        cols = [ctx.take(c, sel) for c in self.columns]
+        cols = [lazy_take(c, sel) for c in self.raw_columns]
         return RecordBatch(self.schema, cols, num_rows=len(sel))
 
     @property
@@ -148,9 +183,9 @@ class Column(PhysicalExpr):
         return Column(name, schema.index_of(name))
 
     def evaluate(self, batch):
-        if self.index >= len(batch.columns):
-            raise DfgpuError(2, f"PhysicalExpr Column references column '{self.name}' at index {self.index} (zero-based) but input schema only has {len(batch.columns)} columns")
-        return ColumnarValue(batch.columns[self.index])
+        if self.index >= len(batch.raw_columns):
+            raise DfgpuError(2, f"PhysicalExpr Column references column '{self.name}' at index {self.index} (zero-based) but input schema only has {len(batch.raw_columns)} columns")
+        return ColumnarValue(batch.column(self.index))
 
     def __repr__(self):
         return f"{self.name}@{self.index}"
@@ -357,7 +392,7 @@ class FilterExec(ExecutionPlan):
                 raise DfgpuError(2, "Cannot create filter_array from non-boolean predicates")
             if batch.selection is not None:
                 mask = batch.ctx.binary(capi.OP_AND, _known_mask(batch.ctx, mask), batch.selection)
-            yield RecordBatch(batch.schema, batch.columns, selection=mask)
+            yield RecordBatch(batch.schema, batch.raw_columns, selection=mask)
 
 
 def _known_mask(ctx: Context, mask: Array) -> Array:
@@ -407,8 +442,13 @@ class ProjectionExec(ExecutionPlan):
             if batch.selection is not None and not only_columns:
                 needed = sorted(_columns_of([e for e, _ in self.exprs]))
                 batch = _materialize_subset(batch, needed)
-            cols = [e.evaluate(batch).into_array(batch.ctx, batch.base_rows) for e, _ in self.exprs]
-            schema = Schema([field_of_array(n, c) for (_, n), c in zip(self.exprs, cols)])
+            if only_columns:            # Column = Arc clone in the reference (expressions/column.rs:91): pass (lazy) columns through untouched
+                cols = [batch.raw_columns[e.index] for e, _ in self.exprs]
+                schema = Schema([Field(n, f.dtype, f.precision, f.scale, f.nullable) for (e, n) in self.exprs for f in [batch.schema.fields[e.index]]])
+            else:
+                cols = [batch.raw_columns[e.index] if isinstance(e, Column) else e.evaluate(batch).into_array(batch.ctx, batch.base_rows) for e, _ in self.exprs]
+                schema = Schema([batch.schema.fields[e.index] if isinstance(e, Column) else field_of_array(n, c) for (e, n), c in zip(self.exprs, cols)])
+                schema = Schema([Field(n, f.dtype, f.precision, f.scale, f.nullable) for (_, n), f in zip(self.exprs, schema.fields)])
             self._schema = schema
             yield RecordBatch(schema, cols, num_rows=batch.base_rows, selection=batch.selection)
 
@@ -429,8 +469,8 @@ def _materialize_subset(batch: RecordBatch, needed: Sequence[int]) -> RecordBatc
     ctx = batch.ctx
     sel = ctx.mask_to_indices(batch.selection)
     cols = []
-    for i, c in enumerate(batch.columns):
-        cols.append(ctx.take(c, sel) if i in needed else None)
+    for i in range(len(batch.raw_columns)):
+        cols.append(ctx.take(batch.column(i), sel) if i in needed else None)
     n = len(sel)
     filler = None
     for i, c in enumerate(cols):
@@ -549,7 +589,7 @@ def partition_batch(batch: RecordBatch, exprs: Sequence[PhysicalExpr], n: int) -
     if batch.selection is not None:
         sel = ctx.mask_to_indices(batch.selection)
         needed = sorted(_columns_of(list(exprs)))
-        cols = [ctx.take(c, sel) if i in needed else None for i, c in enumerate(batch.columns)]
+        cols = [ctx.take(batch.column(i), sel) if i in needed else None for i in range(len(batch.raw_columns))]
         filler = ctx.new_null(capi.INT8, len(sel))
         kb = RecordBatch(batch.schema, [c if c is not None else filler for c in cols], num_rows=len(sel))
     if kb.base_rows == 0:
@@ -561,7 +601,7 @@ def partition_batch(batch: RecordBatch, exprs: Sequence[PhysicalExpr], n: int) -
         if cnt:
             idx = indices.slice(off, cnt)
             rows = ctx.take(sel, idx) if sel is not None else idx
-            out.append((dest, RecordBatch(batch.schema, [ctx.take(c, rows) for c in batch.columns], num_rows=cnt)))
+            out.append((dest, RecordBatch(batch.schema, [lazy_take(c, rows) for c in batch.raw_columns], num_rows=cnt)))
         off += cnt
     return out
 
@@ -623,7 +663,7 @@ class HashJoinExec(ExecutionPlan):
         if len(batches) == 1 and batches[0].selection is not None:
             build = batches[0]                      # fused FilterExec: table built under the mask
             fused_mask = build.selection
-            build = RecordBatch(build.schema, build.columns, num_rows=build.base_rows)
+            build = RecordBatch(build.schema, build.raw_columns, num_rows=build.base_rows)
         else:
             mats = [b.materialize() for b in batches]
             mats = [b for b in mats if b.num_rows > 0]
@@ -654,7 +694,7 @@ class HashJoinExec(ExecutionPlan):
                 continue
             any_probe = True
             mask = probe.selection
-            pbase = RecordBatch(probe.schema, probe.columns, num_rows=probe.base_rows)
+            pbase = RecordBatch(probe.schema, probe.raw_columns, num_rows=probe.base_rows)
             if built is None:
                 bidx = ctx.from_arrow(_pa_empty("uint64"))
                 pidx = ctx.from_arrow(_pa_empty("uint32"))
@@ -681,7 +721,7 @@ class HashJoinExec(ExecutionPlan):
             fidx = table.final_indices(jt)
             fidx = _reference_final_order(ctx, fidx, segments)
             n = len(fidx)
-            lcols = [ctx.take(c, fidx) for c in build.columns]
+            lcols = [lazy_take(c, fidx) for c in build.raw_columns]
             if self.join_type in ("LeftSemi", "LeftAnti"):
                 yield RecordBatch(out_schema, lcols, num_rows=n)
             else:
@@ -692,7 +732,7 @@ class HashJoinExec(ExecutionPlan):
         """apply_join_filter_to_indices (joins/utils.rs:1143-1176)"""
         cols = []
         for side, index in self.filter.column_indices:
-            cols.append(ctx.take(build.columns[index], bidx) if side == "left" else ctx.take(probe.columns[index], pidx))
+            cols.append(ctx.take(build.column(index), bidx) if side == "left" else ctx.take(probe.column(index), pidx))
         inter = RecordBatch(self.filter.schema, cols, num_rows=len(bidx))
         m = self.filter.expression.evaluate(inter).into_array(ctx, len(bidx))
         return ctx.filter(bidx, m), ctx.filter(pidx, m)
@@ -704,10 +744,10 @@ class HashJoinExec(ExecutionPlan):
         cols = []
         if jt not in ("RightSemi", "RightAnti"):
             for i, f in enumerate(lfields):
-                cols.append(ctx.take(build.columns[i], bidx) if build is not None else ctx.new_null(f.dtype, n, f.precision, f.scale))
+                cols.append(lazy_take(build.raw_columns[i], bidx) if build is not None else ctx.new_null(f.dtype, n, f.precision, f.scale))
         if jt not in ("LeftSemi", "LeftAnti"):
             for i in range(len(rfields)):
-                cols.append(ctx.take(probe.columns[i], pidx))
+                cols.append(lazy_take(probe.raw_columns[i], pidx))
         return RecordBatch(schema, cols, num_rows=n)
 
 
@@ -791,7 +831,7 @@ class AggregateExec(ExecutionPlan):
             if batch.base_rows == 0:
                 continue
             mask = batch.selection
-            base = RecordBatch(batch.schema, batch.columns, num_rows=batch.base_rows)
+            base = RecordBatch(batch.schema, batch.raw_columns, num_rows=batch.base_rows)
             gcols = [e.evaluate(base).into_array(ctx, base.base_rows) for e, _ in self.group_by]
             gids = groups.intern(gcols, mask=mask)                         # group_aggregate_batch (row_hash.rs:524-613)
             total = len(groups)
@@ -799,7 +839,7 @@ class AggregateExec(ExecutionPlan):
             for i, a in enumerate(self.aggr_expr):
                 if merging:
                     nst = 2 if a.fun.upper() == "AVG" else 1
-                    states = [base.columns[col + k] for k in range(nst)]
+                    states = [base.column(col + k) for k in range(nst)]
                     col += nst
                     if accs[i] is None:
                         accs[i] = self._make_acc_from_state(ctx, a, states)
@@ -897,4 +937,4 @@ class SortExec(ExecutionPlan):
             return
         keys = [s.expr.evaluate(batch).into_array(ctx, batch.num_rows) for s in self.expr]
         idx = ctx.sort_to_indices(keys, [s.descending for s in self.expr], [s.nulls_first for s in self.expr], self.fetch)
-        yield RecordBatch(batch.schema, [ctx.take(c, idx) for c in batch.columns], num_rows=len(idx))
+        yield RecordBatch(batch.schema, [lazy_take(c, idx) for c in batch.raw_columns], num_rows=len(idx))

@@ -98,6 +98,8 @@ LINEITEM_SCHEMA = [("l_orderkey", capi.INT64, 0, 0), ("l_extendedprice", capi.DE
 
 def tables_from_torch(ctx: Context, tt: dict) -> Dict[str, ops.RecordBatch]:
     """tt: torch CUDA tensors keyed by column name (decimals as (n,2) int64 [lo,hi])."""
+    import torch
+    torch.cuda.synchronize()       # the tensors were produced on torch's stream; the ctx may run on another one
     segd = _segment_dictionary(ctx)
     cust = [ctx.wrap_tensor(tt["c_custkey"], capi.INT64), _wrap_dictionary(ctx, tt["c_mktsegment"], segd)]
     orders = [ctx.wrap_tensor(tt["o_orderkey"], capi.INT64), ctx.wrap_tensor(tt["o_custkey"], capi.INT64),

@@ -1,0 +1,55 @@
+// Diagnostic micro-benchmark (not part of the product): where does k_probe_match_bitmap's time go?
+// A: stream Int64 keys -> ballot; B: + selection bitmap; C: + membership bitmap gather (sorted keys); D: C with random keys.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+__device__ inline uint64_t spread32(uint64_t x) { x &= 0xFFFFFFFFull; x = (x | (x << 16)) & 0x0000FFFF0000FFFFull; x = (x | (x << 8)) & 0x00FF00FF00FF00FFull; x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full; x = (x | (x << 2)) & 0x3333333333333333ull; x = (x | (x << 1)) & 0x5555555555555555ull; return x; }
+template <int MODE, int ROWS>
+__global__ void __launch_bounds__(256) k(const int64_t* keys, const uint64_t* mask, const uint64_t* bitmap, int64_t n, uint64_t range, uint64_t* out) {
+  int lane = threadIdx.x & 63;
+  int64_t base = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * ROWS);
+  int64_t kk[ROWS / 2][2];
+#pragma unroll
+  for (int r = 0; r < ROWS / 2; r++) { int64_t j = base + r * 128 + 2 * lane; if (j + 1 < n) { longlong2 p = *(const longlong2*)(keys + j); kk[r][0] = p.x; kk[r][1] = p.y; } else { kk[r][0] = kk[r][1] = 0; } }
+#pragma unroll
+  for (int r = 0; r < ROWS / 2; r++) {
+    int64_t j = base + r * 128 + 2 * lane;
+    uint64_t mw = 3; if (MODE >= 1 && j < n) mw = mask[j >> 6] >> (j & 63);
+    bool h[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      uint64_t d = (uint64_t)kk[r][e];
+      bool go = j + e < n && ((mw >> e) & 1) && d < range;
+      if (MODE >= 2) h[e] = go ? (bitmap[d >> 6] >> (d & 63)) & 1 : false; else h[e] = go && (d & 4);
+    }
+    uint64_t be = __ballot(h[0]), bo = __ballot(h[1]);
+    uint64_t w0 = spread32(be) | (spread32(bo) << 1), w1 = spread32(be >> 32) | (spread32(bo >> 32) << 1);
+    if (lane == 0 && base + r * 128 < n) { out[(base >> 6) + 2 * r] = w0; out[(base >> 6) + 2 * r + 1] = w1; }
+  }
+}
+__global__ void init_keys(int64_t* k, int64_t n, int rnd) { int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; if (i < n) { uint64_t x = i; if (rnd) { x *= 0x9E3779B97F4A7C15ull; x ^= x >> 29; x %= 600000000ull; } else x = i; k[i] = (int64_t)x; } }
+__global__ void init_words(uint64_t* w, int64_t nw, uint64_t mul) { int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; if (i < nw) { uint64_t x = (i + 1) * mul; x ^= x >> 31; w[i] = x; } }
+template <int MODE, int ROWS> float run(const int64_t* keys, const uint64_t* mask, const uint64_t* bm, int64_t n, uint64_t* out) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  int64_t grid = (n + 256 * ROWS - 1) / (256 * ROWS);
+  for (int it = 0; it < 2; it++) hipLaunchKernelGGL((k<MODE, ROWS>), dim3(grid), dim3(256), 0, 0, keys, mask, bm, n, 600000000ull, out);
+  hipEventRecord(a); for (int it = 0; it < 5; it++) hipLaunchKernelGGL((k<MODE, ROWS>), dim3(grid), dim3(256), 0, 0, keys, mask, bm, n, 600000000ull, out); hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b); return ms / 5;
+}
+int main() {
+  int64_t n = 600000000; int64_t nw = (n + 63) / 64;
+  int64_t* keys; uint64_t *mask, *bm, *out;
+  CK(hipMalloc(&keys, n * 8)); CK(hipMalloc(&mask, nw * 8)); CK(hipMalloc(&bm, nw * 8)); CK(hipMalloc(&out, nw * 8 + 64));
+  hipLaunchKernelGGL(init_words, dim3((nw + 255) / 256), dim3(256), 0, 0, mask, nw, 0x9E3779B97F4A7C15ull);
+  hipLaunchKernelGGL(init_words, dim3((nw + 255) / 256), dim3(256), 0, 0, bm, nw, 0xD1B54A32D192ED03ull);
+  for (int rnd = 0; rnd < 2; rnd++) {
+    hipLaunchKernelGGL(init_keys, dim3((n + 255) / 256), dim3(256), 0, 0, keys, n, rnd); CK(hipDeviceSynchronize());
+    float a8 = run<0, 8>(keys, mask, bm, n, out), b8 = run<1, 8>(keys, mask, bm, n, out), c8 = run<2, 8>(keys, mask, bm, n, out);
+    float a16 = run<0, 16>(keys, mask, bm, n, out), c16 = run<2, 16>(keys, mask, bm, n, out), c4 = run<2, 4>(keys, mask, bm, n, out);
+    printf("%s keys: A(keys only) %.3f ms = %.2f TB/s | B(+mask) %.3f | C(+bitmap) %.3f ms = %.2f TB/s | rows/lane 16: A %.3f C %.3f | rows/lane 4: C %.3f\n", rnd ? "random" : "sorted",
+           a8, n * 8.0 / a8 / 1e9, b8, c8, n * 8.25 / c8 / 1e9, a16, c16, c4);
+  }
+  return 0;
+}

@@ -13,6 +13,7 @@ def big(ctx):
     import torch
     import dfgpu
     t = torch.arange(N, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()          # the test ctx runs on its own stream: torch's producer kernel must have finished
     return t, ctx.wrap_tensor(t, dfgpu.capi.INT64)
 
 
@@ -35,6 +36,7 @@ def test_probe_dense_keys_at_scale(ctx, big):
     import torch
     t, col = big
     bt = torch.arange(0, N, 1000, dtype=torch.int64, device="cuda")          # 300k build keys, every 1000th probe key matches
+    torch.cuda.synchronize()
     table = dfgpu.JoinTable(ctx, [ctx.wrap_tensor(bt, dfgpu.capi.INT64)])
     bidx, pidx = table.probe([col])
     assert len(bidx) == len(bt)
@@ -48,6 +50,7 @@ def test_group_cardinality_and_sum_at_scale(ctx, big):
     import torch
     t, col = big
     keys = (t % 1_000_003).contiguous()
+    torch.cuda.synchronize()
     kc = ctx.wrap_tensor(keys, dfgpu.capi.INT64)
     gv = dfgpu.GroupValues(ctx, 1)
     gids = gv.intern([kc])
