@@ -37,6 +37,11 @@ def all_to_all_buffers(send, send_elems: Sequence[int], recv_elems: Sequence[int
     return out
 
 
+def _staged(t, group):
+    """RCCL moves device tensors directly; under gloo (CPU tests, or 2 ranks rehearsing on ONE GPU) stage through host memory."""
+    return t if _is_nccl(group) or not t.is_cuda else t.cpu()
+
+
 def exchange_byte_columns(parts: List[Optional[List]], counts: Sequence[int], widths: Sequence[int], group=None):
     """parts[dest] = list (one per column) of 1-D uint8 tensors holding counts[dest] rows of widths[c] bytes,
     or None when nothing goes to `dest`.  Returns (recv_counts, [uint8 tensor per column]) with the received
@@ -50,7 +55,8 @@ def exchange_byte_columns(parts: List[Optional[List]], counts: Sequence[int], wi
         segs = [p[c] for p, n in zip(parts, counts) if p and n]
         send = torch.cat(segs) if segs else torch.empty(0, dtype=torch.uint8, device=device)
         assert send.numel() == sum(counts) * w, "segment sizes do not match the row counts"
-        out.append(all_to_all_buffers(send, [n * w for n in counts], [n * w for n in recv_counts], group))
+        got = all_to_all_buffers(_staged(send, group), [n * w for n in counts], [n * w for n in recv_counts], group)
+        out.append(got.to(device) if got.device != send.device else got)
     return recv_counts, out
 
 
@@ -96,7 +102,9 @@ def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=No
                 if col.describe().validity:
                     has_valid[c] = 1
     if world > 1:
-        dist.all_reduce(has_valid, op=dist.ReduceOp.MAX, group=group)
+        hv = _staged(has_valid, group)
+        dist.all_reduce(hv, op=dist.ReduceOp.MAX, group=group)
+        has_valid = hv
     nullable = [bool(x) for x in has_valid.cpu().tolist()]
     ctx.synchronize()                      # producers ran on the ctx stream
     tparts: List[Optional[List]] = []
@@ -128,7 +136,7 @@ def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=No
             continue
         segs = [vp[vi] for vp, n in zip(vparts, counts) if vp is not None and n]
         send = torch.cat(segs) if segs else torch.empty(0, dtype=torch.uint8, device="cuda")
-        vrecv = all_to_all_buffers(send, [((n + 63) // 64) * 8 for n in counts], [((n + 63) // 64) * 8 for n in recv_counts], group)
+        vrecv = all_to_all_buffers(_staged(send, group), [((n + 63) // 64) * 8 for n in counts], [((n + 63) // 64) * 8 for n in recv_counts], group).to("cuda")
         torch.cuda.current_stream().synchronize()
         pieces, off = [], 0
         for n in recv_counts:
