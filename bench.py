@@ -58,7 +58,7 @@ def main():
     import torch
     import torch.distributed as dist
     import dfgpu
-    from dfgpu import exchange, operators as ops, tpch
+    from dfgpu import exchange, physical_plan as ops, tpch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -90,14 +90,16 @@ def main():
         else:
             plan = tpch.q3_distributed_plan(tables, batch_size=8192)
             local = [b for b in plan.execute(0, tc)]
-            schema = local[0].schema if local else plan.schema()
+            schema = local[0].schema if local else None
             mine = ops.concat_batches(schema, local) if local else None
+            schema = exchange.agree_schema(schema)
             gathered = exchange.gather_batches(ctx, schema, mine, 0)           # ≙ SortPreservingMergeExec gathering the sorted partitions
             out = []
             if rank == 0 and gathered.num_rows:
                 C = ops.Column
+                gb = gathered
                 final = ops.SortExec([ops.PhysicalSortExpr(C("revenue", 1), True, True), ops.PhysicalSortExpr(C("o_orderdate", 2), False, False)],
-                                     ops.MemoryExec([[gathered]], gathered.schema))
+                                     ops.MemoryExec([[gb]], schema))
                 out = [b for b in final.execute(0, tc)]
         ctx.synchronize()
         result_rows[0] = sum(b.num_rows for b in out)
@@ -164,12 +166,7 @@ def main():
         import numpy as np
         cpu_sf = min(args.cpu_sf, args.sf)
         small = tpch.gen_device(ctx, cpu_sf, seed=tpch.SEED + 1)
-        host = {}
-        for tname, batch in small.items():
-            for f, col in zip(batch.schema.fields, batch.columns):
-                keep = col._keepalive[0] if isinstance(col._keepalive, tuple) else col._keepalive
-                a = keep.cpu().numpy()
-                host[f.name] = a.view(np.uint64) if a.ndim == 2 else a
+        host = tpch.tables_to_host(small)
         del small
         torch.cuda.empty_cache()
         # a one-GPU box is given a 16-core share of the host (os.cpu_count() reports the whole machine)

@@ -4,8 +4,10 @@ Layers (DESIGN.md):
   csrc/        hand-written HIP kernels + the C ABI of include/dfgpu.h  -> libdfgpu.so (built in-tree)
   capi.py      ctypes binding of exactly those symbols
   device.py    Context / Array / JoinTable / GroupValues / GroupsAccumulator wrappers
-  operators.py host mirror of ExecutionPlan / PhysicalExpr for the hot path (FilterExec, ProjectionExec,
-               HashJoinExec, AggregateExec, SortExec, RepartitionExec, CoalesceBatchesExec)
+  csrc/exec/   C++ host layer: ExecutionPlan / PhysicalExpr mirror (FilterExec, ProjectionExec, HashJoinExec, AggregateExec,
+               SortExec, RepartitionExec, CoalesceBatchesExec ...) over the kernel ABI; C ABI in include/dfgpu_exec.h
+  physical_plan.py  typed Python builders over that C++ layer (same class names as the reference operators)
+  operators.py shared plain dataclasses (Field, Schema, TaskContext)
   exchange.py  RCCL all-to-all(v) of partitioned column buffers via torch.distributed (multi-GPU shuffle)
   tpch.py      synthetic TPC-H-shaped columns + the Q3 physical plan of the reference
 
@@ -16,6 +18,7 @@ from . import capi
 from .capi import DfgpuError, load_library
 from .device import Array, Context, GroupValues, GroupsAccumulator, JoinTable, join_adjust_indices
 from . import operators
+from . import physical_plan
 
 __all__ = ["capi", "DfgpuError", "load_library", "Array", "Context", "GroupValues", "GroupsAccumulator", "JoinTable",
-           "join_adjust_indices", "operators"]
+           "join_adjust_indices", "operators", "physical_plan"]

@@ -129,6 +129,45 @@ PROTOTYPES = {
     "dfgpu_hash_partition": (C.c_int32, [_P, _PP, C.c_int32, C.c_int32, _PP, C.POINTER(C.c_int64)]),
 }
 
+# include/dfgpu_exec.h: the C++ host layer (ExecutionPlan / PhysicalExpr mirror)
+_CPP = C.POINTER(C.c_char_p)
+_I32P = C.POINTER(C.c_int32)
+PROTOTYPES.update({
+    "dfgpu_exec_last_error": (C.c_char_p, []),
+    "dfgpu_batch_new": (C.c_int32, [_CPP, _PP, C.c_int32, _PP]),
+    "dfgpu_batch_free": (None, [_P]),
+    "dfgpu_batch_num_columns": (C.c_int32, [_P]),
+    "dfgpu_batch_num_rows": (C.c_int32, [_P, _P, C.POINTER(C.c_int64)]),
+    "dfgpu_batch_column_name": (C.c_char_p, [_P, C.c_int32]),
+    "dfgpu_batch_column": (C.c_int32, [_P, _P, C.c_int32, _PP]),
+    "dfgpu_expr_column": (C.c_int32, [C.c_char_p, C.c_int32, _PP]),
+    "dfgpu_expr_literal": (C.c_int32, [_P, _PP]),
+    "dfgpu_expr_binary": (C.c_int32, [_P, C.c_int32, _P, _PP]),
+    "dfgpu_expr_not": (C.c_int32, [_P, _PP]),
+    "dfgpu_expr_is_null": (C.c_int32, [_P, C.c_int32, _PP]),
+    "dfgpu_expr_negative": (C.c_int32, [_P, _PP]),
+    "dfgpu_expr_cast": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, _PP]),
+    "dfgpu_expr_in_list": (C.c_int32, [_P, _P, C.c_int32, _PP]),
+    "dfgpu_expr_free": (None, [_P]),
+    "dfgpu_plan_memory": (C.c_int32, [_PP, _I32P, C.c_int32, _PP]),
+    "dfgpu_plan_filter": (C.c_int32, [_P, _P, _PP]),
+    "dfgpu_plan_projection": (C.c_int32, [_PP, _CPP, C.c_int32, _P, _PP]),
+    "dfgpu_plan_coalesce_batches": (C.c_int32, [_P, C.c_int64, _PP]),
+    "dfgpu_plan_coalesce_partitions": (C.c_int32, [_P, _PP]),
+    "dfgpu_plan_repartition": (C.c_int32, [_P, _PP, C.c_int32, C.c_int32, _PP]),
+    "dfgpu_plan_hash_join": (C.c_int32, [_P, _P, _PP, _PP, C.c_int32, _P, _I32P, _I32P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _PP]),
+    "dfgpu_plan_aggregate": (C.c_int32, [C.c_int32, _PP, _CPP, C.c_int32, _I32P, _PP, _PP, _CPP, _I32P, C.c_int32, _P, _PP]),
+    "dfgpu_plan_sort": (C.c_int32, [_PP, C.c_char_p, C.c_char_p, C.c_int32, C.c_int64, C.c_int32, _P, _PP]),
+    "dfgpu_plan_free": (None, [_P]),
+    "dfgpu_plan_partition_count": (C.c_int32, [_P]),
+    "dfgpu_plan_schema_len": (C.c_int32, [_P]),
+    "dfgpu_plan_schema_name": (C.c_char_p, [_P, C.c_int32]),
+    "dfgpu_plan_name": (C.c_char_p, [_P]),
+    "dfgpu_plan_execute": (C.c_int32, [_P, C.c_int32, _P, C.c_int64, _PP]),
+    "dfgpu_stream_next": (C.c_int32, [_P, _PP]),
+    "dfgpu_stream_free": (None, [_P]),
+})
+
 _lib = None
 
 

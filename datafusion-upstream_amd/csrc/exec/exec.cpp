@@ -1,0 +1,717 @@
+// exec.cpp -- C++ host layer mirroring the reference's operator interface for the hot path.
+//
+//   trait PhysicalExpr   datafusion/physical-expr/src/physical_expr.rs:96-123
+//   trait ExecutionPlan  datafusion/physical-plan/src/lib.rs:115-405
+//   MemoryExec memory.rs | FilterExec filter.rs:315-363 | ProjectionExec projection.rs:295-340 |
+//   CoalesceBatchesExec coalesce_batches.rs:198-260 | CoalescePartitionsExec | RepartitionExec repartition/mod.rs:148-294 |
+//   HashJoinExec joins/hash_join.rs:574-1388 | AggregateExec aggregates/{mod,row_hash}.rs | SortExec sorts/sort.rs:584-988
+//
+// It only uses the public kernel-level C ABI (include/dfgpu.h): exactly what a Rust shim would do per operator.
+// MI355X-first differences from the reference (results identical): batches are whole partitions; FilterExec emits a
+// selection bitmap that join build/probe, group interning and repartitioning consume fused; join outputs are lazy
+// (source, indices) columns so that columns a later ProjectionExec drops are never gathered.
+#include "../../../include/dfgpu_exec.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace dfx {
+
+struct Err : std::exception {
+  dfgpu_status code; std::string msg;
+  Err(dfgpu_status c, std::string m) : code(c), msg(std::move(m)) {}
+  const char* what() const noexcept override { return msg.c_str(); }
+};
+[[noreturn]] static void fail(dfgpu_status code, const char* fmt, ...) {
+  char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  throw Err(code, buf);
+}
+static thread_local std::string g_err;
+
+// ------------------------------------------------------------------ handles
+struct ArrayRef {
+  dfgpu_array* a = nullptr;
+  ArrayRef() = default;
+  static ArrayRef adopt(dfgpu_array* owned) { ArrayRef r; r.a = owned; return r; }
+  static ArrayRef share(const dfgpu_array* x) { ArrayRef r; r.a = const_cast<dfgpu_array*>(x); if (r.a) dfgpu_array_retain(r.a); return r; }
+  ArrayRef(const ArrayRef& o) : a(o.a) { if (a) dfgpu_array_retain(a); }
+  ArrayRef(ArrayRef&& o) noexcept : a(o.a) { o.a = nullptr; }
+  ArrayRef& operator=(ArrayRef o) { std::swap(a, o.a); return *this; }
+  ~ArrayRef() { if (a) dfgpu_array_release(a); }
+  explicit operator bool() const { return a != nullptr; }
+  int64_t len() const { return a ? dfgpu_array_length(a) : 0; }
+};
+
+struct TaskContext {          // ≙ datafusion_execution::TaskContext (execution/src/task.rs:44-59)
+  dfgpu_ctx* ctx; int64_t batch_size;
+  void check(dfgpu_status st) const { if (st != DFGPU_OK) throw Err(st, dfgpu_last_error(ctx)); }
+};
+
+struct Field { std::string name; int32_t type = 0, precision = 0, scale = 0; };
+struct Schema { std::vector<Field> f; };
+using SchemaPtr = std::shared_ptr<Schema>;
+
+static Field field_of(const std::string& name, const dfgpu_array* a) {
+  dfgpu_array_desc d; dfgpu_array_describe(a, &d);
+  if (d.type == DFGPU_DICTIONARY && d.dictionary) return Field{name, d.dictionary->type, d.dictionary->precision, d.dictionary->scale};
+  return Field{name, d.type, d.precision, d.scale};
+}
+
+// a column is a materialised array or a pending gather take(source, indices) (late materialisation)
+struct Col {
+  ArrayRef arr, source, indices;
+  int64_t len() const { return arr ? arr.len() : indices.len(); }
+};
+static ArrayRef take(const TaskContext& tc, const ArrayRef& v, const ArrayRef& idx) { dfgpu_array* o = nullptr; tc.check(dfgpu_take(tc.ctx, v.a, idx.a, &o)); return ArrayRef::adopt(o); }
+static const ArrayRef& col_get(const TaskContext& tc, Col& c) {
+  if (!c.arr) { c.arr = take(tc, c.source, c.indices); c.source = ArrayRef(); c.indices = ArrayRef(); }
+  return c.arr;
+}
+static Col col_take(const TaskContext& tc, const Col& c, const ArrayRef& idx) {
+  Col o;
+  if (c.arr) { o.source = c.arr; o.indices = idx; }
+  else { o.source = c.source; o.indices = take(tc, c.indices, idx); }       // gather of a gather: compose the indices
+  return o;
+}
+static Col col_of(ArrayRef a) { Col c; c.arr = std::move(a); return c; }
+
+struct Batch {
+  SchemaPtr schema; std::vector<Col> cols; ArrayRef selection; int64_t base_rows = 0;
+  const ArrayRef& column(const TaskContext& tc, int i) { return col_get(tc, cols.at((size_t)i)); }
+};
+static ArrayRef mask_indices(const TaskContext& tc, const ArrayRef& mask) { dfgpu_array* o = nullptr; tc.check(dfgpu_mask_to_indices(tc.ctx, mask.a, &o)); return ArrayRef::adopt(o); }
+// ≙ filter_record_batch (filter.rs:325), lazily per column
+static Batch materialize(const TaskContext& tc, const Batch& b) {
+  if (!b.selection) return b;
+  ArrayRef sel = mask_indices(tc, b.selection);
+  Batch o; o.schema = b.schema; o.base_rows = sel.len();
+  for (auto& c : b.cols) o.cols.push_back(col_take(tc, c, sel));
+  return o;
+}
+static int64_t num_rows(const TaskContext& tc, const Batch& b) { return b.selection ? mask_indices(tc, b.selection).len() : b.base_rows; }
+static ArrayRef concat_arrays(const TaskContext& tc, std::vector<ArrayRef>& parts) {
+  std::vector<const dfgpu_array*> p; for (auto& x : parts) p.push_back(x.a);
+  dfgpu_array* o = nullptr; tc.check(dfgpu_concat(tc.ctx, p.data(), (int32_t)p.size(), &o)); return ArrayRef::adopt(o);
+}
+// concat_batches (arrow-select), after applying selections; empty batches are skipped
+static bool concat_batches(const TaskContext& tc, std::vector<Batch>& in, Batch* out) {
+  std::vector<Batch> m;
+  for (auto& b : in) { Batch x = materialize(tc, b); if (x.base_rows > 0) m.push_back(std::move(x)); }
+  if (m.empty()) { if (in.empty()) return false; *out = materialize(tc, in[0]); return true; }
+  if (m.size() == 1) { *out = std::move(m[0]); return true; }
+  Batch o; o.schema = m[0].schema;
+  for (size_t c = 0; c < m[0].cols.size(); c++) {
+    std::vector<ArrayRef> parts; for (auto& b : m) parts.push_back(col_get(tc, b.cols[c]));
+    o.cols.push_back(col_of(concat_arrays(tc, parts)));
+  }
+  for (auto& b : m) o.base_rows += b.base_rows;
+  *out = std::move(o); return true;
+}
+
+// ------------------------------------------------------------------ PhysicalExpr
+struct Value { ArrayRef arr; bool scalar = false; };      // ≙ ColumnarValue (expr/src/columnar_value.rs:35-40)
+struct Expr {
+  virtual ~Expr() = default;
+  virtual Value eval(const TaskContext& tc, Batch& b) const = 0;
+  virtual bool safe() const { return false; }            // cannot raise on rows a selection mask has dropped
+  virtual void columns(std::set<int>& out) const {}
+  virtual int column_index() const { return -1; }
+};
+using ExprPtr = std::shared_ptr<const Expr>;
+
+static ArrayRef into_array(const TaskContext& tc, const Value& v, int64_t n) {       // ColumnarValue::into_array
+  if (!v.scalar) return v.arr;
+  std::vector<uint32_t> zeros((size_t)n, 0u);
+  dfgpu_array_desc d{}; d.type = DFGPU_UINT32; d.length = n; d.values = zeros.empty() ? (const void*)&d : (const void*)zeros.data();
+  dfgpu_array* idx = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &d, &idx));
+  ArrayRef i = ArrayRef::adopt(idx);
+  return take(tc, v.arr, i);
+}
+
+struct ColumnExpr : Expr {        // expressions/column.rs:91
+  std::string name; int index;
+  ColumnExpr(std::string n, int i) : name(std::move(n)), index(i) {}
+  Value eval(const TaskContext& tc, Batch& b) const override {
+    if (index < 0 || index >= (int)b.cols.size())
+      fail(DFGPU_INTERNAL, "PhysicalExpr Column references column '%s' at index %d (zero-based) but input schema only has %zu columns", name.c_str(), index, b.cols.size());
+    return Value{b.column(tc, index), false};
+  }
+  bool safe() const override { return true; }
+  void columns(std::set<int>& out) const override { out.insert(index); }
+  int column_index() const override { return index; }
+};
+struct LiteralExpr : Expr {       // expressions/literal.rs:73
+  ArrayRef scalar;
+  explicit LiteralExpr(ArrayRef s) : scalar(std::move(s)) {}
+  Value eval(const TaskContext&, Batch&) const override { return Value{scalar, true}; }
+  bool safe() const override { return true; }
+};
+struct BinaryExpr : Expr {        // expressions/binary.rs:259-315
+  ExprPtr l, r; int op;
+  BinaryExpr(ExprPtr a, int o, ExprPtr b) : l(std::move(a)), r(std::move(b)), op(o) {}
+  Value eval(const TaskContext& tc, Batch& b) const override {
+    Value x = l->eval(tc, b), y = r->eval(tc, b);
+    dfgpu_array* o = nullptr; tc.check(dfgpu_binary(tc.ctx, op, x.arr.a, x.scalar, y.arr.a, y.scalar, &o));
+    return Value{ArrayRef::adopt(o), x.scalar && y.scalar};
+  }
+  bool safe() const override { return op >= DFGPU_OP_EQ && l->safe() && r->safe(); }      // comparisons / AND / OR never raise
+  void columns(std::set<int>& out) const override { l->columns(out); r->columns(out); }
+};
+struct UnaryExpr : Expr {
+  ExprPtr e; int kind, a0, a1, a2; ArrayRef list;      // kind: 0 NOT, 1 IS NULL, 2 IS NOT NULL, 3 negative, 4 cast, 5 IN, 6 NOT IN
+  Value eval(const TaskContext& tc, Batch& b) const override {
+    Value x = e->eval(tc, b); dfgpu_array* o = nullptr;
+    switch (kind) {
+      case 0: tc.check(dfgpu_not(tc.ctx, x.arr.a, &o)); break;
+      case 1: tc.check(dfgpu_is_null(tc.ctx, x.arr.a, 0, &o)); break;
+      case 2: tc.check(dfgpu_is_null(tc.ctx, x.arr.a, 1, &o)); break;
+      case 3: tc.check(dfgpu_negative(tc.ctx, x.arr.a, &o)); break;
+      case 4: tc.check(dfgpu_cast(tc.ctx, x.arr.a, a0, a1, a2, &o)); break;
+      default: tc.check(dfgpu_in_list(tc.ctx, x.arr.a, list.a, kind == 6, &o)); break;
+    }
+    return Value{ArrayRef::adopt(o), x.scalar};
+  }
+  bool safe() const override { return kind <= 2 && e->safe(); }
+  void columns(std::set<int>& out) const override { e->columns(out); }
+};
+
+// ------------------------------------------------------------------ ExecutionPlan
+struct Stream { virtual ~Stream() = default; virtual bool next(Batch& out) = 0; };     // poll_next: false = end of stream
+struct Plan;
+using PlanPtr = std::shared_ptr<const Plan>;
+struct Plan : std::enable_shared_from_this<Plan> {
+  virtual ~Plan() = default;
+  virtual const char* name() const = 0;
+  virtual SchemaPtr schema() const = 0;
+  virtual int partitions() const = 0;                                   // output_partitioning().partition_count()
+  virtual std::unique_ptr<Stream> execute(int partition, const TaskContext& tc) const = 0;
+};
+static void drain(const PlanPtr& p, int partition, const TaskContext& tc, std::vector<Batch>& out) {
+  auto s = p->execute(partition, tc); Batch b; while (s->next(b)) out.push_back(std::move(b));
+}
+
+struct VecStream : Stream {
+  std::vector<Batch> v; size_t i = 0;
+  explicit VecStream(std::vector<Batch> x) : v(std::move(x)) {}
+  bool next(Batch& out) override { if (i >= v.size()) return false; out = std::move(v[i++]); return true; }
+};
+
+struct MemoryExec : Plan {        // memory.rs:40,150
+  std::vector<std::vector<Batch>> parts; SchemaPtr sch;
+  const char* name() const override { return "MemoryExec"; }
+  SchemaPtr schema() const override { return sch; }
+  int partitions() const override { return (int)parts.size(); }
+  std::unique_ptr<Stream> execute(int p, const TaskContext&) const override {
+    if (p < 0 || p >= (int)parts.size()) fail(DFGPU_INTERNAL, "MemoryExec invalid partition %d (expected less than %zu)", p, parts.size());
+    return std::unique_ptr<Stream>(new VecStream(parts[(size_t)p]));
+  }
+};
+
+static ArrayRef known_mask(const TaskContext& tc, const ArrayRef& m) {     // NULL -> false before AND-ing selections
+  dfgpu_array_desc d; dfgpu_array_describe(m.a, &d);
+  if (!d.validity) return m;
+  dfgpu_array *nn = nullptr, *o = nullptr;
+  tc.check(dfgpu_is_null(tc.ctx, m.a, 1, &nn)); ArrayRef n1 = ArrayRef::adopt(nn);
+  tc.check(dfgpu_binary(tc.ctx, DFGPU_OP_AND, m.a, 0, n1.a, 0, &o)); return ArrayRef::adopt(o);
+}
+
+struct FilterExec : Plan {        // filter.rs:56-66, batch_filter :315-327
+  ExprPtr pred; PlanPtr input;
+  const char* name() const override { return "FilterExec"; }
+  SchemaPtr schema() const override { return input->schema(); }
+  int partitions() const override { return input->partitions(); }
+  struct S : Stream {
+    const FilterExec* op; std::unique_ptr<Stream> in; TaskContext tc;
+    S(const FilterExec* o, std::unique_ptr<Stream> i, TaskContext t) : op(o), in(std::move(i)), tc(t) {}
+    bool next(Batch& out) override {
+      Batch b; if (!in->next(b)) return false;
+      if (b.selection && !op->pred->safe()) b = materialize(tc, b);
+      Value v = op->pred->eval(tc, b);
+      ArrayRef mask = into_array(tc, v, b.base_rows);
+      dfgpu_array_desc d; dfgpu_array_describe(mask.a, &d);
+      if (d.type != DFGPU_BOOL) fail(DFGPU_INTERNAL, "Cannot create filter_array from non-boolean predicates");
+      if (b.selection) { ArrayRef km = known_mask(tc, mask); dfgpu_array* o = nullptr; tc.check(dfgpu_binary(tc.ctx, DFGPU_OP_AND, km.a, 0, b.selection.a, 0, &o)); mask = ArrayRef::adopt(o); }
+      b.selection = mask; out = std::move(b); return true;
+    }
+  };
+  std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override { return std::unique_ptr<Stream>(new S(this, input->execute(p, tc), tc)); }
+};
+
+static Batch materialize_subset(const TaskContext& tc, Batch& b, const std::set<int>& needed) {   // compact only referenced columns
+  ArrayRef sel = mask_indices(tc, b.selection);
+  Batch o; o.schema = b.schema; o.base_rows = sel.len();
+  ArrayRef filler;
+  for (size_t i = 0; i < b.cols.size(); i++) {
+    if (needed.count((int)i)) o.cols.push_back(col_take(tc, b.cols[i], sel));
+    else { if (!filler) { dfgpu_array* f = nullptr; tc.check(dfgpu_array_new_null(tc.ctx, DFGPU_INT8, 0, 0, o.base_rows, &f)); filler = ArrayRef::adopt(f); } o.cols.push_back(col_of(filler)); }
+  }
+  return o;
+}
+
+struct ProjectionExec : Plan {    // projection.rs:52-62, batch_project :295-317
+  std::vector<ExprPtr> exprs; std::vector<std::string> names; PlanPtr input; mutable SchemaPtr sch; mutable std::mutex mu;
+  const char* name() const override { return "ProjectionExec"; }
+  SchemaPtr schema() const override {
+    std::lock_guard<std::mutex> l(mu);
+    if (!sch) { auto s = std::make_shared<Schema>(); auto in = input->schema();
+      for (size_t i = 0; i < exprs.size(); i++) { int ci = exprs[i]->column_index(); Field f = (ci >= 0 && in && ci < (int)in->f.size()) ? in->f[(size_t)ci] : Field{}; f.name = names[i]; s->f.push_back(f); }
+      sch = s; }
+    return sch;
+  }
+  int partitions() const override { return input->partitions(); }
+  struct S : Stream {
+    const ProjectionExec* op; std::unique_ptr<Stream> in; TaskContext tc;
+    S(const ProjectionExec* o, std::unique_ptr<Stream> i, TaskContext t) : op(o), in(std::move(i)), tc(t) {}
+    bool next(Batch& out) override {
+      Batch b; if (!in->next(b)) return false;
+      bool only_columns = true; for (auto& e : op->exprs) only_columns &= e->column_index() >= 0;
+      if (b.selection && !only_columns) { std::set<int> need; for (auto& e : op->exprs) e->columns(need); b = materialize_subset(tc, b, need); }
+      Batch o; o.base_rows = b.base_rows; o.selection = b.selection; auto s = std::make_shared<Schema>();
+      for (size_t i = 0; i < op->exprs.size(); i++) {
+        int ci = op->exprs[i]->column_index();
+        if (ci >= 0) {                 // Column = Arc clone in the reference: pass the (possibly lazy) column through
+          if (ci >= (int)b.cols.size()) fail(DFGPU_INTERNAL, "PhysicalExpr Column references column at index %d but input schema only has %zu columns", ci, b.cols.size());
+          o.cols.push_back(b.cols[(size_t)ci]); Field f = b.schema->f[(size_t)ci]; f.name = op->names[i]; s->f.push_back(f);
+        } else { ArrayRef a = into_array(tc, op->exprs[i]->eval(tc, b), b.base_rows); s->f.push_back(field_of(op->names[i], a.a)); o.cols.push_back(col_of(a)); }
+      }
+      o.schema = s; { std::lock_guard<std::mutex> l(op->mu); op->sch = s; }
+      out = std::move(o); return true;
+    }
+  };
+  std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override { return std::unique_ptr<Stream>(new S(this, input->execute(p, tc), tc)); }
+};
+
+struct CoalesceBatchesExec : Plan {    // coalesce_batches.rs:198-260
+  PlanPtr input; int64_t target;
+  const char* name() const override { return "CoalesceBatchesExec"; }
+  SchemaPtr schema() const override { return input->schema(); }
+  int partitions() const override { return input->partitions(); }
+  struct S : Stream {
+    const CoalesceBatchesExec* op; std::unique_ptr<Stream> in; TaskContext tc; std::vector<Batch> buf; int64_t rows = 0; bool done = false;
+    S(const CoalesceBatchesExec* o, std::unique_ptr<Stream> i, TaskContext t) : op(o), in(std::move(i)), tc(t) {}
+    bool flush(Batch& out) { bool ok = concat_batches(tc, buf, &out); buf.clear(); rows = 0; return ok; }
+    bool next(Batch& out) override {
+      while (!done) {
+        Batch b; if (!in->next(b)) { done = true; break; }
+        if (b.selection) { if (b.base_rows >= op->target) { out = std::move(b); return true; } b = materialize(tc, b); }   // device mega-batch: keep the fused mask
+        if (b.base_rows == 0) continue;
+        if (b.base_rows >= op->target && buf.empty()) { out = std::move(b); return true; }
+        rows += b.base_rows; buf.push_back(std::move(b));
+        if (rows >= op->target) return flush(out);
+      }
+      if (!buf.empty()) return flush(out);
+      return false;
+    }
+  };
+  std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override { return std::unique_ptr<Stream>(new S(this, input->execute(p, tc), tc)); }
+};
+
+struct CoalescePartitionsExec : Plan {   // coalesce_partitions.rs
+  PlanPtr input;
+  const char* name() const override { return "CoalescePartitionsExec"; }
+  SchemaPtr schema() const override { return input->schema(); }
+  int partitions() const override { return 1; }
+  std::unique_ptr<Stream> execute(int, const TaskContext& tc) const override {
+    std::vector<Batch> all; for (int p = 0; p < input->partitions(); p++) drain(input, p, tc, all);
+    return std::unique_ptr<Stream>(new VecStream(std::move(all)));
+  }
+};
+
+// ≙ BatchPartitioner::partition_iter for Partitioning::Hash (repartition/mod.rs:148-221); honours a fused selection
+static void partition_batch(const TaskContext& tc, Batch& b, const std::vector<ExprPtr>& exprs, int n, std::vector<std::vector<Batch>>& outs) {
+  ArrayRef sel; Batch kb = b;
+  if (b.selection) { std::set<int> need; for (auto& e : exprs) e->columns(need); sel = mask_indices(tc, b.selection); kb = materialize_subset(tc, b, need); }
+  if (kb.base_rows == 0) return;
+  std::vector<ArrayRef> keys; std::vector<const dfgpu_array*> kp;
+  for (auto& e : exprs) { keys.push_back(into_array(tc, e->eval(tc, kb), kb.base_rows)); kp.push_back(keys.back().a); }
+  std::vector<int64_t> counts((size_t)n); dfgpu_array* idx = nullptr;
+  tc.check(dfgpu_hash_partition(tc.ctx, kp.data(), (int32_t)kp.size(), n, &idx, counts.data()));
+  ArrayRef indices = ArrayRef::adopt(idx); int64_t off = 0;
+  for (int d = 0; d < n; d++) {
+    if (counts[(size_t)d]) {
+      dfgpu_array* s = nullptr; tc.check(dfgpu_array_slice(tc.ctx, indices.a, off, counts[(size_t)d], &s)); ArrayRef part = ArrayRef::adopt(s);
+      ArrayRef rows = sel ? take(tc, sel, part) : part;
+      Batch o; o.schema = b.schema; o.base_rows = counts[(size_t)d];
+      for (auto& c : b.cols) o.cols.push_back(col_take(tc, c, rows));
+      outs[(size_t)d].push_back(std::move(o));
+    }
+    off += counts[(size_t)d];
+  }
+}
+
+struct RepartitionExec : Plan {   // repartition/mod.rs:232-294; all inputs are pulled once, outputs cached per partition
+  PlanPtr input; std::vector<ExprPtr> exprs; int n;
+  mutable std::mutex mu; mutable bool ran = false; mutable std::vector<std::vector<Batch>> outs;
+  const char* name() const override { return "RepartitionExec"; }
+  SchemaPtr schema() const override { return input->schema(); }
+  int partitions() const override { return n; }
+  std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override {
+    std::lock_guard<std::mutex> l(mu);
+    if (!ran) {
+      outs.assign((size_t)n, {}); int rr = 0;
+      for (int ip = 0; ip < input->partitions(); ip++) {
+        std::vector<Batch> in; drain(input, ip, tc, in);
+        for (auto& b : in) {
+          if (exprs.empty()) { Batch m = materialize(tc, b); if (m.base_rows) outs[(size_t)(rr++ % n)].push_back(std::move(m)); }   // RoundRobinBatch
+          else partition_batch(tc, b, exprs, n, outs);
+        }
+      }
+      ran = true;
+    }
+    if (p < 0 || p >= n) fail(DFGPU_INTERNAL, "RepartitionExec invalid partition %d", p);
+    return std::unique_ptr<Stream>(new VecStream(outs[(size_t)p]));
+  }
+};
+
+// ------------------------------------------------------------------ HashJoinExec
+struct JoinTableRef { dfgpu_join_table* t = nullptr; ~JoinTableRef() { if (t) dfgpu_join_table_free(t); } };
+struct BuildSide { Batch batch; std::shared_ptr<JoinTableRef> table; std::vector<int64_t> segments; bool empty = true; };
+
+struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
+  PlanPtr left, right; std::vector<ExprPtr> on_l, on_r; ExprPtr filter; std::vector<int> f_side, f_index;
+  int join_type, mode; bool null_equals_null;
+  mutable std::mutex mu; mutable std::shared_ptr<BuildSide> shared;     // CollectLeft: OnceAsync (joins/utils.rs:736-776)
+  const char* name() const override { return "HashJoinExec"; }
+  bool left_only() const { return join_type == DFGPU_JOIN_LEFT_SEMI || join_type == DFGPU_JOIN_LEFT_ANTI; }
+  bool right_only() const { return join_type == DFGPU_JOIN_RIGHT_SEMI || join_type == DFGPU_JOIN_RIGHT_ANTI; }
+  SchemaPtr schema() const override {       // build_join_schema (joins/utils.rs:657-729)
+    auto s = std::make_shared<Schema>(); auto l = left->schema(), r = right->schema();
+    if (!right_only() && l) s->f.insert(s->f.end(), l->f.begin(), l->f.end());
+    if (!left_only() && r) s->f.insert(s->f.end(), r->f.begin(), r->f.end());
+    return s;
+  }
+  int partitions() const override { return right->partitions(); }
+  // collect_left_input (hash_join.rs:678-768); the device table indexes the build side in ORIGINAL input order
+  std::shared_ptr<BuildSide> collect_build(int partition, const TaskContext& tc) const {
+    auto bs = std::make_shared<BuildSide>();
+    std::vector<Batch> in;
+    if (partition < 0) { for (int p = 0; p < left->partitions(); p++) drain(left, p, tc, in); } else drain(left, partition, tc, in);
+    ArrayRef fused;
+    if (in.size() == 1 && in[0].selection) { bs->batch = in[0]; fused = in[0].selection; bs->batch.selection = ArrayRef(); bs->segments = { bs->batch.base_rows }; bs->empty = false; }
+    else {
+      std::vector<Batch> m; for (auto& b : in) { Batch x = materialize(tc, b); if (x.base_rows) { bs->segments.push_back(x.base_rows); m.push_back(std::move(x)); } }
+      if (m.empty()) return bs;
+      concat_batches(tc, m, &bs->batch); bs->empty = false;
+    }
+    std::vector<ArrayRef> keys; std::vector<const dfgpu_array*> kp;
+    for (auto& e : on_l) { keys.push_back(into_array(tc, e->eval(tc, bs->batch), bs->batch.base_rows)); kp.push_back(keys.back().a); }
+    bs->table = std::make_shared<JoinTableRef>();
+    tc.check(dfgpu_join_build(tc.ctx, kp.data(), (int32_t)kp.size(), fused.a, null_equals_null ? 1 : 0, &bs->table->t));
+    return bs;
+  }
+  struct S : Stream {
+    const HashJoinExec* op; TaskContext tc; int partition; std::unique_ptr<Stream> probe; std::shared_ptr<BuildSide> bs; int state = 0;   // 0 WaitBuildSide, 1 probing, 2 done
+    SchemaPtr out_schema;
+    S(const HashJoinExec* o, int p, TaskContext t) : op(o), tc(t), partition(p) {}
+    ArrayRef filter_idx(const ArrayRef& idx, const ArrayRef& m) { dfgpu_array* o = nullptr; tc.check(dfgpu_filter(tc.ctx, idx.a, m.a, &o)); return ArrayRef::adopt(o); }
+    Batch build_batch(Batch* build, Batch& probe_b, const ArrayRef& bidx, const ArrayRef& pidx) {     // build_batch_from_indices (joins/utils.rs:1180-1230)
+      Batch o; o.schema = out_schema; o.base_rows = pidx.len();
+      auto lf = op->left->schema();
+      if (!op->right_only()) for (size_t i = 0; i < (lf ? lf->f.size() : 0); i++) {
+        if (build) o.cols.push_back(col_take(tc, build->cols[i], bidx));
+        else { dfgpu_array* nn = nullptr; tc.check(dfgpu_array_new_null(tc.ctx, lf->f[i].type, lf->f[i].precision, lf->f[i].scale, o.base_rows, &nn)); o.cols.push_back(col_of(ArrayRef::adopt(nn))); }
+      }
+      if (!op->left_only()) for (auto& c : probe_b.cols) o.cols.push_back(col_take(tc, c, pidx));
+      return o;
+    }
+    bool next(Batch& out) override {
+      if (state == 0) {           // WaitBuildSide (hash_join.rs:1149-1193)
+        if (op->mode == 0) { std::lock_guard<std::mutex> l(op->mu); if (!op->shared) op->shared = op->collect_build(-1, tc); bs = op->shared; }
+        else bs = op->collect_build(partition, tc);
+        probe = op->right->execute(partition, tc); out_schema = op->schema(); state = 1;
+      }
+      bool need_final = op->join_type == DFGPU_JOIN_LEFT || op->join_type == DFGPU_JOIN_FULL || op->left_only();     // need_produce_result_in_final
+      while (state == 1) {        // FetchProbeBatch / ProcessProbeBatch (:1199-1343)
+        Batch pb; if (!probe->next(pb)) { state = 2; break; }
+        if (pb.base_rows == 0) continue;
+        ArrayRef mask = pb.selection; pb.selection = ArrayRef();
+        ArrayRef bidx, pidx;
+        if (bs->empty) { dfgpu_array *a = nullptr, *b = nullptr; dfgpu_array_desc d{}; d.type = DFGPU_UINT64; d.values = &d; tc.check(dfgpu_array_import_host(tc.ctx, &d, &a)); d.type = DFGPU_UINT32; tc.check(dfgpu_array_import_host(tc.ctx, &d, &b)); bidx = ArrayRef::adopt(a); pidx = ArrayRef::adopt(b); }
+        else {
+          std::vector<ArrayRef> keys; std::vector<const dfgpu_array*> kp;
+          for (auto& e : op->on_r) { keys.push_back(into_array(tc, e->eval(tc, pb), pb.base_rows)); kp.push_back(keys.back().a); }
+          dfgpu_array *b = nullptr, *p = nullptr;
+          tc.check(dfgpu_join_probe(tc.ctx, bs->table->t, kp.data(), (int32_t)kp.size(), mask.a, &b, &p)); bidx = ArrayRef::adopt(b); pidx = ArrayRef::adopt(p);
+          if (op->filter && bidx.len()) {     // apply_join_filter_to_indices (joins/utils.rs:1143-1176)
+            Batch inter; inter.schema = std::make_shared<Schema>(); inter.base_rows = bidx.len();
+            for (size_t i = 0; i < op->f_side.size(); i++) {
+              Col src = op->f_side[i] == 0 ? bs->batch.cols.at((size_t)op->f_index[i]) : pb.cols.at((size_t)op->f_index[i]);
+              Col t = col_take(tc, src, op->f_side[i] == 0 ? bidx : pidx); inter.cols.push_back(col_of(col_get(tc, t))); inter.schema->f.push_back(Field{"x"});
+            }
+            ArrayRef m = into_array(tc, op->filter->eval(tc, inter), inter.base_rows);
+            ArrayRef nb = filter_idx(bidx, m), np = filter_idx(pidx, m); bidx = nb; pidx = np;
+          }
+          if (need_final) tc.check(dfgpu_join_mark_visited(tc.ctx, bs->table->t, bidx.a));
+        }
+        int jt = op->join_type;
+        if (jt == DFGPU_JOIN_RIGHT || jt == DFGPU_JOIN_FULL || op->right_only()) {
+          if (mask) fail(DFGPU_NOT_IMPLEMENTED, "Right/Full/RightSemi/RightAnti join over a fused probe-side selection; materialise the probe input (CoalesceBatchesExec)");
+          dfgpu_array *b2 = nullptr, *p2 = nullptr;
+          tc.check(dfgpu_join_adjust_indices(tc.ctx, bidx.a, pidx.a, 0, pb.base_rows, jt, &b2, &p2)); bidx = ArrayRef::adopt(b2); pidx = ArrayRef::adopt(p2);
+        } else if (op->left_only()) continue;
+        out = build_batch(bs->empty ? nullptr : &bs->batch, pb, bidx, pidx); return true;
+      }
+      if (state == 2) {           // ExhaustedProbeSide -> process_unmatched_build_batch (:1348-1388)
+        state = 3;
+        if (!need_final || bs->empty) return false;
+        dfgpu_array* f = nullptr; tc.check(dfgpu_join_final_indices(tc.ctx, bs->table->t, op->join_type, &f)); ArrayRef fidx = ArrayRef::adopt(f);
+        fidx = reference_final_order(fidx);
+        Batch o; o.schema = out_schema; o.base_rows = fidx.len();
+        for (auto& c : bs->batch.cols) o.cols.push_back(col_take(tc, c, fidx));
+        if (!op->left_only()) { auto rf = op->right->schema(); for (auto& fd : rf->f) { dfgpu_array* nn = nullptr; tc.check(dfgpu_array_new_null(tc.ctx, fd.type, fd.precision, fd.scale, o.base_rows, &nn)); o.cols.push_back(col_of(ArrayRef::adopt(nn))); } }
+        out = std::move(o); return true;
+      }
+      return false;
+    }
+    // The reference concatenates the build batches in REVERSED order (hash_join.rs:746,764) and emits the final
+    // unmatched / semi rows in ascending index of THAT batch (joins/utils.rs:1119-1141): last input batch first.
+    ArrayRef reference_final_order(const ArrayRef& fidx) {
+      if (bs->segments.size() <= 1 || fidx.len() == 0) return fidx;
+      int64_t n = fidx.len(); std::vector<uint64_t> h((size_t)n);
+      tc.check(dfgpu_array_export_host(tc.ctx, fidx.a, h.data(), nullptr, nullptr));
+      std::vector<int64_t> bounds{0}; for (auto s : bs->segments) bounds.push_back(bounds.back() + s);
+      std::vector<uint64_t> o; o.reserve((size_t)n);
+      for (size_t s = bs->segments.size(); s-- > 0;) for (auto v : h) if ((int64_t)v >= bounds[s] && (int64_t)v < bounds[s + 1]) o.push_back(v);
+      dfgpu_array_desc d{}; d.type = DFGPU_UINT64; d.length = n; d.values = o.data();
+      dfgpu_array* a = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &d, &a)); return ArrayRef::adopt(a);
+    }
+  };
+  std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override { return std::unique_ptr<Stream>(new S(this, p, tc)); }
+};
+
+// ------------------------------------------------------------------ AggregateExec
+struct AggExpr { int kind; ExprPtr arg, filter; std::string name; int32_t type, precision, scale; };    // ≙ AggregateExpr for Sum/Avg/Count/Min/Max
+struct GroupsRef { dfgpu_groups* g = nullptr; ~GroupsRef() { if (g) dfgpu_groups_free(g); } };
+struct AccRef { dfgpu_acc* a = nullptr; ~AccRef() { if (a) dfgpu_acc_free(a); } };
+static const char* agg_fun_name(int k) { switch (k) { case DFGPU_AGG_SUM: return "sum"; case DFGPU_AGG_AVG: return "avg"; case DFGPU_AGG_COUNT: return "count"; case DFGPU_AGG_MIN: return "min"; default: return "max"; } }
+
+struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggregateStream row_hash.rs:423-662
+  int mode; std::vector<ExprPtr> gexprs; std::vector<std::string> gnames; std::vector<AggExpr> aggs; PlanPtr input; mutable SchemaPtr sch; mutable std::mutex mu;
+  const char* name() const override { return "AggregateExec"; }
+  bool merging() const { return mode == 1 || mode == 2; }
+  std::vector<std::string> out_names() const {
+    std::vector<std::string> n = gnames;
+    for (auto& a : aggs) { if (mode == 0) { if (a.kind == DFGPU_AGG_AVG) { n.push_back(a.name + "[count]"); n.push_back(a.name + "[sum]"); } else n.push_back(a.name + "[" + agg_fun_name(a.kind) + "]"); } else n.push_back(a.name); }
+    return n;
+  }
+  SchemaPtr schema() const override { std::lock_guard<std::mutex> l(mu); if (!sch) { auto s = std::make_shared<Schema>(); for (auto& n : out_names()) s->f.push_back(Field{n}); sch = s; } return sch; }
+  int partitions() const override { return (mode == 1 || mode == 3) ? 1 : input->partitions(); }
+  std::unique_ptr<Stream> execute(int partition, const TaskContext& tc) const override {
+    if (gexprs.empty()) fail(DFGPU_NOT_IMPLEMENTED, "AggregateExec without GROUP BY (AggregateStream, no_grouping.rs) is not on the device path yet");
+    std::vector<Batch> in;
+    if (mode == 1 || mode == 3) { for (int p = 0; p < input->partitions(); p++) drain(input, p, tc, in); } else drain(input, partition, tc, in);
+    GroupsRef groups; tc.check(dfgpu_groups_new(tc.ctx, (int32_t)gexprs.size(), &groups.g));
+    std::vector<AccRef> accs(aggs.size());
+    for (size_t i = 0; i < aggs.size(); i++) {
+      int32_t t = aggs[i].kind == DFGPU_AGG_COUNT ? DFGPU_INT64 : aggs[i].type;
+      tc.check(dfgpu_acc_new(tc.ctx, aggs[i].kind, t, aggs[i].precision, aggs[i].scale, &accs[i].a));
+    }
+    for (auto& b : in) {          // group_aggregate_batch (row_hash.rs:524-613)
+      if (b.base_rows == 0) continue;
+      ArrayRef mask = b.selection; b.selection = ArrayRef();
+      std::vector<ArrayRef> gc; std::vector<const dfgpu_array*> gp;
+      for (auto& e : gexprs) { gc.push_back(into_array(tc, e->eval(tc, b), b.base_rows)); gp.push_back(gc.back().a); }
+      dfgpu_array* ids = nullptr; tc.check(dfgpu_groups_intern(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids)); ArrayRef gids = ArrayRef::adopt(ids);
+      int64_t total = dfgpu_groups_len(groups.g); size_t col = gexprs.size();
+      for (size_t i = 0; i < aggs.size(); i++) {
+        if (merging()) {
+          int nst = aggs[i].kind == DFGPU_AGG_AVG ? 2 : 1; const dfgpu_array* st[2];
+          for (int k = 0; k < nst; k++) st[k] = b.column(tc, (int)(col + (size_t)k)).a;
+          col += (size_t)nst;
+          tc.check(dfgpu_acc_merge_batch(tc.ctx, accs[i].a, st, nst, gids.a, nullptr, total));
+        } else {
+          ArrayRef vals, filt;
+          if (aggs[i].arg) vals = into_array(tc, aggs[i].arg->eval(tc, b), b.base_rows);
+          if (aggs[i].filter) filt = into_array(tc, aggs[i].filter->eval(tc, b), b.base_rows);
+          tc.check(dfgpu_acc_update_batch(tc.ctx, accs[i].a, vals.a, gids.a, filt.a, total));
+        }
+      }
+    }
+    std::vector<Batch> outv; int64_t total = dfgpu_groups_len(groups.g);
+    if (total > 0) {              // emit(EmitTo::All) (row_hash.rs:626-662)
+      Batch o; o.base_rows = total; std::vector<dfgpu_array*> keys(gexprs.size(), nullptr);
+      tc.check(dfgpu_groups_emit(tc.ctx, groups.g, keys.data()));
+      for (auto k : keys) o.cols.push_back(col_of(ArrayRef::adopt(k)));
+      dfgpu_array_desc ed{}; ed.type = DFGPU_UINT32; ed.values = &ed; dfgpu_array* e = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &ed, &e)); ArrayRef empty_ids = ArrayRef::adopt(e);
+      for (size_t i = 0; i < aggs.size(); i++) {
+        tc.check(dfgpu_acc_update_batch(tc.ctx, accs[i].a, nullptr, empty_ids.a, nullptr, total));      // zero-row update: grow the state to `total` groups
+        if (mode == 0) { dfgpu_array* st[2] = {nullptr, nullptr}; int32_t n = 0; tc.check(dfgpu_acc_state(tc.ctx, accs[i].a, st, &n)); for (int k = 0; k < n; k++) o.cols.push_back(col_of(ArrayRef::adopt(st[k]))); }
+        else { dfgpu_array* v = nullptr; tc.check(dfgpu_acc_evaluate(tc.ctx, accs[i].a, &v)); o.cols.push_back(col_of(ArrayRef::adopt(v))); }
+      }
+      auto s = std::make_shared<Schema>(); auto names = out_names();
+      for (size_t i = 0; i < o.cols.size(); i++) s->f.push_back(field_of(names[i], o.cols[i].arr.a));
+      o.schema = s; { std::lock_guard<std::mutex> l(mu); sch = s; }
+      outv.push_back(std::move(o));
+    }
+    return std::unique_ptr<Stream>(new VecStream(std::move(outv)));
+  }
+};
+
+// ------------------------------------------------------------------ SortExec
+struct SortExec : Plan {          // sorts/sort.rs:719-733; sort_batch :584-609
+  std::vector<ExprPtr> exprs; std::vector<uint8_t> desc, nulls_first; int64_t fetch; bool preserve; PlanPtr input;
+  const char* name() const override { return "SortExec"; }
+  SchemaPtr schema() const override { return input->schema(); }
+  int partitions() const override { return preserve ? input->partitions() : 1; }
+  std::unique_ptr<Stream> execute(int partition, const TaskContext& tc) const override {
+    std::vector<Batch> in;
+    if (preserve) drain(input, partition, tc, in); else for (int p = 0; p < input->partitions(); p++) drain(input, p, tc, in);
+    std::vector<Batch> outv; Batch b;
+    if (!in.empty() && concat_batches(tc, in, &b) && b.base_rows > 0) {
+      std::vector<ArrayRef> keys; std::vector<const dfgpu_array*> kp;
+      for (auto& e : exprs) { keys.push_back(into_array(tc, e->eval(tc, b), b.base_rows)); kp.push_back(keys.back().a); }
+      dfgpu_array* idx = nullptr; tc.check(dfgpu_sort_to_indices(tc.ctx, kp.data(), desc.data(), nulls_first.data(), (int32_t)kp.size(), fetch, &idx)); ArrayRef ix = ArrayRef::adopt(idx);
+      Batch o; o.schema = b.schema; o.base_rows = ix.len();
+      for (auto& c : b.cols) o.cols.push_back(col_take(tc, c, ix));
+      outv.push_back(std::move(o));
+    }
+    return std::unique_ptr<Stream>(new VecStream(std::move(outv)));
+  }
+};
+
+}  // namespace dfx
+
+// ==================================================================== C ABI
+using namespace dfx;
+struct dfgpu_expr { ExprPtr e; };
+struct dfgpu_plan { PlanPtr p; };
+struct dfgpu_batch { Batch b; };
+struct dfgpu_stream { std::unique_ptr<Stream> s; PlanPtr keep; TaskContext tc; };
+
+template <typename F> static dfgpu_status guard(F&& f) {
+  try { f(); return DFGPU_OK; }
+  catch (const Err& e) { g_err = e.msg; return e.code; }
+  catch (const std::bad_alloc&) { g_err = "host allocation failed"; return DFGPU_RESOURCES_EXHAUSTED; }
+  catch (const std::exception& e) { g_err = e.what(); return DFGPU_INTERNAL; }
+}
+static ExprPtr ex(const dfgpu_expr* e) { if (!e) fail(DFGPU_INVALID_ARGUMENT, "null expression"); return e->e; }
+static PlanPtr pl(const dfgpu_plan* p) { if (!p) fail(DFGPU_INVALID_ARGUMENT, "null plan"); return p->p; }
+
+extern "C" {
+
+const char* dfgpu_exec_last_error(void) { return g_err.c_str(); }
+
+dfgpu_status dfgpu_batch_new(const char* const* names, const dfgpu_array* const* columns, int32_t ncols, dfgpu_batch** out) {
+  return guard([&] {
+    if (ncols < 0 || !out) fail(DFGPU_INVALID_ARGUMENT, "batch_new: bad arguments");
+    auto* b = new dfgpu_batch(); b->b.schema = std::make_shared<Schema>();
+    for (int i = 0; i < ncols; i++) {
+      if (!columns[i]) { delete b; fail(DFGPU_INVALID_ARGUMENT, "batch_new: null column"); }
+      if (i && dfgpu_array_length(columns[i]) != dfgpu_array_length(columns[0])) { delete b; fail(DFGPU_INVALID_ARGUMENT, "batch_new: columns differ in length"); }
+      b->b.cols.push_back(col_of(ArrayRef::share(columns[i]))); b->b.schema->f.push_back(field_of(names && names[i] ? names[i] : "", columns[i]));
+    }
+    b->b.base_rows = ncols ? dfgpu_array_length(columns[0]) : 0;
+    *out = b;
+  });
+}
+void dfgpu_batch_free(dfgpu_batch* b) { delete b; }
+int32_t dfgpu_batch_num_columns(const dfgpu_batch* b) { return b ? (int32_t)b->b.cols.size() : 0; }
+const char* dfgpu_batch_column_name(const dfgpu_batch* b, int32_t i) { return (b && i >= 0 && i < (int)b->b.schema->f.size()) ? b->b.schema->f[(size_t)i].name.c_str() : ""; }
+dfgpu_status dfgpu_batch_num_rows(dfgpu_ctx* ctx, dfgpu_batch* b, int64_t* out) { return guard([&] { TaskContext tc{ctx, 8192}; *out = num_rows(tc, b->b); }); }
+dfgpu_status dfgpu_batch_column(dfgpu_ctx* ctx, dfgpu_batch* b, int32_t i, dfgpu_array** out) {
+  return guard([&] {
+    TaskContext tc{ctx, 8192};
+    if (b->b.selection) b->b = materialize(tc, b->b);
+    const ArrayRef& a = b->b.column(tc, i); dfgpu_array_retain(a.a); *out = a.a;
+  });
+}
+
+dfgpu_status dfgpu_expr_column(const char* name, int32_t index, dfgpu_expr** out) { return guard([&] { *out = new dfgpu_expr{std::make_shared<ColumnExpr>(name ? name : "", index)}; }); }
+dfgpu_status dfgpu_expr_literal(const dfgpu_array* s, dfgpu_expr** out) {
+  return guard([&] { if (!s || dfgpu_array_length(s) != 1) fail(DFGPU_INVALID_ARGUMENT, "literal must be a length-1 array"); *out = new dfgpu_expr{std::make_shared<LiteralExpr>(ArrayRef::share(s))}; });
+}
+dfgpu_status dfgpu_expr_binary(const dfgpu_expr* l, int32_t op, const dfgpu_expr* r, dfgpu_expr** out) { return guard([&] { *out = new dfgpu_expr{std::make_shared<BinaryExpr>(ex(l), op, ex(r))}; }); }
+static dfgpu_status unary(const dfgpu_expr* e, int kind, int a0, int a1, int a2, const dfgpu_array* list, dfgpu_expr** out) {
+  return guard([&] { auto u = std::make_shared<UnaryExpr>(); u->e = ex(e); u->kind = kind; u->a0 = a0; u->a1 = a1; u->a2 = a2; if (list) u->list = ArrayRef::share(list); *out = new dfgpu_expr{u}; });
+}
+dfgpu_status dfgpu_expr_not(const dfgpu_expr* e, dfgpu_expr** out) { return unary(e, 0, 0, 0, 0, nullptr, out); }
+dfgpu_status dfgpu_expr_is_null(const dfgpu_expr* e, int32_t negated, dfgpu_expr** out) { return unary(e, negated ? 2 : 1, 0, 0, 0, nullptr, out); }
+dfgpu_status dfgpu_expr_negative(const dfgpu_expr* e, dfgpu_expr** out) { return unary(e, 3, 0, 0, 0, nullptr, out); }
+dfgpu_status dfgpu_expr_cast(const dfgpu_expr* e, int32_t t, int32_t p, int32_t s, dfgpu_expr** out) { return unary(e, 4, t, p, s, nullptr, out); }
+dfgpu_status dfgpu_expr_in_list(const dfgpu_expr* e, const dfgpu_array* list, int32_t negated, dfgpu_expr** out) { return unary(e, negated ? 6 : 5, 0, 0, 0, list, out); }
+void dfgpu_expr_free(dfgpu_expr* e) { delete e; }
+
+dfgpu_status dfgpu_plan_memory(const dfgpu_batch* const* batches, const int32_t* sizes, int32_t nparts, dfgpu_plan** out) {
+  return guard([&] {
+    auto m = std::make_shared<MemoryExec>(); int k = 0;
+    for (int p = 0; p < nparts; p++) { m->parts.emplace_back(); for (int i = 0; i < sizes[p]; i++) { const dfgpu_batch* b = batches[k++]; if (!b) fail(DFGPU_INVALID_ARGUMENT, "null batch"); if (!m->sch) m->sch = b->b.schema; m->parts.back().push_back(b->b); } }
+    if (!m->sch) m->sch = std::make_shared<Schema>();
+    *out = new dfgpu_plan{m};
+  });
+}
+dfgpu_status dfgpu_plan_filter(const dfgpu_expr* pred, const dfgpu_plan* input, dfgpu_plan** out) { return guard([&] { auto f = std::make_shared<FilterExec>(); f->pred = ex(pred); f->input = pl(input); *out = new dfgpu_plan{f}; }); }
+dfgpu_status dfgpu_plan_projection(const dfgpu_expr* const* exprs, const char* const* names, int32_t n, const dfgpu_plan* input, dfgpu_plan** out) {
+  return guard([&] { auto p = std::make_shared<ProjectionExec>(); for (int i = 0; i < n; i++) { p->exprs.push_back(ex(exprs[i])); p->names.push_back(names[i] ? names[i] : ""); } p->input = pl(input); *out = new dfgpu_plan{p}; });
+}
+dfgpu_status dfgpu_plan_coalesce_batches(const dfgpu_plan* input, int64_t target, dfgpu_plan** out) { return guard([&] { auto c = std::make_shared<CoalesceBatchesExec>(); c->input = pl(input); c->target = target; *out = new dfgpu_plan{c}; }); }
+dfgpu_status dfgpu_plan_coalesce_partitions(const dfgpu_plan* input, dfgpu_plan** out) { return guard([&] { auto c = std::make_shared<CoalescePartitionsExec>(); c->input = pl(input); *out = new dfgpu_plan{c}; }); }
+dfgpu_status dfgpu_plan_repartition(const dfgpu_plan* input, const dfgpu_expr* const* exprs, int32_t nexprs, int32_t n, dfgpu_plan** out) {
+  return guard([&] { if (n < 1) fail(DFGPU_INVALID_ARGUMENT, "repartition: partition count must be positive"); auto r = std::make_shared<RepartitionExec>(); r->input = pl(input); r->n = n; for (int i = 0; i < nexprs; i++) r->exprs.push_back(ex(exprs[i])); *out = new dfgpu_plan{r}; });
+}
+dfgpu_status dfgpu_plan_hash_join(const dfgpu_plan* left, const dfgpu_plan* right, const dfgpu_expr* const* on_left, const dfgpu_expr* const* on_right, int32_t non,
+                                  const dfgpu_expr* filter, const int32_t* fs, const int32_t* fi, int32_t nf, int32_t join_type, int32_t mode, int32_t nen, dfgpu_plan** out) {
+  return guard([&] {
+    if (non < 1) fail(DFGPU_EXECUTION, "Plan error: On constraints in HashJoinExec should be non-empty");       // hash_join.rs:303-305
+    if (join_type < 0 || join_type > DFGPU_JOIN_RIGHT_ANTI) fail(DFGPU_INVALID_ARGUMENT, "unknown join type %d", join_type);
+    auto j = std::make_shared<HashJoinExec>(); j->left = pl(left); j->right = pl(right);
+    for (int i = 0; i < non; i++) { j->on_l.push_back(ex(on_left[i])); j->on_r.push_back(ex(on_right[i])); }
+    if (filter) { j->filter = ex(filter); for (int i = 0; i < nf; i++) { j->f_side.push_back(fs[i]); j->f_index.push_back(fi[i]); } }
+    j->join_type = join_type; j->mode = mode; j->null_equals_null = nen != 0;
+    *out = new dfgpu_plan{j};
+  });
+}
+dfgpu_status dfgpu_plan_aggregate(int32_t mode, const dfgpu_expr* const* gexprs, const char* const* gnames, int32_t ng, const int32_t* kinds, const dfgpu_expr* const* args,
+                                  const dfgpu_expr* const* filters, const char* const* names, const int32_t* types, int32_t na, const dfgpu_plan* input, dfgpu_plan** out) {
+  return guard([&] {
+    if (mode < 0 || mode > 4) fail(DFGPU_INVALID_ARGUMENT, "unknown AggregateMode %d", mode);
+    auto a = std::make_shared<AggregateExec>(); a->mode = mode; a->input = pl(input);
+    for (int i = 0; i < ng; i++) { a->gexprs.push_back(ex(gexprs[i])); a->gnames.push_back(gnames[i] ? gnames[i] : ""); }
+    for (int i = 0; i < na; i++) {
+      AggExpr x; x.kind = kinds[i]; if (args && args[i]) x.arg = args[i]->e; if (filters && filters[i]) x.filter = filters[i]->e; x.name = names[i] ? names[i] : "";
+      x.type = types[3 * i]; x.precision = types[3 * i + 1]; x.scale = types[3 * i + 2];
+      if (x.kind < DFGPU_AGG_SUM || x.kind > DFGPU_AGG_MAX) fail(DFGPU_NOT_IMPLEMENTED, "aggregate kind %d has no GroupsAccumulator on device", x.kind);
+      if (!x.arg && x.kind != DFGPU_AGG_COUNT && mode != 1 && mode != 2) fail(DFGPU_INVALID_ARGUMENT, "aggregate %s needs an argument", x.name.c_str());
+      a->aggs.push_back(std::move(x));
+    }
+    *out = new dfgpu_plan{a};
+  });
+}
+dfgpu_status dfgpu_plan_sort(const dfgpu_expr* const* exprs, const uint8_t* desc, const uint8_t* nf, int32_t n, int64_t fetch, int32_t preserve, const dfgpu_plan* input, dfgpu_plan** out) {
+  return guard([&] {
+    if (n < 1) fail(DFGPU_INVALID_ARGUMENT, "Sort requires at least one column");
+    auto s = std::make_shared<SortExec>(); s->input = pl(input); s->fetch = fetch; s->preserve = preserve != 0;
+    for (int i = 0; i < n; i++) { s->exprs.push_back(ex(exprs[i])); s->desc.push_back(desc ? desc[i] : 0); s->nulls_first.push_back(nf ? nf[i] : 1); }
+    *out = new dfgpu_plan{s};
+  });
+}
+void dfgpu_plan_free(dfgpu_plan* p) { delete p; }
+int32_t dfgpu_plan_partition_count(const dfgpu_plan* p) { return p ? p->p->partitions() : 0; }
+int32_t dfgpu_plan_schema_len(const dfgpu_plan* p) { if (!p) return 0; auto s = p->p->schema(); return s ? (int32_t)s->f.size() : 0; }
+const char* dfgpu_plan_schema_name(const dfgpu_plan* p, int32_t i) {
+  static thread_local std::string name; if (!p) return ""; auto s = p->p->schema(); if (!s || i < 0 || i >= (int)s->f.size()) return ""; name = s->f[(size_t)i].name; return name.c_str();
+}
+const char* dfgpu_plan_name(const dfgpu_plan* p) { return p ? p->p->name() : ""; }
+
+dfgpu_status dfgpu_plan_execute(const dfgpu_plan* p, int32_t partition, dfgpu_ctx* ctx, int64_t batch_size, dfgpu_stream** out) {
+  return guard([&] {
+    if (!p || !ctx || !out) fail(DFGPU_INVALID_ARGUMENT, "plan_execute: null argument");
+    TaskContext tc{ctx, batch_size > 0 ? batch_size : 8192};
+    auto* s = new dfgpu_stream{nullptr, p->p, tc};
+    try { s->s = p->p->execute(partition, tc); } catch (...) { delete s; throw; }
+    *out = s;
+  });
+}
+dfgpu_status dfgpu_stream_next(dfgpu_stream* s, dfgpu_batch** out) {
+  return guard([&] { if (!s || !out) fail(DFGPU_INVALID_ARGUMENT, "stream_next: null argument"); Batch b; if (!s->s->next(b)) { *out = nullptr; return; } *out = new dfgpu_batch{std::move(b)}; });
+}
+void dfgpu_stream_free(dfgpu_stream* s) { delete s; }
+
+}  // extern "C"

@@ -85,7 +85,7 @@ def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=No
     its bitmap words per destination, and the receiver splices the per-source bitmaps at bit granularity."""
     import torch
     import torch.distributed as dist
-    from . import capi, operators as ops
+    from . import capi, operators as ops, physical_plan as pp
     world = dist.get_world_size(group)
     assert len(parts) == world
     counts = [0 if p is None else p.num_rows for p in parts]
@@ -132,7 +132,8 @@ def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=No
     vi = 0
     for c, f in enumerate(schema.fields):
         if not nullable[c]:
-            out_cols.append(ctx.wrap_tensor(recv[c], f.dtype, f.precision, f.scale))
+            # own the bytes: the torch receive buffer dies with this function, the column may outlive it inside a C++ plan
+            out_cols.append(ctx.concat([ctx.wrap_tensor(recv[c], f.dtype, f.precision, f.scale)]))
             continue
         segs = [vp[vi] for vp, n in zip(vparts, counts) if vp is not None and n]
         send = torch.cat(segs) if segs else torch.empty(0, dtype=torch.uint8, device="cuda")
@@ -150,10 +151,11 @@ def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=No
         d.values = recv[c].data_ptr() if total else 0
         if validity is not None:
             d.validity = validity.describe().values
-        out_cols.append(ctx.wrap_device(d, keepalive=(recv[c], validity, vrecv)) if total else ctx.wrap_tensor(recv[c], f.dtype, f.precision, f.scale))
+        view = ctx.wrap_device(d, keepalive=(recv[c], validity, vrecv)) if total else ctx.wrap_tensor(recv[c], f.dtype, f.precision, f.scale)
+        out_cols.append(ctx.concat([view]))          # owned copy (values + spliced validity)
         vi += 1
-    torch.cuda.current_stream().synchronize()      # consumers run on the ctx stream
-    return ops.RecordBatch(schema, out_cols, num_rows=total)
+    ctx.synchronize()                              # the owned copies are complete before the torch buffers are released
+    return pp.RecordBatch.from_arrays(ctx, schema.names(), out_cols)
 
 
 def gather_batches(ctx, schema, batch, dst: int = 0, group=None):
@@ -167,17 +169,18 @@ def gather_batches(ctx, schema, batch, dst: int = 0, group=None):
 
 class ShuffleExec:
     """RepartitionExec(Partitioning::Hash(exprs, world_size)) across GPUs: this rank's input rows are
-    hash-partitioned on device (dfgpu_hash_partition, same create_hashes on every rank), exchanged with one
-    all-to-all per column, and the rows received form output partition `rank`
-    (≙ physical-plan/src/repartition/mod.rs:232-294 with the channels replaced by RCCL over xGMI)."""
+    hash-partitioned on device by the C++ RepartitionExec (dfgpu_hash_partition, same create_hashes on every rank),
+    exchanged with one all-to-all per column, and the rows received form this rank's output partition
+    (≙ physical-plan/src/repartition/mod.rs:232-294 with the in-process channels replaced by RCCL over xGMI).
+    A Python-only node: the C++ plan above it sees a MemoryExec of the received rows (physical_plan._child_handle)."""
 
     def __init__(self, input, exprs, group=None):
         import torch.distributed as dist
-        from . import operators as ops
+        from . import physical_plan as pp
         self.input, self.exprs, self.group = input, list(exprs), group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self._ops = ops
+        self._pp = pp
         self.bytes_sent = 0
 
     def schema(self):
@@ -187,23 +190,49 @@ class ShuffleExec:
         return [self.input]
 
     def output_partitioning(self):
-        return self._ops.Partitioning.Hash(self.exprs, 1)      # one local output partition per rank
+        return self._pp.Partitioning.Hash(self.exprs, 1)      # one local output partition per rank
 
     def execute(self, partition, context):
-        ops = self._ops
-        parts = [[] for _ in range(self.world)]
-        schema = None
-        for p in range(self.input.output_partitioning().partition_count()):
-            for batch in self.input.execute(p, context):
-                schema = batch.schema
-                for dest, part in ops.partition_batch(batch, self.exprs, self.world):
-                    parts[dest].append(part)
-        if schema is None:
-            schema = self.input.schema()
-        merged = [ops.concat_batches(schema, ps) if ps else None for ps in parts]
-        for d, m in enumerate(merged):
-            if m is not None and d != self.rank:
-                self.bytes_sent += sum(_WIDTH.get(f.dtype, 0) for f in schema.fields) * m.num_rows
+        pp = self._pp
+        rep = pp.RepartitionExec(self.input, pp.Partitioning.Hash(self.exprs, self.world))
+        merged, schema = [], None
+        for d in range(self.world):
+            bs = [b for b in rep.execute(d, context) if b.num_rows]
+            m = pp.concat_batches(None, bs) if bs else None
+            if m is not None:
+                schema = m.schema
+                if d != self.rank:
+                    self.bytes_sent += sum(_WIDTH.get(f.dtype, 0) for f in schema.fields) * m.num_rows
+            merged.append(m)
+        schema = self._agree_schema(context.ctx, schema)
         out = exchange_batches(context.ctx, schema, merged, self.group)
         if out.num_rows:
             yield out
+
+    def _agree_schema(self, ctx, schema):
+        """A rank with no local rows still has to take part in the collectives with the right column list."""
+        import torch.distributed as dist
+        objs = [None] * self.world
+        mine = None if schema is None else [(f.name, f.dtype, f.precision, f.scale) for f in schema.fields]
+        if self.world == 1:
+            objs = [mine]
+        else:
+            dist.all_gather_object(objs, mine, group=self.group)
+        ref = next((o for o in objs if o is not None), None)
+        if ref is None:
+            return self._pp.Schema([])
+        return self._pp.Schema([self._pp.Field(n, t, p, s) for n, t, p, s in ref])
+
+
+def agree_schema(schema, group=None):
+    """All ranks must call a collective with the same column list even when some rank holds no rows."""
+    import torch.distributed as dist
+    from . import physical_plan as pp
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    mine = None if schema is None else [(f.name, f.dtype, f.precision, f.scale) for f in schema.fields]
+    objs = [mine]
+    if world > 1:
+        objs = [None] * world
+        dist.all_gather_object(objs, mine, group=group)
+    ref = next((o for o in objs if o is not None), None)
+    return pp.Schema([pp.Field(n, t, p, s) for n, t, p, s in ref]) if ref else pp.Schema([])

@@ -20,7 +20,7 @@ from typing import Dict, List, Optional
 import numpy as np
 
 from . import capi
-from . import operators as ops
+from . import physical_plan as ops
 from .device import Array, Context
 
 SEGMENTS = ["AUTOMOBILE", "BUILDING", "FURNITURE", "HOUSEHOLD", "MACHINERY"]
@@ -106,9 +106,8 @@ def tables_from_torch(ctx: Context, tt: dict) -> Dict[str, ops.RecordBatch]:
               ctx.wrap_tensor(tt["o_orderdate"], capi.DATE32), ctx.wrap_tensor(tt["o_shippriority"], capi.INT32)]
     line = [ctx.wrap_tensor(tt["l_orderkey"], capi.INT64), ctx.wrap_tensor(tt["l_extendedprice"], capi.DECIMAL128, 15, 2),
             ctx.wrap_tensor(tt["l_discount"], capi.DECIMAL128, 15, 2), ctx.wrap_tensor(tt["l_shipdate"], capi.DATE32)]
-    return {"customer": ops.RecordBatch(_schema(CUSTOMER_SCHEMA), cust, num_rows=len(cust[0])),
-            "orders": ops.RecordBatch(_schema(ORDERS_SCHEMA), orders, num_rows=len(orders[0])),
-            "lineitem": ops.RecordBatch(_schema(LINEITEM_SCHEMA), line, num_rows=len(line[0]))}
+    mk = lambda sch, cols: ops.RecordBatch.from_arrays(ctx, [n for n, _, _, _ in sch], cols)
+    return {"customer": mk(CUSTOMER_SCHEMA, cust), "orders": mk(ORDERS_SCHEMA, orders), "lineitem": mk(LINEITEM_SCHEMA, line)}
 
 
 def upload(ctx: Context, host: Dict[str, np.ndarray], device: str = "cuda") -> Dict[str, ops.RecordBatch]:
@@ -149,6 +148,24 @@ def gen_device(ctx: Context, sf: float, seed: int = SEED, rank: int = 0, world: 
     return tables_from_torch(ctx, tt)
 
 
+def tables_to_host(tables: Dict[str, "ops.RecordBatch"]) -> Dict[str, np.ndarray]:
+    """Device tables -> the numpy layout of gen_host (Decimal128 as (n,2) uint64 [lo,hi], c_mktsegment as Int8 codes)."""
+    import pyarrow as pa
+    host = {}
+    for batch in tables.values():
+        for name, col in zip(batch.schema.names(), batch.columns):
+            a = col.to_arrow()
+            if pa.types.is_dictionary(a.type):
+                host[name] = np.asarray(a.indices).astype(np.int8)
+            elif pa.types.is_decimal(a.type):
+                host[name] = np.frombuffer(a.buffers()[1], dtype=np.uint64, count=2 * len(a), offset=a.offset * 16).reshape(-1, 2).copy()
+            elif pa.types.is_date32(a.type):
+                host[name] = np.asarray(a.cast(pa.int32()))
+            else:
+                host[name] = np.asarray(a)
+    return host
+
+
 # ----------------------------------------------------------------------------- Q3 physical plan
 def q3_plan(tables: Dict[str, ops.RecordBatch], batch_size: int = 8192) -> ops.ExecutionPlan:
     """The reference's physical plan for TPC-H Q3 (sqllogictest/test_files/tpch/q3.slt.part, benchmarks/queries/q3.sql)
@@ -156,9 +173,9 @@ def q3_plan(tables: Dict[str, ops.RecordBatch], batch_size: int = 8192) -> ops.E
     CombinePartialFinalAggregate folds Partial+Final into AggregateExec(mode=Single)."""
     import pyarrow as pa
     C, L, B = ops.Column, ops.Literal, ops.BinaryExpr
-    cust = ops.MemoryExec([[tables["customer"]]], tables["customer"].schema)
-    orders = ops.MemoryExec([[tables["orders"]]], tables["orders"].schema)
-    line = ops.MemoryExec([[tables["lineitem"]]], tables["lineitem"].schema)
+    cust = ops.MemoryExec([[tables["customer"]]], _schema(CUSTOMER_SCHEMA))
+    orders = ops.MemoryExec([[tables["orders"]]], _schema(ORDERS_SCHEMA))
+    line = ops.MemoryExec([[tables["lineitem"]]], _schema(LINEITEM_SCHEMA))
 
     cb = lambda p: ops.CoalesceBatchesExec(p, batch_size)
     f_c = cb(ops.FilterExec(B(C("c_mktsegment", 1), "=", L(Q3_SEGMENT, pa.utf8())), cust))
@@ -204,9 +221,9 @@ def q3_distributed_plan(tables: Dict[str, ops.RecordBatch], group=None, batch_si
     import pyarrow as pa
     from .exchange import ShuffleExec
     C, L, B = ops.Column, ops.Literal, ops.BinaryExpr
-    cust = ops.MemoryExec([[tables["customer"]]], tables["customer"].schema)
-    orders = ops.MemoryExec([[tables["orders"]]], tables["orders"].schema)
-    line = ops.MemoryExec([[tables["lineitem"]]], tables["lineitem"].schema)
+    cust = ops.MemoryExec([[tables["customer"]]], _schema(CUSTOMER_SCHEMA))
+    orders = ops.MemoryExec([[tables["orders"]]], _schema(ORDERS_SCHEMA))
+    line = ops.MemoryExec([[tables["lineitem"]]], _schema(LINEITEM_SCHEMA))
     cb = lambda p: ops.CoalesceBatchesExec(p, batch_size)
     f_c = cb(ops.FilterExec(B(C("c_mktsegment", 1), "=", L(Q3_SEGMENT, pa.utf8())), cust))
     p_c = ops.ProjectionExec([(C("c_custkey", 0), "c_custkey")], f_c)

@@ -1,0 +1,91 @@
+/*
+ * dfgpu_exec.h -- C ABI of the C++ host layer (datafusion-upstream_amd/csrc/exec/) that mirrors the reference's
+ * operator interface for the hot path on top of the kernel-level ABI of dfgpu.h:
+ *
+ *   trait PhysicalExpr   datafusion/physical-expr/src/physical_expr.rs:96-123
+ *   trait ExecutionPlan  datafusion/physical-plan/src/lib.rs:115-405   (execute(partition, ctx) -> RecordBatchStream)
+ *   MemoryExec memory.rs:40 | FilterExec filter.rs:56 | ProjectionExec projection.rs:52 | CoalesceBatchesExec
+ *   coalesce_batches.rs | CoalescePartitionsExec coalesce_partitions.rs | RepartitionExec repartition/mod.rs:232 |
+ *   HashJoinExec joins/hash_join.rs:283 | AggregateExec aggregates/mod.rs:242 | SortExec sorts/sort.rs:719
+ *
+ * A Rust shim can bind either level: dfgpu.h (one call per reference inner function) or this one (one handle per plan
+ * node; `dfgpu_plan_execute` + `dfgpu_stream_next` are `ExecutionPlan::execute` + `Stream::poll_next`).
+ * Ownership: constructors take shared ownership of their inputs (reference counted inside); every handle returned to
+ * the caller is released with the matching *_free.  Errors: dfgpu_status + dfgpu_exec_last_error() (thread local).
+ */
+#ifndef DFGPU_EXEC_H
+#define DFGPU_EXEC_H
+#include "dfgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dfgpu_expr dfgpu_expr;       /* Arc<dyn PhysicalExpr> */
+typedef struct dfgpu_plan dfgpu_plan;       /* Arc<dyn ExecutionPlan> */
+typedef struct dfgpu_batch dfgpu_batch;     /* RecordBatch resident in HBM */
+typedef struct dfgpu_stream dfgpu_stream;   /* SendableRecordBatchStream */
+
+DFGPU_API const char *dfgpu_exec_last_error(void);
+
+/* ---- RecordBatch */
+DFGPU_API dfgpu_status dfgpu_batch_new(const char *const *names, const dfgpu_array *const *columns, int32_t ncols, dfgpu_batch **out);
+DFGPU_API void dfgpu_batch_free(dfgpu_batch *b);
+DFGPU_API int32_t dfgpu_batch_num_columns(const dfgpu_batch *b);
+/* rows after applying the selection mask (materialises nothing but the mask popcount) */
+DFGPU_API dfgpu_status dfgpu_batch_num_rows(dfgpu_ctx *ctx, dfgpu_batch *b, int64_t *out);
+DFGPU_API const char *dfgpu_batch_column_name(const dfgpu_batch *b, int32_t i);
+/* column i, selection applied and lazy gathers executed; caller releases the array */
+DFGPU_API dfgpu_status dfgpu_batch_column(dfgpu_ctx *ctx, dfgpu_batch *b, int32_t i, dfgpu_array **out);
+
+/* ---- PhysicalExpr (physical-expr/src/expressions/) */
+DFGPU_API dfgpu_status dfgpu_expr_column(const char *name, int32_t index, dfgpu_expr **out);                       /* column.rs */
+DFGPU_API dfgpu_status dfgpu_expr_literal(const dfgpu_array *scalar_len1, dfgpu_expr **out);                      /* literal.rs */
+DFGPU_API dfgpu_status dfgpu_expr_binary(const dfgpu_expr *l, int32_t op /* DFGPU_OP_* */, const dfgpu_expr *r, dfgpu_expr **out); /* binary.rs */
+DFGPU_API dfgpu_status dfgpu_expr_not(const dfgpu_expr *e, dfgpu_expr **out);
+DFGPU_API dfgpu_status dfgpu_expr_is_null(const dfgpu_expr *e, int32_t negated, dfgpu_expr **out);
+DFGPU_API dfgpu_status dfgpu_expr_negative(const dfgpu_expr *e, dfgpu_expr **out);
+DFGPU_API dfgpu_status dfgpu_expr_cast(const dfgpu_expr *e, int32_t to_type, int32_t precision, int32_t scale, dfgpu_expr **out);
+DFGPU_API dfgpu_status dfgpu_expr_in_list(const dfgpu_expr *e, const dfgpu_array *list, int32_t negated, dfgpu_expr **out);
+DFGPU_API void dfgpu_expr_free(dfgpu_expr *e);
+
+/* ---- ExecutionPlan nodes */
+/* MemoryExec: batches of all partitions back to back, partition_sizes[p] batches each */
+DFGPU_API dfgpu_status dfgpu_plan_memory(const dfgpu_batch *const *batches, const int32_t *partition_sizes, int32_t npartitions, dfgpu_plan **out);
+DFGPU_API dfgpu_status dfgpu_plan_filter(const dfgpu_expr *predicate, const dfgpu_plan *input, dfgpu_plan **out);
+DFGPU_API dfgpu_status dfgpu_plan_projection(const dfgpu_expr *const *exprs, const char *const *names, int32_t n, const dfgpu_plan *input, dfgpu_plan **out);
+DFGPU_API dfgpu_status dfgpu_plan_coalesce_batches(const dfgpu_plan *input, int64_t target_batch_size, dfgpu_plan **out);
+DFGPU_API dfgpu_status dfgpu_plan_coalesce_partitions(const dfgpu_plan *input, dfgpu_plan **out);
+/* Partitioning::Hash(exprs, n) when nexprs > 0, else Partitioning::RoundRobinBatch(n) */
+DFGPU_API dfgpu_status dfgpu_plan_repartition(const dfgpu_plan *input, const dfgpu_expr *const *exprs, int32_t nexprs, int32_t num_partitions, dfgpu_plan **out);
+/* HashJoinExec::try_new(left, right, on, filter, join_type, mode, null_equals_null); mode 0 = CollectLeft, 1 = Partitioned.
+ * JoinFilter: filter == NULL for none; filter_sides[i] 0 = left, 1 = right; filter_indices[i] = column of that side. */
+DFGPU_API dfgpu_status dfgpu_plan_hash_join(const dfgpu_plan *left, const dfgpu_plan *right, const dfgpu_expr *const *on_left, const dfgpu_expr *const *on_right,
+                                            int32_t non, const dfgpu_expr *filter, const int32_t *filter_sides, const int32_t *filter_indices, int32_t nfilter_cols,
+                                            int32_t join_type, int32_t mode, int32_t null_equals_null, dfgpu_plan **out);
+/* AggregateExec::try_new(mode, group_by, aggr_expr, input): mode 0 Partial, 1 Final, 2 FinalPartitioned, 3 Single,
+ * 4 SinglePartitioned.  Aggregate i: kind DFGPU_AGG_*, argument expr (NULL = COUNT(*)), optional FILTER expr, output name,
+ * argument data type (type, precision, scale) as the AggregateExpr knows it in every mode. */
+DFGPU_API dfgpu_status dfgpu_plan_aggregate(int32_t mode, const dfgpu_expr *const *group_exprs, const char *const *group_names, int32_t ngroups,
+                                            const int32_t *agg_kinds, const dfgpu_expr *const *agg_args, const dfgpu_expr *const *agg_filters, const char *const *agg_names,
+                                            const int32_t *agg_arg_types /* 3 per aggregate */, int32_t naggs, const dfgpu_plan *input, dfgpu_plan **out);
+/* SortExec::new(expr, input).with_fetch(fetch).with_preserve_partitioning(..); fetch < 0 = none */
+DFGPU_API dfgpu_status dfgpu_plan_sort(const dfgpu_expr *const *exprs, const uint8_t *descending, const uint8_t *nulls_first, int32_t n, int64_t fetch,
+                                       int32_t preserve_partitioning, const dfgpu_plan *input, dfgpu_plan **out);
+DFGPU_API void dfgpu_plan_free(dfgpu_plan *p);
+DFGPU_API int32_t dfgpu_plan_partition_count(const dfgpu_plan *p);               /* output_partitioning().partition_count() */
+DFGPU_API int32_t dfgpu_plan_schema_len(const dfgpu_plan *p);
+DFGPU_API const char *dfgpu_plan_schema_name(const dfgpu_plan *p, int32_t i);
+DFGPU_API const char *dfgpu_plan_name(const dfgpu_plan *p);                      /* DisplayAs: "HashJoinExec", ... */
+
+/* ---- execution */
+/* ExecutionPlan::execute(partition, TaskContext{session_config.batch_size}) */
+DFGPU_API dfgpu_status dfgpu_plan_execute(const dfgpu_plan *p, int32_t partition, dfgpu_ctx *ctx, int64_t batch_size, dfgpu_stream **out);
+/* Stream::poll_next: *out = NULL at end of stream */
+DFGPU_API dfgpu_status dfgpu_stream_next(dfgpu_stream *s, dfgpu_batch **out);
+DFGPU_API void dfgpu_stream_free(dfgpu_stream *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -21,5 +21,5 @@ def ctx():
 
 @pytest.fixture(scope="session")
 def task_ctx(ctx):
-    from dfgpu import operators as ops
+    from dfgpu import physical_plan as ops
     return ops.TaskContext(ctx, batch_size=8192)

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "dfgpu.h")).read()
+    text = open(os.path.join(ROOT, "include", "dfgpu.h")).read() + open(os.path.join(ROOT, "include", "dfgpu_exec.h")).read()
     return sorted(set(re.findall(r"DFGPU_API[^;(]*?\b(dfgpu_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -19,10 +19,10 @@ def test_header_symbols_are_exported_and_bound():
         subprocess.check_call(["make", "-j8", "-C", os.path.join(ROOT, "datafusion-upstream_amd", "csrc")])
     lib = dfgpu.load_library()
     names = declared_symbols()
-    assert len(names) >= 55
+    assert len(names) >= 88
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/dfgpu.h but not exported by libdfgpu.so"
-    assert sorted(dfgpu.capi.PROTOTYPES) == names, "capi.PROTOTYPES must bind exactly the symbols of include/dfgpu.h"
+    assert sorted(dfgpu.capi.PROTOTYPES) == names, "capi.PROTOTYPES must bind exactly the symbols of include/dfgpu.h + include/dfgpu_exec.h"
 
 
 def test_exported_symbols_are_only_the_abi():

@@ -129,7 +129,7 @@ def test_aggregate_exec_partial_final_matches_reference_vector(ctx, task_ctx):
     """check_aggregates (physical-plan/src/aggregates/mod.rs:1256-1286 data, :1509-1613): AVG(b) GROUP BY a over two
     batches: Partial state (count,sum) = a=2:(2,2.0) 3:(3,7.0) 4:(3,11.0) -- wait for the merged Final: 2->1.0, 3->2.3333333333333335, 4->3.6666666666666665."""
     import dfgpu
-    from dfgpu import operators as ops
+    from dfgpu import physical_plan as ops
     b1 = pa.table({"a": pa.array([2, 3, 4, 4], type=pa.uint32()), "b": pa.array([1.0, 2.0, 3.0, 4.0])})
     b2 = pa.table({"a": pa.array([2, 3, 3, 4], type=pa.uint32()), "b": pa.array([1.0, 2.0, 3.0, 4.0])})
     src = ops.MemoryExec([[ops.batch_from_arrow(ctx, b1), ops.batch_from_arrow(ctx, b2)]], ops.batch_from_arrow(ctx, b1).schema)

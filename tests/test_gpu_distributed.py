@@ -17,10 +17,12 @@ def _worker(rank, world, port, sf, q):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     try:
+        import faulthandler
+        faulthandler.dump_traceback_later(150, exit=True)      # a rank stuck in a collective must not hold the GPU box
         import torch
         import torch.distributed as dist
         import dfgpu
-        from dfgpu import exchange, operators as ops, tpch
+        from dfgpu import exchange, physical_plan as ops, tpch
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         ctx = dfgpu.Context(0, stream=torch.cuda.current_stream().cuda_stream)
@@ -60,7 +62,7 @@ def test_q3_distributed_two_ranks_one_gpu_matches_oracle(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, sf, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=280) for _ in procs)
+    results = dict(q.get(timeout=170) for _ in procs)
     for p in procs:
         p.join(timeout=60)
     for r in range(1, world):

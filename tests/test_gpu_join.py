@@ -15,17 +15,15 @@ RNG = np.random.default_rng(99)
 
 def device_join(ctx, case, batch_size):
     import dfgpu
-    from dfgpu import operators as ops
+    from dfgpu import physical_plan as ops
     tc = ops.TaskContext(ctx, batch_size=batch_size)
 
     def side(name):
         names = case[name]["names"]
-        batches = [ops.batch_from_arrow(ctx, pa.table(dict(zip([f"c{i}" for i in range(len(names))], cols)))) for cols in side_batches(case, name)]
+        batches = [ops.batch_from_arrow(ctx, pa.table(cols, names=names)) for cols in side_batches(case, name)]
         ts = pa_types_for(case, len(names))
         code = {pa.int32(): dfgpu.capi.INT32, pa.int64(): dfgpu.capi.INT64, pa.date32(): dfgpu.capi.DATE32}
         schema = ops.Schema([ops.Field(n, code[t]) for n, t in zip(names, ts)])
-        for b in batches:
-            b.schema = schema
         parts = [[b] for b in batches] if "two_parts" in case["name"] else [batches]
         return ops.MemoryExec(parts, schema), schema
 
@@ -133,7 +131,7 @@ def test_probe_with_fused_masks_equals_filtered_inputs(ctx):
 def test_join_types_fuzz_vs_oracle(ctx, task_ctx, jt):
     """All 8 join types over multi-batch inputs with NULL keys and duplicate keys; multiset of output rows equals the oracle's."""
     import dfgpu
-    from dfgpu import operators as ops
+    from dfgpu import physical_plan as ops
     lb = [pa.table({"k": keycols(["int64"], n, 0.1, 50)[0], "v": pa.array(RNG.integers(0, 10**6, n))}) for n in (300, 1, 500)]
     rb = [pa.table({"k": keycols(["int64"], n, 0.1, 70)[0], "w": pa.array(RNG.integers(0, 10**6, n))}) for n in (700, 64, 200)]
     mk = lambda tabs: ops.MemoryExec([[ops.batch_from_arrow(ctx, t) for t in tabs]], ops.batch_from_arrow(ctx, tabs[0]).schema)
@@ -162,7 +160,7 @@ def test_join_key_type_mismatch_is_rejected(ctx):
 
 def test_join_requires_on_columns(ctx):
     import dfgpu
-    from dfgpu import operators as ops
+    from dfgpu import physical_plan as ops
     s = ops.Schema([ops.Field("a", dfgpu.capi.INT32)])
     with pytest.raises(dfgpu.DfgpuError):     # hash_join.rs:303-305
         ops.HashJoinExec(ops.MemoryExec([[]], s), ops.MemoryExec([[]], s), [], None, "Inner")

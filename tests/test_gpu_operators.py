@@ -25,14 +25,14 @@ def table(n, nulls=0.1):
 
 
 def source(ctx, tabs, partitions=1):
-    from dfgpu import operators as ops
+    from dfgpu import physical_plan as ops
     batches = [ops.batch_from_arrow(ctx, t) for t in tabs]
     per = [batches[i::partitions] for i in range(partitions)]
     return ops.MemoryExec(per, batches[0].schema)
 
 
 def collect_table(plan, tc):
-    from dfgpu import operators as ops
+    from dfgpu import physical_plan as ops
     bs = ops.collect(plan, tc)
     if not bs:
         return None
@@ -41,7 +41,7 @@ def collect_table(plan, tc):
 
 def test_filter_projection_match_arrow(ctx, task_ctx):
     """FilterExec keeps input order and drops NULL predicate rows (filter.rs:222-225, :315-327); ProjectionExec evaluates per column."""
-    from dfgpu import operators as ops
+    from dfgpu import physical_plan as ops
     tabs = [table(5000), table(1), table(3000)]
     src = source(ctx, tabs)
     C, L, B = ops.Column, ops.Literal, ops.BinaryExpr
@@ -62,7 +62,7 @@ def test_filter_projection_match_arrow(ctx, task_ctx):
 
 def test_filter_rejects_non_boolean_predicate(ctx, task_ctx):
     import dfgpu
-    from dfgpu import operators as ops
+    from dfgpu import physical_plan as ops
     plan = ops.FilterExec(ops.Column("k", 0), source(ctx, [table(10)]))
     with pytest.raises(dfgpu.DfgpuError):
         list(plan.execute(0, task_ctx))
@@ -72,7 +72,7 @@ def test_filter_rejects_non_boolean_predicate(ctx, task_ctx):
 def test_aggregate_partial_repartition_final_vs_single(ctx, task_ctx, partitions):
     """Two-phase plan (Partial -> RepartitionExec Hash(keys) -> FinalPartitioned, physical_planner.rs:802-850) == Single == oracle."""
     import dfgpu
-    from dfgpu import operators as ops
+    from dfgpu import physical_plan as ops
     tabs = [table(4000), table(2500), table(1), table(3000)]
     C = ops.Column
     F = ops.Field
@@ -108,7 +108,7 @@ def test_aggregate_partial_repartition_final_vs_single(ctx, task_ctx, partitions
 
 
 def test_sort_exec_and_fetch(ctx, task_ctx):
-    from dfgpu import operators as ops
+    from dfgpu import physical_plan as ops
     tabs = [table(3000), table(2000)]
     C = ops.Column
     sort = ops.SortExec([ops.PhysicalSortExpr(C("k", 0), descending=True, nulls_first=False), ops.PhysicalSortExpr(C("f", 3), descending=False, nulls_first=True)], source(ctx, tabs))
@@ -124,7 +124,7 @@ def test_sort_exec_and_fetch(ctx, task_ctx):
 
 def test_repartition_conserves_rows_and_routes_by_hash(ctx, task_ctx):
     """repartition/mod.rs:952-1031 (many_to_many etc.): every input row appears exactly once; equal keys share a partition."""
-    from dfgpu import operators as ops
+    from dfgpu import physical_plan as ops
     tabs = [table(2000, 0.0), table(3000, 0.0), table(50, 0.0)]
     rep = ops.RepartitionExec(source(ctx, tabs, 3), ops.Partitioning.Hash([ops.Column("k", 0)], 5))
     seen, total = {}, 0
@@ -141,7 +141,7 @@ def test_repartition_conserves_rows_and_routes_by_hash(ctx, task_ctx):
 
 def test_coalesce_batches(ctx, task_ctx):
     """coalesce_batches.rs tests: small batches are concatenated up to target_batch_size, order preserved."""
-    from dfgpu import operators as ops
+    from dfgpu import physical_plan as ops
     tabs = [table(8) for _ in range(10)]
     co = ops.CoalesceBatchesExec(source(ctx, tabs), 21)
     sizes = [b.num_rows for b in co.execute(0, task_ctx)]

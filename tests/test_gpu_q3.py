@@ -25,7 +25,7 @@ def assert_sorted(res):
 @pytest.mark.parametrize("sf", [0.002, 0.02, 0.1])
 def test_q3_matches_oracle(ctx, sf):
     import dfgpu
-    from dfgpu import operators as ops, tpch
+    from dfgpu import physical_plan as ops, tpch
     from oracle import pyoracle as po
     host = tpch.gen_host(sf)
     tables = tpch.upload(ctx, host)
@@ -59,7 +59,7 @@ def test_q3_distributed_plan_world1_rccl_matches_single(ctx):
     import os
     import torch
     import torch.distributed as dist
-    from dfgpu import exchange, operators as ops, tpch
+    from dfgpu import exchange, physical_plan as ops, tpch
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29611")
     torch.cuda.set_device(0)
