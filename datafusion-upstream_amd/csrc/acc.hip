@@ -64,7 +64,7 @@ __device__ inline void atomic_min_f64(double* p, double x, bool is_min) {
 __global__ void __launch_bounds__(BLOCK) k_acc_update(int kind, int cls, ColView v, int has_values, const uint32_t* gids, const uint64_t* fbits, const uint64_t* fvalid,
                                                       int64_t n, int64_t total, void* vals, uint64_t* counts, uint8_t* seen, int count_only_valid, uint32_t* flags) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-    uint32_t g = gids[i];
+    uint32_t g = gids ? gids[i] : 0u;
     if (g == GID_NONE || !filter_pass(fbits, fvalid, i)) continue;
     if ((int64_t)g >= total) { atomicOr(flags, DFGPU_FLAG_OOB); continue; }
     int64_t r = i; bool ok = !has_values || cell_resolve(v, i, &r);
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(BLOCK) k_acc_update(int kind, int cls, ColView
 // Decimal128 MIN/MAX pass 2: among rows whose high word equals the group's extreme high word, extreme of the low word
 __global__ void __launch_bounds__(BLOCK) k_acc_minmax128_lo(int is_min, ColView v, const uint32_t* gids, const uint64_t* fbits, const uint64_t* fvalid, int64_t n, uint64_t* vals) {
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-    uint32_t g = gids[i]; int64_t r;
+    uint32_t g = gids ? gids[i] : 0u; int64_t r;
     if (g == GID_NONE || !filter_pass(fbits, fvalid, i) || !cell_resolve(v, i, &r)) continue;
     i128 x = acc_cell_int(v, r);
     if ((uint64_t)((u128)x >> 64) != vals[2 * (int64_t)g + 1]) continue;
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(BLOCK) k_acc_small(int kind, ColView v, int ha
 #pragma unroll
   for (int k = 0; k < SMALL_G; k++) { acc[k] = 0; cnt[k] = 0; }
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
-    uint32_t g = gids[i];
+    uint32_t g = gids ? gids[i] : 0u;
     if (g == GID_NONE || !filter_pass(fbits, fvalid, i)) continue;
     int64_t r = i; bool ok = !has_values || cell_resolve(v, i, &r);
     if (kind == DFGPU_AGG_COUNT) { if (!(ok || !count_only_valid)) continue; }

@@ -356,6 +356,16 @@ dfgpu_status dfgpu_array_new_null(dfgpu_ctx* ctx, int32_t type, int32_t precisio
   });
 }
 
+dfgpu_status dfgpu_array_new_zeros(dfgpu_ctx* ctx, int32_t type, int32_t precision, int32_t scale, int64_t length, dfgpu_array** out) {
+  return guard(ctx, [&] {
+    validate_type(type);
+    if (!type_width(type) && type != DFGPU_BOOL) fail(DFGPU_INVALID_ARGUMENT, "new_zeros: fixed-width type expected");
+    ArrayHolder h(new_fixed(ctx, type, length, precision, scale));
+    if (type != DFGPU_BOOL && length) HIP_CHECK(hipMemsetAsync(h.get()->values->ptr, 0, (size_t)length * type_width(type), ctx->stream));
+    *out = h.release();
+  });
+}
+
 dfgpu_status dfgpu_array_slice(dfgpu_ctx* ctx, const dfgpu_array* a, int64_t offset, int64_t length, dfgpu_array** out) {
   return guard(ctx, [&] {
     if (offset < 0 || length < 0 || offset + length > a->length) fail(DFGPU_INVALID_ARGUMENT, "slice [%lld, +%lld) outside array of %lld rows", (long long)offset, (long long)length, (long long)a->length);

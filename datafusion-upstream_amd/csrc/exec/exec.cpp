@@ -129,9 +129,7 @@ using ExprPtr = std::shared_ptr<const Expr>;
 
 static ArrayRef into_array(const TaskContext& tc, const Value& v, int64_t n) {       // ColumnarValue::into_array
   if (!v.scalar) return v.arr;
-  std::vector<uint32_t> zeros((size_t)n, 0u);
-  dfgpu_array_desc d{}; d.type = DFGPU_UINT32; d.length = n; d.values = zeros.empty() ? (const void*)&d : (const void*)zeros.data();
-  dfgpu_array* idx = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &d, &idx));
+  dfgpu_array* idx = nullptr; tc.check(dfgpu_array_new_zeros(tc.ctx, DFGPU_UINT32, 0, 0, n, &idx));     // broadcast = take(scalar, [0; n])
   ArrayRef i = ArrayRef::adopt(idx);
   return take(tc, v.arr, i);
 }
@@ -505,10 +503,10 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
   SchemaPtr schema() const override { std::lock_guard<std::mutex> l(mu); if (!sch) { auto s = std::make_shared<Schema>(); for (auto& n : out_names()) s->f.push_back(Field{n}); sch = s; } return sch; }
   int partitions() const override { return (mode == 1 || mode == 3) ? 1 : input->partitions(); }
   std::unique_ptr<Stream> execute(int partition, const TaskContext& tc) const override {
-    if (gexprs.empty()) fail(DFGPU_NOT_IMPLEMENTED, "AggregateExec without GROUP BY (AggregateStream, no_grouping.rs) is not on the device path yet");
     std::vector<Batch> in;
     if (mode == 1 || mode == 3) { for (int p = 0; p < input->partitions(); p++) drain(input, p, tc, in); } else drain(input, partition, tc, in);
-    GroupsRef groups; tc.check(dfgpu_groups_new(tc.ctx, (int32_t)gexprs.size(), &groups.g));
+    const bool grouped = !gexprs.empty();      // false: AggregateStream (aggregates/no_grouping.rs): one implicit group
+    GroupsRef groups; if (grouped) tc.check(dfgpu_groups_new(tc.ctx, (int32_t)gexprs.size(), &groups.g));
     std::vector<AccRef> accs(aggs.size());
     for (size_t i = 0; i < aggs.size(); i++) {
       int32_t t = aggs[i].kind == DFGPU_AGG_COUNT ? DFGPU_INT64 : aggs[i].type;
@@ -517,28 +515,35 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
     for (auto& b : in) {          // group_aggregate_batch (row_hash.rs:524-613)
       if (b.base_rows == 0) continue;
       ArrayRef mask = b.selection; b.selection = ArrayRef();
-      std::vector<ArrayRef> gc; std::vector<const dfgpu_array*> gp;
-      for (auto& e : gexprs) { gc.push_back(into_array(tc, e->eval(tc, b), b.base_rows)); gp.push_back(gc.back().a); }
-      dfgpu_array* ids = nullptr; tc.check(dfgpu_groups_intern(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids)); ArrayRef gids = ArrayRef::adopt(ids);
-      int64_t total = dfgpu_groups_len(groups.g); size_t col = gexprs.size();
+      ArrayRef gids; int64_t total = 1;
+      if (grouped) {
+        std::vector<ArrayRef> gc; std::vector<const dfgpu_array*> gp;
+        for (auto& e : gexprs) { gc.push_back(into_array(tc, e->eval(tc, b), b.base_rows)); gp.push_back(gc.back().a); }
+        dfgpu_array* ids = nullptr; tc.check(dfgpu_groups_intern(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids)); gids = ArrayRef::adopt(ids);
+        total = dfgpu_groups_len(groups.g);
+      } else { dfgpu_array* z = nullptr; tc.check(dfgpu_array_new_zeros(tc.ctx, DFGPU_UINT32, 0, 0, b.base_rows, &z)); gids = ArrayRef::adopt(z); }
+      size_t col = gexprs.size();
       for (size_t i = 0; i < aggs.size(); i++) {
         if (merging()) {
           int nst = aggs[i].kind == DFGPU_AGG_AVG ? 2 : 1; const dfgpu_array* st[2];
           for (int k = 0; k < nst; k++) st[k] = b.column(tc, (int)(col + (size_t)k)).a;
           col += (size_t)nst;
-          tc.check(dfgpu_acc_merge_batch(tc.ctx, accs[i].a, st, nst, gids.a, nullptr, total));
+          tc.check(dfgpu_acc_merge_batch(tc.ctx, accs[i].a, st, nst, gids.a, grouped ? nullptr : mask.a, total));
         } else {
           ArrayRef vals, filt;
           if (aggs[i].arg) vals = into_array(tc, aggs[i].arg->eval(tc, b), b.base_rows);
           if (aggs[i].filter) filt = into_array(tc, aggs[i].filter->eval(tc, b), b.base_rows);
+          if (!grouped && mask) {         // rows dropped by a fused FilterExec must not reach the single group
+            if (filt) { ArrayRef kf = known_mask(tc, filt); dfgpu_array* o = nullptr; tc.check(dfgpu_binary(tc.ctx, DFGPU_OP_AND, kf.a, 0, mask.a, 0, &o)); filt = ArrayRef::adopt(o); } else filt = mask;
+          }
           tc.check(dfgpu_acc_update_batch(tc.ctx, accs[i].a, vals.a, gids.a, filt.a, total));
         }
       }
     }
-    std::vector<Batch> outv; int64_t total = dfgpu_groups_len(groups.g);
+    std::vector<Batch> outv; int64_t total = grouped ? dfgpu_groups_len(groups.g) : 1;     // no GROUP BY: always one row, even on empty input
     if (total > 0) {              // emit(EmitTo::All) (row_hash.rs:626-662)
       Batch o; o.base_rows = total; std::vector<dfgpu_array*> keys(gexprs.size(), nullptr);
-      tc.check(dfgpu_groups_emit(tc.ctx, groups.g, keys.data()));
+      if (grouped) tc.check(dfgpu_groups_emit(tc.ctx, groups.g, keys.data()));
       for (auto k : keys) o.cols.push_back(col_of(ArrayRef::adopt(k)));
       dfgpu_array_desc ed{}; ed.type = DFGPU_UINT32; ed.values = &ed; dfgpu_array* e = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &ed, &e)); ArrayRef empty_ids = ArrayRef::adopt(e);
       for (size_t i = 0; i < aggs.size(); i++) {

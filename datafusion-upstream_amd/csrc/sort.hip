@@ -102,7 +102,7 @@ void radix_sort_pairs_u32(dfgpu_ctx* ctx, uint32_t* keys, uint32_t* vals, int64_
 }
 
 // ---------------------------------------------------------------- order-preserving key encoding
-struct SortCol { ColView v; int32_t byte_off; int32_t has_null_byte; int32_t descending; int32_t nulls_first; };
+struct SortCol { ColView v; int32_t byte_off; int32_t has_null_byte; int32_t descending; int32_t nulls_first; int32_t max_len; };   // max_len: Utf8 only
 struct SortCols { int32_t n; SortCol c[MAX_KEYS]; };
 
 __device__ inline void put_be(uint8_t* planes, int64_t n, int64_t row, int off, uint64_t v, int width, uint8_t inv) {
@@ -116,9 +116,17 @@ __global__ void __launch_bounds__(BLOCK) k_encode_sort_keys(SortCols sc, int64_t
     int64_t r; bool ok = cell_resolve(v, i, &r);
     int off = s.byte_off;
     if (s.has_null_byte) { planes[(int64_t)off * n + i] = ok ? (s.nulls_first ? 1 : 0) : (s.nulls_first ? 0 : 1); off++; }
-    int w = v.type == DFGPU_BOOL ? 1 : v.width;
+    int w = v.type == DFGPU_BOOL ? 1 : (v.type == DFGPU_UTF8 ? s.max_len + 4 : v.width);
     if (!ok) { for (int b = 0; b < w; b++) planes[(int64_t)(off + b) * n + i] = 0; continue; }
     uint8_t inv = s.descending ? 0xFF : 0x00;
+    if (v.type == DFGPU_UTF8) {
+      // bytes zero-padded to the longest string, then the length (big endian): byte-wise lexicographic order with a
+      // prefix sorting before its extensions -- arrow-ord's order for Utf8 (memcmp, then length)
+      int32_t o = v.offsets[r], len = v.offsets[r + 1] - o; const uint8_t* p = (const uint8_t*)v.values + o;
+      for (int b = 0; b < s.max_len; b++) planes[(int64_t)(off + b) * n + i] = (uint8_t)((b < len ? p[b] : 0) ^ inv);
+      put_be(planes, n, i, off + s.max_len, (uint32_t)len, 4, inv);
+      continue;
+    }
     switch (v.type) {
       case DFGPU_BOOL: put_be(planes, n, i, off, bit_get((const uint64_t*)v.values, r), 1, inv); break;
       case DFGPU_INT8: put_be(planes, n, i, off, (uint8_t)(((const uint8_t*)v.values)[r] ^ 0x80u), 1, inv); break;
@@ -135,6 +143,15 @@ __global__ void __launch_bounds__(BLOCK) k_encode_sort_keys(SortCols sc, int64_t
       default: break;
     }
   }
+}
+__global__ void __launch_bounds__(BLOCK) k_max_utf8_len(ColView v, int64_t n, unsigned int* out) {
+  unsigned int m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    int64_t r; if (cell_resolve(v, i, &r)) { unsigned int len = (unsigned int)(v.offsets[r + 1] - v.offsets[r]); m = len > m ? len : m; }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { unsigned int o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
+  if (lane_id() == 0 && m) atomicMax(out, m);
 }
 // per-plane digit totals: tot[plane * 256 + digit]
 __global__ void __launch_bounds__(BLOCK) k_plane_totals(const uint8_t* planes, int64_t n, uint32_t* tot) {
@@ -159,10 +176,17 @@ extern "C" dfgpu_status dfgpu_sort_to_indices(dfgpu_ctx* ctx, const dfgpu_array*
     for (int c = 0; c < k; c++) {
       if (cols[c]->length != n) fail(DFGPU_INVALID_ARGUMENT, "sort columns differ in length");
       int32_t lt = logical_type(cols[c]);
-      if (lt == DFGPU_UTF8) fail(DFGPU_NOT_IMPLEMENTED, "Utf8 sort keys are not supported on device yet");
-      SortCol& s = sc.c[c]; s.v = make_view(cols[c]); s.byte_off = W;
+      SortCol& s = sc.c[c]; s.v = make_view(cols[c]); s.byte_off = W; s.max_len = 0;
+      if (lt == DFGPU_UTF8) {
+        HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 12, 0, 8, ctx->stream));
+        if (n) hipLaunchKernelGGL(k_max_utf8_len, dim3(grid_for(n, BLOCK * 8, 512)), dim3(BLOCK), 0, ctx->stream, s.v, n, (unsigned int*)(ctx->d_scratch64 + 12));
+        KERNEL_CHECK();
+        uint64_t ml = read_scratch(ctx, 12) & 0xFFFFFFFFull;
+        if (ml > 1024) fail(DFGPU_NOT_IMPLEMENTED, "Utf8 sort keys longer than 1024 bytes (%llu) are not supported on device", (unsigned long long)ml);
+        s.max_len = (int32_t)ml;
+      }
       s.has_null_byte = (s.v.validity || s.v.key_validity) ? 1 : 0; s.descending = descending && descending[c]; s.nulls_first = nulls_first ? nulls_first[c] : 1;
-      W += s.has_null_byte + (lt == DFGPU_BOOL ? 1 : type_width(lt));
+      W += s.has_null_byte + (lt == DFGPU_BOOL ? 1 : (lt == DFGPU_UTF8 ? s.max_len + 4 : type_width(lt)));
     }
     ArrayHolder idx(new_fixed(ctx, DFGPU_UINT32, n));
     launch_iota_u32(ctx, (uint32_t*)idx.get()->values->ptr, n, 0);

@@ -117,6 +117,8 @@ DFGPU_API int64_t dfgpu_array_null_count(dfgpu_ctx *ctx, const dfgpu_array *a); 
 DFGPU_API dfgpu_status dfgpu_array_slice(dfgpu_ctx *ctx, const dfgpu_array *a, int64_t offset, int64_t length, dfgpu_array **out);
 /* concat_batches per column (hash_join.rs:764, coalesce_batches.rs:198-260, sorts/sort.rs:505). */
 DFGPU_API dfgpu_status dfgpu_concat(dfgpu_ctx *ctx, const dfgpu_array *const *arrays, int32_t n, dfgpu_array **out);
+/* fixed-width column of `length` zeros, no validity (e.g. the single group id of an AggregateExec without GROUP BY) */
+DFGPU_API dfgpu_status dfgpu_array_new_zeros(dfgpu_ctx *ctx, int32_t type, int32_t precision, int32_t scale, int64_t length, dfgpu_array **out);
 /* new_null_array (joins/utils.rs:1214) */
 DFGPU_API dfgpu_status dfgpu_array_new_null(dfgpu_ctx *ctx, int32_t type, int32_t precision, int32_t scale, int64_t length, dfgpu_array **out);
 

@@ -57,10 +57,24 @@ def test_multi_column_sort_q3_shape_and_fetch(ctx):
     assert np.array_equal(got3, po.lexsort_to_indices(three, [False, True, False], [False, True, True]))
 
 
-def test_utf8_sort_key_reports_not_implemented(ctx):
+@pytest.mark.parametrize("desc,nf_first", [(False, True), (True, False)])
+def test_utf8_and_mixed_sort_keys(ctx, desc, nf_first):
+    """Q1 sorts on two Utf8 columns (tpch/q1.slt.part SortExec [l_returnflag ASC, l_linestatus ASC]): byte-wise order, prefix first."""
+    words = ["", "a", "ab", "abc", "b", "A", "R", "N", "O", "F", "zz", "日本", "a\x00", "ab\x00\x00"]
+    for n, nf in [(0, 0), (1, 0), (300, 0.2), (20000, 0.05)]:
+        a = pa.array([None if RNG.random() < nf else words[i] for i in RNG.integers(0, len(words), n)], type=pa.utf8())
+        b = rand_array("int32", n, 0.1, RNG)
+        c = pa.array([None if RNG.random() < nf else "x" * int(k) for k in RNG.integers(0, 40, n)], type=pa.utf8()).dictionary_encode()
+        got = ctx.sort_to_indices([ctx.from_arrow(a)], [desc], [nf_first]).to_numpy()
+        assert np.array_equal(got, po.lexsort_to_indices([a], [desc], [nf_first])), f"n={n}"
+        got3 = ctx.sort_to_indices([ctx.from_arrow(c), ctx.from_arrow(a), ctx.from_arrow(b)], [desc, not desc, False], [nf_first, True, False]).to_numpy()
+        assert np.array_equal(got3, po.lexsort_to_indices([c, a, b], [desc, not desc, False], [nf_first, True, False]))
+
+
+def test_utf8_sort_key_too_long_reports_not_implemented(ctx):
     import dfgpu
     with pytest.raises(dfgpu.DfgpuError) as e:
-        ctx.sort_to_indices([ctx.from_arrow(pa.array(["b", "a"]))], [False], [True])
+        ctx.sort_to_indices([ctx.from_arrow(pa.array(["b" * 2000, "a"]))], [False], [True])
     assert e.value.kind == "NotImplemented"
 
 
