@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--sf", type=float, default=100.0, help="TPC-H scale factor of the whole job")
     ap.add_argument("--cpu-sf", type=float, default=10.0, help="scale factor of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plan", choices=["broadcast", "shuffle"], default="broadcast",
+                    help="N > 1: broadcast = CollectLeft joins (all-gather the build sides, probe local shards); shuffle = the reference's fully partitioned plan")
     return ap.parse_args()
 
 
@@ -88,7 +90,7 @@ def main():
             plan = tpch.q3_plan(tables, batch_size=8192)
             out = [b for b in plan.execute(0, tc)]
         else:
-            plan = tpch.q3_distributed_plan(tables, batch_size=8192)
+            plan = (tpch.q3_broadcast_plan if args.plan == "broadcast" else tpch.q3_distributed_plan)(tables, batch_size=8192)
             local = [b for b in plan.execute(0, tc)]
             schema = local[0].schema if local else None
             mine = ops.concat_batches(schema, local) if local else None
@@ -188,7 +190,8 @@ def main():
         line = {"metric": "rows/sec hash-join+agg, TPC-H SF100 Q3", "value": round(value, 1), "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64 keys / i128 (Decimal128) sums",
                 "data": "synthetic", "config": {"workload": f"TPC-H SF{args.sf:g} Q3 (3-way hash join + group-by SUM + sort), int64 keys, Decimal128(15,2) money, resident in HBM",
-                                                "input_rows": rows_total, "result_rows": result_rows[0], "parallelism": f"{world} x (hash-partition + RCCL all-to-all)" if world > 1 else "1 GPU"},
+                                                "input_rows": rows_total, "result_rows": result_rows[0], "parallelism": (f"{world} GPUs, CollectLeft joins: RCCL all-gather of build sides + all-to-all of partial aggregates" if args.plan == "broadcast"
+                                                                else f"{world} GPUs, partitioned joins: hash partition + RCCL all-to-all per exchange") if world > 1 else "1 GPU"},
                 "roofline": roofline, "cpu_baseline": cpu_baseline}
         print(json.dumps(line), flush=True)
     if world > 1:

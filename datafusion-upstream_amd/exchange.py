@@ -224,6 +224,44 @@ class ShuffleExec:
         return self._pp.Schema([self._pp.Field(n, t, p, s) for n, t, p, s in ref])
 
 
+class BroadcastExec:
+    """PartitionMode::CollectLeft across GPUs: the (small) build side of a HashJoinExec is replicated on every rank
+    with one all-gather per column instead of shuffling the (large) probe side -- the reference shares one build table
+    between all probe partitions through OnceAsync (joins/hash_join.rs:594-606, joins/utils.rs:736-776); here every rank
+    receives every rank's rows (source ranks in order) and builds the same table.  On xGMI an all-gather of B bytes costs
+    each GPU (N-1)/N * B over 7 concurrent links, independent of the probe side's size."""
+
+    def __init__(self, input, group=None):
+        import torch.distributed as dist
+        from . import physical_plan as pp
+        self.input, self.group = input, group
+        self.world = dist.get_world_size(group)
+        self._pp = pp
+        self.bytes_sent = 0
+
+    def schema(self):
+        return self.input.schema()
+
+    def children(self):
+        return [self.input]
+
+    def output_partitioning(self):
+        return self._pp.Partitioning.UnknownPartitioning(1)
+
+    def execute(self, partition, context):
+        pp = self._pp
+        local = []
+        for p in range(self.input.output_partitioning().partition_count()):
+            local += [b for b in self.input.execute(p, context) if b.num_rows]
+        mine = pp.concat_batches(None, local) if local else None
+        schema = agree_schema(mine.schema if mine is not None else None, self.group)
+        if mine is not None:
+            self.bytes_sent += sum(_WIDTH.get(f.dtype, 0) for f in schema.fields) * mine.num_rows * (self.world - 1)
+        out = exchange_batches(context.ctx, schema, [mine] * self.world, self.group)      # same rows to every rank = all-gather
+        if out.num_rows:
+            yield out
+
+
 def agree_schema(schema, group=None):
     """All ranks must call a collective with the same column list even when some rank holds no rows."""
     import torch.distributed as dist

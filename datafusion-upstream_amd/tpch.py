@@ -212,6 +212,43 @@ def q3_result_to_numpy(batches: List[ops.RecordBatch]) -> Dict[str, np.ndarray]:
     return {"l_orderkey": np.asarray(cols[0]), "revenue": raw, "o_orderdate": np.asarray(cols[2].cast(pa.int32())), "o_shippriority": np.asarray(cols[3])}
 
 
+def q3_broadcast_plan(tables: Dict[str, ops.RecordBatch], group=None, batch_size: int = 8192) -> ops.ExecutionPlan:
+    """Q3 on N GPUs with both joins in PartitionMode::CollectLeft (JoinSelection picks it when the build side is under
+    hash_join_single_partition_threshold, common/src/config.rs:562-566; with 288 GB of HBM per GPU that threshold is GBs):
+    the filtered customers (SF100: 24 MB) and the customer-orders join result (234 MB) are all-gathered (BroadcastExec) and
+    every rank probes its LOCAL orders / lineitem shard -- the 13 GB filtered lineitem never crosses xGMI.  Only the Partial
+    aggregate state (36 MB) is shuffled.  Same rows as q3_distributed_plan / q3_plan."""
+    import decimal
+    import pyarrow as pa
+    from .exchange import BroadcastExec, ShuffleExec
+    C, L, B = ops.Column, ops.Literal, ops.BinaryExpr
+    cust = ops.MemoryExec([[tables["customer"]]], _schema(CUSTOMER_SCHEMA))
+    orders = ops.MemoryExec([[tables["orders"]]], _schema(ORDERS_SCHEMA))
+    line = ops.MemoryExec([[tables["lineitem"]]], _schema(LINEITEM_SCHEMA))
+    cb = lambda p: ops.CoalesceBatchesExec(p, batch_size)
+    f_c = cb(ops.FilterExec(B(C("c_mktsegment", 1), "=", L(Q3_SEGMENT, pa.utf8())), cust))
+    b_c = BroadcastExec(ops.ProjectionExec([(C("c_custkey", 0), "c_custkey")], f_c), group)
+    f_o = cb(ops.FilterExec(B(C("o_orderdate", 2), "<", L(Q3_DATE, pa.date32())), orders))
+    j1 = cb(ops.HashJoinExec(b_c, f_o, [(C("c_custkey", 0), C("o_custkey", 1))], None, "Inner", "CollectLeft"))
+    p_j1 = ops.ProjectionExec([(C("o_orderkey", 1), "o_orderkey"), (C("o_orderdate", 3), "o_orderdate"), (C("o_shippriority", 4), "o_shippriority")], j1)
+    b_j1 = BroadcastExec(p_j1, group)
+    f_l = cb(ops.FilterExec(B(C("l_shipdate", 3), ">", L(Q3_DATE, pa.date32())), line))
+    p_l = ops.ProjectionExec([(C("l_orderkey", 0), "l_orderkey"), (C("l_extendedprice", 1), "l_extendedprice"), (C("l_discount", 2), "l_discount")], f_l)
+    j2 = cb(ops.HashJoinExec(b_j1, p_l, [(C("o_orderkey", 0), C("l_orderkey", 0))], None, "Inner", "CollectLeft"))
+    p_j2 = ops.ProjectionExec([(C("o_orderdate", 1), "o_orderdate"), (C("o_shippriority", 2), "o_shippriority"), (C("l_orderkey", 3), "l_orderkey"),
+                               (C("l_extendedprice", 4), "l_extendedprice"), (C("l_discount", 5), "l_discount")], j2)
+    revenue = B(C("l_extendedprice", 3), "*", B(L(decimal.Decimal(1), pa.decimal128(20, 0)), "-", C("l_discount", 4)))
+    gby = [(C("l_orderkey", 2), "l_orderkey"), (C("o_orderdate", 0), "o_orderdate"), (C("o_shippriority", 1), "o_shippriority")]
+    aggr = [ops.AggregateFunctionExpr("SUM", revenue, "SUM(lineitem.l_extendedprice * Int64(1) - lineitem.l_discount)",
+                                      input_field=ops.Field("rev", capi.DECIMAL128, 38, 4))]
+    partial = ops.AggregateExec("Partial", gby, aggr, p_j2)
+    s_a = cb(ShuffleExec(partial, [C("l_orderkey", 0), C("o_orderdate", 1), C("o_shippriority", 2)], group))
+    final = ops.AggregateExec("FinalPartitioned", [(C("l_orderkey", 0), "l_orderkey"), (C("o_orderdate", 1), "o_orderdate"), (C("o_shippriority", 2), "o_shippriority")], aggr, s_a)
+    proj = ops.ProjectionExec([(C("l_orderkey", 0), "l_orderkey"), (C("revenue", 3), "revenue"), (C("o_orderdate", 1), "o_orderdate"), (C("o_shippriority", 2), "o_shippriority")], final)
+    return ops.SortExec([ops.PhysicalSortExpr(C("revenue", 1), descending=True, nulls_first=True),
+                         ops.PhysicalSortExpr(C("o_orderdate", 2), descending=False, nulls_first=False)], proj, preserve_partitioning=True)
+
+
 def q3_distributed_plan(tables: Dict[str, ops.RecordBatch], group=None, batch_size: int = 8192) -> ops.ExecutionPlan:
     """The reference's PARTITIONED Q3 plan (tpch/q3.slt.part physical_plan) with one output partition per GPU:
     every `RepartitionExec: partitioning=Hash(..)` becomes a ShuffleExec (device hash partition + RCCL all-to-all),

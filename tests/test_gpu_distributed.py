@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, sf, q):
+def _worker(rank, world, port, sf, q, plan_name="q3_distributed_plan"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -34,7 +34,7 @@ def _worker(rank, world, port, sf, q):
         shard = {k: (v[c0:c1] if k.startswith("c_") else v[o0:o1] if k.startswith("o_") else v[lsel]) for k, v in host.items()}
         tables = tpch.upload(ctx, shard)
         tc = ops.TaskContext(ctx, batch_size=8192)
-        plan = tpch.q3_distributed_plan(tables)
+        plan = getattr(tpch, plan_name)(tables)
         local = list(plan.execute(0, tc))
         schema = local[0].schema
         gathered = exchange.gather_batches(ctx, schema, ops.concat_batches(schema, local), 0)
@@ -49,8 +49,8 @@ def _worker(rank, world, port, sf, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_q3_distributed_two_ranks_one_gpu_matches_oracle(world):
+@pytest.mark.parametrize("world,plan_name", [(2, "q3_distributed_plan"), (3, "q3_distributed_plan"), (2, "q3_broadcast_plan"), (3, "q3_broadcast_plan")])
+def test_q3_distributed_two_ranks_one_gpu_matches_oracle(world, plan_name):
     import torch.multiprocessing as mp
     from dfgpu import tpch
     from oracle import pyoracle as po
@@ -58,8 +58,8 @@ def test_q3_distributed_two_ranks_one_gpu_matches_oracle(world):
     sf = 0.05
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 1000) + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, sf, q)) for r in range(world)]
+    port = 29700 + (os.getpid() % 1000) + world + (10 if plan_name == "q3_broadcast_plan" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, sf, q, plan_name)) for r in range(world)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=170) for _ in procs)
