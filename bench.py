@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--sf", type=float, default=100.0, help="TPC-H scale factor of the whole job")
     ap.add_argument("--cpu-sf", type=float, default=10.0, help="scale factor of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--plan", choices=["broadcast", "shuffle"], default="broadcast",
                     help="N > 1: broadcast = CollectLeft joins (all-gather the build sides, probe local shards); shuffle = the reference's fully partitioned plan")
     return ap.parse_args()
@@ -67,9 +69,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     # one ctx on torch's current stream: dfgpu kernels, torch ops and RCCL collectives are stream ordered
     ctx = dfgpu.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
@@ -78,7 +85,7 @@ def main():
     rows_local = sum(t.num_rows for t in tables.values())
     rows_total = rows_local
     if world > 1:
-        t = torch.tensor([rows_local], dtype=torch.int64, device="cuda")
+        t = torch.tensor([rows_local], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t)
         rows_total = int(t.item())
     torch.cuda.synchronize()
@@ -125,7 +132,7 @@ def main():
     prof = ctx.profile_read()
     ctx.profile_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
