@@ -270,6 +270,7 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     std::string k = key ? key : "";
     if (k == "force_hash_collisions") ctx->force_hash_collisions = value != 0;
     else if (k == "first_seen_group_order") ctx->first_seen_group_order = value != 0;
+    else if (k == "join_rank_index") ctx->join_rank_index = value != 0;
     else fail(DFGPU_INVALID_ARGUMENT, "unknown option '%s'", k.c_str());
   });
 }

@@ -40,6 +40,7 @@ struct dfgpu_ctx {
   std::string err;
   bool force_hash_collisions = false;
   bool first_seen_group_order = true;
+  bool join_rank_index = true;
   uint32_t* d_flags = nullptr;      // device word for kernel error flags
   uint64_t* d_scratch64 = nullptr;  // 64 x u64 device scratch for counters / totals
   uint64_t* h_pinned = nullptr;     // 64 x u64 pinned host mirror

@@ -33,8 +33,14 @@ struct dfgpu_join_table {
   // exact membership bitmap over [key_min, key_min + range) for single integer keys with a dense domain: the probe tests
   // one bit (L2 / Infinity Cache resident, perfectly local for clustered keys) and touches the hash table for matches only
   BufferPtr bitmap; int64_t key_min = 0; uint64_t range = 0;
+  // rank index (strictly increasing single integer key, the shape of every clustered primary key): no hash table at all.
+  // The bitmap IS the table: build row = rank of the key's bit among the set bits (word prefix + popcount), mapped through
+  // sel_rows when a build selection is fused; rank_identity = the keys are key_min + row, so the row is the key offset.
+  bool rank_mode = false, rank_identity = false;
+  BufferPtr rank_prefix;  // u32[range / 64]   set bits before each bitmap word
+  dfgpu_array* sel_rows = nullptr;   // u32[selected] ascending build rows (masked builds only)
   int64_t mem = 0;
-  ~dfgpu_join_table() { for (auto* a : keys) dfgpu_array_release(a); }
+  ~dfgpu_join_table() { for (auto* a : keys) dfgpu_array_release(a); if (sel_rows) dfgpu_array_release(sel_rows); }
 };
 
 namespace dfgpu {
@@ -198,6 +204,45 @@ __global__ void __launch_bounds__(BLOCK) k_key_setbits(const T* keys, const uint
   uint64_t d = (uint64_t)((int64_t)keys[i] - kmin);
   atomicOr((unsigned long long*)&bitmap[d >> 6], 1ull << (d & 63));
 }
+// ---- rank index: the build keys are strictly increasing, so the membership bitmap alone locates the build row
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_check_increasing(const T* keys, int64_t n, unsigned long long* flag) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x + 1; i < n; i += (int64_t)gridDim.x * BLOCK) bad |= !(keys[i - 1] < keys[i]);
+  if (ballot64(bad) && lane_id() == 0) *flag = 1ull;
+}
+// set the bit of every selected row's key.  Equal bitmap words of neighbouring lanes are OR-combined first (segmented
+// scan over runs of the same word; sorted keys put 16+ lanes on one word) so one atomic per run reaches L2.
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_key_setbits_masked(const T* keys, const uint64_t* mask, int64_t n, int64_t kmin, uint64_t* bitmap) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  int lane = lane_id();
+  bool on = i < n && row_selected(mask, i);
+  uint64_t d = on ? (uint64_t)((int64_t)keys[i] - kmin) : 0;
+  int64_t w = on ? (int64_t)(d >> 6) : -1 - lane;            // unselected lanes never combine
+  uint64_t b = on ? 1ull << (d & 63) : 0ull;
+#pragma unroll
+  for (int s = 1; s < WAVE; s <<= 1) {
+    uint64_t ob = __shfl_up(b, s, 64); int64_t ow = __shfl_up(w, s, 64);
+    if (lane >= s && ow == w) b |= ob;
+  }
+  int64_t nxt = __shfl_down(w, 1, 64);
+  if (on && (lane == WAVE - 1 || nxt != w)) atomicOr((unsigned long long*)&bitmap[w], (unsigned long long)b);
+}
+__global__ void __launch_bounds__(BLOCK) k_popc_words(const uint64_t* words, int64_t nw, uint32_t* out) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < nw) out[i] = (uint32_t)__popcll(words[i]);
+}
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_probe_lookup_rank(const T* pkeys, const uint32_t* rows, int64_t m, int64_t kmin, const uint64_t* bitmap,
+                                                             const uint32_t* prefix, const uint32_t* sel_rows, int identity, uint64_t* out_build) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= m) return;
+  uint64_t d = (uint64_t)((int64_t)pkeys[rows[i]] - kmin);      // pass 1 proved d < range and the bit set
+  uint64_t r = d;
+  if (!identity) { r = prefix[d >> 6] + (uint32_t)__popcll(bitmap[d >> 6] & ((1ull << (d & 63)) - 1ull)); if (sel_rows) r = sel_rows[r]; }
+  out_build[i] = r;
+}
 #define DFGPU_INT_KEY_DISPATCH(TYPE, CALL)                                                                      \
   switch (TYPE) {                                                                                               \
     case DFGPU_INT8: { using T = int8_t; CALL; break; } case DFGPU_INT16: { using T = int16_t; CALL; break; }   \
@@ -239,6 +284,102 @@ static void check_key_types(const dfgpu_join_table* t, const dfgpu_array* const*
     if (logical_type(pk[c]) != logical_type(t->keys[c])) fail(DFGPU_INVALID_ARGUMENT, "join key %d: build type %d vs probe type %d (the planner coerces first)", c, logical_type(t->keys[c]), logical_type(pk[c]));
 }
 
+// The general table: open addressing over all key types (and the CSR of repeated keys), plus the membership bitmap when the
+// key is one integer column with a dense domain.
+static void build_hash_table(dfgpu_ctx* ctx, dfgpu_join_table* t, bool with_bitmap) {
+  int64_t n = t->n_build; const bool null_equals_null = t->null_equals_null;
+  uint64_t cap = 64; int bits = 6; while (cap < (uint64_t)n * 2) { cap <<= 1; bits++; }
+  if (cap > (1ull << 31)) fail(DFGPU_RESOURCES_EXHAUSTED, "build side of %lld rows exceeds the 2^30-row hash table limit", (long long)n);
+  t->capacity = cap; t->cap_bits = bits;
+  t->slots = alloc_buffer(ctx, cap * 8); HIP_CHECK(hipMemsetAsync(t->slots->ptr, 0xFF, cap * 8, ctx->stream));
+  BufferPtr row_slot = alloc_buffer(ctx, (size_t)(n + 1) * 4);
+  zero_scratch(ctx);
+  if (n) { KernelTimer kt_(ctx, "k_join_build"); hipLaunchKernelGGL(k_join_build, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, t->ks, n,
+                            t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr, null_equals_null ? 1 : 0, ctx->force_hash_collisions ? 1 : 0,
+                            (uint64_t*)t->slots->ptr, (uint32_t*)nullptr, cap - 1, (uint32_t*)row_slot->ptr, (unsigned long long*)ctx->d_scratch64); }
+  KERNEL_CHECK();
+  t->unique = read_scratch(ctx, 0) == 0;
+  t->mem += (int64_t)(cap * 8);
+  const dfgpu_array* key0 = t->keys[0];
+  if (with_bitmap && n && t->nkeys == 1 && !null_equals_null && key0->type != DFGPU_DICTIONARY && int_key_type(key0->type)) {
+    KernelTimer kt_(ctx, "join_build_bitmap");
+    long long init[2] = { INT64_MAX, INT64_MIN };
+    HIP_CHECK(hipMemcpyAsync(ctx->d_scratch64 + 4, init, 16, hipMemcpyHostToDevice, ctx->stream));
+    const void* kv = key0->values->ptr; const uint32_t* rs = (const uint32_t*)row_slot->ptr;
+    DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_minmax<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 2)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, rs, n,
+                                                          (long long*)(ctx->d_scratch64 + 4), (long long*)(ctx->d_scratch64 + 5)));
+    KERNEL_CHECK();
+    HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 4, ctx->d_scratch64 + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    long long lo = (long long)ctx->h_pinned[4], hi = (long long)ctx->h_pinned[5];
+    if (lo <= hi) {
+      uint64_t range = (uint64_t)hi - (uint64_t)lo + 1;
+      if (range != 0 && range <= (1ull << 32) && range <= (uint64_t)n * 4096 + 65536) {      // <= 512 MB and not absurdly sparse
+        t->bitmap = alloc_buffer(ctx, bitmap_bytes((int64_t)range), true); t->key_min = lo; t->range = range;
+        DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_setbits<T>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, rs, n, (int64_t)lo, (uint64_t*)t->bitmap->ptr));
+        KERNEL_CHECK();
+        t->mem += (int64_t)bitmap_bytes((int64_t)range);
+      }
+    }
+  }
+  if (!t->unique) {
+    t->slot_count = alloc_buffer(ctx, cap * 4, true);
+    hipLaunchKernelGGL(k_count_slots, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)row_slot->ptr, n, (uint32_t*)t->slot_count->ptr);
+    // CSR of build rows per key group: stable radix sort of (slot, row) then exclusive scan of group sizes
+    hipLaunchKernelGGL(k_fix_unslotted, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (uint32_t*)row_slot->ptr, n, (uint32_t)cap);
+    BufferPtr rows = alloc_buffer(ctx, (size_t)n * 4);
+    launch_iota_u32(ctx, (uint32_t*)rows->ptr, n, 0);
+    radix_sort_pairs_u32(ctx, (uint32_t*)row_slot->ptr, (uint32_t*)rows->ptr, n, bits + 1);
+    t->csr_rows = rows;
+    t->slot_start = alloc_buffer(ctx, cap * 4);
+    HIP_CHECK(hipMemcpyAsync(t->slot_start->ptr, t->slot_count->ptr, cap * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    exclusive_scan_u32_inplace32(ctx, (uint32_t*)t->slot_start->ptr, (int64_t)cap, nullptr);
+    t->mem += (int64_t)(cap * 8 + (size_t)n * 4);
+  }
+}
+
+// Rank index: taken when the single integer key column is strictly increasing (checked on the device, one streaming pass)
+// and its domain is dense enough for a bitmap.  Returns false (nothing built) otherwise.
+static bool build_rank_index(dfgpu_ctx* ctx, dfgpu_join_table* t) {
+  int64_t n = t->n_build;
+  if (!ctx->join_rank_index || ctx->force_hash_collisions || n < 2 || t->nkeys != 1 || t->null_equals_null) return false;
+  const dfgpu_array* key0 = t->keys[0];
+  if (key0->type == DFGPU_DICTIONARY || !int_key_type(key0->type) || key0->validity) return false;
+  const void* kv = key0->values->ptr; int w = type_width(key0->type);
+  KernelTimer kt_(ctx, "join_build_rank");
+  zero_scratch(ctx);
+  DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_check_increasing<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 8)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, n, (unsigned long long*)ctx->d_scratch64));
+  KERNEL_CHECK();
+  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 0, ctx->d_scratch64, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 4, kv, w, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 5, (const char*)kv + (size_t)(n - 1) * w, w, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (ctx->h_pinned[0] != 0) return false;
+  auto widen = [&](uint64_t raw) -> long long {
+    switch (key0->type) {
+      case DFGPU_INT8: return (int8_t)raw; case DFGPU_INT16: return (int16_t)raw; case DFGPU_INT32: case DFGPU_DATE32: return (int32_t)raw;
+      case DFGPU_UINT8: return (uint8_t)raw; case DFGPU_UINT16: return (uint16_t)raw; case DFGPU_UINT32: return (uint32_t)raw; default: return (long long)raw; } };
+  long long lo = widen(ctx->h_pinned[4]), hi = widen(ctx->h_pinned[5]);
+  uint64_t range = (uint64_t)hi - (uint64_t)lo + 1;
+  if (range == 0 || range > (1ull << 32) || range > (uint64_t)n * 4096 + 65536) return false;
+  const uint64_t* mk = t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr;
+  int64_t nw = (int64_t)((range + 63) / 64);
+  t->bitmap = alloc_buffer(ctx, bitmap_bytes((int64_t)range), true); t->key_min = lo; t->range = range;
+  DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_setbits_masked<T>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, mk, n, (int64_t)lo, (uint64_t*)t->bitmap->ptr));
+  KERNEL_CHECK();
+  t->mem += (int64_t)bitmap_bytes((int64_t)range);
+  t->rank_mode = true; t->unique = true; t->rank_identity = range == (uint64_t)n;
+  if (!t->rank_identity) {
+    t->rank_prefix = alloc_buffer(ctx, (size_t)nw * 4);
+    hipLaunchKernelGGL(k_popc_words, dim3(grid_for(nw, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)t->bitmap->ptr, nw, (uint32_t*)t->rank_prefix->ptr);
+    exclusive_scan_u32_inplace32(ctx, (uint32_t*)t->rank_prefix->ptr, nw, nullptr);
+    KERNEL_CHECK();
+    t->mem += nw * 4;
+    if (mk) { t->sel_rows = mask_to_indices_impl(ctx, mk, n); t->mem += t->sel_rows->length * 4; }
+  }
+  return true;
+}
+
 }  // namespace dfgpu
 
 extern "C" {
@@ -253,54 +394,9 @@ dfgpu_status dfgpu_join_build(dfgpu_ctx* ctx, const dfgpu_array* const* keys, in
     for (int c = 0; c < nkeys; c++) { t->keys.push_back(const_cast<dfgpu_array*>(keys[c])); dfgpu_array_retain(t->keys.back()); }
     int64_t n = keys[0]->length; t->n_build = n;
     t->build_mask = effective_mask(ctx, opt_mask, n);
-    uint64_t cap = 64; int bits = 6; while (cap < (uint64_t)n * 2) { cap <<= 1; bits++; }
-    if (cap > (1ull << 31)) fail(DFGPU_RESOURCES_EXHAUSTED, "build side of %lld rows exceeds the 2^30-row hash table limit", (long long)n);
-    t->capacity = cap; t->cap_bits = bits;
-    t->slots = alloc_buffer(ctx, cap * 8); HIP_CHECK(hipMemsetAsync(t->slots->ptr, 0xFF, cap * 8, ctx->stream));
     t->visited = alloc_buffer(ctx, bitmap_bytes(n), true);
-    BufferPtr row_slot = alloc_buffer(ctx, (size_t)(n + 1) * 4);
-    zero_scratch(ctx);
-    if (n) { KernelTimer kt_(ctx, "k_join_build"); hipLaunchKernelGGL(k_join_build, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, t->ks, n,
-                              t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr, null_equals_null ? 1 : 0, ctx->force_hash_collisions ? 1 : 0,
-                              (uint64_t*)t->slots->ptr, (uint32_t*)nullptr, cap - 1, (uint32_t*)row_slot->ptr, (unsigned long long*)ctx->d_scratch64); }
-    KERNEL_CHECK();
-    t->unique = read_scratch(ctx, 0) == 0;
-    t->mem = (int64_t)(cap * 12 + bitmap_bytes(n));
-    if (n && nkeys == 1 && !null_equals_null && keys[0]->type != DFGPU_DICTIONARY && int_key_type(keys[0]->type)) {
-      KernelTimer kt_(ctx, "join_build_bitmap");
-      long long init[2] = { INT64_MAX, INT64_MIN };
-      HIP_CHECK(hipMemcpyAsync(ctx->d_scratch64 + 4, init, 16, hipMemcpyHostToDevice, ctx->stream));
-      const void* kv = keys[0]->values->ptr; const uint32_t* rs = (const uint32_t*)row_slot->ptr;
-      DFGPU_INT_KEY_DISPATCH(keys[0]->type, hipLaunchKernelGGL((k_key_minmax<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 2)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, rs, n,
-                                                               (long long*)(ctx->d_scratch64 + 4), (long long*)(ctx->d_scratch64 + 5)));
-      KERNEL_CHECK();
-      HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 4, ctx->d_scratch64 + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
-      HIP_CHECK(hipStreamSynchronize(ctx->stream));
-      long long lo = (long long)ctx->h_pinned[4], hi = (long long)ctx->h_pinned[5];
-      if (lo <= hi) {
-        uint64_t range = (uint64_t)hi - (uint64_t)lo + 1;
-        if (range != 0 && range <= (1ull << 32) && range <= (uint64_t)n * 4096 + 65536) {      // <= 512 MB and not absurdly sparse
-          t->bitmap = alloc_buffer(ctx, bitmap_bytes((int64_t)range), true); t->key_min = lo; t->range = range;
-          DFGPU_INT_KEY_DISPATCH(keys[0]->type, hipLaunchKernelGGL((k_key_setbits<T>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, rs, n, (int64_t)lo, (uint64_t*)t->bitmap->ptr));
-          KERNEL_CHECK();
-          t->mem += (int64_t)bitmap_bytes((int64_t)range);
-        }
-      }
-    }
-    if (!t->unique) {
-      t->slot_count = alloc_buffer(ctx, cap * 4, true);
-      hipLaunchKernelGGL(k_count_slots, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)row_slot->ptr, n, (uint32_t*)t->slot_count->ptr);
-      // CSR of build rows per key group: stable radix sort of (slot, row) then exclusive scan of group sizes
-      hipLaunchKernelGGL(k_fix_unslotted, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (uint32_t*)row_slot->ptr, n, (uint32_t)cap);
-      BufferPtr rows = alloc_buffer(ctx, (size_t)n * 4);
-      launch_iota_u32(ctx, (uint32_t*)rows->ptr, n, 0);
-      radix_sort_pairs_u32(ctx, (uint32_t*)row_slot->ptr, (uint32_t*)rows->ptr, n, bits + 1);
-      t->csr_rows = rows;
-      t->slot_start = alloc_buffer(ctx, cap * 4);
-      HIP_CHECK(hipMemcpyAsync(t->slot_start->ptr, t->slot_count->ptr, cap * 4, hipMemcpyDeviceToDevice, ctx->stream));
-      exclusive_scan_u32_inplace32(ctx, (uint32_t*)t->slot_start->ptr, (int64_t)cap, nullptr);
-      t->mem += (int64_t)(cap * 4 + (size_t)n * 4);
-    }
+    t->mem = (int64_t)bitmap_bytes(n);
+    if (!build_rank_index(ctx, t.get())) build_hash_table(ctx, t.get(), true);
     *out = t.release();
   });
 }
@@ -321,9 +417,11 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
     int nen = t->null_equals_null ? 1 : 0, fz = ctx->force_hash_collisions ? 1 : 0;
     // pass 1: match bit per probe row
     BufferPtr match_bits = alloc_buffer(ctx, bitmap_bytes(n), n == 0);
+    bool use_bitmap = false;
     if (n) {
       const dfgpu_array* pk = probe_keys[0];
-      bool use_bitmap = t->bitmap && pk->type == t->keys[0]->type;      // same physical integer type, no dictionary
+      use_bitmap = t->bitmap && pk->type == t->keys[0]->type;      // same physical integer type, no dictionary
+      if (!use_bitmap && !t->slots) build_hash_table(ctx, const_cast<dfgpu_join_table*>(t), false);   // rank index cannot serve this probe column
       if (use_bitmap) {
         KernelTimer kt_(ctx, "k_probe_match_bitmap");
         int64_t rows_per_block = (int64_t)BLOCK * PM_ROWS;
@@ -340,7 +438,16 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
     int64_t m = rows.get()->length;
     const uint32_t* rp = (const uint32_t*)rows.get()->values->ptr;
     ArrayHolder ob, op;
-    if (t->unique) {
+    if (t->rank_mode && use_bitmap) {
+      ob.a = new_fixed(ctx, DFGPU_UINT64, m);
+      const dfgpu_array* pk = probe_keys[0];
+      if (m) { KernelTimer kt_(ctx, "k_probe_lookup_rank");
+        DFGPU_INT_KEY_DISPATCH(pk->type, hipLaunchKernelGGL((k_probe_lookup_rank<T>), dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const T*)pk->values->ptr, rp, m, t->key_min,
+                                                            (const uint64_t*)t->bitmap->ptr, t->rank_prefix ? (const uint32_t*)t->rank_prefix->ptr : nullptr,
+                                                            t->sel_rows ? (const uint32_t*)t->sel_rows->values->ptr : nullptr, t->rank_identity ? 1 : 0, (uint64_t*)ob.get()->values->ptr)); }
+      KERNEL_CHECK();
+      op.a = rows.release();
+    } else if (t->unique) {
       ob.a = new_fixed(ctx, DFGPU_UINT64, m);
       if (m) { KernelTimer kt_(ctx, "k_probe_lookup");
         hipLaunchKernelGGL(k_probe_lookup, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, t->ks, pks, rp, m, nen, fz, (const uint64_t*)t->slots->ptr, (const uint32_t*)nullptr,

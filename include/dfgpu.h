@@ -86,7 +86,9 @@ DFGPU_API void dfgpu_ctx_destroy(dfgpu_ctx *ctx);
 DFGPU_API const char *dfgpu_last_error(const dfgpu_ctx *ctx);
 DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
 /* options: "force_hash_collisions" (0/1) == cargo feature of common/src/hash_utils.rs:306-318;
- * "first_seen_group_order" (1/0) == group ids in first-seen order (group_values/primitive.rs:137-141). */
+ * "first_seen_group_order" (1/0) == group ids in first-seen order (group_values/primitive.rs:137-141);
+ * "join_rank_index" (1/0) == let join_build replace the hash table by a bitmap rank index when the single integer key
+ * column is strictly increasing (results identical either way; the switch exists for A/B tests). */
 DFGPU_API dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx *ctx, const char *key, int64_t value);
 DFGPU_API void *dfgpu_ctx_stream(dfgpu_ctx *ctx);
 DFGPU_API const char *dfgpu_version(void);

@@ -127,6 +127,67 @@ def test_probe_with_fused_masks_equals_filtered_inputs(ctx):
     assert np.array_equal(fin, np.flatnonzero(bm & ~visited))
 
 
+def sorted_unique_keys(n, dtype, shape):
+    """strictly increasing build keys: 'dense' = k0 + row (identity), 'sparse' = TPC-H style gaps, 'wide' = too sparse for a bitmap."""
+    if shape == "dense": k = np.arange(n, dtype=np.int64) - 1000
+    elif shape == "sparse": k = np.cumsum(RNG.integers(1, 9, n)) - 5000
+    else: k = np.cumsum(RNG.integers(1, 10**7 if dtype == np.int64 else 50000, n))
+    return k.astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64], ids=["int32", "int64"])
+@pytest.mark.parametrize("shape", ["dense", "sparse", "wide"])
+@pytest.mark.parametrize("masked", [False, True])
+def test_rank_index_build_equals_hash_build_and_oracle(ctx, dtype, shape, masked):
+    """Strictly increasing integer build keys take the bitmap rank index (join.hip build_rank_index) instead of the hash table:
+    pairs must equal the oracle's and the hash-table path's (option join_rank_index=0), probe NULLs / misses / selection included."""
+    import dfgpu
+    nb, npr = 40000, 150000
+    bk = sorted_unique_keys(nb, dtype, shape)
+    lo, hi = int(bk[0]) - 500, int(bk[-1]) + 500
+    pk = RNG.integers(lo, hi, npr).astype(dtype)
+    hit = RNG.random(npr) < 0.4
+    pk[hit] = RNG.choice(bk, int(hit.sum()))
+    b = pa.array(bk); p = pa.array(pk, mask=RNG.random(npr) < 0.05)
+    bm = RNG.random(nb) < 0.5 if masked else None
+    pm = RNG.random(npr) < 0.7 if masked else None
+    got = []
+    for rank in (1, 0):
+        ctx.set_option("join_rank_index", rank)
+        try:
+            table = dfgpu.JoinTable(ctx, [ctx.from_arrow(b)], mask=ctx.from_arrow(pa.array(bm)) if masked else None)
+            bi, pi = table.probe([ctx.from_arrow(p)], mask=ctx.from_arrow(pa.array(pm)) if masked else None)
+            got.append((bi.to_numpy().astype(np.int64), pi.to_numpy().astype(np.int64)))
+            table.mark_visited(bi)
+            got[-1] += (table.final_indices(dfgpu.capi.JOIN_LEFT).to_numpy(),)
+        finally:
+            ctx.set_option("join_rank_index", 1)
+    bsel, psel = (b.filter(pa.array(bm)), p.filter(pa.array(pm))) if masked else (b, p)
+    want = po.hash_join([[bsel]], [[psel]], "Inner", batch_size=1 << 40)
+    bmap = np.flatnonzero(bm) if masked else np.arange(nb)
+    pmap = np.flatnonzero(pm) if masked else np.arange(npr)
+    for bi, pi, fin in got:
+        assert np.array_equal(bi, bmap[want.build_idx])
+        assert np.array_equal(pi, pmap[want.probe_idx])
+        visited = np.zeros(nb, bool); visited[bmap[want.build_idx]] = True
+        assert np.array_equal(fin, np.flatnonzero((bm if masked else np.ones(nb, bool)) & ~visited))
+
+
+def test_rank_index_falls_back_to_hash_for_dictionary_probe_keys(ctx):
+    """A rank-indexed build probed by a dictionary-encoded column of the same logical type builds its hash table lazily."""
+    import dfgpu
+    bk = np.arange(0, 3000, 3, dtype=np.int64)
+    table = dfgpu.JoinTable(ctx, [ctx.from_arrow(pa.array(bk))])
+    plain = pa.array(RNG.integers(-10, 3100, 20000).astype(np.int64), mask=RNG.random(20000) < 0.1)
+    bi0, pi0 = table.probe([ctx.from_arrow(plain)])
+    bi1, pi1 = table.probe([ctx.from_arrow(plain.dictionary_encode())])
+    bi2, pi2 = table.probe([ctx.from_arrow(plain)])                       # rank path again after the fallback
+    want = po.hash_join([[pa.array(bk)]], [[plain]], "Inner", batch_size=1 << 40)
+    for bi, pi in ((bi0, pi0), (bi1, pi1), (bi2, pi2)):
+        assert np.array_equal(bi.to_numpy().astype(np.int64), want.build_idx)
+        assert np.array_equal(pi.to_numpy().astype(np.int64), want.probe_idx)
+
+
 @pytest.mark.parametrize("jt", ["Inner", "Left", "Right", "Full", "LeftSemi", "RightSemi", "LeftAnti", "RightAnti"])
 def test_join_types_fuzz_vs_oracle(ctx, task_ctx, jt):
     """All 8 join types over multi-batch inputs with NULL keys and duplicate keys; multiset of output rows equals the oracle's."""
