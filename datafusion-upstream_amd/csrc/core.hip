@@ -82,7 +82,16 @@ dfgpu_array* new_fixed(dfgpu_ctx* ctx, int32_t type, int64_t length, int32_t pre
   return h.release();
 }
 
+void flush_flags(dfgpu_ctx* ctx) {
+  if (!ctx->flags_pending) return;
+  ctx->flags_pending = false;
+  int saved = ctx->defer_flag_checks; ctx->defer_flag_checks = 0;
+  std::string what = ctx->flags_what;
+  struct Restore { dfgpu_ctx* c; int v; ~Restore() { c->defer_flag_checks = v; } } r{ctx, saved};
+  check_flags(ctx, what.c_str());
+}
 void check_flags(dfgpu_ctx* ctx, const char* what) {
+  if (ctx->defer_flag_checks > 0) { if (!ctx->flags_pending) ctx->flags_what = what; else if (ctx->flags_what.find(what) == std::string::npos) ctx->flags_what += std::string(", ") + what; ctx->flags_pending = true; return; }
   uint32_t f = 0;
   HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 63, ctx->d_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -264,13 +273,17 @@ dfgpu_status dfgpu_ctx_create(int32_t device_id, void* stream, dfgpu_ctx** out) 
 void dfgpu_ctx_destroy(dfgpu_ctx* ctx) { if (ctx) ctx_unref(ctx); }
 const char* dfgpu_last_error(const dfgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 void* dfgpu_ctx_stream(dfgpu_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
-dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx* ctx) { return guard(ctx, [&] { HIP_CHECK(hipSetDevice(ctx->device)); HIP_CHECK(hipStreamSynchronize(ctx->stream)); }); }
+dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx* ctx) { return guard(ctx, [&] { HIP_CHECK(hipSetDevice(ctx->device)); HIP_CHECK(hipStreamSynchronize(ctx->stream)); flush_flags(ctx); }); }
 dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value) {
   return guard(ctx, [&] {
     std::string k = key ? key : "";
     if (k == "force_hash_collisions") ctx->force_hash_collisions = value != 0;
     else if (k == "first_seen_group_order") ctx->first_seen_group_order = value != 0;
     else if (k == "join_rank_index") ctx->join_rank_index = value != 0;
+    else if (k == "defer_flag_checks") {            // nests: +1 enters a deferred region, 0 leaves it and raises what the region deferred
+      if (value) ctx->defer_flag_checks++;
+      else { if (ctx->defer_flag_checks > 0) ctx->defer_flag_checks--; if (ctx->defer_flag_checks == 0) flush_flags(ctx); }
+    }
     else fail(DFGPU_INVALID_ARGUMENT, "unknown option '%s'", k.c_str());
   });
 }
@@ -320,6 +333,7 @@ dfgpu_status dfgpu_array_describe(const dfgpu_array* a, dfgpu_array_desc* o) {
 dfgpu_status dfgpu_array_export_host(dfgpu_ctx* ctx, const dfgpu_array* a, void* values, uint8_t* validity, int32_t* offsets) {
   return guard(ctx, [&] {
     HIP_CHECK(hipSetDevice(ctx->device));
+    flush_flags(ctx);                                   // data never leaves the device past a deferred kernel error
     int64_t n = a->length; int32_t vt = a->type == DFGPU_DICTIONARY ? a->key_type : a->type;
     size_t vbytes = a->type == DFGPU_UTF8 ? (size_t)a->values_bytes : (vt == DFGPU_BOOL ? (size_t)(n + 7) / 8 : (size_t)n * type_width(vt));
     if (values && vbytes) HIP_CHECK(hipMemcpyAsync(values, a->values->ptr, vbytes, hipMemcpyDeviceToHost, ctx->stream));

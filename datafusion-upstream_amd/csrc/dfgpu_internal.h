@@ -41,6 +41,9 @@ struct dfgpu_ctx {
   bool force_hash_collisions = false;
   bool first_seen_group_order = true;
   bool join_rank_index = true;
+  // kernel error flags (overflow, divide by zero, cast range, index bounds): checked after the raising call, or -- inside one
+  // poll of a plan's output stream -- once before the batch is handed out (saves a stream sync per kernel-level call)
+  int defer_flag_checks = 0; bool flags_pending = false; std::string flags_what;
   uint32_t* d_flags = nullptr;      // device word for kernel error flags
   uint64_t* d_scratch64 = nullptr;  // 64 x u64 device scratch for counters / totals
   uint64_t* h_pinned = nullptr;     // 64 x u64 pinned host mirror
@@ -114,6 +117,7 @@ struct ArrayHolder {   // RAII release on exception paths
 
 // Read back the kernel error flags (synchronises) and raise the matching DataFusionError analogue.
 void check_flags(dfgpu_ctx* ctx, const char* what);
+void flush_flags(dfgpu_ctx* ctx);                          // the deferred check, now
 uint64_t read_scratch(dfgpu_ctx* ctx, int slot);          // sync + D2H of d_scratch64[slot]
 void zero_scratch(dfgpu_ctx* ctx);
 

@@ -715,7 +715,16 @@ dfgpu_status dfgpu_plan_execute(const dfgpu_plan* p, int32_t partition, dfgpu_ct
   });
 }
 dfgpu_status dfgpu_stream_next(dfgpu_stream* s, dfgpu_batch** out) {
-  return guard([&] { if (!s || !out) fail(DFGPU_INVALID_ARGUMENT, "stream_next: null argument"); Batch b; if (!s->s->next(b)) { *out = nullptr; return; } *out = new dfgpu_batch{std::move(b)}; });
+  return guard([&] {
+    if (!s || !out) fail(DFGPU_INVALID_ARGUMENT, "stream_next: null argument");
+    // one poll of the output stream = one deferred region for kernel error flags: raised before the batch is handed out
+    struct Region { dfgpu_ctx* c; bool open = true; Region(dfgpu_ctx* c_) : c(c_) { dfgpu_ctx_set_option(c, "defer_flag_checks", 1); }
+                    dfgpu_status close() { open = false; return dfgpu_ctx_set_option(c, "defer_flag_checks", 0); } ~Region() { if (open) close(); } } region(s->tc.ctx);
+    Batch b; bool more = s->s->next(b);
+    s->tc.check(region.close());
+    if (!more) { *out = nullptr; return; }
+    *out = new dfgpu_batch{std::move(b)};
+  });
 }
 void dfgpu_stream_free(dfgpu_stream* s) { delete s; }
 

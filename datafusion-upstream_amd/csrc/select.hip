@@ -121,7 +121,7 @@ dfgpu_array* take_impl(dfgpu_ctx* ctx, const dfgpu_array* a, const void* idx, in
 }
 
 // ---------------------------------------------------------------- mask -> ascending selection vector
-constexpr int SEL_WORDS = 32;           // 64-bit mask words per workgroup = 2048 rows
+constexpr int SEL_WORDS = BLOCK;        // 64-bit mask words per workgroup (one per thread) = 16384 rows
 __device__ inline uint64_t mask_word(const uint64_t* bits, int64_t w, int64_t n) {
   int64_t nw = (n + 63) >> 6; if (w >= nw) return 0;
   uint64_t x = bits[w];
@@ -129,25 +129,32 @@ __device__ inline uint64_t mask_word(const uint64_t* bits, int64_t w, int64_t n)
   return x;
 }
 __global__ void __launch_bounds__(BLOCK) k_sel_count(const uint64_t* bits, int64_t n, uint32_t* counts) {
-  int64_t w0 = (int64_t)blockIdx.x * SEL_WORDS;
-  if (threadIdx.x < 64) {
-    uint32_t c = threadIdx.x < SEL_WORDS ? __popcll(mask_word(bits, w0 + threadIdx.x, n)) : 0;
-    c = wave_sum(c);
-    if (threadIdx.x == 0) counts[blockIdx.x] = c;
-  }
+  uint32_t c = (uint32_t)__popcll(mask_word(bits, (int64_t)blockIdx.x * SEL_WORDS + threadIdx.x, n));
+  __shared__ uint32_t lds[BLOCK / WAVE];
+  uint32_t tot; (void)block_exclusive_sum<uint32_t>(c, lds, &tot);
+  if (threadIdx.x == 0) counts[blockIdx.x] = tot;
 }
+// Each lane owns one mask word.  A wave whose 4096 rows hold few set bits lets every lane walk its own bits; a dense
+// wave goes word by word with all 64 lanes testing one bit each so that the index stores coalesce.
 __global__ void __launch_bounds__(BLOCK) k_sel_write(const uint64_t* bits, int64_t n, const uint32_t* offsets, uint32_t* out) {
-  int64_t w0 = (int64_t)blockIdx.x * SEL_WORDS;
-  int lane = lane_id(), wave = threadIdx.x >> 6;
-  uint64_t word = lane < SEL_WORDS ? mask_word(bits, w0 + lane, n) : 0;
-  uint32_t pc = __popcll(word);
-  uint32_t ex = wave_inclusive_sum(pc) - pc;
-  uint32_t base = offsets[blockIdx.x];
-#pragma unroll
-  for (int k = 0; k < SEL_WORDS / 4; k++) {
-    int wi = wave * (SEL_WORDS / 4) + k;
-    uint64_t m = __shfl(word, wi, 64); uint32_t p = __shfl(ex, wi, 64);
-    if ((m >> lane) & 1) out[base + p + __popcll(m & lanemask_lt())] = (uint32_t)((w0 + wi) * 64 + lane);
+  int64_t w = (int64_t)blockIdx.x * SEL_WORDS + threadIdx.x;
+  int lane = lane_id();
+  uint64_t word = mask_word(bits, w, n);
+  uint32_t pc = (uint32_t)__popcll(word);
+  __shared__ uint32_t lds[BLOCK / WAVE];
+  uint32_t tot; uint32_t ex = block_exclusive_sum<uint32_t>(pc, lds, &tot) + offsets[blockIdx.x];
+  uint32_t wave_tot = wave_sum(pc);
+  if (wave_tot == 0) return;
+  if (wave_tot <= 8 * WAVE) {
+    uint32_t row0 = (uint32_t)(w * 64);
+    while (word) { out[ex++] = row0 + (uint32_t)__builtin_ctzll(word); word &= word - 1; }
+  } else {
+    int64_t wave_w0 = w - lane;
+    for (int k = 0; k < WAVE; k++) {
+      uint64_t m = __shfl(word, k, 64); uint32_t p = __shfl(ex, k, 64);
+      if (m == 0) continue;
+      if ((m >> lane) & 1) out[p + __popcll(m & lanemask_lt())] = (uint32_t)((wave_w0 + k) * 64 + lane);
+    }
   }
 }
 dfgpu_array* mask_to_indices_impl(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n) {

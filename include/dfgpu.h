@@ -88,7 +88,11 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
 /* options: "force_hash_collisions" (0/1) == cargo feature of common/src/hash_utils.rs:306-318;
  * "first_seen_group_order" (1/0) == group ids in first-seen order (group_values/primitive.rs:137-141);
  * "join_rank_index" (1/0) == let join_build replace the hash table by a bitmap rank index when the single integer key
- * column is strictly increasing (results identical either way; the switch exists for A/B tests). */
+ * column is strictly increasing (results identical either way; the switch exists for A/B tests);
+ * "defer_flag_checks" (1 = enter / 0 = leave a deferred region, nests) == kernel error flags (overflow, divide by zero,
+ * cast range, index bounds -- the ArrowError cases of arrow-arith / arrow-cast / arrow-select) are normally checked by the
+ * call that ran the kernel; inside a region they are checked once, by the call that leaves it (which returns the error),
+ * and always before array_export_host / ctx_synchronize return.  dfgpu_stream_next polls inside one region. */
 DFGPU_API dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx *ctx, const char *key, int64_t value);
 DFGPU_API void *dfgpu_ctx_stream(dfgpu_ctx *ctx);
 DFGPU_API const char *dfgpu_version(void);

@@ -10,6 +10,12 @@ template <int MODE, int ROWS>
 __global__ void __launch_bounds__(256) k(const int64_t* keys, const uint64_t* mask, const uint64_t* bitmap, int64_t n, uint64_t range, uint64_t* out) {
   int lane = threadIdx.x & 63;
   int64_t base = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * ROWS);
+  // MODE 3/4: the wave's 64*ROWS clustered keys fall into one 64-word bitmap window: one coalesced load, then LDS / bpermute lookups
+  __shared__ uint64_t win_lds[4][64];
+  uint64_t win = 0; int64_t w0i = 0;
+  if (MODE >= 3 && base < n) { uint64_t d0 = (uint64_t)__builtin_nontemporal_load(keys + base); d0 = __builtin_amdgcn_readfirstlane((uint32_t)d0) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(d0 >> 32)) << 32);
+    w0i = (int64_t)(d0 >> 6); int64_t wi = w0i + lane; win = (uint64_t)wi * 64 < range ? bitmap[wi] : 0;
+    if (MODE == 3) win_lds[threadIdx.x >> 6][lane] = win; }
   int64_t kk[ROWS / 2][2];
 #pragma unroll
   for (int r = 0; r < ROWS / 2; r++) { int64_t j = base + r * 128 + 2 * lane; if (j + 1 < n) { longlong2 p = *(const longlong2*)(keys + j); kk[r][0] = p.x; kk[r][1] = p.y; } else { kk[r][0] = kk[r][1] = 0; } }
@@ -22,6 +28,13 @@ __global__ void __launch_bounds__(256) k(const int64_t* keys, const uint64_t* ma
     for (int e = 0; e < 2; e++) {
       uint64_t d = (uint64_t)kk[r][e];
       bool go = j + e < n && ((mw >> e) & 1) && d < range;
+      if (MODE >= 3) {
+        int64_t rel = (int64_t)(d >> 6) - w0i; bool in = rel >= 0 && rel < 64;
+        uint64_t word;
+        if (MODE == 3) word = win_lds[threadIdx.x >> 6][rel & 63]; else word = __shfl(win, (int)(rel & 63), 64);
+        if (go && !in) word = bitmap[d >> 6];
+        h[e] = go && ((word >> (d & 63)) & 1);
+      } else
       if (MODE >= 2) h[e] = go ? (bitmap[d >> 6] >> (d & 63)) & 1 : false; else h[e] = go && (d & 4);
     }
     uint64_t be = __ballot(h[0]), bo = __ballot(h[1]);
@@ -47,6 +60,8 @@ int main() {
   for (int rnd = 0; rnd < 2; rnd++) {
     hipLaunchKernelGGL(init_keys, dim3((n + 255) / 256), dim3(256), 0, 0, keys, n, rnd); CK(hipDeviceSynchronize());
     float a8 = run<0, 8>(keys, mask, bm, n, out), b8 = run<1, 8>(keys, mask, bm, n, out), c8 = run<2, 8>(keys, mask, bm, n, out);
+    float w3 = run<3, 8>(keys, mask, bm, n, out), w4 = run<4, 8>(keys, mask, bm, n, out), w3_16 = run<3, 16>(keys, mask, bm, n, out), w4_16 = run<4, 16>(keys, mask, bm, n, out);
+    printf("window variants: LDS %.3f ms, bpermute %.3f ms | rows/lane 16: LDS %.3f bpermute %.3f\n", w3, w4, w3_16, w4_16);
     float a16 = run<0, 16>(keys, mask, bm, n, out), c16 = run<2, 16>(keys, mask, bm, n, out), c4 = run<2, 4>(keys, mask, bm, n, out);
     printf("%s keys: A(keys only) %.3f ms = %.2f TB/s | B(+mask) %.3f | C(+bitmap) %.3f ms = %.2f TB/s | rows/lane 16: A %.3f C %.3f | rows/lane 4: C %.3f\n", rnd ? "random" : "sorted",
            a8, n * 8.0 / a8 / 1e9, b8, c8, n * 8.25 / c8 / 1e9, a16, c16, c4);

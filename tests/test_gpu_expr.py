@@ -118,6 +118,31 @@ def test_decimal_overflow_is_an_error(ctx):
         po.binary("*", big, big)
 
 
+def test_deferred_flag_region_raises_when_left_and_before_export(ctx):
+    """Option defer_flag_checks (include/dfgpu.h): inside a region the kernel error surfaces when the region is left, and
+    never later than an export of device data; afterwards the context is clean again."""
+    import dfgpu
+    big = pa.array([decimal.Decimal(10**37)], type=pa.decimal128(38, 0))
+    ok = pa.array([decimal.Decimal(3)], type=pa.decimal128(38, 0))
+    ctx.set_option("defer_flag_checks", 1)
+    ctx.set_option("defer_flag_checks", 1)           # regions nest
+    dev_binary(ctx, "*", ok, ok)
+    bad = ctx.from_arrow(big)
+    ctx.binary(OPCODE["*"], bad, bad)                # no error yet
+    ctx.set_option("defer_flag_checks", 0)           # inner region left: still deferred
+    with pytest.raises(dfgpu.DfgpuError) as e:
+        ctx.set_option("defer_flag_checks", 0)
+    assert e.value.kind == "Execution" and "overflow" in str(e.value).lower()
+    ctx.set_option("defer_flag_checks", 1)
+    try:
+        out = ctx.binary(OPCODE["*"], bad, bad)
+        with pytest.raises(dfgpu.DfgpuError):
+            out.to_arrow()
+    finally:
+        ctx.set_option("defer_flag_checks", 0)
+    assert dev_binary(ctx, "*", ok, ok).to_pylist() == [decimal.Decimal(9)]
+
+
 @pytest.mark.parametrize("op", ["AND", "OR"])
 def test_kleene_logic(ctx, op):
     l, r = rand_array("bool", 5000, 0.3), rand_array("bool", 5000, 0.3)
