@@ -80,6 +80,7 @@ PROTOTYPES = {
     "dfgpu_ctx_stream": (_P, [_P]),
     "dfgpu_version": (C.c_char_p, []),
     "dfgpu_profile_enable": (C.c_int32, [_P, C.c_int32]),
+    "dfgpu_profile_select": (C.c_int32, [_P, C.c_char_p]),
     "dfgpu_profile_read": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
     "dfgpu_array_import_host": (C.c_int32, [_P, C.POINTER(ArrayDesc), _PP]),
     "dfgpu_array_wrap_device": (C.c_int32, [_P, C.POINTER(ArrayDesc), _PP]),

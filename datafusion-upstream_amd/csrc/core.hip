@@ -292,6 +292,10 @@ dfgpu_status dfgpu_profile_enable(dfgpu_ctx* ctx, int32_t on) {
   if (!ctx) return DFGPU_INVALID_ARGUMENT;
   ctx->profile = on != 0; return DFGPU_OK;
 }
+dfgpu_status dfgpu_profile_select(dfgpu_ctx* ctx, const char* kernel_name) {
+  if (!ctx) return DFGPU_INVALID_ARGUMENT;
+  ctx->profile_only = kernel_name ? kernel_name : ""; return DFGPU_OK;
+}
 dfgpu_status dfgpu_profile_read(dfgpu_ctx* ctx, char* buf, int64_t capacity) {
   return guard(ctx, [&] {
     if (!buf || capacity < 1) fail(DFGPU_INVALID_ARGUMENT, "profile_read: no buffer");

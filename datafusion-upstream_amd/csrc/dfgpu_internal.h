@@ -54,7 +54,7 @@ struct dfgpu_ctx {
   std::mutex* alloc_mu = nullptr;
   std::vector<std::pair<size_t, void*>>* free_blocks = nullptr;   // (class bytes, ptr)
   size_t cached_bytes = 0, live_bytes = 0;
-  bool profile = false;
+  bool profile = false; std::string profile_only;
   struct ProfRec { const char* name; hipEvent_t start, stop; };
   std::vector<ProfRec> prof;
 };
@@ -160,7 +160,7 @@ void radix_sort_pairs_u32(dfgpu_ctx* ctx, uint32_t* keys, uint32_t* vals, int64_
 struct KernelTimer {
   dfgpu_ctx* c; int idx = -1;
   KernelTimer(dfgpu_ctx* ctx, const char* name) : c(ctx) {
-    if (!c->profile) return;
+    if (!c->profile || (!c->profile_only.empty() && c->profile_only != name)) return;
     dfgpu_ctx::ProfRec r{name, nullptr, nullptr};
     if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
     (void)hipEventRecord(r.start, c->stream); c->prof.push_back(r); idx = (int)c->prof.size() - 1;

@@ -153,14 +153,12 @@ __global__ void __launch_bounds__(BLOCK) k_max_utf8_len(ColView v, int64_t n, un
   for (int d = 32; d > 0; d >>= 1) { unsigned int o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
   if (lane_id() == 0 && m) atomicMax(out, m);
 }
-// per-plane digit totals: tot[plane * 256 + digit]
-__global__ void __launch_bounds__(BLOCK) k_plane_totals(const uint8_t* planes, int64_t n, uint32_t* tot) {
-  __shared__ uint32_t h[256];
-  h[threadIdx.x] = 0; __syncthreads();
+// varies[plane] = 1 when the plane holds more than one byte value (a constant plane needs no radix pass)
+__global__ void __launch_bounds__(BLOCK) k_plane_varies(const uint8_t* planes, int64_t n, uint32_t* varies) {
   const uint8_t* p = planes + (int64_t)blockIdx.y * n;
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) atomicAdd(&h[p[i]], 1u);
-  __syncthreads();
-  if (h[threadIdx.x]) atomicAdd(&tot[blockIdx.y * 256 + threadIdx.x], h[threadIdx.x]);
+  uint8_t first = p[0]; bool diff = false;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) diff |= p[i] != first;
+  if (ballot64(diff) && lane_id() == 0) varies[blockIdx.y] = 1u;
 }
 
 }  // namespace dfgpu
@@ -191,25 +189,22 @@ extern "C" dfgpu_status dfgpu_sort_to_indices(dfgpu_ctx* ctx, const dfgpu_array*
     ArrayHolder idx(new_fixed(ctx, DFGPU_UINT32, n));
     launch_iota_u32(ctx, (uint32_t*)idx.get()->values->ptr, n, 0);
     if (n > 1) {
-      BufferPtr planes = alloc_buffer(ctx, (size_t)W * n), tot = alloc_buffer(ctx, (size_t)W * 256 * 4, true);
+      BufferPtr planes = alloc_buffer(ctx, (size_t)W * n), varies = alloc_buffer(ctx, (size_t)W * 4, true);
       hipLaunchKernelGGL(k_encode_sort_keys, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, sc, n, (uint8_t*)planes->ptr);
-      hipLaunchKernelGGL(k_plane_totals, dim3(grid_for(n, BLOCK * 16, 256), W), dim3(BLOCK), 0, ctx->stream, (const uint8_t*)planes->ptr, n, (uint32_t*)tot->ptr);
+      hipLaunchKernelGGL(k_plane_varies, dim3(grid_for(n, BLOCK * 16, 256), W), dim3(BLOCK), 0, ctx->stream, (const uint8_t*)planes->ptr, n, (uint32_t*)varies->ptr);
       KERNEL_CHECK();
-      std::vector<uint32_t> h((size_t)W * 256);
-      HIP_CHECK(hipMemcpyAsync(h.data(), tot->ptr, h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+      std::vector<uint32_t> h((size_t)W);
+      HIP_CHECK(hipMemcpyAsync(h.data(), varies->ptr, h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
       HIP_CHECK(hipStreamSynchronize(ctx->stream));
       RadixPlan p = plan_for(n);
       BufferPtr tmp = alloc_buffer(ctx, (size_t)n * 4), hist = alloc_buffer(ctx, (size_t)256 * p.nb * 4);
       uint32_t *v0 = (uint32_t*)idx.get()->values->ptr, *v1 = (uint32_t*)tmp->ptr;
       for (int b = W - 1; b >= 0; b--) {        // least significant plane first
-        bool constant = false;
-        for (int d = 0; d < 256; d++) if (h[(size_t)b * 256 + d] == (uint32_t)n) { constant = true; break; }
-        if (constant) continue;
+        if (!h[(size_t)b]) continue;
         radix_pass(ctx, DigitPlane{ (const uint8_t*)planes->ptr + (int64_t)b * n }, (const uint32_t*)nullptr, v0, (uint32_t*)nullptr, v1, n, (uint32_t*)hist->ptr, p);
         std::swap(v0, v1);
       }
       if (v0 != (uint32_t*)idx.get()->values->ptr) HIP_CHECK(hipMemcpyAsync(idx.get()->values->ptr, v0, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-      HIP_CHECK(hipStreamSynchronize(ctx->stream));   // tmp / planes are released on return
     }
     if (fetch >= 0 && fetch < n) { dfgpu_array* s = nullptr; dfgpu_status st = dfgpu_array_slice(ctx, idx.get(), 0, fetch, &s); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str()); *out = s; }
     else *out = idx.release();

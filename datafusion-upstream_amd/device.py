@@ -46,6 +46,9 @@ class Context:
     def profile_enable(self, on: bool = True):
         self.check(self.lib.dfgpu_profile_enable(self.h, int(on)))
 
+    def profile_select(self, kernel_name: Optional[str] = None):
+        self.check(self.lib.dfgpu_profile_select(self.h, kernel_name.encode() if kernel_name else None))
+
     def profile_read(self) -> dict:
         """kernel name -> (launches, total_ms) since the last read; HIP events on this ctx's stream."""
         buf = C.create_string_buffer(1 << 16)

@@ -98,8 +98,11 @@ DFGPU_API void *dfgpu_ctx_stream(dfgpu_ctx *ctx);
 DFGPU_API const char *dfgpu_version(void);
 /* Per-kernel device time measured with HIP events on the ctx stream (used by bench.py for the roofline
  * figure; ≙ the BaselineMetrics elapsed_compute timers of physical-plan/src/metrics/baseline.rs:47-56).
- * dfgpu_profile_read writes lines "kernel_name launches total_ms\n" into buf, then clears the records. */
+ * dfgpu_profile_read writes lines "kernel_name launches total_ms\n" into buf, then clears the records.
+ * dfgpu_profile_select restricts the timers to one kernel name (NULL = all): an event pair costs ~10 us of stream
+ * bubble, so a timed region is measured with only its dominant kernel bracketed. */
 DFGPU_API dfgpu_status dfgpu_profile_enable(dfgpu_ctx *ctx, int32_t on);
+DFGPU_API dfgpu_status dfgpu_profile_select(dfgpu_ctx *ctx, const char *kernel_name);
 DFGPU_API dfgpu_status dfgpu_profile_read(dfgpu_ctx *ctx, char *buf, int64_t capacity);
 
 /* ------------------------------------------------------------------ arrays */
