@@ -107,26 +107,23 @@ __global__ void __launch_bounds__(BLOCK) k_probe_match_hash(KeySet bks, KeySet p
   uint64_t m = ballot64(hit);
   if (lane_id() == 0 && (j >> 6) < ((n + 63) >> 6)) match_bits[j >> 6] = m;
 }
-// dense integer key domain: stream the probe keys, test one bit each.  4 rows per lane, 4 loads in flight.
+// dense integer key domain: stream the probe keys, test one bit each
 constexpr int PM_ROWS = 8;          // rows per lane: 4 iterations x 2 consecutive keys (one 16-B load for Int64 keys)
 __device__ inline uint64_t spread32(uint64_t x) {      // bit i -> bit 2i
   x &= 0xFFFFFFFFull;
   x = (x | (x << 16)) & 0x0000FFFF0000FFFFull; x = (x | (x << 8)) & 0x00FF00FF00FF00FFull; x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
   x = (x | (x << 2)) & 0x3333333333333333ull; x = (x | (x << 1)) & 0x5555555555555555ull; return x;
 }
-template <typename T>
-__global__ void __launch_bounds__(BLOCK) k_probe_match_bitmap(const T* keys, const uint64_t* key_valid, const uint64_t* mask, int64_t n, int64_t kmin, uint64_t range,
-                                                              const uint64_t* bitmap, uint64_t* match_bits) {
-  int lane = lane_id();
-  // one 512-row chunk per wave when launched 1:1 (measured faster than a persistent grid: consecutive workgroups keep
-  // the key stream and the bitmap window local); the loop only matters if a caller caps the grid
-  for (int64_t base = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * (WAVE * PM_ROWS); base < n;
-       base += (int64_t)gridDim.x * (BLOCK / WAVE) * (WAVE * PM_ROWS)) {
-  // bitmap window: clustered probe keys (a fact table stored in key order) put the wave's 512 keys inside one run of 64
-  // bitmap words, so the wave loads that run once, coalesced, from the first key of its chunk (a scalar load that is in
-  // flight together with the vector key loads) and looks bits up with ds_bpermute; keys outside the window take the
-  // per-lane gather.  Measured (profiles/experiments/probe_stream_microbench.hip): 1.29 -> 1.05 ms per 600M sorted keys,
-  // unchanged for random keys.
+// One 512-row chunk per wave, launched 1:1 (measured faster than a persistent grid: consecutive workgroups keep the key
+// stream and the bitmap window local).  Mask / validity presence and "the whole chunk is in range" are compile-time so
+// that the loads of one chunk are not split across branches (measured 1.34 -> 1.18 ms per 600M keys).
+// Bitmap window: clustered probe keys (a fact table stored in key order) put the wave's 512 keys inside one run of 64
+// bitmap words, so the wave loads that run once, coalesced, from the first key of its chunk and looks bits up with
+// ds_bpermute; keys outside the window take the per-lane gather (profiles/experiments/probe_stream_microbench.hip:
+// 1.29 -> 1.05 ms per 600M sorted keys, unchanged for random keys).
+template <typename T, bool HAS_MASK, bool HAS_VALID, bool FULL>
+__device__ inline void probe_match_chunk(const T* keys, const uint64_t* key_valid, const uint64_t* mask, int64_t n, int64_t kmin, uint64_t range,
+                                         const uint64_t* bitmap, uint64_t* match_bits, int64_t base, int lane) {
   uint64_t d0 = (uint64_t)((int64_t)keys[base] - kmin);
   d0 = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)d0) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(d0 >> 32)) << 32);
   int64_t w0i = d0 < range ? (int64_t)(d0 >> 6) : 0;
@@ -135,34 +132,36 @@ __global__ void __launch_bounds__(BLOCK) k_probe_match_bitmap(const T* keys, con
 #pragma unroll
   for (int r = 0; r < PM_ROWS / 2; r++) {                      // lane l owns rows base + 128 r + 2l, +1
     int64_t j = base + r * 2 * WAVE + 2 * lane;
-    if (j + 1 < n) { struct alignas(2 * sizeof(T)) P { T a, b; }; P p = *(const P*)(keys + j); k[r][0] = p.a; k[r][1] = p.b; }
+    if (FULL || j + 1 < n) { struct alignas(2 * sizeof(T)) P { T a, b; }; P p = *(const P*)(keys + j); k[r][0] = p.a; k[r][1] = p.b; }
     else { k[r][0] = j < n ? keys[j] : (T)0; k[r][1] = 0; }
   }
-  uint64_t mw[PM_ROWS / 2];
-#pragma unroll
-  for (int r = 0; r < PM_ROWS / 2; r++) { int64_t j = base + r * 2 * WAVE + 2 * lane; mw[r] = (mask && j < n) ? mask[j >> 6] >> (j & 63) : 3ull; }
-  uint64_t bw[PM_ROWS / 2][2];
 #pragma unroll
   for (int r = 0; r < PM_ROWS / 2; r++) {
     int64_t j = base + r * 2 * WAVE + 2 * lane;
+    uint64_t mw = (HAS_MASK && (FULL || j < n)) ? mask[j >> 6] >> (j & 63) : 3ull;
+    bool h[2];
 #pragma unroll
     for (int e = 0; e < 2; e++) {
       uint64_t d = (uint64_t)((int64_t)k[r][e] - kmin);
-      bool go = j + e < n && ((mw[r] >> e) & 1) && valid_at(key_valid, j + e) && d < range;
+      bool go = (FULL || j + e < n) && ((mw >> e) & 1) && (!HAS_VALID || valid_at(key_valid, j + e)) && d < range;
       int64_t rel = (int64_t)(d >> 6) - w0i;
       uint64_t word = __shfl(win, (int)(rel & 63), 64);
       if (go && (rel < 0 || rel >= WAVE)) word = bitmap[d >> 6];
-      bw[r][e] = go ? (word >> (d & 63)) & 1ull : 0ull;
+      h[e] = go && ((word >> (d & 63)) & 1ull);
     }
-  }
-#pragma unroll
-  for (int r = 0; r < PM_ROWS / 2; r++) {
-    uint64_t be = ballot64(bw[r][0] != 0), bo = ballot64(bw[r][1] != 0);   // wave-uniform: the interleave below runs on the scalar unit
+    uint64_t be = ballot64(h[0]), bo = ballot64(h[1]);           // wave-uniform: the interleave below runs on the scalar unit
     uint64_t w0 = spread32(be) | (spread32(bo) << 1), w1 = spread32(be >> 32) | (spread32(bo >> 32) << 1);
     int64_t wbase = (base >> 6) + 2 * r;
-    if (lane == 0) { if (base + r * 2 * WAVE < n) match_bits[wbase] = w0; if (base + r * 2 * WAVE + WAVE < n) match_bits[wbase + 1] = w1; }
+    if (lane == 0) { if (FULL || base + r * 2 * WAVE < n) match_bits[wbase] = w0; if (FULL || base + r * 2 * WAVE + WAVE < n) match_bits[wbase + 1] = w1; }
   }
-  }
+}
+template <typename T, bool HAS_MASK, bool HAS_VALID>
+__global__ void __launch_bounds__(BLOCK) k_probe_match_bitmap(const T* keys, const uint64_t* key_valid, const uint64_t* mask, int64_t n, int64_t kmin, uint64_t range,
+                                                              const uint64_t* bitmap, uint64_t* match_bits) {
+  int lane = lane_id();
+  int64_t base = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * (WAVE * PM_ROWS);
+  if (base + WAVE * PM_ROWS <= n) probe_match_chunk<T, HAS_MASK, HAS_VALID, true>(keys, key_valid, mask, n, kmin, range, bitmap, match_bits, base, lane);
+  else if (base < n) probe_match_chunk<T, HAS_MASK, HAS_VALID, false>(keys, key_valid, mask, n, kmin, range, bitmap, match_bits, base, lane);
 }
 // ---- probe pass 2: the matched probe rows (ascending) look their key group up; unique builds emit the build row directly
 __global__ void __launch_bounds__(BLOCK) k_probe_lookup(KeySet bks, KeySet pks, const uint32_t* rows, int64_t m, int null_eq, int force_zero,
@@ -440,8 +439,11 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
       if (use_bitmap) {
         KernelTimer kt_(ctx, "k_probe_match_bitmap");
         int64_t rows_per_block = (int64_t)BLOCK * PM_ROWS;
-        DFGPU_INT_KEY_DISPATCH(pk->type, hipLaunchKernelGGL((k_probe_match_bitmap<T>), dim3(grid_for(n, (int)rows_per_block)), dim3(BLOCK), 0, ctx->stream, (const T*)pk->values->ptr,
-                                                            pk->validity ? (const uint64_t*)pk->validity->ptr : nullptr, mk, n, t->key_min, t->range, (const uint64_t*)t->bitmap->ptr, (uint64_t*)match_bits->ptr));
+        const uint64_t* kvp = pk->validity ? (const uint64_t*)pk->validity->ptr : nullptr;
+#define PM_LAUNCH(HM, HV) DFGPU_INT_KEY_DISPATCH(pk->type, hipLaunchKernelGGL((k_probe_match_bitmap<T, HM, HV>), dim3(grid_for(n, (int)rows_per_block)), dim3(BLOCK), 0, ctx->stream, (const T*)pk->values->ptr, \
+                                                            kvp, mk, n, t->key_min, t->range, (const uint64_t*)t->bitmap->ptr, (uint64_t*)match_bits->ptr))
+        if (mk && kvp) { PM_LAUNCH(true, true); } else if (mk) { PM_LAUNCH(true, false); } else if (kvp) { PM_LAUNCH(false, true); } else { PM_LAUNCH(false, false); }
+#undef PM_LAUNCH
       } else {
         KernelTimer kt_(ctx, "k_probe_match_hash");
         hipLaunchKernelGGL(k_probe_match_hash, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, t->ks, pks, n, mk, nen, fz, (const uint64_t*)t->slots->ptr, t->capacity - 1, (uint64_t*)match_bits->ptr);
