@@ -81,25 +81,54 @@ __global__ void __launch_bounds__(BLOCK) k_compare(int op, Operand l, Operand r,
 }
 
 // Fast path of the FilterExec predicates that dominate TPC-H (`l_shipdate > date`, `o_orderdate < date`, `key = c`):
-// non-null fixed-width integer column vs scalar.  4 rows per lane (4 loads in flight), one 64-bit ballot per 64 rows.
-constexpr int CMP_ROWS = 4;
-template <typename T>
-__global__ void __launch_bounds__(BLOCK) k_compare_scalar_fast(int op, const T* v, T s, int64_t n, uint64_t* out_bits) {
-  int lane = lane_id();
-  for (int64_t base = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * (WAVE * CMP_ROWS); base < n;
-       base += (int64_t)gridDim.x * (BLOCK / WAVE) * (WAVE * CMP_ROWS)) {      // persistent grid-stride loop
-  T x[CMP_ROWS];
+// non-null fixed-width integer column vs scalar.  64 bytes per lane in flight, one 64-bit ballot per 64 rows, one chunk
+// per wave (1:1 grid).  Operator and "whole chunk in range" are compile-time: a bounds-checked load compiles to a branch
+// plus s_waitcnt vmcnt(0) per load, i.e. no memory parallelism (profiles/experiments/compare_stream_microbench.hip:
+// 0.56 -> 0.40 ms per 600M Date32 rows = 6.2 TB/s).
+template <typename T> constexpr int cmp_rows() { return 64 / (int)sizeof(T); }
+template <typename T, int OP, bool FULL>
+__device__ inline void compare_scalar_chunk(const T* v, T s, int64_t n, uint64_t* out_bits, int64_t base, int lane) {
+  constexpr int ROWS = cmp_rows<T>();
+  T x[ROWS];
 #pragma unroll
-  for (int r = 0; r < CMP_ROWS; r++) { int64_t j = base + r * WAVE + lane; x[r] = j < n ? v[j] : s; }
+  for (int r = 0; r < ROWS; r++) { int64_t j = base + r * WAVE + lane; x[r] = (FULL || j < n) ? v[j] : s; }
 #pragma unroll
-  for (int r = 0; r < CMP_ROWS; r++) {
+  for (int r = 0; r < ROWS; r++) {
     int64_t j = base + r * WAVE + lane; bool b;
-    switch (op) { case DFGPU_OP_EQ: b = x[r] == s; break; case DFGPU_OP_NEQ: b = x[r] != s; break; case DFGPU_OP_LT: b = x[r] < s; break;
+    switch (OP) { case DFGPU_OP_EQ: b = x[r] == s; break; case DFGPU_OP_NEQ: b = x[r] != s; break; case DFGPU_OP_LT: b = x[r] < s; break;
       case DFGPU_OP_LTEQ: b = x[r] <= s; break; case DFGPU_OP_GT: b = x[r] > s; break; default: b = x[r] >= s; }
-    uint64_t m = ballot64(b && j < n);
-    if (lane == 0 && base + r * WAVE < n) out_bits[(base >> 6) + r] = m;
+    uint64_t m = ballot64(b && (FULL || j < n));
+    if (lane == 0 && (FULL || base + r * WAVE < n)) out_bits[(base >> 6) + r] = m;
   }
+}
+template <typename T, int OP>
+__global__ void __launch_bounds__(BLOCK) k_compare_scalar_fast(const T* v, T s, int64_t n, uint64_t* out_bits) {
+  int lane = lane_id();
+  int64_t base = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * (WAVE * cmp_rows<T>());
+  if (base + WAVE * cmp_rows<T>() <= n) compare_scalar_chunk<T, OP, true>(v, s, n, out_bits, base, lane);
+  else if (base < n) compare_scalar_chunk<T, OP, false>(v, s, n, out_bits, base, lane);
+}
+template <typename T>
+static void launch_compare_scalar_fast(dfgpu_ctx* ctx, int op, const T* v, T s, int64_t n, uint64_t* out_bits) {
+  dim3 g(grid_for(n, BLOCK * cmp_rows<T>())), block(BLOCK);
+  switch (op) {
+#define CMP_CASE(OP) case OP: hipLaunchKernelGGL((k_compare_scalar_fast<T, OP>), g, block, 0, ctx->stream, v, s, n, out_bits); break;
+    CMP_CASE(DFGPU_OP_EQ) CMP_CASE(DFGPU_OP_NEQ) CMP_CASE(DFGPU_OP_LT) CMP_CASE(DFGPU_OP_LTEQ) CMP_CASE(DFGPU_OP_GT) CMP_CASE(DFGPU_OP_GTEQ)
+#undef CMP_CASE
+    default: fail(DFGPU_INTERNAL, "compare fast path: operator %d", op);
   }
+}
+// dictionary column vs scalar: the predicate is evaluated once per dictionary entry (dict_bits / dict_valid), rows map their code
+__global__ void __launch_bounds__(BLOCK) k_dict_predicate(const void* keys, int key_type, const uint64_t* key_valid, int64_t n, const uint64_t* dict_bits, const uint64_t* dict_valid,
+                                                          int64_t dict_len, uint64_t* out_bits, uint64_t* out_valid) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  bool v = false, ok = false;
+  if (i < n && valid_at(key_valid, i)) {
+    int64_t c = key_at(keys, key_type, i);
+    if (c >= 0 && c < dict_len) { ok = valid_at(dict_valid, c); v = ok && bit_get(dict_bits, c); }
+  }
+  uint64_t mv = ballot64(v), mo = ballot64(ok);
+  if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) { out_bits[i >> 6] = mv; if (out_valid) out_valid[i >> 6] = mo; }
 }
 static int swap_cmp(int op) { switch (op) { case DFGPU_OP_LT: return DFGPU_OP_GT; case DFGPU_OP_LTEQ: return DFGPU_OP_GTEQ; case DFGPU_OP_GT: return DFGPU_OP_LT; case DFGPU_OP_GTEQ: return DFGPU_OP_LTEQ; default: return op; } }
 
@@ -293,15 +322,31 @@ dfgpu_status dfgpu_binary(dfgpu_ctx* ctx, int32_t op, const dfgpu_array* l, int3
       if (lt == DFGPU_DECIMAL128 && lo.v.scale != ro.v.scale) fail(DFGPU_INVALID_ARGUMENT, "compare: decimal scales differ; the planner coerces first");
       bool need_valid = nulls && op != DFGPU_OP_DISTINCT && op != DFGPU_OP_NOT_DISTINCT;
       ArrayHolder h(new_fixed(ctx, DFGPU_BOOL, n, 0, 0, need_valid));
+      {   // dictionary column vs scalar (`c_mktsegment = 'BUILDING'`): compare the dictionary values, then map the codes
+        const dfgpu_array* dcol = rs && !ls && l->type == DFGPU_DICTIONARY && r->type != DFGPU_DICTIONARY ? l : (ls && !rs && r->type == DFGPU_DICTIONARY && l->type != DFGPU_DICTIONARY ? r : nullptr);
+        if (dcol && n && op <= DFGPU_OP_GTEQ && dcol->dictionary && dcol->dictionary->length < n) {
+          dfgpu_array* dres = nullptr;
+          dfgpu_status st = dcol == l ? dfgpu_binary(ctx, op, dcol->dictionary, 0, r, 1, &dres) : dfgpu_binary(ctx, op, l, 1, dcol->dictionary, 0, &dres);
+          if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str());
+          ArrayHolder dh(dres);
+          bool nv = dcol->validity || dres->validity;
+          ArrayHolder hd(new_fixed(ctx, DFGPU_BOOL, n, 0, 0, nv));
+          KernelTimer kt_(ctx, "k_dict_predicate");
+          hipLaunchKernelGGL(k_dict_predicate, grid, block, 0, ctx->stream, dcol->values->ptr, dcol->key_type, dcol->validity ? (const uint64_t*)dcol->validity->ptr : nullptr, n,
+                             (const uint64_t*)dres->values->ptr, dres->validity ? (const uint64_t*)dres->validity->ptr : nullptr, dres->length,
+                             (uint64_t*)hd.get()->values->ptr, nv ? (uint64_t*)hd.get()->validity->ptr : nullptr);
+          KERNEL_CHECK(); if (nv) hd.get()->null_count = -1;
+          *out = hd.release(); return;
+        }
+      }
       {   // fast path: non-null fixed-width integer column vs non-null scalar
         const dfgpu_array* col = rs && !ls ? l : (ls && !rs ? r : nullptr); const dfgpu_array* sc = col == l ? r : l;
         int fop = col == l ? op : swap_cmp(op);
         if (col && n && !nulls && op <= DFGPU_OP_GTEQ && col->type != DFGPU_DICTIONARY && sc->type != DFGPU_DICTIONARY && sc->has_host_scalar && sc->host_scalar_valid &&
             (lt == DFGPU_INT32 || lt == DFGPU_DATE32 || lt == DFGPU_INT64)) {
           KernelTimer kt_(ctx, "k_compare_scalar_fast");
-          dim3 g(grid_for(n, BLOCK * CMP_ROWS, ctx->num_cus * 8));
-          if (lt == DFGPU_INT64) { int64_t sv; memcpy(&sv, sc->host_scalar, 8); hipLaunchKernelGGL((k_compare_scalar_fast<int64_t>), g, block, 0, ctx->stream, fop, (const int64_t*)col->values->ptr, sv, n, (uint64_t*)h.get()->values->ptr); }
-          else { int32_t sv; memcpy(&sv, sc->host_scalar, 4); hipLaunchKernelGGL((k_compare_scalar_fast<int32_t>), g, block, 0, ctx->stream, fop, (const int32_t*)col->values->ptr, sv, n, (uint64_t*)h.get()->values->ptr); }
+          if (lt == DFGPU_INT64) { int64_t sv; memcpy(&sv, sc->host_scalar, 8); launch_compare_scalar_fast<int64_t>(ctx, fop, (const int64_t*)col->values->ptr, sv, n, (uint64_t*)h.get()->values->ptr); }
+          else { int32_t sv; memcpy(&sv, sc->host_scalar, 4); launch_compare_scalar_fast<int32_t>(ctx, fop, (const int32_t*)col->values->ptr, sv, n, (uint64_t*)h.get()->values->ptr); }
           KERNEL_CHECK();
           *out = h.release(); return;
         }

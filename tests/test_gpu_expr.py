@@ -143,6 +143,23 @@ def test_deferred_flag_region_raises_when_left_and_before_export(ctx):
     assert dev_binary(ctx, "*", ok, ok).to_pylist() == [decimal.Decimal(9)]
 
 
+@pytest.mark.parametrize("op", CMP[:6])
+def test_dictionary_column_vs_plain_scalar_uses_dictionary_predicate(ctx, op):
+    """`c_mktsegment = 'BUILDING'` shape: dictionary-encoded column against a plain Utf8 / Int64 literal (either side).
+    The device evaluates the predicate on the dictionary values and maps the codes; same answer as on the decoded column,
+    NULL codes and a NULL dictionary VALUE included."""
+    words = pa.array(["AUTOMOBILE", "BUILDING", None, "FURNITURE", "MACHINERY", "HOUSEHOLD"], type=pa.utf8())
+    codes = pa.array(RNG.integers(0, 6, 5000).astype(np.int8), mask=RNG.random(5000) < 0.1)
+    col = pa.DictionaryArray.from_arrays(codes, words)
+    lit = pa.array(["BUILDING"], type=pa.utf8())
+    plain = col.cast(pa.utf8())
+    assert same(dev_binary(ctx, op, col, lit, rs=True), po.binary(op, plain, lit, r_scalar=True))
+    assert same(dev_binary(ctx, op, lit, col, ls=True), po.binary(op, lit, plain, l_scalar=True))
+    nums = pa.DictionaryArray.from_arrays(pa.array(RNG.integers(0, 4, 3000).astype(np.int32)), pa.array([10, 20, 30, 40], type=pa.int64()))
+    k = pa.array([30], type=pa.int64())
+    assert same(dev_binary(ctx, op, nums, k, rs=True), po.binary(op, nums.cast(pa.int64()), k, r_scalar=True))
+
+
 @pytest.mark.parametrize("op", ["AND", "OR"])
 def test_kleene_logic(ctx, op):
     l, r = rand_array("bool", 5000, 0.3), rand_array("bool", 5000, 0.3)
