@@ -93,6 +93,7 @@ void flush_flags(dfgpu_ctx* ctx) {
 void check_flags(dfgpu_ctx* ctx, const char* what) {
   if (ctx->defer_flag_checks > 0) { if (!ctx->flags_pending) ctx->flags_what = what; else if (ctx->flags_what.find(what) == std::string::npos) ctx->flags_what += std::string(", ") + what; ctx->flags_pending = true; return; }
   uint32_t f = 0;
+  ctx->count_sync((std::string("sync:flags:") + what).c_str());
   HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 63, ctx->d_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
   f = *(uint32_t*)(ctx->h_pinned + 63);
@@ -105,6 +106,7 @@ void check_flags(dfgpu_ctx* ctx, const char* what) {
   fail(DFGPU_INTERNAL, "kernel raised flag %u (%s)", f, what);
 }
 uint64_t read_scratch(dfgpu_ctx* ctx, int slot) {
+  ctx->count_sync((std::string("sync:count") + std::to_string(slot)).c_str());
   HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + slot, ctx->d_scratch64 + slot, 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return ctx->h_pinned[slot];
@@ -310,6 +312,8 @@ dfgpu_status dfgpu_profile_read(dfgpu_ctx* ctx, char* buf, int64_t capacity) {
     }
     ctx->prof.clear();
     std::string out;
+    for (auto& kv : ctx->sync_counts) { char line[256]; snprintf(line, sizeof line, "%s %lld 0.0\n", kv.first.c_str(), (long long)kv.second); out += line; }
+    ctx->sync_counts.clear();
     for (size_t k = 0; k < names.size(); k++) { char line[256]; snprintf(line, sizeof line, "%s %lld %.6f\n", names[k].c_str(), (long long)cnt[k], ms[k]); out += line; }
     if ((int64_t)out.size() + 1 > capacity) out.resize((size_t)capacity - 1);
     memcpy(buf, out.c_str(), out.size() + 1);

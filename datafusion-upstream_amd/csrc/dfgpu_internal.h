@@ -55,6 +55,8 @@ struct dfgpu_ctx {
   std::vector<std::pair<size_t, void*>>* free_blocks = nullptr;   // (class bytes, ptr)
   size_t cached_bytes = 0, live_bytes = 0;
   bool profile = false; std::string profile_only;
+  std::vector<std::pair<std::string, int64_t>> sync_counts;   // host<->stream synchronisation points by cause (profiling only)
+  void count_sync(const char* why) { if (!profile) return; for (auto& kv : sync_counts) if (kv.first == why) { kv.second++; return; } sync_counts.emplace_back(why, 1); }
   struct ProfRec { const char* name; hipEvent_t start, stop; };
   std::vector<ProfRec> prof;
 };

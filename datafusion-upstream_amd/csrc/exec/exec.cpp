@@ -191,6 +191,10 @@ struct Plan : std::enable_shared_from_this<Plan> {
   virtual SchemaPtr schema() const = 0;
   virtual int partitions() const = 0;                                   // output_partitioning().partition_count()
   virtual std::unique_ptr<Stream> execute(int partition, const TaskContext& tc) const = 0;
+  // ≙ ExecutionPlan::with_new_children over the same (recursively fresh) children (physical-plan/src/lib.rs:198-201): a new node
+  // without the run-once state of this one (HashJoinExec's OnceAsync build side, RepartitionExec's pulled input), so a plan
+  // description built once can be executed again from scratch.
+  virtual PlanPtr fresh() const = 0;
 };
 static void drain(const PlanPtr& p, int partition, const TaskContext& tc, std::vector<Batch>& out) {
   auto s = p->execute(partition, tc); Batch b; while (s->next(b)) out.push_back(std::move(b));
@@ -205,6 +209,7 @@ struct VecStream : Stream {
 struct MemoryExec : Plan {        // memory.rs:40,150
   std::vector<std::vector<Batch>> parts; SchemaPtr sch;
   const char* name() const override { return "MemoryExec"; }
+  PlanPtr fresh() const override { return shared_from_this(); }
   SchemaPtr schema() const override { return sch; }
   int partitions() const override { return (int)parts.size(); }
   std::unique_ptr<Stream> execute(int p, const TaskContext&) const override {
@@ -223,6 +228,7 @@ static ArrayRef known_mask(const TaskContext& tc, const ArrayRef& m) {     // NU
 
 struct FilterExec : Plan {        // filter.rs:56-66, batch_filter :315-327
   ExprPtr pred; PlanPtr input;
+  PlanPtr fresh() const override { auto f = std::make_shared<FilterExec>(); f->pred = pred; f->input = input->fresh(); return f; }
   const char* name() const override { return "FilterExec"; }
   SchemaPtr schema() const override { return input->schema(); }
   int partitions() const override { return input->partitions(); }
@@ -256,6 +262,7 @@ static Batch materialize_subset(const TaskContext& tc, Batch& b, const std::set<
 
 struct ProjectionExec : Plan {    // projection.rs:52-62, batch_project :295-317
   std::vector<ExprPtr> exprs; std::vector<std::string> names; PlanPtr input; mutable SchemaPtr sch; mutable std::mutex mu;
+  PlanPtr fresh() const override { auto p = std::make_shared<ProjectionExec>(); p->exprs = exprs; p->names = names; p->input = input->fresh(); return p; }
   const char* name() const override { return "ProjectionExec"; }
   SchemaPtr schema() const override {
     std::lock_guard<std::mutex> l(mu);
@@ -289,6 +296,7 @@ struct ProjectionExec : Plan {    // projection.rs:52-62, batch_project :295-317
 
 struct CoalesceBatchesExec : Plan {    // coalesce_batches.rs:198-260
   PlanPtr input; int64_t target;
+  PlanPtr fresh() const override { auto c = std::make_shared<CoalesceBatchesExec>(); c->input = input->fresh(); c->target = target; return c; }
   const char* name() const override { return "CoalesceBatchesExec"; }
   SchemaPtr schema() const override { return input->schema(); }
   int partitions() const override { return input->partitions(); }
@@ -314,6 +322,7 @@ struct CoalesceBatchesExec : Plan {    // coalesce_batches.rs:198-260
 
 struct CoalescePartitionsExec : Plan {   // coalesce_partitions.rs
   PlanPtr input;
+  PlanPtr fresh() const override { auto c = std::make_shared<CoalescePartitionsExec>(); c->input = input->fresh(); return c; }
   const char* name() const override { return "CoalescePartitionsExec"; }
   SchemaPtr schema() const override { return input->schema(); }
   int partitions() const override { return 1; }
@@ -348,6 +357,7 @@ static void partition_batch(const TaskContext& tc, Batch& b, const std::vector<E
 struct RepartitionExec : Plan {   // repartition/mod.rs:232-294; all inputs are pulled once, outputs cached per partition
   PlanPtr input; std::vector<ExprPtr> exprs; int n;
   mutable std::mutex mu; mutable bool ran = false; mutable std::vector<std::vector<Batch>> outs;
+  PlanPtr fresh() const override { auto r = std::make_shared<RepartitionExec>(); r->input = input->fresh(); r->exprs = exprs; r->n = n; return r; }
   const char* name() const override { return "RepartitionExec"; }
   SchemaPtr schema() const override { return input->schema(); }
   int partitions() const override { return n; }
@@ -377,6 +387,10 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
   PlanPtr left, right; std::vector<ExprPtr> on_l, on_r; ExprPtr filter; std::vector<int> f_side, f_index;
   int join_type, mode; bool null_equals_null;
   mutable std::mutex mu; mutable std::shared_ptr<BuildSide> shared;     // CollectLeft: OnceAsync (joins/utils.rs:736-776)
+  PlanPtr fresh() const override {
+    auto j = std::make_shared<HashJoinExec>(); j->left = left->fresh(); j->right = right->fresh(); j->on_l = on_l; j->on_r = on_r; j->filter = filter; j->f_side = f_side; j->f_index = f_index;
+    j->join_type = join_type; j->mode = mode; j->null_equals_null = null_equals_null; return j;
+  }
   const char* name() const override { return "HashJoinExec"; }
   bool left_only() const { return join_type == DFGPU_JOIN_LEFT_SEMI || join_type == DFGPU_JOIN_LEFT_ANTI; }
   bool right_only() const { return join_type == DFGPU_JOIN_RIGHT_SEMI || join_type == DFGPU_JOIN_RIGHT_ANTI; }
@@ -493,6 +507,7 @@ static const char* agg_fun_name(int k) { switch (k) { case DFGPU_AGG_SUM: return
 
 struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggregateStream row_hash.rs:423-662
   int mode; std::vector<ExprPtr> gexprs; std::vector<std::string> gnames; std::vector<AggExpr> aggs; PlanPtr input; mutable SchemaPtr sch; mutable std::mutex mu;
+  PlanPtr fresh() const override { auto a = std::make_shared<AggregateExec>(); a->mode = mode; a->gexprs = gexprs; a->gnames = gnames; a->aggs = aggs; a->input = input->fresh(); return a; }
   const char* name() const override { return "AggregateExec"; }
   bool merging() const { return mode == 1 || mode == 2; }
   std::vector<std::string> out_names() const {
@@ -563,6 +578,7 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
 // ------------------------------------------------------------------ SortExec
 struct SortExec : Plan {          // sorts/sort.rs:719-733; sort_batch :584-609
   std::vector<ExprPtr> exprs; std::vector<uint8_t> desc, nulls_first; int64_t fetch; bool preserve; PlanPtr input;
+  PlanPtr fresh() const override { auto s = std::make_shared<SortExec>(); s->exprs = exprs; s->desc = desc; s->nulls_first = nulls_first; s->fetch = fetch; s->preserve = preserve; s->input = input->fresh(); return s; }
   const char* name() const override { return "SortExec"; }
   SchemaPtr schema() const override { return input->schema(); }
   int partitions() const override { return preserve ? input->partitions() : 1; }
@@ -698,6 +714,7 @@ dfgpu_status dfgpu_plan_sort(const dfgpu_expr* const* exprs, const uint8_t* desc
   });
 }
 void dfgpu_plan_free(dfgpu_plan* p) { delete p; }
+dfgpu_status dfgpu_plan_with_fresh_state(const dfgpu_plan* p, dfgpu_plan** out) { return guard([&] { if (!out) fail(DFGPU_INVALID_ARGUMENT, "plan_with_fresh_state: null argument"); *out = new dfgpu_plan{pl(p)->fresh()}; }); }
 int32_t dfgpu_plan_partition_count(const dfgpu_plan* p) { return p ? p->p->partitions() : 0; }
 int32_t dfgpu_plan_schema_len(const dfgpu_plan* p) { if (!p) return 0; auto s = p->p->schema(); return s ? (int32_t)s->f.size() : 0; }
 const char* dfgpu_plan_schema_name(const dfgpu_plan* p, int32_t i) {
@@ -705,21 +722,28 @@ const char* dfgpu_plan_schema_name(const dfgpu_plan* p, int32_t i) {
 }
 const char* dfgpu_plan_name(const dfgpu_plan* p) { return p ? p->p->name() : ""; }
 
+// One C-ABI call that drives operators = one deferred region for kernel error flags (include/dfgpu.h "defer_flag_checks"):
+// the flags are read back once, when the region is left, and the call returns that error -- before any batch is handed out.
+struct FlagRegion {
+  dfgpu_ctx* c; bool open = true;
+  explicit FlagRegion(dfgpu_ctx* c_) : c(c_) { dfgpu_ctx_set_option(c, "defer_flag_checks", 1); }
+  dfgpu_status close() { open = false; return dfgpu_ctx_set_option(c, "defer_flag_checks", 0); }
+  ~FlagRegion() { if (open) close(); }
+};
 dfgpu_status dfgpu_plan_execute(const dfgpu_plan* p, int32_t partition, dfgpu_ctx* ctx, int64_t batch_size, dfgpu_stream** out) {
   return guard([&] {
     if (!p || !ctx || !out) fail(DFGPU_INVALID_ARGUMENT, "plan_execute: null argument");
     TaskContext tc{ctx, batch_size > 0 ? batch_size : 8192};
     auto* s = new dfgpu_stream{nullptr, p->p, tc};
-    try { s->s = p->p->execute(partition, tc); } catch (...) { delete s; throw; }
+    FlagRegion region(ctx);           // operators that drain their input when the stream is created (SortExec, build sides)
+    try { s->s = p->p->execute(partition, tc); tc.check(region.close()); } catch (...) { delete s; throw; }
     *out = s;
   });
 }
 dfgpu_status dfgpu_stream_next(dfgpu_stream* s, dfgpu_batch** out) {
   return guard([&] {
     if (!s || !out) fail(DFGPU_INVALID_ARGUMENT, "stream_next: null argument");
-    // one poll of the output stream = one deferred region for kernel error flags: raised before the batch is handed out
-    struct Region { dfgpu_ctx* c; bool open = true; Region(dfgpu_ctx* c_) : c(c_) { dfgpu_ctx_set_option(c, "defer_flag_checks", 1); }
-                    dfgpu_status close() { open = false; return dfgpu_ctx_set_option(c, "defer_flag_checks", 0); } ~Region() { if (open) close(); } } region(s->tc.ctx);
+    FlagRegion region(s->tc.ctx);
     Batch b; bool more = s->s->next(b);
     s->tc.check(region.close());
     if (!more) { *out = nullptr; return; }

@@ -296,6 +296,29 @@ class ExecutionPlan:
             yield RecordBatch(context.ctx, _BatchH(b))
 
 
+class FreshPlan(ExecutionPlan):
+    """A node whose C++ tree is `template` with fresh run-once state (≙ ExecutionPlan::with_new_children over the same
+    children, physical-plan/src/lib.rs:198-201): build the description once, take `with_fresh_state()` per execution."""
+
+    def __init__(self, template: ExecutionPlan):
+        self.template = template
+
+    def children(self):
+        return self.template.children()
+
+    def output_partitioning(self):
+        return self.template.output_partitioning()
+
+    def _build(self, context: TaskContext) -> _PlanH:
+        out = C.c_void_p()
+        _check(_lib().dfgpu_plan_with_fresh_state(self.template.handle(context).h, C.byref(out)))
+        return _PlanH(out)
+
+
+def with_fresh_state(plan: ExecutionPlan) -> ExecutionPlan:
+    return FreshPlan(plan.template if isinstance(plan, FreshPlan) else plan)
+
+
 def _child_handle(child, context: TaskContext) -> _PlanH:
     """C++ handle of a child node; Python-only nodes (ShuffleExec) are run here and enter as a MemoryExec."""
     if isinstance(child, ExecutionPlan):

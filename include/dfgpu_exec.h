@@ -73,6 +73,10 @@ DFGPU_API dfgpu_status dfgpu_plan_aggregate(int32_t mode, const dfgpu_expr *cons
 DFGPU_API dfgpu_status dfgpu_plan_sort(const dfgpu_expr *const *exprs, const uint8_t *descending, const uint8_t *nulls_first, int32_t n, int64_t fetch,
                                        int32_t preserve_partitioning, const dfgpu_plan *input, dfgpu_plan **out);
 DFGPU_API void dfgpu_plan_free(dfgpu_plan *p);
+/* ExecutionPlan::with_new_children(self, same children, recursively) (physical-plan/src/lib.rs:198-201): a copy of the plan tree
+ * without run-once state -- HashJoinExec's OnceAsync build side (joins/utils.rs:736-776; with_new_children hash_join.rs:559),
+ * RepartitionExec's pulled input (repartition/mod.rs:422) -- so one plan description can be executed again from scratch. */
+DFGPU_API dfgpu_status dfgpu_plan_with_fresh_state(const dfgpu_plan *p, dfgpu_plan **out);
 DFGPU_API int32_t dfgpu_plan_partition_count(const dfgpu_plan *p);               /* output_partitioning().partition_count() */
 DFGPU_API int32_t dfgpu_plan_schema_len(const dfgpu_plan *p);
 DFGPU_API const char *dfgpu_plan_schema_name(const dfgpu_plan *p, int32_t i);

@@ -148,3 +148,21 @@ def test_coalesce_batches(ctx, task_ctx):
     assert sizes == [24, 24, 24, 8]
     got = collect_table(co, task_ctx)
     assert got["c0"].combine_chunks().equals(pa.concat_tables(tabs)["k"].combine_chunks())
+
+
+def test_with_fresh_state_reexecutes_from_scratch(ctx, task_ctx):
+    """≙ ExecutionPlan::with_new_children (physical-plan/src/lib.rs:198-201): a copy of the plan without the OnceAsync build side /
+    pulled RepartitionExec input gives the same rows again, any number of times, and leaves the template usable."""
+    import pyarrow as pa
+    from dfgpu import physical_plan as ops
+    rng = np.random.default_rng(5)
+    l = pa.table({"k": pa.array(rng.integers(0, 500, 3000)), "v": pa.array(rng.integers(0, 10**6, 3000))})
+    r = pa.table({"k": pa.array(rng.integers(0, 500, 9000)), "w": pa.array(rng.integers(0, 10**6, 9000))})
+    mk = lambda t: ops.MemoryExec([[ops.batch_from_arrow(ctx, t)]], ops.batch_from_arrow(ctx, t).schema)
+    join = ops.HashJoinExec(mk(l), ops.RepartitionExec(mk(r), ops.Partitioning.Hash([ops.Column("k", 0)], 3)), [(ops.Column("k", 0), ops.Column("k", 0))], None, "Inner", "CollectLeft")
+    plan = ops.SortExec([ops.PhysicalSortExpr(ops.Column("v", 1), False, False), ops.PhysicalSortExpr(ops.Column("w", 3), False, False)], ops.CoalescePartitionsExec(join))
+    rows = lambda p: [c.to_arrow().to_pylist() for b in ops.collect(p, task_ctx) for c in [b.columns[1], b.columns[3]]]
+    first = rows(plan)
+    assert len(first[0]) > 0
+    for _ in range(3):
+        assert rows(ops.with_fresh_state(plan)) == first
