@@ -82,5 +82,30 @@ sort = [{"name": "lex_sort_by_float", "ref": "datafusion/physical-plan/src/sorts
          "columns": [{"type": "float32", "values": [NAN, N, N, NAN, 1.0, 1.0, 2.0, 3.0], "descending": True, "nulls_first": True},
                      {"type": "float64", "values": [200.0, 20.0, 10.0, 100.0, NAN, N, N, NAN], "descending": False, "nulls_first": False}],
          "expected": [[N, 10.0], [N, 20.0], [NAN, 100.0], [NAN, 200.0], [3.0, NAN], [2.0, N], [1.0, NAN], [1.0, N]]}]
-json.dump({"scalar": scalar, "some_data": some_data, "grouped": grouped, "sort": sort}, open(__file__.replace("transcribe_aggregates.py", "aggregates.json"), "w"), indent=1)
+
+# ClickBench shapes over the in-tree 10-row sample (datafusion/core/tests/data/clickbench_hits_10.parquet; 5 of its 105 columns, read
+# with pyarrow), answers from datafusion/sqllogictest/test_files/clickbench.slt.  COUNT(DISTINCT ..) columns of those queries are
+# outside the path and left out; SUM / AVG arguments are coerced as the reference does (Int16 -> Int64 / Float64).
+CB = "datafusion/sqllogictest/test_files/clickbench.slt:"
+clickbench = {
+    "ref": "datafusion/core/tests/data/clickbench_hits_10.parquet",
+    "columns": {"RegionID": {"type": "int32", "values": [839, 839, 839, 839, 39, 839, 197, 197, 229, 839]},
+                "AdvEngineID": {"type": "int16", "values": [0] * 10},
+                "ResolutionWidth": {"type": "int16", "values": [0] * 10},
+                "UserID": {"type": "int64", "values": [-2461439046089301801, -2461439046089301801, -2461439046089301801, -2461439046089301801, 376160620089546609,
+                                                        427738049800818189, 519640690937130534, 519640690937130534, 7418527520126366595, -2461439046089301801]},
+                "SearchPhrase": {"type": "utf8", "values": [""] * 10}},
+    "cases": [
+        {"name": "q2_sum_count_avg", "ref": CB + "47-50", "group_by": [], "aggs": [["SUM", "AdvEngineID", "int64"], ["COUNT", None, "int64"], ["AVG", "ResolutionWidth", "float64"]],
+         "expected_rowsort": [[0, 10, 0.0]]},
+        {"name": "q3_avg_userid", "ref": CB + "52-55", "group_by": [], "aggs": [["AVG", "UserID", "float64"]], "expected_rowsort": [[-304548765855551740.0]]},
+        {"name": "q10_group_by_region", "ref": CB + "84-90", "group_by": ["RegionID"], "aggs": [["SUM", "AdvEngineID", "int64"], ["COUNT", None, "int64"], ["AVG", "ResolutionWidth", "float64"]],
+         "expected_rowsort": [[197, 0, 2, 0.0], [229, 0, 1, 0.0], [39, 0, 1, 0.0], [839, 0, 6, 0.0]]},
+        {"name": "q16_group_by_userid", "ref": CB + "112-119", "group_by": ["UserID"], "aggs": [["COUNT", None, "int64"]],
+         "expected_rowsort": [[-2461439046089301801, 5], [376160620089546609, 1], [427738049800818189, 1], [519640690937130534, 2], [7418527520126366595, 1]]},
+        {"name": "q17_group_by_userid_searchphrase", "ref": CB + "121-128", "group_by": ["UserID", "SearchPhrase"], "aggs": [["COUNT", None, "int64"]],
+         "expected_rowsort": [[-2461439046089301801, "", 5], [376160620089546609, "", 1], [427738049800818189, "", 1], [519640690937130534, "", 2], [7418527520126366595, "", 1]]},
+    ],
+}
+json.dump({"clickbench": clickbench, "scalar": scalar, "some_data": some_data, "grouped": grouped, "sort": sort}, open(__file__.replace("transcribe_aggregates.py", "aggregates.json"), "w"), indent=1)
 print(len(scalar), "scalar,", len(grouped), "grouped,", len(sort), "sort cases")

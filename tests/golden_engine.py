@@ -15,7 +15,7 @@ def pa_type(t):
     if isinstance(t, dict):
         p, s = t["decimal128"]
         return pa.decimal128(p, s)
-    return {"int32": pa.int32(), "int64": pa.int64(), "uint32": pa.uint32(), "uint64": pa.uint64(), "float32": pa.float32(), "float64": pa.float64(),
+    return {"int16": pa.int16(), "int32": pa.int32(), "int64": pa.int64(), "uint32": pa.uint32(), "uint64": pa.uint64(), "float32": pa.float32(), "float64": pa.float64(),
             "bool": pa.bool_(), "utf8": pa.utf8(), "date32": pa.date32()}[t]
 
 
@@ -89,7 +89,7 @@ class DeviceEngine:
         c = self.dfgpu.capi
         if pa.types.is_decimal(typ):
             return c.DECIMAL128, typ.precision, typ.scale
-        return {pa.int32(): c.INT32, pa.int64(): c.INT64, pa.uint32(): c.UINT32, pa.uint64(): c.UINT64, pa.float32(): c.FLOAT32, pa.float64(): c.FLOAT64,
+        return {pa.int16(): c.INT16, pa.int32(): c.INT32, pa.int64(): c.INT64, pa.uint32(): c.UINT32, pa.uint64(): c.UINT64, pa.float32(): c.FLOAT32, pa.float64(): c.FLOAT64,
                 pa.bool_(): c.BOOL, pa.utf8(): c.UTF8, pa.date32(): c.DATE32}[typ], 0, 0
 
     def binary(self, op, l, r, ls=False, rs=False):
@@ -271,3 +271,31 @@ def run_sort_case(eng, case):
     norm = lambda v: None if v is None else ("NaN" if isinstance(v, float) and math.isnan(v) else v)
     got = [[norm(out[0][i]), norm(out[1][i])] for i in range(len(idx))]
     assert got == case["expected"], f"{case['name']}: {got}"
+
+
+def run_clickbench_case(eng, fix, case):
+    """GROUP BY (or one global group) with SUM / COUNT(*) / AVG; arguments cast to the coerced type first; rows compared as a
+    multiset, Float64 results within 1e-9 relative (the parity contract for float SUM / AVG)."""
+    cols = {n: pa.array(c["values"], type=pa_type(c["type"])) for n, c in fix["clickbench"]["columns"].items()}
+    n = len(cols["UserID"])
+    if case["group_by"]:
+        ids, ng, emitted = eng.group_ids([cols[k] for k in case["group_by"]])
+    else:
+        ids, ng, emitted = np.zeros(n, dtype=np.int64), 1, []
+    outs = list(emitted)
+    for func, column, coerced in case["aggs"]:
+        t = pa_type(coerced)
+        v = None
+        if column is not None:
+            v = cols[column] if cols[column].type == t else eng.cast(cols[column], t)
+        res, _ = eng.accumulate(func, v, t, ids, ng)
+        outs.append(res)
+    got = sorted(rows_as_values(outs), key=repr)
+    want = sorted((tuple(r) for r in case["expected_rowsort"]), key=repr)
+    assert len(got) == len(want), case["name"]
+    for g, w in zip(got, want):
+        for a, b in zip(g, w):
+            if isinstance(b, float):
+                assert a == b or abs(a - b) <= 1e-9 * abs(b), f"{case['name']}: {a} vs {b}"
+            else:
+                assert a == b, f"{case['name']}: {g} vs {w}"

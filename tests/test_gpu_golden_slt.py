@@ -2,7 +2,7 @@
 (decimal.slt, aggregate unit tests, AggregateExec Partial -> Final, SortExec floats), through the C ABI."""
 import pytest
 
-from golden_engine import DeviceEngine, run_grouped_case, run_scalar_case, run_slt_case, run_sort_case
+from golden_engine import run_clickbench_case, DeviceEngine, run_grouped_case, run_scalar_case, run_slt_case, run_sort_case
 from helpers import load_golden
 
 pytestmark = pytest.mark.gpu
@@ -33,3 +33,8 @@ def test_device_aggregate_exec_partial_final(eng, case):
 @pytest.mark.parametrize("case", AGG["sort"], ids=[c["name"] for c in AGG["sort"]])
 def test_device_sort_exec_known_answers(eng, case):
     run_sort_case(eng, case)
+
+
+@pytest.mark.parametrize("case", AGG["clickbench"]["cases"], ids=[c["name"] for c in AGG["clickbench"]["cases"]])
+def test_device_clickbench_sample(eng, case):
+    run_clickbench_case(eng, AGG, case)

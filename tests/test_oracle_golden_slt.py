@@ -4,7 +4,7 @@ GROUP BY COUNT), the Sum / Avg / Count / Min / Max unit tests, AggregateExec Par
 Fixtures: tests/golden/decimal_slt.json, tests/golden/aggregates.json (hand-transcribed; scripts beside them)."""
 import pytest
 
-from golden_engine import OracleEngine, run_grouped_case, run_scalar_case, run_slt_case, run_sort_case
+from golden_engine import run_clickbench_case, OracleEngine, run_grouped_case, run_scalar_case, run_slt_case, run_sort_case
 from helpers import load_golden
 
 SLT = load_golden("decimal_slt.json")
@@ -34,3 +34,8 @@ def test_oracle_aggregate_exec_partial_final(eng, case):
 @pytest.mark.parametrize("case", AGG["sort"], ids=[c["name"] for c in AGG["sort"]])
 def test_oracle_sort_exec_known_answers(eng, case):
     run_sort_case(eng, case)
+
+
+@pytest.mark.parametrize("case", AGG["clickbench"]["cases"], ids=[c["name"] for c in AGG["clickbench"]["cases"]])
+def test_oracle_clickbench_sample(eng, case):
+    run_clickbench_case(eng, AGG, case)
