@@ -52,8 +52,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
-    ap.add_argument("--plan", choices=["broadcast", "shuffle"], default="broadcast",
-                    help="N > 1: broadcast = CollectLeft joins (all-gather the build sides, probe local shards); shuffle = the reference's fully partitioned plan")
+    ap.add_argument("--plan", choices=["colocated", "broadcast", "shuffle"], default="colocated",
+                    help="N > 1: colocated = customer build side broadcast, orders-lineitem join and aggregation partition-local (the shards are co-partitioned on "
+                         "the order key, as TPC-H files are); broadcast = both build sides all-gathered (CollectLeft), partial aggregates shuffled; "
+                         "shuffle = the reference's fully partitioned plan (hash repartition of every join / aggregate input)")
     return ap.parse_args()
 
 
@@ -92,6 +94,8 @@ def main():
 
     result_rows = [0]
 
+    PLANS = {"colocated": tpch.q3_colocated_plan, "broadcast": tpch.q3_broadcast_plan, "shuffle": tpch.q3_distributed_plan}
+    Q3_OUTPUT = ["l_orderkey", "revenue", "o_orderdate", "o_shippriority"]
     # N = 1: the plan description is built once; every step executes a copy with fresh run-once state (no cached build side)
     template = tpch.q3_plan(tables, batch_size=8192) if world == 1 else None
 
@@ -100,18 +104,16 @@ def main():
             plan = ops.with_fresh_state(template)
             out = [b for b in plan.execute(0, tc)]
         else:
-            plan = (tpch.q3_broadcast_plan if args.plan == "broadcast" else tpch.q3_distributed_plan)(tables, batch_size=8192)
+            plan = PLANS[args.plan](tables, batch_size=8192)
             local = [b for b in plan.execute(0, tc)]
-            schema = local[0].schema if local else None
-            mine = ops.concat_batches(schema, local) if local else None
-            schema = exchange.agree_schema(schema)
-            gathered = exchange.gather_batches(ctx, schema, mine, 0)           # ≙ SortPreservingMergeExec gathering the sorted partitions
+            mine = ops.concat_batches(local[0].schema, local) if local else None
+            gathered = exchange.gather_batches(ctx, None, mine, 0, names=Q3_OUTPUT)           # ≙ SortPreservingMergeExec gathering the sorted partitions
             out = []
             if rank == 0 and gathered.num_rows:
                 C = ops.Column
                 gb = gathered
                 final = ops.SortExec([ops.PhysicalSortExpr(C("revenue", 1), True, True), ops.PhysicalSortExpr(C("o_orderdate", 2), False, False)],
-                                     ops.MemoryExec([[gb]], schema))
+                                     ops.MemoryExec([[gb]], gb.schema))
                 out = [b for b in final.execute(0, tc)]
         ctx.synchronize()
         result_rows[0] = sum(b.num_rows for b in out)
@@ -227,8 +229,9 @@ def main():
         line = {"metric": "rows/sec hash-join+agg, TPC-H SF100 Q3", "value": round(value, 1), "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64 keys / i128 (Decimal128) sums",
                 "data": "synthetic", "config": {"workload": f"TPC-H SF{args.sf:g} Q3 (3-way hash join + group-by SUM + sort), int64 keys, Decimal128(15,2) money, resident in HBM",
-                                                "input_rows": rows_total, "result_rows": result_rows[0], "parallelism": (f"{world} GPUs, CollectLeft joins: RCCL all-gather of build sides + all-to-all of partial aggregates" if args.plan == "broadcast"
-                                                                else f"{world} GPUs, partitioned joins: hash partition + RCCL all-to-all per exchange") if world > 1 else "1 GPU"},
+                                                "input_rows": rows_total, "result_rows": result_rows[0], "parallelism": {"colocated": f"{world} GPUs, range-sharded tables: RCCL all-gather of the customer build side, partition-local orders-lineitem join + aggregation, gather of sorted partitions",
+                                                                "broadcast": f"{world} GPUs, CollectLeft joins: RCCL all-gather of build sides + all-to-all of partial aggregates",
+                                                                "shuffle": f"{world} GPUs, partitioned joins: hash partition + RCCL all-to-all per exchange"}[args.plan] if world > 1 else "1 GPU"},
                 "roofline": roofline, "cpu_baseline": cpu_baseline}
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -77,94 +77,173 @@ class _DevicePtr:
 _WIDTH = {2: 1, 6: 1, 3: 2, 7: 2, 4: 4, 8: 4, 10: 4, 12: 4, 5: 8, 9: 8, 11: 8, 13: 16}
 
 
-def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=None):
-    """parts[dest] = the rows of this rank bound for rank `dest` (None/empty allowed; fixed-width columns, nullable
-    or not).  Returns one RecordBatch holding everything this rank received, source ranks in order (≙ the batches a
-    RepartitionExec output partition yields).  Values travel as one all-to-all per column; a column that carries a
-    validity bitmap on ANY rank (agreed with one all-reduce so every rank issues the same collectives) also sends
-    its bitmap words per destination, and the receiver splices the per-source bitmaps at bit granularity."""
+_MAX_COLS = 64
+
+
+def _same_stream(ctx) -> bool:
+    """dfgpu kernels and torch / RCCL work are stream ordered when the context runs on torch's current stream (bench.py);
+    a context with a private stream (the unit tests) needs explicit synchronisation around the collectives."""
+    import torch
+    return ctx.stream == torch.cuda.current_stream().cuda_stream
+
+
+def _exchange_meta(counts: Sequence[int], fields, has_valid: Sequence[int], group):
+    """ONE small all-gather carries everything the ranks must agree on before the data moves: the row-count matrix, and --
+    for ranks that hold no rows and therefore no arrays -- the column types and which columns carry a validity bitmap.
+    Returns (recv_counts[src], all_counts[src][dst], fields [(dtype, precision, scale)], nullable [bool])."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    ncols = len(fields) if fields is not None else 0
+    if ncols > _MAX_COLS:
+        raise ValueError(f"exchange of {ncols} columns (max {_MAX_COLS})")
+    row = list(counts) + [ncols]
+    for c in range(ncols):
+        row += [fields[c][0], fields[c][1], fields[c][2], int(has_valid[c])]
+    row += [0] * (world + 1 + 4 * _MAX_COLS - len(row))
+    dev = "cuda" if _is_nccl(group) else "cpu"
+    mine = torch.tensor(row, dtype=torch.int64, device=dev)
+    if world > 1:
+        allm = torch.empty((world, mine.numel()), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allm, mine, group=group) if _is_nccl(group) else dist.all_gather(list(allm.unbind(0)), mine, group=group)
+    else:
+        allm = mine.unsqueeze(0)
+    m = allm.cpu().tolist()                                     # the one host round trip of an exchange
+    all_counts = [r[:world] for r in m]
+    src = next((r for r in m if r[world] > 0), None)
+    if src is None:
+        return [0] * world, all_counts, [], []
+    nc = src[world]
+    flds = [tuple(src[world + 1 + 4 * c: world + 4 + 4 * c]) for c in range(nc)]
+    nullable = [any(r[world] > 0 and r[world + 4 + 4 * c] for r in m) for c in range(nc)]
+    return [all_counts[s][rank] for s in range(world)], all_counts, flds, nullable
+
+
+def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=None, names: Optional[Sequence[str]] = None, broadcast: bool = False):
+    """parts[dest] = the rows of this rank bound for rank `dest` (None/empty allowed; fixed-width columns, nullable or not).
+    Returns one RecordBatch holding everything this rank received, source ranks in order (≙ the batches a RepartitionExec
+    output partition yields).  One metadata all-gather (_exchange_meta), then one collective per column buffer: all-to-all(v)
+    for a shuffle, all-gather for `broadcast` (every part is the same batch).  A column that carries a validity bitmap on ANY
+    rank also moves its bitmap words, and the receiver splices the per-source bitmaps at bit granularity.  `schema` may be
+    None on a rank without rows; `names` (static, from the plan) then names the columns."""
     import torch
     import torch.distributed as dist
     from . import capi, operators as ops, physical_plan as pp
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     assert len(parts) == world
     counts = [0 if p is None else p.num_rows for p in parts]
-    widths = []
-    for f in schema.fields:
-        if f.dtype not in _WIDTH:
-            raise ops.DfgpuError(4, f"exchange of column type {f.dtype} is not supported yet")
-        widths.append(_WIDTH[f.dtype])
-    ncols = len(widths)
-    has_valid = torch.zeros(ncols, dtype=torch.int32, device="cuda")
-    for p, n in zip(parts, counts):
-        if p is not None and n:
-            for c, col in enumerate(p.columns):
-                if col.describe().validity:
-                    has_valid[c] = 1
-    if world > 1:
-        hv = _staged(has_valid, group)
-        dist.all_reduce(hv, op=dist.ReduceOp.MAX, group=group)
-        has_valid = hv
-    nullable = [bool(x) for x in has_valid.cpu().tolist()]
-    ctx.synchronize()                      # producers ran on the ctx stream
-    tparts: List[Optional[List]] = []
-    vparts: List[Optional[List]] = []      # validity words of the nullable columns
+    first = next((p for p, n in zip(parts, counts) if p is not None and n), None)
+    fields = has_valid = None
+    if first is not None:
+        fs = (schema or first.schema).fields
+        fields = [(f.dtype, f.precision, f.scale) for f in fs]
+        for f in fs:
+            if f.dtype not in _WIDTH:
+                raise ops.DfgpuError(4, f"exchange of column type {f.dtype} is not supported yet")
+        has_valid = [0] * len(fs)
+        for p, n in zip(parts[:1] if broadcast else parts, counts):
+            if p is not None and n:
+                for c, col in enumerate(p.columns):
+                    if col.describe().validity:
+                        has_valid[c] = 1
+    recv_counts, all_counts, flds, nullable = _exchange_meta(counts, fields, has_valid, group)
+    if not flds:
+        return pp.RecordBatch.from_arrays(ctx, [], [])
+    if names is None:
+        names = (schema or first.schema).names() if (schema is not None or first is not None) else [f"c{c}" for c in range(len(flds))]
+    widths = [_WIDTH[t] for t, _, _ in flds]
+    sync = not _same_stream(ctx)
+    nccl = _is_nccl(group)
+    total = int(sum(recv_counts))
+    vwords = lambda n: ((n + 63) // 64) * 8
+
+    def device_bytes(arr, nbytes):
+        d = arr.describe()
+        return torch.as_tensor(_DevicePtr(d.values, nbytes, arr), device="cuda")
+
+    def move(segs_of_dest, send_sizes, recv_sizes):
+        """one collective for one buffer: segs_of_dest[d] = uint8 tensor for rank d (or None).  Returns the per-source pieces
+        (8-byte aligned when every size is a multiple of 8) and, for the all-to-all, the whole contiguous receive buffer."""
+        if broadcast:
+            mine = segs_of_dest[rank] if segs_of_dest[rank] is not None else torch.empty(0, dtype=torch.uint8, device="cuda")
+            if world == 1:
+                return [mine], mine
+            mx = (max(recv_sizes) + 63) // 64 * 64               # row stride of the gathered buffer: keeps every source's piece aligned
+            pad = torch.empty(mx, dtype=torch.uint8, device="cuda")
+            pad[:mine.numel()] = mine
+            out = torch.empty((world, mx), dtype=torch.uint8, device="cuda" if nccl else "cpu")
+            if nccl:
+                dist.all_gather_into_tensor(out, pad, group=group)
+            else:
+                dist.all_gather(list(out.unbind(0)), pad.cpu(), group=group)
+                out = out.to("cuda")
+            return [out[s, :recv_sizes[s]] for s in range(world)], None
+        segs = [t for t in segs_of_dest if t is not None and t.numel()]
+        send = torch.cat(segs) if len(segs) > 1 else (segs[0] if segs else torch.empty(0, dtype=torch.uint8, device="cuda"))
+        got = all_to_all_buffers(_staged(send, group), send_sizes, recv_sizes, group)
+        got = got.to("cuda") if got.device.type != "cuda" else got
+        outs, off = [], 0
+        for n in recv_sizes:
+            outs.append(got[off:off + n]); off += n
+        return outs, got
+
+    if sync:
+        ctx.synchronize()                  # producers ran on the ctx stream
     keep = []
-    for p, n in zip(parts, counts):
-        if p is None or n == 0:
-            tparts.append(None)
-            vparts.append(None)
-            continue
-        cols, vcols = [], []
-        for c, col in enumerate(p.columns):
-            d = col.describe()
-            cols.append(torch.as_tensor(_DevicePtr(d.values, d.length * widths[c], col), device="cuda"))
+    out_cols = []
+    for c, (t, prec, scale) in enumerate(flds):
+        w = widths[c]
+        vsegs = [None] * world
+        segs = [None] * world
+        for d, (p, n) in enumerate(zip(parts, counts)):
+            if p is None or n == 0 or (broadcast and d != rank):
+                continue
+            col = p.columns[c]
+            segs[d] = device_bytes(col, n * w)
             if nullable[c]:
                 bm = ctx.is_null(col, negate=True)           # validity as a Boolean column (all ones when there is no bitmap)
                 keep.append(bm)
-                vcols.append(torch.as_tensor(_DevicePtr(bm.describe().values, ((n + 63) // 64) * 8, bm), device="cuda"))
-        tparts.append(cols)
-        vparts.append(vcols)
-    ctx.synchronize()
-    recv_counts, recv = exchange_byte_columns(tparts, counts, widths, group)
-    total = int(sum(recv_counts))
-    out_cols = []
-    vi = 0
-    for c, f in enumerate(schema.fields):
+                vsegs[d] = device_bytes(bm, vwords(n))
+        if sync and nullable[c]:
+            ctx.synchronize()
+        pieces, whole = move(segs, [n * w for n in counts], [n * w for n in recv_counts])
+        if whole is not None:
+            values = ctx.wrap_tensor(whole, t, prec, scale)                     # sources back to back: one contiguous column
+        else:
+            parts_v = [ctx.wrap_tensor(pc, t, prec, scale) for pc, n in zip(pieces, recv_counts) if n]
+            values = ctx.concat(parts_v) if parts_v else ctx.new_null(t, 0, prec, scale)
         if not nullable[c]:
-            # own the bytes: the torch receive buffer dies with this function, the column may outlive it inside a C++ plan
-            out_cols.append(ctx.concat([ctx.wrap_tensor(recv[c], f.dtype, f.precision, f.scale)]))
+            if sync:
+                torch.cuda.current_stream().synchronize()
+            # own the bytes: the torch receive buffers die with this function, the column may outlive it inside a C++ plan
+            out_cols.append(ctx.concat([values]) if whole is not None else values)
             continue
-        segs = [vp[vi] for vp, n in zip(vparts, counts) if vp is not None and n]
-        send = torch.cat(segs) if segs else torch.empty(0, dtype=torch.uint8, device="cuda")
-        vrecv = all_to_all_buffers(_staged(send, group), [((n + 63) // 64) * 8 for n in counts], [((n + 63) // 64) * 8 for n in recv_counts], group).to("cuda")
-        torch.cuda.current_stream().synchronize()
-        pieces, off = [], 0
-        for n in recv_counts:
-            nb = ((n + 63) // 64) * 8
-            if n:
-                pieces.append(ctx.wrap_tensor_bool(vrecv[off:off + nb], n))
-            off += nb
-        validity = ctx.concat(pieces) if len(pieces) > 1 else (pieces[0] if pieces else None)
+        vpieces, _ = move(vsegs, [vwords(n) for n in counts], [vwords(n) for n in recv_counts])
+        if sync:
+            torch.cuda.current_stream().synchronize()
+        bools = [ctx.wrap_tensor_bool(vp, n) for vp, n in zip(vpieces, recv_counts) if n]      # every piece is a multiple of 8 bytes
+        validity = ctx.concat(bools) if len(bools) > 1 else (bools[0] if bools else None)       # spliced at bit granularity
         d = capi.ArrayDesc()
-        d.type, d.precision, d.scale, d.length, d.null_count = f.dtype, f.precision, f.scale, total, -1
-        d.values = recv[c].data_ptr() if total else 0
+        d.type, d.precision, d.scale, d.length, d.null_count = t, prec, scale, total, -1
+        d.values = values.describe().values if total else 0
         if validity is not None:
             d.validity = validity.describe().values
-        view = ctx.wrap_device(d, keepalive=(recv[c], validity, vrecv)) if total else ctx.wrap_tensor(recv[c], f.dtype, f.precision, f.scale)
+        view = ctx.wrap_device(d, keepalive=(values, validity, vpieces, whole, pieces)) if total else values
         out_cols.append(ctx.concat([view]))          # owned copy (values + spliced validity)
-        vi += 1
-    ctx.synchronize()                              # the owned copies are complete before the torch buffers are released
-    return pp.RecordBatch.from_arrays(ctx, schema.names(), out_cols)
+    if sync:
+        ctx.synchronize()                              # the owned copies are complete before the torch buffers are released
+    return pp.RecordBatch.from_arrays(ctx, list(names), out_cols)
 
 
-def gather_batches(ctx, schema, batch, dst: int = 0, group=None):
+def gather_batches(ctx, schema, batch, dst: int = 0, group=None, names: Optional[Sequence[str]] = None):
     """≙ CoalescePartitionsExec / SortPreservingMergeExec input gathering: every rank's batch to rank `dst`."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     parts = [None] * world
     parts[dst] = batch
-    return exchange_batches(ctx, schema, parts, group)
+    return exchange_batches(ctx, schema, parts, group, names=names)
 
 
 class ShuffleExec:
@@ -204,8 +283,7 @@ class ShuffleExec:
                 if d != self.rank:
                     self.bytes_sent += sum(_WIDTH.get(f.dtype, 0) for f in schema.fields) * m.num_rows
             merged.append(m)
-        schema = self._agree_schema(context.ctx, schema)
-        out = exchange_batches(context.ctx, schema, merged, self.group)
+        out = exchange_batches(context.ctx, schema, merged, self.group, names=self.input.schema().names())
         if out.num_rows:
             yield out
 
@@ -254,10 +332,9 @@ class BroadcastExec:
         for p in range(self.input.output_partitioning().partition_count()):
             local += [b for b in self.input.execute(p, context) if b.num_rows]
         mine = pp.concat_batches(None, local) if local else None
-        schema = agree_schema(mine.schema if mine is not None else None, self.group)
         if mine is not None:
-            self.bytes_sent += sum(_WIDTH.get(f.dtype, 0) for f in schema.fields) * mine.num_rows * (self.world - 1)
-        out = exchange_batches(context.ctx, schema, [mine] * self.world, self.group)      # same rows to every rank = all-gather
+            self.bytes_sent += sum(_WIDTH.get(f.dtype, 0) for f in mine.schema.fields) * mine.num_rows * (self.world - 1)
+        out = exchange_batches(context.ctx, None, [mine] * self.world, self.group, names=self.input.schema().names(), broadcast=True)
         if out.num_rows:
             yield out
 

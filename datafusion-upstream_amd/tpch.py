@@ -249,6 +249,43 @@ def q3_broadcast_plan(tables: Dict[str, ops.RecordBatch], group=None, batch_size
                          ops.PhysicalSortExpr(C("o_orderdate", 2), descending=False, nulls_first=False)], proj, preserve_partitioning=True)
 
 
+def q3_colocated_plan(tables: Dict[str, ops.RecordBatch], group=None, batch_size: int = 8192) -> ops.ExecutionPlan:
+    """Q3 on N GPUs over CO-PARTITIONED shards: gen_device gives every rank a contiguous range of orders and the lineitems
+    of exactly those orders (TPC-H files are clustered that way; dbgen -C/-S chunks have the same property), so equal
+    o_orderkey / l_orderkey values already live on one rank.  The distribution requirement of the orders-lineitem HashJoinExec
+    and of the GROUP BY l_orderkey, .. aggregation (hash_join.rs:520-527, aggregates/mod.rs:653-655: equal keys in one
+    partition) is therefore met WITHOUT a RepartitionExec -- what EnforceDistribution does when its input already satisfies
+    the requirement (core/src/physical_optimizer/enforce_distribution.rs).  Only the customer join has a real exchange step:
+    customers are sharded by c_custkey, orders reference any customer, so the filtered customer keys (SF100: 24 MB) are
+    all-gathered (PartitionMode::CollectLeft).  Every rank then runs join -> join -> AggregateExec(Single) -> SortExec on its
+    own shard; the driver gathers the sorted partitions.  Same rows as q3_plan / q3_broadcast_plan / q3_distributed_plan."""
+    import decimal
+    import pyarrow as pa
+    from .exchange import BroadcastExec
+    C, L, B = ops.Column, ops.Literal, ops.BinaryExpr
+    cust = ops.MemoryExec([[tables["customer"]]], _schema(CUSTOMER_SCHEMA))
+    orders = ops.MemoryExec([[tables["orders"]]], _schema(ORDERS_SCHEMA))
+    line = ops.MemoryExec([[tables["lineitem"]]], _schema(LINEITEM_SCHEMA))
+    cb = lambda p: ops.CoalesceBatchesExec(p, batch_size)
+    f_c = cb(ops.FilterExec(B(C("c_mktsegment", 1), "=", L(Q3_SEGMENT, pa.utf8())), cust))
+    b_c = BroadcastExec(ops.ProjectionExec([(C("c_custkey", 0), "c_custkey")], f_c), group)
+    f_o = cb(ops.FilterExec(B(C("o_orderdate", 2), "<", L(Q3_DATE, pa.date32())), orders))
+    j1 = cb(ops.HashJoinExec(b_c, f_o, [(C("c_custkey", 0), C("o_custkey", 1))], None, "Inner", "CollectLeft"))
+    p_j1 = ops.ProjectionExec([(C("o_orderkey", 1), "o_orderkey"), (C("o_orderdate", 3), "o_orderdate"), (C("o_shippriority", 4), "o_shippriority")], j1)
+    f_l = cb(ops.FilterExec(B(C("l_shipdate", 3), ">", L(Q3_DATE, pa.date32())), line))
+    p_l = ops.ProjectionExec([(C("l_orderkey", 0), "l_orderkey"), (C("l_extendedprice", 1), "l_extendedprice"), (C("l_discount", 2), "l_discount")], f_l)
+    j2 = cb(ops.HashJoinExec(p_j1, p_l, [(C("o_orderkey", 0), C("l_orderkey", 0))], None, "Inner", "Partitioned"))
+    p_j2 = ops.ProjectionExec([(C("o_orderdate", 1), "o_orderdate"), (C("o_shippriority", 2), "o_shippriority"), (C("l_orderkey", 3), "l_orderkey"),
+                               (C("l_extendedprice", 4), "l_extendedprice"), (C("l_discount", 5), "l_discount")], j2)
+    revenue = B(C("l_extendedprice", 3), "*", B(L(decimal.Decimal(1), pa.decimal128(20, 0)), "-", C("l_discount", 4)))
+    agg = ops.AggregateExec("SinglePartitioned", [(C("l_orderkey", 2), "l_orderkey"), (C("o_orderdate", 0), "o_orderdate"), (C("o_shippriority", 1), "o_shippriority")],
+                            [ops.AggregateFunctionExpr("SUM", revenue, "SUM(lineitem.l_extendedprice * Int64(1) - lineitem.l_discount)",
+                                                       input_field=ops.Field("rev", capi.DECIMAL128, 38, 4))], p_j2)
+    proj = ops.ProjectionExec([(C("l_orderkey", 0), "l_orderkey"), (C("revenue", 3), "revenue"), (C("o_orderdate", 1), "o_orderdate"), (C("o_shippriority", 2), "o_shippriority")], agg)
+    return ops.SortExec([ops.PhysicalSortExpr(C("revenue", 1), descending=True, nulls_first=True),
+                         ops.PhysicalSortExpr(C("o_orderdate", 2), descending=False, nulls_first=False)], proj, preserve_partitioning=True)
+
+
 def q3_distributed_plan(tables: Dict[str, ops.RecordBatch], group=None, batch_size: int = 8192) -> ops.ExecutionPlan:
     """The reference's PARTITIONED Q3 plan (tpch/q3.slt.part physical_plan) with one output partition per GPU:
     every `RepartitionExec: partitioning=Hash(..)` becomes a ShuffleExec (device hash partition + RCCL all-to-all),

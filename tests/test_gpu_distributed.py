@@ -25,7 +25,8 @@ def _worker(rank, world, port, sf, q, plan_name="q3_distributed_plan"):
         from dfgpu import exchange, physical_plan as ops, tpch
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        ctx = dfgpu.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        # odd ranks run on a private stream: the exchange must then synchronise around the collectives by itself
+        ctx = dfgpu.Context(0, stream=torch.cuda.current_stream().cuda_stream) if rank % 2 == 0 else dfgpu.Context(0)
         host = tpch.gen_host(sf)
         nc, no = len(host["c_custkey"]), len(host["o_orderkey"])
         c0, c1, o0, o1 = nc * rank // world, nc * (rank + 1) // world, no * rank // world, no * (rank + 1) // world
@@ -36,8 +37,8 @@ def _worker(rank, world, port, sf, q, plan_name="q3_distributed_plan"):
         tc = ops.TaskContext(ctx, batch_size=8192)
         plan = getattr(tpch, plan_name)(tables)
         local = list(plan.execute(0, tc))
-        schema = local[0].schema
-        gathered = exchange.gather_batches(ctx, schema, ops.concat_batches(schema, local), 0)
+        mine = ops.concat_batches(local[0].schema, local) if local else None
+        gathered = exchange.gather_batches(ctx, None, mine, 0, names=["l_orderkey", "revenue", "o_orderdate", "o_shippriority"])
         if rank == 0:
             q.put((rank, tpch.q3_result_to_numpy([gathered])))
         else:
@@ -49,7 +50,8 @@ def _worker(rank, world, port, sf, q, plan_name="q3_distributed_plan"):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,plan_name", [(2, "q3_distributed_plan"), (3, "q3_distributed_plan"), (2, "q3_broadcast_plan"), (3, "q3_broadcast_plan")])
+@pytest.mark.parametrize("world,plan_name", [(2, "q3_distributed_plan"), (3, "q3_distributed_plan"), (2, "q3_broadcast_plan"), (3, "q3_broadcast_plan"),
+                                             (2, "q3_colocated_plan"), (3, "q3_colocated_plan")])
 def test_q3_distributed_two_ranks_one_gpu_matches_oracle(world, plan_name):
     import torch.multiprocessing as mp
     from dfgpu import tpch
@@ -58,7 +60,7 @@ def test_q3_distributed_two_ranks_one_gpu_matches_oracle(world, plan_name):
     sf = 0.05
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 1000) + world + (10 if plan_name == "q3_broadcast_plan" else 0)
+    port = 29700 + (os.getpid() % 1000) + world + {"q3_distributed_plan": 0, "q3_broadcast_plan": 10, "q3_colocated_plan": 20}[plan_name]
     procs = [ctx.Process(target=_worker, args=(r, world, port, sf, q, plan_name)) for r in range(world)]
     for p in procs:
         p.start()
