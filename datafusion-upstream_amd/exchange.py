@@ -104,11 +104,8 @@ def _exchange_meta(counts: Sequence[int], fields, has_valid: Sequence[int], grou
     row += [0] * (world + 1 + 4 * _MAX_COLS - len(row))
     dev = "cuda" if _is_nccl(group) else "cpu"
     mine = torch.tensor(row, dtype=torch.int64, device=dev)
-    if world > 1:
-        allm = torch.empty((world, mine.numel()), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(allm, mine, group=group) if _is_nccl(group) else dist.all_gather(list(allm.unbind(0)), mine, group=group)
-    else:
-        allm = mine.unsqueeze(0)
+    allm = torch.empty((world, mine.numel()), dtype=torch.int64, device=dev)      # also at world 1: the RCCL path is the one a 1-rank test covers
+    dist.all_gather_into_tensor(allm, mine, group=group) if _is_nccl(group) else dist.all_gather(list(allm.unbind(0)), mine, group=group)
     m = allm.cpu().tolist()                                     # the one host round trip of an exchange
     all_counts = [r[:world] for r in m]
     src = next((r for r in m if r[world] > 0), None)
@@ -168,8 +165,6 @@ def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=No
         (8-byte aligned when every size is a multiple of 8) and, for the all-to-all, the whole contiguous receive buffer."""
         if broadcast:
             mine = segs_of_dest[rank] if segs_of_dest[rank] is not None else torch.empty(0, dtype=torch.uint8, device="cuda")
-            if world == 1:
-                return [mine], mine
             mx = (max(recv_sizes) + 63) // 64 * 64               # row stride of the gathered buffer: keeps every source's piece aligned
             pad = torch.empty(mx, dtype=torch.uint8, device="cuda")
             pad[:mine.numel()] = mine

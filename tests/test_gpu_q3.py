@@ -69,13 +69,14 @@ def test_q3_distributed_plan_world1_rccl_matches_single(ctx):
         tables = tpch.upload(ctx, host)
         tc = ops.TaskContext(ctx, batch_size=1 << 30)
         single = tpch.q3_result_to_numpy(ops.collect(tpch.q3_plan(tables), tc))
-        plan = tpch.q3_distributed_plan(tables)
-        local = list(plan.execute(0, tc))
-        gathered = exchange.gather_batches(ctx, local[0].schema, ops.concat_batches(local[0].schema, local), 0)
-        multi = tpch.q3_result_to_numpy([gathered])
-        g, w = canon(multi), canon(single)
-        assert len(g["l_orderkey"]) == len(w["l_orderkey"]) > 0
-        for k in w:
-            assert np.array_equal(g[k], w[k]), k
+        w = canon(single)
+        # every N > 1 plan: all-to-all(v) (shuffle), all-gather (broadcast / colocated) and the metadata all-gather all run on RCCL here
+        for make in (tpch.q3_distributed_plan, tpch.q3_broadcast_plan, tpch.q3_colocated_plan):
+            local = list(make(tables).execute(0, tc))
+            gathered = exchange.gather_batches(ctx, None, ops.concat_batches(local[0].schema, local), 0, names=local[0].schema.names())
+            g = canon(tpch.q3_result_to_numpy([gathered]))
+            assert len(g["l_orderkey"]) == len(w["l_orderkey"]) > 0, make.__name__
+            for k in w:
+                assert np.array_equal(g[k], w[k]), (make.__name__, k)
     finally:
         dist.destroy_process_group()
