@@ -154,79 +154,92 @@ def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=No
     sync = not _same_stream(ctx)
     nccl = _is_nccl(group)
     total = int(sum(recv_counts))
+    pad8 = lambda x: (x + 7) // 8 * 8
     vwords = lambda n: ((n + 63) // 64) * 8
+
+    # One message per (source, destination): every column's values (padded to 8 bytes) followed by its validity words when the
+    # column is nullable anywhere -- so an exchange is ONE data collective, whatever the number of columns (a collective costs
+    # ~100 us of launch latency on RCCL; TPC-H Q3's gather has 4 columns, its shuffles 3-5).
+    def layout(n):
+        offs, o = [], 0
+        for c, w in enumerate(widths):
+            vo = o; o += pad8(n * w)
+            bo = None
+            if nullable[c]:
+                bo = o; o += vwords(n)
+            offs.append((vo, bo))
+        return offs, o
 
     def device_bytes(arr, nbytes):
         d = arr.describe()
         return torch.as_tensor(_DevicePtr(d.values, nbytes, arr), device="cuda")
 
-    def move(segs_of_dest, send_sizes, recv_sizes):
-        """one collective for one buffer: segs_of_dest[d] = uint8 tensor for rank d (or None).  Returns the per-source pieces
-        (8-byte aligned when every size is a multiple of 8) and, for the all-to-all, the whole contiguous receive buffer."""
-        if broadcast:
-            mine = segs_of_dest[rank] if segs_of_dest[rank] is not None else torch.empty(0, dtype=torch.uint8, device="cuda")
-            mx = (max(recv_sizes) + 63) // 64 * 64               # row stride of the gathered buffer: keeps every source's piece aligned
-            pad = torch.empty(mx, dtype=torch.uint8, device="cuda")
-            pad[:mine.numel()] = mine
-            out = torch.empty((world, mx), dtype=torch.uint8, device="cuda" if nccl else "cpu")
-            if nccl:
-                dist.all_gather_into_tensor(out, pad, group=group)
-            else:
-                dist.all_gather(list(out.unbind(0)), pad.cpu(), group=group)
-                out = out.to("cuda")
-            return [out[s, :recv_sizes[s]] for s in range(world)], None
-        segs = [t for t in segs_of_dest if t is not None and t.numel()]
-        send = torch.cat(segs) if len(segs) > 1 else (segs[0] if segs else torch.empty(0, dtype=torch.uint8, device="cuda"))
-        got = all_to_all_buffers(_staged(send, group), send_sizes, recv_sizes, group)
-        got = got.to("cuda") if got.device.type != "cuda" else got
-        outs, off = [], 0
-        for n in recv_sizes:
-            outs.append(got[off:off + n]); off += n
-        return outs, got
-
-    if sync:
-        ctx.synchronize()                  # producers ran on the ctx stream
+    zeros8 = torch.zeros(8, dtype=torch.uint8, device="cuda")
     keep = []
-    out_cols = []
-    for c, (t, prec, scale) in enumerate(flds):
-        w = widths[c]
-        vsegs = [None] * world
-        segs = [None] * world
-        for d, (p, n) in enumerate(zip(parts, counts)):
-            if p is None or n == 0 or (broadcast and d != rank):
-                continue
-            col = p.columns[c]
-            segs[d] = device_bytes(col, n * w)
+
+    def message(p, n):
+        """the packed bytes of batch p (n rows) as a list of tensors to concatenate"""
+        segs = []
+        for c, col in enumerate(p.columns):
+            nb = n * widths[c]
+            segs.append(device_bytes(col, nb))
+            if pad8(nb) != nb:
+                segs.append(zeros8[:pad8(nb) - nb])
             if nullable[c]:
                 bm = ctx.is_null(col, negate=True)           # validity as a Boolean column (all ones when there is no bitmap)
                 keep.append(bm)
-                vsegs[d] = device_bytes(bm, vwords(n))
-        if sync and nullable[c]:
-            ctx.synchronize()
-        pieces, whole = move(segs, [n * w for n in counts], [n * w for n in recv_counts])
-        if whole is not None:
-            values = ctx.wrap_tensor(whole, t, prec, scale)                     # sources back to back: one contiguous column
-        else:
-            parts_v = [ctx.wrap_tensor(pc, t, prec, scale) for pc, n in zip(pieces, recv_counts) if n]
-            values = ctx.concat(parts_v) if parts_v else ctx.new_null(t, 0, prec, scale)
-        if not nullable[c]:
-            if sync:
-                torch.cuda.current_stream().synchronize()
-            # own the bytes: the torch receive buffers die with this function, the column may outlive it inside a C++ plan
-            out_cols.append(ctx.concat([values]) if whole is not None else values)
-            continue
-        vpieces, _ = move(vsegs, [vwords(n) for n in counts], [vwords(n) for n in recv_counts])
+                segs.append(device_bytes(bm, vwords(n)))
+        return segs
+
+    recv_sizes = [layout(n)[1] for n in recv_counts]
+    if broadcast:
+        segs = message(parts[rank], counts[rank]) if parts[rank] is not None and counts[rank] else []
         if sync:
-            torch.cuda.current_stream().synchronize()
-        bools = [ctx.wrap_tensor_bool(vp, n) for vp, n in zip(vpieces, recv_counts) if n]      # every piece is a multiple of 8 bytes
-        validity = ctx.concat(bools) if len(bools) > 1 else (bools[0] if bools else None)       # spliced at bit granularity
+            ctx.synchronize()                  # producers (and is_null above) ran on the ctx stream
+        stride = (max(recv_sizes) + 63) // 64 * 64           # row stride of the gathered buffer: keeps every source's message aligned
+        pad = torch.empty(stride, dtype=torch.uint8, device="cuda")
+        if segs:
+            torch.cat(segs, out=pad[:recv_sizes[rank]])
+        out = torch.empty((world, stride), dtype=torch.uint8, device="cuda" if nccl else "cpu")
+        if nccl:
+            dist.all_gather_into_tensor(out, pad, group=group)
+        else:
+            dist.all_gather(list(out.unbind(0)), pad.cpu(), group=group)
+            out = out.to("cuda")
+        base = [s * stride for s in range(world)]
+        buf = out.view(-1)
+    else:
+        segs, send_sizes = [], []
+        for p, n in zip(parts, counts):
+            send_sizes.append(layout(n)[1] if p is not None and n else 0)
+            if p is not None and n:
+                segs += message(p, n)
+        if sync:
+            ctx.synchronize()
+        send = torch.cat(segs) if len(segs) > 1 else (segs[0] if segs else torch.empty(0, dtype=torch.uint8, device="cuda"))
+        buf = all_to_all_buffers(_staged(send, group), send_sizes, recv_sizes, group)
+        buf = buf.to("cuda") if buf.device.type != "cuda" else buf
+        base, o = [], 0
+        for sz in recv_sizes:
+            base.append(o); o += sz
+    if sync:
+        torch.cuda.current_stream().synchronize()
+    out_cols = []
+    lay = [layout(n)[0] for n in recv_counts]
+    for c, (t, prec, scale) in enumerate(flds):
+        w = widths[c]
+        vals = [ctx.wrap_tensor(buf[base[s] + lay[s][c][0]: base[s] + lay[s][c][0] + n * w], t, prec, scale) for s, n in enumerate(recv_counts) if n]
+        # concat = the owned copy: the torch receive buffer dies with this function, the column may outlive it inside a C++ plan
+        values = ctx.concat(vals) if vals else ctx.new_null(t, 0, prec, scale)
+        if not nullable[c] or not total:
+            out_cols.append(values)
+            continue
+        bools = [ctx.wrap_tensor_bool(buf[base[s] + lay[s][c][1]: base[s] + lay[s][c][1] + vwords(n)], n) for s, n in enumerate(recv_counts) if n]
+        validity = ctx.concat(bools) if len(bools) > 1 else bools[0]            # spliced at bit granularity
         d = capi.ArrayDesc()
         d.type, d.precision, d.scale, d.length, d.null_count = t, prec, scale, total, -1
-        d.values = values.describe().values if total else 0
-        if validity is not None:
-            d.validity = validity.describe().values
-        view = ctx.wrap_device(d, keepalive=(values, validity, vpieces, whole, pieces)) if total else values
-        out_cols.append(ctx.concat([view]))          # owned copy (values + spliced validity)
+        d.values, d.validity = values.describe().values, validity.describe().values
+        out_cols.append(ctx.concat([ctx.wrap_device(d, keepalive=(values, validity, buf))]))          # values + spliced validity in one owned array
     if sync:
         ctx.synchronize()                              # the owned copies are complete before the torch buffers are released
     return pp.RecordBatch.from_arrays(ctx, list(names), out_cols)
