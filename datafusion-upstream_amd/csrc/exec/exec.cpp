@@ -598,6 +598,37 @@ struct SortExec : Plan {          // sorts/sort.rs:719-733; sort_batch :584-609
   }
 };
 
+// ------------------------------------------------------------------ SortPreservingMergeExec
+// sorts/sort_preserving_merge.rs:67-120, execute :186-247; streaming_merge / loser tree (sorts/merge.rs:38-110) picks, among
+// streams whose heads compare equal, the lower stream index.  On the device the k sorted input partitions are concatenated in
+// partition order and ranked by the STABLE radix sort of dfgpu_sort_to_indices: for inputs that are sorted on `exprs` (the
+// operator's precondition) that is the same row order as the k-way merge, ties included, in one pass over whole partitions.
+struct SortPreservingMergeExec : Plan {
+  std::vector<ExprPtr> exprs; std::vector<uint8_t> desc, nulls_first; int64_t fetch; PlanPtr input;
+  PlanPtr fresh() const override { auto s = std::make_shared<SortPreservingMergeExec>(); s->exprs = exprs; s->desc = desc; s->nulls_first = nulls_first; s->fetch = fetch; s->input = input->fresh(); return s; }
+  const char* name() const override { return "SortPreservingMergeExec"; }
+  SchemaPtr schema() const override { return input->schema(); }
+  int partitions() const override { return 1; }
+  std::unique_ptr<Stream> execute(int partition, const TaskContext& tc) const override {
+    if (partition != 0) fail(DFGPU_INTERNAL, "SortPreservingMergeExec invalid partition %d", partition);
+    int np = input->partitions();
+    if (np == 0) fail(DFGPU_INTERNAL, "SortPreservingMergeExec requires at least one input partition");
+    if (np == 1) return input->execute(0, tc);              // bypass (:213-218)
+    if (exprs.empty()) fail(DFGPU_INTERNAL, "Sort expressions cannot be empty for streaming merge");      // sorts/streaming_merge.rs
+    std::vector<Batch> in; for (int p = 0; p < np; p++) drain(input, p, tc, in);
+    std::vector<Batch> outv; Batch b;
+    if (!in.empty() && concat_batches(tc, in, &b) && b.base_rows > 0) {
+      std::vector<ArrayRef> keys; std::vector<const dfgpu_array*> kp;
+      for (auto& e : exprs) { keys.push_back(into_array(tc, e->eval(tc, b), b.base_rows)); kp.push_back(keys.back().a); }
+      dfgpu_array* idx = nullptr; tc.check(dfgpu_sort_to_indices(tc.ctx, kp.data(), desc.data(), nulls_first.data(), (int32_t)kp.size(), fetch, &idx)); ArrayRef ix = ArrayRef::adopt(idx);
+      Batch o; o.schema = b.schema; o.base_rows = ix.len();
+      for (auto& c : b.cols) o.cols.push_back(col_take(tc, c, ix));
+      outv.push_back(std::move(o));
+    }
+    return std::unique_ptr<Stream>(new VecStream(std::move(outv)));
+  }
+};
+
 }  // namespace dfx
 
 // ==================================================================== C ABI
@@ -709,6 +740,13 @@ dfgpu_status dfgpu_plan_sort(const dfgpu_expr* const* exprs, const uint8_t* desc
   return guard([&] {
     if (n < 1) fail(DFGPU_INVALID_ARGUMENT, "Sort requires at least one column");
     auto s = std::make_shared<SortExec>(); s->input = pl(input); s->fetch = fetch; s->preserve = preserve != 0;
+    for (int i = 0; i < n; i++) { s->exprs.push_back(ex(exprs[i])); s->desc.push_back(desc ? desc[i] : 0); s->nulls_first.push_back(nf ? nf[i] : 1); }
+    *out = new dfgpu_plan{s};
+  });
+}
+dfgpu_status dfgpu_plan_sort_preserving_merge(const dfgpu_expr* const* exprs, const uint8_t* desc, const uint8_t* nf, int32_t n, int64_t fetch, const dfgpu_plan* input, dfgpu_plan** out) {
+  return guard([&] {
+    auto s = std::make_shared<SortPreservingMergeExec>(); s->input = pl(input); s->fetch = fetch;
     for (int i = 0; i < n; i++) { s->exprs.push_back(ex(exprs[i])); s->desc.push_back(desc ? desc[i] : 0); s->nulls_first.push_back(nf ? nf[i] : 1); }
     *out = new dfgpu_plan{s};
   });

@@ -216,10 +216,11 @@ __global__ void __launch_bounds__(BLOCK) k_key_setbits(const T* keys, const uint
 }
 // ---- rank index: the build keys are strictly increasing, so the membership bitmap alone locates the build row
 template <typename T>
-__global__ void __launch_bounds__(BLOCK) k_check_increasing(const T* keys, int64_t n, unsigned long long* flag) {
+__global__ void __launch_bounds__(BLOCK) k_check_increasing(const T* keys, int64_t n, unsigned long long* out /* [0] flag, [1] first key, [2] last key */) {
   bool bad = false;
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x + 1; i < n; i += (int64_t)gridDim.x * BLOCK) bad |= !(keys[i - 1] < keys[i]);
-  if (ballot64(bad) && lane_id() == 0) *flag = 1ull;
+  if (ballot64(bad) && lane_id() == 0) out[0] = 1ull;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { out[1] = (unsigned long long)(long long)keys[0]; out[2] = (unsigned long long)(long long)keys[n - 1]; }   // one read-back for all three
 }
 // set the bit of every selected row's key.  Equal bitmap words of neighbouring lanes are OR-combined first (segmented
 // scan over runs of the same word; sorted keys put 16+ lanes on one word) so one atomic per run reaches L2.
@@ -355,21 +356,16 @@ static bool build_rank_index(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   if (!ctx->join_rank_index || ctx->force_hash_collisions || n < 2 || t->nkeys != 1 || t->null_equals_null) return false;
   const dfgpu_array* key0 = t->keys[0];
   if (key0->type == DFGPU_DICTIONARY || !int_key_type(key0->type) || key0->validity) return false;
-  const void* kv = key0->values->ptr; int w = type_width(key0->type);
+  const void* kv = key0->values->ptr;
   KernelTimer kt_(ctx, "join_build_rank");
   zero_scratch(ctx);
   DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_check_increasing<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 8)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, n, (unsigned long long*)ctx->d_scratch64));
   KERNEL_CHECK();
-  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 0, ctx->d_scratch64, 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 4, kv, w, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 5, (const char*)kv + (size_t)(n - 1) * w, w, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 0, ctx->d_scratch64, 24, hipMemcpyDeviceToHost, ctx->stream));
+  ctx->count_sync("sync:rank_index_check");
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (ctx->h_pinned[0] != 0) return false;
-  auto widen = [&](uint64_t raw) -> long long {
-    switch (key0->type) {
-      case DFGPU_INT8: return (int8_t)raw; case DFGPU_INT16: return (int16_t)raw; case DFGPU_INT32: case DFGPU_DATE32: return (int32_t)raw;
-      case DFGPU_UINT8: return (uint8_t)raw; case DFGPU_UINT16: return (uint16_t)raw; case DFGPU_UINT32: return (uint32_t)raw; default: return (long long)raw; } };
-  long long lo = widen(ctx->h_pinned[4]), hi = widen(ctx->h_pinned[5]);
+  long long lo = (long long)ctx->h_pinned[1], hi = (long long)ctx->h_pinned[2];       // sign/zero-extended by the kernel
   uint64_t range = (uint64_t)hi - (uint64_t)lo + 1;
   if (range == 0 || range > (1ull << 32) || range > (uint64_t)n * 4096 + 65536) return false;
   const uint64_t* mk = t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr;

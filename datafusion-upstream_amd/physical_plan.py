@@ -569,6 +569,27 @@ class SortExec(ExecutionPlan):
         return self._new(out)
 
 
+class SortPreservingMergeExec(ExecutionPlan):
+    """≙ SortPreservingMergeExec::new(expr, input).with_fetch(fetch) (sorts/sort_preserving_merge.rs:67-120)."""
+
+    def __init__(self, expr: List[PhysicalSortExpr], input, fetch: Optional[int] = None):
+        self.expr, self.input, self.fetch = expr, input, fetch
+
+    def children(self):
+        return [self.input]
+
+    def output_partitioning(self):
+        return Partitioning.UnknownPartitioning(1)
+
+    def _build(self, context):
+        ctx = context.ctx
+        out = C.c_void_p()
+        _check(_lib().dfgpu_plan_sort_preserving_merge(_ptrs([s.expr.handle(ctx).h for s in self.expr]), bytes(int(s.descending) for s in self.expr),
+                                                       bytes(int(s.nulls_first) for s in self.expr), len(self.expr), -1 if self.fetch is None else int(self.fetch),
+                                                       _child_handle(self.input, context).h, C.byref(out)))
+        return self._new(out)
+
+
 def concat_batches(schema: Schema, batches: Sequence[RecordBatch]) -> Optional[RecordBatch]:
     batches = [b for b in batches if b.num_rows > 0] or list(batches[:1])
     if not batches:

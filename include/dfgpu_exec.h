@@ -72,6 +72,11 @@ DFGPU_API dfgpu_status dfgpu_plan_aggregate(int32_t mode, const dfgpu_expr *cons
 /* SortExec::new(expr, input).with_fetch(fetch).with_preserve_partitioning(..); fetch < 0 = none */
 DFGPU_API dfgpu_status dfgpu_plan_sort(const dfgpu_expr *const *exprs, const uint8_t *descending, const uint8_t *nulls_first, int32_t n, int64_t fetch,
                                        int32_t preserve_partitioning, const dfgpu_plan *input, dfgpu_plan **out);
+/* SortPreservingMergeExec::new(expr, input).with_fetch(fetch) (sorts/sort_preserving_merge.rs:67-120): merges the input's sorted
+ * partitions into one sorted partition; equal keys keep partition order (lower partition first); one input partition is passed
+ * through; fetch < 0 = none.  The inputs must already be sorted on `exprs`. */
+DFGPU_API dfgpu_status dfgpu_plan_sort_preserving_merge(const dfgpu_expr *const *exprs, const uint8_t *descending, const uint8_t *nulls_first, int32_t n, int64_t fetch,
+                                                        const dfgpu_plan *input, dfgpu_plan **out);
 DFGPU_API void dfgpu_plan_free(dfgpu_plan *p);
 /* ExecutionPlan::with_new_children(self, same children, recursively) (physical-plan/src/lib.rs:198-201): a copy of the plan tree
  * without run-once state -- HashJoinExec's OnceAsync build side (joins/utils.rs:736-776; with_new_children hash_join.rs:559),

@@ -166,3 +166,53 @@ def test_with_fresh_state_reexecutes_from_scratch(ctx, task_ctx):
     assert len(first[0]) > 0
     for _ in range(3):
         assert rows(ops.with_fresh_state(plan)) == first
+
+
+# SortPreservingMergeExec known answers transcribed from physical-plan/src/sorts/sort_preserving_merge.rs `mod tests`
+# (sort key (b, c), default SortOptions; the TimestampNanosecond column c is carried as its Int64 payload):
+SPM_B1 = {"a": [1, 2, 7, 9, 3], "c": [8, 7, 6, 5, 8]}
+SPM_CASES = [
+    ("test_merge_interleave :283-328", dict(SPM_B1, b=["a", "c", "e", "g", "j"]), {"a": [10, 20, 70, 90, 30], "b": ["b", "d", "f", "h", "j"], "c": [4, 6, 2, 2, 6]},
+     [(1, "a", 8), (10, "b", 4), (2, "c", 7), (20, "d", 6), (7, "e", 6), (70, "f", 2), (9, "g", 5), (90, "h", 2), (30, "j", 6), (3, "j", 8)]),
+    ("test_merge_some_overlap :350-395", dict(SPM_B1, b=["a", "b", "c", "d", "e"]), {"a": [70, 90, 30, 100, 110], "b": ["c", "d", "e", "f", "g"], "c": [4, 6, 2, 2, 6]},
+     [(1, "a", 8), (2, "b", 7), (70, "c", 4), (7, "c", 6), (9, "d", 5), (90, "d", 6), (30, "e", 2), (3, "e", 8), (100, "f", 2), (110, "g", 6)]),
+    ("test_merge_no_overlap :398-443", dict(SPM_B1, b=["a", "b", "c", "d", "e"]), {"a": [10, 20, 70, 90, 30], "b": ["f", "g", "h", "i", "j"], "c": [4, 6, 2, 2, 6]},
+     [(1, "a", 8), (2, "b", 7), (7, "c", 6), (9, "d", 5), (3, "e", 8), (10, "f", 4), (20, "g", 6), (70, "h", 2), (90, "i", 2), (30, "j", 6)]),
+]
+
+
+def _spm_table(d):
+    return pa.table({"a": pa.array(d["a"], type=pa.int32()), "b": pa.array(d["b"], type=pa.utf8()), "c": pa.array(d["c"], type=pa.int64())})
+
+
+@pytest.mark.parametrize("ref,b1,b2,expected", SPM_CASES, ids=[c[0].split()[0] for c in SPM_CASES])
+def test_sort_preserving_merge_reference_known_answers(ctx, task_ctx, ref, b1, b2, expected):
+    from dfgpu import physical_plan as ops
+    bs = [ops.batch_from_arrow(ctx, _spm_table(b)) for b in (b1, b2)]
+    src = ops.MemoryExec([[bs[0]], [bs[1]]], bs[0].schema)
+    keys = [ops.PhysicalSortExpr(ops.Column("b", 1), False, True), ops.PhysicalSortExpr(ops.Column("c", 2), False, True)]
+    merge = ops.SortPreservingMergeExec(keys, src)
+    assert merge.output_partitioning().partition_count() == 1
+    out = ops.collect(merge, task_ctx)
+    got = [r for b in out for r in zip(*[c.to_arrow().to_pylist() for c in b.columns])]
+    assert got == expected, ref
+
+
+def test_sort_preserving_merge_is_stable_across_partitions_and_applies_fetch(ctx, task_ctx):
+    """test_stable_sort (sort_preserving_merge.rs:947-1020): 10 partitions of (batch_number, ["A", "B"]) merged on `value` only
+    come out in partition order within equal values; with_fetch keeps the first rows of that order; one input partition is
+    passed through; no sort expressions is the reference's Internal error."""
+    import dfgpu
+    from dfgpu import physical_plan as ops
+    parts = [[ops.batch_from_arrow(ctx, pa.table({"batch_number": pa.array([i, i], type=pa.int32()), "value": pa.array(["A", "B"])}))] for i in range(10)]
+    src = ops.MemoryExec(parts, parts[0][0].schema)
+    key = [ops.PhysicalSortExpr(ops.Column("value", 1), False, True)]
+    rows = lambda plan: [r for b in ops.collect(plan, task_ctx) for r in zip(*[c.to_arrow().to_pylist() for c in b.columns])]
+    want = [(i, "A") for i in range(10)] + [(i, "B") for i in range(10)]
+    assert rows(ops.SortPreservingMergeExec(key, src)) == want
+    assert rows(ops.SortPreservingMergeExec(key, src, fetch=13)) == want[:13]
+    single = ops.MemoryExec([parts[3]], parts[0][0].schema)
+    assert rows(ops.SortPreservingMergeExec(key, single)) == [(3, "A"), (3, "B")]
+    with pytest.raises(dfgpu.DfgpuError) as e:
+        rows(ops.SortPreservingMergeExec([], src))
+    assert "Sort expressions cannot be empty for streaming merge" in str(e.value)
