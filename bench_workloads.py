@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench_workloads.py -- the other target plan shapes of SURVEY.md section 8(d), measured like bench.py measures Q3: synthetic
+TPC-H-shaped columns resident in HBM, one step = one pass of the reference's physical plan through the dfgpu operator layer,
+rows/s = input rows / wall time; per-kernel device time from one fully bracketed step.  One JSON line per workload.
+
+  q1_decimal   tpch/q1.slt.part: Filter l_shipdate <= d -> Projection (disc_price once) -> Aggregate (2 dictionary keys, 4 groups)
+               4 SUM + 3 AVG + COUNT(*) over Decimal128(15,2) money -> Sort          [algorithmic bytes 70 B/row]
+  q1_float64   the same with Float64 money columns ("fp64 accumulators")                  [38 B/row]
+  q18_groups   the Q18 subquery: GROUP BY l_orderkey (one Int64 key, 1/4 rows distinct) SUM(l_quantity) -> Filter SUM > 300
+               (GroupValuesPrimitive at 150 M groups for SF100)                            [24 B/row]
+  clickbench   ClickBench Q28 shape: filter key <> '' -> GROUP BY a dictionary-encoded Utf8 key -> AVG(Int32 as f64), COUNT(*),
+               MAX(Int64) -> HAVING -> ORDER BY avg DESC LIMIT 25; uniform and Zipf(1.1) keys  [code 4 + 4 + 8 B/row]
+This is NOT the driver's bench contract (bench.py is); it exists so that DESIGN.md can quote measured numbers for these shapes.
+"""
+import argparse
+import decimal
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0
+
+
+def dec_tensor(torch, n, lo, hi, g):
+    v = torch.zeros((n, 2), dtype=torch.int64, device="cuda")
+    v[:, 0] = torch.randint(lo, hi, (n,), generator=g, device="cuda", dtype=torch.int64)
+    return v
+
+
+def wrap_dict(ctx, capi, keys, dictionary, key_type):
+    import ctypes as C
+    d = capi.ArrayDesc()
+    dd = dictionary.describe()
+    d.type, d.key_type, d.length, d.null_count = capi.DICTIONARY, key_type, keys.numel(), 0
+    d.values = keys.data_ptr()
+    d.dictionary = C.pointer(dd)
+    return ctx.wrap_device(d, keepalive=(keys, dictionary, dd))
+
+
+def time_plan(ctx, ops, tc, template, steps, warmup):
+    def step():
+        out = [b for b in ops.with_fresh_state(template).execute(0, tc)]
+        ctx.synchronize()
+        return sum(b.num_rows for b in out)
+    breakdown = None
+    for w in range(max(warmup, 1)):
+        if w == max(warmup, 1) - 1:
+            ctx.profile_select(None); ctx.profile_enable(True); ctx.profile_read()
+            rows = step()
+            breakdown = ctx.profile_read(); ctx.profile_enable(False)
+        else:
+            step()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rows = step()
+    dt = (time.perf_counter() - t0) / steps
+    kern = {k: round(v[1], 3) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][1]) if not k.startswith("sync:")}
+    syncs = sum(v[0] for k, v in breakdown.items() if k.startswith("sync:"))
+    return dt, rows, kern, syncs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sf", type=float, default=100.0)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    import pyarrow as pa
+    import torch
+    import dfgpu
+    from dfgpu import capi, physical_plan as ops
+    torch.cuda.set_device(0)
+    ctx = dfgpu.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    tc = ops.TaskContext(ctx, batch_size=8192)
+    C, L, B, F = ops.Column, ops.Literal, ops.BinaryExpr, ops.Field
+    g = torch.Generator(device="cuda"); g.manual_seed(20241024)
+    n_orders = int(1_500_000 * args.sf)
+    want = set(args.only.split(",")) if args.only else None
+    lines = torch.randint(1, 8, (n_orders,), generator=g, device="cuda", dtype=torch.int64)
+    i = torch.arange(n_orders, dtype=torch.int64, device="cuda")
+    l_orderkey = torch.repeat_interleave((i // 8) * 32 + (i % 8) + 1, lines)
+    n = l_orderkey.numel()
+    del lines, i
+    out = []
+
+    def report(name, dt, rows_in, rows_out, bytes_per_row, kern, syncs, extra=None):
+        line = {"workload": name, "sf": args.sf, "input_rows": rows_in, "result_rows": rows_out, "ms_per_step": round(dt * 1e3, 3), "rows_per_s": round(rows_in / dt, 1),
+                "algorithmic_GBps": round(bytes_per_row * rows_in / dt / 1e9, 1), "frac_of_hbm_peak": round(bytes_per_row * rows_in / dt / 1e9 / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_row": bytes_per_row, "kernel_ms_per_step": kern, "host_syncs_per_step": syncs}
+        if extra:
+            line.update(extra)
+        print(json.dumps(line), flush=True)
+        out.append(line)
+
+    # ------------------------------------------------------------------ Q1
+    for money in ("decimal", "float64"):
+        name = "q1_" + money
+        if want and name not in want:
+            continue
+        if money == "decimal":
+            cols = {k: dec_tensor(torch, n, lo, hi, g) for k, lo, hi in (("l_quantity", 100, 5001), ("l_extendedprice", 90000, 10494951), ("l_discount", 0, 11), ("l_tax", 0, 9))}
+            wrap = lambda t: ctx.wrap_tensor(t, capi.DECIMAL128, 15, 2)
+            one = L(decimal.Decimal(1), pa.decimal128(20, 0))
+            m = lambda p, s: F("x", capi.DECIMAL128, p, s)
+            bpr = 16 * 4 + 1 + 1 + 4
+        else:
+            cols = {k: torch.randint(lo, hi, (n,), generator=g, device="cuda", dtype=torch.int64).to(torch.float64) / 100.0
+                    for k, lo, hi in (("l_quantity", 100, 5001), ("l_extendedprice", 90000, 10494951), ("l_discount", 0, 11), ("l_tax", 0, 9))}
+            wrap = lambda t: ctx.wrap_tensor(t, capi.FLOAT64)
+            one = L(1.0, pa.float64())
+            m = lambda p, s: F("x", capi.FLOAT64)
+            bpr = 8 * 4 + 1 + 1 + 4
+        rf = torch.randint(0, 3, (n,), generator=g, device="cuda", dtype=torch.int8)
+        ls = torch.randint(0, 2, (n,), generator=g, device="cuda", dtype=torch.int8)
+        shipdate = torch.randint(8035, 10560, (n,), generator=g, device="cuda", dtype=torch.int32)
+        torch.cuda.synchronize()
+        rfd, lsd = ctx.from_arrow(pa.array(["A", "N", "R"])), ctx.from_arrow(pa.array(["F", "O"]))
+        names = ["l_quantity", "l_extendedprice", "l_discount", "l_tax", "l_returnflag", "l_linestatus", "l_shipdate"]
+        arrays = [wrap(cols[k]) for k in names[:4]] + [wrap_dict(ctx, capi, rf, rfd, capi.INT8), wrap_dict(ctx, capi, ls, lsd, capi.INT8), ctx.wrap_tensor(shipdate, capi.DATE32)]
+        batch = ops.RecordBatch.from_arrays(ctx, names, arrays)
+        src = ops.MemoryExec([[batch]], batch.schema)
+        f = ops.CoalesceBatchesExec(ops.FilterExec(B(C("l_shipdate", 6), "<=", L(10471, pa.date32())), src), 8192)
+        proj = ops.ProjectionExec([(B(C("l_extendedprice", 1), "*", B(one, "-", C("l_discount", 2))), "disc_price"), (C("l_quantity", 0), "l_quantity"), (C("l_extendedprice", 1), "l_extendedprice"),
+                                   (C("l_discount", 2), "l_discount"), (C("l_tax", 3), "l_tax"), (C("l_returnflag", 4), "l_returnflag"), (C("l_linestatus", 5), "l_linestatus")], f)
+        charge = B(C("disc_price", 0), "*", B(one, "+", C("l_tax", 4)))
+        aggs = [ops.AggregateFunctionExpr("SUM", C("l_quantity", 1), "sum_qty", input_field=m(15, 2)), ops.AggregateFunctionExpr("SUM", C("l_extendedprice", 2), "sum_base_price", input_field=m(15, 2)),
+                ops.AggregateFunctionExpr("SUM", C("disc_price", 0), "sum_disc_price", input_field=m(38, 4)), ops.AggregateFunctionExpr("SUM", charge, "sum_charge", input_field=m(38, 6)),
+                ops.AggregateFunctionExpr("AVG", C("l_quantity", 1), "avg_qty", input_field=m(15, 2)), ops.AggregateFunctionExpr("AVG", C("l_extendedprice", 2), "avg_price", input_field=m(15, 2)),
+                ops.AggregateFunctionExpr("AVG", C("l_discount", 3), "avg_disc", input_field=m(15, 2)), ops.AggregateFunctionExpr("COUNT", None, "count_order")]
+        agg = ops.AggregateExec("Single", [(C("l_returnflag", 5), "l_returnflag"), (C("l_linestatus", 6), "l_linestatus")], aggs, proj)
+        plan = ops.SortExec([ops.PhysicalSortExpr(C("l_returnflag", 0), False, False), ops.PhysicalSortExpr(C("l_linestatus", 1), False, False)], agg)
+        dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan, args.steps, args.warmup)
+        report(name, dt, n, rows, bpr, kern, syncs)
+        del cols, rf, ls, shipdate, arrays, batch, src, plan
+        torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ Q18 subquery: 1 Int64 key, n/4 groups
+    if not want or "q18_groups" in want:
+        qty = dec_tensor(torch, n, 100, 5001, g)
+        torch.cuda.synchronize()
+        batch = ops.RecordBatch.from_arrays(ctx, ["l_orderkey", "l_quantity"], [ctx.wrap_tensor(l_orderkey, capi.INT64), ctx.wrap_tensor(qty, capi.DECIMAL128, 15, 2)])
+        src = ops.MemoryExec([[batch]], batch.schema)
+        sub = ops.AggregateExec("Single", [(C("l_orderkey", 0), "l_orderkey")], [ops.AggregateFunctionExpr("SUM", C("l_quantity", 1), "SUM(l_quantity)", input_field=F("q", capi.DECIMAL128, 15, 2))], src)
+        plan = ops.CoalesceBatchesExec(ops.FilterExec(B(C("SUM(l_quantity)", 1), ">", L(decimal.Decimal(300), pa.decimal128(25, 2))), sub), 8192)
+        dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan, args.steps, args.warmup)
+        report("q18_groups", dt, n, rows, 8 + 16, kern, syncs, {"groups": n_orders})
+        del qty, batch, src, plan
+        torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ ClickBench-style string-key group-by (100 M rows at sf 100)
+    nrows = int(1_000_000 * args.sf)
+    for card, zipf in ((1000, False), (1_000_000, False), (20_000_000, False), (1_000_000, True)):
+        card = max(10, int(card * min(1.0, args.sf / 100.0)) if card > 1000 else card)
+        name = f"clickbench_{'zipf' if zipf else 'uniform'}_{card}"
+        if want and not any(w in name for w in want):
+            continue
+        import numpy as np
+        rng = np.random.default_rng(7)
+        if zipf:
+            ids = torch.from_numpy((rng.zipf(1.1, nrows) % card).astype(np.int32)).cuda()
+        else:
+            ids = torch.randint(0, card, (nrows,), generator=g, device="cuda", dtype=torch.int32)
+        # dictionary values: URL-like strings of 20-40 bytes, entry 0 is the empty string (filtered out)
+        words = pa.array([""] + [f"https://site{k}.example/{k * 7919 % 1000}" for k in range(1, card)], type=pa.utf8())
+        dictionary = ctx.from_arrow(words)
+        length = torch.randint(0, 500, (nrows,), generator=g, device="cuda", dtype=torch.int32)
+        w = torch.randint(0, 10**6, (nrows,), generator=g, device="cuda", dtype=torch.int64)
+        torch.cuda.synchronize()
+        batch = ops.RecordBatch.from_arrays(ctx, ["key", "len", "w"], [wrap_dict(ctx, capi, ids, dictionary, capi.INT32), ctx.wrap_tensor(length, capi.INT32), ctx.wrap_tensor(w, capi.INT64)])
+        src = ops.MemoryExec([[batch]], batch.schema)
+        f = ops.CoalesceBatchesExec(ops.FilterExec(B(C("key", 0), "!=", L("", pa.utf8())), src), 8192)
+        proj = ops.ProjectionExec([(C("key", 0), "key"), (ops.CastExpr(C("len", 1), capi.FLOAT64), "lenf"), (C("w", 2), "w")], f)
+        aggs = [ops.AggregateFunctionExpr("AVG", C("lenf", 1), "l", input_field=F("x", capi.FLOAT64)), ops.AggregateFunctionExpr("COUNT", None, "c"),
+                ops.AggregateFunctionExpr("MAX", C("w", 2), "m", input_field=F("x", capi.INT64))]
+        agg = ops.AggregateExec("Single", [(C("key", 0), "k")], aggs, proj)
+        having = ops.FilterExec(B(C("c", 2), ">", L(3, pa.int64())), agg)
+        plan = ops.SortExec([ops.PhysicalSortExpr(C("l", 1), True, True), ops.PhysicalSortExpr(C("k", 0), False, False)], having, fetch=25)
+        dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan, args.steps, args.warmup)
+        report(name, dt, nrows, rows, 4 + 4 + 8, kern, syncs, {"cardinality": card})
+        del ids, length, w, batch, src, plan, dictionary
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -149,6 +149,71 @@ __global__ void __launch_bounds__(BLOCK) k_acc_small(int kind, ColView v, int ha
   }
 }
 
+// ------------------------------------------------------------ repeated groups: per-workgroup LDS cache in front of the global atomics
+// Atomics on one address serialise in L2 (~2 ns each): 10 M rows of a Zipf(1.1) key spent 36 ms in k_acc_update, 1000 uniform
+// groups 4 ms.  Each workgroup therefore keeps a 1024-entry, 2-probe cache (group id tag, partial value, row count) in LDS:
+// the first groups a workgroup meets claim entries and accumulate with LDS atomics; a group that finds both probes taken
+// falls through to the global atomic.  Hot groups are met first with overwhelming probability, so their traffic stays in
+// LDS and reaches HBM as one atomic per (workgroup, group) at the end.  Chosen by launch_update when the batch has >= 8 rows
+// per known group on average (uniform high-cardinality batches keep the direct path).
+constexpr int ACC_CACHE = 1024;
+constexpr uint32_t TAG_EMPTY = 0xFFFFFFFFu;
+enum { OP_ADD = 0, OP_MIN = 1, OP_MAX = 2 };
+
+template <typename T, int OP> __device__ inline T op_identity() {
+  if constexpr (OP == OP_ADD) return (T)0;
+  else if constexpr (std::is_same<T, double>::value) return OP == OP_MIN ? __longlong_as_double(0x7FF0000000000000ll) : __longlong_as_double((long long)0xFFF0000000000000ull);
+  else if constexpr (std::is_same<T, long long>::value) return OP == OP_MIN ? INT64_MAX : INT64_MIN;
+  else return OP == OP_MIN ? (T)~0ull : (T)0;
+}
+template <typename T, int OP> __device__ inline void lds_apply(T* p, T x) {
+  if constexpr (std::is_same<T, i128>::value) {        // OP_ADD only: two 64-bit adds with carry, as in HBM
+    uint64_t* q = (uint64_t*)p; uint64_t lo = (uint64_t)(u128)x, hi = (uint64_t)((u128)x >> 64);
+    uint64_t old = atomicAdd((unsigned long long*)&q[0], (unsigned long long)lo); uint64_t carry = (uint64_t)(old + lo < old);
+    if (hi + carry) atomicAdd((unsigned long long*)&q[1], (unsigned long long)(hi + carry));
+  } else if constexpr (OP == OP_ADD) {
+    if constexpr (std::is_same<T, double>::value) unsafeAtomicAdd(p, x); else atomicAdd((unsigned long long*)p, (unsigned long long)x);
+  } else if constexpr (std::is_same<T, double>::value) atomic_min_f64(p, x, OP == OP_MIN);
+  else { if (OP == OP_MIN) atomicMin(p, x); else atomicMax(p, x); }
+}
+template <typename T, int CLS, int OP> __device__ inline void global_apply(int kind, uint32_t g, T x, uint64_t c, void* vals, uint64_t* counts, uint8_t* seen) {
+  if (kind == DFGPU_AGG_COUNT) { atomicAdd((unsigned long long*)&counts[g], (unsigned long long)c); return; }
+  seen[g] = 1;
+  if (kind == DFGPU_AGG_AVG) atomicAdd((unsigned long long*)&counts[g], (unsigned long long)c);
+  if constexpr (CLS == CLS_I128) atomic_add_i128((uint64_t*)vals + 2 * (int64_t)g, x);
+  else if constexpr (OP == OP_ADD) { if constexpr (CLS == CLS_F64) unsafeAtomicAdd((double*)vals + g, x); else atomicAdd((unsigned long long*)vals + g, (unsigned long long)x); }
+  else if constexpr (CLS == CLS_F64) atomic_min_f64((double*)vals + g, x, OP == OP_MIN);
+  else { if (OP == OP_MIN) atomicMin((T*)vals + g, x); else atomicMax((T*)vals + g, x); }
+}
+template <typename T, int CLS, int OP>
+__global__ void __launch_bounds__(BLOCK) k_acc_cached(int kind, ColView v, int has_values, const uint32_t* gids, const uint64_t* fbits, const uint64_t* fvalid,
+                                                      int64_t n, int64_t total, void* vals, uint64_t* counts, uint8_t* seen, int count_only_valid, uint32_t* flags) {
+  __shared__ uint32_t s_tag[ACC_CACHE]; __shared__ uint32_t s_cnt[ACC_CACHE]; __shared__ T s_val[ACC_CACHE];
+  for (int s = threadIdx.x; s < ACC_CACHE; s += BLOCK) { s_tag[s] = TAG_EMPTY; s_cnt[s] = 0; s_val[s] = op_identity<T, OP>(); }
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    uint32_t g = gids[i];
+    if (g == GID_NONE || !filter_pass(fbits, fvalid, i)) continue;
+    if ((int64_t)g >= total) { atomicOr(flags, DFGPU_FLAG_OOB); continue; }
+    int64_t r = i; bool ok = !has_values || cell_resolve(v, i, &r);
+    if (kind == DFGPU_AGG_COUNT) { if (!(ok || !count_only_valid)) continue; }
+    else if (!ok) continue;
+    T x = op_identity<T, OP>();
+    if (kind != DFGPU_AGG_COUNT) { if constexpr (CLS == CLS_F64) x = acc_cell_f64(v, r); else x = (T)acc_cell_int(v, r); }
+    uint32_t h = (g * 0x9E3779B1u) >> 22; int slot = -1;
+#pragma unroll
+    for (int p = 0; p < 2 && slot < 0; p++) {
+      int s = (int)((h + p) & (ACC_CACHE - 1)); uint32_t t = s_tag[s];
+      if (t == TAG_EMPTY) { t = atomicCAS(&s_tag[s], TAG_EMPTY, g); if (t == TAG_EMPTY) t = g; }
+      if (t == g) slot = s;
+    }
+    if (slot >= 0) { if (kind != DFGPU_AGG_COUNT) lds_apply<T, OP>(&s_val[slot], x); atomicAdd(&s_cnt[slot], 1u); }
+    else global_apply<T, CLS, OP>(kind, g, x, 1, vals, counts, seen);
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < ACC_CACHE; s += BLOCK) { uint32_t g = s_tag[s], c = s_cnt[s]; if (g != TAG_EMPTY && c) global_apply<T, CLS, OP>(kind, g, s_val[s], c, vals, counts, seen); }
+}
+
 // ------------------------------------------------------------ emit
 __global__ void __launch_bounds__(BLOCK) k_seen_to_bits(const uint8_t* seen, int64_t n, uint64_t* bits) {
   int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -234,6 +299,13 @@ static void launch_update(dfgpu_acc* a, int kind, int cls, const dfgpu_array* va
 #define SMALL(T, C) hipLaunchKernelGGL((k_acc_small<T, C>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, kind, v, values ? 1 : 0, g, fb, fv, n, (int)total, vals, (uint64_t*)a->counts->ptr, (uint8_t*)a->seen->ptr, 1)
     if (cls == CLS_F64) SMALL(double, CLS_F64); else if (cls == CLS_I128) SMALL(i128, CLS_I128); else SMALL(uint64_t, CLS_U64);
 #undef SMALL
+  } else if (n >= 8 * total && !(cls == CLS_I128 && !sumlike)) {
+    int cblocks = grid_for(n, BLOCK * 32, ctx->num_cus * 4);         // >= 8192 rows per workgroup amortise the cache flush
+#define CACHED(T, C, O) hipLaunchKernelGGL((k_acc_cached<T, C, O>), dim3(cblocks), dim3(BLOCK), 0, ctx->stream, kind, v, values ? 1 : 0, g, fb, fv, n, total, vals, (uint64_t*)a->counts->ptr, (uint8_t*)a->seen->ptr, 1, ctx->d_flags)
+    if (sumlike) { if (cls == CLS_F64) CACHED(double, CLS_F64, OP_ADD); else if (cls == CLS_I128) CACHED(i128, CLS_I128, OP_ADD); else CACHED(unsigned long long, CLS_U64, OP_ADD); }
+    else if (kind == DFGPU_AGG_MIN) { if (cls == CLS_F64) CACHED(double, CLS_F64, OP_MIN); else if (cls == CLS_U64) CACHED(unsigned long long, CLS_U64, OP_MIN); else CACHED(long long, CLS_I64, OP_MIN); }
+    else { if (cls == CLS_F64) CACHED(double, CLS_F64, OP_MAX); else if (cls == CLS_U64) CACHED(unsigned long long, CLS_U64, OP_MAX); else CACHED(long long, CLS_I64, OP_MAX); }
+#undef CACHED
   } else {
     hipLaunchKernelGGL(k_acc_update, dim3(blocks), dim3(BLOCK), 0, ctx->stream, kind, cls, v, values ? 1 : 0, g, fb, fv, n, total, vals, (uint64_t*)a->counts->ptr, (uint8_t*)a->seen->ptr, 1, ctx->d_flags);
   }

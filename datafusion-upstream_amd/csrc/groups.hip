@@ -56,7 +56,12 @@ __global__ void __launch_bounds__(BLOCK) k_groups_find(KeySet bk, KeySet stored,
         uint32_t pl = (uint32_t)cur;
         if (pl & G_NEW) {
           int64_t rep = pl & ~G_NEW;
-          if (rep == i || keyset_equal(bk, i, bk, rep, true)) { atomicMin(&first_row[s], (uint32_t)i); res = G_NEW | (uint32_t)s; done = true; }
+          if (rep == i || keyset_equal(bk, i, bk, rep, true)) {
+            // first_row only ever decreases, so a (possibly stale) read that is already <= i proves the atomic a no-op: with few or
+            // skewed groups nearly every row skips it (60 M rows into 6 groups: 110 ms of serialised atomics -> 3 ms)
+            if (__hip_atomic_load(&first_row[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (uint32_t)i) atomicMin(&first_row[s], (uint32_t)i);
+            res = G_NEW | (uint32_t)s; done = true;
+          }
         } else if (has_stored && keyset_equal(bk, i, stored, (int64_t)pl, true)) { res = pl; done = true; }
       }
       s = (s + 1) & cap_mask;

@@ -74,7 +74,7 @@ AGG_CASES = [("SUM", "int64"), ("SUM", "int32"), ("SUM", "uint64"), ("SUM", "flo
 
 
 @pytest.mark.parametrize("fun,kind", AGG_CASES, ids=[f"{f}-{k}" for f, k in AGG_CASES])
-@pytest.mark.parametrize("ngroups", [4, 8, 9, 5000])
+@pytest.mark.parametrize("ngroups", [4, 8, 9, 300, 5000])
 def test_accumulators_update_evaluate_state_merge(ctx, fun, kind, ngroups):
     """Partial (update_batch over several batches, growing group count, opt_filter) -> state -> Final (merge_batch) -> evaluate."""
     import dfgpu
@@ -103,6 +103,26 @@ def test_accumulators_update_evaluate_state_merge(ctx, fun, kind, ngroups):
         ofin.merge_batch(ost, perm, None, total)
     check_equal(fin.evaluate().to_arrow(), ofin.evaluate(), floats)
     assert acc.size() > 0
+
+
+@pytest.mark.parametrize("fun,kind", AGG_CASES, ids=[f"{f}-{k}" for f, k in AGG_CASES])
+def test_accumulators_skewed_groups_use_the_lds_cache(ctx, fun, kind):
+    """Heavy hitters + a long tail (Zipf(1.1) over 5000 groups, 300 K rows): more groups than the 1024-entry per-workgroup LDS cache
+    of k_acc_cached, so hot groups accumulate in LDS while the tail falls through to the global atomics -- same results as the
+    oracle's row-by-row loop (acc.hip k_acc_cached; prim_op.rs:101-109)."""
+    import dfgpu
+    n, ng = 300000, 5000
+    v = value_array(kind, n)
+    g = (RNG.zipf(1.1, n) % ng).astype(np.int64)
+    f = dfgpu.operators.field_of_array("v", ctx.from_arrow(v.slice(0, 10)))
+    acc, oacc = dfgpu.GroupsAccumulator(ctx, KIND[fun], f.dtype, f.precision, f.scale), po.Acc(fun, v.type)
+    filt = pa.array(RNG.random(n) < 0.9)
+    acc.update_batch(ctx.from_arrow(v), ctx.from_arrow(pa.array(g.astype(np.uint32))), ctx.from_arrow(filt), ng)
+    oacc.update_batch(v, g, filt, ng)
+    floats = kind.startswith("float") and fun in ("SUM", "AVG")
+    for a, b in zip(acc.state(), oacc.state()):
+        check_equal(a.to_arrow(), b, floats)
+    check_equal(acc.evaluate().to_arrow(), oacc.evaluate(), floats)
 
 
 def test_count_star_and_resize_only_update(ctx):
