@@ -41,6 +41,7 @@ struct dfgpu_ctx {
   bool force_hash_collisions = false;
   bool first_seen_group_order = true;
   bool join_rank_index = true;
+  bool group_run_detection = true;
   // kernel error flags (overflow, divide by zero, cast range, index bounds): checked after the raising call, or -- inside one
   // poll of a plan's output stream -- once before the batch is handed out (saves a stream sync per kernel-level call)
   int defer_flag_checks = 0; bool flags_pending = false; std::string flags_what;

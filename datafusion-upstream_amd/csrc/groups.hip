@@ -26,6 +26,9 @@ struct dfgpu_groups {
   uint64_t capacity = 0;
   BufferPtr slots, first_row;          // u64[capacity], u32[capacity]
   BufferPtr ghash; int64_t ghash_cap = 0;   // u64 per group
+  // run mode: every batch so far arrived with its keys clustered (first key column non-decreasing, the other columns constant within
+  // equal first keys), so group ids are run numbers and no hash table exists yet; ghash is filled only if a later batch breaks the order
+  bool run_mode = false;
   ~dfgpu_groups() { for (auto* a : keys) if (a) dfgpu_array_release(a); }
 };
 
@@ -104,6 +107,47 @@ __global__ void __launch_bounds__(BLOCK) k_groups_rehash(const uint64_t* ghash, 
   }
 }
 
+// ---- clustered keys (≙ GroupOrdering::Full, aggregates/order/full.rs: input sorted on the group keys): groups are runs.
+// bad = the batch is not clustered; heads bit i = row i starts a new run.  `prev` (device, 1 value, may be null) is the
+// first-column key of the last group of earlier batches: the batch must start strictly above it.
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_run_heads(KeySet bk, int64_t n, const T* prev, uint64_t* heads, unsigned long long* bad) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  bool head = false, wrong = false;
+  if (i < n) {
+    const T* k0 = (const T*)bk.c[0].values;
+    if (i == 0) { head = true; wrong = prev != nullptr && !(prev[0] < k0[0]); }
+    else {
+      T a = k0[i - 1], b = k0[i];
+      if (b < a) wrong = true;
+      else if (a < b) head = true;
+      else for (int c = 1; c < bk.n && !wrong; c++) {          // equal first key: every other key column must repeat too (NULL == NULL)
+        int64_t ri, rj; bool va = cell_resolve(bk.c[c], i, &ri), vb = cell_resolve(bk.c[c], i - 1, &rj);
+        if (va != vb || (va && !cell_equal(bk.c[c], ri, bk.c[c], rj))) wrong = true;
+      }
+    }
+  }
+  uint64_t m = ballot64(head);
+  if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) heads[i >> 6] = m;
+  if (ballot64(wrong) && lane_id() == 0) *bad = 1ull;
+}
+__global__ void __launch_bounds__(BLOCK) k_popc_words_g(const uint64_t* words, int64_t nw, uint32_t* out) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < nw) out[i] = (uint32_t)__popcll(words[i]);
+}
+__global__ void __launch_bounds__(BLOCK) k_run_ids(const uint64_t* heads, const uint32_t* word_prefix, int64_t n, uint32_t base, uint32_t* out) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint64_t w = heads[i >> 6]; int b = (int)(i & 63);
+  out[i] = base + word_prefix[i >> 6] + (uint32_t)__popcll(w & ((b == 63) ? ~0ull : ((2ull << b) - 1ull))) - 1u;      // heads at or before i, minus one
+}
+__global__ void __launch_bounds__(BLOCK) k_groups_hash_stored(KeySet stored, int64_t n_groups, int force_zero, uint64_t* ghash) {
+  int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (g >= n_groups) return;
+  bool an; uint64_t h = keyset_hash(stored, g, GROUP_SEED, &an);
+  ghash[g] = force_zero ? 0 : h;
+}
+
 static void groups_alloc_table(dfgpu_groups* g, uint64_t cap) {
   dfgpu_ctx* ctx = g->ctx;
   g->capacity = cap;
@@ -133,6 +177,64 @@ int64_t dfgpu_groups_size(const dfgpu_groups* g) {
   return b;
 }
 
+// append the key values of the new groups (first-seen rows, in id order) to the stored key columns
+static void groups_append_keys(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_array* const* cols, int32_t nkeys, const dfgpu_array* firsts, int64_t n_new) {
+  for (int c = 0; c < nkeys; c++) {
+    ArrayHolder nk(take_impl(ctx, cols[c], firsts->values->ptr, 4, nullptr, n_new));
+    if (nk.get()->type == DFGPU_DICTIONARY) {       // store plain values (GroupValues emits the value type)
+      dfgpu_array* k = nk.get(); int kw = type_width(k->key_type);
+      if (kw != 4 && kw != 8) { dfgpu_array* wide = nullptr; ArrayHolder keys_only(new_array(ctx, k->key_type, k->length)); keys_only.get()->values = k->values; keys_only.get()->validity = k->validity; keys_only.get()->null_count = k->null_count;
+        dfgpu_status st = dfgpu_cast(ctx, keys_only.get(), DFGPU_INT64, 0, 0, &wide); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str());
+        ArrayHolder w(wide); ArrayHolder dec(take_impl(ctx, k->dictionary, w.get()->values->ptr, 8, w.get()->validity ? (const uint64_t*)w.get()->validity->ptr : nullptr, k->length)); dfgpu_array_release(nk.release()); nk.a = dec.release(); }
+      else { ArrayHolder dec(take_impl(ctx, k->dictionary, k->values->ptr, kw, k->validity ? (const uint64_t*)k->validity->ptr : nullptr, k->length)); dfgpu_array_release(nk.release()); nk.a = dec.release(); }
+    }
+    if (!g->keys[c]) g->keys[c] = nk.release();
+    else { const dfgpu_array* parts[2] = { g->keys[c], nk.get() }; dfgpu_array* cat = nullptr; dfgpu_status st = dfgpu_concat(ctx, parts, 2, &cat); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str());
+           dfgpu_array_release(g->keys[c]); g->keys[c] = cat; }
+  }
+}
+static void groups_reserve_ghash(dfgpu_ctx* ctx, dfgpu_groups* g, int64_t need, int64_t keep) {
+  if (need <= g->ghash_cap) return;
+  int64_t nc = g->ghash_cap ? g->ghash_cap : 1024; while (nc < need) nc *= 2;
+  BufferPtr nh = alloc_buffer(ctx, (size_t)nc * 8);
+  if (keep && g->ghash) HIP_CHECK(hipMemcpyAsync(nh->ptr, g->ghash->ptr, (size_t)keep * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  g->ghash = nh; g->ghash_cap = nc;
+}
+static bool run_key_type(const dfgpu_array* a) {
+  if (a->type == DFGPU_DICTIONARY || a->validity) return false;
+  switch (a->type) { case DFGPU_INT8: case DFGPU_INT16: case DFGPU_INT32: case DFGPU_INT64: case DFGPU_DATE32: case DFGPU_UINT8: case DFGPU_UINT16: case DFGPU_UINT32: case DFGPU_UINT64: return true; default: return false; }
+}
+// Clustered batch -> ids by run number.  Returns false (nothing changed) when the batch is not clustered.
+static bool groups_intern_runs(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_array* const* cols, int32_t nkeys, const KeySet& bk, int64_t n, dfgpu_array* ids) {
+  const dfgpu_array* k0 = cols[0];
+  if (g->n_groups && logical_type(k0) != g->keys[0]->type) return false;
+  KernelTimer kt_(ctx, "k_groups_runs");
+  BufferPtr heads = alloc_buffer(ctx, bitmap_bytes(n));
+  zero_scratch(ctx);
+  int w = type_width(k0->type);
+  const void* prev = g->n_groups ? (const void*)((const char*)g->keys[0]->values->ptr + (size_t)(g->n_groups - 1) * w) : nullptr;
+  dim3 grid(grid_for(n, BLOCK)), block(BLOCK);
+#define RUNS(T) hipLaunchKernelGGL((k_run_heads<T>), grid, block, 0, ctx->stream, bk, n, (const T*)prev, (uint64_t*)heads->ptr, (unsigned long long*)(ctx->d_scratch64 + 2))
+  switch (k0->type) {
+    case DFGPU_INT8: RUNS(int8_t); break; case DFGPU_INT16: RUNS(int16_t); break; case DFGPU_INT32: case DFGPU_DATE32: RUNS(int32_t); break; case DFGPU_INT64: RUNS(int64_t); break;
+    case DFGPU_UINT8: RUNS(uint8_t); break; case DFGPU_UINT16: RUNS(uint16_t); break; case DFGPU_UINT32: RUNS(uint32_t); break; default: RUNS(uint64_t); break; }
+#undef RUNS
+  KERNEL_CHECK();
+  if (read_scratch(ctx, 2) != 0) return false;
+  ArrayHolder firsts(mask_to_indices_impl(ctx, (const uint64_t*)heads->ptr, n));
+  int64_t n_new = firsts.get()->length;
+  if (g->n_groups + n_new >= (int64_t)G_NEW) fail(DFGPU_RESOURCES_EXHAUSTED, "more than 2^31 groups");
+  int64_t nw = (n + 63) / 64;
+  BufferPtr prefix = alloc_buffer(ctx, (size_t)nw * 4);
+  hipLaunchKernelGGL(k_popc_words_g, dim3(grid_for(nw, BLOCK)), block, 0, ctx->stream, (const uint64_t*)heads->ptr, nw, (uint32_t*)prefix->ptr);
+  exclusive_scan_u32_inplace32(ctx, (uint32_t*)prefix->ptr, nw, nullptr);
+  hipLaunchKernelGGL(k_run_ids, grid, block, 0, ctx->stream, (const uint64_t*)heads->ptr, (const uint32_t*)prefix->ptr, n, (uint32_t)g->n_groups, (uint32_t*)ids->values->ptr);
+  KERNEL_CHECK();
+  if (n_new) groups_append_keys(ctx, g, cols, nkeys, firsts.get(), n_new);
+  g->n_groups += n_new; g->run_mode = true;
+  return true;
+}
+
 dfgpu_status dfgpu_groups_intern(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_array* const* cols, int32_t nkeys, const dfgpu_array* opt_mask, dfgpu_array** out_group_ids) {
   return guard(ctx, [&] {
     if (!g || !cols || !out_group_ids) fail(DFGPU_INVALID_ARGUMENT, "groups_intern: null argument");
@@ -141,11 +243,21 @@ dfgpu_status dfgpu_groups_intern(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_ar
     int64_t n = cols[0]->length;
     if (n >= (int64_t)G_NEW) fail(DFGPU_NOT_IMPLEMENTED, "intern batches above 2^31 rows; split the batch");
     for (int c = 0; c < nkeys; c++) if (g->keys[c] && logical_type(cols[c]) != g->keys[c]->type) fail(DFGPU_INVALID_ARGUMENT, "groups_intern: key %d changed type", c);
-    KeySet stored{}; int has_stored = 0;
-    if (g->n_groups) { std::vector<const dfgpu_array*> sk(g->keys.begin(), g->keys.end()); stored = make_keyset(sk.data(), nkeys); has_stored = 1; }
     BufferPtr mask = effective_mask(ctx, opt_mask, n);
     ArrayHolder ids(new_fixed(ctx, DFGPU_UINT32, n));
     if (n == 0) { *out_group_ids = ids.release(); return; }
+    // clustered keys: group ids are run numbers, no hash table (the shape of GROUP BY over a fact table stored in key order)
+    if (ctx->group_run_detection && !ctx->force_hash_collisions && !mask && g->capacity == 0 && (g->n_groups == 0 || g->run_mode) && run_key_type(cols[0]) &&
+        groups_intern_runs(ctx, g, cols, nkeys, bk, n, ids.get())) { *out_group_ids = ids.release(); return; }
+    if (g->run_mode) {          // a batch broke the order: hash the groups numbered so far, the table is built below
+      std::vector<const dfgpu_array*> sk(g->keys.begin(), g->keys.end()); KeySet stored_ks = make_keyset(sk.data(), nkeys);
+      groups_reserve_ghash(ctx, g, g->n_groups, 0);
+      hipLaunchKernelGGL(k_groups_hash_stored, dim3(grid_for(g->n_groups, BLOCK)), dim3(BLOCK), 0, ctx->stream, stored_ks, g->n_groups, ctx->force_hash_collisions ? 1 : 0, (uint64_t*)g->ghash->ptr);
+      KERNEL_CHECK();
+      g->run_mode = false;
+    }
+    KeySet stored{}; int has_stored = 0;
+    if (g->n_groups) { std::vector<const dfgpu_array*> sk(g->keys.begin(), g->keys.end()); stored = make_keyset(sk.data(), nkeys); has_stored = 1; }
     BufferPtr tmp = alloc_buffer(ctx, (size_t)n * 4);
     // optimistic table size (at most 2^23 slots up front); a batch that overfills it is redone on a table 8x larger
     uint64_t guess = (uint64_t)g->n_groups * 4 + 2 * (uint64_t)(n < (1 << 22) ? n : (1 << 22));
@@ -172,29 +284,11 @@ dfgpu_status dfgpu_groups_intern(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_ar
     n_new = firsts.get()->length;
     if (g->n_groups + n_new >= (int64_t)G_NEW) fail(DFGPU_RESOURCES_EXHAUSTED, "more than 2^31 groups");
     if (n_new) {
-      if (g->n_groups + n_new > g->ghash_cap) {
-        int64_t nc = g->ghash_cap ? g->ghash_cap : 1024; while (nc < g->n_groups + n_new) nc *= 2;
-        BufferPtr nh = alloc_buffer(ctx, (size_t)nc * 8);
-        if (g->n_groups) HIP_CHECK(hipMemcpyAsync(nh->ptr, g->ghash->ptr, (size_t)g->n_groups * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        g->ghash = nh; g->ghash_cap = nc;
-      }
+      groups_reserve_ghash(ctx, g, g->n_groups + n_new, g->n_groups);
       hipLaunchKernelGGL(k_groups_assign, dim3(grid_for(n_new, BLOCK)), dim3(BLOCK), 0, ctx->stream, bk, (const uint32_t*)firsts.get()->values->ptr, n_new, (const uint32_t*)tmp->ptr,
                          (uint64_t*)g->slots->ptr, (uint32_t*)g->first_row->ptr, (uint32_t)g->n_groups, ctx->force_hash_collisions ? 1 : 0, (uint64_t*)g->ghash->ptr);
       KERNEL_CHECK();
-      // append the key values of the new groups (first-seen rows, in id order) to the stored key columns
-      for (int c = 0; c < nkeys; c++) {
-        ArrayHolder nk(take_impl(ctx, cols[c], firsts.get()->values->ptr, 4, nullptr, n_new));
-        if (nk.get()->type == DFGPU_DICTIONARY) {       // store plain values (GroupValues emits the value type)
-          dfgpu_array* k = nk.get(); int kw = type_width(k->key_type);
-          if (kw != 4 && kw != 8) { dfgpu_array* wide = nullptr; ArrayHolder keys_only(new_array(ctx, k->key_type, k->length)); keys_only.get()->values = k->values; keys_only.get()->validity = k->validity; keys_only.get()->null_count = k->null_count;
-            dfgpu_status st = dfgpu_cast(ctx, keys_only.get(), DFGPU_INT64, 0, 0, &wide); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str());
-            ArrayHolder w(wide); ArrayHolder dec(take_impl(ctx, k->dictionary, w.get()->values->ptr, 8, w.get()->validity ? (const uint64_t*)w.get()->validity->ptr : nullptr, k->length)); dfgpu_array_release(nk.release()); nk.a = dec.release(); }
-          else { ArrayHolder dec(take_impl(ctx, k->dictionary, k->values->ptr, kw, k->validity ? (const uint64_t*)k->validity->ptr : nullptr, k->length)); dfgpu_array_release(nk.release()); nk.a = dec.release(); }
-        }
-        if (!g->keys[c]) g->keys[c] = nk.release();
-        else { const dfgpu_array* parts[2] = { g->keys[c], nk.get() }; dfgpu_array* cat = nullptr; dfgpu_status st = dfgpu_concat(ctx, parts, 2, &cat); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str());
-               dfgpu_array_release(g->keys[c]); g->keys[c] = cat; }
-      }
+      groups_append_keys(ctx, g, cols, nkeys, firsts.get(), n_new);
       check_flags(ctx, "groups_intern");
     }
     hipLaunchKernelGGL(k_groups_finalize, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)tmp->ptr, (const uint64_t*)g->slots->ptr, n, (uint32_t*)ids.get()->values->ptr);

@@ -52,6 +52,42 @@ def test_intern_under_forced_collisions_and_mask(ctx):
     assert np.array_equal(ids2[m].astype(np.int64), want) and (ids2[~m] == 0xFFFFFFFF).all()
 
 
+def test_clustered_keys_are_numbered_by_runs_like_the_hash_path(ctx):
+    """GROUP BY over batches that arrive clustered on their keys (≙ GroupOrdering::Full): groups.hip numbers groups by runs without a
+    hash table.  Ids must equal the oracle's first-seen ids across: a clustered batch, a second clustered batch that continues above
+    the first, then a batch that breaks the order (falls back: the numbered groups are hashed, the table is built), then more rows."""
+    import dfgpu
+    def batch(lo, n, width):
+        k0 = np.sort(RNG.integers(lo, lo + width, n)).astype(np.int64)
+        return [pa.array(k0), pa.array((k0 * 7 % 13).astype(np.int32)), pa.array([None if v % 5 == 0 else f"s{v % 11}" for v in k0], type=pa.utf8())]
+    b1, b2 = batch(0, 5000, 800), batch(1000, 7000, 900)
+    b3 = [pa.array(RNG.integers(0, 2500, 3000).astype(np.int64))]
+    b3 += [pa.array((np.asarray(b3[0]) * 7 % 13).astype(np.int32)), pa.array([None if v % 5 == 0 else f"s{v % 11}" for v in np.asarray(b3[0])], type=pa.utf8())]
+    b4 = batch(5000, 100, 50)
+    for runs in (1, 0):
+        ctx.set_option("group_run_detection", runs)
+        try:
+            gv, og = dfgpu.GroupValues(ctx, 3), po.Groups([c.type for c in b1])
+            for b in (b1, b2, b3, b4):
+                got = gv.intern([ctx.from_arrow(c) for c in b]).to_numpy().astype(np.int64)
+                assert np.array_equal(got, og.intern(b)), f"runs={runs}"
+            assert len(gv) == len(og)
+            for a, w in zip(gv.emit(), og.emit()):
+                assert a.to_arrow().equals(w)
+        finally:
+            ctx.set_option("group_run_detection", 1)
+
+
+def test_first_key_sorted_but_other_keys_alternating_is_not_a_run(ctx):
+    """(a,1),(a,2),(a,1): sorted on the first column yet equal keys are not adjacent -- the run path must decline."""
+    import dfgpu
+    k0 = pa.array(np.repeat(np.arange(2000, dtype=np.int64), 3))
+    k1 = pa.array(np.tile(np.array([1, 2, 1], dtype=np.int32), 2000))
+    gv, og = dfgpu.GroupValues(ctx, 2), po.Groups([k0.type, k1.type])
+    got = gv.intern([ctx.from_arrow(k0), ctx.from_arrow(k1)]).to_numpy().astype(np.int64)
+    assert np.array_equal(got, og.intern([k0, k1])) and len(gv) == 4000
+
+
 def value_array(kind, n):
     if kind == "decimal":
         return pa.array([None if RNG.random() < 0.1 else decimal.Decimal(int(v)).scaleb(-2) for v in RNG.integers(-10**13, 10**13, n)], type=pa.decimal128(15, 2))
