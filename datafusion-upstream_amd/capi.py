@@ -79,6 +79,8 @@ PROTOTYPES = {
     "dfgpu_ctx_set_option": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
     "dfgpu_ctx_stream": (_P, [_P]),
     "dfgpu_version": (C.c_char_p, []),
+    "dfgpu_ctx_set_row_selection": (C.c_int32, [_P, _P]),
+    "dfgpu_mask_count": (C.c_int32, [_P, _P, C.POINTER(C.c_int64)]),
     "dfgpu_profile_enable": (C.c_int32, [_P, C.c_int32]),
     "dfgpu_profile_select": (C.c_int32, [_P, C.c_char_p]),
     "dfgpu_profile_read": (C.c_int32, [_P, C.c_char_p, C.c_int64]),

@@ -291,6 +291,19 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
   });
 }
 
+dfgpu_status dfgpu_ctx_set_row_selection(dfgpu_ctx* ctx, const dfgpu_array* mask) {
+  return guard(ctx, [&] {
+    if (!mask) { ctx->row_selection.reset(); ctx->row_selection_len = 0; return; }
+    ctx->row_selection = effective_mask(ctx, mask, mask->length); ctx->row_selection_len = mask->length;
+  });
+}
+dfgpu_status dfgpu_mask_count(dfgpu_ctx* ctx, const dfgpu_array* mask, int64_t* out) {
+  return guard(ctx, [&] {
+    if (!mask || !out) fail(DFGPU_INVALID_ARGUMENT, "mask_count: null argument");
+    BufferPtr m = effective_mask(ctx, mask, mask->length);
+    *out = mask->length ? count_set_bits(ctx, (const uint64_t*)m->ptr, mask->length) : 0;
+  });
+}
 dfgpu_status dfgpu_profile_enable(dfgpu_ctx* ctx, int32_t on) {
   if (!ctx) return DFGPU_INVALID_ARGUMENT;
   ctx->profile = on != 0; return DFGPU_OK;

@@ -33,6 +33,7 @@ struct Error : std::exception {
 // Device error flags raised by kernels (checked by the op that launched them).
 enum : uint32_t { DFGPU_FLAG_DIV_ZERO = 1, DFGPU_FLAG_OVERFLOW = 2, DFGPU_FLAG_CAST = 4, DFGPU_FLAG_OOB = 8, DFGPU_FLAG_TABLE_FULL = 16 };
 
+namespace dfgpu { struct Buffer; }
 struct dfgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -42,6 +43,9 @@ struct dfgpu_ctx {
   bool first_seen_group_order = true;
   bool join_rank_index = true;
   bool group_run_detection = true;
+  // row selection of the running operator (dfgpu_ctx_set_row_selection): expression kernels evaluate every row of full-length
+  // columns but raise errors only for selected rows
+  std::shared_ptr<dfgpu::Buffer> row_selection; int64_t row_selection_len = 0;
   // kernel error flags (overflow, divide by zero, cast range, index bounds): checked after the raising call, or -- inside one
   // poll of a plan's output stream -- once before the batch is handed out (saves a stream sync per kernel-level call)
   int defer_flag_checks = 0; bool flags_pending = false; std::string flags_what;
@@ -149,6 +153,7 @@ void exclusive_scan_u32_inplace32(dfgpu_ctx* ctx, uint32_t* data, int64_t n, uin
 dfgpu_array* take_impl(dfgpu_ctx* ctx, const dfgpu_array* values, const void* idx, int idx_width, const uint64_t* idx_validity, int64_t n_out);
 dfgpu_array* mask_to_indices_impl(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n);
 int64_t count_set_bits(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n);
+inline const uint64_t* row_selection_words(dfgpu_ctx* ctx, int64_t n) { return ctx->row_selection && ctx->row_selection_len == n ? (const uint64_t*)ctx->row_selection->ptr : nullptr; }
 
 void launch_iota_u32(dfgpu_ctx* ctx, uint32_t* out, int64_t n, uint32_t start);
 void launch_set_bits_prefix(dfgpu_ctx* ctx, uint64_t* bits, int64_t m);   // bits[0..m) = 1

@@ -278,7 +278,14 @@ struct ProjectionExec : Plan {    // projection.rs:52-62, batch_project :295-317
     bool next(Batch& out) override {
       Batch b; if (!in->next(b)) return false;
       bool only_columns = true; for (auto& e : op->exprs) only_columns &= e->column_index() >= 0;
-      if (b.selection && !only_columns) { std::set<int> need; for (auto& e : op->exprs) e->columns(need); b = materialize_subset(tc, b, need); }
+      // A dense selection (>= 1/4 of the rows, e.g. TPC-H Q1's 98 %) is carried: expressions run over the full columns with the
+      // selection set as the context's row selection so that dropped rows cannot raise; a sparse one is compacted first.
+      struct RowSel { dfgpu_ctx* c = nullptr; ~RowSel() { if (c) dfgpu_ctx_set_row_selection(c, nullptr); } } rowsel;
+      if (b.selection && !only_columns) {
+        int64_t kept = 0; tc.check(dfgpu_mask_count(tc.ctx, b.selection.a, &kept));
+        if (kept * 4 >= b.base_rows) { tc.check(dfgpu_ctx_set_row_selection(tc.ctx, b.selection.a)); rowsel.c = tc.ctx; }
+        else { std::set<int> need; for (auto& e : op->exprs) e->columns(need); b = materialize_subset(tc, b, need); }
+      }
       Batch o; o.base_rows = b.base_rows; o.selection = b.selection; auto s = std::make_shared<Schema>();
       for (size_t i = 0; i < op->exprs.size(); i++) {
         int ci = op->exprs[i]->column_index();

@@ -165,9 +165,12 @@ __global__ void __launch_bounds__(BLOCK) k_both_valid(Operand l, Operand r, int6
 
 // ---------------------------------------------------------------- arithmetic
 struct DecRule { i128 lmul, rmul; };
-__global__ void __launch_bounds__(BLOCK) k_arith(int op, Operand l, Operand r, int64_t n, int32_t out_type, DecRule dr, void* out, uint32_t* flags) {
+__device__ inline void raise(uint32_t* flags, uint32_t f) { if (flags) atomicOr(flags, f); }
+// emask: row selection of the caller (dfgpu_ctx_set_row_selection): a row it drops cannot raise
+__global__ void __launch_bounds__(BLOCK) k_arith(int op, Operand l, Operand r, int64_t n, int32_t out_type, DecRule dr, void* out, uint32_t* flags_, const uint64_t* emask) {
   int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
+  uint32_t* flags = (emask == nullptr || bit_get(emask, i)) ? flags_ : nullptr;
   int64_t a, b;
   if (!op_resolve(l, i, &a) || !op_resolve(r, i, &b)) {     // NULL in -> NULL out (validity written by k_both_valid); keep bytes defined
     if (out_type == DFGPU_FLOAT64) ((double*)out)[i] = 0; else if (out_type == DFGPU_FLOAT32) ((float*)out)[i] = 0; else store_int(out, out_type, i, 0);
@@ -192,10 +195,10 @@ __global__ void __launch_bounds__(BLOCK) k_arith(int op, Operand l, Operand r, i
       case DFGPU_OP_SUB: ok = sub128_checked(x, y, &v); break;
       case DFGPU_OP_MUL: ok = mul128_checked(x, y, &v); break;
       default:
-        if (y == 0) { atomicOr(flags, DFGPU_FLAG_DIV_ZERO); v = 0; }
+        if (y == 0) { raise(flags, DFGPU_FLAG_DIV_ZERO); v = 0; }
         else { i128 rem; i128 q = sdiv128(x, y, &rem); v = op == DFGPU_OP_DIV ? q : rem; }
     }
-    if (!ok) { atomicOr(flags, DFGPU_FLAG_OVERFLOW); v = 0; }
+    if (!ok) { raise(flags, DFGPU_FLAG_OVERFLOW); v = 0; }
     store_i128(out, i, v); return;
   }
   switch (op) {                                             // integer: *_wrapping kernels, checked div/rem
@@ -203,9 +206,9 @@ __global__ void __launch_bounds__(BLOCK) k_arith(int op, Operand l, Operand r, i
     case DFGPU_OP_SUB: v = wrap_to(out_type, x - y); break;
     case DFGPU_OP_MUL: v = wrap_to(out_type, (i128)((u128)x * (u128)y)); break;
     default:
-      if (y == 0) { atomicOr(flags, DFGPU_FLAG_DIV_ZERO); v = 0; }
+      if (y == 0) { raise(flags, DFGPU_FLAG_DIV_ZERO); v = 0; }
       else { i128 rem; i128 q = sdiv128(x, y, &rem);
-        if (op == DFGPU_OP_DIV) { v = q; if (wrap_to(out_type, q) != q) { atomicOr(flags, DFGPU_FLAG_OVERFLOW); v = 0; } } else v = rem; }
+        if (op == DFGPU_OP_DIV) { v = q; if (wrap_to(out_type, q) != q) { raise(flags, DFGPU_FLAG_OVERFLOW); v = 0; } } else v = rem; }
   }
   store_int(out, out_type, i, v);
 }
@@ -220,7 +223,7 @@ __global__ void __launch_bounds__(BLOCK) k_negative(ColView c, int64_t n, void* 
 }
 
 // ---------------------------------------------------------------- cast (safe = false)
-__global__ void __launch_bounds__(BLOCK) k_cast(ColView c, int64_t n, int32_t to, int32_t p, int32_t s, void* out, uint32_t* flags) {
+__global__ void __launch_bounds__(BLOCK) k_cast(ColView c, int64_t n, int32_t to, int32_t p, int32_t s, void* out, uint32_t* flags, const uint64_t* emask) {
   int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   bool bit = false;
   if (i < n) {
@@ -260,7 +263,7 @@ __global__ void __launch_bounds__(BLOCK) k_cast(ColView c, int64_t n, int32_t to
           double d = (double)(uint64_t)(u >> 64) * 18446744073709551616.0 + (double)(uint64_t)u; fv = (neg ? -d : d) / pow10_f64(fs);
         } else if (to_int) { iv = sdiv128(v, pow10_i128(fs), nullptr); err = wrap_to(to, iv) != iv; }
       }
-      if (err) { atomicOr(flags, DFGPU_FLAG_CAST); iv = 0; fv = 0; }
+      if (err) { if (emask == nullptr || bit_get(emask, i)) atomicOr(flags, DFGPU_FLAG_CAST); iv = 0; fv = 0; }
     }
     if (to == DFGPU_FLOAT64) ((double*)out)[i] = fv;
     else if (to == DFGPU_FLOAT32) ((float*)out)[i] = (float)fv;
@@ -371,7 +374,7 @@ dfgpu_status dfgpu_binary(dfgpu_ctx* ctx, int32_t op, const dfgpu_array* l, int3
     ArrayHolder h(new_fixed(ctx, ot, n, rp, rsc, nulls));
     if (n) {
       KernelTimer kt_(ctx, "k_arith");
-      hipLaunchKernelGGL(k_arith, grid, block, 0, ctx->stream, op, lo, ro, n, ot, dr, h.get()->values->ptr, ctx->d_flags);
+      hipLaunchKernelGGL(k_arith, grid, block, 0, ctx->stream, op, lo, ro, n, ot, dr, h.get()->values->ptr, ctx->d_flags, row_selection_words(ctx, n));
       if (nulls) hipLaunchKernelGGL(k_both_valid, grid, block, 0, ctx->stream, lo, ro, n, (uint64_t*)h.get()->validity->ptr);
       KERNEL_CHECK();
     }
@@ -426,7 +429,7 @@ dfgpu_status dfgpu_cast(dfgpu_ctx* ctx, const dfgpu_array* a, int32_t to, int32_
     if (to == DFGPU_DECIMAL128 && (p < 1 || p > 38 || s < 0 || s > p)) fail(DFGPU_INVALID_ARGUMENT, "cast: bad Decimal128(%d, %d)", p, s);
     ColView v = make_view(a);
     ArrayHolder h(new_fixed(ctx, to, a->length, to == DFGPU_DECIMAL128 ? p : 0, to == DFGPU_DECIMAL128 ? s : 0));
-    if (a->length) hipLaunchKernelGGL(k_cast, dim3(grid_for(a->length, BLOCK)), dim3(BLOCK), 0, ctx->stream, v, a->length, to, p, s, h.get()->values->ptr, ctx->d_flags);
+    if (a->length) hipLaunchKernelGGL(k_cast, dim3(grid_for(a->length, BLOCK)), dim3(BLOCK), 0, ctx->stream, v, a->length, to, p, s, h.get()->values->ptr, ctx->d_flags, row_selection_words(ctx, a->length));
     KERNEL_CHECK();
     if (a->type != DFGPU_DICTIONARY) { h.get()->validity = a->validity; h.get()->null_count = a->null_count; }
     else if (may_have_nulls(a)) { h.get()->validity = alloc_buffer(ctx, bitmap_bytes(a->length), true); hipLaunchKernelGGL(k_is_null, dim3(grid_for(a->length, BLOCK)), dim3(BLOCK), 0, ctx->stream, v, a->length, 1, (uint64_t*)h.get()->validity->ptr); h.get()->null_count = -1; }

@@ -97,6 +97,13 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
  * and always before array_export_host / ctx_synchronize return.  dfgpu_stream_next polls inside one region. */
 DFGPU_API dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx *ctx, const char *key, int64_t value);
 DFGPU_API void *dfgpu_ctx_stream(dfgpu_ctx *ctx);
+/* Selection-vector evaluation (the reference evaluates expressions on compacted batches, filter.rs:315-327 then
+ * projection.rs:295-317; here a dense selection is carried instead of compacting): while a row selection (Boolean array; NULL
+ * counts as false) is set, dfgpu_binary / dfgpu_cast over full-length columns of the same length still compute every row but
+ * raise ArrowError conditions (overflow, divide by zero, cast range) only for selected rows; values of unselected rows are
+ * unspecified and must stay behind the selection.  NULL clears it.  dfgpu_mask_count = number of true bits. */
+DFGPU_API dfgpu_status dfgpu_ctx_set_row_selection(dfgpu_ctx *ctx, const dfgpu_array *mask);
+DFGPU_API dfgpu_status dfgpu_mask_count(dfgpu_ctx *ctx, const dfgpu_array *mask, int64_t *out);
 DFGPU_API const char *dfgpu_version(void);
 /* Per-kernel device time measured with HIP events on the ctx stream (used by bench.py for the roofline
  * figure; ≙ the BaselineMetrics elapsed_compute timers of physical-plan/src/metrics/baseline.rs:47-56).

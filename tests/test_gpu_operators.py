@@ -216,3 +216,35 @@ def test_sort_preserving_merge_is_stable_across_partitions_and_applies_fetch(ctx
     with pytest.raises(dfgpu.DfgpuError) as e:
         rows(ops.SortPreservingMergeExec([], src))
     assert "Sort expressions cannot be empty for streaming merge" in str(e.value)
+
+
+def test_projection_over_dense_selection_does_not_compact_and_dropped_rows_cannot_raise(ctx, task_ctx):
+    """FilterExec -> ProjectionExec with a dense selection: the device evaluates `a / b` and a Decimal128 product over the FULL columns
+    with the selection as row selection (include/dfgpu.h dfgpu_ctx_set_row_selection) -- rows the filter dropped (b = 0, an
+    overflowing decimal) must not raise, the kept rows' values equal the reference's compact-then-evaluate order; a kept row that
+    divides by zero still raises the reference's error."""
+    import dfgpu
+    from dfgpu import physical_plan as ops
+    n = 4000
+    a = RNG.integers(-10**6, 10**6, n).astype(np.int64)
+    b = RNG.integers(1, 50, n).astype(np.int64)
+    keep = RNG.random(n) < 0.8
+    b[~keep] = 0                                              # every dropped row would divide by zero
+    big = decimal.Decimal(10**37)
+    d = [big if not k else decimal.Decimal(int(v)) for k, v in zip(keep, RNG.integers(1, 1000, n))]        # dropped rows would overflow d * d
+    t = pa.table({"a": pa.array(a), "b": pa.array(b), "keep": pa.array(keep), "d": pa.array(d, type=pa.decimal128(38, 0))})
+    C, B = ops.Column, ops.BinaryExpr
+    src = ops.MemoryExec([[ops.batch_from_arrow(ctx, t)]], ops.batch_from_arrow(ctx, t).schema)
+    plan = ops.ProjectionExec([(B(C("a", 0), "/", C("b", 1)), "q"), (B(C("d", 3), "*", C("d", 3)), "dd"), (C("a", 0), "a")], ops.FilterExec(C("keep", 2), src))
+    out = ops.collect(plan, task_ctx)
+    got = pa.Table.from_arrays([pa.concat_arrays([x.columns[i].to_arrow() for x in out]) for i in range(3)], names=["q", "dd", "a"])
+    kt = t.filter(pa.array(keep))
+    assert got["a"].to_pylist() == kt["a"].to_pylist()
+    assert got["q"].to_pylist() == po.binary("/", kt["a"].combine_chunks(), kt["b"].combine_chunks()).to_pylist()
+    assert got["dd"].combine_chunks().equals(po.binary("*", kt["d"].combine_chunks(), kt["d"].combine_chunks()))
+    b2 = b.copy(); b2[np.flatnonzero(keep)[7]] = 0              # a KEPT row divides by zero
+    t2 = t.set_column(1, "b", pa.array(b2))
+    src2 = ops.MemoryExec([[ops.batch_from_arrow(ctx, t2)]], ops.batch_from_arrow(ctx, t2).schema)
+    with pytest.raises(dfgpu.DfgpuError) as e:
+        ops.collect(ops.ProjectionExec([(B(C("a", 0), "/", C("b", 1)), "q")], ops.FilterExec(C("keep", 2), src2)), task_ctx)
+    assert "Divide by zero" in str(e.value)
