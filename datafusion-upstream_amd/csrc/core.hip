@@ -283,6 +283,7 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "first_seen_group_order") ctx->first_seen_group_order = value != 0;
     else if (k == "join_rank_index") ctx->join_rank_index = value != 0;
     else if (k == "group_run_detection") ctx->group_run_detection = value != 0;
+    else if (k == "group_dictionary_canon") ctx->group_dictionary_canon = value != 0;
     else if (k == "defer_flag_checks") {            // nests: +1 enters a deferred region, 0 leaves it and raises what the region deferred
       if (value) ctx->defer_flag_checks++;
       else { if (ctx->defer_flag_checks > 0) ctx->defer_flag_checks--; if (ctx->defer_flag_checks == 0) flush_flags(ctx); }

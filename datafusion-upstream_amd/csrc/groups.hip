@@ -29,7 +29,14 @@ struct dfgpu_groups {
   // run mode: every batch so far arrived with its keys clustered (first key column non-decreasing, the other columns constant within
   // equal first keys), so group ids are run numbers and no hash table exists yet; ghash is filled only if a later batch breaks the order
   bool run_mode = false;
-  ~dfgpu_groups() { for (auto* a : keys) if (a) dfgpu_array_release(a); }
+  // canon mode: dictionary key columns are interned through a de-duplicated dictionary -- canon[code] = id of the distinct dictionary
+  // VALUE (so codes with equal values stay one group) -- and rows are hashed / compared as u32 tuples instead of strings.  Valid while
+  // every batch brings the same dictionary arrays; another dictionary drops back to value keys (stored groups are re-hashed).
+  bool canon_mode = false;
+  struct Canon { dfgpu_array* dict = nullptr; BufferPtr ids; int64_t n_ids = 0; };
+  std::vector<Canon> canon;               // per key column (dict == null: not a dictionary column)
+  std::vector<dfgpu_array*> canon_keys;   // per key column: u32 canon id per group (dictionary columns) or null (use keys[c])
+  ~dfgpu_groups() { for (auto* a : keys) if (a) dfgpu_array_release(a); for (auto* a : canon_keys) if (a) dfgpu_array_release(a); for (auto& c : canon) if (c.dict) dfgpu_array_release(c.dict); }
 };
 
 namespace dfgpu {
@@ -148,6 +155,14 @@ __global__ void __launch_bounds__(BLOCK) k_groups_hash_stored(KeySet stored, int
   ghash[g] = force_zero ? 0 : h;
 }
 
+// rows of a dictionary key column -> canonical id of the value (NULL -> n_ids, one extra id)
+__global__ void __launch_bounds__(BLOCK) k_canon_lookup(const void* keys, int key_type, const uint64_t* key_valid, int64_t n, const uint32_t* canon, const uint64_t* dict_valid, int64_t dict_len, uint32_t n_ids, uint32_t* out) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  int64_t c = valid_at(key_valid, i) ? key_at(keys, key_type, i) : -1;
+  out[i] = (c >= 0 && c < dict_len && valid_at(dict_valid, c)) ? canon[c] : n_ids;          // a NULL code and a NULL dictionary value are the same NULL key
+}
+
 static void groups_alloc_table(dfgpu_groups* g, uint64_t cap) {
   dfgpu_ctx* ctx = g->ctx;
   g->capacity = cap;
@@ -256,8 +271,55 @@ dfgpu_status dfgpu_groups_intern(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_ar
       KERNEL_CHECK();
       g->run_mode = false;
     }
+    // dictionary key columns: intern u32 canonical ids of the dictionary VALUES instead of hashing / comparing the values per row
+    std::vector<const dfgpu_array*> eff(cols, cols + nkeys); std::vector<ArrayHolder> sub((size_t)nkeys);
+    bool any_dict = false; for (int c = 0; c < nkeys; c++) any_dict |= cols[c]->type == DFGPU_DICTIONARY && cols[c]->dictionary != nullptr;
+    bool want_canon = ctx->group_dictionary_canon && !ctx->force_hash_collisions && any_dict && (g->n_groups == 0 || g->canon_mode);
+    if (want_canon && g->canon_mode)
+      for (int c = 0; c < nkeys; c++) { const dfgpu_array* d = cols[c]->type == DFGPU_DICTIONARY ? cols[c]->dictionary : nullptr; if (d != g->canon[(size_t)c].dict) want_canon = false; }
+    if (g->canon_mode && !want_canon) {       // another dictionary (or none): back to value keys; the numbered groups are re-hashed by value
+      for (auto*& a : g->canon_keys) { if (a) dfgpu_array_release(a); a = nullptr; }
+      for (auto& cc : g->canon) { if (cc.dict) dfgpu_array_release(cc.dict); cc = dfgpu_groups::Canon{}; }
+      g->canon_mode = false;
+      if (g->n_groups) {
+        std::vector<const dfgpu_array*> sk(g->keys.begin(), g->keys.end()); KeySet stored_ks = make_keyset(sk.data(), nkeys);
+        hipLaunchKernelGGL(k_groups_hash_stored, dim3(grid_for(g->n_groups, BLOCK)), dim3(BLOCK), 0, ctx->stream, stored_ks, g->n_groups, 0, (uint64_t*)g->ghash->ptr);
+        KERNEL_CHECK();
+        if (g->capacity) groups_alloc_table(g, g->capacity);
+      }
+    }
+    if (want_canon) {
+      if (!g->canon_mode) {
+        g->canon.assign((size_t)nkeys, dfgpu_groups::Canon{}); g->canon_keys.assign((size_t)nkeys, nullptr);
+        for (int c = 0; c < nkeys; c++) {
+          if (cols[c]->type != DFGPU_DICTIONARY) continue;
+          const dfgpu_array* dict = cols[c]->dictionary;
+          dfgpu_groups tmp; tmp.ctx = ctx; tmp.nkeys = 1; tmp.keys.assign(1, nullptr);
+          dfgpu_array* dids = nullptr; dfgpu_status st = dfgpu_groups_intern(ctx, &tmp, &dict, 1, nullptr, &dids);
+          if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str());
+          ArrayHolder hold(dids);
+          auto& cc = g->canon[(size_t)c]; cc.dict = const_cast<dfgpu_array*>(dict); dfgpu_array_retain(cc.dict); cc.ids = dids->values; cc.n_ids = tmp.n_groups;
+        }
+        g->canon_mode = true;
+      }
+      for (int c = 0; c < nkeys; c++) {
+        if (cols[c]->type != DFGPU_DICTIONARY) continue;
+        auto& cc = g->canon[(size_t)c];
+        sub[(size_t)c].a = new_fixed(ctx, DFGPU_UINT32, n);
+        KernelTimer kt_(ctx, "k_canon_lookup");
+        hipLaunchKernelGGL(k_canon_lookup, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, cols[c]->values->ptr, cols[c]->key_type, cols[c]->validity ? (const uint64_t*)cols[c]->validity->ptr : nullptr, n,
+                           (const uint32_t*)cc.ids->ptr, cc.dict->validity ? (const uint64_t*)cc.dict->validity->ptr : nullptr, cc.dict->length, (uint32_t)cc.n_ids, (uint32_t*)sub[(size_t)c].get()->values->ptr);
+        KERNEL_CHECK();
+        eff[(size_t)c] = sub[(size_t)c].get();
+      }
+    }
+    KeySet hk = make_keyset(eff.data(), nkeys);
     KeySet stored{}; int has_stored = 0;
-    if (g->n_groups) { std::vector<const dfgpu_array*> sk(g->keys.begin(), g->keys.end()); stored = make_keyset(sk.data(), nkeys); has_stored = 1; }
+    if (g->n_groups) {
+      std::vector<const dfgpu_array*> sk(g->keys.begin(), g->keys.end());
+      if (g->canon_mode) for (int c = 0; c < nkeys; c++) if (g->canon_keys[(size_t)c]) sk[(size_t)c] = g->canon_keys[(size_t)c];
+      stored = make_keyset(sk.data(), nkeys); has_stored = 1;
+    }
     BufferPtr tmp = alloc_buffer(ctx, (size_t)n * 4);
     // optimistic table size (at most 2^23 slots up front); a batch that overfills it is redone on a table 8x larger
     uint64_t guess = (uint64_t)g->n_groups * 4 + 2 * (uint64_t)(n < (1 << 22) ? n : (1 << 22));
@@ -268,7 +330,7 @@ dfgpu_status dfgpu_groups_intern(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_ar
       uint64_t max_steps = g->capacity - 1 < 4096 ? g->capacity - 1 : 4096;
       zero_scratch(ctx);
       { KernelTimer kt_(ctx, "k_groups_find");
-      hipLaunchKernelGGL(k_groups_find, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, bk, stored, has_stored, n, mask ? (const uint64_t*)mask->ptr : nullptr,
+      hipLaunchKernelGGL(k_groups_find, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, hk, stored, has_stored, n, mask ? (const uint64_t*)mask->ptr : nullptr,
                          ctx->force_hash_collisions ? 1 : 0, (uint64_t*)g->slots->ptr, g->capacity - 1, (uint32_t*)g->first_row->ptr, (uint32_t*)tmp->ptr,
                          (unsigned long long*)ctx->d_scratch64, max_steps); }
       KERNEL_CHECK();
@@ -285,10 +347,17 @@ dfgpu_status dfgpu_groups_intern(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_ar
     if (g->n_groups + n_new >= (int64_t)G_NEW) fail(DFGPU_RESOURCES_EXHAUSTED, "more than 2^31 groups");
     if (n_new) {
       groups_reserve_ghash(ctx, g, g->n_groups + n_new, g->n_groups);
-      hipLaunchKernelGGL(k_groups_assign, dim3(grid_for(n_new, BLOCK)), dim3(BLOCK), 0, ctx->stream, bk, (const uint32_t*)firsts.get()->values->ptr, n_new, (const uint32_t*)tmp->ptr,
+      hipLaunchKernelGGL(k_groups_assign, dim3(grid_for(n_new, BLOCK)), dim3(BLOCK), 0, ctx->stream, hk, (const uint32_t*)firsts.get()->values->ptr, n_new, (const uint32_t*)tmp->ptr,
                          (uint64_t*)g->slots->ptr, (uint32_t*)g->first_row->ptr, (uint32_t)g->n_groups, ctx->force_hash_collisions ? 1 : 0, (uint64_t*)g->ghash->ptr);
       KERNEL_CHECK();
       groups_append_keys(ctx, g, cols, nkeys, firsts.get(), n_new);
+      if (g->canon_mode) for (int c = 0; c < nkeys; c++) {          // the new groups' canon tuples, for comparisons in later batches
+        if (!sub[(size_t)c].get()) continue;
+        ArrayHolder nk(take_impl(ctx, sub[(size_t)c].get(), firsts.get()->values->ptr, 4, nullptr, n_new));
+        dfgpu_array*& dst = g->canon_keys[(size_t)c];
+        if (!dst) dst = nk.release();
+        else { const dfgpu_array* parts[2] = { dst, nk.get() }; dfgpu_array* cat = nullptr; dfgpu_status st = dfgpu_concat(ctx, parts, 2, &cat); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str()); dfgpu_array_release(dst); dst = cat; }
+      }
       check_flags(ctx, "groups_intern");
     }
     hipLaunchKernelGGL(k_groups_finalize, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)tmp->ptr, (const uint64_t*)g->slots->ptr, n, (uint32_t*)ids.get()->values->ptr);

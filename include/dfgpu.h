@@ -91,6 +91,8 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
  * column is strictly increasing (results identical either way; the switch exists for A/B tests);
  * "group_run_detection" (1/0) == let groups_intern number groups by runs when a batch arrives clustered on its keys
  * (≙ GroupOrdering::Full, aggregates/order/full.rs; ids identical to the hash path: first-seen order);
+ * "group_dictionary_canon" (1/0) == let groups_intern map dictionary key columns through a de-duplicated dictionary (u32 id of
+ * the distinct VALUE per code) and intern those ids; groups, ids and emitted keys are identical to interning the values;
  * "defer_flag_checks" (1 = enter / 0 = leave a deferred region, nests) == kernel error flags (overflow, divide by zero,
  * cast range, index bounds -- the ArrowError cases of arrow-arith / arrow-cast / arrow-select) are normally checked by the
  * call that ran the kernel; inside a region they are checked once, by the call that leaves it (which returns the error),

@@ -88,6 +88,38 @@ def test_first_key_sorted_but_other_keys_alternating_is_not_a_run(ctx):
     assert np.array_equal(got, og.intern([k0, k1])) and len(gv) == 4000
 
 
+def test_dictionary_keys_through_canonical_ids_match_value_interning(ctx):
+    """Dictionary key columns are interned as u32 ids of the distinct dictionary VALUES (groups.hip canon mode): a dictionary that
+    repeats a value under two codes, holds a NULL value and NULL codes must give exactly the oracle's groups / first-seen ids / emitted
+    keys -- over batches that share the dictionary (slices of one device array), then over a batch with ANOTHER dictionary (drops back
+    to value keys, the numbered groups are re-hashed), with a plain Int64 second key column, and with the option switched off."""
+    import dfgpu
+    words = pa.array(["x", "y", None, "x", "z", "w", "y"], type=pa.utf8())          # codes 0/3 and 1/6 carry equal values; code 2 is a NULL value
+    n = 9000
+    codes = pa.array(RNG.integers(0, 7, n).astype(np.int32), mask=RNG.random(n) < 0.05)
+    col = pa.DictionaryArray.from_arrays(codes, words)
+    k2 = pa.array(RNG.integers(0, 4, n).astype(np.int64))
+    other = pa.array([None if v % 7 == 0 else "xyzwq"[v % 5] for v in RNG.integers(0, 100, 3000)], type=pa.utf8()).dictionary_encode()
+    other2 = pa.array(RNG.integers(0, 4, 3000).astype(np.int64))
+    for canon in (1, 0):
+        ctx.set_option("group_dictionary_canon", canon)
+        try:
+            dev, dev2 = ctx.from_arrow(col), ctx.from_arrow(k2)
+            gv, og = dfgpu.GroupValues(ctx, 2), po.Groups([pa.utf8(), pa.int64()])
+            for lo, hi in ((0, 4000), (4000, 4001), (4001, n)):
+                got = gv.intern([dev.slice(lo, hi - lo), dev2.slice(lo, hi - lo)]).to_numpy().astype(np.int64)
+                assert np.array_equal(got, og.intern([col.slice(lo, hi - lo), k2.slice(lo, hi - lo)])), f"canon={canon} rows {lo}:{hi}"
+            got = gv.intern([ctx.from_arrow(other), ctx.from_arrow(other2)]).to_numpy().astype(np.int64)      # a different dictionary
+            assert np.array_equal(got, og.intern([other, other2])), f"canon={canon} other dictionary"
+            got = gv.intern([dev.slice(0, 500), dev2.slice(0, 500)]).to_numpy().astype(np.int64)
+            assert np.array_equal(got, og.intern([col.slice(0, 500), k2.slice(0, 500)]))
+            assert len(gv) == len(og)
+            for a, w in zip(gv.emit(), og.emit()):
+                assert a.to_arrow().equals(w)
+        finally:
+            ctx.set_option("group_dictionary_canon", 1)
+
+
 def value_array(kind, n):
     if kind == "decimal":
         return pa.array([None if RNG.random() < 0.1 else decimal.Decimal(int(v)).scaleb(-2) for v in RNG.integers(-10**13, 10**13, n)], type=pa.decimal128(15, 2))
