@@ -87,10 +87,14 @@ def _same_stream(ctx) -> bool:
     return ctx.stream == torch.cuda.current_stream().cuda_stream
 
 
-def _exchange_meta(counts: Sequence[int], fields, has_valid: Sequence[int], group):
-    """ONE small all-gather carries everything the ranks must agree on before the data moves: the row-count matrix, and --
-    for ranks that hold no rows and therefore no arrays -- the column types and which columns carry a validity bitmap.
-    Returns (recv_counts[src], all_counts[src][dst], fields [(dtype, precision, scale)], nullable [bool])."""
+_MAX_UTF8 = 8
+
+
+def _exchange_meta(counts: Sequence[int], fields, has_valid: Sequence[int], group, utf8_bytes: Optional[Sequence[Sequence[int]]] = None):
+    """ONE small all-gather carries everything the ranks must agree on before the data moves: the row-count matrix, the value
+    bytes of every Utf8 column per destination, and -- for ranks that hold no rows and therefore no arrays -- the column types
+    and which columns carry a validity bitmap.
+    Returns (recv_counts[src], all_counts[src][dst], fields [(dtype, precision, scale)], nullable [bool], recv_utf8[src][k])."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -102,6 +106,13 @@ def _exchange_meta(counts: Sequence[int], fields, has_valid: Sequence[int], grou
     for c in range(ncols):
         row += [fields[c][0], fields[c][1], fields[c][2], int(has_valid[c])]
     row += [0] * (world + 1 + 4 * _MAX_COLS - len(row))
+    ub = [[0] * _MAX_UTF8 for _ in range(world)]
+    if utf8_bytes is not None:
+        for d in range(world):
+            for k, b in enumerate(utf8_bytes[d]):
+                ub[d][k] = int(b)
+    for d in range(world):
+        row += ub[d]
     dev = "cuda" if _is_nccl(group) else "cpu"
     mine = torch.tensor(row, dtype=torch.int64, device=dev)
     allm = torch.empty((world, mine.numel()), dtype=torch.int64, device=dev)      # also at world 1: the RCCL path is the one a 1-rank test covers
@@ -110,15 +121,17 @@ def _exchange_meta(counts: Sequence[int], fields, has_valid: Sequence[int], grou
     all_counts = [r[:world] for r in m]
     src = next((r for r in m if r[world] > 0), None)
     if src is None:
-        return [0] * world, all_counts, [], []
+        return [0] * world, all_counts, [], [], [[0] * _MAX_UTF8 for _ in range(world)]
     nc = src[world]
     flds = [tuple(src[world + 1 + 4 * c: world + 4 + 4 * c]) for c in range(nc)]
     nullable = [any(r[world] > 0 and r[world + 4 + 4 * c] for r in m) for c in range(nc)]
-    return [all_counts[s][rank] for s in range(world)], all_counts, flds, nullable
+    ub0 = world + 1 + 4 * _MAX_COLS
+    recv_utf8 = [m[s][ub0 + rank * _MAX_UTF8: ub0 + (rank + 1) * _MAX_UTF8] for s in range(world)]
+    return [all_counts[s][rank] for s in range(world)], all_counts, flds, nullable, recv_utf8
 
 
 def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=None, names: Optional[Sequence[str]] = None, broadcast: bool = False):
-    """parts[dest] = the rows of this rank bound for rank `dest` (None/empty allowed; fixed-width columns, nullable or not).
+    """parts[dest] = the rows of this rank bound for rank `dest` (None/empty allowed; fixed-width and Utf8 columns, nullable or not).
     Returns one RecordBatch holding everything this rank received, source ranks in order (≙ the batches a RepartitionExec
     output partition yields).  One metadata all-gather (_exchange_meta), then one collective per column buffer: all-to-all(v)
     for a shuffle, all-gather for `broadcast` (every part is the same batch).  A column that carries a validity bitmap on ANY
@@ -137,37 +150,53 @@ def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=No
         fs = (schema or first.schema).fields
         fields = [(f.dtype, f.precision, f.scale) for f in fs]
         for f in fs:
-            if f.dtype not in _WIDTH:
+            if f.dtype not in _WIDTH and f.dtype != capi.UTF8:
                 raise ops.DfgpuError(4, f"exchange of column type {f.dtype} is not supported yet")
+        ucols = [c for c, f in enumerate(fs) if f.dtype == capi.UTF8]
+        if len(ucols) > _MAX_UTF8:
+            raise ops.DfgpuError(4, f"exchange of more than {_MAX_UTF8} Utf8 columns")
         has_valid = [0] * len(fs)
         for p, n in zip(parts[:1] if broadcast else parts, counts):
             if p is not None and n:
                 for c, col in enumerate(p.columns):
-                    if col.describe().validity:
+                    d = col.describe()
+                    if d.type == capi.DICTIONARY:
+                        raise ops.DfgpuError(4, "exchange of dictionary-encoded columns is not supported yet (cast to the value type first)")
+                    if d.validity:
                         has_valid[c] = 1
-    recv_counts, all_counts, flds, nullable = _exchange_meta(counts, fields, has_valid, group)
+        utf8_bytes = [[(p.columns[c].describe().values_bytes if p is not None and n else 0) for c in ucols] for p, n in zip(parts, counts)]
+    else:
+        utf8_bytes = None
+    recv_counts, all_counts, flds, nullable, recv_utf8 = _exchange_meta(counts, fields, has_valid, group, utf8_bytes)
     if not flds:
         return pp.RecordBatch.from_arrays(ctx, [], [])
     if names is None:
         names = (schema or first.schema).names() if (schema is not None or first is not None) else [f"c{c}" for c in range(len(flds))]
-    widths = [_WIDTH[t] for t, _, _ in flds]
+    widths = [_WIDTH.get(t, 0) for t, _, _ in flds]            # 0 = Utf8: (n + 1) int32 offsets + value bytes
+    ucols = [c for c, (t, _, _) in enumerate(flds) if t == capi.UTF8]
     sync = not _same_stream(ctx)
     nccl = _is_nccl(group)
     total = int(sum(recv_counts))
     pad8 = lambda x: (x + 7) // 8 * 8
     vwords = lambda n: ((n + 63) // 64) * 8
 
-    # One message per (source, destination): every column's values (padded to 8 bytes) followed by its validity words when the
-    # column is nullable anywhere -- so an exchange is ONE data collective, whatever the number of columns (a collective costs
-    # ~100 us of launch latency on RCCL; TPC-H Q3's gather has 4 columns, its shuffles 3-5).
-    def layout(n):
+    # One message per (source, destination): every column's values (padded to 8 bytes; a Utf8 column = its offsets, then its value
+    # bytes) followed by its validity words when the column is nullable anywhere -- so an exchange is ONE data collective, whatever
+    # the number of columns (a collective costs ~100 us of launch latency on RCCL; TPC-H Q3's gather has 4 columns, its shuffles 3-5).
+    def layout(n, ubytes):
         offs, o = [], 0
+        if n == 0:
+            return [(0, None, None)] * len(widths), 0          # nothing is sent for an empty part (not even a Utf8 column's single offset)
         for c, w in enumerate(widths):
-            vo = o; o += pad8(n * w)
+            vo = o
+            if w:
+                o += pad8(n * w); bo2 = None
+            else:
+                o += pad8((n + 1) * 4); bo2 = o; o += pad8(ubytes[ucols.index(c)])
             bo = None
             if nullable[c]:
                 bo = o; o += vwords(n)
-            offs.append((vo, bo))
+            offs.append((vo, bo, bo2))
         return offs, o
 
     def device_bytes(arr, nbytes):
@@ -181,17 +210,28 @@ def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=No
         """the packed bytes of batch p (n rows) as a list of tensors to concatenate"""
         segs = []
         for c, col in enumerate(p.columns):
-            nb = n * widths[c]
-            segs.append(device_bytes(col, nb))
+            d = col.describe()
+            if widths[c]:
+                nb = n * widths[c]
+                segs.append(device_bytes(col, nb))
+            else:
+                nb = (n + 1) * 4
+                segs.append(torch.as_tensor(_DevicePtr(d.offsets, nb, col), device="cuda"))
             if pad8(nb) != nb:
                 segs.append(zeros8[:pad8(nb) - nb])
+            if not widths[c]:
+                vb = d.values_bytes
+                if vb:
+                    segs.append(torch.as_tensor(_DevicePtr(d.values, vb, col), device="cuda"))
+                if pad8(vb) != vb:
+                    segs.append(zeros8[:pad8(vb) - vb])
             if nullable[c]:
                 bm = ctx.is_null(col, negate=True)           # validity as a Boolean column (all ones when there is no bitmap)
                 keep.append(bm)
                 segs.append(device_bytes(bm, vwords(n)))
         return segs
 
-    recv_sizes = [layout(n)[1] for n in recv_counts]
+    recv_sizes = [layout(n, recv_utf8[s_])[1] for s_, n in enumerate(recv_counts)]
     if broadcast:
         segs = message(parts[rank], counts[rank]) if parts[rank] is not None and counts[rank] else []
         if sync:
@@ -211,7 +251,7 @@ def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=No
     else:
         segs, send_sizes = [], []
         for p, n in zip(parts, counts):
-            send_sizes.append(layout(n)[1] if p is not None and n else 0)
+            send_sizes.append(layout(n, utf8_bytes[len(send_sizes)])[1] if p is not None and n else 0)
             if p is not None and n:
                 segs += message(p, n)
         if sync:
@@ -225,10 +265,22 @@ def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=No
     if sync:
         torch.cuda.current_stream().synchronize()
     out_cols = []
-    lay = [layout(n)[0] for n in recv_counts]
+    lay = [layout(n, recv_utf8[s_])[0] for s_, n in enumerate(recv_counts)]
     for c, (t, prec, scale) in enumerate(flds):
         w = widths[c]
-        vals = [ctx.wrap_tensor(buf[base[s] + lay[s][c][0]: base[s] + lay[s][c][0] + n * w], t, prec, scale) for s, n in enumerate(recv_counts) if n]
+        if w:
+            vals = [ctx.wrap_tensor(buf[base[s] + lay[s][c][0]: base[s] + lay[s][c][0] + n * w], t, prec, scale) for s, n in enumerate(recv_counts) if n]
+        else:
+            vals = []
+            for s_, n in enumerate(recv_counts):
+                if not n:
+                    continue
+                d = capi.ArrayDesc()
+                d.type, d.length, d.null_count = capi.UTF8, n, 0
+                d.offsets = buf.data_ptr() + base[s_] + lay[s_][c][0]
+                d.values_bytes = recv_utf8[s_][ucols.index(c)]
+                d.values = buf.data_ptr() + base[s_] + lay[s_][c][2]
+                vals.append(ctx.wrap_device(d, keepalive=buf))
         # concat = the owned copy: the torch receive buffer dies with this function, the column may outlive it inside a C++ plan
         values = ctx.concat(vals) if vals else ctx.new_null(t, 0, prec, scale)
         if not nullable[c] or not total:
@@ -236,9 +288,10 @@ def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=No
             continue
         bools = [ctx.wrap_tensor_bool(buf[base[s] + lay[s][c][1]: base[s] + lay[s][c][1] + vwords(n)], n) for s, n in enumerate(recv_counts) if n]
         validity = ctx.concat(bools) if len(bools) > 1 else bools[0]            # spliced at bit granularity
+        vd = values.describe()
         d = capi.ArrayDesc()
         d.type, d.precision, d.scale, d.length, d.null_count = t, prec, scale, total, -1
-        d.values, d.validity = values.describe().values, validity.describe().values
+        d.values, d.validity, d.offsets, d.values_bytes = vd.values, validity.describe().values, vd.offsets, vd.values_bytes
         out_cols.append(ctx.concat([ctx.wrap_device(d, keepalive=(values, validity, buf))]))          # values + spliced validity in one owned array
     if sync:
         ctx.synchronize()                              # the owned copies are complete before the torch buffers are released

@@ -76,3 +76,76 @@ def test_q3_distributed_two_ranks_one_gpu_matches_oracle(world, plan_name):
     assert len(got["l_orderkey"]) == len(want["l_orderkey"]) > 0
     for k in want:
         assert np.array_equal(got[k], want[k]), k
+
+
+def _utf8_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        import faulthandler
+        faulthandler.dump_traceback_later(120, exit=True)
+        import pyarrow as pa
+        import torch
+        import torch.distributed as dist
+        import dfgpu
+        from dfgpu import exchange, physical_plan as ops
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ctx = dfgpu.Context(0, stream=torch.cuda.current_stream().cuda_stream) if rank == 0 else dfgpu.Context(0)
+        rng = np.random.default_rng(100 + rank)
+        n = [0, 3000, 1777][rank % 3] if world == 3 else [2500, 1300][rank]                    # one rank of three holds no rows at all
+        k = rng.integers(0, 500, n).astype(np.int64)
+        s_col = pa.array([None if v % 9 == 0 else f"rank{rank}-" + "x" * int(v % 23) for v in k], type=pa.utf8())
+        t_col = pa.array([f"{v:05d}" for v in k], type=pa.utf8())
+        tab = pa.table({"k": pa.array(k), "s": s_col, "t": t_col})
+        C = ops.Column
+        outs = {}
+        if n:
+            b = ops.batch_from_arrow(ctx, tab)
+            src = ops.MemoryExec([[b]], b.schema)
+        else:
+            b0 = ops.batch_from_arrow(ctx, pa.table({"k": pa.array([], type=pa.int64()), "s": pa.array([], type=pa.utf8()), "t": pa.array([], type=pa.utf8())}))
+            src = ops.MemoryExec([[b0]], b0.schema)
+        tc = ops.TaskContext(ctx, 8192)
+        for name, node in (("shuffle", exchange.ShuffleExec(src, [C("k", 0)])), ("broadcast", exchange.BroadcastExec(src))):
+            got = [x for x in node.execute(0, tc)]
+            rows = []
+            for x in got:
+                cols = [c.to_arrow().to_pylist() for c in x.columns]
+                rows += list(zip(*cols))
+            outs[name] = rows
+        q.put((rank, {"mine": list(zip(k.tolist(), s_col.to_pylist(), t_col.to_pylist())), **outs}))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_of_utf8_and_nullable_utf8_columns(world):
+    """ShuffleExec / BroadcastExec over batches with Utf8 columns (one nullable): offsets + value bytes travel inside the packed
+    per-destination message; a rank without rows still takes part.  Shuffle: every row arrives exactly once, rows with equal keys on
+    one rank; broadcast: every rank holds every rank's rows in rank order."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 900) + world
+    procs = [ctx.Process(target=_utf8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=150) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        assert isinstance(results[r], dict), results[r]
+    everything = [row for r in range(world) for row in results[r]["mine"]]
+    shuffled = [row for r in range(world) for row in results[r]["shuffle"]]
+    assert sorted(shuffled, key=repr) == sorted(everything, key=repr)
+    owner = {}
+    for r in range(world):
+        for row in results[r]["shuffle"]:
+            assert owner.setdefault(row[0], r) == r, "equal keys must land on one rank"
+    for r in range(world):
+        assert results[r]["broadcast"] == everything
