@@ -96,24 +96,26 @@ def main():
 
     PLANS = {"colocated": tpch.q3_colocated_plan, "broadcast": tpch.q3_broadcast_plan, "shuffle": tpch.q3_distributed_plan}
     Q3_OUTPUT = ["l_orderkey", "revenue", "o_orderdate", "o_shippriority"]
-    # N = 1: the plan description is built once; every step executes a copy with fresh run-once state (no cached build side)
+    # The plan description is built once; every step executes a copy with fresh run-once state (no cached build side).  N > 1: the
+    # colocated plan is cut at its one exchange into two prebuilt segments (tpch.Q3ColocatedStaged); the other plans are rebuilt per step.
     template = tpch.q3_plan(tables, batch_size=8192) if world == 1 else None
+    staged = tpch.Q3ColocatedStaged(tables, batch_size=8192) if world > 1 and args.plan == "colocated" else None
+    C_ = ops.Column
+    final_keys = [ops.PhysicalSortExpr(C_("revenue", 1), True, True), ops.PhysicalSortExpr(C_("o_orderdate", 2), False, False)]
 
     def step():
         if world == 1:
             plan = ops.with_fresh_state(template)
             out = [b for b in plan.execute(0, tc)]
         else:
-            plan = PLANS[args.plan](tables, batch_size=8192)
+            plan = staged if staged is not None else PLANS[args.plan](tables, batch_size=8192)
             local = [b for b in plan.execute(0, tc)]
             mine = ops.concat_batches(local[0].schema, local) if local else None
             gathered = exchange.gather_batches(ctx, None, mine, 0, names=Q3_OUTPUT)           # ≙ SortPreservingMergeExec gathering the sorted partitions
             out = []
             if rank == 0 and gathered.num_rows:
-                C = ops.Column
                 gb = gathered
-                final = ops.SortExec([ops.PhysicalSortExpr(C("revenue", 1), True, True), ops.PhysicalSortExpr(C("o_orderdate", 2), False, False)],
-                                     ops.MemoryExec([[gb]], gb.schema))
+                final = ops.SortExec(final_keys, ops.MemoryExec([[gb]], gb.schema))
                 out = [b for b in final.execute(0, tc)]
         ctx.synchronize()
         result_rows[0] = sum(b.num_rows for b in out)

@@ -154,6 +154,7 @@ PROTOTYPES.update({
     "dfgpu_expr_in_list": (C.c_int32, [_P, _P, C.c_int32, _PP]),
     "dfgpu_expr_free": (None, [_P]),
     "dfgpu_plan_memory": (C.c_int32, [_PP, _I32P, C.c_int32, _PP]),
+    "dfgpu_plan_memory_replace": (C.c_int32, [_P, _PP, _I32P, C.c_int32]),
     "dfgpu_plan_filter": (C.c_int32, [_P, _P, _PP]),
     "dfgpu_plan_projection": (C.c_int32, [_PP, _CPP, C.c_int32, _P, _PP]),
     "dfgpu_plan_coalesce_batches": (C.c_int32, [_P, C.c_int64, _PP]),

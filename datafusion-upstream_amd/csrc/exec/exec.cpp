@@ -207,12 +207,13 @@ struct VecStream : Stream {
 };
 
 struct MemoryExec : Plan {        // memory.rs:40,150
-  std::vector<std::vector<Batch>> parts; SchemaPtr sch;
+  mutable std::mutex mu; mutable std::vector<std::vector<Batch>> parts; SchemaPtr sch;      // parts: replaceable (dfgpu_plan_memory_replace), read under mu
   const char* name() const override { return "MemoryExec"; }
   PlanPtr fresh() const override { return shared_from_this(); }
   SchemaPtr schema() const override { return sch; }
-  int partitions() const override { return (int)parts.size(); }
+  int partitions() const override { std::lock_guard<std::mutex> l(mu); return (int)parts.size(); }
   std::unique_ptr<Stream> execute(int p, const TaskContext&) const override {
+    std::lock_guard<std::mutex> l(mu);
     if (p < 0 || p >= (int)parts.size()) fail(DFGPU_INTERNAL, "MemoryExec invalid partition %d (expected less than %zu)", p, parts.size());
     return std::unique_ptr<Stream>(new VecStream(parts[(size_t)p]));
   }
@@ -704,6 +705,15 @@ dfgpu_status dfgpu_plan_memory(const dfgpu_batch* const* batches, const int32_t*
     for (int p = 0; p < nparts; p++) { m->parts.emplace_back(); for (int i = 0; i < sizes[p]; i++) { const dfgpu_batch* b = batches[k++]; if (!b) fail(DFGPU_INVALID_ARGUMENT, "null batch"); if (!m->sch) m->sch = b->b.schema; m->parts.back().push_back(b->b); } }
     if (!m->sch) m->sch = std::make_shared<Schema>();
     *out = new dfgpu_plan{m};
+  });
+}
+dfgpu_status dfgpu_plan_memory_replace(dfgpu_plan* p, const dfgpu_batch* const* batches, const int32_t* sizes, int32_t nparts) {
+  return guard([&] {
+    auto* m = p ? dynamic_cast<const MemoryExec*>(p->p.get()) : nullptr;
+    if (!m) fail(DFGPU_INVALID_ARGUMENT, "plan_memory_replace: not a MemoryExec");
+    std::vector<std::vector<Batch>> np; int k = 0;
+    for (int i = 0; i < nparts; i++) { np.emplace_back(); for (int j = 0; j < sizes[i]; j++) { const dfgpu_batch* b = batches[k++]; if (!b) fail(DFGPU_INVALID_ARGUMENT, "null batch"); np.back().push_back(b->b); } }
+    std::lock_guard<std::mutex> l(m->mu); m->parts = std::move(np);
   });
 }
 dfgpu_status dfgpu_plan_filter(const dfgpu_expr* pred, const dfgpu_plan* input, dfgpu_plan** out) { return guard([&] { auto f = std::make_shared<FilterExec>(); f->pred = ex(pred); f->input = pl(input); *out = new dfgpu_plan{f}; }); }

@@ -374,6 +374,15 @@ class MemoryExec(ExecutionPlan):
         _check(_lib().dfgpu_plan_memory(_ptrs([b._h.h for b in flat]), sizes, len(self.partitions), C.byref(out)))
         return self._new(out)
 
+    def replace(self, partitions: List[List[RecordBatch]]):
+        """New batches (same schema) for every C++ node already built from this description: the input slot of a plan segment that is
+        built once and executed per step with `with_fresh_state`."""
+        self.partitions = partitions
+        flat = [b for p in partitions for b in p]
+        sizes = (C.c_int32 * max(1, len(partitions)))(*[len(p) for p in partitions])
+        for h in self.__dict__.get("_pcache", {}).values():
+            _check(_lib().dfgpu_plan_memory_replace(h.h, _ptrs([b._h.h for b in flat]), sizes, len(partitions)))
+
 
 class FilterExec(ExecutionPlan):
     def __init__(self, predicate: PhysicalExpr, input):

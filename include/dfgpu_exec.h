@@ -52,6 +52,9 @@ DFGPU_API void dfgpu_expr_free(dfgpu_expr *e);
 /* ---- ExecutionPlan nodes */
 /* MemoryExec: batches of all partitions back to back, partition_sizes[p] batches each */
 DFGPU_API dfgpu_status dfgpu_plan_memory(const dfgpu_batch *const *batches, const int32_t *partition_sizes, int32_t npartitions, dfgpu_plan **out);
+/* Replaces the batches of a MemoryExec in place (same schema): the input slot of a plan that is built once and executed many times
+ * -- e.g. the segment above an exchange, whose input is whatever the collective delivered in this execution. */
+DFGPU_API dfgpu_status dfgpu_plan_memory_replace(dfgpu_plan *memory_exec, const dfgpu_batch *const *batches, const int32_t *partition_sizes, int32_t npartitions);
 DFGPU_API dfgpu_status dfgpu_plan_filter(const dfgpu_expr *predicate, const dfgpu_plan *input, dfgpu_plan **out);
 DFGPU_API dfgpu_status dfgpu_plan_projection(const dfgpu_expr *const *exprs, const char *const *names, int32_t n, const dfgpu_plan *input, dfgpu_plan **out);
 DFGPU_API dfgpu_status dfgpu_plan_coalesce_batches(const dfgpu_plan *input, int64_t target_batch_size, dfgpu_plan **out);

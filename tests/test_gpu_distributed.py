@@ -37,6 +37,8 @@ def _worker(rank, world, port, sf, q, plan_name="q3_distributed_plan"):
         tc = ops.TaskContext(ctx, batch_size=8192)
         plan = getattr(tpch, plan_name)(tables)
         local = list(plan.execute(0, tc))
+        if plan_name == "Q3ColocatedStaged":
+            local = list(plan.execute(0, tc))                    # built once, executed again: the second run must not see the first one's state
         mine = ops.concat_batches(local[0].schema, local) if local else None
         gathered = exchange.gather_batches(ctx, None, mine, 0, names=["l_orderkey", "revenue", "o_orderdate", "o_shippriority"])
         if rank == 0:
@@ -51,7 +53,7 @@ def _worker(rank, world, port, sf, q, plan_name="q3_distributed_plan"):
 
 
 @pytest.mark.parametrize("world,plan_name", [(2, "q3_distributed_plan"), (3, "q3_distributed_plan"), (2, "q3_broadcast_plan"), (3, "q3_broadcast_plan"),
-                                             (2, "q3_colocated_plan"), (3, "q3_colocated_plan")])
+                                             (2, "q3_colocated_plan"), (3, "q3_colocated_plan"), (2, "Q3ColocatedStaged"), (3, "Q3ColocatedStaged")])
 def test_q3_distributed_two_ranks_one_gpu_matches_oracle(world, plan_name):
     import torch.multiprocessing as mp
     from dfgpu import tpch
@@ -60,7 +62,7 @@ def test_q3_distributed_two_ranks_one_gpu_matches_oracle(world, plan_name):
     sf = 0.05
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 1000) + world + {"q3_distributed_plan": 0, "q3_broadcast_plan": 10, "q3_colocated_plan": 20}[plan_name]
+    port = 29700 + (os.getpid() % 1000) + world + {"q3_distributed_plan": 0, "q3_broadcast_plan": 10, "q3_colocated_plan": 20, "Q3ColocatedStaged": 30}[plan_name]
     procs = [ctx.Process(target=_worker, args=(r, world, port, sf, q, plan_name)) for r in range(world)]
     for p in procs:
         p.start()

@@ -71,12 +71,13 @@ def test_q3_distributed_plan_world1_rccl_matches_single(ctx):
         single = tpch.q3_result_to_numpy(ops.collect(tpch.q3_plan(tables), tc))
         w = canon(single)
         # every N > 1 plan: all-to-all(v) (shuffle), all-gather (broadcast / colocated) and the metadata all-gather all run on RCCL here
-        for make in (tpch.q3_distributed_plan, tpch.q3_broadcast_plan, tpch.q3_colocated_plan):
+        staged = tpch.Q3ColocatedStaged(tables)
+        for make in (tpch.q3_distributed_plan, tpch.q3_broadcast_plan, tpch.q3_colocated_plan, lambda t: staged, lambda t: staged):      # the staged plan is executed twice
             local = list(make(tables).execute(0, tc))
             gathered = exchange.gather_batches(ctx, None, ops.concat_batches(local[0].schema, local), 0, names=local[0].schema.names())
             g = canon(tpch.q3_result_to_numpy([gathered]))
-            assert len(g["l_orderkey"]) == len(w["l_orderkey"]) > 0, make.__name__
+            assert len(g["l_orderkey"]) == len(w["l_orderkey"]) > 0, getattr(make, "__name__", "staged")
             for k in w:
-                assert np.array_equal(g[k], w[k]), (make.__name__, k)
+                assert np.array_equal(g[k], w[k]), (getattr(make, "__name__", "staged"), k)
     finally:
         dist.destroy_process_group()
