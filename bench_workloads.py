@@ -153,6 +153,87 @@ def main():
         del qty, batch, src, plan
         torch.cuda.empty_cache()
 
+    # ------------------------------------------------------------------ Q5: 6 tables, 5 hash joins (one on two keys), SUM by n_name (Utf8)
+    if not want or "q5" in want:
+        n_cust, n_supp = int(150_000 * args.sf), max(10, int(10_000 * args.sf))
+        ii = torch.arange(n_orders, dtype=torch.int64, device="cuda")
+        o_orderkey = (ii // 8) * 32 + (ii % 8) + 1
+        del ii
+        o_custkey = torch.randint(1, n_cust + 1, (n_orders,), generator=g, device="cuda", dtype=torch.int64)
+        o_orderdate = torch.randint(8035, 10441, (n_orders,), generator=g, device="cuda", dtype=torch.int32)
+        c_custkey = torch.arange(1, n_cust + 1, dtype=torch.int64, device="cuda")
+        c_nationkey = torch.randint(0, 25, (n_cust,), generator=g, device="cuda", dtype=torch.int64)
+        s_suppkey = torch.arange(1, n_supp + 1, dtype=torch.int64, device="cuda")
+        s_nationkey = torch.randint(0, 25, (n_supp,), generator=g, device="cuda", dtype=torch.int64)
+        l_suppkey = torch.randint(1, n_supp + 1, (n,), generator=g, device="cuda", dtype=torch.int64)
+        price, disc = dec_tensor(torch, n, 90000, 10494951, g), dec_tensor(torch, n, 0, 11, g)
+        torch.cuda.synchronize()
+        W = lambda t, ty=capi.INT64: ctx.wrap_tensor(t, ty)
+        mk = lambda names, arrays: (lambda b: ops.MemoryExec([[b]], b.schema))(ops.RecordBatch.from_arrays(ctx, names, arrays))
+        customer = mk(["c_custkey", "c_nationkey"], [W(c_custkey), W(c_nationkey)])
+        orders = mk(["o_orderkey", "o_custkey", "o_orderdate"], [W(o_orderkey), W(o_custkey), W(o_orderdate, capi.DATE32)])
+        line = mk(["l_orderkey", "l_suppkey", "l_extendedprice", "l_discount"], [W(l_orderkey), W(l_suppkey), ctx.wrap_tensor(price, capi.DECIMAL128, 15, 2), ctx.wrap_tensor(disc, capi.DECIMAL128, 15, 2)])
+        supplier = mk(["s_suppkey", "s_nationkey"], [W(s_suppkey), W(s_nationkey)])
+        nat = pa.table({"n_nationkey": pa.array(list(range(25)), type=pa.int64()), "n_name": pa.array([f"NATION{i:02d}" for i in range(25)]), "n_regionkey": pa.array([i % 5 for i in range(25)], type=pa.int64())})
+        reg = pa.table({"r_regionkey": pa.array(list(range(5)), type=pa.int64()), "r_name": pa.array(["AFRICA", "AMERICA", "ASIA", "EUROPE", "MIDDLE EAST"])})
+        nation = (lambda b: ops.MemoryExec([[b]], b.schema))(ops.batch_from_arrow(ctx, nat))
+        region = (lambda b: ops.MemoryExec([[b]], b.schema))(ops.batch_from_arrow(ctx, reg))
+        cb = lambda p: ops.CoalesceBatchesExec(p, 8192)
+        hj = lambda l, r, on: cb(ops.HashJoinExec(l, r, on, None, "Inner", "Partitioned"))
+        fo = cb(ops.FilterExec(B(B(C("o_orderdate", 2), ">=", L(8766, pa.date32())), "AND", B(C("o_orderdate", 2), "<", L(9131, pa.date32()))), orders))
+        j1 = hj(customer, fo, [(C("c_custkey", 0), C("o_custkey", 1))])
+        p1 = ops.ProjectionExec([(C("c_nationkey", 1), "c_nationkey"), (C("o_orderkey", 2), "o_orderkey")], j1)
+        j2 = hj(p1, line, [(C("o_orderkey", 1), C("l_orderkey", 0))])
+        p2 = ops.ProjectionExec([(C("c_nationkey", 0), "c_nationkey"), (C("l_suppkey", 3), "l_suppkey"), (C("l_extendedprice", 4), "l_extendedprice"), (C("l_discount", 5), "l_discount")], j2)
+        j3 = hj(supplier, p2, [(C("s_suppkey", 0), C("l_suppkey", 1)), (C("s_nationkey", 1), C("c_nationkey", 0))])
+        p3 = ops.ProjectionExec([(C("s_nationkey", 1), "s_nationkey"), (C("l_extendedprice", 4), "l_extendedprice"), (C("l_discount", 5), "l_discount")], j3)
+        fr = cb(ops.FilterExec(B(C("r_name", 1), "=", L("ASIA", pa.utf8())), region))
+        jn = hj(ops.ProjectionExec([(C("r_regionkey", 0), "r_regionkey")], fr), nation, [(C("r_regionkey", 0), C("n_regionkey", 2))])
+        pn = ops.ProjectionExec([(C("n_nationkey", 1), "n_nationkey"), (C("n_name", 2), "n_name")], jn)
+        j4 = hj(pn, p3, [(C("n_nationkey", 0), C("s_nationkey", 0))])
+        rev = B(C("l_extendedprice", 3), "*", B(L(decimal.Decimal(1), pa.decimal128(20, 0)), "-", C("l_discount", 4)))
+        agg = ops.AggregateExec("Single", [(C("n_name", 1), "n_name")], [ops.AggregateFunctionExpr("SUM", rev, "revenue", input_field=F("r", capi.DECIMAL128, 38, 4))], j4)
+        plan = ops.SortExec([ops.PhysicalSortExpr(C("revenue", 1), True, True)], agg)
+        rows_in = n + n_orders + n_cust + n_supp + 30
+        dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan, args.steps, args.warmup)
+        bytes_total = n * (8 + 8 + 16 + 16) + n_orders * (8 + 8 + 4) + n_cust * 16 + n_supp * 16
+        report("q5", dt, rows_in, rows, round(bytes_total / rows_in, 2), kern, syncs)
+        del customer, orders, line, supplier, plan, price, disc, l_suppkey, o_custkey, o_orderdate, o_orderkey
+        torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ Q18: sub-aggregate + HAVING -> LeftSemi against customer-orders-lineitem, 5-key group-by
+    if not want or "q18" in want:
+        n_cust = int(150_000 * args.sf)
+        ii = torch.arange(n_orders, dtype=torch.int64, device="cuda")
+        o_orderkey = (ii // 8) * 32 + (ii % 8) + 1
+        del ii
+        o_custkey = torch.randint(1, n_cust + 1, (n_orders,), generator=g, device="cuda", dtype=torch.int64)
+        o_orderdate = torch.randint(8035, 10441, (n_orders,), generator=g, device="cuda", dtype=torch.int32)
+        o_totalprice = dec_tensor(torch, n_orders, 10**5, 5 * 10**7, g)
+        c_custkey = torch.arange(1, n_cust + 1, dtype=torch.int64, device="cuda")
+        qty = dec_tensor(torch, n, 100, 5001, g)
+        torch.cuda.synchronize()
+        W = lambda t, ty=capi.INT64: ctx.wrap_tensor(t, ty)
+        mk = lambda names, arrays: (lambda b: ops.MemoryExec([[b]], b.schema))(ops.RecordBatch.from_arrays(ctx, names, arrays))
+        customer = mk(["c_custkey"], [W(c_custkey)])          # c_name is a function of c_custkey in TPC-H ("Customer#%09d"); carried as the key itself
+        orders = mk(["o_orderkey", "o_custkey", "o_totalprice", "o_orderdate"], [W(o_orderkey), W(o_custkey), ctx.wrap_tensor(o_totalprice, capi.DECIMAL128, 15, 2), W(o_orderdate, capi.DATE32)])
+        line = mk(["l_orderkey", "l_quantity"], [W(l_orderkey), ctx.wrap_tensor(qty, capi.DECIMAL128, 15, 2)])
+        qf = F("q", capi.DECIMAL128, 15, 2)
+        sub = ops.AggregateExec("Single", [(C("l_orderkey", 0), "l_orderkey")], [ops.AggregateFunctionExpr("SUM", C("l_quantity", 1), "SUM(l_quantity)", input_field=qf)], line)
+        having = ops.CoalesceBatchesExec(ops.FilterExec(B(C("SUM(l_quantity)", 1), ">", L(decimal.Decimal(300), pa.decimal128(25, 2))), sub), 8192)
+        j1 = ops.HashJoinExec(customer, orders, [(C("c_custkey", 0), C("o_custkey", 1))], None, "Inner", "CollectLeft")          # c_custkey,o_orderkey,o_custkey,o_totalprice,o_orderdate
+        j2 = ops.HashJoinExec(j1, line, [(C("o_orderkey", 1), C("l_orderkey", 0))], None, "Inner", "CollectLeft")                 # + l_orderkey,l_quantity
+        semi = ops.HashJoinExec(j2, ops.ProjectionExec([(C("l_orderkey", 0), "l_orderkey")], having), [(C("o_orderkey", 1), C("l_orderkey", 0))], None, "LeftSemi", "CollectLeft")
+        gby = [(C("c_custkey", 0), "c_custkey"), (C("o_orderkey", 1), "o_orderkey"), (C("o_orderdate", 4), "o_orderdate"), (C("o_totalprice", 3), "o_totalprice")]
+        agg = ops.AggregateExec("Single", gby, [ops.AggregateFunctionExpr("SUM", C("l_quantity", 6), "SUM(l_quantity)", input_field=qf)], semi)
+        plan = ops.SortExec([ops.PhysicalSortExpr(C("o_totalprice", 3), True, True), ops.PhysicalSortExpr(C("o_orderdate", 2), False, False)], agg)
+        rows_in = 2 * n + n_orders + n_cust
+        dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan, args.steps, args.warmup)
+        bytes_total = 2 * n * (8 + 16) + n_orders * (8 + 8 + 16 + 4) + n_cust * 8
+        report("q18", dt, rows_in, rows, round(bytes_total / rows_in, 2), kern, syncs)
+        del customer, orders, line, plan, qty, o_totalprice, o_custkey, o_orderdate, o_orderkey
+        torch.cuda.empty_cache()
+
     # ------------------------------------------------------------------ ClickBench-style string-key group-by (100 M rows at sf 100)
     nrows = int(1_000_000 * args.sf)
     for card, zipf in ((1000, False), (1_000_000, False), (20_000_000, False), (1_000_000, True)):

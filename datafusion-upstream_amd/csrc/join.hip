@@ -37,6 +37,9 @@ struct dfgpu_join_table {
   // The bitmap IS the table: build row = rank of the key's bit among the set bits (word prefix + popcount), mapped through
   // sel_rows when a build selection is fused; rank_identity = the keys are key_min + row, so the row is the key offset.
   bool rank_mode = false, rank_identity = false;
+  // rank_runs: the keys are non-decreasing WITH repeats (a sorted foreign key): sel_rows[r] = first build row of the r-th distinct key,
+  // its rows are the run up to sel_rows[r + 1] (or n_build) -- the CSR of the hash path without hashing or sorting
+  bool rank_runs = false;
   BufferPtr rank_prefix;  // u32[range / 64]   set bits before each bitmap word
   dfgpu_array* sel_rows = nullptr;   // u32[selected] ascending build rows (masked builds only)
   int64_t mem = 0;
@@ -189,7 +192,7 @@ __global__ void __launch_bounds__(BLOCK) k_probe_expand(const uint32_t* rows, co
   int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= m) return;
   uint32_t c = cnt[i], st = slot_start[slot_of[i]], j = rows[i]; uint64_t o = offsets[i];
-  for (uint32_t k = 0; k < c; k++) { out_build[o + k] = csr_rows[st + k]; out_probe[o + k] = j; }
+  for (uint32_t k = 0; k < c; k++) { out_build[o + k] = csr_rows ? csr_rows[st + k] : st + k; out_probe[o + k] = j; }      // csr_rows == null: the run is contiguous (rank_runs)
 }
 // ---- membership bitmap of the build keys
 template <typename T>
@@ -216,11 +219,31 @@ __global__ void __launch_bounds__(BLOCK) k_key_setbits(const T* keys, const uint
 }
 // ---- rank index: the build keys are strictly increasing, so the membership bitmap alone locates the build row
 template <typename T>
-__global__ void __launch_bounds__(BLOCK) k_check_increasing(const T* keys, int64_t n, unsigned long long* out /* [0] flag, [1] first key, [2] last key */) {
-  bool bad = false;
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x + 1; i < n; i += (int64_t)gridDim.x * BLOCK) bad |= !(keys[i - 1] < keys[i]);
+__global__ void __launch_bounds__(BLOCK) k_check_increasing(const T* keys, int64_t n, unsigned long long* out /* [0] not sorted, [1] first key, [2] last key, [3] repeats */) {
+  bool bad = false, dup = false;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x + 1; i < n; i += (int64_t)gridDim.x * BLOCK) { T a = keys[i - 1], b = keys[i]; bad |= b < a; dup |= a == b; }
   if (ballot64(bad) && lane_id() == 0) out[0] = 1ull;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { out[1] = (unsigned long long)(long long)keys[0]; out[2] = (unsigned long long)(long long)keys[n - 1]; }   // one read-back for all three
+  if (ballot64(dup) && lane_id() == 0) out[3] = 1ull;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { out[1] = (unsigned long long)(long long)keys[0]; out[2] = (unsigned long long)(long long)keys[n - 1]; }   // one read-back for all of them
+}
+// heads bit i = row i starts a run of equal keys
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_key_run_heads(const T* keys, int64_t n, uint64_t* heads) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  bool h = i < n && (i == 0 || keys[i - 1] != keys[i]);
+  uint64_t m = ballot64(h);
+  if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) heads[i >> 6] = m;
+}
+// matched probe rows of a rank_runs build: rank of the key -> (run id, run length)
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_probe_lookup_runs(const T* pkeys, const uint32_t* rows, int64_t m, int64_t kmin, const uint64_t* bitmap, const uint32_t* prefix,
+                                                             const uint32_t* run_starts, int64_t n_runs, int64_t n_build, uint32_t* out_run, uint32_t* out_cnt) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= m) return;
+  uint64_t d = (uint64_t)((int64_t)pkeys[rows[i]] - kmin);
+  uint32_t r = prefix[d >> 6] + (uint32_t)__popcll(bitmap[d >> 6] & ((1ull << (d & 63)) - 1ull));
+  uint32_t st = run_starts[r], en = (int64_t)r + 1 < n_runs ? run_starts[r + 1] : (uint32_t)n_build;
+  out_run[i] = r; out_cnt[i] = en - st;
 }
 // set the bit of every selected row's key.  Equal bitmap words of neighbouring lanes are OR-combined first (segmented
 // scan over runs of the same word; sorted keys put 16+ lanes on one word) so one atomic per run reaches L2.
@@ -361,17 +384,26 @@ static bool build_rank_index(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   zero_scratch(ctx);
   DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_check_increasing<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 8)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, n, (unsigned long long*)ctx->d_scratch64));
   KERNEL_CHECK();
-  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 0, ctx->d_scratch64, 24, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 0, ctx->d_scratch64, 32, hipMemcpyDeviceToHost, ctx->stream));
   ctx->count_sync("sync:rank_index_check");
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (ctx->h_pinned[0] != 0) return false;
+  const bool runs = ctx->h_pinned[3] != 0;                 // sorted with repeats
+  if (runs && (t->build_mask || n > 0xFFFFFFF0ll)) return false;
   long long lo = (long long)ctx->h_pinned[1], hi = (long long)ctx->h_pinned[2];       // sign/zero-extended by the kernel
   uint64_t range = (uint64_t)hi - (uint64_t)lo + 1;
   if (range == 0 || range > (1ull << 32) || range > (uint64_t)n * 4096 + 65536) return false;
   const uint64_t* mk = t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr;
   int64_t nw = (int64_t)((range + 63) / 64);
   t->key_min = lo; t->range = range;
-  t->rank_mode = true; t->unique = true; t->rank_identity = range == (uint64_t)n;
+  t->rank_mode = true; t->unique = !runs; t->rank_runs = runs; t->rank_identity = !runs && range == (uint64_t)n;
+  BufferPtr heads;
+  if (runs) {             // one bit per run head: it is the selection for the key bitmap, and its indices are the run starts
+    heads = alloc_buffer(ctx, bitmap_bytes(n));
+    DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_run_heads<T>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, n, (uint64_t*)heads->ptr));
+    KERNEL_CHECK();
+    mk = (const uint64_t*)heads->ptr;
+  }
   if (t->rank_identity && mk) t->bitmap = t->build_mask;       // key = key_min + row: the build selection IS the membership bitmap
   else {
     t->bitmap = alloc_buffer(ctx, bitmap_bytes((int64_t)range)); t->mem += (int64_t)bitmap_bytes((int64_t)range);
@@ -385,7 +417,7 @@ static bool build_rank_index(dfgpu_ctx* ctx, dfgpu_join_table* t) {
     exclusive_scan_u32_inplace32(ctx, (uint32_t*)t->rank_prefix->ptr, nw, nullptr);
     KERNEL_CHECK();
     t->mem += nw * 4;
-    if (mk) { t->sel_rows = mask_to_indices_impl(ctx, mk, n); t->mem += t->sel_rows->length * 4; }
+    if (mk) { t->sel_rows = mask_to_indices_impl(ctx, mk, n); t->mem += t->sel_rows->length * 4; }          // masked build: rank -> build row; runs: rank -> first row of the run
   }
   return true;
 }
@@ -451,7 +483,26 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
     int64_t m = rows.get()->length;
     const uint32_t* rp = (const uint32_t*)rows.get()->values->ptr;
     ArrayHolder ob, op;
-    if (t->rank_mode && use_bitmap) {
+    if (t->rank_mode && use_bitmap && t->rank_runs) {          // sorted build key with repeats: every match emits its contiguous run
+      const dfgpu_array* pk = probe_keys[0];
+      BufferPtr run_of = alloc_buffer(ctx, (size_t)(m + 1) * 4), cnt = alloc_buffer(ctx, (size_t)(m + 1) * 4), offs = alloc_buffer(ctx, (size_t)(m + 1) * 8);
+      int64_t total = 0;
+      if (m) {
+        { KernelTimer kt_(ctx, "k_probe_lookup_rank");
+          DFGPU_INT_KEY_DISPATCH(pk->type, hipLaunchKernelGGL((k_probe_lookup_runs<T>), dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const T*)pk->values->ptr, rp, m, t->key_min,
+                                                              (const uint64_t*)t->bitmap->ptr, (const uint32_t*)t->rank_prefix->ptr, (const uint32_t*)t->sel_rows->values->ptr, t->sel_rows->length, t->n_build,
+                                                              (uint32_t*)run_of->ptr, (uint32_t*)cnt->ptr)); }
+        KERNEL_CHECK();
+        exclusive_scan_u32(ctx, (const uint32_t*)cnt->ptr, (uint64_t*)offs->ptr, m, ctx->d_scratch64 + 8);
+        total = (int64_t)read_scratch(ctx, 8);
+      }
+      if (total > 0xFFFFFFF0ll) fail(DFGPU_RESOURCES_EXHAUSTED, "join output of %lld rows for one probe batch; split the probe batch", (long long)total);
+      ob.a = new_fixed(ctx, DFGPU_UINT64, total); op.a = new_fixed(ctx, DFGPU_UINT32, total);
+      if (total) { KernelTimer kt_(ctx, "k_probe_expand");
+        hipLaunchKernelGGL(k_probe_expand, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, rp, (const uint32_t*)run_of->ptr, (const uint32_t*)cnt->ptr, (const uint64_t*)offs->ptr, m,
+                           (const uint32_t*)t->sel_rows->values->ptr, (const uint32_t*)nullptr, (uint64_t*)ob.get()->values->ptr, (uint32_t*)op.get()->values->ptr); }
+      KERNEL_CHECK();
+    } else if (t->rank_mode && use_bitmap) {
       ob.a = new_fixed(ctx, DFGPU_UINT64, m);
       const dfgpu_array* pk = probe_keys[0];
       if (m) { KernelTimer kt_(ctx, "k_probe_lookup_rank");

@@ -129,17 +129,19 @@ def test_probe_with_fused_masks_equals_filtered_inputs(ctx):
 
 def sorted_unique_keys(n, dtype, shape):
     """strictly increasing build keys: 'dense' = k0 + row (identity), 'sparse' = TPC-H style gaps, 'wide' = too sparse for a bitmap."""
-    if shape == "dense": k = np.arange(n, dtype=np.int64) - 1000
+    if shape == "dups": k = np.sort(RNG.integers(0, n // 3, n)) * 3 - 700          # non-decreasing with repeats (a sorted foreign key)
+    elif shape == "dense": k = np.arange(n, dtype=np.int64) - 1000
     elif shape == "sparse": k = np.cumsum(RNG.integers(1, 9, n)) - 5000
     else: k = np.cumsum(RNG.integers(1, 10**7 if dtype == np.int64 else 50000, n))
     return k.astype(dtype)
 
 
 @pytest.mark.parametrize("dtype", [np.int32, np.int64], ids=["int32", "int64"])
-@pytest.mark.parametrize("shape", ["dense", "sparse", "wide"])
+@pytest.mark.parametrize("shape", ["dense", "sparse", "wide", "dups"])
 @pytest.mark.parametrize("masked", [False, True])
 def test_rank_index_build_equals_hash_build_and_oracle(ctx, dtype, shape, masked):
-    """Strictly increasing integer build keys take the bitmap rank index (join.hip build_rank_index) instead of the hash table:
+    """Sorted integer build keys (strictly increasing, or -- "dups" -- non-decreasing with repeats, whose equal keys form contiguous
+    runs) take the bitmap rank index (join.hip build_rank_index) instead of the hash table:
     pairs must equal the oracle's and the hash-table path's (option join_rank_index=0), probe NULLs / misses / selection included."""
     import dfgpu
     nb, npr = 40000, 150000
