@@ -151,3 +151,108 @@ def test_exchange_of_utf8_and_nullable_utf8_columns(world):
             assert owner.setdefault(row[0], r) == r, "equal keys must land on one rank"
     for r in range(world):
         assert results[r]["broadcast"] == everything
+
+
+def _q5_tables(seed=77):
+    import decimal
+    import pyarrow as pa
+    rng = np.random.default_rng(seed)
+    dec = lambda v: pa.array([decimal.Decimal(int(x)).scaleb(-2) for x in v], type=pa.decimal128(15, 2))
+    nc, no, nl, ns = 600, 3000, 12000, 80
+    customer = pa.table({"c_custkey": pa.array(np.arange(nc, dtype=np.int64)), "c_nationkey": pa.array(rng.integers(0, 25, nc).astype(np.int64))})
+    orders = pa.table({"o_orderkey": pa.array(np.arange(no, dtype=np.int64) * 4 + 1), "o_custkey": pa.array(rng.integers(0, nc, no).astype(np.int64)),
+                       "o_orderdate": pa.array(rng.integers(8766, 9500, no).astype(np.int32)).cast(pa.date32())})
+    line = pa.table({"l_orderkey": pa.array(rng.integers(0, no, nl).astype(np.int64) * 4 + 1), "l_suppkey": pa.array(rng.integers(0, ns, nl).astype(np.int64)),
+                     "l_extendedprice": dec(rng.integers(90000, 10494951, nl)), "l_discount": dec(rng.integers(0, 11, nl))})
+    supplier = pa.table({"s_suppkey": pa.array(np.arange(ns, dtype=np.int64)), "s_nationkey": pa.array(rng.integers(0, 25, ns).astype(np.int64))})
+    nation = pa.table({"n_nationkey": pa.array(np.arange(25, dtype=np.int64)), "n_name": pa.array([f"NATION{i:02d}" for i in range(25)]), "n_regionkey": pa.array((np.arange(25) % 5).astype(np.int64))})
+    region = pa.table({"r_regionkey": pa.array(np.arange(5, dtype=np.int64)), "r_name": pa.array(["AFRICA", "AMERICA", "ASIA", "EUROPE", "MIDDLE EAST"])})
+    return dict(customer=customer, orders=orders, line=line, supplier=supplier, nation=nation, region=region)
+
+
+def _q5_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        import decimal
+        import faulthandler
+        faulthandler.dump_traceback_later(140, exit=True)
+        import pyarrow as pa
+        import torch
+        import torch.distributed as dist
+        import dfgpu
+        from dfgpu import exchange, physical_plan as ops
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ctx = dfgpu.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        tc = ops.TaskContext(ctx, 8192)
+        t = _q5_tables()
+        shard = lambda tab: tab.slice(tab.num_rows * rank // world, tab.num_rows * (rank + 1) // world - tab.num_rows * rank // world)      # round-robin file groups
+        def mem(tab):
+            b = ops.batch_from_arrow(ctx, shard(tab))
+            return ops.MemoryExec([[b]], b.schema)
+        C, L, B = ops.Column, ops.Literal, ops.BinaryExpr
+        rep = lambda plan, keys: ops.CoalesceBatchesExec(exchange.ShuffleExec(plan, keys), 8192)         # RepartitionExec Hash(keys, world) across ranks
+        hj = lambda l, r, on: ops.CoalesceBatchesExec(ops.HashJoinExec(l, r, on, None, "Inner", "Partitioned"), 8192)
+        fo = ops.FilterExec(B(B(C("o_orderdate", 2), ">=", L(8766, pa.date32())), "AND", B(C("o_orderdate", 2), "<", L(9131, pa.date32()))), mem(t["orders"]))
+        j1 = hj(rep(mem(t["customer"]), [C("c_custkey", 0)]), rep(fo, [C("o_custkey", 1)]), [(C("c_custkey", 0), C("o_custkey", 1))])
+        p1 = ops.ProjectionExec([(C("c_nationkey", 1), "c_nationkey"), (C("o_orderkey", 2), "o_orderkey")], j1)
+        j2 = hj(rep(p1, [C("o_orderkey", 1)]), rep(mem(t["line"]), [C("l_orderkey", 0)]), [(C("o_orderkey", 1), C("l_orderkey", 0))])
+        p2 = ops.ProjectionExec([(C("c_nationkey", 0), "c_nationkey"), (C("l_suppkey", 3), "l_suppkey"), (C("l_extendedprice", 4), "l_extendedprice"), (C("l_discount", 5), "l_discount")], j2)
+        j3 = hj(rep(mem(t["supplier"]), [C("s_suppkey", 0), C("s_nationkey", 1)]), rep(p2, [C("l_suppkey", 1), C("c_nationkey", 0)]),
+                [(C("s_suppkey", 0), C("l_suppkey", 1)), (C("s_nationkey", 1), C("c_nationkey", 0))])                      # TWO-key partitioned join
+        p3 = ops.ProjectionExec([(C("s_nationkey", 1), "s_nationkey"), (C("l_extendedprice", 4), "l_extendedprice"), (C("l_discount", 5), "l_discount")], j3)
+        fr = ops.FilterExec(B(C("r_name", 1), "=", L("ASIA", pa.utf8())), mem(t["region"]))
+        jn = hj(rep(ops.ProjectionExec([(C("r_regionkey", 0), "r_regionkey")], fr), [C("r_regionkey", 0)]), rep(mem(t["nation"]), [C("n_regionkey", 2)]), [(C("r_regionkey", 0), C("n_regionkey", 2))])
+        pn = ops.ProjectionExec([(C("n_nationkey", 1), "n_nationkey"), (C("n_name", 2), "n_name")], jn)          # n_name: Utf8 through the exchange
+        j4 = hj(rep(pn, [C("n_nationkey", 0)]), rep(p3, [C("s_nationkey", 0)]), [(C("n_nationkey", 0), C("s_nationkey", 0))])
+        rev = B(C("l_extendedprice", 3), "*", B(L(decimal.Decimal(1), pa.decimal128(20, 0)), "-", C("l_discount", 4)))
+        aggs = [ops.AggregateFunctionExpr("SUM", rev, "revenue", input_field=ops.Field("r", dfgpu.capi.DECIMAL128, 38, 4))]
+        partial = ops.AggregateExec("Partial", [(C("n_name", 1), "n_name")], aggs, j4)
+        final = ops.AggregateExec("FinalPartitioned", [(C("n_name", 0), "n_name")], aggs, rep(partial, [C("n_name", 0)]))       # Utf8 group key + nullable Decimal128 state shuffled
+        local = [b for b in final.execute(0, tc)]
+        mine = ops.concat_batches(local[0].schema, local) if local else None
+        g = exchange.gather_batches(ctx, None, mine, 0, names=["n_name", "revenue"])
+        rows = sorted(zip(*[c.to_arrow().to_pylist() for c in g.columns])) if rank == 0 and g.num_rows else []
+        q.put((rank, rows))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_q5_partitioned_joins_over_all_to_all(world):
+    """BASELINE config 4's shape (tpch/q5.slt.part): every join input and the partial aggregate hash-repartitioned across ranks
+    (ShuffleExec = device hash partition + all-to-all), one join on TWO keys, a Utf8 column and a Utf8 group key through the exchange;
+    the gathered result must equal the single-process oracle."""
+    import decimal
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    import torch.multiprocessing as mp
+    from oracle import pyoracle as po
+    from test_gpu_workloads import oracle_agg, oracle_join
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() % 600) + world
+    procs = [ctx.Process(target=_q5_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=160) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        assert isinstance(results[r], list), results[r]
+    t = _q5_tables()
+    okeep = pc.and_(pc.greater_equal(t["orders"]["o_orderdate"].cast(pa.int32()), 8766), pc.less(t["orders"]["o_orderdate"].cast(pa.int32()), 9131))
+    x = oracle_join(t["customer"], t["orders"].filter(okeep), ["c_custkey"], ["o_custkey"]).select(["c_nationkey", "o_orderkey"])
+    x = oracle_join(x, t["line"], ["o_orderkey"], ["l_orderkey"]).select(["c_nationkey", "l_suppkey", "l_extendedprice", "l_discount"])
+    x = oracle_join(t["supplier"], x, ["s_suppkey", "s_nationkey"], ["l_suppkey", "c_nationkey"]).select(["s_nationkey", "l_extendedprice", "l_discount"])
+    nt = oracle_join(t["region"].filter(pc.equal(t["region"]["r_name"], "ASIA")).select(["r_regionkey"]), t["nation"], ["r_regionkey"], ["n_regionkey"]).select(["n_nationkey", "n_name"])
+    x = oracle_join(nt, x, ["n_nationkey"], ["s_nationkey"])
+    r = po.binary("*", x["l_extendedprice"], po.binary("-", pa.array([decimal.Decimal(1)], type=pa.decimal128(20, 0)), x["l_discount"], l_scalar=True))
+    want = oracle_agg(x.append_column("rev", r), ["n_name"], [("SUM", "rev")])
+    want_rows = sorted(zip(want["c0"].to_pylist(), want["c1"].to_pylist()))
+    assert len(want_rows) == 5 and results[0] == want_rows
