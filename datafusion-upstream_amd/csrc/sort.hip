@@ -161,6 +161,42 @@ __global__ void __launch_bounds__(BLOCK) k_plane_varies(const uint8_t* planes, i
   if (ballot64(diff) && lane_id() == 0) varies[blockIdx.y] = 1u;
 }
 
+// ---- TopK (SortExec with fetch, ≙ physical-plan/src/topk/mod.rs): radix SELECT over the same order-preserving byte planes, most
+// significant varying plane first.  One step applies the previous plane's decision (digit < chosen: accepted into the top set;
+// == chosen: still a candidate; > chosen: out) and histograms the next plane over the surviving candidates.  The host picks the digit
+// holding the k-th row.  When few candidates are left they all join the accepted rows and that small set is sorted by the full path --
+// same rows and same order as sorting everything and slicing (ties keep row order).
+__global__ void __launch_bounds__(BLOCK) k_topk_step(const uint8_t* planes, int64_t n, int prev_plane, int prev_digit, int cur_plane, uint64_t* cand, uint64_t* accept, uint32_t* hist) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  int lane = lane_id();
+  int64_t nw = (n + 63) >> 6;
+  for (int64_t w = (int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6); w < nw; w += (int64_t)gridDim.x * (BLOCK / WAVE)) {
+    int64_t i = w * 64 + lane;
+    bool c = i < n && ((cand[w] >> lane) & 1ull), acc = false;
+    if (prev_plane >= 0 && c) { int dg = planes[(int64_t)prev_plane * n + i]; if (dg < prev_digit) { acc = true; c = false; } else if (dg > prev_digit) c = false; }
+    uint64_t cm = ballot64(c), am = ballot64(acc);
+    if (lane == 0 && prev_plane >= 0) { cand[w] = cm; if (am) accept[w] |= am; }
+    if (cur_plane >= 0 && cm) {
+      int d = c ? (int)planes[(int64_t)cur_plane * n + i] : -1;
+      uint64_t left = cm;
+      while (left) {                                            // one LDS add per distinct digit of the wave (a near-constant plane would serialise 64 ways)
+        int src = __ffsll((long long)left) - 1; int d0 = __shfl(d, src, 64);
+        uint64_t same = ballot64(d == d0);
+        if (lane == 0) atomicAdd(&h[d0], (uint32_t)__popcll(same));
+        left &= ~same;
+      }
+    }
+  }
+  __syncthreads();
+  if (cur_plane >= 0 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void k_or_words(const uint64_t* a, const uint64_t* b, uint64_t* out, int64_t nw) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nw) out[i] = a[i] | b[i];
+}
+
 }  // namespace dfgpu
 
 using namespace dfgpu;
@@ -196,6 +232,47 @@ extern "C" dfgpu_status dfgpu_sort_to_indices(dfgpu_ctx* ctx, const dfgpu_array*
       std::vector<uint32_t> h((size_t)W);
       HIP_CHECK(hipMemcpyAsync(h.data(), varies->ptr, h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
       HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      if (fetch > 0 && fetch * 16 <= n && n >= (1 << 16)) {          // TopK: select, then sort the few selected rows
+        std::vector<int> vp; for (int b = 0; b < W; b++) if (h[(size_t)b]) vp.push_back(b);
+        int64_t nwords = (n + 63) / 64, remaining = fetch, ncand = n; bool small = false;
+        BufferPtr cand = alloc_buffer(ctx, (size_t)nwords * 8), accept = alloc_buffer(ctx, (size_t)nwords * 8, true), hist = alloc_buffer(ctx, 256 * 4);
+        HIP_CHECK(hipMemsetAsync(cand->ptr, 0xFF, (size_t)nwords * 8, ctx->stream));        // bits >= n are masked by i < n in the kernel
+        KernelTimer kt_(ctx, "k_topk_select");
+        int grid = grid_for(nwords, BLOCK / WAVE, ctx->num_cus * 16);
+        int prev = -1, prev_digit = 0;
+        for (size_t it = 0; it <= vp.size() && !small; it++) {
+          int cur = it < vp.size() ? vp[it] : -1;
+          if (cur >= 0) HIP_CHECK(hipMemsetAsync(hist->ptr, 0, 256 * 4, ctx->stream));
+          hipLaunchKernelGGL(k_topk_step, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const uint8_t*)planes->ptr, n, prev, prev_digit, cur, (uint64_t*)cand->ptr, (uint64_t*)accept->ptr, (uint32_t*)hist->ptr);
+          KERNEL_CHECK();
+          if (cur < 0) break;
+          uint32_t hh[256];
+          HIP_CHECK(hipMemcpyAsync(hh, hist->ptr, sizeof hh, hipMemcpyDeviceToHost, ctx->stream));
+          ctx->count_sync("sync:topk_histogram");
+          HIP_CHECK(hipStreamSynchronize(ctx->stream));
+          int64_t cum = 0; int d = 0;
+          for (; d < 255; d++) { if (cum + (int64_t)hh[d] >= remaining) break; cum += hh[d]; }
+          remaining -= cum; ncand = hh[d]; prev = cur; prev_digit = d;
+          if (ncand <= remaining + 4096) {                     // few enough: apply this decision and stop selecting
+            hipLaunchKernelGGL(k_topk_step, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const uint8_t*)planes->ptr, n, prev, prev_digit, -1, (uint64_t*)cand->ptr, (uint64_t*)accept->ptr, (uint32_t*)hist->ptr);
+            KERNEL_CHECK(); small = true;
+          }
+        }
+        if (small) {
+          hipLaunchKernelGGL(k_or_words, dim3(grid_for(nwords, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)accept->ptr, (const uint64_t*)cand->ptr, (uint64_t*)accept->ptr, nwords);
+          KERNEL_CHECK();
+          ArrayHolder rows(mask_to_indices_impl(ctx, (const uint64_t*)accept->ptr, n));         // the top set plus boundary ties, ascending row order
+          std::vector<ArrayHolder> keys((size_t)k); std::vector<const dfgpu_array*> kp;
+          for (int c = 0; c < k; c++) { keys[(size_t)c].a = take_impl(ctx, cols[c], rows.get()->values->ptr, 4, nullptr, rows.get()->length); kp.push_back(keys[(size_t)c].get()); }
+          dfgpu_array* local = nullptr;
+          dfgpu_status st = dfgpu_sort_to_indices(ctx, kp.data(), descending, nulls_first, k, fetch, &local);      // small: the full path (stable)
+          if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str());
+          ArrayHolder lh(local);
+          *out = take_impl(ctx, rows.get(), lh.get()->values->ptr, 4, nullptr, lh.get()->length);
+          return;
+        }
+        // every varying plane is decided and the candidates (rows with identical keys) still outnumber what is needed: sort everything
+      }
       RadixPlan p = plan_for(n);
       BufferPtr tmp = alloc_buffer(ctx, (size_t)n * 4), hist = alloc_buffer(ctx, (size_t)256 * p.nb * 4);
       uint32_t *v0 = (uint32_t*)idx.get()->values->ptr, *v1 = (uint32_t*)tmp->ptr;

@@ -57,6 +57,38 @@ def test_multi_column_sort_q3_shape_and_fetch(ctx):
     assert np.array_equal(got3, po.lexsort_to_indices(three, [False, True, False], [False, True, True]))
 
 
+@pytest.mark.parametrize("kind", ["int64", "float64", "decimal", "int8", "utf8", "mixed", "ties"])
+@pytest.mark.parametrize("desc,nf_first", [(False, True), (True, False)])
+def test_topk_selection_equals_full_sort_then_slice(ctx, kind, desc, nf_first):
+    """SortExec with fetch (≙ physical-plan/src/topk/mod.rs) on inputs large enough for the radix-select path (sort.hip k_topk_step):
+    indices must equal the first `fetch` indices of the full (stable) sort -- ties at the boundary keep row order, NULL / NaN
+    placement included; an input whose keys are all equal falls back to the full sort."""
+    import decimal
+    n = 200000
+    if kind == "utf8":
+        cols = [pa.array([None if RNG.random() < 0.05 else f"k{v:07d}" for v in RNG.integers(0, 10**6, n)], type=pa.utf8())]
+    elif kind == "mixed":
+        cols = [pa.array(RNG.integers(0, 50, n).astype(np.int32)), pa.array([None if RNG.random() < 0.1 else float(v) for v in RNG.integers(0, 1000, n)], type=pa.float64()),
+                pa.array([decimal.Decimal(int(v)).scaleb(-2) for v in RNG.integers(-10**6, 10**6, n)], type=pa.decimal128(15, 2))]
+    elif kind == "ties":
+        cols = [pa.array(np.full(n, 7, dtype=np.int64))]
+    elif kind == "decimal":
+        cols = [pa.array([None if RNG.random() < 0.1 else decimal.Decimal(int(v)).scaleb(-2) for v in RNG.integers(-10**13, 10**13, n)], type=pa.decimal128(15, 2))]
+    elif kind == "float64":
+        v = RNG.normal(size=n); v[RNG.random(n) < 0.01] = np.nan
+        cols = [pa.array(v, mask=RNG.random(n) < 0.05)]
+    else:
+        cols = [rand_array(kind, n, 0.1, RNG)]
+    d, f = [desc] * len(cols), [nf_first] * len(cols)
+    if kind == "mixed":
+        d, f = [desc, not desc, desc], [nf_first, not nf_first, nf_first]
+    dev = [ctx.from_arrow(c) for c in cols]
+    full = po.lexsort_to_indices(cols, d, f)
+    for fetch in (1, 25, 1000, n // 16):
+        got = ctx.sort_to_indices(dev, d, f, fetch=fetch).to_numpy()
+        assert np.array_equal(got, full[:fetch]), f"fetch={fetch}"
+
+
 @pytest.mark.parametrize("desc,nf_first", [(False, True), (True, False)])
 def test_utf8_and_mixed_sort_keys(ctx, desc, nf_first):
     """Q1 sorts on two Utf8 columns (tpch/q1.slt.part SortExec [l_returnflag ASC, l_linestatus ASC]): byte-wise order, prefix first."""
