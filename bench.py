@@ -42,6 +42,53 @@ KERNEL_BYTES_PER_ROW = {
 }
 
 
+def acero_q3(host, tpch, n_in):
+    """TPC-H Q3 over the same host sample with pyarrow Acero (Table.join / group_by / sort_by, all host threads); money as Float64
+    because Acero's decimal typing differs from DataFusion's.  1 warm-up + 1 timed run."""
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    cust = pa.table({"c_custkey": host["c_custkey"], "seg": host["c_mktsegment"]})
+    orders = pa.table({"o_orderkey": host["o_orderkey"], "o_custkey": host["o_custkey"], "o_orderdate": host["o_orderdate"], "o_shippriority": host["o_shippriority"]})
+    line = pa.table({"l_orderkey": host["l_orderkey"], "l_extendedprice": host["l_extendedprice"][:, 0].astype(np.float64) / 100.0,
+                     "l_discount": host["l_discount"][:, 0].astype(np.float64) / 100.0, "l_shipdate": host["l_shipdate"]})
+    seg = tpch.SEGMENTS.index(tpch.Q3_SEGMENT)
+
+    def run():
+        t = time.perf_counter()
+        c = cust.filter(pc.equal(cust["seg"], seg)).select(["c_custkey"])
+        o = orders.filter(pc.less(orders["o_orderdate"], tpch.Q3_DATE))
+        l = line.filter(pc.greater(line["l_shipdate"], tpch.Q3_DATE))
+        l = l.append_column("rev", pc.multiply(l["l_extendedprice"], pc.subtract(1.0, l["l_discount"]))).select(["l_orderkey", "rev"])
+        j1 = o.join(c, keys="o_custkey", right_keys="c_custkey", join_type="inner").select(["o_orderkey", "o_orderdate", "o_shippriority"])
+        j2 = l.join(j1, keys="l_orderkey", right_keys="o_orderkey", join_type="inner")
+        g = j2.group_by(["l_orderkey", "o_orderdate", "o_shippriority"]).aggregate([("rev", "sum")])
+        r = g.sort_by([("rev_sum", "descending"), ("o_orderdate", "ascending")])
+        return time.perf_counter() - t, r.num_rows
+    run()
+    dt, rows = run()
+    return {"value": round(n_in / dt, 1), "unit": "rows/s", "seconds": round(dt, 3), "result_rows": rows,
+            "note": f"pyarrow {pa.__version__} Acero, independent engine (not DataFusion), Float64 money, same SF sample, all host threads"}
+
+
+def measure_copy_bandwidth(torch):
+    """Device-to-device copy of 4 GiB with torch's copy kernel: the practical HBM ceiling on this box (read + write bytes / time)."""
+    a = torch.empty(1 << 30, dtype=torch.int32, device="cuda")
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    del a, b
+    torch.cuda.empty_cache()
+    return 2 * 4 * (1 << 30) / (ms * 1e-3) / 1e9
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,6 +244,11 @@ def main():
             roofline = {"bound": "hbm", "kernel": name, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                         "launches_per_step": per_step, "avg_launch_ms": round(avg_ms, 4)}
         roofline["kernel_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][1])}     # from the one fully bracketed untimed step
+        if rank == 0:
+            copy_gbs = measure_copy_bandwidth(torch)              # outside the timed region
+            roofline["measured_copy_GBps"] = round(copy_gbs, 1)
+            if roofline.get("achieved"):
+                roofline["frac_of_measured_copy"] = round(roofline["achieved"] / copy_gbs, 4)
         roofline["host_syncs_per_step"] = host_syncs       # stream synchronisations by cause (counts the host must read back)
         q_gbs = Q3_BYTES_PER_ROW * rows_total / (ms_per_step * 1e-3) / 1e9
         roofline["query"] = {"achieved": round(q_gbs, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(q_gbs / (HBM_PEAK_GBS * world), 4),
@@ -222,10 +274,19 @@ def main():
             res = po.tpch_q3(host, seg, tpch.Q3_DATE, cores, 8192)
             times.append(time.perf_counter() - t1)
         med = statistics.median(times)
-        cpu_baseline = {"value": round(n_in / med, 1), "unit": "rows/s", "cores": cores, "kind": "port",
+        try:
+            model = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "unknown")
+        except OSError:
+            model = "unknown"
+        cpu_baseline = {"value": round(n_in / med, 1), "unit": "rows/s", "cores": cores, "cpu_model": model, "kind": "port",
                         "sample": f"oracle/dfo_tpch.c restatement of DataFusion 36 CPU operators (Q3 plan, target_partitions={cores}, batch_size=8192) on synthetic SF{cpu_sf:g} "
                                   f"({n_in} input rows, {len(res['l_orderkey'])} result rows); 1 warm-up + 3 runs, median {med:.3f}s, min {min(times):.3f}s",
                         "min_value": round(n_in / min(times), 1)}
+        # a second, INDEPENDENT CPU number (not the reference, not the oracle): the same query through pyarrow's Acero engine
+        try:
+            cpu_baseline["acero"] = acero_q3(host, tpch, n_in)
+        except Exception as e:  # noqa: an optional leg must not fail the bench
+            cpu_baseline["acero"] = {"error": repr(e)[:200]}
 
     if rank == 0:
         line = {"metric": "rows/sec hash-join+agg, TPC-H SF100 Q3", "value": round(value, 1), "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
