@@ -10,6 +10,7 @@
 // atomicMin(first row); rows that are "first of their group" are flagged in a bitmap, compacted in
 // row order (ballot + scan), and their rank is the new id -- O(rows) streaming work, no sort.
 #include "device_utils.h"
+#include <algorithm>
 
 namespace dfgpu {
 constexpr uint64_t G_EMPTY = ~0ull;
@@ -36,6 +37,9 @@ struct dfgpu_groups {
   struct Canon { dfgpu_array* dict = nullptr; BufferPtr ids; int64_t n_ids = 0; };
   std::vector<Canon> canon;               // per key column (dict == null: not a dictionary column)
   std::vector<dfgpu_array*> canon_keys;   // per key column: u32 canon id per group (dictionary columns) or null (use keys[c])
+  // dense canon mode: every key column is a dictionary column and the product of the canonical domains is <= 4096 (TPC-H Q1: 4 x 3):
+  // the composite canonical id indexes dense_map (-> group id or none) directly -- no hashing, no table, two streaming passes
+  BufferPtr dense_map; int64_t dense_size = 0; std::vector<uint32_t> dense_host;
   ~dfgpu_groups() { for (auto* a : keys) if (a) dfgpu_array_release(a); for (auto* a : canon_keys) if (a) dfgpu_array_release(a); for (auto& c : canon) if (c.dict) dfgpu_array_release(c.dict); }
 };
 
@@ -163,6 +167,91 @@ __global__ void __launch_bounds__(BLOCK) k_canon_lookup(const void* keys, int ke
   out[i] = (c >= 0 && c < dict_len && valid_at(dict_valid, c)) ? canon[c] : n_ids;          // a NULL code and a NULL dictionary value are the same NULL key
 }
 
+constexpr int DENSE_MAX = 4096;
+constexpr int DENSE_ROWS = 8;
+struct DenseCol { const void* keys; const uint64_t* key_valid; const uint32_t* canon; const uint64_t* dict_valid; int64_t dict_len; uint32_t n_ids, stride; int32_t key_type; };
+struct DenseCols { int32_t n; DenseCol c[MAX_KEYS]; };
+__device__ inline uint32_t dense_composite(const DenseCols& dc, int64_t i) {
+  uint32_t comp = 0;
+#pragma unroll
+  for (int c = 0; c < MAX_KEYS; c++) {              // constant indices: a runtime-indexed kernel-argument array would live in scratch
+    if (c >= dc.n) break;
+    const DenseCol& d = dc.c[c];
+    int64_t code = valid_at(d.key_valid, i) ? key_at(d.keys, d.key_type, i) : -1;
+    uint32_t id = (code >= 0 && code < d.dict_len && valid_at(d.dict_valid, code)) ? d.canon[code] : d.n_ids;
+    comp += id * d.stride;
+  }
+  return comp;
+}
+// straight-line variant for the common shape (all code columns of one integer type K, no NULL codes, no NULL dictionary values):
+// the generic dense_composite branches per column (validity pointers, code type), which puts every load behind its own
+// s_waitcnt; here the loads of a lane's rows are unconditional and overlap
+template <typename K, int NC>
+__device__ inline uint32_t dense_composite_fast(const DenseCols& dc, int64_t i) {
+  uint32_t comp = 0;
+#pragma unroll
+  for (int c = 0; c < NC; c++) comp += dc.c[c].canon[((const K*)dc.c[c].keys)[i]] * dc.c[c].stride;
+  return comp;
+}
+template <typename K, int NC, bool HAS_MASK>
+__global__ void __launch_bounds__(BLOCK) k_dense_first_fast(DenseCols dc, int64_t n, const uint64_t* mask, const uint32_t* dense_map, uint32_t* first, int dsize) {
+  __shared__ uint32_t lfirst[DENSE_MAX];
+  for (int t = threadIdx.x; t < dsize; t += BLOCK) lfirst[t] = dense_map[t] == G_NONE ? G_NONE : 0u;
+  __syncthreads();
+  for (int64_t base = (int64_t)blockIdx.x * BLOCK * DENSE_ROWS; base < n; base += (int64_t)gridDim.x * BLOCK * DENSE_ROWS) {
+    if (base + (int64_t)BLOCK * DENSE_ROWS <= n) {
+      uint32_t comp[DENSE_ROWS];
+#pragma unroll
+      for (int r = 0; r < DENSE_ROWS; r++) comp[r] = dense_composite_fast<K, NC>(dc, base + (int64_t)r * BLOCK + threadIdx.x);
+#pragma unroll
+      for (int r = 0; r < DENSE_ROWS; r++) { int64_t i64 = base + (int64_t)r * BLOCK + threadIdx.x; uint32_t i = (uint32_t)i64; if ((!HAS_MASK || bit_get(mask, i64)) && lfirst[comp[r]] > i) atomicMin(&lfirst[comp[r]], i); }
+    } else {
+      for (int r = 0; r < DENSE_ROWS; r++) { int64_t i = base + (int64_t)r * BLOCK + threadIdx.x; if (i < n && (!HAS_MASK || bit_get(mask, i))) { uint32_t c = dense_composite_fast<K, NC>(dc, i); if (lfirst[c] > (uint32_t)i) atomicMin(&lfirst[c], (uint32_t)i); } }
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < dsize; t += BLOCK) if (dense_map[t] == G_NONE && lfirst[t] != G_NONE) atomicMin(&first[t], lfirst[t]);
+}
+template <typename K, int NC, bool HAS_MASK>
+__global__ void __launch_bounds__(BLOCK) k_dense_ids_fast(DenseCols dc, int64_t n, const uint64_t* mask, const uint32_t* dense_map, uint32_t* out) {
+  int64_t base = (int64_t)blockIdx.x * BLOCK * DENSE_ROWS;
+  if (base + (int64_t)BLOCK * DENSE_ROWS <= n) {
+    uint32_t g[DENSE_ROWS];
+#pragma unroll
+    for (int r = 0; r < DENSE_ROWS; r++) g[r] = dense_map[dense_composite_fast<K, NC>(dc, base + (int64_t)r * BLOCK + threadIdx.x)];
+#pragma unroll
+    for (int r = 0; r < DENSE_ROWS; r++) { int64_t i = base + (int64_t)r * BLOCK + threadIdx.x; out[i] = (!HAS_MASK || bit_get(mask, i)) ? g[r] : G_NONE; }
+  } else {
+    for (int r = 0; r < DENSE_ROWS; r++) { int64_t i = base + (int64_t)r * BLOCK + threadIdx.x; if (i < n) out[i] = (!HAS_MASK || bit_get(mask, i)) ? dense_map[dense_composite_fast<K, NC>(dc, i)] : G_NONE; }
+  }
+}
+// pass A: first row of every composite that has no group id yet.  Workgroups stride over the rows keeping their minima in LDS (a
+// single global line hammered by every wave serialises in its L2 channel), one global atomicMin per workgroup and composite at the
+// end.  8 rows per lane and iteration: code -> canonical id -> map is a chain of dependent loads, so the rows' chains must overlap.
+__global__ void __launch_bounds__(BLOCK) k_dense_first(DenseCols dc, int64_t n, const uint64_t* mask, const uint32_t* dense_map, uint32_t* first, int dsize) {
+  __shared__ uint32_t lfirst[DENSE_MAX];
+  for (int t = threadIdx.x; t < dsize; t += BLOCK) lfirst[t] = dense_map[t] == G_NONE ? G_NONE : 0u;       // 0: already numbered, nothing can lower it
+  __syncthreads();
+  for (int64_t base = (int64_t)blockIdx.x * BLOCK * DENSE_ROWS; base < n; base += (int64_t)gridDim.x * BLOCK * DENSE_ROWS) {
+    uint32_t comp[DENSE_ROWS]; bool on[DENSE_ROWS];
+#pragma unroll
+    for (int r = 0; r < DENSE_ROWS; r++) { int64_t i = base + (int64_t)r * BLOCK + threadIdx.x; on[r] = i < n && (mask == nullptr || bit_get(mask, i)); comp[r] = on[r] ? dense_composite(dc, i) : 0; }
+#pragma unroll
+    for (int r = 0; r < DENSE_ROWS; r++) { uint32_t i = (uint32_t)(base + (int64_t)r * BLOCK + threadIdx.x); if (on[r] && lfirst[comp[r]] > i) atomicMin(&lfirst[comp[r]], i); }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < dsize; t += BLOCK) if (dense_map[t] == G_NONE && lfirst[t] != G_NONE) atomicMin(&first[t], lfirst[t]);
+}
+// pass B: group id of every row
+__global__ void __launch_bounds__(BLOCK) k_dense_ids(DenseCols dc, int64_t n, const uint64_t* mask, const uint32_t* dense_map, uint32_t* out) {
+  int64_t base = (int64_t)blockIdx.x * BLOCK * DENSE_ROWS;
+  uint32_t g[DENSE_ROWS];
+#pragma unroll
+  for (int r = 0; r < DENSE_ROWS; r++) { int64_t i = base + (int64_t)r * BLOCK + threadIdx.x; g[r] = (i < n && (mask == nullptr || bit_get(mask, i))) ? dense_map[dense_composite(dc, i)] : G_NONE; }
+#pragma unroll
+  for (int r = 0; r < DENSE_ROWS; r++) { int64_t i = base + (int64_t)r * BLOCK + threadIdx.x; if (i < n) out[i] = g[r]; }
+}
+
 static void groups_alloc_table(dfgpu_groups* g, uint64_t cap) {
   dfgpu_ctx* ctx = g->ctx;
   g->capacity = cap;
@@ -280,9 +369,10 @@ dfgpu_status dfgpu_groups_intern(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_ar
     if (g->canon_mode && !want_canon) {       // another dictionary (or none): back to value keys; the numbered groups are re-hashed by value
       for (auto*& a : g->canon_keys) { if (a) dfgpu_array_release(a); a = nullptr; }
       for (auto& cc : g->canon) { if (cc.dict) dfgpu_array_release(cc.dict); cc = dfgpu_groups::Canon{}; }
-      g->canon_mode = false;
+      g->canon_mode = false; g->dense_size = 0; g->dense_map.reset(); g->dense_host.clear();
       if (g->n_groups) {
         std::vector<const dfgpu_array*> sk(g->keys.begin(), g->keys.end()); KeySet stored_ks = make_keyset(sk.data(), nkeys);
+        groups_reserve_ghash(ctx, g, g->n_groups, 0);
         hipLaunchKernelGGL(k_groups_hash_stored, dim3(grid_for(g->n_groups, BLOCK)), dim3(BLOCK), 0, ctx->stream, stored_ks, g->n_groups, 0, (uint64_t*)g->ghash->ptr);
         KERNEL_CHECK();
         if (g->capacity) groups_alloc_table(g, g->capacity);
@@ -301,6 +391,66 @@ dfgpu_status dfgpu_groups_intern(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_ar
           auto& cc = g->canon[(size_t)c]; cc.dict = const_cast<dfgpu_array*>(dict); dfgpu_array_retain(cc.dict); cc.ids = dids->values; cc.n_ids = tmp.n_groups;
         }
         g->canon_mode = true;
+      }
+      // dense composite domain: index a small map directly
+      bool all_dict = true; int64_t dsize = 1;
+      for (int c = 0; c < nkeys; c++) { if (!g->canon[(size_t)c].dict) { all_dict = false; break; } dsize *= g->canon[(size_t)c].n_ids + 1; if (dsize > DENSE_MAX) break; }
+      if (all_dict && dsize <= DENSE_MAX && (g->dense_size == dsize || g->n_groups == 0)) {
+        KernelTimer kt_(ctx, "k_groups_dense");
+        if (g->dense_size != dsize) { g->dense_size = dsize; g->dense_host.assign((size_t)dsize, G_NONE); g->dense_map = alloc_buffer(ctx, (size_t)dsize * 4); HIP_CHECK(hipMemsetAsync(g->dense_map->ptr, 0xFF, (size_t)dsize * 4, ctx->stream)); }
+        DenseCols dc{}; dc.n = nkeys; uint32_t stride = 1;
+        for (int c = nkeys - 1; c >= 0; c--) {
+          auto& cc = g->canon[(size_t)c]; DenseCol& d = dc.c[c];
+          d.keys = cols[c]->values->ptr; d.key_valid = cols[c]->validity ? (const uint64_t*)cols[c]->validity->ptr : nullptr; d.key_type = cols[c]->key_type;
+          d.canon = (const uint32_t*)cc.ids->ptr; d.dict_valid = cc.dict->validity ? (const uint64_t*)cc.dict->validity->ptr : nullptr; d.dict_len = cc.dict->length;
+          d.n_ids = (uint32_t)cc.n_ids; d.stride = stride; stride *= (uint32_t)cc.n_ids + 1;
+        }
+        BufferPtr first = alloc_buffer(ctx, (size_t)dsize * 4);
+        HIP_CHECK(hipMemsetAsync(first->ptr, 0xFF, (size_t)dsize * 4, ctx->stream));
+        const uint64_t* mk = mask ? (const uint64_t*)mask->ptr : nullptr;
+        dim3 grid(grid_for(n, BLOCK)), block(BLOCK);
+        // straight-line kernels when every code column has the same integer type and nothing is nullable (codes must then be in range:
+        // Arrow requires valid dictionary codes; the generic kernels also tolerate out-of-range codes as NULL)
+        bool fast = nkeys <= 2; int kt0 = cols[0]->key_type;
+        for (int c = 0; c < nkeys; c++) fast = fast && cols[c]->key_type == kt0 && !dc.c[c].key_valid && !dc.c[c].dict_valid;
+        fast = fast && (kt0 == DFGPU_INT8 || kt0 == DFGPU_INT16 || kt0 == DFGPU_INT32);
+        int fgrid = grid_for(n, BLOCK * DENSE_ROWS, ctx->num_cus * 8);
+#define DENSE_FAST(K, NC, WHICH, GRID, ...) do { if (mk) hipLaunchKernelGGL((WHICH<K, NC, true>), dim3(GRID), block, 0, ctx->stream, __VA_ARGS__); else hipLaunchKernelGGL((WHICH<K, NC, false>), dim3(GRID), block, 0, ctx->stream, __VA_ARGS__); } while (0)
+#define DENSE_DISPATCH(WHICH, GRID, ...) do { \
+          if (kt0 == DFGPU_INT8) { if (nkeys == 1) DENSE_FAST(int8_t, 1, WHICH, GRID, __VA_ARGS__); else DENSE_FAST(int8_t, 2, WHICH, GRID, __VA_ARGS__); } \
+          else if (kt0 == DFGPU_INT16) { if (nkeys == 1) DENSE_FAST(int16_t, 1, WHICH, GRID, __VA_ARGS__); else DENSE_FAST(int16_t, 2, WHICH, GRID, __VA_ARGS__); } \
+          else { if (nkeys == 1) DENSE_FAST(int32_t, 1, WHICH, GRID, __VA_ARGS__); else DENSE_FAST(int32_t, 2, WHICH, GRID, __VA_ARGS__); } } while (0)
+        if (fast) DENSE_DISPATCH(k_dense_first_fast, fgrid, dc, n, mk, (const uint32_t*)g->dense_map->ptr, (uint32_t*)first->ptr, (int)dsize);
+        else hipLaunchKernelGGL(k_dense_first, dim3(fgrid), block, 0, ctx->stream, dc, n, mk, (const uint32_t*)g->dense_map->ptr, (uint32_t*)first->ptr, (int)dsize);
+        KERNEL_CHECK();
+        std::vector<uint32_t> fh((size_t)dsize);
+        HIP_CHECK(hipMemcpyAsync(fh.data(), first->ptr, (size_t)dsize * 4, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->count_sync("sync:dense_groups");
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        std::vector<std::pair<uint32_t, uint32_t>> fresh;             // (first row, composite) of the composites met for the first time
+        for (int64_t comp = 0; comp < dsize; comp++) if (fh[(size_t)comp] != G_NONE) fresh.emplace_back(fh[(size_t)comp], (uint32_t)comp);
+        std::sort(fresh.begin(), fresh.end());                        // first-seen order
+        int64_t n_new = (int64_t)fresh.size();
+        if (n_new) {
+          std::vector<uint32_t> rows((size_t)n_new);
+          for (int64_t k2 = 0; k2 < n_new; k2++) { g->dense_host[fresh[(size_t)k2].second] = (uint32_t)(g->n_groups + k2); rows[(size_t)k2] = fresh[(size_t)k2].first; }
+          HIP_CHECK(hipMemcpyAsync(g->dense_map->ptr, g->dense_host.data(), (size_t)dsize * 4, hipMemcpyHostToDevice, ctx->stream));
+          ArrayHolder firsts(new_fixed(ctx, DFGPU_UINT32, n_new));
+          HIP_CHECK(hipMemcpyAsync(firsts.get()->values->ptr, rows.data(), (size_t)n_new * 4, hipMemcpyHostToDevice, ctx->stream));
+          HIP_CHECK(hipStreamSynchronize(ctx->stream));               // rows / dense_host are host vectors
+          groups_append_keys(ctx, g, cols, nkeys, firsts.get(), n_new);
+        }
+        if (fast) DENSE_DISPATCH(k_dense_ids_fast, grid_for(n, BLOCK * DENSE_ROWS), dc, n, mk, (const uint32_t*)g->dense_map->ptr, (uint32_t*)ids.get()->values->ptr);
+        else hipLaunchKernelGGL(k_dense_ids, dim3(grid_for(n, BLOCK * DENSE_ROWS)), block, 0, ctx->stream, dc, n, mk, (const uint32_t*)g->dense_map->ptr, (uint32_t*)ids.get()->values->ptr);
+#undef DENSE_DISPATCH
+#undef DENSE_FAST
+        KERNEL_CHECK();
+        g->n_groups += n_new;
+        *out_group_ids = ids.release();
+        return;
+      }
+      if (g->dense_size) {           // the composite domain outgrew the dense map (cannot happen with unchanged dictionaries); safest: value keys
+        fail(DFGPU_INTERNAL, "dense dictionary group map changed size");
       }
       for (int c = 0; c < nkeys; c++) {
         if (cols[c]->type != DFGPU_DICTIONARY) continue;

@@ -120,6 +120,37 @@ def test_dictionary_keys_through_canonical_ids_match_value_interning(ctx):
             ctx.set_option("group_dictionary_canon", 1)
 
 
+def test_all_dictionary_keys_with_a_small_domain_use_the_dense_map(ctx):
+    """Two dictionary key columns whose canonical domains multiply to <= 4096 (TPC-H Q1's l_returnflag, l_linestatus): groups.hip indexes
+    a dense composite map (k_dense_first / k_dense_ids) instead of hashing.  Same first-seen ids / emitted keys as the oracle over batches
+    sharing the dictionaries (with a fused selection mask), NULL codes and a repeated dictionary value included; a batch with other
+    dictionaries then drops back to value keys."""
+    import dfgpu
+    w1 = pa.array(["A", "N", "R", "A", None], type=pa.utf8())                    # codes 0 and 3 carry the same value; code 4 is a NULL value
+    w2 = pa.array(["F", "O"], type=pa.utf8())
+    n = 20000
+    c1 = pa.DictionaryArray.from_arrays(pa.array(RNG.integers(0, 5, n).astype(np.int8), mask=RNG.random(n) < 0.03), w1)
+    c2 = pa.DictionaryArray.from_arrays(pa.array(RNG.integers(0, 2, n).astype(np.int8)), w2)
+    o1 = pa.array([["N", "R", "X"][v] for v in RNG.integers(0, 3, 2000)], type=pa.utf8()).dictionary_encode()
+    o2 = pa.array([["O", "F"][v] for v in RNG.integers(0, 2, 2000)], type=pa.utf8()).dictionary_encode()
+    d1, d2 = ctx.from_arrow(c1), ctx.from_arrow(c2)
+    gv, og = dfgpu.GroupValues(ctx, 2), po.Groups([pa.utf8(), pa.utf8()])
+    m = RNG.random(6000) < 0.5
+    ids = gv.intern([d1.slice(0, 6000), d2.slice(0, 6000)], mask=ctx.from_arrow(pa.array(m))).to_numpy()
+    want = og.intern([c1.slice(0, 6000).filter(pa.array(m)), c2.slice(0, 6000).filter(pa.array(m))])
+    assert np.array_equal(ids[m].astype(np.int64), want) and (ids[~m] == 0xFFFFFFFF).all()
+    for lo, hi in ((6000, 6001), (6001, n)):
+        got = gv.intern([d1.slice(lo, hi - lo), d2.slice(lo, hi - lo)]).to_numpy().astype(np.int64)
+        assert np.array_equal(got, og.intern([c1.slice(lo, hi - lo), c2.slice(lo, hi - lo)]))
+    got = gv.intern([ctx.from_arrow(o1), ctx.from_arrow(o2)]).to_numpy().astype(np.int64)             # other dictionaries
+    assert np.array_equal(got, og.intern([o1, o2]))
+    got = gv.intern([d1.slice(0, 100), d2.slice(0, 100)]).to_numpy().astype(np.int64)
+    assert np.array_equal(got, og.intern([c1.slice(0, 100), c2.slice(0, 100)]))
+    assert len(gv) == len(og)
+    for a, w in zip(gv.emit(), og.emit()):
+        assert a.to_arrow().equals(w)
+
+
 def value_array(kind, n):
     if kind == "decimal":
         return pa.array([None if RNG.random() < 0.1 else decimal.Decimal(int(v)).scaleb(-2) for v in RNG.integers(-10**13, 10**13, n)], type=pa.decimal128(15, 2))
