@@ -65,10 +65,12 @@ def _worker(rank, world, port, q):
         assert rc == [s * 10 + rank for s in range(world)]
         # the single metadata all-gather of exchange_batches: count matrix + column types / validity flags; rank 1 holds no rows
         fields = [(5, 0, 0), (13, 15, 2)] if rank == 0 else None
-        recv, allc, flds, nullable = exchange._exchange_meta([3, 4] if rank == 0 else [0, 0], fields, [0, 1] if rank == 0 else None, None)
+        ub = [[30, 7], [41, 0]] if rank == 0 else None                  # value bytes of two Utf8 columns per destination
+        recv, allc, flds, nullable, ru = exchange._exchange_meta([3, 4] if rank == 0 else [0, 0], fields, [0, 1] if rank == 0 else None, None, ub)
         assert allc == [[3, 4], [0, 0]] and recv == ([3, 0] if rank == 0 else [4, 0])
         assert flds == [(5, 0, 0), (13, 15, 2)] and nullable == [False, True]
-        recv, allc, flds, nullable = exchange._exchange_meta([0, 0], None, None, None)       # nobody holds rows: no columns, no data collectives
+        assert ru[0][:2] == ([30, 7] if rank == 0 else [41, 0]) and ru[1][:2] == [0, 0]      # what each source sends to ME
+        recv, allc, flds, nullable, ru = exchange._exchange_meta([0, 0], None, None, None)       # nobody holds rows: no columns, no data collectives
         assert flds == [] and recv == [0, 0]
         q.put((rank, "ok"))
     except Exception as e:  # noqa
