@@ -125,6 +125,7 @@ PROTOTYPES = {
     "dfgpu_acc_new": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _PP]),
     "dfgpu_acc_free": (None, [_P]),
     "dfgpu_acc_update_batch": (C.c_int32, [_P, _P, _P, _P, _P, C.c_int64]),
+    "dfgpu_acc_update_batch_multi": (C.c_int32, [_P, _PP, _PP, _PP, C.c_int32, _P, C.c_int64]),
     "dfgpu_acc_merge_batch": (C.c_int32, [_P, _P, _PP, C.c_int32, _P, _P, C.c_int64]),
     "dfgpu_acc_evaluate": (C.c_int32, [_P, _P, _PP]),
     "dfgpu_acc_state": (C.c_int32, [_P, _P, _PP, C.POINTER(C.c_int32)]),

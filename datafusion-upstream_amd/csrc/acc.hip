@@ -149,6 +149,58 @@ __global__ void __launch_bounds__(BLOCK) k_acc_small(int kind, ColView v, int ha
   }
 }
 
+// ------------------------------------------------------------ few groups, several SUM / AVG accumulators in ONE pass
+// TPC-H Q1 updates 7 sum-like accumulators over the same 6 groups: one pass per accumulator re-reads the group ids and the selection
+// 7 times and SUM(x) / AVG(x) read x twice.  dfgpu_acc_update_batch_multi hands all accumulators of a batch over at once; runs of
+// compatible ones (same value class, plain fixed-width values, same filter, <= 8 groups) share a pass: ids and filter are read once,
+// a value column that repeats in the next slot is read once, every (slot, group) partial lives in registers.
+constexpr int MULTI_MAX = 4;
+struct MultiArgs { const void* vals[MULTI_MAX]; const uint64_t* valid[MULTI_MAX]; void* out_vals[MULTI_MAX]; uint64_t* out_counts[MULTI_MAX]; uint8_t* out_seen[MULTI_MAX]; int kind[MULTI_MAX]; };
+template <typename T, int CLS, int NACC>
+__global__ void __launch_bounds__(BLOCK) k_acc_small_multi(MultiArgs a, const uint32_t* gids, const uint64_t* fbits, const uint64_t* fvalid, int64_t n, int G) {
+  T acc[NACC][SMALL_G]; uint32_t cnt[NACC][SMALL_G];
+#pragma unroll
+  for (int s = 0; s < NACC; s++)
+#pragma unroll
+    for (int k = 0; k < SMALL_G; k++) { acc[s][k] = (T)0; cnt[s][k] = 0; }
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    uint32_t g = gids[i];
+    if (g == GID_NONE || !filter_pass(fbits, fvalid, i)) continue;
+    T x[NACC]; bool ok[NACC];
+#pragma unroll
+    for (int s = 0; s < NACC; s++) {
+      if (s > 0 && a.vals[s] == a.vals[s - 1]) x[s] = x[s - 1];               // SUM(x), AVG(x): one load
+      else if constexpr (CLS == CLS_I128) x[s] = load_i128(a.vals[s], i); else x[s] = ((const T*)a.vals[s])[i];
+      ok[s] = valid_at(a.valid[s], i);
+    }
+#pragma unroll
+    for (int s = 0; s < NACC; s++)
+#pragma unroll
+      for (int k = 0; k < SMALL_G; k++) { bool m = ok[s] && g == (uint32_t)k; acc[s][k] += m ? x[s] : (T)0; cnt[s][k] += m ? 1u : 0u; }
+  }
+  __shared__ T s_acc[BLOCK / WAVE][NACC][SMALL_G]; __shared__ uint32_t s_cnt[BLOCK / WAVE][NACC][SMALL_G];
+  int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int s = 0; s < NACC; s++)
+#pragma unroll
+    for (int k = 0; k < SMALL_G; k++) { T v = wave_sum_any<T>(acc[s][k]); uint32_t c = wave_sum(cnt[s][k]); if (lane_id() == 0) { s_acc[wave][s][k] = v; s_cnt[wave][s][k] = c; } }
+  __syncthreads();
+  if (threadIdx.x < NACC * SMALL_G) {
+    int s = threadIdx.x / SMALL_G, k = threadIdx.x % SMALL_G;
+    if (k < G) {
+      T v = (T)0; uint64_t c = 0;
+      for (int w = 0; w < BLOCK / WAVE; w++) { v += s_acc[w][s][k]; c += s_cnt[w][s][k]; }
+      if (c) {
+        a.out_seen[s][k] = 1;
+        if (a.kind[s] == DFGPU_AGG_AVG) atomicAdd((unsigned long long*)&a.out_counts[s][k], (unsigned long long)c);
+        if constexpr (CLS == CLS_F64) unsafeAtomicAdd((double*)a.out_vals[s] + k, v);
+        else if constexpr (CLS == CLS_I128) atomic_add_i128((uint64_t*)a.out_vals[s] + 2 * k, v);
+        else atomicAdd((unsigned long long*)a.out_vals[s] + k, (unsigned long long)v);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------ many groups, sum-like kinds: runs of equal adjacent group ids are combined first
 // Clustered input (GROUP BY over a fact table in key order, ids from groups.hip's run numbering) puts the rows of a group in
 // neighbouring lanes: a segmented wave scan adds them up and only the last lane of each run issues the atomic -- 4x fewer atomics
@@ -420,6 +472,57 @@ dfgpu_status dfgpu_acc_update_batch(dfgpu_ctx* ctx, dfgpu_acc* a, const dfgpu_ar
     }
     check_flags(ctx, "acc_update_batch");
   });
+}
+
+// can accumulator a take part in a shared small-group pass over `values`?
+static bool multi_ok(const dfgpu_acc* a, const dfgpu_array* values, int64_t total) {
+  if (!a || !values || total > SMALL_G || (a->kind != DFGPU_AGG_SUM && a->kind != DFGPU_AGG_AVG)) return false;
+  if (values->type == DFGPU_DICTIONARY) return false;
+  return a->cls == CLS_F64 ? values->type == DFGPU_FLOAT64 : a->cls == CLS_I128 ? values->type == DFGPU_DECIMAL128 : (values->type == DFGPU_INT64 || values->type == DFGPU_UINT64);
+}
+dfgpu_status dfgpu_acc_update_batch_multi(dfgpu_ctx* ctx, dfgpu_acc* const* accs, const dfgpu_array* const* values, const dfgpu_array* const* filters, int32_t n_accs,
+                                          const dfgpu_array* gids, int64_t total) {
+  if (!accs || !values || !gids || n_accs < 0) { if (ctx) ctx->err = "acc_update_batch_multi: null argument"; return DFGPU_INVALID_ARGUMENT; }
+  int32_t i = 0;
+  while (i < n_accs) {
+    const dfgpu_array* f = filters ? filters[i] : nullptr;
+    int32_t j = i;
+    int cap = accs[i] && accs[i]->cls == CLS_I128 ? 2 : MULTI_MAX;
+    if (gids->length && multi_ok(accs[i], values[i], total))
+      while (j + 1 < n_accs && j + 1 - i < cap && multi_ok(accs[j + 1], values[j + 1], total) && accs[j + 1]->cls == accs[i]->cls && (filters ? filters[j + 1] : nullptr) == f &&
+             values[j + 1]->length == gids->length) j++;
+    if (j == i) {                 // alone: the single-accumulator path
+      dfgpu_status st = dfgpu_acc_update_batch(ctx, accs[i], values[i], gids, f, total);
+      if (st != DFGPU_OK) return st;
+      i++; continue;
+    }
+    dfgpu_status st = guard(ctx, [&] {
+      int64_t n = gids->length;
+      if (gids->type != DFGPU_UINT32) fail(DFGPU_INVALID_ARGUMENT, "group ids must be a UINT32 array");
+      if (f && (f->type != DFGPU_BOOL || f->length != n)) fail(DFGPU_INVALID_ARGUMENT, "opt_filter must be a Boolean array of the batch length");
+      MultiArgs ma{}; int na = j - i + 1;
+      for (int s = 0; s < na; s++) {
+        dfgpu_acc* a = accs[i + s]; const dfgpu_array* v = values[i + s];
+        if (v->length != n) fail(DFGPU_INVALID_ARGUMENT, "values (%lld rows) and group ids (%lld rows) differ in length", (long long)v->length, (long long)n);
+        acc_resize(a, total);
+        ma.vals[s] = v->values->ptr; ma.valid[s] = v->validity ? (const uint64_t*)v->validity->ptr : nullptr;
+        ma.out_vals[s] = a->vals->ptr; ma.out_counts[s] = (uint64_t*)a->counts->ptr; ma.out_seen[s] = (uint8_t*)a->seen->ptr; ma.kind[s] = a->kind;
+      }
+      const uint64_t* fb = f ? (const uint64_t*)f->values->ptr : nullptr; const uint64_t* fv = f && f->validity ? (const uint64_t*)f->validity->ptr : nullptr;
+      int blocks = grid_for(n, BLOCK * 8, ctx->num_cus * 8);
+      KernelTimer kt_(ctx, "k_acc_update");
+#define MULTI(T, C, N) hipLaunchKernelGGL((k_acc_small_multi<T, C, N>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, ma, (const uint32_t*)gids->values->ptr, fb, fv, n, (int)total)
+      int cls = accs[i]->cls;
+      if (cls == CLS_I128) MULTI(i128, CLS_I128, 2);
+      else if (cls == CLS_F64) { if (na == 2) MULTI(double, CLS_F64, 2); else if (na == 3) MULTI(double, CLS_F64, 3); else MULTI(double, CLS_F64, 4); }
+      else { if (na == 2) MULTI(unsigned long long, CLS_U64, 2); else if (na == 3) MULTI(unsigned long long, CLS_U64, 3); else MULTI(unsigned long long, CLS_U64, 4); }
+#undef MULTI
+      KERNEL_CHECK();
+    });
+    if (st != DFGPU_OK) return st;
+    i = j + 1;
+  }
+  return DFGPU_OK;
 }
 
 dfgpu_status dfgpu_acc_merge_batch(dfgpu_ctx* ctx, dfgpu_acc* a, const dfgpu_array* const* st, int32_t nst, const dfgpu_array* gids, const dfgpu_array* filt, int64_t total) {

@@ -546,6 +546,7 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
         total = dfgpu_groups_len(groups.g);
       } else { dfgpu_array* z = nullptr; tc.check(dfgpu_array_new_zeros(tc.ctx, DFGPU_UINT32, 0, 0, b.base_rows, &z)); gids = ArrayRef::adopt(z); }
       size_t col = gexprs.size();
+      std::vector<ArrayRef> uvals(aggs.size()), ufilt(aggs.size());       // update mode: all accumulators of the batch go down together
       for (size_t i = 0; i < aggs.size(); i++) {
         if (merging()) {
           int nst = aggs[i].kind == DFGPU_AGG_AVG ? 2 : 1; const dfgpu_array* st[2];
@@ -559,8 +560,13 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
           if (!grouped && mask) {         // rows dropped by a fused FilterExec must not reach the single group
             if (filt) { ArrayRef kf = known_mask(tc, filt); dfgpu_array* o = nullptr; tc.check(dfgpu_binary(tc.ctx, DFGPU_OP_AND, kf.a, 0, mask.a, 0, &o)); filt = ArrayRef::adopt(o); } else filt = mask;
           }
-          tc.check(dfgpu_acc_update_batch(tc.ctx, accs[i].a, vals.a, gids.a, filt.a, total));
+          uvals[i] = vals; ufilt[i] = filt;
         }
+      }
+      if (!merging() && !aggs.empty()) {
+        std::vector<dfgpu_acc*> ap; std::vector<const dfgpu_array*> vp, fp;
+        for (size_t i = 0; i < aggs.size(); i++) { ap.push_back(accs[i].a); vp.push_back(uvals[i].a); fp.push_back(ufilt[i].a); }
+        tc.check(dfgpu_acc_update_batch_multi(tc.ctx, ap.data(), vp.data(), fp.data(), (int32_t)ap.size(), gids.a, total));
       }
     }
     std::vector<Batch> outv; int64_t total = grouped ? dfgpu_groups_len(groups.g) : 1;     // no GROUP BY: always one row, even on empty input

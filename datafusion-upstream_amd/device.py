@@ -343,6 +343,15 @@ class GroupsAccumulator:
         self.ctx.check(self.ctx.lib.dfgpu_acc_update_batch(self.ctx.h, self.h, values.h if values is not None else None, group_ids.h,
                                                            opt_filter.h if opt_filter is not None else None, total_num_groups))
 
+    @staticmethod
+    def update_batch_multi(ctx: "Context", accs: Sequence["GroupsAccumulator"], values: Sequence[Optional[Array]], filters: Sequence[Optional[Array]], group_ids: Array, total_num_groups: int):
+        """All update_batch calls of one input batch at once (dfgpu_acc_update_batch_multi): same results, shared passes where possible."""
+        n = len(accs)
+        ah = (C.c_void_p * n)(*[a.h for a in accs])
+        vh = (C.c_void_p * n)(*[(v.h if v is not None else None) for v in values])
+        fh = (C.c_void_p * n)(*[(f.h if f is not None else None) for f in filters])
+        ctx.check(ctx.lib.dfgpu_acc_update_batch_multi(ctx.h, ah, vh, fh, n, group_ids.h, total_num_groups))
+
     def merge_batch(self, states: Sequence[Array], group_ids: Array, opt_filter: Optional[Array], total_num_groups: int):
         hs, n = capi.handle_array([a.h.value for a in states])
         self.ctx.check(self.ctx.lib.dfgpu_acc_merge_batch(self.ctx.h, self.h, hs, n, group_ids.h, opt_filter.h if opt_filter is not None else None, total_num_groups))

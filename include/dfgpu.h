@@ -233,6 +233,12 @@ DFGPU_API void dfgpu_acc_free(dfgpu_acc *a);
  * COUNT(*); group_ids UINT32 (0xFFFFFFFF = skip); opt_filter BOOL (NULL/false rows skipped). */
 DFGPU_API dfgpu_status dfgpu_acc_update_batch(dfgpu_ctx *ctx, dfgpu_acc *a, const dfgpu_array *values, const dfgpu_array *group_ids,
                                               const dfgpu_array *opt_filter, int64_t total_num_groups);
+/* The update_batch calls of one group_aggregate_batch (row_hash.rs:560-600: for every accumulator acc.update_batch(values, group_indices,
+ * opt_filter, total_num_groups)) handed over together; same results as calling dfgpu_acc_update_batch per accumulator in order.
+ * Neighbouring SUM / AVG accumulators over <= 8 groups with the same filter share one pass over the group ids (values[i] == NULL is
+ * allowed for COUNT(*); filters may be NULL or hold NULL entries). */
+DFGPU_API dfgpu_status dfgpu_acc_update_batch_multi(dfgpu_ctx *ctx, dfgpu_acc *const *accs, const dfgpu_array *const *values, const dfgpu_array *const *filters,
+                                                    int32_t n_accs, const dfgpu_array *group_ids, int64_t total_num_groups);
 /* ≙ GroupsAccumulator::merge_batch (:136-142): states as produced by dfgpu_acc_state. */
 DFGPU_API dfgpu_status dfgpu_acc_merge_batch(dfgpu_ctx *ctx, dfgpu_acc *a, const dfgpu_array *const *states, int32_t nstates,
                                              const dfgpu_array *group_ids, const dfgpu_array *opt_filter, int64_t total_num_groups);

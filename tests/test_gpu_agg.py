@@ -224,6 +224,39 @@ def test_accumulators_skewed_groups_use_the_lds_cache(ctx, fun, kind):
     check_equal(acc.evaluate().to_arrow(), oacc.evaluate(), floats)
 
 
+@pytest.mark.parametrize("ngroups", [1, 6, 8, 9])
+def test_update_batch_multi_equals_separate_updates(ctx, ngroups):
+    """dfgpu_acc_update_batch_multi (all accumulators of a batch at once; SUM / AVG neighbours over <= 8 groups share a pass, SUM(x) and
+    AVG(x) share the load of x) must leave every accumulator exactly as separate update_batch calls do -- TPC-H Q1's aggregate list over
+    Float64 and Decimal128 columns with NULLs, a filter, and a COUNT(*) in between; 9 groups take the single-accumulator paths."""
+    import dfgpu
+    n = 30000
+    g = RNG.integers(0, ngroups, n)
+    f64 = lambda: pa.array(RNG.normal(size=n) * 100, mask=RNG.random(n) < 0.1)
+    dec = lambda: pa.array([None if RNG.random() < 0.1 else decimal.Decimal(int(v)).scaleb(-2) for v in RNG.integers(-10**9, 10**9, n)], type=pa.decimal128(15, 2))
+    x, y, d1, d2, i64 = f64(), f64(), dec(), dec(), pa.array(RNG.integers(-10**6, 10**6, n).astype(np.int64))
+    filt = pa.array(RNG.random(n) < 0.8)
+    spec = [("SUM", x), ("AVG", x), ("SUM", y), ("AVG", y), ("AVG", x), ("COUNT", None), ("SUM", d1), ("AVG", d1), ("SUM", d2), ("SUM", i64), ("SUM", i64), ("MIN", x)]
+    for use_filter in (False, True):
+        fl = filt if use_filter else None
+        accs, oaccs = [], []
+        for fun, col in spec:
+            t = col.type if col is not None else pa.int64()
+            fld = dfgpu.operators.field_of_array("v", ctx.from_arrow(col.slice(0, 4))) if col is not None else None
+            accs.append(dfgpu.GroupsAccumulator(ctx, KIND[fun], fld.dtype if fld else dfgpu.capi.INT64, fld.precision if fld else 0, fld.scale if fld else 0))
+            oaccs.append(po.Acc(fun, t))
+        dev = {id(c): ctx.from_arrow(c) for _, c in spec if c is not None}
+        gd = ctx.from_arrow(pa.array(g.astype(np.uint32)))
+        fd = ctx.from_arrow(fl) if fl is not None else None
+        dfgpu.GroupsAccumulator.update_batch_multi(ctx, accs, [dev[id(c)] if c is not None else None for _, c in spec], [fd] * len(spec), gd, ngroups)
+        for (fun, col), a, o in zip(spec, accs, oaccs):
+            o.update_batch(col, g, fl, ngroups)
+            floats = col is not None and pa.types.is_floating(col.type) and fun in ("SUM", "AVG")
+            for st, ost in zip(a.state(), o.state()):
+                check_equal(st.to_arrow(), ost, floats)
+            check_equal(a.evaluate().to_arrow(), o.evaluate(), floats)
+
+
 def test_count_star_and_resize_only_update(ctx):
     import dfgpu
     acc = dfgpu.GroupsAccumulator(ctx, KIND["COUNT"], dfgpu.capi.INT64)
