@@ -103,6 +103,7 @@ PROTOTYPES = {
     "dfgpu_filter": (C.c_int32, [_P, _P, _P, _PP]),
     "dfgpu_mask_to_indices": (C.c_int32, [_P, _P, _PP]),
     "dfgpu_binary": (C.c_int32, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _PP]),
+    "dfgpu_binary_fused2": (C.c_int32, [_P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _PP]),
     "dfgpu_not": (C.c_int32, [_P, _P, _PP]),
     "dfgpu_is_null": (C.c_int32, [_P, _P, C.c_int32, _PP]),
     "dfgpu_negative": (C.c_int32, [_P, _P, _PP]),

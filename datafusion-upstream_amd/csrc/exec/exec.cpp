@@ -155,7 +155,31 @@ struct LiteralExpr : Expr {       // expressions/literal.rs:73
 struct BinaryExpr : Expr {        // expressions/binary.rs:259-315
   ExprPtr l, r; int op;
   BinaryExpr(ExprPtr a, int o, ExprPtr b) : l(std::move(a)), r(std::move(b)), op(o) {}
+  static bool arith_op(int o) { return o >= DFGPU_OP_ADD && o <= DFGPU_OP_REM; }
+  // `x op (literal op2 y)` / `(literal op2 y) op x`: one fused pass when the device takes the shape (dfgpu_binary_fused2), else node by node
+  bool eval_fused(const TaskContext& tc, Batch& b, Value* out) const {
+    if (!arith_op(op)) return false;
+    for (int inner_left = 0; inner_left < 2; inner_left++) {
+      auto* in = dynamic_cast<const BinaryExpr*>((inner_left ? l : r).get());
+      if (!in || !arith_op(in->op)) continue;
+      auto* lit_l = dynamic_cast<const LiteralExpr*>(in->l.get()); auto* lit_r = dynamic_cast<const LiteralExpr*>(in->r.get());
+      if ((lit_l != nullptr) == (lit_r != nullptr)) continue;                     // exactly one literal side
+      Value x = (inner_left ? r : l)->eval(tc, b), y = (lit_l ? in->r : in->l)->eval(tc, b);
+      if (x.scalar || y.scalar) return false;
+      dfgpu_array* o = nullptr;
+      dfgpu_status st = dfgpu_binary_fused2(tc.ctx, op, x.arr.a, in->op, (lit_l ? lit_l : lit_r)->scalar.a, y.arr.a, lit_l ? 1 : 0, inner_left, &o);
+      if (st == DFGPU_NOT_IMPLEMENTED) {           // node by node, with the children already evaluated
+        const ArrayRef& lit = (lit_l ? lit_l : lit_r)->scalar; dfgpu_array* t = nullptr;
+        tc.check(lit_l ? dfgpu_binary(tc.ctx, in->op, lit.a, 1, y.arr.a, 0, &t) : dfgpu_binary(tc.ctx, in->op, y.arr.a, 0, lit.a, 1, &t));
+        ArrayRef inner = ArrayRef::adopt(t);
+        tc.check(inner_left ? dfgpu_binary(tc.ctx, op, inner.a, 0, x.arr.a, 0, &o) : dfgpu_binary(tc.ctx, op, x.arr.a, 0, inner.a, 0, &o));
+      } else tc.check(st);
+      *out = Value{ArrayRef::adopt(o), false}; return true;
+    }
+    return false;
+  }
   Value eval(const TaskContext& tc, Batch& b) const override {
+    Value fused; if (eval_fused(tc, b, &fused)) return fused;
     Value x = l->eval(tc, b), y = r->eval(tc, b);
     dfgpu_array* o = nullptr; tc.check(dfgpu_binary(tc.ctx, op, x.arr.a, x.scalar, y.arr.a, y.scalar, &o));
     return Value{ArrayRef::adopt(o), x.scalar && y.scalar};

@@ -169,6 +169,12 @@ enum { DFGPU_OP_ADD = 0, DFGPU_OP_SUB = 1, DFGPU_OP_MUL = 2, DFGPU_OP_DIV = 3, D
  * length-1 array with *_is_scalar = 1 (arrow Datum / ColumnarValue::Scalar). */
 DFGPU_API dfgpu_status dfgpu_binary(dfgpu_ctx *ctx, int32_t op, const dfgpu_array *lhs, int32_t lhs_is_scalar,
                                     const dfgpu_array *rhs, int32_t rhs_is_scalar, dfgpu_array **out);
+/* x op_outer (scalar op_inner y)  [or with either pair swapped: scalar_on_left / inner_on_left] in one pass over x and y: the value
+ * and result type of dfgpu_binary(op_outer, x, dfgpu_binary(op_inner, scalar, y)) without the intermediate column (TPC-H's
+ * l_extendedprice * (1 - l_discount)).  Decimal128 or Float64 operands without NULLs; any other shape returns DFGPU_NOT_IMPLEMENTED
+ * and the caller evaluates the two nodes separately (BinaryExpr::evaluate, physical-expr/src/expressions/binary.rs:259-315). */
+DFGPU_API dfgpu_status dfgpu_binary_fused2(dfgpu_ctx *ctx, int32_t op_outer, const dfgpu_array *x, int32_t op_inner, const dfgpu_array *scalar, const dfgpu_array *y,
+                                           int32_t scalar_on_left, int32_t inner_on_left, dfgpu_array **out);
 DFGPU_API dfgpu_status dfgpu_not(dfgpu_ctx *ctx, const dfgpu_array *a, dfgpu_array **out);                 /* not.rs:71 */
 DFGPU_API dfgpu_status dfgpu_is_null(dfgpu_ctx *ctx, const dfgpu_array *a, int32_t negate, dfgpu_array **out); /* is_null.rs:74 / is_not_null.rs */
 DFGPU_API dfgpu_status dfgpu_negative(dfgpu_ctx *ctx, const dfgpu_array *a, dfgpu_array **out);            /* negative.rs:79 */

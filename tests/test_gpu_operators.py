@@ -248,3 +248,41 @@ def test_projection_over_dense_selection_does_not_compact_and_dropped_rows_canno
     with pytest.raises(dfgpu.DfgpuError) as e:
         ops.collect(ops.ProjectionExec([(B(C("a", 0), "/", C("b", 1)), "q")], ops.FilterExec(C("keep", 2), src2)), task_ctx)
     assert "Divide by zero" in str(e.value)
+
+
+@pytest.mark.parametrize("money", ["decimal", "float64", "decimal_nulls", "int64"])
+@pytest.mark.parametrize("shape", ["x*(1-y)", "(1+y)*x", "x-(y/2)", "(y-1)/x"])
+def test_fused_two_level_arithmetic_equals_node_by_node(ctx, task_ctx, money, shape):
+    """BinaryExpr over `x op (literal op2 y)` (TPC-H revenue / charge expressions) runs as ONE device pass (dfgpu_binary_fused2) for
+    Decimal128 / Float64 columns without NULLs: values and result TYPE must equal the oracle's node-by-node evaluation, in all four
+    operand orders; nullable or integer operands take the node-by-node path through the same code."""
+    from dfgpu import physical_plan as ops
+    n = 5000
+    if money.startswith("decimal"):
+        mk = lambda lo, hi: pa.array([None if (money == "decimal_nulls" and RNG.random() < 0.1) else decimal.Decimal(int(v)).scaleb(-2) for v in RNG.integers(lo, hi, n)], type=pa.decimal128(15, 2))
+        x, y = mk(1, 10**9), mk(1, 100)
+        lit = lambda v: (ops.Literal(decimal.Decimal(v), pa.decimal128(20, 0)), pa.array([decimal.Decimal(v)], type=pa.decimal128(20, 0)))
+    elif money == "float64":
+        x, y = pa.array(RNG.normal(size=n) * 1000 + 5), pa.array(RNG.random(n) + 0.5)
+        lit = lambda v: (ops.Literal(float(v), pa.float64()), pa.array([float(v)]))
+    else:
+        x, y = pa.array(RNG.integers(1, 10**6, n).astype(np.int64)), pa.array(RNG.integers(3, 100, n).astype(np.int64))
+        lit = lambda v: (ops.Literal(int(v), pa.int64()), pa.array([int(v)], type=pa.int64()))
+    C, B = ops.Column, ops.BinaryExpr
+    one, one_a = lit(1); two, two_a = lit(2)
+    expr, want = {
+        "x*(1-y)": (B(C("x", 0), "*", B(one, "-", C("y", 1))), lambda: po.binary("*", x, po.binary("-", one_a, y, l_scalar=True))),
+        "(1+y)*x": (B(B(one, "+", C("y", 1)), "*", C("x", 0)), lambda: po.binary("*", po.binary("+", one_a, y, l_scalar=True), x)),
+        "x-(y/2)": (B(C("x", 0), "-", B(C("y", 1), "/", two)), lambda: po.binary("-", x, po.binary("/", y, two_a, r_scalar=True))),
+        "(y-1)/x": (B(B(C("y", 1), "-", one), "/", C("x", 0)), lambda: po.binary("/", po.binary("-", y, one_a, r_scalar=True), x)),
+    }[shape]
+    t = pa.table({"x": x, "y": y})
+    b = ops.batch_from_arrow(ctx, t)
+    out = ops.collect(ops.ProjectionExec([(expr, "e")], ops.MemoryExec([[b]], b.schema)), task_ctx)
+    got = pa.concat_arrays([o.columns[0].to_arrow() for o in out])
+    w = want()
+    assert got.type == w.type, f"{got.type} vs {w.type}"
+    if pa.types.is_floating(w.type):
+        assert np.array_equal(np.asarray(got).view(np.uint64), np.asarray(w).view(np.uint64))          # same IEEE operations in the same order
+    else:
+        assert got.equals(w)
