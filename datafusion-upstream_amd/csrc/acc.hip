@@ -13,6 +13,8 @@
 // Float64 SUM is order dependent in the reference too (sequential add in row order, prim_op.rs:101-109):
 // the contract is <= 1e-9 relative.
 #include "int128.h"
+#include <algorithm>
+#include <tuple>
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace dfgpu {
@@ -156,13 +158,44 @@ __global__ void __launch_bounds__(BLOCK) k_acc_small(int kind, ColView v, int ha
 // a value column that repeats in the next slot is read once, every (slot, group) partial lives in registers.
 constexpr int MULTI_MAX = 4;
 struct MultiArgs { const void* vals[MULTI_MAX]; const uint64_t* valid[MULTI_MAX]; void* out_vals[MULTI_MAX]; uint64_t* out_counts[MULTI_MAX]; uint8_t* out_seen[MULTI_MAX]; int kind[MULTI_MAX]; };
-template <typename T, int CLS, int NACC>
+// PLAIN: no value validity and no filter validity anywhere -> the rows' counts are the same for every slot (one counter set), and the
+// loop body is branch-free with index-clamped loads, R rows per lane in flight; a load behind a branch waits for the branch's own loads
+// first (s_waitcnt), which makes the generic one-row loop latency bound
+template <typename T, int CLS, int NACC, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_acc_small_multi(MultiArgs a, const uint32_t* gids, const uint64_t* fbits, const uint64_t* fvalid, int64_t n, int G) {
-  T acc[NACC][SMALL_G]; uint32_t cnt[NACC][SMALL_G];
+  constexpr int NC = PLAIN ? 1 : NACC;
+  T acc[NACC][SMALL_G]; uint32_t cnt[NC][SMALL_G];
 #pragma unroll
   for (int s = 0; s < NACC; s++)
 #pragma unroll
-    for (int k = 0; k < SMALL_G; k++) { acc[s][k] = (T)0; cnt[s][k] = 0; }
+    for (int k = 0; k < SMALL_G; k++) { acc[s][k] = (T)0; if (s < NC) cnt[s][k] = 0; }
+  if constexpr (PLAIN) {
+    constexpr int R = 2;
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t base = (int64_t)blockIdx.x * BLOCK + threadIdx.x; base < n; base += stride * R) {
+      uint32_t g[R]; T x[R][NACC];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        int64_t i = base + r * stride; bool in = i < n; int64_t ii = in ? i : n - 1;
+        uint32_t gg = gids[ii];
+        bool pass = in && (fbits == nullptr || ((fbits[ii >> 6] >> (ii & 63)) & 1ull));
+        g[r] = pass ? gg : GID_NONE;
+#pragma unroll
+        for (int s = 0; s < NACC; s++) {
+          if (s > 0 && a.vals[s] == a.vals[s - 1]) x[r][s] = x[r][s - 1];
+          else if constexpr (CLS == CLS_I128) x[r][s] = load_i128(a.vals[s], ii); else x[r][s] = ((const T*)a.vals[s])[ii];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int k = 0; k < SMALL_G; k++) {
+          bool m = g[r] == (uint32_t)k; cnt[0][k] += m ? 1u : 0u;
+#pragma unroll
+          for (int s = 0; s < NACC; s++) acc[s][k] += m ? x[r][s] : (T)0;
+        }
+    }
+  } else
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
     uint32_t g = gids[i];
     if (g == GID_NONE || !filter_pass(fbits, fvalid, i)) continue;
@@ -183,7 +216,7 @@ __global__ void __launch_bounds__(BLOCK) k_acc_small_multi(MultiArgs a, const ui
 #pragma unroll
   for (int s = 0; s < NACC; s++)
 #pragma unroll
-    for (int k = 0; k < SMALL_G; k++) { T v = wave_sum_any<T>(acc[s][k]); uint32_t c = wave_sum(cnt[s][k]); if (lane_id() == 0) { s_acc[wave][s][k] = v; s_cnt[wave][s][k] = c; } }
+    for (int k = 0; k < SMALL_G; k++) { T v = wave_sum_any<T>(acc[s][k]); uint32_t c = wave_sum(cnt[s < NC ? s : 0][k]); if (lane_id() == 0) { s_acc[wave][s][k] = v; s_cnt[wave][s][k] = c; } }
   __syncthreads();
   if (threadIdx.x < NACC * SMALL_G) {
     int s = threadIdx.x / SMALL_G, k = threadIdx.x % SMALL_G;
@@ -483,6 +516,14 @@ static bool multi_ok(const dfgpu_acc* a, const dfgpu_array* values, int64_t tota
 dfgpu_status dfgpu_acc_update_batch_multi(dfgpu_ctx* ctx, dfgpu_acc* const* accs, const dfgpu_array* const* values, const dfgpu_array* const* filters, int32_t n_accs,
                                           const dfgpu_array* gids, int64_t total) {
   if (!accs || !values || !gids || n_accs < 0) { if (ctx) ctx->err = "acc_update_batch_multi: null argument"; return DFGPU_INVALID_ARGUMENT; }
+  // accumulators are independent of each other: visit them ordered by (shareable, value class, filter, value column) so that SUM(x) and
+  // AVG(x) become neighbours and share both the pass and the load of x
+  std::vector<int32_t> order((size_t)n_accs); for (int32_t k = 0; k < n_accs; k++) order[(size_t)k] = k;
+  auto key = [&](int32_t k) { bool ok = multi_ok(accs[k], values[k], total); return std::make_tuple(ok ? 0 : 1, ok ? accs[k]->cls : 0, (const void*)(filters ? filters[k] : nullptr), (const void*)(ok ? values[k]->values->ptr : nullptr)); };
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key(a) < key(b); });
+  std::vector<dfgpu_acc*> accs_o; std::vector<const dfgpu_array*> values_o, filters_o;
+  for (int32_t k : order) { accs_o.push_back(accs[k]); values_o.push_back(values[k]); filters_o.push_back(filters ? filters[k] : nullptr); }
+  accs = accs_o.data(); values = values_o.data(); filters = filters_o.data();
   int32_t i = 0;
   while (i < n_accs) {
     const dfgpu_array* f = filters ? filters[i] : nullptr;
@@ -511,7 +552,9 @@ dfgpu_status dfgpu_acc_update_batch_multi(dfgpu_ctx* ctx, dfgpu_acc* const* accs
       const uint64_t* fb = f ? (const uint64_t*)f->values->ptr : nullptr; const uint64_t* fv = f && f->validity ? (const uint64_t*)f->validity->ptr : nullptr;
       int blocks = grid_for(n, BLOCK * 8, ctx->num_cus * 8);
       KernelTimer kt_(ctx, "k_acc_update");
-#define MULTI(T, C, N) hipLaunchKernelGGL((k_acc_small_multi<T, C, N>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, ma, (const uint32_t*)gids->values->ptr, fb, fv, n, (int)total)
+      bool plain = fv == nullptr; for (int s2 = 0; s2 < na; s2++) plain = plain && ma.valid[s2] == nullptr;
+#define MULTI(T, C, N) do { if (plain) hipLaunchKernelGGL((k_acc_small_multi<T, C, N, true>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, ma, (const uint32_t*)gids->values->ptr, fb, fv, n, (int)total); \
+                            else hipLaunchKernelGGL((k_acc_small_multi<T, C, N, false>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, ma, (const uint32_t*)gids->values->ptr, fb, fv, n, (int)total); } while (0)
       int cls = accs[i]->cls;
       if (cls == CLS_I128) MULTI(i128, CLS_I128, 2);
       else if (cls == CLS_F64) { if (na == 2) MULTI(double, CLS_F64, 2); else if (na == 3) MULTI(double, CLS_F64, 3); else MULTI(double, CLS_F64, 4); }
