@@ -149,6 +149,14 @@ def main():
     staged = tpch.Q3ColocatedStaged(tables, batch_size=8192) if world > 1 and args.plan == "colocated" else None
     C_ = ops.Column
     final_keys = [ops.PhysicalSortExpr(C_("revenue", 1), True, True), ops.PhysicalSortExpr(C_("o_orderdate", 2), False, False)]
+    final_slot = final_plan = None
+    if world > 1 and rank == 0:          # rank 0's merge of the gathered partitions: built once around an input slot, like the staged plan
+        import pyarrow as pa
+        empty = ops.batch_from_arrow(ctx, pa.table({"l_orderkey": pa.array([], type=pa.int64()), "revenue": pa.array([], type=pa.decimal128(38, 4)),
+                                                    "o_orderdate": pa.array([], type=pa.date32()), "o_shippriority": pa.array([], type=pa.int32())}))
+        final_slot = ops.MemoryExec([[empty]], empty.schema)
+        final_plan = ops.SortExec(final_keys, final_slot)
+        final_plan.handle(tc)
 
     def step():
         if world == 1:
@@ -161,9 +169,8 @@ def main():
             gathered = exchange.gather_batches(ctx, None, mine, 0, names=Q3_OUTPUT)           # ≙ SortPreservingMergeExec gathering the sorted partitions
             out = []
             if rank == 0 and gathered.num_rows:
-                gb = gathered
-                final = ops.SortExec(final_keys, ops.MemoryExec([[gb]], gb.schema))
-                out = [b for b in final.execute(0, tc)]
+                final_slot.replace([[gathered]])
+                out = [b for b in ops.with_fresh_state(final_plan).execute(0, tc)]
         ctx.synchronize()
         result_rows[0] = sum(b.num_rows for b in out)
 
