@@ -98,6 +98,7 @@ PROTOTYPES = {
     "dfgpu_concat": (C.c_int32, [_P, _PP, C.c_int32, _PP]),
     "dfgpu_array_new_null": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _PP]),
     "dfgpu_array_new_zeros": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _PP]),
+    "dfgpu_array_make_dictionary": (C.c_int32, [_P, _P, _P, _PP]),
     "dfgpu_hash_columns": (C.c_int32, [_P, _PP, C.c_int32, C.c_uint64, _PP]),
     "dfgpu_take": (C.c_int32, [_P, _P, _P, _PP]),
     "dfgpu_filter": (C.c_int32, [_P, _P, _P, _PP]),

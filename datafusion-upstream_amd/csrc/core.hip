@@ -380,6 +380,18 @@ int64_t dfgpu_array_null_count(dfgpu_ctx* ctx, const dfgpu_array* a) {
   return nc;
 }
 
+dfgpu_status dfgpu_array_make_dictionary(dfgpu_ctx* ctx, const dfgpu_array* keys, const dfgpu_array* values, dfgpu_array** out) {
+  return guard(ctx, [&] {
+    if (!keys || !values || !out) fail(DFGPU_INVALID_ARGUMENT, "make_dictionary: null argument");
+    if (!(keys->type >= DFGPU_INT8 && keys->type <= DFGPU_UINT64)) fail(DFGPU_INVALID_ARGUMENT, "make_dictionary: keys must be an integer array (got type %d)", keys->type);
+    if (values->type == DFGPU_DICTIONARY) fail(DFGPU_INVALID_ARGUMENT, "make_dictionary: values are a dictionary array already");
+    ArrayHolder h(new_array(ctx, DFGPU_DICTIONARY, keys->length, values->precision, values->scale));
+    dfgpu_array* a = h.get();
+    a->key_type = keys->type; a->values = keys->values; a->validity = keys->validity; a->null_count = keys->validity ? -1 : 0;
+    a->dictionary = const_cast<dfgpu_array*>(values); dfgpu_array_retain(a->dictionary);
+    *out = h.release();
+  });
+}
 dfgpu_status dfgpu_array_new_null(dfgpu_ctx* ctx, int32_t type, int32_t precision, int32_t scale, int64_t length, dfgpu_array** out) {
   return guard(ctx, [&] {
     validate_type(type);

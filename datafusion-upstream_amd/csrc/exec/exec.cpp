@@ -565,7 +565,19 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
       ArrayRef gids; int64_t total = 1;
       if (grouped) {
         std::vector<ArrayRef> gc; std::vector<const dfgpu_array*> gp;
-        for (auto& e : gexprs) { gc.push_back(into_array(tc, e->eval(tc, b), b.base_rows)); gp.push_back(gc.back().a); }
+        for (auto& e : gexprs) {
+          // A group key that is still a pending gather take(source, indices) from a small source (a dimension attribute carried through
+          // joins: GROUP BY n_name) IS a dictionary array: intern its codes instead of materialising and hashing the values per row.
+          int ci = e->column_index();
+          if (ci >= 0 && ci < (int)b.cols.size() && !b.cols[(size_t)ci].arr && b.cols[(size_t)ci].source && b.cols[(size_t)ci].source.len() * 4 <= b.base_rows) {
+            const Col& c = b.cols[(size_t)ci]; dfgpu_array_desc sd; dfgpu_array_describe(c.source.a, &sd);
+            if (sd.type != DFGPU_DICTIONARY) {
+              dfgpu_array* d = nullptr; tc.check(dfgpu_array_make_dictionary(tc.ctx, c.indices.a, c.source.a, &d));
+              gc.push_back(ArrayRef::adopt(d)); gp.push_back(gc.back().a); continue;
+            }
+          }
+          gc.push_back(into_array(tc, e->eval(tc, b), b.base_rows)); gp.push_back(gc.back().a);
+        }
         dfgpu_array* ids = nullptr; tc.check(dfgpu_groups_intern(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids)); gids = ArrayRef::adopt(ids);
         total = dfgpu_groups_len(groups.g);
       } else { dfgpu_array* z = nullptr; tc.check(dfgpu_array_new_zeros(tc.ctx, DFGPU_UINT32, 0, 0, b.base_rows, &z)); gids = ArrayRef::adopt(z); }

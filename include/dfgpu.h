@@ -139,6 +139,10 @@ DFGPU_API dfgpu_status dfgpu_array_slice(dfgpu_ctx *ctx, const dfgpu_array *a, i
 DFGPU_API dfgpu_status dfgpu_concat(dfgpu_ctx *ctx, const dfgpu_array *const *arrays, int32_t n, dfgpu_array **out);
 /* fixed-width column of `length` zeros, no validity (e.g. the single group id of an AggregateExec without GROUP BY) */
 DFGPU_API dfgpu_status dfgpu_array_new_zeros(dfgpu_ctx *ctx, int32_t type, int32_t precision, int32_t scale, int64_t length, dfgpu_array **out);
+/* DictionaryArray::try_new(keys, values) without copying: an integer array of codes (its validity = NULL codes) over a values array.
+ * A gather take(values, keys) that is never materialised is exactly this array -- group-by and comparison kernels then work on the
+ * codes (a join output column taken from a small dimension table: GROUP BY n_name). */
+DFGPU_API dfgpu_status dfgpu_array_make_dictionary(dfgpu_ctx *ctx, const dfgpu_array *keys, const dfgpu_array *values, dfgpu_array **out);
 /* new_null_array (joins/utils.rs:1214) */
 DFGPU_API dfgpu_status dfgpu_array_new_null(dfgpu_ctx *ctx, int32_t type, int32_t precision, int32_t scale, int64_t length, dfgpu_array **out);
 
