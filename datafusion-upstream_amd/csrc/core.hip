@@ -282,6 +282,7 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     if (k == "force_hash_collisions") ctx->force_hash_collisions = value != 0;
     else if (k == "first_seen_group_order") ctx->first_seen_group_order = value != 0;
     else if (k == "join_rank_index") ctx->join_rank_index = value != 0;
+    else if (k == "join_key_packing") ctx->join_key_packing = value != 0;
     else if (k == "group_run_detection") ctx->group_run_detection = value != 0;
     else if (k == "group_dictionary_canon") ctx->group_dictionary_canon = value != 0;
     else if (k == "defer_flag_checks") {            // nests: +1 enters a deferred region, 0 leaves it and raises what the region deferred

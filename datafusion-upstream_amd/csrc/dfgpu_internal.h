@@ -42,6 +42,7 @@ struct dfgpu_ctx {
   bool force_hash_collisions = false;
   bool first_seen_group_order = true;
   bool join_rank_index = true;
+  bool join_key_packing = true;
   bool group_run_detection = true;
   bool group_dictionary_canon = true;
   // row selection of the running operator (dfgpu_ctx_set_row_selection): expression kernels evaluate every row of full-length

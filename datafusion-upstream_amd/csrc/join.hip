@@ -40,6 +40,10 @@ struct dfgpu_join_table {
   // rank_runs: the keys are non-decreasing WITH repeats (a sorted foreign key): sel_rows[r] = first build row of the r-th distinct key,
   // its rows are the run up to sel_rows[r + 1] (or n_build) -- the CSR of the hash path without hashing or sorting
   bool rank_runs = false;
+  // key packing: 2..4 integer key columns whose value ranges multiply to < 2^40 are packed into ONE Int64 key (sum of (k - min) * stride):
+  // tuple equality == packed equality, and the single-key paths (rank index, bitmap prefilter) apply.  The table then holds the packed
+  // column as its only key; probes pack their tuples with the same parameters (a component outside the build range = NULL = no match).
+  int pack_n = 0; int32_t pack_types[MAX_KEYS] = {0}; int64_t pack_min[MAX_KEYS] = {0}; uint64_t pack_range[MAX_KEYS] = {0}, pack_stride[MAX_KEYS] = {0};
   BufferPtr rank_prefix;  // u32[range / 64]   set bits before each bitmap word
   dfgpu_array* sel_rows = nullptr;   // u32[selected] ascending build rows (masked builds only)
   int64_t mem = 0;
@@ -312,7 +316,56 @@ __global__ void k_add_u32(uint32_t* v, int64_t n, uint32_t add) {
   if (i < n) v[i] += add;
 }
 
+// ---- key packing
+struct PackCols { int32_t n; const void* v[MAX_KEYS]; const uint64_t* valid[MAX_KEYS]; int32_t type[MAX_KEYS]; int64_t mn[MAX_KEYS]; uint64_t range[MAX_KEYS], stride[MAX_KEYS]; };
+__global__ void __launch_bounds__(BLOCK) k_cols_minmax(PackCols pc, int64_t n, long long* out /* [2c] min, [2c+1] max */) {
+  for (int c = 0; c < MAX_KEYS; c++) {
+    if (c >= pc.n) break;
+    long long lo = INT64_MAX, hi = INT64_MIN;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
+      if (valid_at(pc.valid[c], i)) { long long v = key_at(pc.v[c], pc.type[c], i); lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { long long a = __shfl_xor(lo, d, 64), b = __shfl_xor(hi, d, 64); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+    if (lane_id() == 0 && lo <= hi) { atomicMin(&out[2 * c], lo); atomicMax(&out[2 * c + 1], hi); }
+  }
+}
+__global__ void __launch_bounds__(BLOCK) k_pack_keys(PackCols pc, int64_t n, int64_t* out, uint64_t* out_valid) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  bool ok = i < n; uint64_t p = 0;
+#pragma unroll
+  for (int c = 0; c < MAX_KEYS; c++) {
+    if (c >= pc.n) break;
+    if (ok) {
+      if (!valid_at(pc.valid[c], i)) ok = false;
+      else { uint64_t d = (uint64_t)(key_at(pc.v[c], pc.type[c], i) - pc.mn[c]); if (d >= pc.range[c]) ok = false; else p += d * pc.stride[c]; }
+    }
+  }
+  if (i < n) out[i] = ok ? (int64_t)p : 0;
+  if (out_valid) { uint64_t m = ballot64(ok); if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) out_valid[i >> 6] = m; }
+}
+static PackCols pack_cols(const dfgpu_join_table* t, const dfgpu_array* const* cols) {
+  PackCols pc{}; pc.n = t->pack_n;
+  for (int c = 0; c < t->pack_n; c++) { pc.v[c] = cols[c]->values->ptr; pc.valid[c] = cols[c]->validity ? (const uint64_t*)cols[c]->validity->ptr : nullptr; pc.type[c] = cols[c]->type;
+                                        pc.mn[c] = t->pack_min[c]; pc.range[c] = t->pack_range[c]; pc.stride[c] = t->pack_stride[c]; }
+  return pc;
+}
+// packed Int64 key column of `cols` (validity only when a tuple can be NULL / out of the build's ranges)
+static dfgpu_array* pack_key_array(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* cols, bool need_valid) {
+  int64_t n = cols[0]->length;
+  ArrayHolder h(new_fixed(ctx, DFGPU_INT64, n, 0, 0, need_valid));
+  if (n) { KernelTimer kt_(ctx, "k_pack_keys");
+    hipLaunchKernelGGL(k_pack_keys, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, pack_cols(t, cols), n, (int64_t*)h.get()->values->ptr, need_valid ? (uint64_t*)h.get()->validity->ptr : nullptr);
+    KERNEL_CHECK(); }
+  h.get()->null_count = need_valid ? -1 : 0;
+  return h.release();
+}
+
 static void check_key_types(const dfgpu_join_table* t, const dfgpu_array* const* pk, int32_t nkeys) {
+  if (t->pack_n) {
+    if (nkeys != t->pack_n) fail(DFGPU_INVALID_ARGUMENT, "probe has %d key columns, build has %d", nkeys, t->pack_n);
+    for (int c = 0; c < nkeys; c++) if (logical_type(pk[c]) != t->pack_types[c]) fail(DFGPU_INVALID_ARGUMENT, "join key %d: build type %d vs probe type %d (the planner coerces first)", c, t->pack_types[c], logical_type(pk[c]));
+    return;
+  }
   if (nkeys != t->nkeys) fail(DFGPU_INVALID_ARGUMENT, "probe has %d key columns, build has %d", nkeys, t->nkeys);
   for (int c = 0; c < nkeys; c++)
     if (logical_type(pk[c]) != logical_type(t->keys[c])) fail(DFGPU_INVALID_ARGUMENT, "join key %d: build type %d vs probe type %d (the planner coerces first)", c, logical_type(t->keys[c]), logical_type(pk[c]));
@@ -432,9 +485,41 @@ dfgpu_status dfgpu_join_build(dfgpu_ctx* ctx, const dfgpu_array* const* keys, in
     if (!keys || !out) fail(DFGPU_INVALID_ARGUMENT, "join_build: null argument");
     std::unique_ptr<dfgpu_join_table> t(new dfgpu_join_table());
     t->ctx = ctx; t->nkeys = nkeys; t->null_equals_null = null_equals_null != 0;
-    t->ks = make_keyset(keys, nkeys);
-    for (int c = 0; c < nkeys; c++) { t->keys.push_back(const_cast<dfgpu_array*>(keys[c])); dfgpu_array_retain(t->keys.back()); }
     int64_t n = keys[0]->length; t->n_build = n;
+    ArrayHolder packed;
+    bool packable = ctx->join_key_packing && nkeys >= 2 && nkeys <= 4 && !null_equals_null && !ctx->force_hash_collisions && n > 0;
+    for (int c = 0; c < nkeys && packable; c++) packable = keys[c]->type != DFGPU_DICTIONARY && int_key_type(keys[c]->type) && keys[c]->length == n;
+    if (packable) {
+      t->pack_n = nkeys; for (int c = 0; c < nkeys; c++) t->pack_types[c] = logical_type(keys[c]);
+      std::vector<long long> init((size_t)2 * nkeys); for (int c = 0; c < nkeys; c++) { init[(size_t)2 * c] = INT64_MAX; init[(size_t)2 * c + 1] = INT64_MIN; }
+      HIP_CHECK(hipMemcpyAsync(ctx->d_scratch64 + 16, init.data(), init.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+      PackCols pc = pack_cols(t.get(), keys);
+      hipLaunchKernelGGL(k_cols_minmax, dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 4)), dim3(BLOCK), 0, ctx->stream, pc, n, (long long*)(ctx->d_scratch64 + 16));
+      KERNEL_CHECK();
+      HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 16, ctx->d_scratch64 + 16, init.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+      ctx->count_sync("sync:key_packing_ranges");
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      unsigned __int128 prod = 1; bool any_valid = true, nullable = false;
+      for (int c = nkeys - 1; c >= 0; c--) {
+        long long lo = (long long)ctx->h_pinned[16 + 2 * c], hi = (long long)ctx->h_pinned[16 + 2 * c + 1];
+        if (lo > hi) { any_valid = false; lo = hi = 0; }                       // a column of NULLs only: nothing can match
+        t->pack_min[c] = lo; t->pack_range[c] = (uint64_t)hi - (uint64_t)lo + 1; t->pack_stride[c] = (uint64_t)prod;
+        if (t->pack_range[c] == 0) { prod = (unsigned __int128)1 << 100; break; }
+        prod *= t->pack_range[c]; nullable = nullable || keys[c]->validity != nullptr;
+        if (prod > ((unsigned __int128)1 << 40)) break;
+      }
+      if (prod <= ((unsigned __int128)1 << 40)) {
+        (void)any_valid;
+        packed.a = pack_key_array(ctx, t.get(), keys, nullable);
+        const dfgpu_array* pk1 = packed.get(); keys = &pk1; nkeys = 1; t->nkeys = 1;
+        t->ks = make_keyset(keys, 1);
+        t->keys.push_back(packed.release());                                   // the table owns the packed column
+      } else t->pack_n = 0;
+    }
+    if (!t->pack_n) {
+      t->ks = make_keyset(keys, nkeys);
+      for (int c = 0; c < nkeys; c++) { t->keys.push_back(const_cast<dfgpu_array*>(keys[c])); dfgpu_array_retain(t->keys.back()); }
+    }
     t->build_mask = effective_mask(ctx, opt_mask, n);
     t->visited = alloc_buffer(ctx, bitmap_bytes(n), true);
     t->mem = (int64_t)bitmap_bytes(n);
@@ -451,6 +536,12 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
   return guard(ctx, [&] {
     if (!t || !probe_keys || !out_build_idx || !out_probe_idx) fail(DFGPU_INVALID_ARGUMENT, "join_probe: null argument");
     check_key_types(t, probe_keys, nkeys);
+    ArrayHolder packed_probe; const dfgpu_array* pk1 = nullptr;
+    if (t->pack_n) {
+      for (int c = 0; c < nkeys; c++) if (probe_keys[c]->type == DFGPU_DICTIONARY || probe_keys[c]->length != probe_keys[0]->length) fail(DFGPU_NOT_IMPLEMENTED, "probe of a packed multi-key table with dictionary-encoded keys");
+      packed_probe.a = pack_key_array(ctx, t, probe_keys, true);
+      pk1 = packed_probe.get(); probe_keys = &pk1; nkeys = 1;
+    }
     KeySet pks = make_keyset(probe_keys, nkeys);
     int64_t n = probe_keys[0]->length;
     BufferPtr mask = effective_mask(ctx, opt_mask, n);

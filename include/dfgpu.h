@@ -89,6 +89,8 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
  * "first_seen_group_order" (1/0) == group ids in first-seen order (group_values/primitive.rs:137-141);
  * "join_rank_index" (1/0) == let join_build replace the hash table by a bitmap rank index when the single integer key
  * column is strictly increasing (results identical either way; the switch exists for A/B tests);
+ * "join_key_packing" (1/0) == let join_build pack 2..4 integer key columns with small value ranges into one Int64 key (tuple
+ * equality == packed equality), so that the single-key paths apply; results identical;
  * "group_run_detection" (1/0) == let groups_intern number groups by runs when a batch arrives clustered on its keys
  * (≙ GroupOrdering::Full, aggregates/order/full.rs; ids identical to the hash path: first-seen order);
  * "group_dictionary_canon" (1/0) == let groups_intern map dictionary key columns through a de-duplicated dictionary (u32 id of

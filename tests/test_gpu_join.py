@@ -108,6 +108,27 @@ def test_probe_pairs_match_oracle_exactly(ctx, kinds, nb, npr, nf, card, nen):
     assert table.num_rows == nb and table.memory > 0
 
 
+@pytest.mark.parametrize("kinds,nb,npr,nf,card", [(["int64", "int32"], 20000, 60000, 0.0, 300), (["int32", "int64", "int32"], 5000, 20000, 0.1, 40), (["int64", "int64"], 3000, 9000, 0.05, 10**9)],
+                         ids=["2keys", "3keys-nulls", "2keys-wide-range"])
+def test_multi_integer_key_packing_equals_unpacked(ctx, kinds, nb, npr, nf, card):
+    """2..4 integer key columns with small ranges are packed into one Int64 key (join.hip k_pack_keys): pairs (order included) must equal
+    the oracle's and the unpacked hash path's (option join_key_packing=0); probe tuples outside the build ranges and NULL components never
+    match; ranges too wide to pack (10^9 x 10^9) keep the multi-column table."""
+    import dfgpu
+    b, p = keycols(kinds, nb, nf, card), keycols(kinds, npr, nf, card)
+    p = [pa.concat_arrays([c, pa.array([10**6 + 7, -10**6 - 7], type=c.type)]) for c in p]          # components far outside the build ranges
+    want = po.hash_join([b], [p], "Inner", False, batch_size=1 << 40)
+    for packing in (1, 0):
+        ctx.set_option("join_key_packing", packing)
+        try:
+            table = dfgpu.JoinTable(ctx, [ctx.from_arrow(c) for c in b])
+            bi, pi = table.probe([ctx.from_arrow(c) for c in p])
+        finally:
+            ctx.set_option("join_key_packing", 1)
+        assert np.array_equal(bi.to_numpy().astype(np.int64), want.build_idx), f"packing={packing}"
+        assert np.array_equal(pi.to_numpy().astype(np.int64), want.probe_idx), f"packing={packing}"
+
+
 def test_probe_with_fused_masks_equals_filtered_inputs(ctx):
     """FilterExec fused into build and probe: same pairs as compacting first (indices mapped back)."""
     import dfgpu
