@@ -66,29 +66,41 @@ static Field field_of(const std::string& name, const dfgpu_array* a) {
   return Field{name, d.type, d.precision, d.scale};
 }
 
-// a column is a materialised array or a pending gather take(source, indices) (late materialisation)
+// a column is a materialised array or a pending gather (late materialisation).  The gather's row i reads
+// source[chain[0][chain[1][...[i]]]]: gathering a pending column only appends to the chain, and the chain collapses from its short
+// (outer) end when the column is finally read, so an operator that keeps few of a huge join output's rows (TPC-H Q18's semi join)
+// never composes index arrays at the join output's length.
+struct Composed { ArrayRef inner, outer, out; };
+// Columns that came out of one operator share their chain arrays; they also share this memo so each composition runs once, not once
+// per column.  Entries pin the arrays their key points at.
+struct TakeMemo { std::map<std::pair<const dfgpu_array*, const dfgpu_array*>, Composed> composed; };
+using MemoPtr = std::shared_ptr<TakeMemo>;
 struct Col {
-  ArrayRef arr, source, indices;
-  int64_t len() const { return arr ? arr.len() : indices.len(); }
+  ArrayRef arr, source; std::vector<ArrayRef> chain; MemoPtr memo;
+  int64_t len() const { return arr ? arr.len() : chain.back().len(); }
 };
 static ArrayRef take(const TaskContext& tc, const ArrayRef& v, const ArrayRef& idx) { dfgpu_array* o = nullptr; tc.check(dfgpu_take(tc.ctx, v.a, idx.a, &o)); return ArrayRef::adopt(o); }
+static const ArrayRef& col_indices(const TaskContext& tc, Col& c) {           // the chain as one index array into c.source
+  while (c.chain.size() > 1) {
+    ArrayRef outer = std::move(c.chain.back()); c.chain.pop_back();
+    ArrayRef& inner = c.chain.back();
+    if (c.memo) {
+      auto key = std::make_pair((const dfgpu_array*)inner.a, (const dfgpu_array*)outer.a);
+      auto it = c.memo->composed.find(key);
+      if (it == c.memo->composed.end()) it = c.memo->composed.emplace(key, Composed{inner, outer, take(tc, inner, outer)}).first;
+      inner = it->second.out;
+    } else inner = take(tc, inner, outer);
+  }
+  return c.chain[0];
+}
 static const ArrayRef& col_get(const TaskContext& tc, Col& c) {
-  if (!c.arr) { c.arr = take(tc, c.source, c.indices); c.source = ArrayRef(); c.indices = ArrayRef(); }
+  if (!c.arr) { c.arr = take(tc, c.source, col_indices(tc, c)); c.source = ArrayRef(); c.chain.clear(); c.memo.reset(); }
   return c.arr;
 }
-// Columns that came out of one earlier join share ONE pending index array; gathering a batch of them through `idx` composes that array
-// once, not once per column (TPC-H Q18's 600 M-row join output: 5 columns x 9.6 GB of index traffic -> 1 x).
-struct TakeMemo { std::map<std::pair<const dfgpu_array*, const dfgpu_array*>, ArrayRef> composed; };
-static Col col_take(const TaskContext& tc, const Col& c, const ArrayRef& idx, TakeMemo* memo = nullptr) {
-  Col o;
-  if (c.arr) { o.source = c.arr; o.indices = idx; return o; }
-  o.source = c.source;                                                       // gather of a gather: compose the indices
-  if (memo) {
-    auto key = std::make_pair((const dfgpu_array*)c.indices.a, (const dfgpu_array*)idx.a);
-    auto it = memo->composed.find(key);
-    if (it == memo->composed.end()) it = memo->composed.emplace(key, take(tc, c.indices, idx)).first;
-    o.indices = it->second;
-  } else o.indices = take(tc, c.indices, idx);
+static Col col_take(const Col& c, const ArrayRef& idx, const MemoPtr& memo = nullptr) {
+  Col o; o.memo = memo;
+  if (c.arr) { o.source = c.arr; o.chain.push_back(idx); return o; }
+  o.source = c.source; o.chain = c.chain; o.chain.push_back(idx);
   return o;
 }
 static Col col_of(ArrayRef a) { Col c; c.arr = std::move(a); return c; }
@@ -103,7 +115,7 @@ static Batch materialize(const TaskContext& tc, const Batch& b) {
   if (!b.selection) return b;
   ArrayRef sel = mask_indices(tc, b.selection);
   Batch o; o.schema = b.schema; o.base_rows = sel.len();
-  TakeMemo memo; for (auto& c : b.cols) o.cols.push_back(col_take(tc, c, sel, &memo));
+  MemoPtr memo = std::make_shared<TakeMemo>(); for (auto& c : b.cols) o.cols.push_back(col_take(c, sel, memo));
   return o;
 }
 static int64_t num_rows(const TaskContext& tc, const Batch& b) { return b.selection ? mask_indices(tc, b.selection).len() : b.base_rows; }
@@ -287,9 +299,9 @@ struct FilterExec : Plan {        // filter.rs:56-66, batch_filter :315-327
 static Batch materialize_subset(const TaskContext& tc, Batch& b, const std::set<int>& needed) {   // compact only referenced columns
   ArrayRef sel = mask_indices(tc, b.selection);
   Batch o; o.schema = b.schema; o.base_rows = sel.len();
-  ArrayRef filler; TakeMemo memo;
+  ArrayRef filler; MemoPtr memo = std::make_shared<TakeMemo>();
   for (size_t i = 0; i < b.cols.size(); i++) {
-    if (needed.count((int)i)) o.cols.push_back(col_take(tc, b.cols[i], sel, &memo));
+    if (needed.count((int)i)) o.cols.push_back(col_take(b.cols[i], sel, memo));
     else { if (!filler) { dfgpu_array* f = nullptr; tc.check(dfgpu_array_new_null(tc.ctx, DFGPU_INT8, 0, 0, o.base_rows, &f)); filler = ArrayRef::adopt(f); } o.cols.push_back(col_of(filler)); }
   }
   return o;
@@ -389,7 +401,7 @@ static void partition_batch(const TaskContext& tc, Batch& b, const std::vector<E
       dfgpu_array* s = nullptr; tc.check(dfgpu_array_slice(tc.ctx, indices.a, off, counts[(size_t)d], &s)); ArrayRef part = ArrayRef::adopt(s);
       ArrayRef rows = sel ? take(tc, sel, part) : part;
       Batch o; o.schema = b.schema; o.base_rows = counts[(size_t)d];
-      TakeMemo memo; for (auto& c : b.cols) o.cols.push_back(col_take(tc, c, rows, &memo));
+      MemoPtr memo = std::make_shared<TakeMemo>(); for (auto& c : b.cols) o.cols.push_back(col_take(c, rows, memo));
       outs[(size_t)d].push_back(std::move(o));
     }
     off += counts[(size_t)d];
@@ -467,13 +479,13 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
     S(const HashJoinExec* o, int p, TaskContext t) : op(o), tc(t), partition(p) {}
     ArrayRef filter_idx(const ArrayRef& idx, const ArrayRef& m) { dfgpu_array* o = nullptr; tc.check(dfgpu_filter(tc.ctx, idx.a, m.a, &o)); return ArrayRef::adopt(o); }
     Batch build_batch(Batch* build, Batch& probe_b, const ArrayRef& bidx, const ArrayRef& pidx) {     // build_batch_from_indices (joins/utils.rs:1180-1230)
-      Batch o; o.schema = out_schema; o.base_rows = pidx.len(); TakeMemo memo;
+      Batch o; o.schema = out_schema; o.base_rows = pidx.len(); MemoPtr memo = std::make_shared<TakeMemo>();
       auto lf = op->left->schema();
       if (!op->right_only()) for (size_t i = 0; i < (lf ? lf->f.size() : 0); i++) {
-        if (build) o.cols.push_back(col_take(tc, build->cols[i], bidx, &memo));
+        if (build) o.cols.push_back(col_take(build->cols[i], bidx, memo));
         else { dfgpu_array* nn = nullptr; tc.check(dfgpu_array_new_null(tc.ctx, lf->f[i].type, lf->f[i].precision, lf->f[i].scale, o.base_rows, &nn)); o.cols.push_back(col_of(ArrayRef::adopt(nn))); }
       }
-      if (!op->left_only()) for (auto& c : probe_b.cols) o.cols.push_back(col_take(tc, c, pidx, &memo));
+      if (!op->left_only()) for (auto& c : probe_b.cols) o.cols.push_back(col_take(c, pidx, memo));
       return o;
     }
     bool next(Batch& out) override {
@@ -498,7 +510,7 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
             Batch inter; inter.schema = std::make_shared<Schema>(); inter.base_rows = bidx.len();
             for (size_t i = 0; i < op->f_side.size(); i++) {
               Col src = op->f_side[i] == 0 ? bs->batch.cols.at((size_t)op->f_index[i]) : pb.cols.at((size_t)op->f_index[i]);
-              Col t = col_take(tc, src, op->f_side[i] == 0 ? bidx : pidx); inter.cols.push_back(col_of(col_get(tc, t))); inter.schema->f.push_back(Field{"x"});
+              Col t = col_take(src, op->f_side[i] == 0 ? bidx : pidx); inter.cols.push_back(col_of(col_get(tc, t))); inter.schema->f.push_back(Field{"x"});
             }
             ArrayRef m = into_array(tc, op->filter->eval(tc, inter), inter.base_rows);
             ArrayRef nb = filter_idx(bidx, m), np = filter_idx(pidx, m); bidx = nb; pidx = np;
@@ -519,7 +531,7 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
         dfgpu_array* f = nullptr; tc.check(dfgpu_join_final_indices(tc.ctx, bs->table->t, op->join_type, &f)); ArrayRef fidx = ArrayRef::adopt(f);
         fidx = reference_final_order(fidx);
         Batch o; o.schema = out_schema; o.base_rows = fidx.len();
-        TakeMemo memo; for (auto& c : bs->batch.cols) o.cols.push_back(col_take(tc, c, fidx, &memo));
+        MemoPtr memo = std::make_shared<TakeMemo>(); for (auto& c : bs->batch.cols) o.cols.push_back(col_take(c, fidx, memo));
         if (!op->left_only()) { auto rf = op->right->schema(); for (auto& fd : rf->f) { dfgpu_array* nn = nullptr; tc.check(dfgpu_array_new_null(tc.ctx, fd.type, fd.precision, fd.scale, o.base_rows, &nn)); o.cols.push_back(col_of(ArrayRef::adopt(nn))); } }
         out = std::move(o); return true;
       }
@@ -580,9 +592,9 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
           // joins: GROUP BY n_name) IS a dictionary array: intern its codes instead of materialising and hashing the values per row.
           int ci = e->column_index();
           if (ci >= 0 && ci < (int)b.cols.size() && !b.cols[(size_t)ci].arr && b.cols[(size_t)ci].source && b.cols[(size_t)ci].source.len() * 4 <= b.base_rows) {
-            const Col& c = b.cols[(size_t)ci]; dfgpu_array_desc sd; dfgpu_array_describe(c.source.a, &sd);
+            Col& c = b.cols[(size_t)ci]; dfgpu_array_desc sd; dfgpu_array_describe(c.source.a, &sd);
             if (sd.type != DFGPU_DICTIONARY) {
-              dfgpu_array* d = nullptr; tc.check(dfgpu_array_make_dictionary(tc.ctx, c.indices.a, c.source.a, &d));
+              dfgpu_array* d = nullptr; tc.check(dfgpu_array_make_dictionary(tc.ctx, col_indices(tc, c).a, c.source.a, &d));
               gc.push_back(ArrayRef::adopt(d)); gp.push_back(gc.back().a); continue;
             }
           }
@@ -651,7 +663,7 @@ struct SortExec : Plan {          // sorts/sort.rs:719-733; sort_batch :584-609
       for (auto& e : exprs) { keys.push_back(into_array(tc, e->eval(tc, b), b.base_rows)); kp.push_back(keys.back().a); }
       dfgpu_array* idx = nullptr; tc.check(dfgpu_sort_to_indices(tc.ctx, kp.data(), desc.data(), nulls_first.data(), (int32_t)kp.size(), fetch, &idx)); ArrayRef ix = ArrayRef::adopt(idx);
       Batch o; o.schema = b.schema; o.base_rows = ix.len();
-      TakeMemo memo; for (auto& c : b.cols) o.cols.push_back(col_take(tc, c, ix, &memo));
+      MemoPtr memo = std::make_shared<TakeMemo>(); for (auto& c : b.cols) o.cols.push_back(col_take(c, ix, memo));
       outv.push_back(std::move(o));
     }
     return std::unique_ptr<Stream>(new VecStream(std::move(outv)));
@@ -682,7 +694,7 @@ struct SortPreservingMergeExec : Plan {
       for (auto& e : exprs) { keys.push_back(into_array(tc, e->eval(tc, b), b.base_rows)); kp.push_back(keys.back().a); }
       dfgpu_array* idx = nullptr; tc.check(dfgpu_sort_to_indices(tc.ctx, kp.data(), desc.data(), nulls_first.data(), (int32_t)kp.size(), fetch, &idx)); ArrayRef ix = ArrayRef::adopt(idx);
       Batch o; o.schema = b.schema; o.base_rows = ix.len();
-      TakeMemo memo; for (auto& c : b.cols) o.cols.push_back(col_take(tc, c, ix, &memo));
+      MemoPtr memo = std::make_shared<TakeMemo>(); for (auto& c : b.cols) o.cols.push_back(col_take(c, ix, memo));
       outv.push_back(std::move(o));
     }
     return std::unique_ptr<Stream>(new VecStream(std::move(outv)));
