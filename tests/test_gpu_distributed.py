@@ -256,3 +256,100 @@ def test_q5_partitioned_joins_over_all_to_all(world):
     want = oracle_agg(x.append_column("rev", r), ["n_name"], [("SUM", "rev")])
     want_rows = sorted(zip(want["c0"].to_pylist(), want["c1"].to_pylist()))
     assert len(want_rows) == 5 and results[0] == want_rows
+
+
+def _click_rows(seed=91, n=60000, card=900, zipf=True):
+    rng = np.random.default_rng(seed)
+    ids = (rng.zipf(1.1, n) % card) if zipf else rng.integers(0, card, n)
+    words = np.array([""] + [f"https://site{k}.example/{k * 7919 % 1000}" for k in range(1, card)], dtype=object)
+    key = words[ids]
+    key_null = rng.random(n) < 0.01                                      # NULL keys are one group of their own (primitive.rs:118-122)
+    length = rng.integers(0, 500, n).astype(np.int32)
+    w = rng.integers(0, 10**6, n).astype(np.int64)
+    return key, key_null, length, w
+
+
+def _click_worker(rank, world, port, q, zipf):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        import faulthandler
+        faulthandler.dump_traceback_later(140, exit=True)
+        import pyarrow as pa
+        import torch
+        import torch.distributed as dist
+        import dfgpu
+        from dfgpu import capi, exchange, physical_plan as ops
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ctx = dfgpu.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        tc = ops.TaskContext(ctx, 8192)
+        key, key_null, length, w = _click_rows(zipf=zipf)
+        n = len(key)
+        lo, hi = n * rank // world, n * (rank + 1) // world
+        # every rank (≙ every parquet file group) carries its OWN dictionary: the distinct values of its rows in a rank-specific order,
+        # so equal codes on two ranks mean different strings and the exchange has to move values, not codes
+        keys = pa.array(list(key[lo:hi]), type=pa.utf8(), mask=key_null[lo:hi])
+        enc = keys.dictionary_encode()
+        perm = np.random.default_rng(rank + 5).permutation(len(enc.dictionary))
+        inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
+        codes = pa.array(inv[enc.indices.fill_null(0).to_numpy()].astype(np.int32), mask=key_null[lo:hi])
+        dkeys = pa.DictionaryArray.from_arrays(codes, enc.dictionary.take(pa.array(perm)))
+        tab = pa.table({"key": dkeys, "len": pa.array(length[lo:hi]), "w": pa.array(w[lo:hi])})
+        halves = [ops.batch_from_arrow(ctx, tab.slice(0, tab.num_rows // 2)), ops.batch_from_arrow(ctx, tab.slice(tab.num_rows // 2))]
+        src = ops.MemoryExec([halves], halves[0].schema)
+        C, L, B, F = ops.Column, ops.Literal, ops.BinaryExpr, ops.Field
+        f = ops.CoalesceBatchesExec(ops.FilterExec(B(C("key", 0), "!=", L("", pa.utf8())), src), 8192)            # NULL <> '' is NULL: those rows go too
+        proj = ops.ProjectionExec([(C("key", 0), "key"), (ops.CastExpr(C("len", 1), capi.FLOAT64), "lenf"), (C("w", 2), "w")], f)
+        aggs = [ops.AggregateFunctionExpr("AVG", C("lenf", 1), "l", input_field=F("x", capi.FLOAT64)), ops.AggregateFunctionExpr("COUNT", None, "c"),
+                ops.AggregateFunctionExpr("MAX", C("w", 2), "m", input_field=F("x", capi.INT64))]
+        partial = ops.AggregateExec("Partial", [(C("key", 0), "k")], aggs, proj)
+        shuffled = ops.CoalesceBatchesExec(exchange.ShuffleExec(partial, [C("k", 0)]), 8192)                       # Utf8 group key + AVG (count, sum) + COUNT + MAX states
+        final = ops.AggregateExec("FinalPartitioned", [(C("k", 0), "k")], aggs, shuffled)
+        having = ops.FilterExec(B(C("c", 2), ">", L(3, pa.int64())), final)
+        order = [ops.PhysicalSortExpr(C("l", 1), True, True), ops.PhysicalSortExpr(C("k", 0), False, False)]
+        local = [b for b in ops.SortExec(order, having, fetch=25).execute(0, tc)]                                 # per-rank TopK, merged on rank 0
+        mine = ops.concat_batches(local[0].schema, local) if local else None
+        g = exchange.gather_batches(ctx, None, mine, 0, names=["k", "l", "c", "m"])
+        rows = []
+        if rank == 0 and g is not None and g.num_rows:
+            merged = [b for b in ops.SortExec(order, ops.MemoryExec([[g]], g.schema), fetch=25).execute(0, tc)]
+            rows = list(zip(*[c.to_arrow().to_pylist() for c in ops.concat_batches(merged[0].schema, merged).columns]))
+        q.put((rank, rows))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world,zipf", [(2, True), (3, False)])
+def test_clickbench_group_by_dictionary_key_across_ranks(world, zipf):
+    """BASELINE config 5's shape (ClickBench Q28, queries.sql:29): filter -> GROUP BY a dictionary-encoded Utf8 key -> AVG/COUNT/MAX ->
+    HAVING -> ORDER BY .. LIMIT 25, as Partial -> hash shuffle on the group key -> FinalPartitioned -> per-rank TopK -> merge.  Each rank's
+    rows use a different dictionary, so the group key crosses the exchange by value; Zipf keys put one heavy group on one rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 28100 + (os.getpid() % 700) + world
+    procs = [ctx.Process(target=_click_worker, args=(r, world, port, q, zipf)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=160) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        assert isinstance(results[r], list), results[r]
+    key, key_null, length, w = _click_rows(zipf=zipf)
+    groups = {}
+    for k, isnull, ln, wt in zip(key, key_null, length, w):
+        if isnull or k == "":
+            continue
+        g = groups.setdefault(k, [0, 0.0, -1])
+        g[0] += 1; g[1] += float(ln); g[2] = max(g[2], int(wt))
+    want = sorted(((k, s / c, c, m) for k, (c, s, m) in groups.items() if c > 3), key=lambda r: (-r[1], r[0]))[:25]
+    got = results[0]
+    assert len(got) == len(want) == 25
+    for a, b in zip(got, want):
+        assert a[0] == b[0] and a[2] == b[2] and a[3] == b[3] and abs(a[1] - b[1]) <= 1e-9 * abs(b[1]), (a, b)
