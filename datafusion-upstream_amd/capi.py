@@ -77,6 +77,7 @@ PROTOTYPES = {
     "dfgpu_last_error": (C.c_char_p, [_P]),
     "dfgpu_ctx_synchronize": (C.c_int32, [_P]),
     "dfgpu_ctx_set_option": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
+    "dfgpu_ctx_get_option": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     "dfgpu_ctx_stream": (_P, [_P]),
     "dfgpu_version": (C.c_char_p, []),
     "dfgpu_ctx_set_row_selection": (C.c_int32, [_P, _P]),

@@ -439,13 +439,14 @@ struct BuildSide { Batch batch; std::shared_ptr<JoinTableRef> table; std::vector
 
 struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
   PlanPtr left, right; std::vector<ExprPtr> on_l, on_r; ExprPtr filter; std::vector<int> f_side, f_index;
-  int join_type, mode; bool null_equals_null;
+  int join_type, mode; bool null_equals_null; bool swap_small_right = true;
   mutable std::mutex mu; mutable std::shared_ptr<BuildSide> shared;     // CollectLeft: OnceAsync (joins/utils.rs:736-776)
   PlanPtr fresh() const override {
     auto j = std::make_shared<HashJoinExec>(); j->left = left->fresh(); j->right = right->fresh(); j->on_l = on_l; j->on_r = on_r; j->filter = filter; j->f_side = f_side; j->f_index = f_index;
-    j->join_type = join_type; j->mode = mode; j->null_equals_null = null_equals_null; return j;
+    j->join_type = join_type; j->mode = mode; j->null_equals_null = null_equals_null; j->swap_small_right = swap_small_right; return j;
   }
   const char* name() const override { return "HashJoinExec"; }
+  bool swap_allowed(const TaskContext& tc) const { int64_t v = 1; dfgpu_ctx_get_option(tc.ctx, "join_swap_small_semi", &v); return swap_small_right && v != 0; }
   bool left_only() const { return join_type == DFGPU_JOIN_LEFT_SEMI || join_type == DFGPU_JOIN_LEFT_ANTI; }
   bool right_only() const { return join_type == DFGPU_JOIN_RIGHT_SEMI || join_type == DFGPU_JOIN_RIGHT_ANTI; }
   SchemaPtr schema() const override {       // build_join_schema (joins/utils.rs:657-729)
@@ -456,25 +457,30 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
   }
   int partitions() const override { return right->partitions(); }
   // collect_left_input (hash_join.rs:678-768); the device table indexes the build side in ORIGINAL input order
-  std::shared_ptr<BuildSide> collect_build(int partition, const TaskContext& tc) const {
+  std::shared_ptr<BuildSide> collect_left(int partition, const TaskContext& tc, ArrayRef* fused) const {
     auto bs = std::make_shared<BuildSide>();
     std::vector<Batch> in;
     if (partition < 0) { for (int p = 0; p < left->partitions(); p++) drain(left, p, tc, in); } else drain(left, partition, tc, in);
-    ArrayRef fused;
-    if (in.size() == 1 && in[0].selection) { bs->batch = in[0]; fused = in[0].selection; bs->batch.selection = ArrayRef(); bs->segments = { bs->batch.base_rows }; bs->empty = false; }
+    if (in.size() == 1 && in[0].selection) { bs->batch = in[0]; *fused = in[0].selection; bs->batch.selection = ArrayRef(); bs->segments = { bs->batch.base_rows }; bs->empty = false; }
     else {
       std::vector<Batch> m; for (auto& b : in) { Batch x = materialize(tc, b); if (x.base_rows) { bs->segments.push_back(x.base_rows); m.push_back(std::move(x)); } }
       if (m.empty()) return bs;
       concat_batches(tc, m, &bs->batch); bs->empty = false;
     }
+    return bs;
+  }
+  void build_table(const std::shared_ptr<BuildSide>& bs, const ArrayRef& fused, const TaskContext& tc) const {
+    if (bs->empty) return;
     std::vector<ArrayRef> keys; std::vector<const dfgpu_array*> kp;
     for (auto& e : on_l) { keys.push_back(into_array(tc, e->eval(tc, bs->batch), bs->batch.base_rows)); kp.push_back(keys.back().a); }
     bs->table = std::make_shared<JoinTableRef>();
     tc.check(dfgpu_join_build(tc.ctx, kp.data(), (int32_t)kp.size(), fused.a, null_equals_null ? 1 : 0, &bs->table->t));
-    return bs;
+  }
+  std::shared_ptr<BuildSide> collect_build(int partition, const TaskContext& tc) const {
+    ArrayRef fused; auto bs = collect_left(partition, tc, &fused); build_table(bs, fused, tc); return bs;
   }
   struct S : Stream {
-    const HashJoinExec* op; TaskContext tc; int partition; std::unique_ptr<Stream> probe; std::shared_ptr<BuildSide> bs; int state = 0;   // 0 WaitBuildSide, 1 probing, 2 done
+    const HashJoinExec* op; TaskContext tc; int partition; std::unique_ptr<Stream> probe; std::shared_ptr<BuildSide> bs; Batch swapped; int state = 0;   // 0 WaitBuildSide, 1 probing, 2 final pass, 3 done, 4 swapped semi/anti result pending
     SchemaPtr out_schema;
     S(const HashJoinExec* o, int p, TaskContext t) : op(o), tc(t), partition(p) {}
     ArrayRef filter_idx(const ArrayRef& idx, const ArrayRef& m) { dfgpu_array* o = nullptr; tc.check(dfgpu_filter(tc.ctx, idx.a, m.a, &o)); return ArrayRef::adopt(o); }
@@ -490,10 +496,22 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
     }
     bool next(Batch& out) override {
       if (state == 0) {           // WaitBuildSide (hash_join.rs:1149-1193)
-        if (op->mode == 0) { std::lock_guard<std::mutex> l(op->mu); if (!op->shared) op->shared = op->collect_build(-1, tc); bs = op->shared; }
+        if (op->left_only() && op->swap_allowed(tc) && (op->mode != 0 || op->right->partitions() == 1)) {
+          // LeftSemi / LeftAnti keep only left rows, in ascending index of the collected left batch, so WHICH side the device table indexes
+          // is not observable: with a right side much smaller than the left (TPC-H Q18: 600 M joined rows IN a few thousand order keys)
+          // the table is built on the right and the collected left batch probes it once.
+          ArrayRef fused; bs = op->collect_left(op->mode == 0 ? -1 : partition, tc, &fused);
+          std::vector<Batch> rin; drain(op->right, partition, tc, rin);
+          Batch rb; bool have_right = concat_batches(tc, rin, &rb) && rb.base_rows > 0;       // selections applied: base_rows is the row count
+          out_schema = op->schema();
+          if (!bs->empty && rb.base_rows * 8 <= bs->batch.base_rows) { swapped = semi_by_probing_left(fused, have_right ? &rb : nullptr); state = 4; }
+          else { op->build_table(bs, fused, tc); std::vector<Batch> one; if (have_right) one.push_back(std::move(rb)); probe.reset(new VecStream(std::move(one))); state = 1; }
+        }
+        else if (op->mode == 0) { std::lock_guard<std::mutex> l(op->mu); if (!op->shared) op->shared = op->collect_build(-1, tc); bs = op->shared; }
         else bs = op->collect_build(partition, tc);
-        probe = op->right->execute(partition, tc); out_schema = op->schema(); state = 1;
+        if (state == 0) { probe = op->right->execute(partition, tc); out_schema = op->schema(); state = 1; }
       }
+      if (state == 4) { state = 3; if (swapped.base_rows == 0) return false; out = std::move(swapped); return true; }
       bool need_final = op->join_type == DFGPU_JOIN_LEFT || op->join_type == DFGPU_JOIN_FULL || op->left_only();     // need_produce_result_in_final
       while (state == 1) {        // FetchProbeBatch / ProcessProbeBatch (:1199-1343)
         Batch pb; if (!probe->next(pb)) { state = 2; break; }
@@ -536,6 +554,47 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
         out = std::move(o); return true;
       }
       return false;
+    }
+    Batch semi_by_probing_left(ArrayRef fused, Batch* right_rows) {
+      Batch o; o.schema = out_schema;
+      const bool have_right = right_rows != nullptr; Batch none; Batch& rb = have_right ? *right_rows : none;
+      Batch& lb = bs->batch;
+      const bool anti = op->join_type == DFGPU_JOIN_LEFT_ANTI;
+      if (anti && fused) {          // the complement below runs over every row of the left batch: apply a fused selection first
+        Batch sel = lb; sel.selection = fused; lb = materialize(tc, sel); fused = ArrayRef(); bs->segments = { lb.base_rows };
+      }
+      ArrayRef lidx;
+      if (!have_right) {
+        if (!anti) return o;
+        dfgpu_array *e0 = nullptr, *e1 = nullptr; dfgpu_array_desc d{}; d.type = DFGPU_UINT64; d.values = &d; tc.check(dfgpu_array_import_host(tc.ctx, &d, &e0)); ArrayRef b0 = ArrayRef::adopt(e0);
+        d.type = DFGPU_UINT32; tc.check(dfgpu_array_import_host(tc.ctx, &d, &e1)); ArrayRef p0 = ArrayRef::adopt(e1);
+        dfgpu_array *b2 = nullptr, *p2 = nullptr; tc.check(dfgpu_join_adjust_indices(tc.ctx, b0.a, p0.a, 0, lb.base_rows, DFGPU_JOIN_RIGHT_ANTI, &b2, &p2)); ArrayRef drop = ArrayRef::adopt(b2); lidx = ArrayRef::adopt(p2);
+      } else {
+        std::vector<ArrayRef> rk, lk; std::vector<const dfgpu_array*> rp, lp;
+        for (auto& e : op->on_r) { rk.push_back(into_array(tc, e->eval(tc, rb), rb.base_rows)); rp.push_back(rk.back().a); }
+        JoinTableRef table; tc.check(dfgpu_join_build(tc.ctx, rp.data(), (int32_t)rp.size(), nullptr, op->null_equals_null ? 1 : 0, &table.t));
+        for (auto& e : op->on_l) { lk.push_back(into_array(tc, e->eval(tc, lb), lb.base_rows)); lp.push_back(lk.back().a); }
+        dfgpu_array *b = nullptr, *p = nullptr;
+        tc.check(dfgpu_join_probe(tc.ctx, table.t, lp.data(), (int32_t)lp.size(), fused.a, &b, &p)); ArrayRef ridx = ArrayRef::adopt(b); lidx = ArrayRef::adopt(p);
+        if (op->filter && ridx.len()) {       // the filter's side 0 is still the left input
+          Batch inter; inter.schema = std::make_shared<Schema>(); inter.base_rows = ridx.len();
+          for (size_t i = 0; i < op->f_side.size(); i++) {
+            Col src = op->f_side[i] == 0 ? lb.cols.at((size_t)op->f_index[i]) : rb.cols.at((size_t)op->f_index[i]);
+            Col t = col_take(src, op->f_side[i] == 0 ? lidx : ridx); inter.cols.push_back(col_of(col_get(tc, t))); inter.schema->f.push_back(Field{"x"});
+          }
+          ArrayRef m = into_array(tc, op->filter->eval(tc, inter), inter.base_rows);
+          ArrayRef nr = filter_idx(ridx, m), nl = filter_idx(lidx, m); ridx = nr; lidx = nl;
+        }
+        dfgpu_array *b2 = nullptr, *p2 = nullptr;       // get_semi_indices / get_anti_indices over the left rows (joins/utils.rs:1309-1364)
+        tc.check(dfgpu_join_adjust_indices(tc.ctx, ridx.a, lidx.a, 0, lb.base_rows, anti ? DFGPU_JOIN_RIGHT_ANTI : DFGPU_JOIN_RIGHT_SEMI, &b2, &p2));
+        ArrayRef drop = ArrayRef::adopt(b2); lidx = ArrayRef::adopt(p2);
+      }
+      if (bs->segments.size() > 1 && lidx.len()) {
+        dfgpu_array* w = nullptr; tc.check(dfgpu_cast(tc.ctx, lidx.a, DFGPU_UINT64, 0, 0, &w)); lidx = reference_final_order(ArrayRef::adopt(w));
+      }
+      o.base_rows = lidx.len();
+      MemoPtr memo = std::make_shared<TakeMemo>(); for (auto& c : lb.cols) o.cols.push_back(col_take(c, lidx, memo));
+      return o;
     }
     // The reference concatenates the build batches in REVERSED order (hash_join.rs:746,764) and emits the final
     // unmatched / semi rows in ascending index of THAT batch (joins/utils.rs:1119-1141): last input batch first.

@@ -33,6 +33,9 @@ struct dfgpu_join_table {
   // exact membership bitmap over [key_min, key_min + range) for single integer keys with a dense domain: the probe tests
   // one bit (L2 / Infinity Cache resident, perfectly local for clustered keys) and touches the hash table for matches only
   BufferPtr bitmap; int64_t key_min = 0; uint64_t range = 0;
+  // a build side that is tiny against its key range (a few thousand order keys out of 600 M) gets no bitmap up front; a probe batch
+  // of >= range / 16 rows builds it on arrival (clearing range / 8 bytes is then small against streaming the probe keys)
+  bool lazy_bitmap = false; BufferPtr lazy_row_slot;
   // rank index (strictly increasing single integer key, the shape of every clustered primary key): no hash table at all.
   // The bitmap IS the table: build row = rank of the key's bit among the set bits (word prefix + popcount), mapped through
   // sel_rows when a build selection is fused; rank_identity = the keys are key_min + row, so the row is the key offset.
@@ -406,6 +409,10 @@ static void build_hash_table(dfgpu_ctx* ctx, dfgpu_join_table* t, bool with_bitm
         DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_setbits<T>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, rs, n, (int64_t)lo, (uint64_t*)t->bitmap->ptr));
         KERNEL_CHECK();
         t->mem += (int64_t)bitmap_bytes((int64_t)range);
+      } else if (range != 0 && range <= (1ull << 32)) {     // too sparse to pay for up front; a probe batch large enough to amortise it builds it (join_probe)
+        t->lazy_bitmap = true; t->key_min = lo; t->range = range;
+        t->lazy_row_slot = alloc_buffer(ctx, (size_t)(n + 1) * 4);
+        HIP_CHECK(hipMemcpyAsync(t->lazy_row_slot->ptr, row_slot->ptr, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
       }
     }
   }
@@ -553,6 +560,15 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
     bool use_bitmap = false;
     if (n) {
       const dfgpu_array* pk = probe_keys[0];
+      if (!t->bitmap && t->lazy_bitmap && pk->type == t->keys[0]->type && t->range <= (uint64_t)n * 16) {
+        auto* mt = const_cast<dfgpu_join_table*>(t); const dfgpu_array* key0 = t->keys[0];
+        KernelTimer kt_(ctx, "join_build_bitmap");
+        mt->bitmap = alloc_buffer(ctx, bitmap_bytes((int64_t)t->range), true); mt->mem += (int64_t)bitmap_bytes((int64_t)t->range);
+        DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_setbits<T>), dim3(grid_for(t->n_build, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const T*)key0->values->ptr,
+                                                              (const uint32_t*)t->lazy_row_slot->ptr, t->n_build, t->key_min, (uint64_t*)mt->bitmap->ptr));
+        KERNEL_CHECK();
+        mt->lazy_bitmap = false; mt->lazy_row_slot.reset();
+      }
       use_bitmap = t->bitmap && pk->type == t->keys[0]->type;      // same physical integer type, no dictionary
       if (!use_bitmap && !t->slots) build_hash_table(ctx, const_cast<dfgpu_join_table*>(t), false);   // rank index cannot serve this probe column
       if (use_bitmap) {

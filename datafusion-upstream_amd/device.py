@@ -43,6 +43,12 @@ class Context:
     def set_option(self, key: str, value: int):
         self.check(self.lib.dfgpu_ctx_set_option(self.h, key.encode(), int(value)))
 
+    def get_option(self, key: str) -> int:
+        import ctypes
+        v = ctypes.c_int64(0)
+        self.check(self.lib.dfgpu_ctx_get_option(self.h, key.encode(), ctypes.byref(v)))
+        return int(v.value)
+
     def profile_enable(self, on: bool = True):
         self.check(self.lib.dfgpu_profile_enable(self.h, int(on)))
 

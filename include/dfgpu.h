@@ -95,11 +95,14 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
  * (≙ GroupOrdering::Full, aggregates/order/full.rs; ids identical to the hash path: first-seen order);
  * "group_dictionary_canon" (1/0) == let groups_intern map dictionary key columns through a de-duplicated dictionary (u32 id of
  * the distinct VALUE per code) and intern those ids; groups, ids and emitted keys are identical to interning the values;
+ * "join_swap_small_semi" (1/0) == let the plan layer's HashJoinExec index the RIGHT input of a LeftSemi / LeftAnti join when it is
+ * at least 8x smaller than the collected left input (rows and row order identical: both are "left rows by ascending index");
  * "defer_flag_checks" (1 = enter / 0 = leave a deferred region, nests) == kernel error flags (overflow, divide by zero,
  * cast range, index bounds -- the ArrowError cases of arrow-arith / arrow-cast / arrow-select) are normally checked by the
  * call that ran the kernel; inside a region they are checked once, by the call that leaves it (which returns the error),
  * and always before array_export_host / ctx_synchronize return.  dfgpu_stream_next polls inside one region. */
 DFGPU_API dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx *ctx, const char *key, int64_t value);
+DFGPU_API dfgpu_status dfgpu_ctx_get_option(dfgpu_ctx *ctx, const char *key, int64_t *out_value);
 DFGPU_API void *dfgpu_ctx_stream(dfgpu_ctx *ctx);
 /* Selection-vector evaluation (the reference evaluates expressions on compacted batches, filter.rs:315-327 then
  * projection.rs:295-317; here a dense selection is carried instead of compacting): while a row selection (Boolean array; NULL

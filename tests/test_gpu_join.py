@@ -248,3 +248,66 @@ def test_join_requires_on_columns(ctx):
     s = ops.Schema([ops.Field("a", dfgpu.capi.INT32)])
     with pytest.raises(dfgpu.DfgpuError):     # hash_join.rs:303-305
         ops.HashJoinExec(ops.MemoryExec([[]], s), ops.MemoryExec([[]], s), [], None, "Inner")
+
+
+@pytest.mark.parametrize("mode", ["CollectLeft", "Partitioned"])
+@pytest.mark.parametrize("with_filter", [False, True])
+@pytest.mark.parametrize("jt", ["LeftSemi", "LeftAnti"])
+def test_left_semi_anti_with_small_right_side_keeps_reference_order(ctx, task_ctx, jt, with_filter, mode):
+    """A LeftSemi / LeftAnti join whose right input is much smaller than its left one indexes the RIGHT side on the device and probes
+    with the collected left batch; rows and their order (ascending index of the reversed-batch concatenation, hash_join.rs:746,764;
+    joins/utils.rs:1119-1141) must stay the reference's, with NULL keys, duplicate keys, a join filter and a multi-batch left input."""
+    import dfgpu
+    from dfgpu import physical_plan as ops
+    rng = np.random.default_rng(5)
+    lb = [pa.table({"k": pa.array(rng.integers(0, 400, n), mask=rng.random(n) < 0.05), "v": pa.array(rng.integers(0, 1000, n))}) for n in (4000, 1, 6000)]
+    rb = [pa.table({"k": pa.array(rng.integers(0, 400, n), mask=rng.random(n) < 0.2), "w": pa.array(rng.integers(0, 1000, n))}) for n in (20, 5)]
+    mk = lambda tabs: ops.MemoryExec([[ops.batch_from_arrow(ctx, t) for t in tabs]], ops.batch_from_arrow(ctx, tabs[0]).schema)
+    filt = None
+    if with_filter:
+        filt = ops.JoinFilter(ops.BinaryExpr(ops.Column("x", 0), ">", ops.Column("y", 1)), [("left", 1), ("right", 1)],
+                              ops.Schema([ops.Field("x", dfgpu.capi.INT64), ops.Field("y", dfgpu.capi.INT64)]))
+    join = ops.HashJoinExec(mk(lb), mk(rb), [(ops.Column("k", 0), ops.Column("k", 0))], filt, jt, mode)
+    got = []
+    for b in ops.collect(join, task_ctx):
+        got += rows_of([c.to_arrow() for c in b.columns])
+    lcat = pa.concat_tables(lb[::-1])
+    lv = lcat["v"].to_numpy()
+    fn = (lambda pb, bi, pi: (lv[bi] > rb[pb]["w"].to_numpy()[pi]).astype(np.uint8)) if with_filter else None
+    res = po.hash_join([[t["k"]] for t in lb], [[t["k"]] for t in rb], jt, batch_size=8192, filter_fn=fn)
+    want = [[lcat["k"][int(bi)].as_py(), lcat["v"][int(bi)].as_py()] for bi in res.build_idx]
+    assert len(want) > 0 and got == want
+    # the same plan with the swap disabled is the build-on-left path: identical rows in identical order
+    ctx.set_option("join_swap_small_semi", 0)
+    try:
+        plain = []
+        for b in ops.collect(ops.HashJoinExec(mk(lb), mk(rb), [(ops.Column("k", 0), ops.Column("k", 0))], filt, jt, mode), task_ctx):
+            plain += rows_of([c.to_arrow() for c in b.columns])
+    finally:
+        ctx.set_option("join_swap_small_semi", 1)
+    assert plain == want
+
+
+@pytest.mark.parametrize("dups", [False, True])
+def test_sparse_small_build_gets_its_bitmap_from_the_first_large_probe(ctx, dups):
+    """A build side tiny against its key range (here 60 keys over a 3 M range) starts as a plain hash table; a probe batch of at least
+    range / 16 rows builds the membership bitmap on arrival.  Results before, at and after that probe equal the oracle's."""
+    import dfgpu
+    rng = np.random.default_rng(11)
+    bk = np.sort(rng.choice(3_000_000, 60, replace=False)).astype(np.int64)[::-1].copy()          # not sorted ascending: no rank index
+    if dups:
+        bk = np.concatenate([bk, bk[:7]])
+    bkeys = pa.array(bk, mask=np.arange(len(bk)) % 13 == 5)
+    table = dfgpu.JoinTable(ctx, [ctx.from_arrow(bkeys)])
+    def probe(n):
+        pk = rng.integers(0, 3_000_000, n)
+        pk[rng.random(n) < 0.3] = rng.choice(bk, 1)[0]
+        pk[::7] = rng.choice(bk, len(pk[::7]))
+        parr = pa.array(pk.astype(np.int64), mask=rng.random(n) < 0.05)
+        bi, pi = table.probe([ctx.from_arrow(parr)])
+        want = po.hash_join([[bkeys]], [[parr]], "Inner", batch_size=1 << 40)
+        assert len(want.build_idx) > 0
+        assert np.array_equal(bi.to_numpy().astype(np.int64), want.build_idx) and np.array_equal(pi.to_numpy().astype(np.int64), want.probe_idx)
+    probe(1000)
+    probe(400_000)
+    probe(1000)
