@@ -281,6 +281,52 @@ __global__ void __launch_bounds__(BLOCK) k_acc_update_add(int kind, ColView v, i
   }
 }
 
+// The same segmented combine for the plain case -- no filter, values of exactly the state type without validity or dictionary -- with
+// ADD_ROWS slabs of 64 rows per wave whose loads are all issued up front, unconditionally (rows past the end re-read the last row and
+// are dropped by their group id): the general kernel's one conditional row per lane per iteration leaves HBM latency exposed.
+constexpr int ADD_ROWS = 4;
+template <typename T, int CLS, bool HAS_VALUES>
+__global__ void __launch_bounds__(BLOCK) k_acc_add_plain(int kind, const T* values, const uint32_t* gids, int64_t n, int64_t total, void* vals, uint64_t* counts, uint8_t* seen, uint32_t* flags) {
+  int lane = lane_id();
+  int64_t base = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * (WAVE * ADD_ROWS);
+  if (base >= n) return;                                             // wave-uniform
+  uint32_t gs[ADD_ROWS]; T xs[ADD_ROWS];
+#pragma unroll
+  for (int r = 0; r < ADD_ROWS; r++) {
+    int64_t i = base + r * WAVE + lane, ic = i < n ? i : n - 1;
+    gs[r] = gids[ic]; if constexpr (HAS_VALUES) xs[r] = values[ic]; else xs[r] = (T)0;
+    if (i >= n) gs[r] = GID_NONE;
+  }
+#pragma unroll
+  for (int r = 0; r < ADD_ROWS; r++) {
+    uint32_t g = gs[r]; T x = xs[r];
+    bool act = g != GID_NONE;
+    if (act && (int64_t)g >= total) { atomicOr(flags, DFGPU_FLAG_OOB); act = false; }
+    if (!act) x = (T)0;
+    uint32_t c = act ? 1u : 0u;
+    uint32_t gp = __shfl_up(g, 1, 64); int ap = __shfl_up((int)act, 1, 64);
+    bool head = !(lane > 0 && act && ap && gp == g);
+    uint64_t hm = ballot64(head);
+    if (hm != ~0ull) {
+      int start = 63 - __clzll((long long)(hm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull))));
+#pragma unroll
+      for (int d = 1; d < WAVE; d <<= 1) { T ox = shfl_up_any<T>(x, d); uint32_t oc = __shfl_up(c, d, 64); if (lane - d >= start) { x += ox; c += oc; } }
+    }
+    uint32_t gn = __shfl_down(g, 1, 64); int an = __shfl_down((int)act, 1, 64);
+    bool tail = act && (lane == 63 || !an || gn != g);
+    if (tail) {
+      if (kind == DFGPU_AGG_COUNT) atomicAdd((unsigned long long*)&counts[g], (unsigned long long)c);
+      else {
+        seen[g] = 1;
+        if (kind == DFGPU_AGG_AVG) atomicAdd((unsigned long long*)&counts[g], (unsigned long long)c);
+        if constexpr (CLS == CLS_F64) unsafeAtomicAdd((double*)vals + g, x);
+        else if constexpr (CLS == CLS_I128) atomic_add_i128((uint64_t*)vals + 2 * (int64_t)g, x);
+        else atomicAdd((unsigned long long*)vals + g, (unsigned long long)x);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------ repeated groups: per-workgroup LDS cache in front of the global atomics
 // Atomics on one address serialise in L2 (~2 ns each): 10 M rows of a Zipf(1.1) key spent 36 ms in k_acc_update, 1000 uniform
 // groups 4 ms.  Each workgroup therefore keeps a 1024-entry, 2-probe cache (group id tag, partial value, row count) in LDS:
@@ -438,6 +484,14 @@ static void launch_update(dfgpu_acc* a, int kind, int cls, const dfgpu_array* va
     else if (kind == DFGPU_AGG_MIN) { if (cls == CLS_F64) CACHED(double, CLS_F64, OP_MIN); else if (cls == CLS_U64) CACHED(unsigned long long, CLS_U64, OP_MIN); else CACHED(long long, CLS_I64, OP_MIN); }
     else { if (cls == CLS_F64) CACHED(double, CLS_F64, OP_MAX); else if (cls == CLS_U64) CACHED(unsigned long long, CLS_U64, OP_MAX); else CACHED(long long, CLS_I64, OP_MAX); }
 #undef CACHED
+  } else if (sumlike && !filt && (kind == DFGPU_AGG_COUNT ? (!values || !values->validity)
+                                  : (!values->validity && values->type == (cls == CLS_I128 ? DFGPU_DECIMAL128 : cls == CLS_F64 ? DFGPU_FLOAT64 : values->type) &&
+                                     (cls == CLS_I128 || cls == CLS_F64 || values->type == DFGPU_INT64 || values->type == DFGPU_UINT64)))) {
+    int pblocks = grid_for(n, BLOCK * ADD_ROWS);
+    const void* vp = kind == DFGPU_AGG_COUNT ? nullptr : values->values->ptr;
+#define PLAIN(T, C, HV) hipLaunchKernelGGL((k_acc_add_plain<T, C, HV>), dim3(pblocks), dim3(BLOCK), 0, ctx->stream, kind, (const T*)vp, g, n, total, vals, (uint64_t*)a->counts->ptr, (uint8_t*)a->seen->ptr, ctx->d_flags)
+    if (kind == DFGPU_AGG_COUNT) PLAIN(unsigned long long, CLS_U64, false); else if (cls == CLS_F64) PLAIN(double, CLS_F64, true); else if (cls == CLS_I128) PLAIN(i128, CLS_I128, true); else PLAIN(unsigned long long, CLS_U64, true);
+#undef PLAIN
   } else if (sumlike) {
 #define ADD(T, C) hipLaunchKernelGGL((k_acc_update_add<T, C>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, kind, v, values ? 1 : 0, g, fb, fv, n, total, vals, (uint64_t*)a->counts->ptr, (uint8_t*)a->seen->ptr, 1, ctx->d_flags)
     if (cls == CLS_F64) ADD(double, CLS_F64); else if (cls == CLS_I128) ADD(i128, CLS_I128); else ADD(unsigned long long, CLS_U64);
