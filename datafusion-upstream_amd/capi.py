@@ -71,12 +71,15 @@ _P = C.c_void_p
 _PP = C.POINTER(C.c_void_p)
 
 # name -> (restype, argtypes); every symbol declared in include/dfgpu.h
+NODE_COLUMN, NODE_SCALAR = -1, -2     # dfgpu_expr_node.op of leaves
 PROTOTYPES = {
     "dfgpu_ctx_create": (C.c_int32, [C.c_int32, _P, _PP]),
     "dfgpu_ctx_destroy": (None, [_P]),
     "dfgpu_last_error": (C.c_char_p, [_P]),
     "dfgpu_ctx_synchronize": (C.c_int32, [_P]),
     "dfgpu_ctx_set_option": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
+    "dfgpu_acc_update_batch_fused": (C.c_int32, [_P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int32, _P, C.c_int32, C.POINTER(_P), C.c_int32, _P, _P, C.c_int64]),
+    "dfgpu_jit_selftest": (C.c_int32, [C.c_char_p, C.c_char_p, C.c_int64]),
     "dfgpu_ctx_get_option": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     "dfgpu_ctx_stream": (_P, [_P]),
     "dfgpu_version": (C.c_char_p, []),

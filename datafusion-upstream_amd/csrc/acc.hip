@@ -622,6 +622,220 @@ dfgpu_status dfgpu_acc_update_batch_multi(dfgpu_ctx* ctx, dfgpu_acc* const* accs
   return DFGPU_OK;
 }
 
+// ------------------------------------------------------------------ fused "evaluate arguments + accumulate" (run-time compiled)
+// TPC-H Q1's shape: a handful of groups, eight accumulators whose arguments are arithmetic over four columns.  Operator at a time that
+// is ~64 GB of HBM traffic at SF100 (intermediate columns written and re-read, every accumulator pass re-reading its inputs and the
+// group ids); here one kernel reads each input column once, evaluates the argument expressions in registers and keeps per-lane partial
+// sums for every (accumulator, group) pair.  The kernel text below is fixed except for the straight-line expression body, and is
+// compiled for the expression at hand by hiprtc (jit.hip), so that the partials stay in registers.
+extern "C++" {
+namespace dfgpu {
+void* jit_kernel(dfgpu_ctx* ctx, const std::string& source, const char* name);
+bool jit_compile_only(const std::string& source, const char* arch, std::string* log);
+void decimal_arith_plan(int op, int p1, int s1, int p2, int s2, int* rp, int* rs, i128* lmul, i128* rmul);      // expr.hip
+
+constexpr int FUSED_MAX = 16;
+struct FusedArgs { const void* col[FUSED_MAX]; const uint32_t* gids; const uint64_t* fbits; long long n; void* vals[FUSED_MAX]; uint64_t* counts[FUSED_MAX]; uint8_t* seen[FUSED_MAX]; uint32_t* flags; };
+
+static const char* FUSED_PRELUDE = R"SRC(
+typedef __int128 i128; typedef unsigned __int128 u128; typedef unsigned long long u64; typedef unsigned int u32;
+#define I128(hi, lo) ((i128)(((u128)(u64)(hi) << 64) | (u128)(u64)(lo)))
+#define GID_NONE 0xFFFFFFFFu
+struct Args { const void* col[16]; const u32* gids; const u64* fbits; long long n; void* vals[16]; u64* counts[16]; unsigned char* seen[16]; u32* flags; };
+__device__ inline bool add128_checked(i128 a, i128 b, i128* out) { i128 r = (i128)((u128)a + (u128)b); if ((a >= 0) == (b >= 0) && (r >= 0) != (a >= 0)) return false; *out = r; return true; }
+__device__ inline bool sub128_checked(i128 a, i128 b, i128* out) { i128 r = (i128)((u128)a - (u128)b); if ((a >= 0) != (b >= 0) && (r >= 0) != (a >= 0)) return false; *out = r; return true; }
+__device__ inline bool mul128_checked(i128 a, i128 b, i128* out) {
+  bool neg = (a < 0) != (b < 0);
+  u128 ua = a < 0 ? (u128)0 - (u128)a : (u128)a, ub = b < 0 ? (u128)0 - (u128)b : (u128)b;
+  u64 a0 = (u64)ua, a1 = (u64)(ua >> 64), b0 = (u64)ub, b1 = (u64)(ub >> 64);
+  if (a1 && b1) return false;
+  u128 lo = (u128)a0 * (u128)b0;
+  u128 cross = a1 ? (u128)a1 * (u128)b0 : (u128)b1 * (u128)a0;
+  if (cross >> 64) return false;
+  u128 r = lo + (cross << 64);
+  if (r < lo) return false;
+  if (neg) { if (r > ((u128)1 << 127)) return false; *out = (i128)((u128)0 - r); } else { if (r >> 127) return false; *out = (i128)r; }
+  return true;
+}
+// checked decimal arithmetic of arrow-arith (operands rescaled to the result scale first); a row no accumulator sees cannot raise
+__device__ inline i128 dec_arith(int op, i128 x, i128 y, i128 lmul, i128 rmul, bool live, u32* flags) {
+  bool ok = true; i128 v = 0;
+  if (op != 2) ok = mul128_checked(x, lmul, &x) && mul128_checked(y, rmul, &y);
+  if (ok) ok = op == 0 ? add128_checked(x, y, &v) : op == 1 ? sub128_checked(x, y, &v) : mul128_checked(x, y, &v);
+  if (!ok) { if (live) atomicOr(flags, 2u); v = 0; }
+  return v;
+}
+__device__ inline i128 ld_i128(const void* p, long long i) { const u64* q = (const u64*)p + 2 * i; return I128(q[1], q[0]); }
+__device__ inline double ld_f64(const void* p, long long i) { return ((const double*)p)[i]; }
+__device__ inline u32 wsum(u32 v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64); return v; }
+__device__ inline double wsum(double v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64); return v; }
+__device__ inline i128 wsum(i128 v) {
+  for (int d = 32; d > 0; d >>= 1) { u64 lo = __shfl_xor((u64)(u128)v, d, 64), hi = __shfl_xor((u64)((u128)v >> 64), d, 64); v = (i128)((u128)v + (u128)I128(hi, lo)); }
+  return v;
+}
+__device__ inline void gadd(void* vals, int k, double v) { atomicAdd((double*)vals + k, v); }
+__device__ inline void gadd(void* vals, int k, i128 v) {
+  u64* slot = (u64*)vals + 2 * k; u64 lo = (u64)(u128)v, hi = (u64)((u128)v >> 64);
+  u64 old = atomicAdd(&slot[0], lo); u64 carry = (u64)(old + lo < old);
+  if (hi + carry) atomicAdd(&slot[1], hi + carry);
+}
+)SRC";
+
+static std::string i128_text(i128 v) { char b[96]; snprintf(b, sizeof b, "I128(0x%016llxull, 0x%016llxull)", (unsigned long long)(uint64_t)((u128)v >> 64), (unsigned long long)(uint64_t)(u128)v); return b; }
+static std::string f64_text(double d) { uint64_t u; memcpy(&u, &d, 8); char b[64]; snprintf(b, sizeof b, "__longlong_as_double((long long)0x%016llxull)", (unsigned long long)u); return b; }
+
+struct FusedNodeInfo { int p = 0, s = 0; i128 lmul = 1, rmul = 1; };
+// The kernel text for one (expression DAG, accumulator list, group count, mask presence) shape
+static std::string fused_source(bool dec, int G, int R, bool has_mask, const dfgpu_expr_node* nodes, int n_nodes, const std::vector<FusedNodeInfo>& info,
+                                const dfgpu_array* const* cols, dfgpu_acc* const* accs, const int32_t* acc_nodes, int n_accs, std::vector<int>* value_nodes) {
+  std::string T = dec ? "i128" : "double", LD = dec ? "ld_i128" : "ld_f64";
+  std::vector<int> vn;                                  // distinct argument nodes of SUM / AVG accumulators
+  std::vector<int> acc_v((size_t)n_accs, -1);
+  for (int i = 0; i < n_accs; i++) if (accs[i]->kind != DFGPU_AGG_COUNT) {
+    int j = 0; for (; j < (int)vn.size(); j++) if (vn[(size_t)j] == acc_nodes[i]) break;
+    if (j == (int)vn.size()) vn.push_back(acc_nodes[i]);
+    acc_v[(size_t)i] = j;
+  }
+  *value_nodes = vn;
+  const int NV = (int)vn.size();
+  std::vector<int> used_cols;
+  for (int k = 0; k < n_nodes; k++) if (nodes[k].op == DFGPU_NODE_COLUMN && std::find(used_cols.begin(), used_cols.end(), nodes[k].lhs) == used_cols.end()) used_cols.push_back(nodes[k].lhs);
+  std::string s = FUSED_PRELUDE;
+  char b[512];
+  snprintf(b, sizeof b, "typedef %s T;\n#define G %d\n#define R %d\n#define NV %d\n", T.c_str(), G, R, NV > 0 ? NV : 1); s += b;
+  s += "extern \"C\" __global__ void __launch_bounds__(256) dfgpu_fused_agg(Args a) {\n"
+       "  T acc[NV][G]; u32 cnt[G];\n"
+       "#pragma unroll\n  for (int k = 0; k < G; k++) { cnt[k] = 0;\n#pragma unroll\n    for (int v = 0; v < NV; v++) acc[v][k] = (T)0; }\n"
+       "  const long long stride = (long long)gridDim.x * 256;\n"
+       "  for (long long base = (long long)blockIdx.x * 256 + threadIdx.x; base < a.n; base += stride * R) {\n"
+       "    u32 g[R];";
+  for (int c : used_cols) { snprintf(b, sizeof b, " T c%d[R];", c); s += b; }
+  s += "\n#pragma unroll\n    for (int r = 0; r < R; r++) {\n"
+       "      long long i = base + r * stride; bool in = i < a.n; long long ii = in ? i : a.n - 1;\n"
+       "      u32 gg = a.gids[ii];\n";
+  s += has_mask ? "      bool pass = in && ((a.fbits[ii >> 6] >> (ii & 63)) & 1ull);\n" : "      bool pass = in;\n";
+  s += "      g[r] = pass ? gg : GID_NONE;\n";
+  for (int c : used_cols) { snprintf(b, sizeof b, "      c%d[r] = %s(a.col[%d], ii);\n", c, LD.c_str(), c); s += b; }
+  s += "    }\n#pragma unroll\n    for (int r = 0; r < R; r++) {\n      const bool live = g[r] != GID_NONE; (void)live;\n";
+  for (int k = 0; k < n_nodes; k++) {
+    const dfgpu_expr_node& nd = nodes[k];
+    if (nd.op == DFGPU_NODE_COLUMN) { snprintf(b, sizeof b, "      const T n%d = c%d[r];\n", k, nd.lhs); s += b; }
+    else if (nd.op == DFGPU_NODE_SCALAR) {
+      const dfgpu_array* sc = cols[nd.lhs];
+      std::string lit; if (dec) { i128 v; memcpy(&v, sc->host_scalar, 16); lit = i128_text(v); } else { double d; memcpy(&d, sc->host_scalar, 8); lit = f64_text(d); }
+      snprintf(b, sizeof b, "      const T n%d = %s;\n", k, lit.c_str()); s += b;
+    } else if (dec) {
+      snprintf(b, sizeof b, "      const T n%d = dec_arith(%d, n%d, n%d, %s, %s, live, a.flags);\n", k, nd.op, nd.lhs, nd.rhs, i128_text(info[(size_t)k].lmul).c_str(), i128_text(info[(size_t)k].rmul).c_str()); s += b;
+    } else {
+      snprintf(b, sizeof b, "      const T n%d = n%d %c n%d;\n", k, nd.lhs, nd.op == DFGPU_OP_ADD ? '+' : nd.op == DFGPU_OP_SUB ? '-' : '*', nd.rhs); s += b;
+    }
+  }
+  s += "#pragma unroll\n      for (int k = 0; k < G; k++) { const bool m = g[r] == (u32)k; cnt[k] += m ? 1u : 0u;\n";
+  for (int v = 0; v < NV; v++) { snprintf(b, sizeof b, "        acc[%d][k] += m ? n%d : (T)0;\n", v, vn[(size_t)v]); s += b; }
+  s += "      }\n    }\n  }\n"
+       "  __shared__ T s_acc[4][NV][G]; __shared__ u32 s_cnt[4][G];\n"
+       "  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;\n"
+       "#pragma unroll\n  for (int k = 0; k < G; k++) { u32 c = wsum(cnt[k]); if (lane == 0) s_cnt[wave][k] = c;\n"
+       "#pragma unroll\n    for (int v = 0; v < NV; v++) { T x = wsum(acc[v][k]); if (lane == 0) s_acc[wave][v][k] = x; } }\n"
+       "  __syncthreads();\n"
+       "  if (threadIdx.x >= G) return;\n"
+       "  const int k = threadIdx.x; u64 c = 0; for (int w = 0; w < 4; w++) c += s_cnt[w][k];\n"
+       "  if (c == 0) return;\n"
+       "  T tot[NV];\n#pragma unroll\n  for (int v = 0; v < NV; v++) { tot[v] = (T)0; for (int w = 0; w < 4; w++) tot[v] += s_acc[w][v][k]; }\n";
+  for (int i = 0; i < n_accs; i++) {
+    if (accs[i]->kind == DFGPU_AGG_COUNT) { snprintf(b, sizeof b, "  atomicAdd(&a.counts[%d][k], c);\n", i); s += b; continue; }
+    snprintf(b, sizeof b, "  a.seen[%d][k] = 1; gadd(a.vals[%d], k, tot[%d]);\n", i, i, acc_v[(size_t)i]); s += b;
+    if (accs[i]->kind == DFGPU_AGG_AVG) { snprintf(b, sizeof b, "  atomicAdd(&a.counts[%d][k], c);\n", i); s += b; }
+  }
+  s += "}\n";
+  return s;
+}
+
+}  // namespace dfgpu
+}  // extern "C++"
+
+dfgpu_status dfgpu_acc_update_batch_fused(dfgpu_ctx* ctx, dfgpu_acc* const* accs, const int32_t* acc_nodes, int32_t n_accs, const dfgpu_expr_node* nodes, int32_t n_nodes,
+                                          const dfgpu_array* const* cols, int32_t n_cols, const dfgpu_array* gids, const dfgpu_array* filt, int64_t total) {
+  return guard(ctx, [&] {
+    if (!accs || !acc_nodes || n_accs < 1 || !gids || (n_nodes > 0 && (!nodes || !cols))) fail(DFGPU_INVALID_ARGUMENT, "acc_update_batch_fused: null argument");
+    if (n_accs > FUSED_MAX || n_cols > FUSED_MAX || n_nodes > 64) fail(DFGPU_NOT_IMPLEMENTED, "acc_update_batch_fused: more than %d accumulators / columns or 64 nodes", FUSED_MAX);
+    if (total < 1 || total > SMALL_G) fail(DFGPU_NOT_IMPLEMENTED, "acc_update_batch_fused: %lld groups (register partials hold up to %d)", (long long)total, SMALL_G);
+    if (gids->type != DFGPU_UINT32) fail(DFGPU_INVALID_ARGUMENT, "group ids must be a UINT32 array");
+    int64_t n = gids->length;
+    if (filt && (filt->type != DFGPU_BOOL || filt->length != n)) fail(DFGPU_INVALID_ARGUMENT, "opt_filter must be a Boolean array of the batch length");
+    if (filt && filt->validity) fail(DFGPU_NOT_IMPLEMENTED, "acc_update_batch_fused: nullable filter");
+    // one arithmetic class for the whole DAG: Float64, or Decimal128 with arrow-arith's result types per node
+    int32_t cls_type = 0; std::vector<FusedNodeInfo> info((size_t)n_nodes);
+    for (int k = 0; k < n_nodes; k++) {
+      const dfgpu_expr_node& nd = nodes[k];
+      if (nd.op == DFGPU_NODE_COLUMN || nd.op == DFGPU_NODE_SCALAR) {
+        if (nd.lhs < 0 || nd.lhs >= n_cols || !cols[nd.lhs]) fail(DFGPU_INVALID_ARGUMENT, "acc_update_batch_fused: node %d references column %d of %d", k, nd.lhs, n_cols);
+        const dfgpu_array* c = cols[nd.lhs];
+        if (c->type != DFGPU_FLOAT64 && c->type != DFGPU_DECIMAL128) fail(DFGPU_NOT_IMPLEMENTED, "acc_update_batch_fused: column type %d", c->type);
+        if (cls_type && c->type != cls_type) fail(DFGPU_NOT_IMPLEMENTED, "acc_update_batch_fused: mixed Float64 / Decimal128 arguments");
+        cls_type = c->type;
+        if (nd.op == DFGPU_NODE_COLUMN) { if (c->length != n) fail(DFGPU_INVALID_ARGUMENT, "column (%lld rows) and group ids (%lld rows) differ in length", (long long)c->length, (long long)n);
+                                          if (c->validity) fail(DFGPU_NOT_IMPLEMENTED, "acc_update_batch_fused: nullable column"); }
+        else if (c->length != 1 || !c->has_host_scalar || !c->host_scalar_valid) fail(DFGPU_NOT_IMPLEMENTED, "acc_update_batch_fused: scalar operand must be a non-null 1-row literal");
+        info[(size_t)k].p = c->precision; info[(size_t)k].s = c->scale;
+      } else if (nd.op == DFGPU_OP_ADD || nd.op == DFGPU_OP_SUB || nd.op == DFGPU_OP_MUL) {
+        if (nd.lhs < 0 || nd.lhs >= k || nd.rhs < 0 || nd.rhs >= k) fail(DFGPU_INVALID_ARGUMENT, "acc_update_batch_fused: node %d must reference earlier nodes", k);
+        if (cls_type == DFGPU_DECIMAL128) {
+          FusedNodeInfo& o = info[(size_t)k]; const FusedNodeInfo &l = info[(size_t)nd.lhs], &r = info[(size_t)nd.rhs];
+          decimal_arith_plan(nd.op, l.p, l.s, r.p, r.s, &o.p, &o.s, &o.lmul, &o.rmul);
+        }
+      } else fail(DFGPU_NOT_IMPLEMENTED, "acc_update_batch_fused: operator %d", nd.op);
+    }
+    const bool dec = cls_type == DFGPU_DECIMAL128;
+    for (int i = 0; i < n_accs; i++) {
+      dfgpu_acc* a = accs[i]; if (!a) fail(DFGPU_INVALID_ARGUMENT, "acc_update_batch_fused: null accumulator");
+      if (a->kind == DFGPU_AGG_COUNT) { if (acc_nodes[i] >= n_nodes) fail(DFGPU_INVALID_ARGUMENT, "acc_update_batch_fused: bad node"); continue; }
+      if (a->kind != DFGPU_AGG_SUM && a->kind != DFGPU_AGG_AVG) fail(DFGPU_NOT_IMPLEMENTED, "acc_update_batch_fused: aggregate kind %d", a->kind);
+      if (acc_nodes[i] < 0 || acc_nodes[i] >= n_nodes) fail(DFGPU_INVALID_ARGUMENT, "acc_update_batch_fused: accumulator %d has no argument node", i);
+      if (a->cls != (dec ? CLS_I128 : CLS_F64)) fail(DFGPU_NOT_IMPLEMENTED, "acc_update_batch_fused: accumulator state class differs from the argument class");
+    }
+    for (int i = 0; i < n_accs; i++) acc_resize(accs[i], total);
+    if (n == 0) return;
+    const int R = dec ? 2 : 4;
+    std::vector<int> vn;
+    std::string src = fused_source(dec, (int)total, R, filt != nullptr, nodes, n_nodes, info, cols, accs, acc_nodes, n_accs, &vn);
+    hipFunction_t fn = (hipFunction_t)jit_kernel(ctx, src, "dfgpu_fused_agg");
+    FusedArgs fa{};
+    for (int c = 0; c < n_cols; c++) fa.col[c] = cols[c] && cols[c]->values ? cols[c]->values->ptr : nullptr;
+    fa.gids = (const uint32_t*)gids->values->ptr; fa.fbits = filt ? (const uint64_t*)filt->values->ptr : nullptr; fa.n = n; fa.flags = ctx->d_flags;
+    for (int i = 0; i < n_accs; i++) { fa.vals[i] = accs[i]->vals ? accs[i]->vals->ptr : nullptr; fa.counts[i] = (uint64_t*)accs[i]->counts->ptr; fa.seen[i] = (uint8_t*)accs[i]->seen->ptr; }
+    void* params[] = { &fa };
+    int blocks = grid_for(n, BLOCK * R * 4, ctx->num_cus * 8);
+    { KernelTimer kt_(ctx, "k_acc_fused");
+      HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)blocks, 1, 1, BLOCK, 1, 1, 0, ctx->stream, params, nullptr)); }
+    check_flags(ctx, "acc_update_batch_fused");
+  });
+}
+
+/* Build check without a device: compile the generator's output for one representative shape (Decimal128 and Float64). */
+dfgpu_status dfgpu_jit_selftest(const char* arch, char* log, int64_t log_cap) {
+  using namespace dfgpu;
+  try {
+    for (int dec = 0; dec < 2; dec++) {
+      dfgpu_array one{}; one.type = dec ? DFGPU_DECIMAL128 : DFGPU_FLOAT64; one.length = 1; one.has_host_scalar = true; one.host_scalar_valid = true; one.precision = 20;
+      if (dec) { i128 v = 1; memcpy(one.host_scalar, &v, 16); } else { double d = 1.0; memcpy(one.host_scalar, &d, 8); }
+      dfgpu_array col{}; col.type = one.type; col.precision = 15; col.scale = 2;
+      const dfgpu_array* cols[3] = { &col, &col, &one };
+      dfgpu_expr_node nodes[5] = { {DFGPU_NODE_COLUMN, 0, 0}, {DFGPU_NODE_COLUMN, 1, 0}, {DFGPU_NODE_SCALAR, 2, 0}, {DFGPU_OP_SUB, 2, 1}, {DFGPU_OP_MUL, 0, 3} };
+      std::vector<FusedNodeInfo> info(5);
+      if (dec) { info[0] = info[1] = FusedNodeInfo{15, 2, 1, 1}; info[2] = FusedNodeInfo{20, 0, 1, 1};
+        decimal_arith_plan(DFGPU_OP_SUB, 20, 0, 15, 2, &info[3].p, &info[3].s, &info[3].lmul, &info[3].rmul);
+        decimal_arith_plan(DFGPU_OP_MUL, 15, 2, info[3].p, info[3].s, &info[4].p, &info[4].s, &info[4].lmul, &info[4].rmul); }
+      dfgpu_acc a0{}, a1{}, a2{}; a0.kind = DFGPU_AGG_SUM; a1.kind = DFGPU_AGG_AVG; a2.kind = DFGPU_AGG_COUNT;
+      dfgpu_acc* accs[3] = { &a0, &a1, &a2 }; int32_t acc_nodes[3] = { 4, 0, -1 }; std::vector<int> vn;
+      std::string src = fused_source(dec != 0, 6, dec ? 2 : 4, true, nodes, 5, info, cols, accs, acc_nodes, 3, &vn);
+      std::string l;
+      if (!jit_compile_only(src, arch ? arch : "gfx950", &l)) { if (log && log_cap > 0) snprintf(log, (size_t)log_cap, "%s", l.c_str()); return DFGPU_INTERNAL; }
+    }
+  } catch (...) { if (log && log_cap > 0) snprintf(log, (size_t)log_cap, "kernel text generation failed"); return DFGPU_INTERNAL; }
+  return DFGPU_OK;
+}
+
 dfgpu_status dfgpu_acc_merge_batch(dfgpu_ctx* ctx, dfgpu_acc* a, const dfgpu_array* const* st, int32_t nst, const dfgpu_array* gids, const dfgpu_array* filt, int64_t total) {
   if (!a || !st) return DFGPU_INVALID_ARGUMENT;
   if (a->kind == DFGPU_AGG_COUNT) {         // count.rs:135-170: add the partial counts (never null)

@@ -286,6 +286,7 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "group_run_detection") ctx->group_run_detection = value != 0;
     else if (k == "group_dictionary_canon") ctx->group_dictionary_canon = value != 0;
     else if (k == "join_swap_small_semi") ctx->join_swap_small_semi = value != 0;
+    else if (k == "fused_aggregate_min_rows") ctx->fused_aggregate_min_rows = value;
     else if (k == "defer_flag_checks") {            // nests: +1 enters a deferred region, 0 leaves it and raises what the region deferred
       if (value) ctx->defer_flag_checks++;
       else { if (ctx->defer_flag_checks > 0) ctx->defer_flag_checks--; if (ctx->defer_flag_checks == 0) flush_flags(ctx); }
@@ -305,6 +306,7 @@ dfgpu_status dfgpu_ctx_get_option(dfgpu_ctx* ctx, const char* key, int64_t* out)
     else if (k == "group_run_detection") *out = ctx->group_run_detection;
     else if (k == "group_dictionary_canon") *out = ctx->group_dictionary_canon;
     else if (k == "join_swap_small_semi") *out = ctx->join_swap_small_semi;
+    else if (k == "fused_aggregate_min_rows") *out = ctx->fused_aggregate_min_rows;
     else if (k == "defer_flag_checks") *out = ctx->defer_flag_checks;
     else fail(DFGPU_INVALID_ARGUMENT, "unknown option '%s'", k.c_str());
   });

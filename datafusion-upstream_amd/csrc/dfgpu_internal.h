@@ -46,6 +46,7 @@ struct dfgpu_ctx {
   bool group_run_detection = true;
   bool group_dictionary_canon = true;
   bool join_swap_small_semi = true;
+  int64_t fused_aggregate_min_rows = 1 << 20;
   // row selection of the running operator (dfgpu_ctx_set_row_selection): expression kernels evaluate every row of full-length
   // columns but raise errors only for selected rows
   std::shared_ptr<dfgpu::Buffer> row_selection; int64_t row_selection_len = 0;

@@ -19,6 +19,7 @@
 #include <memory>
 #include <mutex>
 #include <map>
+#include <tuple>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -319,30 +320,45 @@ struct ProjectionExec : Plan {    // projection.rs:52-62, batch_project :295-317
     return sch;
   }
   int partitions() const override { return input->partitions(); }
+  struct RowSel { dfgpu_ctx* c = nullptr; ~RowSel() { if (c) dfgpu_ctx_set_row_selection(c, nullptr); } };
+  bool only_columns() const { bool oc = true; for (auto& e : exprs) oc &= e->column_index() >= 0; return oc; }
+  // batch_project (projection.rs:295-317).  `defer` (optional, one flag per expression) leaves computed columns unevaluated (empty Col) for
+  // a consumer that can evaluate them inside its own pass (AggregateExec's fused accumulate); *deferred says whether any was left.
+  Batch project(const TaskContext& tc, Batch b, std::vector<bool>* defer = nullptr) const {
+    // A dense selection (>= 1/4 of the rows, e.g. TPC-H Q1's 98 %) is carried: expressions run over the full columns with the
+    // selection set as the context's row selection so that dropped rows cannot raise; a sparse one is compacted first.
+    RowSel rowsel;
+    if (b.selection && !only_columns()) {
+      int64_t kept = 0; tc.check(dfgpu_mask_count(tc.ctx, b.selection.a, &kept));
+      if (kept * 4 >= b.base_rows) { tc.check(dfgpu_ctx_set_row_selection(tc.ctx, b.selection.a)); rowsel.c = tc.ctx; }
+      else { std::set<int> need; for (auto& e : exprs) e->columns(need); b = materialize_subset(tc, b, need); if (defer) defer->assign(exprs.size(), false); defer = nullptr; }
+    }
+    Batch o; o.base_rows = b.base_rows; o.selection = b.selection; auto s = std::make_shared<Schema>();
+    if (defer) defer->assign(exprs.size(), false);
+    for (size_t i = 0; i < exprs.size(); i++) {
+      int ci = exprs[i]->column_index();
+      if (ci >= 0) {                 // Column = Arc clone in the reference: pass the (possibly lazy) column through
+        if (ci >= (int)b.cols.size()) fail(DFGPU_INTERNAL, "PhysicalExpr Column references column at index %d but input schema only has %zu columns", ci, b.cols.size());
+        o.cols.push_back(b.cols[(size_t)ci]); Field f = b.schema->f[(size_t)ci]; f.name = names[i]; s->f.push_back(f);
+      } else if (defer) { (*defer)[i] = true; o.cols.push_back(Col()); s->f.push_back(Field{names[i]}); }
+      else { ArrayRef a = into_array(tc, exprs[i]->eval(tc, b), b.base_rows); s->f.push_back(field_of(names[i], a.a)); o.cols.push_back(col_of(a)); }
+    }
+    o.schema = s; if (!defer) { std::lock_guard<std::mutex> l(mu); sch = s; }
+    return o;
+  }
+  // evaluate one deferred expression of project() over the batch it was deferred on
+  void evaluate_deferred(const TaskContext& tc, Batch& raw, Batch& projected, size_t i) const {
+    RowSel rowsel;
+    if (raw.selection) { tc.check(dfgpu_ctx_set_row_selection(tc.ctx, raw.selection.a)); rowsel.c = tc.ctx; }
+    ArrayRef a = into_array(tc, exprs[i]->eval(tc, raw), raw.base_rows);
+    projected.schema->f[i] = field_of(names[i], a.a); projected.cols[i] = col_of(a);
+  }
   struct S : Stream {
     const ProjectionExec* op; std::unique_ptr<Stream> in; TaskContext tc;
     S(const ProjectionExec* o, std::unique_ptr<Stream> i, TaskContext t) : op(o), in(std::move(i)), tc(t) {}
     bool next(Batch& out) override {
       Batch b; if (!in->next(b)) return false;
-      bool only_columns = true; for (auto& e : op->exprs) only_columns &= e->column_index() >= 0;
-      // A dense selection (>= 1/4 of the rows, e.g. TPC-H Q1's 98 %) is carried: expressions run over the full columns with the
-      // selection set as the context's row selection so that dropped rows cannot raise; a sparse one is compacted first.
-      struct RowSel { dfgpu_ctx* c = nullptr; ~RowSel() { if (c) dfgpu_ctx_set_row_selection(c, nullptr); } } rowsel;
-      if (b.selection && !only_columns) {
-        int64_t kept = 0; tc.check(dfgpu_mask_count(tc.ctx, b.selection.a, &kept));
-        if (kept * 4 >= b.base_rows) { tc.check(dfgpu_ctx_set_row_selection(tc.ctx, b.selection.a)); rowsel.c = tc.ctx; }
-        else { std::set<int> need; for (auto& e : op->exprs) e->columns(need); b = materialize_subset(tc, b, need); }
-      }
-      Batch o; o.base_rows = b.base_rows; o.selection = b.selection; auto s = std::make_shared<Schema>();
-      for (size_t i = 0; i < op->exprs.size(); i++) {
-        int ci = op->exprs[i]->column_index();
-        if (ci >= 0) {                 // Column = Arc clone in the reference: pass the (possibly lazy) column through
-          if (ci >= (int)b.cols.size()) fail(DFGPU_INTERNAL, "PhysicalExpr Column references column at index %d but input schema only has %zu columns", ci, b.cols.size());
-          o.cols.push_back(b.cols[(size_t)ci]); Field f = b.schema->f[(size_t)ci]; f.name = op->names[i]; s->f.push_back(f);
-        } else { ArrayRef a = into_array(tc, op->exprs[i]->eval(tc, b), b.base_rows); s->f.push_back(field_of(op->names[i], a.a)); o.cols.push_back(col_of(a)); }
-      }
-      o.schema = s; { std::lock_guard<std::mutex> l(op->mu); op->sch = s; }
-      out = std::move(o); return true;
+      out = op->project(tc, std::move(b)); return true;
     }
   };
   std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override { return std::unique_ptr<Stream>(new S(this, input->execute(p, tc), tc)); }
@@ -623,6 +639,56 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
   PlanPtr fresh() const override { auto a = std::make_shared<AggregateExec>(); a->mode = mode; a->gexprs = gexprs; a->gnames = gnames; a->aggs = aggs; a->input = input->fresh(); return a; }
   const char* name() const override { return "AggregateExec"; }
   bool merging() const { return mode == 1 || mode == 2; }
+  // The accumulator arguments as ONE expression DAG over plain columns (common subexpressions shared; references to deferred projection
+  // columns expand into the projection's expression over ITS input) handed to dfgpu_acc_update_batch_fused.  false = shape not taken,
+  // nothing was accumulated: the caller evaluates the arguments node by node.
+  struct DagBuilder {
+    const TaskContext& tc; const ProjectionExec* pj; Batch& raw; Batch& proj; const std::vector<bool>& deferred;
+    std::vector<dfgpu_expr_node> nodes; std::vector<ArrayRef> keep; std::vector<const dfgpu_array*> cols; std::map<std::tuple<int, int, int>, int> seen;
+    int leaf(int kind, ArrayRef a) {
+      int ci = -1; for (size_t i = 0; i < cols.size(); i++) if (cols[i] == a.a) ci = (int)i;
+      if (ci < 0) { ci = (int)cols.size(); cols.push_back(a.a); keep.push_back(a); }
+      return node(kind, ci, 0);
+    }
+    int node(int op, int l, int r) {
+      auto key = std::make_tuple(op, l, r); auto it = seen.find(key); if (it != seen.end()) return it->second;
+      nodes.push_back(dfgpu_expr_node{op, l, r}); seen[key] = (int)nodes.size() - 1; return (int)nodes.size() - 1;
+    }
+    int build(const Expr* e, bool over_raw) {
+      if (auto* c = dynamic_cast<const ColumnExpr*>(e)) {
+        Batch& src = over_raw ? raw : proj;
+        if (c->index < 0 || c->index >= (int)src.cols.size()) return -1;
+        if (!over_raw && c->index < (int)deferred.size() && deferred[(size_t)c->index]) return build(pj->exprs[(size_t)c->index].get(), true);
+        return leaf(DFGPU_NODE_COLUMN, src.column(tc, c->index));
+      }
+      if (auto* l = dynamic_cast<const LiteralExpr*>(e)) return leaf(DFGPU_NODE_SCALAR, l->scalar);
+      if (auto* x = dynamic_cast<const BinaryExpr*>(e)) {
+        if (x->op != DFGPU_OP_ADD && x->op != DFGPU_OP_SUB && x->op != DFGPU_OP_MUL) return -1;
+        int a = build(x->l.get(), over_raw); if (a < 0) return -1;
+        int b2 = build(x->r.get(), over_raw); if (b2 < 0) return -1;
+        return node(x->op, a, b2);
+      }
+      return -1;
+    }
+  };
+  bool try_fused(const TaskContext& tc, const ProjectionExec* pj, Batch& raw, Batch& b, const std::vector<bool>& deferred, std::vector<AccRef>& accs,
+                 const ArrayRef& gids, const ArrayRef& filt, int64_t total) const {
+    bool computed = false;          // worth it only when some argument is an expression, not a stored column
+    for (auto& a : aggs) { if (a.filter || (a.kind != DFGPU_AGG_SUM && a.kind != DFGPU_AGG_AVG && a.kind != DFGPU_AGG_COUNT)) return false;
+      if (a.arg) { int ci = a.arg->column_index(); computed |= ci < 0 || (ci < (int)deferred.size() && deferred[(size_t)ci]); } }
+    if (!computed) return false;
+    DagBuilder d{tc, pj, raw, b, deferred};
+    std::vector<int32_t> acc_nodes; std::vector<dfgpu_acc*> ap;
+    for (size_t i = 0; i < aggs.size(); i++) {
+      int nd = -1;
+      if (aggs[i].arg && aggs[i].kind != DFGPU_AGG_COUNT) { nd = d.build(aggs[i].arg.get(), false); if (nd < 0) return false; }
+      else if (aggs[i].arg) return false;      // COUNT(expr) counts non-NULL values: leave it to the ordinary path
+      acc_nodes.push_back(nd); ap.push_back(accs[i].a);
+    }
+    dfgpu_status st = dfgpu_acc_update_batch_fused(tc.ctx, ap.data(), acc_nodes.data(), (int32_t)ap.size(), d.nodes.data(), (int32_t)d.nodes.size(), d.cols.data(), (int32_t)d.cols.size(), gids.a, filt.a, total);
+    if (st == DFGPU_NOT_IMPLEMENTED) return false;
+    tc.check(st); return true;
+  }
   std::vector<std::string> out_names() const {
     std::vector<std::string> n = gnames;
     for (auto& a : aggs) { if (mode == 0) { if (a.kind == DFGPU_AGG_AVG) { n.push_back(a.name + "[count]"); n.push_back(a.name + "[sum]"); } else n.push_back(a.name + "[" + agg_fun_name(a.kind) + "]"); } else n.push_back(a.name); }
@@ -631,8 +697,13 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
   SchemaPtr schema() const override { std::lock_guard<std::mutex> l(mu); if (!sch) { auto s = std::make_shared<Schema>(); for (auto& n : out_names()) s->f.push_back(Field{n}); sch = s; } return sch; }
   int partitions() const override { return (mode == 1 || mode == 3) ? 1 : input->partitions(); }
   std::unique_ptr<Stream> execute(int partition, const TaskContext& tc) const override {
+    // An input ProjectionExec is looked through: its computed columns that only feed accumulator arguments are evaluated inside the
+    // accumulate pass (dfgpu_acc_update_batch_fused) instead of being written out as columns first.
+    int64_t fuse_min_rows = 1 << 20; dfgpu_ctx_get_option(tc.ctx, "fused_aggregate_min_rows", &fuse_min_rows);
+    const ProjectionExec* pj = (!merging() && !aggs.empty() && fuse_min_rows >= 0) ? dynamic_cast<const ProjectionExec*>(input.get()) : nullptr;
+    const PlanPtr& src = pj ? pj->input : input;
     std::vector<Batch> in;
-    if (mode == 1 || mode == 3) { for (int p = 0; p < input->partitions(); p++) drain(input, p, tc, in); } else drain(input, partition, tc, in);
+    if (mode == 1 || mode == 3) { for (int p = 0; p < src->partitions(); p++) drain(src, p, tc, in); } else drain(src, partition, tc, in);
     const bool grouped = !gexprs.empty();      // false: AggregateStream (aggregates/no_grouping.rs): one implicit group
     GroupsRef groups; if (grouped) tc.check(dfgpu_groups_new(tc.ctx, (int32_t)gexprs.size(), &groups.g));
     std::vector<AccRef> accs(aggs.size());
@@ -640,7 +711,17 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
       int32_t t = aggs[i].kind == DFGPU_AGG_COUNT ? DFGPU_INT64 : aggs[i].type;
       tc.check(dfgpu_acc_new(tc.ctx, aggs[i].kind, t, aggs[i].precision, aggs[i].scale, &accs[i].a));
     }
-    for (auto& b : in) {          // group_aggregate_batch (row_hash.rs:524-613)
+    for (auto& b_in : in) {       // group_aggregate_batch (row_hash.rs:524-613)
+      if (b_in.base_rows == 0) continue;
+      Batch raw; std::vector<bool> deferred;
+      if (pj) { raw = b_in; b_in = pj->project(tc, raw, &deferred); }
+      Batch& b = b_in;
+      bool any_deferred = false; for (bool d : deferred) any_deferred |= d;
+      auto ensure = [&](int ci) { if (ci >= 0 && ci < (int)deferred.size() && deferred[(size_t)ci]) { pj->evaluate_deferred(tc, raw, b, (size_t)ci); deferred[(size_t)ci] = false; } };
+      if (any_deferred) {         // group keys and accumulator filters read their columns the ordinary way
+        std::set<int> need; for (auto& e : gexprs) e->columns(need); for (auto& a : aggs) if (a.filter) a.filter->columns(need);
+        for (int ci : need) ensure(ci);
+      }
       if (b.base_rows == 0) continue;
       ArrayRef mask = b.selection; b.selection = ArrayRef();
       ArrayRef gids; int64_t total = 1;
@@ -662,6 +743,8 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
         dfgpu_array* ids = nullptr; tc.check(dfgpu_groups_intern(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids)); gids = ArrayRef::adopt(ids);
         total = dfgpu_groups_len(groups.g);
       } else { dfgpu_array* z = nullptr; tc.check(dfgpu_array_new_zeros(tc.ctx, DFGPU_UINT32, 0, 0, b.base_rows, &z)); gids = ArrayRef::adopt(z); }
+      if (!merging() && total <= 8 && fuse_min_rows >= 0 && b.base_rows >= fuse_min_rows && try_fused(tc, pj, raw, b, deferred, accs, gids, grouped ? ArrayRef() : mask, total)) continue;
+      for (size_t ci = 0; ci < deferred.size(); ci++) ensure((int)ci);
       size_t col = gexprs.size();
       std::vector<ArrayRef> uvals(aggs.size()), ufilt(aggs.size());       // update mode: all accumulators of the batch go down together
       for (size_t i = 0; i < aggs.size(); i++) {

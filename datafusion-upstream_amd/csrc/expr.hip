@@ -433,6 +433,13 @@ static ArithPlan plan_decimal(int op, int p1, int s1, int p2, int s2) {
   }
   return a;
 }
+extern "C++" {
+namespace dfgpu {
+void decimal_arith_plan(int op, int p1, int s1, int p2, int s2, int* rp, int* rs, i128* lmul, i128* rmul) {
+  ArithPlan a = plan_decimal(op, p1, s1, p2, s2); *rp = a.rp; *rs = a.rsc; *lmul = a.dr.lmul; *rmul = a.dr.rmul;
+}
+}  // namespace dfgpu
+}
 dfgpu_status dfgpu_binary_fused2(dfgpu_ctx* ctx, int32_t op_outer, const dfgpu_array* x, int32_t op_inner, const dfgpu_array* scalar, const dfgpu_array* y,
                                  int32_t scalar_on_left, int32_t inner_on_left, dfgpu_array** out) {
   return guard(ctx, [&] {

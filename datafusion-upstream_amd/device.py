@@ -358,6 +358,20 @@ class GroupsAccumulator:
         fh = (C.c_void_p * n)(*[(f.h if f is not None else None) for f in filters])
         ctx.check(ctx.lib.dfgpu_acc_update_batch_multi(ctx.h, ah, vh, fh, n, group_ids.h, total_num_groups))
 
+    @staticmethod
+    def update_batch_fused(ctx: "Context", accs: Sequence["GroupsAccumulator"], acc_nodes: Sequence[int], nodes: Sequence[tuple], cols: Sequence[Array],
+                           group_ids: Array, opt_filter: Optional[Array], total_num_groups: int):
+        """dfgpu_acc_update_batch_fused: nodes[k] = (op, lhs, rhs) with op "column" / "scalar" (lhs = index into cols) or "+", "-", "*" over
+        earlier nodes; acc_nodes[i] = argument node of accumulator i (-1 for COUNT(*)).  Raises DfgpuError(NOT_IMPLEMENTED) for shapes it
+        does not take; nothing has been accumulated then."""
+        ops = {"column": capi.NODE_COLUMN, "scalar": capi.NODE_SCALAR, "+": 0, "-": 1, "*": 2}
+        n = len(accs)
+        ah = (C.c_void_p * n)(*[a.h for a in accs])
+        an = (C.c_int32 * n)(*acc_nodes)
+        nd = (C.c_int32 * (3 * max(1, len(nodes))))(*[x for op, l, r in nodes for x in (ops[op], l, r)])
+        ch = (C.c_void_p * max(1, len(cols)))(*[c.h for c in cols])
+        ctx.check(ctx.lib.dfgpu_acc_update_batch_fused(ctx.h, ah, an, n, nd, len(nodes), ch, len(cols), group_ids.h, opt_filter.h if opt_filter is not None else None, total_num_groups))
+
     def merge_batch(self, states: Sequence[Array], group_ids: Array, opt_filter: Optional[Array], total_num_groups: int):
         hs, n = capi.handle_array([a.h.value for a in states])
         self.ctx.check(self.ctx.lib.dfgpu_acc_merge_batch(self.ctx.h, self.h, hs, n, group_ids.h, opt_filter.h if opt_filter is not None else None, total_num_groups))

@@ -97,6 +97,8 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
  * the distinct VALUE per code) and intern those ids; groups, ids and emitted keys are identical to interning the values;
  * "join_swap_small_semi" (1/0) == let the plan layer's HashJoinExec index the RIGHT input of a LeftSemi / LeftAnti join when it is
  * at least 8x smaller than the collected left input (rows and row order identical: both are "left rows by ascending index");
+ * "fused_aggregate_min_rows" (rows, default 2^20; negative = never) == smallest batch for which the plan layer's AggregateExec hands
+ * accumulator argument expressions to dfgpu_acc_update_batch_fused instead of evaluating them node by node (results identical);
  * "defer_flag_checks" (1 = enter / 0 = leave a deferred region, nests) == kernel error flags (overflow, divide by zero,
  * cast range, index bounds -- the ArrowError cases of arrow-arith / arrow-cast / arrow-select) are normally checked by the
  * call that ran the kernel; inside a region they are checked once, by the call that leaves it (which returns the error),
@@ -254,6 +256,24 @@ DFGPU_API dfgpu_status dfgpu_acc_update_batch(dfgpu_ctx *ctx, dfgpu_acc *a, cons
  * allowed for COUNT(*); filters may be NULL or hold NULL entries). */
 DFGPU_API dfgpu_status dfgpu_acc_update_batch_multi(dfgpu_ctx *ctx, dfgpu_acc *const *accs, const dfgpu_array *const *values, const dfgpu_array *const *filters,
                                                     int32_t n_accs, const dfgpu_array *group_ids, int64_t total_num_groups);
+/* The same group_aggregate_batch step with the accumulators' ARGUMENT EXPRESSIONS handed over instead of their evaluated values
+ * (row_hash.rs:540-560 evaluates aggregate_expressions per batch, then calls update_batch per accumulator): one pass reads every input
+ * column once, evaluates the expression DAG per row in registers and feeds all accumulators.  nodes[k] is a full-length column
+ * (op DFGPU_NODE_COLUMN, lhs = index into cols), a literal (DFGPU_NODE_SCALAR, lhs = index into cols of a 1-row array, ≙
+ * ColumnarValue::Scalar) or DFGPU_OP_ADD / SUB / MUL over EARLIER nodes lhs, rhs with the result types and checked arithmetic of
+ * dfgpu_binary; acc_nodes[i] is accumulator i's argument node (-1 for COUNT(*)).  Taken for SUM / AVG / COUNT over <= 8 groups with
+ * all-Float64 or all-Decimal128 non-nullable columns; any other shape returns DFGPU_NOT_IMPLEMENTED and the caller evaluates node by
+ * node (dfgpu_binary) and calls dfgpu_acc_update_batch_multi -- the results are identical.  The kernel is compiled for the expression
+ * at hand on first use (hiprtc) and cached for the process. */
+typedef struct dfgpu_expr_node { int32_t op; int32_t lhs; int32_t rhs; } dfgpu_expr_node;
+#define DFGPU_NODE_COLUMN (-1)
+#define DFGPU_NODE_SCALAR (-2)
+DFGPU_API dfgpu_status dfgpu_acc_update_batch_fused(dfgpu_ctx *ctx, dfgpu_acc *const *accs, const int32_t *acc_nodes, int32_t n_accs,
+                                                    const dfgpu_expr_node *nodes, int32_t n_nodes, const dfgpu_array *const *cols, int32_t n_cols,
+                                                    const dfgpu_array *group_ids, const dfgpu_array *opt_filter, int64_t total_num_groups);
+/* Build check without a device: compiles the fused-aggregate kernel text for a representative Float64 and Decimal128 shape for `arch`
+ * (NULL = "gfx950"); the compiler log lands in `log` on failure. */
+DFGPU_API dfgpu_status dfgpu_jit_selftest(const char *arch, char *log, int64_t log_capacity);
 /* ≙ GroupsAccumulator::merge_batch (:136-142): states as produced by dfgpu_acc_state. */
 DFGPU_API dfgpu_status dfgpu_acc_merge_batch(dfgpu_ctx *ctx, dfgpu_acc *a, const dfgpu_array *const *states, int32_t nstates,
                                              const dfgpu_array *group_ids, const dfgpu_array *opt_filter, int64_t total_num_groups);

@@ -298,3 +298,78 @@ def test_aggregate_exec_partial_final_matches_reference_vector(ctx, task_ctx):
 def sort_rows_local(batch):
     from helpers import rows_of, sort_rows
     return sort_rows(rows_of([c.to_arrow() for c in batch.columns]))
+
+
+def _fused_inputs(money, n):
+    if money == "decimal":
+        mk = lambda lo, hi, p=15, s=2: pa.array([decimal.Decimal(int(v)).scaleb(-s) for v in RNG.integers(lo, hi, n)], type=pa.decimal128(p, s))
+        one = pa.array([decimal.Decimal(1)], type=pa.decimal128(20, 0))
+        types = {"qty": (15, 2), "price": (38, 4), "charge": (38, 6)}
+    else:
+        mk = lambda lo, hi, p=0, s=0: pa.array(RNG.integers(lo, hi, n).astype(np.float64) / 100.0)
+        one = pa.array([1.0])
+        types = {"qty": (0, 0), "price": (0, 0), "charge": (0, 0)}
+    return mk(90000, 10494951), mk(0, 11), mk(0, 9), mk(100, 5001), one, types
+
+
+@pytest.mark.parametrize("ngroups,masked", [(1, True), (6, False), (6, True), (8, False)])
+@pytest.mark.parametrize("money", ["float64", "decimal"])
+def test_update_batch_fused_equals_node_by_node(ctx, money, ngroups, masked):
+    """dfgpu_acc_update_batch_fused (argument expressions evaluated inside the accumulate pass, kernel compiled for the expression DAG) must
+    leave every accumulator as dfgpu_binary node by node + update_batch_multi do: TPC-H Q1's list -- SUM(qty), SUM(price * (1 - disc)),
+    SUM(price * (1 - disc) * (1 + tax)), AVG(qty), AVG(disc), COUNT(*) -- over two batches (ragged tail, growing group count), skipped
+    group ids and, for the single group, a filter."""
+    import dfgpu
+    T = dfgpu.capi.DECIMAL128 if money == "decimal" else dfgpu.capi.FLOAT64
+    nodes = [("column", 0, 0), ("column", 1, 0), ("scalar", 2, 0), ("-", 2, 1), ("*", 0, 3), ("column", 3, 0), ("+", 2, 5), ("*", 4, 6), ("column", 4, 0)]
+    acc_nodes = [8, 4, 7, 8, 1, -1]
+    def make(types):
+        spec = [("SUM", types["qty"]), ("SUM", types["price"]), ("SUM", types["charge"]), ("AVG", types["qty"]), ("AVG", (15, 2) if money == "decimal" else (0, 0)), ("COUNT", (0, 0))]
+        return [dfgpu.GroupsAccumulator(ctx, KIND[f], dfgpu.capi.INT64 if f == "COUNT" else T, p, s) for f, (p, s) in spec]
+    fused = plain = None
+    for n, total in ((50001, max(1, ngroups - 2)), (1234, ngroups)):
+        ext, disc, tax, qty, one, types = _fused_inputs(money, n)
+        if fused is None:
+            fused, plain = make(types), make(types)
+        g = RNG.integers(0, total, n).astype(np.uint32)
+        filt = None
+        if masked and ngroups > 1:
+            g[RNG.random(n) < 0.2] = 0xFFFFFFFF
+        elif masked:
+            filt = ctx.from_arrow(pa.array(RNG.random(n) < 0.7))
+        d = {k: ctx.from_arrow(v) for k, v in dict(ext=ext, disc=disc, tax=tax, qty=qty, one=one).items()}
+        gd = ctx.from_arrow(pa.array(g))
+        dfgpu.GroupsAccumulator.update_batch_fused(ctx, fused, acc_nodes, nodes, [d["ext"], d["disc"], d["one"], d["tax"], d["qty"]], gd, filt, total)
+        price = ctx.binary(2, d["ext"], ctx.binary(1, d["one"], d["disc"], lhs_scalar=True))
+        charge = ctx.binary(2, price, ctx.binary(0, d["one"], d["tax"], lhs_scalar=True))
+        dfgpu.GroupsAccumulator.update_batch_multi(ctx, plain, [d["qty"], price, charge, d["qty"], d["disc"], None], [filt] * 6, gd, total)
+    for a, b in zip(fused, plain):
+        for x, y in zip(a.state(), b.state()):
+            check_equal(x.to_arrow(), y.to_arrow(), money == "float64")
+        check_equal(a.evaluate().to_arrow(), b.evaluate().to_arrow(), money == "float64")
+
+
+def test_update_batch_fused_overflow_and_unsupported_shapes(ctx):
+    """Checked Decimal128 arithmetic inside the fused pass raises for rows an accumulator sees and only for those; shapes it does not
+    take (nullable column, more than 8 groups, MIN / MAX) answer NOT_IMPLEMENTED before anything is accumulated."""
+    import dfgpu
+    big = pa.array([decimal.Decimal(10**37), decimal.Decimal(5), decimal.Decimal(10**37)], type=pa.decimal128(38, 0))
+    hundred = pa.array([decimal.Decimal(100)], type=pa.decimal128(20, 0))
+    nodes = [("column", 0, 0), ("scalar", 1, 0), ("*", 0, 1)]
+    cols = [ctx.from_arrow(big), ctx.from_arrow(hundred)]
+    mk = lambda kind="SUM": dfgpu.GroupsAccumulator(ctx, KIND[kind], dfgpu.capi.DECIMAL128, 38, 0)
+    gids = lambda v: ctx.from_arrow(pa.array(v, type=pa.uint32()))
+    with pytest.raises(dfgpu.DfgpuError) as e:
+        dfgpu.GroupsAccumulator.update_batch_fused(ctx, [mk()], [2], nodes, cols, gids([0, 0, 0]), None, 1)
+    assert "verflow" in str(e.value)
+    acc = mk()
+    dfgpu.GroupsAccumulator.update_batch_fused(ctx, [acc], [2], nodes, cols, gids([0xFFFFFFFF, 0, 0xFFFFFFFF]), None, 1)       # the overflowing rows are skipped
+    assert acc.evaluate().to_arrow().to_pylist() == [decimal.Decimal(500)]
+    acc = mk()
+    dfgpu.GroupsAccumulator.update_batch_fused(ctx, [acc], [2], nodes, cols, gids([0, 0, 0]), ctx.from_arrow(pa.array([False, True, False])), 1)
+    assert acc.evaluate().to_arrow().to_pylist() == [decimal.Decimal(500)]
+    nullable = [ctx.from_arrow(pa.array([decimal.Decimal(1), None, decimal.Decimal(3)], type=pa.decimal128(38, 0))), cols[1]]
+    for args in (([mk()], [2], nodes, nullable, gids([0, 0, 0]), None, 1), ([mk()], [2], nodes, cols, gids([0, 8, 3]), None, 9), ([mk("MIN")], [2], nodes, cols, gids([0, 0, 0]), None, 1)):
+        with pytest.raises(dfgpu.DfgpuError) as e:
+            dfgpu.GroupsAccumulator.update_batch_fused(ctx, *args)
+        assert e.value.kind == "NotImplemented"

@@ -82,10 +82,23 @@ def lineitem(n, money="decimal"):
                      "l_shipdate": pa.array(RNG.integers(8035, 10560, n).astype(np.int32)).cast(pa.date32())})
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("money", ["decimal", "float64"])
-def test_q1_grouped_aggregate(ctx, money):
+def test_q1_grouped_aggregate(ctx, money, fused):
     """tpch/q1.slt.part: Filter l_shipdate <= 10471 -> Projection (disc_price computed once) -> Aggregate Partial (2 Utf8 keys,
-    4 SUM + 3 AVG + COUNT(*)) -> Repartition Hash -> FinalPartitioned -> Sort [l_returnflag, l_linestatus]."""
+    4 SUM + 3 AVG + COUNT(*)) -> Repartition Hash -> FinalPartitioned -> Sort [l_returnflag, l_linestatus].  `fused`: the Partial
+    aggregate looks through the projection and evaluates its arguments inside the accumulate pass (dfgpu_acc_update_batch_fused), which
+    large batches do by default; otherwise node by node."""
+    import dfgpu
+    from dfgpu import physical_plan as ops
+    ctx.set_option("fused_aggregate_min_rows", 0 if fused else -1)
+    try:
+        _q1_body(ctx, money)
+    finally:
+        ctx.set_option("fused_aggregate_min_rows", 1 << 20)
+
+
+def _q1_body(ctx, money):
     import dfgpu
     from dfgpu import physical_plan as ops
     tabs = [lineitem(6000, money), lineitem(9000, money), lineitem(50, money)]
@@ -129,6 +142,7 @@ def test_q5_partitioned_multi_join_two_key(ctx):
     from dfgpu import physical_plan as ops
     import dfgpu
     nc, no, nl, ns = 600, 3000, 12000, 80
+    RNG = np.random.default_rng(77)          # own stream: the 5-nation sanity check below must not depend on which tests ran before
     customer = pa.table({"c_custkey": pa.array(np.arange(nc, dtype=np.int64)), "c_nationkey": pa.array(RNG.integers(0, 25, nc).astype(np.int64))})
     orders = pa.table({"o_orderkey": pa.array(np.arange(no, dtype=np.int64) * 4 + 1), "o_custkey": pa.array(RNG.integers(0, nc, no).astype(np.int64)),
                        "o_orderdate": pa.array(RNG.integers(8766, 9500, no).astype(np.int32)).cast(pa.date32())})
