@@ -164,9 +164,10 @@ def main():
             out = [b for b in plan.execute(0, tc)]
         else:
             plan = staged if staged is not None else PLANS[args.plan](tables, batch_size=8192)
-            local = [b for b in plan.execute(0, tc)]
-            mine = ops.concat_batches(local[0].schema, local) if local else None
-            gathered = exchange.gather_batches(ctx, None, mine, 0, names=Q3_OUTPUT)           # ≙ SortPreservingMergeExec gathering the sorted partitions
+            with ctx.deferred_flags():          # one error-flag read-back for the rank's plan + gather instead of one per materialised column
+                local = [b for b in plan.execute(0, tc)]
+                mine = ops.concat_batches(local[0].schema, local) if local else None
+                gathered = exchange.gather_batches(ctx, None, mine, 0, names=Q3_OUTPUT)       # ≙ SortPreservingMergeExec gathering the sorted partitions
             out = []
             if rank == 0 and gathered.num_rows:
                 final_slot.replace([[gathered]])

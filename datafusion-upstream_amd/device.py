@@ -49,6 +49,20 @@ class Context:
         self.check(self.lib.dfgpu_ctx_get_option(self.h, key.encode(), ctypes.byref(v)))
         return int(v.value)
 
+    def deferred_flags(self):
+        """Context manager: kernel error flags raised inside are checked once, on exit (option "defer_flag_checks"), instead of after
+        every C-ABI call -- one stream sync for a sequence of calls (materialising the columns of a batch before an exchange)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def region():
+            self.set_option("defer_flag_checks", 1)
+            try:
+                yield
+            finally:
+                self.set_option("defer_flag_checks", 0)
+        return region()
+
     def profile_enable(self, on: bool = True):
         self.check(self.lib.dfgpu_profile_enable(self.h, int(on)))
 

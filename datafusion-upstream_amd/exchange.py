@@ -131,6 +131,11 @@ def _exchange_meta(counts: Sequence[int], fields, has_valid: Sequence[int], grou
 
 
 def exchange_batches(ctx, schema, parts: List[Optional["RecordBatch"]], group=None, names: Optional[Sequence[str]] = None, broadcast: bool = False):
+    with ctx.deferred_flags():          # materialising pending gathers of the outgoing columns: one flag check for all of them
+        return _exchange_batches(ctx, schema, parts, group, names, broadcast)
+
+
+def _exchange_batches(ctx, schema, parts, group, names, broadcast):
     """parts[dest] = the rows of this rank bound for rank `dest` (None/empty allowed; fixed-width and Utf8 columns, nullable or not).
     Returns one RecordBatch holding everything this rank received, source ranks in order (≙ the batches a RepartitionExec
     output partition yields).  One metadata all-gather (_exchange_meta), then one collective per column buffer: all-to-all(v)
@@ -336,15 +341,16 @@ class ShuffleExec:
         pp = self._pp
         rep = pp.RepartitionExec(self.input, pp.Partitioning.Hash(self.exprs, self.world))
         merged, schema = [], None
-        for d in range(self.world):
-            bs = [b for b in rep.execute(d, context) if b.num_rows]
-            m = pp.concat_batches(None, bs) if bs else None
-            if m is not None:
-                schema = m.schema
-                if d != self.rank:
-                    self.bytes_sent += sum(_WIDTH.get(f.dtype, 0) for f in schema.fields) * m.num_rows
-            merged.append(m)
-        out = exchange_batches(context.ctx, schema, merged, self.group, names=self.input.schema().names())
+        with context.ctx.deferred_flags():
+            for d in range(self.world):
+                bs = [b for b in rep.execute(d, context) if b.num_rows]
+                m = pp.concat_batches(None, bs) if bs else None
+                if m is not None:
+                    schema = m.schema
+                    if d != self.rank:
+                        self.bytes_sent += sum(_WIDTH.get(f.dtype, 0) for f in schema.fields) * m.num_rows
+                merged.append(m)
+            out = exchange_batches(context.ctx, schema, merged, self.group, names=self.input.schema().names())
         if out.num_rows:
             yield out
 
@@ -389,13 +395,14 @@ class BroadcastExec:
 
     def execute(self, partition, context):
         pp = self._pp
-        local = []
-        for p in range(self.input.output_partitioning().partition_count()):
-            local += [b for b in self.input.execute(p, context) if b.num_rows]
-        mine = pp.concat_batches(None, local) if local else None
-        if mine is not None:
-            self.bytes_sent += sum(_WIDTH.get(f.dtype, 0) for f in mine.schema.fields) * mine.num_rows * (self.world - 1)
-        out = exchange_batches(context.ctx, None, [mine] * self.world, self.group, names=self.input.schema().names(), broadcast=True)
+        with context.ctx.deferred_flags():
+            local = []
+            for p in range(self.input.output_partitioning().partition_count()):
+                local += [b for b in self.input.execute(p, context) if b.num_rows]
+            mine = pp.concat_batches(None, local) if local else None
+            if mine is not None:
+                self.bytes_sent += sum(_WIDTH.get(f.dtype, 0) for f in mine.schema.fields) * mine.num_rows * (self.world - 1)
+            out = exchange_batches(context.ctx, None, [mine] * self.world, self.group, names=self.input.schema().names(), broadcast=True)
         if out.num_rows:
             yield out
 
