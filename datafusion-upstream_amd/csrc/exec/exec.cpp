@@ -636,7 +636,9 @@ static const char* agg_fun_name(int k) { switch (k) { case DFGPU_AGG_SUM: return
 
 struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggregateStream row_hash.rs:423-662
   int mode; std::vector<ExprPtr> gexprs; std::vector<std::string> gnames; std::vector<AggExpr> aggs; PlanPtr input; mutable SchemaPtr sch; mutable std::mutex mu;
-  PlanPtr fresh() const override { auto a = std::make_shared<AggregateExec>(); a->mode = mode; a->gexprs = gexprs; a->gnames = gnames; a->aggs = aggs; a->input = input->fresh(); return a; }
+  // PhysicalGroupBy grouping sets (aggregates/mod.rs:103-160): sets[s][i] != 0 = key i is replaced by null_exprs[i] in set s; empty = the single set of all keys
+  std::vector<ExprPtr> null_exprs; std::vector<std::vector<uint8_t>> sets;
+  PlanPtr fresh() const override { auto a = std::make_shared<AggregateExec>(); a->mode = mode; a->gexprs = gexprs; a->gnames = gnames; a->aggs = aggs; a->input = input->fresh(); a->null_exprs = null_exprs; a->sets = sets; return a; }
   const char* name() const override { return "AggregateExec"; }
   bool merging() const { return mode == 1 || mode == 2; }
   // The accumulator arguments as ONE expression DAG over plain columns (common subexpressions shared; references to deferred projection
@@ -689,6 +691,36 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
     if (st == DFGPU_NOT_IMPLEMENTED) return false;
     tc.check(st); return true;
   }
+  // evaluate_group_by + the per-set loop of group_aggregate_batch (aggregates/mod.rs:1161-1200, row_hash.rs:540-600): keys and accumulator
+  // arguments are evaluated once per batch; every grouping set interns its own key tuples (masked keys come from null_exprs) into the
+  // one GroupValues and updates every accumulator with the resulting group ids.
+  void group_aggregate_sets(const TaskContext& tc, Batch& b, const ArrayRef& mask, GroupsRef& groups, std::vector<AccRef>& accs) const {
+    std::vector<ArrayRef> keys, nulls, vals(aggs.size()), filts(aggs.size());
+    for (auto& e : gexprs) keys.push_back(into_array(tc, e->eval(tc, b), b.base_rows));
+    for (auto& e : null_exprs) nulls.push_back(into_array(tc, e->eval(tc, b), b.base_rows));
+    for (size_t i = 0; i < aggs.size(); i++) {
+      if (merging()) continue;
+      if (aggs[i].arg) vals[i] = into_array(tc, aggs[i].arg->eval(tc, b), b.base_rows);
+      if (aggs[i].filter) filts[i] = into_array(tc, aggs[i].filter->eval(tc, b), b.base_rows);
+    }
+    for (auto& set : sets) {
+      std::vector<const dfgpu_array*> gp;
+      for (size_t i = 0; i < keys.size(); i++) gp.push_back(set[i] ? nulls[i].a : keys[i].a);
+      dfgpu_array* ids = nullptr; tc.check(dfgpu_groups_intern(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids)); ArrayRef gids = ArrayRef::adopt(ids);
+      int64_t total = dfgpu_groups_len(groups.g);
+      size_t col = gexprs.size();
+      std::vector<dfgpu_acc*> ap; std::vector<const dfgpu_array*> vp, fp;
+      for (size_t i = 0; i < aggs.size(); i++) {
+        if (merging()) {
+          int nst = aggs[i].kind == DFGPU_AGG_AVG ? 2 : 1; const dfgpu_array* st[2];
+          for (int k = 0; k < nst; k++) st[k] = b.column(tc, (int)(col + (size_t)k)).a;
+          col += (size_t)nst;
+          tc.check(dfgpu_acc_merge_batch(tc.ctx, accs[i].a, st, nst, gids.a, nullptr, total));
+        } else { ap.push_back(accs[i].a); vp.push_back(vals[i].a); fp.push_back(filts[i].a); }
+      }
+      if (!ap.empty()) tc.check(dfgpu_acc_update_batch_multi(tc.ctx, ap.data(), vp.data(), fp.data(), (int32_t)ap.size(), gids.a, total));
+    }
+  }
   std::vector<std::string> out_names() const {
     std::vector<std::string> n = gnames;
     for (auto& a : aggs) { if (mode == 0) { if (a.kind == DFGPU_AGG_AVG) { n.push_back(a.name + "[count]"); n.push_back(a.name + "[sum]"); } else n.push_back(a.name + "[" + agg_fun_name(a.kind) + "]"); } else n.push_back(a.name); }
@@ -724,6 +756,7 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
       }
       if (b.base_rows == 0) continue;
       ArrayRef mask = b.selection; b.selection = ArrayRef();
+      if (!sets.empty()) { for (size_t ci = 0; ci < deferred.size(); ci++) ensure((int)ci); group_aggregate_sets(tc, b, mask, groups, accs); continue; }
       ArrayRef gids; int64_t total = 1;
       if (grouped) {
         std::vector<ArrayRef> gc; std::vector<const dfgpu_array*> gp;
@@ -957,6 +990,16 @@ dfgpu_status dfgpu_plan_aggregate(int32_t mode, const dfgpu_expr* const* gexprs,
       a->aggs.push_back(std::move(x));
     }
     *out = new dfgpu_plan{a};
+  });
+}
+dfgpu_status dfgpu_plan_aggregate_grouping_sets(dfgpu_plan* aggregate, const dfgpu_expr* const* null_exprs, int32_t nkeys, const uint8_t* groups, int32_t nsets) {
+  return guard([&] {
+    auto* a = aggregate ? const_cast<AggregateExec*>(dynamic_cast<const AggregateExec*>(aggregate->p.get())) : nullptr;       // the node is still private to its builder
+    if (!a) fail(DFGPU_INVALID_ARGUMENT, "plan_aggregate_grouping_sets: not an AggregateExec");
+    if (nkeys != (int32_t)a->gexprs.size() || nkeys < 1 || nsets < 1 || !null_exprs || !groups) fail(DFGPU_INVALID_ARGUMENT, "plan_aggregate_grouping_sets: %d null expressions / %d sets for %zu group expressions", nkeys, nsets, a->gexprs.size());
+    a->null_exprs.clear(); a->sets.clear();
+    for (int i = 0; i < nkeys; i++) a->null_exprs.push_back(ex(null_exprs[i]));
+    for (int s2 = 0; s2 < nsets; s2++) a->sets.emplace_back(groups + (size_t)s2 * (size_t)nkeys, groups + (size_t)(s2 + 1) * (size_t)nkeys);
   });
 }
 dfgpu_status dfgpu_plan_sort(const dfgpu_expr* const* exprs, const uint8_t* desc, const uint8_t* nf, int32_t n, int64_t fetch, int32_t preserve, const dfgpu_plan* input, dfgpu_plan** out) {

@@ -519,10 +519,23 @@ class AggregateFunctionExpr:
 _AGG_MODES = {"Partial": 0, "Final": 1, "FinalPartitioned": 2, "Single": 3, "SinglePartitioned": 4}
 
 
+@dataclass
+class PhysicalGroupBy:
+    """aggregates/mod.rs:103-160: `expr` the group expressions, `null_expr` the typed NULL literal standing in for each of them, `groups[s][i]`
+    True when grouping set s replaces expression i by its NULL (GROUPING SETS / CUBE / ROLLUP).  A plain list of (expr, name) pairs is
+    PhysicalGroupBy::new_single."""
+    expr: List[Tuple[PhysicalExpr, str]]
+    null_expr: List[Tuple[PhysicalExpr, str]]
+    groups: List[List[bool]]
+
+
 class AggregateExec(ExecutionPlan):
-    def __init__(self, mode: str, group_by: List[Tuple[PhysicalExpr, str]], aggr_expr: List[AggregateFunctionExpr], input):
+    def __init__(self, mode: str, group_by, aggr_expr: List[AggregateFunctionExpr], input):
         if mode not in _AGG_MODES:
             raise DfgpuError(5, f"unknown AggregateMode {mode}")
+        self.grouping = group_by if isinstance(group_by, PhysicalGroupBy) else None
+        if self.grouping is not None:
+            group_by = self.grouping.expr
         for a in aggr_expr:
             if a.kind != capi.AGG_COUNT and a.input_field is None:
                 raise DfgpuError(5, f"aggregate {a.name}: input_field (argument data type) is required")
@@ -550,6 +563,10 @@ class AggregateExec(ExecutionPlan):
         out = C.c_void_p()
         _check(_lib().dfgpu_plan_aggregate(_AGG_MODES[self.mode], _ptrs([e.handle(ctx).h for e, _ in self.group_by]), _strs([n for _, n in self.group_by]), len(self.group_by),
                                            kinds, args, filts, _strs([a.name for a in self.aggr_expr]), tarr, na, _child_handle(self.input, context).h, C.byref(out)))
+        if self.grouping is not None:
+            g = self.grouping
+            flat = [1 if m else 0 for s in g.groups for m in s]
+            _check(_lib().dfgpu_plan_aggregate_grouping_sets(out, _ptrs([e.handle(ctx).h for e, _ in g.null_expr]), len(g.null_expr), (C.c_uint8 * max(1, len(flat)))(*flat), len(g.groups)))
         return self._new(out)
 
 

@@ -72,6 +72,10 @@ DFGPU_API dfgpu_status dfgpu_plan_hash_join(const dfgpu_plan *left, const dfgpu_
 DFGPU_API dfgpu_status dfgpu_plan_aggregate(int32_t mode, const dfgpu_expr *const *group_exprs, const char *const *group_names, int32_t ngroups,
                                             const int32_t *agg_kinds, const dfgpu_expr *const *agg_args, const dfgpu_expr *const *agg_filters, const char *const *agg_names,
                                             const int32_t *agg_arg_types /* 3 per aggregate */, int32_t naggs, const dfgpu_plan *input, dfgpu_plan **out);
+/* PhysicalGroupBy with grouping sets (aggregates/mod.rs:103-160; GROUPING SETS / CUBE / ROLLUP): null_exprs[i] is the typed NULL
+ * literal that stands in for group expression i, groups[s * nkeys + i] != 0 says set s replaces key i by it.  Every input batch is
+ * grouped once per set into the same GroupValues (evaluate_group_by, :1161-1200).  Call before the plan first executes. */
+DFGPU_API dfgpu_status dfgpu_plan_aggregate_grouping_sets(dfgpu_plan *aggregate, const dfgpu_expr *const *null_exprs, int32_t nkeys, const uint8_t *groups, int32_t nsets);
 /* SortExec::new(expr, input).with_fetch(fetch).with_preserve_partitioning(..); fetch < 0 = none */
 DFGPU_API dfgpu_status dfgpu_plan_sort(const dfgpu_expr *const *exprs, const uint8_t *descending, const uint8_t *nulls_first, int32_t n, int64_t fetch,
                                        int32_t preserve_partitioning, const dfgpu_plan *input, dfgpu_plan **out);

@@ -276,3 +276,26 @@ def test_aggregate_without_group_by(ctx):
             assert row[5] == sum(sel["d"].to_pylist()) and row[6] == max(sel["d"].to_pylist())
         else:
             assert row == [None, 0, 0, None, None, None, None]
+
+
+def test_aggregate_grouping_sets_reference_vector(ctx):
+    """aggregates/mod.rs:1353-1507 (`check_grouping_sets`, no spill): PhysicalGroupBy with the sets (a, NULL), (NULL, b), (a, b) over
+    `some_data()` (:1256-1286), COUNT(1) Partial then Final over the merged partitions; both expected tables transcribed."""
+    import dfgpu
+    from dfgpu import physical_plan as ops
+    a0, b0 = pa.array([2, 3, 4, 4], type=pa.uint32()), pa.array([1.0, 2.0, 3.0, 4.0])
+    a1, b1 = pa.array([2, 3, 3, 4], type=pa.uint32()), pa.array([1.0, 2.0, 3.0, 4.0])
+    tabs = [pa.table({"a": a0, "b": b0}), pa.table({"a": a1, "b": b1})]
+    C, L = ops.Column, ops.Literal
+    gb = ops.PhysicalGroupBy([(C("a", 0), "a"), (C("b", 1), "b")], [(L(None, pa.uint32()), "a"), (L(None, pa.float64()), "b")],
+                             [[False, True], [True, False], [False, False]])
+    aggs = [ops.AggregateFunctionExpr("COUNT", L(1, pa.int8()), "COUNT(1)")]
+    partial = ops.AggregateExec("Partial", gb, aggs, src(ctx, tabs, 1))
+    want = [[None, 1.0, 2], [None, 2.0, 2], [None, 3.0, 2], [None, 4.0, 2], [2, None, 2], [2, 1.0, 2], [3, None, 3], [3, 2.0, 2], [3, 3.0, 1], [4, None, 3], [4, 3.0, 1], [4, 4.0, 2]]
+    assert ops.collect(ops.AggregateExec("Partial", gb, aggs, src(ctx, tabs, 1)), ops.TaskContext(ctx, 8192))[0].schema.names() == ["a", "b", "COUNT(1)[count]"]
+    got = run(partial, ctx)
+    assert sort_rows(rows_of([got.column(i) for i in range(3)])) == sort_rows(want)
+    final = ops.AggregateExec("Final", [(C("a", 0), "a"), (C("b", 1), "b")], aggs, ops.AggregateExec("Partial", gb, aggs, src(ctx, tabs, 2)))
+    got = run(final, ctx)
+    assert got.num_rows == 12
+    assert sort_rows(rows_of([got.column(i) for i in range(3)])) == sort_rows(want)

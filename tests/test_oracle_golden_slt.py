@@ -39,3 +39,25 @@ def test_oracle_sort_exec_known_answers(eng, case):
 @pytest.mark.parametrize("case", AGG["clickbench"]["cases"], ids=[c["name"] for c in AGG["clickbench"]["cases"]])
 def test_oracle_clickbench_sample(eng, case):
     run_clickbench_case(eng, AGG, case)
+
+
+def test_oracle_grouping_sets_reference_vector():
+    """aggregates/mod.rs:1353-1507 (`check_grouping_sets`): evaluate_group_by (:1161-1200) restated over the oracle's GroupValues /
+    GroupsAccumulator -- every batch is interned once per grouping set (masked keys replaced by typed NULLs) into ONE group table and
+    COUNT(1) updated with those ids -- gives the reference's Partial table (no-spill variant)."""
+    import numpy as np
+    import pyarrow as pa
+    from oracle import pyoracle as po
+    batches = [(pa.array([2, 3, 4, 4], type=pa.uint32()), pa.array([1.0, 2.0, 3.0, 4.0])), (pa.array([2, 3, 3, 4], type=pa.uint32()), pa.array([1.0, 2.0, 3.0, 4.0]))]
+    sets = [[False, True], [True, False], [False, False]]
+    groups, acc = po.Groups([pa.uint32(), pa.float64()]), po.Acc("COUNT", pa.int8())
+    for a, b in batches:
+        nulls = [pa.nulls(len(a), pa.uint32()), pa.nulls(len(b), pa.float64())]
+        ones = pa.array(np.ones(len(a), dtype=np.int8))
+        for mask in sets:
+            gids = groups.intern([nulls[i] if m else c for i, (m, c) in enumerate(zip(mask, (a, b)))])
+            acc.update_batch(ones, gids, None, len(groups))
+    ka, kb = groups.emit()
+    got = sorted(zip(ka.to_pylist(), kb.to_pylist(), acc.evaluate().to_pylist()), key=lambda r: tuple((0, 0) if v is None else (1, v) for v in r))
+    want = [(None, 1.0, 2), (None, 2.0, 2), (None, 3.0, 2), (None, 4.0, 2), (2, None, 2), (2, 1.0, 2), (3, None, 3), (3, 2.0, 2), (3, 3.0, 1), (4, None, 3), (4, 3.0, 1), (4, 4.0, 2)]
+    assert got == want
