@@ -125,6 +125,7 @@ PROTOTYPES = {
     "dfgpu_groups_new": (C.c_int32, [_P, C.c_int32, _PP]),
     "dfgpu_groups_free": (None, [_P]),
     "dfgpu_groups_intern": (C.c_int32, [_P, _P, _PP, C.c_int32, _P, _PP]),
+    "dfgpu_groups_intern_deferred": (C.c_int32, [_P, _P, _PP, C.c_int32, _P, _PP]),
     "dfgpu_groups_len": (C.c_int64, [_P]),
     "dfgpu_groups_size": (C.c_int64, [_P]),
     "dfgpu_groups_emit": (C.c_int32, [_P, _P, _PP]),

@@ -464,6 +464,7 @@ static void acc_resize(dfgpu_acc* a, int64_t total) {
 static void launch_update(dfgpu_acc* a, int kind, int cls, const dfgpu_array* values, const dfgpu_array* gids, const dfgpu_array* filt, int64_t total, void* vals) {
   dfgpu_ctx* ctx = a->ctx; int64_t n = gids->length;
   if (gids->type != DFGPU_UINT32) fail(DFGPU_INVALID_ARGUMENT, "group ids must be a UINT32 array");
+  materialize_ids(ctx, gids);
   if (values && values->length != n) fail(DFGPU_INVALID_ARGUMENT, "values (%lld rows) and group ids (%lld rows) differ in length", (long long)values->length, (long long)n);
   if (filt && (filt->type != DFGPU_BOOL || filt->length != n)) fail(DFGPU_INVALID_ARGUMENT, "opt_filter must be a Boolean array of the batch length");
   if (!n) return;
@@ -594,6 +595,7 @@ dfgpu_status dfgpu_acc_update_batch_multi(dfgpu_ctx* ctx, dfgpu_acc* const* accs
     dfgpu_status st = guard(ctx, [&] {
       int64_t n = gids->length;
       if (gids->type != DFGPU_UINT32) fail(DFGPU_INVALID_ARGUMENT, "group ids must be a UINT32 array");
+      materialize_ids(ctx, gids);
       if (f && (f->type != DFGPU_BOOL || f->length != n)) fail(DFGPU_INVALID_ARGUMENT, "opt_filter must be a Boolean array of the batch length");
       MultiArgs ma{}; int na = j - i + 1;
       for (int s = 0; s < na; s++) {
@@ -635,16 +637,20 @@ bool jit_compile_only(const std::string& source, const char* arch, std::string* 
 void decimal_arith_plan(int op, int p1, int s1, int p2, int s2, int* rp, int* rs, i128* lmul, i128* rmul);      // expr.hip
 
 constexpr int FUSED_MAX = 16;
-struct FusedArgs { const void* col[FUSED_MAX]; const uint32_t* gids; const uint64_t* fbits; long long n; void* vals[FUSED_MAX]; uint64_t* counts[FUSED_MAX]; uint8_t* seen[FUSED_MAX]; uint32_t* flags; };
+struct FusedArgs { const void* col[FUSED_MAX]; const uint32_t* gids; const uint64_t* fbits; long long n; void* vals[FUSED_MAX]; uint64_t* counts[FUSED_MAX]; uint8_t* seen[FUSED_MAX]; uint32_t* flags;
+                   const void* kcode[2]; const uint32_t* canon[2]; const uint32_t* dense_map; const uint64_t* gmask; };
 
 static const char* FUSED_PRELUDE = R"SRC(
 typedef __int128 i128; typedef unsigned __int128 u128; typedef unsigned long long u64; typedef unsigned int u32;
 #define I128(hi, lo) ((i128)(((u128)(u64)(hi) << 64) | (u128)(u64)(lo)))
 #define GID_NONE 0xFFFFFFFFu
-struct Args { const void* col[16]; const u32* gids; const u64* fbits; long long n; void* vals[16]; u64* counts[16]; unsigned char* seen[16]; u32* flags; };
+struct Args { const void* col[16]; const u32* gids; const u64* fbits; long long n; void* vals[16]; u64* counts[16]; unsigned char* seen[16]; u32* flags;
+              const void* kcode[2]; const u32* canon[2]; const u32* dense_map; const u64* gmask; };
 __device__ inline bool add128_checked(i128 a, i128 b, i128* out) { i128 r = (i128)((u128)a + (u128)b); if ((a >= 0) == (b >= 0) && (r >= 0) != (a >= 0)) return false; *out = r; return true; }
 __device__ inline bool sub128_checked(i128 a, i128 b, i128* out) { i128 r = (i128)((u128)a - (u128)b); if ((a >= 0) != (b >= 0) && (r >= 0) != (a >= 0)) return false; *out = r; return true; }
 __device__ inline bool mul128_checked(i128 a, i128 b, i128* out) {
+  const long long al = (long long)a, bl = (long long)b;
+  if ((i128)al == a && (i128)bl == b) { *out = (i128)al * (i128)bl; return true; }      // both operands fit 64 bits: the product fits 128 (every TPC-H money value)
   bool neg = (a < 0) != (b < 0);
   u128 ua = a < 0 ? (u128)0 - (u128)a : (u128)a, ub = b < 0 ? (u128)0 - (u128)b : (u128)b;
   u64 a0 = (u64)ua, a1 = (u64)(ua >> 64), b0 = (u64)ub, b1 = (u64)(ub >> 64);
@@ -665,6 +671,7 @@ __device__ inline i128 dec_arith(int op, i128 x, i128 y, i128 lmul, i128 rmul, b
   if (!ok) { if (live) atomicOr(flags, 2u); v = 0; }
   return v;
 }
+template <typename E, int N, int AL> struct __attribute__((aligned(AL))) Vec { E v[N]; };
 __device__ inline i128 ld_i128(const void* p, long long i) { const u64* q = (const u64*)p + 2 * i; return I128(q[1], q[0]); }
 __device__ inline double ld_f64(const void* p, long long i) { return ((const double*)p)[i]; }
 __device__ inline u32 wsum(u32 v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64); return v; }
@@ -686,8 +693,13 @@ static std::string f64_text(double d) { uint64_t u; memcpy(&u, &d, 8); char b[64
 
 struct FusedNodeInfo { int p = 0, s = 0; i128 lmul = 1, rmul = 1; };
 // The kernel text for one (expression DAG, accumulator list, group count, mask presence) shape
+// dense: the group ids come from dictionary code columns (DeferredIds of dfgpu_groups_intern_deferred) instead of a stored id column:
+// nk code columns of type kt, canonical-id tables and strides as in groups.hip's dense_composite_fast
+struct FusedDense { int nk = 0; int32_t kt = 0; uint32_t stride[2] = {0, 0}; int64_t len[2] = {1, 1}; bool has_mask = false; };
+constexpr int64_t FUSED_DENSE_TABLE = 4096;      // code tuple -> group id table held in LDS
 static std::string fused_source(bool dec, int G, int R, bool has_mask, const dfgpu_expr_node* nodes, int n_nodes, const std::vector<FusedNodeInfo>& info,
-                                const dfgpu_array* const* cols, dfgpu_acc* const* accs, const int32_t* acc_nodes, int n_accs, std::vector<int>* value_nodes) {
+                                const dfgpu_array* const* cols, dfgpu_acc* const* accs, const int32_t* acc_nodes, int n_accs, std::vector<int>* value_nodes,
+                                const FusedDense* dense = nullptr) {
   std::string T = dec ? "i128" : "double", LD = dec ? "ld_i128" : "ld_f64";
   std::vector<int> vn;                                  // distinct argument nodes of SUM / AVG accumulators
   std::vector<int> acc_v((size_t)n_accs, -1);
@@ -706,16 +718,50 @@ static std::string fused_source(bool dec, int G, int R, bool has_mask, const dfg
   s += "extern \"C\" __global__ void __launch_bounds__(256) dfgpu_fused_agg(Args a) {\n"
        "  T acc[NV][G]; u32 cnt[G];\n"
        "#pragma unroll\n  for (int k = 0; k < G; k++) { cnt[k] = 0;\n#pragma unroll\n    for (int v = 0; v < NV; v++) acc[v][k] = (T)0; }\n"
-       "  const long long stride = (long long)gridDim.x * 256;\n"
-       "  for (long long base = (long long)blockIdx.x * 256 + threadIdx.x; base < a.n; base += stride * R) {\n"
+       ;
+  if (dense) {      // code tuple -> group id, composed once per workgroup from the canonical-id tables and the dense map (codes are in range: Arrow)
+    snprintf(b, sizeof b, "  __shared__ u32 gtab[%lld];\n  for (int t = threadIdx.x; t < %lld; t += 256) gtab[t] = a.dense_map[a.canon[0][t / %lld] * %uu", (long long)(dense->len[0] * dense->len[1]),
+             (long long)(dense->len[0] * dense->len[1]), (long long)dense->len[1], dense->stride[0]); s += b;
+    if (dense->nk == 2) { snprintf(b, sizeof b, " + a.canon[1][t %% %lld] * %uu", (long long)dense->len[1], dense->stride[1]); s += b; }
+    s += "];\n  __syncthreads();\n";
+  }
+  // Each lane owns R CONSECUTIVE rows per iteration: its R values of a column are one or two 16-byte loads, its R group ids (or code
+  // bytes) one load, its R mask bits one word -- a wave still covers a contiguous 64 R-row span.  Whole groups of R rows take the vector
+  // path; the ragged last group loads element by element with clamped indices.
+  const char* kt = dense ? (dense->kt == DFGPU_INT8 ? "signed char" : dense->kt == DFGPU_INT16 ? "short" : "int") : "int";
+  snprintf(b, sizeof b, "  typedef Vec<T, R, 16> TV; typedef Vec<u32, R, 4 * R> GV; typedef Vec<%s, R, sizeof(%s) * R> KV;\n", kt, kt); s += b;
+  s += "  const long long stride = (long long)gridDim.x * 256, nvec = (a.n + R - 1) / R;\n"
+       "  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {\n"
+       "    const long long i0 = v * R;\n"
        "    u32 g[R];";
   for (int c : used_cols) { snprintf(b, sizeof b, " T c%d[R];", c); s += b; }
-  s += "\n#pragma unroll\n    for (int r = 0; r < R; r++) {\n"
-       "      long long i = base + r * stride; bool in = i < a.n; long long ii = in ? i : a.n - 1;\n"
-       "      u32 gg = a.gids[ii];\n";
-  s += has_mask ? "      bool pass = in && ((a.fbits[ii >> 6] >> (ii & 63)) & 1ull);\n" : "      bool pass = in;\n";
-  s += "      g[r] = pass ? gg : GID_NONE;\n";
-  for (int c : used_cols) { snprintf(b, sizeof b, "      c%d[r] = %s(a.col[%d], ii);\n", c, LD.c_str(), c); s += b; }
+  s += "\n    if (i0 + R <= a.n) {\n";
+  if (dense) {
+    s += "      const KV k0 = *(const KV*)((const " + std::string(kt) + "*)a.kcode[0] + i0);\n";
+    if (dense->nk == 2) s += "      const KV k1 = *(const KV*)((const " + std::string(kt) + "*)a.kcode[1] + i0);\n";
+    if (dense->has_mask) s += "      const u64 gm = a.gmask[i0 >> 6] >> (i0 & 63);\n";
+  } else s += "      const GV gv = *(const GV*)(a.gids + i0);\n";
+  if (has_mask) s += "      const u64 fm = a.fbits[i0 >> 6] >> (i0 & 63);\n";
+  for (int c : used_cols) { snprintf(b, sizeof b, "      const TV v%d = *(const TV*)((const T*)a.col[%d] + i0);\n", c, c); s += b; }
+  s += "#pragma unroll\n      for (int r = 0; r < R; r++) {\n";
+  if (dense) {
+    snprintf(b, sizeof b, "        u32 gg = gtab[(u32)k0.v[r] * %lldu%s];\n", (long long)dense->len[1], dense->nk == 2 ? " + (u32)k1.v[r]" : ""); s += b;
+    if (dense->has_mask) s += "        if (!((gm >> r) & 1ull)) gg = GID_NONE;\n";
+  } else s += "        u32 gg = gv.v[r];\n";
+  s += has_mask ? "        g[r] = ((fm >> r) & 1ull) ? gg : GID_NONE;\n" : "        g[r] = gg;\n";
+  for (int c : used_cols) { snprintf(b, sizeof b, "        c%d[r] = v%d.v[r];\n", c, c); s += b; }
+  s += "      }\n    } else {\n#pragma unroll\n      for (int r = 0; r < R; r++) {\n"
+       "        const long long i = i0 + r; const bool in = i < a.n; const long long ii = in ? i : a.n - 1;\n";
+  if (dense) {
+    snprintf(b, sizeof b, "        u32 gg = gtab[(u32)((const %s*)a.kcode[0])[ii] * %lldu", kt, (long long)dense->len[1]); s += b;
+    if (dense->nk == 2) { snprintf(b, sizeof b, " + (u32)((const %s*)a.kcode[1])[ii]", kt); s += b; }
+    s += "];\n";
+    if (dense->has_mask) s += "        if (!((a.gmask[ii >> 6] >> (ii & 63)) & 1ull)) gg = GID_NONE;\n";
+  } else s += "        u32 gg = a.gids[ii];\n";
+  s += has_mask ? "        const bool pass = in && ((a.fbits[ii >> 6] >> (ii & 63)) & 1ull);\n" : "        const bool pass = in;\n";
+  s += "        g[r] = pass ? gg : GID_NONE;\n";
+  for (int c : used_cols) { snprintf(b, sizeof b, "        c%d[r] = %s(a.col[%d], ii);\n", c, LD.c_str(), c); s += b; }
+  s += "      }\n";
   s += "    }\n#pragma unroll\n    for (int r = 0; r < R; r++) {\n      const bool live = g[r] != GID_NONE; (void)live;\n";
   for (int k = 0; k < n_nodes; k++) {
     const dfgpu_expr_node& nd = nodes[k];
@@ -794,14 +840,24 @@ dfgpu_status dfgpu_acc_update_batch_fused(dfgpu_ctx* ctx, dfgpu_acc* const* accs
       if (acc_nodes[i] < 0 || acc_nodes[i] >= n_nodes) fail(DFGPU_INVALID_ARGUMENT, "acc_update_batch_fused: accumulator %d has no argument node", i);
       if (a->cls != (dec ? CLS_I128 : CLS_F64)) fail(DFGPU_NOT_IMPLEMENTED, "acc_update_batch_fused: accumulator state class differs from the argument class");
     }
+    for (int k = 0; k < n_nodes; k++) if (nodes[k].op == DFGPU_NODE_COLUMN && ((uintptr_t)cols[nodes[k].lhs]->values->ptr & 15)) fail(DFGPU_NOT_IMPLEMENTED, "acc_update_batch_fused: column buffer not 16-byte aligned");
+    if (((uintptr_t)gids->values->ptr & 15) || (filt && ((uintptr_t)filt->values->ptr & 7))) fail(DFGPU_NOT_IMPLEMENTED, "acc_update_batch_fused: id / filter buffer alignment");
     for (int i = 0; i < n_accs; i++) acc_resize(accs[i], total);
     if (n == 0) return;
     const int R = dec ? 2 : 4;
     std::vector<int> vn;
-    std::string src = fused_source(dec, (int)total, R, filt != nullptr, nodes, n_nodes, info, cols, accs, acc_nodes, n_accs, &vn);
+    FusedDense fd; std::shared_ptr<DeferredIds> di = gids->deferred_ids;       // keeps the recipe's buffers alive over the launch
+    if (di) {       // the code tuple table must fit LDS and the code columns must take R-element vector loads
+      bool ok = di->dc.c[0].dict_len * (di->dc.n > 1 ? di->dc.c[1].dict_len : 1) <= FUSED_DENSE_TABLE;
+      for (int c = 0; c < di->dc.n; c++) ok = ok && (((uintptr_t)di->dc.c[c].keys) & 15) == 0;
+      if (!ok) { materialize_ids(ctx, gids); di.reset(); }
+    }
+    if (di) { fd.nk = di->dc.n; fd.kt = di->key_type; fd.len[0] = di->dc.c[0].dict_len; fd.len[1] = di->dc.n > 1 ? di->dc.c[1].dict_len : 1; fd.stride[0] = di->dc.c[0].stride; fd.stride[1] = di->dc.n > 1 ? di->dc.c[1].stride : 0; fd.has_mask = di->mask != nullptr; }
+    std::string src = fused_source(dec, (int)total, R, filt != nullptr, nodes, n_nodes, info, cols, accs, acc_nodes, n_accs, &vn, di ? &fd : nullptr);
     hipFunction_t fn = (hipFunction_t)jit_kernel(ctx, src, "dfgpu_fused_agg");
     FusedArgs fa{};
     for (int c = 0; c < n_cols; c++) fa.col[c] = cols[c] && cols[c]->values ? cols[c]->values->ptr : nullptr;
+    if (di) { for (int c = 0; c < di->dc.n; c++) { fa.kcode[c] = di->dc.c[c].keys; fa.canon[c] = di->dc.c[c].canon; } fa.dense_map = (const uint32_t*)di->dense_map->ptr; fa.gmask = di->mask ? (const uint64_t*)di->mask->ptr : nullptr; }
     fa.gids = (const uint32_t*)gids->values->ptr; fa.fbits = filt ? (const uint64_t*)filt->values->ptr : nullptr; fa.n = n; fa.flags = ctx->d_flags;
     for (int i = 0; i < n_accs; i++) { fa.vals[i] = accs[i]->vals ? accs[i]->vals->ptr : nullptr; fa.counts[i] = (uint64_t*)accs[i]->counts->ptr; fa.seen[i] = (uint8_t*)accs[i]->seen->ptr; }
     void* params[] = { &fa };
@@ -828,9 +884,12 @@ dfgpu_status dfgpu_jit_selftest(const char* arch, char* log, int64_t log_cap) {
         decimal_arith_plan(DFGPU_OP_MUL, 15, 2, info[3].p, info[3].s, &info[4].p, &info[4].s, &info[4].lmul, &info[4].rmul); }
       dfgpu_acc a0{}, a1{}, a2{}; a0.kind = DFGPU_AGG_SUM; a1.kind = DFGPU_AGG_AVG; a2.kind = DFGPU_AGG_COUNT;
       dfgpu_acc* accs[3] = { &a0, &a1, &a2 }; int32_t acc_nodes[3] = { 4, 0, -1 }; std::vector<int> vn;
-      std::string src = fused_source(dec != 0, 6, dec ? 2 : 4, true, nodes, 5, info, cols, accs, acc_nodes, 3, &vn);
-      std::string l;
-      if (!jit_compile_only(src, arch ? arch : "gfx950", &l)) { if (log && log_cap > 0) snprintf(log, (size_t)log_cap, "%s", l.c_str()); return DFGPU_INTERNAL; }
+      FusedDense fd; fd.nk = 2; fd.kt = DFGPU_INT8; fd.stride[0] = 3; fd.stride[1] = 1; fd.len[0] = 3; fd.len[1] = 2; fd.has_mask = true;
+      for (int dense = 0; dense < 2; dense++) {       // group ids from a stored column, and from two dictionary code columns
+        std::string src = fused_source(dec != 0, 6, dec ? 2 : 4, true, nodes, 5, info, cols, accs, acc_nodes, 3, &vn, dense ? &fd : nullptr);
+        std::string l;
+        if (!jit_compile_only(src, arch ? arch : "gfx950", &l)) { if (log && log_cap > 0) snprintf(log, (size_t)log_cap, "%s", l.c_str()); return DFGPU_INTERNAL; }
+      }
     }
   } catch (...) { if (log && log_cap > 0) snprintf(log, (size_t)log_cap, "kernel text generation failed"); return DFGPU_INTERNAL; }
   return DFGPU_OK;

@@ -114,6 +114,7 @@ uint64_t read_scratch(dfgpu_ctx* ctx, int slot) {
 void zero_scratch(dfgpu_ctx* ctx) { HIP_CHECK(hipMemsetAsync(ctx->d_scratch64, 0, 64 * 8, ctx->stream)); }
 
 ColView make_view(const dfgpu_array* a) {
+  if (a->deferred_ids) materialize_ids(a->ctx, a);     // deferred group ids handed to a kernel that reads them as a column
   ColView v{};
   const dfgpu_array* d = a;
   if (a->type == DFGPU_DICTIONARY) {
@@ -376,6 +377,7 @@ dfgpu_status dfgpu_array_describe(const dfgpu_array* a, dfgpu_array_desc* o) {
 dfgpu_status dfgpu_array_export_host(dfgpu_ctx* ctx, const dfgpu_array* a, void* values, uint8_t* validity, int32_t* offsets) {
   return guard(ctx, [&] {
     HIP_CHECK(hipSetDevice(ctx->device));
+    materialize_ids(ctx, a);
     flush_flags(ctx);                                   // data never leaves the device past a deferred kernel error
     int64_t n = a->length; int32_t vt = a->type == DFGPU_DICTIONARY ? a->key_type : a->type;
     size_t vbytes = a->type == DFGPU_UTF8 ? (size_t)a->values_bytes : (vt == DFGPU_BOOL ? (size_t)(n + 7) / 8 : (size_t)n * type_width(vt));

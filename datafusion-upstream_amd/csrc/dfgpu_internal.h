@@ -83,6 +83,7 @@ BufferPtr borrow_buffer(const void* ptr, size_t bytes);
 
 }  // namespace dfgpu
 
+namespace dfgpu { struct DeferredIds; }
 struct dfgpu_array {
   std::atomic<int64_t> refs{1};
   dfgpu_ctx* ctx = nullptr;
@@ -95,6 +96,9 @@ struct dfgpu_array {
   // host mirror of a length-1 array (scalar Datum) so kernels can take it by value
   bool has_host_scalar = false; unsigned char host_scalar[16] = {0}; bool host_scalar_valid = true;
   dfgpu_array_desc dict_desc{};        // storage for describe()
+  // group ids of dfgpu_groups_intern_deferred whose values are not written yet: the recipe that computes them (dense dictionary keys).
+  // The accumulator entry points either compute the ids inside their own pass or write them out first (materialize_ids).
+  std::shared_ptr<dfgpu::DeferredIds> deferred_ids;
 };
 
 namespace dfgpu {
@@ -144,6 +148,13 @@ ColView make_view(const dfgpu_array* a);
 
 constexpr int MAX_KEYS = 8;
 struct KeySet { int32_t n; ColView c[MAX_KEYS]; };
+// dense composite group map over dictionary key columns (groups.hip): code -> canonical id of the dictionary value -> sum(id * stride) -> map
+struct DenseCol { const void* keys; const uint64_t* key_valid; const uint32_t* canon; const uint64_t* dict_valid; int64_t dict_len; uint32_t n_ids, stride; int32_t key_type; };
+struct DenseCols { int32_t n; DenseCol c[MAX_KEYS]; };
+struct DeferredIds {
+  DenseCols dc{}; int32_t key_type = 0; BufferPtr mask, dense_map; std::vector<BufferPtr> keep;      // keep: code columns and canonical id tables
+};
+void materialize_ids(dfgpu_ctx* ctx, const dfgpu_array* ids);         // no-op for ordinary arrays
 KeySet make_keyset(const dfgpu_array* const* cols, int32_t n);
 
 // mask (BOOL array) -> effective selection bitmap words (values & validity), null if no mask

@@ -773,7 +773,7 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
           }
           gc.push_back(into_array(tc, e->eval(tc, b), b.base_rows)); gp.push_back(gc.back().a);
         }
-        dfgpu_array* ids = nullptr; tc.check(dfgpu_groups_intern(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids)); gids = ArrayRef::adopt(ids);
+        dfgpu_array* ids = nullptr; tc.check(dfgpu_groups_intern_deferred(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids)); gids = ArrayRef::adopt(ids);      // only the accumulators read them
         total = dfgpu_groups_len(groups.g);
       } else { dfgpu_array* z = nullptr; tc.check(dfgpu_array_new_zeros(tc.ctx, DFGPU_UINT32, 0, 0, b.base_rows, &z)); gids = ArrayRef::adopt(z); }
       if (!merging() && total <= 8 && fuse_min_rows >= 0 && b.base_rows >= fuse_min_rows && try_fused(tc, pj, raw, b, deferred, accs, gids, grouped ? ArrayRef() : mask, total)) continue;

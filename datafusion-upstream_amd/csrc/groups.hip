@@ -169,8 +169,6 @@ __global__ void __launch_bounds__(BLOCK) k_canon_lookup(const void* keys, int ke
 
 constexpr int DENSE_MAX = 4096;
 constexpr int DENSE_ROWS = 8;
-struct DenseCol { const void* keys; const uint64_t* key_valid; const uint32_t* canon; const uint64_t* dict_valid; int64_t dict_len; uint32_t n_ids, stride; int32_t key_type; };
-struct DenseCols { int32_t n; DenseCol c[MAX_KEYS]; };
 __device__ inline uint32_t dense_composite(const DenseCols& dc, int64_t i) {
   uint32_t comp = 0;
 #pragma unroll
@@ -250,6 +248,22 @@ __global__ void __launch_bounds__(BLOCK) k_dense_ids(DenseCols dc, int64_t n, co
   for (int r = 0; r < DENSE_ROWS; r++) { int64_t i = base + (int64_t)r * BLOCK + threadIdx.x; g[r] = (i < n && (mask == nullptr || bit_get(mask, i))) ? dense_map[dense_composite(dc, i)] : G_NONE; }
 #pragma unroll
   for (int r = 0; r < DENSE_ROWS; r++) { int64_t i = base + (int64_t)r * BLOCK + threadIdx.x; if (i < n) out[i] = g[r]; }
+}
+
+void materialize_ids(dfgpu_ctx* ctx, const dfgpu_array* ids_c) {
+  if (!ids_c || !ids_c->deferred_ids) return;
+  dfgpu_array* ids = const_cast<dfgpu_array*>(ids_c); std::shared_ptr<DeferredIds> d = ids->deferred_ids;
+  int64_t n = ids->length; const uint64_t* mk = d->mask ? (const uint64_t*)d->mask->ptr : nullptr;
+  dim3 grid(grid_for(n, BLOCK * DENSE_ROWS)), block(BLOCK);
+  KernelTimer kt_(ctx, "k_groups_dense");
+#define IDS(K, NC) do { if (mk) hipLaunchKernelGGL((k_dense_ids_fast<K, NC, true>), grid, block, 0, ctx->stream, d->dc, n, mk, (const uint32_t*)d->dense_map->ptr, (uint32_t*)ids->values->ptr); \
+                        else hipLaunchKernelGGL((k_dense_ids_fast<K, NC, false>), grid, block, 0, ctx->stream, d->dc, n, mk, (const uint32_t*)d->dense_map->ptr, (uint32_t*)ids->values->ptr); } while (0)
+  if (d->key_type == DFGPU_INT8) { if (d->dc.n == 1) IDS(int8_t, 1); else IDS(int8_t, 2); }
+  else if (d->key_type == DFGPU_INT16) { if (d->dc.n == 1) IDS(int16_t, 1); else IDS(int16_t, 2); }
+  else { if (d->dc.n == 1) IDS(int32_t, 1); else IDS(int32_t, 2); }
+#undef IDS
+  KERNEL_CHECK();
+  ids->deferred_ids.reset();
 }
 
 static void groups_alloc_table(dfgpu_groups* g, uint64_t cap) {
@@ -339,7 +353,14 @@ static bool groups_intern_runs(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_arra
   return true;
 }
 
+static dfgpu_status groups_intern_impl(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_array* const* cols, int32_t nkeys, const dfgpu_array* opt_mask, dfgpu_array** out_group_ids, bool allow_deferred);
 dfgpu_status dfgpu_groups_intern(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_array* const* cols, int32_t nkeys, const dfgpu_array* opt_mask, dfgpu_array** out_group_ids) {
+  return groups_intern_impl(ctx, g, cols, nkeys, opt_mask, out_group_ids, false);
+}
+dfgpu_status dfgpu_groups_intern_deferred(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_array* const* cols, int32_t nkeys, const dfgpu_array* opt_mask, dfgpu_array** out_group_ids) {
+  return groups_intern_impl(ctx, g, cols, nkeys, opt_mask, out_group_ids, true);
+}
+static dfgpu_status groups_intern_impl(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_array* const* cols, int32_t nkeys, const dfgpu_array* opt_mask, dfgpu_array** out_group_ids, bool allow_deferred) {
   return guard(ctx, [&] {
     if (!g || !cols || !out_group_ids) fail(DFGPU_INVALID_ARGUMENT, "groups_intern: null argument");
     if (nkeys != g->nkeys) fail(DFGPU_INVALID_ARGUMENT, "groups_intern: %d key columns given, %d expected", nkeys, g->nkeys);
@@ -440,7 +461,12 @@ dfgpu_status dfgpu_groups_intern(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_ar
           HIP_CHECK(hipStreamSynchronize(ctx->stream));               // rows / dense_host are host vectors
           groups_append_keys(ctx, g, cols, nkeys, firsts.get(), n_new);
         }
-        if (fast) DENSE_DISPATCH(k_dense_ids_fast, grid_for(n, BLOCK * DENSE_ROWS), dc, n, mk, (const uint32_t*)g->dense_map->ptr, (uint32_t*)ids.get()->values->ptr);
+        if (fast && allow_deferred) {       // the ids are a pure function of the code columns and the map: the consumer computes them in its own pass
+          auto d = std::make_shared<DeferredIds>(); d->dc = dc; d->key_type = kt0; d->mask = mask; d->dense_map = g->dense_map;
+          for (int c = 0; c < nkeys; c++) { d->keep.push_back(cols[c]->values); d->keep.push_back(g->canon[(size_t)c].ids); }
+          ids.get()->deferred_ids = d;
+        }
+        else if (fast) DENSE_DISPATCH(k_dense_ids_fast, grid_for(n, BLOCK * DENSE_ROWS), dc, n, mk, (const uint32_t*)g->dense_map->ptr, (uint32_t*)ids.get()->values->ptr);
         else hipLaunchKernelGGL(k_dense_ids, dim3(grid_for(n, BLOCK * DENSE_ROWS)), block, 0, ctx->stream, dc, n, mk, (const uint32_t*)g->dense_map->ptr, (uint32_t*)ids.get()->values->ptr);
 #undef DENSE_DISPATCH
 #undef DENSE_FAST

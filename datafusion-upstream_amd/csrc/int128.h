@@ -38,6 +38,8 @@ __device__ inline bool sub128_checked(i128 a, i128 b, i128* out) {
   *out = r; return true;
 }
 __device__ inline bool mul128_checked(i128 a, i128 b, i128* out) {
+  const long long al = (long long)a, bl = (long long)b;
+  if ((i128)al == a && (i128)bl == b) { *out = (i128)al * (i128)bl; return true; }      // both operands fit 64 bits: the product fits 128
   bool neg = (a < 0) != (b < 0);
   u128 ua = a < 0 ? (u128)0 - (u128)a : (u128)a, ub = b < 0 ? (u128)0 - (u128)b : (u128)b;
   uint64_t a0 = (uint64_t)ua, a1 = (uint64_t)(ua >> 64), b0 = (uint64_t)ub, b1 = (uint64_t)(ub >> 64);

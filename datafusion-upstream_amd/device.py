@@ -324,11 +324,15 @@ class GroupValues:
         except Exception:
             pass
 
-    def intern(self, cols: Sequence[Array], mask: Optional[Array] = None) -> Array:
+    def intern(self, cols: Sequence[Array], mask: Optional[Array] = None, deferred: bool = False) -> Array:
+        """`deferred`: dfgpu_groups_intern_deferred -- the ids may only be handed to accumulators (or exported), see include/dfgpu.h."""
         hs, n = capi.handle_array([a.h.value for a in cols])
         out = C.c_void_p()
-        self.ctx.check(self.ctx.lib.dfgpu_groups_intern(self.ctx.h, self.h, hs, n, mask.h if mask is not None else None, C.byref(out)))
-        return Array(self.ctx, out)
+        fn = self.ctx.lib.dfgpu_groups_intern_deferred if deferred else self.ctx.lib.dfgpu_groups_intern
+        self.ctx.check(fn(self.ctx.h, self.h, hs, n, mask.h if mask is not None else None, C.byref(out)))
+        a = Array(self.ctx, out)
+        a._keepalive = list(cols)
+        return a
 
     def __len__(self) -> int:
         return self.ctx.lib.dfgpu_groups_len(self.h)

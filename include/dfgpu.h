@@ -234,6 +234,13 @@ DFGPU_API void dfgpu_groups_free(dfgpu_groups *g);
  * form their own group.  opt_mask: rows not selected get id 0xFFFFFFFF and are skipped by accumulators. */
 DFGPU_API dfgpu_status dfgpu_groups_intern(dfgpu_ctx *ctx, dfgpu_groups *g, const dfgpu_array *const *cols, int32_t nkeys,
                                            const dfgpu_array *opt_mask, dfgpu_array **out_group_ids);
+/* Same call, but the ids may come back DEFERRED: when every key column is dictionary-encoded over a small composite domain (the dense
+ * map of dfgpu_groups_intern) the ids are a pure function of the code columns, and writing 4 B per row only for the accumulators to
+ * read them back is the largest avoidable transfer of a TPC-H Q1 style aggregate.  A deferred id array is valid ONLY as the group_ids
+ * argument of dfgpu_acc_update_batch / _multi / _fused / dfgpu_acc_merge_batch and of dfgpu_array_export_host (which write the ids
+ * out on demand; _fused computes them inside its pass); groups, ids and emitted keys are identical to dfgpu_groups_intern. */
+DFGPU_API dfgpu_status dfgpu_groups_intern_deferred(dfgpu_ctx *ctx, dfgpu_groups *g, const dfgpu_array *const *key_columns, int32_t nkeys,
+                                                    const dfgpu_array *opt_mask, dfgpu_array **out_group_ids);
 DFGPU_API int64_t dfgpu_groups_len(const dfgpu_groups *g);                   /* GroupValues::len */
 DFGPU_API int64_t dfgpu_groups_size(const dfgpu_groups *g);                  /* GroupValues::size (bytes) */
 /* ≙ GroupValues::emit(EmitTo::All) (primitive.rs:163-209): key columns in group id order. */

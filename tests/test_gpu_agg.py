@@ -373,3 +373,37 @@ def test_update_batch_fused_overflow_and_unsupported_shapes(ctx):
         with pytest.raises(dfgpu.DfgpuError) as e:
             dfgpu.GroupsAccumulator.update_batch_fused(ctx, *args)
         assert e.value.kind == "NotImplemented"
+
+
+@pytest.mark.parametrize("nkeys,masked", [(1, False), (2, True), (2, False)])
+def test_deferred_dense_group_ids_feed_accumulators_like_stored_ids(ctx, nkeys, masked):
+    """dfgpu_groups_intern_deferred over dictionary keys with a small composite domain hands back ids that are not written yet: the fused
+    accumulate pass computes them from the code columns, every other accumulator entry point (and export) writes them out first.  States
+    must equal those fed with dfgpu_groups_intern's stored ids, over two batches (the second one meets new groups)."""
+    import dfgpu
+    w1, w2 = pa.array(["A", "N", "R"], type=pa.utf8()), pa.array(["F", "O"], type=pa.utf8())
+    T = dfgpu.capi.FLOAT64
+    nodes = [("column", 0, 0), ("column", 1, 0), ("scalar", 2, 0), ("-", 2, 1), ("*", 0, 3)]
+    mk = lambda: [dfgpu.GroupsAccumulator(ctx, KIND["SUM"], T), dfgpu.GroupsAccumulator(ctx, KIND["AVG"], T), dfgpu.GroupsAccumulator(ctx, KIND["COUNT"], dfgpu.capi.INT64)]
+    gv = {k: dfgpu.GroupValues(ctx, nkeys) for k in ("stored", "fused", "multi", "export")}
+    accs = {k: mk() for k in ("stored", "fused", "multi")}
+    for n, hi1 in ((40001, 2), (9000, 3)):
+        c1 = pa.DictionaryArray.from_arrays(pa.array(RNG.integers(0, hi1, n).astype(np.int8)), w1)
+        c2 = pa.DictionaryArray.from_arrays(pa.array(RNG.integers(0, 2, n).astype(np.int8)), w2)
+        keys = [ctx.from_arrow(c1), ctx.from_arrow(c2)][:nkeys]
+        mask = ctx.from_arrow(pa.array(RNG.random(n) < 0.6)) if masked else None
+        x, y, one = ctx.from_arrow(pa.array(RNG.normal(size=n))), ctx.from_arrow(pa.array(RNG.random(n))), ctx.from_arrow(pa.array([1.0]))
+        ids = gv["stored"].intern(keys, mask)
+        assert np.array_equal(gv["export"].intern(keys, mask, deferred=True).to_numpy(), ids.to_numpy())
+        total = len(gv["stored"])
+        dfgpu.GroupsAccumulator.update_batch_fused(ctx, accs["stored"], [4, 1, -1], nodes, [x, y, one], ids, None, total)
+        dfgpu.GroupsAccumulator.update_batch_fused(ctx, accs["fused"], [4, 1, -1], nodes, [x, y, one], gv["fused"].intern(keys, mask, deferred=True), None, total)
+        price = ctx.binary(2, x, ctx.binary(1, one, y, lhs_scalar=True))
+        dfgpu.GroupsAccumulator.update_batch_multi(ctx, accs["multi"], [price, y, None], [None] * 3, gv["multi"].intern(keys, mask, deferred=True), total)
+        assert len(gv["fused"]) == len(gv["multi"]) == total
+    for k in ("fused", "multi"):
+        for a, b in zip(accs[k], accs["stored"]):
+            for s1, s2 in zip(a.state(), b.state()):
+                check_equal(s1.to_arrow(), s2.to_arrow(), True)
+    for a, b in zip(gv["fused"].emit(), gv["stored"].emit()):
+        assert a.to_arrow().equals(b.to_arrow())
