@@ -285,8 +285,11 @@ __global__ void __launch_bounds__(BLOCK) k_acc_update_add(int kind, ColView v, i
 // ADD_ROWS slabs of 64 rows per wave whose loads are all issued up front, unconditionally (rows past the end re-read the last row and
 // are dropped by their group id): the general kernel's one conditional row per lane per iteration leaves HBM latency exposed.
 constexpr int ADD_ROWS = 4;
-template <typename T, int CLS, bool HAS_VALUES>
-__global__ void __launch_bounds__(BLOCK) k_acc_add_plain(int kind, const T* values, const uint32_t* gids, int64_t n, int64_t total, void* vals, uint64_t* counts, uint8_t* seen, uint32_t* flags) {
+// RUNS: the ids are run numbers that were never written out (DeferredIds kind 1): row i's id = base + prefix[i / 64] + popcount of the
+// head bits up to i -- one 8-B word and one 4-B prefix per 64-row slab instead of 4 B per row.
+struct RunIds { const uint64_t* heads; const uint32_t* prefix; uint32_t base; };
+template <typename T, int CLS, bool HAS_VALUES, bool RUNS>
+__global__ void __launch_bounds__(BLOCK) k_acc_add_plain(int kind, const T* values, const uint32_t* gids, RunIds ri, int64_t n, int64_t total, void* vals, uint64_t* counts, uint8_t* seen, uint32_t* flags) {
   int lane = lane_id();
   int64_t base = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * (WAVE * ADD_ROWS);
   if (base >= n) return;                                             // wave-uniform
@@ -294,7 +297,9 @@ __global__ void __launch_bounds__(BLOCK) k_acc_add_plain(int kind, const T* valu
 #pragma unroll
   for (int r = 0; r < ADD_ROWS; r++) {
     int64_t i = base + r * WAVE + lane, ic = i < n ? i : n - 1;
-    gs[r] = gids[ic]; if constexpr (HAS_VALUES) xs[r] = values[ic]; else xs[r] = (T)0;
+    if constexpr (RUNS) { int64_t w = ic >> 6; gs[r] = ri.base + ri.prefix[w] + (uint32_t)__popcll(ri.heads[w] & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull))) - 1u; }      // base is a multiple of 64: bit = lane
+    else gs[r] = gids[ic];
+    if constexpr (HAS_VALUES) xs[r] = values[ic]; else xs[r] = (T)0;
     if (i >= n) gs[r] = GID_NONE;
   }
 #pragma unroll
@@ -464,7 +469,17 @@ static void acc_resize(dfgpu_acc* a, int64_t total) {
 static void launch_update(dfgpu_acc* a, int kind, int cls, const dfgpu_array* values, const dfgpu_array* gids, const dfgpu_array* filt, int64_t total, void* vals) {
   dfgpu_ctx* ctx = a->ctx; int64_t n = gids->length;
   if (gids->type != DFGPU_UINT32) fail(DFGPU_INVALID_ARGUMENT, "group ids must be a UINT32 array");
-  materialize_ids(ctx, gids);
+  // run numbers that were never written out are derived inside the plain accumulate kernel; every other kernel reads stored ids
+  std::shared_ptr<DeferredIds> runs = gids->deferred_ids && gids->deferred_ids->kind == 1 ? gids->deferred_ids : nullptr;
+  {
+    bool sl = kind == DFGPU_AGG_SUM || kind == DFGPU_AGG_AVG || kind == DFGPU_AGG_COUNT;
+    bool plain = sl && !filt && total > SMALL_G && n < 8 * total &&
+                 (kind == DFGPU_AGG_COUNT ? (!values || !values->validity)
+                                          : (values && !values->validity && values->type == (cls == CLS_I128 ? DFGPU_DECIMAL128 : cls == CLS_F64 ? DFGPU_FLOAT64 : values->type) &&
+                                             (cls == CLS_I128 || cls == CLS_F64 || values->type == DFGPU_INT64 || values->type == DFGPU_UINT64)));
+    if (!plain) runs.reset();
+    if (!runs) materialize_ids(ctx, gids);
+  }
   if (values && values->length != n) fail(DFGPU_INVALID_ARGUMENT, "values (%lld rows) and group ids (%lld rows) differ in length", (long long)values->length, (long long)n);
   if (filt && (filt->type != DFGPU_BOOL || filt->length != n)) fail(DFGPU_INVALID_ARGUMENT, "opt_filter must be a Boolean array of the batch length");
   if (!n) return;
@@ -490,8 +505,10 @@ static void launch_update(dfgpu_acc* a, int kind, int cls, const dfgpu_array* va
                                      (cls == CLS_I128 || cls == CLS_F64 || values->type == DFGPU_INT64 || values->type == DFGPU_UINT64)))) {
     int pblocks = grid_for(n, BLOCK * ADD_ROWS);
     const void* vp = kind == DFGPU_AGG_COUNT ? nullptr : values->values->ptr;
-#define PLAIN(T, C, HV) hipLaunchKernelGGL((k_acc_add_plain<T, C, HV>), dim3(pblocks), dim3(BLOCK), 0, ctx->stream, kind, (const T*)vp, g, n, total, vals, (uint64_t*)a->counts->ptr, (uint8_t*)a->seen->ptr, ctx->d_flags)
-    if (kind == DFGPU_AGG_COUNT) PLAIN(unsigned long long, CLS_U64, false); else if (cls == CLS_F64) PLAIN(double, CLS_F64, true); else if (cls == CLS_I128) PLAIN(i128, CLS_I128, true); else PLAIN(unsigned long long, CLS_U64, true);
+    RunIds ri{}; if (runs) { ri.heads = (const uint64_t*)runs->heads->ptr; ri.prefix = (const uint32_t*)runs->prefix->ptr; ri.base = runs->base; }
+#define PLAIN(T, C, HV) do { if (runs) hipLaunchKernelGGL((k_acc_add_plain<T, C, HV, true>), dim3(pblocks), dim3(BLOCK), 0, ctx->stream, kind, (const T*)vp, g, ri, n, total, vals, (uint64_t*)a->counts->ptr, (uint8_t*)a->seen->ptr, ctx->d_flags); \
+                             else hipLaunchKernelGGL((k_acc_add_plain<T, C, HV, false>), dim3(pblocks), dim3(BLOCK), 0, ctx->stream, kind, (const T*)vp, g, ri, n, total, vals, (uint64_t*)a->counts->ptr, (uint8_t*)a->seen->ptr, ctx->d_flags); } while (0)
+    if (kind == DFGPU_AGG_COUNT) { PLAIN(unsigned long long, CLS_U64, false); } else if (cls == CLS_F64) { PLAIN(double, CLS_F64, true); } else if (cls == CLS_I128) { PLAIN(i128, CLS_I128, true); } else { PLAIN(unsigned long long, CLS_U64, true); }
 #undef PLAIN
   } else if (sumlike) {
 #define ADD(T, C) hipLaunchKernelGGL((k_acc_update_add<T, C>), dim3(blocks), dim3(BLOCK), 0, ctx->stream, kind, v, values ? 1 : 0, g, fb, fv, n, total, vals, (uint64_t*)a->counts->ptr, (uint8_t*)a->seen->ptr, 1, ctx->d_flags)
@@ -847,6 +864,7 @@ dfgpu_status dfgpu_acc_update_batch_fused(dfgpu_ctx* ctx, dfgpu_acc* const* accs
     const int R = dec ? 2 : 4;
     std::vector<int> vn;
     FusedDense fd; std::shared_ptr<DeferredIds> di = gids->deferred_ids;       // keeps the recipe's buffers alive over the launch
+    if (di && di->kind != 0) { materialize_ids(ctx, gids); di.reset(); }
     if (di) {       // the code tuple table must fit LDS and the code columns must take R-element vector loads
       bool ok = di->dc.c[0].dict_len * (di->dc.n > 1 ? di->dc.c[1].dict_len : 1) <= FUSED_DENSE_TABLE;
       for (int c = 0; c < di->dc.n; c++) ok = ok && (((uintptr_t)di->dc.c[c].keys) & 15) == 0;

@@ -152,7 +152,9 @@ struct KeySet { int32_t n; ColView c[MAX_KEYS]; };
 struct DenseCol { const void* keys; const uint64_t* key_valid; const uint32_t* canon; const uint64_t* dict_valid; int64_t dict_len; uint32_t n_ids, stride; int32_t key_type; };
 struct DenseCols { int32_t n; DenseCol c[MAX_KEYS]; };
 struct DeferredIds {
+  int kind = 0;          // 0: dense dictionary keys (dc, dense_map); 1: run numbers of a clustered batch (heads, prefix, base)
   DenseCols dc{}; int32_t key_type = 0; BufferPtr mask, dense_map; std::vector<BufferPtr> keep;      // keep: code columns and canonical id tables
+  BufferPtr heads, prefix; uint32_t base = 0;          // id of row i = base + prefix[i / 64] + popcount(heads[i / 64] up to bit i % 64) - 1
 };
 void materialize_ids(dfgpu_ctx* ctx, const dfgpu_array* ids);         // no-op for ordinary arrays
 KeySet make_keyset(const dfgpu_array* const* cols, int32_t n);

@@ -254,6 +254,11 @@ void materialize_ids(dfgpu_ctx* ctx, const dfgpu_array* ids_c) {
   if (!ids_c || !ids_c->deferred_ids) return;
   dfgpu_array* ids = const_cast<dfgpu_array*>(ids_c); std::shared_ptr<DeferredIds> d = ids->deferred_ids;
   int64_t n = ids->length; const uint64_t* mk = d->mask ? (const uint64_t*)d->mask->ptr : nullptr;
+  if (d->kind == 1) {
+    KernelTimer kt_(ctx, "k_groups_runs");
+    hipLaunchKernelGGL(k_run_ids, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)d->heads->ptr, (const uint32_t*)d->prefix->ptr, n, d->base, (uint32_t*)ids->values->ptr);
+    KERNEL_CHECK(); ids->deferred_ids.reset(); return;
+  }
   dim3 grid(grid_for(n, BLOCK * DENSE_ROWS)), block(BLOCK);
   KernelTimer kt_(ctx, "k_groups_dense");
 #define IDS(K, NC) do { if (mk) hipLaunchKernelGGL((k_dense_ids_fast<K, NC, true>), grid, block, 0, ctx->stream, d->dc, n, mk, (const uint32_t*)d->dense_map->ptr, (uint32_t*)ids->values->ptr); \
@@ -323,7 +328,7 @@ static bool run_key_type(const dfgpu_array* a) {
   switch (a->type) { case DFGPU_INT8: case DFGPU_INT16: case DFGPU_INT32: case DFGPU_INT64: case DFGPU_DATE32: case DFGPU_UINT8: case DFGPU_UINT16: case DFGPU_UINT32: case DFGPU_UINT64: return true; default: return false; }
 }
 // Clustered batch -> ids by run number.  Returns false (nothing changed) when the batch is not clustered.
-static bool groups_intern_runs(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_array* const* cols, int32_t nkeys, const KeySet& bk, int64_t n, dfgpu_array* ids) {
+static bool groups_intern_runs(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_array* const* cols, int32_t nkeys, const KeySet& bk, int64_t n, dfgpu_array* ids, bool allow_deferred) {
   const dfgpu_array* k0 = cols[0];
   if (g->n_groups && logical_type(k0) != g->keys[0]->type) return false;
   KernelTimer kt_(ctx, "k_groups_runs");
@@ -346,7 +351,9 @@ static bool groups_intern_runs(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_arra
   BufferPtr prefix = alloc_buffer(ctx, (size_t)nw * 4);
   hipLaunchKernelGGL(k_popc_words_g, dim3(grid_for(nw, BLOCK)), block, 0, ctx->stream, (const uint64_t*)heads->ptr, nw, (uint32_t*)prefix->ptr);
   exclusive_scan_u32_inplace32(ctx, (uint32_t*)prefix->ptr, nw, nullptr);
-  hipLaunchKernelGGL(k_run_ids, grid, block, 0, ctx->stream, (const uint64_t*)heads->ptr, (const uint32_t*)prefix->ptr, n, (uint32_t)g->n_groups, (uint32_t*)ids->values->ptr);
+  if (allow_deferred && n >= (1 << 20)) {      // the run number of a row is a popcount away from the head bits: the accumulate pass derives it
+    auto d = std::make_shared<DeferredIds>(); d->kind = 1; d->heads = heads; d->prefix = prefix; d->base = (uint32_t)g->n_groups; ids->deferred_ids = d;
+  } else hipLaunchKernelGGL(k_run_ids, grid, block, 0, ctx->stream, (const uint64_t*)heads->ptr, (const uint32_t*)prefix->ptr, n, (uint32_t)g->n_groups, (uint32_t*)ids->values->ptr);
   KERNEL_CHECK();
   if (n_new) groups_append_keys(ctx, g, cols, nkeys, firsts.get(), n_new);
   g->n_groups += n_new; g->run_mode = true;
@@ -373,7 +380,7 @@ static dfgpu_status groups_intern_impl(dfgpu_ctx* ctx, dfgpu_groups* g, const df
     if (n == 0) { *out_group_ids = ids.release(); return; }
     // clustered keys: group ids are run numbers, no hash table (the shape of GROUP BY over a fact table stored in key order)
     if (ctx->group_run_detection && !ctx->force_hash_collisions && !mask && g->capacity == 0 && (g->n_groups == 0 || g->run_mode) && run_key_type(cols[0]) &&
-        groups_intern_runs(ctx, g, cols, nkeys, bk, n, ids.get())) { *out_group_ids = ids.release(); return; }
+        groups_intern_runs(ctx, g, cols, nkeys, bk, n, ids.get(), allow_deferred)) { *out_group_ids = ids.release(); return; }
     if (g->run_mode) {          // a batch broke the order: hash the groups numbered so far, the table is built below
       std::vector<const dfgpu_array*> sk(g->keys.begin(), g->keys.end()); KeySet stored_ks = make_keyset(sk.data(), nkeys);
       groups_reserve_ghash(ctx, g, g->n_groups, 0);

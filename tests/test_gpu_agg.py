@@ -407,3 +407,31 @@ def test_deferred_dense_group_ids_feed_accumulators_like_stored_ids(ctx, nkeys, 
                 check_equal(s1.to_arrow(), s2.to_arrow(), True)
     for a, b in zip(gv["fused"].emit(), gv["stored"].emit()):
         assert a.to_arrow().equals(b.to_arrow())
+
+
+def test_deferred_run_number_ids_feed_accumulators_like_stored_ids(ctx):
+    """A clustered batch of >= 2^20 rows interned through dfgpu_groups_intern_deferred hands back run numbers that are not written yet:
+    the plain SUM / AVG / COUNT pass derives them from the run-head bits, MIN (another kernel) and export write them out first."""
+    import dfgpu
+    n = (1 << 20) + 4321
+    keys = np.repeat(np.arange(n // 3 + 1, dtype=np.int64) * 7, 3)[:n]
+    kd = ctx.from_arrow(pa.array(keys))
+    x = pa.array(RNG.normal(size=n))
+    d = pa.array([decimal.Decimal(int(v)).scaleb(-2) for v in RNG.integers(-10**9, 10**9, 4096)] * (n // 4096 + 1), type=pa.decimal128(15, 2)).slice(0, n)
+    xd, dd = ctx.from_arrow(x), ctx.from_arrow(d)
+    spec = [("SUM", xd, dfgpu.capi.FLOAT64, 0, 0), ("AVG", dd, dfgpu.capi.DECIMAL128, 15, 2), ("COUNT", None, dfgpu.capi.INT64, 0, 0), ("MIN", xd, dfgpu.capi.FLOAT64, 0, 0), ("SUM", dd, dfgpu.capi.DECIMAL128, 15, 2)]
+    out = {}
+    for deferred in (False, True):
+        gv = dfgpu.GroupValues(ctx, 1)
+        accs = [dfgpu.GroupsAccumulator(ctx, KIND[f], t, p, s) for f, _, t, p, s in spec]
+        if deferred:
+            assert np.array_equal(dfgpu.GroupValues(ctx, 1).intern([kd], deferred=True).to_numpy(), out["ids"])
+        ids = gv.intern([kd], deferred=deferred)
+        for a, (f, v, _, _, _) in zip(accs, spec):
+            a.update_batch(v, ids, None, len(gv))
+        if not deferred:
+            out["ids"] = ids.to_numpy()
+            assert np.array_equal(out["ids"], np.arange(n) // 3)
+        out[deferred] = [a.evaluate().to_arrow() for a in accs]
+    for (f, _, t, _, _), a, b in zip(spec, out[True], out[False]):
+        check_equal(a, b, t == dfgpu.capi.FLOAT64 and f != "MIN")
