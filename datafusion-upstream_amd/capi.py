@@ -96,6 +96,7 @@ PROTOTYPES = {
     "dfgpu_array_export_arrow": (C.c_int32, [_P, _P, C.POINTER(ArrowArray), C.POINTER(ArrowSchema)]),
     "dfgpu_array_retain": (None, [_P]),
     "dfgpu_array_release": (None, [_P]),
+    "dfgpu_array_is_identity": (C.c_int32, [_P]),
     "dfgpu_array_length": (C.c_int64, [_P]),
     "dfgpu_array_null_count": (C.c_int64, [_P, _P]),
     "dfgpu_array_slice": (C.c_int32, [_P, _P, C.c_int64, C.c_int64, _PP]),

@@ -392,6 +392,7 @@ void dfgpu_array_release(dfgpu_array* a) {
   if (!a) return;
   if (a->refs.fetch_sub(1) == 1) { if (a->dictionary) dfgpu_array_release(a->dictionary); delete a; }
 }
+int32_t dfgpu_array_is_identity(const dfgpu_array* a) { return a && a->identity ? 1 : 0; }
 int64_t dfgpu_array_length(const dfgpu_array* a) { return a ? a->length : 0; }
 int64_t dfgpu_array_null_count(dfgpu_ctx* ctx, const dfgpu_array* a) {
   if (!a) return 0;

@@ -99,6 +99,9 @@ struct dfgpu_array {
   // group ids of dfgpu_groups_intern_deferred whose values are not written yet: the recipe that computes them (dense dictionary keys).
   // The accumulator entry points either compute the ids inside their own pass or write them out first (materialize_ids).
   std::shared_ptr<dfgpu::DeferredIds> deferred_ids;
+  // an index array known to be 0, 1, .., length - 1 (a compaction that kept every row, the probe indices of a join whose probe rows
+  // all matched once): gathering through it is the identity
+  bool identity = false;
 };
 
 namespace dfgpu {

@@ -78,7 +78,7 @@ struct TakeMemo { std::map<std::pair<const dfgpu_array*, const dfgpu_array*>, Co
 using MemoPtr = std::shared_ptr<TakeMemo>;
 struct Col {
   ArrayRef arr, source; std::vector<ArrayRef> chain; MemoPtr memo;
-  int64_t len() const { return arr ? arr.len() : chain.back().len(); }
+  int64_t len() const { return arr ? arr.len() : chain.empty() ? 0 : chain.back().len(); }
 };
 static ArrayRef take(const TaskContext& tc, const ArrayRef& v, const ArrayRef& idx) { dfgpu_array* o = nullptr; tc.check(dfgpu_take(tc.ctx, v.a, idx.a, &o)); return ArrayRef::adopt(o); }
 static const ArrayRef& col_indices(const TaskContext& tc, Col& c) {           // the chain as one index array into c.source
@@ -99,6 +99,7 @@ static const ArrayRef& col_get(const TaskContext& tc, Col& c) {
   return c.arr;
 }
 static Col col_take(const Col& c, const ArrayRef& idx, const MemoPtr& memo = nullptr) {
+  if (dfgpu_array_is_identity(idx.a) && idx.len() == c.len()) return c;          // every row, in order: the column itself
   Col o; o.memo = memo;
   if (c.arr) { o.source = c.arr; o.chain.push_back(idx); return o; }
   o.source = c.source; o.chain = c.chain; o.chain.push_back(idx);

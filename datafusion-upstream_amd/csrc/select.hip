@@ -167,6 +167,7 @@ dfgpu_array* mask_to_indices_impl(dfgpu_ctx* ctx, const uint64_t* bits, int64_t 
   int64_t total = (int64_t)read_scratch(ctx, 60);
   ArrayHolder h(new_fixed(ctx, DFGPU_UINT32, total));
   if (total) hipLaunchKernelGGL(k_sel_write, dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream, bits, n, (const uint32_t*)counts->ptr, (uint32_t*)h.get()->values->ptr);
+  h.get()->identity = total == n;                        // every row selected: the selection vector is 0 .. n-1
   KERNEL_CHECK();
   return h.release();
 }
@@ -181,6 +182,7 @@ dfgpu_status dfgpu_take(dfgpu_ctx* ctx, const dfgpu_array* values, const dfgpu_a
     if (!values || !indices || !out) fail(DFGPU_INVALID_ARGUMENT, "take: null argument");
     int w = indices->type == DFGPU_UINT32 || indices->type == DFGPU_INT32 ? 4 : (indices->type == DFGPU_UINT64 || indices->type == DFGPU_INT64 ? 8 : 0);
     if (!w) fail(DFGPU_INVALID_ARGUMENT, "take: indices must be 32/64-bit integers");
+    if (indices->identity && indices->length == values->length) { dfgpu_array_retain(const_cast<dfgpu_array*>(values)); *out = const_cast<dfgpu_array*>(values); return; }      // arrays are immutable: share
     *out = take_impl(ctx, values, indices->values->ptr, w, indices->validity ? (const uint64_t*)indices->validity->ptr : nullptr, indices->length);
     check_flags(ctx, "take");
   });

@@ -139,6 +139,10 @@ DFGPU_API dfgpu_status dfgpu_array_export_arrow(dfgpu_ctx *ctx, const dfgpu_arra
 DFGPU_API void dfgpu_array_retain(dfgpu_array *a);
 DFGPU_API void dfgpu_array_release(dfgpu_array *a);
 DFGPU_API int64_t dfgpu_array_length(const dfgpu_array *a);
+/* 1 when the array is an index array KNOWN to be 0, 1, .., length - 1 (dfgpu_mask_to_indices over a mask that keeps every row; the probe
+ * indices of dfgpu_join_probe when every probe row matched exactly once): dfgpu_take through it returns the values array itself, and
+ * a caller composing gathers can skip it.  0 says nothing (the array may still happen to be the identity). */
+DFGPU_API int32_t dfgpu_array_is_identity(const dfgpu_array *a);
 DFGPU_API int64_t dfgpu_array_null_count(dfgpu_ctx *ctx, const dfgpu_array *a);   /* computes if unknown */
 /* RecordBatch::slice: zero copy when offset % 64 == 0 (batch_size 8192 chunks), otherwise a copy. */
 DFGPU_API dfgpu_status dfgpu_array_slice(dfgpu_ctx *ctx, const dfgpu_array *a, int64_t offset, int64_t length, dfgpu_array **out);

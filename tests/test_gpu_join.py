@@ -311,3 +311,35 @@ def test_sparse_small_build_gets_its_bitmap_from_the_first_large_probe(ctx, dups
     probe(1000)
     probe(400_000)
     probe(1000)
+
+
+def test_identity_index_arrays_are_recognised_and_skipped(ctx, task_ctx):
+    """A compaction that keeps every row and the probe indices of a join whose probe rows all match once are 0 .. n-1: the producer marks
+    them (dfgpu_array_is_identity), dfgpu_take through them hands back the values array, and the plan layer passes probe-side columns
+    through instead of gathering them.  Results are unchanged (oracle), a selective probe is not marked."""
+    import dfgpu
+    from dfgpu import physical_plan as ops
+    lib = ctx.lib
+    n = 5000
+    all_true = ctx.mask_to_indices(ctx.from_arrow(pa.array(np.ones(n, dtype=bool))))
+    some = ctx.mask_to_indices(ctx.from_arrow(pa.array(np.arange(n) % 7 != 0)))
+    assert lib.dfgpu_array_is_identity(all_true.h) == 1 and lib.dfgpu_array_is_identity(some.h) == 0
+    vals = pa.array(RNG.integers(0, 10**6, n), mask=RNG.random(n) < 0.1)
+    assert ctx.take(ctx.from_arrow(vals), all_true).to_arrow().equals(vals)
+    bk = np.arange(0, 3 * 400, 3, dtype=np.int64)
+    table = dfgpu.JoinTable(ctx, [ctx.from_arrow(pa.array(bk))])
+    pk_all, pk_some = RNG.choice(bk, n), RNG.integers(0, 1200, n).astype(np.int64)
+    _, pi = table.probe([ctx.from_arrow(pa.array(pk_all))])
+    assert lib.dfgpu_array_is_identity(pi.h) == 1 and np.array_equal(pi.to_numpy(), np.arange(n))
+    _, pi = table.probe([ctx.from_arrow(pa.array(pk_some))])
+    assert lib.dfgpu_array_is_identity(pi.h) == 0
+    lt = pa.table({"k": pa.array(bk), "v": pa.array(RNG.integers(0, 100, len(bk)))})
+    rt = pa.table({"k": pa.array(pk_all), "w": pa.array(RNG.integers(0, 100, n)), "s": pa.array([f"row{i}" for i in range(n)])})
+    mk = lambda t: ops.MemoryExec([[ops.batch_from_arrow(ctx, t)]], ops.batch_from_arrow(ctx, t).schema)
+    join = ops.HashJoinExec(mk(lt), mk(rt), [(ops.Column("k", 0), ops.Column("k", 0))], None, "Inner")
+    got = []
+    for b in ops.collect(ops.FilterExec(ops.BinaryExpr(ops.Column("w", 3), ">=", ops.Literal(0, pa.int64())), join), task_ctx):      # a filter that keeps every row on top
+        got += rows_of([c.to_arrow() for c in b.columns])
+    res = po.hash_join([[lt["k"]]], [[rt["k"]]], "Inner", batch_size=1 << 40)
+    want = [[lt["k"][int(bi)].as_py(), lt["v"][int(bi)].as_py(), rt["k"][int(p)].as_py(), rt["w"][int(p)].as_py(), rt["s"][int(p)].as_py()] for bi, p in zip(res.build_idx, res.probe_idx)]
+    assert got == want
