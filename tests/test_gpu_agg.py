@@ -435,3 +435,54 @@ def test_deferred_run_number_ids_feed_accumulators_like_stored_ids(ctx):
         out[deferred] = [a.evaluate().to_arrow() for a in accs]
     for (f, _, t, _, _), a, b in zip(spec, out[True], out[False]):
         check_equal(a, b, t == dfgpu.capi.FLOAT64 and f != "MIN")
+
+
+@pytest.mark.parametrize("money", ["float64", "decimal"])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_update_batch_fused_random_expression_dags(ctx, money, seed):
+    """Random + - * trees over four columns and two literals (either operand side, shared subtrees, a bare column, a bare product): the
+    generated kernel must agree with dfgpu_binary node by node -- bit-exact for Decimal128 (result types and checked arithmetic of every
+    node included: an overflow must be raised by both or by neither), 1e-9 relative for Float64."""
+    import dfgpu
+    rng = np.random.default_rng(100 + seed)
+    n, G = 30011, 5
+    if money == "decimal":
+        mk = lambda: pa.array([decimal.Decimal(int(v)).scaleb(-2) for v in rng.integers(-5000, 5000, n)], type=pa.decimal128(9, 2))
+        lits = [pa.array([decimal.Decimal(1)], type=pa.decimal128(20, 0)), pa.array([decimal.Decimal("2.5")], type=pa.decimal128(3, 1))]
+        T = dfgpu.capi.DECIMAL128
+    else:
+        mk = lambda: pa.array(rng.normal(size=n) * 10)
+        lits = [pa.array([1.0]), pa.array([-0.25])]
+        T = dfgpu.capi.FLOAT64
+    host = [mk() for _ in range(4)] + lits
+    cols = [ctx.from_arrow(a) for a in host]
+    nodes = [("column", c, 0) for c in range(4)] + [("scalar", 4, 0), ("scalar", 5, 0)]
+    arrays = list(cols)                               # node index -> evaluated array (node by node)
+    is_scalar = [False] * 4 + [True, True]
+    ops_code = {"+": 0, "-": 1, "*": 2}
+    depth = [0] * 6
+    for _ in range(7):
+        while True:
+            l, r = int(rng.integers(0, len(nodes))), int(rng.integers(0, len(nodes)))
+            if not (is_scalar[l] and is_scalar[r]) and depth[l] + depth[r] <= 3:
+                break
+        op = "+-*"[int(rng.integers(0, 3))]
+        if money == "decimal" and op == "*" and (depth[l] > 1 or depth[r] > 1):
+            op = "+"                                  # keep the scale of nested products inside 38 digits
+        nodes.append((op, l, r)); depth.append(max(depth[l], depth[r]) + (2 if op == "*" else 1)); is_scalar.append(False)
+        arrays.append(ctx.binary(ops_code[op], arrays[l], arrays[r], lhs_scalar=is_scalar[l], rhs_scalar=is_scalar[r]))
+    picks = [0, len(nodes) - 1, len(nodes) - 2, len(nodes) - 4, len(nodes) - 1]
+    kinds = ["SUM", "SUM", "AVG", "SUM", "AVG"]
+    def accs():
+        out = []
+        for k, nd in zip(kinds, picks):
+            f = dfgpu.operators.field_of_array("v", arrays[nd])
+            out.append(dfgpu.GroupsAccumulator(ctx, KIND[k], T, f.precision, f.scale))
+        return out + [dfgpu.GroupsAccumulator(ctx, KIND["COUNT"], dfgpu.capi.INT64)]
+    g = rng.integers(0, G, n).astype(np.uint32); g[rng.random(n) < 0.1] = 0xFFFFFFFF
+    gd = ctx.from_arrow(pa.array(g))
+    fused, plain = accs(), accs()
+    dfgpu.GroupsAccumulator.update_batch_fused(ctx, fused, picks + [-1], nodes, cols, gd, None, G)
+    dfgpu.GroupsAccumulator.update_batch_multi(ctx, plain, [arrays[nd] for nd in picks] + [None], [None] * 6, gd, G)
+    for a, b in zip(fused, plain):
+        check_equal(a.evaluate().to_arrow(), b.evaluate().to_arrow(), money == "float64")
