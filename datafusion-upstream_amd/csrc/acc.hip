@@ -315,7 +315,10 @@ __global__ void __launch_bounds__(BLOCK) k_acc_add_plain(int kind, const T* valu
     if (hm != ~0ull) {
       int start = 63 - __clzll((long long)(hm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull))));
 #pragma unroll
-      for (int d = 1; d < WAVE; d <<= 1) { T ox = shfl_up_any<T>(x, d); uint32_t oc = __shfl_up(c, d, 64); if (lane - d >= start) { x += ox; c += oc; } }
+      for (int d = 1; d < WAVE; d <<= 1) {
+        if (ballot64(lane - d >= start) == 0) break;                 // every run of the slab is shorter than d lanes (wave-uniform): short runs stop early
+        T ox = shfl_up_any<T>(x, d); uint32_t oc = __shfl_up(c, d, 64); if (lane - d >= start) { x += ox; c += oc; }
+      }
     }
     uint32_t gn = __shfl_down(g, 1, 64); int an = __shfl_down((int)act, 1, 64);
     bool tail = act && (lane == 63 || !an || gn != g);
