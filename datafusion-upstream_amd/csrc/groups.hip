@@ -142,6 +142,32 @@ __global__ void __launch_bounds__(BLOCK) k_run_heads(KeySet bk, int64_t n, const
   if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) heads[i >> 6] = m;
   if (ballot64(wrong) && lane_id() == 0) *bad = 1ull;
 }
+// single key column: 4 slabs of 64 rows per wave, every key loaded once and unconditionally (the neighbour comes from the lane below)
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_run_heads1(const T* k0, int64_t n, const T* prev, uint64_t* heads, unsigned long long* bad) {
+  constexpr int SLABS = 4;
+  const int lane = lane_id();
+  const int64_t base = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * (WAVE * SLABS);
+  if (base >= n) return;                                             // wave-uniform
+  T k[SLABS];
+#pragma unroll
+  for (int r = 0; r < SLABS; r++) { int64_t i = base + r * WAVE + lane; k[r] = k0[i < n ? i : n - 1]; }
+  T edge = base > 0 ? k0[base - 1] : (T)0;                           // the key before this wave's rows
+  bool wrong = false;
+#pragma unroll
+  for (int r = 0; r < SLABS; r++) {
+    int64_t i = base + r * WAVE + lane;
+    T p = (T)__shfl_up((long long)k[r], 1, 64);
+    if (lane == 0) p = edge;
+    edge = (T)__shfl((long long)k[r], 63, 64);
+    bool in = i < n;
+    bool head = in && (i == 0 || p < k[r]);
+    wrong |= in && (i == 0 ? (prev != nullptr && !(prev[0] < k[r])) : (k[r] < p));
+    uint64_t m = ballot64(head);
+    if (lane == 0 && base + r * WAVE < n) heads[(base >> 6) + r] = m;
+  }
+  if (ballot64(wrong) && lane == 0) *bad = 1ull;
+}
 __global__ void __launch_bounds__(BLOCK) k_popc_words_g(const uint64_t* words, int64_t nw, uint32_t* out) {
   int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i < nw) out[i] = (uint32_t)__popcll(words[i]);
@@ -337,7 +363,8 @@ static bool groups_intern_runs(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_arra
   int w = type_width(k0->type);
   const void* prev = g->n_groups ? (const void*)((const char*)g->keys[0]->values->ptr + (size_t)(g->n_groups - 1) * w) : nullptr;
   dim3 grid(grid_for(n, BLOCK)), block(BLOCK);
-#define RUNS(T) hipLaunchKernelGGL((k_run_heads<T>), grid, block, 0, ctx->stream, bk, n, (const T*)prev, (uint64_t*)heads->ptr, (unsigned long long*)(ctx->d_scratch64 + 2))
+#define RUNS(T) do { if (nkeys == 1) hipLaunchKernelGGL((k_run_heads1<T>), dim3(grid_for(n, BLOCK * 4)), block, 0, ctx->stream, (const T*)k0->values->ptr, n, (const T*)prev, (uint64_t*)heads->ptr, (unsigned long long*)(ctx->d_scratch64 + 2)); \
+                     else hipLaunchKernelGGL((k_run_heads<T>), grid, block, 0, ctx->stream, bk, n, (const T*)prev, (uint64_t*)heads->ptr, (unsigned long long*)(ctx->d_scratch64 + 2)); } while (0)
   switch (k0->type) {
     case DFGPU_INT8: RUNS(int8_t); break; case DFGPU_INT16: RUNS(int16_t); break; case DFGPU_INT32: case DFGPU_DATE32: RUNS(int32_t); break; case DFGPU_INT64: RUNS(int64_t); break;
     case DFGPU_UINT8: RUNS(uint8_t); break; case DFGPU_UINT16: RUNS(uint16_t); break; case DFGPU_UINT32: RUNS(uint32_t); break; default: RUNS(uint64_t); break; }
