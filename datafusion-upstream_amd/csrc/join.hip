@@ -274,15 +274,38 @@ __global__ void __launch_bounds__(BLOCK) k_popc_words(const uint64_t* words, int
   int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i < nw) out[i] = (uint32_t)__popcll(words[i]);
 }
-template <typename T>
+// LR_ROWS matches per lane, each level of the dependent chain (row -> key -> bitmap word + prefix -> selected row) issued for all of them
+// before the next level; ALL = every probe row matched (the match list is 0 .. m-1 and is not read); SEL = a build selection is fused.
+constexpr int LR_ROWS = 4;
+template <typename T, bool ALL, bool SEL>
 __global__ void __launch_bounds__(BLOCK) k_probe_lookup_rank(const T* pkeys, const uint32_t* rows, int64_t m, int64_t kmin, const uint64_t* bitmap,
                                                              const uint32_t* prefix, const uint32_t* sel_rows, int identity, uint64_t* out_build) {
-  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= m) return;
-  uint64_t d = (uint64_t)((int64_t)pkeys[rows[i]] - kmin);      // pass 1 proved d < range and the bit set
-  uint64_t r = d;
-  if (!identity) { r = prefix[d >> 6] + (uint32_t)__popcll(bitmap[d >> 6] & ((1ull << (d & 63)) - 1ull)); if (sel_rows) r = sel_rows[r]; }
-  out_build[i] = r;
+  const int64_t base = (int64_t)blockIdx.x * BLOCK * LR_ROWS + threadIdx.x;
+  int64_t ic[LR_ROWS]; uint64_t d[LR_ROWS], r[LR_ROWS];
+#pragma unroll
+  for (int q = 0; q < LR_ROWS; q++) { int64_t i = base + (int64_t)q * BLOCK; ic[q] = i < m ? i : m - 1; }
+  if constexpr (!ALL) {
+#pragma unroll
+    for (int q = 0; q < LR_ROWS; q++) ic[q] = rows[ic[q]];
+  }
+#pragma unroll
+  for (int q = 0; q < LR_ROWS; q++) d[q] = (uint64_t)((int64_t)pkeys[ic[q]] - kmin);      // pass 1 proved d < range and the bit set
+  if (identity) {
+#pragma unroll
+    for (int q = 0; q < LR_ROWS; q++) r[q] = d[q];
+  } else {
+    uint64_t w[LR_ROWS]; uint32_t p[LR_ROWS];
+#pragma unroll
+    for (int q = 0; q < LR_ROWS; q++) { w[q] = bitmap[d[q] >> 6]; p[q] = prefix[d[q] >> 6]; }
+#pragma unroll
+    for (int q = 0; q < LR_ROWS; q++) r[q] = p[q] + (uint32_t)__popcll(w[q] & ((1ull << (d[q] & 63)) - 1ull));
+    if constexpr (SEL) {
+#pragma unroll
+      for (int q = 0; q < LR_ROWS; q++) r[q] = sel_rows[r[q]];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < LR_ROWS; q++) { int64_t i = base + (int64_t)q * BLOCK; if (i < m) out_build[i] = r[q]; }
 }
 #define DFGPU_INT_KEY_DISPATCH(TYPE, CALL)                                                                      \
   switch (TYPE) {                                                                                               \
@@ -613,9 +636,13 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
       ob.a = new_fixed(ctx, DFGPU_UINT64, m);
       const dfgpu_array* pk = probe_keys[0];
       if (m) { KernelTimer kt_(ctx, "k_probe_lookup_rank");
-        DFGPU_INT_KEY_DISPATCH(pk->type, hipLaunchKernelGGL((k_probe_lookup_rank<T>), dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const T*)pk->values->ptr, rp, m, t->key_min,
-                                                            (const uint64_t*)t->bitmap->ptr, t->rank_prefix ? (const uint32_t*)t->rank_prefix->ptr : nullptr,
-                                                            t->sel_rows ? (const uint32_t*)t->sel_rows->values->ptr : nullptr, t->rank_identity ? 1 : 0, (uint64_t*)ob.get()->values->ptr)); }
+        const bool all = rows.get()->identity && m == n, sel = t->sel_rows != nullptr;
+#define LR(ALL, SEL) DFGPU_INT_KEY_DISPATCH(pk->type, hipLaunchKernelGGL((k_probe_lookup_rank<T, ALL, SEL>), dim3(grid_for(m, BLOCK * LR_ROWS)), dim3(BLOCK), 0, ctx->stream, (const T*)pk->values->ptr, rp, m, t->key_min, \
+                                                            (const uint64_t*)t->bitmap->ptr, t->rank_prefix ? (const uint32_t*)t->rank_prefix->ptr : nullptr, \
+                                                            t->sel_rows ? (const uint32_t*)t->sel_rows->values->ptr : nullptr, t->rank_identity ? 1 : 0, (uint64_t*)ob.get()->values->ptr))
+        if (all && sel) { LR(true, true); } else if (all) { LR(true, false); } else if (sel) { LR(false, true); } else { LR(false, false); }
+#undef LR
+      }
       KERNEL_CHECK();
       op.a = rows.release();
     } else if (t->unique) {
