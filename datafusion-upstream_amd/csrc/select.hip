@@ -42,6 +42,24 @@ __global__ void __launch_bounds__(BLOCK) k_take_fixed(const typename WT<W>::T* s
   if (i < n) out[i] = v;
   if (out_valid) { uint64_t m = ballot64(ok); if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) out_valid[i >> 6] = m; }
 }
+// No validity on either side (the shape of every gather behind a join of non-nullable columns): TAKE_ROWS rows per lane, their indices
+// loaded together and unconditionally (row index clamped), then their values (source index clamped after the bounds check) -- the
+// general kernel's load-behind-branch chain serialises the two dependent levels per row.
+constexpr int TAKE_ROWS = 4;
+template <int W, typename IT>
+__global__ void __launch_bounds__(BLOCK) k_take_fixed_plain(const typename WT<W>::T* src, int64_t src_len, const IT* idx, int64_t n, typename WT<W>::T* out, uint32_t* flags) {
+  const int64_t base = (int64_t)blockIdx.x * BLOCK * TAKE_ROWS + threadIdx.x;
+  int64_t j[TAKE_ROWS]; typename WT<W>::T v[TAKE_ROWS]; bool oob = false;
+#pragma unroll
+  for (int q = 0; q < TAKE_ROWS; q++) { int64_t i = base + (int64_t)q * BLOCK; j[q] = (int64_t)idx[i < n ? i : n - 1]; }
+#pragma unroll
+  for (int q = 0; q < TAKE_ROWS; q++) { bool bad = j[q] < 0 || j[q] >= src_len; oob |= bad && (base + (int64_t)q * BLOCK < n); if (bad) j[q] = 0; }
+#pragma unroll
+  for (int q = 0; q < TAKE_ROWS; q++) v[q] = src[j[q]];
+#pragma unroll
+  for (int q = 0; q < TAKE_ROWS; q++) { int64_t i = base + (int64_t)q * BLOCK; if (i < n) out[i] = v[q]; }
+  if (oob) atomicOr(flags, DFGPU_FLAG_OOB);
+}
 __global__ void __launch_bounds__(BLOCK) k_take_bool(const uint64_t* src, const uint64_t* src_valid, int64_t src_len,
                                                      const void* idx, int idx_w, const uint64_t* idx_valid, int64_t n,
                                                      uint64_t* out, uint64_t* out_valid, uint32_t* flags) {
@@ -107,7 +125,13 @@ dfgpu_array* take_impl(dfgpu_ctx* ctx, const dfgpu_array* a, const void* idx, in
     int w = type_width(vt);
     o->values = alloc_buffer(ctx, (size_t)n * w);
     KernelTimer kt_(ctx, "k_take_fixed");
-    if (n) switch (w) {
+    if (n && !need_valid && a->length > 0 && (idx_w == 4 || idx_w == 8)) {
+      dim3 pgrid(grid_for(n, BLOCK * TAKE_ROWS));
+#define TAKE_PLAIN(W) case W: if (idx_w == 4) hipLaunchKernelGGL((k_take_fixed_plain<W, uint32_t>), pgrid, block, 0, ctx->stream, (const WT<W>::T*)a->values->ptr, a->length, (const uint32_t*)idx, n, (WT<W>::T*)o->values->ptr, ctx->d_flags); \
+                              else hipLaunchKernelGGL((k_take_fixed_plain<W, uint64_t>), pgrid, block, 0, ctx->stream, (const WT<W>::T*)a->values->ptr, a->length, (const uint64_t*)idx, n, (WT<W>::T*)o->values->ptr, ctx->d_flags); break;
+      switch (w) { TAKE_PLAIN(1) TAKE_PLAIN(2) TAKE_PLAIN(4) TAKE_PLAIN(8) TAKE_PLAIN(16) default: fail(DFGPU_INTERNAL, "take: width %d", w); }
+#undef TAKE_PLAIN
+    } else if (n) switch (w) {
 #define TAKE_CASE(W) case W: hipLaunchKernelGGL((k_take_fixed<W>), grid, block, 0, ctx->stream, (const WT<W>::T*)a->values->ptr, sv, a->length, idx, idx_w, idx_valid, n, (WT<W>::T*)o->values->ptr, ov, ctx->d_flags); break;
       TAKE_CASE(1) TAKE_CASE(2) TAKE_CASE(4) TAKE_CASE(8) TAKE_CASE(16)
 #undef TAKE_CASE
