@@ -337,12 +337,13 @@ __global__ void __launch_bounds__(BLOCK) k_acc_add_plain(int kind, const T* valu
 
 // ------------------------------------------------------------ repeated groups: per-workgroup LDS cache in front of the global atomics
 // Atomics on one address serialise in L2 (~2 ns each): 10 M rows of a Zipf(1.1) key spent 36 ms in k_acc_update, 1000 uniform
-// groups 4 ms.  Each workgroup therefore keeps a 1024-entry, 2-probe cache (group id tag, partial value, row count) in LDS:
+// groups 4 ms.  Each workgroup therefore keeps a 4096-entry, 4-probe cache (group id tag, partial value, row count) in LDS:
 // the first groups a workgroup meets claim entries and accumulate with LDS atomics; a group that finds both probes taken
 // falls through to the global atomic.  Hot groups are met first with overwhelming probability, so their traffic stays in
 // LDS and reaches HBM as one atomic per (workgroup, group) at the end.  Chosen by launch_update when the batch has >= 8 rows
 // per known group on average (uniform high-cardinality batches keep the direct path).
-constexpr int ACC_CACHE = 1024;
+constexpr int ACC_CACHE = 4096;        // entries per workgroup: 64 KB of LDS for 8-byte states, 96 KB for i128
+constexpr int ACC_PROBES = 4;
 constexpr uint32_t TAG_EMPTY = 0xFFFFFFFFu;
 enum { OP_ADD = 0, OP_MIN = 1, OP_MAX = 2 };
 
@@ -371,12 +372,42 @@ template <typename T, int CLS, int OP> __device__ inline void global_apply(int k
   else if constexpr (CLS == CLS_F64) atomic_min_f64((double*)vals + g, x, OP == OP_MIN);
   else { if (OP == OP_MIN) atomicMin((T*)vals + g, x); else atomicMax((T*)vals + g, x); }
 }
-template <typename T, int CLS, int OP>
+// PLAIN: no filter and values of exactly T without validity or dictionary (or COUNT(*)): CACHED_ROWS rows per lane whose group ids and
+// values are loaded together, unconditionally, before any of them touches the cache.
+constexpr int CACHED_ROWS = 4;
+template <typename T, int CLS, int OP, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_acc_cached(int kind, ColView v, int has_values, const uint32_t* gids, const uint64_t* fbits, const uint64_t* fvalid,
                                                       int64_t n, int64_t total, void* vals, uint64_t* counts, uint8_t* seen, int count_only_valid, uint32_t* flags) {
   __shared__ uint32_t s_tag[ACC_CACHE]; __shared__ uint32_t s_cnt[ACC_CACHE]; __shared__ T s_val[ACC_CACHE];
   for (int s = threadIdx.x; s < ACC_CACHE; s += BLOCK) { s_tag[s] = TAG_EMPTY; s_cnt[s] = 0; s_val[s] = op_identity<T, OP>(); }
   __syncthreads();
+  if constexpr (PLAIN) {
+    const T* vp = (const T*)v.values;
+    for (int64_t base = (int64_t)blockIdx.x * BLOCK * CACHED_ROWS + threadIdx.x; base < n; base += (int64_t)gridDim.x * BLOCK * CACHED_ROWS) {
+      uint32_t gq[CACHED_ROWS]; T xq[CACHED_ROWS];
+#pragma unroll
+      for (int q = 0; q < CACHED_ROWS; q++) {
+        int64_t i = base + (int64_t)q * BLOCK, ic = i < n ? i : n - 1;
+        gq[q] = gids[ic]; xq[q] = has_values ? vp[ic] : op_identity<T, OP>();
+        if (i >= n) gq[q] = GID_NONE;
+      }
+#pragma unroll
+      for (int q = 0; q < CACHED_ROWS; q++) {
+        uint32_t g = gq[q]; T x = xq[q];
+        if (g == GID_NONE) continue;
+        if ((int64_t)g >= total) { atomicOr(flags, DFGPU_FLAG_OOB); continue; }
+        uint32_t h = (g * 0x9E3779B1u) >> 20; int slot = -1;
+#pragma unroll
+        for (int p = 0; p < ACC_PROBES && slot < 0; p++) {
+          int s = (int)((h + p) & (ACC_CACHE - 1)); uint32_t t = s_tag[s];
+          if (t == TAG_EMPTY) { t = atomicCAS(&s_tag[s], TAG_EMPTY, g); if (t == TAG_EMPTY) t = g; }
+          if (t == g) slot = s;
+        }
+        if (slot >= 0) { if (kind != DFGPU_AGG_COUNT) lds_apply<T, OP>(&s_val[slot], x); atomicAdd(&s_cnt[slot], 1u); }
+        else global_apply<T, CLS, OP>(kind, g, x, 1, vals, counts, seen);
+      }
+    }
+  } else
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
     uint32_t g = gids[i];
     if (g == GID_NONE || !filter_pass(fbits, fvalid, i)) continue;
@@ -386,9 +417,9 @@ __global__ void __launch_bounds__(BLOCK) k_acc_cached(int kind, ColView v, int h
     else if (!ok) continue;
     T x = op_identity<T, OP>();
     if (kind != DFGPU_AGG_COUNT) { if constexpr (CLS == CLS_F64) x = acc_cell_f64(v, r); else x = (T)acc_cell_int(v, r); }
-    uint32_t h = (g * 0x9E3779B1u) >> 22; int slot = -1;
+    uint32_t h = (g * 0x9E3779B1u) >> 20; int slot = -1;
 #pragma unroll
-    for (int p = 0; p < 2 && slot < 0; p++) {
+    for (int p = 0; p < ACC_PROBES && slot < 0; p++) {
       int s = (int)((h + p) & (ACC_CACHE - 1)); uint32_t t = s_tag[s];
       if (t == TAG_EMPTY) { t = atomicCAS(&s_tag[s], TAG_EMPTY, g); if (t == TAG_EMPTY) t = g; }
       if (t == g) slot = s;
@@ -498,7 +529,14 @@ static void launch_update(dfgpu_acc* a, int kind, int cls, const dfgpu_array* va
 #undef SMALL
   } else if (n >= 8 * total && !(cls == CLS_I128 && !sumlike)) {
     int cblocks = grid_for(n, BLOCK * 32, ctx->num_cus * 4);         // >= 8192 rows per workgroup amortise the cache flush
-#define CACHED(T, C, O) hipLaunchKernelGGL((k_acc_cached<T, C, O>), dim3(cblocks), dim3(BLOCK), 0, ctx->stream, kind, v, values ? 1 : 0, g, fb, fv, n, total, vals, (uint64_t*)a->counts->ptr, (uint8_t*)a->seen->ptr, 1, ctx->d_flags)
+    // plain: the values are stored exactly as the kernel's T (MIN / MAX state keeps the input type; SUM / AVG of a narrower integer widens per row)
+    bool cplain = !filt && (!values ? kind == DFGPU_AGG_COUNT
+                                    : (kind == DFGPU_AGG_COUNT ? !values->validity
+                                       : (!values->validity && values->type != DFGPU_DICTIONARY &&
+                                          (cls == CLS_F64 ? values->type == DFGPU_FLOAT64 : cls == CLS_I128 ? values->type == DFGPU_DECIMAL128 : cls == CLS_U64 ? values->type == DFGPU_UINT64 : values->type == DFGPU_INT64))));
+    const bool cvals = values && kind != DFGPU_AGG_COUNT;
+#define CACHED(T, C, O) do { if (cplain) hipLaunchKernelGGL((k_acc_cached<T, C, O, true>), dim3(cblocks), dim3(BLOCK), 0, ctx->stream, kind, v, cvals ? 1 : 0, g, fb, fv, n, total, vals, (uint64_t*)a->counts->ptr, (uint8_t*)a->seen->ptr, 1, ctx->d_flags); \
+                             else hipLaunchKernelGGL((k_acc_cached<T, C, O, false>), dim3(cblocks), dim3(BLOCK), 0, ctx->stream, kind, v, values ? 1 : 0, g, fb, fv, n, total, vals, (uint64_t*)a->counts->ptr, (uint8_t*)a->seen->ptr, 1, ctx->d_flags); } while (0)
     if (sumlike) { if (cls == CLS_F64) CACHED(double, CLS_F64, OP_ADD); else if (cls == CLS_I128) CACHED(i128, CLS_I128, OP_ADD); else CACHED(unsigned long long, CLS_U64, OP_ADD); }
     else if (kind == DFGPU_AGG_MIN) { if (cls == CLS_F64) CACHED(double, CLS_F64, OP_MIN); else if (cls == CLS_U64) CACHED(unsigned long long, CLS_U64, OP_MIN); else CACHED(long long, CLS_I64, OP_MIN); }
     else { if (cls == CLS_F64) CACHED(double, CLS_F64, OP_MAX); else if (cls == CLS_U64) CACHED(unsigned long long, CLS_U64, OP_MAX); else CACHED(long long, CLS_I64, OP_MAX); }
