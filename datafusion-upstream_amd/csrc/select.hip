@@ -86,15 +86,30 @@ __global__ void __launch_bounds__(BLOCK) k_take_utf8_len(const int32_t* src_off,
   if (i < n) out_len[i] = len;
   if (out_valid) { uint64_t m = ballot64(ok); if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) out_valid[i >> 6] = m; }
 }
+// One wave per 64 output rows: their bytes are one contiguous span of the output, which the lanes copy byte-interleaved (coalesced
+// stores; every byte finds its row by a 6-step search over the wave's 64 row starts held in registers).  A lane copying its own row
+// byte by byte -- the obvious kernel -- moved 0.17 TB/s on 20 M short strings.
 __global__ void __launch_bounds__(BLOCK) k_take_utf8_copy(const uint8_t* src, const int32_t* src_off, const void* idx, int idx_w,
                                                           const uint64_t* out_off64, int64_t n, int32_t* out_off, uint8_t* out, uint64_t total) {
-  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i > n) return;
-  if (i == n) { out_off[n] = (int32_t)total; return; }
-  uint64_t o = out_off64[i]; out_off[i] = (int32_t)o;
-  uint64_t next = i + 1 < n ? out_off64[i + 1] : total;
-  int64_t len = (int64_t)(next - o);
-  if (len > 0) { int64_t j = load_index(idx, idx_w, i); const uint8_t* p = src + src_off[j]; for (int64_t b = 0; b < len; b++) out[o + b] = p[b]; }
+  const int lane = lane_id();
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;                      // rows 0 .. n (row n only carries the final offset)
+  const uint64_t o = i < n ? out_off64[i] : total;
+  const uint64_t next = i + 1 < n ? out_off64[i + 1] : total;
+  if (i <= n) out_off[i] = (int32_t)o;
+  int64_t s = 0;
+  if (i < n && next > o) s = (int64_t)src_off[load_index(idx, idx_w, i)];             // rows without bytes (NULL, empty) never read their index
+  const uint64_t wbeg = __shfl((unsigned long long)o, 0, 64), wend = __shfl((unsigned long long)next, 63, 64);
+  const uint32_t rel = (uint32_t)(o - wbeg);                                          // 64 rows span < 4 GB (the whole output is < 2 GB)
+  for (uint64_t pb = wbeg; pb < wend; pb += WAVE) {                                    // wave-uniform trip count: the row starts are read from every lane
+    const uint64_t p = pb + (uint64_t)lane; const bool act = p < wend;
+    const uint32_t pr = (uint32_t)((act ? p : wend - 1) - wbeg);
+    int lo = 0;                                                                        // largest r with rel_r <= pr: among rows starting at p the last one, which is the one with bytes
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) { int mid = lo + step; uint32_t om = (uint32_t)__shfl((int)rel, mid & 63, 64); if (mid < WAVE && om <= pr) lo = mid; }
+    const uint32_t orow = (uint32_t)__shfl((int)rel, lo, 64);
+    const int64_t srow = (int64_t)__shfl((long long)s, lo, 64);
+    if (act) out[p] = src[srow + (int64_t)(pr - orow)];
+  }
 }
 
 dfgpu_array* take_impl(dfgpu_ctx* ctx, const dfgpu_array* a, const void* idx, int idx_w, const uint64_t* idx_valid, int64_t n) {
