@@ -25,6 +25,7 @@ struct dfgpu_groups {
   int64_t n_groups = 0;
   std::vector<dfgpu_array*> keys;     // stored key columns, one row per group (null until first batch)
   uint64_t capacity = 0;
+  int64_t size_hint = 0;               // upper bound / expectation of the number of groups when the caller knows one (0 = none)
   BufferPtr slots, first_row;          // u64[capacity], u32[capacity]
   BufferPtr ghash; int64_t ghash_cap = 0;   // u64 per group
   // run mode: every batch so far arrived with its keys clustered (first key column non-decreasing, the other columns constant within
@@ -439,7 +440,7 @@ static dfgpu_status groups_intern_impl(dfgpu_ctx* ctx, dfgpu_groups* g, const df
         for (int c = 0; c < nkeys; c++) {
           if (cols[c]->type != DFGPU_DICTIONARY) continue;
           const dfgpu_array* dict = cols[c]->dictionary;
-          dfgpu_groups tmp; tmp.ctx = ctx; tmp.nkeys = 1; tmp.keys.assign(1, nullptr);
+          dfgpu_groups tmp; tmp.ctx = ctx; tmp.nkeys = 1; tmp.keys.assign(1, nullptr); tmp.size_hint = dict->length;
           dfgpu_array* dids = nullptr; dfgpu_status st = dfgpu_groups_intern(ctx, &tmp, &dict, 1, nullptr, &dids);
           if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str());
           ArrayHolder hold(dids);
@@ -532,7 +533,12 @@ static dfgpu_status groups_intern_impl(dfgpu_ctx* ctx, dfgpu_groups* g, const df
     }
     BufferPtr tmp = alloc_buffer(ctx, (size_t)n * 4);
     // optimistic table size (at most 2^23 slots up front); a batch that overfills it is redone on a table 8x larger
-    uint64_t guess = (uint64_t)g->n_groups * 4 + 2 * (uint64_t)(n < (1 << 22) ? n : (1 << 22));
+    // Known bounds beat the optimism: a dictionary is interned whole (its entries are mostly distinct: that is what it is for), and
+    // canonical-id tuples cannot form more groups than the product of their domains.
+    uint64_t expect = (uint64_t)(n < (1 << 22) ? n : (1 << 22));
+    if (g->canon_mode) { uint64_t dom = 1; for (int c = 0; c < nkeys && dom < (1ull << 31); c++) dom *= g->canon[(size_t)c].dict ? (uint64_t)g->canon[(size_t)c].n_ids + 1 : (1ull << 31); g->size_hint = (int64_t)(dom < (1ull << 31) ? dom : (1ull << 31)); }
+    if (g->size_hint > 0) { uint64_t h = (uint64_t)g->size_hint < (uint64_t)n ? (uint64_t)g->size_hint : (uint64_t)n; if (h > expect) expect = h; }
+    uint64_t guess = (uint64_t)g->n_groups * 4 + 2 * expect;
     uint64_t want = 1ull << 16; while (want < guess) want <<= 1;
     if (g->capacity < want) groups_alloc_table(g, want);
     int64_t n_new = 0;
