@@ -120,3 +120,27 @@ def test_hash_partition_matches_oracle(ctx, nparts):
         oidx, ocounts = po.hash_partition(cols, nparts)
         assert counts == ocounts.tolist() and sum(counts) == n
         assert np.array_equal(idx.to_numpy(), oidx)
+
+
+@pytest.mark.parametrize("shape", ["two_ints", "decimal_date_utf8", "many_ties"])
+def test_large_input_sort_with_packed_moving_keys(ctx, shape):
+    """From 2^20 rows on, the radix passes carry up to four key bytes with every row id instead of looking the digit up by row id; the
+    row order must stay the oracle's stable lexsort (ties in input order) for multi-column keys, NULLs first / last and DESC columns,
+    across several groups of four planes and a ragged last group."""
+    rng = np.random.default_rng(3)
+    n = (1 << 20) + 12345
+    if shape == "two_ints":
+        cols = [pa.array(rng.integers(0, 50, n).astype(np.int32), mask=rng.random(n) < 0.05), pa.array(rng.integers(-2**40, 2**40, n), mask=rng.random(n) < 0.05)]
+        desc, nf = [False, True], [True, False]
+    elif shape == "decimal_date_utf8":
+        import decimal
+        vals = [decimal.Decimal(int(v)).scaleb(-2) for v in rng.integers(-10**7, 10**7, 5000)]
+        cols = [pa.array([vals[i] for i in rng.integers(0, 5000, n)], type=pa.decimal128(15, 2)),
+                pa.array(rng.integers(8000, 8060, n).astype(np.int32)).cast(pa.date32()),
+                pa.array(np.array(["", "a", "ab", "b", "zz", "abc"], dtype=object)[rng.integers(0, 6, n)], type=pa.utf8())]
+        desc, nf = [True, False, False], [True, True, False]
+    else:
+        cols = [pa.array(rng.integers(0, 3, n).astype(np.int8)), pa.array((rng.integers(0, 4, n) * 0.5).astype(np.float64))]
+        desc, nf = [False, True], [True, True]
+    got = ctx.sort_to_indices([ctx.from_arrow(c) for c in cols], desc, nf).to_numpy()
+    assert np.array_equal(got, po.lexsort_to_indices(cols, desc, nf))
