@@ -30,39 +30,64 @@ __global__ void __launch_bounds__(BLOCK) k_rs_hist(D dg, const uint32_t* keys, c
   hist[(int64_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
 }
 
+// Stable scatter of one pass.  A workgroup walks its chunk in tiles of RS_ITEMS x 256 rows: every lane loads its RS_ITEMS elements up
+// front (element q of the tile's q-th 256-row slab, so slab order = input order), each wave ranks its elements slab by slab with
+// 64-wide match-any ballots while keeping per-digit counts of the slabs already ranked in LDS (waves touch only their own rows of the
+// count table between the barriers); the thread that owns a digit then turns the tile's counts into start positions in (slab, wave)
+// order, and every element lands at start[slab][wave][digit] + its rank inside (slab, wave): 4 barriers per 1024 rows.
+constexpr int RS_ITEMS = 4;
 template <typename D>
 __global__ void __launch_bounds__(BLOCK) k_rs_scatter(D dg, const uint32_t* keys, const uint32_t* vals, int64_t n, int64_t chunk, int nb,
                                                       const uint32_t* offsets, uint32_t* out_keys, uint32_t* out_vals) {
+  constexpr int NW = BLOCK / WAVE;
   __shared__ uint32_t running[256];
-  __shared__ uint32_t wave_cnt[BLOCK / WAVE][256];
+  __shared__ uint32_t cnt[RS_ITEMS][NW][256];            // rows with digit d in (slab q, wave w) of the current tile
   running[threadIdx.x] = offsets[(int64_t)threadIdx.x * nb + blockIdx.x];
 #pragma unroll
-  for (int w = 0; w < BLOCK / WAVE; w++) wave_cnt[w][threadIdx.x] = 0;
+  for (int q = 0; q < RS_ITEMS; q++)
+#pragma unroll
+    for (int w = 0; w < NW; w++) cnt[q][w][threadIdx.x] = 0;
   __syncthreads();
   int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
-  int lane = lane_id(), wave = threadIdx.x >> 6;
-  for (int64_t t0 = lo; t0 < hi; t0 += BLOCK) {
-    int64_t i = t0 + threadIdx.x;
-    bool active = i < hi;
-    uint32_t key = 0, val = 0, d = 0;
-    if (active) { val = vals[i]; key = keys ? keys[i] : 0u; d = digit_of(dg, key, val); }
-    // match-any: lanes of this wave holding the same digit
-    uint64_t peers = ballot64(active);
+  const int wave = threadIdx.x >> 6;
+  for (int64_t t0 = lo; t0 < hi; t0 += (int64_t)BLOCK * RS_ITEMS) {
+    uint32_t key[RS_ITEMS], val[RS_ITEMS], d[RS_ITEMS], rank[RS_ITEMS]; bool active[RS_ITEMS];
 #pragma unroll
-    for (int b = 0; b < 8; b++) { uint64_t m = ballot64((d >> b) & 1u); peers &= ((d >> b) & 1u) ? m : ~m; }
-    uint32_t rank = __popcll(peers & lanemask_lt());
-    if (active && rank == 0) wave_cnt[wave][d] = __popcll(peers);
-    __syncthreads();
-    if (active) {
-      uint32_t pos = running[d] + rank;
-      for (int w = 0; w < wave; w++) pos += wave_cnt[w][d];
-      out_vals[pos] = val; if (out_keys) out_keys[pos] = key;
+    for (int q = 0; q < RS_ITEMS; q++) {
+      int64_t i = t0 + (int64_t)q * BLOCK + threadIdx.x; active[q] = i < hi;
+      int64_t ic = active[q] ? i : hi - 1;
+      val[q] = vals[ic]; key[q] = keys ? keys[ic] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < RS_ITEMS; q++) d[q] = digit_of(dg, key[q], val[q]);
+#pragma unroll
+    for (int q = 0; q < RS_ITEMS; q++) {
+      uint64_t peers = ballot64(active[q]);
+#pragma unroll
+      for (int b = 0; b < 8; b++) { uint64_t m = ballot64((d[q] >> b) & 1u); peers &= ((d[q] >> b) & 1u) ? m : ~m; }
+      rank[q] = __popcll(peers & lanemask_lt());
+      if (active[q] && rank[q] == 0) cnt[q][wave][d[q]] = __popcll(peers);
     }
     __syncthreads();
-    uint32_t add = 0;
+    {                                                     // thread t owns digit t: counts -> start positions, in (slab, wave) order
+      uint32_t run = running[threadIdx.x];
 #pragma unroll
-    for (int w = 0; w < BLOCK / WAVE; w++) { add += wave_cnt[w][threadIdx.x]; wave_cnt[w][threadIdx.x] = 0; }
-    running[threadIdx.x] += add;
+      for (int q = 0; q < RS_ITEMS; q++)
+#pragma unroll
+        for (int w = 0; w < NW; w++) { uint32_t c = cnt[q][w][threadIdx.x]; cnt[q][w][threadIdx.x] = run; run += c; }
+      running[threadIdx.x] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RS_ITEMS; q++) if (active[q]) {
+      uint32_t pos = cnt[q][wave][d[q]] + rank[q];
+      out_vals[pos] = val[q]; if (out_keys) out_keys[pos] = key[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RS_ITEMS; q++)
+#pragma unroll
+      for (int w = 0; w < NW; w++) cnt[q][w][threadIdx.x] = 0;
     __syncthreads();
   }
 }
