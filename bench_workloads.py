@@ -8,6 +8,8 @@ rows/s = input rows / wall time; per-kernel device time from one fully bracketed
   q1_float64   the same with Float64 money columns ("fp64 accumulators")                  [38 B/row]
   q18_groups   the Q18 subquery: GROUP BY l_orderkey (one Int64 key, 1/4 rows distinct) SUM(l_quantity) -> Filter SUM > 300
                (GroupValuesPrimitive at 150 M groups for SF100)                            [24 B/row]
+  sort         SortExec over 1 M x sf rows: ORDER BY l_extendedprice DESC, l_shipdate, three columns materialised in the new order
+               [28 B/row in + 28 B/row out]
   clickbench   ClickBench Q28 shape: filter key <> '' -> GROUP BY a dictionary-encoded Utf8 key -> AVG(Int32 as f64), COUNT(*),
                MAX(Int64) -> HAVING -> ORDER BY avg DESC LIMIT 25; uniform and Zipf(1.1) keys  [code 4 + 4 + 8 B/row]
 This is NOT the driver's bench contract (bench.py is); it exists so that DESIGN.md can quote measured numbers for these shapes.
@@ -232,6 +234,39 @@ def main():
         bytes_total = 2 * n * (8 + 16) + n_orders * (8 + 8 + 16 + 4) + n_cust * 8
         report("q18", dt, rows_in, rows, round(bytes_total / rows_in, 2), kern, syncs)
         del customer, orders, line, plan, qty, o_totalprice, o_custkey, o_orderdate, o_orderkey
+        torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ SortExec at scale: ORDER BY l_extendedprice DESC, l_shipdate over 1 M x sf rows, 3 columns out
+    if not want or "sort" in want:
+        ns = int(1_000_000 * args.sf)
+        price = dec_tensor(torch, ns, 90000, 10494951, g)
+        sdate = torch.randint(8035, 10560, (ns,), generator=g, device="cuda", dtype=torch.int32)
+        okey = torch.randint(1, 6 * 10**8, (ns,), generator=g, device="cuda", dtype=torch.int64)
+        torch.cuda.synchronize()
+        batch = ops.RecordBatch.from_arrays(ctx, ["l_orderkey", "l_extendedprice", "l_shipdate"],
+                                            [ctx.wrap_tensor(okey, capi.INT64), ctx.wrap_tensor(price, capi.DECIMAL128, 15, 2), ctx.wrap_tensor(sdate, capi.DATE32)])
+        plan = ops.SortExec([ops.PhysicalSortExpr(C("l_extendedprice", 1), True, True), ops.PhysicalSortExpr(C("l_shipdate", 2), False, False)], ops.MemoryExec([[batch]], batch.schema))
+
+        def timed_sort():
+            def step():
+                out = [b for b in ops.with_fresh_state(plan).execute(0, tc)]
+                with ctx.deferred_flags():
+                    for b in out:
+                        b.columns                        # the sorted columns, not only the order
+                ctx.synchronize()
+                return sum(b.num_rows for b in out)
+            for _ in range(max(args.warmup, 1)):
+                step()
+            ctx.profile_enable(True); ctx.profile_read(); step(); p = ctx.profile_read(); ctx.profile_enable(False)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                rows = step()
+            dt = (time.perf_counter() - t0) / args.steps
+            kern = {k: round(v[1], 3) for k, v in sorted(p.items(), key=lambda kv: -kv[1][1]) if not k.startswith("sync:")}
+            return dt, rows, kern, sum(v[0] for k, v in p.items() if k.startswith("sync:"))
+        dt, rows, kern, syncs = timed_sort()
+        report("sort", dt, ns, rows, 2 * (8 + 16 + 4), kern, syncs, {"sort_keys": "Decimal128 DESC NULLS FIRST, Date32 ASC NULLS LAST"})
+        del price, sdate, okey, batch, plan
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ ClickBench-style string-key group-by (100 M rows at sf 100)
