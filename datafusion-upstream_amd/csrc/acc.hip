@@ -102,6 +102,9 @@ __global__ void k_minmax128_prepare(int is_min, uint64_t* vals, const uint64_t* 
   int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g < total && vals[2 * g + 1] != old_hi[g]) vals[2 * g] = is_min ? ~0ull : 0ull;
 }
+__global__ void k_add_count_delta(uint64_t* dst, const uint64_t* now, const uint64_t* before, int64_t total) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (g < total) dst[g] += now[g] - before[g];
+}
 __global__ void k_copy_hi(const uint64_t* vals, uint64_t* hi, int64_t total) { int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (g < total) hi[g] = vals[2 * g + 1]; }
 
 // ------------------------------------------------------------ few groups: register partials
@@ -637,8 +640,33 @@ dfgpu_status dfgpu_acc_update_batch_multi(dfgpu_ctx* ctx, dfgpu_acc* const* accs
   std::vector<dfgpu_acc*> accs_o; std::vector<const dfgpu_array*> values_o, filters_o;
   for (int32_t k : order) { accs_o.push_back(accs[k]); values_o.push_back(values[k]); filters_o.push_back(filters ? filters[k] : nullptr); }
   accs = accs_o.data(); values = values_o.data(); filters = filters_o.data();
+  // COUNT(*) (or COUNT of a NULL-free column) counts exactly the rows an AVG over a NULL-free column with the same filter counts: with
+  // many groups every state array costs one memory-side atomic per row, so the COUNT takes the AVG's per-group count delta of this
+  // batch instead of its own pass over the rows.
+  int donor = -1; std::vector<int> followers; BufferPtr before;
+  if (total > SMALL_G && gids->length >= (1 << 20)) {
+    auto null_free = [](const dfgpu_array* v) { return v && !v->validity && v->type != DFGPU_DICTIONARY; };
+    for (int32_t k = 0; k < n_accs && donor < 0; k++) if (accs[k] && accs[k]->kind == DFGPU_AGG_AVG && null_free(values[k]) && values[k]->length == gids->length) donor = k;
+    if (donor >= 0) for (int32_t k = 0; k < n_accs; k++)
+      if (accs[k] && accs[k]->kind == DFGPU_AGG_COUNT && filters[k] == filters[donor] && (!values[k] || null_free(values[k]))) followers.push_back(k);
+    if (!followers.empty()) {
+      dfgpu_status st = guard(ctx, [&] {
+        acc_resize(accs[donor], total);
+        before = alloc_buffer(ctx, (size_t)total * 8);
+        HIP_CHECK(hipMemcpyAsync(before->ptr, accs[donor]->counts->ptr, (size_t)total * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      });
+      if (st != DFGPU_OK) return st;
+    }
+  }
+  auto is_follower = [&](int32_t k) { return std::find(followers.begin(), followers.end(), (int)k) != followers.end(); };
+  struct AddDeltas { dfgpu_ctx* ctx; dfgpu_acc* const* accs; const std::vector<int>& fol; int donor; const BufferPtr& before; int64_t total;
+    dfgpu_status run() const { if (fol.empty()) return DFGPU_OK; return guard(ctx, [&] {
+      for (int k : fol) { acc_resize(accs[k], total);
+        hipLaunchKernelGGL(k_add_count_delta, dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, ctx->stream, (uint64_t*)accs[k]->counts->ptr, (const uint64_t*)accs[donor]->counts->ptr, (const uint64_t*)before->ptr, total); }
+      KERNEL_CHECK(); }); } } add_deltas{ctx, accs, followers, donor, before, total};
   int32_t i = 0;
   while (i < n_accs) {
+    if (is_follower(i)) { i++; continue; }
     const dfgpu_array* f = filters ? filters[i] : nullptr;
     int32_t j = i;
     int cap = accs[i] && accs[i]->cls == CLS_I128 ? 2 : MULTI_MAX;
@@ -679,7 +707,7 @@ dfgpu_status dfgpu_acc_update_batch_multi(dfgpu_ctx* ctx, dfgpu_acc* const* accs
     if (st != DFGPU_OK) return st;
     i = j + 1;
   }
-  return DFGPU_OK;
+  return add_deltas.run();
 }
 
 // ------------------------------------------------------------------ fused "evaluate arguments + accumulate" (run-time compiled)

@@ -486,3 +486,30 @@ def test_update_batch_fused_random_expression_dags(ctx, money, seed):
     dfgpu.GroupsAccumulator.update_batch_multi(ctx, plain, [arrays[nd] for nd in picks] + [None], [None] * 6, gd, G)
     for a, b in zip(fused, plain):
         check_equal(a.evaluate().to_arrow(), b.evaluate().to_arrow(), money == "float64")
+
+
+def test_count_takes_the_avg_count_delta_in_large_many_group_batches(ctx):
+    """update_batch_multi over >= 2^20 rows and more than 8 groups: COUNT(*) / COUNT(NULL-free column) with the same filter as an AVG over
+    a NULL-free column receive the AVG's per-group count delta of the batch instead of their own pass; COUNT of a nullable column and a
+    COUNT under another filter keep theirs.  States must equal separate update_batch calls, over two batches with growing groups."""
+    import dfgpu
+    n = (1 << 20) + 777
+    def build():
+        return [dfgpu.GroupsAccumulator(ctx, KIND["AVG"], dfgpu.capi.FLOAT64), dfgpu.GroupsAccumulator(ctx, KIND["COUNT"], dfgpu.capi.INT64),
+                dfgpu.GroupsAccumulator(ctx, KIND["COUNT"], dfgpu.capi.INT64), dfgpu.GroupsAccumulator(ctx, KIND["COUNT"], dfgpu.capi.INT64),
+                dfgpu.GroupsAccumulator(ctx, KIND["COUNT"], dfgpu.capi.INT64), dfgpu.GroupsAccumulator(ctx, KIND["SUM"], dfgpu.capi.FLOAT64)]
+    multi, single = build(), build()
+    for total in (3000, 5000):
+        g = RNG.integers(0, total, n).astype(np.uint32); g[RNG.random(n) < 0.05] = 0xFFFFFFFF
+        x = ctx.from_arrow(pa.array(RNG.normal(size=n)))
+        y = ctx.from_arrow(pa.array(RNG.integers(0, 100, n)))
+        z = ctx.from_arrow(pa.array(RNG.integers(0, 100, n), mask=RNG.random(n) < 0.3))
+        f = ctx.from_arrow(pa.array(RNG.random(n) < 0.5))
+        gd = ctx.from_arrow(pa.array(g))
+        vals, filts = [x, None, y, z, None, x], [None, None, None, None, f, None]
+        dfgpu.GroupsAccumulator.update_batch_multi(ctx, multi, vals, filts, gd, total)
+        for a, v, fl in zip(single, vals, filts):
+            a.update_batch(v, gd, fl, total)
+    for a, b in zip(multi, single):
+        for s1, s2 in zip(a.state(), b.state()):
+            check_equal(s1.to_arrow(), s2.to_arrow(), True)
