@@ -81,8 +81,12 @@ __global__ void __launch_bounds__(BLOCK) k_acc_update(int kind, int cls, ColView
     } else {
       bool is_min = kind == DFGPU_AGG_MIN;
       if (cls == CLS_F64) atomic_min_f64((double*)vals + g, acc_cell_f64(v, r), is_min);
-      else if (cls == CLS_U64) { unsigned long long x = (unsigned long long)(uint64_t)acc_cell_int(v, r); if (is_min) atomicMin((unsigned long long*)vals + g, x); else atomicMax((unsigned long long*)vals + g, x); }
-      else if (cls == CLS_I64) { long long x = (long long)acc_cell_int(v, r); if (is_min) atomicMin((long long*)vals + g, x); else atomicMax((long long*)vals + g, x); }
+      // read first: an extreme only moves one way, so a (possibly stale) value that already beats x proves the atomic is not needed --
+      // with r rows per group only ~ln r of them are records
+      else if (cls == CLS_U64) { unsigned long long x = (unsigned long long)(uint64_t)acc_cell_int(v, r), cur = ((const unsigned long long*)vals)[g];
+                                 if (is_min) { if (x < cur) atomicMin((unsigned long long*)vals + g, x); } else if (x > cur) atomicMax((unsigned long long*)vals + g, x); }
+      else if (cls == CLS_I64) { long long x = (long long)acc_cell_int(v, r), cur = ((const long long*)vals)[g];
+                                 if (is_min) { if (x < cur) atomicMin((long long*)vals + g, x); } else if (x > cur) atomicMax((long long*)vals + g, x); }
       else { long long hi = (long long)(acc_cell_int(v, r) >> 64); if (is_min) atomicMin((long long*)vals + 2 * (int64_t)g + 1, hi); else atomicMax((long long*)vals + 2 * (int64_t)g + 1, hi); }   // i128 pass 1: high word
     }
   }
@@ -373,7 +377,7 @@ template <typename T, int CLS, int OP> __device__ inline void global_apply(int k
   if constexpr (CLS == CLS_I128) atomic_add_i128((uint64_t*)vals + 2 * (int64_t)g, x);
   else if constexpr (OP == OP_ADD) { if constexpr (CLS == CLS_F64) unsafeAtomicAdd((double*)vals + g, x); else atomicAdd((unsigned long long*)vals + g, (unsigned long long)x); }
   else if constexpr (CLS == CLS_F64) atomic_min_f64((double*)vals + g, x, OP == OP_MIN);
-  else { if (OP == OP_MIN) atomicMin((T*)vals + g, x); else atomicMax((T*)vals + g, x); }
+  else { T cur = ((const T*)vals)[g]; if (OP == OP_MIN) { if (x < cur) atomicMin((T*)vals + g, x); } else if (x > cur) atomicMax((T*)vals + g, x); }     // read first, as in k_acc_update
 }
 // PLAIN: no filter and values of exactly T without validity or dictionary (or COUNT(*)): CACHED_ROWS rows per lane whose group ids and
 // values are loaded together, unconditionally, before any of them touches the cache.
