@@ -41,6 +41,9 @@ struct dfgpu_groups {
   // dense canon mode: every key column is a dictionary column and the product of the canonical domains is <= 4096 (TPC-H Q1: 4 x 3):
   // the composite canonical id indexes dense_map (-> group id or none) directly -- no hashing, no table, two streaming passes
   BufferPtr dense_map; int64_t dense_size = 0; std::vector<uint32_t> dense_host;
+  // direct map: ONE dictionary key column with a larger canonical domain: dmap[canonical id] = group id (or none) replaces the hash table
+  // altogether -- the ids are dense in [0, n_ids], so "find or insert" is an array access
+  BufferPtr dmap; int64_t dmap_size = 0;
   ~dfgpu_groups() { for (auto* a : keys) if (a) dfgpu_array_release(a); for (auto* a : canon_keys) if (a) dfgpu_array_release(a); for (auto& c : canon) if (c.dict) dfgpu_array_release(c.dict); }
 };
 
@@ -277,6 +280,56 @@ __global__ void __launch_bounds__(BLOCK) k_dense_ids(DenseCols dc, int64_t n, co
   for (int r = 0; r < DENSE_ROWS; r++) { int64_t i = base + (int64_t)r * BLOCK + threadIdx.x; if (i < n) out[i] = g[r]; }
 }
 
+// ---- direct map over canonical ids (one dictionary key column).  4 rows per lane, loads clamped and unconditional.
+constexpr int DM_ROWS = 4;
+// pass 1: first row of every canonical id that has no group yet (read before the atomicMin: it only ever moves down)
+__global__ void __launch_bounds__(BLOCK) k_dm_first(const uint32_t* cid, int64_t n, const uint64_t* mask, const uint32_t* dmap, uint32_t* first) {
+  const int64_t base = (int64_t)blockIdx.x * BLOCK * DM_ROWS + threadIdx.x;
+  uint32_t id[DM_ROWS], gm[DM_ROWS], fr[DM_ROWS]; bool on[DM_ROWS];
+#pragma unroll
+  for (int q = 0; q < DM_ROWS; q++) { int64_t i = base + (int64_t)q * BLOCK; on[q] = i < n && (mask == nullptr || bit_get(mask, i)); id[q] = cid[i < n ? i : n - 1]; }
+#pragma unroll
+  for (int q = 0; q < DM_ROWS; q++) { gm[q] = dmap[id[q]]; fr[q] = first[id[q]]; }
+#pragma unroll
+  for (int q = 0; q < DM_ROWS; q++) { uint32_t i = (uint32_t)(base + (int64_t)q * BLOCK); if (on[q] && gm[q] == G_NONE && fr[q] > i) atomicMin(&first[id[q]], i); }
+}
+// pass 2: head bit of row i = it is the first row of a canonical id without a group (one word per wave slab)
+__global__ void __launch_bounds__(BLOCK) k_dm_heads(const uint32_t* cid, int64_t n, const uint64_t* mask, const uint32_t* dmap, const uint32_t* first, uint64_t* heads) {
+  const int64_t base = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * (WAVE * DM_ROWS);
+  if (base >= n) return;
+  const int lane = lane_id();
+  uint32_t id[DM_ROWS], gm[DM_ROWS], fr[DM_ROWS]; bool on[DM_ROWS];
+#pragma unroll
+  for (int q = 0; q < DM_ROWS; q++) { int64_t i = base + q * WAVE + lane; on[q] = i < n && (mask == nullptr || bit_get(mask, i)); id[q] = cid[i < n ? i : n - 1]; }
+#pragma unroll
+  for (int q = 0; q < DM_ROWS; q++) { gm[q] = dmap[id[q]]; fr[q] = first[id[q]]; }
+#pragma unroll
+  for (int q = 0; q < DM_ROWS; q++) {
+    int64_t i = base + q * WAVE + lane;
+    uint64_t m = ballot64(on[q] && gm[q] == G_NONE && fr[q] == (uint32_t)i);
+    if (lane == 0 && base + q * WAVE < n) heads[(base >> 6) + q] = m;
+  }
+}
+// the r-th new group (first rows ascending = first-seen order) takes id base + r
+__global__ void __launch_bounds__(BLOCK) k_dm_assign(const uint32_t* firsts, int64_t n_new, const uint32_t* cid, uint32_t base, uint32_t* dmap, uint32_t* new_cid) {
+  int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (r >= n_new) return;
+  uint32_t id = cid[firsts[r]]; dmap[id] = base + (uint32_t)r; new_cid[r] = id;
+}
+__global__ void __launch_bounds__(BLOCK) k_dm_ids(const uint32_t* cid, int64_t n, const uint64_t* mask, const uint32_t* dmap, uint32_t* out) {
+  const int64_t base = (int64_t)blockIdx.x * BLOCK * DM_ROWS + threadIdx.x;
+  uint32_t id[DM_ROWS], g[DM_ROWS];
+#pragma unroll
+  for (int q = 0; q < DM_ROWS; q++) { int64_t i = base + (int64_t)q * BLOCK; id[q] = cid[i < n ? i : n - 1]; }
+#pragma unroll
+  for (int q = 0; q < DM_ROWS; q++) g[q] = dmap[id[q]];
+#pragma unroll
+  for (int q = 0; q < DM_ROWS; q++) { int64_t i = base + (int64_t)q * BLOCK; if (i < n) out[i] = (mask == nullptr || bit_get(mask, i)) ? g[q] : G_NONE; }
+}
+__global__ void __launch_bounds__(BLOCK) k_dm_seed(const uint32_t* group_cid, int64_t n_groups, uint32_t* dmap) {       // groups numbered by earlier (hash-path) batches
+  int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (g < n_groups) dmap[group_cid[g]] = (uint32_t)g;
+}
+
 void materialize_ids(dfgpu_ctx* ctx, const dfgpu_array* ids_c) {
   if (!ids_c || !ids_c->deferred_ids) return;
   dfgpu_array* ids = const_cast<dfgpu_array*>(ids_c); std::shared_ptr<DeferredIds> d = ids->deferred_ids;
@@ -425,13 +478,13 @@ static dfgpu_status groups_intern_impl(dfgpu_ctx* ctx, dfgpu_groups* g, const df
     if (g->canon_mode && !want_canon) {       // another dictionary (or none): back to value keys; the numbered groups are re-hashed by value
       for (auto*& a : g->canon_keys) { if (a) dfgpu_array_release(a); a = nullptr; }
       for (auto& cc : g->canon) { if (cc.dict) dfgpu_array_release(cc.dict); cc = dfgpu_groups::Canon{}; }
-      g->canon_mode = false; g->dense_size = 0; g->dense_map.reset(); g->dense_host.clear();
+      g->canon_mode = false; g->dense_size = 0; g->dense_map.reset(); g->dense_host.clear(); g->dmap.reset(); g->dmap_size = 0;
       if (g->n_groups) {
         std::vector<const dfgpu_array*> sk(g->keys.begin(), g->keys.end()); KeySet stored_ks = make_keyset(sk.data(), nkeys);
         groups_reserve_ghash(ctx, g, g->n_groups, 0);
         hipLaunchKernelGGL(k_groups_hash_stored, dim3(grid_for(g->n_groups, BLOCK)), dim3(BLOCK), 0, ctx->stream, stored_ks, g->n_groups, 0, (uint64_t*)g->ghash->ptr);
         KERNEL_CHECK();
-        if (g->capacity) groups_alloc_table(g, g->capacity);
+        if (g->capacity) { uint64_t cap = g->capacity; while (cap < (uint64_t)g->n_groups * 4) cap <<= 1; groups_alloc_table(g, cap); }     // groups numbered through the direct map never entered the table
       }
     }
     if (want_canon) {
@@ -523,6 +576,43 @@ static dfgpu_status groups_intern_impl(dfgpu_ctx* ctx, dfgpu_groups* g, const df
         KERNEL_CHECK();
         eff[(size_t)c] = sub[(size_t)c].get();
       }
+    }
+    // one dictionary key column: the canonical ids are dense, so a direct map replaces the hash table (find, first-row marking, numbering)
+    if (g->canon_mode && nkeys == 1 && sub[0].get() && (g->dmap || n >= (1 << 16)) && g->canon[0].n_ids + 1 <= (1ll << 28)) {
+      KernelTimer kt_(ctx, "k_groups_dmap");
+      const int64_t dom = g->canon[0].n_ids + 1;
+      const uint32_t* cid = (const uint32_t*)sub[0].get()->values->ptr;
+      const uint64_t* mk = mask ? (const uint64_t*)mask->ptr : nullptr;
+      if (!g->dmap) {
+        g->dmap = alloc_buffer(ctx, (size_t)dom * 4); g->dmap_size = dom;
+        HIP_CHECK(hipMemsetAsync(g->dmap->ptr, 0xFF, (size_t)dom * 4, ctx->stream));
+        if (g->n_groups) { hipLaunchKernelGGL(k_dm_seed, dim3(grid_for(g->n_groups, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)g->canon_keys[0]->values->ptr, g->n_groups, (uint32_t*)g->dmap->ptr); KERNEL_CHECK(); }
+      }
+      if (g->dmap_size != dom) fail(DFGPU_INTERNAL, "dictionary group map changed size");
+      BufferPtr first = alloc_buffer(ctx, (size_t)dom * 4), heads = alloc_buffer(ctx, bitmap_bytes(n));
+      HIP_CHECK(hipMemsetAsync(first->ptr, 0xFF, (size_t)dom * 4, ctx->stream));
+      dim3 rgrid(grid_for(n, BLOCK * DM_ROWS)), block(BLOCK);
+      hipLaunchKernelGGL(k_dm_first, rgrid, block, 0, ctx->stream, cid, n, mk, (const uint32_t*)g->dmap->ptr, (uint32_t*)first->ptr);
+      hipLaunchKernelGGL(k_dm_heads, rgrid, block, 0, ctx->stream, cid, n, mk, (const uint32_t*)g->dmap->ptr, (const uint32_t*)first->ptr, (uint64_t*)heads->ptr);
+      KERNEL_CHECK();
+      ArrayHolder firsts(mask_to_indices_impl(ctx, (const uint64_t*)heads->ptr, n));
+      int64_t n_new = firsts.get()->length;
+      if (g->n_groups + n_new >= (int64_t)G_NEW) fail(DFGPU_RESOURCES_EXHAUSTED, "more than 2^31 groups");
+      if (n_new) {
+        ArrayHolder nc(new_fixed(ctx, DFGPU_UINT32, n_new));
+        hipLaunchKernelGGL(k_dm_assign, dim3(grid_for(n_new, BLOCK)), block, 0, ctx->stream, (const uint32_t*)firsts.get()->values->ptr, n_new, cid, (uint32_t)g->n_groups, (uint32_t*)g->dmap->ptr, (uint32_t*)nc.get()->values->ptr);
+        KERNEL_CHECK();
+        groups_append_keys(ctx, g, cols, nkeys, firsts.get(), n_new);
+        dfgpu_array*& dst = g->canon_keys[0];             // the groups' canonical ids, should a later batch fall back to the table
+        if (!dst) dst = nc.release();
+        else { const dfgpu_array* parts[2] = { dst, nc.get() }; dfgpu_array* cat = nullptr; dfgpu_status st = dfgpu_concat(ctx, parts, 2, &cat); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str()); dfgpu_array_release(dst); dst = cat; }
+        check_flags(ctx, "groups_intern");
+      }
+      hipLaunchKernelGGL(k_dm_ids, rgrid, block, 0, ctx->stream, cid, n, mk, (const uint32_t*)g->dmap->ptr, (uint32_t*)ids.get()->values->ptr);
+      KERNEL_CHECK();
+      g->n_groups += n_new;
+      *out_group_ids = ids.release();
+      return;
     }
     KeySet hk = make_keyset(eff.data(), nkeys);
     KeySet stored{}; int has_stored = 0;

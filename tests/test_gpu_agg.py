@@ -513,3 +513,37 @@ def test_count_takes_the_avg_count_delta_in_large_many_group_batches(ctx):
     for a, b in zip(multi, single):
         for s1, s2 in zip(a.state(), b.state()):
             check_equal(s1.to_arrow(), s2.to_arrow(), True)
+
+
+@pytest.mark.parametrize("small_first", [False, True])
+def test_single_dictionary_key_with_a_large_domain_uses_the_direct_map(ctx, small_first):
+    """One dictionary key column whose canonical domain is beyond the dense map (here 6000 values, two codes sharing a value, a NULL value,
+    NULL codes): from 2^16 rows on groups.hip numbers groups through dmap[canonical id] instead of a hash table.  First-seen ids and
+    emitted keys must equal the oracle's over batches sharing the dictionary (one with a fused mask, one single row), also when a small
+    first batch went through the hash table (the map is seeded from its groups), and after a batch with ANOTHER dictionary dropped the
+    groups back to value keys."""
+    import dfgpu
+    words = [f"w{k:05d}" for k in range(6000)]
+    words[17] = words[4000]; words[99] = None
+    dictionary = pa.array(words, type=pa.utf8())
+    n = 200000
+    codes = pa.array(RNG.integers(0, 6000, n).astype(np.int32), mask=RNG.random(n) < 0.02)
+    col = pa.DictionaryArray.from_arrays(codes, dictionary)
+    dev = ctx.from_arrow(col)
+    gv, og = dfgpu.GroupValues(ctx, 1), po.Groups([pa.utf8()])
+    cuts = [(0, 300), (300, 100000)] if small_first else [(0, 100000)]
+    for lo, hi in cuts + [(100000, 100001)]:
+        got = gv.intern([dev.slice(lo, hi - lo)]).to_numpy().astype(np.int64)
+        assert np.array_equal(got, og.intern([col.slice(lo, hi - lo)])), f"rows {lo}:{hi}"
+    m = RNG.random(n - 100001) < 0.5
+    got = gv.intern([dev.slice(100001, n - 100001)], mask=ctx.from_arrow(pa.array(m))).to_numpy()
+    want = og.intern([col.slice(100001, n - 100001).filter(pa.array(m))])
+    assert np.array_equal(got[m].astype(np.int64), want) and (got[~m] == 0xFFFFFFFF).all()
+    other = pa.array([None if v % 11 == 0 else f"w{v:05d}" for v in RNG.integers(5000, 7000, 70000)], type=pa.utf8()).dictionary_encode()
+    got = gv.intern([ctx.from_arrow(other)]).to_numpy().astype(np.int64)                    # another dictionary: value keys from here on
+    assert np.array_equal(got, og.intern([other]))
+    got = gv.intern([dev.slice(0, 70000)]).to_numpy().astype(np.int64)
+    assert np.array_equal(got, og.intern([col.slice(0, 70000)]))
+    assert len(gv) == len(og)
+    for a, w in zip(gv.emit(), og.emit()):
+        assert a.to_arrow().equals(w)
