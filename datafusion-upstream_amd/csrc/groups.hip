@@ -240,6 +240,35 @@ __global__ void __launch_bounds__(BLOCK) k_dense_first_fast(DenseCols dc, int64_
   __syncthreads();
   for (int t = threadIdx.x; t < dsize; t += BLOCK) if (dense_map[t] == G_NONE && lfirst[t] != G_NONE) atomicMin(&first[t], lfirst[t]);
 }
+// Same pass with the code tuple -> composite table composed in LDS per workgroup (the two dependent global lookups of
+// dense_composite_fast become one LDS read) and 4 consecutive rows per lane (one load per code column and 4 rows).  Host checks:
+// len0 * len1 <= DENSE_MAX and 16-byte aligned code columns.
+template <typename K, int NC, bool HAS_MASK>
+__global__ void __launch_bounds__(BLOCK) k_dense_first_tab(DenseCols dc, int64_t n, const uint64_t* mask, const uint32_t* dense_map, uint32_t* first, int dsize, int len1) {
+  __shared__ uint32_t lfirst[DENSE_MAX]; __shared__ uint16_t ctab[DENSE_MAX];
+  const int tsize = (int)dc.c[0].dict_len * len1;
+  for (int t = threadIdx.x; t < dsize; t += BLOCK) lfirst[t] = dense_map[t] == G_NONE ? G_NONE : 0u;
+  for (int t = threadIdx.x; t < tsize; t += BLOCK) ctab[t] = (uint16_t)(dc.c[0].canon[t / len1] * dc.c[0].stride + (NC == 2 ? dc.c[1].canon[t % len1] * dc.c[1].stride : 0u));
+  __syncthreads();
+  struct alignas(sizeof(K) * 4) K4 { K v[4]; };
+  const int64_t nvec = n / 4;
+  for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * BLOCK) {
+    const int64_t i0 = v * 4;
+    K4 a = *(const K4*)((const K*)dc.c[0].keys + i0); K4 b{}; if (NC == 2) b = *(const K4*)((const K*)dc.c[1].keys + i0);
+    uint64_t m = HAS_MASK ? mask[i0 >> 6] >> (i0 & 63) : 0xFull;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      uint32_t comp = ctab[(uint32_t)a.v[r] * (uint32_t)len1 + (NC == 2 ? (uint32_t)b.v[r] : 0u)], i = (uint32_t)(i0 + r);
+      if (((m >> r) & 1ull) && lfirst[comp] > i) atomicMin(&lfirst[comp], i);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {           // ragged tail
+    int64_t i = nvec * 4 + threadIdx.x;
+    if (!HAS_MASK || bit_get(mask, i)) { uint32_t c = dense_composite_fast<K, NC>(dc, i); if (lfirst[c] > (uint32_t)i) atomicMin(&lfirst[c], (uint32_t)i); }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < dsize; t += BLOCK) if (dense_map[t] == G_NONE && lfirst[t] != G_NONE) atomicMin(&first[t], lfirst[t]);
+}
 template <typename K, int NC, bool HAS_MASK>
 __global__ void __launch_bounds__(BLOCK) k_dense_ids_fast(DenseCols dc, int64_t n, const uint64_t* mask, const uint32_t* dense_map, uint32_t* out) {
   int64_t base = (int64_t)blockIdx.x * BLOCK * DENSE_ROWS;
@@ -529,7 +558,11 @@ static dfgpu_status groups_intern_impl(dfgpu_ctx* ctx, dfgpu_groups* g, const df
           if (kt0 == DFGPU_INT8) { if (nkeys == 1) DENSE_FAST(int8_t, 1, WHICH, GRID, __VA_ARGS__); else DENSE_FAST(int8_t, 2, WHICH, GRID, __VA_ARGS__); } \
           else if (kt0 == DFGPU_INT16) { if (nkeys == 1) DENSE_FAST(int16_t, 1, WHICH, GRID, __VA_ARGS__); else DENSE_FAST(int16_t, 2, WHICH, GRID, __VA_ARGS__); } \
           else { if (nkeys == 1) DENSE_FAST(int32_t, 1, WHICH, GRID, __VA_ARGS__); else DENSE_FAST(int32_t, 2, WHICH, GRID, __VA_ARGS__); } } while (0)
-        if (fast) DENSE_DISPATCH(k_dense_first_fast, fgrid, dc, n, mk, (const uint32_t*)g->dense_map->ptr, (uint32_t*)first->ptr, (int)dsize);
+        const int64_t len1 = nkeys == 2 ? dc.c[1].dict_len : 1;
+        bool tab = fast && dc.c[0].dict_len * len1 <= DENSE_MAX && dsize <= 65535;
+        for (int c = 0; c < nkeys && tab; c++) tab = (((uintptr_t)dc.c[c].keys) & 15) == 0;
+        if (tab) DENSE_DISPATCH(k_dense_first_tab, grid_for(n, BLOCK * 4, ctx->num_cus * 8), dc, n, mk, (const uint32_t*)g->dense_map->ptr, (uint32_t*)first->ptr, (int)dsize, (int)len1);
+        else if (fast) DENSE_DISPATCH(k_dense_first_fast, fgrid, dc, n, mk, (const uint32_t*)g->dense_map->ptr, (uint32_t*)first->ptr, (int)dsize);
         else hipLaunchKernelGGL(k_dense_first, dim3(fgrid), block, 0, ctx->stream, dc, n, mk, (const uint32_t*)g->dense_map->ptr, (uint32_t*)first->ptr, (int)dsize);
         KERNEL_CHECK();
         std::vector<uint32_t> fh((size_t)dsize);
