@@ -547,3 +547,39 @@ def test_single_dictionary_key_with_a_large_domain_uses_the_direct_map(ctx, smal
     assert len(gv) == len(og)
     for a, w in zip(gv.emit(), og.emit()):
         assert a.to_arrow().equals(w)
+
+
+def test_new_paths_on_empty_masked_and_degenerate_inputs(ctx):
+    """Edge cases of the fused accumulate pass, the deferred ids and the direct map: zero rows, every row masked out or skipped, NULL-only
+    codes, a single group -- nothing is accumulated that should not be, no group appears that should not."""
+    import dfgpu
+    T = dfgpu.capi.FLOAT64
+    one = ctx.from_arrow(pa.array([1.0]))
+    nodes = [("column", 0, 0), ("scalar", 1, 0), ("*", 0, 1)]
+    # fused: zero rows, then rows that are all skipped (group id NONE) or all filtered
+    acc = dfgpu.GroupsAccumulator(ctx, KIND["SUM"], T)
+    dfgpu.GroupsAccumulator.update_batch_fused(ctx, [acc], [2], nodes, [ctx.from_arrow(pa.array([], type=pa.float64())), one], ctx.from_arrow(pa.array([], type=pa.uint32())), None, 3)
+    assert acc.evaluate().to_arrow().to_pylist() == [None, None, None]
+    x = ctx.from_arrow(pa.array(np.arange(5000, dtype=np.float64)))
+    dfgpu.GroupsAccumulator.update_batch_fused(ctx, [acc], [2], nodes, [x, one], ctx.from_arrow(pa.array(np.full(5000, 0xFFFFFFFF, dtype=np.uint32))), None, 3)
+    dfgpu.GroupsAccumulator.update_batch_fused(ctx, [acc], [2], nodes, [x, one], ctx.from_arrow(pa.array(np.zeros(5000, dtype=np.uint32))), ctx.from_arrow(pa.array(np.zeros(5000, dtype=bool))), 3)
+    assert acc.evaluate().to_arrow().to_pylist() == [None, None, None]
+    dfgpu.GroupsAccumulator.update_batch_fused(ctx, [acc], [2], nodes, [x, one], ctx.from_arrow(pa.array(np.ones(5000, dtype=np.uint32))), None, 3)
+    assert acc.evaluate().to_arrow().to_pylist() == [None, float(np.arange(5000).sum()), None]
+    # deferred dense ids with every row masked out, then a batch that brings the groups
+    w = pa.array(["A", "B"], type=pa.utf8())
+    codes = pa.DictionaryArray.from_arrays(pa.array(RNG.integers(0, 2, 3000).astype(np.int8)), w)
+    gv = dfgpu.GroupValues(ctx, 1)
+    ids = gv.intern([ctx.from_arrow(codes)], mask=ctx.from_arrow(pa.array(np.zeros(3000, dtype=bool))), deferred=True)
+    assert len(gv) == 0 and (ids.to_numpy() == 0xFFFFFFFF).all()
+    ids = gv.intern([ctx.from_arrow(codes)], deferred=True)
+    assert len(gv) == 2 and set(ids.to_numpy().tolist()) == {0, 1}
+    # direct map: NULL-only codes are one group; an all-masked batch adds nothing
+    big = pa.array([f"v{k}" for k in range(5000)], type=pa.utf8())
+    n = 70000
+    nulls = pa.DictionaryArray.from_arrays(pa.array(np.zeros(n, dtype=np.int32), mask=np.ones(n, dtype=bool)), big)
+    gv = dfgpu.GroupValues(ctx, 1)
+    assert (gv.intern([ctx.from_arrow(nulls)]).to_numpy() == 0).all() and len(gv) == 1 and gv.emit()[0].to_arrow().to_pylist() == [None]
+    some = pa.DictionaryArray.from_arrays(pa.array(RNG.integers(0, 5000, n).astype(np.int32)), big)
+    got = gv.intern([ctx.from_arrow(some)], mask=ctx.from_arrow(pa.array(np.zeros(n, dtype=bool)))).to_numpy()
+    assert (got == 0xFFFFFFFF).all() and len(gv) == 1

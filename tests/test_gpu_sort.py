@@ -144,3 +144,13 @@ def test_large_input_sort_with_packed_moving_keys(ctx, shape):
         desc, nf = [False, True], [True, True]
     got = ctx.sort_to_indices([ctx.from_arrow(c) for c in cols], desc, nf).to_numpy()
     assert np.array_equal(got, po.lexsort_to_indices(cols, desc, nf))
+
+
+def test_large_sort_degenerate_keys(ctx):
+    """2^20 rows exactly: all keys equal (no varying plane: the order is the input order), and a single varying byte."""
+    n = 1 << 20
+    same = pa.array(np.full(n, 7, dtype=np.int64))
+    assert np.array_equal(ctx.sort_to_indices([ctx.from_arrow(same)], [True], [True]).to_numpy(), np.arange(n))
+    one_byte = pa.array((np.arange(n) % 3).astype(np.int32))
+    got = ctx.sort_to_indices([ctx.from_arrow(one_byte)], [True], [False]).to_numpy()
+    assert np.array_equal(got, po.lexsort_to_indices([one_byte], [True], [False]))
