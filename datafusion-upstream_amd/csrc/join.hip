@@ -117,6 +117,60 @@ __global__ void __launch_bounds__(BLOCK) k_probe_match_hash(KeySet bks, KeySet p
   uint64_t m = ballot64(hit);
   if (lane_id() == 0 && (j >> 6) < ((n + 63) >> 6)) match_bits[j >> 6] = m;
 }
+// The same pass for the plain case -- one or two 8-byte integer key columns, no NULLs on either side: HP_ROWS rows per lane, each
+// level of the chain (key -> first slot -> build key behind a matching tag) issued for all of them before the next; the rare longer
+// probe sequences finish row by row.  The slot a row was found in is kept (4 B per probe row), so pass 2 is a gather through the
+// match list instead of a second hash probe.
+constexpr int HP_ROWS = 4;
+template <int NK, bool HAS_MASK>
+__global__ void __launch_bounds__(BLOCK) k_probe_hash_i64(const uint64_t* b0, const uint64_t* b1, const uint64_t* p0, const uint64_t* p1, int64_t n, const uint64_t* mask,
+                                                          const uint64_t* slots, uint64_t cap_mask, uint64_t* match_bits, uint32_t* found_slot) {
+  const int64_t base = (int64_t)blockIdx.x * BLOCK * HP_ROWS + threadIdx.x;
+  uint64_t k0[HP_ROWS], k1[HP_ROWS], tag[HP_ROWS], sl[HP_ROWS], cur[HP_ROWS], v0[HP_ROWS], v1[HP_ROWS]; bool on[HP_ROWS];
+#pragma unroll
+  for (int q = 0; q < HP_ROWS; q++) {
+    int64_t i = base + (int64_t)q * BLOCK, ic = i < n ? i : n - 1;
+    on[q] = i < n && (!HAS_MASK || bit_get(mask, i));
+    k0[q] = p0[ic]; k1[q] = NK == 2 ? p1[ic] : 0;
+  }
+#pragma unroll
+  for (int q = 0; q < HP_ROWS; q++) {
+    uint64_t h = mix64(k0[q]); if (NK == 2) h = combine_hashes(mix64(k1[q]), h);          // keyset_hash over the key columns, seed 0
+    tag[q] = h >> 32; sl[q] = h & cap_mask;
+  }
+#pragma unroll
+  for (int q = 0; q < HP_ROWS; q++) cur[q] = slots[sl[q]];
+#pragma unroll
+  for (int q = 0; q < HP_ROWS; q++) { uint64_t r = (cur[q] != SLOT_EMPTY && (cur[q] >> 32) == tag[q]) ? (cur[q] & 0xFFFFFFFFull) : 0; v0[q] = b0[r]; v1[q] = NK == 2 ? b1[r] : 0; }
+#pragma unroll
+  for (int q = 0; q < HP_ROWS; q++) {
+    bool hit = false;
+    if (on[q]) {
+      uint64_t c = cur[q], s2 = sl[q];
+      if (c != SLOT_EMPTY && (c >> 32) == tag[q] && v0[q] == k0[q] && (NK == 1 || v1[q] == k1[q])) hit = true;
+      else if (c != SLOT_EMPTY) {
+        for (uint64_t step = 0; step < cap_mask; step++) {
+          s2 = (s2 + 1) & cap_mask; c = slots[s2];
+          if (c == SLOT_EMPTY) break;
+          if ((c >> 32) == tag[q]) { uint64_t r = c & 0xFFFFFFFFull; if (b0[r] == k0[q] && (NK == 1 || b1[r] == k1[q])) { hit = true; break; } }
+        }
+      }
+      if (hit) found_slot[base + (int64_t)q * BLOCK] = (uint32_t)s2;
+    }
+    int64_t i = base + (int64_t)q * BLOCK;
+    uint64_t m = ballot64(hit);
+    if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) match_bits[i >> 6] = m;
+  }
+}
+// pass 2 after k_probe_hash_i64: the build row (unique keys) or the slot and its group size (repeated keys) of every match
+__global__ void __launch_bounds__(BLOCK) k_probe_found(const uint32_t* rows, int64_t m, const uint32_t* found_slot, const uint64_t* slots, const uint32_t* slot_count, int unique,
+                                                       uint64_t* out_build, uint32_t* out_slot, uint32_t* out_cnt) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= m) return;
+  uint32_t s2 = found_slot[rows[i]];
+  if (unique) out_build[i] = slots[s2] & 0xFFFFFFFFull;
+  else { out_slot[i] = s2; out_cnt[i] = slot_count[s2]; }
+}
 // dense integer key domain: stream the probe keys, test one bit each
 constexpr int PM_ROWS = 8;          // rows per lane: 4 iterations x 2 consecutive keys (one 16-B load for Int64 keys)
 __device__ inline uint64_t spread32(uint64_t x) {      // bit i -> bit 2i
@@ -580,7 +634,7 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
     int nen = t->null_equals_null ? 1 : 0, fz = ctx->force_hash_collisions ? 1 : 0;
     // pass 1: match bit per probe row
     BufferPtr match_bits = alloc_buffer(ctx, bitmap_bytes(n), n == 0);
-    bool use_bitmap = false;
+    bool use_bitmap = false, fast_hash = false; BufferPtr found_slot;
     if (n) {
       const dfgpu_array* pk = probe_keys[0];
       if (!t->bitmap && t->lazy_bitmap && pk->type == t->keys[0]->type && t->range <= (uint64_t)n * 16) {
@@ -604,6 +658,18 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
 #undef PM_LAUNCH
       } else {
         KernelTimer kt_(ctx, "k_probe_match_hash");
+        auto plain8 = [](const dfgpu_array* a) { return (a->type == DFGPU_INT64 || a->type == DFGPU_UINT64) && !a->validity; };
+        fast_hash = (nkeys == 1 || nkeys == 2) && !nen && !fz && t->n_build > 0;
+        for (int c = 0; c < nkeys && fast_hash; c++) fast_hash = plain8(probe_keys[c]) && plain8(t->keys[(size_t)c]);
+        if (fast_hash) {
+          found_slot = alloc_buffer(ctx, (size_t)n * 4);
+          const uint64_t *b0 = (const uint64_t*)t->keys[0]->values->ptr, *b1 = nkeys == 2 ? (const uint64_t*)t->keys[1]->values->ptr : nullptr;
+          const uint64_t *p0 = (const uint64_t*)probe_keys[0]->values->ptr, *p1 = nkeys == 2 ? (const uint64_t*)probe_keys[1]->values->ptr : nullptr;
+          dim3 hgrid(grid_for(n, BLOCK * HP_ROWS));
+#define HP(NK, HM) hipLaunchKernelGGL((k_probe_hash_i64<NK, HM>), hgrid, dim3(BLOCK), 0, ctx->stream, b0, b1, p0, p1, n, mk, (const uint64_t*)t->slots->ptr, t->capacity - 1, (uint64_t*)match_bits->ptr, (uint32_t*)found_slot->ptr)
+          if (nkeys == 1) { if (mk) HP(1, true); else HP(1, false); } else { if (mk) HP(2, true); else HP(2, false); }
+#undef HP
+        } else
         hipLaunchKernelGGL(k_probe_match_hash, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, t->ks, pks, n, mk, nen, fz, (const uint64_t*)t->slots->ptr, t->capacity - 1, (uint64_t*)match_bits->ptr);
       }
       KERNEL_CHECK();
@@ -648,6 +714,9 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
     } else if (t->unique) {
       ob.a = new_fixed(ctx, DFGPU_UINT64, m);
       if (m) { KernelTimer kt_(ctx, "k_probe_lookup");
+        if (fast_hash) hipLaunchKernelGGL(k_probe_found, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, rp, m, (const uint32_t*)found_slot->ptr, (const uint64_t*)t->slots->ptr, (const uint32_t*)nullptr, 1,
+                                          (uint64_t*)ob.get()->values->ptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+        else
         hipLaunchKernelGGL(k_probe_lookup, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, t->ks, pks, rp, m, nen, fz, (const uint64_t*)t->slots->ptr, (const uint32_t*)nullptr,
                            t->capacity - 1, 1, (uint64_t*)ob.get()->values->ptr, (uint32_t*)nullptr, (uint32_t*)nullptr, ctx->d_flags); }
       KERNEL_CHECK();
@@ -657,6 +726,9 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
       int64_t total = 0;
       if (m) {
         { KernelTimer kt_(ctx, "k_probe_lookup");
+        if (fast_hash) hipLaunchKernelGGL(k_probe_found, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, rp, m, (const uint32_t*)found_slot->ptr, (const uint64_t*)t->slots->ptr, (const uint32_t*)t->slot_count->ptr, 0,
+                                          (uint64_t*)nullptr, (uint32_t*)slot_of->ptr, (uint32_t*)cnt->ptr);
+        else
         hipLaunchKernelGGL(k_probe_lookup, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, t->ks, pks, rp, m, nen, fz, (const uint64_t*)t->slots->ptr, (const uint32_t*)t->slot_count->ptr,
                            t->capacity - 1, 0, (uint64_t*)nullptr, (uint32_t*)slot_of->ptr, (uint32_t*)cnt->ptr, ctx->d_flags); }
         KERNEL_CHECK();
