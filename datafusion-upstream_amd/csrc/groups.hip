@@ -666,7 +666,10 @@ static dfgpu_status groups_intern_impl(dfgpu_ctx* ctx, dfgpu_groups* g, const df
     if (g->capacity < want) groups_alloc_table(g, want);
     int64_t n_new = 0;
     for (;;) {
-      uint64_t max_steps = g->capacity - 1 < 4096 ? g->capacity - 1 : 4096;
+      // a probe sequence this long means the table is ~95 % full (linear probing: ~1 / (2 (1 - load)^2) steps): stop and grow now rather
+      // than crawl to 4096-step sequences first.  Forced collisions put every key in one sequence: its length says nothing there.
+      uint64_t step_cap = ctx->force_hash_collisions ? 4096 : 256;
+      uint64_t max_steps = g->capacity - 1 < step_cap ? g->capacity - 1 : step_cap;
       zero_scratch(ctx);
       { KernelTimer kt_(ctx, "k_groups_find");
       hipLaunchKernelGGL(k_groups_find, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, hk, stored, has_stored, n, mask ? (const uint64_t*)mask->ptr : nullptr,
