@@ -8,6 +8,9 @@ rows/s = input rows / wall time; per-kernel device time from one fully bracketed
   q1_float64   the same with Float64 money columns ("fp64 accumulators")                  [38 B/row]
   q18_groups   the Q18 subquery: GROUP BY l_orderkey (one Int64 key, 1/4 rows distinct) SUM(l_quantity) -> Filter SUM > 300
                (GroupValuesPrimitive at 150 M groups for SF100)                            [24 B/row]
+  hash_join    HashJoinExec on sparse random Int64 keys (no rank index, no bitmap): 150 K x sf build rows, 1.5 M x sf probe rows, 20 % match,
+               SUM + COUNT over the join output  [8 B/build row + 16 B/probe row]
+  groupby_int64  GROUP BY an unclustered Int64 key (hash table path), 1 M and 20 M groups over 1 M x sf rows, SUM + COUNT, top 10  [16 B/row]
   sort         SortExec over 1 M x sf rows: ORDER BY l_extendedprice DESC, l_shipdate, three columns materialised in the new order
                [28 B/row in + 28 B/row out]
   clickbench   ClickBench Q28 shape: filter key <> '' -> GROUP BY a dictionary-encoded Utf8 key -> AVG(Int32 as f64), COUNT(*),
@@ -235,6 +238,37 @@ def main():
         report("q18", dt, rows_in, rows, round(bytes_total / rows_in, 2), kern, syncs)
         del customer, orders, line, plan, qty, o_totalprice, o_custkey, o_orderdate, o_orderkey
         torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ general-case operators: keys that are neither clustered nor dense
+    if not want or "hash_join" in want:
+        nb, npr = int(150_000 * args.sf), int(1_500_000 * args.sf)
+        bk = torch.randint(0, 2**62, (nb,), generator=g, device="cuda", dtype=torch.int64)
+        pk = torch.cat([bk[torch.randint(0, nb, (npr // 5,), generator=g, device="cuda")], torch.randint(0, 2**62, (npr - npr // 5,), generator=g, device="cuda", dtype=torch.int64)])
+        pk = pk[torch.randperm(npr, generator=g, device="cuda")]
+        pv = torch.randint(0, 10**6, (npr,), generator=g, device="cuda", dtype=torch.int64)
+        torch.cuda.synchronize()
+        left = ops.RecordBatch.from_arrays(ctx, ["k"], [ctx.wrap_tensor(bk, capi.INT64)])
+        right = ops.RecordBatch.from_arrays(ctx, ["k", "v"], [ctx.wrap_tensor(pk, capi.INT64), ctx.wrap_tensor(pv, capi.INT64)])
+        j = ops.HashJoinExec(ops.MemoryExec([[left]], left.schema), ops.MemoryExec([[right]], right.schema), [(C("k", 0), C("k", 0))], None, "Inner", "CollectLeft")
+        plan = ops.AggregateExec("Single", [], [ops.AggregateFunctionExpr("SUM", C("v", 2), "s", input_field=F("v", capi.INT64)), ops.AggregateFunctionExpr("COUNT", None, "c")], j)
+        dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan, args.steps, args.warmup)
+        report("hash_join_sparse_keys", dt, nb + npr, rows, round((nb * 8 + npr * 16) / (nb + npr), 2), kern, syncs, {"build_rows": nb, "probe_rows": npr, "match_fraction": 0.2})
+        del bk, pk, pv, left, right, plan
+        torch.cuda.empty_cache()
+    if not want or "groupby_int64" in want:
+        ng = int(1_000_000 * args.sf)
+        for total in (10**6, 2 * 10**7):
+            keys = torch.randint(0, total, (ng,), generator=g, device="cuda", dtype=torch.int64) * 7919
+            val = torch.randint(0, 10**6, (ng,), generator=g, device="cuda", dtype=torch.int64)
+            torch.cuda.synchronize()
+            b = ops.RecordBatch.from_arrays(ctx, ["k", "v"], [ctx.wrap_tensor(keys, capi.INT64), ctx.wrap_tensor(val, capi.INT64)])
+            agg = ops.AggregateExec("Single", [(C("k", 0), "k")], [ops.AggregateFunctionExpr("SUM", C("v", 1), "s", input_field=F("v", capi.INT64)), ops.AggregateFunctionExpr("COUNT", None, "c")],
+                                    ops.MemoryExec([[b]], b.schema))
+            plan = ops.SortExec([ops.PhysicalSortExpr(C("s", 1), True, True), ops.PhysicalSortExpr(C("k", 0), False, False)], agg, fetch=10)
+            dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan, args.steps, args.warmup)
+            report(f"groupby_int64_unclustered_{total}", dt, ng, rows, 16, kern, syncs, {"cardinality": total})
+            del keys, val, b, agg, plan
+            torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ SortExec at scale: ORDER BY l_extendedprice DESC, l_shipdate over 1 M x sf rows, 3 columns out
     if not want or "sort" in want:
