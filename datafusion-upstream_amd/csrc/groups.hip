@@ -44,6 +44,10 @@ struct dfgpu_groups {
   // direct map: ONE dictionary key column with a larger canonical domain: dmap[canonical id] = group id (or none) replaces the hash table
   // altogether -- the ids are dense in [0, n_ids], so "find or insert" is an array access
   BufferPtr dmap; int64_t dmap_size = 0;
+  // primitive-key table (≙ GroupValuesPrimitive, group_values/primitive.rs): ONE 8-byte integer key column without NULLs.  A slot is
+  // 16 bytes {key, group id, first row}: find-or-insert touches one sector per row (the general table needs the slot, its first-row
+  // word and the representative key behind a matching tag: three), and no stored-key column is consulted.
+  BufferPtr pslots; uint64_t pcap = 0; bool prim_mode = false, prim_banned = false;
   ~dfgpu_groups() { for (auto* a : keys) if (a) dfgpu_array_release(a); for (auto* a : canon_keys) if (a) dfgpu_array_release(a); for (auto& c : canon) if (c.dict) dfgpu_array_release(c.dict); }
 };
 
@@ -64,7 +68,7 @@ __global__ void __launch_bounds__(BLOCK) k_groups_find(KeySet bk, KeySet stored,
     // popcount of the first-row bitmap computed afterwards.  A table that fills up shows as a probe sequence longer
     // than max_steps; the flag is polled so that the remaining workgroups drain quickly before the host retries.
     for (uint64_t step = 0; step <= max_steps && !done; step++) {
-      if ((step & 63) == 63 && __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      if ((step & 15) == 0 && __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;       // also before the first step: rows that start after an overflow leave at once
       uint64_t cur = slots[s];
       if (cur == G_EMPTY) {
         cur = atomicCAS((unsigned long long*)&slots[s], (unsigned long long)G_EMPTY, (unsigned long long)mine);
@@ -88,6 +92,78 @@ __global__ void __launch_bounds__(BLOCK) k_groups_find(KeySet bk, KeySet stored,
   }
   tmp[i] = res;
 }
+// ---------------------------------------------------------------- primitive-key table
+struct alignas(16) PSlot { unsigned long long key; uint32_t gid; uint32_t first; };     // all-ones = empty key / no group id yet / no first row
+constexpr unsigned long long P_EMPTY = ~0ull;
+constexpr int PF_ROWS = 4;
+// tmp[i] = slot of row i's key (G_NONE for masked rows).  New keys are claimed by a CAS on the key word; every row of a key without a
+// group id lowers the slot's first-row word (read first: it only moves down).  counters[1] = table too full, counters[3] = a key equals
+// the empty marker (the caller leaves this table for the general one).
+template <bool HAS_MASK>
+__global__ void __launch_bounds__(BLOCK) k_prim_find(const unsigned long long* keys, int64_t n, const uint64_t* mask, PSlot* slots, uint64_t cap_mask, uint32_t* tmp,
+                                                     unsigned long long* counters, uint64_t max_steps) {
+  const int64_t base = (int64_t)blockIdx.x * BLOCK * PF_ROWS + threadIdx.x;
+  unsigned long long k[PF_ROWS]; uint64_t sl[PF_ROWS]; PSlot cur[PF_ROWS]; bool on[PF_ROWS];
+#pragma unroll
+  for (int q = 0; q < PF_ROWS; q++) { int64_t i = base + (int64_t)q * BLOCK; on[q] = i < n && (!HAS_MASK || bit_get(mask, i)); k[q] = keys[i < n ? i : n - 1]; }
+#pragma unroll
+  for (int q = 0; q < PF_ROWS; q++) sl[q] = mix64(k[q] ^ GROUP_SEED) & cap_mask;
+#pragma unroll
+  for (int q = 0; q < PF_ROWS; q++) cur[q] = slots[sl[q]];                  // one 16-byte load per row, all rows in flight
+#pragma unroll
+  for (int q = 0; q < PF_ROWS; q++) {
+    const int64_t i = base + (int64_t)q * BLOCK;
+    if (i >= n) continue;
+    uint32_t res = G_NONE;
+    if (on[q] && k[q] == P_EMPTY) counters[3] = 1ull;
+    else if (on[q]) {
+      uint64_t s = sl[q]; unsigned long long c = cur[q].key; uint32_t gid = cur[q].gid, first = cur[q].first; bool done = false;
+      for (uint64_t step = 0; step <= max_steps; step++) {
+        if ((step & 15) == 0 && __hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;       // the table overflowed somewhere: drain (also before the first step)
+        if (step) { PSlot t = slots[s]; c = t.key; gid = t.gid; first = t.first; }
+        if (c == P_EMPTY) { c = atomicCAS(&slots[s].key, P_EMPTY, k[q]); if (c == P_EMPTY) c = k[q]; gid = 0xFFFFFFFFu; first = 0xFFFFFFFFu; }
+        if (c == k[q]) { done = true; break; }
+        s = (s + 1) & cap_mask;
+      }
+      if (!done) counters[1] = 1ull;
+      else { res = (uint32_t)s; if (gid == 0xFFFFFFFFu && first > (uint32_t)i) atomicMin(&slots[s].first, (uint32_t)i); }
+    }
+    tmp[i] = res;
+  }
+}
+// slots claimed in this batch: key set, no group id yet
+__global__ void __launch_bounds__(BLOCK) k_prim_new_bits(const PSlot* slots, int64_t cap, uint64_t* bits) {
+  int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  bool f = false;
+  if (s < cap) { PSlot t = slots[s]; f = t.key != P_EMPTY && t.gid == 0xFFFFFFFFu && t.first != 0xFFFFFFFFu; }
+  uint64_t m = ballot64(f);
+  if (lane_id() == 0 && (s >> 6) < ((cap + 63) >> 6)) bits[s >> 6] = m;
+}
+__global__ void __launch_bounds__(BLOCK) k_prim_first_of(const uint32_t* new_slots, int64_t n_new, const PSlot* slots, uint32_t* first) {
+  int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (r < n_new) first[r] = slots[new_slots[r]].first;
+}
+__global__ void __launch_bounds__(BLOCK) k_prim_assign(const uint32_t* new_slots, int64_t n_new, uint32_t base, PSlot* slots) {
+  int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (r < n_new) slots[new_slots[r]].gid = base + (uint32_t)r;
+}
+__global__ void __launch_bounds__(BLOCK) k_prim_ids(const uint32_t* tmp, int64_t n, const PSlot* slots, uint32_t* out) {
+  const int64_t base = (int64_t)blockIdx.x * BLOCK * PF_ROWS + threadIdx.x;
+  uint32_t t[PF_ROWS], g[PF_ROWS];
+#pragma unroll
+  for (int q = 0; q < PF_ROWS; q++) { int64_t i = base + (int64_t)q * BLOCK; t[q] = tmp[i < n ? i : n - 1]; }
+#pragma unroll
+  for (int q = 0; q < PF_ROWS; q++) g[q] = t[q] == G_NONE ? G_NONE : slots[t[q]].gid;
+#pragma unroll
+  for (int q = 0; q < PF_ROWS; q++) { int64_t i = base + (int64_t)q * BLOCK; if (i < n) out[i] = g[q]; }
+}
+// (re)build: the numbered groups' keys into an empty table (keys are distinct)
+__global__ void __launch_bounds__(BLOCK) k_prim_insert(const unsigned long long* gkeys, int64_t n_groups, PSlot* slots, uint64_t cap_mask) {
+  int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (g >= n_groups) return;
+  unsigned long long k = gkeys[g]; uint64_t s = mix64(k ^ GROUP_SEED) & cap_mask;
+  for (;;) { unsigned long long c = atomicCAS(&slots[s].key, P_EMPTY, k); if (c == P_EMPTY) break; s = (s + 1) & cap_mask; }
+  slots[s].gid = (uint32_t)g; slots[s].first = 0u;
+}
+
 __global__ void __launch_bounds__(BLOCK) k_groups_mark_first(const uint32_t* tmp, const uint32_t* first_row, int64_t n, uint64_t* bits) {
   int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   bool f = false;
@@ -404,7 +480,7 @@ void dfgpu_groups_free(dfgpu_groups* g) { delete g; }
 int64_t dfgpu_groups_len(const dfgpu_groups* g) { return g ? g->n_groups : 0; }
 int64_t dfgpu_groups_size(const dfgpu_groups* g) {
   if (!g) return 0;
-  int64_t b = (int64_t)g->capacity * 12 + g->ghash_cap * 8;
+  int64_t b = (int64_t)g->capacity * 12 + g->ghash_cap * 8 + (int64_t)g->pcap * 16 + g->dmap_size * 4;
   for (auto* a : g->keys) if (a) b += (a->values ? (int64_t)a->values->bytes : 0) + (a->validity ? (int64_t)a->validity->bytes : 0) + (a->offsets ? (int64_t)a->offsets->bytes : 0);
   return b;
 }
@@ -491,6 +567,69 @@ static dfgpu_status groups_intern_impl(dfgpu_ctx* ctx, dfgpu_groups* g, const df
     // clustered keys: group ids are run numbers, no hash table (the shape of GROUP BY over a fact table stored in key order)
     if (ctx->group_run_detection && !ctx->force_hash_collisions && !mask && g->capacity == 0 && (g->n_groups == 0 || g->run_mode) && run_key_type(cols[0]) &&
         groups_intern_runs(ctx, g, cols, nkeys, bk, n, ids.get(), allow_deferred)) { *out_group_ids = ids.release(); return; }
+    // one 8-byte integer key column without NULLs: the primitive-key table
+    auto plain8 = [](const dfgpu_array* a) { return a && (a->type == DFGPU_INT64 || a->type == DFGPU_UINT64) && !a->validity; };
+    const bool prim_ok = nkeys == 1 && !ctx->force_hash_collisions && !g->prim_banned && !g->canon_mode && g->capacity == 0 && plain8(cols[0]) && (g->n_groups == 0 || plain8(g->keys[0]));
+    if (g->prim_mode && !prim_ok) { g->prim_mode = false; g->pslots.reset(); g->pcap = 0; g->run_mode = g->n_groups > 0; }      // NULLs / another type arrived: re-hash the stored groups below
+    if (prim_ok) {
+      const uint64_t* mk = mask ? (const uint64_t*)mask->ptr : nullptr;
+      const unsigned long long* kp = (const unsigned long long*)cols[0]->values->ptr;
+      auto rebuild = [&](uint64_t cap) {
+        g->pslots = alloc_buffer(ctx, (size_t)cap * sizeof(PSlot)); g->pcap = cap;
+        HIP_CHECK(hipMemsetAsync(g->pslots->ptr, 0xFF, (size_t)cap * sizeof(PSlot), ctx->stream));
+        if (g->n_groups) { hipLaunchKernelGGL(k_prim_insert, dim3(grid_for(g->n_groups, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const unsigned long long*)g->keys[0]->values->ptr, g->n_groups, (PSlot*)g->pslots->ptr, cap - 1); KERNEL_CHECK(); }
+      };
+      uint64_t expect = (uint64_t)(n < (1 << 22) ? n : (1 << 22));
+      if (g->size_hint > 0) { uint64_t h = (uint64_t)g->size_hint < (uint64_t)n ? (uint64_t)g->size_hint : (uint64_t)n; if (h > expect) expect = h; }
+      uint64_t want = 1ull << 16; while (want < (uint64_t)g->n_groups * 4 + 2 * expect) want <<= 1;
+      if (g->pcap < want) rebuild(want);
+      g->prim_mode = true; g->run_mode = false;
+      BufferPtr tmp = alloc_buffer(ctx, (size_t)n * 4);
+      bool banned = false;
+      for (;;) {
+        zero_scratch(ctx);
+        { KernelTimer kt_(ctx, "k_groups_find");
+          dim3 fg(grid_for(n, BLOCK * PF_ROWS));
+          if (mk) hipLaunchKernelGGL((k_prim_find<true>), fg, dim3(BLOCK), 0, ctx->stream, kp, n, mk, (PSlot*)g->pslots->ptr, g->pcap - 1, (uint32_t*)tmp->ptr, (unsigned long long*)ctx->d_scratch64, (uint64_t)256);
+          else hipLaunchKernelGGL((k_prim_find<false>), fg, dim3(BLOCK), 0, ctx->stream, kp, n, mk, (PSlot*)g->pslots->ptr, g->pcap - 1, (uint32_t*)tmp->ptr, (unsigned long long*)ctx->d_scratch64, (uint64_t)256); }
+        KERNEL_CHECK();
+        HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 0, ctx->d_scratch64, 32, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->count_sync("sync:group_table");
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->h_pinned[3]) { banned = true; break; }
+        if (ctx->h_pinned[1] == 0) break;
+        if (g->pcap >= (1ull << 31)) fail(DFGPU_RESOURCES_EXHAUSTED, "group table would exceed 2^31 slots");
+        uint64_t ncap = g->pcap << 3; if (ncap > (1ull << 31)) ncap = 1ull << 31;
+        rebuild(ncap);                                            // the claims of the overfull pass go with the old table
+      }
+      if (banned) {                                               // a key equals the empty marker: this column takes the general table from now on
+        g->prim_banned = true; g->prim_mode = false; g->pslots.reset(); g->pcap = 0; g->run_mode = g->n_groups > 0;
+      } else {
+        BufferPtr bits = alloc_buffer(ctx, bitmap_bytes((int64_t)g->pcap));
+        hipLaunchKernelGGL(k_prim_new_bits, dim3(grid_for((int64_t)g->pcap, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const PSlot*)g->pslots->ptr, (int64_t)g->pcap, (uint64_t*)bits->ptr);
+        KERNEL_CHECK();
+        ArrayHolder new_slots(mask_to_indices_impl(ctx, (const uint64_t*)bits->ptr, (int64_t)g->pcap));
+        int64_t n_new = new_slots.get()->length;
+        if (g->n_groups + n_new >= (int64_t)G_NEW) fail(DFGPU_RESOURCES_EXHAUSTED, "more than 2^31 groups");
+        if (n_new) {
+          ArrayHolder firsts(new_fixed(ctx, DFGPU_UINT32, n_new));
+          hipLaunchKernelGGL(k_prim_first_of, dim3(grid_for(n_new, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)new_slots.get()->values->ptr, n_new, (const PSlot*)g->pslots->ptr, (uint32_t*)firsts.get()->values->ptr);
+          KERNEL_CHECK();
+          int bitsn = 1; while ((1ll << bitsn) < n) bitsn++;
+          radix_sort_pairs_u32(ctx, (uint32_t*)firsts.get()->values->ptr, (uint32_t*)new_slots.get()->values->ptr, n_new, bitsn);      // first-seen order
+          hipLaunchKernelGGL(k_prim_assign, dim3(grid_for(n_new, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)new_slots.get()->values->ptr, n_new, (uint32_t)g->n_groups, (PSlot*)g->pslots->ptr);
+          KERNEL_CHECK();
+          groups_append_keys(ctx, g, cols, nkeys, firsts.get(), n_new);
+          check_flags(ctx, "groups_intern");
+        }
+        hipLaunchKernelGGL(k_prim_ids, dim3(grid_for(n, BLOCK * PF_ROWS)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)tmp->ptr, n, (const PSlot*)g->pslots->ptr, (uint32_t*)ids.get()->values->ptr);
+        KERNEL_CHECK();
+        g->n_groups += n_new;
+        if ((uint64_t)g->n_groups * 2 > g->pcap) { uint64_t ncap = g->pcap; while (ncap < (uint64_t)g->n_groups * 4) ncap <<= 1; if (ncap > (1ull << 31)) ncap = 1ull << 31; rebuild(ncap); }
+        *out_group_ids = ids.release();
+        return;
+      }
+    }
     if (g->run_mode) {          // a batch broke the order: hash the groups numbered so far, the table is built below
       std::vector<const dfgpu_array*> sk(g->keys.begin(), g->keys.end()); KeySet stored_ks = make_keyset(sk.data(), nkeys);
       groups_reserve_ghash(ctx, g, g->n_groups, 0);

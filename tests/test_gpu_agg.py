@@ -583,3 +583,36 @@ def test_new_paths_on_empty_masked_and_degenerate_inputs(ctx):
     some = pa.DictionaryArray.from_arrays(pa.array(RNG.integers(0, 5000, n).astype(np.int32)), big)
     got = gv.intern([ctx.from_arrow(some)], mask=ctx.from_arrow(pa.array(np.zeros(n, dtype=bool)))).to_numpy()
     assert (got == 0xFFFFFFFF).all() and len(gv) == 1
+
+
+@pytest.mark.parametrize("scenario", ["plain", "after_runs", "nulls_arrive", "marker_key", "uint64"])
+def test_primitive_key_table_matches_the_oracle(ctx, scenario):
+    """One 8-byte integer key column without NULLs goes through the primitive-key table (key, group id and first-row word in one slot).
+    First-seen ids and emitted keys must equal the oracle's over several batches (a masked one, a single row, one that forces the table
+    to grow), after a clustered first batch (run numbering), when a later batch brings NULLs (the groups move to the general table),
+    and when a key equals the table's empty marker (-1: the column is banned from the primitive table)."""
+    import dfgpu
+    rng = np.random.default_rng(21)
+    t = pa.uint64() if scenario == "uint64" else pa.int64()
+    gv, og = dfgpu.GroupValues(ctx, 1), po.Groups([t])
+    def check(arr, mask=None):
+        got = gv.intern([ctx.from_arrow(arr)], mask=ctx.from_arrow(pa.array(mask)) if mask is not None else None).to_numpy()
+        if mask is None:
+            assert np.array_equal(got.astype(np.int64), og.intern([arr]))
+        else:
+            assert np.array_equal(got[mask].astype(np.int64), og.intern([arr.filter(pa.array(mask))])) and (got[~mask] == 0xFFFFFFFF).all()
+        assert len(gv) == len(og)
+    mk = (lambda v: pa.array(v.astype(np.uint64))) if scenario == "uint64" else (lambda v: pa.array(v.astype(np.int64)))
+    if scenario == "after_runs":
+        check(mk(np.repeat(np.arange(5000), 3) * 11))                                   # clustered: run numbering, no table yet
+    check(mk(rng.integers(0, 3000, 20000) * 7))
+    check(mk(rng.integers(0, 3000, 1)))
+    check(mk(rng.integers(0, 400000, 300000) * 13), mask=rng.random(300000) < 0.7)       # more new groups than the first table holds
+    if scenario == "nulls_arrive":
+        check(pa.array(rng.integers(0, 5000, 40000) * 7, mask=rng.random(40000) < 0.1))
+    if scenario == "marker_key":
+        v = rng.integers(0, 5000, 40000) * 7; v[::97] = -1
+        check(pa.array(v.astype(np.int64)))
+    check(mk(rng.integers(0, 500000, 100000) * 13))
+    for a, w in zip(gv.emit(), og.emit()):
+        assert a.to_arrow().equals(w)
