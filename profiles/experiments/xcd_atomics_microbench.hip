@@ -32,6 +32,17 @@ __global__ void k_xcd(const unsigned* g, const double* v, long n, double* acc, u
     }
   }
 }
+// Variant 3: no row partitioning -- every XCD owns a full REPLICA of the state array; a workgroup adds its rows into the replica of the
+// XCD it runs on (workgroup-scope atomics, that XCD's L2), a second kernel sums the 8 replicas.
+__global__ void k_replica(const unsigned* g, const double* v, long n, double* rep /*[8][G]*/, long G) {
+  double* mine = rep + (long)xcc_id() * G;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    __hip_atomic_fetch_add(&mine[g[i]], v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__global__ void k_reduce8(const double* rep, long G, double* acc) {
+  long k = (long)blockIdx.x * blockDim.x + threadIdx.x; if (k >= G) return;
+  double s = 0; for (int x = 0; x < 8; x++) s += rep[(long)x * G + k]; acc[k] = s;
+}
 int main() {
   const long n = 100000000; const unsigned G = 1000000;
   std::vector<unsigned> hg(n); std::vector<double> hv(n);
@@ -49,6 +60,15 @@ int main() {
     CK(hipEventRecord(e0)); hipLaunchKernelGGL(k_xcd, dim3(2048), dim3(256), 0, 0, g, v, n, a1, next, seen); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1)); printf("XCD-partitioned workgroup-scope atomics: %.3f ms\n", ms);
   }
+  double *rep, *a2; CK(hipMalloc(&rep, 8l * G * 8)); CK(hipMalloc(&a2, G * 8));
+  for (int r = 0; r < 3; r++) {
+    CK(hipMemset(rep, 0, 8l * G * 8)); CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_replica, dim3(2048), dim3(256), 0, 0, g, v, n, rep, (long)G);
+    hipLaunchKernelGGL(k_reduce8, dim3((G + 255) / 256), dim3(256), 0, 0, rep, (long)G, a2);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); printf("per-XCD replicas, workgroup-scope atomics + reduce: %.3f ms\n", ms);
+  }
+  { std::vector<double> r2(G), rr(G); CK(hipMemcpy(r2.data(), a2, G * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(rr.data(), a0, G * 8, hipMemcpyDeviceToHost));
+    long bad2 = 0; for (unsigned k = 0; k < G; k++) if (r2[k] != rr[k]) bad2++; printf("replica variant mismatching groups: %ld\n", bad2); }
   std::vector<double> r0(G), r1(G); unsigned hs[8], hn[8];
   CK(hipMemcpy(r0.data(), a0, G * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), a1, G * 8, hipMemcpyDeviceToHost));
   CK(hipMemcpy(hs, seen, 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(hn, next, 32, hipMemcpyDeviceToHost));
