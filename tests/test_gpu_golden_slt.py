@@ -38,3 +38,43 @@ def test_device_sort_exec_known_answers(eng, case):
 @pytest.mark.parametrize("case", AGG["clickbench"]["cases"], ids=[c["name"] for c in AGG["clickbench"]["cases"]])
 def test_device_clickbench_sample(eng, case):
     run_clickbench_case(eng, AGG, case)
+
+
+def _joins_slt_cases():
+    from joins_slt_common import GOLDEN
+    return GOLDEN["cases"]
+
+
+@pytest.mark.parametrize("mode", ["CollectLeft", "Partitioned"])
+@pytest.mark.parametrize("case", _joins_slt_cases(), ids=lambda c: c["name"])
+def test_device_joins_slt(ctx, case, mode):
+    """The same joins.slt cases through the plan layer: HashJoinExec (with the JoinFilter where the query has one) -> FilterExec
+    IS [NOT] NULL -> ProjectionExec -> SortExec ASC NULLS LAST, rows equal to the reference's expected output."""
+    import pyarrow as pa
+    import dfgpu
+    from dfgpu import physical_plan as ops
+    from joins_slt_common import GOLDEN, table
+    lt, rt = table(case["left"]), table(case["right"])
+    mk = lambda t: ops.MemoryExec([[ops.batch_from_arrow(ctx, t)]], ops.batch_from_arrow(ctx, t).schema)
+    C = ops.Column
+    on = [(C(lt.column_names[l], l), C(rt.column_names[r], r)) for l, r in case["on"]]
+    filt = None
+    if "filter" in case:
+        f = case["filter"]
+        tcode = {pa.int32(): dfgpu.capi.INT32, pa.uint32(): dfgpu.capi.UINT32, pa.utf8(): dfgpu.capi.UTF8}
+        types = [(lt if side == "left" else rt).schema.field(ci).type for side, ci in f["columns"]]
+        rhs = C("y", 1) if len(f["columns"]) > 1 else ops.Literal(f["literal"], types[0])
+        filt = ops.JoinFilter(ops.BinaryExpr(C("x", 0), f["op"], rhs), [tuple(c) for c in f["columns"]],
+                              ops.Schema([ops.Field(n, tcode[t]) for n, t in zip("xy", types)]))
+    plan = ops.HashJoinExec(mk(lt), mk(rt), on, filt, case["join_type"], mode)
+    names = plan.schema().names()
+    if "where" in case:
+        ci, pred = case["where"]
+        plan = ops.FilterExec(ops.IsNullExpr(C(names[ci], ci), negated=(pred == "is_not_null")), plan)
+    plan = ops.ProjectionExec([(C(names[i], i), names[i]) for i in case["project"]], plan)
+    pos = case["project"].index(case["order_by"])
+    plan = ops.SortExec([ops.PhysicalSortExpr(C("k", pos), False, False)], plan)
+    got = []
+    for b in ops.collect(plan, ops.TaskContext(ctx, 2)):          # batch_size 2, as the .slt file sets it
+        got += [list(r) for r in zip(*[c.to_arrow().to_pylist() for c in b.columns])]
+    assert got == case["expected"]

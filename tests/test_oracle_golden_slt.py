@@ -61,3 +61,16 @@ def test_oracle_grouping_sets_reference_vector():
     got = sorted(zip(ka.to_pylist(), kb.to_pylist(), acc.evaluate().to_pylist()), key=lambda r: tuple((0, 0) if v is None else (1, v) for v in r))
     want = [(None, 1.0, 2), (None, 2.0, 2), (None, 3.0, 2), (None, 4.0, 2), (2, None, 2), (2, 1.0, 2), (3, None, 3), (3, 2.0, 2), (3, 3.0, 1), (4, None, 3), (4, 3.0, 1), (4, 4.0, 2)]
     assert got == want
+
+
+def _joins_slt_cases():
+    from joins_slt_common import GOLDEN
+    return GOLDEN["cases"]
+
+
+@pytest.mark.parametrize("case", _joins_slt_cases(), ids=lambda c: c["name"])
+def test_oracle_joins_slt(case):
+    """sqllogictest/test_files/joins.slt equi-join cases (outer joins under IS [NOT] NULL filters, semi / anti joins with duplicate and
+    NULL keys and join filters): the oracle's hash join reproduces the reference's expected rows."""
+    from joins_slt_common import oracle_rows
+    assert oracle_rows(case) == case["expected"]
