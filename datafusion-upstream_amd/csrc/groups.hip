@@ -99,13 +99,14 @@ constexpr int PF_ROWS = 4;
 // tmp[i] = slot of row i's key (G_NONE for masked rows).  New keys are claimed by a CAS on the key word; every row of a key without a
 // group id lowers the slot's first-row word (read first: it only moves down).  counters[1] = table too full, counters[3] = a key equals
 // the empty marker (the caller leaves this table for the general one).
-template <bool HAS_MASK>
-__global__ void __launch_bounds__(BLOCK) k_prim_find(const unsigned long long* keys, int64_t n, const uint64_t* mask, PSlot* slots, uint64_t cap_mask, uint32_t* tmp,
+// KT: unsigned long long (8-byte keys) or uint32_t (4-byte keys, zero-extended: the bit pattern is the key, so they can never equal the marker)
+template <typename KT, bool HAS_MASK>
+__global__ void __launch_bounds__(BLOCK) k_prim_find(const KT* keys, int64_t n, const uint64_t* mask, PSlot* slots, uint64_t cap_mask, uint32_t* tmp,
                                                      unsigned long long* counters, uint64_t max_steps) {
   const int64_t base = (int64_t)blockIdx.x * BLOCK * PF_ROWS + threadIdx.x;
   unsigned long long k[PF_ROWS]; uint64_t sl[PF_ROWS]; PSlot cur[PF_ROWS]; bool on[PF_ROWS];
 #pragma unroll
-  for (int q = 0; q < PF_ROWS; q++) { int64_t i = base + (int64_t)q * BLOCK; on[q] = i < n && (!HAS_MASK || bit_get(mask, i)); k[q] = keys[i < n ? i : n - 1]; }
+  for (int q = 0; q < PF_ROWS; q++) { int64_t i = base + (int64_t)q * BLOCK; on[q] = i < n && (!HAS_MASK || bit_get(mask, i)); k[q] = (unsigned long long)keys[i < n ? i : n - 1]; }
 #pragma unroll
   for (int q = 0; q < PF_ROWS; q++) sl[q] = mix64(k[q] ^ GROUP_SEED) & cap_mask;
 #pragma unroll
@@ -156,10 +157,11 @@ __global__ void __launch_bounds__(BLOCK) k_prim_ids(const uint32_t* tmp, int64_t
   for (int q = 0; q < PF_ROWS; q++) { int64_t i = base + (int64_t)q * BLOCK; if (i < n) out[i] = g[q]; }
 }
 // (re)build: the numbered groups' keys into an empty table (keys are distinct)
-__global__ void __launch_bounds__(BLOCK) k_prim_insert(const unsigned long long* gkeys, int64_t n_groups, PSlot* slots, uint64_t cap_mask) {
+template <typename KT>
+__global__ void __launch_bounds__(BLOCK) k_prim_insert(const KT* gkeys, int64_t n_groups, PSlot* slots, uint64_t cap_mask) {
   int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (g >= n_groups) return;
-  unsigned long long k = gkeys[g]; uint64_t s = mix64(k ^ GROUP_SEED) & cap_mask;
+  unsigned long long k = (unsigned long long)gkeys[g]; uint64_t s = mix64(k ^ GROUP_SEED) & cap_mask;
   for (;;) { unsigned long long c = atomicCAS(&slots[s].key, P_EMPTY, k); if (c == P_EMPTY) break; s = (s + 1) & cap_mask; }
   slots[s].gid = (uint32_t)g; slots[s].first = 0u;
 }
@@ -568,16 +570,21 @@ static dfgpu_status groups_intern_impl(dfgpu_ctx* ctx, dfgpu_groups* g, const df
     if (ctx->group_run_detection && !ctx->force_hash_collisions && !mask && g->capacity == 0 && (g->n_groups == 0 || g->run_mode) && run_key_type(cols[0]) &&
         groups_intern_runs(ctx, g, cols, nkeys, bk, n, ids.get(), allow_deferred)) { *out_group_ids = ids.release(); return; }
     // one 8-byte integer key column without NULLs: the primitive-key table
-    auto plain8 = [](const dfgpu_array* a) { return a && (a->type == DFGPU_INT64 || a->type == DFGPU_UINT64) && !a->validity; };
-    const bool prim_ok = nkeys == 1 && !ctx->force_hash_collisions && !g->prim_banned && !g->canon_mode && g->capacity == 0 && plain8(cols[0]) && (g->n_groups == 0 || plain8(g->keys[0]));
+    auto plain8 = [](const dfgpu_array* a) { return a && (a->type == DFGPU_INT64 || a->type == DFGPU_UINT64 || a->type == DFGPU_INT32 || a->type == DFGPU_UINT32 || a->type == DFGPU_DATE32) && !a->validity; };
+    const bool prim_ok = nkeys == 1 && !ctx->force_hash_collisions && !g->prim_banned && !g->canon_mode && g->capacity == 0 && plain8(cols[0]) && (g->n_groups == 0 || (plain8(g->keys[0]) && g->keys[0]->type == cols[0]->type));
+    const bool key4 = prim_ok && type_width(cols[0]->type) == 4;
     if (g->prim_mode && !prim_ok) { g->prim_mode = false; g->pslots.reset(); g->pcap = 0; g->run_mode = g->n_groups > 0; }      // NULLs / another type arrived: re-hash the stored groups below
     if (prim_ok) {
       const uint64_t* mk = mask ? (const uint64_t*)mask->ptr : nullptr;
-      const unsigned long long* kp = (const unsigned long long*)cols[0]->values->ptr;
+      const void* kp = cols[0]->values->ptr;
       auto rebuild = [&](uint64_t cap) {
         g->pslots = alloc_buffer(ctx, (size_t)cap * sizeof(PSlot)); g->pcap = cap;
         HIP_CHECK(hipMemsetAsync(g->pslots->ptr, 0xFF, (size_t)cap * sizeof(PSlot), ctx->stream));
-        if (g->n_groups) { hipLaunchKernelGGL(k_prim_insert, dim3(grid_for(g->n_groups, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const unsigned long long*)g->keys[0]->values->ptr, g->n_groups, (PSlot*)g->pslots->ptr, cap - 1); KERNEL_CHECK(); }
+        if (g->n_groups) {
+          if (key4) hipLaunchKernelGGL((k_prim_insert<uint32_t>), dim3(grid_for(g->n_groups, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)g->keys[0]->values->ptr, g->n_groups, (PSlot*)g->pslots->ptr, cap - 1);
+          else hipLaunchKernelGGL((k_prim_insert<unsigned long long>), dim3(grid_for(g->n_groups, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const unsigned long long*)g->keys[0]->values->ptr, g->n_groups, (PSlot*)g->pslots->ptr, cap - 1);
+          KERNEL_CHECK();
+        }
       };
       uint64_t expect = (uint64_t)(n < (1 << 22) ? n : (1 << 22));
       if (g->size_hint > 0) { uint64_t h = (uint64_t)g->size_hint < (uint64_t)n ? (uint64_t)g->size_hint : (uint64_t)n; if (h > expect) expect = h; }
@@ -590,8 +597,10 @@ static dfgpu_status groups_intern_impl(dfgpu_ctx* ctx, dfgpu_groups* g, const df
         zero_scratch(ctx);
         { KernelTimer kt_(ctx, "k_groups_find");
           dim3 fg(grid_for(n, BLOCK * PF_ROWS));
-          if (mk) hipLaunchKernelGGL((k_prim_find<true>), fg, dim3(BLOCK), 0, ctx->stream, kp, n, mk, (PSlot*)g->pslots->ptr, g->pcap - 1, (uint32_t*)tmp->ptr, (unsigned long long*)ctx->d_scratch64, (uint64_t)256);
-          else hipLaunchKernelGGL((k_prim_find<false>), fg, dim3(BLOCK), 0, ctx->stream, kp, n, mk, (PSlot*)g->pslots->ptr, g->pcap - 1, (uint32_t*)tmp->ptr, (unsigned long long*)ctx->d_scratch64, (uint64_t)256); }
+#define PFIND(KT, HM) hipLaunchKernelGGL((k_prim_find<KT, HM>), fg, dim3(BLOCK), 0, ctx->stream, (const KT*)kp, n, mk, (PSlot*)g->pslots->ptr, g->pcap - 1, (uint32_t*)tmp->ptr, (unsigned long long*)ctx->d_scratch64, (uint64_t)256)
+          if (key4) { if (mk) PFIND(uint32_t, true); else PFIND(uint32_t, false); } else { if (mk) PFIND(unsigned long long, true); else PFIND(unsigned long long, false); }
+#undef PFIND
+        }
         KERNEL_CHECK();
         HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 0, ctx->d_scratch64, 32, hipMemcpyDeviceToHost, ctx->stream));
         ctx->count_sync("sync:group_table");

@@ -585,7 +585,7 @@ def test_new_paths_on_empty_masked_and_degenerate_inputs(ctx):
     assert (got == 0xFFFFFFFF).all() and len(gv) == 1
 
 
-@pytest.mark.parametrize("scenario", ["plain", "after_runs", "nulls_arrive", "marker_key", "uint64"])
+@pytest.mark.parametrize("scenario", ["plain", "after_runs", "nulls_arrive", "marker_key", "uint64", "int32", "date32"])
 def test_primitive_key_table_matches_the_oracle(ctx, scenario):
     """One 8-byte integer key column without NULLs goes through the primitive-key table (key, group id and first-row word in one slot).
     First-seen ids and emitted keys must equal the oracle's over several batches (a masked one, a single row, one that forces the table
@@ -593,7 +593,7 @@ def test_primitive_key_table_matches_the_oracle(ctx, scenario):
     and when a key equals the table's empty marker (-1: the column is banned from the primitive table)."""
     import dfgpu
     rng = np.random.default_rng(21)
-    t = pa.uint64() if scenario == "uint64" else pa.int64()
+    t = {"uint64": pa.uint64(), "int32": pa.int32(), "date32": pa.date32()}.get(scenario, pa.int64())
     gv, og = dfgpu.GroupValues(ctx, 1), po.Groups([t])
     def check(arr, mask=None):
         got = gv.intern([ctx.from_arrow(arr)], mask=ctx.from_arrow(pa.array(mask)) if mask is not None else None).to_numpy()
@@ -602,7 +602,8 @@ def test_primitive_key_table_matches_the_oracle(ctx, scenario):
         else:
             assert np.array_equal(got[mask].astype(np.int64), og.intern([arr.filter(pa.array(mask))])) and (got[~mask] == 0xFFFFFFFF).all()
         assert len(gv) == len(og)
-    mk = (lambda v: pa.array(v.astype(np.uint64))) if scenario == "uint64" else (lambda v: pa.array(v.astype(np.int64)))
+    mk = {"uint64": lambda v: pa.array(v.astype(np.uint64)), "int32": lambda v: pa.array((v - 1000).astype(np.int32)),       # 4-byte keys incl. negative ones
+          "date32": lambda v: pa.array(v.astype(np.int32)).cast(pa.date32())}.get(scenario, lambda v: pa.array(v.astype(np.int64)))
     if scenario == "after_runs":
         check(mk(np.repeat(np.arange(5000), 3) * 11))                                   # clustered: run numbering, no table yet
     check(mk(rng.integers(0, 3000, 20000) * 7))
