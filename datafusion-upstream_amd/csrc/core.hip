@@ -288,6 +288,10 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "group_dictionary_canon") ctx->group_dictionary_canon = value != 0;
     else if (k == "join_swap_small_semi") ctx->join_swap_small_semi = value != 0;
     else if (k == "fused_aggregate_min_rows") ctx->fused_aggregate_min_rows = value;
+    else if (k == "join_partitioned") ctx->join_partitioned = value != 0;
+    else if (k == "join_partitioned_min_build") ctx->join_partitioned_min_build = value;
+    else if (k == "join_partitioned_min_probe") ctx->join_partitioned_min_probe = value;
+    else if (k == "join_partition_rows") ctx->join_partition_rows = value;
     else if (k == "defer_flag_checks") {            // nests: +1 enters a deferred region, 0 leaves it and raises what the region deferred
       if (value) ctx->defer_flag_checks++;
       else { if (ctx->defer_flag_checks > 0) ctx->defer_flag_checks--; if (ctx->defer_flag_checks == 0) flush_flags(ctx); }
@@ -308,6 +312,10 @@ dfgpu_status dfgpu_ctx_get_option(dfgpu_ctx* ctx, const char* key, int64_t* out)
     else if (k == "group_dictionary_canon") *out = ctx->group_dictionary_canon;
     else if (k == "join_swap_small_semi") *out = ctx->join_swap_small_semi;
     else if (k == "fused_aggregate_min_rows") *out = ctx->fused_aggregate_min_rows;
+    else if (k == "join_partitioned") *out = ctx->join_partitioned;
+    else if (k == "join_partitioned_min_build") *out = ctx->join_partitioned_min_build;
+    else if (k == "join_partitioned_min_probe") *out = ctx->join_partitioned_min_probe;
+    else if (k == "join_partition_rows") *out = ctx->join_partition_rows;
     else if (k == "defer_flag_checks") *out = ctx->defer_flag_checks;
     else fail(DFGPU_INVALID_ARGUMENT, "unknown option '%s'", k.c_str());
   });

@@ -46,6 +46,8 @@ struct dfgpu_ctx {
   bool group_run_detection = true;
   bool group_dictionary_canon = true;
   bool join_swap_small_semi = true;
+  // radix-partitioned hash join (pjoin.hip): on/off, smallest build / probe batch that takes it, build rows per partition (<= 14000)
+  bool join_partitioned = true; int64_t join_partitioned_min_build = 1 << 20, join_partitioned_min_probe = 1 << 22, join_partition_rows = 14000;
   int64_t fused_aggregate_min_rows = 1 << 20;
   // row selection of the running operator (dfgpu_ctx_set_row_selection): expression kernels evaluate every row of full-length
   // columns but raise errors only for selected rows

@@ -10,7 +10,7 @@
 // reproduces the reference's emission order (probe order, then build input order; hash_join.rs:161-197)
 // without pointer chasing; unique-key builds (every TPC-H PK join) skip the CSR entirely.
 // The probe is count -> exclusive scan -> fill, so output order never depends on scheduling.
-#include "device_utils.h"
+#include "join_table.h"
 
 namespace dfgpu {
 constexpr uint64_t SLOT_EMPTY = ~0ull;
@@ -18,40 +18,6 @@ constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
 }
 using namespace dfgpu;
 
-struct dfgpu_join_table {
-  dfgpu_ctx* ctx = nullptr;
-  int64_t n_build = 0; int32_t nkeys = 0; bool null_equals_null = false;
-  std::vector<dfgpu_array*> keys; KeySet ks{};
-  uint64_t capacity = 0; int cap_bits = 0;
-  BufferPtr slots;        // u64[capacity]
-  BufferPtr slot_count;   // u32[capacity]   rows per key group
-  BufferPtr slot_start;   // u32[capacity]   CSR start (non-unique only)
-  BufferPtr csr_rows;     // u32[n_inserted] build rows ordered by (slot, row) (non-unique only)
-  BufferPtr build_mask;   // effective opt_mask words or null
-  BufferPtr visited;      // u64 words over n_build
-  bool unique = true;
-  // exact membership bitmap over [key_min, key_min + range) for single integer keys with a dense domain: the probe tests
-  // one bit (L2 / Infinity Cache resident, perfectly local for clustered keys) and touches the hash table for matches only
-  BufferPtr bitmap; int64_t key_min = 0; uint64_t range = 0;
-  // a build side that is tiny against its key range (a few thousand order keys out of 600 M) gets no bitmap up front; a probe batch
-  // of >= range / 16 rows builds it on arrival (clearing range / 8 bytes is then small against streaming the probe keys)
-  bool lazy_bitmap = false; BufferPtr lazy_row_slot;
-  // rank index (strictly increasing single integer key, the shape of every clustered primary key): no hash table at all.
-  // The bitmap IS the table: build row = rank of the key's bit among the set bits (word prefix + popcount), mapped through
-  // sel_rows when a build selection is fused; rank_identity = the keys are key_min + row, so the row is the key offset.
-  bool rank_mode = false, rank_identity = false;
-  // rank_runs: the keys are non-decreasing WITH repeats (a sorted foreign key): sel_rows[r] = first build row of the r-th distinct key,
-  // its rows are the run up to sel_rows[r + 1] (or n_build) -- the CSR of the hash path without hashing or sorting
-  bool rank_runs = false;
-  // key packing: 2..4 integer key columns whose value ranges multiply to < 2^40 are packed into ONE Int64 key (sum of (k - min) * stride):
-  // tuple equality == packed equality, and the single-key paths (rank index, bitmap prefilter) apply.  The table then holds the packed
-  // column as its only key; probes pack their tuples with the same parameters (a component outside the build range = NULL = no match).
-  int pack_n = 0; int32_t pack_types[MAX_KEYS] = {0}; int64_t pack_min[MAX_KEYS] = {0}; uint64_t pack_range[MAX_KEYS] = {0}, pack_stride[MAX_KEYS] = {0};
-  BufferPtr rank_prefix;  // u32[range / 64]   set bits before each bitmap word
-  dfgpu_array* sel_rows = nullptr;   // u32[selected] ascending build rows (masked builds only)
-  int64_t mem = 0;
-  ~dfgpu_join_table() { for (auto* a : keys) dfgpu_array_release(a); if (sel_rows) dfgpu_array_release(sel_rows); }
-};
 
 namespace dfgpu {
 
@@ -559,6 +525,44 @@ static bool build_rank_index(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   return true;
 }
 
+// The partitioned join (pjoin.hip) is for key domains the membership bitmap cannot prefilter: min / max of the selected build keys in one
+// streaming pass.  true = range beyond 256 x rows (or beyond 2^32): a bitmap over it would be mostly empty lines.
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_key_minmax_masked(const T* keys, const uint64_t* valid, const uint64_t* mask, int64_t n, long long* mn, long long* mx) {
+  long long lo = INT64_MAX, hi = INT64_MIN;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
+    if (row_selected(mask, i) && valid_at(valid, i)) { long long v = (long long)keys[i]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { long long a = __shfl_xor(lo, d, 64), b = __shfl_xor(hi, d, 64); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+  __shared__ long long slo[BLOCK / WAVE], shi[BLOCK / WAVE];
+  if (lane_id() == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < BLOCK / WAVE; w++) { lo = slo[w] < lo ? slo[w] : lo; hi = shi[w] > hi ? shi[w] : hi; }
+    if (lo <= hi) { atomicMin(mn, lo); atomicMax(mx, hi); }
+  }
+}
+static bool pj_domain_is_sparse(dfgpu_ctx* ctx, dfgpu_join_table* t) {
+  int64_t n = t->n_build;
+  if (!ctx->join_partitioned || ctx->force_hash_collisions || t->nkeys != 1 || t->null_equals_null || n < ctx->join_partitioned_min_build) return false;
+  const dfgpu_array* key0 = t->keys[0];
+  if (key0->type == DFGPU_UINT64) return true;
+  if (key0->type == DFGPU_DICTIONARY || !int_key_type(key0->type)) return false;
+  long long init[2] = { INT64_MAX, INT64_MIN };
+  HIP_CHECK(hipMemcpyAsync(ctx->d_scratch64 + 4, init, 16, hipMemcpyHostToDevice, ctx->stream));
+  DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_minmax_masked<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 4)), dim3(BLOCK), 0, ctx->stream, (const T*)key0->values->ptr,
+                                                        key0->validity ? (const uint64_t*)key0->validity->ptr : nullptr, t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr, n,
+                                                        (long long*)(ctx->d_scratch64 + 4), (long long*)(ctx->d_scratch64 + 5)));
+  KERNEL_CHECK();
+  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 4, ctx->d_scratch64 + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
+  ctx->count_sync("sync:pj_key_range");
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  long long lo = (long long)ctx->h_pinned[4], hi = (long long)ctx->h_pinned[5];
+  if (lo > hi) return false;
+  uint64_t range = (uint64_t)hi - (uint64_t)lo + 1;
+  return range == 0 || range > (1ull << 32) || range > (uint64_t)n * 256;
+}
+
 }  // namespace dfgpu
 
 extern "C" {
@@ -607,7 +611,9 @@ dfgpu_status dfgpu_join_build(dfgpu_ctx* ctx, const dfgpu_array* const* keys, in
     t->build_mask = effective_mask(ctx, opt_mask, n);
     t->visited = alloc_buffer(ctx, bitmap_bytes(n), true);
     t->mem = (int64_t)bitmap_bytes(n);
-    if (!build_rank_index(ctx, t.get())) build_hash_table(ctx, t.get(), true);
+    // order of preference: rank index (clustered keys: no table at all), radix-partitioned LDS tables (large builds on unsorted keys
+    // whose domain is too sparse for the membership bitmap in front of the general table), general open-addressing table
+    if (!build_rank_index(ctx, t.get()) && !(pj_domain_is_sparse(ctx, t.get()) && pj_build(ctx, t.get()))) build_hash_table(ctx, t.get(), true);
     *out = t.release();
   });
 }
@@ -632,6 +638,11 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
     int64_t nw = (n + 63) / 64;
     const uint64_t* mk = mask ? (const uint64_t*)mask->ptr : nullptr;
     int nen = t->null_equals_null ? 1 : 0, fz = ctx->force_hash_collisions ? 1 : 0;
+    if (nkeys == 1 && pj_probe_eligible(ctx, t, probe_keys[0], n)) {        // large batch against a partitioned build: partition by partition out of LDS
+      pj_probe(ctx, t, probe_keys[0], mk, out_build_idx, out_probe_idx);
+      check_flags(ctx, "join_probe");
+      return;
+    }
     // pass 1: match bit per probe row
     BufferPtr match_bits = alloc_buffer(ctx, bitmap_bytes(n), n == 0);
     bool use_bitmap = false, fast_hash = false; BufferPtr found_slot;

@@ -1,0 +1,57 @@
+// join_table.h -- the build side of a HashJoinExec as the device sees it (shared by join.hip and pjoin.hip).
+#pragma once
+#include "device_utils.h"
+
+namespace dfgpu {
+// radix-partitioned build side (pjoin.hip): (key widened to 64 bits, original build row) grouped by partition of the key hash, sized so
+// that one partition's open-addressing table fits the 160 KB LDS of a CU
+struct PartitionedBuild {
+  uint32_t P = 0; int sbits = 0;            // partitions; log2 of the LDS table slots
+  int64_t rows = 0;                         // selected, non-NULL build rows
+  BufferPtr recs, row_ids;                  // u64 keys[rows], u32 build rows[rows], partition-major
+  BufferPtr starts;                         // u32[P + 1]
+};
+}  // namespace dfgpu
+
+struct dfgpu_join_table {
+  dfgpu_ctx* ctx = nullptr;
+  int64_t n_build = 0; int32_t nkeys = 0; bool null_equals_null = false;
+  std::vector<dfgpu_array*> keys; dfgpu::KeySet ks{};
+  uint64_t capacity = 0; int cap_bits = 0;
+  dfgpu::BufferPtr slots;        // u64[capacity]
+  dfgpu::BufferPtr slot_count;   // u32[capacity]   rows per key group
+  dfgpu::BufferPtr slot_start;   // u32[capacity]   CSR start (non-unique only)
+  dfgpu::BufferPtr csr_rows;     // u32[n_inserted] build rows ordered by (slot, row) (non-unique only)
+  dfgpu::BufferPtr build_mask;   // effective opt_mask words or null
+  dfgpu::BufferPtr visited;      // u64 words over n_build
+  bool unique = true;
+  // exact membership bitmap over [key_min, key_min + range) for single integer keys with a dense domain: the probe tests
+  // one bit (L2 / Infinity Cache resident, perfectly local for clustered keys) and touches the hash table for matches only
+  dfgpu::BufferPtr bitmap; int64_t key_min = 0; uint64_t range = 0;
+  // a build side that is tiny against its key range (a few thousand order keys out of 600 M) gets no bitmap up front; a probe batch
+  // of >= range / 16 rows builds it on arrival (clearing range / 8 bytes is then small against streaming the probe keys)
+  bool lazy_bitmap = false; dfgpu::BufferPtr lazy_row_slot;
+  // rank index (strictly increasing single integer key, the shape of every clustered primary key): no hash table at all.
+  // The bitmap IS the table: build row = rank of the key's bit among the set bits (word prefix + popcount), mapped through
+  // sel_rows when a build selection is fused; rank_identity = the keys are key_min + row, so the row is the key offset.
+  bool rank_mode = false, rank_identity = false;
+  // rank_runs: the keys are non-decreasing WITH repeats (a sorted foreign key): sel_rows[r] = first build row of the r-th distinct key,
+  // its rows are the run up to sel_rows[r + 1] (or n_build) -- the CSR of the hash path without hashing or sorting
+  bool rank_runs = false;
+  // key packing: 2..4 integer key columns whose value ranges multiply to < 2^40 are packed into ONE Int64 key (sum of (k - min) * stride):
+  // tuple equality == packed equality, and the single-key paths (rank index, bitmap prefilter) apply.  The table then holds the packed
+  // column as its only key; probes pack their tuples with the same parameters (a component outside the build range = NULL = no match).
+  int pack_n = 0; int32_t pack_types[dfgpu::MAX_KEYS] = {0}; int64_t pack_min[dfgpu::MAX_KEYS] = {0}; uint64_t pack_range[dfgpu::MAX_KEYS] = {0}, pack_stride[dfgpu::MAX_KEYS] = {0};
+  dfgpu::BufferPtr rank_prefix;  // u32[range / 64]   set bits before each bitmap word
+  dfgpu_array* sel_rows = nullptr;   // u32[selected] ascending build rows (masked builds only)
+  std::unique_ptr<dfgpu::PartitionedBuild> part;   // set = probes of large batches run partition by partition out of LDS (pjoin.hip)
+  int64_t mem = 0;
+  ~dfgpu_join_table() { for (auto* a : keys) dfgpu_array_release(a); if (sel_rows) dfgpu_array_release(sel_rows); }
+};
+
+namespace dfgpu {
+// pjoin.hip
+bool pj_build(dfgpu_ctx* ctx, dfgpu_join_table* t);      // false = shape not taken (nothing kept)
+bool pj_probe_eligible(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* probe_key, int64_t n);
+void pj_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* probe_key, const uint64_t* mask, dfgpu_array** out_build, dfgpu_array** out_probe);
+}  // namespace dfgpu

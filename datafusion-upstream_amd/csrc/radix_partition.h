@@ -1,0 +1,233 @@
+// radix_partition.h -- one-pass, deterministic hash partitioning of rows into P partitions on gfx950.
+//
+// Shared by the radix-partitioned hash join (pjoin.hip), the partitioned aggregation (pagg.hip) and RepartitionExec's
+// BatchPartitioner (partition.hip; repartition/mod.rs:148-221).  Three launches:
+//   k_rp_hist     every workgroup counts RP_G consecutive tiles into an LDS histogram and writes counts[p][t .. t + RP_G) as one burst
+//   scan          ONE exclusive scan over the partition-major matrix counts[P][ntiles] gives goff[p][t] = first output slot of tile t's
+//                 rows in partition p (partition-major output: partition p is the contiguous range [goff[p][0], goff[p + 1][0]))
+//   k_rp_scatter  per tile: counting sort of the tile inside LDS, then every column is staged through LDS in sorted order and written
+//                 out linearly, so consecutive lanes write consecutive slots of a run
+// Ranking inside a tile: STABLE (P <= 256) ranks with 64-wide match-any ballots per (slab, wave) and a small LDS count table, so rows
+// of a partition keep input order (what BatchPartitioner promises, repartition/mod.rs:196-214); otherwise ranks come from LDS atomics
+// (rows of one (tile, partition) run land in arbitrary order inside the run -- consumers that only need the partition's row SET, the
+// join and the aggregation, take that).  Tiles are always laid out in input order inside a partition.
+// Write combining happens at two levels: a tile's run for one partition is contiguous (LDS-staged), and the runs of NEIGHBOURING tiles
+// are adjacent in the output, so the blockIdx -> tile map gives each XCD a contiguous range of tiles: the workgroups an XCD runs
+// concurrently extend the same cache lines inside that XCD's L2 (measured on MI355X, 150 M rows of 8 B key -> 12 B out, P = 1024:
+// 1.88 ms with the plain map, 1.03 ms with the XCD-aware map; profiles/experiments/radix_partition_microbench.hip).
+#pragma once
+#include "device_utils.h"
+
+namespace dfgpu {
+
+constexpr int RP_R = 8;              // rows per lane and tile
+constexpr int RP_G = 16;             // tiles per histogram workgroup: 16 x 4 B = one 64-B burst per partition
+constexpr int RP_MAX_COLS = 12;
+constexpr uint32_t RP_MAX_P = 2048;  // LDS: histogram [P][RP_G] u32 = 128 KB
+constexpr uint32_t RP_MAX_STABLE_P = 256;
+
+__device__ inline uint32_t rp_pid(uint64_t h, uint32_t P) { return (uint32_t)(((h >> 32) * (uint64_t)P) >> 32); }   // monotone in the top hash bits, any P
+
+// hashers: selected(i) + partition id of row i
+template <typename T> struct RpHashInt {        // one integer key column (widened to 64 bits, hashed with mix64), optional validity / selection bitmap
+  const T* keys; const uint64_t* valid; const uint64_t* mask;
+  __device__ inline bool operator()(int64_t i, uint32_t P, uint32_t* pid, uint64_t* key) const {
+    *key = (uint64_t)(int64_t)keys[i];
+    *pid = rp_pid(mix64(*key), P);
+    return (!mask || bit_get(mask, i)) && (!valid || bit_get(valid, i));
+  }
+};
+// rows already carrying a 32-bit row number in their low half (the join's (probe row, build row) matches): bucket = row >> shift.
+// Partition ids are then monotone in the row number, so bucket order is row order.
+struct RpHashRowBucket {
+  const uint64_t* recs; int shift;
+  __device__ inline bool operator()(int64_t i, uint32_t, uint32_t* pid, uint64_t* key) const { *key = recs[i]; *pid = (uint32_t)(*key & 0xFFFFFFFFull) >> shift; return true; }
+};
+struct RpHashKeySet {     // create_hashes % P (repartition/mod.rs:185) over any key columns
+  KeySet ks; const uint64_t* mask; int force_zero;
+  __device__ inline bool operator()(int64_t i, uint32_t P, uint32_t* pid, uint64_t* key) const {
+    bool an; uint64_t h = force_zero ? 0 : keyset_hash(ks, i, 0, &an);
+    *pid = (uint32_t)(h % P); *key = h;
+    return !mask || bit_get(mask, i);
+  }
+};
+
+// columns moved by the scatter
+enum { RP_RAW = 0, RP_KEY64 = 2, RP_HASHKEY = 3 };
+struct RpCol { const void* src; void* dst; int32_t width; int32_t kind; int32_t type; };   // RAW: width bytes per row (1, 2, 4, 8, 16); KEY64: src integer column of `type`, dst u64; HASHKEY: dst u64 = the 64-bit key the hasher produced for the row
+struct RpCols { int32_t n; uint32_t* rowid_dst; RpCol c[RP_MAX_COLS]; };                  // rowid_dst (optional): the original row number of every moved row (rides along with the first column's round)
+
+template <int NT, typename H>
+__global__ void __launch_bounds__(NT) k_rp_hist(H hs, int64_t n, uint32_t P, int64_t ntiles, uint32_t* counts /*[P][ntiles]*/) {
+  extern __shared__ uint32_t rp_lds[];        // [P][RP_G]
+  const int64_t t0 = (int64_t)blockIdx.x * RP_G;
+  for (int x = threadIdx.x; x < (int)P * RP_G; x += NT) rp_lds[x] = 0;
+  __syncthreads();
+  for (int g = 0; g < RP_G; g++) {
+    const int64_t base = (t0 + g) * (int64_t)(NT * RP_R);
+    if (base >= n) break;
+#pragma unroll
+    for (int q = 0; q < RP_R; q++) {
+      int64_t i = base + (int64_t)q * NT + threadIdx.x; uint32_t pid; uint64_t hk;
+      if (i < n && hs(i, P, &pid, &hk)) atomicAdd(&rp_lds[pid * RP_G + g], 1u);
+    }
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < (int)P * RP_G; x += NT) { int p = x / RP_G, g = x % RP_G; if (t0 + g < ntiles) counts[(int64_t)p * ntiles + t0 + g] = rp_lds[x]; }
+}
+
+// LDS of the scatter: cnt[P] u32 | delta[P] u32 | spid[TILE] u16 | slidx[TILE] u16 | stage[TILE] u64 | (STABLE) wcnt[RP_R][NT / 64][P] u16
+template <int NT> static inline size_t rp_scatter_lds(uint32_t P, bool stable) {
+  return (size_t)P * 8 + (size_t)NT * RP_R * 4 + 8 + (size_t)NT * RP_R * 8 + (stable ? (size_t)RP_R * (NT / WAVE) * P * 2 : 0);
+}
+
+template <int NT, bool STABLE, typename H>
+__global__ void __launch_bounds__(NT) k_rp_scatter(H hs, int64_t n, uint32_t P, int64_t ntiles, const uint32_t* goff, RpCols cols) {
+  extern __shared__ uint32_t rp_lds[];
+  constexpr int TILE = NT * RP_R, NW = NT / WAVE;
+  uint32_t* cnt = rp_lds; uint32_t* delta = rp_lds + P; uint16_t* spid = (uint16_t*)(rp_lds + 2 * P);
+  uint16_t* slidx = spid + TILE;                                    // tile-local index of the row staged at each position
+  uint64_t* stage = (uint64_t*)(((uintptr_t)(slidx + TILE) + 7) & ~(uintptr_t)7);
+  uint16_t* wcnt = (uint16_t*)(stage + TILE);                       // STABLE only: rows of partition p in (slab q, wave w)
+  __shared__ uint32_t wsum[NW]; __shared__ uint32_t moved_sh; __shared__ RpCol scol[RP_MAX_COLS];
+#pragma unroll
+  for (int c = 0; c < RP_MAX_COLS; c++) if ((int)threadIdx.x == c) scol[c] = cols.c[c];       // static indexing of the by-value argument; the column loop reads LDS
+  const int64_t per = (ntiles + 7) / 8, t = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);      // XCD x works on tiles [x * per, (x + 1) * per)
+  if (t >= ntiles || (int64_t)(blockIdx.x >> 3) >= per) return;
+  const int64_t base = t * (int64_t)TILE;
+  const int wave = threadIdx.x >> 6;
+  for (int p = threadIdx.x; p < (int)P; p += NT) cnt[p] = 0;
+  if (STABLE) for (int x = threadIdx.x; x < RP_R * NW * (int)P; x += NT) wcnt[x] = 0;
+  __syncthreads();
+  uint32_t pid[RP_R], rk[RP_R]; bool on[RP_R]; uint64_t hk[RP_R];          // hk: the key the hasher read (column kind RP_HASHKEY moves it without a second load)
+#pragma unroll
+  for (int q = 0; q < RP_R; q++) {
+    int64_t i = base + (int64_t)q * NT + threadIdx.x; pid[q] = 0; hk[q] = 0;
+    on[q] = i < n && hs(i, P, &pid[q], &hk[q]);
+    if (STABLE) {
+      uint64_t peers = ballot64(on[q]);
+      for (uint32_t b = 1; b < P; b <<= 1) { uint64_t mb = ballot64((pid[q] & b) != 0); peers &= (pid[q] & b) ? mb : ~mb; }
+      rk[q] = (uint32_t)__popcll(peers & lanemask_lt());
+      if (on[q] && rk[q] == 0) { wcnt[((size_t)q * NW + wave) * P + pid[q]] = (uint16_t)__popcll(peers); atomicAdd(&cnt[pid[q]], (uint32_t)__popcll(peers)); }
+    } else rk[q] = on[q] ? atomicAdd(&cnt[pid[q]], 1u) : 0;
+  }
+  __syncthreads();
+  if (STABLE) {       // thread p: counts of partition p per (slab, wave) -> exclusive prefix in (slab, wave) order
+    for (int p = threadIdx.x; p < (int)P; p += NT) { uint32_t run = 0; for (int x = 0; x < RP_R * NW; x++) { uint16_t c = wcnt[(size_t)x * P + p]; wcnt[(size_t)x * P + p] = (uint16_t)run; run += c; } }
+  }
+  {   // exclusive scan of cnt[P]: thread t owns the PER consecutive bins from t * PER
+    constexpr int PER = ((int)RP_MAX_P + NT - 1) / NT; uint32_t loc[PER]; uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) { int p = threadIdx.x * PER + j; loc[j] = p < (int)P ? cnt[p] : 0; s += loc[j]; }
+    uint32_t inc = wave_inclusive_sum(s);
+    __syncthreads();
+    if (lane_id() == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - s; for (int w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+    for (int j = 0; j < PER; j++) { int p = threadIdx.x * PER + j; if (p < (int)P) { cnt[p] = run; delta[p] = goff[(int64_t)p * ntiles + t] - run; run += loc[j]; } }   // mod 2^32: slot = delta + staged position
+    if (threadIdx.x == NT - 1) moved_sh = run;
+  }
+  __syncthreads();
+  const uint32_t moved = moved_sh;
+  uint32_t spos[RP_R];
+#pragma unroll
+  for (int q = 0; q < RP_R; q++) {
+    spos[q] = on[q] ? cnt[pid[q]] + rk[q] + (STABLE ? (uint32_t)wcnt[((size_t)q * NW + wave) * P + pid[q]] : 0u) : 0u;
+    if (on[q]) { spid[spos[q]] = (uint16_t)pid[q]; slidx[spos[q]] = (uint16_t)(q * NT + threadIdx.x); }
+  }
+  uint32_t* const rowid_dst = cols.rowid_dst;
+  if (rowid_dst && cols.n == 0) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < moved; i += NT) rowid_dst[(int64_t)(uint32_t)(delta[spid[i]] + i)] = (uint32_t)(base + slidx[i]);
+  }
+  for (int c = 0; c < cols.n; c++) {
+    const RpCol col = scol[c];
+    const int halves = col.width == 16 ? 2 : 1;
+    for (int hf = 0; hf < halves; hf++) {
+      if (c || hf) __syncthreads();                    // the previous column's write-out has read the staging buffer
+      const int64_t i0 = base + threadIdx.x;
+      // the width switch sits outside the unrolled row loop: one load shape per column, RP_R loads in flight
+#define RP_GATHER(EXPR) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) { const int64_t i = i0 + (int64_t)q * NT; stage[spos[q]] = (uint64_t)(EXPR); } }
+      if (col.kind == RP_HASHKEY) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) stage[spos[q]] = hk[q]; }
+      else if (col.kind == RP_KEY64) switch (col.type) {            // widened exactly as key_at() does
+        case DFGPU_INT8: RP_GATHER((int64_t)((const int8_t*)col.src)[i]) break;
+        case DFGPU_INT16: RP_GATHER((int64_t)((const int16_t*)col.src)[i]) break;
+        case DFGPU_INT32: case DFGPU_DATE32: RP_GATHER((int64_t)((const int32_t*)col.src)[i]) break;
+        case DFGPU_UINT8: RP_GATHER(((const uint8_t*)col.src)[i]) break;
+        case DFGPU_UINT16: RP_GATHER(((const uint16_t*)col.src)[i]) break;
+        case DFGPU_UINT32: RP_GATHER(((const uint32_t*)col.src)[i]) break;
+        default: RP_GATHER(((const uint64_t*)col.src)[i]) break;
+      }
+      else switch (col.width) {
+        case 1: RP_GATHER(((const uint8_t*)col.src)[i]) break;
+        case 2: RP_GATHER(((const uint16_t*)col.src)[i]) break;
+        case 4: RP_GATHER(((const uint32_t*)col.src)[i]) break;
+        case 8: RP_GATHER(((const uint64_t*)col.src)[i]) break;
+        default: RP_GATHER(((const uint64_t*)col.src)[2 * i + hf]) break;
+      }
+#undef RP_GATHER
+      __syncthreads();
+#define RP_WRITE(T, IDX) for (uint32_t i = threadIdx.x; i < moved; i += NT) { const int64_t pos = (int64_t)(uint32_t)(delta[spid[i]] + i); ((T*)col.dst)[IDX] = (T)stage[i]; }
+      if (rowid_dst && c == 0 && hf == 0 && col.width == 8) {           // the common (key, row id) pair in one sweep
+        for (uint32_t i = threadIdx.x; i < moved; i += NT) { const int64_t pos = (int64_t)(uint32_t)(delta[spid[i]] + i); ((uint64_t*)col.dst)[pos] = stage[i]; rowid_dst[pos] = (uint32_t)(base + slidx[i]); }
+      } else {
+      if (rowid_dst && c == 0 && hf == 0) for (uint32_t i = threadIdx.x; i < moved; i += NT) rowid_dst[(int64_t)(uint32_t)(delta[spid[i]] + i)] = (uint32_t)(base + slidx[i]);
+      switch (col.width) {
+        case 1: RP_WRITE(uint8_t, pos) break;
+        case 2: RP_WRITE(uint16_t, pos) break;
+        case 4: RP_WRITE(uint32_t, pos) break;
+        case 8: RP_WRITE(uint64_t, pos) break;
+        default: RP_WRITE(uint64_t, 2 * pos + hf) break;
+      }
+      }
+#undef RP_WRITE
+    }
+  }
+}
+
+// starts[p] = first slot of partition p, starts[P] = rows moved (the scan's total)
+static __global__ void k_rp_starts(const uint32_t* goff, int64_t ntiles, uint32_t P, const uint64_t* d_total, uint32_t* starts) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < P) starts[p] = goff[(int64_t)p * ntiles];
+  if (p == P) starts[P] = (uint32_t)*d_total;
+}
+
+struct RpResult { uint32_t P = 0; int64_t ntiles = 0; BufferPtr starts; };     // starts: u32[P + 1] on the device
+
+// Partition rows 0 .. n-1 (those the hasher selects) into P partitions, moving `cols`.  Destination buffers must hold n rows.
+// d_total: device u64 that receives the number of rows moved.  timer names: <prefix>_hist / _scan / _scatter.
+template <typename H>
+static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const RpCols& cols, bool stable, uint64_t* d_total,
+                             const char* t_hist, const char* t_scan, const char* t_scatter) {
+  if (P < 1 || P > RP_MAX_P) fail(DFGPU_INTERNAL, "rp_partition: %u partitions (1..%u supported)", P, RP_MAX_P);
+  if (stable && P > RP_MAX_STABLE_P) fail(DFGPU_INTERNAL, "rp_partition: stable order supports up to %u partitions, got %u", RP_MAX_STABLE_P, P);
+  if (n > 0xFFFFFFF0ll) fail(DFGPU_NOT_IMPLEMENTED, "partitioning above 2^32-16 rows");
+  RpResult r; r.P = P;
+  r.starts = alloc_buffer(ctx, (size_t)(P + 1) * 4);
+  const bool big = P > 512 && !stable;                     // 8192-row tiles halve the count matrix; 4096-row tiles give more workgroups per CU
+  const int nt = big ? 1024 : 512, tile = nt * RP_R;
+  const int64_t ntiles = n ? (n + tile - 1) / tile : 1; r.ntiles = ntiles;
+  BufferPtr counts = alloc_buffer(ctx, (size_t)P * ntiles * 4);
+  const size_t hl = (size_t)P * RP_G * 4;
+  const int64_t nh = (ntiles + RP_G - 1) / RP_G;
+  { KernelTimer kt_(ctx, t_hist);
+    if (big) { static bool once = false; if (!once) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_hist<1024, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); once = true; }
+      hipLaunchKernelGGL((k_rp_hist<1024, H>), dim3((unsigned)nh), dim3(1024), hl, ctx->stream, hs, n, P, ntiles, (uint32_t*)counts->ptr); }
+    else { static bool once = false; if (!once) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_hist<512, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); once = true; }
+      hipLaunchKernelGGL((k_rp_hist<512, H>), dim3((unsigned)nh), dim3(512), hl, ctx->stream, hs, n, P, ntiles, (uint32_t*)counts->ptr); }
+    KERNEL_CHECK(); }
+  { KernelTimer kt_(ctx, t_scan); exclusive_scan_u32_inplace32(ctx, (uint32_t*)counts->ptr, (int64_t)P * ntiles, d_total); }
+  hipLaunchKernelGGL(k_rp_starts, dim3((P + 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)counts->ptr, ntiles, P, (const uint64_t*)d_total, (uint32_t*)r.starts->ptr);
+  KERNEL_CHECK();
+  if (n) { KernelTimer kt_(ctx, t_scatter);
+    const unsigned grid = (unsigned)(((ntiles + 7) / 8) * 8);
+#define RP_LAUNCH(NT_, ST_) { static bool once = false; if (!once) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_scatter<NT_, ST_, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); once = true; } \
+      hipLaunchKernelGGL((k_rp_scatter<NT_, ST_, H>), dim3(grid), dim3(NT_), rp_scatter_lds<NT_>(P, ST_), ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols); }
+    if (stable) RP_LAUNCH(512, true) else if (big) RP_LAUNCH(1024, false) else RP_LAUNCH(512, false)
+#undef RP_LAUNCH
+    KERNEL_CHECK(); }
+  return r;
+}
+
+}  // namespace dfgpu

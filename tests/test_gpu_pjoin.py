@@ -1,0 +1,173 @@
+"""-m gpu: the radix-partitioned hash join (csrc/pjoin.hip + radix_partition.h) against the CPU oracle.
+
+The (build, probe) index pairs must equal the oracle's bit for bit INCLUDING ORDER (probe order, then build order: hash_join.rs:161-197,
+asserted :1593-1594), whatever the number of partitions, with NULL keys, fused selections on either side and every integer key width.
+Thresholds are lowered through the ctx options so that small inputs take the partitioned path; each test also checks that the path really
+ran (its kernels show up in the profile) or really fell back (repeated build keys, an over-full partition)."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+RNG = np.random.default_rng(4242)
+M64 = (1 << 64) - 1
+
+
+def mix64(x: int) -> int:
+    x = (x + 0x9e3779b97f4a7c15) & M64
+    x = ((x ^ (x >> 30)) * 0xbf58476d1ce4e5b9) & M64
+    x = ((x ^ (x >> 27)) * 0x94d049bb133111eb) & M64
+    return x ^ (x >> 31)
+
+
+class forced:
+    """ctx options that send small inputs down the partitioned path"""
+
+    def __init__(self, ctx, rows_per_partition=12800, on=1):
+        self.ctx, self.opts = ctx, {"join_partitioned": on, "join_partitioned_min_build": 1, "join_partitioned_min_probe": 1, "join_partition_rows": rows_per_partition}
+
+    def __enter__(self):
+        self.saved = {k: self.ctx.get_option(k) for k in self.opts}
+        for k, v in self.opts.items():
+            self.ctx.set_option(k, v)
+        self.ctx.profile_select(None); self.ctx.profile_enable(True); self.ctx.profile_read()
+        return self
+
+    def kernels(self):
+        return set(self.ctx.profile_read())
+
+    def __exit__(self, *a):
+        self.ctx.profile_enable(False)
+        for k, v in self.saved.items():
+            self.ctx.set_option(k, v)
+
+
+def unique_keys(n, dtype=np.int64, lo=-(1 << 62), hi=1 << 62):
+    k = np.unique(RNG.integers(lo, hi, int(n * 1.1) + 8, dtype=np.int64))
+    RNG.shuffle(k)
+    assert len(k) >= n
+    return k[:n].astype(dtype)
+
+
+def probe_keys(b, n, frac, dtype=np.int64, lo=-(1 << 62), hi=1 << 62):
+    p = RNG.integers(lo, hi, n, dtype=np.int64).astype(dtype)
+    if len(b) and n:
+        hit = RNG.random(n) < frac
+        p[hit] = b[RNG.integers(0, len(b), int(hit.sum()))]
+    return p
+
+
+def check(ctx, b, p, bmask=None, pmask=None, bnull=None, pnull=None, typ=None):
+    import dfgpu
+    ba = pa.array(b, type=typ, mask=bnull); pa_ = pa.array(p, type=typ, mask=pnull)
+    table = dfgpu.JoinTable(ctx, [ctx.from_arrow(ba)], mask=ctx.from_arrow(pa.array(bmask)) if bmask is not None else None)
+    bi, pi = table.probe([ctx.from_arrow(pa_)], mask=ctx.from_arrow(pa.array(pmask)) if pmask is not None else None)
+    # oracle over the compacted inputs, indices mapped back
+    bsel = np.arange(len(b)) if bmask is None else np.flatnonzero(bmask)
+    psel = np.arange(len(p)) if pmask is None else np.flatnonzero(pmask)
+    want = po.hash_join([[ba.take(pa.array(bsel))]], [[pa_.take(pa.array(psel))]], "Inner", False, batch_size=1 << 40)
+    assert np.array_equal(bi.to_numpy().astype(np.int64), bsel[want.build_idx])
+    assert np.array_equal(pi.to_numpy().astype(np.int64), psel[want.probe_idx])
+    return len(want.probe_idx)
+
+
+SHAPES = [(50000, 200000, 0.2, 12800), (50000, 200000, 0.2, 64), (20000, 70001, 1.0, 100), (3000, 100000, 0.0, 16), (1, 5000, 0.5, 12800), (2, 5000, 0.5, 12800),
+          (4097, 4096, 0.3, 33), (130000, 400000, 0.25, 64), (60000, 1, 1.0, 500), (60000, 0, 0.0, 500)]
+
+
+@pytest.mark.parametrize("nb,npr,frac,per", SHAPES, ids=[f"{s[0]}x{s[1]}-m{s[2]}-r{s[3]}" for s in SHAPES])
+def test_partitioned_pairs_match_oracle_exactly(ctx, nb, npr, frac, per):
+    b = unique_keys(nb); p = probe_keys(b, npr, frac)
+    with forced(ctx, per) as f:
+        check(ctx, b, p)
+        ran = f.kernels()
+    if nb == 1:
+        return                      # one key is a dense domain: the bitmap path keeps it
+    assert "pj_build_check" in ran
+    if npr:
+        assert "pj_join" in ran and "k_probe_match_hash" not in ran, ran
+
+
+def test_partitioned_equals_general_path(ctx):
+    """A/B: option join_partitioned = 0 gives the same arrays."""
+    import dfgpu
+    b = unique_keys(40000); p = probe_keys(b, 150000, 0.3)
+    out = []
+    for on in (1, 0):
+        with forced(ctx, 256, on) as f:
+            t = dfgpu.JoinTable(ctx, [ctx.from_arrow(pa.array(b))])
+            bi, pi = t.probe([ctx.from_arrow(pa.array(p))])
+            out.append((bi.to_numpy(), pi.to_numpy()))
+            assert ("pj_join" in f.kernels()) == bool(on)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_partitioned_nulls_and_fused_selections(ctx):
+    nb, npr = 30000, 120000
+    b = unique_keys(nb); p = probe_keys(b, npr, 0.5)
+    with forced(ctx, 200) as f:
+        m = check(ctx, b, p, bmask=RNG.random(nb) < 0.7, pmask=RNG.random(npr) < 0.6, bnull=RNG.random(nb) < 0.1, pnull=RNG.random(npr) < 0.1)
+        assert m > 1000 and "pj_join" in f.kernels()
+
+
+@pytest.mark.parametrize("typ,lo,hi", [(pa.int32(), -(1 << 31), 1 << 31), (pa.uint32(), 0, 1 << 32), (pa.date32(), -(1 << 31), 1 << 31), (pa.int16(), -(1 << 15), 1 << 15),
+                                       (pa.uint64(), 0, 1 << 63)], ids=["int32", "uint32", "date32", "int16", "uint64"])
+def test_partitioned_integer_key_widths(ctx, typ, lo, hi):
+    nb = 20000 if typ != pa.int16() else 200
+    dt = {pa.int32(): np.int32, pa.uint32(): np.uint32, pa.date32(): np.int32, pa.int16(): np.int16, pa.uint64(): np.uint64}[typ]
+    b = unique_keys(nb, dt, lo, hi); p = probe_keys(b, 90000, 0.4, dt, lo, hi)
+    with forced(ctx, 50) as f:
+        check(ctx, b, p, typ=typ)
+        assert "pj_join" in f.kernels()
+
+
+def test_dense_domain_keeps_the_bitmap_path(ctx):
+    """keys 0 .. 4n shuffled: the membership bitmap prefilter stays in charge (range <= 256 x rows)"""
+    nb = 30000
+    b = RNG.permutation(4 * nb)[:nb].astype(np.int64); p = RNG.integers(0, 4 * nb, 100000).astype(np.int64)
+    with forced(ctx, 100) as f:
+        check(ctx, b, p)
+        assert "pj_join" not in f.kernels()
+
+
+def test_repeated_build_keys_fall_back(ctx):
+    b = unique_keys(30000); b[1234] = b[77]; p = probe_keys(b, 80000, 0.5)
+    with forced(ctx, 100) as f:
+        check(ctx, b, p)
+        ran = f.kernels()
+        assert "pj_build_check" in ran and "pj_join" not in ran
+
+
+def test_overfull_partition_falls_back(ctx):
+    """20 000 distinct keys whose hash lands in partition 0 of 2: beyond the 16 382 rows an LDS table indexes -> general path, same pairs"""
+    ks = []
+    x = 1
+    while len(ks) < 20000:
+        x += 1
+        if (mix64(x * 7919) >> 32) * 2 >> 32 == 0:
+            ks.append(x * 7919)
+    b = np.array(ks, dtype=np.int64)[RNG.permutation(len(ks))]          # range / rows ~ 16 000: too sparse for the bitmap path
+    p = probe_keys(b, 60000, 0.5)
+    with forced(ctx, 12800) as f:
+        check(ctx, b, p)
+        ran = f.kernels()
+        assert "pj_join" not in ran
+
+
+def test_two_packed_key_columns_take_the_partitioned_path(ctx):
+    """(a, b) with ranges 10^4 x 10^5 packs into one sparse Int64 key (join.hip k_pack_keys) -> partitioned probe; pairs equal the oracle's"""
+    import dfgpu
+    nb, npr = 20000, 90000
+    flat = unique_keys(nb, np.int64, 0, 10**9)
+    b0, b1 = (flat // 10**5).astype(np.int64), (flat % 10**5).astype(np.int64)
+    pf = probe_keys(flat, npr, 0.4, np.int64, 0, 10**9)
+    p0, p1 = (pf // 10**5).astype(np.int64), (pf % 10**5).astype(np.int64)
+    with forced(ctx, 128) as f:
+        t = dfgpu.JoinTable(ctx, [ctx.from_arrow(pa.array(b0)), ctx.from_arrow(pa.array(b1))])
+        bi, pi = t.probe([ctx.from_arrow(pa.array(p0)), ctx.from_arrow(pa.array(p1))])
+        ran = f.kernels()
+    want = po.hash_join([[pa.array(b0), pa.array(b1)]], [[pa.array(p0), pa.array(p1)]], "Inner", False, batch_size=1 << 40)
+    assert np.array_equal(bi.to_numpy().astype(np.int64), want.build_idx) and np.array_equal(pi.to_numpy().astype(np.int64), want.probe_idx)
+    assert "pj_join" in ran
