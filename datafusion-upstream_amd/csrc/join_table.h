@@ -8,7 +8,7 @@ namespace dfgpu {
 struct PartitionedBuild {
   uint32_t P = 0; int sbits = 0;            // partitions; log2 of the LDS table slots
   int64_t rows = 0;                         // selected, non-NULL build rows
-  BufferPtr recs, row_ids;                  // u64 keys[rows], u32 build rows[rows], partition-major
+  BufferPtr recs;                           // RpRec12 {key lo, key hi, build row}[rows], partition-major
   BufferPtr starts;                         // u32[P + 1]
 };
 }  // namespace dfgpu

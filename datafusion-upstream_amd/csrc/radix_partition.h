@@ -55,7 +55,11 @@ struct RpHashKeySet {     // create_hashes % P (repartition/mod.rs:185) over any
 // columns moved by the scatter
 enum { RP_RAW = 0, RP_KEY64 = 2, RP_HASHKEY = 3 };
 struct RpCol { const void* src; void* dst; int32_t width; int32_t kind; int32_t type; };   // RAW: width bytes per row (1, 2, 4, 8, 16); KEY64: src integer column of `type`, dst u64; HASHKEY: dst u64 = the 64-bit key the hasher produced for the row
-struct RpCols { int32_t n; uint32_t* rowid_dst; RpCol c[RP_MAX_COLS]; };                  // rowid_dst (optional): the original row number of every moved row (rides along with the first column's round)
+// rowid_dst (optional): the original row number of every moved row (rides along with the first column's round).
+// pack12_dst (optional; column 0 must be 8 bytes wide): column 0 and the row number leave as ONE array of 12-byte records
+// (RpRec12: one global_store_dwordx3 per row, a (tile, partition) run is one contiguous piece instead of two)
+struct RpRec12 { uint32_t lo, hi, row; };
+struct RpCols { int32_t n; uint32_t* rowid_dst; RpRec12* pack12_dst; RpCol c[RP_MAX_COLS]; };
 
 template <int NT, typename H>
 __global__ void __launch_bounds__(NT) k_rp_hist(H hs, int64_t n, uint32_t P, int64_t ntiles, uint32_t* counts /*[P][ntiles]*/) {
@@ -169,7 +173,10 @@ __global__ void __launch_bounds__(NT) k_rp_scatter(H hs, int64_t n, uint32_t P, 
 #undef RP_GATHER
       __syncthreads();
 #define RP_WRITE(T, IDX) for (uint32_t i = threadIdx.x; i < moved; i += NT) { const int64_t pos = (int64_t)(uint32_t)(delta[spid[i]] + i); ((T*)col.dst)[IDX] = (T)stage[i]; }
-      if (rowid_dst && c == 0 && hf == 0 && col.width == 8) {           // the common (key, row id) pair in one sweep
+      if (cols.pack12_dst && c == 0) {
+        RpRec12* const d12 = cols.pack12_dst;
+        for (uint32_t i = threadIdx.x; i < moved; i += NT) { const int64_t pos = (int64_t)(uint32_t)(delta[spid[i]] + i); const uint64_t v = stage[i]; d12[pos] = RpRec12{ (uint32_t)v, (uint32_t)(v >> 32), (uint32_t)(base + slidx[i]) }; }
+      } else if (rowid_dst && c == 0 && hf == 0 && col.width == 8) {           // the common (key, row id) pair in one sweep
         for (uint32_t i = threadIdx.x; i < moved; i += NT) { const int64_t pos = (int64_t)(uint32_t)(delta[spid[i]] + i); ((uint64_t*)col.dst)[pos] = stage[i]; rowid_dst[pos] = (uint32_t)(base + slidx[i]); }
       } else {
       if (rowid_dst && c == 0 && hf == 0) for (uint32_t i = threadIdx.x; i < moved; i += NT) rowid_dst[(int64_t)(uint32_t)(delta[spid[i]] + i)] = (uint32_t)(base + slidx[i]);
