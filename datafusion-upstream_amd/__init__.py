@@ -16,7 +16,7 @@ The package never falls back to a CPU implementation: without libdfgpu.so or a H
 """
 from . import capi
 from .capi import DfgpuError, load_library
-from .device import Array, Context, GroupValues, GroupsAccumulator, JoinTable, join_adjust_indices
+from .device import Array, Context, GroupValues, GroupsAccumulator, JoinTable, agg_preaggregate, join_adjust_indices
 from . import operators
 from . import physical_plan
 

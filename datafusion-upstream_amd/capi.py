@@ -80,6 +80,7 @@ PROTOTYPES = {
     "dfgpu_ctx_set_option": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
     "dfgpu_acc_update_batch_fused": (C.c_int32, [_P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int32, _P, C.c_int32, C.POINTER(_P), C.c_int32, _P, _P, C.c_int64]),
     "dfgpu_jit_selftest": (C.c_int32, [C.c_char_p, C.c_char_p, C.c_int64]),
+    "dfgpu_agg_preaggregate": (C.c_int32, [_P, C.POINTER(_P), C.c_int32, C.POINTER(C.c_int32), C.POINTER(_P), C.c_int32, _P, C.POINTER(_P), C.POINTER(_P)]),
     "dfgpu_ctx_get_option": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     "dfgpu_ctx_stream": (_P, [_P]),
     "dfgpu_version": (C.c_char_p, []),

@@ -692,6 +692,36 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
     if (st == DFGPU_NOT_IMPLEMENTED) return false;
     tc.check(st); return true;
   }
+  // dfgpu_agg_preaggregate over one batch, then intern + merge_batch of its partial rows.  false = shape not taken, nothing accumulated.
+  template <typename Ensure>
+  bool preaggregate(const TaskContext& tc, Batch& b, const std::vector<bool>& deferred, Ensure&& ensure, const dfgpu_array* key, const ArrayRef& mask, GroupsRef& groups, std::vector<AccRef>& accs) const {
+    std::vector<ArrayRef> vals(aggs.size()); std::vector<const dfgpu_array*> vp; std::vector<int32_t> kinds;
+    for (auto& a : aggs) if (a.filter) return false;
+    // the key column decides (type, clustering, number of groups): ask before any computed argument is evaluated for it
+    dfgpu_status v0 = dfgpu_agg_preaggregate(tc.ctx, &key, 1, nullptr, nullptr, 0, mask.a, nullptr, nullptr);
+    if (v0 == DFGPU_NOT_IMPLEMENTED) return false;
+    tc.check(v0);
+    for (size_t i = 0; i < aggs.size(); i++) {
+      if (aggs[i].arg) {
+        std::set<int> need; aggs[i].arg->columns(need); for (int ci : need) ensure(ci);
+        vals[i] = into_array(tc, aggs[i].arg->eval(tc, b), b.base_rows);
+      }
+      vp.push_back(vals[i].a); kinds.push_back(aggs[i].kind);
+    }
+    std::vector<dfgpu_array*> st(aggs.size() * 2 + 2, nullptr); dfgpu_array* pk = nullptr;
+    dfgpu_status rc = dfgpu_agg_preaggregate(tc.ctx, &key, 1, kinds.data(), vp.data(), (int32_t)aggs.size(), mask.a, &pk, st.data());
+    if (rc == DFGPU_NOT_IMPLEMENTED) return false;
+    tc.check(rc);
+    ArrayRef pkeys = ArrayRef::adopt(pk); std::vector<ArrayRef> states; for (auto* x : st) states.push_back(ArrayRef::adopt(x));
+    const dfgpu_array* kp = pkeys.a; dfgpu_array* ids = nullptr;
+    tc.check(dfgpu_groups_intern(tc.ctx, groups.g, &kp, 1, nullptr, &ids)); ArrayRef gids = ArrayRef::adopt(ids);
+    int64_t total = dfgpu_groups_len(groups.g);
+    for (size_t i = 0; i < aggs.size(); i++) {
+      const dfgpu_array* sp[2] = { states[2 * i].a, states[2 * i + 1].a };
+      tc.check(dfgpu_acc_merge_batch(tc.ctx, accs[i].a, sp, aggs[i].kind == DFGPU_AGG_AVG ? 2 : 1, gids.a, nullptr, total));
+    }
+    return true;
+  }
   // evaluate_group_by + the per-set loop of group_aggregate_batch (aggregates/mod.rs:1161-1200, row_hash.rs:540-600): keys and accumulator
   // arguments are evaluated once per batch; every grouping set interns its own key tuples (masked keys come from null_exprs) into the
   // one GroupValues and updates every accumulator with the resulting group ids.
@@ -733,6 +763,8 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
     // An input ProjectionExec is looked through: its computed columns that only feed accumulator arguments are evaluated inside the
     // accumulate pass (dfgpu_acc_update_batch_fused) instead of being written out as columns first.
     int64_t fuse_min_rows = 1 << 20; dfgpu_ctx_get_option(tc.ctx, "fused_aggregate_min_rows", &fuse_min_rows);
+    int64_t preagg_min_rows = 1 << 22, preagg_on = 1; dfgpu_ctx_get_option(tc.ctx, "agg_partitioned_min_rows", &preagg_min_rows); dfgpu_ctx_get_option(tc.ctx, "agg_partitioned", &preagg_on);
+    if (!preagg_on) preagg_min_rows = INT64_MAX;
     const ProjectionExec* pj = (!merging() && !aggs.empty() && fuse_min_rows >= 0) ? dynamic_cast<const ProjectionExec*>(input.get()) : nullptr;
     const PlanPtr& src = pj ? pj->input : input;
     std::vector<Batch> in;
@@ -774,6 +806,9 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
           }
           gc.push_back(into_array(tc, e->eval(tc, b), b.base_rows)); gp.push_back(gc.back().a);
         }
+        // A large batch of high-cardinality keys is first reduced to one row per group partition by partition out of LDS (the Partial stage
+        // of a two-phase plan, applied inside the operator): its partial rows are then interned and MERGED like the Final stage does.
+        if (!merging() && gp.size() == 1 && b.base_rows >= preagg_min_rows && preaggregate(tc, b, deferred, ensure, gp[0], mask, groups, accs)) continue;
         dfgpu_array* ids = nullptr; tc.check(dfgpu_groups_intern_deferred(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids)); gids = ArrayRef::adopt(ids);      // only the accumulators read them
         total = dfgpu_groups_len(groups.g);
       } else { dfgpu_array* z = nullptr; tc.check(dfgpu_array_new_zeros(tc.ctx, DFGPU_UINT32, 0, 0, b.base_rows, &z)); gids = ArrayRef::adopt(z); }

@@ -1,0 +1,307 @@
+// pagg.hip -- partitioned pre-aggregation for high-cardinality, unclustered group keys: every partition's groups live in LDS.
+//
+// Reference semantics: the Partial stage of a two-phase aggregation (AggregateMode::Partial, physical-plan/src/aggregates/mod.rs:64-100;
+// GroupedHashAggregateStream::group_aggregate_batch, row_hash.rs:524-613) applied to ONE batch inside the operator: the batch is reduced
+// to (group key, partial state...) rows, which the caller interns (GroupValues::intern, group_values/primitive.rs:112-149) and merges
+// (GroupsAccumulator::merge_batch, prim_op.rs:119-127; average.rs:472-509; count.rs:135-170) exactly as a Final stage would.
+//
+// Why: with more groups than an LDS cache holds, dfgpu_acc_update_batch pays one memory-side atomic per row and state array
+// (~24 G/s: 8.5 ms per 100 M rows for SUM + COUNT) and groups.hip one random 64-byte sector per row for the key table.  Here the rows
+// are split by key hash (radix_partition.h, one pass) into P partitions so that a partition's distinct keys fit an LDS table
+// (4096 slots of key + first row + row count + one 8-byte state per aggregate); one workgroup per partition accumulates its rows with
+// LDS atomics and writes one row per group.  If a partition holds more keys than the table (the cardinality estimate was low, or
+// the keys are skewed towards it) the workgroup flushes the table and goes on: a key may then leave in several partial rows, which
+// the merge downstream adds up -- never wrong, only less reduction.
+//
+// Order: partial rows come back sorted by the first input row of their group, so interning them numbers the groups in first-seen order
+// of the ORIGINAL batch (group_values/primitive.rs:137-141).  Integer / count states are exact; Float64 sums are added in a different
+// order than row order (as every multi-partition plan of the reference does): within 1e-9 relative of the sequential sum.
+#include "device_utils.h"
+#include "radix_partition.h"
+
+namespace dfgpu {
+
+constexpr uint64_t PA_EMPTY = ~0ull;
+constexpr int PA_NT = 1024;
+constexpr int PA_MAX_AGGS = 6;
+enum { PA_SUM_I64 = 0, PA_SUM_F64 = 1, PA_MIN_I64 = 2, PA_MAX_I64 = 3, PA_MIN_U64 = 4, PA_MAX_U64 = 5, PA_MIN_F64 = 6, PA_MAX_F64 = 7, PA_NONE = 8 };
+
+struct PaPlan { int32_t n_acc; int32_t op[PA_MAX_AGGS]; const uint64_t* val[PA_MAX_AGGS]; uint64_t* out[PA_MAX_AGGS]; };
+
+__device__ inline uint64_t pa_identity(int op) {
+  switch (op) {
+    case PA_MIN_I64: return (uint64_t)INT64_MAX; case PA_MAX_I64: return (uint64_t)INT64_MIN; case PA_MIN_U64: return ~0ull; case PA_MAX_U64: return 0ull;
+    case PA_MIN_F64: return 0x7FF0000000000000ull /* +inf */; case PA_MAX_F64: return 0xFFF0000000000000ull /* -inf */;
+    default: return 0ull;
+  }
+}
+__device__ inline void pa_apply(int op, unsigned long long* cell, uint64_t v) {
+  switch (op) {
+    case PA_SUM_I64: atomicAdd(cell, (unsigned long long)v); break;                                   // wrapping, sum.rs:137
+    case PA_SUM_F64: atomicAdd((double*)cell, __longlong_as_double((long long)v)); break;
+    case PA_MIN_I64: atomicMin((long long*)cell, (long long)v); break; case PA_MAX_I64: atomicMax((long long*)cell, (long long)v); break;
+    case PA_MIN_U64: atomicMin(cell, (unsigned long long)v); break; case PA_MAX_U64: atomicMax(cell, (unsigned long long)v); break;
+    case PA_MIN_F64: { double d = __longlong_as_double((long long)v); if (d == d) atomicMin((double*)cell, d); break; }     // NaN inputs: handled by the caller's eligibility (MIN/MAX over Float64 keep the general path when NaNs matter)
+    case PA_MAX_F64: { double d = __longlong_as_double((long long)v); if (d == d) atomicMax((double*)cell, d); break; }
+    default: break;
+  }
+}
+__device__ inline uint32_t pa_slot(uint64_t k, int cbits) {
+  uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
+  uint32_t a = lo ^ (hi * 0x9E3779B1u), x = a * 0x85EBCA6Bu; x ^= x >> 13;
+  return (x * 0xC2B2AE35u) >> (32 - cbits);
+}
+
+__global__ void k_pa_max_len(const uint32_t* pstart, uint32_t P, unsigned long long* out) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; uint32_t len = p < P ? pstart[p + 1] - pstart[p] : 0;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_xor(len, d, 64); len = o > len ? o : len; }
+  if (lane_id() == 0 && len) atomicMax(out, (unsigned long long)len);
+}
+// one workgroup per partition (and slice).  LDS: keys u64[C + 1] | acc[n_acc] u64[C + 1] | first u32[C + 1] | cnt u32[C + 1]; slot C belongs to the key
+// that equals the EMPTY marker.  Rows are taken PA_NT at a time with a barrier in between; before a chunk the table is flushed if the
+// chunk could fill it beyond 7/8.
+__global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, const uint32_t* prow, PaPlan plan_arg, const uint32_t* pstart, int cbits, uint32_t slice,
+                                                      uint64_t* okey, uint32_t* ofirst, uint32_t* ocnt, unsigned long long* cursor) {
+  extern __shared__ unsigned long long pa_lds[];
+  const uint32_t C = 1u << cbits, M = C - 1, C1 = C + 1;
+  unsigned long long* keys = pa_lds; unsigned long long* acc = pa_lds + C1;
+  uint32_t* first = (uint32_t*)(pa_lds + (size_t)C1 * (1 + plan_arg.n_acc)); uint32_t* cnt = first + C1;
+  __shared__ uint32_t nfilled, wsum[PA_NT / WAVE], out_base; __shared__ PaPlan splan;
+  if (threadIdx.x == 0) splan = plan_arg;              // the per-aggregate loops index the plan at run time: from LDS, not from the by-value argument
+  __syncthreads();
+  const PaPlan& plan = splan;
+  // blockIdx.y: a partition far above the average size (skewed keys) is cut into slices of `slice` rows, each with a table of its own
+  const int p = blockIdx.x, lane = lane_id();
+  const uint32_t p0 = pstart[p], p1 = pstart[p + 1];
+  if ((uint64_t)blockIdx.y * slice >= (uint64_t)(p1 - p0)) return;
+  const uint32_t q0 = p0 + blockIdx.y * slice, q1 = (uint64_t)q0 + slice < (uint64_t)p1 ? q0 + slice : p1;
+  auto reset = [&]() {
+    for (uint32_t s = threadIdx.x; s < C1; s += PA_NT) { keys[s] = PA_EMPTY; first[s] = 0xFFFFFFFFu; cnt[s] = 0;
+      for (int a = 0; a < plan.n_acc; a++) acc[(size_t)a * C1 + s] = pa_identity(plan.op[a]); }
+    if (threadIdx.x == 0) nfilled = 0;
+  };
+  auto flush = [&]() {      // occupied slots -> one output row each; slot ranks by a block scan over PER consecutive slots per thread
+    const uint32_t per = (C1 + PA_NT - 1) / PA_NT, s0 = threadIdx.x * per; uint32_t c = 0;
+    for (uint32_t j = 0; j < per; j++) { uint32_t s = s0 + j; if (s < C1 && cnt[s]) c++; }
+    uint32_t inc = wave_inclusive_sum(c);
+    if (lane == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t run = inc - c, tot = 0;
+    for (int w = 0; w < PA_NT / WAVE; w++) { if (w < (int)(threadIdx.x >> 6)) run += wsum[w]; tot += wsum[w]; }
+    if (threadIdx.x == 0) out_base = tot ? (uint32_t)atomicAdd(cursor, (unsigned long long)tot) : 0u;
+    __syncthreads();
+    uint32_t o = out_base + run;
+    for (uint32_t j = 0; j < per; j++) { uint32_t s = s0 + j; if (s < C1 && cnt[s]) {
+      okey[o] = s == C ? PA_EMPTY : keys[s]; ofirst[o] = first[s]; ocnt[o] = cnt[s];
+      for (int a = 0; a < plan.n_acc; a++) plan.out[a][o] = acc[(size_t)a * C1 + s];
+      o++; } }
+    __syncthreads();
+  };
+  reset();
+  __syncthreads();
+  // the next chunk's row (key, row number, value cells) is loaded while the current one goes through the table
+  uint64_t kn = 0, vn[PA_MAX_AGGS]; uint32_t rn = 0;
+  const int na = plan_arg.n_acc;
+  { const uint32_t i = q0 + threadIdx.x, ic = i < q1 ? i : q1 - 1; kn = pkey[ic]; rn = prow[ic];
+#pragma unroll
+    for (int a = 0; a < PA_MAX_AGGS; a++) vn[a] = a < na ? plan_arg.val[a][ic] : 0; }
+  for (uint32_t i0 = q0; i0 < q1; i0 += PA_NT) {
+    if (nfilled + PA_NT > C - C / 8) { __syncthreads(); flush(); reset(); __syncthreads(); }      // nfilled is only written between barriers: uniform
+    const uint32_t i = i0 + threadIdx.x; const bool on = i < q1;
+    const uint64_t k = kn; const uint32_t row = rn; uint64_t v[PA_MAX_AGGS];
+#pragma unroll
+    for (int a = 0; a < PA_MAX_AGGS; a++) v[a] = vn[a];
+    { const uint32_t i2 = i + PA_NT, ic = i2 < q1 ? i2 : q1 - 1; kn = pkey[ic]; rn = prow[ic];
+#pragma unroll
+      for (int a = 0; a < PA_MAX_AGGS; a++) vn[a] = a < na ? plan_arg.val[a][ic] : 0; }
+    uint32_t s = C; bool fresh = false;
+    if (on) {
+      if (k != PA_EMPTY) {
+        s = pa_slot(k, cbits);
+        for (;;) {
+          unsigned long long old = keys[s];
+          if (old == PA_EMPTY) { old = atomicCAS(&keys[s], (unsigned long long)PA_EMPTY, (unsigned long long)k); if (old == PA_EMPTY) { fresh = true; break; } }
+          if (old == k) break;
+          s = (s + 1) & M;
+        }
+      }
+      if (row < first[s]) atomicMin(&first[s], row);           // a stale read only costs a redundant atomic
+      atomicAdd(&cnt[s], 1u);
+#pragma unroll
+      for (int a = 0; a < PA_MAX_AGGS; a++) if (a < na) pa_apply(plan_arg.op[a], &acc[(size_t)a * C1 + s], v[a]);
+    }
+    uint64_t fb = ballot64(fresh);
+    if (lane == 0 && fb) atomicAdd(&nfilled, (uint32_t)__popcll(fb));
+    __syncthreads();
+  }
+  flush();
+}
+
+// sample of the batch: distinct keys among `s` evenly spaced rows (open-addressing u64 table of `cap` slots) and how many sampled
+// rows are not smaller than their predecessor row (clustered input keeps the run-numbering path of groups.hip)
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_pa_sample(const T* keys, const uint64_t* mask, int64_t n, int64_t s, int64_t stride, unsigned long long* table, uint64_t cap_mask, unsigned long long* out /*[0] distinct, [1] non-decreasing pairs, [2] pairs*/) {
+  uint32_t nf = 0, nn = 0, np = 0;
+  for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < s; j += (int64_t)gridDim.x * BLOCK) {
+    int64_t i = j * stride;
+    if (i >= n || (mask && !bit_get(mask, i))) continue;
+    T kt = keys[i]; if (i > 0) { np++; nn += keys[i - 1] <= kt; }
+    uint64_t k = (uint64_t)(int64_t)kt;
+    uint64_t kk = k == PA_EMPTY ? 0x5555555555555555ull : k;                 // the marker value itself: folded onto another key (estimate only)
+    uint64_t h = mix64(kk) & cap_mask;
+    for (;;) {
+      unsigned long long old = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // frequent keys: no atomic once they are in
+      if (old == PA_EMPTY) { old = atomicCAS(&table[h], (unsigned long long)PA_EMPTY, (unsigned long long)kk); if (old == PA_EMPTY) { nf++; break; } }
+      if (old == kk) break;
+      h = (h + 1) & cap_mask;
+    }
+  }
+  nf = wave_sum(nf); nn = wave_sum(nn); np = wave_sum(np);                    // one atomic per workgroup and counter: same-address atomics serialise
+  __shared__ uint32_t sh[3][BLOCK / WAVE];
+  if (lane_id() == 0) { sh[0][threadIdx.x >> 6] = nf; sh[1][threadIdx.x >> 6] = nn; sh[2][threadIdx.x >> 6] = np; }
+  __syncthreads();
+  if (threadIdx.x < 3) { uint32_t t = 0; for (int w = 0; w < BLOCK / WAVE; w++) t += sh[threadIdx.x][w]; if (t) atomicAdd(&out[threadIdx.x], (unsigned long long)t); }
+}
+
+template <typename T> __global__ void __launch_bounds__(BLOCK) k_pa_gather_key(const uint64_t* src, const uint32_t* perm, int64_t m, T* out) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < m) out[i] = (T)src[perm[i]];
+}
+__global__ void __launch_bounds__(BLOCK) k_pa_gather_u64(const uint64_t* src, const uint32_t* perm, int64_t m, uint64_t* out) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < m) out[i] = src[perm[i]];
+}
+__global__ void __launch_bounds__(BLOCK) k_pa_gather_cnt(const uint32_t* src, const uint32_t* perm, int64_t m, uint64_t* out) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < m) out[i] = src[perm[i]];
+}
+
+static bool pa_key_type_ok(int32_t t) { return t == DFGPU_INT64 || t == DFGPU_UINT64 || t == DFGPU_INT32 || t == DFGPU_UINT32 || t == DFGPU_DATE32; }
+
+}  // namespace dfgpu
+
+using namespace dfgpu;
+extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array* const* keys, int32_t nkeys, const int32_t* kinds, const dfgpu_array* const* values, int32_t n_aggs,
+                                               const dfgpu_array* opt_mask, dfgpu_array** out_keys, dfgpu_array** out_states) {
+  return guard(ctx, [&] {
+    const bool verdict_only = out_keys == nullptr;         // would this batch be taken?  (key column + selection only; see include/dfgpu.h)
+    if (!keys || (!verdict_only && n_aggs && (!kinds || !values || !out_states))) fail(DFGPU_INVALID_ARGUMENT, "agg_preaggregate: null argument");
+    if (verdict_only) n_aggs = 0;
+    auto skip = [&](const char* why) { fail(DFGPU_NOT_IMPLEMENTED, "agg_preaggregate: %s", why); };
+    if (!ctx->agg_partitioned) skip("switched off (option agg_partitioned)");
+    if (nkeys != 1) skip("one key column");
+    const dfgpu_array* key = keys[0]; const int64_t n = key->length;
+    // A dictionary key column is pre-aggregated by its CODES: codes with equal dictionary values leave as separate partial rows, which
+    // interning the emitted dictionary array merges (dictionary keys intern by value).
+    const int32_t ktype = key->type == DFGPU_DICTIONARY ? key->key_type : key->type;
+    if (!pa_key_type_ok(ktype) || key->validity) skip("a 4- or 8-byte integer key column (or dictionary codes of that width) without NULLs");
+    if (n < ctx->agg_partitioned_min_rows || n > 0xFFFF0000ll) skip("batch below agg_partitioned_min_rows");
+    if (n_aggs > 16) skip("at most 16 aggregates");
+    // accumulator plan: one 8-byte LDS cell per SUM / MIN / MAX; COUNT and AVG counts come from the row count (value columns carry no NULLs)
+    PaPlan plan{}; int cell_of[16]; const dfgpu_array* cell_src[PA_MAX_AGGS];
+    for (int i = 0; i < n_aggs; i++) {
+      const dfgpu_array* v = values[i]; cell_of[i] = -1;
+      if (v && (v->validity || v->length != n || v->type == DFGPU_DICTIONARY)) skip("value columns without NULLs");
+      if (kinds[i] == DFGPU_AGG_COUNT) continue;
+      if (!v) skip("aggregate without an argument");
+      int op = PA_NONE;
+      const bool i64 = v->type == DFGPU_INT64, u64 = v->type == DFGPU_UINT64, f64 = v->type == DFGPU_FLOAT64;
+      if (!i64 && !u64 && !f64) skip("Int64 / UInt64 / Float64 aggregate arguments");
+      switch (kinds[i]) {
+        case DFGPU_AGG_SUM: op = f64 ? PA_SUM_F64 : PA_SUM_I64; break;
+        case DFGPU_AGG_AVG: if (!f64) skip("AVG over Float64"); op = PA_SUM_F64; break;
+        case DFGPU_AGG_MIN: if (f64) skip("MIN over Float64 (NaN order)"); op = i64 ? PA_MIN_I64 : PA_MIN_U64; break;
+        case DFGPU_AGG_MAX: if (f64) skip("MAX over Float64 (NaN order)"); op = i64 ? PA_MAX_I64 : PA_MAX_U64; break;
+        default: skip("SUM / AVG / COUNT / MIN / MAX");
+      }
+      int c = -1; for (int j = 0; j < plan.n_acc; j++) if (plan.op[j] == op && cell_src[j] == v) c = j;          // SUM(x) and AVG(x) share a cell
+      if (c < 0) { if (plan.n_acc == PA_MAX_AGGS) skip("at most 6 distinct accumulator cells"); c = plan.n_acc++; plan.op[c] = op; cell_src[c] = v; }
+      cell_of[i] = c;
+    }
+    const uint64_t* mk = nullptr; BufferPtr mask = effective_mask(ctx, opt_mask, n); if (mask) mk = (const uint64_t*)mask->ptr;
+    // ---- sample: clustered? how many groups?  (a verdict-only call leaves its sample for the call that follows on the same column)
+    const int64_t s = n < (1 << 19) ? n : (1 << 19), stride = n / s; const uint64_t cap = 1ull << 21;
+    if (ctx->pa_sample_key == key->values->ptr && ctx->pa_sample_n == n && ctx->pa_sample_mask == (const void*)mk) { for (int q = 0; q < 3; q++) ctx->h_pinned[q] = ctx->pa_sample[q]; ctx->pa_sample_key = nullptr; }
+    else {
+    BufferPtr table = alloc_buffer(ctx, cap * 8); HIP_CHECK(hipMemsetAsync(table->ptr, 0xFF, cap * 8, ctx->stream));
+    zero_scratch(ctx);
+    { KernelTimer kt_(ctx, "pa_sample");
+#define PA_SAMPLE(T) hipLaunchKernelGGL((k_pa_sample<T>), dim3(grid_for(s, BLOCK * 8, 256)), dim3(BLOCK), 0, ctx->stream, (const T*)key->values->ptr, mk, n, s, stride, (unsigned long long*)table->ptr, cap - 1, (unsigned long long*)ctx->d_scratch64)
+      switch (ktype) { case DFGPU_INT64: PA_SAMPLE(int64_t); break; case DFGPU_UINT64: PA_SAMPLE(uint64_t); break; case DFGPU_UINT32: PA_SAMPLE(uint32_t); break; default: PA_SAMPLE(int32_t); break; }
+#undef PA_SAMPLE
+      KERNEL_CHECK(); }
+    HIP_CHECK(hipMemcpyAsync(ctx->h_pinned, ctx->d_scratch64, 24, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->count_sync("sync:pa_sample");
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (verdict_only) { ctx->pa_sample_key = key->values->ptr; ctx->pa_sample_n = n; ctx->pa_sample_mask = (const void*)mk; for (int q = 0; q < 3; q++) ctx->pa_sample[q] = ctx->h_pinned[q]; }
+    }
+    const double d = (double)ctx->h_pinned[0], nondec = (double)ctx->h_pinned[1], pairs = (double)ctx->h_pinned[2], ss = pairs + 1;
+    if (pairs > 0 && nondec >= 0.98 * pairs && !ctx->agg_partitioned_force) skip("keys arrive clustered (run numbering is cheaper)");
+    // distinct keys D of the batch from d distinct among ss sampled rows: d = D (1 - exp(-ss / D))
+    double D = d;
+    if (d >= 0.999 * ss) D = 1e12; else { double lo = d, hi = 1e12; for (int it = 0; it < 200; it++) { double mid = 0.5 * (lo + hi); double e = mid * (1.0 - exp(-ss / mid)); if (e < d) lo = mid; else hi = mid; } D = 0.5 * (lo + hi); }
+    if (D > (double)n) D = (double)n;
+    if (!ctx->agg_partitioned_force) {
+      if (D < 3000) skip("few groups (the LDS cache of the accumulators holds them)");
+      if (D > 4.5e6) skip("more groups than one partition pass brings into LDS (a fan-out beyond 2048 costs more than it saves)");
+    }
+    if (verdict_only) return;
+    const int cell_bytes = 16 + 8 * plan.n_acc; int cbits = 12; while (cbits > 6 && (((size_t)1 << cbits) + 1) * cell_bytes > 150 * 1024) cbits--;
+    const double per_part = ((double)(1u << cbits)) * 0.55;
+    const double Dp = D > 4.0 * d ? D : 4.0 * d;          // skewed keys: the uniform model underestimates the tail, stay on the many-partitions side
+    int64_t P = (int64_t)(Dp / per_part) + 1; if (P < 64) P = 64; if (P > 2048) P = 2048; if (P > n / 2048 + 1) P = n / 2048 + 1;
+    if (P > ctx->num_cus) P = std::min<int64_t>(2048, (P + ctx->num_cus - 1) / ctx->num_cus * ctx->num_cus);
+    // ---- partition (key, row, value cells)
+    BufferPtr pkey = alloc_buffer(ctx, (size_t)n * 8), prow = alloc_buffer(ctx, (size_t)n * 4); std::vector<BufferPtr> pval((size_t)plan.n_acc);
+    RpCols cols{}; cols.n = 1 + plan.n_acc; cols.rowid_dst = (uint32_t*)prow->ptr;
+    cols.c[0] = RpCol{ key->values->ptr, pkey->ptr, 8, RP_HASHKEY, ktype };
+    for (int c = 0; c < plan.n_acc; c++) { pval[(size_t)c] = alloc_buffer(ctx, (size_t)n * 8); cols.c[1 + c] = RpCol{ cell_src[c]->values->ptr, pval[(size_t)c]->ptr, 8, RP_RAW, 0 }; plan.val[c] = (const uint64_t*)pval[(size_t)c]->ptr; }
+    RpResult r;
+#define PA_PART(T) r = rp_partition(ctx, RpHashInt<T>{ (const T*)key->values->ptr, nullptr, mk }, n, (uint32_t)P, cols, false, ctx->d_scratch64 + 9, "pa_hist", "pa_scan", "pa_scatter")
+    switch (ktype) { case DFGPU_INT64: case DFGPU_UINT64: PA_PART(int64_t); break; case DFGPU_UINT32: PA_PART(uint32_t); break; default: PA_PART(int32_t); break; }
+#undef PA_PART
+    // ---- aggregate every partition out of LDS
+    BufferPtr okey = alloc_buffer(ctx, (size_t)n * 8), ofirst = alloc_buffer(ctx, (size_t)n * 4), ocnt = alloc_buffer(ctx, (size_t)n * 4); std::vector<BufferPtr> oacc((size_t)plan.n_acc);
+    for (int c = 0; c < plan.n_acc; c++) { oacc[(size_t)c] = alloc_buffer(ctx, (size_t)n * 8); plan.out[c] = (uint64_t*)oacc[(size_t)c]->ptr; }
+    HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 12, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(k_pa_max_len, dim3((unsigned)((P + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)r.starts->ptr, (uint32_t)P, (unsigned long long*)(ctx->d_scratch64 + 13));
+    KERNEL_CHECK();
+    const int64_t max_len = (int64_t)read_scratch(ctx, 13);
+    int64_t slice = (n / P + 1) * 3 / 2; if (slice < 65536) slice = 65536;          // uniform keys never split (a partition is within a percent of the average) if (slice > 0x7FFFFFFF) slice = 0x7FFFFFFF;
+    const int64_t n_slices = max_len ? (max_len + slice - 1) / slice : 1;
+    { KernelTimer kt_(ctx, "pa_aggregate");
+      static bool once = false; if (!once) { HIP_CHECK(hipFuncSetAttribute((const void*)k_pa_aggregate, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); once = true; }
+      hipLaunchKernelGGL(k_pa_aggregate, dim3((unsigned)P, (unsigned)n_slices), dim3(PA_NT), (((size_t)1 << cbits) + 1) * cell_bytes, ctx->stream, (const uint64_t*)pkey->ptr, (const uint32_t*)prow->ptr, plan, (const uint32_t*)r.starts->ptr, cbits, (uint32_t)slice,
+                         (uint64_t*)okey->ptr, (uint32_t*)ofirst->ptr, (uint32_t*)ocnt->ptr, (unsigned long long*)(ctx->d_scratch64 + 12));
+      KERNEL_CHECK(); }
+    const int64_t m = (int64_t)read_scratch(ctx, 12);
+    pkey.reset(); prow.reset(); pval.clear();
+    // ---- partial rows in first-seen order of their groups
+    BufferPtr perm = alloc_buffer(ctx, (size_t)(m + 1) * 4);
+    { KernelTimer kt_(ctx, "pa_order");
+      launch_iota_u32(ctx, (uint32_t*)perm->ptr, m, 0);
+      if (ctx->first_seen_group_order) radix_sort_pairs_u32(ctx, (uint32_t*)ofirst->ptr, (uint32_t*)perm->ptr, m, 32); }
+    KernelTimer kt_(ctx, "pa_emit");
+    const uint32_t* pp = (const uint32_t*)perm->ptr; dim3 grid(grid_for(m, BLOCK));
+    ArrayHolder ok(new_fixed(ctx, ktype, m));
+    if (m) {
+      switch (ktype) {
+        case DFGPU_INT64: case DFGPU_UINT64: hipLaunchKernelGGL((k_pa_gather_key<uint64_t>), grid, dim3(BLOCK), 0, ctx->stream, (const uint64_t*)okey->ptr, pp, m, (uint64_t*)ok.get()->values->ptr); break;
+        default: hipLaunchKernelGGL((k_pa_gather_key<uint32_t>), grid, dim3(BLOCK), 0, ctx->stream, (const uint64_t*)okey->ptr, pp, m, (uint32_t*)ok.get()->values->ptr); break;
+      }
+    }
+    std::vector<ArrayHolder> st((size_t)n_aggs * 2);
+    for (int i = 0; i < n_aggs; i++) {
+      auto counts_as = [&](int32_t type) { dfgpu_array* a = new_fixed(ctx, type, m); if (m) hipLaunchKernelGGL(k_pa_gather_cnt, grid, dim3(BLOCK), 0, ctx->stream, (const uint32_t*)ocnt->ptr, pp, m, (uint64_t*)a->values->ptr); return a; };
+      auto cell_as = [&](int32_t type) { dfgpu_array* a = new_fixed(ctx, type, m); if (m) hipLaunchKernelGGL(k_pa_gather_u64, grid, dim3(BLOCK), 0, ctx->stream, (const uint64_t*)oacc[(size_t)cell_of[i]]->ptr, pp, m, (uint64_t*)a->values->ptr); return a; };
+      if (kinds[i] == DFGPU_AGG_COUNT) st[(size_t)2 * i].a = counts_as(DFGPU_INT64);                                                       // count.rs: Int64 state
+      else if (kinds[i] == DFGPU_AGG_AVG) { st[(size_t)2 * i].a = counts_as(DFGPU_UINT64); st[(size_t)2 * i + 1].a = cell_as(DFGPU_FLOAT64); }   // average.rs:392-430: (counts, sums)
+      else st[(size_t)2 * i].a = cell_as(values[i]->type);          // SUM / MIN / MAX of an 8-byte type: state type == input type (sum.rs:75-86, min_max.rs:102-139)
+    }
+    KERNEL_CHECK();
+    if (key->type == DFGPU_DICTIONARY) {           // DictionaryArray::try_new(codes, the input's dictionary)
+      dfgpu_array* d = nullptr; dfgpu_status st2 = dfgpu_array_make_dictionary(ctx, ok.get(), key->dictionary, &d);
+      if (st2 != DFGPU_OK) fail(st2, "%s", ctx->err.c_str());
+      out_keys[0] = d;
+    } else out_keys[0] = ok.release();
+    for (int i = 0; i < n_aggs; i++) { out_states[2 * i] = st[(size_t)2 * i].release(); out_states[2 * i + 1] = st[(size_t)2 * i + 1].release(); }
+  });
+}

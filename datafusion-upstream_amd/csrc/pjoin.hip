@@ -214,8 +214,8 @@ bool pj_build(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   if (!pj_key_type_ok(key0)) return false;
   int64_t per = ctx->join_partition_rows; if (per < 16) per = 16; if (per > 14000) per = 14000;
   int64_t P64 = (n + per - 1) / per; if (P64 < 1) P64 = 1;
-  if (P64 > ctx->num_cus && P64 <= RP_MAX_P) P64 = std::min<int64_t>(RP_MAX_P, (P64 + ctx->num_cus - 1) / ctx->num_cus * ctx->num_cus);      // whole rounds of one workgroup per CU
-  if (P64 > RP_MAX_P) return false;                    // larger builds: two partition passes (not built yet) -> general path
+  if (P64 > ctx->num_cus && P64 <= 2048) P64 = std::min<int64_t>(2048, (P64 + ctx->num_cus - 1) / ctx->num_cus * ctx->num_cus);      // whole rounds of one workgroup per CU
+  if (P64 > 2048) return false;                        // larger builds: finer partitions cost more than the general path saves
   auto part = std::make_unique<PartitionedBuild>();
   part->P = (uint32_t)P64;
   BufferPtr recs = alloc_buffer(ctx, (size_t)n * 12);

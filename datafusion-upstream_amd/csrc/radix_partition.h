@@ -21,9 +21,9 @@
 namespace dfgpu {
 
 constexpr int RP_R = 8;              // rows per lane and tile
-constexpr int RP_G = 16;             // tiles per histogram workgroup: 16 x 4 B = one 64-B burst per partition
+constexpr int RP_G = 16;             // tiles per histogram workgroup (P <= 2048): 16 x 4 B = one 64-B burst per partition; 4 beyond
 constexpr int RP_MAX_COLS = 12;
-constexpr uint32_t RP_MAX_P = 2048;  // LDS: histogram [P][RP_G] u32 = 128 KB
+constexpr uint32_t RP_MAX_P = 8192;  // LDS: histogram [P][G] u32 <= 128 KB, scatter cnt + delta = 64 KB
 constexpr uint32_t RP_MAX_STABLE_P = 256;
 
 __device__ inline uint32_t rp_pid(uint64_t h, uint32_t P) { return (uint32_t)(((h >> 32) * (uint64_t)P) >> 32); }   // monotone in the top hash bits, any P
@@ -62,22 +62,22 @@ struct RpRec12 { uint32_t lo, hi, row; };
 struct RpCols { int32_t n; uint32_t* rowid_dst; RpRec12* pack12_dst; RpCol c[RP_MAX_COLS]; };
 
 template <int NT, typename H>
-__global__ void __launch_bounds__(NT) k_rp_hist(H hs, int64_t n, uint32_t P, int64_t ntiles, uint32_t* counts /*[P][ntiles]*/) {
-  extern __shared__ uint32_t rp_lds[];        // [P][RP_G]
-  const int64_t t0 = (int64_t)blockIdx.x * RP_G;
-  for (int x = threadIdx.x; x < (int)P * RP_G; x += NT) rp_lds[x] = 0;
+__global__ void __launch_bounds__(NT) k_rp_hist(H hs, int64_t n, uint32_t P, int64_t ntiles, int G, uint32_t* counts /*[P][ntiles]*/) {
+  extern __shared__ uint32_t rp_lds[];        // [P][G]
+  const int64_t t0 = (int64_t)blockIdx.x * G;
+  for (int x = threadIdx.x; x < (int)P * G; x += NT) rp_lds[x] = 0;
   __syncthreads();
-  for (int g = 0; g < RP_G; g++) {
+  for (int g = 0; g < G; g++) {
     const int64_t base = (t0 + g) * (int64_t)(NT * RP_R);
     if (base >= n) break;
 #pragma unroll
     for (int q = 0; q < RP_R; q++) {
       int64_t i = base + (int64_t)q * NT + threadIdx.x; uint32_t pid; uint64_t hk;
-      if (i < n && hs(i, P, &pid, &hk)) atomicAdd(&rp_lds[pid * RP_G + g], 1u);
+      if (i < n && hs(i, P, &pid, &hk)) atomicAdd(&rp_lds[pid * G + g], 1u);
     }
   }
   __syncthreads();
-  for (int x = threadIdx.x; x < (int)P * RP_G; x += NT) { int p = x / RP_G, g = x % RP_G; if (t0 + g < ntiles) counts[(int64_t)p * ntiles + t0 + g] = rp_lds[x]; }
+  for (int x = threadIdx.x; x < (int)P * G; x += NT) { int p = x / G, g = x % G; if (t0 + g < ntiles) counts[(int64_t)p * ntiles + t0 + g] = rp_lds[x]; }
 }
 
 // LDS of the scatter: cnt[P] u32 | delta[P] u32 | spid[TILE] u16 | slidx[TILE] u16 | stage[TILE] u64 | (STABLE) wcnt[RP_R][NT / 64][P] u16
@@ -212,17 +212,18 @@ static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const 
   if (n > 0xFFFFFFF0ll) fail(DFGPU_NOT_IMPLEMENTED, "partitioning above 2^32-16 rows");
   RpResult r; r.P = P;
   r.starts = alloc_buffer(ctx, (size_t)(P + 1) * 4);
-  const bool big = P > 512 && !stable;                     // 8192-row tiles halve the count matrix; 4096-row tiles give more workgroups per CU
+  const bool big = P > 512 && P <= 2048 && !stable;        // 8192-row tiles halve the count matrix; 4096-row tiles give more workgroups per CU (and leave LDS for P > 2048)
+  const int G = P <= 2048 ? RP_G : 4;
   const int nt = big ? 1024 : 512, tile = nt * RP_R;
   const int64_t ntiles = n ? (n + tile - 1) / tile : 1; r.ntiles = ntiles;
   BufferPtr counts = alloc_buffer(ctx, (size_t)P * ntiles * 4);
-  const size_t hl = (size_t)P * RP_G * 4;
-  const int64_t nh = (ntiles + RP_G - 1) / RP_G;
+  const size_t hl = (size_t)P * G * 4;
+  const int64_t nh = (ntiles + G - 1) / G;
   { KernelTimer kt_(ctx, t_hist);
     if (big) { static bool once = false; if (!once) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_hist<1024, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); once = true; }
-      hipLaunchKernelGGL((k_rp_hist<1024, H>), dim3((unsigned)nh), dim3(1024), hl, ctx->stream, hs, n, P, ntiles, (uint32_t*)counts->ptr); }
+      hipLaunchKernelGGL((k_rp_hist<1024, H>), dim3((unsigned)nh), dim3(1024), hl, ctx->stream, hs, n, P, ntiles, G, (uint32_t*)counts->ptr); }
     else { static bool once = false; if (!once) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_hist<512, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); once = true; }
-      hipLaunchKernelGGL((k_rp_hist<512, H>), dim3((unsigned)nh), dim3(512), hl, ctx->stream, hs, n, P, ntiles, (uint32_t*)counts->ptr); }
+      hipLaunchKernelGGL((k_rp_hist<512, H>), dim3((unsigned)nh), dim3(512), hl, ctx->stream, hs, n, P, ntiles, G, (uint32_t*)counts->ptr); }
     KERNEL_CHECK(); }
   { KernelTimer kt_(ctx, t_scan); exclusive_scan_u32_inplace32(ctx, (uint32_t*)counts->ptr, (int64_t)P * ntiles, d_total); }
   hipLaunchKernelGGL(k_rp_starts, dim3((P + 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)counts->ptr, ntiles, P, (const uint64_t*)d_total, (uint32_t*)r.starts->ptr);

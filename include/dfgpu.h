@@ -99,6 +99,11 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
  * at least 8x smaller than the collected left input (rows and row order identical: both are "left rows by ascending index");
  * "fused_aggregate_min_rows" (rows, default 2^20; negative = never) == smallest batch for which the plan layer's AggregateExec hands
  * accumulator argument expressions to dfgpu_acc_update_batch_fused instead of evaluating them node by node (results identical);
+ * "join_partitioned" (1/0), "join_partitioned_min_build" / "join_partitioned_min_probe" (rows), "join_partition_rows" (build rows per partition, <= 14000) ==
+ * radix-partitioned hash join (csrc/pjoin.hip): large builds on unsorted integer keys with a sparse domain are split by key hash so that
+ * every partition's table sits in LDS; probe batches of >= min_probe rows are partitioned the same way.  Pairs and their order are identical;
+ * "agg_partitioned" (1/0), "agg_partitioned_min_rows", "agg_partitioned_force" (1 = skip the sample's verdict; tests) == let the plan layer's
+ * AggregateExec pre-aggregate large batches of high-cardinality unclustered keys partition by partition out of LDS (dfgpu_agg_preaggregate);
  * "defer_flag_checks" (1 = enter / 0 = leave a deferred region, nests) == kernel error flags (overflow, divide by zero,
  * cast range, index bounds -- the ArrowError cases of arrow-arith / arrow-cast / arrow-select) are normally checked by the
  * call that ran the kernel; inside a region they are checked once, by the call that leaves it (which returns the error),
@@ -288,6 +293,21 @@ DFGPU_API dfgpu_status dfgpu_jit_selftest(const char *arch, char *log, int64_t l
 /* ≙ GroupsAccumulator::merge_batch (:136-142): states as produced by dfgpu_acc_state. */
 DFGPU_API dfgpu_status dfgpu_acc_merge_batch(dfgpu_ctx *ctx, dfgpu_acc *a, const dfgpu_array *const *states, int32_t nstates,
                                              const dfgpu_array *group_ids, const dfgpu_array *opt_filter, int64_t total_num_groups);
+/* Partial aggregation of ONE batch ahead of intern / merge_batch (≙ AggregateMode::Partial applied inside the operator, aggregates/mod.rs:64-100,
+ * row_hash.rs:524-613): the batch is reduced to one row per group -- out_keys[0] = the group keys (type of keys[0]) in first-seen order of
+ * their groups, out_states[2 i], out_states[2 i + 1] = the state arrays of aggregate i exactly as dfgpu_acc_state returns them (COUNT: Int64;
+ * SUM / MIN / MAX: one array; AVG: UInt64 counts, sums; the second entry is NULL unless AVG).  The caller interns out_keys and calls
+ * dfgpu_acc_merge_batch with the states: results equal updating the accumulators with the batch row by row (Float64 sums within 1e-9
+ * relative: the additions are reassociated).  Rows are hash-partitioned on the key so that every partition's groups fit one LDS table
+ * (csrc/pagg.hip); a key may come back in more than one row when a partition held more groups than the table -- the merge adds them up.
+ * Taken for one 4- / 8-byte integer key column without NULLs, SUM / MIN / MAX over Int64 / UInt64, SUM / AVG over Float64, COUNT, value
+ * columns without NULLs, no per-aggregate filter, a batch of >= option "agg_partitioned_min_rows" rows whose keys are neither clustered
+ * nor few (a sample decides); any other shape returns DFGPU_NOT_IMPLEMENTED and the caller updates the accumulators the ordinary way.
+ * values[i] may be NULL for COUNT(*).  opt_mask: BOOL selection, unselected rows do not take part.
+ * out_keys == NULL asks for the verdict only (DFGPU_OK = a following call with the same key column and selection will be taken, as far as the
+ * key decides; kinds / values are ignored): the plan layer asks before it evaluates computed aggregate arguments. */
+DFGPU_API dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx *ctx, const dfgpu_array *const *keys, int32_t nkeys, const int32_t *kinds, const dfgpu_array *const *values, int32_t n_aggs,
+                                              const dfgpu_array *opt_mask, dfgpu_array **out_keys, dfgpu_array **out_states);
 /* ≙ evaluate(EmitTo::All) / state(EmitTo::All) (:106-134).  out_states holds up to 2 arrays. */
 DFGPU_API dfgpu_status dfgpu_acc_evaluate(dfgpu_ctx *ctx, dfgpu_acc *a, dfgpu_array **out);
 DFGPU_API dfgpu_status dfgpu_acc_state(dfgpu_ctx *ctx, dfgpu_acc *a, dfgpu_array **out_states, int32_t *n_states);

@@ -1,0 +1,172 @@
+"""-m gpu: partitioned pre-aggregation (csrc/pagg.hip, dfgpu_agg_preaggregate) against the CPU oracle.
+
+The partial rows of a batch, interned and merged (GroupValues::intern + GroupsAccumulator::merge_batch), must give exactly what the oracle's
+row-by-row update gives: the same groups in the same first-seen order, bit-exact integer / count states, Float64 sums within 1e-9
+relative.  Thresholds are lowered through the ctx options; the LDS table is made to overflow (more groups per partition than slots) to
+cover the flush path, and the key that equals the table's EMPTY marker (-1) gets its own slot."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+RNG = np.random.default_rng(20262)
+FLOAT_RTOL = 1e-9
+KIND = {"SUM": 0, "AVG": 1, "COUNT": 2, "MIN": 3, "MAX": 4}
+
+
+class forced:
+    def __init__(self, ctx, force=1, min_rows=1):
+        self.ctx, self.opts = ctx, {"agg_partitioned": 1, "agg_partitioned_force": force, "agg_partitioned_min_rows": min_rows}
+
+    def __enter__(self):
+        self.saved = {k: self.ctx.get_option(k) for k in self.opts}
+        for k, v in self.opts.items():
+            self.ctx.set_option(k, v)
+        self.ctx.profile_select(None); self.ctx.profile_enable(True); self.ctx.profile_read()
+        return self
+
+    def kernels(self):
+        return set(self.ctx.profile_read())
+
+    def __exit__(self, *a):
+        self.ctx.profile_enable(False)
+        for k, v in self.saved.items():
+            self.ctx.set_option(k, v)
+
+
+def run_device(ctx, key, aggs, mask=None):
+    """aggs: list of (kind name, pyarrow values or None).  -> (emitted keys, [evaluated arrays]) after preaggregate + intern + merge"""
+    import dfgpu
+    kd = ctx.from_arrow(key)
+    vals = [ctx.from_arrow(v) if v is not None else None for _, v in aggs]
+    pk, states = dfgpu.agg_preaggregate(ctx, kd, [KIND[k] for k, _ in aggs], vals, mask=ctx.from_arrow(pa.array(mask)) if mask is not None else None)
+    gv = dfgpu.GroupValues(ctx, 1)
+    gids = gv.intern([pk])
+    out = []
+    for (k, v), st in zip(aggs, states):
+        acc = dfgpu.GroupsAccumulator(ctx, KIND[k], dfgpu.capi.INT64 if v is None else {pa.int64(): dfgpu.capi.INT64, pa.uint64(): dfgpu.capi.UINT64, pa.float64(): dfgpu.capi.FLOAT64}[v.type])
+        acc.merge_batch(st, gids, None, len(gv))
+        out.append(acc.evaluate().to_arrow())
+    return gv.emit()[0].to_arrow(), out, len(pk)
+
+
+def run_oracle(key, aggs, mask=None):
+    if mask is not None:
+        key = key.filter(pa.array(mask)); aggs = [(k, v.filter(pa.array(mask)) if v is not None else None) for k, v in aggs]
+    og = po.Groups([key.type]); gids = og.intern([key])
+    out = []
+    for k, v in aggs:
+        acc = po.Acc(k, pa.int64() if v is None else v.type)
+        acc.update_batch(v, gids, None, len(og))
+        out.append(acc.evaluate())
+    return og.emit()[0], out
+
+
+def compare(got_keys, got, want_keys, want):
+    assert got_keys.equals(want_keys)                # same groups, same first-seen order
+    for g, w in zip(got, want):
+        assert g.type == w.type and len(g) == len(w)
+        if pa.types.is_floating(g.type):
+            a, b = g.to_numpy(zero_copy_only=False), w.to_numpy(zero_copy_only=False)
+            assert np.allclose(a, b, rtol=FLOAT_RTOL, atol=0.0)
+        else:
+            assert g.equals(w)
+
+
+CASES = [(200000, 5000, np.int64), (300000, 120000, np.int64), (100000, 100000, np.int64), (150000, 40, np.int64), (250000, 30000, np.int32), (4096, 4096, np.int64), (1, 1, np.int64)]
+
+
+@pytest.mark.parametrize("n,card,dt", CASES, ids=[f"{c[0]}r-{c[1]}g-{np.dtype(c[2]).name}" for c in CASES])
+def test_preaggregate_then_merge_equals_row_by_row(ctx, n, card, dt):
+    lo, hi = (-(1 << 62), 1 << 62) if dt == np.int64 else (-(1 << 31), 1 << 31)
+    pool = RNG.integers(lo, hi, card, dtype=np.int64).astype(dt)
+    pool[0] = -1                                       # the EMPTY marker of the LDS table as a real key
+    key = pa.array(pool[RNG.integers(0, card, n)])
+    vi = pa.array(RNG.integers(-10**9, 10**9, n).astype(np.int64)); vf = pa.array(RNG.random(n) * 1000 - 300)
+    aggs = [("SUM", vi), ("COUNT", None), ("MIN", vi), ("MAX", vi), ("AVG", vf), ("SUM", vf), ("COUNT", vi)]
+    with forced(ctx) as f:
+        gk, got, m = run_device(ctx, key, aggs)
+        assert "pa_aggregate" in f.kernels()
+    wk, want = run_oracle(key, aggs)
+    compare(gk, got, wk, want)
+    assert m >= len(wk)
+
+
+def test_table_overflow_flushes_and_still_merges_exactly(ctx):
+    """The sample (every 2nd row of 2.2 M) sees 100 keys, the other rows are all distinct: 64 partitions of ~17 000 groups each against
+    4096-slot tables -> the workgroups flush again and again, keys come back in several partial rows, the merge adds them up exactly."""
+    n = 2200000
+    key = np.arange(n, dtype=np.int64) * 7919 + 12345
+    key[0::2] = RNG.integers(0, 100, len(key[0::2])) * 3
+    key = pa.array(key)
+    vu = pa.array(RNG.integers(0, 10**12, n).astype(np.uint64))
+    aggs = [("SUM", vu), ("MAX", vu), ("COUNT", None)]
+    with forced(ctx) as f:
+        gk, got, m = run_device(ctx, key, aggs)
+    wk, want = run_oracle(key, aggs)
+    compare(gk, got, wk, want)
+    assert m > len(wk)                                   # some key came back in more than one partial row
+
+
+def test_skewed_keys_cut_the_hot_partition_into_slices(ctx):
+    """Zipf keys: one partition holds a large share of the rows and is aggregated by several workgroups (slices), each leaving its own
+    partial rows for the hot keys -- merged downstream, results exact."""
+    n = 3000000
+    key = pa.array(((np.random.default_rng(5).zipf(1.2, n) % 200000) * 7919).astype(np.int64))
+    v = pa.array(RNG.integers(-1000, 1000, n).astype(np.int64)); f = pa.array(RNG.random(n))
+    aggs = [("SUM", v), ("COUNT", None), ("MIN", v), ("AVG", f)]
+    with forced(ctx):
+        gk, got, m = run_device(ctx, key, aggs)
+    wk, want = run_oracle(key, aggs)
+    compare(gk, got, wk, want)
+
+
+def test_fused_selection_mask(ctx):
+    n = 200000
+    key = pa.array(RNG.integers(0, 20000, n).astype(np.int64)); v = pa.array(RNG.integers(0, 1000, n).astype(np.int64)); mask = RNG.random(n) < 0.4
+    aggs = [("SUM", v), ("COUNT", None)]
+    with forced(ctx):
+        gk, got, _ = run_device(ctx, key, aggs, mask)
+    wk, want = run_oracle(key, aggs, mask)
+    compare(gk, got, wk, want)
+
+
+def test_sample_declines_clustered_few_and_unsupported_shapes(ctx):
+    import dfgpu
+    n = 300000
+    v = ctx.from_arrow(pa.array(np.arange(n, dtype=np.int64)))
+    with forced(ctx, force=0):
+        for key in (np.sort(RNG.integers(0, 50000, n)), RNG.integers(0, 100, n)):          # clustered; few groups
+            with pytest.raises(dfgpu.DfgpuError):
+                dfgpu.agg_preaggregate(ctx, ctx.from_arrow(pa.array(key.astype(np.int64))), [0], [v])
+        with pytest.raises(dfgpu.DfgpuError):                                                # nullable key
+            dfgpu.agg_preaggregate(ctx, ctx.from_arrow(pa.array(RNG.integers(0, 50000, n), mask=RNG.random(n) < 0.1)), [0], [v])
+        pk, _ = dfgpu.agg_preaggregate(ctx, ctx.from_arrow(pa.array(RNG.integers(0, 50000, n).astype(np.int64))), [0], [v])     # taken
+        assert len(pk) >= 49000
+
+
+def test_aggregate_exec_takes_the_partitioned_path_and_matches(ctx):
+    """AggregateExec(Single) GROUP BY an unclustered Int64 key through the plan layer: partial rows interned + merged == the ordinary path."""
+    import dfgpu
+    from dfgpu import capi, physical_plan as ops
+    n = 400000
+    k = RNG.integers(0, 60000, n).astype(np.int64) * 104729; v = RNG.integers(-1000, 1000, n).astype(np.int64); f = RNG.random(n)
+    batch = ops.batch_from_arrow(ctx, pa.table({"k": pa.array(k), "v": pa.array(v), "f": pa.array(f)}))
+    C, F = ops.Column, ops.Field
+    aggs = lambda: [ops.AggregateFunctionExpr("SUM", C("v", 1), "s", input_field=F("v", capi.INT64)), ops.AggregateFunctionExpr("COUNT", None, "c"),
+                    ops.AggregateFunctionExpr("AVG", C("f", 2), "a", input_field=F("f", capi.FLOAT64)), ops.AggregateFunctionExpr("MAX", C("v", 1), "m", input_field=F("v", capi.INT64))]
+    tc = ops.TaskContext(ctx, batch_size=8192)
+    res = []
+    for on in (1, 0):
+        with forced(ctx, force=0) as fz:
+            ctx.set_option("agg_partitioned", on)
+            plan = ops.AggregateExec("Single", [(C("k", 0), "k")], aggs(), ops.MemoryExec([[batch]], batch.schema))
+            cols = [[c.to_arrow() for c in b.materialize().columns] for b in plan.execute(0, tc)]
+            ran = fz.kernels()
+        assert ("pa_aggregate" in ran) == bool(on)
+        res.append([pa.concat_arrays([c[i] for c in cols]) for i in range(5)])
+    a, b = res
+    assert a[0].equals(b[0]) and a[1].equals(b[1]) and a[2].equals(b[2]) and a[4].equals(b[4])         # keys in the same (first-seen) order, SUM / COUNT / MAX exact
+    assert np.allclose(a[3].to_numpy(), b[3].to_numpy(), rtol=FLOAT_RTOL, atol=0.0)
