@@ -11,6 +11,12 @@ Extra objects in the JSON line:
                recorded on the stream the kernel runs on, through dfgpu_profile_*), against 8 TB/s HBM3E.
   cpu_baseline the oracle's restatement of the same plan (oracle/dfo_tpch.c, "port") timed on this box's host cores
                over a bounded SF sample of the same workload; reported, never the target.
+  result_check (N = 1) the step's result against a recomputation of Q3 with plain torch ops over the same tensors, outside the timed region.
+  q3_general_paths (N = 1) the same plan with the rank index and the run numbering switched off: joins through the radix-partitioned /
+               open-addressing hash tables, group-by through the hash table -- the paths unsorted keys take.
+  workloads    (N = 1) the other target plan shapes (bench_workloads.py): Q1 (Decimal128 and Float64), Q5, Q18, the sparse-key hash join,
+               unclustered group-bys, SortExec, the ClickBench Q28 shape, each with ms_per_step, rows_per_s and its roofline figures.
+  plans        (N > 1) ms per step of the other two distribution plans, measured after the timed region.
 Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N
 """
 import argparse
@@ -99,7 +105,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
-    ap.add_argument("--plan", choices=["colocated", "broadcast", "shuffle"], default="colocated",
+    ap.add_argument("--no-workloads", action="store_true", help="N = 1: skip the nested other plan shapes (bench_workloads.py)")
+    ap.add_argument("--workloads", default="q1_decimal,q1_float64,q5,q18,hash_join,groupby_int64,sort,partition,clickbench_uniform_1000000,clickbench_zipf_1000000",
+                    help="N = 1: which plan shapes of bench_workloads.py to nest under \"workloads\"")
+    ap.add_argument("--plan", choices=["colocated", "broadcast", "shuffle"], default="shuffle",
                     help="N > 1: colocated = customer build side broadcast, orders-lineitem join and aggregation partition-local (the shards are co-partitioned on "
                          "the order key, as TPC-H files are); broadcast = both build sides all-gathered (CollectLeft), partial aggregates shuffled; "
                          "shuffle = the reference's fully partitioned plan (hash repartition of every join / aggregate input)")
@@ -130,7 +139,10 @@ def main():
     # one ctx on torch's current stream: dfgpu kernels, torch ops and RCCL collectives are stream ordered
     ctx = dfgpu.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
     tc = ops.TaskContext(ctx, batch_size=8192)
-    tables = tpch.gen_device(ctx, args.sf, rank=rank, world=world)
+    tensors = tpch.gen_device_tensors(args.sf, rank=rank, world=world)
+    tables = tpch.tables_from_torch(ctx, tensors)
+    if world > 1:
+        tensors = None
     rows_local = sum(t.num_rows for t in tables.values())
     rows_total = rows_local
     if world > 1:
@@ -139,7 +151,7 @@ def main():
         rows_total = int(t.item())
     torch.cuda.synchronize()
 
-    result_rows = [0]
+    result_rows, last_out = [0], [None]
 
     PLANS = {"colocated": tpch.q3_colocated_plan, "broadcast": tpch.q3_broadcast_plan, "shuffle": tpch.q3_distributed_plan}
     Q3_OUTPUT = ["l_orderkey", "revenue", "o_orderdate", "o_shippriority"]
@@ -174,6 +186,7 @@ def main():
                 out = [b for b in ops.with_fresh_state(final_plan).execute(0, tc)]
         ctx.synchronize()
         result_rows[0] = sum(b.num_rows for b in out)
+        last_out[0] = out
 
     def barrier():
         torch.cuda.synchronize()
@@ -258,9 +271,73 @@ def main():
             if roofline.get("achieved"):
                 roofline["frac_of_measured_copy"] = round(roofline["achieved"] / copy_gbs, 4)
         roofline["host_syncs_per_step"] = host_syncs       # stream synchronisations by cause (counts the host must read back)
-        q_gbs = Q3_BYTES_PER_ROW * rows_total / (ms_per_step * 1e-3) / 1e9
-        roofline["query"] = {"achieved": round(q_gbs, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(q_gbs / (HBM_PEAK_GBS * world), 4),
-                             "algorithmic_bytes_per_step": int(Q3_BYTES_PER_ROW * rows_total)}
+        roofline["traffic_source"] = "profiles/traffic_r01.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel, gfx950 x2 FETCH correction; a tracked file, not measured in this run)"
+        if roofline.get("achieved") and rank == 0:
+            assert roofline["achieved"] <= roofline["measured_copy_GBps"] * 1.25, "kernel bandwidth above the box's copy ceiling: wrong byte count"
+    # Not a bandwidth: SURVEY 8(d)'s 39.4 B per input row counts every referenced column in full, while the plan (late materialisation, fused
+    # selections) touches about 12 GB of the 30 GB at SF100.  Reported as a logical scan rate only.
+    logical_scan = {"bytes_per_input_row": Q3_BYTES_PER_ROW, "GBps": round(Q3_BYTES_PER_ROW * rows_total / (ms_per_step * 1e-3) / 1e9, 1),
+                    "note": "logical bytes of every referenced column / step time; NOT HBM traffic (filtered rows' payload columns are never read)"}
+
+    # ---- N = 1: result check at full scale, the general (hash) paths of the same query, the other target plan shapes
+    result_check = general = workloads = other_plans = None
+    if world == 1:
+        got = tpch.q3_checksum_result(last_out[0] or [])
+        want = tpch.q3_checksum_torch(tensors)
+        result_check = {"ok": got == want, "device": got, "torch": want, "what": "result groups, wrapping Int64 sums of l_orderkey and of unscaled revenue: the last timed step against plain torch ops over the same tensors"}
+        assert got == want, f"Q3 result differs from the torch recomputation: {got} vs {want}"
+        del want
+        # the same plan with the clustered-key shortcuts off: joins build hash tables (radix-partitioned LDS tables for the 150 M-row orders build is not
+        # taken -- dense domain -- so: membership bitmap + open addressing), the 3-key group-by goes through the hash table
+        saved = {k: ctx.get_option(k) for k in ("join_rank_index", "group_run_detection")}
+        for k in saved:
+            ctx.set_option(k, 0)
+        try:
+            step()
+            ctx.profile_select(None); ctx.profile_enable(True); ctx.profile_read(); step(); gp, _ = split_syncs(ctx.profile_read()); ctx.profile_enable(False)
+            barrier(); t1 = time.perf_counter()
+            for _ in range(3):
+                step()
+            barrier(); g_ms = (time.perf_counter() - t1) / 3 * 1e3
+            assert tpch.q3_checksum_result(last_out[0] or []) == got, "general-path Q3 result differs"
+        finally:
+            for k, v in saved.items():
+                ctx.set_option(k, v)
+        general = {"options": {"join_rank_index": 0, "group_run_detection": 0}, "ms_per_step": round(g_ms, 3), "rows_per_s": round(rows_total / (g_ms * 1e-3), 1), "steps": 3, "result_check": "same checksums as the default paths",
+                   "kernel_ms_per_step": {k: round(v[1], 3) for k, v in sorted(gp.items(), key=lambda kv: -kv[1][1])[:12]}}
+        last_out[0] = None
+        if not args.no_workloads:
+            import argparse as _ap
+            import bench_workloads
+            del template, tables, tensors
+            torch.cuda.empty_cache()
+            res = bench_workloads.run(_ap.Namespace(sf=args.sf, steps=3, warmup=2, only=args.workloads), ctx=ctx, emit=False)
+            workloads = {r["workload"]: {k: r[k] for k in ("input_rows", "result_rows", "ms_per_step", "rows_per_s", "algorithmic_GBps", "frac_of_hbm_peak", "algorithmic_bytes_per_row", "roofline", "host_syncs_per_step") if k in r}
+                         | {"kernel_ms_per_step": dict(list(r["kernel_ms_per_step"].items())[:8])} | {k: r[k] for k in r if k in ("cardinality", "build_rows", "probe_rows", "partitions", "exchange")} for r in res}
+    else:
+        # the other two distribution plans, after the timed region (every rank takes part: they hold collectives)
+        other_plans = {}
+        for name in ("shuffle", "broadcast", "colocated"):
+            if name == args.plan:
+                continue
+            st2 = tpch.Q3ColocatedStaged(tables, batch_size=8192) if name == "colocated" else None
+            def step2():
+                plan = st2 if st2 is not None else PLANS[name](tables, batch_size=8192)
+                with ctx.deferred_flags():
+                    local = [b for b in plan.execute(0, tc)]
+                    mine = ops.concat_batches(local[0].schema, local) if local else None
+                    gathered = exchange.gather_batches(ctx, None, mine, 0, names=Q3_OUTPUT)
+                if rank == 0 and gathered.num_rows:
+                    final_slot.replace([[gathered]])
+                    [b for b in ops.with_fresh_state(final_plan).execute(0, tc)]
+                ctx.synchronize()
+            step2(); barrier(); t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step2()
+            barrier(); el = time.perf_counter() - t1
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            other_plans[name] = {"ms_per_step": round(float(t.item()) / args.steps * 1e3, 3), "rows_per_s": round(rows_total * args.steps / float(t.item()), 1)}
 
     # ---- CPU baseline: the oracle's restatement of the same plan on a bounded sample (rank 0, N = 1 only)
     cpu_baseline = None
@@ -303,7 +380,15 @@ def main():
                                                 "input_rows": rows_total, "result_rows": result_rows[0], "parallelism": {"colocated": f"{world} GPUs, range-sharded tables: RCCL all-gather of the customer build side, partition-local orders-lineitem join + aggregation, gather of sorted partitions",
                                                                 "broadcast": f"{world} GPUs, CollectLeft joins: RCCL all-gather of build sides + all-to-all of partial aggregates",
                                                                 "shuffle": f"{world} GPUs, partitioned joins: hash partition + RCCL all-to-all per exchange"}[args.plan] if world > 1 else "1 GPU"},
-                "roofline": roofline, "cpu_baseline": cpu_baseline}
+                "roofline": roofline, "cpu_baseline": cpu_baseline, "logical_scan_rate": logical_scan}
+        line["config"]["paths"] = "joins: membership bitmap + rank index (clustered, dense TPC-H keys: no hash table); group-by: run numbering (input clustered on l_orderkey); see q3_general_paths for the hash paths"
+        if world == 1:
+            line["result_check"] = result_check; line["q3_general_paths"] = general
+            if workloads is not None:
+                line["workloads"] = workloads
+        else:
+            line["plans"] = other_plans
+            line["config"]["plan"] = args.plan
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -13,6 +13,8 @@ rows/s = input rows / wall time; per-kernel device time from one fully bracketed
   groupby_int64  GROUP BY an unclustered Int64 key (hash table path), 1 M and 20 M groups over 1 M x sf rows, SUM + COUNT, top 10  [16 B/row]
   sort         SortExec over 1 M x sf rows: ORDER BY l_extendedprice DESC, l_shipdate, three columns materialised in the new order
                [28 B/row in + 28 B/row out]
+  partition    RepartitionExec Hash([l_orderkey], 8) over the four Q3 lineitem columns (Int64, 2 x Decimal128, Date32), every partition's
+               columns materialised: the per-rank work of one shuffle of the 8-GPU plan  [44 B/row in + 44 B/row out]
   clickbench   ClickBench Q28 shape: filter key <> '' -> GROUP BY a dictionary-encoded Utf8 key -> AVG(Int32 as f64), COUNT(*),
                MAX(Int64) -> HAVING -> ORDER BY avg DESC LIMIT 25; uniform and Zipf(1.1) keys  [code 4 + 4 + 8 B/row]
 This is NOT the driver's bench contract (bench.py is); it exists so that DESIGN.md can quote measured numbers for these shapes.
@@ -76,12 +78,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--only", default="")
     args = ap.parse_args()
+    run(args)
+
+
+def run(args, ctx=None, emit=True):
+    """args: .sf .steps .warmup .only (comma separated workload names, "" = all).  Returns the list of result dicts (bench.py nests them
+    in its JSON line); emit = also print one JSON line per workload."""
     import pyarrow as pa
     import torch
     import dfgpu
     from dfgpu import capi, physical_plan as ops
-    torch.cuda.set_device(0)
-    ctx = dfgpu.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    if ctx is None:
+        torch.cuda.set_device(0)
+        ctx = dfgpu.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     tc = ops.TaskContext(ctx, batch_size=8192)
     C, L, B, F = ops.Column, ops.Literal, ops.BinaryExpr, ops.Field
     g = torch.Generator(device="cuda"); g.manual_seed(20241024)
@@ -100,7 +109,12 @@ def main():
                 "algorithmic_bytes_per_row": bytes_per_row, "kernel_ms_per_step": kern, "host_syncs_per_step": syncs}
         if extra:
             line.update(extra)
-        print(json.dumps(line), flush=True)
+        if kern:
+            dk = next(iter(kern))
+            line["roofline"] = {"bound": "hbm", "kernel": dk, "kernel_ms_per_step": kern[dk], "frac": line["frac_of_hbm_peak"], "unit": "GB/s", "achieved": line["algorithmic_GBps"], "peak": HBM_PEAK_GBS,
+                                "note": "achieved = the workload's algorithmic bytes / step time (the plan's whole pass, not one kernel); kernel = largest device time of the bracketed step"}
+        if emit:
+            print(json.dumps(line), flush=True)
         out.append(line)
 
     # ------------------------------------------------------------------ Q1
@@ -303,6 +317,40 @@ def main():
         del price, sdate, okey, batch, plan
         torch.cuda.empty_cache()
 
+    # ------------------------------------------------------------------ RepartitionExec: lineitem's Q3 columns hashed on l_orderkey into 8 partitions
+    if not want or "partition" in want:
+        price, disc = dec_tensor(torch, n, 90000, 10494951, g), dec_tensor(torch, n, 0, 11, g)
+        sdate = torch.randint(8035, 10560, (n,), generator=g, device="cuda", dtype=torch.int32)
+        torch.cuda.synchronize()
+        batch = ops.RecordBatch.from_arrays(ctx, ["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"],
+                                            [ctx.wrap_tensor(l_orderkey, capi.INT64), ctx.wrap_tensor(price, capi.DECIMAL128, 15, 2), ctx.wrap_tensor(disc, capi.DECIMAL128, 15, 2), ctx.wrap_tensor(sdate, capi.DATE32)])
+        nparts = 8
+        plan = ops.RepartitionExec(ops.MemoryExec([[batch]], batch.schema), ops.Partitioning.Hash([C("l_orderkey", 0)], nparts))
+
+        def timed_partition():
+            def step():
+                p2 = ops.with_fresh_state(plan); rows = 0
+                with ctx.deferred_flags():
+                    for d in range(nparts):
+                        for b in p2.execute(d, tc):
+                            b.columns; rows += b.num_rows
+                ctx.synchronize()
+                return rows
+            for _ in range(max(args.warmup, 1)):
+                step()
+            ctx.profile_enable(True); ctx.profile_read(); step(); pr = ctx.profile_read(); ctx.profile_enable(False)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                rows = step()
+            dt = (time.perf_counter() - t0) / args.steps
+            kern = {k: round(v[1], 3) for k, v in sorted(pr.items(), key=lambda kv: -kv[1][1]) if not k.startswith("sync:")}
+            return dt, rows, kern, sum(v[0] for k, v in pr.items() if k.startswith("sync:"))
+        dt, rows, kern, syncs = timed_partition()
+        assert rows == n
+        report("partition_hash_8", dt, n, rows, 2 * (8 + 16 + 16 + 4), kern, syncs, {"partitions": nparts})
+        del price, disc, sdate, batch, plan
+        torch.cuda.empty_cache()
+
     # ------------------------------------------------------------------ ClickBench-style string-key group-by (100 M rows at sf 100)
     nrows = int(1_000_000 * args.sf)
     for card, zipf in ((1000, False), (1_000_000, False), (20_000_000, False), (1_000_000, True)):
@@ -335,6 +383,7 @@ def main():
         report(name, dt, nrows, rows, 4 + 4 + 8, kern, syncs, {"cardinality": card})
         del ids, length, w, batch, src, plan, dictionary
         torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":

@@ -141,6 +141,7 @@ PROTOTYPES = {
     "dfgpu_acc_size": (C.c_int64, [_P]),
     "dfgpu_sort_to_indices": (C.c_int32, [_P, _PP, C.c_char_p, C.c_char_p, C.c_int32, C.c_int64, _PP]),
     "dfgpu_hash_partition": (C.c_int32, [_P, _PP, C.c_int32, C.c_int32, _PP, C.POINTER(C.c_int64)]),
+    "dfgpu_partition_columns": (C.c_int32, [_P, _PP, C.c_int32, C.c_int32, _PP, C.c_int32, _P, _PP, _PP, C.POINTER(C.c_int64)]),
 }
 
 # include/dfgpu_exec.h: the C++ host layer (ExecutionPlan / PhysicalExpr mirror)

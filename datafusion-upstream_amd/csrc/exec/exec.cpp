@@ -405,6 +405,36 @@ struct CoalescePartitionsExec : Plan {   // coalesce_partitions.rs
 
 // ≙ BatchPartitioner::partition_iter for Partitioning::Hash (repartition/mod.rs:148-221); honours a fused selection
 static void partition_batch(const TaskContext& tc, Batch& b, const std::vector<ExprPtr>& exprs, int n, std::vector<std::vector<Batch>>& outs) {
+  if (b.base_rows == 0) return;
+  bool safe_keys = true; for (auto& e : exprs) safe_keys &= e->safe();
+  if (n <= 256 && (!b.selection || safe_keys)) {
+    // one pass (dfgpu_partition_columns): the key expressions run over the full-length batch (a fused selection goes along as the mask),
+    // every materialised fixed-width column is written grouped by destination in the same read; lazy / variable-width columns follow
+    // through the grouped row numbers
+    Batch kb = b; kb.selection = ArrayRef();
+    std::vector<ArrayRef> keys; std::vector<const dfgpu_array*> kp;
+    for (auto& e : exprs) { keys.push_back(into_array(tc, e->eval(tc, kb), kb.base_rows)); kp.push_back(keys.back().a); }
+    std::vector<const dfgpu_array*> cp; for (auto& c : b.cols) cp.push_back(c.arr ? c.arr.a : nullptr);
+    std::vector<dfgpu_array*> oc(b.cols.size(), nullptr); std::vector<int64_t> counts((size_t)n); dfgpu_array* idx = nullptr;
+    tc.check(dfgpu_partition_columns(tc.ctx, kp.data(), (int32_t)kp.size(), n, cp.data(), (int32_t)cp.size(), b.selection.a, oc.data(), &idx, counts.data()));
+    ArrayRef indices = ArrayRef::adopt(idx); std::vector<ArrayRef> moved; for (auto* x : oc) moved.push_back(ArrayRef::adopt(x));
+    int64_t off = 0;
+    for (int d = 0; d < n; d++) {
+      const int64_t cnt = counts[(size_t)d];
+      if (cnt) {
+        auto slice = [&](const ArrayRef& a) { dfgpu_array* s = nullptr; tc.check(dfgpu_array_slice(tc.ctx, a.a, off, cnt, &s)); return ArrayRef::adopt(s); };
+        ArrayRef rows;
+        Batch o; o.schema = b.schema; o.base_rows = cnt; MemoPtr memo = std::make_shared<TakeMemo>();
+        for (size_t c = 0; c < b.cols.size(); c++) {
+          if (moved[c]) o.cols.push_back(col_of(slice(moved[c])));
+          else { if (!rows) rows = slice(indices); o.cols.push_back(col_take(b.cols[c], rows, memo)); }
+        }
+        outs[(size_t)d].push_back(std::move(o));
+      }
+      off += cnt;
+    }
+    return;
+  }
   ArrayRef sel; Batch kb = b;
   if (b.selection) { std::set<int> need; for (auto& e : exprs) e->columns(need); sel = mask_indices(tc, b.selection); kb = materialize_subset(tc, b, need); }
   if (kb.base_rows == 0) return;

@@ -5,6 +5,7 @@
 // with the grouped index list (`take`, :202) and slices it by the returned counts -- on N GPUs those
 // slices are the send buffers of the RCCL all-to-all that replaces the in-process channels (:442-580).
 #include "device_utils.h"
+#include "radix_partition.h"
 
 namespace dfgpu {
 
@@ -32,6 +33,18 @@ extern "C" dfgpu_status dfgpu_hash_partition(dfgpu_ctx* ctx, const dfgpu_array* 
     if (num_partitions < 1 || num_partitions > 4096) fail(DFGPU_INVALID_ARGUMENT, "hash_partition: 1..4096 partitions supported, got %d", num_partitions);
     KeySet ks = make_keyset(keys, nkeys);
     int64_t n = keys[0]->length;
+    if ((uint32_t)num_partitions <= RP_MAX_STABLE_P && n > 0 && n <= 0xFFFFFFF0ll) {        // one stable LDS-staged pass (radix_partition.h): the row numbers only
+      ArrayHolder idx(new_fixed(ctx, DFGPU_UINT32, n));
+      RpCols cols{}; cols.n = 0; cols.rowid_dst = (uint32_t*)idx.get()->values->ptr;
+      RpResult r = rp_partition(ctx, RpHashKeySet{ ks, nullptr, ctx->force_hash_collisions ? 1 : 0 }, n, (uint32_t)num_partitions, cols, true, ctx->d_scratch64 + 9, "rp_hist", "rp_scan", "rp_scatter");
+      std::vector<uint32_t> st((size_t)num_partitions + 1);
+      HIP_CHECK(hipMemcpyAsync(st.data(), r.starts->ptr, st.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+      ctx->count_sync("sync:partition_counts");
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      for (int32_t p2 = 0; p2 < num_partitions; p2++) counts_host[p2] = (int64_t)st[(size_t)p2 + 1] - (int64_t)st[(size_t)p2];
+      *out_indices = idx.release();
+      return;
+    }
     ArrayHolder idx(new_fixed(ctx, DFGPU_UINT32, n));
     launch_iota_u32(ctx, (uint32_t*)idx.get()->values->ptr, n, 0);
     BufferPtr dest = alloc_buffer(ctx, (size_t)(n + 1) * 4), counts = alloc_buffer(ctx, (size_t)num_partitions * 8, true);
@@ -45,5 +58,54 @@ extern "C" dfgpu_status dfgpu_hash_partition(dfgpu_ctx* ctx, const dfgpu_array* 
     HIP_CHECK(hipMemcpyAsync(counts_host, counts->ptr, (size_t)num_partitions * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     *out_indices = idx.release();
+  });
+}
+
+// ≙ BatchPartitioner::partition_iter with the `take` of every column folded in (repartition/mod.rs:196-214): ONE pass reads the key and
+// payload columns and writes them grouped by destination (input order kept inside a destination).  out_cols[c] receives column c of all
+// destinations back to back (the caller slices it by counts_host) for fixed-width columns without NULLs; for any other column (Utf8,
+// dictionary, nullable) out_cols[c] stays NULL and the caller gathers it through out_indices, which is always produced.
+// opt_mask: rows not selected are dropped (a fused FilterExec).
+extern "C" dfgpu_status dfgpu_partition_columns(dfgpu_ctx* ctx, const dfgpu_array* const* keys, int32_t nkeys, int32_t num_partitions, const dfgpu_array* const* cols, int32_t ncols,
+                                                const dfgpu_array* opt_mask, dfgpu_array** out_cols, dfgpu_array** out_indices, int64_t* counts_host) {
+  return guard(ctx, [&] {
+    if (!keys || !out_indices || !counts_host || (ncols && (!cols || !out_cols))) fail(DFGPU_INVALID_ARGUMENT, "partition_columns: null argument");
+    if (num_partitions < 1 || (uint32_t)num_partitions > RP_MAX_STABLE_P) fail(DFGPU_NOT_IMPLEMENTED, "partition_columns: 1..%u partitions, got %d", RP_MAX_STABLE_P, num_partitions);
+    KeySet ks = make_keyset(keys, nkeys);
+    const int64_t n = keys[0]->length;
+    if (n > 0xFFFFFFF0ll) fail(DFGPU_NOT_IMPLEMENTED, "partition_columns above 2^32-16 rows");
+    BufferPtr mask = effective_mask(ctx, opt_mask, n);
+    for (int32_t c = 0; c < ncols; c++) { out_cols[c] = nullptr; if (cols[c] && cols[c]->length != n) fail(DFGPU_INVALID_ARGUMENT, "partition_columns: column %d has %lld rows, keys have %lld", c, (long long)cols[c]->length, (long long)n); }
+    ArrayHolder idx(new_fixed(ctx, DFGPU_UINT32, n));
+    std::vector<ArrayHolder> outs((size_t)ncols);
+    std::vector<int> direct;
+    for (int32_t c = 0; c < ncols; c++) {
+      const dfgpu_array* a = cols[c];
+      if (!a || a->type == DFGPU_DICTIONARY || a->type == DFGPU_UTF8 || a->type == DFGPU_BOOL || a->validity || !type_width(a->type)) continue;
+      direct.push_back(c);
+      outs[(size_t)c].a = new_fixed(ctx, a->type, n, a->precision, a->scale);
+    }
+    RpResult r; std::vector<uint32_t> st((size_t)num_partitions + 1, 0);
+    if (n) {
+      // RP_MAX_COLS columns per pass; the row numbers ride with the first pass
+      for (size_t c0 = 0; c0 < direct.size() || c0 == 0; c0 += RP_MAX_COLS) {
+        RpCols rc{}; rc.rowid_dst = c0 == 0 ? (uint32_t*)idx.get()->values->ptr : nullptr;
+        for (size_t j = c0; j < direct.size() && j < c0 + RP_MAX_COLS; j++) { const dfgpu_array* a = cols[direct[j]]; rc.c[rc.n++] = RpCol{ a->values->ptr, outs[(size_t)direct[j]].get()->values->ptr, type_width(a->type), RP_RAW, a->type }; }
+        r = rp_partition(ctx, RpHashKeySet{ ks, mask ? (const uint64_t*)mask->ptr : nullptr, ctx->force_hash_collisions ? 1 : 0 }, n, (uint32_t)num_partitions, rc, true, ctx->d_scratch64 + 9, "rp_hist", "rp_scan", "rp_scatter");
+        if (direct.size() <= c0 + RP_MAX_COLS) break;
+      }
+      HIP_CHECK(hipMemcpyAsync(st.data(), r.starts->ptr, st.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+      ctx->count_sync("sync:partition_counts");
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    const int64_t moved = st[(size_t)num_partitions];
+    for (int32_t p2 = 0; p2 < num_partitions; p2++) counts_host[p2] = (int64_t)st[(size_t)p2 + 1] - (int64_t)st[(size_t)p2];
+    auto trim = [&](ArrayHolder& h) {        // rows dropped by the selection leave the tail unused
+      if (moved == n) return h.release();
+      dfgpu_array* s2 = nullptr; dfgpu_status rc2 = dfgpu_array_slice(ctx, h.get(), 0, moved, &s2); if (rc2 != DFGPU_OK) fail(rc2, "%s", ctx->err.c_str());
+      return s2;
+    };
+    for (int c : direct) out_cols[c] = trim(outs[(size_t)c]);
+    *out_indices = trim(idx);
   });
 }

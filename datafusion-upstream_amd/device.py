@@ -212,6 +212,17 @@ class Context:
         return self._wrap(out), list(counts)
 
 
+    def partition_columns(self, keys: Sequence["Array"], num_partitions: int, cols: Sequence[Optional["Array"]], mask: Optional["Array"] = None):
+        """dfgpu_partition_columns -> ([column grouped by destination or None], row numbers grouped by destination, counts)"""
+        hs, n = capi.handle_array([a.h.value for a in keys])
+        ch = (C.c_void_p * max(1, len(cols)))(*[(c.h if c is not None else None) for c in cols])
+        oc = (C.c_void_p * max(1, len(cols)))()
+        out = C.c_void_p()
+        counts = (C.c_int64 * num_partitions)()
+        self.check(self.lib.dfgpu_partition_columns(self.h, hs, n, num_partitions, ch, len(cols), mask.h if mask is not None else None, oc, C.byref(out), counts))
+        return [self._wrap(C.c_void_p(oc[i])) if oc[i] else None for i in range(len(cols))], self._wrap(out), list(counts)
+
+
 class Array:
     """Immutable Arrow column in HBM (dfgpu_array)."""
 

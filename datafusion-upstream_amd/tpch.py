@@ -120,6 +120,11 @@ def upload(ctx: Context, host: Dict[str, np.ndarray], device: str = "cuda") -> D
 def gen_device(ctx: Context, sf: float, seed: int = SEED, rank: int = 0, world: int = 1, device: str = "cuda") -> Dict[str, ops.RecordBatch]:
     """Generate rank's 1/world shard of the tables directly in HBM (contiguous ranges of customers / orders;
     lineitems stay with their order, as TPC-H files are clustered)."""
+    return tables_from_torch(ctx, gen_device_tensors(sf, seed, rank, world, device))
+
+
+def gen_device_tensors(sf: float, seed: int = SEED, rank: int = 0, world: int = 1, device: str = "cuda") -> dict:
+    """The torch tensors behind gen_device (the same generator calls in the same order: identical values for identical arguments)."""
     import torch
     nc, no = table_rows(sf)
     g = torch.Generator(device=device)
@@ -145,7 +150,34 @@ def gen_device(ctx: Context, sf: float, seed: int = SEED, rank: int = 0, world: 
         v = torch.zeros((nl, 2), dtype=torch.int64, device=device)          # [lo, hi] words; values are non-negative => hi = 0
         v[:, 0] = torch.randint(lo, hi, (nl,), generator=g, device=device, dtype=torch.int64)
         tt[name] = v
-    return tables_from_torch(ctx, tt)
+    return tt
+
+
+def q3_checksum_torch(tt: dict) -> dict:
+    """TPC-H Q3 over the tensors of gen_device_tensors(rank 0 of 1) recomputed with plain torch ops (no dfgpu code): number of result groups,
+    wrapping Int64 sums of their l_orderkey and of their revenue (unscaled Decimal128(38,4) = price * (100 - discount), exact in Int64 here).
+    Used by bench.py to check the SF100 result outside the timed region."""
+    import torch
+    seg = SEGMENTS.index(Q3_SEGMENT)
+    cust_ok = tt["c_mktsegment"] == seg                                              # index = c_custkey - 1 (dense keys)
+    o_sel = (tt["o_orderdate"] < Q3_DATE) & cust_ok[tt["o_custkey"] - 1]
+    k = tt["l_orderkey"] - 1
+    oidx = (k // 32) * 8 + (k % 32)                                                   # inverse of orderkey_of
+    del k
+    l_sel = (tt["l_shipdate"] > Q3_DATE) & o_sel[oidx]
+    rev = tt["l_extendedprice"][:, 0] * (100 - tt["l_discount"][:, 0])
+    sums = torch.zeros(tt["o_orderkey"].numel(), dtype=torch.int64, device=rev.device)
+    sums.index_add_(0, oidx[l_sel], rev[l_sel])
+    grp = sums > 0
+    return {"groups": int(grp.sum().item()), "sum_orderkey": int(tt["o_orderkey"][grp].sum().item()), "sum_revenue": int(sums.sum().item())}
+
+
+def q3_checksum_result(batches: List["ops.RecordBatch"]) -> dict:
+    """The same three numbers from a Q3 result (columns l_orderkey, revenue Decimal128(38,4), o_orderdate, o_shippriority)."""
+    r = q3_result_to_numpy(batches)
+    rev = r["revenue"]
+    lo = rev[:, 0].view(np.int64) if rev.ndim == 2 else rev.astype(np.int64)
+    return {"groups": int(len(r["l_orderkey"])), "sum_orderkey": int(r["l_orderkey"].astype(np.int64).sum()), "sum_revenue": int(lo.sum())}
 
 
 def tables_to_host(tables: Dict[str, "ops.RecordBatch"]) -> Dict[str, np.ndarray]:

@@ -327,6 +327,16 @@ DFGPU_API dfgpu_status dfgpu_sort_to_indices(dfgpu_ctx *ctx, const dfgpu_array *
 DFGPU_API dfgpu_status dfgpu_hash_partition(dfgpu_ctx *ctx, const dfgpu_array *const *keys, int32_t nkeys, int32_t num_partitions,
                                             dfgpu_array **out_indices, int64_t *counts_host);
 
+/* The same partitioning with the `take` of every column folded in (repartition/mod.rs:196-214): ONE pass reads key and payload columns and
+ * writes them grouped by destination.  out_cols[c] = column c of all destinations back to back (slice it by counts_host) for fixed-width
+ * columns without NULLs; NULL for any other column (Utf8, dictionary, Boolean, nullable), which the caller gathers through out_indices
+ * (always produced: the original row numbers grouped by destination, input order kept inside a destination).  cols[c] may be NULL
+ * (a column the caller keeps lazy).  opt_mask: BOOL selection, unselected rows are dropped.  1..256 partitions (else NOT_IMPLEMENTED:
+ * use dfgpu_hash_partition). */
+DFGPU_API dfgpu_status dfgpu_partition_columns(dfgpu_ctx *ctx, const dfgpu_array *const *keys, int32_t nkeys, int32_t num_partitions,
+                                               const dfgpu_array *const *cols, int32_t ncols, const dfgpu_array *opt_mask,
+                                               dfgpu_array **out_cols, dfgpu_array **out_indices, int64_t *counts_host);
+
 #ifdef __cplusplus
 }
 #endif
