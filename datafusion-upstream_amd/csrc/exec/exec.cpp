@@ -560,9 +560,17 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
       }
       if (state == 4) { state = 3; if (swapped.base_rows == 0) return false; out = std::move(swapped); return true; }
       bool need_final = op->join_type == DFGPU_JOIN_LEFT || op->join_type == DFGPU_JOIN_FULL || op->left_only();     // need_produce_result_in_final
+      // CollectLeft shares ONE build side between the probe partitions; the reference gives every stream a visited bitmap of its own
+      // (hash_join.rs:1172-1190), so with several probe partitions each stream would emit unmatched build rows from a partial view.
+      // That plan shape is refused rather than answered differently from either reading.
+      if (need_final && op->mode == 0 && op->right->partitions() > 1 && state != 4)
+        fail(DFGPU_NOT_IMPLEMENTED, "HashJoinExec mode=CollectLeft with %d probe partitions and a join type that emits build rows in a final pass; repartition both sides (Partitioned) or coalesce the probe side", op->right->partitions());
       while (state == 1) {        // FetchProbeBatch / ProcessProbeBatch (:1199-1343)
         Batch pb; if (!probe->next(pb)) { state = 2; break; }
         if (pb.base_rows == 0) continue;
+        // Right / Full / RightSemi / RightAnti emit the probe rows WITHOUT a match (adjust_indices_by_join_type over the batch's row range,
+        // joins/utils.rs:1234-1279): rows a fused FilterExec dropped must not come back as unmatched rows, so the selection is applied first
+        if (pb.selection && (op->join_type == DFGPU_JOIN_RIGHT || op->join_type == DFGPU_JOIN_FULL || op->right_only())) { pb = materialize(tc, pb); if (pb.base_rows == 0) continue; }
         ArrayRef mask = pb.selection; pb.selection = ArrayRef();
         ArrayRef bidx, pidx;
         if (bs->empty) { dfgpu_array *a = nullptr, *b = nullptr; dfgpu_array_desc d{}; d.type = DFGPU_UINT64; d.values = &d; tc.check(dfgpu_array_import_host(tc.ctx, &d, &a)); d.type = DFGPU_UINT32; tc.check(dfgpu_array_import_host(tc.ctx, &d, &b)); bidx = ArrayRef::adopt(a); pidx = ArrayRef::adopt(b); }
@@ -584,7 +592,6 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
         }
         int jt = op->join_type;
         if (jt == DFGPU_JOIN_RIGHT || jt == DFGPU_JOIN_FULL || op->right_only()) {
-          if (mask) fail(DFGPU_NOT_IMPLEMENTED, "Right/Full/RightSemi/RightAnti join over a fused probe-side selection; materialise the probe input (CoalesceBatchesExec)");
           dfgpu_array *b2 = nullptr, *p2 = nullptr;
           tc.check(dfgpu_join_adjust_indices(tc.ctx, bidx.a, pidx.a, 0, pb.base_rows, jt, &b2, &p2)); bidx = ArrayRef::adopt(b2); pidx = ArrayRef::adopt(p2);
         } else if (op->left_only()) continue;

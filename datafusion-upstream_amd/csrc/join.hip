@@ -663,7 +663,10 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
         KernelTimer kt_(ctx, "k_probe_match_bitmap");
         int64_t rows_per_block = (int64_t)BLOCK * PM_ROWS;
         const uint64_t* kvp = pk->validity ? (const uint64_t*)pk->validity->ptr : nullptr;
-#define PM_LAUNCH(HM, HV) DFGPU_INT_KEY_DISPATCH(pk->type, hipLaunchKernelGGL((k_probe_match_bitmap<T, HM, HV>), dim3(grid_for(n, (int)rows_per_block)), dim3(BLOCK), 0, ctx->stream, (const T*)pk->values->ptr, \
+        // the kernel reads two keys per load (2 x sizeof(T) aligned): a zero-copy slice at an odd row offset (dfgpu_array_slice) is copied once
+        const void* kptr = pk->values->ptr; BufferPtr aligned_keys; const size_t kw = (size_t)type_width(pk->type);
+        if ((uintptr_t)kptr % (2 * kw)) { aligned_keys = alloc_buffer(ctx, (size_t)n * kw); HIP_CHECK(hipMemcpyAsync(aligned_keys->ptr, kptr, (size_t)n * kw, hipMemcpyDeviceToDevice, ctx->stream)); kptr = aligned_keys->ptr; }
+#define PM_LAUNCH(HM, HV) DFGPU_INT_KEY_DISPATCH(pk->type, hipLaunchKernelGGL((k_probe_match_bitmap<T, HM, HV>), dim3(grid_for(n, (int)rows_per_block)), dim3(BLOCK), 0, ctx->stream, (const T*)kptr, \
                                                             kvp, mk, n, t->key_min, t->range, (const uint64_t*)t->bitmap->ptr, (uint64_t*)match_bits->ptr))
         if (mk && kvp) { PM_LAUNCH(true, true); } else if (mk) { PM_LAUNCH(true, false); } else if (kvp) { PM_LAUNCH(false, true); } else { PM_LAUNCH(false, false); }
 #undef PM_LAUNCH

@@ -343,3 +343,48 @@ def test_identity_index_arrays_are_recognised_and_skipped(ctx, task_ctx):
     res = po.hash_join([[lt["k"]]], [[rt["k"]]], "Inner", batch_size=1 << 40)
     want = [[lt["k"][int(bi)].as_py(), lt["v"][int(bi)].as_py(), rt["k"][int(p)].as_py(), rt["w"][int(p)].as_py(), rt["s"][int(p)].as_py()] for bi, p in zip(res.build_idx, res.probe_idx)]
     assert got == want
+
+
+@pytest.mark.parametrize("jt", ["Right", "Full", "RightSemi", "RightAnti", "Inner", "LeftSemi"])
+def test_joins_over_a_filtered_probe_side_above_batch_size(ctx, jt):
+    """Filter -> CoalesceBatches -> HashJoin with >= batch_size probe rows keeps the filter as a fused selection; the join types that emit
+    unmatched probe rows (adjust_indices_by_join_type, joins/utils.rs:1234-1279) must not bring dropped rows back as unmatched ones.
+    Rows must equal the same join over a probe side filtered beforehand (and the oracle's pair count for Inner)."""
+    from dfgpu import physical_plan as ops
+    nb, npr = 3000, 40000
+    left = pa.table({"k": pa.array(RNG.integers(0, 2500, nb)), "a": pa.array(np.arange(nb, dtype=np.int64))})
+    right = pa.table({"k": pa.array(RNG.integers(0, 5000, npr)), "v": pa.array(np.arange(npr, dtype=np.int64))})
+    keep = np.asarray(right["v"]) < 30000
+    tc = ops.TaskContext(ctx, batch_size=8192)
+    C, L, B = ops.Column, ops.Literal, ops.BinaryExpr
+
+    def rows(plan):
+        out = []
+        for p in range(plan.output_partitioning().partition_count()):
+            for b in plan.execute(p, tc):
+                out += rows_of([c.to_arrow() for c in b.materialize().columns])
+        return sort_rows(out)
+    lb = ops.batch_from_arrow(ctx, left); rb = ops.batch_from_arrow(ctx, right); rf = ops.batch_from_arrow(ctx, right.filter(pa.array(keep)))
+    on = [(C("k", 0), C("k", 0))]
+    fused = ops.HashJoinExec(ops.MemoryExec([[lb]], lb.schema), ops.CoalesceBatchesExec(ops.FilterExec(B(C("v", 1), "<", L(30000, pa.int64())), ops.MemoryExec([[rb]], rb.schema)), 8192),
+                             on, None, jt, "CollectLeft")
+    plain = ops.HashJoinExec(ops.MemoryExec([[lb]], lb.schema), ops.MemoryExec([[rf]], rf.schema), on, None, jt, "CollectLeft")
+    got, want = rows(fused), rows(plain)
+    assert got == want and len(got) > 0
+    if jt == "Inner":
+        assert len(got) == len(po.hash_join([[left["k"].combine_chunks()]], [[right["k"].combine_chunks().filter(pa.array(keep))]], "Inner", False, batch_size=1 << 40).probe_idx)
+
+
+def test_probe_key_column_sliced_at_an_odd_row_offset(ctx):
+    """RecordBatch::slice of a non-null fixed-width column is a pointer-offset view (dfgpu_array_slice): an Int64 key column starting at an
+    odd row is 8-byte but not 16-byte aligned, and the bitmap probe reads two keys per load -- pairs must still equal the oracle's."""
+    import dfgpu
+    nb, npr = 4000, 60001
+    b = np.arange(nb, dtype=np.int64) * 3 + 5                      # strictly increasing dense keys: rank index + bitmap probe
+    p = RNG.integers(0, 3 * nb + 10, npr).astype(np.int64)
+    table = dfgpu.JoinTable(ctx, [ctx.from_arrow(pa.array(b))])
+    for off in (1, 3, 64, 65):
+        sliced = ctx.from_arrow(pa.array(p)).slice(off, npr - off)
+        bi, pi = table.probe([sliced])
+        want = po.hash_join([[pa.array(b)]], [[pa.array(p[off:])]], "Inner", False, batch_size=1 << 40)
+        assert np.array_equal(bi.to_numpy().astype(np.int64), want.build_idx) and np.array_equal(pi.to_numpy().astype(np.int64), want.probe_idx)
