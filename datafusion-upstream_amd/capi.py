@@ -80,6 +80,7 @@ PROTOTYPES = {
     "dfgpu_ctx_set_option": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
     "dfgpu_acc_update_batch_fused": (C.c_int32, [_P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int32, _P, C.c_int32, C.POINTER(_P), C.c_int32, _P, _P, C.c_int64]),
     "dfgpu_jit_selftest": (C.c_int32, [C.c_char_p, C.c_char_p, C.c_int64]),
+
     "dfgpu_agg_preaggregate": (C.c_int32, [_P, C.POINTER(_P), C.c_int32, C.POINTER(C.c_int32), C.POINTER(_P), C.c_int32, _P, C.POINTER(_P), C.POINTER(_P)]),
     "dfgpu_ctx_get_option": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     "dfgpu_ctx_stream": (_P, [_P]),
@@ -91,6 +92,7 @@ PROTOTYPES = {
     "dfgpu_profile_read": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
     "dfgpu_array_import_host": (C.c_int32, [_P, C.POINTER(ArrayDesc), _PP]),
     "dfgpu_array_wrap_device": (C.c_int32, [_P, C.POINTER(ArrayDesc), _PP]),
+    "dfgpu_array_wrap_device_owned": (C.c_int32, [_P, C.POINTER(ArrayDesc), _P, _P, _PP]),
     "dfgpu_array_describe": (C.c_int32, [_P, C.POINTER(ArrayDesc)]),
     "dfgpu_array_export_host": (C.c_int32, [_P, _P, _P, _P, _P]),
     "dfgpu_array_import_arrow": (C.c_int32, [_P, C.POINTER(ArrowArray), C.POINTER(ArrowSchema), _PP]),

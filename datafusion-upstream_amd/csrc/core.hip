@@ -199,7 +199,7 @@ int64_t count_set_bits(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n) {
 
 static void validate_type(int32_t t) { if (t < DFGPU_BOOL || t > DFGPU_DICTIONARY) fail(DFGPU_INVALID_ARGUMENT, "unknown type id %d", t); }
 
-static dfgpu_array* import_desc(dfgpu_ctx* ctx, const dfgpu_array_desc* d, bool copy) {
+static dfgpu_array* import_desc(dfgpu_ctx* ctx, const dfgpu_array_desc* d, bool copy, const std::shared_ptr<void>& owner = nullptr) {
   validate_type(d->type);
   if (d->length < 0) fail(DFGPU_INVALID_ARGUMENT, "negative length");
   if (d->length > 0xFFFFFFF0ll) fail(DFGPU_NOT_IMPLEMENTED, "arrays above 2^32-16 rows are not supported (UInt32 row ids, joins/utils.rs probe indices)");
@@ -215,7 +215,7 @@ static dfgpu_array* import_desc(dfgpu_ctx* ctx, const dfgpu_array_desc* d, bool 
   auto put = [&](const void* src, size_t bytes, size_t padded) -> BufferPtr {
     if (!copy) {
       if (((uintptr_t)src & 7) != 0) fail(DFGPU_INVALID_ARGUMENT, "device buffers must be 8-byte aligned");
-      return borrow_buffer(src, bytes);
+      BufferPtr bb = borrow_buffer(src, bytes); bb->owner = owner; return bb;
     }
     BufferPtr b = alloc_buffer(ctx, padded, true);
     if (bytes) HIP_CHECK(hipMemcpyAsync(b->ptr, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -230,7 +230,7 @@ static dfgpu_array* import_desc(dfgpu_ctx* ctx, const dfgpu_array_desc* d, bool 
     if (!d->dictionary) fail(DFGPU_INVALID_ARGUMENT, "dictionary array without dictionary");
     if (d->dictionary->type == DFGPU_DICTIONARY) fail(DFGPU_NOT_IMPLEMENTED, "nested dictionaries");
     if (!is_signed_int(d->key_type) && !is_unsigned_int(d->key_type)) fail(DFGPU_INVALID_ARGUMENT, "dictionary key type %d", d->key_type);
-    a->dictionary = import_desc(ctx, d->dictionary, copy);
+    a->dictionary = import_desc(ctx, d->dictionary, copy, owner);
   }
   if (copy) {
     if (n == 1 && d->type != DFGPU_UTF8 && d->type != DFGPU_DICTIONARY) {      // scalar Datum mirror
@@ -375,6 +375,12 @@ dfgpu_status dfgpu_array_import_host(dfgpu_ctx* ctx, const dfgpu_array_desc* hos
 }
 dfgpu_status dfgpu_array_wrap_device(dfgpu_ctx* ctx, const dfgpu_array_desc* dev, dfgpu_array** out) {
   return guard(ctx, [&] { *out = import_desc(ctx, dev, false); });
+}
+dfgpu_status dfgpu_array_wrap_device_owned(dfgpu_ctx* ctx, const dfgpu_array_desc* dev, void (*release)(void*), void* cookie, dfgpu_array** out) {
+  // the token is created first: if the import fails the callback still fires exactly once (the caller gave the reference away)
+  std::shared_ptr<void> owner;
+  if (release) owner = std::shared_ptr<void>(cookie ? cookie : (void*)&owner, [release, cookie](void*) { release(cookie); });
+  return guard(ctx, [&] { *out = import_desc(ctx, dev, false, owner); });
 }
 dfgpu_status dfgpu_array_describe(const dfgpu_array* a, dfgpu_array_desc* o) {
   if (!a || !o) return DFGPU_INVALID_ARGUMENT;

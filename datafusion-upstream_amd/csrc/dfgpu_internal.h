@@ -79,6 +79,7 @@ namespace dfgpu {
 struct Buffer {
   void* ptr = nullptr; size_t bytes = 0; dfgpu_ctx* ctx = nullptr; bool owned = true;
   std::shared_ptr<Buffer> parent;   // keeps a sliced parent alive
+  std::shared_ptr<void> owner;      // borrowed memory: the caller's release callback fires when the last buffer / view over it is gone
   ~Buffer();
 };
 using BufferPtr = std::shared_ptr<Buffer>;

@@ -9,6 +9,26 @@ from . import capi
 from .capi import DfgpuError
 
 
+# memory lent to the library (Context.wrap_device): owner objects by cookie, dropped by the library's release callback
+_OWNERS = {}
+_OWNER_SEQ = 0
+
+
+def _release_owner(cookie):
+    try:
+        _OWNERS.pop(int(cookie), None)
+    except Exception:       # interpreter shutdown
+        pass
+
+
+_RELEASE_CB = C.CFUNCTYPE(None, C.c_void_p)(_release_owner)
+
+
+def lent_memory_owners() -> int:
+    """number of owner objects the library still holds a reference to (tests)"""
+    return len(_OWNERS)
+
+
 class Context:
     """One device + one HIP stream (what ExecutionPlan::execute(partition, ..) runs on)."""
 
@@ -106,11 +126,19 @@ class Context:
         return self._wrap(out)
 
     def wrap_device(self, desc: capi.ArrayDesc, keepalive=None) -> "Array":
+        """Zero-copy view of caller-owned device memory.  `keepalive` (the tensors behind the pointers) is handed to the library through
+        dfgpu_array_wrap_device_owned: it stays referenced until the last array, slice or C++ plan node over the memory is gone, whatever
+        happens to the Python objects meanwhile."""
         out = C.c_void_p()
-        self.check(self.lib.dfgpu_array_wrap_device(self.h, C.byref(desc), C.byref(out)))
-        a = self._wrap(out)
-        a._keepalive = keepalive
-        return a
+        if keepalive is None:
+            self.check(self.lib.dfgpu_array_wrap_device(self.h, C.byref(desc), C.byref(out)))
+            return self._wrap(out)
+        global _OWNER_SEQ
+        _OWNER_SEQ += 1
+        key = _OWNER_SEQ
+        _OWNERS[key] = keepalive
+        self.check(self.lib.dfgpu_array_wrap_device_owned(self.h, C.byref(desc), C.cast(_RELEASE_CB, C.c_void_p), C.c_void_p(key), C.byref(out)))
+        return self._wrap(out)
 
     def wrap_tensor(self, tensor, dtype: int, precision: int = 0, scale: int = 0) -> "Array":
         """Zero-copy view of a contiguous torch CUDA tensor as a non-null fixed-width column."""

@@ -133,6 +133,11 @@ DFGPU_API dfgpu_status dfgpu_profile_read(dfgpu_ctx *ctx, char *buf, int64_t cap
 DFGPU_API dfgpu_status dfgpu_array_import_host(dfgpu_ctx *ctx, const dfgpu_array_desc *host, dfgpu_array **out);
 /* Wrap device memory owned by the caller (zero copy; caller keeps it alive until release). */
 DFGPU_API dfgpu_status dfgpu_array_wrap_device(dfgpu_ctx *ctx, const dfgpu_array_desc *dev, dfgpu_array **out);
+/* The same with ownership handed over (the Arrow C Data Interface's release callback, ArrowArray::release): the library calls release(cookie)
+ * exactly once, when the last array, slice or plan node that refers to the memory is gone -- also when this call fails.  What a Rust shim
+ * passes is a leaked Arc<Buffer> (cookie) and a function that drops it; operators below the C boundary (the C++ plan layer keeps raw device
+ * pointers inside MemoryExec / HashJoinExec build sides) then cannot outlive the memory they read. */
+DFGPU_API dfgpu_status dfgpu_array_wrap_device_owned(dfgpu_ctx *ctx, const dfgpu_array_desc *dev, void (*release)(void *cookie), void *cookie, dfgpu_array **out);
 /* Device pointers + metadata of an array (for RCCL / torch interop). `out->dictionary` points
  * into storage owned by the array. */
 DFGPU_API dfgpu_status dfgpu_array_describe(const dfgpu_array *a, dfgpu_array_desc *out);

@@ -286,3 +286,27 @@ def test_fused_two_level_arithmetic_equals_node_by_node(ctx, task_ctx, money, sh
         assert np.array_equal(np.asarray(got).view(np.uint64), np.asarray(w).view(np.uint64))          # same IEEE operations in the same order
     else:
         assert got.equals(w)
+
+
+def test_lent_device_memory_outlives_its_python_owner_until_the_plan_is_gone(ctx, task_ctx):
+    """dfgpu_array_wrap_device_owned: a torch tensor wrapped zero-copy stays referenced by the library while any array, slice or C++ plan node
+    (MemoryExec keeps raw device pointers) refers to it -- the Python objects may go first -- and is released when the last of them is gone."""
+    import gc
+    import torch
+    from dfgpu import capi, device, physical_plan as ops
+    before = device.lent_memory_owners()
+    t = torch.arange(200000, dtype=torch.int64, device="cuda")
+    arr = ctx.wrap_tensor(t, capi.INT64)
+    batch = ops.RecordBatch.from_arrays(ctx, ["x"], [arr])
+    plan = ops.FilterExec(ops.BinaryExpr(ops.Column("x", 0), "<", ops.Literal(1000, pa.int64())), ops.MemoryExec([[batch]], batch.schema))
+    plan.handle(task_ctx)                                  # the C++ nodes exist now
+    assert device.lent_memory_owners() == before + 1
+    del t, arr, batch
+    gc.collect(); torch.cuda.empty_cache()
+    junk = torch.full((200000,), -1, dtype=torch.int64, device="cuda")       # would reuse the freed block if the tensor had died
+    rows = sum(b.materialize().num_rows for b in plan.execute(0, task_ctx))
+    assert rows == 1000
+    assert device.lent_memory_owners() == before + 1
+    del plan, junk
+    gc.collect()
+    assert device.lent_memory_owners() == before
