@@ -80,6 +80,9 @@ PROTOTYPES = {
     "dfgpu_ctx_set_option": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
     "dfgpu_acc_update_batch_fused": (C.c_int32, [_P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int32, _P, C.c_int32, C.POINTER(_P), C.c_int32, _P, _P, C.c_int64]),
     "dfgpu_jit_selftest": (C.c_int32, [C.c_char_p, C.c_char_p, C.c_int64]),
+    "dfgpu_span_begin": (C.c_int32, [_P, C.POINTER(C.c_int64)]),
+    "dfgpu_span_end": (C.c_int32, [_P, C.c_int64]),
+    "dfgpu_span_elapsed_ns": (C.c_int32, [_P, C.c_int64, C.POINTER(C.c_int64)]),
 
     "dfgpu_agg_preaggregate": (C.c_int32, [_P, C.POINTER(_P), C.c_int32, C.POINTER(C.c_int32), C.POINTER(_P), C.c_int32, _P, C.POINTER(_P), C.POINTER(_P)]),
     "dfgpu_ctx_get_option": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
@@ -184,6 +187,7 @@ PROTOTYPES.update({
     "dfgpu_plan_schema_len": (C.c_int32, [_P]),
     "dfgpu_plan_schema_name": (C.c_char_p, [_P, C.c_int32]),
     "dfgpu_plan_name": (C.c_char_p, [_P]),
+    "dfgpu_plan_metrics": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
     "dfgpu_plan_execute": (C.c_int32, [_P, C.c_int32, _P, C.c_int64, _PP]),
     "dfgpu_stream_next": (C.c_int32, [_P, _PP]),
     "dfgpu_stream_free": (None, [_P]),

@@ -51,6 +51,11 @@ BufferPtr alloc_buffer(dfgpu_ctx* ctx, size_t bytes, bool zero) {
     auto& fb = *ctx->free_blocks;
     for (size_t i = fb.size(); i-- > 0;) if (fb[i].first == n) { p = fb[i].second; fb[i] = fb.back(); fb.pop_back(); ctx->cached_bytes -= n; break; }
   }
+  if (ctx->memory_limit > 0 && (int64_t)(ctx->live_bytes + n) > ctx->memory_limit) {
+    if (p) { std::lock_guard<std::mutex> l(*ctx->alloc_mu); ctx->free_blocks->emplace_back(n, p); ctx->cached_bytes += n; }
+    // the message of MemoryPool::try_grow's error (execution/src/memory_pool/pool.rs:243-249)
+    fail(DFGPU_RESOURCES_EXHAUSTED, "Resources exhausted: Failed to allocate additional %zu bytes for dfgpu with %zu bytes already allocated - maximum available is %lld", n, ctx->live_bytes, (long long)ctx->memory_limit);
+  }
   if (!p) {
     hipError_t e = hipMalloc(&p, n);
     if (e == hipErrorOutOfMemory) {          // give cached blocks back to the driver and retry once
@@ -288,6 +293,8 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "group_dictionary_canon") ctx->group_dictionary_canon = value != 0;
     else if (k == "join_swap_small_semi") ctx->join_swap_small_semi = value != 0;
     else if (k == "fused_aggregate_min_rows") ctx->fused_aggregate_min_rows = value;
+    else if (k == "memory_limit") ctx->memory_limit = value;
+    else if (k == "collect_metrics") ctx->collect_metrics = value != 0;
     else if (k == "agg_partitioned") ctx->agg_partitioned = value != 0;
     else if (k == "agg_partitioned_force") ctx->agg_partitioned_force = value != 0;
     else if (k == "agg_partitioned_min_rows") ctx->agg_partitioned_min_rows = value;
@@ -315,6 +322,10 @@ dfgpu_status dfgpu_ctx_get_option(dfgpu_ctx* ctx, const char* key, int64_t* out)
     else if (k == "group_dictionary_canon") *out = ctx->group_dictionary_canon;
     else if (k == "join_swap_small_semi") *out = ctx->join_swap_small_semi;
     else if (k == "fused_aggregate_min_rows") *out = ctx->fused_aggregate_min_rows;
+    else if (k == "memory_limit") *out = ctx->memory_limit;
+    else if (k == "collect_metrics") *out = ctx->collect_metrics;
+    else if (k == "live_bytes") *out = (int64_t)ctx->live_bytes;              // read only: device bytes held by live buffers of this ctx
+    else if (k == "cached_bytes") *out = (int64_t)ctx->cached_bytes;          // read only: freed blocks kept for reuse
     else if (k == "agg_partitioned") *out = ctx->agg_partitioned;
     else if (k == "agg_partitioned_force") *out = ctx->agg_partitioned_force;
     else if (k == "agg_partitioned_min_rows") *out = ctx->agg_partitioned_min_rows;
@@ -338,6 +349,32 @@ dfgpu_status dfgpu_mask_count(dfgpu_ctx* ctx, const dfgpu_array* mask, int64_t* 
     if (!mask || !out) fail(DFGPU_INVALID_ARGUMENT, "mask_count: null argument");
     BufferPtr m = effective_mask(ctx, mask, mask->length);
     *out = mask->length ? count_set_bits(ctx, (const uint64_t*)m->ptr, mask->length) : 0;
+  });
+}
+dfgpu_status dfgpu_span_begin(dfgpu_ctx* ctx, int64_t* out_span) {
+  return guard(ctx, [&] {
+    if (!out_span) fail(DFGPU_INVALID_ARGUMENT, "span_begin: null argument");
+    dfgpu_ctx::Span sp; HIP_CHECK(hipEventCreate(&sp.start)); HIP_CHECK(hipEventCreate(&sp.stop));
+    HIP_CHECK(hipEventRecord(sp.start, ctx->stream));
+    size_t k = 0; for (; k < ctx->spans.size(); k++) if (!ctx->spans[k].start) break;
+    if (k == ctx->spans.size()) ctx->spans.push_back(sp); else ctx->spans[k] = sp;
+    *out_span = (int64_t)k;
+  });
+}
+dfgpu_status dfgpu_span_end(dfgpu_ctx* ctx, int64_t span) {
+  return guard(ctx, [&] {
+    if (span < 0 || (size_t)span >= ctx->spans.size() || !ctx->spans[(size_t)span].start) fail(DFGPU_INVALID_ARGUMENT, "span_end: unknown span");
+    HIP_CHECK(hipEventRecord(ctx->spans[(size_t)span].stop, ctx->stream));
+  });
+}
+dfgpu_status dfgpu_span_elapsed_ns(dfgpu_ctx* ctx, int64_t span, int64_t* out_ns) {
+  return guard(ctx, [&] {
+    if (!out_ns || span < 0 || (size_t)span >= ctx->spans.size() || !ctx->spans[(size_t)span].start) fail(DFGPU_INVALID_ARGUMENT, "span_elapsed: unknown span");
+    dfgpu_ctx::Span& sp = ctx->spans[(size_t)span];
+    HIP_CHECK(hipEventSynchronize(sp.stop));
+    float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, sp.start, sp.stop));
+    (void)hipEventDestroy(sp.start); (void)hipEventDestroy(sp.stop); sp.start = sp.stop = nullptr;
+    *out_ns = (int64_t)((double)ms * 1e6);
   });
 }
 dfgpu_status dfgpu_profile_enable(dfgpu_ctx* ctx, int32_t on) {

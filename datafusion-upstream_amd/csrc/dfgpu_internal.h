@@ -67,6 +67,10 @@ struct dfgpu_ctx {
   std::mutex* alloc_mu = nullptr;
   std::vector<std::pair<size_t, void*>>* free_blocks = nullptr;   // (class bytes, ptr)
   size_t cached_bytes = 0, live_bytes = 0;
+  int64_t memory_limit = 0;         // bytes of live device memory this ctx may hold (0 = none): ≙ a bounded MemoryPool (execution/src/memory_pool/pool.rs GreedyMemoryPool)
+  bool collect_metrics = false;     // the plan layer meters its operators (device-time spans + row counts)
+  struct Span { hipEvent_t start = nullptr, stop = nullptr; };
+  std::vector<Span> spans;          // dfgpu_span_*
   bool profile = false; std::string profile_only;
   std::vector<std::pair<std::string, int64_t>> sync_counts;   // host<->stream synchronisation points by cause (profiling only)
   void count_sync(const char* why) { if (!profile) return; for (auto& kv : sync_counts) if (kv.first == why) { kv.second++; return; } sync_counts.emplace_back(why, 1); }

@@ -53,7 +53,7 @@ struct ArrayRef {
 };
 
 struct TaskContext {          // ≙ datafusion_execution::TaskContext (execution/src/task.rs:44-59)
-  dfgpu_ctx* ctx; int64_t batch_size;
+  dfgpu_ctx* ctx; int64_t batch_size; bool metrics = false;       // metrics: option "collect_metrics" when the stream was created
   void check(dfgpu_status st) const { if (st != DFGPU_OK) throw Err(st, dfgpu_last_error(ctx)); }
 };
 
@@ -233,8 +233,29 @@ struct UnaryExpr : Expr {
 struct Stream { virtual ~Stream() = default; virtual bool next(Batch& out) = 0; };     // poll_next: false = end of stream
 struct Plan;
 using PlanPtr = std::shared_ptr<const Plan>;
+// ≙ BaselineMetrics (output_rows, elapsed_compute; physical-plan/src/metrics/baseline.rs:47-56), BuildProbeJoinMetrics (build_time, join_time;
+// joins/utils.rs:1368-1426) and RepartitionMetrics (repartition_time; repartition/mod.rs:312-349).  Times are DEVICE times of the spans the
+// operator enqueued (dfgpu_span_*), resolved when the metrics are read; elapsed_compute excludes the children's spans.
+struct Metrics {
+  std::mutex mu; int64_t output_rows = 0, output_batches = 0;
+  struct Open { dfgpu_ctx* c; int64_t id; int which; };        // which: 0 inclusive compute, 1 build, 2 join, 3 repartition
+  std::vector<Open> open; int64_t ns[4] = {0, 0, 0, 0};
+  void resolve() {
+    std::lock_guard<std::mutex> l(mu);
+    for (auto& o : open) { int64_t t = 0; if (dfgpu_span_elapsed_ns(o.c, o.id, &t) == DFGPU_OK) ns[o.which] += t; }
+    open.clear();
+  }
+};
+struct SpanGuard {
+  dfgpu_ctx* c = nullptr; int64_t id = -1; Metrics* m = nullptr; int which = 0;
+  SpanGuard(const TaskContext& tc, Metrics* met, int w) { if (tc.metrics && met && dfgpu_span_begin(tc.ctx, &id) == DFGPU_OK) { c = tc.ctx; m = met; which = w; } else id = -1; }
+  ~SpanGuard() { if (id >= 0) { dfgpu_span_end(c, id); std::lock_guard<std::mutex> l(m->mu); m->open.push_back(Metrics::Open{c, id, which}); } }
+};
 struct Plan : std::enable_shared_from_this<Plan> {
   virtual ~Plan() = default;
+  mutable std::shared_ptr<Metrics> met = std::make_shared<Metrics>();
+  virtual std::vector<std::shared_ptr<const Plan>> children() const { return {}; }
+  std::unique_ptr<Stream> run(int partition, const TaskContext& tc) const;          // execute() + metering
   virtual const char* name() const = 0;
   virtual SchemaPtr schema() const = 0;
   virtual int partitions() const = 0;                                   // output_partitioning().partition_count()
@@ -244,8 +265,23 @@ struct Plan : std::enable_shared_from_this<Plan> {
   // description built once can be executed again from scratch.
   virtual PlanPtr fresh() const = 0;
 };
+static int64_t metric_rows(const TaskContext& tc, const Batch& b) { if (!b.selection) return b.base_rows; int64_t k = 0; tc.check(dfgpu_mask_count(tc.ctx, b.selection.a, &k)); return k; }
+struct MeteredStream : Stream {
+  const Plan* op; PlanPtr keep; std::unique_ptr<Stream> in; TaskContext tc;
+  MeteredStream(PlanPtr k, std::unique_ptr<Stream> i, TaskContext t) : op(k.get()), keep(std::move(k)), in(std::move(i)), tc(t) {}
+  bool next(Batch& out) override {
+    bool ok; { SpanGuard sp(tc, op->met.get(), 0); ok = in->next(out); }
+    if (ok) { int64_t r = metric_rows(tc, out); std::lock_guard<std::mutex> l(op->met->mu); op->met->output_rows += r; op->met->output_batches++; }
+    return ok;
+  }
+};
+std::unique_ptr<Stream> Plan::run(int partition, const TaskContext& tc) const {
+  if (!tc.metrics) return execute(partition, tc);
+  std::unique_ptr<Stream> s; { SpanGuard sp(tc, met.get(), 0); s = execute(partition, tc); }       // operators that drain their input in execute()
+  return std::unique_ptr<Stream>(new MeteredStream(shared_from_this(), std::move(s), tc));
+}
 static void drain(const PlanPtr& p, int partition, const TaskContext& tc, std::vector<Batch>& out) {
-  auto s = p->execute(partition, tc); Batch b; while (s->next(b)) out.push_back(std::move(b));
+  auto s = p->run(partition, tc); Batch b; while (s->next(b)) out.push_back(std::move(b));
 }
 
 struct VecStream : Stream {
@@ -278,6 +314,7 @@ static ArrayRef known_mask(const TaskContext& tc, const ArrayRef& m) {     // NU
 struct FilterExec : Plan {        // filter.rs:56-66, batch_filter :315-327
   ExprPtr pred; PlanPtr input;
   PlanPtr fresh() const override { auto f = std::make_shared<FilterExec>(); f->pred = pred; f->input = input->fresh(); return f; }
+  std::vector<std::shared_ptr<const Plan>> children() const override { return {input}; }
   const char* name() const override { return "FilterExec"; }
   SchemaPtr schema() const override { return input->schema(); }
   int partitions() const override { return input->partitions(); }
@@ -295,7 +332,7 @@ struct FilterExec : Plan {        // filter.rs:56-66, batch_filter :315-327
       b.selection = mask; out = std::move(b); return true;
     }
   };
-  std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override { return std::unique_ptr<Stream>(new S(this, input->execute(p, tc), tc)); }
+  std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override { return std::unique_ptr<Stream>(new S(this, input->run(p, tc), tc)); }
 };
 
 static Batch materialize_subset(const TaskContext& tc, Batch& b, const std::set<int>& needed) {   // compact only referenced columns
@@ -312,6 +349,7 @@ static Batch materialize_subset(const TaskContext& tc, Batch& b, const std::set<
 struct ProjectionExec : Plan {    // projection.rs:52-62, batch_project :295-317
   std::vector<ExprPtr> exprs; std::vector<std::string> names; PlanPtr input; mutable SchemaPtr sch; mutable std::mutex mu;
   PlanPtr fresh() const override { auto p = std::make_shared<ProjectionExec>(); p->exprs = exprs; p->names = names; p->input = input->fresh(); return p; }
+  std::vector<std::shared_ptr<const Plan>> children() const override { return {input}; }
   const char* name() const override { return "ProjectionExec"; }
   SchemaPtr schema() const override {
     std::lock_guard<std::mutex> l(mu);
@@ -362,12 +400,13 @@ struct ProjectionExec : Plan {    // projection.rs:52-62, batch_project :295-317
       out = op->project(tc, std::move(b)); return true;
     }
   };
-  std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override { return std::unique_ptr<Stream>(new S(this, input->execute(p, tc), tc)); }
+  std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override { return std::unique_ptr<Stream>(new S(this, input->run(p, tc), tc)); }
 };
 
 struct CoalesceBatchesExec : Plan {    // coalesce_batches.rs:198-260
   PlanPtr input; int64_t target;
   PlanPtr fresh() const override { auto c = std::make_shared<CoalesceBatchesExec>(); c->input = input->fresh(); c->target = target; return c; }
+  std::vector<std::shared_ptr<const Plan>> children() const override { return {input}; }
   const char* name() const override { return "CoalesceBatchesExec"; }
   SchemaPtr schema() const override { return input->schema(); }
   int partitions() const override { return input->partitions(); }
@@ -388,12 +427,13 @@ struct CoalesceBatchesExec : Plan {    // coalesce_batches.rs:198-260
       return false;
     }
   };
-  std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override { return std::unique_ptr<Stream>(new S(this, input->execute(p, tc), tc)); }
+  std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override { return std::unique_ptr<Stream>(new S(this, input->run(p, tc), tc)); }
 };
 
 struct CoalescePartitionsExec : Plan {   // coalesce_partitions.rs
   PlanPtr input;
   PlanPtr fresh() const override { auto c = std::make_shared<CoalescePartitionsExec>(); c->input = input->fresh(); return c; }
+  std::vector<std::shared_ptr<const Plan>> children() const override { return {input}; }
   const char* name() const override { return "CoalescePartitionsExec"; }
   SchemaPtr schema() const override { return input->schema(); }
   int partitions() const override { return 1; }
@@ -459,6 +499,7 @@ struct RepartitionExec : Plan {   // repartition/mod.rs:232-294; all inputs are 
   PlanPtr input; std::vector<ExprPtr> exprs; int n;
   mutable std::mutex mu; mutable bool ran = false; mutable std::vector<std::vector<Batch>> outs;
   PlanPtr fresh() const override { auto r = std::make_shared<RepartitionExec>(); r->input = input->fresh(); r->exprs = exprs; r->n = n; return r; }
+  std::vector<std::shared_ptr<const Plan>> children() const override { return {input}; }
   const char* name() const override { return "RepartitionExec"; }
   SchemaPtr schema() const override { return input->schema(); }
   int partitions() const override { return n; }
@@ -470,7 +511,7 @@ struct RepartitionExec : Plan {   // repartition/mod.rs:232-294; all inputs are 
         std::vector<Batch> in; drain(input, ip, tc, in);
         for (auto& b : in) {
           if (exprs.empty()) { Batch m = materialize(tc, b); if (m.base_rows) outs[(size_t)(rr++ % n)].push_back(std::move(m)); }   // RoundRobinBatch
-          else partition_batch(tc, b, exprs, n, outs);
+          else { SpanGuard sp(tc, met.get(), 3); partition_batch(tc, b, exprs, n, outs); }      // repartition_time (repartition/mod.rs:318)
         }
       }
       ran = true;
@@ -492,6 +533,7 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
     auto j = std::make_shared<HashJoinExec>(); j->left = left->fresh(); j->right = right->fresh(); j->on_l = on_l; j->on_r = on_r; j->filter = filter; j->f_side = f_side; j->f_index = f_index;
     j->join_type = join_type; j->mode = mode; j->null_equals_null = null_equals_null; j->swap_small_right = swap_small_right; return j;
   }
+  std::vector<std::shared_ptr<const Plan>> children() const override { return {left, right}; }
   const char* name() const override { return "HashJoinExec"; }
   bool swap_allowed(const TaskContext& tc) const { int64_t v = 1; dfgpu_ctx_get_option(tc.ctx, "join_swap_small_semi", &v); return swap_small_right && v != 0; }
   bool left_only() const { return join_type == DFGPU_JOIN_LEFT_SEMI || join_type == DFGPU_JOIN_LEFT_ANTI; }
@@ -524,6 +566,7 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
     tc.check(dfgpu_join_build(tc.ctx, kp.data(), (int32_t)kp.size(), fused.a, null_equals_null ? 1 : 0, &bs->table->t));
   }
   std::shared_ptr<BuildSide> collect_build(int partition, const TaskContext& tc) const {
+    SpanGuard sp(tc, met.get(), 1);            // build_time (joins/utils.rs:1370): collecting the build input + building the table
     ArrayRef fused; auto bs = collect_left(partition, tc, &fused); build_table(bs, fused, tc); return bs;
   }
   struct S : Stream {
@@ -556,7 +599,7 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
         }
         else if (op->mode == 0) { std::lock_guard<std::mutex> l(op->mu); if (!op->shared) op->shared = op->collect_build(-1, tc); bs = op->shared; }
         else bs = op->collect_build(partition, tc);
-        if (state == 0) { probe = op->right->execute(partition, tc); out_schema = op->schema(); state = 1; }
+        if (state == 0) { probe = op->right->run(partition, tc); out_schema = op->schema(); state = 1; }
       }
       if (state == 4) { state = 3; if (swapped.base_rows == 0) return false; out = std::move(swapped); return true; }
       bool need_final = op->join_type == DFGPU_JOIN_LEFT || op->join_type == DFGPU_JOIN_FULL || op->left_only();     // need_produce_result_in_final
@@ -568,6 +611,7 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
       while (state == 1) {        // FetchProbeBatch / ProcessProbeBatch (:1199-1343)
         Batch pb; if (!probe->next(pb)) { state = 2; break; }
         if (pb.base_rows == 0) continue;
+        SpanGuard join_span(tc, op->met.get(), 2);        // join_time (joins/utils.rs:1381): probing one batch and building its output
         // Right / Full / RightSemi / RightAnti emit the probe rows WITHOUT a match (adjust_indices_by_join_type over the batch's row range,
         // joins/utils.rs:1234-1279): rows a fused FilterExec dropped must not come back as unmatched rows, so the selection is applied first
         if (pb.selection && (op->join_type == DFGPU_JOIN_RIGHT || op->join_type == DFGPU_JOIN_FULL || op->right_only())) { pb = materialize(tc, pb); if (pb.base_rows == 0) continue; }
@@ -677,6 +721,7 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
   // PhysicalGroupBy grouping sets (aggregates/mod.rs:103-160): sets[s][i] != 0 = key i is replaced by null_exprs[i] in set s; empty = the single set of all keys
   std::vector<ExprPtr> null_exprs; std::vector<std::vector<uint8_t>> sets;
   PlanPtr fresh() const override { auto a = std::make_shared<AggregateExec>(); a->mode = mode; a->gexprs = gexprs; a->gnames = gnames; a->aggs = aggs; a->input = input->fresh(); a->null_exprs = null_exprs; a->sets = sets; return a; }
+  std::vector<std::shared_ptr<const Plan>> children() const override { return {input}; }
   const char* name() const override { return "AggregateExec"; }
   bool merging() const { return mode == 1 || mode == 2; }
   // The accumulator arguments as ONE expression DAG over plain columns (common subexpressions shared; references to deferred projection
@@ -899,6 +944,7 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
 struct SortExec : Plan {          // sorts/sort.rs:719-733; sort_batch :584-609
   std::vector<ExprPtr> exprs; std::vector<uint8_t> desc, nulls_first; int64_t fetch; bool preserve; PlanPtr input;
   PlanPtr fresh() const override { auto s = std::make_shared<SortExec>(); s->exprs = exprs; s->desc = desc; s->nulls_first = nulls_first; s->fetch = fetch; s->preserve = preserve; s->input = input->fresh(); return s; }
+  std::vector<std::shared_ptr<const Plan>> children() const override { return {input}; }
   const char* name() const override { return "SortExec"; }
   SchemaPtr schema() const override { return input->schema(); }
   int partitions() const override { return preserve ? input->partitions() : 1; }
@@ -926,6 +972,7 @@ struct SortExec : Plan {          // sorts/sort.rs:719-733; sort_batch :584-609
 struct SortPreservingMergeExec : Plan {
   std::vector<ExprPtr> exprs; std::vector<uint8_t> desc, nulls_first; int64_t fetch; PlanPtr input;
   PlanPtr fresh() const override { auto s = std::make_shared<SortPreservingMergeExec>(); s->exprs = exprs; s->desc = desc; s->nulls_first = nulls_first; s->fetch = fetch; s->input = input->fresh(); return s; }
+  std::vector<std::shared_ptr<const Plan>> children() const override { return {input}; }
   const char* name() const override { return "SortPreservingMergeExec"; }
   SchemaPtr schema() const override { return input->schema(); }
   int partitions() const override { return 1; }
@@ -933,7 +980,7 @@ struct SortPreservingMergeExec : Plan {
     if (partition != 0) fail(DFGPU_INTERNAL, "SortPreservingMergeExec invalid partition %d", partition);
     int np = input->partitions();
     if (np == 0) fail(DFGPU_INTERNAL, "SortPreservingMergeExec requires at least one input partition");
-    if (np == 1) return input->execute(0, tc);              // bypass (:213-218)
+    if (np == 1) return input->run(0, tc);              // bypass (:213-218)
     if (exprs.empty()) fail(DFGPU_INTERNAL, "Sort expressions cannot be empty for streaming merge");      // sorts/streaming_merge.rs
     std::vector<Batch> in; for (int p = 0; p < np; p++) drain(input, p, tc, in);
     std::vector<Batch> outv; Batch b;
@@ -1107,13 +1154,37 @@ struct FlagRegion {
   dfgpu_status close() { open = false; return dfgpu_ctx_set_option(c, "defer_flag_checks", 0); }
   ~FlagRegion() { if (open) close(); }
 };
+static void metrics_lines(const std::shared_ptr<const Plan>& p, int depth, std::string& out, int64_t* inclusive_out) {
+  p->met->resolve();
+  int64_t child_ns = 0; std::string below;
+  for (auto& c : p->children()) { int64_t ci = 0; metrics_lines(c, depth + 1, below, &ci); child_ns += ci; }
+  Metrics& m = *p->met; std::lock_guard<std::mutex> l(m.mu);
+  const int64_t inclusive = m.ns[0] + m.ns[1];           // a CollectLeft build runs inside the first poll of ONE stream; count it once
+  int64_t self = m.ns[0] - child_ns; if (self < 0) self = 0;
+  char line[512]; int k = snprintf(line, sizeof line, "%d %s output_rows=%lld output_batches=%lld elapsed_compute=%lld", depth, p->name(), (long long)m.output_rows, (long long)m.output_batches, (long long)self);
+  if (!strcmp(p->name(), "HashJoinExec")) k += snprintf(line + k, sizeof line - (size_t)k, " build_time=%lld join_time=%lld", (long long)m.ns[1], (long long)m.ns[2]);
+  if (!strcmp(p->name(), "RepartitionExec")) k += snprintf(line + k, sizeof line - (size_t)k, " repartition_time=%lld", (long long)m.ns[3]);
+  out += line; out += "\n"; out += below;
+  if (inclusive_out) *inclusive_out = m.ns[0];
+  (void)inclusive;
+}
+/* see include/dfgpu_exec.h */
+dfgpu_status dfgpu_plan_metrics(const dfgpu_plan* p, char* buf, int64_t capacity) {
+  return guard([&] {
+    if (!p || !buf || capacity < 1) fail(DFGPU_INVALID_ARGUMENT, "plan_metrics: null argument");
+    std::string out; metrics_lines(p->p, 0, out, nullptr);
+    if ((int64_t)out.size() + 1 > capacity) fail(DFGPU_INVALID_ARGUMENT, "plan_metrics: buffer of %lld bytes, need %zu", (long long)capacity, out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+  });
+}
 dfgpu_status dfgpu_plan_execute(const dfgpu_plan* p, int32_t partition, dfgpu_ctx* ctx, int64_t batch_size, dfgpu_stream** out) {
   return guard([&] {
     if (!p || !ctx || !out) fail(DFGPU_INVALID_ARGUMENT, "plan_execute: null argument");
     TaskContext tc{ctx, batch_size > 0 ? batch_size : 8192};
+    { int64_t m = 0; dfgpu_ctx_get_option(ctx, "collect_metrics", &m); tc.metrics = m != 0; }
     auto* s = new dfgpu_stream{nullptr, p->p, tc};
     FlagRegion region(ctx);           // operators that drain their input when the stream is created (SortExec, build sides)
-    try { s->s = p->p->execute(partition, tc); tc.check(region.close()); } catch (...) { delete s; throw; }
+    try { s->s = p->p->run(partition, tc); tc.check(region.close()); } catch (...) { delete s; throw; }
     *out = s;
   });
 }

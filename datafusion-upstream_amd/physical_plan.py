@@ -282,6 +282,18 @@ class ExecutionPlan:
         ch = self.children()
         return ch[0].schema() if ch else Schema([])
 
+    def metrics(self, context: TaskContext) -> List[dict]:
+        """≙ ExecutionPlan::metrics() over the tree (dfgpu_plan_metrics): one dict per node, pre-order, with the reference's metric names
+        (output_rows, elapsed_compute, build_time, join_time, repartition_time; times in ns of device time).  Collected while the ctx option
+        "collect_metrics" is 1."""
+        buf = C.create_string_buffer(1 << 16)
+        _check(_lib().dfgpu_plan_metrics(self.handle(context).h, buf, len(buf)))
+        out = []
+        for line in buf.value.decode().splitlines():
+            depth, name, *kv = line.split(" ")
+            out.append({"depth": int(depth), "name": name, **{k: int(v) for k, v in (x.split("=") for x in kv)}})
+        return out
+
     def execute(self, partition: int, context: TaskContext) -> Iterator[RecordBatch]:
         """≙ ExecutionPlan::execute(partition, ctx) -> SendableRecordBatchStream; iterating = poll_next."""
         h = self.handle(context)

@@ -104,6 +104,9 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
  * every partition's table sits in LDS; probe batches of >= min_probe rows are partitioned the same way.  Pairs and their order are identical;
  * "agg_partitioned" (1/0), "agg_partitioned_min_rows", "agg_partitioned_force" (1 = skip the sample's verdict; tests) == let the plan layer's
  * AggregateExec pre-aggregate large batches of high-cardinality unclustered keys partition by partition out of LDS (dfgpu_agg_preaggregate);
+ * "memory_limit" (bytes, 0 = none) == live device memory this ctx may hold; an allocation beyond it fails with DFGPU_RESOURCES_EXHAUSTED and the
+ * message of MemoryPool::try_grow (≙ RuntimeConfig::with_memory_limit, execution/src/runtime_env.rs); "live_bytes" / "cached_bytes" (read only);
+ * "collect_metrics" (1/0) == the plan layer records per-operator metrics (dfgpu_plan_metrics);
  * "defer_flag_checks" (1 = enter / 0 = leave a deferred region, nests) == kernel error flags (overflow, divide by zero,
  * cast range, index bounds -- the ArrowError cases of arrow-arith / arrow-cast / arrow-select) are normally checked by the
  * call that ran the kernel; inside a region they are checked once, by the call that leaves it (which returns the error),
@@ -124,6 +127,13 @@ DFGPU_API const char *dfgpu_version(void);
  * dfgpu_profile_read writes lines "kernel_name launches total_ms\n" into buf, then clears the records.
  * dfgpu_profile_select restricts the timers to one kernel name (NULL = all): an event pair costs ~10 us of stream
  * bubble, so a timed region is measured with only its dominant kernel bracketed. */
+/* Device-time spans on the ctx stream (one HIP event pair each): what the plan layer fills elapsed_compute / build_time / join_time /
+ * repartition_time with (≙ metrics::Time of BaselineMetrics / BuildProbeJoinMetrics / RepartitionMetrics, physical-plan/src/metrics/baseline.rs:47,
+ * joins/utils.rs:1368, repartition/mod.rs:312-349 -- measured on the device instead of on the host thread).  span_elapsed_ns waits for the
+ * span's end, returns its device time and frees it. */
+DFGPU_API dfgpu_status dfgpu_span_begin(dfgpu_ctx *ctx, int64_t *out_span);
+DFGPU_API dfgpu_status dfgpu_span_end(dfgpu_ctx *ctx, int64_t span);
+DFGPU_API dfgpu_status dfgpu_span_elapsed_ns(dfgpu_ctx *ctx, int64_t span, int64_t *out_ns);
 DFGPU_API dfgpu_status dfgpu_profile_enable(dfgpu_ctx *ctx, int32_t on);
 DFGPU_API dfgpu_status dfgpu_profile_select(dfgpu_ctx *ctx, const char *kernel_name);
 DFGPU_API dfgpu_status dfgpu_profile_read(dfgpu_ctx *ctx, char *buf, int64_t capacity);

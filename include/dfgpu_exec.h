@@ -94,6 +94,14 @@ DFGPU_API int32_t dfgpu_plan_schema_len(const dfgpu_plan *p);
 DFGPU_API const char *dfgpu_plan_schema_name(const dfgpu_plan *p, int32_t i);
 DFGPU_API const char *dfgpu_plan_name(const dfgpu_plan *p);                      /* DisplayAs: "HashJoinExec", ... */
 
+/* ExecutionPlan::metrics() of every node of the tree (physical-plan/src/lib.rs:385-390; DisplayableExecutionPlan::with_metrics), collected while
+ * the ctx option "collect_metrics" was 1 when the plan's streams were created.  One line per node, pre-order:
+ *   "<depth> <NodeName> output_rows=<n> output_batches=<n> elapsed_compute=<ns> [build_time=<ns> join_time=<ns>] [repartition_time=<ns>]"
+ * -- the names of BaselineMetrics (metrics/baseline.rs:47), BuildProbeJoinMetrics (joins/utils.rs:1368) and RepartitionMetrics
+ * (repartition/mod.rs:312-349).  Times are device times of what the operator enqueued (HIP events on the ctx stream), elapsed_compute without
+ * the children's share.  Reading the metrics waits for the recorded work. */
+DFGPU_API dfgpu_status dfgpu_plan_metrics(const dfgpu_plan *p, char *buf, int64_t capacity);
+
 /* ---- execution */
 /* ExecutionPlan::execute(partition, TaskContext{session_config.batch_size}) */
 DFGPU_API dfgpu_status dfgpu_plan_execute(const dfgpu_plan *p, int32_t partition, dfgpu_ctx *ctx, int64_t batch_size, dfgpu_stream **out);

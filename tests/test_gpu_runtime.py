@@ -1,0 +1,106 @@
+"""-m gpu: the auxiliary behaviour the reference's own tests pin for the hot path's operators:
+per-operator metrics under the reference's names (physical-plan/src/metrics/baseline.rs:47, joins/utils.rs:1368, repartition/mod.rs:312),
+error propagation out of a failing child stream (hash_join.rs:3227 join_with_error_right), dropping a stream before its end frees what it held
+(aggregates/mod.rs:1888-1958 test_drop_cancel_*), and ResourcesExhausted under a memory limit (hash_join.rs:3418-3547, aggregates/mod.rs:1803)."""
+import gc
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+pytestmark = pytest.mark.gpu
+RNG = np.random.default_rng(31)
+
+
+def q_plan(ctx, nb=20000, npr=200000, parts=4):
+    from dfgpu import capi, physical_plan as ops
+    C, F = ops.Column, ops.Field
+    left = ops.batch_from_arrow(ctx, pa.table({"k": pa.array(np.arange(nb, dtype=np.int64) * 3), "a": pa.array(RNG.integers(0, 100, nb))}))
+    right = ops.batch_from_arrow(ctx, pa.table({"k": pa.array(RNG.integers(0, 3 * nb, npr)), "v": pa.array(RNG.integers(0, 1000, npr))}))
+    rep = lambda b: ops.RepartitionExec(ops.MemoryExec([[b]], b.schema), ops.Partitioning.Hash([C("k", 0)], parts))
+    join = ops.HashJoinExec(rep(left), ops.CoalesceBatchesExec(ops.FilterExec(ops.BinaryExpr(C("v", 1), "<", ops.Literal(900, pa.int64())), rep(right)), 8192),
+                            [(C("k", 0), C("k", 0))], None, "Inner", "Partitioned")
+    agg = ops.AggregateExec("Single", [(C("a", 1), "a")], [ops.AggregateFunctionExpr("SUM", C("v", 3), "s", input_field=F("v", capi.INT64))], ops.CoalescePartitionsExec(join))
+    return agg, left, right
+
+
+def test_operator_metrics_carry_the_reference_names_and_add_up(ctx):
+    from dfgpu import physical_plan as ops
+    tc = ops.TaskContext(ctx, batch_size=8192)
+    plan, left, right = q_plan(ctx)
+    ctx.set_option("collect_metrics", 1)
+    try:
+        rows = sum(b.num_rows for b in plan.execute(0, tc))
+        m = plan.metrics(tc)
+    finally:
+        ctx.set_option("collect_metrics", 0)
+    names = [x["name"] for x in m]
+    assert names[0] == "AggregateExec" and "HashJoinExec" in names and names.count("RepartitionExec") == 2 and "FilterExec" in names
+    by = {n: [x for x in m if x["name"] == n] for n in set(names)}
+    assert by["AggregateExec"][0]["output_rows"] == rows == 100
+    j = by["HashJoinExec"][0]
+    assert j["build_time"] > 0 and j["join_time"] > 0 and j["output_rows"] > 0
+    rp = by["RepartitionExec"]
+    assert sorted(x["output_rows"] for x in rp) == [20000, 200000] and all(x["repartition_time"] > 0 for x in rp)
+    kept = int((np.asarray(right.columns[1].to_arrow()) < 900).sum())
+    assert by["FilterExec"][0]["output_rows"] == kept                        # rows of the fused selection, not of the carried batch
+    assert all(x["elapsed_compute"] >= 0 for x in m) and sum(x["elapsed_compute"] for x in m) > 0
+    # metrics are off by default: nothing is recorded
+    plan2, _, _ = q_plan(ctx)
+    list(plan2.execute(0, tc))
+    assert all(x["output_rows"] == 0 for x in plan2.metrics(tc))
+
+
+def test_error_in_a_child_stream_reaches_the_consumer(ctx):
+    """≙ join_with_error_right (hash_join.rs:3227): the probe side's stream fails (here: divide by zero in its projection); the join's
+    stream returns that error, with the reference's message, instead of a result."""
+    import dfgpu
+    from dfgpu import physical_plan as ops
+    C = ops.Column
+    tc = ops.TaskContext(ctx, batch_size=8192)
+    left = ops.batch_from_arrow(ctx, pa.table({"k": pa.array(np.arange(100, dtype=np.int64))}))
+    right = ops.batch_from_arrow(ctx, pa.table({"k": pa.array(np.arange(50, dtype=np.int64)), "d": pa.array(np.array([1] * 49 + [0], dtype=np.int64))}))
+    bad = ops.ProjectionExec([(ops.BinaryExpr(C("k", 0), "/", C("d", 1)), "k")], ops.MemoryExec([[right]], right.schema))
+    join = ops.HashJoinExec(ops.MemoryExec([[left]], left.schema), bad, [(C("k", 0), C("k", 0))], None, "Inner", "CollectLeft")
+    with pytest.raises(dfgpu.DfgpuError) as e:
+        [b.materialize() for b in join.execute(0, tc)]
+    assert "Divide by zero" in str(e.value)
+
+
+def test_dropping_a_stream_early_returns_its_memory(ctx):
+    """≙ test_drop_cancel_without_groups / _with_groups (aggregates/mod.rs:1888-1958): a consumer that drops the stream (and the plan)
+    before the end leaves nothing behind -- the ctx's live device bytes return to what they were."""
+    from dfgpu import physical_plan as ops
+    tc = ops.TaskContext(ctx, batch_size=8192)
+    gc.collect(); ctx.synchronize()
+    before = ctx.get_option("live_bytes")
+    plan, left, right = q_plan(ctx, parts=2)
+    held = ctx.get_option("live_bytes")
+    assert held > before
+    it = plan.execute(0, tc)
+    first = next(it)                       # the aggregate has run: build sides, partitions and group state exist
+    assert ctx.get_option("live_bytes") > held
+    del first, it, plan, left, right
+    gc.collect(); ctx.synchronize()
+    assert ctx.get_option("live_bytes") == before
+
+
+def test_memory_limit_raises_resources_exhausted_and_leaves_the_ctx_usable(ctx):
+    """≙ single_partition_join_overallocation (hash_join.rs:3418-3480) and the aggregate's memory-limit test (aggregates/mod.rs:1803): with a
+    pool far below what the build side needs the operator fails with ResourcesExhausted (MemoryPool::try_grow's message); afterwards the same
+    plan runs fine without the limit."""
+    import dfgpu
+    from dfgpu import physical_plan as ops
+    tc = ops.TaskContext(ctx, batch_size=8192)
+    plan, left, right = q_plan(ctx, nb=400000, npr=800000, parts=2)
+    live = ctx.get_option("live_bytes")
+    ctx.set_option("memory_limit", live + (1 << 20))          # one more MiB: the first partitioned column does not fit
+    try:
+        with pytest.raises(dfgpu.DfgpuError) as e:
+            [b.materialize() for b in plan.execute(0, tc)]
+        assert e.value.kind == "ResourcesExhausted" and "Failed to allocate additional" in str(e.value) and "maximum available" in str(e.value)
+    finally:
+        ctx.set_option("memory_limit", 0)
+    gc.collect()
+    from dfgpu import physical_plan as ops2
+    assert sum(b.num_rows for b in ops2.with_fresh_state(plan).execute(0, tc)) == 100
