@@ -570,9 +570,47 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
     ArrayRef fused; auto bs = collect_left(partition, tc, &fused); build_table(bs, fused, tc); return bs;
   }
   struct S : Stream {
-    const HashJoinExec* op; TaskContext tc; int partition; std::unique_ptr<Stream> probe; std::shared_ptr<BuildSide> bs; Batch swapped; int state = 0;   // 0 WaitBuildSide, 1 probing, 2 final pass, 3 done, 4 swapped semi/anti result pending
+    const HashJoinExec* op; TaskContext tc; int partition; std::unique_ptr<Stream> probe; std::shared_ptr<BuildSide> bs; Batch swapped; int state = 0;
+    // reference-sized probe batches are answered in the reference's output chunks (get_matched_indices_with_limit_offset, joins/utils.rs:284-348;
+    // process_probe_batch, hash_join.rs:1238-1343): `batch_size` candidate pairs per emitted batch, index alignment per chunk
+    Batch chunk_pb; ArrayRef chunk_b, chunk_p; int64_t chunk_k = -1, chunk_total = 0, chunk_joined = -1;   // 0 WaitBuildSide, 1 probing, 2 final pass, 3 done, 4 swapped semi/anti result pending
     SchemaPtr out_schema;
     S(const HashJoinExec* o, int p, TaskContext t) : op(o), tc(t), partition(p) {}
+    int64_t last_u32(const ArrayRef& a) {
+      int64_t n = a.len(); if (!n) return -1;
+      dfgpu_array* s1 = nullptr; tc.check(dfgpu_array_slice(tc.ctx, a.a, n - 1, 1, &s1)); ArrayRef one = ArrayRef::adopt(s1);
+      uint32_t v = 0; tc.check(dfgpu_array_export_host(tc.ctx, one.a, &v, nullptr, nullptr)); return (int64_t)v;
+    }
+    ArrayRef slice_of(const ArrayRef& a, int64_t off, int64_t len) { dfgpu_array* s1 = nullptr; tc.check(dfgpu_array_slice(tc.ctx, a.a, off, len, &s1)); return ArrayRef::adopt(s1); }
+    void apply_filter(Batch& pb, ArrayRef& bidx, ArrayRef& pidx) {      // apply_join_filter_to_indices (joins/utils.rs:1143-1176)
+      if (!op->filter || !bidx.len()) return;
+      Batch inter; inter.schema = std::make_shared<Schema>(); inter.base_rows = bidx.len();
+      for (size_t i = 0; i < op->f_side.size(); i++) {
+        Col src = op->f_side[i] == 0 ? bs->batch.cols.at((size_t)op->f_index[i]) : pb.cols.at((size_t)op->f_index[i]);
+        Col t = col_take(src, op->f_side[i] == 0 ? bidx : pidx); inter.cols.push_back(col_of(col_get(tc, t))); inter.schema->f.push_back(Field{"x"});
+      }
+      ArrayRef m = into_array(tc, op->filter->eval(tc, inter), inter.base_rows);
+      ArrayRef nb = filter_idx(bidx, m), np = filter_idx(pidx, m); bidx = nb; pidx = np;
+    }
+    // one output chunk of the current reference-sized probe batch
+    void emit_chunk(Batch& out, bool need_final) {
+      const int64_t bsz = tc.batch_size > 0 ? tc.batch_size : 8192, m = chunk_b.len(), off = chunk_k * bsz;
+      const int64_t len = off >= m ? 0 : (m - off < bsz ? m - off : bsz);
+      const bool last = chunk_k == chunk_total - 1;
+      ArrayRef b = slice_of(chunk_b, off < m ? off : m, len), p = slice_of(chunk_p, off < m ? off : m, len);
+      apply_filter(chunk_pb, b, p);
+      if (need_final && !bs->empty && b.len()) tc.check(dfgpu_join_mark_visited(tc.ctx, bs->table->t, b.a));
+      const int64_t last_joined = last_u32(p);                       // counts as joined after the key comparison and the join filter
+      const int64_t r0 = chunk_joined + 1, r1 = last ? chunk_pb.base_rows : (last_joined >= 0 ? last_joined + 1 : 0);
+      if (!last && last_joined >= 0) chunk_joined = last_joined;
+      const int jt = op->join_type;
+      if (jt == DFGPU_JOIN_RIGHT || jt == DFGPU_JOIN_FULL || op->right_only()) {
+        dfgpu_array *b2 = nullptr, *p2 = nullptr;
+        tc.check(dfgpu_join_adjust_indices(tc.ctx, b.a, p.a, r0, r1, jt, &b2, &p2)); b = ArrayRef::adopt(b2); p = ArrayRef::adopt(p2);
+      } else if (op->left_only()) { b = slice_of(b, 0, 0); p = slice_of(p, 0, 0); }
+      out = build_batch(bs->empty ? nullptr : &bs->batch, chunk_pb, b, p);
+      if (last) { chunk_k = -1; chunk_pb = Batch(); chunk_b = ArrayRef(); chunk_p = ArrayRef(); } else chunk_k++;
+    }
     ArrayRef filter_idx(const ArrayRef& idx, const ArrayRef& m) { dfgpu_array* o = nullptr; tc.check(dfgpu_filter(tc.ctx, idx.a, m.a, &o)); return ArrayRef::adopt(o); }
     Batch build_batch(Batch* build, Batch& probe_b, const ArrayRef& bidx, const ArrayRef& pidx) {     // build_batch_from_indices (joins/utils.rs:1180-1230)
       Batch o; o.schema = out_schema; o.base_rows = pidx.len(); MemoPtr memo = std::make_shared<TakeMemo>();
@@ -609,9 +647,14 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
       if (need_final && op->mode == 0 && op->right->partitions() > 1 && state != 4)
         fail(DFGPU_NOT_IMPLEMENTED, "HashJoinExec mode=CollectLeft with %d probe partitions and a join type that emits build rows in a final pass; repartition both sides (Partitioned) or coalesce the probe side", op->right->partitions());
       while (state == 1) {        // FetchProbeBatch / ProcessProbeBatch (:1199-1343)
+        if (chunk_k >= 0) { SpanGuard join_span(tc, op->met.get(), 2); emit_chunk(out, need_final); return true; }
         Batch pb; if (!probe->next(pb)) { state = 2; break; }
         if (pb.base_rows == 0) continue;
         SpanGuard join_span(tc, op->met.get(), 2);        // join_time (joins/utils.rs:1381): probing one batch and building its output
+        // a probe batch of the reference's size (<= max(batch_size, 8192) rows) comes out in the reference's chunks; the device's own
+        // whole-partition batches are answered in one piece (their consumers re-slice to batch_size)
+        const bool chunked = pb.base_rows <= (tc.batch_size > 8192 ? tc.batch_size : 8192);
+        if (chunked && pb.selection) { pb = materialize(tc, pb); if (pb.base_rows == 0) continue; }
         // Right / Full / RightSemi / RightAnti emit the probe rows WITHOUT a match (adjust_indices_by_join_type over the batch's row range,
         // joins/utils.rs:1234-1279): rows a fused FilterExec dropped must not come back as unmatched rows, so the selection is applied first
         if (pb.selection && (op->join_type == DFGPU_JOIN_RIGHT || op->join_type == DFGPU_JOIN_FULL || op->right_only())) { pb = materialize(tc, pb); if (pb.base_rows == 0) continue; }
@@ -623,16 +666,16 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
           for (auto& e : op->on_r) { keys.push_back(into_array(tc, e->eval(tc, pb), pb.base_rows)); kp.push_back(keys.back().a); }
           dfgpu_array *b = nullptr, *p = nullptr;
           tc.check(dfgpu_join_probe(tc.ctx, bs->table->t, kp.data(), (int32_t)kp.size(), mask.a, &b, &p)); bidx = ArrayRef::adopt(b); pidx = ArrayRef::adopt(p);
-          if (op->filter && bidx.len()) {     // apply_join_filter_to_indices (joins/utils.rs:1143-1176)
-            Batch inter; inter.schema = std::make_shared<Schema>(); inter.base_rows = bidx.len();
-            for (size_t i = 0; i < op->f_side.size(); i++) {
-              Col src = op->f_side[i] == 0 ? bs->batch.cols.at((size_t)op->f_index[i]) : pb.cols.at((size_t)op->f_index[i]);
-              Col t = col_take(src, op->f_side[i] == 0 ? bidx : pidx); inter.cols.push_back(col_of(col_get(tc, t))); inter.schema->f.push_back(Field{"x"});
-            }
-            ArrayRef m = into_array(tc, op->filter->eval(tc, inter), inter.base_rows);
-            ArrayRef nb = filter_idx(bidx, m), np = filter_idx(pidx, m); bidx = nb; pidx = np;
-          }
-          if (need_final) tc.check(dfgpu_join_mark_visited(tc.ctx, bs->table->t, bidx.a));
+          if (!chunked) { apply_filter(pb, bidx, pidx); if (need_final) tc.check(dfgpu_join_mark_visited(tc.ctx, bs->table->t, bidx.a)); }
+        }
+        if (chunked) {
+          // chunks of `batch_size` pairs; one more (empty) lookup follows when the limit was hit before the scan reached the end of the batch
+          // (chain_traverse!, joins/utils.rs:147-187: next_offset is None only at the last chain element of the last probe row)
+          const int64_t bsz = tc.batch_size > 0 ? tc.batch_size : 8192, m = bidx.len();
+          chunk_total = m == 0 ? 1 : (m + bsz - 1) / bsz;
+          if (m > 0 && m % bsz == 0 && last_u32(pidx) != pb.base_rows - 1) chunk_total++;
+          chunk_pb = std::move(pb); chunk_b = bidx; chunk_p = pidx; chunk_k = 0; chunk_joined = -1;
+          continue;
         }
         int jt = op->join_type;
         if (jt == DFGPU_JOIN_RIGHT || jt == DFGPU_JOIN_FULL || op->right_only()) {

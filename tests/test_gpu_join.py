@@ -37,19 +37,23 @@ def device_join(ctx, case, batch_size):
         filt = ops.JoinFilter(ops.BinaryExpr(ops.Column("x", 0), spec["op"], rhs), [tuple(ci) for ci in spec["column_indices"]],
                               ops.Schema([ops.Field("x", dfgpu.capi.INT32)] * len(spec["column_indices"])))
     join = ops.HashJoinExec(left, right, on, filt, case["join_type"], "CollectLeft", case["null_equals_null"])
-    per_partition = []
+    per_partition, n_batches = [], 0
     for p in range(join.output_partitioning().partition_count()):
         rows = []
         for b in join.execute(p, tc):
             rows += rows_of([c.to_arrow() for c in b.materialize().columns])
+            n_batches += 1
         per_partition.append(rows)
+    join.emitted_batches = n_batches
     return per_partition, join
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_hash_join_reference_golden(ctx, case):
-    for bs in case["batch_sizes"][:3]:
+    for bs in case["batch_sizes"]:
         parts, join = device_join(ctx, case, bs)
+        if case["batch_count"]:         # the reference asserts the number of emitted RecordBatches per batch_size (hash_join.rs:3388-3412)
+            assert join.emitted_batches == case["batch_count"][str(bs)], f"batch_size={bs}: {join.emitted_batches} batches"
         rows = [r for p in parts for r in p]
         if case["ordered"]:
             assert rows == case["expected"], f"batch_size={bs}"
