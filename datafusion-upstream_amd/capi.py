@@ -80,6 +80,7 @@ PROTOTYPES = {
     "dfgpu_ctx_set_option": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
     "dfgpu_acc_update_batch_fused": (C.c_int32, [_P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int32, _P, C.c_int32, C.POINTER(_P), C.c_int32, _P, _P, C.c_int64]),
     "dfgpu_jit_selftest": (C.c_int32, [C.c_char_p, C.c_char_p, C.c_int64]),
+    "dfgpu_take_multi": (C.c_int32, [_P, C.POINTER(_P), C.c_int32, _P, C.POINTER(_P)]),
     "dfgpu_span_begin": (C.c_int32, [_P, C.POINTER(C.c_int64)]),
     "dfgpu_span_end": (C.c_int32, [_P, C.c_int64]),
     "dfgpu_span_elapsed_ns": (C.c_int32, [_P, C.c_int64, C.POINTER(C.c_int64)]),
@@ -159,6 +160,7 @@ PROTOTYPES.update({
     "dfgpu_batch_num_columns": (C.c_int32, [_P]),
     "dfgpu_batch_num_rows": (C.c_int32, [_P, _P, C.POINTER(C.c_int64)]),
     "dfgpu_batch_column_name": (C.c_char_p, [_P, C.c_int32]),
+    "dfgpu_batch_materialize": (C.c_int32, [_P, _P]),
     "dfgpu_batch_column": (C.c_int32, [_P, _P, C.c_int32, _PP]),
     "dfgpu_expr_column": (C.c_int32, [C.c_char_p, C.c_int32, _PP]),
     "dfgpu_expr_literal": (C.c_int32, [_P, _PP]),

@@ -293,6 +293,7 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "group_dictionary_canon") ctx->group_dictionary_canon = value != 0;
     else if (k == "join_swap_small_semi") ctx->join_swap_small_semi = value != 0;
     else if (k == "fused_aggregate_min_rows") ctx->fused_aggregate_min_rows = value;
+    else if (k == "sort_packed_keys") ctx->sort_packed_keys = value != 0;
     else if (k == "memory_limit") ctx->memory_limit = value;
     else if (k == "collect_metrics") ctx->collect_metrics = value != 0;
     else if (k == "agg_partitioned") ctx->agg_partitioned = value != 0;
@@ -322,6 +323,7 @@ dfgpu_status dfgpu_ctx_get_option(dfgpu_ctx* ctx, const char* key, int64_t* out)
     else if (k == "group_dictionary_canon") *out = ctx->group_dictionary_canon;
     else if (k == "join_swap_small_semi") *out = ctx->join_swap_small_semi;
     else if (k == "fused_aggregate_min_rows") *out = ctx->fused_aggregate_min_rows;
+    else if (k == "sort_packed_keys") *out = ctx->sort_packed_keys;
     else if (k == "memory_limit") *out = ctx->memory_limit;
     else if (k == "collect_metrics") *out = ctx->collect_metrics;
     else if (k == "live_bytes") *out = (int64_t)ctx->live_bytes;              // read only: device bytes held by live buffers of this ctx

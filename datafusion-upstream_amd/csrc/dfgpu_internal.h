@@ -49,6 +49,7 @@ struct dfgpu_ctx {
   // radix-partitioned hash join (pjoin.hip): on/off, smallest build / probe batch that takes it, build rows per partition (<= 14000)
   bool join_partitioned = true; int64_t join_partitioned_min_build = 1 << 20, join_partitioned_min_probe = 1 << 22, join_partition_rows = 14000;
   int64_t fused_aggregate_min_rows = 1 << 20;
+  bool sort_packed_keys = true;     // large sorts over fixed-width keys: range-packed u64 keys + stable one-pass partition per digit (sort.hip)
   bool agg_partitioned = true, agg_partitioned_force = false; int64_t agg_partitioned_min_rows = 1 << 22;      // partitioned pre-aggregation (pagg.hip)
   const void* pa_sample_key = nullptr; const void* pa_sample_mask = nullptr; int64_t pa_sample_n = 0; uint64_t pa_sample[3] = {0, 0, 0};   // sample of a verdict-only dfgpu_agg_preaggregate call
   // row selection of the running operator (dfgpu_ctx_set_row_selection): expression kernels evaluate every row of full-length

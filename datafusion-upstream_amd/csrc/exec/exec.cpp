@@ -1078,6 +1078,24 @@ void dfgpu_batch_free(dfgpu_batch* b) { delete b; }
 int32_t dfgpu_batch_num_columns(const dfgpu_batch* b) { return b ? (int32_t)b->b.cols.size() : 0; }
 const char* dfgpu_batch_column_name(const dfgpu_batch* b, int32_t i) { return (b && i >= 0 && i < (int)b->b.schema->f.size()) ? b->b.schema->f[(size_t)i].name.c_str() : ""; }
 dfgpu_status dfgpu_batch_num_rows(dfgpu_ctx* ctx, dfgpu_batch* b, int64_t* out) { return guard([&] { TaskContext tc{ctx, 8192}; *out = num_rows(tc, b->b); }); }
+// every pending gather of the batch: columns that go through the same index array are gathered together (dfgpu_take_multi)
+static void materialize_all(const TaskContext& tc, Batch& b) {
+  if (b.selection) b = materialize(tc, b);
+  std::map<const dfgpu_array*, std::vector<size_t>> groups;
+  for (size_t i = 0; i < b.cols.size(); i++) { Col& c = b.cols[i]; if (!c.arr && c.source && !c.chain.empty()) groups[col_indices(tc, c).a].push_back(i); }
+  for (auto& g : groups) {
+    if (g.second.size() < 2) continue;
+    std::vector<const dfgpu_array*> vals; for (size_t i : g.second) vals.push_back(b.cols[i].source.a);
+    std::vector<dfgpu_array*> outs(vals.size(), nullptr);
+    ArrayRef idx = b.cols[g.second[0]].chain[0];
+    tc.check(dfgpu_take_multi(tc.ctx, vals.data(), (int32_t)vals.size(), idx.a, outs.data()));
+    for (size_t k = 0; k < g.second.size(); k++) { Col& c = b.cols[g.second[k]]; c.arr = ArrayRef::adopt(outs[k]); c.source = ArrayRef(); c.chain.clear(); c.memo.reset(); }
+  }
+  for (auto& c : b.cols) (void)col_get(tc, c);
+}
+dfgpu_status dfgpu_batch_materialize(dfgpu_ctx* ctx, dfgpu_batch* b) {
+  return guard([&] { if (!ctx || !b) fail(DFGPU_INVALID_ARGUMENT, "batch_materialize: null argument"); TaskContext tc{ctx, 8192}; materialize_all(tc, b->b); });
+}
 dfgpu_status dfgpu_batch_column(dfgpu_ctx* ctx, dfgpu_batch* b, int32_t i, dfgpu_array** out) {
   return guard([&] {
     TaskContext tc{ctx, 8192};

@@ -33,7 +33,7 @@ extern "C" dfgpu_status dfgpu_hash_partition(dfgpu_ctx* ctx, const dfgpu_array* 
     if (num_partitions < 1 || num_partitions > 4096) fail(DFGPU_INVALID_ARGUMENT, "hash_partition: 1..4096 partitions supported, got %d", num_partitions);
     KeySet ks = make_keyset(keys, nkeys);
     int64_t n = keys[0]->length;
-    if ((uint32_t)num_partitions <= RP_MAX_STABLE_P && n > 0 && n <= 0xFFFFFFF0ll) {        // one stable LDS-staged pass (radix_partition.h): the row numbers only
+    if (num_partitions <= 256 && n > 0 && n <= 0xFFFFFFF0ll) {        // one stable LDS-staged pass (radix_partition.h): the row numbers only
       ArrayHolder idx(new_fixed(ctx, DFGPU_UINT32, n));
       RpCols cols{}; cols.n = 0; cols.rowid_dst = (uint32_t*)idx.get()->values->ptr;
       RpResult r = rp_partition(ctx, RpHashKeySet{ ks, nullptr, ctx->force_hash_collisions ? 1 : 0 }, n, (uint32_t)num_partitions, cols, true, ctx->d_scratch64 + 9, "rp_hist", "rp_scan", "rp_scatter");
@@ -70,7 +70,7 @@ extern "C" dfgpu_status dfgpu_partition_columns(dfgpu_ctx* ctx, const dfgpu_arra
                                                 const dfgpu_array* opt_mask, dfgpu_array** out_cols, dfgpu_array** out_indices, int64_t* counts_host) {
   return guard(ctx, [&] {
     if (!keys || !out_indices || !counts_host || (ncols && (!cols || !out_cols))) fail(DFGPU_INVALID_ARGUMENT, "partition_columns: null argument");
-    if (num_partitions < 1 || (uint32_t)num_partitions > RP_MAX_STABLE_P) fail(DFGPU_NOT_IMPLEMENTED, "partition_columns: 1..%u partitions, got %d", RP_MAX_STABLE_P, num_partitions);
+    if (num_partitions < 1 || num_partitions > 256) fail(DFGPU_NOT_IMPLEMENTED, "partition_columns: 1..256 partitions, got %d", num_partitions);
     KeySet ks = make_keyset(keys, nkeys);
     const int64_t n = keys[0]->length;
     if (n > 0xFFFFFFF0ll) fail(DFGPU_NOT_IMPLEMENTED, "partition_columns above 2^32-16 rows");

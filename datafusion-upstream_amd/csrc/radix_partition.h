@@ -117,10 +117,20 @@ __global__ void __launch_bounds__(NT) k_rp_scatter(H hs, int64_t n, uint32_t P, 
   }
   __syncthreads();
   if (STABLE) {       // thread p: counts of partition p per (slab, wave) -> exclusive prefix in (slab, wave) order
-    for (int p = threadIdx.x; p < (int)P; p += NT) { uint32_t run = 0; for (int x = 0; x < RP_R * NW; x++) { uint16_t c = wcnt[(size_t)x * P + p]; wcnt[(size_t)x * P + p] = (uint16_t)run; run += c; } }
+    for (int p = threadIdx.x; p < (int)P; p += NT) {
+      uint32_t run = 0;                                // 16 loads in flight, then their running sums: RP_R * NW / 16 LDS round trips
+#pragma unroll 1
+      for (int x0 = 0; x0 < RP_R * NW; x0 += 16) {
+        uint16_t c[16];
+#pragma unroll
+        for (int x = 0; x < 16; x++) c[x] = wcnt[(size_t)(x0 + x) * P + p];
+#pragma unroll
+        for (int x = 0; x < 16; x++) { wcnt[(size_t)(x0 + x) * P + p] = (uint16_t)run; run += c[x]; }
+      }
+    }
   }
   {   // exclusive scan of cnt[P]: thread t owns the PER consecutive bins from t * PER
-    constexpr int PER = ((int)RP_MAX_P + NT - 1) / NT; uint32_t loc[PER]; uint32_t s = 0;
+    constexpr int PER = ((int)(STABLE ? RP_MAX_STABLE_P : RP_MAX_P) + NT - 1) / NT; uint32_t loc[PER]; uint32_t s = 0;
 #pragma unroll
     for (int j = 0; j < PER; j++) { int p = threadIdx.x * PER + j; loc[j] = p < (int)P ? cnt[p] : 0; s += loc[j]; }
     uint32_t inc = wave_inclusive_sum(s);
@@ -214,7 +224,8 @@ static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const 
   r.starts = alloc_buffer(ctx, (size_t)(P + 1) * 4);
   const bool big = P > 512 && P <= 2048 && !stable;        // 8192-row tiles halve the count matrix; 4096-row tiles give more workgroups per CU (and leave LDS for P > 2048)
   const int G = P <= 2048 ? RP_G : 4;
-  const int nt = big ? 1024 : 512, tile = nt * RP_R;
+  const bool small_wg = stable && P > 16;                  // stable with many partitions: 256-thread workgroups (the count table is 64 P bytes) keep several on a CU;
+  const int nt = small_wg ? 256 : big ? 1024 : 512, tile = nt * RP_R;      // few partitions want the longer runs of a 4096-row tile
   const int64_t ntiles = n ? (n + tile - 1) / tile : 1; r.ntiles = ntiles;
   BufferPtr counts = alloc_buffer(ctx, (size_t)P * ntiles * 4);
   const size_t hl = (size_t)P * G * 4;
@@ -222,6 +233,7 @@ static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const 
   { KernelTimer kt_(ctx, t_hist);
     if (big) { static bool once = false; if (!once) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_hist<1024, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); once = true; }
       hipLaunchKernelGGL((k_rp_hist<1024, H>), dim3((unsigned)nh), dim3(1024), hl, ctx->stream, hs, n, P, ntiles, G, (uint32_t*)counts->ptr); }
+    else if (small_wg) hipLaunchKernelGGL((k_rp_hist<256, H>), dim3((unsigned)nh), dim3(256), hl, ctx->stream, hs, n, P, ntiles, G, (uint32_t*)counts->ptr);
     else { static bool once = false; if (!once) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_hist<512, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); once = true; }
       hipLaunchKernelGGL((k_rp_hist<512, H>), dim3((unsigned)nh), dim3(512), hl, ctx->stream, hs, n, P, ntiles, G, (uint32_t*)counts->ptr); }
     KERNEL_CHECK(); }
@@ -232,7 +244,7 @@ static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const 
     const unsigned grid = (unsigned)(((ntiles + 7) / 8) * 8);
 #define RP_LAUNCH(NT_, ST_) { static bool once = false; if (!once) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_scatter<NT_, ST_, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); once = true; } \
       hipLaunchKernelGGL((k_rp_scatter<NT_, ST_, H>), dim3(grid), dim3(NT_), rp_scatter_lds<NT_>(P, ST_), ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols); }
-    if (stable) RP_LAUNCH(512, true) else if (big) RP_LAUNCH(1024, false) else RP_LAUNCH(512, false)
+    if (small_wg) RP_LAUNCH(256, true) else if (stable) RP_LAUNCH(512, true) else if (big) RP_LAUNCH(1024, false) else RP_LAUNCH(512, false)
 #undef RP_LAUNCH
     KERNEL_CHECK(); }
   return r;

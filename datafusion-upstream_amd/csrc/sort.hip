@@ -9,6 +9,7 @@
 // Stable => ties keep input order (the reference leaves tie order unspecified: sort_unstable_by,
 // sorts/sort.rs:641).
 #include "device_utils.h"
+#include "radix_partition.h"
 #include <algorithm>
 
 namespace dfgpu {
@@ -254,6 +255,73 @@ __global__ void k_or_words(const uint64_t* a, const uint64_t* b, uint64_t* out, 
   if (i < nw) out[i] = a[i] | b[i];
 }
 
+
+// ---------------------------------------------------------------- packed-key path (large inputs, fixed-width keys)
+// Every sort column is reduced to an unsigned offset inside its value range (ascending: v - min, descending: max - v; NULLs take the
+// slot below / above the range as nulls_first says), the offsets are concatenated into ONE u64 (first column in the top bits): comparing
+// the packed keys == comparing the rows lexicographically.  Only the bits that vary are sorted: LSD passes over the packed key
+// through the stable one-pass partition of radix_partition.h (digits of up to 8 bits), the (key, row id) pair moving with every pass.
+struct PkCol { const void* v; const uint64_t* valid; int32_t type; int32_t desc; int32_t nulls_first; int32_t shift; uint64_t lo_bits, hi_bits; uint64_t span; };   // lo/hi: order-preserving 128-bit minimum as two words (hi only for Decimal128)
+struct PkCols { int32_t n; PkCol c[MAX_KEYS]; };
+__device__ inline void pk_order_bits(const void* v, int32_t type, int64_t i, uint64_t* hi, uint64_t* lo) {      // value -> unsigned 128-bit pattern whose order is the value order
+  *hi = 0;
+  switch (type) {
+    case DFGPU_INT8: *lo = (uint64_t)((int64_t)((const int8_t*)v)[i]) ^ 0x8000000000000000ull; break;
+    case DFGPU_INT16: *lo = (uint64_t)((int64_t)((const int16_t*)v)[i]) ^ 0x8000000000000000ull; break;
+    case DFGPU_INT32: case DFGPU_DATE32: *lo = (uint64_t)((int64_t)((const int32_t*)v)[i]) ^ 0x8000000000000000ull; break;
+    case DFGPU_INT64: *lo = ((const uint64_t*)v)[i] ^ 0x8000000000000000ull; break;
+    case DFGPU_UINT8: *lo = ((const uint8_t*)v)[i]; break; case DFGPU_UINT16: *lo = ((const uint16_t*)v)[i]; break;
+    case DFGPU_UINT32: *lo = ((const uint32_t*)v)[i]; break; case DFGPU_UINT64: *lo = ((const uint64_t*)v)[i]; break;
+    case DFGPU_FLOAT32: { uint32_t b = ((const uint32_t*)v)[i]; b ^= (b >> 31) ? 0xFFFFFFFFu : 0x80000000u; *lo = b; break; }          // IEEE totalOrder (NaN above every number)
+    case DFGPU_FLOAT64: { uint64_t b = ((const uint64_t*)v)[i]; b ^= (b >> 63) ? ~0ull : 0x8000000000000000ull; *lo = b; break; }
+    default: { const uint64_t* p = (const uint64_t*)v + 2 * i; *lo = p[0]; *hi = p[1] ^ 0x8000000000000000ull; break; }                   // DECIMAL128
+  }
+}
+__device__ inline bool pk_less(uint64_t ah, uint64_t al, uint64_t bh, uint64_t bl) { return ah < bh || (ah == bh && al < bl); }
+// per column: minimum and maximum order pattern over the valid rows -> out[4 c .. 4 c + 3] = (min hi, min lo, max hi, max lo)
+__global__ void __launch_bounds__(BLOCK) k_pk_minmax(PkCols pc, int64_t n, unsigned long long* out) {
+  __shared__ unsigned long long sh[BLOCK / WAVE][4];
+  for (int c = 0; c < MAX_KEYS; c++) {
+    if (c >= pc.n) break;
+    uint64_t mnh = ~0ull, mnl = ~0ull, mxh = 0, mxl = 0;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+      if (!valid_at(pc.c[c].valid, i)) continue;
+      uint64_t h, l; pk_order_bits(pc.c[c].v, pc.c[c].type, i, &h, &l);
+      if (pk_less(h, l, mnh, mnl)) { mnh = h; mnl = l; }
+      if (pk_less(mxh, mxl, h, l)) { mxh = h; mxl = l; }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      uint64_t oh = __shfl_xor(mnh, d, 64), ol = __shfl_xor(mnl, d, 64); if (pk_less(oh, ol, mnh, mnl)) { mnh = oh; mnl = ol; }
+      oh = __shfl_xor(mxh, d, 64); ol = __shfl_xor(mxl, d, 64); if (pk_less(mxh, mxl, oh, ol)) { mxh = oh; mxl = ol; }
+    }
+    if (lane_id() == 0) { sh[threadIdx.x >> 6][0] = mnh; sh[threadIdx.x >> 6][1] = mnl; sh[threadIdx.x >> 6][2] = mxh; sh[threadIdx.x >> 6][3] = mxl; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < BLOCK / WAVE; w++) { if (pk_less(sh[w][0], sh[w][1], mnh, mnl)) { mnh = sh[w][0]; mnl = sh[w][1]; } if (pk_less(mxh, mxl, sh[w][2], sh[w][3])) { mxh = sh[w][2]; mxl = sh[w][3]; } }
+      // 128-bit min / max through two 64-bit atomics is not atomic as a pair: one slot per workgroup, reduced on the host
+      unsigned long long* o = out + ((size_t)blockIdx.x * MAX_KEYS + c) * 4; o[0] = mnh; o[1] = mnl; o[2] = mxh; o[3] = mxl;
+    }
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(BLOCK) k_pk_encode(PkCols pc, int64_t n, uint64_t* keys, uint32_t* idx) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint64_t key = 0;
+  for (int c = 0; c < MAX_KEYS; c++) {
+    if (c >= pc.n) break;
+    const PkCol& k = pc.c[c]; uint64_t off;
+    if (!valid_at(k.valid, i)) off = k.nulls_first ? 0 : k.span + 1;        // slot 0 / span + 1 are the NULL slots, values occupy 1 .. span (span = max - min + 1)
+    else { uint64_t h, l; pk_order_bits(k.v, k.type, i, &h, &l); uint64_t d = l - k.lo_bits; off = 1 + (k.desc ? k.span - 1 - d : d); }     // the range fits 63 bits: the high words cancel
+    key |= off << k.shift;
+  }
+  keys[i] = key; idx[i] = (uint32_t)i;
+}
+struct RpHashDigit {      // partition = one 8-bit digit of the packed key
+  const uint64_t* keys; int shift; uint32_t mask;
+  __device__ inline bool operator()(int64_t i, uint32_t, uint32_t* pid, uint64_t* key) const { *key = keys[i]; *pid = (uint32_t)(*key >> shift) & mask; return true; }
+};
 }  // namespace dfgpu
 
 using namespace dfgpu;
@@ -278,6 +346,62 @@ extern "C" dfgpu_status dfgpu_sort_to_indices(dfgpu_ctx* ctx, const dfgpu_array*
       }
       s.has_null_byte = (s.v.validity || s.v.key_validity) ? 1 : 0; s.descending = descending && descending[c]; s.nulls_first = nulls_first ? nulls_first[c] : 1;
       W += s.has_null_byte + (lt == DFGPU_BOOL ? 1 : (lt == DFGPU_UTF8 ? s.max_len + 4 : type_width(lt)));
+    }
+    // ---- packed-key path: large input, fixed-width keys whose value ranges concatenate into 64 bits, no TopK
+    if (n >= (1 << 20) && ctx->sort_packed_keys && !(fetch > 0 && fetch * 16 <= n)) {
+      bool ok = true; PkCols pc{}; pc.n = k;
+      for (int c = 0; c < k && ok; c++) {
+        const dfgpu_array* a = cols[c];
+        ok = a->type != DFGPU_DICTIONARY && a->type != DFGPU_UTF8 && a->type != DFGPU_BOOL && type_width(a->type) > 0;
+        pc.c[c].v = ok ? a->values->ptr : nullptr; pc.c[c].valid = a->validity ? (const uint64_t*)a->validity->ptr : nullptr; pc.c[c].type = a->type;
+        pc.c[c].desc = descending && descending[c]; pc.c[c].nulls_first = nulls_first ? nulls_first[c] : 1;
+      }
+      if (ok) {
+        const int nb = ctx->num_cus * 4;
+        BufferPtr mm = alloc_buffer(ctx, (size_t)nb * MAX_KEYS * 32);
+        { KernelTimer kt_(ctx, "sort_key_ranges");
+          hipLaunchKernelGGL(k_pk_minmax, dim3(nb), dim3(BLOCK), 0, ctx->stream, pc, n, (unsigned long long*)mm->ptr); KERNEL_CHECK(); }
+        std::vector<uint64_t> h((size_t)nb * MAX_KEYS * 4);
+        HIP_CHECK(hipMemcpyAsync(h.data(), mm->ptr, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->count_sync("sync:sort_key_ranges");
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        int total_bits = 0; int bits_of[MAX_KEYS];
+        for (int c = 0; c < k && ok; c++) {
+          uint64_t mnh = ~0ull, mnl = ~0ull, mxh = 0, mxl = 0;
+          for (int b = 0; b < nb; b++) { const uint64_t* o = &h[((size_t)b * MAX_KEYS + c) * 4];
+            if (o[0] < mnh || (o[0] == mnh && o[1] < mnl)) { mnh = o[0]; mnl = o[1]; } if (mxh < o[2] || (mxh == o[2] && mxl < o[3])) { mxh = o[2]; mxl = o[3]; } }
+          uint64_t span = 1;            // a column of NULLs only: one (unused) value slot
+          if (!(mnh == ~0ull && mnl == ~0ull && mxh == 0 && mxl == 0)) {
+            unsigned __int128 mn = ((unsigned __int128)mnh << 64) | mnl, mx = ((unsigned __int128)mxh << 64) | mxl, d = mx - mn;
+            if (d >= ((unsigned __int128)1 << 62)) { ok = false; break; }
+            span = (uint64_t)d + 1; pc.c[c].lo_bits = mnl; pc.c[c].hi_bits = mnh;
+          }
+          pc.c[c].span = span;
+          int b = 1; while (((span + 2) >> b) != 0 && b < 64) b++;       // offsets 0 .. span + 1
+          bits_of[c] = b; total_bits += b;
+        }
+        if (ok && total_bits <= 64) {
+          int sh = total_bits; for (int c = 0; c < k; c++) { sh -= bits_of[c]; pc.c[c].shift = sh; }
+          BufferPtr k0 = alloc_buffer(ctx, (size_t)n * 8), k1 = alloc_buffer(ctx, (size_t)n * 8), v1 = alloc_buffer(ctx, (size_t)n * 4);
+          ArrayHolder idx(new_fixed(ctx, DFGPU_UINT32, n));
+          { KernelTimer kt_(ctx, "sort_key_encode");
+            hipLaunchKernelGGL(k_pk_encode, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, pc, n, (uint64_t*)k0->ptr, (uint32_t*)idx.get()->values->ptr); KERNEL_CHECK(); }
+          uint64_t* ka = (uint64_t*)k0->ptr; uint64_t* kb = (uint64_t*)k1->ptr; uint32_t* va = (uint32_t*)idx.get()->values->ptr; uint32_t* vb = (uint32_t*)v1->ptr;
+          const int npass = (total_bits + 7) / 8, dbits = (total_bits + npass - 1) / npass;          // up to 8-bit digits, evened out over the passes
+          for (int shift = 0; shift < total_bits; shift += dbits) {
+            const int bits = total_bits - shift < dbits ? total_bits - shift : dbits; const bool last = shift + dbits >= total_bits;
+            RpCols rc{}; rc.n = last ? 1 : 2;
+            rc.c[0] = RpCol{ va, vb, 4, RP_RAW, 0 };
+            if (!last) rc.c[1] = RpCol{ nullptr, kb, 8, RP_HASHKEY, 0 };                 // the last pass only needs the row ids
+            (void)rp_partition(ctx, RpHashDigit{ ka, shift, (1u << bits) - 1u }, n, 1u << bits, rc, true, ctx->d_scratch64 + 9, "sort_pass_hist", "sort_pass_scan", "sort_pass_scatter");
+            std::swap(ka, kb); std::swap(va, vb);
+          }
+          if (va != (uint32_t*)idx.get()->values->ptr) HIP_CHECK(hipMemcpyAsync(idx.get()->values->ptr, va, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+          if (fetch >= 0 && fetch < n) { dfgpu_array* s2 = nullptr; dfgpu_status st = dfgpu_array_slice(ctx, idx.get(), 0, fetch, &s2); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str()); *out = s2; }
+          else *out = idx.release();
+          return;
+        }
+      }
     }
     ArrayHolder idx(new_fixed(ctx, DFGPU_UINT32, n));
     launch_iota_u32(ctx, (uint32_t*)idx.get()->values->ptr, n, 0);

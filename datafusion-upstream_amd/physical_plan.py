@@ -105,6 +105,7 @@ class RecordBatch:
     @property
     def columns(self) -> List[Array]:
         if self._cols is None:
+            _check(_lib().dfgpu_batch_materialize(self._ctx.h, self._h.h))      # all pending gathers at once (shared index arrays: one pass)
             self._cols = [self.column(i) for i in range(self.num_columns)]
         return self._cols
 

@@ -104,6 +104,7 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
  * every partition's table sits in LDS; probe batches of >= min_probe rows are partitioned the same way.  Pairs and their order are identical;
  * "agg_partitioned" (1/0), "agg_partitioned_min_rows", "agg_partitioned_force" (1 = skip the sample's verdict; tests) == let the plan layer's
  * AggregateExec pre-aggregate large batches of high-cardinality unclustered keys partition by partition out of LDS (dfgpu_agg_preaggregate);
+ * "sort_packed_keys" (1/0) == let sort_to_indices sort large inputs over fixed-width keys through range-packed 64-bit keys (identical indices);
  * "memory_limit" (bytes, 0 = none) == live device memory this ctx may hold; an allocation beyond it fails with DFGPU_RESOURCES_EXHAUSTED and the
  * message of MemoryPool::try_grow (≙ RuntimeConfig::with_memory_limit, execution/src/runtime_env.rs); "live_bytes" / "cached_bytes" (read only);
  * "collect_metrics" (1/0) == the plan layer records per-operator metrics (dfgpu_plan_metrics);
@@ -188,6 +189,11 @@ DFGPU_API dfgpu_status dfgpu_hash_columns(dfgpu_ctx *ctx, const dfgpu_array *con
 /* ≙ arrow::compute::take (joins/utils.rs:1216,1224; sorts/sort.rs:605; repartition/mod.rs:202).
  * indices: UINT32 / UINT64 / INT32 / INT64 array; a NULL index yields a NULL row. */
 DFGPU_API dfgpu_status dfgpu_take(dfgpu_ctx *ctx, const dfgpu_array *values, const dfgpu_array *indices, dfgpu_array **out);
+/* `take` of n columns through ONE index array (build_batch_from_indices / sort_batch gather every output column through the same indices,
+ * joins/utils.rs:1180-1230, sorts/sort.rs:605): out[c] = take(values[c], indices); values[c] may be NULL (out[c] = NULL).  Same results as n
+ * dfgpu_take calls; fixed-width columns without NULLs travel together as row-major records when many rows are gathered from a large source
+ * (one memory sector per gathered row instead of one per row and column). */
+DFGPU_API dfgpu_status dfgpu_take_multi(dfgpu_ctx *ctx, const dfgpu_array *const *values, int32_t n, const dfgpu_array *indices, dfgpu_array **out);
 /* ≙ arrow::compute::filter with a BooleanArray mask (filter.rs:325): keeps rows whose mask is
  * valid AND true, input order preserved. */
 DFGPU_API dfgpu_status dfgpu_filter(dfgpu_ctx *ctx, const dfgpu_array *values, const dfgpu_array *mask, dfgpu_array **out);

@@ -35,6 +35,9 @@ DFGPU_API int32_t dfgpu_batch_num_columns(const dfgpu_batch *b);
 /* rows after applying the selection mask (materialises nothing but the mask popcount) */
 DFGPU_API dfgpu_status dfgpu_batch_num_rows(dfgpu_ctx *ctx, dfgpu_batch *b, int64_t *out);
 DFGPU_API const char *dfgpu_batch_column_name(const dfgpu_batch *b, int32_t i);
+/* applies the selection and executes every pending gather of the batch at once: columns that go through the same index array are gathered
+ * together (dfgpu_take_multi).  Optional: dfgpu_batch_column does the same for one column at a time. */
+DFGPU_API dfgpu_status dfgpu_batch_materialize(dfgpu_ctx *ctx, dfgpu_batch *b);
 /* column i, selection applied and lazy gathers executed; caller releases the array */
 DFGPU_API dfgpu_status dfgpu_batch_column(dfgpu_ctx *ctx, dfgpu_batch *b, int32_t i, dfgpu_array **out);
 
