@@ -147,6 +147,13 @@ PROTOTYPES = {
     "dfgpu_acc_size": (C.c_int64, [_P]),
     "dfgpu_sort_to_indices": (C.c_int32, [_P, _PP, C.c_char_p, C.c_char_p, C.c_int32, C.c_int64, _PP]),
     "dfgpu_hash_partition": (C.c_int32, [_P, _PP, C.c_int32, C.c_int32, _PP, C.POINTER(C.c_int64)]),
+    "dfgpu_comm_unique_id": (C.c_int32, [C.c_char_p]),
+    "dfgpu_comm_create_rccl": (C.c_int32, [_P, C.c_char_p, C.c_int32, C.c_int32, _PP]),
+    "dfgpu_comm_create_custom": (C.c_int32, [_P, _PP]),
+    "dfgpu_comm_free": (None, [_P]),
+    "dfgpu_comm_rank": (C.c_int32, [_P]),
+    "dfgpu_comm_world": (C.c_int32, [_P]),
+    "dfgpu_exchange": (C.c_int32, [_P, _P, _PP, C.c_int32, _PP, C.c_int32, _P, _PP, C.POINTER(C.c_int64)]),
     "dfgpu_partition_columns": (C.c_int32, [_P, _PP, C.c_int32, C.c_int32, _PP, C.c_int32, _P, _PP, _PP, C.POINTER(C.c_int64)]),
 }
 

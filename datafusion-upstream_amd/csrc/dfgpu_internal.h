@@ -140,6 +140,7 @@ struct ArrayHolder {   // RAII release on exception paths
   ~ArrayHolder() { if (a) dfgpu_array_release(a); }
   dfgpu_array* release() { dfgpu_array* x = a; a = nullptr; return x; }
   dfgpu_array* get() const { return a; }
+  ArrayHolder(ArrayHolder&& o) noexcept : a(o.a) { o.a = nullptr; }
   ArrayHolder(const ArrayHolder&) = delete; ArrayHolder& operator=(const ArrayHolder&) = delete;
 };
 

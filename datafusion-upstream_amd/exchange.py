@@ -303,6 +303,93 @@ def _exchange_batches(ctx, schema, parts, group, names, broadcast):
     return pp.RecordBatch.from_arrays(ctx, list(names), out_cols)
 
 
+# ----------------------------------------------------------------------------- the exchange behind the C ABI (dfgpu_exchange)
+class Comm:
+    """dfgpu_comm (include/dfgpu.h): the communicator the C entry point dfgpu_exchange runs over.  Under torch.distributed's nccl backend it is
+    RCCL itself (ncclCommInitRank inside libdfgpu.so; the 128-byte id travels from rank 0 by a torch broadcast); under gloo -- the CPU-launched
+    tests and several ranks rehearsing on ONE GPU -- it is a caller-provided transport: two callbacks that move the device buffers through the
+    host with torch.distributed."""
+
+    def __init__(self, ctx, group=None, force_callbacks: bool = False):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import capi
+        self.ctx, self.group, self.lib = ctx, group, ctx.lib
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.h = C.c_void_p()
+        if _is_nccl(group) and not force_callbacks:
+            ident = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if self.rank == 0:
+                buf = C.create_string_buffer(128)
+                ctx.check(self.lib.dfgpu_comm_unique_id(buf))
+                ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).cuda()
+            dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ctx.check(self.lib.dfgpu_comm_create_rccl(ctx.h, bytes(ident.cpu().numpy().tobytes()), self.rank, self.world, C.byref(self.h)))
+            self.kind = "rccl"
+            return
+        self.kind = "callbacks"
+        world, rank = self.world, self.rank
+
+        def all_gather_host(user, send, nbytes, recv):
+            try:
+                mine = torch.frombuffer(bytearray(C.string_at(send, nbytes)), dtype=torch.uint8)
+                dev = "cuda" if _is_nccl(group) else "cpu"
+                outs = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(world)]
+                dist.all_gather(outs, mine.to(dev), group=group)
+                C.memmove(recv, torch.cat([o.cpu() for o in outs]).numpy().tobytes(), nbytes * world)
+                return 0
+            except Exception:       # noqa: a callback must not raise through C
+                import traceback; traceback.print_exc()
+                return 1
+
+        def all_to_all_v(user, send, so, sb, recv, ro, rb):
+            try:
+                so, sb, ro, rb = ([int(a[i]) for i in range(world)] for a in (so, sb, ro, rb))
+                tot_s, tot_r = so[-1] + sb[-1], ro[-1] + rb[-1]
+                sd = torch.as_tensor(_DevicePtr(send, tot_s, None), device="cuda") if tot_s else torch.empty(0, dtype=torch.uint8, device="cuda")
+                staged = sd if _is_nccl(group) else sd.cpu()
+                out = torch.empty(tot_r, dtype=torch.uint8, device=staged.device)
+                dist.all_to_all_single(out, staged.contiguous(), output_split_sizes=rb, input_split_sizes=sb, group=group)
+                if tot_r:
+                    torch.as_tensor(_DevicePtr(recv, tot_r, None), device="cuda").copy_(out)
+                torch.cuda.synchronize()
+                return 0
+            except Exception:       # noqa
+                import traceback; traceback.print_exc()
+                return 1
+        I64P = C.POINTER(C.c_int64)
+        self._ag = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)(all_gather_host)
+        self._aa = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, I64P, I64P, C.c_void_p, I64P, I64P)(all_to_all_v)
+
+        class VT(C.Structure):
+            _fields_ = [("user", C.c_void_p), ("rank", C.c_int32), ("world", C.c_int32), ("all_gather_host", C.c_void_p), ("all_to_all_v", C.c_void_p)]
+        self._vt = VT(None, rank, world, C.cast(self._ag, C.c_void_p), C.cast(self._aa, C.c_void_p))
+        st = self.lib.dfgpu_comm_create_custom(C.byref(self._vt), C.byref(self.h))
+        if st != 0:
+            raise capi.DfgpuError(st, "dfgpu_comm_create_custom failed")
+
+    def __del__(self):
+        try:
+            if self.h is not None and self.h.value:
+                self.lib.dfgpu_comm_free(self.h); self.h = None
+        except Exception:
+            pass
+
+    def exchange(self, keys, cols, ncols: int, mask=None):
+        """dfgpu_exchange: hash-partition this rank's rows on `keys`, all-to-all, -> (columns this rank owns afterwards or None when no rank had
+        rows, rows sent per rank, rows received per rank).  keys = cols = None on a rank without rows."""
+        import ctypes as C
+        from .device import Array
+        kh = (C.c_void_p * max(1, len(keys or [])))(*[k.h for k in (keys or [])])
+        ch = (C.c_void_p * max(1, ncols))(*[c.h for c in (cols or [])])
+        out = (C.c_void_p * ncols)()
+        counts = (C.c_int64 * (2 * self.world))()
+        self.ctx.check(self.lib.dfgpu_exchange(self.ctx.h, self.h, kh if keys else None, len(keys or []), ch if cols else None, ncols, mask.h if mask is not None else None, out, counts))
+        arrays = [Array(self.ctx, C.c_void_p(out[i])) for i in range(ncols)] if out[0] else None
+        return arrays, list(counts[:self.world]), list(counts[self.world:])
+
+
 def gather_batches(ctx, schema, batch, dst: int = 0, group=None, names: Optional[Sequence[str]] = None):
     """≙ CoalescePartitionsExec / SortPreservingMergeExec input gathering: every rank's batch to rank `dst`."""
     import torch.distributed as dist
@@ -319,7 +406,10 @@ class ShuffleExec:
     (≙ physical-plan/src/repartition/mod.rs:232-294 with the in-process channels replaced by RCCL over xGMI).
     A Python-only node: the C++ plan above it sees a MemoryExec of the received rows (physical_plan._child_handle)."""
 
-    def __init__(self, input, exprs, group=None):
+    def __init__(self, input, exprs, group=None, native: bool = False):
+        """native: run the exchange through the C entry point dfgpu_exchange (one-pass partition of all columns + one grouped collective; RCCL
+        under the nccl backend).  For inputs whose columns are all fixed width and whose keys are plain columns -- every rank must make the
+        same choice, so it is the plan builder's, not a run-time test."""
         import torch.distributed as dist
         from . import physical_plan as pp
         self.input, self.exprs, self.group = input, list(exprs), group
@@ -327,6 +417,8 @@ class ShuffleExec:
         self.rank = dist.get_rank(group)
         self._pp = pp
         self.bytes_sent = 0
+        self.native = native and all(isinstance(e, pp.Column) for e in self.exprs)
+        self._comm = None
 
     def schema(self):
         return self.input.schema()
@@ -337,7 +429,29 @@ class ShuffleExec:
     def output_partitioning(self):
         return self._pp.Partitioning.Hash(self.exprs, 1)      # one local output partition per rank
 
+    def _execute_native(self, context):
+        pp = self._pp
+        if self._comm is None or self._comm.ctx is not context.ctx:
+            self._comm = Comm(context.ctx, self.group)
+        names = self.input.schema().names()
+        local = []
+        with context.ctx.deferred_flags():
+            for p in range(self.input.output_partitioning().partition_count()):
+                local += [b for b in self.input.execute(p, context) if b.num_rows]
+            mine = pp.concat_batches(None, local) if local else None
+            cols = mine.columns if mine is not None else None
+            keys = [cols[e.index] for e in self.exprs] if cols is not None else None
+            got, sent, _ = self._comm.exchange(keys, cols, len(names), None)
+        if cols is not None:
+            row_bytes = sum(_WIDTH.get(c.describe().type, 0) for c in cols)
+            self.bytes_sent += row_bytes * sum(n for d, n in enumerate(sent) if d != self.rank)
+        if got is not None and len(got[0]):
+            yield pp.RecordBatch.from_arrays(context.ctx, names, got)
+
     def execute(self, partition, context):
+        if self.native:
+            yield from self._execute_native(context)
+            return
         pp = self._pp
         rep = pp.RepartitionExec(self.input, pp.Partitioning.Hash(self.exprs, self.world))
         merged, schema = [], None

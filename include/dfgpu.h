@@ -358,6 +358,36 @@ DFGPU_API dfgpu_status dfgpu_partition_columns(dfgpu_ctx *ctx, const dfgpu_array
                                                const dfgpu_array *const *cols, int32_t ncols, const dfgpu_array *opt_mask,
                                                dfgpu_array **out_cols, dfgpu_array **out_indices, int64_t *counts_host);
 
+/* ------------------------------------------------------------------ a14 across GPUs: the exchange of RepartitionExec */
+/* One process (or ctx) per GPU.  A dfgpu_comm is the job's communicator: RCCL over xGMI (dfgpu_comm_create_rccl; rank 0 obtains the 128-byte
+ * id from dfgpu_comm_unique_id and hands it to the other ranks by any means, as with ncclCommInitRank), or a transport the caller provides as
+ * two callbacks (dfgpu_comm_create_custom: an MPI host, or the CPU tests over torch.distributed's gloo backend). */
+typedef struct dfgpu_comm dfgpu_comm;
+typedef struct dfgpu_comm_vtable {
+  void *user; int32_t rank, world;
+  /* every rank contributes `bytes` HOST bytes; recv (world * bytes, host) receives the contributions in rank order */
+  int32_t (*all_gather_host)(void *user, const void *send, int64_t bytes, void *recv);
+  /* DEVICE buffers: segment p of `send` (send_off[p], send_bytes[p]) goes to rank p, segment p of `recv` receives what rank p sends here.
+   * Returns (0 = ok) when `recv` is complete. */
+  int32_t (*all_to_all_v)(void *user, const void *send, const int64_t *send_off, const int64_t *send_bytes, void *recv, const int64_t *recv_off, const int64_t *recv_bytes);
+} dfgpu_comm_vtable;
+DFGPU_API dfgpu_status dfgpu_comm_unique_id(uint8_t *out_id128);
+DFGPU_API dfgpu_status dfgpu_comm_create_rccl(dfgpu_ctx *ctx, const uint8_t *id128, int32_t rank, int32_t world, dfgpu_comm **out);
+DFGPU_API dfgpu_status dfgpu_comm_create_custom(const dfgpu_comm_vtable *vtable, dfgpu_comm **out);
+DFGPU_API void dfgpu_comm_free(dfgpu_comm *comm);
+DFGPU_API int32_t dfgpu_comm_rank(const dfgpu_comm *comm);
+DFGPU_API int32_t dfgpu_comm_world(const dfgpu_comm *comm);
+/* ≙ RepartitionExec with Partitioning::Hash(keys, world) between processes (repartition/mod.rs:442-580, :684-760 -- the in-process channels
+ * become an all-to-all): every rank hash-partitions its rows (create_hashes % world, identical on all ranks; dfgpu_partition_columns), the
+ * row-count matrix is exchanged, then ONE grouped collective moves every column buffer.  out_cols[c] = the rows of column c this rank owns
+ * afterwards, ordered by source rank (row i of every column belongs to one row).  Fixed-width columns, with or without NULLs; dictionary /
+ * Utf8 columns return DFGPU_NOT_IMPLEMENTED (cast them first).  opt_mask: unselected rows are not sent.  out_counts (optional, 2 * world):
+ * rows sent to / received from every rank.  Collective: every rank of the communicator must call it with the same number of columns; a rank
+ * whose input produced no batch passes keys = cols = NULL and learns the column types from the others (out_cols stay NULL when no rank had
+ * rows).  A column that is nullable on any rank arrives with a validity bitmap on every rank. */
+DFGPU_API dfgpu_status dfgpu_exchange(dfgpu_ctx *ctx, dfgpu_comm *comm, const dfgpu_array *const *keys, int32_t nkeys, const dfgpu_array *const *cols, int32_t ncols,
+                                      const dfgpu_array *opt_mask, dfgpu_array **out_cols, int64_t *out_counts);
+
 #ifdef __cplusplus
 }
 #endif
