@@ -155,6 +155,19 @@ PROTOTYPES = {
     "dfgpu_comm_world": (C.c_int32, [_P]),
     "dfgpu_exchange": (C.c_int32, [_P, _P, _PP, C.c_int32, _PP, C.c_int32, _P, _PP, C.POINTER(C.c_int64)]),
     "dfgpu_partition_columns": (C.c_int32, [_P, _PP, C.c_int32, C.c_int32, _PP, C.c_int32, _P, _PP, _PP, C.POINTER(C.c_int64)]),
+    "dfgpu_parquet_open": (C.c_int32, [_P, _P, C.c_int64, _P, _PP]),
+    "dfgpu_parquet_open_file": (C.c_int32, [_P, C.c_char_p, C.c_int32, _PP]),
+    "dfgpu_parquet_close": (None, [_P]),
+    "dfgpu_parquet_set_option": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
+    "dfgpu_parquet_num_rows": (C.c_int64, [_P]),
+    "dfgpu_parquet_num_row_groups": (C.c_int32, [_P]),
+    "dfgpu_parquet_num_columns": (C.c_int32, [_P]),
+    "dfgpu_parquet_row_group_rows": (C.c_int64, [_P, C.c_int32]),
+    "dfgpu_parquet_column_name": (C.c_char_p, [_P, C.c_int32]),
+    "dfgpu_parquet_column_type": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "dfgpu_parquet_column_stats": (C.c_int32, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "dfgpu_parquet_column_chunk_bytes": (C.c_int64, [_P, C.c_int32, C.c_int32, C.c_int32]),
+    "dfgpu_parquet_read": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, _PP]),
 }
 
 # include/dfgpu_exec.h: the C++ host layer (ExecutionPlan / PhysicalExpr mirror)
@@ -162,6 +175,9 @@ _CPP = C.POINTER(C.c_char_p)
 _I32P = C.POINTER(C.c_int32)
 PROTOTYPES.update({
     "dfgpu_exec_last_error": (C.c_char_p, []),
+    "dfgpu_plan_parquet": (C.c_int32, [_P, _I32P, C.c_int32, C.c_int32, C.c_int32, _PP]),
+    "dfgpu_plan_parquet_prune": (C.c_int32, [_P, C.c_int32, C.c_int64, C.c_int64]),
+    "dfgpu_plan_parquet_pruned": (C.c_int64, [_P]),
     "dfgpu_batch_new": (C.c_int32, [_CPP, _PP, C.c_int32, _PP]),
     "dfgpu_batch_free": (None, [_P]),
     "dfgpu_batch_num_columns": (C.c_int32, [_P]),

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <atomic>
 #include <map>
 #include <tuple>
 #include <set>
@@ -300,6 +301,45 @@ struct MemoryExec : Plan {        // memory.rs:40,150
     std::lock_guard<std::mutex> l(mu);
     if (p < 0 || p >= (int)parts.size()) fail(DFGPU_INTERNAL, "MemoryExec invalid partition %d (expected less than %zu)", p, parts.size());
     return std::unique_ptr<Stream>(new VecStream(parts[(size_t)p]));
+  }
+};
+
+// ≙ ParquetExec (core/src/datasource/physical_plan/parquet/mod.rs:78-117, execute :356-414): one file, its row groups dealt to the output
+// partitions in contiguous runs (the reference splits a file's byte range over target_partitions, file_groups / repartition_file_groups);
+// a projection by leaf index; row groups whose statistics cannot satisfy a [min, max] bound on an integer / date column are skipped
+// (≙ parquet/row_groups.rs prune_row_groups_by_statistics -- the FilterExec above still runs).  Batches are whole row groups (the kernels
+// want large launches), not batch_size slices.
+struct ParquetExec : Plan {
+  dfgpu_parquet* file = nullptr; std::vector<int32_t> proj; SchemaPtr sch; int nparts = 1, per_batch = 1;
+  struct Bound { int32_t col; int64_t lo, hi; }; mutable std::mutex mu; mutable std::vector<Bound> bounds; mutable std::atomic<int64_t> pruned{0};
+  const char* name() const override { return "ParquetExec"; }
+  PlanPtr fresh() const override { return shared_from_this(); }
+  SchemaPtr schema() const override { return sch; }
+  int partitions() const override { return nparts; }
+  bool keep(int rg) const {
+    std::lock_guard<std::mutex> l(mu);
+    for (auto& b : bounds) { int64_t mn, mx, nc; int32_t has; if (dfgpu_parquet_column_stats(file, rg, b.col, &mn, &mx, &nc, &has) == DFGPU_OK && has && (mx < b.lo || mn > b.hi)) return false; }
+    return true;
+  }
+  struct S : Stream {
+    const ParquetExec* op; TaskContext tc; int next_rg, end_rg;
+    S(const ParquetExec* o, TaskContext t, int a, int b) : op(o), tc(t), next_rg(a), end_rg(b) {}
+    bool next(Batch& out) override {
+      while (next_rg < end_rg && !op->keep(next_rg)) { next_rg++; op->pruned++; }
+      if (next_rg >= end_rg) return false;
+      int first = next_rg, n = 0;
+      while (next_rg < end_rg && n < op->per_batch && op->keep(next_rg)) { next_rg++; n++; }
+      std::vector<dfgpu_array*> cols(op->proj.size(), nullptr);
+      tc.check(dfgpu_parquet_read(tc.ctx, op->file, first, n, op->proj.data(), (int32_t)op->proj.size(), cols.data()));
+      Batch b; b.schema = op->sch; b.base_rows = 0; for (int g = first; g < first + n; g++) b.base_rows += dfgpu_parquet_row_group_rows(op->file, g);
+      for (auto* a : cols) b.cols.push_back(col_of(ArrayRef::adopt(a)));
+      out = std::move(b); return true;
+    }
+  };
+  std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override {
+    if (p < 0 || p >= nparts) fail(DFGPU_INTERNAL, "ParquetExec invalid partition %d (expected less than %d)", p, nparts);
+    int64_t R = dfgpu_parquet_num_row_groups(file);
+    return std::unique_ptr<Stream>(new S(this, tc, (int)(R * p / nparts), (int)(R * (p + 1) / nparts)));
   }
 };
 
@@ -1127,6 +1167,27 @@ dfgpu_status dfgpu_plan_memory(const dfgpu_batch* const* batches, const int32_t*
     *out = new dfgpu_plan{m};
   });
 }
+dfgpu_status dfgpu_plan_parquet(dfgpu_parquet* file, const int32_t* columns, int32_t ncols, int32_t npartitions, int32_t row_groups_per_batch, dfgpu_plan** out) {
+  return guard([&] {
+    if (!file || !out || (ncols > 0 && !columns) || npartitions < 1) fail(DFGPU_INVALID_ARGUMENT, "plan_parquet: bad argument");
+    auto n = std::make_shared<ParquetExec>(); n->file = file; n->nparts = npartitions; n->per_batch = row_groups_per_batch > 0 ? row_groups_per_batch : 1; n->sch = std::make_shared<Schema>();
+    for (int32_t i = 0; i < ncols; i++) {
+      int32_t t = 0, vt = 0, pr = 0, sc = 0, nl = 0;
+      if (dfgpu_parquet_column_type(file, columns[i], &t, &vt, &pr, &sc, &nl) != DFGPU_OK) fail(DFGPU_INVALID_ARGUMENT, "plan_parquet: column %d is not in the file", columns[i]);
+      if (!t) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: Parquet column '%s' has a type outside the device scan", dfgpu_parquet_column_name(file, columns[i]));
+      n->proj.push_back(columns[i]); n->sch->f.push_back(Field{dfgpu_parquet_column_name(file, columns[i]), vt, pr, sc});
+    }
+    *out = new dfgpu_plan{n};
+  });
+}
+dfgpu_status dfgpu_plan_parquet_prune(dfgpu_plan* p, int32_t column, int64_t min_value, int64_t max_value) {
+  return guard([&] {
+    auto* n = p ? dynamic_cast<const ParquetExec*>(p->p.get()) : nullptr;
+    if (!n) fail(DFGPU_INVALID_ARGUMENT, "plan_parquet_prune: not a ParquetExec");
+    std::lock_guard<std::mutex> l(n->mu); n->bounds.push_back(ParquetExec::Bound{column, min_value, max_value});
+  });
+}
+int64_t dfgpu_plan_parquet_pruned(const dfgpu_plan* p) { auto* n = p ? dynamic_cast<const ParquetExec*>(p->p.get()) : nullptr; return n ? n->pruned.load() : -1; }
 dfgpu_status dfgpu_plan_memory_replace(dfgpu_plan* p, const dfgpu_batch* const* batches, const int32_t* sizes, int32_t nparts) {
   return guard([&] {
     auto* m = p ? dynamic_cast<const MemoryExec*>(p->p.get()) : nullptr;

@@ -397,6 +397,37 @@ class MemoryExec(ExecutionPlan):
             _check(_lib().dfgpu_plan_memory_replace(h.h, _ptrs([b._h.h for b in flat]), sizes, len(partitions)))
 
 
+class ParquetExec(ExecutionPlan):
+    """≙ ParquetExec (core/src/datasource/physical_plan/parquet/mod.rs:78): scan of one parquet.ParquetFile.  projection = leaf indices or
+    names; the file's row groups are dealt to `partitions` output partitions in contiguous runs; `prune` = [(column, min, max)] bounds checked
+    against the row-group statistics (≙ parquet/row_groups.rs)."""
+
+    def __init__(self, file, projection=None, partitions: int = 1, row_groups_per_batch: int = 1, prune=()):
+        names = file.column_names()
+        self.file = file
+        self.projection = list(range(file.num_columns)) if projection is None else [names.index(c) if isinstance(c, str) else int(c) for c in projection]
+        self.partitions, self.row_groups_per_batch = partitions, row_groups_per_batch
+        self.prune = [((names.index(c) if isinstance(c, str) else int(c)), lo, hi) for c, lo, hi in prune]
+
+    def output_partitioning(self):
+        return Partitioning.UnknownPartitioning(self.partitions)
+
+    def schema(self):
+        return self.file.schema(self.projection)
+
+    def _build(self, context):
+        out = C.c_void_p()
+        idx = (C.c_int32 * max(1, len(self.projection)))(*self.projection)
+        _check(_lib().dfgpu_plan_parquet(self.file.h, idx, len(self.projection), self.partitions, self.row_groups_per_batch, C.byref(out)))
+        h = self._new(out)
+        for c, lo, hi in self.prune:
+            _check(_lib().dfgpu_plan_parquet_prune(h.h, c, lo, hi))
+        return h
+
+    def row_groups_pruned(self, context) -> int:
+        return _lib().dfgpu_plan_parquet_pruned(self.handle(context).h)
+
+
 class FilterExec(ExecutionPlan):
     def __init__(self, predicate: PhysicalExpr, input):
         self.predicate, self.input = predicate, input

@@ -388,6 +388,40 @@ DFGPU_API int32_t dfgpu_comm_world(const dfgpu_comm *comm);
 DFGPU_API dfgpu_status dfgpu_exchange(dfgpu_ctx *ctx, dfgpu_comm *comm, const dfgpu_array *const *keys, int32_t nkeys, const dfgpu_array *const *cols, int32_t ncols,
                                       const dfgpu_array *opt_mask, dfgpu_array **out_cols, int64_t *out_counts);
 
+/* ------------------------------------------------------------------ scan: Parquet column chunks -> Arrow columns in HBM */
+/* ≙ what ParquetExec's stream does per row group (core/src/datasource/physical_plan/parquet/mod.rs: ParquetOpener::open :417-560 ->
+ * ParquetRecordBatchStreamBuilder of the `parquet` crate (arrow-rs 50, not part of the reference tree) -> RecordBatches), for flat schemas:
+ * the footer and the page headers are parsed on the host, pages are decompressed (UNCOMPRESSED, SNAPPY) and decoded (PLAIN, PLAIN_DICTIONARY /
+ * RLE_DICTIONARY, RLE definition levels; data pages v1 and v2) by device kernels.  Column types follow the crate's parquet -> arrow rules:
+ * BOOLEAN, INT32 / INT64 with their INT(8..64, signed / unsigned), DATE and DECIMAL annotations, FLOAT, DOUBLE, BYTE_ARRAY (STRING / UTF8),
+ * FIXED_LEN_BYTE_ARRAY (DECIMAL, <= 16 bytes).  Other columns (nested, INT96, timestamps, binary) report type 0 and fail to read with
+ * DFGPU_NOT_IMPLEMENTED -- the file's other columns stay readable (projection).
+ * dfgpu_parquet_open: `file_bytes` is the whole file in host memory (kept by the caller until close); `device_bytes` (optional) is the same image
+ * already resident in HBM (a GPUDirect read, or a cached file) -- pages are then decoded in place, otherwise each column chunk read is copied
+ * to the device first.  dfgpu_parquet_open_file maps `path` (stage_on_device = 1 also copies the image to HBM once).
+ * Option "utf8_dictionary" (default 1): Utf8 columns are handed over as Dictionary(Int32, Utf8) -- the page indices plus the row group's base in
+ * the concatenated dictionaries; nothing is expanded, and dictionary predicates / the canonical-id group-by take the column as it is.  Chunks that
+ * fell back to PLAIN pages get identity keys, so the column type is the same in every batch.  0 = plain Utf8 columns, as the reference decodes. */
+typedef struct dfgpu_parquet dfgpu_parquet;
+DFGPU_API dfgpu_status dfgpu_parquet_open(dfgpu_ctx *ctx, const uint8_t *file_bytes, int64_t len, const uint8_t *device_bytes, dfgpu_parquet **out);
+DFGPU_API dfgpu_status dfgpu_parquet_open_file(dfgpu_ctx *ctx, const char *path, int32_t stage_on_device, dfgpu_parquet **out);
+DFGPU_API void dfgpu_parquet_close(dfgpu_parquet *file);
+DFGPU_API dfgpu_status dfgpu_parquet_set_option(dfgpu_parquet *file, const char *key, int64_t value);
+DFGPU_API int64_t dfgpu_parquet_num_rows(const dfgpu_parquet *file);
+DFGPU_API int32_t dfgpu_parquet_num_row_groups(const dfgpu_parquet *file);
+DFGPU_API int32_t dfgpu_parquet_num_columns(const dfgpu_parquet *file);              /* leaf columns == column chunks per row group */
+DFGPU_API int64_t dfgpu_parquet_row_group_rows(const dfgpu_parquet *file, int32_t row_group);
+DFGPU_API const char *dfgpu_parquet_column_name(const dfgpu_parquet *file, int32_t column);
+/* type: DFGPU_* of the column as read (DFGPU_DICTIONARY for Utf8 under "utf8_dictionary"; 0 = unsupported); value_type: the logical type */
+DFGPU_API dfgpu_status dfgpu_parquet_column_type(const dfgpu_parquet *file, int32_t column, int32_t *type, int32_t *value_type, int32_t *precision, int32_t *scale, int32_t *nullable);
+/* Row-group statistics of an integer / date column for pruning (≙ parquet/row_groups.rs: prune_row_groups_by_statistics): has_min_max = 0 when the
+ * chunk carries none (or the column's order is not the physical one); null_count -1 = unknown */
+DFGPU_API dfgpu_status dfgpu_parquet_column_stats(const dfgpu_parquet *file, int32_t row_group, int32_t column, int64_t *min_value, int64_t *max_value, int64_t *null_count, int32_t *has_min_max);
+DFGPU_API int64_t dfgpu_parquet_column_chunk_bytes(const dfgpu_parquet *file, int32_t row_group, int32_t column, int32_t uncompressed);
+/* Decode `ncols` columns (leaf indices) of row groups [first_row_group, first_row_group + num_row_groups) into one array per column, rows of
+ * consecutive row groups back to back.  A column without NULLs in these row groups comes without a validity bitmap. */
+DFGPU_API dfgpu_status dfgpu_parquet_read(dfgpu_ctx *ctx, dfgpu_parquet *file, int32_t first_row_group, int32_t num_row_groups, const int32_t *columns, int32_t ncols, dfgpu_array **out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,14 @@ DFGPU_API dfgpu_status dfgpu_plan_memory(const dfgpu_batch *const *batches, cons
 /* Replaces the batches of a MemoryExec in place (same schema): the input slot of a plan that is built once and executed many times
  * -- e.g. the segment above an exchange, whose input is whatever the collective delivered in this execution. */
 DFGPU_API dfgpu_status dfgpu_plan_memory_replace(dfgpu_plan *memory_exec, const dfgpu_batch *const *batches, const int32_t *partition_sizes, int32_t npartitions);
+/* ParquetExec (core/src/datasource/physical_plan/parquet/mod.rs:78): scan of one open file (include/dfgpu.h dfgpu_parquet_*; it must stay open while
+ * the plan lives).  columns = leaf indices (the projection); the file's row groups are dealt to `npartitions` output partitions in contiguous runs;
+ * every batch holds `row_groups_per_batch` row groups.  dfgpu_plan_parquet_prune: skip row groups whose statistics of an integer / date column lie
+ * outside [min_value, max_value] (≙ parquet/row_groups.rs; conservative -- keep the FilterExec); dfgpu_plan_parquet_pruned = row groups skipped so far
+ * (≙ ParquetFileMetrics::row_groups_pruned, parquet/metrics.rs). */
+DFGPU_API dfgpu_status dfgpu_plan_parquet(dfgpu_parquet *file, const int32_t *columns, int32_t ncols, int32_t npartitions, int32_t row_groups_per_batch, dfgpu_plan **out);
+DFGPU_API dfgpu_status dfgpu_plan_parquet_prune(dfgpu_plan *parquet_exec, int32_t column, int64_t min_value, int64_t max_value);
+DFGPU_API int64_t dfgpu_plan_parquet_pruned(const dfgpu_plan *parquet_exec);
 DFGPU_API dfgpu_status dfgpu_plan_filter(const dfgpu_expr *predicate, const dfgpu_plan *input, dfgpu_plan **out);
 DFGPU_API dfgpu_status dfgpu_plan_projection(const dfgpu_expr *const *exprs, const char *const *names, int32_t n, const dfgpu_plan *input, dfgpu_plan **out);
 DFGPU_API dfgpu_status dfgpu_plan_coalesce_batches(const dfgpu_plan *input, int64_t target_batch_size, dfgpu_plan **out);
