@@ -351,6 +351,60 @@ def run(args, ctx=None, emit=True):
         del price, disc, sdate, batch, plan
         torch.cuda.empty_cache()
 
+    # ------------------------------------------------------------------ ParquetExec: lineitem-shaped file (written by pyarrow here) -> columns in HBM
+    if not want or any("parquet" in w for w in want):
+        import os
+        import tempfile
+        import numpy as np
+        import pyarrow.parquet as pq
+        from dfgpu.parquet import ParquetFile
+        nr = int(min(12_000_000, 120_000 * args.sf)) or 1000
+        rng = np.random.default_rng(11)
+
+        def dec(lo, hi):
+            v = rng.integers(lo, hi, nr).astype(np.int64)
+            buf = np.empty((nr, 2), dtype=np.int64); buf[:, 0] = v; buf[:, 1] = v >> 63
+            return pa.Array.from_buffers(pa.decimal128(15, 2), nr, [None, pa.py_buffer(buf.tobytes())])
+        pick = lambda words: pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, len(words), nr).astype(np.int32)), pa.array(words)).cast(pa.string())
+        table = pa.table({"l_orderkey": pa.array(np.sort(rng.integers(0, nr // 4 * 32, nr)).astype(np.int64)), "l_quantity": dec(100, 5001), "l_extendedprice": dec(90000, 10494951),
+                          "l_discount": dec(0, 11), "l_shipdate": pa.array(rng.integers(8035, 10560, nr).astype(np.int32), type=pa.date32()),
+                          "l_returnflag": pick(["A", "N", "R"]), "l_linestatus": pick(["F", "O"]), "l_shipmode": pick(["AIR", "FOB", "MAIL", "RAIL", "REG AIR", "SHIP", "TRUCK"])})
+        decoded = nr * (8 + 3 * 16 + 4 + 3 * 4)
+        for label, kw in (("snappy_dict", dict(compression="snappy", use_dictionary=True)), ("plain", dict(compression="none", use_dictionary=False))):
+            name = "parquet_scan_" + label
+            if want and not any(w in name for w in want):
+                continue
+            path = os.path.join(tempfile.gettempdir(), f"dfgpu_bench_{os.getpid()}_{label}.parquet")
+            pq.write_table(table, path, row_group_size=1 << 20, **kw)
+            fbytes = os.path.getsize(path)
+            try:
+                f = ParquetFile(ctx, path=path, stage_on_device=True)
+
+                def step():
+                    cols = f.read()
+                    ctx.synchronize()
+                    return len(cols[0])
+                for _ in range(max(args.warmup, 1)):
+                    step()
+                ctx.profile_enable(True); ctx.profile_read(); step(); pr = ctx.profile_read(); ctx.profile_enable(False)
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    rows = step()
+                dt = (time.perf_counter() - t0) / args.steps
+                kern = {k: round(v[1], 3) for k, v in sorted(pr.items(), key=lambda kv: -kv[1][1]) if not k.startswith("sync:")}
+                syncs = sum(v[0] for k, v in pr.items() if k.startswith("sync:"))
+                f.close()
+                fh = ParquetFile(ctx, path=path, stage_on_device=False)       # the same read with the file image in host memory: column chunks cross PCIe first
+                fh.read(); ctx.synchronize(); t0 = time.perf_counter(); fh.read(); ctx.synchronize(); dth = time.perf_counter() - t0
+                fh.close()
+            finally:
+                os.unlink(path)
+            assert rows == nr
+            report(name, dt, nr, rows, decoded // nr, kern, syncs, {"file_bytes": fbytes, "decoded_bytes": decoded, "row_groups": (nr + (1 << 20) - 1) >> 20, "decoded_GBps": round(decoded / dt / 1e9, 1),
+                                                                    "file_GBps": round(fbytes / dt / 1e9, 1), "from_host_image_ms": round(dth * 1e3, 1), "from_host_image_decoded_GBps": round(decoded / dth / 1e9, 2),
+                                                                    "columns": "Int64 key, 3 x Decimal128(15,2) (FIXED_LEN_BYTE_ARRAY), Date32, 3 x Utf8 kept as Dictionary(Int32, Utf8)"})
+        del table
+
     # ------------------------------------------------------------------ ClickBench-style string-key group-by (100 M rows at sf 100)
     nrows = int(1_000_000 * args.sf)
     for card, zipf in ((1000, False), (1_000_000, False), (20_000_000, False), (1_000_000, True)):

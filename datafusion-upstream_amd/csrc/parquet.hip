@@ -461,21 +461,33 @@ __global__ void __launch_bounds__(BLOCK) k_pq_bytes_to_bits(const uint8_t* in, i
   if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) bits[i >> 6] = m;
 }
 
-// ---- Snappy (raw format): one wave per page
-constexpr int SN_RING = 65536, SN_WIN = 4096, SN_FLUSH = 16384;
+// ---- Snappy (raw format): one wave per page.  The element chain is inherently serial (a tag's position follows from the tag before it, a copy may
+// read what the element before it wrote), so the loop keeps that chain short: tags are decoded on the scalar unit from an LDS window of the input, the
+// next tag's bytes are requested before the current element's bytes move, output goes to an LDS ring that holds the last 64 KB (every reference of
+// the standard 64 KB-block compressor resolves there) and is flushed to HBM in 16-byte stores.  One wave per workgroup: LDS operations of a wave
+// execute in order, no barrier is needed between an element's write and the next element's read.
+constexpr int SN_RING = 65536, SN_WIN = 8192, SN_FLUSH = 16384;
 struct SnJob { const uint8_t* src; uint8_t* dst; uint32_t csize, usize; int32_t raw; int32_t pad; };
+
+__device__ inline void sn_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__device__ inline uint64_t sn_peek(const uint32_t* win, uint32_t rel) { uint32_t a = rel >> 2, sh = (rel & 3) * 8; return ((uint64_t)win[a] | ((uint64_t)win[a + 1] << 32)) >> sh; }   // >= 5 bytes at win + rel
 
 __global__ void __launch_bounds__(64) k_pq_snappy(const SnJob* __restrict__ jobs, uint32_t* flags) {
   __shared__ __attribute__((aligned(16))) uint8_t ring[SN_RING];
-  __shared__ uint8_t win[SN_WIN + 8];
+  __shared__ __attribute__((aligned(16))) uint32_t win[SN_WIN / 4 + 4];
   const SnJob jb = jobs[blockIdx.x]; const uint32_t lane = threadIdx.x;
   if (jb.raw) { for (uint32_t i = lane; i < jb.usize; i += 64) jb.dst[i] = jb.src[i]; return; }
   uint32_t pin = 0, ulen = 0; { int sh = 0; bool ok = false; while (pin < jb.csize && sh < 35) { uint8_t b = jb.src[pin++]; ulen |= (uint32_t)(b & 0x7f) << sh; sh += 7; if (!(b & 0x80)) { ok = true; break; } } if (!ok) ulen = 0xFFFFFFFFu; }
   if (ulen != jb.usize) { if (lane == 0) atomicOr(flags, DFGPU_FLAG_OOB); return; }
-  uint32_t pout = 0, flushed = 0, wb = 0xFFFFFFFFu, wl = 0; bool bad = false;
+  // every cursor below is wave-uniform; sn_u() pins it to the scalar unit, so the element loop branches on SCC instead of masking lanes
+#define sn_u(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+  pin = sn_u(pin);
+  const uint32_t csize = sn_u(jb.csize), usize = sn_u(jb.usize);
+  uint32_t pout = 0, flushed = 0, wb = 0, wl = 0; bool bad = false;
   const bool dst16 = ((uintptr_t)jb.dst & 15) == 0;
+  const uint8_t* winb = (const uint8_t*)win;
   auto flush = [&](uint32_t upto) {            // ring -> dst for [flushed, upto)
-    uint32_t a = flushed; flushed = upto;
+    uint32_t a = flushed; flushed = sn_u(upto);
     if (!dst16) { for (uint32_t o = a + lane; o < upto; o += 64) jb.dst[o] = ring[o & (SN_RING - 1)]; return; }
     uint32_t head = min(upto, (a + 15u) & ~15u);
     for (uint32_t o = a + lane; o < head; o += 64) jb.dst[o] = ring[o & (SN_RING - 1)];
@@ -483,54 +495,70 @@ __global__ void __launch_bounds__(64) k_pq_snappy(const SnJob* __restrict__ jobs
     for (uint32_t i = lane; i < n16; i += 64) { uint32_t o = head + (i << 4); *(uint4*)(jb.dst + o) = *(const uint4*)(ring + (o & (SN_RING - 1))); }
     for (uint32_t o = head + (n16 << 4) + lane; o < upto; o += 64) jb.dst[o] = ring[o & (SN_RING - 1)];
   };
-  while (pin < jb.csize && pout < jb.usize) {
-    if (!(pin >= wb && pin + 5 <= wb + wl) && !(pin >= wb && wb + wl == jb.csize)) {
-      __syncthreads();
-      wb = pin; wl = min((uint32_t)SN_WIN, jb.csize - pin);
-      for (uint32_t i = lane; i < wl; i += 64) win[i] = jb.src[wb + i];
-      for (uint32_t i = wl + lane; i < wl + 8 && i < SN_WIN + 8; i += 64) win[i] = 0;
-      __syncthreads();
-    }
-    const uint8_t* w = win + (pin - wb);
-    uint32_t tag = __builtin_amdgcn_readfirstlane((uint32_t)w[0] | ((uint32_t)w[1] << 8) | ((uint32_t)w[2] << 16) | ((uint32_t)w[3] << 24));
-    uint32_t t4 = __builtin_amdgcn_readfirstlane((uint32_t)w[4]);
-    uint32_t kind = tag & 3, b0 = tag & 0xff;
+  auto reload = [&](uint32_t at) {             // window = input [at, at + SN_WIN), two zero words behind it
+    sn_order();
+    wb = sn_u(at); wl = sn_u(min((uint32_t)SN_WIN, csize - at));
+    uint32_t nw = (wl + 3) >> 2;
+    for (uint32_t i = lane; i < nw; i += 64) win[i] = ld32u(jb.src + wb + 4 * i);
+    if (lane < 2) win[nw + lane] = 0;
+    sn_order();
+  };
+  reload(pin);
+  uint64_t tv = sn_peek(win, pin - wb);
+  while (pin < csize && pout < usize) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)tv), hi = __builtin_amdgcn_readfirstlane((uint32_t)(tv >> 32));
+    const uint32_t kind = lo & 3, b0 = lo & 0xff;
+    uint32_t len, off = 0, hdr;
     if (kind == 0) {
-      uint32_t len = (b0 >> 2) + 1, hdr = 1;
-      if (len > 60) { uint32_t nb = len - 60; uint64_t ext = ((uint64_t)(tag >> 8) | ((uint64_t)t4 << 24)); len = (uint32_t)(ext & (nb == 4 ? 0xFFFFFFFFull : ((1ull << (8 * nb)) - 1))) + 1; hdr = 1 + nb; }
-      pin += hdr;
-      if (len > jb.usize - pout || len > jb.csize - pin) { bad = true; break; }
-      while (len) {
-        uint32_t piece = min(len, (uint32_t)SN_FLUSH);
-        if (pin >= wb && pin + piece <= wb + wl) { for (uint32_t i = lane; i < piece; i += 64) ring[(pout + i) & (SN_RING - 1)] = win[pin - wb + i]; }
-        else { for (uint32_t i = lane; i < piece; i += 64) ring[(pout + i) & (SN_RING - 1)] = jb.src[pin + i]; }
-        pout += piece; pin += piece; len -= piece;
-        __syncthreads();
-        if (pout - flushed >= (uint32_t)SN_FLUSH) { flush(pout & ~15u); __syncthreads(); }
+      len = (b0 >> 2) + 1; hdr = 1;
+      if (len > 60) { uint32_t nb = len - 60; uint32_t ext = (lo >> 8) | (hi << 24); len = (nb == 4 ? ext : (ext & ((1u << (8 * nb)) - 1u))) + 1; hdr = 1 + nb; if (len == 0) { bad = true; break; } }
+    } else if (kind == 1) { len = 4 + ((b0 >> 2) & 7); off = ((b0 >> 5) << 8) | ((lo >> 8) & 0xff); hdr = 2; }
+    else if (kind == 2) { len = 1 + (b0 >> 2); off = (lo >> 8) & 0xffff; hdr = 3; }
+    else { len = 1 + (b0 >> 2); off = (lo >> 8) | (hi << 24); hdr = 5; }
+    const uint32_t body = kind == 0 ? len : 0;
+    if (len > usize - pout || hdr > csize - pin || body > csize - pin - hdr || (kind != 0 && (off == 0 || off > pout))) { bad = true; break; }
+    const uint32_t next = pin + hdr + body;
+    const bool inwin = next + 8 <= wb + wl || wb + wl == csize;
+    if (!inwin || body > 64) {                 // a long literal, or the window ends: move the literal from HBM, refill the window at the next tag
+      if (kind == 0) {
+        uint32_t from = pin + hdr, left = len;
+        while (left) {
+          uint32_t piece = min(left, (uint32_t)SN_FLUSH);
+          for (uint32_t i = lane; i < piece; i += 64) ring[(pout + i) & (SN_RING - 1)] = jb.src[from + i];
+          pout = sn_u(pout + piece); from = sn_u(from + piece); left = sn_u(left - piece);
+          sn_order();
+          if (pout - flushed >= (uint32_t)SN_FLUSH) { flush(pout & ~15u); sn_order(); }
+        }
+        pin = sn_u(next);
+        if (pin < csize) { reload(pin); tv = sn_peek(win, 0); }
+        continue;
       }
+      reload(pin); tv = sn_peek(win, 0);        // a copy tag whose successor lies beyond the window: same tag again, window now starts at it
+      if (!(next + 8 <= wb + wl || wb + wl == csize)) { bad = true; break; }
       continue;
     }
-    uint32_t len, off;
-    if (kind == 1) { len = 4 + ((b0 >> 2) & 7); off = ((b0 >> 5) << 8) | ((tag >> 8) & 0xff); pin += 2; }
-    else if (kind == 2) { len = 1 + (b0 >> 2); off = (tag >> 8) & 0xffff; pin += 3; }
-    else { len = 1 + (b0 >> 2); off = (tag >> 8) | (t4 << 24); pin += 5; }
-    if (off == 0 || off > pout || len > jb.usize - pout || pin > jb.csize) { bad = true; break; }
-    uint32_t rel = off >= len ? lane : lane % off;
-    uint8_t b = 0;
-    if (off <= (uint32_t)(SN_RING - 64)) { if (lane < len) b = ring[(pout - off + rel) & (SN_RING - 1)]; }
-    else {                                     // a reference beyond the ring: read what was flushed
-      flush(pout); __syncthreads(); __threadfence_block();
-      if (lane < len) b = jb.dst[pout - off + rel];
+    const uint64_t tnext = sn_peek(win, next - wb);           // requested before this element's bytes move
+    if (kind == 0) { if (lane < len) ring[(pout + lane) & (SN_RING - 1)] = winb[pin + hdr - wb + lane]; }
+    else if (off <= (uint32_t)(SN_RING - 64)) {
+      uint32_t rel = lane;
+      if (off < len) { uint32_t q = (uint32_t)((float)lane * __frcp_rn((float)off)); int32_t r = (int32_t)lane - (int32_t)(q * off); rel = r < 0 ? (uint32_t)(r + (int32_t)off) : ((uint32_t)r >= off ? (uint32_t)r - off : (uint32_t)r); }
+      uint8_t b = 0;
+      if (lane < len) b = ring[(pout - off + rel) & (SN_RING - 1)];
+      if (lane < len) ring[(pout + lane) & (SN_RING - 1)] = b;
+    } else {                                   // a reference beyond the ring: read what was flushed
+      flush(pout); sn_order(); __threadfence_block();
+      uint8_t b = 0;
+      if (lane < len) b = jb.dst[pout - off + (off >= len ? lane : lane % off)];
+      if (lane < len) ring[(pout + lane) & (SN_RING - 1)] = b;
     }
-    __syncthreads();
-    if (lane < len) ring[(pout + lane) & (SN_RING - 1)] = b;
-    pout += len;
-    __syncthreads();
-    if (pout - flushed >= (uint32_t)SN_FLUSH) { flush(pout & ~15u); __syncthreads(); }
+    pout = sn_u(pout + len); pin = sn_u(next); tv = tnext;
+    sn_order();
+    if (pout - flushed >= (uint32_t)SN_FLUSH) { flush(pout & ~15u); sn_order(); }
   }
-  if (bad || pout != jb.usize) { if (lane == 0) atomicOr(flags, DFGPU_FLAG_OOB); return; }
-  __syncthreads();
+  if (bad || pout != usize) { if (lane == 0) atomicOr(flags, DFGPU_FLAG_OOB); return; }
+  sn_order();
   flush(pout);
+#undef sn_u
 }
 
 // ================================================================================ host orchestration
@@ -589,16 +617,23 @@ static BufferPtr bytes_to_validity(dfgpu_ctx* ctx, const BufferPtr& vbytes, int6
   KERNEL_CHECK(); return v;
 }
 
-static dfgpu_array* read_column(dfgpu_ctx* ctx, dfgpu_parquet* f, int leaf_idx, int rg0, int nrg) {
+// One column of one read: the host's walk over the page headers (plan_column; stages the chunks, lists the Snappy jobs of ALL columns so that one
+// launch decompresses every page of the read) and the decode launches (decode_column).
+struct ColumnRead {
+  int leaf_idx = 0; int64_t total_rows = 0; std::vector<PqPage> pages, dict_str_pages; std::vector<BufferPtr> keep;
+  bool any_levels = false, all_dict = true; int32_t dict_total = 0; int wp = 0;
+};
+static void plan_column(dfgpu_ctx* ctx, dfgpu_parquet* f, int leaf_idx, int rg0, int nrg, ColumnRead& cr, std::vector<SnJob>& jobs) {
   const Leaf& leaf = f->leaves[(size_t)leaf_idx];
   if (!leaf.arrow) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: Parquet column '%s': %s", leaf.name.c_str(), leaf.why.c_str());
   const bool is_str = leaf.arrow == DFGPU_UTF8;
   const int max_def = leaf.rep == 1 ? 1 : 0;             // OPTIONAL
   int64_t total_rows = 0; for (int g = rg0; g < rg0 + nrg; g++) total_rows += f->rgs[(size_t)g].rows;
 
-  std::vector<PqPage> pages, dict_str_pages; std::vector<SnJob> jobs; std::vector<BufferPtr> keep;
-  bool any_levels = false, all_dict = true; int64_t row = 0; int32_t dict_total = 0;
-  int wp = leaf.phys == PT_INT32 || leaf.phys == PT_FLOAT ? 4 : leaf.phys == PT_INT64 || leaf.phys == PT_DOUBLE ? 8 : leaf.phys == PT_FLBA ? leaf.type_len : 0;
+  std::vector<PqPage>& pages = cr.pages; std::vector<PqPage>& dict_str_pages = cr.dict_str_pages; std::vector<BufferPtr>& keep = cr.keep;
+  bool& any_levels = cr.any_levels; bool& all_dict = cr.all_dict; int64_t row = 0; int32_t& dict_total = cr.dict_total;
+  cr.leaf_idx = leaf_idx; cr.total_rows = total_rows;
+  int& wp = cr.wp; wp = leaf.phys == PT_INT32 || leaf.phys == PT_FLOAT ? 4 : leaf.phys == PT_INT64 || leaf.phys == PT_DOUBLE ? 8 : leaf.phys == PT_FLBA ? leaf.type_len : 0;
   for (int g = rg0; g < rg0 + nrg; g++) {
     const RowGroup& rg = f->rgs[(size_t)g]; const Chunk& ch = rg.cols[(size_t)leaf_idx];
     if (ch.codec != CODEC_NONE && ch.codec != CODEC_SNAPPY) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: Parquet compression codec %d of column '%s' (UNCOMPRESSED and SNAPPY are decoded on the device)", ch.codec, leaf.name.c_str());
@@ -658,11 +693,11 @@ static dfgpu_array* read_column(dfgpu_ctx* ctx, dfgpu_parquet* f, int leaf_idx, 
     }
   }
   if (row != total_rows) fail(DFGPU_EXECUTION, "Parquet error: pages of '%s' hold %lld values for %lld rows", leaf.name.c_str(), (long long)row, (long long)total_rows);
-  if (!jobs.empty()) {
-    BufferPtr dj = upload(ctx, jobs); KernelTimer kt(ctx, "pq_snappy");
-    hipLaunchKernelGGL(k_pq_snappy, dim3((unsigned)jobs.size()), dim3(64), 0, ctx->stream, (const SnJob*)dj->ptr, ctx->d_flags); KERNEL_CHECK();
-  }
-
+}
+static dfgpu_array* decode_column(dfgpu_ctx* ctx, dfgpu_parquet* f, ColumnRead& cr) {
+  const Leaf& leaf = f->leaves[(size_t)cr.leaf_idx]; const bool is_str = leaf.arrow == DFGPU_UTF8;
+  const int64_t total_rows = cr.total_rows; std::vector<PqPage>& pages = cr.pages; std::vector<PqPage>& dict_str_pages = cr.dict_str_pages;
+  const bool any_levels = cr.any_levels, all_dict = cr.all_dict; const int32_t dict_total = cr.dict_total; const int wp = cr.wp;
   BufferPtr vbytes; if (any_levels) vbytes = alloc_buffer(ctx, (size_t)total_rows + 64);
   PqCol col{}; col.vbytes = vbytes ? (uint8_t*)vbytes->ptr : nullptr; col.wp = wp;
   ArrayHolder out;
@@ -714,9 +749,6 @@ static dfgpu_array* read_column(dfgpu_ctx* ctx, dfgpu_parquet* f, int leaf_idx, 
       } else out.a = a.release();
     }
   }
-  // the staged / decompressed bytes must outlive the kernels: they are stream ordered, and the caching allocator hands freed blocks only to later
-  // work of the same stream
-  check_flags(ctx, "Parquet page decode (malformed page, run or dictionary index)");
   return out.release();
 }
 
@@ -797,11 +829,18 @@ dfgpu_status dfgpu_parquet_read(dfgpu_ctx* ctx, dfgpu_parquet* f, int32_t first_
     if (!f || !out || (ncols > 0 && !columns)) fail(DFGPU_INVALID_ARGUMENT, "parquet_read: null argument");
     if (first_row_group < 0 || num_row_groups < 0 || (size_t)first_row_group + (size_t)num_row_groups > f->rgs.size()) fail(DFGPU_INVALID_ARGUMENT, "parquet_read: row groups [%d, %d) of %zu", first_row_group, first_row_group + num_row_groups, f->rgs.size());
     HIP_CHECK(hipSetDevice(ctx->device));
-    std::vector<ArrayHolder> res;
+    std::vector<ArrayHolder> res; std::vector<ColumnRead> reads((size_t)ncols); std::vector<SnJob> jobs;
     for (int32_t i = 0; i < ncols; i++) {
       if (columns[i] < 0 || (size_t)columns[i] >= f->leaves.size()) fail(DFGPU_INVALID_ARGUMENT, "parquet_read: column %d of %zu", columns[i], f->leaves.size());
-      res.emplace_back(read_column(ctx, f, columns[i], first_row_group, num_row_groups));
+      plan_column(ctx, f, columns[i], first_row_group, num_row_groups, reads[(size_t)i], jobs);
     }
+    if (!jobs.empty()) {                          // every compressed page of the read in one launch: the pages are the parallelism
+      BufferPtr dj = upload(ctx, jobs); KernelTimer kt(ctx, "pq_snappy");
+      hipLaunchKernelGGL(k_pq_snappy, dim3((unsigned)jobs.size()), dim3(64), 0, ctx->stream, (const SnJob*)dj->ptr, ctx->d_flags); KERNEL_CHECK();
+    }
+    for (int32_t i = 0; i < ncols; i++) res.emplace_back(decode_column(ctx, f, reads[(size_t)i]));
+    // the staged / decompressed bytes (reads[].keep) outlive the kernels: frees are stream ordered through the caching allocator
+    check_flags(ctx, "Parquet page decode (malformed page, run or dictionary index)");
     for (int32_t i = 0; i < ncols; i++) out[i] = res[(size_t)i].release();
   });
 }
