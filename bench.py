@@ -108,6 +108,7 @@ def parse_args():
     ap.add_argument("--no-workloads", action="store_true", help="N = 1: skip the nested other plan shapes (bench_workloads.py)")
     ap.add_argument("--workloads", default="q1_decimal,q1_float64,q5,q18,hash_join,groupby_int64,sort,partition,clickbench_uniform_1000000,clickbench_zipf_1000000",
                     help="N = 1: which plan shapes of bench_workloads.py to nest under \"workloads\"")
+    ap.add_argument("--native-exchange", action="store_true", help="N > 1 workloads: ShuffleExec through the C entry point dfgpu_exchange (RCCL inside libdfgpu.so) instead of torch.distributed collectives")
     ap.add_argument("--plan", choices=["colocated", "broadcast", "shuffle"], default="shuffle",
                     help="N > 1: colocated = customer build side broadcast, orders-lineitem join and aggregation partition-local (the shards are co-partitioned on "
                          "the order key, as TPC-H files are); broadcast = both build sides all-gathered (CollectLeft), partial aggregates shuffled; "
@@ -280,7 +281,7 @@ def main():
                     "note": "logical bytes of every referenced column / step time; NOT HBM traffic (filtered rows' payload columns are never read)"}
 
     # ---- N = 1: result check at full scale, the general (hash) paths of the same query, the other target plan shapes
-    result_check = general = workloads = other_plans = None
+    result_check = general = workloads = other_plans = dist_workloads = None
     if world == 1:
         got = tpch.q3_checksum_result(last_out[0] or [])
         want = tpch.q3_checksum_torch(tensors)
@@ -339,6 +340,64 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             other_plans[name] = {"ms_per_step": round(float(t.item()) / args.steps * 1e3, 3), "rows_per_s": round(rows_total * args.steps / float(t.item()), 1)}
 
+        # BASELINE configs 4 and 5 at N > 1: TPC-H Q5 as the fully partitioned plan (hash repartition + all-to-all under every join and the aggregate) and the
+        # ClickBench Q28 shape (partial states of a high-cardinality dictionary-key group-by shuffled on the key)
+        if not args.no_workloads:
+            from dfgpu import dist_workloads as dw
+            del tables, staged, st2
+            torch.cuda.empty_cache()
+            dev = "cuda" if args.backend == "nccl" else "cpu"
+            exchange.TIMING = True
+            dist_workloads = {}
+
+            def run_dist(name, build, outputs, sort_keys, fetch, rows_local, checksum):
+                def stepd():
+                    plan = build()
+                    with ctx.deferred_flags():
+                        local = [b for b in plan.execute(0, tc)]
+                        mine = ops.concat_batches(local[0].schema, local) if local else None
+                        gathered = exchange.gather_batches(ctx, None, mine, 0, names=outputs)
+                    res = []
+                    if rank == 0 and gathered.num_rows:
+                        res = [b for b in ops.SortExec(sort_keys, ops.MemoryExec([[gathered]], gathered.schema), fetch=fetch).execute(0, tc)]
+                    ctx.synchronize()
+                    return plan, res
+                for _ in range(max(1, args.warmup)):
+                    stepd()
+                barrier(); t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    plan, res = stepd()
+                barrier(); el = time.perf_counter() - t1
+                tt = torch.tensor([el], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); el = float(tt.item())
+                nodes = dw.shuffle_nodes(plan)
+                sent = sum(nd.bytes_sent for nd in nodes); ex_ms = sum(nd.exchange_ms() for nd in nodes)
+                agg = torch.tensor([rows_local, sent], dtype=torch.int64, device=dev); dist.all_reduce(agg)
+                mx = torch.tensor([ex_ms], dtype=torch.float64, device=dev); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+                rows_all, sent_all = int(agg[0].item()), int(agg[1].item())
+                ms = el / args.steps * 1e3
+                dist_workloads[name] = {"ms_per_step": round(ms, 3), "input_rows": rows_all, "rows_per_s": round(rows_all / (ms * 1e-3), 1), "result_rows": sum(b.num_rows for b in res),
+                                        "exchanges_per_step": len(nodes), "all_to_all_bytes_per_step": sent_all, "all_to_all_bytes_per_rank": sent_all // world,
+                                        "exchange_ms_per_step_max_rank": round(float(mx.item()), 3),
+                                        "GBps_per_link": round(sent_all / world / max(1, world - 1) / max(1e-9, float(mx.item()) * 1e-3) / 1e9, 2),
+                                        "GBps_per_link_note": "bytes one rank sends / (world - 1) peers / the time its exchanges took, partition gathers and waiting for peers included (last timed step)",
+                                        "result_checksum": checksum(res) if rank == 0 else None}
+
+            tt5 = dw.q5_tensors(args.sf, rank, world)
+            t5 = dw.q5_tables(ctx, tt5, rank)
+            rows5 = sum(t5[k].num_rows for k in ("customer", "orders", "lineitem", "supplier", "nation", "region"))
+            q5_sum = lambda res: [[r["n_name"], str(r["revenue"])] for b in res for r in b.to_arrow().to_pylist()]
+            run_dist("q5", lambda: dw.q5_plan(t5, batch_size=8192, native=args.native_exchange), dw.Q5_OUTPUT, [ops.PhysicalSortExpr(C_("revenue", 1), True, True)], None, rows5, q5_sum)
+            del tt5, t5
+            torch.cuda.empty_cache()
+            n_hits, card = int(1_000_000 * args.sf), max(10, int(1_000_000 * min(1.0, args.sf / 100.0)))
+            ids, length, wcol = dw.clickbench_tensors(n_hits, card, rank, world)
+            hits = dw.clickbench_batch(ctx, ids, length, wcol, card)
+            cb_sum = lambda res: [[r["k"], r["c"], r["m"]] for b in res for r in b.to_arrow().to_pylist()][:5]
+            run_dist(f"clickbench_uniform_{card}", lambda: dw.clickbench_plan(hits, batch_size=8192), dw.CLICKBENCH_OUTPUT,
+                     [ops.PhysicalSortExpr(C_("l", 1), True, True), ops.PhysicalSortExpr(C_("k", 0), False, False)], 25, ids.numel(), cb_sum)
+            del ids, length, wcol, hits
+            exchange.TIMING = False
+
     # ---- CPU baseline: the oracle's restatement of the same plan on a bounded sample (rank 0, N = 1 only)
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_sf > 0:
@@ -388,6 +447,8 @@ def main():
                 line["workloads"] = workloads
         else:
             line["plans"] = other_plans
+            if dist_workloads:
+                line["workloads"] = dist_workloads
             line["config"]["plan"] = args.plan
         print(json.dumps(line), flush=True)
     if world > 1:

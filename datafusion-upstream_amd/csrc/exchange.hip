@@ -99,7 +99,7 @@ dfgpu_status dfgpu_exchange(dfgpu_ctx* ctx, dfgpu_comm* comm, const dfgpu_array*
     if (have) {
       for (int32_t c = 0; c < ncols; c++) {
         const dfgpu_array* a = cols[c];
-        if (!a || a->length != n) fail(DFGPU_INVALID_ARGUMENT, "exchange: column %d is missing or differs in length from the keys", c);
+        if (!a || a->length != n) fail(DFGPU_INVALID_ARGUMENT, "exchange: column %d is missing or differs in length from the keys (%lld rows, type %d; keys hold %lld)", c, a ? (long long)a->length : -1ll, a ? a->type : 0, (long long)n);
         if (a->type == DFGPU_DICTIONARY || a->type == DFGPU_UTF8 || a->type == DFGPU_BOOL || !type_width(a->type))
           fail(DFGPU_NOT_IMPLEMENTED, "exchange of column %d (type %d): fixed-width columns only; cast dictionary / Utf8 columns or use the host-side exchange", c, a->type);
       }

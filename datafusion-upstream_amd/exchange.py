@@ -399,6 +399,9 @@ def gather_batches(ctx, schema, batch, dst: int = 0, group=None, names: Optional
     return exchange_batches(ctx, schema, parts, group, names=names)
 
 
+TIMING = False          # bench.py: bracket every ShuffleExec's collectives with events on torch's current stream (the ctx stream in the bench)
+
+
 class ShuffleExec:
     """RepartitionExec(Partitioning::Hash(exprs, world_size)) across GPUs: this rank's input rows are
     hash-partitioned on device by the C++ RepartitionExec (dfgpu_hash_partition, same create_hashes on every rank),
@@ -419,6 +422,7 @@ class ShuffleExec:
         self.bytes_sent = 0
         self.native = native and all(isinstance(e, pp.Column) for e in self.exprs)
         self._comm = None
+        self._events = []           # (start, end) torch events around the collectives while TIMING is on (bench: all-to-all time and GB/s per link)
 
     def schema(self):
         return self.input.schema()
@@ -433,15 +437,17 @@ class ShuffleExec:
         pp = self._pp
         if self._comm is None or self._comm.ctx is not context.ctx:
             self._comm = Comm(context.ctx, self.group)
-        names = self.input.schema().names()
         local = []
         with context.ctx.deferred_flags():
             for p in range(self.input.output_partitioning().partition_count()):
                 local += [b for b in self.input.execute(p, context) if b.num_rows]
+            names = self.input.schema().names()        # after execute: the C++ node exists, its schema is the exact one (a rank without rows needs the column count)
             mine = pp.concat_batches(None, local) if local else None
             cols = mine.columns if mine is not None else None
             keys = [cols[e.index] for e in self.exprs] if cols is not None else None
+            ev = self._mark()
             got, sent, _ = self._comm.exchange(keys, cols, len(names), None)
+            self._mark(ev)
         if cols is not None:
             row_bytes = sum(_WIDTH.get(c.describe().type, 0) for c in cols)
             self.bytes_sent += row_bytes * sum(n for d, n in enumerate(sent) if d != self.rank)
@@ -464,9 +470,25 @@ class ShuffleExec:
                     if d != self.rank:
                         self.bytes_sent += sum(_WIDTH.get(f.dtype, 0) for f in schema.fields) * m.num_rows
                 merged.append(m)
+            ev = self._mark()
             out = exchange_batches(context.ctx, schema, merged, self.group, names=self.input.schema().names())
+            self._mark(ev)
         if out.num_rows:
             yield out
+
+    def _mark(self, start=None):
+        if not TIMING:
+            return None
+        import torch
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        if start is not None:
+            self._events.append((start, e))
+        return e
+
+    def exchange_ms(self) -> float:
+        """device time between entering and leaving the exchange (partition gathers excluded in the non-native path), after a synchronize"""
+        return sum(a.elapsed_time(b) for a, b in self._events)
 
     def _agree_schema(self, ctx, schema):
         """A rank with no local rows still has to take part in the collectives with the right column list."""
