@@ -546,11 +546,12 @@ struct RepartitionExec : Plan {   // repartition/mod.rs:232-294; all inputs are 
   std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override {
     std::lock_guard<std::mutex> l(mu);
     if (!ran) {
-      outs.assign((size_t)n, {}); int rr = 0;
+      outs.assign((size_t)n, {});
       for (int ip = 0; ip < input->partitions(); ip++) {
         std::vector<Batch> in; drain(input, ip, tc, in);
+        int rr = 0;         // every input partition has its own BatchPartitioner, next_idx starts at 0 (repartition/mod.rs:105-109, :156-160)
         for (auto& b : in) {
-          if (exprs.empty()) { Batch m = materialize(tc, b); if (m.base_rows) outs[(size_t)(rr++ % n)].push_back(std::move(m)); }   // RoundRobinBatch
+          if (exprs.empty()) { outs[(size_t)(rr++ % n)].push_back(materialize(tc, b)); }   // RoundRobinBatch: whole batches in rotation
           else { SpanGuard sp(tc, met.get(), 3); partition_batch(tc, b, exprs, n, outs); }      // repartition_time (repartition/mod.rs:318)
         }
       }

@@ -1,0 +1,115 @@
+"""Writes unit_vectors.json: input / expected vectors of the reference's operator-level unit tests, transcribed BY HAND (data only):
+  binary    physical-expr/src/expressions/binary.rs    plus / minus / multiply / divide / modulus over Int32, dictionary Int32 and dictionary
+                                                       Decimal128 columns (array op array, array op scalar), Kleene AND / OR, the six comparisons and
+                                                       IS [NOT] DISTINCT FROM over Boolean columns with NULLs, Decimal128 comparisons
+  sort      physical-plan/src/sorts/sort.rs            test_in_mem_sort (4 x make_partition(100)), test_sort_metadata
+  repartition physical-plan/src/repartition/mod.rs     RoundRobinBatch batch counts, Hash row conservation
+Mixed-type comparisons of the same tests (Int64 / Float64 column against a Decimal128 literal) go through the planner's coercion and are left out.
+Dictionary operands: arrow-arith unpacks dictionaries before computing, the expected arrays are plain.   Run: python transcribe_unit_vectors.py"""
+import json
+
+B = "datafusion/physical-expr/src/expressions/binary.rs:"
+i32 = lambda v: {"type": "int32", "values": v}
+boo = lambda v: {"type": "bool", "values": v}
+dec = lambda v, p, s: {"type": {"decimal128": [p, s]}, "values": v}
+dct = lambda keys, values: {"dict": {"keys_type": "int8", "keys": keys, "values": values}}
+N = None
+cases = []
+
+
+def case(name, ref, op, l, r, expected, ls=False, rs=False):
+    cases.append({"name": name, "ref": B + ref, "op": op, "left": l, "right": r, "left_scalar": ls, "right_scalar": rs, "expected": expected})
+
+
+# ---- Int32 arithmetic
+case("plus_op", "1247-1263", "+", i32([1, 2, 3, 4, 5]), i32([1, 2, 4, 8, 16]), i32([2, 4, 7, 12, 21]))
+case("minus_op", "1455-1469", "-", i32([1, 2, 4, 8, 16]), i32([1, 2, 3, 4, 5]), i32([0, 0, 1, 4, 11]))
+case("minus_op_negative", "1470-1479", "-", i32([1, 2, 3, 4, 5]), i32([1, 2, 4, 8, 16]), i32([0, 0, -1, -4, -11]))
+case("multiply_op", "1671-1687", "*", i32([4, 8, 16, 32, 64]), i32([2, 4, 8, 16, 32]), i32([8, 32, 128, 512, 2048]))
+case("divide_op", "1877-1893", "/", i32([8, 32, 128, 512, 2048]), i32([2, 4, 8, 16, 32]), i32([4, 8, 16, 32, 64]))
+case("modulus_op", "2095-2111", "%", i32([8, 32, 128, 512, 2048]), i32([2, 4, 7, 14, 32]), i32([0, 0, 2, 8, 0]))
+for name, ref, op, k, exp in (("plus_op_scalar", "1358-1371", "+", 1, [2, 3, 4, 5, 6]), ("minus_op_scalar", "1574-1587", "-", 1, [0, 1, 2, 3, 4]),
+                              ("multiply_op_scalar", "1786-1799", "*", 2, [2, 4, 6, 8, 10]), ("divide_op_scalar", "2004-2017", "/", 2, [0, 1, 1, 2, 2]),
+                              ("modulus_op_scalar", "2212-2225", "%", 2, [1, 0, 1, 0, 1])):
+    case(name, ref, op, i32([1, 2, 3, 4, 5]), i32([k]), i32(exp), rs=True)
+
+# ---- dictionary(Int8, Int32) operands
+DA = dct([0, N, 1, 3, N], i32([1, 2, 3, 4, 5]))
+DB = dct([0, 1, 1, 2, 1], i32([1, 2, 4, 8, 16]))
+case("plus_op_dict", "1266-1296", "+", DA, DB, i32([2, N, 4, 8, N]))
+case("minus_op_dict", "1482-1512", "-", DA, DB, i32([0, N, 0, 0, N]))
+case("multiply_op_dict", "1690-1720", "*", DA, DB, i32([1, N, 4, 16, N]))
+BUILT5 = dct([0, N, 1, 2, 3], i32([1, 2, 5, 0]))          # PrimitiveDictionaryBuilder: append 1, null, 2, 5, 0
+case("divide_op_dict", "1896-1932", "/", BUILT5, DB, i32([1, N, 1, 1, 0]))
+case("modulus_op_dict", "2114-2150", "%", BUILT5, DB, i32([0, N, 0, 1, 0]))
+BUILT4 = dct([0, N, 1, 2], i32([1, 2, 5]))                # append 1, null, 2, 5
+for name, ref, op, k, exp in (("plus_op_dict_scalar", "1374-1405", "+", 1, [2, N, 3, 6]), ("minus_op_dict_scalar", "1590-1621", "-", 1, [0, N, 1, 4]),
+                              ("multiply_op_dict_scalar", "1802-1833", "*", 2, [2, N, 4, 10]), ("divide_op_dict_scalar", "2020-2051", "/", 2, [0, N, 1, 2]),
+                              ("modules_op_dict_scalar", "2228-2259", "%", 2, [1, N, 0, 1])):
+    case(name, ref, op, BUILT4, i32([k]), i32(exp), rs=True)
+
+# ---- dictionary(Int8, Decimal128(10, 0)) operands; value = 123
+V = 123
+DDA = dct([0, 2, N, 3, 0], dec([V, V + 2, V - 1, V + 1], 10, 0))
+DDB = dct([0, N, 3, 2, 2], dec([V + 1, V + 3, V, V + 2], 10, 0))
+case("plus_op_dict_decimal", "1299-1355", "+", DDA, DDB, dec([247, N, N, 247, 246], 11, 0))
+case("minus_op_dict_decimal", "1515-1571", "-", DDA, DDB, dec([-1, N, N, 1, 0], 11, 0))
+case("multiply_op_dict_decimal", "1723-1783", "*", DDA, DDB, dec([15252, N, N, 15252, 15129], 21, 0))
+case("divide_op_dict_decimal", "1935-2001", "/", DDA, DDB, dec([9919, N, N, 10081, 10000], 14, 4))
+case("modulus_op_dict_decimal", "2153-2209", "%", DDA, DDB, dec([123, N, N, 1, 0], 10, 0))
+DDS = dct([0, 2, 1, 3, 0], dec([V, N, V - 1, V + 1], 10, 0))
+case("plus_op_dict_scalar_decimal", "1408-1452", "+", DDS, dec([1], 10, 0), dec([V + 1, V, N, V + 2, V + 1], 11, 0), rs=True)
+case("minus_op_dict_scalar_decimal", "1624-1668", "-", DDS, dec([1], 10, 0), dec([V - 1, V - 2, N, V, V - 1], 11, 0), rs=True)
+case("multiply_op_dict_scalar_decimal", "1836-1874", "*", DDS, dec([2], 10, 0), dec([246, 244, N, 248, 246], 21, 0), rs=True)
+case("divide_op_dict_scalar_decimal", "2054-2092", "/", DDS, dec([2], 10, 0), dec([615000, 610000, N, 620000, 615000], 14, 4), rs=True)
+case("modulus_op_dict_scalar_decimal", "2262-2300", "%", DDS, dec([2], 10, 0), dec([1, 0, N, 0, 1], 10, 0), rs=True)
+
+# ---- Kleene logic
+T, F = True, False
+KA = boo([T, F, N, T, F, N, T, F, N]); KB = boo([T, T, T, F, F, F, N, N, N])
+case("and_with_nulls_op", "2399-2441", "AND", KA, KB, boo([T, F, N, F, F, F, N, F, N]))
+case("or_with_nulls_op", "2444-2486", "OR", KA, KB, boo([T, T, T, T, F, N, T, N, N]))
+
+# ---- Boolean comparisons: a = [T, T, T, N, N, N, F, F, F], b = [T, N, F, T, N, F, T, N, F]
+BA = boo([T, T, T, N, N, N, F, F, F]); BB = boo([T, N, F, T, N, F, T, N, F])
+for name, ref, op, exp in (("eq_op_bool", "2534-2550", "=", [T, N, F, N, N, N, F, N, T]), ("neq_op_bool", "2593-2609", "!=", [F, N, T, N, N, N, T, N, F]),
+                           ("lt_op_bool", "2652-2668", "<", [F, N, F, N, N, N, T, N, F]), ("lt_eq_op_bool", "2715-2731", "<=", [T, N, F, N, N, N, T, N, T]),
+                           ("gt_op_bool", "2778-2794", ">", [F, N, T, N, N, N, F, N, F]), ("gt_eq_op_bool", "2841-2857", ">=", [T, N, T, N, N, N, F, N, T]),
+                           ("is_distinct_from_op_bool", "2904-2920", "IS DISTINCT FROM", [F, T, T, T, F, T, T, T, F]),
+                           ("is_not_distinct_from_op_bool", "2923-2939", "IS NOT DISTINCT FROM", [T, F, F, F, T, F, F, F, T])):
+    case(name, ref, op, BA, BB, boo(exp))
+# scalar forms over [T, N, F]: (op, scalar, scalar-on-the-left expected, scalar-on-the-right expected)
+SA = boo([T, N, F])
+for op, ref, rows in (("=", "2553-2590", [(T, [T, N, F], [T, N, F]), (F, [F, N, T], [F, N, T])]), ("!=", "2612-2649", [(T, [F, N, T], [F, N, T]), (F, [T, N, F], [T, N, F])]),
+                      ("<", "2671-2712", [(T, [F, N, F], [F, N, T]), (F, [T, N, F], [F, N, F])]), ("<=", "2734-2775", [(T, [T, N, F], [T, N, T]), (F, [T, N, T], [F, N, T])]),
+                      (">", "2797-2838", [(T, [F, N, T], [F, N, F]), (F, [F, N, F], [T, N, F])]), (">=", "2860-2901", [(T, [T, N, T], [T, N, F]), (F, [F, N, T], [T, N, T])])):
+    for k, left_exp, right_exp in rows:
+        case(f"bool_scalar_{k}_{op}_arr", ref, op, boo([k]), SA, boo(left_exp), ls=True)
+        case(f"bool_arr_{op}_scalar_{k}", ref, op, SA, boo([k]), boo(right_exp), rs=True)
+
+# ---- Decimal128(25, 3) column against a Decimal128(25, 3) literal; plain and behind a dictionary
+DCOL = dec([V, N, V - 1, V + 1], 25, 3); DDCOL = dct([0, N, 2, 3], dec([V, N, V - 1, V + 1], 25, 3))
+for op, exp in (("=", [T, N, F, F]), ("!=", [F, N, T, T]), ("<", [F, N, T, F]), ("<=", [T, N, T, F]), (">", [F, N, F, T]), (">=", [T, N, F, T])):
+    case(f"comparison_decimal_arr_{op}_scalar", "3081-3155", op, DCOL, dec([V], 25, 3), boo(exp), rs=True)
+    case(f"comparison_dict_decimal_arr_{op}_scalar", "2990-3076", op, DDCOL, dec([V], 25, 3), boo(exp), rs=True)
+# Decimal128(10, 0) array against array
+DL = dec([V, N, V - 1, V + 1], 10, 0); DR = dec([V - 1, V, V + 1, V + 1], 10, 0)
+for op, exp in (("=", [F, N, F, T]), ("!=", [T, N, T, F]), ("<", [F, N, T, F]), ("<=", [F, N, T, T]), (">", [T, N, F, F]), (">=", [T, N, F, T])):
+    case(f"comparison_decimal_arr_{op}_arr", "3240-3316", op, DL, DR, boo(exp))
+
+S = "datafusion/physical-plan/src/sorts/sort.rs:"
+sort = [
+    {"name": "test_in_mem_sort", "ref": S + "1022-1049 (test::scan_partitioned(4): 4 partitions of make_partition(100), column i = 0..100)", "type": "int32",
+     "partitions": [list(range(100))] * 4, "descending": False, "nulls_first": True, "expected_rows": 400, "expected_batches": 1},
+    {"name": "test_sort_metadata", "ref": S + "1152-1197", "type": "uint64", "partitions": [[3, 2, 1]], "descending": False, "nulls_first": True, "expected": [1, 2, 3]},
+]
+R = "datafusion/physical-plan/src/repartition/mod.rs:"
+repartition = [
+    {"name": "one_to_many_round_robin", "ref": R + "952-969", "inputs": [50], "scheme": "RoundRobinBatch", "n": 4, "expected_batches": [13, 13, 12, 12]},
+    {"name": "many_to_one_round_robin", "ref": R + "972-986", "inputs": [50, 50, 50], "scheme": "RoundRobinBatch", "n": 1, "expected_batches": [150]},
+    {"name": "many_to_many_round_robin", "ref": R + "989-1007", "inputs": [50, 50, 50], "scheme": "RoundRobinBatch", "n": 5, "expected_batches": [30, 30, 30, 30, 30]},
+    {"name": "many_to_many_hash_partition", "ref": R + "1010-1033", "inputs": [50, 50, 50], "scheme": "Hash", "n": 8, "expected_total_rows": 8 * 50 * 3},
+]
+json.dump({"binary": cases, "sort": sort, "repartition": {"batch": {"ref": R + "1440-1447 create_batch", "type": "uint32", "column": "c0", "values": [1, 2, 3, 4, 5, 6, 7, 8]}, "cases": repartition}},
+          open(__file__.rsplit("/", 1)[0] + "/unit_vectors.json", "w"), indent=1)
+print(len(cases), "binary cases")

@@ -7,7 +7,7 @@ import math
 import numpy as np
 import pyarrow as pa
 
-OPCODE = {"+": 0, "-": 1, "*": 2, "/": 3, "%": 4, "=": 10, "!=": 11, "<": 12, "<=": 13, ">": 14, ">=": 15}
+OPCODE = {"+": 0, "-": 1, "*": 2, "/": 3, "%": 4, "=": 10, "!=": 11, "<": 12, "<=": 13, ">": 14, ">=": 15, "IS DISTINCT FROM": 16, "IS NOT DISTINCT FROM": 17, "AND": 20, "OR": 21}
 AGG = {"SUM": 0, "AVG": 1, "COUNT": 2, "MIN": 3, "MAX": 4}
 
 
@@ -15,7 +15,7 @@ def pa_type(t):
     if isinstance(t, dict):
         p, s = t["decimal128"]
         return pa.decimal128(p, s)
-    return {"int16": pa.int16(), "int32": pa.int32(), "int64": pa.int64(), "uint32": pa.uint32(), "uint64": pa.uint64(), "float32": pa.float32(), "float64": pa.float64(),
+    return {"int8": pa.int8(), "int16": pa.int16(), "int32": pa.int32(), "int64": pa.int64(), "uint32": pa.uint32(), "uint64": pa.uint64(), "float32": pa.float32(), "float64": pa.float64(),
             "bool": pa.bool_(), "utf8": pa.utf8(), "date32": pa.date32()}[t]
 
 
@@ -43,6 +43,8 @@ class OracleEngine:
         self.po = po
 
     def binary(self, op, l, r, ls=False, rs=False):
+        # arrow-arith / arrow-ord unpack dictionary operands before computing (the reference's expected arrays are plain): the restatement takes the values
+        l, r = (x.dictionary_decode() if pa.types.is_dictionary(x.type) else x for x in (l, r))
         return self.po.binary(op, l, r, l_scalar=ls, r_scalar=rs)
 
     def cast(self, a, typ):
@@ -299,3 +301,20 @@ def run_clickbench_case(eng, fix, case):
                 assert a == b or abs(a - b) <= 1e-9 * abs(b), f"{case['name']}: {a} vs {b}"
             else:
                 assert a == b, f"{case['name']}: {g} vs {w}"
+
+
+# ------------------------------------------------------------------ unit_vectors.json (binary.rs / sort.rs / repartition)
+def vector_array(spec):
+    if "dict" in spec:
+        d = spec["dict"]
+        return pa.DictionaryArray.from_arrays(pa.array(d["keys"], type=pa_type(d["keys_type"])), vector_array(d["values"]))
+    return make_array(spec["type"], spec["values"])
+
+
+def run_binary_vector(eng, case):
+    l, r, want = vector_array(case["left"]), vector_array(case["right"]), vector_array(case["expected"])
+    got = eng.binary(case["op"], l, r, case["left_scalar"], case["right_scalar"])
+    if pa.types.is_dictionary(got.type):
+        got = got.dictionary_decode()
+    assert got.type == want.type, (case["name"], got.type, want.type)
+    assert got.equals(want), (case["name"], got.to_pylist(), want.to_pylist())

@@ -2,12 +2,13 @@
 (decimal.slt, aggregate unit tests, AggregateExec Partial -> Final, SortExec floats), through the C ABI."""
 import pytest
 
-from golden_engine import run_clickbench_case, DeviceEngine, run_grouped_case, run_scalar_case, run_slt_case, run_sort_case
+from golden_engine import run_binary_vector, run_clickbench_case, DeviceEngine, run_grouped_case, run_scalar_case, run_slt_case, run_sort_case
 from helpers import load_golden
 
 pytestmark = pytest.mark.gpu
 SLT = load_golden("decimal_slt.json")
 AGG = load_golden("aggregates.json")
+UNIT = load_golden("unit_vectors.json")
 
 
 @pytest.fixture()
@@ -78,3 +79,50 @@ def test_device_joins_slt(ctx, case, mode):
     for b in ops.collect(plan, ops.TaskContext(ctx, 2)):          # batch_size 2, as the .slt file sets it
         got += [list(r) for r in zip(*[c.to_arrow().to_pylist() for c in b.columns])]
     assert got == case["expected"]
+
+
+@pytest.mark.parametrize("case", UNIT["binary"], ids=[c["name"] for c in UNIT["binary"]])
+def test_device_binary_rs_unit_vectors(eng, case):
+    """expressions/binary.rs unit tests on the device; dictionary operands go in as dictionary arrays"""
+    run_binary_vector(eng, case)
+
+
+@pytest.mark.parametrize("case", UNIT["sort"], ids=[c["name"] for c in UNIT["sort"]])
+def test_device_sort_rs_unit_vectors(ctx, case):
+    """sorts/sort.rs test_in_mem_sort / test_sort_metadata through SortExec over CoalescePartitionsExec: one batch, every row, ascending"""
+    import pyarrow as pa
+    from dfgpu import physical_plan as ops
+    from golden_engine import pa_type
+    parts = [[ops.batch_from_arrow(ctx, pa.table({"i": pa.array(p, type=pa_type(case["type"]))}))] for p in case["partitions"]]
+    src = ops.MemoryExec(parts, parts[0][0].schema)
+    plan = ops.SortExec([ops.PhysicalSortExpr(ops.Column("i", 0), case["descending"], case["nulls_first"])], ops.CoalescePartitionsExec(src))
+    out = list(plan.execute(0, ops.TaskContext(ctx, 8192)))
+    assert len(out) == case.get("expected_batches", 1)
+    vals = [v for b in out for v in b.to_arrow()["i"].to_pylist()]
+    assert len(vals) == case.get("expected_rows", len(vals)) and vals == sorted(v for p in case["partitions"] for v in p)
+    if "expected" in case:
+        assert vals == case["expected"]
+
+
+@pytest.mark.parametrize("case", UNIT["repartition"]["cases"], ids=[c["name"] for c in UNIT["repartition"]["cases"]])
+def test_device_repartition_rs_unit_vectors(ctx, case):
+    """repartition/mod.rs: batches per output partition under RoundRobinBatch (every input partition's rotation starts at output 0), row conservation under Hash"""
+    import pyarrow as pa
+    from dfgpu import physical_plan as ops
+    fix = UNIT["repartition"]["batch"]
+    batch = ops.batch_from_arrow(ctx, pa.table({fix["column"]: pa.array(fix["values"], type=pa.uint32())}))
+    src = ops.MemoryExec([[batch] * n for n in case["inputs"]], batch.schema)
+    part = ops.Partitioning.RoundRobinBatch(case["n"]) if case["scheme"] == "RoundRobinBatch" else ops.Partitioning.Hash([ops.Column(fix["column"], 0)], case["n"])
+    plan = ops.RepartitionExec(src, part)
+    tc = ops.TaskContext(ctx, 8192)
+    outs = [list(plan.execute(p, tc)) for p in range(case["n"])]
+    if "expected_batches" in case:
+        assert [len(o) for o in outs] == case["expected_batches"]
+        assert all(b.num_rows == len(fix["values"]) for o in outs for b in o)
+    else:
+        rows = [v for o in outs for b in o for v in b.to_arrow()[fix["column"]].to_pylist()]
+        assert len(rows) == case["expected_total_rows"] and sorted(set(rows)) == fix["values"]
+        for o in outs:                      # one value lands in one partition only
+            for other in outs:
+                if o is not other:
+                    assert not ({v for b in o for v in b.to_arrow()[fix["column"]].to_pylist()} & {v for b in other for v in b.to_arrow()[fix["column"]].to_pylist()})

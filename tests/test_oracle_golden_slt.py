@@ -4,11 +4,12 @@ GROUP BY COUNT), the Sum / Avg / Count / Min / Max unit tests, AggregateExec Par
 Fixtures: tests/golden/decimal_slt.json, tests/golden/aggregates.json (hand-transcribed; scripts beside them)."""
 import pytest
 
-from golden_engine import run_clickbench_case, OracleEngine, run_grouped_case, run_scalar_case, run_slt_case, run_sort_case
+from golden_engine import run_binary_vector, run_clickbench_case, OracleEngine, run_grouped_case, run_scalar_case, run_slt_case, run_sort_case
 from helpers import load_golden
 
 SLT = load_golden("decimal_slt.json")
 AGG = load_golden("aggregates.json")
+UNIT = load_golden("unit_vectors.json")
 
 
 @pytest.fixture(scope="module")
@@ -74,3 +75,39 @@ def test_oracle_joins_slt(case):
     NULL keys and join filters): the oracle's hash join reproduces the reference's expected rows."""
     from joins_slt_common import oracle_rows
     assert oracle_rows(case) == case["expected"]
+
+
+@pytest.mark.parametrize("case", UNIT["binary"], ids=[c["name"] for c in UNIT["binary"]])
+def test_oracle_binary_rs_unit_vectors(eng, case):
+    """expressions/binary.rs unit tests: arithmetic over Int32 / dictionary / Decimal128 operands, Kleene logic, Boolean and Decimal128 comparisons"""
+    run_binary_vector(eng, case)
+
+
+@pytest.mark.parametrize("case", UNIT["sort"], ids=[c["name"] for c in UNIT["sort"]])
+def test_oracle_sort_rs_unit_vectors(eng, case):
+    import numpy as np
+    import pyarrow as pa
+    from golden_engine import make_array
+    col = make_array(case["type"], [v for p in case["partitions"] for v in p])
+    idx = eng.sort_indices([col], [case["descending"]], [case["nulls_first"]])
+    out = eng.take(col, idx)
+    assert len(out) == case.get("expected_rows", len(out))
+    vals = out.to_pylist()
+    assert vals == sorted(vals)
+    if "expected" in case:
+        assert vals == case["expected"]
+
+
+def test_oracle_repartition_hash_conserves_rows():
+    """repartition/mod.rs many_to_many_hash_partition: 3 x 50 batches of [1..8] hashed on c0 into 8 partitions keep every row"""
+    import pyarrow as pa
+    from oracle import pyoracle as po
+    fix = UNIT["repartition"]; case = next(c for c in fix["cases"] if c["scheme"] == "Hash")
+    batch = pa.array(fix["batch"]["values"], type=pa.uint32())
+    total = 0
+    for n_batches in case["inputs"]:
+        for _ in range(n_batches):
+            idx, counts = po.hash_partition([batch], case["n"])
+            assert len(counts) == case["n"] and sum(counts) == len(batch) and sorted(idx) == list(range(len(batch)))
+            total += sum(counts)
+    assert total == case["expected_total_rows"]
