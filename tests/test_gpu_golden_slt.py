@@ -2,13 +2,14 @@
 (decimal.slt, aggregate unit tests, AggregateExec Partial -> Final, SortExec floats), through the C ABI."""
 import pytest
 
-from golden_engine import run_binary_vector, run_clickbench_case, DeviceEngine, run_grouped_case, run_scalar_case, run_slt_case, run_sort_case
+from golden_engine import run_binary_vector, run_order_case, run_table_case, run_clickbench_case, DeviceEngine, run_grouped_case, run_scalar_case, run_slt_case, run_sort_case
 from helpers import load_golden
 
 pytestmark = pytest.mark.gpu
 SLT = load_golden("decimal_slt.json")
 AGG = load_golden("aggregates.json")
 UNIT = load_golden("unit_vectors.json")
+GBO = load_golden("groupby_order_slt.json")
 
 
 @pytest.fixture()
@@ -126,3 +127,14 @@ def test_device_repartition_rs_unit_vectors(ctx, case):
             for other in outs:
                 if o is not other:
                     assert not ({v for b in o for v in b.to_arrow()[fix["column"]].to_pylist()} & {v for b in other for v in b.to_arrow()[fix["column"]].to_pylist()})
+
+
+@pytest.mark.parametrize("case", GBO["cases"], ids=[c["name"] for c in GBO["cases"]])
+def test_device_group_by_and_aggregate_slt_values_cases(eng, case):
+    """group_by.slt GROUP BY ALL (NULL key group) and the dictionary-key tables, aggregate.slt test_decimal_table"""
+    run_table_case(eng, GBO, case)
+
+
+@pytest.mark.parametrize("case", GBO["order"]["cases"], ids=[c["name"] for c in GBO["order"]["cases"]])
+def test_device_order_slt_null_placement(eng, case):
+    run_order_case(eng, GBO, case)

@@ -4,12 +4,13 @@ GROUP BY COUNT), the Sum / Avg / Count / Min / Max unit tests, AggregateExec Par
 Fixtures: tests/golden/decimal_slt.json, tests/golden/aggregates.json (hand-transcribed; scripts beside them)."""
 import pytest
 
-from golden_engine import run_binary_vector, run_clickbench_case, OracleEngine, run_grouped_case, run_scalar_case, run_slt_case, run_sort_case
+from golden_engine import run_binary_vector, run_order_case, run_table_case, run_clickbench_case, OracleEngine, run_grouped_case, run_scalar_case, run_slt_case, run_sort_case
 from helpers import load_golden
 
 SLT = load_golden("decimal_slt.json")
 AGG = load_golden("aggregates.json")
 UNIT = load_golden("unit_vectors.json")
+GBO = load_golden("groupby_order_slt.json")
 
 
 @pytest.fixture(scope="module")
@@ -111,3 +112,14 @@ def test_oracle_repartition_hash_conserves_rows():
             assert len(counts) == case["n"] and sum(counts) == len(batch) and sorted(idx) == list(range(len(batch)))
             total += sum(counts)
     assert total == case["expected_total_rows"]
+
+
+@pytest.mark.parametrize("case", GBO["cases"], ids=[c["name"] for c in GBO["cases"]])
+def test_oracle_group_by_and_aggregate_slt_values_cases(eng, case):
+    """group_by.slt GROUP BY ALL (NULL key group) and the dictionary-key tables, aggregate.slt test_decimal_table"""
+    run_table_case(eng, GBO, case)
+
+
+@pytest.mark.parametrize("case", GBO["order"]["cases"], ids=[c["name"] for c in GBO["order"]["cases"]])
+def test_oracle_order_slt_null_placement(eng, case):
+    run_order_case(eng, GBO, case)
