@@ -2,6 +2,7 @@
   binary    physical-expr/src/expressions/binary.rs    plus / minus / multiply / divide / modulus over Int32, dictionary Int32 and dictionary
                                                        Decimal128 columns (array op array, array op scalar), Kleene AND / OR, the six comparisons and
                                                        IS [NOT] DISTINCT FROM over Boolean columns with NULLs, Decimal128 comparisons
+  in_list   physical-expr/src/expressions/in_list.rs   IN / NOT IN over Utf8, Int64, Float64 (NaN, -NaN), Boolean, Date32, Decimal128 with and without a NULL in the list
   sort      physical-plan/src/sorts/sort.rs            test_in_mem_sort (4 x make_partition(100)), test_sort_metadata
   repartition physical-plan/src/repartition/mod.rs     RoundRobinBatch batch counts, Hash row conservation
 Mixed-type comparisons of the same tests (Int64 / Float64 column against a Decimal128 literal) go through the planner's coercion and are left out.
@@ -97,6 +98,30 @@ DL = dec([V, N, V - 1, V + 1], 10, 0); DR = dec([V - 1, V, V + 1, V + 1], 10, 0)
 for op, exp in (("=", [F, N, F, T]), ("!=", [T, N, T, F]), ("<", [F, N, T, F]), ("<=", [F, N, T, T]), (">", [T, N, F, F]), (">=", [T, N, F, T])):
     case(f"comparison_decimal_arr_{op}_arr", "3240-3316", op, DL, DR, boo(exp))
 
+# ---- InListExpr (physical-expr/src/expressions/in_list.rs): NULL in the list turns "no match" into NULL; NaN matches NaN of the same sign bit pattern
+I = "datafusion/physical-expr/src/expressions/in_list.rs:"
+in_list = []
+
+
+def inl(name, ref, typ, values, lst, negated, expected):
+    in_list.append({"name": name, "ref": I + ref, "type": typ, "values": values, "list": lst, "negated": negated, "expected": expected})
+
+
+for name, ref, typ, vals, l2 in (("utf8", "515-567", "utf8", ["a", "d", N], ["a", "b"]), ("int64", "629-681", "int64", [0, 2, N], [0, 1]), ("date32", "909-975", "date32", [0, 2, N], [0, 1])):
+    inl(f"in_list_{name}", ref, typ, vals, l2, False, [T, F, N]); inl(f"not_in_list_{name}", ref, typ, vals, l2, True, [F, T, N])
+    inl(f"in_list_{name}_with_null", ref, typ, vals, l2 + [N], False, [T, N, N]); inl(f"not_in_list_{name}_with_null", ref, typ, vals, l2 + [N], True, [F, N, N])
+FV = [0.0, 0.2, N, "NaN", "-NaN"]
+for lst, neg, exp in (([0.0, 0.1], False, [T, F, N, F, F]), ([0.0, 0.1], True, [F, T, N, T, T]), ([0.0, 0.1, N], False, [T, N, N, N, N]), ([0.0, 0.1, N], True, [F, N, N, N, N]),
+                      ([0.0, 0.1, "NaN"], False, [T, F, N, T, F]), ([0.0, 0.1, "NaN"], True, [F, T, N, F, T]), ([0.0, 0.1, "-NaN"], False, [T, F, N, F, T]), ([0.0, 0.1, "-NaN"], True, [F, T, N, T, F])):
+    inl(f"{'not_' if neg else ''}in_list_float64_{len(in_list)}", "683-785", "float64", FV, lst, neg, exp)
+for lst, neg, exp in (([T], False, [T, N]), ([T], True, [F, N]), ([T, N], False, [T, N]), ([T, N], True, [F, N])):
+    inl(f"{'not_' if neg else ''}in_list_bool_{len(in_list)}", "787-839", "bool", [T, N], lst, neg, exp)
+# Decimal128(13, 4) column [100.0000, NULL, 200.5000]; the Int32 literals 100 / 200 are cast to the column type by in_list_cast (in_list.rs:459-513)
+DT = {"decimal128": [13, 4]}
+for lst, neg, exp in (([1000000, 2000000], False, [T, N, F]), ([1000000, 2000000], True, [F, N, T]), ([1000000, N], False, [T, N, N]), ([1000000, N], True, [F, N, N]),
+                      ([v * 10000 for v in range(99, 300)], False, [T, N, F]), ([v * 10000 for v in range(99, 300)], True, [F, N, T])):
+    inl(f"{'not_' if neg else ''}in_list_decimal_{len(in_list)}", "977-1075", DT, [1000000, N, 2005000], lst, neg, exp)
+
 S = "datafusion/physical-plan/src/sorts/sort.rs:"
 sort = [
     {"name": "test_in_mem_sort", "ref": S + "1022-1049 (test::scan_partitioned(4): 4 partitions of make_partition(100), column i = 0..100)", "type": "int32",
@@ -110,6 +135,6 @@ repartition = [
     {"name": "many_to_many_round_robin", "ref": R + "989-1007", "inputs": [50, 50, 50], "scheme": "RoundRobinBatch", "n": 5, "expected_batches": [30, 30, 30, 30, 30]},
     {"name": "many_to_many_hash_partition", "ref": R + "1010-1033", "inputs": [50, 50, 50], "scheme": "Hash", "n": 8, "expected_total_rows": 8 * 50 * 3},
 ]
-json.dump({"binary": cases, "sort": sort, "repartition": {"batch": {"ref": R + "1440-1447 create_batch", "type": "uint32", "column": "c0", "values": [1, 2, 3, 4, 5, 6, 7, 8]}, "cases": repartition}},
+json.dump({"binary": cases, "in_list": in_list, "sort": sort, "repartition": {"batch": {"ref": R + "1440-1447 create_batch", "type": "uint32", "column": "c0", "values": [1, 2, 3, 4, 5, 6, 7, 8]}, "cases": repartition}},
           open(__file__.rsplit("/", 1)[0] + "/unit_vectors.json", "w"), indent=1)
-print(len(cases), "binary cases")
+print(len(cases), "binary cases,", len(in_list), "in_list cases")

@@ -24,7 +24,8 @@ def make_array(t, values):
     if pa.types.is_decimal(typ):
         return pa.array([None if v is None else decimal.Decimal(int(v)).scaleb(-typ.scale) for v in values], type=typ)
     if pa.types.is_floating(typ):
-        return pa.array([None if v is None else (math.nan if v == "NaN" else float(v)) for v in values], type=typ)
+        neg_nan = np.frombuffer(np.array([0xFFF8000000000000], dtype=np.uint64).tobytes(), dtype=np.float64)[0]      # -f64::NAN: sign bit set
+        return pa.array([None if v is None else (math.nan if v == "NaN" else neg_nan if v == "-NaN" else float(v)) for v in values], type=typ)
     return pa.array(values, type=typ)
 
 
@@ -49,6 +50,9 @@ class OracleEngine:
 
     def cast(self, a, typ):
         return self.po.cast(a, typ)
+
+    def in_list(self, a, lst, negated):
+        return self.po.in_list(a, lst, negated)
 
     def filter(self, a, mask):
         return self.po.filter_(a, mask)
@@ -96,6 +100,9 @@ class DeviceEngine:
 
     def binary(self, op, l, r, ls=False, rs=False):
         return self.ctx.binary(OPCODE[op], self.ctx.from_arrow(l), self.ctx.from_arrow(r), ls, rs).to_arrow()
+
+    def in_list(self, a, lst, negated):
+        return self.ctx.in_list(self.ctx.from_arrow(a), self.ctx.from_arrow(lst), negated).to_arrow()
 
     def cast(self, a, typ):
         t, p, s = self._code(typ)
@@ -365,3 +372,9 @@ def run_order_case(eng, fix, case):
     idx = eng.sort_indices([cols[0]], [case["descending"]], [case["nulls_first"]])
     got = [list(r) for r in rows_as_values([eng.take(c, idx) for c in cols])]
     assert got == case["expected"], f"{case['name']}: {got}"
+
+
+def run_in_list_vector(eng, case):
+    a, lst = make_array(case["type"], case["values"]), make_array(case["type"], case["list"])
+    got = eng.in_list(a, lst, case["negated"])
+    assert got.to_pylist() == case["expected"], (case["name"], got.to_pylist())

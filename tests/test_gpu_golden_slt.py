@@ -2,7 +2,7 @@
 (decimal.slt, aggregate unit tests, AggregateExec Partial -> Final, SortExec floats), through the C ABI."""
 import pytest
 
-from golden_engine import run_binary_vector, run_order_case, run_table_case, run_clickbench_case, DeviceEngine, run_grouped_case, run_scalar_case, run_slt_case, run_sort_case
+from golden_engine import run_binary_vector, run_in_list_vector, run_order_case, run_table_case, run_clickbench_case, DeviceEngine, run_grouped_case, run_scalar_case, run_slt_case, run_sort_case
 from helpers import load_golden
 
 pytestmark = pytest.mark.gpu
@@ -138,3 +138,8 @@ def test_device_group_by_and_aggregate_slt_values_cases(eng, case):
 @pytest.mark.parametrize("case", GBO["order"]["cases"], ids=[c["name"] for c in GBO["order"]["cases"]])
 def test_device_order_slt_null_placement(eng, case):
     run_order_case(eng, GBO, case)
+
+
+@pytest.mark.parametrize("case", UNIT["in_list"], ids=[c["name"] for c in UNIT["in_list"]])
+def test_device_in_list_rs_unit_vectors(eng, case):
+    run_in_list_vector(eng, case)

@@ -4,7 +4,7 @@ GROUP BY COUNT), the Sum / Avg / Count / Min / Max unit tests, AggregateExec Par
 Fixtures: tests/golden/decimal_slt.json, tests/golden/aggregates.json (hand-transcribed; scripts beside them)."""
 import pytest
 
-from golden_engine import run_binary_vector, run_order_case, run_table_case, run_clickbench_case, OracleEngine, run_grouped_case, run_scalar_case, run_slt_case, run_sort_case
+from golden_engine import run_binary_vector, run_in_list_vector, run_order_case, run_table_case, run_clickbench_case, OracleEngine, run_grouped_case, run_scalar_case, run_slt_case, run_sort_case
 from helpers import load_golden
 
 SLT = load_golden("decimal_slt.json")
@@ -123,3 +123,8 @@ def test_oracle_group_by_and_aggregate_slt_values_cases(eng, case):
 @pytest.mark.parametrize("case", GBO["order"]["cases"], ids=[c["name"] for c in GBO["order"]["cases"]])
 def test_oracle_order_slt_null_placement(eng, case):
     run_order_case(eng, GBO, case)
+
+
+@pytest.mark.parametrize("case", UNIT["in_list"], ids=[c["name"] for c in UNIT["in_list"]])
+def test_oracle_in_list_rs_unit_vectors(eng, case):
+    run_in_list_vector(eng, case)
