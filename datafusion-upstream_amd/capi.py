@@ -145,6 +145,7 @@ PROTOTYPES = {
     "dfgpu_acc_evaluate": (C.c_int32, [_P, _P, _PP]),
     "dfgpu_acc_state": (C.c_int32, [_P, _P, _PP, C.POINTER(C.c_int32)]),
     "dfgpu_acc_size": (C.c_int64, [_P]),
+    "dfgpu_cross_join_indices": (C.c_int32, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _PP, _PP]),
     "dfgpu_sort_to_indices": (C.c_int32, [_P, _PP, C.c_char_p, C.c_char_p, C.c_int32, C.c_int64, _PP]),
     "dfgpu_hash_partition": (C.c_int32, [_P, _PP, C.c_int32, C.c_int32, _PP, C.POINTER(C.c_int64)]),
     "dfgpu_comm_unique_id": (C.c_int32, [C.c_char_p]),
@@ -175,6 +176,7 @@ _CPP = C.POINTER(C.c_char_p)
 _I32P = C.POINTER(C.c_int32)
 PROTOTYPES.update({
     "dfgpu_exec_last_error": (C.c_char_p, []),
+    "dfgpu_plan_nested_loop_join": (C.c_int32, [_P, _P, _P, _I32P, _I32P, C.c_int32, C.c_int32, _PP]),
     "dfgpu_plan_parquet": (C.c_int32, [_P, _I32P, C.c_int32, C.c_int32, C.c_int32, _PP]),
     "dfgpu_plan_parquet_prune": (C.c_int32, [_P, C.c_int32, C.c_int64, C.c_int64]),
     "dfgpu_plan_parquet_pruned": (C.c_int64, [_P]),

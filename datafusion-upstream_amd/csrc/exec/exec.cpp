@@ -794,6 +794,125 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
   std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override { return std::unique_ptr<Stream>(new S(this, p, tc)); }
 };
 
+// ------------------------------------------------------------------ NestedLoopJoinExec
+// joins/nested_loop_join.rs:84-127.  The side named by left_is_build_side (:373-378 -- left for Right / RightSemi / RightAnti / Full, right otherwise) is
+// collected once; every batch of the other side is joined with it: candidate pairs left-major (build_join_indices :405-432), the JoinFilter over the
+// intermediate batch (apply_join_filter_to_indices), adjust_indices_by_join_type per outer batch (:652-708), and for Full one last batch of the left rows
+// no batch matched (:505-531).  Rows and row order per outer batch are the reference's; candidate pairs are generated in runs of left rows so that a
+// large cross product never sits in memory at once.
+struct NestedLoopJoinExec : Plan {
+  PlanPtr left, right; ExprPtr filter; std::vector<int> f_side, f_index; int join_type = 0;
+  mutable std::mutex mu; mutable std::shared_ptr<Batch> inner;          // OnceFut<JoinLeftData>
+  bool build_left() const { return join_type == DFGPU_JOIN_RIGHT || join_type == DFGPU_JOIN_RIGHT_SEMI || join_type == DFGPU_JOIN_RIGHT_ANTI || join_type == DFGPU_JOIN_FULL; }
+  bool left_only() const { return join_type == DFGPU_JOIN_LEFT_SEMI || join_type == DFGPU_JOIN_LEFT_ANTI; }
+  bool right_only() const { return join_type == DFGPU_JOIN_RIGHT_SEMI || join_type == DFGPU_JOIN_RIGHT_ANTI; }
+  PlanPtr fresh() const override { auto j = std::make_shared<NestedLoopJoinExec>(); j->left = left->fresh(); j->right = right->fresh(); j->filter = filter; j->f_side = f_side; j->f_index = f_index; j->join_type = join_type; return j; }
+  std::vector<std::shared_ptr<const Plan>> children() const override { return {left, right}; }
+  const char* name() const override { return "NestedLoopJoinExec"; }
+  SchemaPtr schema() const override {
+    auto s = std::make_shared<Schema>(); auto l = left->schema(), r = right->schema();
+    if (!right_only() && l) s->f.insert(s->f.end(), l->f.begin(), l->f.end());
+    if (!left_only() && r) s->f.insert(s->f.end(), r->f.begin(), r->f.end());
+    return s;
+  }
+  int partitions() const override { return build_left() ? right->partitions() : left->partitions(); }
+  std::shared_ptr<Batch> collect_inner(const TaskContext& tc) const {
+    std::lock_guard<std::mutex> l(mu);
+    if (!inner) {
+      SpanGuard sp(tc, met.get(), 1);
+      const PlanPtr& side = build_left() ? left : right;
+      std::vector<Batch> in; for (int p = 0; p < side->partitions(); p++) drain(side, p, tc, in);
+      auto b = std::make_shared<Batch>();
+      if (!concat_batches(tc, in, b.get())) {           // a side without a single batch: typed empty columns, so that outer joins still null-pad it
+        b->schema = side->schema(); b->base_rows = 0;
+        for (auto& f : b->schema->f) { dfgpu_array* nn = nullptr; tc.check(dfgpu_array_new_null(tc.ctx, f.type, f.precision, f.scale, 0, &nn)); b->cols.push_back(col_of(ArrayRef::adopt(nn))); }
+      }
+      inner = b;
+    }
+    return inner;
+  }
+  struct S : Stream {
+    const NestedLoopJoinExec* op; TaskContext tc; std::unique_ptr<Stream> outer; std::shared_ptr<Batch> in; SchemaPtr out_schema; int state = 0;
+    std::vector<ArrayRef> matched_left;        // Full: per outer batch, the left rows that joined (ascending, distinct)
+    S(const NestedLoopJoinExec* o, int p, TaskContext t) : op(o), tc(t) { in = op->collect_inner(tc); outer = (op->build_left() ? op->right : op->left)->run(p, tc); out_schema = op->schema(); }
+    ArrayRef filter_idx(const ArrayRef& idx, const ArrayRef& m) { dfgpu_array* o = nullptr; tc.check(dfgpu_filter(tc.ctx, idx.a, m.a, &o)); return ArrayRef::adopt(o); }
+    ArrayRef cast_to(const ArrayRef& a, int32_t t) { dfgpu_array* o = nullptr; tc.check(dfgpu_cast(tc.ctx, a.a, t, 0, 0, &o)); return ArrayRef::adopt(o); }
+    ArrayRef empty_idx(int32_t t) { dfgpu_array* o = nullptr; tc.check(dfgpu_array_new_zeros(tc.ctx, t, 0, 0, 0, &o)); return ArrayRef::adopt(o); }
+    ArrayRef cat(std::vector<ArrayRef>& v, int32_t t) { if (v.empty()) return empty_idx(t); if (v.size() == 1) return v[0]; return concat_arrays(tc, v); }
+    Batch build_batch(Batch& lb, Batch& rb, const ArrayRef& li, const ArrayRef& ri, int64_t rows) {
+      Batch o; o.schema = out_schema; o.base_rows = rows; MemoPtr memo = std::make_shared<TakeMemo>();
+      if (!op->right_only()) for (auto& c : lb.cols) o.cols.push_back(col_take(c, li, memo));
+      if (!op->left_only()) for (auto& c : rb.cols) o.cols.push_back(col_take(c, ri, memo));
+      return o;
+    }
+    // all filtered pairs of one (left batch, right batch), left-major
+    void pairs(Batch& lb, Batch& rb, ArrayRef* li, ArrayRef* ri) {
+      const bool bl = op->build_left(); const int64_t nl = lb.base_rows, nr = rb.base_rows;
+      std::vector<ArrayRef> ls, rs;
+      const int64_t run = nr > 0 ? std::max<int64_t>(1, ((int64_t)1 << 25) / nr) : nl;
+      for (int64_t first = 0; first < nl && nr > 0; first += run) {
+        const int64_t cnt = std::min(run, nl - first);
+        dfgpu_array *a = nullptr, *b = nullptr; tc.check(dfgpu_cross_join_indices(tc.ctx, first, cnt, nr, bl ? 1 : 0, &a, &b));
+        ArrayRef l = ArrayRef::adopt(a), r = ArrayRef::adopt(b);
+        if (op->filter) {
+          Batch inter; inter.schema = std::make_shared<Schema>(); inter.base_rows = l.len();
+          for (size_t i = 0; i < op->f_side.size(); i++) {
+            Col src = op->f_side[i] == 0 ? lb.cols.at((size_t)op->f_index[i]) : rb.cols.at((size_t)op->f_index[i]);
+            Col t = col_take(src, op->f_side[i] == 0 ? l : r); inter.cols.push_back(col_of(col_get(tc, t))); inter.schema->f.push_back(Field{"x"});
+          }
+          ArrayRef m = into_array(tc, op->filter->eval(tc, inter), inter.base_rows);
+          l = filter_idx(l, m); r = filter_idx(r, m);
+        }
+        if (l.len()) { ls.push_back(l); rs.push_back(r); }
+      }
+      *li = cat(ls, bl ? DFGPU_UINT64 : DFGPU_UINT32); *ri = cat(rs, bl ? DFGPU_UINT32 : DFGPU_UINT64);
+    }
+    bool next(Batch& out) override {
+      const int jt = op->join_type; const bool bl = op->build_left();
+      while (state == 0) {
+        Batch ob; if (!outer->next(ob)) { state = 1; break; }
+        ob = materialize(tc, ob);
+        SpanGuard join_span(tc, op->met.get(), 2);
+        Batch& lb = bl ? *in : ob; Batch& rb = bl ? ob : *in;
+        ArrayRef li, ri; pairs(lb, rb, &li, &ri);
+        if (jt == DFGPU_JOIN_FULL && li.len()) {          // visited_left_side.set_bit (:620-625)
+          ArrayRef l32 = cast_to(li, DFGPU_UINT32), r64 = cast_to(ri, DFGPU_UINT64); dfgpu_array *b2 = nullptr, *p2 = nullptr;
+          tc.check(dfgpu_join_adjust_indices(tc.ctx, r64.a, l32.a, 0, lb.base_rows, DFGPU_JOIN_RIGHT_SEMI, &b2, &p2)); ArrayRef drop = ArrayRef::adopt(b2); matched_left.push_back(ArrayRef::adopt(p2));
+        }
+        if (jt != DFGPU_JOIN_INNER) {                      // adjust_indices_by_join_type (:652-708): the streamed side plays the probe side of the hash join's index algebra
+          dfgpu_array *b2 = nullptr, *p2 = nullptr;
+          if (bl) { tc.check(dfgpu_join_adjust_indices(tc.ctx, li.a, ri.a, 0, rb.base_rows, jt == DFGPU_JOIN_FULL ? DFGPU_JOIN_RIGHT : jt, &b2, &p2)); li = ArrayRef::adopt(b2); ri = ArrayRef::adopt(p2); }
+          else {
+            int as = jt == DFGPU_JOIN_LEFT ? DFGPU_JOIN_RIGHT : jt == DFGPU_JOIN_LEFT_SEMI ? DFGPU_JOIN_RIGHT_SEMI : DFGPU_JOIN_RIGHT_ANTI;
+            tc.check(dfgpu_join_adjust_indices(tc.ctx, ri.a, li.a, 0, lb.base_rows, as, &b2, &p2)); ri = ArrayRef::adopt(b2); li = ArrayRef::adopt(p2);
+          }
+        }
+        const int64_t rows = (op->right_only() ? ri : li).len();
+        out = build_batch(lb, rb, li, ri, rows); return true;           // one output batch per outer batch, empty ones included (the reference's stream does the same)
+      }
+      if (state == 1) {
+        state = 2;
+        if (jt == DFGPU_JOIN_FULL) {                      // get_final_indices_from_bit_map: left rows no right batch matched, right side NULL
+          SpanGuard join_span(tc, op->met.get(), 2);
+          ArrayRef all = cat(matched_left, DFGPU_UINT32), all64 = cast_to(all, DFGPU_UINT64); dfgpu_array *b2 = nullptr, *p2 = nullptr;
+          tc.check(dfgpu_join_adjust_indices(tc.ctx, all64.a, all.a, 0, in->base_rows, DFGPU_JOIN_RIGHT_ANTI, &b2, &p2)); ArrayRef drop = ArrayRef::adopt(b2); ArrayRef un = ArrayRef::adopt(p2);
+          Batch o; o.schema = out_schema; o.base_rows = un.len(); MemoPtr memo = std::make_shared<TakeMemo>();
+          for (auto& c : in->cols) o.cols.push_back(col_take(c, un, memo));
+          auto rf = op->right->schema();
+          for (size_t i = 0; i < (rf ? rf->f.size() : 0); i++) { dfgpu_array* nn = nullptr; tc.check(dfgpu_array_new_null(tc.ctx, rf->f[i].type, rf->f[i].precision, rf->f[i].scale, o.base_rows, &nn)); o.cols.push_back(col_of(ArrayRef::adopt(nn))); }
+          out = std::move(o); return true;
+        }
+      }
+      return false;
+    }
+  };
+  std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override {
+    if (p < 0 || p >= partitions()) fail(DFGPU_INTERNAL, "NestedLoopJoinExec invalid partition %d", p);
+    if (join_type == DFGPU_JOIN_FULL && right->partitions() > 1) fail(DFGPU_EXECUTION, "Plan error: NestedLoopJoinExec Full requires single partitions on both sides");   // distribution_from_join_type (:312-333)
+    return std::unique_ptr<Stream>(new S(this, p, tc));
+  }
+};
+
 // ------------------------------------------------------------------ AggregateExec
 struct AggExpr { int kind; ExprPtr arg, filter; std::string name; int32_t type, precision, scale; };    // ≙ AggregateExpr for Sum/Avg/Count/Min/Max
 struct GroupsRef { dfgpu_groups* g = nullptr; ~GroupsRef() { if (g) dfgpu_groups_free(g); } };
@@ -1216,6 +1335,14 @@ dfgpu_status dfgpu_plan_hash_join(const dfgpu_plan* left, const dfgpu_plan* righ
     for (int i = 0; i < non; i++) { j->on_l.push_back(ex(on_left[i])); j->on_r.push_back(ex(on_right[i])); }
     if (filter) { j->filter = ex(filter); for (int i = 0; i < nf; i++) { j->f_side.push_back(fs[i]); j->f_index.push_back(fi[i]); } }
     j->join_type = join_type; j->mode = mode; j->null_equals_null = nen != 0;
+    *out = new dfgpu_plan{j};
+  });
+}
+dfgpu_status dfgpu_plan_nested_loop_join(const dfgpu_plan* left, const dfgpu_plan* right, const dfgpu_expr* filter, const int32_t* fs, const int32_t* fi, int32_t nf, int32_t join_type, dfgpu_plan** out) {
+  return guard([&] {
+    if (join_type < 0 || join_type > DFGPU_JOIN_RIGHT_ANTI) fail(DFGPU_INVALID_ARGUMENT, "unknown join type %d", join_type);
+    auto j = std::make_shared<NestedLoopJoinExec>(); j->left = pl(left); j->right = pl(right); j->join_type = join_type;
+    if (filter) { j->filter = ex(filter); for (int i = 0; i < nf; i++) { j->f_side.push_back(fs[i]); j->f_index.push_back(fi[i]); } }
     *out = new dfgpu_plan{j};
   });
 }

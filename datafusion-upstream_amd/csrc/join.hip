@@ -565,6 +565,14 @@ static bool pj_domain_is_sparse(dfgpu_ctx* ctx, dfgpu_join_table* t) {
 
 }  // namespace dfgpu
 
+// ---- NestedLoopJoinExec: the candidate pairs of left rows [first, first + count) x every right row, left-major
+// (build_join_indices, joins/nested_loop_join.rs:405-432: left = [i, i, .., i], right = [0, 1, .., n_right) for every left row i in order)
+template <typename L, typename R>
+__global__ void __launch_bounds__(BLOCK) k_cross_indices(int64_t first, int64_t n_right, int64_t total, L* __restrict__ left, R* __restrict__ right) {
+  int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (k >= total) return;
+  int64_t i = k / n_right; left[k] = (L)(first + i); right[k] = (R)(k - i * n_right);
+}
+
 extern "C" {
 
 dfgpu_status dfgpu_join_build(dfgpu_ctx* ctx, const dfgpu_array* const* keys, int32_t nkeys, const dfgpu_array* opt_mask,
@@ -838,6 +846,24 @@ dfgpu_status dfgpu_join_adjust_indices(dfgpu_ctx* ctx, const dfgpu_array* build_
   });
 }
 
+dfgpu_status dfgpu_cross_join_indices(dfgpu_ctx* ctx, int64_t first_left, int64_t count_left, int64_t n_right, int32_t left_is_u64, dfgpu_array** out_left, dfgpu_array** out_right) {
+  return guard(ctx, [&] {
+    if (!out_left || !out_right || first_left < 0 || count_left < 0 || n_right < 0) fail(DFGPU_INVALID_ARGUMENT, "cross_join_indices: bad argument");
+    const int64_t total = count_left * n_right;
+    if (total > (int64_t)1 << 31) fail(DFGPU_INVALID_ARGUMENT, "cross_join_indices: %lld pairs in one call, split the left rows", (long long)total);
+    if ((left_is_u64 ? n_right : first_left + count_left) > 0xFFFFFFFFll) fail(DFGPU_NOT_IMPLEMENTED, "cross_join_indices: more than 2^32 rows on the UInt32 side");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    ArrayHolder l(new_fixed(ctx, left_is_u64 ? DFGPU_UINT64 : DFGPU_UINT32, total)), r(new_fixed(ctx, left_is_u64 ? DFGPU_UINT32 : DFGPU_UINT64, total));
+    if (total) {
+      KernelTimer kt(ctx, "k_cross_indices");
+      if (left_is_u64) hipLaunchKernelGGL((k_cross_indices<uint64_t, uint32_t>), dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, ctx->stream, first_left, n_right, total, (uint64_t*)l.get()->values->ptr, (uint32_t*)r.get()->values->ptr);
+      else hipLaunchKernelGGL((k_cross_indices<uint32_t, uint64_t>), dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, ctx->stream, first_left, n_right, total, (uint32_t*)l.get()->values->ptr, (uint64_t*)r.get()->values->ptr);
+      KERNEL_CHECK();
+    }
+    *out_left = l.release(); *out_right = r.release();
+  });
+}
+
 }  // extern "C"
 
 namespace dfgpu {
@@ -851,4 +877,5 @@ void launch_set_bits_prefix(dfgpu_ctx* ctx, uint64_t* bits, int64_t m) {
   hipLaunchKernelGGL(k_set_bits_prefix, dim3(grid_for((m + 63) / 64, BLOCK)), dim3(BLOCK), 0, ctx->stream, bits, m);
   KERNEL_CHECK();
 }
+
 }  // namespace dfgpu

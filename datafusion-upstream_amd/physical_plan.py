@@ -547,6 +547,40 @@ class HashJoinExec(ExecutionPlan):
         return self._new(out)
 
 
+class NestedLoopJoinExec(ExecutionPlan):
+    """≙ NestedLoopJoinExec (joins/nested_loop_join.rs:84): join without equi-keys; `filter` = JoinFilter or None (cross join)."""
+
+    def __init__(self, left, right, filter: Optional[JoinFilter], join_type: str):
+        if join_type not in JOIN_TYPES:
+            raise DfgpuError(5, f"unknown join type {join_type}")
+        self.left, self.right, self.filter, self.join_type = left, right, filter, join_type
+
+    def children(self):
+        return [self.left, self.right]
+
+    def output_partitioning(self):
+        build_left = self.join_type in ("Right", "RightSemi", "RightAnti", "Full")
+        return (self.right if build_left else self.left).output_partitioning()
+
+    def schema(self):
+        ls, rs = self.left.schema().fields, self.right.schema().fields
+        if self.join_type in ("LeftSemi", "LeftAnti"):
+            return Schema(list(ls))
+        if self.join_type in ("RightSemi", "RightAnti"):
+            return Schema(list(rs))
+        return Schema(list(ls) + list(rs))
+
+    def _build(self, context):
+        ctx = context.ctx
+        f = self.filter
+        sides = (C.c_int32 * max(1, len(f.column_indices) if f else 1))(*([0 if s == "left" else 1 for s, _ in f.column_indices] if f else [0]))
+        idxs = (C.c_int32 * max(1, len(f.column_indices) if f else 1))(*([i for _, i in f.column_indices] if f else [0]))
+        out = C.c_void_p()
+        _check(_lib().dfgpu_plan_nested_loop_join(_child_handle(self.left, context).h, _child_handle(self.right, context).h, f.expression.handle(ctx).h if f else None,
+                                                  sides, idxs, len(f.column_indices) if f else 0, JOIN_TYPES[self.join_type], C.byref(out)))
+        return self._new(out)
+
+
 @dataclass
 class AggregateFunctionExpr:
     fun: str

@@ -250,6 +250,12 @@ DFGPU_API dfgpu_status dfgpu_join_mark_visited(dfgpu_ctx *ctx, dfgpu_join_table 
 DFGPU_API dfgpu_status dfgpu_join_adjust_indices(dfgpu_ctx *ctx, const dfgpu_array *build_idx, const dfgpu_array *probe_idx,
                                                  int64_t range_start, int64_t range_end, int32_t join_type,
                                                  dfgpu_array **out_build_idx, dfgpu_array **out_probe_idx);
+/* ≙ build_join_indices of NestedLoopJoinExec (joins/nested_loop_join.rs:405-432) for a run of left rows: the candidate pairs of left rows
+ * [first_left, first_left + count_left) with every right row [0, n_right), left-major.  The side that is collected (the inner table) gets UInt64
+ * indices, the streamed side UInt32, like the build / probe indices of dfgpu_join_probe: left_is_u64 = 1 when the left input is the collected side
+ * (Right / RightSemi / RightAnti / Full, nested_loop_join.rs:373-378).  At most 2^31 pairs per call. */
+DFGPU_API dfgpu_status dfgpu_cross_join_indices(dfgpu_ctx *ctx, int64_t first_left, int64_t count_left, int64_t n_right, int32_t left_is_u64,
+                                                dfgpu_array **out_left, dfgpu_array **out_right);
 /* ≙ get_final_indices_from_bit_map (joins/utils.rs:1119-1141): ascending build indices that are
  * unmatched (Left/Full/LeftAnti) or matched (LeftSemi); probe side is all NULL. */
 DFGPU_API dfgpu_status dfgpu_join_final_indices(dfgpu_ctx *ctx, const dfgpu_join_table *t, int32_t join_type, dfgpu_array **out_build_idx);

@@ -77,6 +77,10 @@ DFGPU_API dfgpu_status dfgpu_plan_repartition(const dfgpu_plan *input, const dfg
 DFGPU_API dfgpu_status dfgpu_plan_hash_join(const dfgpu_plan *left, const dfgpu_plan *right, const dfgpu_expr *const *on_left, const dfgpu_expr *const *on_right,
                                             int32_t non, const dfgpu_expr *filter, const int32_t *filter_sides, const int32_t *filter_indices, int32_t nfilter_cols,
                                             int32_t join_type, int32_t mode, int32_t null_equals_null, dfgpu_plan **out);
+/* NestedLoopJoinExec::try_new(left, right, filter, join_type) (joins/nested_loop_join.rs:102-127): no equi-join keys; the side named by left_is_build_side
+ * (:373-378) is collected, the other side streams and decides the output partitioning.  JoinFilter as for dfgpu_plan_hash_join (NULL = cross join). */
+DFGPU_API dfgpu_status dfgpu_plan_nested_loop_join(const dfgpu_plan *left, const dfgpu_plan *right, const dfgpu_expr *filter, const int32_t *filter_sides, const int32_t *filter_indices,
+                                                   int32_t nfilter_cols, int32_t join_type, dfgpu_plan **out);
 /* AggregateExec::try_new(mode, group_by, aggr_expr, input): mode 0 Partial, 1 Final, 2 FinalPartitioned, 3 Single,
  * 4 SinglePartitioned.  Aggregate i: kind DFGPU_AGG_*, argument expr (NULL = COUNT(*)), optional FILTER expr, output name,
  * argument data type (type, precision, scale) as the AggregateExpr knows it in every mode. */

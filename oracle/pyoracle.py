@@ -406,3 +406,63 @@ def tpch_q3(t: dict, segment_code: int, date_cut: int, target_partitions: int = 
            "o_shippriority": np.ctypeslib.as_array(out.o_shippriority, (n,)).copy() if n else np.zeros(0, np.int32)}
     lib().dfo_q3_output_free(C.byref(out))
     return res
+
+
+# ------------------------------------------------------------------ NestedLoopJoinExec (joins/nested_loop_join.rs), small inputs only: plain Python / numpy loops
+def nested_loop_join(left_batches, right_batches, filter_cols, filter_fn, join_type: str):
+    """left_batches / right_batches: lists of batches, a batch = list of pyarrow arrays.  filter_cols: [("left" | "right", column index)] = JoinFilter::column_indices,
+    filter_fn(list of intermediate arrays) -> Boolean array (None = no filter).  Returns the output batches in stream order.
+    Follows poll_next_impl_for_build_left / _build_right (:434-583): the side named by left_is_build_side (:373-378) is concatenated, every batch of the
+    other side gives one output batch -- build_join_indices (:405-432) per left row, adjust_indices_by_join_type (:652-708) per batch -- and Full ends with
+    the left rows no batch matched (get_final_indices_from_bit_map, joins/utils.rs:1119-1141)."""
+    build_left = join_type in ("Right", "RightSemi", "RightAnti", "Full")
+    cat = lambda batches: [pa.concat_arrays([b[c] for b in batches]) for c in range(len(batches[0]))] if batches else []
+    inner = cat(left_batches if build_left else right_batches)
+    outer = right_batches if build_left else left_batches
+    nrows = lambda b: len(b[0]) if b else 0
+    take = lambda arr, idx: arr.take(pa.array(idx, type=pa.int64()))
+
+    def out_batch(lb, rb, li, ri):
+        cols = []
+        if join_type not in ("RightSemi", "RightAnti"):
+            cols += [take(c, li) for c in lb]
+        if join_type not in ("LeftSemi", "LeftAnti"):
+            cols += [take(c, ri) for c in rb]
+        return cols
+
+    visited = [False] * nrows(inner) if join_type == "Full" else None
+    out = []
+    for ob in outer:
+        lb, rb = (inner, ob) if build_left else (ob, inner)
+        nl, nr = nrows(lb), nrows(rb)
+        li, ri = [], []
+        for i in range(nl):                                    # build_join_indices per left row
+            l, r = [i] * nr, list(range(nr))
+            if filter_fn is not None and nr:
+                inter = [take(lb[c] if side == "left" else rb[c], l if side == "left" else r) for side, c in filter_cols]
+                m = filter_fn(inter).to_pylist()
+                l = [x for x, k in zip(l, m) if k]; r = [x for x, k in zip(r, m) if k]         # NULL counts as false (apply_join_filter_to_indices)
+            li += l; ri += r
+        if visited is not None:
+            for x in li:
+                visited[x] = True
+        anti = lambda n, idx: [x for x in range(n) if x not in set(idx)]
+        semi = lambda n, idx: [x for x in range(n) if x in set(idx)]
+        if join_type == "Left":
+            un = anti(nl, li); li, ri = li + un, ri + [None] * len(un)
+        elif join_type == "LeftSemi":
+            li = semi(nl, li)
+        elif join_type == "LeftAnti":
+            li = anti(nl, li)
+        elif join_type in ("Right", "Full"):
+            un = anti(nr, ri); li, ri = li + [None] * len(un), ri + un
+        elif join_type == "RightSemi":
+            ri = semi(nr, ri)
+        elif join_type == "RightAnti":
+            ri = anti(nr, ri)
+        out.append(out_batch(lb, rb, li, ri))
+    if join_type == "Full":
+        un = [i for i, v in enumerate(visited) if not v]
+        rtypes = [c.type for c in right_batches[0]] if right_batches else []
+        out.append([take(c, un) for c in inner] + [pa.nulls(len(un), t) for t in rtypes])
+    return out

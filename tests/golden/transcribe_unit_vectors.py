@@ -3,6 +3,7 @@
                                                        Decimal128 columns (array op array, array op scalar), Kleene AND / OR, the six comparisons and
                                                        IS [NOT] DISTINCT FROM over Boolean columns with NULLs, Decimal128 comparisons
   in_list   physical-expr/src/expressions/in_list.rs   IN / NOT IN over Utf8, Int64, Float64 (NaN, -NaN), Boolean, Date32, Decimal128 with and without a NULL in the list
+  nested_loop_join physical-plan/src/joins/nested_loop_join.rs   the eight join types with a JoinFilter (rows compared sorted, as assert_batches_sorted_eq does)
   sort      physical-plan/src/sorts/sort.rs            test_in_mem_sort (4 x make_partition(100)), test_sort_metadata
   repartition physical-plan/src/repartition/mod.rs     RoundRobinBatch batch counts, Hash row conservation
 Mixed-type comparisons of the same tests (Int64 / Float64 column against a Decimal128 literal) go through the planner's coercion and are left out.
@@ -122,6 +123,21 @@ for lst, neg, exp in (([1000000, 2000000], False, [T, N, F]), ([1000000, 2000000
                       ([v * 10000 for v in range(99, 300)], False, [T, N, F]), ([v * 10000 for v in range(99, 300)], True, [F, N, T])):
     inl(f"{'not_' if neg else ''}in_list_decimal_{len(in_list)}", "977-1075", DT, [1000000, N, 2005000], lst, neg, exp)
 
+# ---- NestedLoopJoinExec (physical-plan/src/joins/nested_loop_join.rs:772-1130): left (a1, b1, c1), right (a2, b2, c2), filter left.b1 != 8 AND right.b2 != 10
+NL = "datafusion/physical-plan/src/joins/nested_loop_join.rs:"
+nlj = {"left": {"ref": NL + "782-788", "columns": {"a1": [5, 9, 11], "b1": [5, 8, 8], "c1": [50, 90, 110]}}, "right": {"ref": NL + "790-796", "columns": {"a2": [12, 2, 10], "b2": [10, 2, 10], "c2": [40, 80, 100]}},
+       "filter": {"ref": NL + "798-840", "column_indices": [["left", 1], ["right", 1]], "expression": "x0 != 8 AND x1 != 10"},
+       "cases": [
+           {"name": "join_inner_with_filter", "ref": NL + "892-917", "join_type": "Inner", "expected_sorted": [[5, 5, 50, 2, 2, 80]]},
+           {"name": "join_left_with_filter", "ref": NL + "920-948", "join_type": "Left", "expected_sorted": [[11, 8, 110, N, N, N], [5, 5, 50, 2, 2, 80], [9, 8, 90, N, N, N]]},
+           {"name": "join_right_with_filter", "ref": NL + "951-979", "join_type": "Right", "expected_sorted": [[N, N, N, 10, 10, 100], [N, N, N, 12, 10, 40], [5, 5, 50, 2, 2, 80]]},
+           {"name": "join_full_with_filter", "ref": NL + "982-1012", "join_type": "Full", "expected_sorted": [[N, N, N, 10, 10, 100], [N, N, N, 12, 10, 40], [11, 8, 110, N, N, N], [5, 5, 50, 2, 2, 80], [9, 8, 90, N, N, N]]},
+           {"name": "join_left_semi_with_filter", "ref": NL + "1015-1041", "join_type": "LeftSemi", "expected_sorted": [[5, 5, 50]]},
+           {"name": "join_left_anti_with_filter", "ref": NL + "1044-1071", "join_type": "LeftAnti", "expected_sorted": [[11, 8, 110], [9, 8, 90]]},
+           {"name": "join_right_semi_with_filter", "ref": NL + "1074-1100", "join_type": "RightSemi", "expected_sorted": [[2, 2, 80]]},
+           {"name": "join_right_anti_with_filter", "ref": NL + "1103-1130", "join_type": "RightAnti", "expected_sorted": [[10, 10, 100], [12, 10, 40]]},
+       ]}
+
 S = "datafusion/physical-plan/src/sorts/sort.rs:"
 sort = [
     {"name": "test_in_mem_sort", "ref": S + "1022-1049 (test::scan_partitioned(4): 4 partitions of make_partition(100), column i = 0..100)", "type": "int32",
@@ -135,6 +151,6 @@ repartition = [
     {"name": "many_to_many_round_robin", "ref": R + "989-1007", "inputs": [50, 50, 50], "scheme": "RoundRobinBatch", "n": 5, "expected_batches": [30, 30, 30, 30, 30]},
     {"name": "many_to_many_hash_partition", "ref": R + "1010-1033", "inputs": [50, 50, 50], "scheme": "Hash", "n": 8, "expected_total_rows": 8 * 50 * 3},
 ]
-json.dump({"binary": cases, "in_list": in_list, "sort": sort, "repartition": {"batch": {"ref": R + "1440-1447 create_batch", "type": "uint32", "column": "c0", "values": [1, 2, 3, 4, 5, 6, 7, 8]}, "cases": repartition}},
+json.dump({"binary": cases, "in_list": in_list, "nested_loop_join": nlj, "sort": sort, "repartition": {"batch": {"ref": R + "1440-1447 create_batch", "type": "uint32", "column": "c0", "values": [1, 2, 3, 4, 5, 6, 7, 8]}, "cases": repartition}},
           open(__file__.rsplit("/", 1)[0] + "/unit_vectors.json", "w"), indent=1)
 print(len(cases), "binary cases,", len(in_list), "in_list cases")
