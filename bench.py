@@ -106,7 +106,7 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--no-workloads", action="store_true", help="N = 1: skip the nested other plan shapes (bench_workloads.py)")
-    ap.add_argument("--workloads", default="q1_decimal,q1_float64,q5,q18,hash_join,groupby_int64,sort,partition,clickbench_uniform_1000000,clickbench_zipf_1000000",
+    ap.add_argument("--workloads", default="q1_decimal,q1_float64,q5,q18,hash_join,groupby_int64,sort,partition,parquet_scan,clickbench_uniform_1000000,clickbench_zipf_1000000",
                     help="N = 1: which plan shapes of bench_workloads.py to nest under \"workloads\"")
     ap.add_argument("--native-exchange", action="store_true", help="N > 1 workloads: ShuffleExec through the C entry point dfgpu_exchange (RCCL inside libdfgpu.so) instead of torch.distributed collectives")
     ap.add_argument("--plan", choices=["colocated", "broadcast", "shuffle"], default="shuffle",
@@ -314,7 +314,7 @@ def main():
             torch.cuda.empty_cache()
             res = bench_workloads.run(_ap.Namespace(sf=args.sf, steps=3, warmup=2, only=args.workloads), ctx=ctx, emit=False)
             workloads = {r["workload"]: {k: r[k] for k in ("input_rows", "result_rows", "ms_per_step", "rows_per_s", "algorithmic_GBps", "frac_of_hbm_peak", "algorithmic_bytes_per_row", "roofline", "host_syncs_per_step") if k in r}
-                         | {"kernel_ms_per_step": dict(list(r["kernel_ms_per_step"].items())[:8])} | {k: r[k] for k in r if k in ("cardinality", "build_rows", "probe_rows", "partitions", "exchange")} for r in res}
+                         | {"kernel_ms_per_step": dict(list(r["kernel_ms_per_step"].items())[:8])} | {k: r[k] for k in r if k in ("cardinality", "build_rows", "probe_rows", "partitions", "exchange", "file_bytes", "decoded_bytes", "decoded_GBps", "file_GBps", "from_host_image_ms", "from_host_image_decoded_GBps", "row_groups")} for r in res}
     else:
         # the other two distribution plans, after the timed region (every rank takes part: they hold collectives)
         other_plans = {}

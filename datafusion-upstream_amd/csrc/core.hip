@@ -326,6 +326,7 @@ dfgpu_status dfgpu_ctx_get_option(dfgpu_ctx* ctx, const char* key, int64_t* out)
     else if (k == "sort_packed_keys") *out = ctx->sort_packed_keys;
     else if (k == "memory_limit") *out = ctx->memory_limit;
     else if (k == "collect_metrics") *out = ctx->collect_metrics;
+    else if (k == "agg_preaggregate_distinct") *out = ctx->pa_last_distinct;      // read only
     else if (k == "live_bytes") *out = (int64_t)ctx->live_bytes;              // read only: device bytes held by live buffers of this ctx
     else if (k == "cached_bytes") *out = (int64_t)ctx->cached_bytes;          // read only: freed blocks kept for reuse
     else if (k == "agg_partitioned") *out = ctx->agg_partitioned;
@@ -498,6 +499,16 @@ dfgpu_status dfgpu_array_new_zeros(dfgpu_ctx* ctx, int32_t type, int32_t precisi
   });
 }
 
+dfgpu_status dfgpu_array_iota(dfgpu_ctx* ctx, int64_t length, dfgpu_array** out) {
+  return guard(ctx, [&] {
+    if (!out || length < 0 || length > 0xFFFFFFF0ll) fail(DFGPU_INVALID_ARGUMENT, "array_iota: bad argument");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    ArrayHolder h(new_fixed(ctx, DFGPU_UINT32, length));
+    launch_iota_u32(ctx, (uint32_t*)h.get()->values->ptr, length, 0);
+    h.get()->identity = true;
+    *out = h.release();
+  });
+}
 dfgpu_status dfgpu_array_slice(dfgpu_ctx* ctx, const dfgpu_array* a, int64_t offset, int64_t length, dfgpu_array** out) {
   return guard(ctx, [&] {
     if (offset < 0 || length < 0 || offset + length > a->length) fail(DFGPU_INVALID_ARGUMENT, "slice [%lld, +%lld) outside array of %lld rows", (long long)offset, (long long)length, (long long)a->length);

@@ -979,7 +979,7 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
   }
   // dfgpu_agg_preaggregate over one batch, then intern + merge_batch of its partial rows.  false = shape not taken, nothing accumulated.
   template <typename Ensure>
-  bool preaggregate(const TaskContext& tc, Batch& b, const std::vector<bool>& deferred, Ensure&& ensure, const dfgpu_array* key, const ArrayRef& mask, GroupsRef& groups, std::vector<AccRef>& accs) const {
+  bool preaggregate(const TaskContext& tc, Batch& b, const std::vector<bool>& deferred, Ensure&& ensure, const dfgpu_array* key, const ArrayRef& mask, GroupsRef& groups, std::vector<AccRef>& accs, ArrayRef* pending) const {
     std::vector<ArrayRef> vals(aggs.size()); std::vector<const dfgpu_array*> vp; std::vector<int32_t> kinds;
     for (auto& a : aggs) if (a.filter) return false;
     // the key column decides (type, clustering, number of groups): ask before any computed argument is evaluated for it
@@ -998,14 +998,23 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
     if (rc == DFGPU_NOT_IMPLEMENTED) return false;
     tc.check(rc);
     ArrayRef pkeys = ArrayRef::adopt(pk); std::vector<ArrayRef> states; for (auto* x : st) states.push_back(ArrayRef::adopt(x));
-    const dfgpu_array* kp = pkeys.a; dfgpu_array* ids = nullptr;
-    tc.check(dfgpu_groups_intern(tc.ctx, groups.g, &kp, 1, nullptr, &ids)); ArrayRef gids = ArrayRef::adopt(ids);
-    int64_t total = dfgpu_groups_len(groups.g);
+    // A FIRST batch whose partial rows hold every key once (in first-seen order) needs no hash table to number its groups: ids are 0, 1, ..; the keys wait
+    // in `pending` and are interned only if another batch follows (merge_partial with pending == nullptr), else they are emitted as they are.
+    int64_t distinct = 0, fs = 1; dfgpu_ctx_get_option(tc.ctx, "agg_preaggregate_distinct", &distinct); dfgpu_ctx_get_option(tc.ctx, "first_seen_group_order", &fs); distinct = distinct && fs;
+    if (pending && distinct && dfgpu_groups_len(groups.g) == 0 && !*pending) { *pending = pkeys; merge_partial(tc, ArrayRef(), states, pkeys.len(), groups, accs); return true; }
+    merge_partial(tc, pkeys, states, 0, groups, accs);
+    return true;
+  }
+  // intern the partial rows' keys (or take ids 0 .. n-1 when `keys` is empty) and merge their states
+  void merge_partial(const TaskContext& tc, const ArrayRef& keys, const std::vector<ArrayRef>& states, int64_t n_ids, GroupsRef& groups, std::vector<AccRef>& accs) const {
+    dfgpu_array* ids = nullptr; int64_t total;
+    if (keys) { const dfgpu_array* kp = keys.a; tc.check(dfgpu_groups_intern(tc.ctx, groups.g, &kp, 1, nullptr, &ids)); total = dfgpu_groups_len(groups.g); }
+    else { tc.check(dfgpu_array_iota(tc.ctx, n_ids, &ids)); total = n_ids; }
+    ArrayRef gids = ArrayRef::adopt(ids);
     for (size_t i = 0; i < aggs.size(); i++) {
       const dfgpu_array* sp[2] = { states[2 * i].a, states[2 * i + 1].a };
       tc.check(dfgpu_acc_merge_batch(tc.ctx, accs[i].a, sp, aggs[i].kind == DFGPU_AGG_AVG ? 2 : 1, gids.a, nullptr, total));
     }
-    return true;
   }
   // evaluate_group_by + the per-set loop of group_aggregate_batch (aggregates/mod.rs:1161-1200, row_hash.rs:540-600): keys and accumulator
   // arguments are evaluated once per batch; every grouping set interns its own key tuples (masked keys come from null_exprs) into the
@@ -1061,8 +1070,16 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
       int32_t t = aggs[i].kind == DFGPU_AGG_COUNT ? DFGPU_INT64 : aggs[i].type;
       tc.check(dfgpu_acc_new(tc.ctx, aggs[i].kind, t, aggs[i].precision, aggs[i].scale, &accs[i].a));
     }
+    ArrayRef pending;             // keys of a first, fully pre-aggregated batch that no hash table holds yet (ids 0 .. n-1)
+    auto settle_pending = [&]() {  // another batch follows: the keys go into the table after all; first-seen interning of distinct keys numbers them 0 .. n-1 again
+      if (!pending) return;
+      const dfgpu_array* kp = pending.a; dfgpu_array* ids = nullptr; tc.check(dfgpu_groups_intern(tc.ctx, groups.g, &kp, 1, nullptr, &ids)); ArrayRef drop = ArrayRef::adopt(ids);
+      if (dfgpu_groups_len(groups.g) != pending.len()) fail(DFGPU_INTERNAL, "AggregateExec: pre-aggregated keys were not distinct");
+      pending = ArrayRef();
+    };
     for (auto& b_in : in) {       // group_aggregate_batch (row_hash.rs:524-613)
       if (b_in.base_rows == 0) continue;
+      settle_pending();
       Batch raw; std::vector<bool> deferred;
       if (pj) { raw = b_in; b_in = pj->project(tc, raw, &deferred); }
       Batch& b = b_in;
@@ -1093,7 +1110,7 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
         }
         // A large batch of high-cardinality keys is first reduced to one row per group partition by partition out of LDS (the Partial stage
         // of a two-phase plan, applied inside the operator): its partial rows are then interned and MERGED like the Final stage does.
-        if (!merging() && gp.size() == 1 && b.base_rows >= preagg_min_rows && preaggregate(tc, b, deferred, ensure, gp[0], mask, groups, accs)) continue;
+        if (!merging() && gp.size() == 1 && b.base_rows >= preagg_min_rows && preaggregate(tc, b, deferred, ensure, gp[0], mask, groups, accs, &pending)) continue;
         dfgpu_array* ids = nullptr; tc.check(dfgpu_groups_intern_deferred(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids)); gids = ArrayRef::adopt(ids);      // only the accumulators read them
         total = dfgpu_groups_len(groups.g);
       } else { dfgpu_array* z = nullptr; tc.check(dfgpu_array_new_zeros(tc.ctx, DFGPU_UINT32, 0, 0, b.base_rows, &z)); gids = ArrayRef::adopt(z); }
@@ -1123,11 +1140,11 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
         tc.check(dfgpu_acc_update_batch_multi(tc.ctx, ap.data(), vp.data(), fp.data(), (int32_t)ap.size(), gids.a, total));
       }
     }
-    std::vector<Batch> outv; int64_t total = grouped ? dfgpu_groups_len(groups.g) : 1;     // no GROUP BY: always one row, even on empty input
+    std::vector<Batch> outv; int64_t total = grouped ? (pending ? pending.len() : dfgpu_groups_len(groups.g)) : 1;     // no GROUP BY: always one row, even on empty input
     if (total > 0) {              // emit(EmitTo::All) (row_hash.rs:626-662)
       Batch o; o.base_rows = total; std::vector<dfgpu_array*> keys(gexprs.size(), nullptr);
-      if (grouped) tc.check(dfgpu_groups_emit(tc.ctx, groups.g, keys.data()));
-      for (auto k : keys) o.cols.push_back(col_of(ArrayRef::adopt(k)));
+      if (grouped && pending) o.cols.push_back(col_of(pending));          // one key column, already in first-seen order
+      else { if (grouped) tc.check(dfgpu_groups_emit(tc.ctx, groups.g, keys.data())); for (auto k : keys) o.cols.push_back(col_of(ArrayRef::adopt(k))); }
       dfgpu_array_desc ed{}; ed.type = DFGPU_UINT32; ed.values = &ed; dfgpu_array* e = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &ed, &e)); ArrayRef empty_ids = ArrayRef::adopt(e);
       for (size_t i = 0; i < aggs.size(); i++) {
         tc.check(dfgpu_acc_update_batch(tc.ctx, accs[i].a, nullptr, empty_ids.a, nullptr, total));      // zero-row update: grow the state to `total` groups

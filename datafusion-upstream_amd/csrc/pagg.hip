@@ -62,7 +62,7 @@ __global__ void k_pa_max_len(const uint32_t* pstart, uint32_t P, unsigned long l
 // that equals the EMPTY marker.  Rows are taken PA_NT at a time with a barrier in between; before a chunk the table is flushed if the
 // chunk could fill it beyond 7/8.
 __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, const uint32_t* prow, PaPlan plan_arg, const uint32_t* pstart, int cbits, uint32_t slice,
-                                                      uint64_t* okey, uint32_t* ofirst, uint32_t* ocnt, unsigned long long* cursor) {
+                                                      uint64_t* okey, uint32_t* ofirst, uint32_t* ocnt, unsigned long long* cursor /*[0] rows written, [2] tables flushed before their partition ended*/) {
   extern __shared__ unsigned long long pa_lds[];
   const uint32_t C = 1u << cbits, M = C - 1, C1 = C + 1;
   unsigned long long* keys = pa_lds; unsigned long long* acc = pa_lds + C1;
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
 #pragma unroll
     for (int a = 0; a < PA_MAX_AGGS; a++) vn[a] = a < na ? plan_arg.val[a][ic] : 0; }
   for (uint32_t i0 = q0; i0 < q1; i0 += PA_NT) {
-    if (nfilled + PA_NT > C - C / 8) { __syncthreads(); flush(); reset(); __syncthreads(); }      // nfilled is only written between barriers: uniform
+    if (nfilled + PA_NT > C - C / 8) { __syncthreads(); flush(); reset(); if (threadIdx.x == 0) atomicAdd(cursor + 2, 1ull); __syncthreads(); }      // nfilled is only written between barriers: uniform
     const uint32_t i = i0 + threadIdx.x; const bool on = i < q1;
     const uint64_t k = kn; const uint32_t row = rn; uint64_t v[PA_MAX_AGGS];
 #pragma unroll
@@ -162,6 +162,26 @@ __global__ void __launch_bounds__(BLOCK) k_pa_sample(const T* keys, const uint64
   if (lane_id() == 0) { sh[0][threadIdx.x >> 6] = nf; sh[1][threadIdx.x >> 6] = nn; sh[2][threadIdx.x >> 6] = np; }
   __syncthreads();
   if (threadIdx.x < 3) { uint32_t t = 0; for (int w = 0; w < BLOCK / WAVE; w++) t += sh[threadIdx.x][w]; if (t) atomicAdd(&out[threadIdx.x], (unsigned long long)t); }
+}
+
+// ---- two-level partition (more groups than 2048 partitions bring into LDS): pass 1 splits on the high hash bits into P1 partitions, pass 2 is a STABLE
+// split of pass 1's output on the low hash bits into P2 <= 256 -- an LSD radix sort on two digits, so the rows end up ordered by (p2, p1): P1 * P2
+// contiguous partitions.  Their boundaries are read off the partitioned keys.
+struct RpHashU64Low {
+  const uint64_t* keys;
+  __device__ inline bool operator()(int64_t i, uint32_t P, uint32_t* pid, uint64_t* key) const { *key = keys[i]; *pid = (uint32_t)(((mix64(*key) & 0xFFFFFFFFull) * (uint64_t)P) >> 32); return true; }
+};
+__device__ inline uint32_t pa_fine_pid(uint64_t k, uint32_t P1, uint32_t P2) { uint64_t h = mix64(k); return (uint32_t)(((h & 0xFFFFFFFFull) * (uint64_t)P2) >> 32) * P1 + rp_pid(h, P1); }
+__global__ void __launch_bounds__(BLOCK) k_pa_bounds(const uint64_t* __restrict__ pkey, int64_t m, uint32_t P1, uint32_t P2, uint32_t* __restrict__ first /*[P1 * P2], preset to ~0*/, uint32_t* unsorted) {
+  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i >= m) return;
+  uint32_t f = pa_fine_pid(pkey[i], P1, P2), fp = i ? pa_fine_pid(pkey[i - 1], P1, P2) : 0xFFFFFFFFu;
+  if (i == 0 || f != fp) first[f] = (uint32_t)i;
+  if (i && f < fp) *unsorted = 1;
+}
+__global__ void __launch_bounds__(BLOCK) k_pa_bounds_fill(const uint32_t* __restrict__ first, uint32_t Pt, uint32_t m, uint32_t* __restrict__ starts /*[Pt + 1]*/) {
+  uint32_t p = blockIdx.x * BLOCK + threadIdx.x; if (p > Pt) return;
+  uint32_t q = p; while (q < Pt && first[q] == 0xFFFFFFFFu) q++;              // an empty partition starts where the next non-empty one does
+  starts[p] = q < Pt ? first[q] : m;
 }
 
 template <typename T> __global__ void __launch_bounds__(BLOCK) k_pa_gather_key(const uint64_t* src, const uint32_t* perm, int64_t m, T* out) {
@@ -241,30 +261,51 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     if (D > (double)n) D = (double)n;
     if (!ctx->agg_partitioned_force) {
       if (D < 3000) skip("few groups (the LDS cache of the accumulators holds them)");
-      if (D > 4.5e6) skip("more groups than one partition pass brings into LDS (a fan-out beyond 2048 costs more than it saves)");
+      if (D > (double)n / 3.0) skip("fewer than three rows per group (pre-aggregation would not reduce the batch)");
     }
     if (verdict_only) return;
     const int cell_bytes = 16 + 8 * plan.n_acc; int cbits = 12; while (cbits > 6 && (((size_t)1 << cbits) + 1) * cell_bytes > 150 * 1024) cbits--;
     const double per_part = ((double)(1u << cbits)) * 0.55;
     const double Dp = D > 4.0 * d ? D : 4.0 * d;          // skewed keys: the uniform model underestimates the tail, stay on the many-partitions side
-    int64_t P = (int64_t)(Dp / per_part) + 1; if (P < 64) P = 64; if (P > 2048) P = 2048; if (P > n / 2048 + 1) P = n / 2048 + 1;
-    if (P > ctx->num_cus) P = std::min<int64_t>(2048, (P + ctx->num_cus - 1) / ctx->num_cus * ctx->num_cus);
+    int64_t P = (int64_t)(Dp / per_part) + 1; if (P < 64) P = 64;
+    // beyond 2048 partitions one pass writes bursts too short to pay (measured: P = 8192 slower than the atomics it replaces): two passes, P1 x P2
+    const bool two_level = P > 2048;
+    int64_t P1 = P, P2 = 1;
+    if (two_level) { P2 = P > 2048 * 128 ? 256 : 128; P1 = (P + P2 - 1) / P2; if (P1 < 16) P1 = 16; if (P1 > 2048) P1 = 2048; P = P1 * P2; }
+    else { if (P > n / 2048 + 1) P = n / 2048 + 1; if (P > ctx->num_cus) P = std::min<int64_t>(2048, (P + ctx->num_cus - 1) / ctx->num_cus * ctx->num_cus); P1 = P; }
     // ---- partition (key, row, value cells)
     BufferPtr pkey = alloc_buffer(ctx, (size_t)n * 8), prow = alloc_buffer(ctx, (size_t)n * 4); std::vector<BufferPtr> pval((size_t)plan.n_acc);
     RpCols cols{}; cols.n = 1 + plan.n_acc; cols.rowid_dst = (uint32_t*)prow->ptr;
     cols.c[0] = RpCol{ key->values->ptr, pkey->ptr, 8, RP_HASHKEY, ktype };
     for (int c = 0; c < plan.n_acc; c++) { pval[(size_t)c] = alloc_buffer(ctx, (size_t)n * 8); cols.c[1 + c] = RpCol{ cell_src[c]->values->ptr, pval[(size_t)c]->ptr, 8, RP_RAW, 0 }; plan.val[c] = (const uint64_t*)pval[(size_t)c]->ptr; }
     RpResult r;
-#define PA_PART(T) r = rp_partition(ctx, RpHashInt<T>{ (const T*)key->values->ptr, nullptr, mk }, n, (uint32_t)P, cols, false, ctx->d_scratch64 + 9, "pa_hist", "pa_scan", "pa_scatter")
+#define PA_PART(T) r = rp_partition(ctx, RpHashInt<T>{ (const T*)key->values->ptr, nullptr, mk }, n, (uint32_t)P1, cols, false, ctx->d_scratch64 + 9, "pa_hist", "pa_scan", "pa_scatter")
     switch (ktype) { case DFGPU_INT64: case DFGPU_UINT64: PA_PART(int64_t); break; case DFGPU_UINT32: PA_PART(uint32_t); break; default: PA_PART(int32_t); break; }
 #undef PA_PART
+    if (two_level) {
+      const int64_t m1 = mk ? (int64_t)read_scratch(ctx, 9) : n;          // rows the selection kept
+      BufferPtr pkey2 = alloc_buffer(ctx, (size_t)n * 8), prow2 = alloc_buffer(ctx, (size_t)n * 4); std::vector<BufferPtr> pval2((size_t)plan.n_acc);
+      RpCols c2{}; c2.n = 2 + plan.n_acc;
+      c2.c[0] = RpCol{ pkey->ptr, pkey2->ptr, 8, RP_RAW, 0 }; c2.c[1] = RpCol{ prow->ptr, prow2->ptr, 4, RP_RAW, 0 };
+      for (int c = 0; c < plan.n_acc; c++) { pval2[(size_t)c] = alloc_buffer(ctx, (size_t)n * 8); c2.c[2 + c] = RpCol{ pval[(size_t)c]->ptr, pval2[(size_t)c]->ptr, 8, RP_RAW, 0 }; }
+      (void)rp_partition(ctx, RpHashU64Low{ (const uint64_t*)pkey->ptr }, m1, (uint32_t)P2, c2, true, ctx->d_scratch64 + 10, "pa_hist2", "pa_scan2", "pa_scatter2");
+      pkey = pkey2; prow = prow2; for (int c = 0; c < plan.n_acc; c++) { pval[(size_t)c] = pval2[(size_t)c]; plan.val[c] = (const uint64_t*)pval[(size_t)c]->ptr; }
+      BufferPtr first = alloc_buffer(ctx, (size_t)P * 4); HIP_CHECK(hipMemsetAsync(first->ptr, 0xFF, (size_t)P * 4, ctx->stream));
+      HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 11, 0, 8, ctx->stream));
+      r.starts = alloc_buffer(ctx, (size_t)(P + 1) * 4); r.P = (uint32_t)P;
+      { KernelTimer kt_(ctx, "pa_bounds");
+        if (m1) hipLaunchKernelGGL(k_pa_bounds, dim3(grid_for(m1, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)pkey->ptr, m1, (uint32_t)P1, (uint32_t)P2, (uint32_t*)first->ptr, (uint32_t*)(ctx->d_scratch64 + 11));
+        hipLaunchKernelGGL(k_pa_bounds_fill, dim3(grid_for(P + 1, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)first->ptr, (uint32_t)P, (uint32_t)m1, (uint32_t*)r.starts->ptr);
+        KERNEL_CHECK(); }
+    }
     // ---- aggregate every partition out of LDS
     BufferPtr okey = alloc_buffer(ctx, (size_t)n * 8), ofirst = alloc_buffer(ctx, (size_t)n * 4), ocnt = alloc_buffer(ctx, (size_t)n * 4); std::vector<BufferPtr> oacc((size_t)plan.n_acc);
     for (int c = 0; c < plan.n_acc; c++) { oacc[(size_t)c] = alloc_buffer(ctx, (size_t)n * 8); plan.out[c] = (uint64_t*)oacc[(size_t)c]->ptr; }
-    HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 12, 0, 16, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 12, 0, 24, ctx->stream));
     hipLaunchKernelGGL(k_pa_max_len, dim3((unsigned)((P + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)r.starts->ptr, (uint32_t)P, (unsigned long long*)(ctx->d_scratch64 + 13));
     KERNEL_CHECK();
     const int64_t max_len = (int64_t)read_scratch(ctx, 13);
+    if (two_level && (uint32_t)read_scratch(ctx, 11) != 0) fail(DFGPU_INTERNAL, "agg_preaggregate: the two-level partition left rows out of partition order");
     int64_t slice = (n / P + 1) * 3 / 2; if (slice < 65536) slice = 65536;          // uniform keys never split (a partition is within a percent of the average) if (slice > 0x7FFFFFFF) slice = 0x7FFFFFFF;
     const int64_t n_slices = max_len ? (max_len + slice - 1) / slice : 1;
     { KernelTimer kt_(ctx, "pa_aggregate");
@@ -273,6 +314,9 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
                          (uint64_t*)okey->ptr, (uint32_t*)ofirst->ptr, (uint32_t*)ocnt->ptr, (unsigned long long*)(ctx->d_scratch64 + 12));
       KERNEL_CHECK(); }
     const int64_t m = (int64_t)read_scratch(ctx, 12);
+    // every key left in exactly one partial row unless a hot partition was cut into slices or a table overflowed mid-partition: the plan layer then
+    // needs no hash table to number the groups of a first batch (option "agg_preaggregate_distinct", read only)
+    ctx->pa_last_distinct = n_slices == 1 && key->type != DFGPU_DICTIONARY && read_scratch(ctx, 14) == 0;          // dictionary codes: two codes may carry one value
     pkey.reset(); prow.reset(); pval.clear();
     // ---- partial rows in first-seen order of their groups
     BufferPtr perm = alloc_buffer(ctx, (size_t)(m + 1) * 4);

@@ -104,6 +104,7 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
  * every partition's table sits in LDS; probe batches of >= min_probe rows are partitioned the same way.  Pairs and their order are identical;
  * "agg_partitioned" (1/0), "agg_partitioned_min_rows", "agg_partitioned_force" (1 = skip the sample's verdict; tests) == let the plan layer's
  * AggregateExec pre-aggregate large batches of high-cardinality unclustered keys partition by partition out of LDS (dfgpu_agg_preaggregate);
+ * "agg_preaggregate_distinct" (read only) == 1 when the last dfgpu_agg_preaggregate call on this ctx emitted every key in exactly one partial row;
  * "sort_packed_keys" (1/0) == let sort_to_indices sort large inputs over fixed-width keys through range-packed 64-bit keys (identical indices);
  * "memory_limit" (bytes, 0 = none) == live device memory this ctx may hold; an allocation beyond it fails with DFGPU_RESOURCES_EXHAUSTED and the
  * message of MemoryPool::try_grow (≙ RuntimeConfig::with_memory_limit, execution/src/runtime_env.rs); "live_bytes" / "cached_bytes" (read only);
@@ -164,6 +165,8 @@ DFGPU_API int64_t dfgpu_array_length(const dfgpu_array *a);
  * indices of dfgpu_join_probe when every probe row matched exactly once): dfgpu_take through it returns the values array itself, and
  * a caller composing gathers can skip it.  0 says nothing (the array may still happen to be the identity). */
 DFGPU_API int32_t dfgpu_array_is_identity(const dfgpu_array *a);
+/* UInt32 0, 1, .., length - 1 (flagged as the identity): group ids of rows that are one group each, in order */
+DFGPU_API dfgpu_status dfgpu_array_iota(dfgpu_ctx *ctx, int64_t length, dfgpu_array **out);
 DFGPU_API int64_t dfgpu_array_null_count(dfgpu_ctx *ctx, const dfgpu_array *a);   /* computes if unknown */
 /* RecordBatch::slice: zero copy when offset % 64 == 0 (batch_size 8192 chunks), otherwise a copy. */
 DFGPU_API dfgpu_status dfgpu_array_slice(dfgpu_ctx *ctx, const dfgpu_array *a, int64_t offset, int64_t length, dfgpu_array **out);

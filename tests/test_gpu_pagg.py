@@ -170,3 +170,44 @@ def test_aggregate_exec_takes_the_partitioned_path_and_matches(ctx):
     a, b = res
     assert a[0].equals(b[0]) and a[1].equals(b[1]) and a[2].equals(b[2]) and a[4].equals(b[4])         # keys in the same (first-seen) order, SUM / COUNT / MAX exact
     assert np.allclose(a[3].to_numpy(), b[3].to_numpy(), rtol=FLOAT_RTOL, atol=0.0)
+
+
+def test_two_level_partition_for_millions_of_groups(ctx):
+    """5 M groups in 16 M rows: more than 2048 partitions would be needed for one pass, so the rows are split twice (P1 on the high hash bits, then a
+    stable split on the low bits): every group still leaves in exactly one partial row, ids in first-seen order, sums exact."""
+    n, card = 16_000_000, 5_000_000
+    rng = np.random.default_rng(99)
+    key = pa.array(rng.integers(0, card, n).astype(np.int64) * 2654435761 - 7)
+    vi = pa.array(rng.integers(-10**6, 10**6, n).astype(np.int64))
+    aggs = [("SUM", vi), ("COUNT", None), ("MAX", vi)]
+    with forced(ctx, force=0) as f:
+        gk, got, m = run_device(ctx, key, aggs)
+        ran = f.kernels()
+    assert "pa_scatter2" in ran and "pa_bounds" in ran
+    wk, want = run_oracle(key, aggs)
+    compare(gk, got, wk, want)
+    assert m == len(wk)                                   # no key was split over partial rows
+
+
+@pytest.mark.parametrize("nbatches", [1, 2, 3])
+def test_first_batch_keeps_its_keys_out_of_the_hash_table_until_a_second_batch_arrives(ctx, nbatches):
+    """One fully pre-aggregated batch is emitted from its partial rows (ids 0 .. n-1, no table); with further batches the keys are interned after all --
+    both ways the result equals the ordinary path: same groups, same first-seen order, exact sums."""
+    from dfgpu import capi, physical_plan as ops
+    n = 300000
+    batches = []
+    for b in range(nbatches):
+        k = RNG.integers(0, 50000 + 20000 * b, n).astype(np.int64) * 7919; v = RNG.integers(-1000, 1000, n).astype(np.int64)
+        batches.append(ops.batch_from_arrow(ctx, pa.table({"k": pa.array(k), "v": pa.array(v)})))
+    C, F = ops.Column, ops.Field
+    aggs = lambda: [ops.AggregateFunctionExpr("SUM", C("v", 1), "s", input_field=F("v", capi.INT64)), ops.AggregateFunctionExpr("COUNT", None, "c"), ops.AggregateFunctionExpr("MIN", C("v", 1), "m", input_field=F("v", capi.INT64))]
+    tc = ops.TaskContext(ctx, batch_size=8192)
+    res = []
+    for on in (1, 0):
+        with forced(ctx, force=0):
+            ctx.set_option("agg_partitioned", on)
+            plan = ops.AggregateExec("Single", [(C("k", 0), "k")], aggs(), ops.MemoryExec([batches], batches[0].schema))
+            cols = [[c.to_arrow() for c in b.materialize().columns] for b in plan.execute(0, tc)]
+        res.append([pa.concat_arrays([c[i] for c in cols]) for i in range(4)])
+    for a, b in zip(*res):
+        assert a.equals(b)
