@@ -8,7 +8,15 @@ use arrow::ffi::{from_ffi, to_ffi, FFI_ArrowArray, FFI_ArrowSchema};
 use datafusion_common::{DataFusionError, Result};
 
 macro_rules! opaque { ($($n:ident),*) => { $(#[repr(C)] pub struct $n { _p: [u8; 0] })* } }
-opaque!(dfgpu_ctx, dfgpu_array, dfgpu_expr, dfgpu_plan, dfgpu_batch, dfgpu_stream);
+opaque!(dfgpu_ctx, dfgpu_array, dfgpu_expr, dfgpu_plan, dfgpu_batch, dfgpu_stream, dfgpu_comm, dfgpu_parquet);
+
+/// dfgpu_comm_vtable (include/dfgpu.h): a transport the host provides instead of RCCL
+#[repr(C)]
+pub struct dfgpu_comm_vtable {
+    pub user: *mut c_void, pub rank: i32, pub world: i32,
+    pub all_gather_host: Option<unsafe extern "C" fn(*mut c_void, *const c_void, i64, *mut c_void) -> i32>,
+    pub all_to_all_v: Option<unsafe extern "C" fn(*mut c_void, *const c_void, *const i64, *const i64, *mut c_void, *const i64, *const i64) -> i32>,
+}
 
 // DFGPU_OP_* (include/dfgpu.h)
 pub const OP_ADD: i32 = 0; pub const OP_SUB: i32 = 1; pub const OP_MUL: i32 = 2; pub const OP_DIV: i32 = 3; pub const OP_REM: i32 = 4;
@@ -26,7 +34,25 @@ extern "C" {
     pub fn dfgpu_array_import_arrow(ctx: *mut dfgpu_ctx, a: *mut FFI_ArrowArray, s: *mut FFI_ArrowSchema, out: *mut *mut dfgpu_array) -> i32;
     pub fn dfgpu_array_export_arrow(ctx: *mut dfgpu_ctx, a: *const dfgpu_array, out_a: *mut FFI_ArrowArray, out_s: *mut FFI_ArrowSchema) -> i32;
     pub fn dfgpu_array_release(a: *mut dfgpu_array);
+    // ---- round 2 (include/dfgpu.h): lent device memory, exchange between ranks, Parquet scan
+    pub fn dfgpu_array_wrap_device_owned(ctx: *mut dfgpu_ctx, desc: *const c_void /* dfgpu_array_desc */, release: Option<unsafe extern "C" fn(*mut c_void)>, cookie: *mut c_void, out: *mut *mut dfgpu_array) -> i32;
+    pub fn dfgpu_comm_unique_id(out_id128: *mut u8) -> i32;
+    pub fn dfgpu_comm_create_rccl(ctx: *mut dfgpu_ctx, id128: *const u8, rank: i32, world: i32, out: *mut *mut dfgpu_comm) -> i32;
+    pub fn dfgpu_comm_create_custom(vtable: *const dfgpu_comm_vtable, out: *mut *mut dfgpu_comm) -> i32;
+    pub fn dfgpu_comm_free(comm: *mut dfgpu_comm);
+    pub fn dfgpu_exchange(ctx: *mut dfgpu_ctx, comm: *mut dfgpu_comm, keys: *const *const dfgpu_array, nkeys: i32, cols: *const *const dfgpu_array, ncols: i32,
+                          opt_mask: *const dfgpu_array, out_cols: *mut *mut dfgpu_array, out_counts: *mut i64) -> i32;
+    pub fn dfgpu_parquet_open(ctx: *mut dfgpu_ctx, file_bytes: *const u8, len: i64, device_bytes: *const u8, out: *mut *mut dfgpu_parquet) -> i32;
+    pub fn dfgpu_parquet_close(file: *mut dfgpu_parquet);
+    pub fn dfgpu_parquet_num_row_groups(file: *const dfgpu_parquet) -> i32;
+    pub fn dfgpu_parquet_column_stats(file: *const dfgpu_parquet, row_group: i32, column: i32, min_value: *mut i64, max_value: *mut i64, null_count: *mut i64, has_min_max: *mut i32) -> i32;
+    pub fn dfgpu_parquet_read(ctx: *mut dfgpu_ctx, file: *mut dfgpu_parquet, first_row_group: i32, num_row_groups: i32, columns: *const i32, ncols: i32, out: *mut *mut dfgpu_array) -> i32;
     // ---- include/dfgpu_exec.h
+    pub fn dfgpu_plan_parquet(file: *mut dfgpu_parquet, columns: *const i32, ncols: i32, npartitions: i32, row_groups_per_batch: i32, out: *mut *mut dfgpu_plan) -> i32;
+    pub fn dfgpu_plan_parquet_prune(parquet_exec: *mut dfgpu_plan, column: i32, min_value: i64, max_value: i64) -> i32;
+    pub fn dfgpu_plan_nested_loop_join(left: *const dfgpu_plan, right: *const dfgpu_plan, filter: *const dfgpu_expr, filter_sides: *const i32, filter_indices: *const i32,
+                                       nfilter_cols: i32, join_type: i32, out: *mut *mut dfgpu_plan) -> i32;
+    pub fn dfgpu_plan_metrics(p: *const dfgpu_plan, buf: *mut c_char, capacity: i64) -> i32;
     pub fn dfgpu_exec_last_error() -> *const c_char;
     pub fn dfgpu_batch_new(names: *const *const c_char, columns: *const *const dfgpu_array, ncols: i32, out: *mut *mut dfgpu_batch) -> i32;
     pub fn dfgpu_batch_free(b: *mut dfgpu_batch);
