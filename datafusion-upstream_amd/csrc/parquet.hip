@@ -15,6 +15,7 @@
 //
 // Utf8 columns keep their dictionary (option): the keys are the page indices plus the row group's base in the concatenated dictionary,
 // so dictionary predicates and the canonical-id group-by take the column without ever expanding it.
+#include <algorithm>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -469,20 +470,56 @@ __global__ void __launch_bounds__(BLOCK) k_pq_bytes_to_bits(const uint8_t* in, i
 constexpr int SN_RING = 65536, SN_WIN = 8192, SN_FLUSH = 16384;
 struct SnJob { const uint8_t* src; uint8_t* dst; uint32_t csize, usize; int32_t raw; int32_t pad; };
 
-__device__ inline void sn_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__device__ inline void sn_order() { __builtin_amdgcn_wave_barrier(); }          // LDS operations of one wave execute in issue order: only the compiler must not move them across
 __device__ inline uint64_t sn_peek(const uint32_t* win, uint32_t rel) { uint32_t a = rel >> 2, sh = (rel & 3) * 8; return ((uint64_t)win[a] | ((uint64_t)win[a + 1] << 32)) >> sh; }   // >= 5 bytes at win + rel
 
-__global__ void __launch_bounds__(64) k_pq_snappy(const SnJob* __restrict__ jobs, uint32_t* flags) {
+// Block mode (blks != nullptr): the standard compressor works on 64 KB fragments of the input one at a time (a fresh hash table per fragment), so elements
+// never straddle a multiple of 64 KB of OUTPUT and copies never reach before it: the 64 KB blocks of a page decode independently.  Workgroup b takes
+// block blks[b].blk of page blks[b].job: it first skips the tags of the blocks before its own (tags only, out of a 512-byte register window read with
+// v_readlane -- no bytes move), then decodes its block.  A page that breaks either assumption is marked in page_bad and decoded front to back by the
+// repair launch (blks == nullptr), which also is where corrupt input raises the error flag.
+struct SnBlk { uint32_t job, blk; };
+__global__ void __launch_bounds__(64) k_pq_snappy(const SnJob* __restrict__ jobs, const SnBlk* __restrict__ blks, uint32_t* page_bad, uint32_t* flags) {
   __shared__ __attribute__((aligned(16))) uint8_t ring[SN_RING];
   __shared__ __attribute__((aligned(16))) uint32_t win[SN_WIN / 4 + 4];
-  const SnJob jb = jobs[blockIdx.x]; const uint32_t lane = threadIdx.x;
+  const uint32_t job = blks ? blks[blockIdx.x].job : blockIdx.x, blk = blks ? blks[blockIdx.x].blk : 0u;
+  if (!blks && !page_bad[job]) return;
+  SnJob jb = jobs[job]; const uint32_t lane = threadIdx.x;
   if (jb.raw) { for (uint32_t i = lane; i < jb.usize; i += 64) jb.dst[i] = jb.src[i]; return; }
   uint32_t pin = 0, ulen = 0; { int sh = 0; bool ok = false; while (pin < jb.csize && sh < 35) { uint8_t b = jb.src[pin++]; ulen |= (uint32_t)(b & 0x7f) << sh; sh += 7; if (!(b & 0x80)) { ok = true; break; } } if (!ok) ulen = 0xFFFFFFFFu; }
-  if (ulen != jb.usize) { if (lane == 0) atomicOr(flags, DFGPU_FLAG_OOB); return; }
   // every cursor below is wave-uniform; sn_u() pins it to the scalar unit, so the element loop branches on SCC instead of masking lanes
 #define sn_u(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+  auto give_up = [&]() { if (lane == 0) { if (blks) page_bad[job] = 1; else atomicOr(flags, DFGPU_FLAG_OOB); } };
+  if (ulen != jb.usize) { give_up(); return; }
   pin = sn_u(pin);
-  const uint32_t csize = sn_u(jb.csize), usize = sn_u(jb.usize);
+  const uint32_t csize = sn_u(jb.csize);
+  uint32_t usize = sn_u(jb.usize);
+  bool last_block = true;
+  if (blks) {
+    const uint32_t target = blk * 65536u;
+    if (target) {           // skip the elements of the blocks in front
+      const uint32_t A = (uint32_t)((uintptr_t)jb.src & 3), vend = csize + A; const uint32_t* base32 = (const uint32_t*)(jb.src - A);
+      auto loadw = [&](uint32_t wv) -> uint32_t { uint32_t o = wv + 4 * lane; return o < vend ? base32[o >> 2] : 0u; };
+      uint32_t v = pin + A, wv = v & ~255u, cur = loadw(wv), nxt = loadw(wv + 256), out = 0; bool bad0 = false;
+      while (out < target) {
+        if (v >= vend) { bad0 = true; break; }
+        if (v - wv >= 256u) { if (v - wv < 512u) { cur = nxt; wv = sn_u(wv + 256u); } else { wv = sn_u(v & ~255u); cur = loadw(wv); } nxt = loadw(wv + 256u); }
+        const uint32_t idx = (v - wv) >> 2, sh = (v & 3u) * 8u;
+        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)idx), a1 = idx == 63u ? (uint32_t)__builtin_amdgcn_readlane((int)nxt, 0) : (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(idx + 1u));
+        const uint64_t t = (((uint64_t)a1 << 32) | a0) >> sh; const uint32_t lo = (uint32_t)t, b0 = lo & 0xff, kind = lo & 3;
+        uint32_t len, step;
+        if (kind == 0) { len = (b0 >> 2) + 1; step = 1; if (len > 60) { uint32_t nb = len - 60; uint32_t ext = (uint32_t)(t >> 8); len = (nb == 4 ? ext : (ext & ((1u << (8 * nb)) - 1u))) + 1; step = 1 + nb; if (len == 0) { bad0 = true; break; } } step += len; }
+        else if (kind == 1) { len = 4 + ((b0 >> 2) & 7); step = 2; } else { len = 1 + (b0 >> 2); step = kind == 2 ? 3 : 5; }
+        if (len > target - out || step > vend - v) { bad0 = true; break; }          // an element across the 64 KB boundary: not the standard block structure
+        out = sn_u(out + len); v = sn_u(v + step);
+      }
+      if (bad0) { give_up(); return; }
+      pin = sn_u(v - A);
+    }
+    if (target >= usize) { give_up(); return; }
+    last_block = usize - target <= 65536u;
+    usize = sn_u(min(65536u, usize - target)); jb.dst += target;
+  }
   uint32_t pout = 0, flushed = 0, wb = 0, wl = 0; bool bad = false;
   const bool dst16 = ((uintptr_t)jb.dst & 15) == 0;
   const uint8_t* winb = (const uint8_t*)win;
@@ -503,6 +540,7 @@ __global__ void __launch_bounds__(64) k_pq_snappy(const SnJob* __restrict__ jobs
     if (lane < 2) win[nw + lane] = 0;
     sn_order();
   };
+  if (pin >= csize) { give_up(); return; }
   reload(pin);
   uint64_t tv = sn_peek(win, pin - wb);
   while (pin < csize && pout < usize) {
@@ -555,7 +593,7 @@ __global__ void __launch_bounds__(64) k_pq_snappy(const SnJob* __restrict__ jobs
     sn_order();
     if (pout - flushed >= (uint32_t)SN_FLUSH) { flush(pout & ~15u); sn_order(); }
   }
-  if (bad || pout != usize) { if (lane == 0) atomicOr(flags, DFGPU_FLAG_OOB); return; }
+  if (bad || pout != usize || (last_block && pin != csize && blks)) { give_up(); return; }
   sn_order();
   flush(pout);
 #undef sn_u
@@ -835,8 +873,16 @@ dfgpu_status dfgpu_parquet_read(dfgpu_ctx* ctx, dfgpu_parquet* f, int32_t first_
       plan_column(ctx, f, columns[i], first_row_group, num_row_groups, reads[(size_t)i], jobs);
     }
     if (!jobs.empty()) {                          // every compressed page of the read in one launch: the pages are the parallelism
-      BufferPtr dj = upload(ctx, jobs); KernelTimer kt(ctx, "pq_snappy");
-      hipLaunchKernelGGL(k_pq_snappy, dim3((unsigned)jobs.size()), dim3(64), 0, ctx->stream, (const SnJob*)dj->ptr, ctx->d_flags); KERNEL_CHECK();
+      BufferPtr dj = upload(ctx, jobs);
+      std::vector<SnBlk> blks;                   // one workgroup per 64 KB output block of every page, the largest pages' blocks first in launch order
+      for (size_t j = 0; j < jobs.size(); j++) { uint32_t nb = jobs[j].raw ? 1u : std::max(1u, (jobs[j].usize + 65535u) / 65536u); for (uint32_t k = 0; k < nb; k++) blks.push_back(SnBlk{(uint32_t)j, k}); }
+      std::stable_sort(blks.begin(), blks.end(), [](const SnBlk& x, const SnBlk& y) { return x.blk > y.blk; });       // blocks with the longest tag skip start first
+      BufferPtr db = upload(ctx, blks), bad = alloc_buffer(ctx, jobs.size() * 4 + 16, true);
+      { KernelTimer kt(ctx, "pq_snappy");
+        hipLaunchKernelGGL(k_pq_snappy, dim3((unsigned)blks.size()), dim3(64), 0, ctx->stream, (const SnJob*)dj->ptr, (const SnBlk*)db->ptr, (uint32_t*)bad->ptr, ctx->d_flags); }
+      { KernelTimer kt(ctx, "pq_snappy_repair");
+        hipLaunchKernelGGL(k_pq_snappy, dim3((unsigned)jobs.size()), dim3(64), 0, ctx->stream, (const SnJob*)dj->ptr, (const SnBlk*)nullptr, (uint32_t*)bad->ptr, ctx->d_flags); }
+      KERNEL_CHECK();
     }
     for (int32_t i = 0; i < ncols; i++) res.emplace_back(decode_column(ctx, f, reads[(size_t)i]));
     // the staged / decompressed bytes (reads[].keep) outlive the kernels: frees are stream ordered through the caching allocator
