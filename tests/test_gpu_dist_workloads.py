@@ -110,3 +110,35 @@ def test_clickbench_shape_equals_direct_evaluation(world):
     assert len(got) == 25
     for g, e in zip(got, want[:25]):
         assert g[1:] == e[1:] and abs(g[0] - e[0]) <= FLOAT_RTOL * abs(e[0])
+
+
+def test_both_workloads_over_the_rccl_backend_at_world_one(ctx):
+    """the same plans with torch.distributed's nccl backend (RCCL) instead of gloo: every collective of the exchanges (metadata all-gather, all-to-all(v) of
+    fixed-width, Utf8 and validity lanes, the gather to rank 0) runs on device buffers; one rank, so the result is the direct evaluation"""
+    import torch
+    import torch.distributed as dist
+    from dfgpu import dist_workloads as dw, exchange, physical_plan as ops
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29150 + os.getpid() % 300))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        tc = ops.TaskContext(ctx, 8192)
+        for native in (False, True):
+            tt = dw.q5_tensors(0.05, 0, 1)
+            plan = dw.q5_plan(dw.q5_tables(ctx, tt, 0), native=native)
+            local = list(plan.execute(0, tc))
+            gathered = exchange.gather_batches(ctx, None, ops.concat_batches(local[0].schema, local), 0, names=dw.Q5_OUTPUT)
+            got = {r["n_name"]: int(r["revenue"].scaleb(4)) for r in gathered.to_arrow().to_pylist()}
+            assert got == q5_expected(tt)
+        ids, length, w = dw.clickbench_tensors(200000, 3000, 0, 1)
+        plan = dw.clickbench_plan(dw.clickbench_batch(ctx, ids, length, w, 3000))
+        local = list(plan.execute(0, tc))
+        gathered = exchange.gather_batches(ctx, None, ops.concat_batches(local[0].schema, local), 0, names=dw.CLICKBENCH_OUTPUT)
+        assert gathered.num_rows == 25
+        idn = ids.cpu().numpy(); keep = idn != 0
+        cnt = np.bincount(idn[keep], minlength=3000)
+        for r in gathered.to_arrow().to_pylist():
+            k = int(r["k"].split("site")[1].split(".")[0])
+            assert r["c"] == cnt[k]
+    finally:
+        dist.destroy_process_group()
