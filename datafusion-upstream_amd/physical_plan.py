@@ -547,6 +547,33 @@ class HashJoinExec(ExecutionPlan):
         return self._new(out)
 
 
+class SortMergeJoinExec(ExecutionPlan):
+    """≙ SortMergeJoinExec (joins/sort_merge_join.rs:62): equi-join of inputs sorted on the keys; rows in streamed-side order."""
+
+    def __init__(self, left, right, on: List[Tuple[PhysicalExpr, PhysicalExpr]], join_type: str, null_equals_null: bool = False, filter: Optional[JoinFilter] = None):
+        if join_type not in JOIN_TYPES:
+            raise DfgpuError(5, f"unknown join type {join_type}")
+        self.left, self.right, self.on, self.join_type, self.null_equals_null, self.filter = left, right, on, join_type, null_equals_null, filter
+
+    def children(self):
+        return [self.left, self.right]
+
+    def output_partitioning(self):
+        return self.left.output_partitioning()
+
+    def schema(self):
+        ls, rs = self.left.schema().fields, self.right.schema().fields
+        return Schema(list(ls)) if self.join_type in ("LeftSemi", "LeftAnti") else Schema(list(ls) + list(rs))
+
+    def _build(self, context):
+        ctx = context.ctx
+        out = C.c_void_p()
+        _check(_lib().dfgpu_plan_sort_merge_join(_child_handle(self.left, context).h, _child_handle(self.right, context).h,
+                                                 _ptrs([l.handle(ctx).h for l, _ in self.on]), _ptrs([r.handle(ctx).h for _, r in self.on]), len(self.on),
+                                                 self.filter.expression.handle(ctx).h if self.filter else None, JOIN_TYPES[self.join_type], int(self.null_equals_null), C.byref(out)))
+        return self._new(out)
+
+
 class NestedLoopJoinExec(ExecutionPlan):
     """≙ NestedLoopJoinExec (joins/nested_loop_join.rs:84): join without equi-keys; `filter` = JoinFilter or None (cross join)."""
 

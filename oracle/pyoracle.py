@@ -466,3 +466,70 @@ def nested_loop_join(left_batches, right_batches, filter_cols, filter_fn, join_t
         rtypes = [c.type for c in right_batches[0]] if right_batches else []
         out.append([take(c, un) for c in inner] + [pa.nulls(len(un), t) for t in rtypes])
     return out
+
+
+# ------------------------------------------------------------------ SortMergeJoinExec (joins/sort_merge_join.rs), small inputs only: a two-cursor merge in plain Python
+def sort_merge_join(left_cols, right_cols, on, join_type: str, descending: bool = False, nulls_first: bool = True, null_equals_null: bool = False):          # SortOptions::default(): ascending, nulls first
+    """left_cols / right_cols: lists of pyarrow arrays (one sorted partition each); on: [(left column index, right column index)].  Returns the output columns.
+    Follows SMJStream (:590-1330) without a filter: the streamed side (left; right for JoinType::Right) advances row by row; compare_join_arrays (:1361-1456) orders the
+    streamed key against the buffered head under the sort options (a NULL never equals unless null_equals_null; NULLs order by nulls_first); join_partial (:968-1060)
+    emits, per streamed row: Equal -> the pairs with every buffered row of the equal-key run (Inner / Left / Right), or the streamed row once (LeftSemi); Less ->
+    the streamed row with NULLs (Left / Right) or alone (LeftAnti); Greater -> the buffered cursor advances."""
+    if join_type not in ("Inner", "Left", "Right", "LeftSemi", "LeftAnti"):
+        raise OracleError("sort_merge_join restates Inner, Left, Right, LeftSemi, LeftAnti")
+    stream_left = join_type != "Right"
+    scols, bcols = (left_cols, right_cols) if stream_left else (right_cols, left_cols)
+    skey = [scols[l if stream_left else r].to_pylist() for l, r in on]
+    bkey = [bcols[r if stream_left else l].to_pylist() for l, r in on]
+    ns, nb = len(scols[0]), len(bcols[0])
+
+    def cmp(i, j):            # streamed row i vs buffered row j: -1 / 0 / 1
+        for a, b in zip(skey, bkey):
+            x, y = a[i], b[j]
+            if x is None and y is None:
+                if null_equals_null:
+                    continue
+                return -1             # (None, None) without null_equals_null: Ordering::Less
+            if x is None:
+                return -1 if nulls_first else 1
+            if y is None:
+                return 1 if nulls_first else -1
+            if x != y:
+                c = -1 if x < y else 1
+                return -c if descending else c
+        return 0
+
+    def same_buffered(j, k):
+        for b in bkey:
+            x, y = b[j], b[k]
+            if x is None or y is None:
+                if not (x is None and y is None and null_equals_null):
+                    return False
+            elif x != y:
+                return False
+        return True
+
+    si, bi = [], []
+    j = 0
+    for i in range(ns):
+        while j < nb and cmp(i, j) > 0:
+            j += 1
+        if j < nb and cmp(i, j) == 0:
+            k = j
+            run = []
+            while k < nb and (k == j or same_buffered(j, k)):
+                run.append(k); k += 1
+            if join_type in ("Inner", "Left", "Right"):
+                si += [i] * len(run); bi += run
+            elif join_type == "LeftSemi":
+                si.append(i); bi.append(None)
+        elif join_type in ("Left", "Right"):
+            si.append(i); bi.append(None)
+        elif join_type == "LeftAnti":
+            si.append(i); bi.append(None)
+    take = lambda arr, idx: arr.take(pa.array(idx, type=pa.int64()))
+    lidx, ridx = (si, bi) if stream_left else (bi, si)
+    out = [take(c, lidx) for c in left_cols]
+    if join_type not in ("LeftSemi", "LeftAnti"):
+        out += [take(c, ridx) for c in right_cols]
+    return out

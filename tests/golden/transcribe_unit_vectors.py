@@ -4,6 +4,7 @@
                                                        IS [NOT] DISTINCT FROM over Boolean columns with NULLs, Decimal128 comparisons
   in_list   physical-expr/src/expressions/in_list.rs   IN / NOT IN over Utf8, Int64, Float64 (NaN, -NaN), Boolean, Date32, Decimal128 with and without a NULL in the list
   nested_loop_join physical-plan/src/joins/nested_loop_join.rs   the eight join types with a JoinFilter (rows compared sorted, as assert_batches_sorted_eq does)
+  sort_merge_join physical-plan/src/joins/sort_merge_join.rs    Inner / Left / Right / LeftSemi / LeftAnti: rows and row ORDER (assert_batches_eq), NULL keys, descending keys with null_equals_null, inputs in several batches
   sort      physical-plan/src/sorts/sort.rs            test_in_mem_sort (4 x make_partition(100)), test_sort_metadata
   repartition physical-plan/src/repartition/mod.rs     RoundRobinBatch batch counts, Hash row conservation
 Mixed-type comparisons of the same tests (Int64 / Float64 column against a Decimal128 literal) go through the planner's coercion and are left out.
@@ -138,6 +139,39 @@ nlj = {"left": {"ref": NL + "782-788", "columns": {"a1": [5, 9, 11], "b1": [5, 8
            {"name": "join_right_anti_with_filter", "ref": NL + "1103-1130", "join_type": "RightAnti", "expected_sorted": [[10, 10, 100], [12, 10, 40]]},
        ]}
 
+# ---- SortMergeJoinExec (physical-plan/src/joins/sort_merge_join.rs:1787-2448): rows AND their order are asserted (assert_batches_eq)
+SM = "datafusion/physical-plan/src/joins/sort_merge_join.rs:"
+T3 = lambda a, b, c: [a, b, c]
+smj = [
+    {"name": "join_inner_one", "ref": SM + "1787-1818", "join_type": "Inner", "left": T3([1, 2, 3], [4, 5, 5], [7, 8, 9]), "right": T3([10, 20, 30], [4, 5, 6], [70, 80, 90]), "on": [[1, 1]],
+     "expected": [[1, 4, 7, 10, 4, 70], [2, 5, 8, 20, 5, 80], [3, 5, 9, 20, 5, 80]]},
+    {"name": "join_inner_two", "ref": SM + "1821-1856", "join_type": "Inner", "left": T3([1, 2, 2], [1, 2, 2], [7, 8, 9]), "right": T3([1, 2, 3], [1, 2, 2], [70, 80, 90]), "on": [[0, 0], [1, 1]],
+     "expected": [[1, 1, 7, 1, 1, 70], [2, 2, 8, 2, 2, 80], [2, 2, 9, 2, 2, 80]]},
+    {"name": "join_inner_with_nulls", "ref": SM + "1898-1933", "join_type": "Inner", "left": T3([1, 1, 2, 2], [N, 1, 2, 2], [1, N, 8, 9]), "right": T3([1, 1, 2, 3], [N, 1, 2, 2], [10, 70, 80, 90]), "on": [[0, 0], [1, 1]],
+     "expected": [[1, 1, N, 1, 1, 70], [2, 2, 8, 2, 2, 80], [2, 2, 9, 2, 2, 80]]},
+    {"name": "join_inner_with_nulls_with_options", "ref": SM + "1936-1985", "join_type": "Inner", "descending": True, "nulls_first": False, "null_equals_null": True,
+     "left": T3([2, 2, 1, 1], [2, 2, 1, N], [9, 8, N, 1]), "right": T3([3, 2, 1, 1], [2, 2, 1, N], [90, 80, 70, 10]), "on": [[0, 0], [1, 1]],
+     "expected": [[2, 2, 9, 2, 2, 80], [2, 2, 8, 2, 2, 80], [1, 1, N, 1, 1, 70], [1, N, 1, 1, N, 10]]},
+    {"name": "join_left_one", "ref": SM + "2030-2059", "join_type": "Left", "left": T3([1, 2, 3], [4, 5, 7], [7, 8, 9]), "right": T3([10, 20, 30], [4, 5, 6], [70, 80, 90]), "on": [[1, 1]],
+     "expected": [[1, 4, 7, 10, 4, 70], [2, 5, 8, 20, 5, 80], [3, 7, 9, N, N, N]]},
+    {"name": "join_right_one", "ref": SM + "2062-2091", "join_type": "Right", "left": T3([1, 2, 3], [4, 5, 7], [7, 8, 9]), "right": T3([10, 20, 30], [4, 5, 6], [70, 80, 90]), "on": [[1, 1]],
+     "expected": [[1, 4, 7, 10, 4, 70], [2, 5, 8, 20, 5, 80], [N, N, N, 30, 6, 90]]},
+    {"name": "join_anti", "ref": SM + "2126-2154", "join_type": "LeftAnti", "left": T3([1, 2, 2, 3, 5], [4, 5, 5, 7, 7], [7, 8, 8, 9, 11]), "right": T3([10, 20, 30], [4, 5, 6], [70, 80, 90]), "on": [[1, 1]],
+     "expected": [[3, 7, 9], [5, 7, 11]]},
+    {"name": "join_semi", "ref": SM + "2157-2186", "join_type": "LeftSemi", "left": T3([1, 2, 2, 3], [4, 5, 5, 7], [7, 8, 8, 9]), "right": T3([10, 20, 30], [4, 5, 6], [70, 80, 90]), "on": [[1, 1]],
+     "expected": [[1, 4, 7], [2, 5, 8], [2, 5, 8]]},
+    {"name": "join_left_sort_order", "ref": SM + "2285-2318", "join_type": "Left", "left": T3([0, 1, 2, 3, 4, 5], [3, 4, 5, 6, 6, 7], [4, 5, 6, 7, 8, 9]), "right": T3([0, 10, 20, 30, 40], [2, 4, 6, 6, 8], [50, 60, 70, 80, 90]), "on": [[1, 1]],
+     "expected": [[0, 3, 4, N, N, N], [1, 4, 5, 10, 4, 60], [2, 5, 6, N, N, N], [3, 6, 7, 20, 6, 70], [3, 6, 7, 30, 6, 80], [4, 6, 8, 20, 6, 70], [4, 6, 8, 30, 6, 80], [5, 7, 9, N, N, N]]},
+    {"name": "join_right_sort_order", "ref": SM + "2321-2350", "join_type": "Right", "left": T3([0, 1, 2, 3], [3, 4, 5, 7], [6, 7, 8, 9]), "right": T3([0, 10, 20, 30], [2, 4, 5, 6], [60, 70, 80, 90]), "on": [[1, 1]],
+     "expected": [[N, N, N, 0, 2, 60], [1, 4, 7, 10, 4, 70], [2, 5, 8, 20, 5, 80], [N, N, N, 30, 6, 90]]},
+    {"name": "join_left_multiple_batches", "ref": SM + "2353-2399", "join_type": "Left", "left_batches": [3, 4], "right_batches": [3, 2],
+     "left": T3([0, 1, 2, 3, 4, 5, 6], [3, 4, 5, 6, 6, 7, 9], [4, 5, 6, 7, 8, 9, 9]), "right": T3([0, 10, 20, 30, 40], [2, 4, 6, 6, 8], [50, 60, 70, 80, 90]), "on": [[1, 1]],
+     "expected": [[0, 3, 4, N, N, N], [1, 4, 5, 10, 4, 60], [2, 5, 6, N, N, N], [3, 6, 7, 20, 6, 70], [3, 6, 7, 30, 6, 80], [4, 6, 8, 20, 6, 70], [4, 6, 8, 30, 6, 80], [5, 7, 9, N, N, N], [6, 9, 9, N, N, N]]},
+    {"name": "join_right_multiple_batches", "ref": SM + "2402-2448", "join_type": "Right", "left_batches": [3, 2], "right_batches": [3, 4],
+     "left": T3([0, 10, 20, 30, 40], [2, 4, 6, 6, 8], [50, 60, 70, 80, 90]), "right": T3([0, 1, 2, 3, 4, 5, 6], [3, 4, 5, 6, 6, 7, 9], [4, 5, 6, 7, 8, 9, 9]), "on": [[1, 1]],
+     "expected": [[N, N, N, 0, 3, 4], [10, 4, 60, 1, 4, 5], [N, N, N, 2, 5, 6], [20, 6, 70, 3, 6, 7], [30, 6, 80, 3, 6, 7], [20, 6, 70, 4, 6, 8], [30, 6, 80, 4, 6, 8], [N, N, N, 5, 7, 9], [N, N, N, 6, 9, 9]]},
+]
+
 S = "datafusion/physical-plan/src/sorts/sort.rs:"
 sort = [
     {"name": "test_in_mem_sort", "ref": S + "1022-1049 (test::scan_partitioned(4): 4 partitions of make_partition(100), column i = 0..100)", "type": "int32",
@@ -151,6 +185,6 @@ repartition = [
     {"name": "many_to_many_round_robin", "ref": R + "989-1007", "inputs": [50, 50, 50], "scheme": "RoundRobinBatch", "n": 5, "expected_batches": [30, 30, 30, 30, 30]},
     {"name": "many_to_many_hash_partition", "ref": R + "1010-1033", "inputs": [50, 50, 50], "scheme": "Hash", "n": 8, "expected_total_rows": 8 * 50 * 3},
 ]
-json.dump({"binary": cases, "in_list": in_list, "nested_loop_join": nlj, "sort": sort, "repartition": {"batch": {"ref": R + "1440-1447 create_batch", "type": "uint32", "column": "c0", "values": [1, 2, 3, 4, 5, 6, 7, 8]}, "cases": repartition}},
+json.dump({"binary": cases, "in_list": in_list, "nested_loop_join": nlj, "sort_merge_join": smj, "sort": sort, "repartition": {"batch": {"ref": R + "1440-1447 create_batch", "type": "uint32", "column": "c0", "values": [1, 2, 3, 4, 5, 6, 7, 8]}, "cases": repartition}},
           open(__file__.rsplit("/", 1)[0] + "/unit_vectors.json", "w"), indent=1)
 print(len(cases), "binary cases,", len(in_list), "in_list cases")
