@@ -46,6 +46,15 @@ __device__ inline void pa_apply(int op, unsigned long long* cell, uint64_t v) {
     default: break;
   }
 }
+__device__ inline uint64_t pa_combine(int op, uint64_t a, uint64_t b) {          // what pa_apply's atomic does, on two values
+  switch (op) {
+    case PA_SUM_I64: return a + b;
+    case PA_SUM_F64: return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
+    case PA_MIN_I64: return (long long)a < (long long)b ? a : b; case PA_MAX_I64: return (long long)a > (long long)b ? a : b;
+    case PA_MIN_U64: return a < b ? a : b; case PA_MAX_U64: return a > b ? a : b;
+    default: return a;
+  }
+}
 __device__ inline uint32_t pa_slot(uint64_t k, int cbits) {
   uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
   uint32_t a = lo ^ (hi * 0x9E3779B1u), x = a * 0x85EBCA6Bu; x ^= x >> 13;
@@ -61,7 +70,29 @@ __global__ void k_pa_max_len(const uint32_t* pstart, uint32_t P, unsigned long l
 // one workgroup per partition (and slice).  LDS: keys u64[C + 1] | acc[n_acc] u64[C + 1] | first u32[C + 1] | cnt u32[C + 1]; slot C belongs to the key
 // that equals the EMPTY marker.  Rows are taken PA_NT at a time with a barrier in between; before a chunk the table is flushed if the
 // chunk could fill it beyond 7/8.
-__global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, const uint32_t* prow, PaPlan plan_arg, const uint32_t* pstart, int cbits, uint32_t slice,
+// (partition, slice) work items of the skewed case: item_start[p] = first item of partition p, item_start[P] = number of items.  A 2-D grid over
+// (partition, max slices) would be mostly empty workgroups, and an empty workgroup still queues for a CU's LDS behind the ones doing work: the slices of the one
+// long partition then start milliseconds late.
+__global__ void __launch_bounds__(PA_NT) k_pa_items(const uint32_t* pstart, uint32_t P, uint32_t slice, uint32_t* item_start) {
+  __shared__ uint32_t wsum[PA_NT / WAVE]; __shared__ uint32_t carry_sh;
+  if (threadIdx.x == 0) carry_sh = 0;
+  __syncthreads();
+  for (uint32_t p0 = 0; p0 < P; p0 += PA_NT) {
+    const uint32_t p = p0 + threadIdx.x; uint32_t c = 0;
+    if (p < P) { const uint32_t len = pstart[p + 1] - pstart[p]; c = (uint32_t)(((uint64_t)len + slice - 1) / slice); }
+    const uint32_t inc = wave_inclusive_sum(c);
+    if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t run = carry_sh + inc - c, tot = 0;
+    for (int w = 0; w < PA_NT / WAVE; w++) { if (w < (int)(threadIdx.x >> 6)) run += wsum[w]; tot += wsum[w]; }
+    if (p < P) item_start[p] = run;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_sh += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) item_start[P] = carry_sh;
+}
+__global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, const uint32_t* prow, PaPlan plan_arg, const uint32_t* pstart, const uint32_t* item_start, uint32_t P, int cbits, uint32_t slice,
                                                       uint64_t* okey, uint32_t* ofirst, uint32_t* ocnt, unsigned long long* cursor /*[0] rows written, [2] tables flushed before their partition ended*/) {
   extern __shared__ unsigned long long pa_lds[];
   const uint32_t C = 1u << cbits, M = C - 1, C1 = C + 1;
@@ -71,11 +102,17 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
   if (threadIdx.x == 0) splan = plan_arg;              // the per-aggregate loops index the plan at run time: from LDS, not from the by-value argument
   __syncthreads();
   const PaPlan& plan = splan;
-  // blockIdx.y: a partition far above the average size (skewed keys) is cut into slices of `slice` rows, each with a table of its own
-  const int p = blockIdx.x, lane = lane_id();
+  // a partition far above the average size (skewed keys) is cut into slices of `slice` rows, each with a table of its own: workgroup = one item of item_start
+  uint32_t p = blockIdx.x, sl = 0; const int lane = lane_id();
+  if (item_start) {
+    if (blockIdx.x >= item_start[P]) return;
+    uint32_t lo = 0, hi = P - 1;
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (item_start[mid] <= blockIdx.x) lo = mid; else hi = mid - 1; }
+    p = lo; sl = blockIdx.x - item_start[p];
+  }
   const uint32_t p0 = pstart[p], p1 = pstart[p + 1];
-  if ((uint64_t)blockIdx.y * slice >= (uint64_t)(p1 - p0)) return;
-  const uint32_t q0 = p0 + blockIdx.y * slice, q1 = (uint64_t)q0 + slice < (uint64_t)p1 ? q0 + slice : p1;
+  if ((uint64_t)sl * slice >= (uint64_t)(p1 - p0)) return;
+  const uint32_t q0 = p0 + sl * slice, q1 = (uint64_t)q0 + slice < (uint64_t)p1 ? q0 + slice : p1;
   auto reset = [&]() {
     for (uint32_t s = threadIdx.x; s < C1; s += PA_NT) { keys[s] = PA_EMPTY; first[s] = 0xFFFFFFFFu; cnt[s] = 0;
       for (int a = 0; a < plan.n_acc; a++) acc[(size_t)a * C1 + s] = pa_identity(plan.op[a]); }
@@ -115,8 +152,31 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
     { const uint32_t i2 = i + PA_NT, ic = i2 < q1 ? i2 : q1 - 1; kn = pkey[ic]; rn = prow[ic];
 #pragma unroll
       for (int a = 0; a < PA_MAX_AGGS; a++) vn[a] = a < na ? plan_arg.val[a][ic] : 0; }
+    // Skewed keys: when at least 16 lanes of a wave carry the key of its first active lane, those lanes are combined in registers (shuffles) and the leader
+    // alone touches the table: one LDS atomic per state instead of one per row on a slot every wave of the workgroup is hammering.
+    uint32_t cntv = 1; uint32_t rowv = row; bool mine = on;
+    {
+      const uint64_t act = ballot64(on);
+      const int lead = act ? __ffsll((long long)act) - 1 : 0;
+      const uint32_t k0lo = (uint32_t)__shfl((int)(uint32_t)k, lead, 64), k0hi = (uint32_t)__shfl((int)(uint32_t)(k >> 32), lead, 64);
+      const bool member = on && (uint32_t)k == k0lo && (uint32_t)(k >> 32) == k0hi;
+      const uint64_t mem = ballot64(member);
+      if (__popcll(mem) >= 16) {
+        uint32_t r = member ? row : 0xFFFFFFFFu;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)r, d, 64); r = o < r ? o : r; }
+#pragma unroll
+        for (int a = 0; a < PA_MAX_AGGS; a++) if (a < na) {
+          const int op = plan_arg.op[a]; uint64_t x = member ? v[a] : pa_identity(op);
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) { uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, d, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), d, 64); x = pa_combine(op, x, ((uint64_t)hi << 32) | lo); }
+          if (lane == lead) v[a] = x;
+        }
+        if (lane == lead) { cntv = (uint32_t)__popcll(mem); rowv = r; } else if (member) mine = false;
+      }
+    }
     uint32_t s = C; bool fresh = false;
-    if (on) {
+    if (mine) {
       if (k != PA_EMPTY) {
         s = pa_slot(k, cbits);
         for (;;) {
@@ -126,8 +186,8 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
           s = (s + 1) & M;
         }
       }
-      if (row < first[s]) atomicMin(&first[s], row);           // a stale read only costs a redundant atomic
-      atomicAdd(&cnt[s], 1u);
+      if (rowv < first[s]) atomicMin(&first[s], rowv);           // a stale read only costs a redundant atomic
+      atomicAdd(&cnt[s], cntv);
 #pragma unroll
       for (int a = 0; a < PA_MAX_AGGS; a++) if (a < na) pa_apply(plan_arg.op[a], &acc[(size_t)a * C1 + s], v[a]);
     }
@@ -310,8 +370,14 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     const int64_t n_slices = max_len ? (max_len + slice - 1) / slice : 1;
     { KernelTimer kt_(ctx, "pa_aggregate");
       static bool once = false; if (!once) { HIP_CHECK(hipFuncSetAttribute((const void*)k_pa_aggregate, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); once = true; }
-      hipLaunchKernelGGL(k_pa_aggregate, dim3((unsigned)P, (unsigned)n_slices), dim3(PA_NT), (((size_t)1 << cbits) + 1) * cell_bytes, ctx->stream, (const uint64_t*)pkey->ptr, (const uint32_t*)prow->ptr, plan, (const uint32_t*)r.starts->ptr, cbits, (uint32_t)slice,
-                         (uint64_t*)okey->ptr, (uint32_t*)ofirst->ptr, (uint32_t*)ocnt->ptr, (unsigned long long*)(ctx->d_scratch64 + 12));
+      BufferPtr items; unsigned grid = (unsigned)P;
+      if (n_slices > 1) {            // sum over partitions of ceil(len / slice) <= P + n / slice
+        items = alloc_buffer(ctx, (size_t)(P + 1) * 4);
+        hipLaunchKernelGGL(k_pa_items, dim3(1), dim3(PA_NT), 0, ctx->stream, (const uint32_t*)r.starts->ptr, (uint32_t)P, (uint32_t)slice, (uint32_t*)items->ptr);
+        grid = (unsigned)(P + n / slice + 1);
+      }
+      hipLaunchKernelGGL(k_pa_aggregate, dim3(grid), dim3(PA_NT), (((size_t)1 << cbits) + 1) * cell_bytes, ctx->stream, (const uint64_t*)pkey->ptr, (const uint32_t*)prow->ptr, plan, (const uint32_t*)r.starts->ptr,
+                         items ? (const uint32_t*)items->ptr : nullptr, (uint32_t)P, cbits, (uint32_t)slice, (uint64_t*)okey->ptr, (uint32_t*)ofirst->ptr, (uint32_t*)ocnt->ptr, (unsigned long long*)(ctx->d_scratch64 + 12));
       KERNEL_CHECK(); }
     const int64_t m = (int64_t)read_scratch(ctx, 12);
     // every key left in exactly one partial row unless a hot partition was cut into slices or a table overflowed mid-partition: the plan layer then
