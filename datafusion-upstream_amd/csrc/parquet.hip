@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(BLOCK) k_pq_bytes_to_bits(const uint8_t* in, i
 // next tag's bytes are requested before the current element's bytes move, output goes to an LDS ring that holds the last 64 KB (every reference of
 // the standard 64 KB-block compressor resolves there) and is flushed to HBM in 16-byte stores.  One wave per workgroup: LDS operations of a wave
 // execute in order, no barrier is needed between an element's write and the next element's read.
-constexpr int SN_RING = 65536, SN_WIN = 8192, SN_FLUSH = 16384;
+constexpr int SN_RING = 32768, SN_WIN = 8192, SN_FLUSH = 8192;        // ring + window = 40 KB: four waves per CU; references further back than the ring are read from HBM
 struct SnJob { const uint8_t* src; uint8_t* dst; uint32_t csize, usize; int32_t raw; int32_t pad; };
 
 __device__ inline void sn_order() { __builtin_amdgcn_wave_barrier(); }          // LDS operations of one wave execute in issue order: only the compiler must not move them across
@@ -501,17 +501,54 @@ __global__ void __launch_bounds__(64) k_pq_snappy(const SnJob* __restrict__ jobs
       const uint32_t A = (uint32_t)((uintptr_t)jb.src & 3), vend = csize + A; const uint32_t* base32 = (const uint32_t*)(jb.src - A);
       auto loadw = [&](uint32_t wv) -> uint32_t { uint32_t o = wv + 4 * lane; return o < vend ? base32[o >> 2] : 0u; };
       uint32_t v = pin + A, wv = v & ~255u, cur = loadw(wv), nxt = loadw(wv + 256), out = 0; bool bad0 = false;
+      // element (output length, bytes to the next tag) if a tag started at the low byte of t (>= 5 bytes of input); len 0 = malformed
+      auto tagdec = [](uint64_t t, uint32_t& len, uint32_t& step) {
+        const uint32_t lo = (uint32_t)t, b0 = lo & 0xff, kind = lo & 3;
+        if (kind == 0) { len = (b0 >> 2) + 1; step = 1; if (len > 60) { uint32_t nb = len - 60; uint32_t ext = (uint32_t)(t >> 8); len = (nb == 4 ? ext : (ext & ((1u << (8 * nb)) - 1u))) + 1; step = 1 + nb; } step += len; }
+        else if (kind == 1) { len = 4 + ((b0 >> 2) & 7); step = 2; } else { len = 1 + (b0 >> 2); step = kind == 2 ? 3 : 5; }
+      };
+      // Tags are skipped a 256-byte chunk at a time by pointer jumping: every byte position of the chunk is decoded as if a tag started there (4 positions per
+      // lane), then 8 doubling rounds over (next position, output bytes, overshoot past the chunk) give, for the true entry position, the chunk's output and
+      // where the next chunk is entered.  Only the chunk in which the output reaches the block boundary is walked tag by tag.
+      __shared__ uint16_t pjN[260]; __shared__ uint32_t pjO[260], pjX[260];
       while (out < target) {
         if (v >= vend) { bad0 = true; break; }
         if (v - wv >= 256u) { if (v - wv < 512u) { cur = nxt; wv = sn_u(wv + 256u); } else { wv = sn_u(v & ~255u); cur = loadw(wv); } nxt = loadw(wv + 256u); }
-        const uint32_t idx = (v - wv) >> 2, sh = (v & 3u) * 8u;
-        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)idx), a1 = idx == 63u ? (uint32_t)__builtin_amdgcn_readlane((int)nxt, 0) : (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(idx + 1u));
-        const uint64_t t = (((uint64_t)a1 << 32) | a0) >> sh; const uint32_t lo = (uint32_t)t, b0 = lo & 0xff, kind = lo & 3;
-        uint32_t len, step;
-        if (kind == 0) { len = (b0 >> 2) + 1; step = 1; if (len > 60) { uint32_t nb = len - 60; uint32_t ext = (uint32_t)(t >> 8); len = (nb == 4 ? ext : (ext & ((1u << (8 * nb)) - 1u))) + 1; step = 1 + nb; if (len == 0) { bad0 = true; break; } } step += len; }
-        else if (kind == 1) { len = 4 + ((b0 >> 2) & 7); step = 2; } else { len = 1 + (b0 >> 2); step = kind == 2 ? 3 : 5; }
-        if (len > target - out || step > vend - v) { bad0 = true; break; }          // an element across the 64 KB boundary: not the standard block structure
-        out = sn_u(out + len); v = sn_u(v + step);
+        {
+          const uint32_t up = (uint32_t)__shfl_down((int)cur, 1, 64), hi = lane == 63 ? (uint32_t)__builtin_amdgcn_readlane((int)nxt, 0) : up;
+          const uint64_t w = ((uint64_t)hi << 32) | cur;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            uint32_t len, step; tagdec(w >> (8 * j), len, step);
+            const uint32_t p = 4 * lane + j; uint32_t np = p + step; if (len == 0 || step == 0) np = 0x7FFFFFFFu;        // malformed: runs out of the stream, caught by v >= vend
+            pjN[p] = (uint16_t)(np < 256u ? np : 256u); pjO[p] = len; pjX[p] = np < 256u ? 0u : np - 256u;
+          }
+          if (lane == 0) { pjN[256] = 256; pjO[256] = 0; pjX[256] = 0; }
+          sn_order();
+#pragma unroll 1
+          for (int r = 0; r < 8; r++) {
+            uint32_t n[4], o[4], x[4], nn[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) n[j] = pjN[4 * lane + j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { o[j] = pjO[n[j]]; x[j] = pjX[n[j]]; nn[j] = pjN[n[j]]; }
+            sn_order();
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (n[j] < 256u) { const uint32_t p = 4 * lane + j; pjO[p] += o[j]; pjX[p] = x[j]; pjN[p] = (uint16_t)nn[j]; }
+            sn_order();
+          }
+          const uint32_t e = v - wv, co = sn_u(pjO[e]), cx = sn_u(pjX[e]), cn = sn_u(pjN[e]);
+          sn_order();
+          if (cn == 256u && co <= target - out && cx < 0x40000000u) { out = sn_u(out + co); v = sn_u(wv + 256u + cx); continue; }
+        }
+        while (out < target && v - wv < 256u && v < vend) {          // the chunk that holds the boundary (or one the jump could not finish): tag by tag
+          const uint32_t idx = (v - wv) >> 2, sh = (v & 3u) * 8u;
+          const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)idx), a1 = idx == 63u ? (uint32_t)__builtin_amdgcn_readlane((int)nxt, 0) : (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(idx + 1u));
+          uint32_t len, step; tagdec((((uint64_t)a1 << 32) | a0) >> sh, len, step);
+          if (len == 0 || len > target - out || step > vend - v) { bad0 = true; break; }          // an element across the 64 KB boundary: not the standard block structure
+          out = sn_u(out + len); v = sn_u(v + step);
+        }
+        if (bad0) break;
       }
       if (bad0) { give_up(); return; }
       pin = sn_u(v - A);
