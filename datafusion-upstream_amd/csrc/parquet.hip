@@ -494,7 +494,6 @@ __global__ void __launch_bounds__(64) k_pq_snappy(const SnJob* __restrict__ jobs
   pin = sn_u(pin);
   const uint32_t csize = sn_u(jb.csize);
   uint32_t usize = sn_u(jb.usize);
-  bool last_block = true;
   if (blks) {
     const uint32_t target = blk * 65536u;
     if (target) {           // skip the elements of the blocks in front
@@ -554,12 +553,19 @@ __global__ void __launch_bounds__(64) k_pq_snappy(const SnJob* __restrict__ jobs
       pin = sn_u(v - A);
     }
     if (target >= usize) { give_up(); return; }
-    last_block = usize - target <= 65536u;
     usize = sn_u(min(65536u, usize - target)); jb.dst += target;
   }
-  uint32_t pout = 0, flushed = 0, wb = 0, wl = 0; bool bad = false;
+  // ---- decode: the input is taken a 256-byte chunk at a time.  Pointer jumping (as in the skip above, with the jump table of every doubling level kept) finds which
+  // byte positions of the chunk start an element and where each element's output goes; the chunk's elements are then listed in order.  Literals of up to 64
+  // bytes do not depend on earlier output: every lane moves one of them (input window -> ring).  Only copies (and long literals) run one after the other, all
+  // lanes moving one element's bytes.
+  uint32_t pout = 0, flushed = 0, wbv = 0xFFFFFFFFu, wlen = 0; bool bad = false;
   const bool dst16 = ((uintptr_t)jb.dst & 15) == 0;
+  const uint32_t A = (uint32_t)((uintptr_t)jb.src & 3), vend = csize + A; const uint32_t* base32 = (const uint32_t*)(jb.src - A);
   const uint8_t* winb = (const uint8_t*)win;
+  __shared__ uint16_t dN[260], dL[8][256], dTS[136]; __shared__ uint32_t dO[260], dX[260]; __shared__ uint8_t dR[264];
+  struct SnSym { uint32_t opos, len, off, src; };
+  __shared__ SnSym dT[136];
   auto flush = [&](uint32_t upto) {            // ring -> dst for [flushed, upto)
     uint32_t a = flushed; flushed = sn_u(upto);
     if (!dst16) { for (uint32_t o = a + lane; o < upto; o += 64) jb.dst[o] = ring[o & (SN_RING - 1)]; return; }
@@ -569,68 +575,121 @@ __global__ void __launch_bounds__(64) k_pq_snappy(const SnJob* __restrict__ jobs
     for (uint32_t i = lane; i < n16; i += 64) { uint32_t o = head + (i << 4); *(uint4*)(jb.dst + o) = *(const uint4*)(ring + (o & (SN_RING - 1))); }
     for (uint32_t o = head + (n16 << 4) + lane; o < upto; o += 64) jb.dst[o] = ring[o & (SN_RING - 1)];
   };
-  auto reload = [&](uint32_t at) {             // window = input [at, at + SN_WIN), two zero words behind it
+  uint32_t v = pin + A;
+  while (pout < usize) {
+    if (v >= vend) { bad = true; break; }
+    const uint32_t wv = sn_u(v & ~255u);
+    if (!(wv >= wbv && (wv + 384u <= wbv + wlen || wbv + wlen >= vend))) {       // LDS window of the input: the chunk and the 128 bytes behind it (short literal bodies)
+      sn_order();
+      wbv = wv; wlen = sn_u(min((uint32_t)SN_WIN, ((vend - wbv) + 3u) & ~3u));
+      const uint32_t nw = wlen >> 2;
+      for (uint32_t i = lane; i < nw; i += 64) win[i] = base32[(wbv >> 2) + i];
+      for (uint32_t i = nw + lane; i < nw + 4; i += 64) win[i] = 0;
+      sn_order();
+    }
+    const uint32_t wi = (wv - wbv) >> 2, nwv = wlen >> 2;
+    const uint32_t cur = wi + lane < nwv ? win[wi + lane] : 0u, nx0 = wi + 64 < nwv ? win[wi + 64] : 0u;
+    const uint32_t up = (uint32_t)__shfl_down((int)cur, 1, 64);
+    const uint64_t w = ((uint64_t)(lane == 63 ? nx0 : up) << 32) | cur;
+    uint32_t len4[4], step4[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint64_t t = w >> (8 * j); const uint32_t lo = (uint32_t)t, b0 = lo & 0xff, kind = lo & 3; uint32_t len, step;
+      if (kind == 0) { len = (b0 >> 2) + 1; step = 1; if (len > 60) { uint32_t nb = len - 60; uint32_t ext = (uint32_t)(t >> 8); len = (nb == 4 ? ext : (ext & ((1u << (8 * nb)) - 1u))) + 1; step = 1 + nb; } step += len; }
+      else if (kind == 1) { len = 4 + ((b0 >> 2) & 7); step = 2; } else { len = 1 + (b0 >> 2); step = kind == 2 ? 3 : 5; }
+      len4[j] = len; step4[j] = step;
+      const uint32_t p = 4 * lane + j; uint32_t np = p + step; if (len == 0 || (kind == 0 && step < len) || step > 0x3FFFFFFFu) np = 0x7FFFFFFFu;        // malformed / absurd lengths: leave the stream, caught below
+      dN[p] = (uint16_t)(np < 256u ? np : 256u); dO[p] = len; dX[p] = np < 256u ? 0u : np - 256u; dR[p] = 0;
+    }
+    if (lane == 0) { dN[256] = 256; dO[256] = 0; dX[256] = 0; }
     sn_order();
-    wb = sn_u(at); wl = sn_u(min((uint32_t)SN_WIN, csize - at));
-    uint32_t nw = (wl + 3) >> 2;
-    for (uint32_t i = lane; i < nw; i += 64) win[i] = ld32u(jb.src + wb + 4 * i);
-    if (lane < 2) win[nw + lane] = 0;
+#pragma unroll 1
+    for (int r = 0; r < 8; r++) {
+      uint32_t n[4], o[4], x[4], nn[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { n[j] = dN[4 * lane + j]; dL[r][4 * lane + j] = (uint16_t)n[j]; }
+#pragma unroll
+      for (int j = 0; j < 4; j++) { o[j] = dO[n[j]]; x[j] = dX[n[j]]; nn[j] = dN[n[j]]; }
+      sn_order();
+#pragma unroll
+      for (int j = 0; j < 4; j++) if (n[j] < 256u) { const uint32_t p = 4 * lane + j; dO[p] += o[j]; dX[p] = x[j]; dN[p] = (uint16_t)nn[j]; }
+      sn_order();
+    }
+    const uint32_t e = v - wv, c_out = sn_u(dO[e]), c_x = sn_u(dX[e]), c_n = sn_u(dN[e]);
+    if (c_n != 256u || c_x >= 0x40000000u) { bad = true; break; }
+    // positions on the path from e: top-down over the doubling levels (a node at distance d is reached through the set bits of d, high to low)
+    if (lane == 0) dR[e] = 1;
     sn_order();
-  };
-  if (pin >= csize) { give_up(); return; }
-  reload(pin);
-  uint64_t tv = sn_peek(win, pin - wb);
-  while (pin < csize && pout < usize) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)tv), hi = __builtin_amdgcn_readfirstlane((uint32_t)(tv >> 32));
-    const uint32_t kind = lo & 3, b0 = lo & 0xff;
-    uint32_t len, off = 0, hdr;
-    if (kind == 0) {
-      len = (b0 >> 2) + 1; hdr = 1;
-      if (len > 60) { uint32_t nb = len - 60; uint32_t ext = (lo >> 8) | (hi << 24); len = (nb == 4 ? ext : (ext & ((1u << (8 * nb)) - 1u))) + 1; hdr = 1 + nb; if (len == 0) { bad = true; break; } }
-    } else if (kind == 1) { len = 4 + ((b0 >> 2) & 7); off = ((b0 >> 5) << 8) | ((lo >> 8) & 0xff); hdr = 2; }
-    else if (kind == 2) { len = 1 + (b0 >> 2); off = (lo >> 8) & 0xffff; hdr = 3; }
-    else { len = 1 + (b0 >> 2); off = (lo >> 8) | (hi << 24); hdr = 5; }
-    const uint32_t body = kind == 0 ? len : 0;
-    if (len > usize - pout || hdr > csize - pin || body > csize - pin - hdr || (kind != 0 && (off == 0 || off > pout))) { bad = true; break; }
-    const uint32_t next = pin + hdr + body;
-    const bool inwin = next + 8 <= wb + wl || wb + wl == csize;
-    if (!inwin || body > 64) {                 // a long literal, or the window ends: move the literal from HBM, refill the window at the next tag
-      if (kind == 0) {
-        uint32_t from = pin + hdr, left = len;
+#pragma unroll 1
+    for (int r = 7; r >= 0; r--) {
+      uint32_t rp[4], t[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { rp[j] = dR[4 * lane + j]; t[j] = dL[r][4 * lane + j]; }
+      sn_order();
+#pragma unroll
+      for (int j = 0; j < 4; j++) if (rp[j] && t[j] < 256u) dR[t[j]] = 1;
+      sn_order();
+    }
+    // the chunk's elements in order: output position, length, copy offset (0 = literal) and literal source; those past the end of the block are left out
+    uint32_t cnt = 0, scnt = 0, flag = 0, sflag = 0; SnSym sy[4]; bool mal = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t p = 4 * lane + j;
+      if (!dR[p]) continue;
+      const uint64_t t = w >> (8 * j); const uint32_t lo = (uint32_t)t, b0 = lo & 0xff, kind = lo & 3;
+      const uint32_t opos = pout + (c_out - dO[p]), len = len4[j];
+      if (opos >= usize) continue;
+      uint32_t off = 0;
+      if (kind == 1) off = ((b0 >> 5) << 8) | ((lo >> 8) & 0xff); else if (kind == 2) off = (lo >> 8) & 0xffff; else if (kind == 3) off = (uint32_t)(t >> 8);
+      const uint32_t ipos = wv + p;          // virtual input position of the tag
+      if (len > usize - opos || ipos >= vend || step4[j] > vend - ipos || (kind != 0 && (off == 0 || off > opos))) { mal = true; continue; }
+      sy[j] = SnSym{opos, len, off, kind == 0 ? ipos + (step4[j] - len) : 0u};       // literal: first byte of the body (virtual position)
+      flag |= 1u << j; cnt++;
+      if (kind != 0 || len > 64u) { sflag |= 1u << j; scnt++; }
+    }
+    if (ballot64(mal)) { bad = true; break; }
+    const uint32_t kinc = wave_inclusive_sum(cnt), sinc = wave_inclusive_sum(scnt);
+    const uint32_t K = (uint32_t)__builtin_amdgcn_readlane((int)kinc, 63), KS = (uint32_t)__builtin_amdgcn_readlane((int)sinc, 63);
+    if (K > 136u) { bad = true; break; }
+    { uint32_t k = kinc - cnt, ks = sinc - scnt;
+#pragma unroll
+      for (int j = 0; j < 4; j++) if ((flag >> j) & 1) { dT[k] = sy[j]; if ((sflag >> j) & 1) dTS[ks++] = (uint16_t)k; k++; } }
+    sn_order();
+    const uint32_t chunk_end = min(pout + c_out, usize);
+    // short literals: one lane each, input window -> ring
+    for (uint32_t k = lane; k < K; k += 64) {
+      const SnSym q = dT[k];
+      if (q.off == 0 && q.len <= 64u) { const uint32_t bi = q.src - wbv; for (uint32_t b = 0; b < q.len; b++) ring[(q.opos + b) & (SN_RING - 1)] = winb[bi + b]; }
+    }
+    sn_order();
+    // copies and long literals, in order
+    for (uint32_t ks = 0; ks < KS && !bad; ks++) {
+      const uint32_t k = dTS[ks];
+      const uint32_t opos = sn_u(dT[k].opos), len = sn_u(dT[k].len), off = sn_u(dT[k].off), src = sn_u(dT[k].src);
+      if (off == 0) {               // long literal: from HBM in pieces, flushing as the ring fills
+        uint32_t from = src - A, left = len, at = opos;
         while (left) {
-          uint32_t piece = min(left, (uint32_t)SN_FLUSH);
-          for (uint32_t i = lane; i < piece; i += 64) ring[(pout + i) & (SN_RING - 1)] = jb.src[from + i];
-          pout = sn_u(pout + piece); from = sn_u(from + piece); left = sn_u(left - piece);
+          const uint32_t piece = min(left, (uint32_t)SN_FLUSH);
+          if (at + piece - flushed > (uint32_t)(SN_RING - 64)) { flush(at); sn_order(); }
+          for (uint32_t i = lane; i < piece; i += 64) ring[(at + i) & (SN_RING - 1)] = jb.src[from + i];
+          at = sn_u(at + piece); from = sn_u(from + piece); left = sn_u(left - piece);
           sn_order();
-          if (pout - flushed >= (uint32_t)SN_FLUSH) { flush(pout & ~15u); sn_order(); }
         }
-        pin = sn_u(next);
-        if (pin < csize) { reload(pin); tv = sn_peek(win, 0); }
         continue;
       }
-      reload(pin); tv = sn_peek(win, 0);        // a copy tag whose successor lies beyond the window: same tag again, window now starts at it
-      if (!(next + 8 <= wb + wl || wb + wl == csize)) { bad = true; break; }
-      continue;
-    }
-    const uint64_t tnext = sn_peek(win, next - wb);           // requested before this element's bytes move
-    if (kind == 0) { if (lane < len) ring[(pout + lane) & (SN_RING - 1)] = winb[pin + hdr - wb + lane]; }
-    else if (off <= (uint32_t)(SN_RING - 64)) {
       uint32_t rel = lane;
       if (off < len) { uint32_t q = (uint32_t)((float)lane * __frcp_rn((float)off)); int32_t r = (int32_t)lane - (int32_t)(q * off); rel = r < 0 ? (uint32_t)(r + (int32_t)off) : ((uint32_t)r >= off ? (uint32_t)r - off : (uint32_t)r); }
-      uint8_t b = 0;
-      if (lane < len) b = ring[(pout - off + rel) & (SN_RING - 1)];
-      if (lane < len) ring[(pout + lane) & (SN_RING - 1)] = b;
-    } else {                                   // a reference beyond the ring: read what was flushed
-      flush(pout); sn_order(); __threadfence_block();
-      uint8_t b = 0;
-      if (lane < len) b = jb.dst[pout - off + (off >= len ? lane : lane % off)];
-      if (lane < len) ring[(pout + lane) & (SN_RING - 1)] = b;
+      uint8_t bt = 0;
+      if (off + (chunk_end - opos) <= (uint32_t)(SN_RING - 64)) { if (lane < len) bt = ring[(opos - off + rel) & (SN_RING - 1)]; }        // the source is still in the ring even with this chunk's literals written ahead
+      else { flush(opos); sn_order(); __threadfence_block(); if (lane < len) bt = jb.dst[opos - off + rel]; }
+      if (lane < len) ring[(opos + lane) & (SN_RING - 1)] = bt;
+      sn_order();
     }
-    pout = sn_u(pout + len); pin = sn_u(next); tv = tnext;
-    sn_order();
+    if (bad) break;
+    pout = sn_u(chunk_end); v = sn_u(wv + 256u + c_x);
     if (pout - flushed >= (uint32_t)SN_FLUSH) { flush(pout & ~15u); sn_order(); }
   }
-  if (bad || pout != usize || (last_block && pin != csize && blks)) { give_up(); return; }
+  if (bad || pout != usize) { give_up(); return; }
   sn_order();
   flush(pout);
 #undef sn_u
