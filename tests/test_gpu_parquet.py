@@ -163,3 +163,32 @@ def test_malformed_pages_raise_instead_of_faulting(ctx, tmp_path):
             assert e.kind in ("Execution", "NotImplemented"), str(e)
             raised += 1
     assert raised >= 1
+
+
+def test_snappy_element_patterns_across_blocks(ctx, tmp_path):
+    """PLAIN pages of several hundred KB under Snappy, chosen for what the decompressor sees: runs (copies of offset 8 / 1 that overlap their own output), incompressible
+    bytes (literals of up to 64 KB), a pattern that repeats every 50 000 bytes (references further back than the 32 KB ring: read from HBM), short repeats inside
+    strings, and a sorted column (two elements per value).  Multi-block pages: every 64 KB output block is decoded by its own wave."""
+    from dfgpu.parquet import ParquetFile
+    n = 400000
+    rng = np.random.default_rng(17)
+    period = rng.integers(0, 1 << 62, 6250).astype(np.int64)             # 50 000 bytes
+    words = np.array(["alpha", "beta", "gamma", "delta-delta-delta", "", "x" * 70, "épsilon"])
+    t = pa.table({
+        "constant": pa.array(np.full(n, 123456789012345, dtype=np.int64)),
+        "random": pa.array(rng.integers(-(1 << 62), 1 << 62, n).astype(np.int64)),
+        "sorted": pa.array(np.cumsum(rng.integers(0, 9, n)).astype(np.int64)),
+        "sawtooth": pa.array((np.arange(n) % 1000).astype(np.int32)),
+        "far_repeat": pa.array(np.tile(period, n // len(period) + 1)[:n]),
+        "zeros_then_noise": pa.array(np.where(np.arange(n) % 20000 < 15000, 0, rng.integers(0, 1 << 40, n)).astype(np.int64)),
+        "text": pa.array(words[rng.integers(0, len(words), n)]),
+        "runs_text": pa.array(["ab" * int(k) for k in rng.integers(0, 40, n)]),
+        "nullable": pa.array(rng.integers(0, 3, n).astype(np.int64), mask=rng.random(n) < 0.5),
+    })
+    path = str(tmp_path / "patterns.parquet")
+    pq.write_table(t, path, compression="snappy", use_dictionary=False, row_group_size=n, data_page_size=1 << 20)
+    want = pq.read_table(path)
+    for staged in (True, False):
+        f = ParquetFile(ctx, path=path, stage_on_device=staged, utf8_dictionary=False)
+        for name, a in zip(f.column_names(), f.read()):
+            same_column(a.to_arrow(), want[name], name)
