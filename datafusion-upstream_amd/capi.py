@@ -145,6 +145,8 @@ PROTOTYPES = {
     "dfgpu_acc_evaluate": (C.c_int32, [_P, _P, _PP]),
     "dfgpu_acc_state": (C.c_int32, [_P, _P, _PP, C.POINTER(C.c_int32)]),
     "dfgpu_acc_size": (C.c_int64, [_P]),
+    "dfgpu_acc_emit_first": (C.c_int32, [_P, _P, C.c_int64, C.c_int32, _PP, C.POINTER(C.c_int32)]),
+    "dfgpu_groups_emit_first": (C.c_int32, [_P, _P, C.c_int64, _PP]),
     "dfgpu_array_iota": (C.c_int32, [_P, C.c_int64, _PP]),
     "dfgpu_cross_join_indices": (C.c_int32, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _PP, _PP]),
     "dfgpu_sort_to_indices": (C.c_int32, [_P, _PP, C.c_char_p, C.c_char_p, C.c_int32, C.c_int64, _PP]),

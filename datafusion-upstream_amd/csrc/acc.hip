@@ -1052,4 +1052,31 @@ dfgpu_status dfgpu_acc_state(dfgpu_ctx* ctx, dfgpu_acc* a, dfgpu_array** out_sta
   });
 }
 
+/* see include/dfgpu.h */
+dfgpu_status dfgpu_acc_emit_first(dfgpu_ctx* ctx, dfgpu_acc* a, int64_t n, int32_t as_state, dfgpu_array** out, int32_t* n_out) {
+  return guard(ctx, [&] {
+    if (!a || !out || n < 0) fail(DFGPU_INVALID_ARGUMENT, "acc_emit_first: bad argument");
+    const int64_t total = a->n, k = n < total ? n : total;
+    dfgpu_array* st[2] = {nullptr, nullptr}; int32_t ns = 0;
+    dfgpu_status rc = dfgpu_acc_state(ctx, a, st, &ns); if (rc != DFGPU_OK) fail(rc, "%s", ctx->err.c_str());
+    ArrayHolder s0(st[0]), s1(st[1]);
+    ArrayHolder ev; if (!as_state) { dfgpu_array* e = nullptr; rc = dfgpu_acc_evaluate(ctx, a, &e); if (rc != DFGPU_OK) fail(rc, "%s", ctx->err.c_str()); ev.a = e; }
+    auto slice = [&](const dfgpu_array* x, int64_t off, int64_t len) { dfgpu_array* o = nullptr; dfgpu_status r2 = dfgpu_array_slice(ctx, x, off, len, &o); if (r2 != DFGPU_OK) fail(r2, "%s", ctx->err.c_str()); return o; };
+    ArrayHolder o0, o1;
+    if (as_state) { o0.a = slice(s0.get(), 0, k); if (ns > 1) o1.a = slice(s1.get(), 0, k); } else o0.a = slice(ev.get(), 0, k);
+    // the groups that stay are renumbered from 0 (EmitTo::take_needed): their states are merged into the emptied accumulator under ids 0 .. total - k - 1
+    const int kind = a->kind; const int32_t it = a->in_type, ip = a->in_precision, is = a->in_scale;
+    a->n = 0; a->cap = 0; a->vals.reset(); a->counts.reset(); a->seen.reset();
+    (void)kind; (void)it; (void)ip; (void)is;
+    if (k < total) {
+      ArrayHolder r0(slice(s0.get(), k, total - k)), r1; if (ns > 1) r1.a = slice(s1.get(), k, total - k);
+      dfgpu_array* ids = nullptr; rc = dfgpu_array_iota(ctx, total - k, &ids); if (rc != DFGPU_OK) fail(rc, "%s", ctx->err.c_str()); ArrayHolder idh(ids);
+      const dfgpu_array* sp[2] = { r0.get(), r1.get() };
+      rc = dfgpu_acc_merge_batch(ctx, a, sp, ns, idh.get(), nullptr, total - k); if (rc != DFGPU_OK) fail(rc, "%s", ctx->err.c_str());
+    }
+    out[0] = o0.release(); if (as_state && ns > 1) out[1] = o1.release();
+    if (n_out) *n_out = as_state ? ns : 1;
+  });
+}
+
 }  // extern "C"

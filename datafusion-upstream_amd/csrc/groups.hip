@@ -9,6 +9,7 @@
 // Ids must come out in FIRST-SEEN order (primitive.rs:137-141): every new slot keeps
 // atomicMin(first row); rows that are "first of their group" are flagged in a bitmap, compacted in
 // row order (ballot + scan), and their rank is the new id -- O(rows) streaming work, no sort.
+#include <new>
 #include "device_utils.h"
 #include <algorithm>
 
@@ -864,6 +865,30 @@ dfgpu_status dfgpu_groups_emit(dfgpu_ctx* ctx, dfgpu_groups* g, dfgpu_array** ou
     if (!g || !out_cols) fail(DFGPU_INVALID_ARGUMENT, "groups_emit: null argument");
     if (g->n_groups == 0) fail(DFGPU_INVALID_ARGUMENT, "groups_emit: no groups interned yet (key types unknown)");
     for (int c = 0; c < g->nkeys; c++) { dfgpu_array_retain(g->keys[c]); out_cols[c] = g->keys[c]; }
+  });
+}
+
+/* see include/dfgpu.h */
+dfgpu_status dfgpu_groups_emit_first(dfgpu_ctx* ctx, dfgpu_groups* g, int64_t n, dfgpu_array** out_cols) {
+  return guard(ctx, [&] {
+    if (!g || !out_cols || n < 0) fail(DFGPU_INVALID_ARGUMENT, "groups_emit_first: bad argument");
+    if (g->n_groups == 0) fail(DFGPU_INVALID_ARGUMENT, "groups_emit_first: no groups interned yet (key types unknown)");
+    const int64_t total = g->n_groups, k = n < total ? n : total; const int32_t nkeys = g->nkeys;
+    std::vector<ArrayHolder> first((size_t)nkeys), rest((size_t)nkeys);
+    for (int c = 0; c < nkeys; c++) {
+      dfgpu_array* a = nullptr; dfgpu_status st = dfgpu_array_slice(ctx, g->keys[c], 0, k, &a); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str()); first[(size_t)c].a = a;
+      if (k < total) { dfgpu_array* b = nullptr; st = dfgpu_array_slice(ctx, g->keys[c], k, total - k, &b); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str()); rest[(size_t)c].a = b; }
+    }
+    // the remaining groups are renumbered from 0 (EmitTo::take_needed, expr/src/groups_accumulator.rs:44-57; GroupValuesRows::emit First(n) rebuilds its map the same way,
+    // group_values/row.rs:176-212): a fresh table over the remaining keys -- distinct, interned in order, so they get ids 0 .. total - k - 1
+    g->~dfgpu_groups(); new (g) dfgpu_groups(); g->ctx = ctx; g->nkeys = nkeys; g->keys.assign((size_t)nkeys, nullptr);
+    if (k < total) {
+      std::vector<const dfgpu_array*> rp; for (auto& h : rest) rp.push_back(h.get());
+      dfgpu_array* ids = nullptr; dfgpu_status st = dfgpu_groups_intern(ctx, g, rp.data(), nkeys, nullptr, &ids); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str());
+      dfgpu_array_release(ids);
+      if (g->n_groups != total - k) fail(DFGPU_INTERNAL, "groups_emit_first: %lld groups left after re-interning %lld keys", (long long)g->n_groups, (long long)(total - k));
+    }
+    for (int c = 0; c < nkeys; c++) out_cols[c] = first[(size_t)c].release();
   });
 }
 

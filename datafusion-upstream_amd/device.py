@@ -393,6 +393,12 @@ class GroupValues:
     def size(self) -> int:
         return self.ctx.lib.dfgpu_groups_size(self.h)
 
+    def emit_first(self, n: int) -> List[Array]:
+        """EmitTo::First(n): the first n groups leave, the others are renumbered from 0"""
+        out = (C.c_void_p * self.nkeys)()
+        self.ctx.check(self.ctx.lib.dfgpu_groups_emit_first(self.ctx.h, self.h, n, out))
+        return [Array(self.ctx, C.c_void_p(out[i])) for i in range(self.nkeys)]
+
     def emit(self) -> List[Array]:
         outs = (C.c_void_p * self.nkeys)()
         self.ctx.check(self.ctx.lib.dfgpu_groups_emit(self.ctx.h, self.h, outs))
@@ -446,6 +452,12 @@ class GroupsAccumulator:
     def merge_batch(self, states: Sequence[Array], group_ids: Array, opt_filter: Optional[Array], total_num_groups: int):
         hs, n = capi.handle_array([a.h.value for a in states])
         self.ctx.check(self.ctx.lib.dfgpu_acc_merge_batch(self.ctx.h, self.h, hs, n, group_ids.h, opt_filter.h if opt_filter is not None else None, total_num_groups))
+
+    def emit_first(self, n: int, as_state: bool = False) -> List[Array]:
+        """evaluate / state with EmitTo::First(n)"""
+        out = (C.c_void_p * 2)(); k = C.c_int32()
+        self.ctx.check(self.ctx.lib.dfgpu_acc_emit_first(self.ctx.h, self.h, n, 1 if as_state else 0, out, C.byref(k)))
+        return [Array(self.ctx, C.c_void_p(out[i])) for i in range(k.value)]
 
     def evaluate(self) -> Array:
         out = C.c_void_p()

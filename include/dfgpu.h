@@ -284,6 +284,9 @@ DFGPU_API int64_t dfgpu_groups_len(const dfgpu_groups *g);                   /* 
 DFGPU_API int64_t dfgpu_groups_size(const dfgpu_groups *g);                  /* GroupValues::size (bytes) */
 /* ≙ GroupValues::emit(EmitTo::All) (primitive.rs:163-209): key columns in group id order. */
 DFGPU_API dfgpu_status dfgpu_groups_emit(dfgpu_ctx *ctx, dfgpu_groups *g, dfgpu_array **out_cols /* nkeys */);
+/* ≙ GroupValues::emit(EmitTo::First(n)) (expr/src/groups_accumulator.rs:25-57, group_values/row.rs:176-212, primitive.rs:151-190): the keys of the first n groups
+ * leave, the remaining groups are renumbered from 0 (group id g becomes g - n); ids handed out earlier refer to the old numbering.  n >= len emits everything. */
+DFGPU_API dfgpu_status dfgpu_groups_emit_first(dfgpu_ctx *ctx, dfgpu_groups *g, int64_t n, dfgpu_array **out_cols /* nkeys */);
 
 /* ------------------------------------------------------------------ a9: GroupsAccumulator */
 enum { DFGPU_AGG_SUM = 0, DFGPU_AGG_AVG = 1, DFGPU_AGG_COUNT = 2, DFGPU_AGG_MIN = 3, DFGPU_AGG_MAX = 4 };
@@ -341,6 +344,9 @@ DFGPU_API dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx *ctx, const dfgpu_array 
 /* ≙ evaluate(EmitTo::All) / state(EmitTo::All) (:106-134).  out_states holds up to 2 arrays. */
 DFGPU_API dfgpu_status dfgpu_acc_evaluate(dfgpu_ctx *ctx, dfgpu_acc *a, dfgpu_array **out);
 DFGPU_API dfgpu_status dfgpu_acc_state(dfgpu_ctx *ctx, dfgpu_acc *a, dfgpu_array **out_states, int32_t *n_states);
+/* ≙ GroupsAccumulator::evaluate / state with EmitTo::First(n) (prim_op.rs:129-140, average.rs:432-470, count.rs:172-190): as_state = 0 -> out[0] = the final values of the
+ * first n groups; as_state = 1 -> out[0 .. *n_out) = their state arrays; the remaining groups keep their state under ids lowered by n. */
+DFGPU_API dfgpu_status dfgpu_acc_emit_first(dfgpu_ctx *ctx, dfgpu_acc *a, int64_t n, int32_t as_state, dfgpu_array **out, int32_t *n_out);
 DFGPU_API int64_t dfgpu_acc_size(const dfgpu_acc *a);
 
 /* ------------------------------------------------------------------ a13: SortExec */
