@@ -975,7 +975,69 @@ struct NestedLoopJoinExec : Plan {
 struct AggExpr { int kind; ExprPtr arg, filter; std::string name; int32_t type, precision, scale; };    // ≙ AggregateExpr for Sum/Avg/Count/Min/Max
 struct GroupsRef { dfgpu_groups* g = nullptr; ~GroupsRef() { if (g) dfgpu_groups_free(g); } };
 struct AccRef { dfgpu_acc* a = nullptr; ~AccRef() { if (a) dfgpu_acc_free(a); } };
-static const char* agg_fun_name(int k) { switch (k) { case DFGPU_AGG_SUM: return "sum"; case DFGPU_AGG_AVG: return "avg"; case DFGPU_AGG_COUNT: return "count"; case DFGPU_AGG_MIN: return "min"; default: return "max"; } }
+static const char* agg_fun_name(int k) { switch (k) { case DFGPU_AGG_SUM: return "sum"; case DFGPU_AGG_AVG: return "avg"; case DFGPU_AGG_COUNT: return "count"; case DFGPU_AGG_MIN: return "min"; case DFGPU_AGG_COUNT_DISTINCT: return "count distinct"; default: return "max"; } }
+
+// ---- aggregates without a GroupsAccumulator of their own in the kernel library, composed from its other entry points
+// MIN / MAX over Utf8 (physical-expr/src/aggregate/min_max.rs: the row-at-a-time Accumulator behind GroupsAccumulatorAdapter): the state is one (group, value) row per
+// group seen with a non-NULL value; a batch is folded in by concatenating its (group id, value) rows with the state, ordering by (group id, value) and keeping
+// every group's first row.  The state of Partial is the value itself (min_max.rs state() = [evaluate()]), so every mode works.
+struct StringMinMax {
+  bool is_max = false; ArrayRef gids, vals;
+  static ArrayRef true1(const TaskContext& tc) { uint64_t one = 1; dfgpu_array_desc d{}; d.type = DFGPU_BOOL; d.length = 1; d.values = &one; dfgpu_array* a = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &d, &a)); return ArrayRef::adopt(a); }
+  static ArrayRef slice(const TaskContext& tc, const ArrayRef& a, int64_t off, int64_t len) { dfgpu_array* o = nullptr; tc.check(dfgpu_array_slice(tc.ctx, a.a, off, len, &o)); return ArrayRef::adopt(o); }
+  void reduce(const TaskContext& tc, ArrayRef g, ArrayRef v) {
+    const int64_t n = g.len();
+    if (n == 0) { gids = g; vals = v; return; }
+    const dfgpu_array* kp[2] = { g.a, v.a }; uint8_t desc[2] = { 0, (uint8_t)(is_max ? 1 : 0) }, nf[2] = { 0, 0 }; dfgpu_array* ix = nullptr;
+    tc.check(dfgpu_sort_to_indices(tc.ctx, kp, desc, nf, 2, -1, &ix)); ArrayRef order = ArrayRef::adopt(ix);
+    ArrayRef gs = take(tc, g, order), vs = take(tc, v, order), head = true1(tc);
+    if (n > 1) {
+      ArrayRef a = slice(tc, gs, 1, n - 1), b = slice(tc, gs, 0, n - 1); dfgpu_array* ne = nullptr; tc.check(dfgpu_binary(tc.ctx, DFGPU_OP_NEQ, a.a, 0, b.a, 0, &ne)); ArrayRef neq = ArrayRef::adopt(ne);
+      std::vector<ArrayRef> parts{head, neq}; head = concat_arrays(tc, parts);
+    }
+    ArrayRef hi = mask_indices(tc, head); gids = take(tc, gs, hi); vals = take(tc, vs, hi);
+  }
+  void update(const TaskContext& tc, const ArrayRef& g_in, ArrayRef v_in, const ArrayRef& filter) {
+    dfgpu_array_desc d; dfgpu_array_describe(v_in.a, &d);
+    if (d.type == DFGPU_DICTIONARY) { dfgpu_array* c = nullptr; tc.check(dfgpu_cast(tc.ctx, v_in.a, DFGPU_UTF8, 0, 0, &c)); v_in = ArrayRef::adopt(c); }
+    dfgpu_array* nn = nullptr; tc.check(dfgpu_is_null(tc.ctx, v_in.a, 1, &nn)); ArrayRef mask = ArrayRef::adopt(nn);
+    if (filter) { ArrayRef kf = known_mask(tc, filter); dfgpu_array* o = nullptr; tc.check(dfgpu_binary(tc.ctx, DFGPU_OP_AND, mask.a, 0, kf.a, 0, &o)); mask = ArrayRef::adopt(o); }
+    dfgpu_array *fg = nullptr, *fv = nullptr; tc.check(dfgpu_filter(tc.ctx, g_in.a, mask.a, &fg)); ArrayRef g = ArrayRef::adopt(fg); tc.check(dfgpu_filter(tc.ctx, v_in.a, mask.a, &fv)); ArrayRef v = ArrayRef::adopt(fv);
+    if (gids && gids.len()) { std::vector<ArrayRef> gp{gids, g}, vp{vals, v}; g = concat_arrays(tc, gp); v = concat_arrays(tc, vp); }
+    reduce(tc, g, v);
+  }
+  ArrayRef emit(const TaskContext& tc, int64_t total) {          // one row per group 0 .. total-1, NULL where no value was seen: a NULL candidate per group orders last
+    dfgpu_array *io = nullptr, *nl = nullptr; tc.check(dfgpu_array_iota(tc.ctx, total, &io)); ArrayRef g = ArrayRef::adopt(io); tc.check(dfgpu_array_new_null(tc.ctx, DFGPU_UTF8, 0, 0, total, &nl)); ArrayRef v = ArrayRef::adopt(nl);
+    if (gids && gids.len()) { std::vector<ArrayRef> gp{gids, g}, vp{vals, v}; g = concat_arrays(tc, gp); v = concat_arrays(tc, vp); }
+    StringMinMax t; t.is_max = is_max; t.reduce(tc, g, v);
+    if (t.vals.len() != total) fail(DFGPU_INTERNAL, "string MIN/MAX: %lld rows for %lld groups", (long long)t.vals.len(), (long long)total);
+    return t.vals;
+  }
+};
+// COUNT(DISTINCT x) (physical-expr/src/aggregate/count_distinct/: a set of values per group): the (group id, value) pairs are interned in a GroupValues of their own;
+// every NEW pair adds one to its group's count.  The reference's Partial state is a List per group, which the flat state arrays here do not carry: Single /
+// SinglePartitioned only (the planner's SingleDistinctToGroupBy rewrite covers the partitioned form with ordinary aggregates).
+struct CountDistinct {
+  GroupsRef pairs; AccRef cnt;
+  void init(const TaskContext& tc) { tc.check(dfgpu_groups_new(tc.ctx, 2, &pairs.g)); tc.check(dfgpu_acc_new(tc.ctx, DFGPU_AGG_COUNT, DFGPU_INT64, 0, 0, &cnt.a)); }
+  void update(const TaskContext& tc, const ArrayRef& g_in, const ArrayRef& v_in, const ArrayRef& filter, int64_t total) {
+    dfgpu_array* nn = nullptr; tc.check(dfgpu_is_null(tc.ctx, v_in.a, 1, &nn)); ArrayRef mask = ArrayRef::adopt(nn);
+    if (filter) { ArrayRef kf = known_mask(tc, filter); dfgpu_array* o = nullptr; tc.check(dfgpu_binary(tc.ctx, DFGPU_OP_AND, mask.a, 0, kf.a, 0, &o)); mask = ArrayRef::adopt(o); }
+    const int64_t before = dfgpu_groups_len(pairs.g);
+    const dfgpu_array* kp[2] = { g_in.a, v_in.a }; dfgpu_array* ids = nullptr; tc.check(dfgpu_groups_intern(tc.ctx, pairs.g, kp, 2, mask.a, &ids)); ArrayRef drop = ArrayRef::adopt(ids);
+    const int64_t fresh = dfgpu_groups_len(pairs.g) - before;
+    if (fresh > 0) {
+      dfgpu_array* keys[2] = { nullptr, nullptr }; tc.check(dfgpu_groups_emit(tc.ctx, pairs.g, keys)); ArrayRef k0 = ArrayRef::adopt(keys[0]), k1 = ArrayRef::adopt(keys[1]);
+      ArrayRef gk = StringMinMax::slice(tc, k0, before, fresh);
+      tc.check(dfgpu_acc_update_batch(tc.ctx, cnt.a, nullptr, gk.a, nullptr, total));
+    }
+  }
+  ArrayRef emit(const TaskContext& tc, int64_t total) {
+    dfgpu_array_desc ed{}; ed.type = DFGPU_UINT32; ed.values = &ed; dfgpu_array* e = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &ed, &e)); ArrayRef empty_ids = ArrayRef::adopt(e);
+    tc.check(dfgpu_acc_update_batch(tc.ctx, cnt.a, nullptr, empty_ids.a, nullptr, total));
+    dfgpu_array* v = nullptr; tc.check(dfgpu_acc_evaluate(tc.ctx, cnt.a, &v)); return ArrayRef::adopt(v);
+  }
+};
 
 struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggregateStream row_hash.rs:423-662
   int mode; std::vector<ExprPtr> gexprs; std::vector<std::string> gnames; std::vector<AggExpr> aggs; PlanPtr input; mutable SchemaPtr sch; mutable std::mutex mu;
@@ -985,6 +1047,9 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
   std::vector<std::shared_ptr<const Plan>> children() const override { return {input}; }
   const char* name() const override { return "AggregateExec"; }
   bool merging() const { return mode == 1 || mode == 2; }
+  bool is_string_minmax(size_t i) const { return (aggs[i].kind == DFGPU_AGG_MIN || aggs[i].kind == DFGPU_AGG_MAX) && aggs[i].type == DFGPU_UTF8; }
+  bool special(size_t i) const { return aggs[i].kind == DFGPU_AGG_COUNT_DISTINCT || is_string_minmax(i); }
+  bool any_special() const { for (size_t i = 0; i < aggs.size(); i++) if (special(i)) return true; return false; }
   // The accumulator arguments as ONE expression DAG over plain columns (common subexpressions shared; references to deferred projection
   // columns expand into the projection's expression over ITS input) handed to dfgpu_acc_update_batch_fused.  false = shape not taken,
   // nothing was accumulated: the caller evaluates the arguments node by node.
@@ -1123,8 +1188,11 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
     if (mode == 1 || mode == 3) { for (int p = 0; p < src->partitions(); p++) drain(src, p, tc, in); } else drain(src, partition, tc, in);
     const bool grouped = !gexprs.empty();      // false: AggregateStream (aggregates/no_grouping.rs): one implicit group
     GroupsRef groups; if (grouped) tc.check(dfgpu_groups_new(tc.ctx, (int32_t)gexprs.size(), &groups.g));
-    std::vector<AccRef> accs(aggs.size());
+    std::vector<AccRef> accs(aggs.size()); std::vector<StringMinMax> smm(aggs.size()); std::vector<CountDistinct> cds(aggs.size());
+    const bool specials = any_special();
     for (size_t i = 0; i < aggs.size(); i++) {
+      if (is_string_minmax(i)) { smm[i].is_max = aggs[i].kind == DFGPU_AGG_MAX; continue; }
+      if (aggs[i].kind == DFGPU_AGG_COUNT_DISTINCT) { cds[i].init(tc); continue; }
       int32_t t = aggs[i].kind == DFGPU_AGG_COUNT ? DFGPU_INT64 : aggs[i].type;
       tc.check(dfgpu_acc_new(tc.ctx, aggs[i].kind, t, aggs[i].precision, aggs[i].scale, &accs[i].a));
     }
@@ -1149,7 +1217,7 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
       }
       if (b.base_rows == 0) continue;
       ArrayRef mask = b.selection; b.selection = ArrayRef();
-      if (!sets.empty()) { for (size_t ci = 0; ci < deferred.size(); ci++) ensure((int)ci); group_aggregate_sets(tc, b, mask, groups, accs); continue; }
+      if (!sets.empty()) { if (specials) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: COUNT(DISTINCT) / string MIN-MAX under grouping sets on the device"); for (size_t ci = 0; ci < deferred.size(); ci++) ensure((int)ci); group_aggregate_sets(tc, b, mask, groups, accs); continue; }
       ArrayRef gids; int64_t total = 1;
       if (grouped) {
         std::vector<ArrayRef> gc; std::vector<const dfgpu_array*> gp;
@@ -1168,16 +1236,19 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
         }
         // A large batch of high-cardinality keys is first reduced to one row per group partition by partition out of LDS (the Partial stage
         // of a two-phase plan, applied inside the operator): its partial rows are then interned and MERGED like the Final stage does.
-        if (!merging() && gp.size() == 1 && b.base_rows >= preagg_min_rows && preaggregate(tc, b, deferred, ensure, gp[0], mask, groups, accs, &pending)) continue;
-        dfgpu_array* ids = nullptr; tc.check(dfgpu_groups_intern_deferred(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids)); gids = ArrayRef::adopt(ids);      // only the accumulators read them
+        if (!specials && !merging() && gp.size() == 1 && b.base_rows >= preagg_min_rows && preaggregate(tc, b, deferred, ensure, gp[0], mask, groups, accs, &pending)) continue;
+        dfgpu_array* ids = nullptr; tc.check(specials ? dfgpu_groups_intern(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids) : dfgpu_groups_intern_deferred(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids)); gids = ArrayRef::adopt(ids);      // deferred ids: only the accumulators read them
         total = dfgpu_groups_len(groups.g);
       } else { dfgpu_array* z = nullptr; tc.check(dfgpu_array_new_zeros(tc.ctx, DFGPU_UINT32, 0, 0, b.base_rows, &z)); gids = ArrayRef::adopt(z); }
-      if (!merging() && total <= 8 && fuse_min_rows >= 0 && b.base_rows >= fuse_min_rows && try_fused(tc, pj, raw, b, deferred, accs, gids, grouped ? ArrayRef() : mask, total)) continue;
+      if (!specials && !merging() && total <= 8 && fuse_min_rows >= 0 && b.base_rows >= fuse_min_rows && try_fused(tc, pj, raw, b, deferred, accs, gids, grouped ? ArrayRef() : mask, total)) continue;
       for (size_t ci = 0; ci < deferred.size(); ci++) ensure((int)ci);
       size_t col = gexprs.size();
       std::vector<ArrayRef> uvals(aggs.size()), ufilt(aggs.size());       // update mode: all accumulators of the batch go down together
       for (size_t i = 0; i < aggs.size(); i++) {
-        if (merging()) {
+        if (merging() && is_string_minmax(i)) {           // the state column is the value (min_max.rs state())
+          ArrayRef stv = b.column(tc, (int)col); col += 1;
+          smm[i].update(tc, gids, stv, mask);              // rows a fused selection dropped carry no state
+        } else if (merging()) {
           int nst = aggs[i].kind == DFGPU_AGG_AVG ? 2 : 1; const dfgpu_array* st[2];
           for (int k = 0; k < nst; k++) st[k] = b.column(tc, (int)(col + (size_t)k)).a;
           col += (size_t)nst;
@@ -1194,8 +1265,15 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
       }
       if (!merging() && !aggs.empty()) {
         std::vector<dfgpu_acc*> ap; std::vector<const dfgpu_array*> vp, fp;
-        for (size_t i = 0; i < aggs.size(); i++) { ap.push_back(accs[i].a); vp.push_back(uvals[i].a); fp.push_back(ufilt[i].a); }
-        tc.check(dfgpu_acc_update_batch_multi(tc.ctx, ap.data(), vp.data(), fp.data(), (int32_t)ap.size(), gids.a, total));
+        for (size_t i = 0; i < aggs.size(); i++) {
+          if (special(i)) {
+            ArrayRef f = ufilt[i]; if (grouped && mask) { if (f) { ArrayRef kf = known_mask(tc, f); dfgpu_array* o = nullptr; tc.check(dfgpu_binary(tc.ctx, DFGPU_OP_AND, kf.a, 0, mask.a, 0, &o)); f = ArrayRef::adopt(o); } else f = mask; }
+            if (is_string_minmax(i)) smm[i].update(tc, gids, uvals[i], f); else cds[i].update(tc, gids, uvals[i], f, total);
+            continue;
+          }
+          ap.push_back(accs[i].a); vp.push_back(uvals[i].a); fp.push_back(ufilt[i].a);
+        }
+        if (!ap.empty()) tc.check(dfgpu_acc_update_batch_multi(tc.ctx, ap.data(), vp.data(), fp.data(), (int32_t)ap.size(), gids.a, total));
       }
     }
     std::vector<Batch> outv; int64_t total = grouped ? (pending ? pending.len() : dfgpu_groups_len(groups.g)) : 1;     // no GROUP BY: always one row, even on empty input
@@ -1205,6 +1283,8 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
       else { if (grouped) tc.check(dfgpu_groups_emit(tc.ctx, groups.g, keys.data())); for (auto k : keys) o.cols.push_back(col_of(ArrayRef::adopt(k))); }
       dfgpu_array_desc ed{}; ed.type = DFGPU_UINT32; ed.values = &ed; dfgpu_array* e = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &ed, &e)); ArrayRef empty_ids = ArrayRef::adopt(e);
       for (size_t i = 0; i < aggs.size(); i++) {
+        if (is_string_minmax(i)) { o.cols.push_back(col_of(smm[i].emit(tc, total))); continue; }          // state and final value are the same column
+        if (aggs[i].kind == DFGPU_AGG_COUNT_DISTINCT) { o.cols.push_back(col_of(cds[i].emit(tc, total))); continue; }
         tc.check(dfgpu_acc_update_batch(tc.ctx, accs[i].a, nullptr, empty_ids.a, nullptr, total));      // zero-row update: grow the state to `total` groups
         if (mode == 0) { dfgpu_array* st[2] = {nullptr, nullptr}; int32_t n = 0; tc.check(dfgpu_acc_state(tc.ctx, accs[i].a, st, &n)); for (int k = 0; k < n; k++) o.cols.push_back(col_of(ArrayRef::adopt(st[k]))); }
         else { dfgpu_array* v = nullptr; tc.check(dfgpu_acc_evaluate(tc.ctx, accs[i].a, &v)); o.cols.push_back(col_of(ArrayRef::adopt(v))); }
@@ -1443,7 +1523,8 @@ dfgpu_status dfgpu_plan_aggregate(int32_t mode, const dfgpu_expr* const* gexprs,
     for (int i = 0; i < na; i++) {
       AggExpr x; x.kind = kinds[i]; if (args && args[i]) x.arg = args[i]->e; if (filters && filters[i]) x.filter = filters[i]->e; x.name = names[i] ? names[i] : "";
       x.type = types[3 * i]; x.precision = types[3 * i + 1]; x.scale = types[3 * i + 2];
-      if (x.kind < DFGPU_AGG_SUM || x.kind > DFGPU_AGG_MAX) fail(DFGPU_NOT_IMPLEMENTED, "aggregate kind %d has no GroupsAccumulator on device", x.kind);
+      if (x.kind < DFGPU_AGG_SUM || x.kind > DFGPU_AGG_COUNT_DISTINCT) fail(DFGPU_NOT_IMPLEMENTED, "aggregate kind %d has no GroupsAccumulator on device", x.kind);
+      if (x.kind == DFGPU_AGG_COUNT_DISTINCT && mode != 3 && mode != 4) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: COUNT(DISTINCT) in AggregateMode %d on the device (its Partial state is a List per group); Single / SinglePartitioned are", mode);
       if (!x.arg && x.kind != DFGPU_AGG_COUNT && mode != 1 && mode != 2) fail(DFGPU_INVALID_ARGUMENT, "aggregate %s needs an argument", x.name.c_str());
       a->aggs.push_back(std::move(x));
     }

@@ -618,7 +618,7 @@ class AggregateFunctionExpr:
 
     @property
     def kind(self) -> int:
-        return {"SUM": capi.AGG_SUM, "AVG": capi.AGG_AVG, "COUNT": capi.AGG_COUNT, "MIN": capi.AGG_MIN, "MAX": capi.AGG_MAX}[self.fun.upper()]
+        return {"SUM": capi.AGG_SUM, "AVG": capi.AGG_AVG, "COUNT": capi.AGG_COUNT, "MIN": capi.AGG_MIN, "MAX": capi.AGG_MAX, "COUNT DISTINCT": 5}[self.fun.upper()]
 
 
 _AGG_MODES = {"Partial": 0, "Final": 1, "FinalPartitioned": 2, "Single": 3, "SinglePartitioned": 4}

@@ -87,6 +87,9 @@ DFGPU_API dfgpu_status dfgpu_plan_sort_merge_join(const dfgpu_plan *left, const 
  * (:373-378) is collected, the other side streams and decides the output partitioning.  JoinFilter as for dfgpu_plan_hash_join (NULL = cross join). */
 DFGPU_API dfgpu_status dfgpu_plan_nested_loop_join(const dfgpu_plan *left, const dfgpu_plan *right, const dfgpu_expr *filter, const int32_t *filter_sides, const int32_t *filter_indices,
                                                    int32_t nfilter_cols, int32_t join_type, dfgpu_plan **out);
+/* Aggregate kinds of the plan layer beyond DFGPU_AGG_* (include/dfgpu.h): COUNT(DISTINCT x) (aggregate/count_distinct/) -- Single / SinglePartitioned modes only.  MIN / MAX
+ * over Utf8 (input type DFGPU_UTF8) are also served by the plan layer, in every mode. */
+enum { DFGPU_AGG_COUNT_DISTINCT = 5 };
 /* AggregateExec::try_new(mode, group_by, aggr_expr, input): mode 0 Partial, 1 Final, 2 FinalPartitioned, 3 Single,
  * 4 SinglePartitioned.  Aggregate i: kind DFGPU_AGG_*, argument expr (NULL = COUNT(*)), optional FILTER expr, output name,
  * argument data type (type, precision, scale) as the AggregateExpr knows it in every mode. */

@@ -533,3 +533,27 @@ def sort_merge_join(left_cols, right_cols, on, join_type: str, descending: bool 
     if join_type not in ("LeftSemi", "LeftAnti"):
         out += [take(c, ridx) for c in right_cols]
     return out
+
+
+# ------------------------------------------------------------------ plan-level aggregates composed on the device from other kernels: plain Python models
+def count_distinct(values, gids, total: int, opt_filter=None):
+    """COUNT(DISTINCT x) per group (aggregate/count_distinct/: one set of values per group; NULLs do not count) -> Int64 array of `total` groups"""
+    sets = [set() for _ in range(total)]
+    flt = opt_filter.to_pylist() if opt_filter is not None else None
+    for i, (g, v) in enumerate(zip(np.asarray(gids).tolist(), values.to_pylist())):
+        if v is not None and (flt is None or flt[i]):
+            sets[g].add(v)
+    return pa.array([len(x) for x in sets], type=pa.int64())
+
+
+def string_min_max(values, gids, total: int, is_max: bool, opt_filter=None):
+    """MIN / MAX over Utf8 per group (aggregate/min_max.rs: byte-wise string order, NULLs skipped, NULL when a group saw no value)"""
+    best = [None] * total
+    flt = opt_filter.to_pylist() if opt_filter is not None else None
+    for i, (g, v) in enumerate(zip(np.asarray(gids).tolist(), values.to_pylist())):
+        if v is None or (flt is not None and not flt[i]):
+            continue
+        b = v.encode()
+        if best[g] is None or (b > best[g] if is_max else b < best[g]):
+            best[g] = b
+    return pa.array([None if b is None else b.decode() for b in best], type=pa.utf8())
