@@ -782,11 +782,27 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
     // unmatched / semi rows in ascending index of THAT batch (joins/utils.rs:1119-1141): last input batch first.
     ArrayRef reference_final_order(const ArrayRef& fidx) {
       if (bs->segments.size() <= 1 || fidx.len() == 0) return fidx;
-      int64_t n = fidx.len(); std::vector<uint64_t> h((size_t)n);
-      tc.check(dfgpu_array_export_host(tc.ctx, fidx.a, h.data(), nullptr, nullptr));
       std::vector<int64_t> bounds{0}; for (auto s : bs->segments) bounds.push_back(bounds.back() + s);
+      if (bs->segments.size() <= 64) {          // on the device: the ascending index list is cut at the batch boundaries and the pieces are put back last batch first
+        auto scalar = [&](uint64_t v) { dfgpu_array_desc d{}; d.type = DFGPU_UINT64; d.length = 1; d.values = &v; dfgpu_array* a = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &d, &a)); return ArrayRef::adopt(a); };
+        std::vector<ArrayRef> pieces;
+        for (size_t sg = bs->segments.size(); sg-- > 0;) {
+          ArrayRef lo = scalar((uint64_t)bounds[sg]), hi = scalar((uint64_t)bounds[sg + 1]); dfgpu_array *ge = nullptr, *lt = nullptr, *both = nullptr, *part = nullptr;
+          tc.check(dfgpu_binary(tc.ctx, DFGPU_OP_GTEQ, fidx.a, 0, lo.a, 1, &ge)); ArrayRef a = ArrayRef::adopt(ge);
+          tc.check(dfgpu_binary(tc.ctx, DFGPU_OP_LT, fidx.a, 0, hi.a, 1, &lt)); ArrayRef b = ArrayRef::adopt(lt);
+          tc.check(dfgpu_binary(tc.ctx, DFGPU_OP_AND, a.a, 0, b.a, 0, &both)); ArrayRef m = ArrayRef::adopt(both);
+          tc.check(dfgpu_filter(tc.ctx, fidx.a, m.a, &part)); ArrayRef pc = ArrayRef::adopt(part);
+          if (pc.len()) pieces.push_back(pc);
+        }
+        if (pieces.size() == 1) return pieces[0];
+        return concat_arrays(tc, pieces);
+      }
+      int64_t n = fidx.len(); std::vector<uint64_t> h((size_t)n);          // very many build batches: one pass on the host
+      tc.check(dfgpu_array_export_host(tc.ctx, fidx.a, h.data(), nullptr, nullptr));
+      std::vector<size_t> cut{0};                                           // fidx ascends: each batch's entries are one run
+      for (size_t sg = 1; sg < bounds.size(); sg++) cut.push_back((size_t)(std::lower_bound(h.begin(), h.end(), (uint64_t)bounds[sg]) - h.begin()));
       std::vector<uint64_t> o; o.reserve((size_t)n);
-      for (size_t s = bs->segments.size(); s-- > 0;) for (auto v : h) if ((int64_t)v >= bounds[s] && (int64_t)v < bounds[s + 1]) o.push_back(v);
+      for (size_t sg = bs->segments.size(); sg-- > 0;) o.insert(o.end(), h.begin() + (std::ptrdiff_t)cut[sg], h.begin() + (std::ptrdiff_t)cut[sg + 1]);
       dfgpu_array_desc d{}; d.type = DFGPU_UINT64; d.length = n; d.values = o.data();
       dfgpu_array* a = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &d, &a)); return ArrayRef::adopt(a);
     }
