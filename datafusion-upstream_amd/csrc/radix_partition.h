@@ -203,6 +203,67 @@ __global__ void __launch_bounds__(NT) k_rp_scatter(H hs, int64_t n, uint32_t P, 
   }
 }
 
+// Few partitions (P <= 16, the RepartitionExec / exchange fan-out of one node): no data goes through LDS at all.  Every row's slot follows from the tile's global
+// offset, the counts of its partition in the (slab, wave) pieces in front of it (a small LDS table) and its rank among the lanes of its wave (ballots); each lane
+// then copies its row's columns straight from source to slot.  A wave's 64 rows land in at most P runs of consecutive slots (~64 / P rows each), reads are fully
+// coalesced, 16-byte columns move in one piece.  Stable by construction.
+template <int NT, typename H>
+__global__ void __launch_bounds__(NT) k_rp_scatter_direct(H hs, int64_t n, uint32_t P, int64_t ntiles, const uint32_t* goff, RpCols cols) {
+  constexpr int TILE = NT * RP_R, NW = NT / WAVE;
+  __shared__ uint16_t wcnt[RP_R * NW * 16]; __shared__ uint32_t tbase[16]; __shared__ RpCol scol[RP_MAX_COLS];
+#pragma unroll
+  for (int c = 0; c < RP_MAX_COLS; c++) if ((int)threadIdx.x == c) scol[c] = cols.c[c];
+  const int64_t per = (ntiles + 7) / 8, t = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (t >= ntiles || (int64_t)(blockIdx.x >> 3) >= per) return;
+  const int64_t base = t * (int64_t)TILE; const int wave = threadIdx.x >> 6;
+  for (int x = threadIdx.x; x < RP_R * NW * 16; x += NT) wcnt[x] = 0;
+  if (threadIdx.x < P) tbase[threadIdx.x] = goff[(int64_t)threadIdx.x * ntiles + t];
+  __syncthreads();
+  uint32_t pid[RP_R], rk[RP_R]; bool on[RP_R]; uint64_t hk[RP_R];
+#pragma unroll
+  for (int q = 0; q < RP_R; q++) {
+    int64_t i = base + (int64_t)q * NT + threadIdx.x; pid[q] = 0; hk[q] = 0;
+    on[q] = i < n && hs(i, P, &pid[q], &hk[q]);
+    uint64_t peers = ballot64(on[q]);
+    for (uint32_t b = 1; b < P; b <<= 1) { uint64_t mb = ballot64((pid[q] & b) != 0); peers &= (pid[q] & b) ? mb : ~mb; }
+    rk[q] = (uint32_t)__popcll(peers & lanemask_lt());
+    if (on[q] && rk[q] == 0) wcnt[((size_t)q * NW + wave) * 16 + pid[q]] = (uint16_t)__popcll(peers);
+  }
+  __syncthreads();
+  if (threadIdx.x < P) { uint32_t run = 0; for (int x = 0; x < RP_R * NW; x++) { uint16_t c = wcnt[(size_t)x * 16 + threadIdx.x]; wcnt[(size_t)x * 16 + threadIdx.x] = (uint16_t)run; run += c; } }
+  __syncthreads();
+  int64_t pos[RP_R];
+#pragma unroll
+  for (int q = 0; q < RP_R; q++) pos[q] = on[q] ? (int64_t)(tbase[pid[q]] + (uint32_t)wcnt[((size_t)q * NW + wave) * 16 + pid[q]] + rk[q]) : 0;
+  if (cols.rowid_dst) {
+#pragma unroll
+    for (int q = 0; q < RP_R; q++) if (on[q]) cols.rowid_dst[pos[q]] = (uint32_t)(base + (int64_t)q * NT + threadIdx.x);
+  }
+  const int64_t i0 = base + threadIdx.x;
+  for (int c = 0; c < cols.n; c++) {
+    const RpCol col = scol[c];
+#define RP_MOVE(DT, EXPR) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) { const int64_t i = i0 + (int64_t)q * NT; ((DT*)col.dst)[pos[q]] = (DT)(EXPR); } }
+    if (col.kind == RP_HASHKEY) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) ((uint64_t*)col.dst)[pos[q]] = hk[q]; }
+    else if (col.kind == RP_KEY64) switch (col.type) {
+      case DFGPU_INT8: RP_MOVE(uint64_t, (int64_t)((const int8_t*)col.src)[i]) break;
+      case DFGPU_INT16: RP_MOVE(uint64_t, (int64_t)((const int16_t*)col.src)[i]) break;
+      case DFGPU_INT32: case DFGPU_DATE32: RP_MOVE(uint64_t, (int64_t)((const int32_t*)col.src)[i]) break;
+      case DFGPU_UINT8: RP_MOVE(uint64_t, ((const uint8_t*)col.src)[i]) break;
+      case DFGPU_UINT16: RP_MOVE(uint64_t, ((const uint16_t*)col.src)[i]) break;
+      case DFGPU_UINT32: RP_MOVE(uint64_t, ((const uint32_t*)col.src)[i]) break;
+      default: RP_MOVE(uint64_t, ((const uint64_t*)col.src)[i]) break;
+    }
+    else switch (col.width) {
+      case 1: RP_MOVE(uint8_t, ((const uint8_t*)col.src)[i]) break;
+      case 2: RP_MOVE(uint16_t, ((const uint16_t*)col.src)[i]) break;
+      case 4: RP_MOVE(uint32_t, ((const uint32_t*)col.src)[i]) break;
+      case 8: RP_MOVE(uint64_t, ((const uint64_t*)col.src)[i]) break;
+      default: { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) ((ulonglong2*)col.dst)[pos[q]] = ((const ulonglong2*)col.src)[i0 + (int64_t)q * NT]; } break;
+    }
+#undef RP_MOVE
+  }
+}
+
 // starts[p] = first slot of partition p, starts[P] = rows moved (the scan's total)
 static __global__ void k_rp_starts(const uint32_t* goff, int64_t ntiles, uint32_t P, const uint64_t* d_total, uint32_t* starts) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -244,7 +305,8 @@ static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const 
     const unsigned grid = (unsigned)(((ntiles + 7) / 8) * 8);
 #define RP_LAUNCH(NT_, ST_) { static bool once = false; if (!once) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_scatter<NT_, ST_, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); once = true; } \
       hipLaunchKernelGGL((k_rp_scatter<NT_, ST_, H>), dim3(grid), dim3(NT_), rp_scatter_lds<NT_>(P, ST_), ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols); }
-    if (small_wg) RP_LAUNCH(256, true) else if (stable) RP_LAUNCH(512, true) else if (big) RP_LAUNCH(1024, false) else RP_LAUNCH(512, false)
+    if (stable && P <= 16 && !cols.pack12_dst && !small_wg) hipLaunchKernelGGL((k_rp_scatter_direct<512, H>), dim3(grid), dim3(512), 0, ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols);
+    else if (small_wg) RP_LAUNCH(256, true) else if (stable) RP_LAUNCH(512, true) else if (big) RP_LAUNCH(1024, false) else RP_LAUNCH(512, false)
 #undef RP_LAUNCH
     KERNEL_CHECK(); }
   return r;
