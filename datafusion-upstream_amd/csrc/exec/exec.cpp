@@ -343,6 +343,42 @@ struct ParquetExec : Plan {
   }
 };
 
+// ≙ CsvExec (core/src/datasource/physical_plan/csv.rs:53-72, execute :222-260, CsvOpener::open :327-420): one file image under the table's schema.  The reference
+// deals byte ranges of the file to partitions and moves each range's ends to the next record boundary (find_first_newline, csv.rs:362-420); here the image is cut
+// once, at plan time, into pieces of about `batch_bytes` that end on a record boundary outside quotes, the pieces are dealt to the partitions in contiguous runs and
+// every piece is one batch parsed on the device (dfgpu_csv_read).  The caller keeps the image alive while the plan lives.
+struct CsvExec : Plan {
+  const uint8_t* bytes = nullptr; int64_t len = 0; int32_t delim = ',', quote = '"', ncols_file = 0; bool header = true;
+  std::vector<int32_t> proj, types; SchemaPtr sch; int nparts = 1; std::vector<int64_t> cuts;      // piece i = [cuts[i], cuts[i + 1])
+  const char* name() const override { return "CsvExec"; }
+  PlanPtr fresh() const override { return shared_from_this(); }
+  SchemaPtr schema() const override { return sch; }
+  int partitions() const override { return nparts; }
+  void cut(int64_t batch_bytes) {
+    cuts.assign(1, 0); bool inside = false; int64_t next = batch_bytes;
+    for (int64_t i = 0; i < len; i++) { const uint8_t c = bytes[i]; if (c == (uint8_t)quote) inside = !inside; else if (c == '\n' && !inside && i + 1 >= next && i + 1 < len) { cuts.push_back(i + 1); next = i + 1 + batch_bytes; } }
+    cuts.push_back(len);
+  }
+  struct S : Stream {
+    const CsvExec* op; TaskContext tc; int next_piece, end_piece;
+    S(const CsvExec* o, TaskContext t, int a, int b) : op(o), tc(t), next_piece(a), end_piece(b) {}
+    bool next(Batch& out) override {
+      if (next_piece >= end_piece) return false;
+      const int i = next_piece++; std::vector<dfgpu_array*> cols(op->proj.size(), nullptr); int64_t rows = 0;
+      tc.check(dfgpu_csv_read(tc.ctx, op->bytes + op->cuts[(size_t)i], op->cuts[(size_t)i + 1] - op->cuts[(size_t)i], 0, op->delim, op->quote, i == 0 && op->header ? 1 : 0, op->ncols_file,
+                              op->proj.data(), op->types.data(), (int32_t)op->proj.size(), cols.data(), &rows));
+      Batch b; b.schema = op->sch; b.base_rows = rows;
+      for (auto* a : cols) b.cols.push_back(col_of(ArrayRef::adopt(a)));
+      out = std::move(b); return true;
+    }
+  };
+  std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override {
+    if (p < 0 || p >= nparts) fail(DFGPU_INTERNAL, "CsvExec invalid partition %d (expected less than %d)", p, nparts);
+    const int64_t P = (int64_t)cuts.size() - 1;
+    return std::unique_ptr<Stream>(new S(this, tc, (int)(P * p / nparts), (int)(P * (p + 1) / nparts)));
+  }
+};
+
 static ArrayRef known_mask(const TaskContext& tc, const ArrayRef& m) {     // NULL -> false before AND-ing selections
   dfgpu_array_desc d; dfgpu_array_describe(m.a, &d);
   if (!d.validity) return m;
@@ -1468,6 +1504,22 @@ dfgpu_status dfgpu_plan_parquet(dfgpu_parquet* file, const int32_t* columns, int
       if (!t) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: Parquet column '%s' has a type outside the device scan", dfgpu_parquet_column_name(file, columns[i]));
       n->proj.push_back(columns[i]); n->sch->f.push_back(Field{dfgpu_parquet_column_name(file, columns[i]), vt, pr, sc});
     }
+    *out = new dfgpu_plan{n};
+  });
+}
+dfgpu_status dfgpu_plan_csv(const uint8_t* bytes, int64_t len, int32_t delimiter, int32_t quote, int32_t has_header, const char* const* names, const int32_t* types, int32_t ncols_file,
+                            const int32_t* columns, int32_t ncols, int32_t npartitions, int64_t batch_bytes, dfgpu_plan** out) {
+  return guard([&] {
+    if ((!bytes && len) || len < 0 || !out || !names || !types || ncols_file < 1 || ncols < 1 || !columns || npartitions < 1) fail(DFGPU_INVALID_ARGUMENT, "plan_csv: bad argument");
+    auto n = std::make_shared<CsvExec>(); n->bytes = bytes; n->len = len; n->delim = delimiter; n->quote = quote; n->header = has_header != 0; n->ncols_file = ncols_file; n->nparts = npartitions;
+    n->sch = std::make_shared<Schema>();
+    for (int32_t i = 0; i < ncols; i++) {
+      const int32_t c = columns[i];
+      if (c < 0 || c >= ncols_file || (i && c <= columns[i - 1])) fail(DFGPU_INVALID_ARGUMENT, "plan_csv: projected columns must be ascending file column indices");
+      n->proj.push_back(c); n->types.insert(n->types.end(), {types[3 * c], types[3 * c + 1], types[3 * c + 2]});
+      n->sch->f.push_back(Field{names[c] ? names[c] : "", types[3 * c], types[3 * c + 1], types[3 * c + 2]});
+    }
+    n->cut(batch_bytes > 0 ? batch_bytes : (int64_t)256 << 20);
     *out = new dfgpu_plan{n};
   });
 }

@@ -428,6 +428,33 @@ class ParquetExec(ExecutionPlan):
         return _lib().dfgpu_plan_parquet_pruned(self.handle(context).h)
 
 
+class CsvExec(ExecutionPlan):
+    """≙ CsvExec (core/src/datasource/physical_plan/csv.rs:53): scan of one CSV file image (bytes, kept alive by this node) under the table's schema
+    [(name, DFGPU type, precision, scale)] of every file column.  The image is cut at record boundaries into pieces of ~batch_bytes, one batch each, dealt to
+    `partitions` in contiguous runs (the reference's byte-range file groups, csv.rs:362-420)."""
+
+    def __init__(self, data: bytes, file_schema, projection=None, partitions: int = 1, has_header: bool = True, delimiter: str = ",", quote: str = '"', batch_bytes: int = 0):
+        names = [f[0] for f in file_schema]
+        self.data, self.file_schema = bytes(data) if not isinstance(data, bytes) else data, [tuple(f) for f in file_schema]
+        self.projection = sorted(range(len(names)) if projection is None else [names.index(c) if isinstance(c, str) else int(c) for c in projection])
+        self.partitions, self.has_header, self.delimiter, self.quote, self.batch_bytes = partitions, has_header, delimiter, quote, batch_bytes
+
+    def output_partitioning(self):
+        return Partitioning.UnknownPartitioning(self.partitions)
+
+    def schema(self):
+        return Schema([Field(*self.file_schema[c][:4]) for c in self.projection])
+
+    def _build(self, context):
+        out = C.c_void_p(); n = len(self.file_schema)
+        names = (C.c_char_p * n)(*[f[0].encode() for f in self.file_schema])
+        types = (C.c_int32 * (3 * n))(*[v for f in self.file_schema for v in f[1:4]])
+        idx = (C.c_int32 * len(self.projection))(*self.projection)
+        _check(_lib().dfgpu_plan_csv(C.cast(C.c_char_p(self.data), C.c_void_p), len(self.data), ord(self.delimiter), ord(self.quote), 1 if self.has_header else 0, names, types, n,
+                                     idx, len(self.projection), self.partitions, self.batch_bytes, C.byref(out)))
+        return self._new(out)
+
+
 class FilterExec(ExecutionPlan):
     def __init__(self, predicate: PhysicalExpr, input):
         self.predicate, self.input = predicate, input

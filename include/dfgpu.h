@@ -437,6 +437,16 @@ DFGPU_API int64_t dfgpu_parquet_column_chunk_bytes(const dfgpu_parquet *file, in
  * consecutive row groups back to back.  A column without NULLs in these row groups comes without a validity bitmap. */
 DFGPU_API dfgpu_status dfgpu_parquet_read(dfgpu_ctx *ctx, dfgpu_parquet *file, int32_t first_row_group, int32_t num_row_groups, const int32_t *columns, int32_t ncols, dfgpu_array **out);
 
+/* ≙ what CsvExec's stream does per file (core/src/datasource/physical_plan/csv.rs: CsvOpener -> the `arrow-csv` reader of arrow-rs 50, not part of the reference tree): records
+ * are lines (LF or CRLF; a line feed inside a quoted field does not end a record; blank lines are skipped), fields are separated by `delimiter`, a field may be wrapped in `quote` characters with a
+ * doubled quote standing for one; an empty field of a non-string column is NULL, of a Utf8 column the empty string.  The schema is the caller's: `columns` = ascending indices
+ * of the wanted file columns, `types` = (DFGPU_* type, precision, scale) per wanted column -- Int8 .. UInt64, Float64 (inputs of up to 15 significant digits and exponents of
+ * at most 22: the exactly rounded path; longer ones raise an error instead of a guess), Boolean, Date32 (YYYY-MM-DD), Decimal128, Utf8.  A field that does not parse as its
+ * column's type, a record with too few fields or broken quoting fail the call with DFGPU_EXECUTION.  `bytes` is the file image in host memory, or already in HBM
+ * (bytes_on_device = 1); at most 4 GB per call.  has_header = 1 skips the first record.  out_rows (optional) = records read. */
+DFGPU_API dfgpu_status dfgpu_csv_read(dfgpu_ctx *ctx, const uint8_t *bytes, int64_t len, int32_t bytes_on_device, int32_t delimiter, int32_t quote, int32_t has_header, int32_t ncols_file,
+                                      const int32_t *columns, const int32_t *types, int32_t ncols, dfgpu_array **out, int64_t *out_rows);
+
 #ifdef __cplusplus
 }
 #endif
