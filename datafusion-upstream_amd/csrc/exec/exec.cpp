@@ -1351,6 +1351,21 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
 };
 
 // ------------------------------------------------------------------ SortExec
+// sort_batch (sorts/sort.rs:584-609): lexsort_to_indices over the evaluated keys, then take() of every column.  A sort column that is a plain input column may
+// come back from the sort already in order (dfgpu_sort_to_indices_keys rebuilds it from the sorted packed keys): that column skips the gather.
+static Batch sorted_batch(const TaskContext& tc, Batch& b, const std::vector<ExprPtr>& exprs, const std::vector<const dfgpu_array*>& kp, const std::vector<uint8_t>& desc, const std::vector<uint8_t>& nulls_first, int64_t fetch) {
+  dfgpu_array* idx = nullptr; std::vector<dfgpu_array*> sk(kp.size(), nullptr);
+  tc.check(dfgpu_sort_to_indices_keys(tc.ctx, kp.data(), desc.data(), nulls_first.data(), (int32_t)kp.size(), fetch, &idx, sk.data()));
+  ArrayRef ix = ArrayRef::adopt(idx); std::vector<ArrayRef> sorted; for (auto* a : sk) sorted.push_back(a ? ArrayRef::adopt(a) : ArrayRef());
+  Batch o; o.schema = b.schema; o.base_rows = ix.len();
+  MemoPtr memo = std::make_shared<TakeMemo>();
+  for (size_t ci = 0; ci < b.cols.size(); ci++) {
+    ArrayRef ready; for (size_t e = 0; e < exprs.size() && !ready; e++) if (sorted[e] && exprs[e]->column_index() == (int)ci) ready = sorted[e];
+    o.cols.push_back(ready ? col_of(ready) : col_take(b.cols[ci], ix, memo));
+  }
+  return o;
+}
+
 struct SortExec : Plan {          // sorts/sort.rs:719-733; sort_batch :584-609
   std::vector<ExprPtr> exprs; std::vector<uint8_t> desc, nulls_first; int64_t fetch; bool preserve; PlanPtr input;
   PlanPtr fresh() const override { auto s = std::make_shared<SortExec>(); s->exprs = exprs; s->desc = desc; s->nulls_first = nulls_first; s->fetch = fetch; s->preserve = preserve; s->input = input->fresh(); return s; }
@@ -1365,10 +1380,7 @@ struct SortExec : Plan {          // sorts/sort.rs:719-733; sort_batch :584-609
     if (!in.empty() && concat_batches(tc, in, &b) && b.base_rows > 0) {
       std::vector<ArrayRef> keys; std::vector<const dfgpu_array*> kp;
       for (auto& e : exprs) { keys.push_back(into_array(tc, e->eval(tc, b), b.base_rows)); kp.push_back(keys.back().a); }
-      dfgpu_array* idx = nullptr; tc.check(dfgpu_sort_to_indices(tc.ctx, kp.data(), desc.data(), nulls_first.data(), (int32_t)kp.size(), fetch, &idx)); ArrayRef ix = ArrayRef::adopt(idx);
-      Batch o; o.schema = b.schema; o.base_rows = ix.len();
-      MemoPtr memo = std::make_shared<TakeMemo>(); for (auto& c : b.cols) o.cols.push_back(col_take(c, ix, memo));
-      outv.push_back(std::move(o));
+      outv.push_back(sorted_batch(tc, b, exprs, kp, desc, nulls_first, fetch));
     }
     return std::unique_ptr<Stream>(new VecStream(std::move(outv)));
   }
@@ -1397,10 +1409,7 @@ struct SortPreservingMergeExec : Plan {
     if (!in.empty() && concat_batches(tc, in, &b) && b.base_rows > 0) {
       std::vector<ArrayRef> keys; std::vector<const dfgpu_array*> kp;
       for (auto& e : exprs) { keys.push_back(into_array(tc, e->eval(tc, b), b.base_rows)); kp.push_back(keys.back().a); }
-      dfgpu_array* idx = nullptr; tc.check(dfgpu_sort_to_indices(tc.ctx, kp.data(), desc.data(), nulls_first.data(), (int32_t)kp.size(), fetch, &idx)); ArrayRef ix = ArrayRef::adopt(idx);
-      Batch o; o.schema = b.schema; o.base_rows = ix.len();
-      MemoPtr memo = std::make_shared<TakeMemo>(); for (auto& c : b.cols) o.cols.push_back(col_take(c, ix, memo));
-      outv.push_back(std::move(o));
+      outv.push_back(sorted_batch(tc, b, exprs, kp, desc, nulls_first, fetch));
     }
     return std::unique_ptr<Stream>(new VecStream(std::move(outv)));
   }

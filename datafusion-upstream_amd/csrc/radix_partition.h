@@ -7,8 +7,9 @@
 //                 rows in partition p (partition-major output: partition p is the contiguous range [goff[p][0], goff[p + 1][0]))
 //   k_rp_scatter  per tile: counting sort of the tile inside LDS, then every column is staged through LDS in sorted order and written
 //                 out linearly, so consecutive lanes write consecutive slots of a run
-// Ranking inside a tile: STABLE (P <= 256) ranks with 64-wide match-any ballots per (slab, wave) and a small LDS count table, so rows
-// of a partition keep input order (what BatchPartitioner promises, repartition/mod.rs:196-214); otherwise ranks come from LDS atomics
+// Ranking inside a tile: STABLE (P <= 256): a wave owns 512 consecutive rows of the tile; 64-wide match-any ballots rank a row among the lanes of its slab, a running
+// count per (wave, partition) -- a row of a small LDS table only that wave touches -- ranks it across the wave's slabs, a prefix over the waves finishes the rank, so
+// rows of a partition keep input order (what BatchPartitioner promises, repartition/mod.rs:196-214); otherwise ranks come from LDS atomics
 // (rows of one (tile, partition) run land in arbitrary order inside the run -- consumers that only need the partition's row SET, the
 // join and the aggregation, take that).  Tiles are always laid out in input order inside a partition.
 // Write combining happens at two levels: a tile's run for one partition is contiguous (LDS-staged), and the runs of NEIGHBOURING tiles
@@ -80,9 +81,9 @@ __global__ void __launch_bounds__(NT) k_rp_hist(H hs, int64_t n, uint32_t P, int
   for (int x = threadIdx.x; x < (int)P * G; x += NT) { int p = x / G, g = x % G; if (t0 + g < ntiles) counts[(int64_t)p * ntiles + t0 + g] = rp_lds[x]; }
 }
 
-// LDS of the scatter: cnt[P] u32 | delta[P] u32 | spid[TILE] u16 | slidx[TILE] u16 | stage[TILE] u64 | (STABLE) wcnt[RP_R][NT / 64][P] u16
+// LDS of the scatter: cnt[P] u32 | delta[P] u32 | spid[TILE] u16 | slidx[TILE] u16 | stage[TILE] u64 | (STABLE) wcnt[NT / 64][P] u16
 template <int NT> static inline size_t rp_scatter_lds(uint32_t P, bool stable) {
-  return (size_t)P * 8 + (size_t)NT * RP_R * 4 + 8 + (size_t)NT * RP_R * 8 + (stable ? (size_t)RP_R * (NT / WAVE) * P * 2 : 0);
+  return (size_t)P * 8 + (size_t)NT * RP_R * 4 + 8 + (size_t)NT * RP_R * 8 + (stable ? (size_t)(NT / WAVE) * P * 2 : 0);
 }
 
 template <int NT, bool STABLE, typename H>
@@ -92,7 +93,7 @@ __global__ void __launch_bounds__(NT) k_rp_scatter(H hs, int64_t n, uint32_t P, 
   uint32_t* cnt = rp_lds; uint32_t* delta = rp_lds + P; uint16_t* spid = (uint16_t*)(rp_lds + 2 * P);
   uint16_t* slidx = spid + TILE;                                    // tile-local index of the row staged at each position
   uint64_t* stage = (uint64_t*)(((uintptr_t)(slidx + TILE) + 7) & ~(uintptr_t)7);
-  uint16_t* wcnt = (uint16_t*)(stage + TILE);                       // STABLE only: rows of partition p in (slab q, wave w)
+  uint16_t* wcnt = (uint16_t*)(stage + TILE);                       // STABLE only: rows of partition p in wave w (running over the wave's slabs while ranking, then exclusive over the waves)
   __shared__ uint32_t wsum[NW]; __shared__ uint32_t moved_sh; __shared__ RpCol scol[RP_MAX_COLS];
 #pragma unroll
   for (int c = 0; c < RP_MAX_COLS; c++) if ((int)threadIdx.x == c) scol[c] = cols.c[c];       // static indexing of the by-value argument; the column loop reads LDS
@@ -101,33 +102,36 @@ __global__ void __launch_bounds__(NT) k_rp_scatter(H hs, int64_t n, uint32_t P, 
   const int64_t base = t * (int64_t)TILE;
   const int wave = threadIdx.x >> 6;
   for (int p = threadIdx.x; p < (int)P; p += NT) cnt[p] = 0;
-  if (STABLE) for (int x = threadIdx.x; x < RP_R * NW * (int)P; x += NT) wcnt[x] = 0;
+  if (STABLE) for (int x = threadIdx.x; x < NW * (int)P; x += NT) wcnt[x] = 0;
   __syncthreads();
   uint32_t pid[RP_R], rk[RP_R]; bool on[RP_R]; uint64_t hk[RP_R];          // hk: the key the hasher read (column kind RP_HASHKEY moves it without a second load)
+  // STABLE: a wave owns RP_R * 64 CONSECUTIVE rows (slab q = 64 of them), so tile order is (wave, slab, lane) and a wave's running count per partition -- its own
+  // row of wcnt, touched by no other wave, LDS operations of one wave execute in order -- ranks its rows across its slabs; otherwise slab q = rows q * NT ..
+  const int64_t i0 = STABLE ? base + (int64_t)wave * (RP_R * WAVE) + lane_id() : base + threadIdx.x;
+  constexpr int QS = STABLE ? WAVE : NT;
 #pragma unroll
   for (int q = 0; q < RP_R; q++) {
-    int64_t i = base + (int64_t)q * NT + threadIdx.x; pid[q] = 0; hk[q] = 0;
+    int64_t i = i0 + (int64_t)q * QS; pid[q] = 0; hk[q] = 0;
     on[q] = i < n && hs(i, P, &pid[q], &hk[q]);
     if (STABLE) {
       uint64_t peers = ballot64(on[q]);
       for (uint32_t b = 1; b < P; b <<= 1) { uint64_t mb = ballot64((pid[q] & b) != 0); peers &= (pid[q] & b) ? mb : ~mb; }
-      rk[q] = (uint32_t)__popcll(peers & lanemask_lt());
-      if (on[q] && rk[q] == 0) { wcnt[((size_t)q * NW + wave) * P + pid[q]] = (uint16_t)__popcll(peers); atomicAdd(&cnt[pid[q]], (uint32_t)__popcll(peers)); }
+      const uint32_t below = (uint32_t)__popcll(peers & lanemask_lt());
+      uint32_t seen = 0;
+      if (on[q] && below == 0) { uint16_t* wc = wcnt + (size_t)wave * P + pid[q]; seen = *wc; *wc = (uint16_t)(seen + (uint32_t)__popcll(peers)); }
+      seen = __shfl(seen, peers ? __ffsll((unsigned long long)peers) - 1 : 0, 64);       // the first lane of every peer group read the count before adding
+      rk[q] = seen + below;
     } else rk[q] = on[q] ? atomicAdd(&cnt[pid[q]], 1u) : 0;
   }
   __syncthreads();
-  if (STABLE) {       // thread p: counts of partition p per (slab, wave) -> exclusive prefix in (slab, wave) order
+  if (STABLE) {       // thread p: counts of partition p per wave -> exclusive prefix over the waves, tile total into cnt
     for (int p = threadIdx.x; p < (int)P; p += NT) {
-      uint32_t run = 0;                                // 16 loads in flight, then their running sums: RP_R * NW / 16 LDS round trips
-#pragma unroll 1
-      for (int x0 = 0; x0 < RP_R * NW; x0 += 16) {
-        uint16_t c[16];
+      uint32_t run = 0;
 #pragma unroll
-        for (int x = 0; x < 16; x++) c[x] = wcnt[(size_t)(x0 + x) * P + p];
-#pragma unroll
-        for (int x = 0; x < 16; x++) { wcnt[(size_t)(x0 + x) * P + p] = (uint16_t)run; run += c[x]; }
-      }
+      for (int w = 0; w < NW; w++) { const uint32_t c = wcnt[(size_t)w * P + p]; wcnt[(size_t)w * P + p] = (uint16_t)run; run += c; }
+      cnt[p] = run;
     }
+    __syncthreads();
   }
   {   // exclusive scan of cnt[P]: thread t owns the PER consecutive bins from t * PER
     constexpr int PER = ((int)(STABLE ? RP_MAX_STABLE_P : RP_MAX_P) + NT - 1) / NT; uint32_t loc[PER]; uint32_t s = 0;
@@ -147,8 +151,8 @@ __global__ void __launch_bounds__(NT) k_rp_scatter(H hs, int64_t n, uint32_t P, 
   uint32_t spos[RP_R];
 #pragma unroll
   for (int q = 0; q < RP_R; q++) {
-    spos[q] = on[q] ? cnt[pid[q]] + rk[q] + (STABLE ? (uint32_t)wcnt[((size_t)q * NW + wave) * P + pid[q]] : 0u) : 0u;
-    if (on[q]) { spid[spos[q]] = (uint16_t)pid[q]; slidx[spos[q]] = (uint16_t)(q * NT + threadIdx.x); }
+    spos[q] = on[q] ? cnt[pid[q]] + rk[q] + (STABLE ? (uint32_t)wcnt[(size_t)wave * P + pid[q]] : 0u) : 0u;
+    if (on[q]) { spid[spos[q]] = (uint16_t)pid[q]; slidx[spos[q]] = (uint16_t)(i0 - base + q * QS); }
   }
   uint32_t* const rowid_dst = cols.rowid_dst;
   if (rowid_dst && cols.n == 0) {
@@ -160,9 +164,8 @@ __global__ void __launch_bounds__(NT) k_rp_scatter(H hs, int64_t n, uint32_t P, 
     const int halves = col.width == 16 ? 2 : 1;
     for (int hf = 0; hf < halves; hf++) {
       if (c || hf) __syncthreads();                    // the previous column's write-out has read the staging buffer
-      const int64_t i0 = base + threadIdx.x;
       // the width switch sits outside the unrolled row loop: one load shape per column, RP_R loads in flight
-#define RP_GATHER(EXPR) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) { const int64_t i = i0 + (int64_t)q * NT; stage[spos[q]] = (uint64_t)(EXPR); } }
+#define RP_GATHER(EXPR) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) { const int64_t i = i0 + (int64_t)q * QS; stage[spos[q]] = (uint64_t)(EXPR); } }
       if (col.kind == RP_HASHKEY) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) stage[spos[q]] = hk[q]; }
       else if (col.kind == RP_KEY64) switch (col.type) {            // widened exactly as key_at() does
         case DFGPU_INT8: RP_GATHER((int64_t)((const int8_t*)col.src)[i]) break;

@@ -261,7 +261,7 @@ __global__ void k_or_words(const uint64_t* a, const uint64_t* b, uint64_t* out, 
 // slot below / above the range as nulls_first says), the offsets are concatenated into ONE u64 (first column in the top bits): comparing
 // the packed keys == comparing the rows lexicographically.  Only the bits that vary are sorted: LSD passes over the packed key
 // through the stable one-pass partition of radix_partition.h (digits of up to 8 bits), the (key, row id) pair moving with every pass.
-struct PkCol { const void* v; const uint64_t* valid; int32_t type; int32_t desc; int32_t nulls_first; int32_t shift; uint64_t lo_bits, hi_bits; uint64_t span; };   // lo/hi: order-preserving 128-bit minimum as two words (hi only for Decimal128)
+struct PkCol { const void* v; const uint64_t* valid; int32_t type; int32_t desc; int32_t nulls_first; int32_t shift; uint64_t lo_bits, hi_bits; uint64_t span; int32_t bits; void* sorted_dst; };   // lo/hi: order-preserving 128-bit minimum as two words (hi only for Decimal128)
 struct PkCols { int32_t n; PkCol c[MAX_KEYS]; };
 __device__ inline void pk_order_bits(const void* v, int32_t type, int64_t i, uint64_t* hi, uint64_t* lo) {      // value -> unsigned 128-bit pattern whose order is the value order
   *hi = 0;
@@ -305,7 +305,8 @@ __global__ void __launch_bounds__(BLOCK) k_pk_minmax(PkCols pc, int64_t n, unsig
     __syncthreads();
   }
 }
-__global__ void __launch_bounds__(BLOCK) k_pk_encode(PkCols pc, int64_t n, uint64_t* keys, uint32_t* idx) {
+// ib = 0: keys[i] = packed key, idx[i] = i.  ib > 0 ("word mode": key bits + row-number bits fit 64): keys[i] = packed key << ib | i, one 8-byte record moves through the passes
+__global__ void __launch_bounds__(BLOCK) k_pk_encode(PkCols pc, int64_t n, uint64_t* keys, uint32_t* idx, int ib) {
   int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   uint64_t key = 0;
@@ -316,18 +317,41 @@ __global__ void __launch_bounds__(BLOCK) k_pk_encode(PkCols pc, int64_t n, uint6
     else { uint64_t h, l; pk_order_bits(k.v, k.type, i, &h, &l); uint64_t d = l - k.lo_bits; off = 1 + (k.desc ? k.span - 1 - d : d); }     // the range fits 63 bits: the high words cancel
     key |= off << k.shift;
   }
-  keys[i] = key; idx[i] = (uint32_t)i;
+  if (ib) keys[i] = (key << ib) | (uint64_t)i; else { keys[i] = key; idx[i] = (uint32_t)i; }
 }
 struct RpHashDigit {      // partition = one 8-bit digit of the packed key
   const uint64_t* keys; int shift; uint32_t mask;
   __device__ inline bool operator()(int64_t i, uint32_t, uint32_t* pid, uint64_t* key) const { *key = keys[i]; *pid = (uint32_t)(*key >> shift) & mask; return true; }
 };
+// word mode, after the last pass: row numbers out of the low bits; every key column that asked for it (sorted_dst) is rebuilt from its bits of the sorted word --
+// offset -> order pattern (minimum + distance, 128-bit) -> value -- with sequential reads and writes instead of a gather through the permutation
+__global__ void __launch_bounds__(BLOCK) k_pk_finish(PkCols pc, const uint64_t* __restrict__ words, int64_t m, int ib, uint32_t* __restrict__ idx) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i >= m) return;
+  const uint64_t w = words[i]; idx[i] = (uint32_t)(w & ((1ull << ib) - 1ull)); const uint64_t key = w >> ib;
+  for (int c = 0; c < MAX_KEYS; c++) {
+    if (c >= pc.n) break;
+    const PkCol& k = pc.c[c]; if (!k.sorted_dst) continue;
+    const uint64_t off = (key >> k.shift) & (k.bits >= 64 ? ~0ull : (1ull << k.bits) - 1ull);
+    uint64_t d = off - 1; if (k.desc) d = k.span - 1 - d;
+    const uint64_t lo = k.lo_bits + d, hi = k.hi_bits + (lo < k.lo_bits ? 1ull : 0ull);
+    switch (k.type) {
+      case DFGPU_INT8: ((int8_t*)k.sorted_dst)[i] = (int8_t)(int64_t)(lo ^ 0x8000000000000000ull); break;
+      case DFGPU_INT16: ((int16_t*)k.sorted_dst)[i] = (int16_t)(int64_t)(lo ^ 0x8000000000000000ull); break;
+      case DFGPU_INT32: case DFGPU_DATE32: ((int32_t*)k.sorted_dst)[i] = (int32_t)(int64_t)(lo ^ 0x8000000000000000ull); break;
+      case DFGPU_INT64: ((uint64_t*)k.sorted_dst)[i] = lo ^ 0x8000000000000000ull; break;
+      case DFGPU_UINT8: ((uint8_t*)k.sorted_dst)[i] = (uint8_t)lo; break; case DFGPU_UINT16: ((uint16_t*)k.sorted_dst)[i] = (uint16_t)lo; break;
+      case DFGPU_UINT32: ((uint32_t*)k.sorted_dst)[i] = (uint32_t)lo; break; case DFGPU_UINT64: ((uint64_t*)k.sorted_dst)[i] = lo; break;
+      case DFGPU_FLOAT32: { uint32_t b = (uint32_t)lo; b ^= (b >> 31) ? 0x80000000u : 0xFFFFFFFFu; ((uint32_t*)k.sorted_dst)[i] = b; break; }
+      case DFGPU_FLOAT64: { uint64_t b = lo; b ^= (b >> 63) ? 0x8000000000000000ull : ~0ull; ((uint64_t*)k.sorted_dst)[i] = b; break; }
+      default: { uint64_t* o = (uint64_t*)k.sorted_dst + 2 * i; o[0] = lo; o[1] = hi ^ 0x8000000000000000ull; break; }      // DECIMAL128
+    }
+  }
+}
 }  // namespace dfgpu
 
 using namespace dfgpu;
-extern "C" dfgpu_status dfgpu_sort_to_indices(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint8_t* descending, const uint8_t* nulls_first,
-                                              int32_t k, int64_t fetch, dfgpu_array** out) {
-  return guard(ctx, [&] {
+static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint8_t* descending, const uint8_t* nulls_first, int32_t k, int64_t fetch, dfgpu_array** out, dfgpu_array** out_sorted) {
+  {
     if (!cols || k < 1 || !out) fail(DFGPU_INVALID_ARGUMENT, "Sort requires at least one column");
     if (k > MAX_KEYS) fail(DFGPU_NOT_IMPLEMENTED, "more than %d sort columns", MAX_KEYS);
     int64_t n = cols[0]->length;
@@ -382,19 +406,34 @@ extern "C" dfgpu_status dfgpu_sort_to_indices(dfgpu_ctx* ctx, const dfgpu_array*
         }
         if (ok && total_bits <= 64) {
           int sh = total_bits; for (int c = 0; c < k; c++) { sh -= bits_of[c]; pc.c[c].shift = sh; }
-          BufferPtr k0 = alloc_buffer(ctx, (size_t)n * 8), k1 = alloc_buffer(ctx, (size_t)n * 8), v1 = alloc_buffer(ctx, (size_t)n * 4);
-          ArrayHolder idx(new_fixed(ctx, DFGPU_UINT32, n));
+          int ib = 1; while (((uint64_t)(n - 1) >> ib) != 0) ib++;                     // bits of the largest row number
+          const bool word = total_bits + ib <= 64;
+          for (int c = 0; c < k; c++) { pc.c[c].bits = bits_of[c]; pc.c[c].sorted_dst = nullptr; }
+          BufferPtr k0 = alloc_buffer(ctx, (size_t)n * 8), k1 = alloc_buffer(ctx, (size_t)n * 8), v1 = word ? BufferPtr() : alloc_buffer(ctx, (size_t)n * 4);
+          ArrayHolder idx(new_fixed(ctx, DFGPU_UINT32, word && fetch >= 0 && fetch < n ? fetch : n));
           { KernelTimer kt_(ctx, "sort_key_encode");
-            hipLaunchKernelGGL(k_pk_encode, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, pc, n, (uint64_t*)k0->ptr, (uint32_t*)idx.get()->values->ptr); KERNEL_CHECK(); }
-          uint64_t* ka = (uint64_t*)k0->ptr; uint64_t* kb = (uint64_t*)k1->ptr; uint32_t* va = (uint32_t*)idx.get()->values->ptr; uint32_t* vb = (uint32_t*)v1->ptr;
-          const int npass = (total_bits + 7) / 8, dbits = (total_bits + npass - 1) / npass;          // up to 8-bit digits, evened out over the passes
+            hipLaunchKernelGGL(k_pk_encode, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, pc, n, (uint64_t*)k0->ptr, word ? (uint32_t*)nullptr : (uint32_t*)idx.get()->values->ptr, word ? ib : 0); KERNEL_CHECK(); }
+          uint64_t* ka = (uint64_t*)k0->ptr; uint64_t* kb = (uint64_t*)k1->ptr; uint32_t* va = (uint32_t*)idx.get()->values->ptr; uint32_t* vb = word ? nullptr : (uint32_t*)v1->ptr;
+          const int npass = (total_bits + 7) / 8, dbits = (total_bits + npass - 1) / npass;          // up to 8-bit digits, evened out over the passes (9-bit digits double the count table of the stable scatter: 4 passes of 9 measured 6.6 ms against 4.5 ms for 5 of 8 on 100 M rows)
           for (int shift = 0; shift < total_bits; shift += dbits) {
             const int bits = total_bits - shift < dbits ? total_bits - shift : dbits; const bool last = shift + dbits >= total_bits;
-            RpCols rc{}; rc.n = last ? 1 : 2;
-            rc.c[0] = RpCol{ va, vb, 4, RP_RAW, 0 };
-            if (!last) rc.c[1] = RpCol{ nullptr, kb, 8, RP_HASHKEY, 0 };                 // the last pass only needs the row ids
-            (void)rp_partition(ctx, RpHashDigit{ ka, shift, (1u << bits) - 1u }, n, 1u << bits, rc, true, ctx->d_scratch64 + 9, "sort_pass_hist", "sort_pass_scan", "sort_pass_scatter");
+            RpCols rc{};
+            if (word) { rc.n = 1; rc.c[0] = RpCol{ nullptr, kb, 8, RP_HASHKEY, 0 }; }       // the whole record is the word the digit is read from
+            else { rc.n = last ? 1 : 2; rc.c[0] = RpCol{ va, vb, 4, RP_RAW, 0 };
+              if (!last) rc.c[1] = RpCol{ nullptr, kb, 8, RP_HASHKEY, 0 }; }                // the last pass only needs the row ids
+            (void)rp_partition(ctx, RpHashDigit{ ka, shift + (word ? ib : 0), (1u << bits) - 1u }, n, 1u << bits, rc, true, ctx->d_scratch64 + 9, "sort_pass_hist", "sort_pass_scan", "sort_pass_scatter");
             std::swap(ka, kb); std::swap(va, vb);
+          }
+          if (word) {
+            const int64_t m = idx.get()->length;
+            std::vector<ArrayHolder> sk((size_t)k);
+            if (out_sorted) for (int c = 0; c < k; c++) if (!pc.c[c].valid) {          // a key column without NULLs comes back in sorted order for the price of its sequential write
+              sk[(size_t)c].a = new_fixed(ctx, cols[c]->type, m, cols[c]->precision, cols[c]->scale); pc.c[c].sorted_dst = sk[(size_t)c].get()->values->ptr; }
+            if (m) { KernelTimer kt_(ctx, "sort_finish");
+              hipLaunchKernelGGL(k_pk_finish, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, pc, (const uint64_t*)ka, m, ib, (uint32_t*)idx.get()->values->ptr); KERNEL_CHECK(); }
+            if (out_sorted) for (int c = 0; c < k; c++) out_sorted[c] = sk[(size_t)c].release();
+            *out = idx.release();
+            return;
           }
           if (va != (uint32_t*)idx.get()->values->ptr) HIP_CHECK(hipMemcpyAsync(idx.get()->values->ptr, va, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
           if (fetch >= 0 && fetch < n) { dfgpu_array* s2 = nullptr; dfgpu_status st = dfgpu_array_slice(ctx, idx.get(), 0, fetch, &s2); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str()); *out = s2; }
@@ -487,5 +526,16 @@ extern "C" dfgpu_status dfgpu_sort_to_indices(dfgpu_ctx* ctx, const dfgpu_array*
     }
     if (fetch >= 0 && fetch < n) { dfgpu_array* s = nullptr; dfgpu_status st = dfgpu_array_slice(ctx, idx.get(), 0, fetch, &s); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str()); *out = s; }
     else *out = idx.release();
+  }
+}
+extern "C" dfgpu_status dfgpu_sort_to_indices(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint8_t* descending, const uint8_t* nulls_first, int32_t k, int64_t fetch, dfgpu_array** out) {
+  return guard(ctx, [&] { sort_impl(ctx, cols, descending, nulls_first, k, fetch, out, nullptr); });
+}
+extern "C" dfgpu_status dfgpu_sort_to_indices_keys(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint8_t* descending, const uint8_t* nulls_first, int32_t k, int64_t fetch, dfgpu_array** out,
+                                                   dfgpu_array** out_sorted) {
+  return guard(ctx, [&] {
+    if (!out_sorted) fail(DFGPU_INVALID_ARGUMENT, "sort_to_indices_keys: null argument");
+    for (int32_t c = 0; c < k; c++) out_sorted[c] = nullptr;
+    sort_impl(ctx, cols, descending, nulls_first, k, fetch, out, out_sorted);
   });
 }

@@ -232,6 +232,14 @@ class Context:
                                                   -1 if fetch is None else int(fetch), C.byref(out)))
         return self._wrap(out)
 
+    def sort_to_indices_keys(self, cols: Sequence["Array"], descending: Sequence[bool], nulls_first: Sequence[bool], fetch: Optional[int] = None):
+        """(indices, [cols[c] in sorted order, or None when the sort did not produce it as a by-product])."""
+        hs, n = capi.handle_array([a.h.value for a in cols])
+        out = C.c_void_p(); sk = (C.c_void_p * n)()
+        self.check(self.lib.dfgpu_sort_to_indices_keys(self.h, hs, bytes(int(bool(x)) for x in descending), bytes(int(bool(x)) for x in nulls_first), n,
+                                                       -1 if fetch is None else int(fetch), C.byref(out), sk))
+        return self._wrap(out), [self._wrap(C.c_void_p(sk[i])) if sk[i] else None for i in range(n)]
+
     def hash_partition(self, keys: Sequence["Array"], num_partitions: int):
         hs, n = capi.handle_array([a.h.value for a in keys])
         out = C.c_void_p()

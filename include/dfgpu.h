@@ -355,6 +355,10 @@ DFGPU_API int64_t dfgpu_acc_size(const dfgpu_acc *a);
  * out: UINT32 indices. */
 DFGPU_API dfgpu_status dfgpu_sort_to_indices(dfgpu_ctx *ctx, const dfgpu_array *const *cols, const uint8_t *descending,
                                              const uint8_t *nulls_first, int32_t k, int64_t fetch, dfgpu_array **out);
+/* dfgpu_sort_to_indices plus a by-product: out_sorted[c] (k entries) = cols[c] in the sorted order (== take(cols[c], *out)) when the sort could rebuild it from its
+ * packed keys -- fixed-width key columns without NULLs on the packed-key path -- else NULL; sort_batch's take() (sorts/sort.rs:598-603) of such a column is then free. */
+DFGPU_API dfgpu_status dfgpu_sort_to_indices_keys(dfgpu_ctx *ctx, const dfgpu_array *const *cols, const uint8_t *descending, const uint8_t *nulls_first, int32_t k, int64_t fetch,
+                                                  dfgpu_array **out, dfgpu_array **out_sorted);
 
 /* ------------------------------------------------------------------ a14: RepartitionExec */
 /* ≙ BatchPartitioner::partition_iter, Hash(exprs, n) (repartition/mod.rs:148-221): destination =

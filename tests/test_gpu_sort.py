@@ -154,3 +154,52 @@ def test_large_sort_degenerate_keys(ctx):
     one_byte = pa.array((np.arange(n) % 3).astype(np.int32))
     got = ctx.sort_to_indices([ctx.from_arrow(one_byte)], [True], [False]).to_numpy()
     assert np.array_equal(got, po.lexsort_to_indices([one_byte], [True], [False]))
+
+
+@pytest.mark.parametrize("shape", ["decimal_desc_date", "ints_one_nullable", "floats_uint", "wide_range_falls_back"])
+@pytest.mark.parametrize("fetch", [None, 700_000])
+def test_sorted_key_columns_come_back_with_the_indices(ctx, shape, fetch):
+    """dfgpu_sort_to_indices_keys: when packed key bits + row-number bits fit one 64-bit word, the passes move that word alone and the key columns are rebuilt
+    from the sorted words.  The indices must stay the oracle's stable lexsort, and every returned column must equal take(column, indices) bit for bit
+    (sort_batch, sorts/sort.rs:598-603); columns with NULLs and key sets too wide for the word come back as None and go through take()."""
+    import decimal
+    rng = np.random.default_rng(17)
+    n = (1 << 20) + 4321
+    if shape == "decimal_desc_date":
+        cols = [pa.array([decimal.Decimal(int(v)).scaleb(-2) for v in rng.integers(-5 * 10**6, 5 * 10**6, n)], type=pa.decimal128(15, 2)), pa.array(rng.integers(8000, 10600, n).astype(np.int32)).cast(pa.date32())]
+        desc, nf, produced = [True, False], [True, False], [True, True]
+    elif shape == "ints_one_nullable":
+        cols = [pa.array(rng.integers(-100, 100, n).astype(np.int16)), pa.array(rng.integers(0, 1000, n), mask=rng.random(n) < 0.1), pa.array(rng.integers(-2**10, 2**10, n).astype(np.int64))]
+        desc, nf, produced = [False, True, True], [True, False, True], [True, False, True]
+    elif shape == "floats_uint":
+        cols = [pa.array((rng.integers(-8, 8, n) * 0.25).astype(np.float64)), pa.array(rng.integers(0, 60000, n).astype(np.uint16)), pa.array((rng.integers(-3, 3, n) * 1.5).astype(np.float32))]
+        desc, nf, produced = [True, False, False], [True, True, True], [False, False, False]      # float bit patterns span more than 62 bits: the plane path, nothing produced
+    else:
+        cols = [pa.array(rng.integers(-2**45, 2**45, n)), pa.array(rng.integers(0, 2**20, n).astype(np.int32))]
+        desc, nf, produced = [False, False], [True, True], [False, False]                         # 46 + 20 key bits + 21 row bits > 64: (key, row id) pairs move instead
+    idx, sk = ctx.sort_to_indices_keys([ctx.from_arrow(c) for c in cols], desc, nf, fetch)
+    want = po.lexsort_to_indices(cols, desc, nf)
+    if fetch is not None:
+        want = want[:fetch]
+    got = idx.to_numpy()
+    assert np.array_equal(got, want)
+    assert [k is not None for k in sk] == produced
+    for c, k in zip(cols, sk):
+        if k is not None:
+            assert k.to_arrow().equals(c.take(pa.array(want))), shape
+
+
+def test_sort_exec_uses_sorted_key_columns(ctx):
+    """SortExec over (payload, Decimal128 key DESC, Date32 key): the two key columns of the output are the rebuilt ones, the payload goes through take(); the batch
+    equals pyarrow's take of the oracle's order."""
+    import decimal
+    from dfgpu import physical_plan as ops
+    rng = np.random.default_rng(23)
+    n = (1 << 20) + 99
+    t = pa.table({"okey": pa.array(rng.integers(0, 10**9, n)), "price": pa.array([decimal.Decimal(int(v)).scaleb(-2) for v in rng.integers(90000, 10**7, n)], type=pa.decimal128(15, 2)),
+                  "d": pa.array(rng.integers(8035, 10560, n).astype(np.int32)).cast(pa.date32()), "tag": pa.array(rng.integers(0, 100, n).astype(np.int32), mask=rng.random(n) < 0.1)})
+    batch = ops.batch_from_arrow(ctx, t)
+    plan = ops.SortExec([ops.PhysicalSortExpr(ops.Column("price", 1), True, True), ops.PhysicalSortExpr(ops.Column("d", 2), False, False)], ops.MemoryExec([[batch]], batch.schema))
+    out = pa.concat_tables([b.to_arrow() for b in plan.execute(0, ops.TaskContext(ctx, 8192))])
+    order = po.lexsort_to_indices([t["price"].combine_chunks(), t["d"].combine_chunks()], [True, False], [True, False])
+    assert out.equals(t.take(pa.array(order)))
