@@ -211,6 +211,7 @@ PROTOTYPES.update({
     "dfgpu_plan_coalesce_partitions": (C.c_int32, [_P, _PP]),
     "dfgpu_plan_repartition": (C.c_int32, [_P, _PP, C.c_int32, C.c_int32, _PP]),
     "dfgpu_plan_hash_join": (C.c_int32, [_P, _P, _PP, _PP, C.c_int32, _P, _I32P, _I32P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _PP]),
+    "dfgpu_plan_aggregate_input_order": (C.c_int32, [_P, C.c_int32, _I32P, C.c_int32]),
     "dfgpu_plan_aggregate_grouping_sets": (C.c_int32, [_P, _PP, C.c_int32, C.POINTER(C.c_uint8), C.c_int32]),
     "dfgpu_plan_aggregate": (C.c_int32, [C.c_int32, _PP, _CPP, C.c_int32, _I32P, _PP, _PP, _CPP, _I32P, C.c_int32, _P, _PP]),
     "dfgpu_plan_sort": (C.c_int32, [_PP, C.c_char_p, C.c_char_p, C.c_int32, C.c_int64, C.c_int32, _P, _PP]),

@@ -19,6 +19,7 @@
 #include <memory>
 #include <mutex>
 #include <atomic>
+#include <deque>
 #include <map>
 #include <tuple>
 #include <set>
@@ -1095,7 +1096,9 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
   int mode; std::vector<ExprPtr> gexprs; std::vector<std::string> gnames; std::vector<AggExpr> aggs; PlanPtr input; mutable SchemaPtr sch; mutable std::mutex mu;
   // PhysicalGroupBy grouping sets (aggregates/mod.rs:103-160): sets[s][i] != 0 = key i is replaced by null_exprs[i] in set s; empty = the single set of all keys
   std::vector<ExprPtr> null_exprs; std::vector<std::vector<uint8_t>> sets;
-  PlanPtr fresh() const override { auto a = std::make_shared<AggregateExec>(); a->mode = mode; a->gexprs = gexprs; a->gnames = gnames; a->aggs = aggs; a->input = input->fresh(); a->null_exprs = null_exprs; a->sets = sets; return a; }
+  // InputOrderMode (physical-plan/src/ordering.rs:33-44): 0 Linear, 1 PartiallySorted(order_indices: the group keys, in order, that the input is sorted on), 2 Sorted -> GroupOrdering (aggregates/order/mod.rs)
+  int order_mode = 0; std::vector<int> order_indices;
+  PlanPtr fresh() const override { auto a = std::make_shared<AggregateExec>(); a->mode = mode; a->gexprs = gexprs; a->gnames = gnames; a->aggs = aggs; a->input = input->fresh(); a->null_exprs = null_exprs; a->sets = sets; a->order_mode = order_mode; a->order_indices = order_indices; return a; }
   std::vector<std::shared_ptr<const Plan>> children() const override { return {input}; }
   const char* name() const override { return "AggregateExec"; }
   bool merging() const { return mode == 1 || mode == 2; }
@@ -1228,7 +1231,17 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
   }
   SchemaPtr schema() const override { std::lock_guard<std::mutex> l(mu); if (!sch) { auto s = std::make_shared<Schema>(); for (auto& n : out_names()) s->f.push_back(Field{n}); sch = s; } return sch; }
   int partitions() const override { return (mode == 1 || mode == 3) ? 1 : input->partitions(); }
-  std::unique_ptr<Stream> execute(int partition, const TaskContext& tc) const override {
+  // ---- GroupedHashAggregateStream (row_hash.rs:423-520): state of one output partition, input pulled batch by batch
+  struct AggState {
+    TaskContext tc; const ProjectionExec* pj = nullptr; PlanPtr src; std::vector<int> parts; size_t next_part = 0; std::unique_ptr<Stream> cur;
+    bool grouped = false, specials = false, input_done = false, emitted_any = false; int64_t fuse_min_rows = 1 << 20, preagg_min_rows = 1 << 22;
+    GroupsRef groups; std::vector<AccRef> accs; std::vector<StringMinMax> smm; std::vector<CountDistinct> cds; ArrayRef pending;
+    GroupsRef sort_groups; int64_t current_sort = 0;          // GroupOrderingPartial: the sort-key prefixes seen (only the latest is kept), first group of the latest prefix
+    std::deque<Batch> ready;
+    explicit AggState(const TaskContext& t) : tc(t) {}
+  };
+  std::shared_ptr<AggState> make_state(int partition, const TaskContext& tc) const {
+    auto SP = std::make_shared<AggState>(tc); AggState& S = *SP;
     // An input ProjectionExec is looked through: its computed columns that only feed accumulator arguments are evaluated inside the
     // accumulate pass (dfgpu_acc_update_batch_fused) instead of being written out as columns first.
     int64_t fuse_min_rows = 1 << 20; dfgpu_ctx_get_option(tc.ctx, "fused_aggregate_min_rows", &fuse_min_rows);
@@ -1236,11 +1249,11 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
     if (!preagg_on) preagg_min_rows = INT64_MAX;
     const ProjectionExec* pj = (!merging() && !aggs.empty() && fuse_min_rows >= 0) ? dynamic_cast<const ProjectionExec*>(input.get()) : nullptr;
     const PlanPtr& src = pj ? pj->input : input;
-    std::vector<Batch> in;
-    if (mode == 1 || mode == 3) { for (int p = 0; p < src->partitions(); p++) drain(src, p, tc, in); } else drain(src, partition, tc, in);
+    if (mode == 1 || mode == 3) { for (int p = 0; p < src->partitions(); p++) S.parts.push_back(p); } else S.parts.push_back(partition);
     const bool grouped = !gexprs.empty();      // false: AggregateStream (aggregates/no_grouping.rs): one implicit group
-    GroupsRef groups; if (grouped) tc.check(dfgpu_groups_new(tc.ctx, (int32_t)gexprs.size(), &groups.g));
-    std::vector<AccRef> accs(aggs.size()); std::vector<StringMinMax> smm(aggs.size()); std::vector<CountDistinct> cds(aggs.size());
+    GroupsRef& groups = S.groups; if (grouped) tc.check(dfgpu_groups_new(tc.ctx, (int32_t)gexprs.size(), &groups.g));
+    S.accs = std::vector<AccRef>(aggs.size()); S.smm = std::vector<StringMinMax>(aggs.size()); S.cds = std::vector<CountDistinct>(aggs.size());
+    std::vector<AccRef>& accs = S.accs; std::vector<StringMinMax>& smm = S.smm; std::vector<CountDistinct>& cds = S.cds;
     const bool specials = any_special();
     for (size_t i = 0; i < aggs.size(); i++) {
       if (is_string_minmax(i)) { smm[i].is_max = aggs[i].kind == DFGPU_AGG_MAX; continue; }
@@ -1248,15 +1261,21 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
       int32_t t = aggs[i].kind == DFGPU_AGG_COUNT ? DFGPU_INT64 : aggs[i].type;
       tc.check(dfgpu_acc_new(tc.ctx, aggs[i].kind, t, aggs[i].precision, aggs[i].scale, &accs[i].a));
     }
-    ArrayRef pending;             // keys of a first, fully pre-aggregated batch that no hash table holds yet (ids 0 .. n-1)
+    if (order_mode != 0) preagg_min_rows = INT64_MAX;        // ordered input is clustered on its keys: run numbering, and the group table has to hold every id for EmitTo::First
+    S.pj = pj; S.src = src; S.grouped = grouped; S.specials = specials; S.fuse_min_rows = fuse_min_rows; S.preagg_min_rows = preagg_min_rows;
+    return SP;
+  }
+  void consume(AggState& S, Batch& b_in) const {           // group_aggregate_batch (row_hash.rs:524-613)
+    const TaskContext& tc = S.tc; const ProjectionExec* pj = S.pj; const bool grouped = S.grouped, specials = S.specials; const int64_t fuse_min_rows = S.fuse_min_rows, preagg_min_rows = S.preagg_min_rows;
+    GroupsRef& groups = S.groups; std::vector<AccRef>& accs = S.accs; std::vector<StringMinMax>& smm = S.smm; std::vector<CountDistinct>& cds = S.cds; ArrayRef& pending = S.pending;
     auto settle_pending = [&]() {  // another batch follows: the keys go into the table after all; first-seen interning of distinct keys numbers them 0 .. n-1 again
       if (!pending) return;
       const dfgpu_array* kp = pending.a; dfgpu_array* ids = nullptr; tc.check(dfgpu_groups_intern(tc.ctx, groups.g, &kp, 1, nullptr, &ids)); ArrayRef drop = ArrayRef::adopt(ids);
       if (dfgpu_groups_len(groups.g) != pending.len()) fail(DFGPU_INTERNAL, "AggregateExec: pre-aggregated keys were not distinct");
       pending = ArrayRef();
     };
-    for (auto& b_in : in) {       // group_aggregate_batch (row_hash.rs:524-613)
-      if (b_in.base_rows == 0) continue;
+    {
+      if (b_in.base_rows == 0) return;
       settle_pending();
       Batch raw; std::vector<bool> deferred;
       if (pj) { raw = b_in; b_in = pj->project(tc, raw, &deferred); }
@@ -1267,9 +1286,9 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
         std::set<int> need; for (auto& e : gexprs) e->columns(need); for (auto& a : aggs) if (a.filter) a.filter->columns(need);
         for (int ci : need) ensure(ci);
       }
-      if (b.base_rows == 0) continue;
+      if (b.base_rows == 0) return;
       ArrayRef mask = b.selection; b.selection = ArrayRef();
-      if (!sets.empty()) { if (specials) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: COUNT(DISTINCT) / string MIN-MAX under grouping sets on the device"); for (size_t ci = 0; ci < deferred.size(); ci++) ensure((int)ci); group_aggregate_sets(tc, b, mask, groups, accs); continue; }
+      if (!sets.empty()) { if (specials) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: COUNT(DISTINCT) / string MIN-MAX under grouping sets on the device"); for (size_t ci = 0; ci < deferred.size(); ci++) ensure((int)ci); group_aggregate_sets(tc, b, mask, groups, accs); return; }
       ArrayRef gids; int64_t total = 1;
       if (grouped) {
         std::vector<ArrayRef> gc; std::vector<const dfgpu_array*> gp;
@@ -1288,11 +1307,12 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
         }
         // A large batch of high-cardinality keys is first reduced to one row per group partition by partition out of LDS (the Partial stage
         // of a two-phase plan, applied inside the operator): its partial rows are then interned and MERGED like the Final stage does.
-        if (!specials && !merging() && gp.size() == 1 && b.base_rows >= preagg_min_rows && preaggregate(tc, b, deferred, ensure, gp[0], mask, groups, accs, &pending)) continue;
-        dfgpu_array* ids = nullptr; tc.check(specials ? dfgpu_groups_intern(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids) : dfgpu_groups_intern_deferred(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids)); gids = ArrayRef::adopt(ids);      // deferred ids: only the accumulators read them
+        if (!specials && !merging() && gp.size() == 1 && b.base_rows >= preagg_min_rows && preaggregate(tc, b, deferred, ensure, gp[0], mask, groups, accs, &pending)) return;
+        dfgpu_array* ids = nullptr; tc.check(specials || order_mode == 1 ? dfgpu_groups_intern(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids) : dfgpu_groups_intern_deferred(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids)); gids = ArrayRef::adopt(ids);      // deferred ids: only the accumulators read them
         total = dfgpu_groups_len(groups.g);
+        if (order_mode == 1 && !specials) note_sort_prefix(S, gp, gids, mask);
       } else { dfgpu_array* z = nullptr; tc.check(dfgpu_array_new_zeros(tc.ctx, DFGPU_UINT32, 0, 0, b.base_rows, &z)); gids = ArrayRef::adopt(z); }
-      if (!specials && !merging() && total <= 8 && fuse_min_rows >= 0 && b.base_rows >= fuse_min_rows && try_fused(tc, pj, raw, b, deferred, accs, gids, grouped ? ArrayRef() : mask, total)) continue;
+      if (!specials && !merging() && total <= 8 && fuse_min_rows >= 0 && b.base_rows >= fuse_min_rows && try_fused(tc, pj, raw, b, deferred, accs, gids, grouped ? ArrayRef() : mask, total)) return;
       for (size_t ci = 0; ci < deferred.size(); ci++) ensure((int)ci);
       size_t col = gexprs.size();
       std::vector<ArrayRef> uvals(aggs.size()), ufilt(aggs.size());       // update mode: all accumulators of the batch go down together
@@ -1328,7 +1348,10 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
         if (!ap.empty()) tc.check(dfgpu_acc_update_batch_multi(tc.ctx, ap.data(), vp.data(), fp.data(), (int32_t)ap.size(), gids.a, total));
       }
     }
-    std::vector<Batch> outv; int64_t total = grouped ? (pending ? pending.len() : dfgpu_groups_len(groups.g)) : 1;     // no GROUP BY: always one row, even on empty input
+  }
+  void finish(AggState& S) const {           // set_input_done_and_produce_output (row_hash.rs:775-790)
+    const TaskContext& tc = S.tc; const bool grouped = S.grouped; GroupsRef& groups = S.groups; std::vector<AccRef>& accs = S.accs; std::vector<StringMinMax>& smm = S.smm; std::vector<CountDistinct>& cds = S.cds; ArrayRef& pending = S.pending;
+    std::deque<Batch>& outv = S.ready; int64_t total = grouped ? (pending ? pending.len() : dfgpu_groups_len(groups.g)) : 1;     // no GROUP BY: always one row, even on empty input
     if (total > 0) {              // emit(EmitTo::All) (row_hash.rs:626-662)
       Batch o; o.base_rows = total; std::vector<dfgpu_array*> keys(gexprs.size(), nullptr);
       if (grouped && pending) o.cols.push_back(col_of(pending));          // one key column, already in first-seen order
@@ -1346,8 +1369,78 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
       o.schema = s; { std::lock_guard<std::mutex> l(mu); sch = s; }
       outv.push_back(std::move(o));
     }
-    return std::unique_ptr<Stream>(new VecStream(std::move(outv)));
   }
+  // emit(EmitTo::First(n)) (row_hash.rs:626-662 with groups_accumulator.rs:25-57): the first n groups leave as one batch, the rest are renumbered from 0
+  void emit_first(AggState& S, int64_t n) const {
+    const TaskContext& tc = S.tc; const int64_t total = dfgpu_groups_len(S.groups.g);
+    if (n <= 0 || n > total) return;
+    Batch o; o.base_rows = n; std::vector<dfgpu_array*> keys(gexprs.size(), nullptr);
+    tc.check(dfgpu_groups_emit_first(tc.ctx, S.groups.g, n, keys.data())); for (auto k : keys) o.cols.push_back(col_of(ArrayRef::adopt(k)));
+    dfgpu_array_desc ed{}; ed.type = DFGPU_UINT32; ed.values = &ed; dfgpu_array* e = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &ed, &e)); ArrayRef empty_ids = ArrayRef::adopt(e);
+    for (size_t i = 0; i < aggs.size(); i++) {
+      tc.check(dfgpu_acc_update_batch(tc.ctx, S.accs[i].a, nullptr, empty_ids.a, nullptr, total));      // zero-row update: grow the state to `total` groups
+      dfgpu_array* st[2] = {nullptr, nullptr}; int32_t ns = 0; tc.check(dfgpu_acc_emit_first(tc.ctx, S.accs[i].a, n, mode == 0 ? 1 : 0, st, &ns));
+      for (int k = 0; k < ns; k++) o.cols.push_back(col_of(ArrayRef::adopt(st[k])));
+    }
+    auto sc = std::make_shared<Schema>(); auto names = out_names();
+    for (size_t i = 0; i < o.cols.size(); i++) sc->f.push_back(field_of(names[i], o.cols[i].arr.a));
+    o.schema = sc; { std::lock_guard<std::mutex> l(mu); sch = sc; }
+    S.ready.push_back(std::move(o)); S.emitted_any = true; S.current_sort = S.current_sort > n ? S.current_sort - n : 0;
+  }
+  // GroupOrderingPartial::new_groups (aggregates/order/partial.rs:196-240): current_sort = group index of the first row that carries the latest sort-key prefix.
+  // The prefixes are interned first-seen into their own table (sorted input: equal prefixes are contiguous, so a new prefix is a new id and the latest is the largest);
+  // the first row with the largest id, and the group that row fell into, are read back (two 4-byte copies per batch).
+  void note_sort_prefix(AggState& S, const std::vector<const dfgpu_array*>& gp, const ArrayRef& gids, const ArrayRef& mask) const {
+    const TaskContext& tc = S.tc;
+    if (!S.sort_groups.g) tc.check(dfgpu_groups_new(tc.ctx, (int32_t)order_indices.size(), &S.sort_groups.g));
+    std::vector<const dfgpu_array*> sk; for (int ix : order_indices) sk.push_back(gp[(size_t)ix]);
+    const int64_t before = dfgpu_groups_len(S.sort_groups.g);
+    dfgpu_array* si = nullptr; tc.check(dfgpu_groups_intern(tc.ctx, S.sort_groups.g, sk.data(), (int32_t)sk.size(), mask.a, &si)); ArrayRef sids = ArrayRef::adopt(si);
+    const int64_t after = dfgpu_groups_len(S.sort_groups.g);
+    if (after == before) return;                         // the batch stayed inside the prefix already current
+    uint32_t latest = (uint32_t)(after - 1); dfgpu_array_desc ld{}; ld.type = DFGPU_UINT32; ld.length = 1; ld.values = &latest;
+    dfgpu_array* la = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &ld, &la)); ArrayRef lit = ArrayRef::adopt(la);
+    dfgpu_array* m = nullptr; tc.check(dfgpu_binary(tc.ctx, DFGPU_OP_EQ, sids.a, 0, lit.a, 1, &m)); ArrayRef eq = ArrayRef::adopt(m);
+    if (mask) { dfgpu_array* o = nullptr; tc.check(dfgpu_binary(tc.ctx, DFGPU_OP_AND, eq.a, 0, mask.a, 0, &o)); eq = ArrayRef::adopt(o); }
+    ArrayRef rows = mask_indices(tc, eq);
+    if (rows.len() == 0) fail(DFGPU_INTERNAL, "AggregateExec: no row carries the latest sort prefix");
+    dfgpu_array* r0 = nullptr; tc.check(dfgpu_array_slice(tc.ctx, rows.a, 0, 1, &r0)); ArrayRef first_row = ArrayRef::adopt(r0);
+    ArrayRef g0 = take(tc, gids, first_row);
+    uint32_t gid = 0; tc.check(dfgpu_array_export_host(tc.ctx, g0.a, &gid, nullptr, nullptr));
+    if (before == 0 && after == 1) S.current_sort = 0;     // State::Start: the first row's prefix, nothing in front of it
+    else S.current_sort = (int64_t)gid;
+    if (after > 1) { std::vector<dfgpu_array*> drop(order_indices.size(), nullptr); tc.check(dfgpu_groups_emit_first(tc.ctx, S.sort_groups.g, after - 1, drop.data())); for (auto d : drop) if (d) dfgpu_array_release(d); }
+  }
+  // GroupOrdering::emit_to after a batch (order/full.rs:87-103, partial.rs:118-132)
+  void emit_ordered(AggState& S) const {
+    if (order_mode == 0 || !S.grouped || S.specials || !sets.empty() || S.pending) return;
+    const int64_t total = dfgpu_groups_len(S.groups.g);
+    const int64_t n = order_mode == 2 ? total - 1 : S.current_sort;
+    if (n > 0) emit_first(S, n);
+  }
+  bool pull(AggState& S, Batch& b) const {
+    for (;;) {
+      if (!S.cur) { if (S.next_part >= S.parts.size()) return false; S.cur = S.src->run(S.parts[S.next_part++], S.tc); }
+      if (S.cur->next(b)) return true;
+      S.cur.reset();
+    }
+  }
+  struct AggStream : Stream {
+    const AggregateExec* op; std::shared_ptr<AggState> st;
+    AggStream(const AggregateExec* o, std::shared_ptr<AggState> s) : op(o), st(std::move(s)) {}
+    bool next(Batch& out) override {
+      AggState& S = *st;
+      for (;;) {
+        if (!S.ready.empty()) { out = std::move(S.ready.front()); S.ready.pop_front(); return true; }
+        if (S.input_done) return false;
+        Batch b;
+        if (!op->pull(S, b)) { S.input_done = true; op->finish(S); continue; }      // set_input_done_and_produce_output
+        op->consume(S, b);
+        op->emit_ordered(S);
+      }
+    }
+  };
+  std::unique_ptr<Stream> execute(int partition, const TaskContext& tc) const override { return std::unique_ptr<Stream>(new AggStream(this, make_state(partition, tc))); }
 };
 
 // ------------------------------------------------------------------ SortExec
@@ -1606,6 +1699,16 @@ dfgpu_status dfgpu_plan_aggregate(int32_t mode, const dfgpu_expr* const* gexprs,
       a->aggs.push_back(std::move(x));
     }
     *out = new dfgpu_plan{a};
+  });
+}
+dfgpu_status dfgpu_plan_aggregate_input_order(dfgpu_plan* aggregate, int32_t input_order_mode, const int32_t* order_indices, int32_t n) {
+  return guard([&] {
+    auto* a = aggregate ? const_cast<AggregateExec*>(dynamic_cast<const AggregateExec*>(aggregate->p.get())) : nullptr;       // the node is still private to its builder
+    if (!a) fail(DFGPU_INVALID_ARGUMENT, "plan_aggregate_input_order: not an AggregateExec");
+    if (input_order_mode < 0 || input_order_mode > 2 || (input_order_mode == 1 && (n < 1 || !order_indices))) fail(DFGPU_INVALID_ARGUMENT, "plan_aggregate_input_order: mode %d with %d order indices", input_order_mode, n);
+    a->order_indices.clear();
+    if (input_order_mode == 1) for (int i = 0; i < n; i++) { if (order_indices[i] < 0 || order_indices[i] >= (int32_t)a->gexprs.size()) fail(DFGPU_INVALID_ARGUMENT, "plan_aggregate_input_order: order index %d of %zu group expressions", order_indices[i], a->gexprs.size()); a->order_indices.push_back(order_indices[i]); }
+    a->order_mode = input_order_mode;
   });
 }
 dfgpu_status dfgpu_plan_aggregate_grouping_sets(dfgpu_plan* aggregate, const dfgpu_expr* const* null_exprs, int32_t nkeys, const uint8_t* groups, int32_t nsets) {

@@ -254,6 +254,20 @@ __global__ void __launch_bounds__(BLOCK) k_pa_gather_cnt(const uint32_t* src, co
   int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < m) out[i] = src[perm[i]];
 }
 
+// first-seen order without a sort: every partial row's first input row is a distinct row number, so its rank among them is the number of marked rows in front of it --
+// mark the rows in a bitmap over the input, prefix-count the words, read the rank back
+__global__ void __launch_bounds__(BLOCK) k_pa_mark(const uint32_t* __restrict__ first, int64_t m, unsigned long long* bits) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < m) { const uint32_t f = first[i]; atomicOr(&bits[f >> 6], 1ull << (f & 63)); }
+}
+__global__ void __launch_bounds__(BLOCK) k_pa_popc(const uint64_t* __restrict__ bits, int64_t nw, uint32_t* __restrict__ pc) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < nw) pc[i] = (uint32_t)__popcll(bits[i]);
+}
+__global__ void __launch_bounds__(BLOCK) k_pa_rank_perm(const uint32_t* __restrict__ first, int64_t m, const uint64_t* __restrict__ bits, const uint32_t* __restrict__ pref, uint32_t* __restrict__ perm) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i >= m) return;
+  const uint32_t f = first[i]; const uint32_t r = pref[f >> 6] + (uint32_t)__popcll(bits[f >> 6] & ((1ull << (f & 63)) - 1ull));
+  perm[r] = (uint32_t)i;
+}
+
 static bool pa_key_type_ok(int32_t t) { return t == DFGPU_INT64 || t == DFGPU_UINT64 || t == DFGPU_INT32 || t == DFGPU_UINT32 || t == DFGPU_DATE32; }
 
 }  // namespace dfgpu
@@ -387,8 +401,18 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     // ---- partial rows in first-seen order of their groups
     BufferPtr perm = alloc_buffer(ctx, (size_t)(m + 1) * 4);
     { KernelTimer kt_(ctx, "pa_order");
-      launch_iota_u32(ctx, (uint32_t*)perm->ptr, m, 0);
-      if (ctx->first_seen_group_order) radix_sort_pairs_u32(ctx, (uint32_t*)ofirst->ptr, (uint32_t*)perm->ptr, m, 32); }
+      if (ctx->first_seen_group_order && m >= 32768 && m <= (4 << 20)) {       // beyond a few million rows the random atomics and rank look-ups lose to the sort (20 M: 1.44 ms against 1.28)
+        const int64_t nw = (n + 63) / 64;
+        BufferPtr bits = alloc_buffer(ctx, (size_t)nw * 8, true), pref = alloc_buffer(ctx, (size_t)(nw + 1) * 4);
+        hipLaunchKernelGGL(k_pa_mark, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)ofirst->ptr, m, (unsigned long long*)bits->ptr);
+        hipLaunchKernelGGL(k_pa_popc, dim3(grid_for(nw, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)bits->ptr, nw, (uint32_t*)pref->ptr);
+        exclusive_scan_u32_inplace32(ctx, (uint32_t*)pref->ptr, nw, nullptr);
+        hipLaunchKernelGGL(k_pa_rank_perm, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)ofirst->ptr, m, (const uint64_t*)bits->ptr, (const uint32_t*)pref->ptr, (uint32_t*)perm->ptr);
+        KERNEL_CHECK();
+      } else {
+        launch_iota_u32(ctx, (uint32_t*)perm->ptr, m, 0);
+        if (ctx->first_seen_group_order) radix_sort_pairs_u32(ctx, (uint32_t*)ofirst->ptr, (uint32_t*)perm->ptr, m, 32);
+      } }
     KernelTimer kt_(ctx, "pa_emit");
     const uint32_t* pp = (const uint32_t*)perm->ptr; dim3 grid(grid_for(m, BLOCK));
     ArrayHolder ok(new_fixed(ctx, ktype, m));

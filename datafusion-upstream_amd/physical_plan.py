@@ -662,7 +662,11 @@ class PhysicalGroupBy:
 
 
 class AggregateExec(ExecutionPlan):
-    def __init__(self, mode: str, group_by, aggr_expr: List[AggregateFunctionExpr], input):
+    def __init__(self, mode: str, group_by, aggr_expr: List[AggregateFunctionExpr], input, input_order_mode="Linear"):
+        """input_order_mode ≙ InputOrderMode (physical-plan/src/ordering.rs:33): "Linear", "Sorted" (input sorted on every group key) or ("PartiallySorted", [indices of
+        the group keys the input is sorted on]) -- the reference derives it from the input's output ordering (aggregates/mod.rs:get_aggregate_exprs_requirement /
+        get_working_mode); here the caller states it.  Ordered modes emit finished groups after every input batch (GroupOrdering, aggregates/order/)."""
+        self.input_order_mode = input_order_mode
         if mode not in _AGG_MODES:
             raise DfgpuError(5, f"unknown AggregateMode {mode}")
         self.grouping = group_by if isinstance(group_by, PhysicalGroupBy) else None
@@ -695,6 +699,11 @@ class AggregateExec(ExecutionPlan):
         out = C.c_void_p()
         _check(_lib().dfgpu_plan_aggregate(_AGG_MODES[self.mode], _ptrs([e.handle(ctx).h for e, _ in self.group_by]), _strs([n for _, n in self.group_by]), len(self.group_by),
                                            kinds, args, filts, _strs([a.name for a in self.aggr_expr]), tarr, na, _child_handle(self.input, context).h, C.byref(out)))
+        om = self.input_order_mode
+        if om != "Linear":
+            idx = list(om[1]) if isinstance(om, (tuple, list)) else []
+            code = 2 if om == "Sorted" else 1 if isinstance(om, (tuple, list)) and om[0] == "PartiallySorted" else -1
+            _check(_lib().dfgpu_plan_aggregate_input_order(out, code, (C.c_int32 * max(1, len(idx)))(*idx), len(idx)))
         if self.grouping is not None:
             g = self.grouping
             flat = [1 if m else 0 for s in g.groups for m in s]

@@ -105,6 +105,11 @@ DFGPU_API dfgpu_status dfgpu_plan_aggregate(int32_t mode, const dfgpu_expr *cons
 /* PhysicalGroupBy with grouping sets (aggregates/mod.rs:103-160; GROUPING SETS / CUBE / ROLLUP): null_exprs[i] is the typed NULL
  * literal that stands in for group expression i, groups[s * nkeys + i] != 0 says set s replaces key i by it.  Every input batch is
  * grouped once per set into the same GroupValues (evaluate_group_by, :1161-1200).  Call before the plan first executes. */
+/* InputOrderMode of an AggregateExec (physical-plan/src/ordering.rs:33-44; GroupOrdering, aggregates/order/{mod,full,partial}.rs): 0 Linear (default), 1 PartiallySorted --
+ * the input is sorted on the group keys order_indices[0..n) (indices into group_exprs, in sort order), 2 Sorted -- on all of them.  After every input batch the groups
+ * that can receive no more rows leave as an output batch (EmitTo::First(n), row_hash.rs:455-461): all but the last group (Sorted) / all groups in front of the latest sort
+ * prefix (PartiallySorted); the group table holds only the open groups.  The concatenated output is the same as in Linear mode. */
+DFGPU_API dfgpu_status dfgpu_plan_aggregate_input_order(dfgpu_plan *aggregate, int32_t input_order_mode, const int32_t *order_indices, int32_t n);
 DFGPU_API dfgpu_status dfgpu_plan_aggregate_grouping_sets(dfgpu_plan *aggregate, const dfgpu_expr *const *null_exprs, int32_t nkeys, const uint8_t *groups, int32_t nsets);
 /* SortExec::new(expr, input).with_fetch(fetch).with_preserve_partitioning(..); fetch < 0 = none */
 DFGPU_API dfgpu_status dfgpu_plan_sort(const dfgpu_expr *const *exprs, const uint8_t *descending, const uint8_t *nulls_first, int32_t n, int64_t fetch,

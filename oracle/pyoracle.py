@@ -557,3 +557,43 @@ def string_min_max(values, gids, total: int, is_max: bool, opt_filter=None):
         if best[g] is None or (b > best[g] if is_max else b < best[g]):
             best[g] = b
     return pa.array([None if b is None else b.decode() for b in best], type=pa.utf8())
+
+
+# ------------------------------------------------------------------ GroupOrdering (aggregates/order/{mod,full,partial}.rs; used by row_hash.rs:455-461, :545-562)
+def group_ordering_emits(batches: Sequence[Sequence], order_indices: Optional[Sequence[int]] = None) -> List[int]:
+    """Rows (groups) of every output batch an AggregateExec with an ordered input emits: after each input batch EmitTo::First(n) when GroupOrdering::emit_to says so,
+    then EmitTo::All at the end of input.  batches = per input batch the group-key columns; order_indices = None for GroupOrderingFull (full.rs:58-140), else the
+    indices of the sorted group keys for GroupOrderingPartial (partial.rs:118-240).  Plain Python over the rows: small inputs only."""
+    seen = {}                     # group key tuple -> group index (after removals)
+    emits: List[int] = []
+    started = False; current = 0; current_sort = 0; sort_key = None
+    for cols in batches:
+        rows = list(zip(*[c.to_pylist() for c in cols]))
+        before = len(seen)
+        gids = []
+        for r in rows:
+            if r not in seen:
+                seen[r] = len(seen)
+            gids.append(seen[r])
+        total = len(seen)
+        if total > before and rows:                                     # new_groups is only called when the batch created groups (row_hash.rs:556)
+            if order_indices is None:
+                current = total - 1; started = True                     # full.rs:120-139
+            else:
+                if not started:
+                    current_sort, sort_key = 0, tuple(rows[0][i] for i in order_indices); started = True
+                for r, g in zip(rows, gids):                            # partial.rs:225-233
+                    k = tuple(r[i] for i in order_indices)
+                    if k != sort_key:
+                        current_sort, sort_key = g, k
+                current = total - 1
+        n = (current if order_indices is None else current_sort) if started else 0
+        if n > 0:                                                       # emit_to: First(n); remove_groups(n) shifts every index down
+            emits.append(n)
+            seen = {k: g - n for k, g in seen.items() if g >= n}
+            current -= n
+            if order_indices is not None:
+                current_sort -= n
+    if len(seen) > 0:
+        emits.append(len(seen))                                         # input_done: EmitTo::All
+    return emits
