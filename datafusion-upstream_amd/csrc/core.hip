@@ -295,6 +295,8 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "fused_aggregate_min_rows") ctx->fused_aggregate_min_rows = value;
     else if (k == "sort_packed_keys") ctx->sort_packed_keys = value != 0;
     else if (k == "memory_limit") ctx->memory_limit = value;
+    else if (k == "agg_spill_state_bytes") ctx->agg_spill_state_bytes = value;
+    else if (k == "agg_spill_ranges") { if (value < 1 || value > 4096) fail(DFGPU_INVALID_ARGUMENT, "agg_spill_ranges: 1 .. 4096"); ctx->agg_spill_ranges = value; }
     else if (k == "collect_metrics") ctx->collect_metrics = value != 0;
     else if (k == "agg_partitioned") ctx->agg_partitioned = value != 0;
     else if (k == "agg_partitioned_force") ctx->agg_partitioned_force = value != 0;
@@ -325,6 +327,8 @@ dfgpu_status dfgpu_ctx_get_option(dfgpu_ctx* ctx, const char* key, int64_t* out)
     else if (k == "fused_aggregate_min_rows") *out = ctx->fused_aggregate_min_rows;
     else if (k == "sort_packed_keys") *out = ctx->sort_packed_keys;
     else if (k == "memory_limit") *out = ctx->memory_limit;
+    else if (k == "agg_spill_state_bytes") *out = ctx->agg_spill_state_bytes;
+    else if (k == "agg_spill_ranges") *out = ctx->agg_spill_ranges;
     else if (k == "collect_metrics") *out = ctx->collect_metrics;
     else if (k == "agg_preaggregate_distinct") *out = ctx->pa_last_distinct;      // read only
     else if (k == "live_bytes") *out = (int64_t)ctx->live_bytes;              // read only: device bytes held by live buffers of this ctx

@@ -1224,20 +1224,22 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
       if (!ap.empty()) tc.check(dfgpu_acc_update_batch_multi(tc.ctx, ap.data(), vp.data(), fp.data(), (int32_t)ap.size(), gids.a, total));
     }
   }
-  std::vector<std::string> out_names() const {
+  std::vector<std::string> out_names() const { return out_names(mode == 0); }
+  std::vector<std::string> out_names(bool as_state) const {
     std::vector<std::string> n = gnames;
-    for (auto& a : aggs) { if (mode == 0) { if (a.kind == DFGPU_AGG_AVG) { n.push_back(a.name + "[count]"); n.push_back(a.name + "[sum]"); } else n.push_back(a.name + "[" + agg_fun_name(a.kind) + "]"); } else n.push_back(a.name); }
+    for (auto& a : aggs) { if (as_state) { if (a.kind == DFGPU_AGG_AVG) { n.push_back(a.name + "[count]"); n.push_back(a.name + "[sum]"); } else n.push_back(a.name + "[" + agg_fun_name(a.kind) + "]"); } else n.push_back(a.name); }
     return n;
   }
   SchemaPtr schema() const override { std::lock_guard<std::mutex> l(mu); if (!sch) { auto s = std::make_shared<Schema>(); for (auto& n : out_names()) s->f.push_back(Field{n}); sch = s; } return sch; }
   int partitions() const override { return (mode == 1 || mode == 3) ? 1 : input->partitions(); }
+  struct SpillState;
   // ---- GroupedHashAggregateStream (row_hash.rs:423-520): state of one output partition, input pulled batch by batch
   struct AggState {
     TaskContext tc; const ProjectionExec* pj = nullptr; PlanPtr src; std::vector<int> parts; size_t next_part = 0; std::unique_ptr<Stream> cur;
     bool grouped = false, specials = false, input_done = false, emitted_any = false; int64_t fuse_min_rows = 1 << 20, preagg_min_rows = 1 << 22;
     GroupsRef groups; std::vector<AccRef> accs; std::vector<StringMinMax> smm; std::vector<CountDistinct> cds; ArrayRef pending;
     GroupsRef sort_groups; int64_t current_sort = 0;          // GroupOrderingPartial: the sort-key prefixes seen (only the latest is kept), first group of the latest prefix
-    std::deque<Batch> ready;
+    std::deque<Batch> ready; std::shared_ptr<SpillState> spill;
     explicit AggState(const TaskContext& t) : tc(t) {}
   };
   std::shared_ptr<AggState> make_state(int partition, const TaskContext& tc) const {
@@ -1261,6 +1263,8 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
       int32_t t = aggs[i].kind == DFGPU_AGG_COUNT ? DFGPU_INT64 : aggs[i].type;
       tc.check(dfgpu_acc_new(tc.ctx, aggs[i].kind, t, aggs[i].precision, aggs[i].scale, &accs[i].a));
     }
+    { int64_t lim = 0, ranges = 16; dfgpu_ctx_get_option(tc.ctx, "agg_spill_state_bytes", &lim); dfgpu_ctx_get_option(tc.ctx, "agg_spill_ranges", &ranges);
+      if (lim > 0 && grouped && !specials && sets.empty()) { S.spill = std::make_shared<SpillState>(); S.spill->limit = lim; S.spill->ranges = ranges; } }
     if (order_mode != 0) preagg_min_rows = INT64_MAX;        // ordered input is clustered on its keys: run numbering, and the group table has to hold every id for EmitTo::First
     S.pj = pj; S.src = src; S.grouped = grouped; S.specials = specials; S.fuse_min_rows = fuse_min_rows; S.preagg_min_rows = preagg_min_rows;
     return SP;
@@ -1276,6 +1280,8 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
     };
     {
       if (b_in.base_rows == 0) return;
+      // spill_previous_if_necessary (row_hash.rs:667-683): not in Partial mode, not with an ordered input
+      if (S.spill && order_mode == 0 && mode != 0 && !pending && dfgpu_groups_len(groups.g) > 0 && state_bytes(S) > S.spill->limit) spill(S, *S.spill);
       settle_pending();
       Batch raw; std::vector<bool> deferred;
       if (pj) { raw = b_in; b_in = pj->project(tc, raw, &deferred); }
@@ -1307,7 +1313,7 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
         }
         // A large batch of high-cardinality keys is first reduced to one row per group partition by partition out of LDS (the Partial stage
         // of a two-phase plan, applied inside the operator): its partial rows are then interned and MERGED like the Final stage does.
-        if (!specials && !merging() && gp.size() == 1 && b.base_rows >= preagg_min_rows && preaggregate(tc, b, deferred, ensure, gp[0], mask, groups, accs, &pending)) return;
+        if (!specials && !merging() && gp.size() == 1 && b.base_rows >= preagg_min_rows && preaggregate(tc, b, deferred, ensure, gp[0], mask, groups, accs, S.spill ? nullptr : &pending)) return;
         dfgpu_array* ids = nullptr; tc.check(specials || order_mode == 1 ? dfgpu_groups_intern(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids) : dfgpu_groups_intern_deferred(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids)); gids = ArrayRef::adopt(ids);      // deferred ids: only the accumulators read them
         total = dfgpu_groups_len(groups.g);
         if (order_mode == 1 && !specials) note_sort_prefix(S, gp, gids, mask);
@@ -1349,9 +1355,10 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
       }
     }
   }
-  void finish(AggState& S) const {           // set_input_done_and_produce_output (row_hash.rs:775-790)
+  // emit(EmitTo::All, spilling) (row_hash.rs:626-662): every group as one batch -- state columns when as_state (Partial output, and what a spill holds), else final values
+  bool emit_all(AggState& S, bool as_state, Batch* out) const {
     const TaskContext& tc = S.tc; const bool grouped = S.grouped; GroupsRef& groups = S.groups; std::vector<AccRef>& accs = S.accs; std::vector<StringMinMax>& smm = S.smm; std::vector<CountDistinct>& cds = S.cds; ArrayRef& pending = S.pending;
-    std::deque<Batch>& outv = S.ready; int64_t total = grouped ? (pending ? pending.len() : dfgpu_groups_len(groups.g)) : 1;     // no GROUP BY: always one row, even on empty input
+    int64_t total = grouped ? (pending ? pending.len() : dfgpu_groups_len(groups.g)) : 1;     // no GROUP BY: always one row, even on empty input
     if (total > 0) {              // emit(EmitTo::All) (row_hash.rs:626-662)
       Batch o; o.base_rows = total; std::vector<dfgpu_array*> keys(gexprs.size(), nullptr);
       if (grouped && pending) o.cols.push_back(col_of(pending));          // one key column, already in first-seen order
@@ -1361,14 +1368,113 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
         if (is_string_minmax(i)) { o.cols.push_back(col_of(smm[i].emit(tc, total))); continue; }          // state and final value are the same column
         if (aggs[i].kind == DFGPU_AGG_COUNT_DISTINCT) { o.cols.push_back(col_of(cds[i].emit(tc, total))); continue; }
         tc.check(dfgpu_acc_update_batch(tc.ctx, accs[i].a, nullptr, empty_ids.a, nullptr, total));      // zero-row update: grow the state to `total` groups
-        if (mode == 0) { dfgpu_array* st[2] = {nullptr, nullptr}; int32_t n = 0; tc.check(dfgpu_acc_state(tc.ctx, accs[i].a, st, &n)); for (int k = 0; k < n; k++) o.cols.push_back(col_of(ArrayRef::adopt(st[k]))); }
+        if (as_state) { dfgpu_array* st[2] = {nullptr, nullptr}; int32_t n = 0; tc.check(dfgpu_acc_state(tc.ctx, accs[i].a, st, &n)); for (int k = 0; k < n; k++) o.cols.push_back(col_of(ArrayRef::adopt(st[k]))); }
         else { dfgpu_array* v = nullptr; tc.check(dfgpu_acc_evaluate(tc.ctx, accs[i].a, &v)); o.cols.push_back(col_of(ArrayRef::adopt(v))); }
       }
-      auto s = std::make_shared<Schema>(); auto names = out_names();
+      auto s = std::make_shared<Schema>(); auto names = out_names(as_state);
       for (size_t i = 0; i < o.cols.size(); i++) s->f.push_back(field_of(names[i], o.cols[i].arr.a));
-      o.schema = s; { std::lock_guard<std::mutex> l(mu); sch = s; }
-      outv.push_back(std::move(o));
+      o.schema = s; if (as_state == (mode == 0)) { std::lock_guard<std::mutex> l(mu); sch = s; }
+      *out = std::move(o); return true;
     }
+    return false;
+  }
+  // ---- spill of the aggregation state to host memory (row_hash.rs:664-771: spill_previous_if_necessary / spill / update_merged_stream).  The reference writes the
+  // sorted state to an IPC file per spill and at the end stream-merges the files with the remaining state, re-aggregating the merged, key-ordered stream under
+  // GroupOrdering::Full.  Here a spill is the sorted state batch cut into key RANGES (splitter keys fixed at the first spill, so every spill and the remainder are cut at
+  // the same keys) and copied to host memory as Arrow arrays; at the end range r of every spill and of the remainder is brought back, merged (merge_batch) in a fresh
+  // table, ordered by key and emitted -- ranges in key order, so the output is in key order like the reference's, and the device only ever holds one range's groups.
+  struct HostColumn { ArrowArray a{}; ArrowSchema s{}; bool live = false;
+    HostColumn() = default; HostColumn(const HostColumn&) = delete; HostColumn& operator=(const HostColumn&) = delete;
+    HostColumn(HostColumn&& o) noexcept : a(o.a), s(o.s), live(o.live) { o.live = false; }
+    ~HostColumn() { if (live) { if (a.release) a.release(&a); if (s.release) s.release(&s); } } };
+  struct SpillPiece { std::vector<HostColumn> cols; int64_t rows = 0; };
+  struct SpillRun { std::vector<SpillPiece> pieces; };
+  struct SpillState { std::vector<SpillRun> runs; std::vector<ArrayRef> splitters; int64_t limit = 0, ranges = 16, spilled_rows = 0, spilled_bytes = 0; };
+  int64_t state_bytes(const AggState& S) const { int64_t b = S.groups.g ? dfgpu_groups_size(S.groups.g) : 0; for (auto& a : S.accs) if (a.a) b += dfgpu_acc_size(a.a); return b; }
+  void new_accs(AggState& S) const {
+    S.accs = std::vector<AccRef>(aggs.size());
+    for (size_t i = 0; i < aggs.size(); i++) { if (special(i)) continue; int32_t t = aggs[i].kind == DFGPU_AGG_COUNT ? DFGPU_INT64 : aggs[i].type; S.tc.check(dfgpu_acc_new(S.tc.ctx, aggs[i].kind, t, aggs[i].precision, aggs[i].scale, &S.accs[i].a)); }
+  }
+  void reset_state(AggState& S) const {            // clear_shrink (row_hash.rs:707-711)
+    if (S.groups.g) { dfgpu_groups_free(S.groups.g); S.groups.g = nullptr; } S.tc.check(dfgpu_groups_new(S.tc.ctx, (int32_t)gexprs.size(), &S.groups.g));
+    new_accs(S);
+  }
+  // the state as one batch ordered by the group keys ascending, NULLs first (spill_expr, row_hash.rs:338-345; sort_batch :688), every column materialised
+  bool sorted_state(AggState& S, std::vector<ArrayRef>* cols) const {
+    Batch b; if (!emit_all(S, true, &b)) return false;
+    std::vector<const dfgpu_array*> kp; for (size_t i = 0; i < gexprs.size(); i++) kp.push_back(b.cols[i].arr.a);
+    std::vector<uint8_t> desc(kp.size(), 0), nf(kp.size(), 1);
+    dfgpu_array* idx = nullptr; S.tc.check(dfgpu_sort_to_indices(S.tc.ctx, kp.data(), desc.data(), nf.data(), (int32_t)kp.size(), -1, &idx)); ArrayRef ix = ArrayRef::adopt(idx);
+    cols->clear(); for (auto& c : b.cols) cols->push_back(take(S.tc, c.arr, ix));
+    return true;
+  }
+  // boundaries[r] = first row of range r in a key-sorted state batch (ranges + 1 entries).  Splitter keys and rows are concatenated (splitters first) and ordered by the
+  // stable sort: a splitter lands in front of the rows equal to it, so position of splitter j in the order minus j = rows strictly below it.
+  std::vector<int64_t> range_bounds(AggState& S, SpillState& P, const std::vector<ArrayRef>& cols) const {
+    const TaskContext& tc = S.tc; const int64_t rows = cols[0].len(), K = P.ranges; const size_t nk = gexprs.size();
+    if (P.splitters.empty()) {                   // first spill: K - 1 of its rows at equal distances
+      std::vector<uint32_t> at; for (int64_t j = 1; j < K; j++) at.push_back((uint32_t)(rows * j / K));
+      dfgpu_array_desc d{}; d.type = DFGPU_UINT32; d.length = (int64_t)at.size(); d.values = at.data(); dfgpu_array* ia = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &d, &ia)); ArrayRef ix = ArrayRef::adopt(ia);
+      for (size_t k = 0; k < nk; k++) P.splitters.push_back(take(tc, cols[k], ix));
+    }
+    const int64_t ns = P.splitters[0].len();
+    std::vector<ArrayRef> both; std::vector<const dfgpu_array*> bp;
+    for (size_t k = 0; k < nk; k++) { const dfgpu_array* two[2] = { P.splitters[k].a, cols[k].a }; dfgpu_array* c = nullptr; tc.check(dfgpu_concat(tc.ctx, two, 2, &c)); both.push_back(ArrayRef::adopt(c)); bp.push_back(both.back().a); }
+    std::vector<uint8_t> desc(nk, 0), nf(nk, 1);
+    dfgpu_array* idx = nullptr; tc.check(dfgpu_sort_to_indices(tc.ctx, bp.data(), desc.data(), nf.data(), (int32_t)nk, -1, &idx)); ArrayRef order = ArrayRef::adopt(idx);
+    uint32_t nsv = (uint32_t)ns; dfgpu_array_desc ld{}; ld.type = DFGPU_UINT32; ld.length = 1; ld.values = &nsv; dfgpu_array* la = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &ld, &la)); ArrayRef lit = ArrayRef::adopt(la);
+    dfgpu_array* m = nullptr; tc.check(dfgpu_binary(tc.ctx, DFGPU_OP_LT, order.a, 0, lit.a, 1, &m)); ArrayRef is_split = ArrayRef::adopt(m);
+    ArrayRef pos = mask_indices(tc, is_split);
+    if (pos.len() != ns) fail(DFGPU_INTERNAL, "AggregateExec spill: %lld splitter positions for %lld splitters", (long long)pos.len(), (long long)ns);
+    std::vector<uint32_t> hp((size_t)ns); tc.check(dfgpu_array_export_host(tc.ctx, pos.a, hp.data(), nullptr, nullptr));
+    std::vector<int64_t> bounds; bounds.push_back(0);
+    for (int64_t j = 0; j < ns; j++) bounds.push_back((int64_t)hp[(size_t)j] - j);      // splitters keep their own order (they are sorted and the sort is stable)
+    bounds.push_back(rows);
+    return bounds;
+  }
+  void spill(AggState& S, SpillState& P) const {           // spill (row_hash.rs:685-705)
+    std::vector<ArrayRef> cols; if (!sorted_state(S, &cols)) return;
+    std::vector<int64_t> bounds = range_bounds(S, P, cols);
+    SpillRun run; run.pieces.resize(bounds.size() - 1);
+    for (size_t r = 0; r + 1 < bounds.size(); r++) {
+      const int64_t lo = bounds[r], len = bounds[r + 1] - bounds[r]; run.pieces[r].rows = len; if (len <= 0) continue;
+      for (auto& c : cols) { dfgpu_array* sl = nullptr; S.tc.check(dfgpu_array_slice(S.tc.ctx, c.a, lo, len, &sl)); ArrayRef piece = ArrayRef::adopt(sl);
+        run.pieces[r].cols.emplace_back(); HostColumn& h = run.pieces[r].cols.back(); S.tc.check(dfgpu_array_export_arrow(S.tc.ctx, piece.a, &h.a, &h.s)); h.live = true; }
+    }
+    P.spilled_rows += cols[0].len(); P.runs.push_back(std::move(run));
+    cols.clear(); reset_state(S);
+  }
+  // update_merged_stream + the re-aggregation of the merged stream (row_hash.rs:736-771, :545-600 with is_stream_merging): range by range
+  void merge_spills(AggState& S, SpillState& P) const {
+    const TaskContext& tc = S.tc; const size_t nk = gexprs.size();
+    std::vector<ArrayRef> rest; std::vector<int64_t> rb;
+    if (dfgpu_groups_len(S.groups.g) > 0 && sorted_state(S, &rest)) rb = range_bounds(S, P, rest);
+    reset_state(S);
+    const size_t R = P.runs[0].pieces.size();
+    for (size_t r = 0; r < R; r++) {
+      auto merge_in = [&](const std::vector<ArrayRef>& cols) {
+        std::vector<const dfgpu_array*> kp; for (size_t k = 0; k < nk; k++) kp.push_back(cols[k].a);
+        dfgpu_array* ids = nullptr; tc.check(dfgpu_groups_intern(tc.ctx, S.groups.g, kp.data(), (int32_t)nk, nullptr, &ids)); ArrayRef gids = ArrayRef::adopt(ids);
+        const int64_t total = dfgpu_groups_len(S.groups.g); size_t col = nk;
+        for (size_t i = 0; i < aggs.size(); i++) { const int nst = aggs[i].kind == DFGPU_AGG_AVG ? 2 : 1; const dfgpu_array* st[2]; for (int k = 0; k < nst; k++) st[k] = cols[col + (size_t)k].a; col += (size_t)nst;
+          tc.check(dfgpu_acc_merge_batch(tc.ctx, S.accs[i].a, st, nst, gids.a, nullptr, total)); }
+      };
+      for (auto& run : P.runs) { SpillPiece& pc = run.pieces[r]; if (pc.rows <= 0) continue;
+        std::vector<ArrayRef> cols; for (auto& h : pc.cols) { dfgpu_array* a = nullptr; tc.check(dfgpu_array_import_arrow(tc.ctx, &h.a, &h.s, &a)); cols.push_back(ArrayRef::adopt(a)); }
+        merge_in(cols); pc.cols.clear(); }
+      if (!rest.empty() && rb[r + 1] > rb[r]) { std::vector<ArrayRef> cols; for (auto& c : rest) { dfgpu_array* sl = nullptr; tc.check(dfgpu_array_slice(tc.ctx, c.a, rb[r], rb[r + 1] - rb[r], &sl)); cols.push_back(ArrayRef::adopt(sl)); } merge_in(cols); }
+      Batch o; if (!emit_all(S, mode == 0, &o)) { reset_state(S); continue; }
+      std::vector<const dfgpu_array*> kp; for (size_t k = 0; k < nk; k++) kp.push_back(o.cols[k].arr.a);
+      std::vector<uint8_t> desc(nk, 0), nf(nk, 1);
+      dfgpu_array* idx = nullptr; tc.check(dfgpu_sort_to_indices(tc.ctx, kp.data(), desc.data(), nf.data(), (int32_t)nk, -1, &idx)); ArrayRef ix = ArrayRef::adopt(idx);
+      for (auto& c : o.cols) c = col_of(take(tc, c.arr, ix));
+      S.ready.push_back(std::move(o)); reset_state(S);
+    }
+    P.runs.clear();
+  }
+  void finish(AggState& S) const {           // set_input_done_and_produce_output (row_hash.rs:775-790)
+    if (S.spill && !S.spill->runs.empty()) { merge_spills(S, *S.spill); return; }
+    Batch o; if (emit_all(S, mode == 0, &o)) S.ready.push_back(std::move(o));
   }
   // emit(EmitTo::First(n)) (row_hash.rs:626-662 with groups_accumulator.rs:25-57): the first n groups leave as one batch, the rest are renumbered from 0
   void emit_first(AggState& S, int64_t n) const {
@@ -1418,6 +1524,12 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
     const int64_t n = order_mode == 2 ? total - 1 : S.current_sort;
     if (n > 0) emit_first(S, n);
   }
+  // emit_early_if_necessary (row_hash.rs:720-733): Partial mode over the memory target hands whole batch_size multiples of its groups on and forgets them
+  void emit_early(AggState& S) const {
+    if (!S.spill || mode != 0 || order_mode != 0 || S.pending) return;
+    const int64_t len = dfgpu_groups_len(S.groups.g), bs = S.tc.batch_size > 0 ? S.tc.batch_size : 8192;
+    if (len >= bs && state_bytes(S) > S.spill->limit) emit_first(S, len / bs * bs);
+  }
   bool pull(AggState& S, Batch& b) const {
     for (;;) {
       if (!S.cur) { if (S.next_part >= S.parts.size()) return false; S.cur = S.src->run(S.parts[S.next_part++], S.tc); }
@@ -1437,6 +1549,7 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
         if (!op->pull(S, b)) { S.input_done = true; op->finish(S); continue; }      // set_input_done_and_produce_output
         op->consume(S, b);
         op->emit_ordered(S);
+        op->emit_early(S);
       }
     }
   };

@@ -108,6 +108,8 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
  * "sort_packed_keys" (1/0) == let sort_to_indices sort large inputs over fixed-width keys through range-packed 64-bit keys (identical indices);
  * "memory_limit" (bytes, 0 = none) == live device memory this ctx may hold; an allocation beyond it fails with DFGPU_RESOURCES_EXHAUSTED and the
  * message of MemoryPool::try_grow (≙ RuntimeConfig::with_memory_limit, execution/src/runtime_env.rs); "live_bytes" / "cached_bytes" (read only);
+ * "agg_spill_state_bytes" (0 = never) == the state size (group table + accumulators) above which AggregateExec spills to host memory (non-Partial modes,
+ * row_hash.rs:667-705) or emits early (Partial, :720-733) -- the reservation a MemoryPool would grant the operator; "agg_spill_ranges" (16) == key ranges a spill is cut into;
  * "collect_metrics" (1/0) == the plan layer records per-operator metrics (dfgpu_plan_metrics);
  * "defer_flag_checks" (1 = enter / 0 = leave a deferred region, nests) == kernel error flags (overflow, divide by zero,
  * cast range, index bounds -- the ArrowError cases of arrow-arith / arrow-cast / arrow-select) are normally checked by the

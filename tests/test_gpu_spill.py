@@ -1,0 +1,99 @@
+"""-m gpu: AggregateExec under a state budget (option agg_spill_state_bytes ≙ the MemoryPool reservation of row_hash.rs:664-771).  Reference behaviour restated:
+non-Partial modes spill the key-sorted state and, at the end of input, re-aggregate the merge of the spills and the remaining state, which leaves the groups in KEY
+order (update_merged_stream switches to GroupOrdering::Full); Partial mode instead emits whole batch_size multiples of its groups early (emit_early_if_necessary).
+Like the reference's own spill tests (aggregates/mod.rs:1803, :1888: assert_batches_sorted_eq) results are compared as sets against pyarrow's group_by; the key order of
+the spilled output and the early batches' sizes are checked on top."""
+import numpy as np
+import pyarrow as pa
+import pyarrow.compute as pc
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _table(n, seed, card):
+    rng = np.random.default_rng(seed)
+    return pa.table({"k": pa.array(rng.integers(0, card, n), mask=rng.random(n) < 0.01), "s": pa.array(np.array(["a", "bb", "", "ccc"], dtype=object)[rng.integers(0, 4, n)], pa.utf8()),
+                     "v": pa.array(rng.integers(-100, 100, n)), "w": pa.array(rng.random(n), mask=rng.random(n) < 0.05)})
+
+
+def _plan(ops, capi, ctx, batches, mode, keys, names, src=None):
+    C, F = ops.Column, ops.Field
+    scan = src if src is not None else ops.MemoryExec([[ops.batch_from_arrow(ctx, b) for b in batches]], ops.batch_from_arrow(ctx, batches[0]).schema)
+    aggs = [ops.AggregateFunctionExpr("SUM", C("v", names.index("v")), "sv", input_field=F("v", capi.INT64)), ops.AggregateFunctionExpr("AVG", C("w", names.index("w")), "aw", input_field=F("w", capi.FLOAT64)),
+            ops.AggregateFunctionExpr("COUNT", None, "c"), ops.AggregateFunctionExpr("MIN", C("v", names.index("v")), "mn", input_field=F("v", capi.INT64))]
+    return ops.AggregateExec(mode, [(C(k, names.index(k)), k) for k in keys], aggs, scan)
+
+
+def _check(out: pa.Table, t: pa.Table, keys):
+    ref = t.group_by(keys, use_threads=False).aggregate([("v", "sum"), ("w", "mean"), ([], "count_all"), ("v", "min")])
+    order = [(k, "ascending") for k in keys]
+    a, b = out.sort_by(order), ref.sort_by(order)
+    assert a.num_rows == b.num_rows
+    for k in keys:
+        assert a[k].combine_chunks().equals(b[k].combine_chunks()), k
+    assert a["sv"].combine_chunks().equals(b["v_sum"].combine_chunks()) and a["c"].combine_chunks().equals(b["count_all"].combine_chunks()) and a["mn"].combine_chunks().equals(b["v_min"].combine_chunks())
+    x, y = a["aw"].combine_chunks(), b["w_mean"].combine_chunks()
+    assert x.is_valid().equals(y.is_valid()) and np.allclose(x.fill_null(0).to_numpy(zero_copy_only=False), y.fill_null(0).to_numpy(zero_copy_only=False), rtol=1e-9)
+
+
+@pytest.mark.parametrize("keys", [["k"], ["s", "k"]])
+@pytest.mark.parametrize("ranges", [1, 5, 16])
+def test_single_mode_spills_and_merges_in_key_order(ctx, keys, ranges):
+    from dfgpu import capi, physical_plan as ops
+    t = _table(120_000, 3, 30_000)
+    batches = [t.slice(o, 8000) for o in range(0, t.num_rows, 8000)]
+    base = ctx.get_option("live_bytes")
+    ctx.set_option("agg_spill_state_bytes", 256 << 10); ctx.set_option("agg_spill_ranges", ranges)
+    try:
+        out = [b.to_arrow() for b in _plan(ops, capi, ctx, batches, "Single", keys, t.column_names).execute(0, ops.TaskContext(ctx, 8192))]
+    finally:
+        ctx.set_option("agg_spill_state_bytes", 0); ctx.set_option("agg_spill_ranges", 16)
+    whole = pa.concat_tables(out)
+    _check(whole, t, keys)
+    # the merged stream is key-ordered (NULLs first): a first-seen-order output of random keys would not be
+    assert whole.equals(whole.sort_by([(k, "ascending") for k in keys], null_placement="at_start")  # noqa)
+    assert len(out) >= min(ranges, 2)
+    del out, whole
+    assert ctx.get_option("live_bytes") <= base + (1 << 20)
+
+
+def test_final_mode_spills_partial_states(ctx):
+    """Partial (no budget) -> Final under a budget: the Final stage spills the states it merged so far, AVG's (count, sum) pair included."""
+    from dfgpu import capi, physical_plan as ops
+    t = _table(100_000, 9, 20_000)
+    batches = [t.slice(o, 5000) for o in range(0, t.num_rows, 5000)]
+    names = t.column_names
+    # one Partial per input batch (each its own partition), merged by Final
+    parts = ops.MemoryExec([[ops.batch_from_arrow(ctx, b)] for b in batches], ops.batch_from_arrow(ctx, batches[0]).schema)
+    partial = _plan(ops, capi, ctx, None, "Partial", ["k"], names, src=parts)
+    C, F = ops.Column, ops.Field
+    final = ops.AggregateExec("Final", [(C("k", 0), "k")], [ops.AggregateFunctionExpr("SUM", C("v", 2), "sv", input_field=F("v", capi.INT64)), ops.AggregateFunctionExpr("AVG", C("w", 3), "aw", input_field=F("w", capi.FLOAT64)),
+                                                           ops.AggregateFunctionExpr("COUNT", None, "c"), ops.AggregateFunctionExpr("MIN", C("v", 2), "mn", input_field=F("v", capi.INT64))], partial)
+    ctx.set_option("agg_spill_state_bytes", 128 << 10)
+    try:
+        out = pa.concat_tables([b.to_arrow() for b in final.execute(0, ops.TaskContext(ctx, 8192))])
+    finally:
+        ctx.set_option("agg_spill_state_bytes", 0)
+    _check(out, t, ["k"])
+    assert out.equals(out.sort_by([("k", "ascending")], null_placement="at_start")  # noqa)
+
+
+def test_partial_mode_emits_early_in_batch_size_multiples(ctx):
+    from dfgpu import capi, physical_plan as ops
+    t = _table(100_000, 11, 50_000)
+    batches = [t.slice(o, 10_000) for o in range(0, t.num_rows, 10_000)]
+    names = t.column_names
+    partial = _plan(ops, capi, ctx, batches, "Partial", ["k"], names)
+    ctx.set_option("agg_spill_state_bytes", 64 << 10)
+    try:
+        early = [b.to_arrow() for b in partial.execute(0, ops.TaskContext(ctx, 1024))]
+    finally:
+        ctx.set_option("agg_spill_state_bytes", 0)
+    assert len(early) > 2 and all(b.num_rows % 1024 == 0 for b in early[:-1])
+    # the early batches are partial states: a Final stage over them gives the answer
+    C, F = ops.Column, ops.Field
+    states = ops.MemoryExec([[ops.batch_from_arrow(ctx, b) for b in early]], ops.batch_from_arrow(ctx, early[0]).schema)
+    final = ops.AggregateExec("Final", [(C("k", 0), "k")], [ops.AggregateFunctionExpr("SUM", C("v", 2), "sv", input_field=F("v", capi.INT64)), ops.AggregateFunctionExpr("AVG", C("w", 3), "aw", input_field=F("w", capi.FLOAT64)),
+                                                           ops.AggregateFunctionExpr("COUNT", None, "c"), ops.AggregateFunctionExpr("MIN", C("v", 2), "mn", input_field=F("v", capi.INT64))], states)
+    _check(pa.concat_tables([b.to_arrow() for b in final.execute(0, ops.TaskContext(ctx, 8192))]), t, ["k"])
