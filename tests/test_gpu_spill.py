@@ -52,7 +52,7 @@ def test_single_mode_spills_and_merges_in_key_order(ctx, keys, ranges):
     whole = pa.concat_tables(out)
     _check(whole, t, keys)
     # the merged stream is key-ordered (NULLs first): a first-seen-order output of random keys would not be
-    assert whole.equals(whole.sort_by([(k, "ascending") for k in keys], null_placement="at_start")  # noqa)
+    assert whole.equals(whole.sort_by([(k, "ascending") for k in keys], null_placement="at_start"))
     assert len(out) >= min(ranges, 2)
     del out, whole
     assert ctx.get_option("live_bytes") <= base + (1 << 20)
@@ -76,7 +76,7 @@ def test_final_mode_spills_partial_states(ctx):
     finally:
         ctx.set_option("agg_spill_state_bytes", 0)
     _check(out, t, ["k"])
-    assert out.equals(out.sort_by([("k", "ascending")], null_placement="at_start")  # noqa)
+    assert out.equals(out.sort_by([("k", "ascending")], null_placement="at_start"))
 
 
 def test_partial_mode_emits_early_in_batch_size_multiples(ctx):
