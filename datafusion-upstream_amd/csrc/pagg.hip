@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(PA_NT) k_pa_items(const uint32_t* pstart, uint
   if (threadIdx.x == 0) item_start[P] = carry_sh;
 }
 __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, const uint32_t* prow, PaPlan plan_arg, const uint32_t* pstart, const uint32_t* item_start, uint32_t P, int cbits, uint32_t slice,
-                                                      uint64_t* okey, uint32_t* ofirst, uint32_t* ocnt, unsigned long long* cursor /*[0] rows written, [2] tables flushed before their partition ended*/) {
+                                                      uint64_t* orec /* records of `rs` words: key, count, accumulator cells */, int rs, uint32_t* ofirst, unsigned long long* cursor /*[0] rows written, [2] tables flushed before their partition ended*/) {
   extern __shared__ unsigned long long pa_lds[];
   const uint32_t C = 1u << cbits, M = C - 1, C1 = C + 1;
   unsigned long long* keys = pa_lds; unsigned long long* acc = pa_lds + C1;
@@ -130,8 +130,8 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
     __syncthreads();
     uint32_t o = out_base + run;
     for (uint32_t j = 0; j < per; j++) { uint32_t s = s0 + j; if (s < C1 && cnt[s]) {
-      okey[o] = s == C ? PA_EMPTY : keys[s]; ofirst[o] = first[s]; ocnt[o] = cnt[s];
-      for (int a = 0; a < plan.n_acc; a++) plan.out[a][o] = acc[(size_t)a * C1 + s];
+      uint64_t* rec = orec + (size_t)o * (size_t)rs; rec[0] = s == C ? PA_EMPTY : keys[s]; rec[1] = cnt[s]; ofirst[o] = first[s];
+      for (int a = 0; a < plan.n_acc; a++) rec[2 + a] = acc[(size_t)a * C1 + s];
       o++; } }
     __syncthreads();
   };
@@ -244,16 +244,6 @@ __global__ void __launch_bounds__(BLOCK) k_pa_bounds_fill(const uint32_t* __rest
   starts[p] = q < Pt ? first[q] : m;
 }
 
-template <typename T> __global__ void __launch_bounds__(BLOCK) k_pa_gather_key(const uint64_t* src, const uint32_t* perm, int64_t m, T* out) {
-  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < m) out[i] = (T)src[perm[i]];
-}
-__global__ void __launch_bounds__(BLOCK) k_pa_gather_u64(const uint64_t* src, const uint32_t* perm, int64_t m, uint64_t* out) {
-  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < m) out[i] = src[perm[i]];
-}
-__global__ void __launch_bounds__(BLOCK) k_pa_gather_cnt(const uint32_t* src, const uint32_t* perm, int64_t m, uint64_t* out) {
-  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < m) out[i] = src[perm[i]];
-}
-
 // first-seen order without a sort: every partial row's first input row is a distinct row number, so its rank among them is the number of marked rows in front of it --
 // mark the rows in a bitmap over the input, prefix-count the words, read the rank back
 __global__ void __launch_bounds__(BLOCK) k_pa_mark(const uint32_t* __restrict__ first, int64_t m, unsigned long long* bits) {
@@ -266,6 +256,31 @@ __global__ void __launch_bounds__(BLOCK) k_pa_rank_perm(const uint32_t* __restri
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i >= m) return;
   const uint32_t f = first[i]; const uint32_t r = pref[f >> 6] + (uint32_t)__popcll(bits[f >> 6] & ((1ull << (f & 63)) - 1ull));
   perm[r] = (uint32_t)i;
+}
+
+// many partial rows: (first row << jb | partial row) words through LSD passes of the stable partition, 8 bytes moving per row and pass
+__global__ void __launch_bounds__(BLOCK) k_pa_order_words(const uint32_t* __restrict__ first, int64_t m, int jb, uint64_t* __restrict__ words) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < m) words[i] = ((uint64_t)first[i] << jb) | (uint64_t)i;
+}
+__global__ void __launch_bounds__(BLOCK) k_pa_perm_of_words(const uint64_t* __restrict__ words, int64_t m, int jb, uint32_t* __restrict__ perm) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < m) perm[i] = (uint32_t)(words[i] & ((1ull << jb) - 1ull));
+}
+// every output column of the partial rows in one pass over the permutation: a row's record (key, count, cells) is one or two 32-byte reads
+struct PaEmit { int32_t n; int32_t word[2 + 2 * PA_MAX_AGGS]; void* dst[2 + 2 * PA_MAX_AGGS]; int32_t narrow[2 + 2 * PA_MAX_AGGS]; };      // narrow: store the low 32 bits
+template <int RS>
+__global__ void __launch_bounds__(BLOCK) k_pa_emit(PaEmit e, const uint64_t* __restrict__ recs, const uint32_t* __restrict__ perm, int64_t m) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i >= m) return;
+  const uint32_t j = perm[i]; uint64_t v[RS];
+  const ulonglong2* r = (const ulonglong2*)(recs + (size_t)j * RS);
+#pragma unroll
+  for (int q = 0; q < RS / 2; q++) { const ulonglong2 t = r[q]; v[2 * q] = t.x; v[2 * q + 1] = t.y; }
+#pragma unroll
+  for (int c = 0; c < 2 + 2 * PA_MAX_AGGS; c++) if (c < e.n) {
+    uint64_t x = 0;
+#pragma unroll
+    for (int w = 0; w < RS; w++) if (e.word[c] == w) x = v[w];
+    if (e.narrow[c]) ((uint32_t*)e.dst[c])[i] = (uint32_t)x; else ((uint64_t*)e.dst[c])[i] = x;
+  }
 }
 
 static bool pa_key_type_ok(int32_t t) { return t == DFGPU_INT64 || t == DFGPU_UINT64 || t == DFGPU_INT32 || t == DFGPU_UINT32 || t == DFGPU_DATE32; }
@@ -373,8 +388,9 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
         KERNEL_CHECK(); }
     }
     // ---- aggregate every partition out of LDS
-    BufferPtr okey = alloc_buffer(ctx, (size_t)n * 8), ofirst = alloc_buffer(ctx, (size_t)n * 4), ocnt = alloc_buffer(ctx, (size_t)n * 4); std::vector<BufferPtr> oacc((size_t)plan.n_acc);
-    for (int c = 0; c < plan.n_acc; c++) { oacc[(size_t)c] = alloc_buffer(ctx, (size_t)n * 8); plan.out[c] = (uint64_t*)oacc[(size_t)c]->ptr; }
+    // a partial row leaves the table as ONE record (key, count, cells; 4 or 8 words): the emit gathers a row with one or two sector reads instead of one per column
+    const int rs = 2 + plan.n_acc <= 4 ? 4 : 8;
+    BufferPtr orec = alloc_buffer(ctx, (size_t)n * (size_t)rs * 8), ofirst = alloc_buffer(ctx, (size_t)n * 4);
     HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 12, 0, 24, ctx->stream));
     hipLaunchKernelGGL(k_pa_max_len, dim3((unsigned)((P + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)r.starts->ptr, (uint32_t)P, (unsigned long long*)(ctx->d_scratch64 + 13));
     KERNEL_CHECK();
@@ -391,7 +407,7 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
         grid = (unsigned)(P + n / slice + 1);
       }
       hipLaunchKernelGGL(k_pa_aggregate, dim3(grid), dim3(PA_NT), (((size_t)1 << cbits) + 1) * cell_bytes, ctx->stream, (const uint64_t*)pkey->ptr, (const uint32_t*)prow->ptr, plan, (const uint32_t*)r.starts->ptr,
-                         items ? (const uint32_t*)items->ptr : nullptr, (uint32_t)P, cbits, (uint32_t)slice, (uint64_t*)okey->ptr, (uint32_t*)ofirst->ptr, (uint32_t*)ocnt->ptr, (unsigned long long*)(ctx->d_scratch64 + 12));
+                         items ? (const uint32_t*)items->ptr : nullptr, (uint32_t)P, cbits, (uint32_t)slice, (uint64_t*)orec->ptr, rs, (uint32_t*)ofirst->ptr, (unsigned long long*)(ctx->d_scratch64 + 12));
       KERNEL_CHECK(); }
     const int64_t m = (int64_t)read_scratch(ctx, 12);
     // every key left in exactly one partial row unless a hot partition was cut into slices or a table overflowed mid-partition: the plan layer then
@@ -409,6 +425,21 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
         exclusive_scan_u32_inplace32(ctx, (uint32_t*)pref->ptr, nw, nullptr);
         hipLaunchKernelGGL(k_pa_rank_perm, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)ofirst->ptr, m, (const uint64_t*)bits->ptr, (const uint32_t*)pref->ptr, (uint32_t*)perm->ptr);
         KERNEL_CHECK();
+      } else if (ctx->first_seen_group_order && m > (4 << 20)) {
+        int jb = 1; while (((uint64_t)(m - 1) >> jb) != 0) jb++;
+        int fb = 1; while (((uint64_t)(n - 1) >> fb) != 0) fb++;
+        BufferPtr w0 = alloc_buffer(ctx, (size_t)m * 8), w1 = alloc_buffer(ctx, (size_t)m * 8);
+        hipLaunchKernelGGL(k_pa_order_words, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)ofirst->ptr, m, jb, (uint64_t*)w0->ptr);
+        uint64_t* wa = (uint64_t*)w0->ptr; uint64_t* wb = (uint64_t*)w1->ptr;
+        const int npass = (fb + 7) / 8, dbits = (fb + npass - 1) / npass;
+        for (int shift = 0; shift < fb; shift += dbits) {
+          const int bits = fb - shift < dbits ? fb - shift : dbits;
+          RpCols rc{}; rc.n = 1; rc.c[0] = RpCol{ nullptr, wb, 8, RP_HASHKEY, 0 };
+          (void)rp_partition(ctx, RpHashDigit{ wa, shift + jb, (1u << bits) - 1u }, m, 1u << bits, rc, true, ctx->d_scratch64 + 9, "pa_order_hist", "pa_order_scan", "pa_order_scatter");
+          std::swap(wa, wb);
+        }
+        hipLaunchKernelGGL(k_pa_perm_of_words, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)wa, m, jb, (uint32_t*)perm->ptr);
+        KERNEL_CHECK();
       } else {
         launch_iota_u32(ctx, (uint32_t*)perm->ptr, m, 0);
         if (ctx->first_seen_group_order) radix_sort_pairs_u32(ctx, (uint32_t*)ofirst->ptr, (uint32_t*)perm->ptr, m, 32);
@@ -416,20 +447,17 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     KernelTimer kt_(ctx, "pa_emit");
     const uint32_t* pp = (const uint32_t*)perm->ptr; dim3 grid(grid_for(m, BLOCK));
     ArrayHolder ok(new_fixed(ctx, ktype, m));
-    if (m) {
-      switch (ktype) {
-        case DFGPU_INT64: case DFGPU_UINT64: hipLaunchKernelGGL((k_pa_gather_key<uint64_t>), grid, dim3(BLOCK), 0, ctx->stream, (const uint64_t*)okey->ptr, pp, m, (uint64_t*)ok.get()->values->ptr); break;
-        default: hipLaunchKernelGGL((k_pa_gather_key<uint32_t>), grid, dim3(BLOCK), 0, ctx->stream, (const uint64_t*)okey->ptr, pp, m, (uint32_t*)ok.get()->values->ptr); break;
-      }
-    }
+    PaEmit em{}; auto add = [&](int word, void* dst, int narrow) { em.word[em.n] = word; em.dst[em.n] = dst; em.narrow[em.n] = narrow; em.n++; };
+    add(0, ok.get()->values->ptr, (ktype == DFGPU_INT64 || ktype == DFGPU_UINT64) ? 0 : 1);
     std::vector<ArrayHolder> st((size_t)n_aggs * 2);
     for (int i = 0; i < n_aggs; i++) {
-      auto counts_as = [&](int32_t type) { dfgpu_array* a = new_fixed(ctx, type, m); if (m) hipLaunchKernelGGL(k_pa_gather_cnt, grid, dim3(BLOCK), 0, ctx->stream, (const uint32_t*)ocnt->ptr, pp, m, (uint64_t*)a->values->ptr); return a; };
-      auto cell_as = [&](int32_t type) { dfgpu_array* a = new_fixed(ctx, type, m); if (m) hipLaunchKernelGGL(k_pa_gather_u64, grid, dim3(BLOCK), 0, ctx->stream, (const uint64_t*)oacc[(size_t)cell_of[i]]->ptr, pp, m, (uint64_t*)a->values->ptr); return a; };
+      auto counts_as = [&](int32_t type) { dfgpu_array* a = new_fixed(ctx, type, m); add(1, a->values->ptr, 0); return a; };
+      auto cell_as = [&](int32_t type) { dfgpu_array* a = new_fixed(ctx, type, m); add(2 + cell_of[i], a->values->ptr, 0); return a; };
       if (kinds[i] == DFGPU_AGG_COUNT) st[(size_t)2 * i].a = counts_as(DFGPU_INT64);                                                       // count.rs: Int64 state
       else if (kinds[i] == DFGPU_AGG_AVG) { st[(size_t)2 * i].a = counts_as(DFGPU_UINT64); st[(size_t)2 * i + 1].a = cell_as(DFGPU_FLOAT64); }   // average.rs:392-430: (counts, sums)
       else st[(size_t)2 * i].a = cell_as(values[i]->type);          // SUM / MIN / MAX of an 8-byte type: state type == input type (sum.rs:75-86, min_max.rs:102-139)
     }
+    if (m) { if (rs == 4) hipLaunchKernelGGL(k_pa_emit<4>, grid, dim3(BLOCK), 0, ctx->stream, em, (const uint64_t*)orec->ptr, pp, m); else hipLaunchKernelGGL(k_pa_emit<8>, grid, dim3(BLOCK), 0, ctx->stream, em, (const uint64_t*)orec->ptr, pp, m); }
     KERNEL_CHECK();
     if (key->type == DFGPU_DICTIONARY) {           // DictionaryArray::try_new(codes, the input's dictionary)
       dfgpu_array* d = nullptr; dfgpu_status st2 = dfgpu_array_make_dictionary(ctx, ok.get(), key->dictionary, &d);

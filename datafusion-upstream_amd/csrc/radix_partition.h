@@ -53,6 +53,11 @@ struct RpHashKeySet {     // create_hashes % P (repartition/mod.rs:185) over any
   }
 };
 
+struct RpHashDigit {      // partition = one digit of a 64-bit word (the LSD passes of sort.hip and of the first-seen ordering in pagg.hip)
+  const uint64_t* keys; int shift; uint32_t mask;
+  __device__ inline bool operator()(int64_t i, uint32_t, uint32_t* pid, uint64_t* key) const { *key = keys[i]; *pid = (uint32_t)(*key >> shift) & mask; return true; }
+};
+
 // columns moved by the scatter
 enum { RP_RAW = 0, RP_KEY64 = 2, RP_HASHKEY = 3 };
 struct RpCol { const void* src; void* dst; int32_t width; int32_t kind; int32_t type; };   // RAW: width bytes per row (1, 2, 4, 8, 16); KEY64: src integer column of `type`, dst u64; HASHKEY: dst u64 = the 64-bit key the hasher produced for the row
@@ -287,10 +292,10 @@ static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const 
   RpResult r; r.P = P;
   r.starts = alloc_buffer(ctx, (size_t)(P + 1) * 4);
   const bool big = P > 512 && P <= 2048 && !stable;        // 8192-row tiles halve the count matrix; 4096-row tiles give more workgroups per CU (and leave LDS for P > 2048)
-  const int G = P <= 2048 ? RP_G : 4;
   const bool small_wg = stable && P > 16;                  // stable with many partitions: 256-thread workgroups (the count table is 64 P bytes) keep several on a CU;
   const int nt = small_wg ? 256 : big ? 1024 : 512, tile = nt * RP_R;      // few partitions want the longer runs of a 4096-row tile
   const int64_t ntiles = n ? (n + tile - 1) / tile : 1; r.ntiles = ntiles;
+  int G = P <= 2048 ? RP_G : 4; while (G > 1 && (ntiles + G - 1) / G < 1024) G >>= 1;      // a small input still wants ~1000 histogram workgroups (a few dozen of them counting 16 tiles each was 0.04 ms per sort pass of 1 M rows)
   BufferPtr counts = alloc_buffer(ctx, (size_t)P * ntiles * 4);
   const size_t hl = (size_t)P * G * 4;
   const int64_t nh = (ntiles + G - 1) / G;

@@ -319,10 +319,6 @@ __global__ void __launch_bounds__(BLOCK) k_pk_encode(PkCols pc, int64_t n, uint6
   }
   if (ib) keys[i] = (key << ib) | (uint64_t)i; else { keys[i] = key; idx[i] = (uint32_t)i; }
 }
-struct RpHashDigit {      // partition = one 8-bit digit of the packed key
-  const uint64_t* keys; int shift; uint32_t mask;
-  __device__ inline bool operator()(int64_t i, uint32_t, uint32_t* pid, uint64_t* key) const { *key = keys[i]; *pid = (uint32_t)(*key >> shift) & mask; return true; }
-};
 // word mode, after the last pass: row numbers out of the low bits; every key column that asked for it (sorted_dst) is rebuilt from its bits of the sorted word --
 // offset -> order pattern (minimum + distance, 128-bit) -> value -- with sequential reads and writes instead of a gather through the permutation
 __global__ void __launch_bounds__(BLOCK) k_pk_finish(PkCols pc, const uint64_t* __restrict__ words, int64_t m, int ib, uint32_t* __restrict__ idx) {
