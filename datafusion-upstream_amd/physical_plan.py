@@ -537,6 +537,36 @@ class JoinFilter:
     schema: Schema
 
 
+def collect_columns(expr) -> set:
+    """≙ physical_expr::utils::collect_columns: every Column (name, index) an expression refers to."""
+    out, stack = set(), [expr]
+    while stack:
+        e = stack.pop()
+        if isinstance(e, Column):
+            out.add((e.name, e.index))
+        elif isinstance(e, PhysicalExpr):
+            stack.extend(v for v in e.__dict__.values() if isinstance(v, PhysicalExpr))
+            stack.extend(x for v in e.__dict__.values() if isinstance(v, (list, tuple)) for x in v if isinstance(x, PhysicalExpr))
+    return out
+
+
+def check_join_is_valid(left: Schema, right: Schema, on) -> None:
+    """≙ joins/utils.rs:387-430 (check_join_is_valid / check_join_set_is_valid): every column of the `on` pairs must be a (name, index) of its side's schema."""
+    lcols = {(f.name, i) for i, f in enumerate(left.fields)}
+    rcols = {(f.name, i) for i, f in enumerate(right.fields)}
+    on_left = set().union(*[collect_columns(l) for l, _ in on]) if on else set()
+    on_right = set().union(*[collect_columns(r) for _, r in on]) if on else set()
+    lm, rm = on_left - lcols, on_right - rcols
+    if lm or rm:
+        fmt = lambda m: "{" + ", ".join(f'Column {{ name: "{n}", index: {i} }}' for n, i in sorted(m)) + "}"
+        raise DfgpuError(1, f'Error during planning: The left or right side of the join does not have all columns on "on": \nMissing on the left: {fmt(lm)}\nMissing on the right: {fmt(rm)}')
+
+
+def _known_schema(plan):
+    """The schema of a child when it is known without building the plan (leaf scans); None otherwise."""
+    return plan.schema() if isinstance(plan, (MemoryExec, ParquetExec, CsvExec)) and (not isinstance(plan, MemoryExec) or plan._schema is not None) else None
+
+
 class HashJoinExec(ExecutionPlan):
     def __init__(self, left, right, on: List[Tuple[PhysicalExpr, PhysicalExpr]], filter: Optional[JoinFilter], join_type: str,
                  partition_mode: str = "CollectLeft", null_equals_null: bool = False):
@@ -544,6 +574,9 @@ class HashJoinExec(ExecutionPlan):
             raise DfgpuError(1, "Plan error: On constraints in HashJoinExec should be non-empty")     # hash_join.rs:303-305
         if join_type not in JOIN_TYPES:
             raise DfgpuError(5, f"unknown join type {join_type}")
+        ls, rs = _known_schema(left), _known_schema(right)
+        if ls is not None and rs is not None:
+            check_join_is_valid(ls, rs, on)                       # hash_join.rs:312 (try_new)
         self.left, self.right, self.on, self.filter = left, right, on, filter
         self.join_type, self.mode, self.null_equals_null = join_type, partition_mode, null_equals_null
 
