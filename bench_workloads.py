@@ -370,7 +370,7 @@ def run(args, ctx=None, emit=True):
                           "l_discount": dec(0, 11), "l_shipdate": pa.array(rng.integers(8035, 10560, nr).astype(np.int32), type=pa.date32()),
                           "l_returnflag": pick(["A", "N", "R"]), "l_linestatus": pick(["F", "O"]), "l_shipmode": pick(["AIR", "FOB", "MAIL", "RAIL", "REG AIR", "SHIP", "TRUCK"])})
         decoded = nr * (8 + 3 * 16 + 4 + 3 * 4)
-        for label, kw in (("snappy_dict", dict(compression="snappy", use_dictionary=True)), ("plain", dict(compression="none", use_dictionary=False))):
+        for label, kw in (("snappy_dict", dict(compression="snappy", use_dictionary=True)), ("zstd_dict", dict(compression="zstd", use_dictionary=True)), ("plain", dict(compression="none", use_dictionary=False))):
             name = "parquet_scan_" + label
             if want and not any(w in name for w in want):
                 continue

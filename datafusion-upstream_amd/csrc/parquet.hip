@@ -21,6 +21,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include "device_utils.h"
+#include "zstd_device.h"
 
 namespace dfgpu {
 namespace pq {
@@ -53,7 +54,7 @@ struct TR {
 
 enum { PT_BOOLEAN = 0, PT_INT32 = 1, PT_INT64 = 2, PT_INT96 = 3, PT_FLOAT = 4, PT_DOUBLE = 5, PT_BYTE_ARRAY = 6, PT_FLBA = 7 };
 enum { ENC_PLAIN = 0, ENC_PLAIN_DICT = 2, ENC_RLE = 3, ENC_BIT_PACKED = 4, ENC_RLE_DICT = 8 };
-enum { CODEC_NONE = 0, CODEC_SNAPPY = 1 };
+enum { CODEC_NONE = 0, CODEC_SNAPPY = 1, CODEC_ZSTD = 6 };
 enum { PG_DATA = 0, PG_INDEX = 1, PG_DICT = 2, PG_DATA_V2 = 3 };
 
 struct Leaf {
@@ -468,7 +469,7 @@ __global__ void __launch_bounds__(BLOCK) k_pq_bytes_to_bits(const uint8_t* in, i
 // the standard 64 KB-block compressor resolves there) and is flushed to HBM in 16-byte stores.  One wave per workgroup: LDS operations of a wave
 // execute in order, no barrier is needed between an element's write and the next element's read.
 constexpr int SN_RING = 32768, SN_WIN = 8192, SN_FLUSH = 8192;        // ring + window = 40 KB: four waves per CU; references further back than the ring are read from HBM
-struct SnJob { const uint8_t* src; uint8_t* dst; uint32_t csize, usize; int32_t raw; int32_t pad; };
+struct SnJob { const uint8_t* src; uint8_t* dst; uint32_t csize, usize; int32_t raw; int32_t codec; };
 
 __device__ inline void sn_order() { __builtin_amdgcn_wave_barrier(); }          // LDS operations of one wave execute in issue order: only the compiler must not move them across
 __device__ inline uint64_t sn_peek(const uint32_t* win, uint32_t rel) { uint32_t a = rel >> 2, sh = (rel & 3) * 8; return ((uint64_t)win[a] | ((uint64_t)win[a + 1] << 32)) >> sh; }   // >= 5 bytes at win + rel
@@ -757,6 +758,16 @@ struct ColumnRead {
   int leaf_idx = 0; int64_t total_rows = 0; std::vector<PqPage> pages, dict_str_pages; std::vector<BufferPtr> keep;
   bool any_levels = false, all_dict = true; int32_t dict_total = 0; int wp = 0;
 };
+// Zstandard pages: one wave per page (zstd_device.h); lit = 128 KB + 64 of literal scratch per job
+constexpr size_t ZS_LIT = 128 * 1024 + 64;
+__global__ void __launch_bounds__(64) k_pq_zstd(const SnJob* __restrict__ jobs, uint8_t* lit, uint32_t* flags) {
+  __shared__ zs::Lds L; __shared__ __attribute__((aligned(16))) uint8_t ring[zs::ZS_RING]; __shared__ __attribute__((aligned(16))) uint8_t litl[zs::ZS_LIT_LDS];
+  const SnJob jb = jobs[blockIdx.x]; const uint32_t lane = threadIdx.x;
+  if (jb.raw) { for (uint32_t i = lane; i < jb.usize; i += 64) jb.dst[i] = jb.src[i]; return; }
+  const bool ok = zs::decode_frame(&L, ring, litl, jb.src, jb.csize, jb.dst, jb.usize, lit + (size_t)blockIdx.x * ZS_LIT, lane);
+  if (!ok && lane == 0) atomicOr(flags, DFGPU_FLAG_OOB);
+}
+
 static void plan_column(dfgpu_ctx* ctx, dfgpu_parquet* f, int leaf_idx, int rg0, int nrg, ColumnRead& cr, std::vector<SnJob>& jobs) {
   const Leaf& leaf = f->leaves[(size_t)leaf_idx];
   if (!leaf.arrow) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: Parquet column '%s': %s", leaf.name.c_str(), leaf.why.c_str());
@@ -770,7 +781,7 @@ static void plan_column(dfgpu_ctx* ctx, dfgpu_parquet* f, int leaf_idx, int rg0,
   int& wp = cr.wp; wp = leaf.phys == PT_INT32 || leaf.phys == PT_FLOAT ? 4 : leaf.phys == PT_INT64 || leaf.phys == PT_DOUBLE ? 8 : leaf.phys == PT_FLBA ? leaf.type_len : 0;
   for (int g = rg0; g < rg0 + nrg; g++) {
     const RowGroup& rg = f->rgs[(size_t)g]; const Chunk& ch = rg.cols[(size_t)leaf_idx];
-    if (ch.codec != CODEC_NONE && ch.codec != CODEC_SNAPPY) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: Parquet compression codec %d of column '%s' (UNCOMPRESSED and SNAPPY are decoded on the device)", ch.codec, leaf.name.c_str());
+    if (ch.codec != CODEC_NONE && ch.codec != CODEC_SNAPPY && ch.codec != CODEC_ZSTD) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: Parquet compression codec %d of column '%s' (UNCOMPRESSED, SNAPPY and ZSTD are decoded on the device)", ch.codec, leaf.name.c_str());
     if (ch.num_values != rg.rows) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: Parquet column '%s' holds %lld values for %lld rows (repeated values)", leaf.name.c_str(), (long long)ch.num_values, (long long)rg.rows);
     if (ch.num_values == 0) continue;                       // a row group without rows: nothing to walk
     int64_t start = ch.dict_off > 0 && ch.dict_off < ch.data_off ? ch.dict_off : ch.data_off;
@@ -790,17 +801,17 @@ static void plan_column(dfgpu_ctx* ctx, dfgpu_parquet* f, int leaf_idx, int rg0,
       pos = payload + h.csize;
     }
     uint8_t* ubase = nullptr;
-    if (ch.codec == CODEC_SNAPPY) { BufferPtr ub = alloc_buffer(ctx, (size_t)ubytes + 16); keep.push_back(ub); ubase = (uint8_t*)ub->ptr; }
+    if (ch.codec != CODEC_NONE) { BufferPtr ub = alloc_buffer(ctx, (size_t)ubytes + 16); keep.push_back(ub); ubase = (uint8_t*)ub->ptr; }
     const uint8_t* dict_data = nullptr; int32_t dict_count = 0, dict_base = dict_total;
     for (auto& p : ps) {
       const PageHdr& h = p.h; const uint8_t* src = dsrc + (p.payload - start); const uint8_t* data = src;
       int32_t lvl = h.type == PG_DATA_V2 ? h.def_len + h.rep_len : 0;
       if (h.type == PG_DATA_V2 && (h.rep_len != 0 || lvl > h.csize || lvl > h.usize)) fail(DFGPU_EXECUTION, "Parquet error: level bytes of a v2 page of '%s'", leaf.name.c_str());
-      if (ch.codec == CODEC_SNAPPY) {
+      if (ch.codec != CODEC_NONE) {
         bool comp = h.type != PG_DATA_V2 || h.v2_compressed;
         if (comp) {
-          if (lvl) jobs.push_back({src, ubase, (uint32_t)lvl, (uint32_t)lvl, 1, 0});
-          if (h.usize - lvl > 0) jobs.push_back({src + lvl, ubase + lvl, (uint32_t)(h.csize - lvl), (uint32_t)(h.usize - lvl), 0, 0});
+          if (lvl) jobs.push_back({src, ubase, (uint32_t)lvl, (uint32_t)lvl, 1, ch.codec});
+          if (h.usize - lvl > 0) jobs.push_back({src + lvl, ubase + lvl, (uint32_t)(h.csize - lvl), (uint32_t)(h.usize - lvl), 0, ch.codec});
           data = ubase; ubase += ((int64_t)h.usize + 31) & ~15ll;
         }
       } else if (h.csize != h.usize) fail(DFGPU_EXECUTION, "Parquet error: uncompressed page of '%s' with different sizes", leaf.name.c_str());
@@ -967,6 +978,15 @@ dfgpu_status dfgpu_parquet_read(dfgpu_ctx* ctx, dfgpu_parquet* f, int32_t first_
     for (int32_t i = 0; i < ncols; i++) {
       if (columns[i] < 0 || (size_t)columns[i] >= f->leaves.size()) fail(DFGPU_INVALID_ARGUMENT, "parquet_read: column %d of %zu", columns[i], f->leaves.size());
       plan_column(ctx, f, columns[i], first_row_group, num_row_groups, reads[(size_t)i], jobs);
+    }
+    std::vector<SnJob> zjobs; { std::vector<SnJob> sj; for (auto& j : jobs) (j.codec == CODEC_ZSTD ? zjobs : sj).push_back(j); jobs.swap(sj); }
+    BufferPtr zlit;
+    if (!zjobs.empty()) {                         // Zstandard: a frame is sequential, the pages of the read are the parallelism -- one wave each
+      std::stable_sort(zjobs.begin(), zjobs.end(), [](const SnJob& x, const SnJob& y) { return x.usize > y.usize; });          // the longest pages start first
+      BufferPtr dz = upload(ctx, zjobs); zlit = alloc_buffer(ctx, zjobs.size() * ZS_LIT);
+      KernelTimer kt(ctx, "pq_zstd");
+      hipLaunchKernelGGL(k_pq_zstd, dim3((unsigned)zjobs.size()), dim3(64), 0, ctx->stream, (const SnJob*)dz->ptr, (uint8_t*)zlit->ptr, ctx->d_flags);
+      KERNEL_CHECK();
     }
     if (!jobs.empty()) {                          // every compressed page of the read in one launch: the pages are the parallelism
       BufferPtr dj = upload(ctx, jobs);

@@ -192,3 +192,64 @@ def test_snappy_element_patterns_across_blocks(ctx, tmp_path):
         f = ParquetFile(ctx, path=path, stage_on_device=staged, utf8_dictionary=False)
         for name, a in zip(f.column_names(), f.read()):
             same_column(a.to_arrow(), want[name], name)
+
+
+def _pattern_table(n, seed=17):
+    rng = np.random.default_rng(seed)
+    period = rng.integers(0, 1 << 62, 6250).astype(np.int64)             # 50 000 bytes
+    words = np.array(["alpha", "beta", "gamma", "delta-delta-delta", "", "x" * 70, "épsilon"])
+    return pa.table({
+        "constant": pa.array(np.full(n, 123456789012345, dtype=np.int64)),
+        "random": pa.array(rng.integers(-(1 << 62), 1 << 62, n).astype(np.int64)),
+        "sorted": pa.array(np.cumsum(rng.integers(0, 9, n)).astype(np.int64)),
+        "sawtooth": pa.array((np.arange(n) % 1000).astype(np.int32)),
+        "far_repeat": pa.array(np.tile(period, n // len(period) + 1)[:n]),
+        "zeros_then_noise": pa.array(np.where(np.arange(n) % 20000 < 15000, 0, rng.integers(0, 1 << 40, n)).astype(np.int64)),
+        "text": pa.array(words[rng.integers(0, len(words), n)]),
+        "runs_text": pa.array(["ab" * int(k) for k in rng.integers(0, 40, n)]),
+        "nullable": pa.array(rng.integers(0, 3, n).astype(np.int64), mask=rng.random(n) < 0.5),
+        "floats": pa.array(np.round(rng.normal(0, 100, n), 2)),
+    })
+
+
+@pytest.mark.parametrize("kw", [dict(compression_level=1, use_dictionary=False), dict(compression_level=3, use_dictionary=True), dict(compression_level=9, use_dictionary=False, data_page_version="2.0"),
+                                dict(compression_level=19, use_dictionary=["text", "sawtooth"], data_page_size=1 << 16)], ids=["level1-plain", "level3-dict", "level9-v2", "level19-small-pages"])
+def test_zstd_pages_equal_pyarrow(ctx, tmp_path, kw):
+    """ZSTD (the codec DataFusion's Parquet writer defaults to): pages of up to 1 MB through every block and literals type the compressor picks for these columns -- RLE blocks
+    (constant), raw blocks and raw literals (random), Huffman literals with one and four streams, FSE-coded weights, predefined / RLE / coded / repeated sequence tables, repeat
+    offsets, matches that overlap their own output, and references further back than the 32 KB LDS ring -- bit-exact against pyarrow (libzstd) on the same file."""
+    from dfgpu.parquet import ParquetFile
+    n = 300000
+    t = _pattern_table(n)
+    path = str(tmp_path / "z.parquet")
+    pq.write_table(t, path, compression="zstd", row_group_size=200000, **{"data_page_size": 1 << 20, **kw})
+    want = pq.read_table(path)
+    for staged in (True, False):
+        f = ParquetFile(ctx, path=path, stage_on_device=staged, utf8_dictionary=False)
+        for name, a in zip(f.column_names(), f.read()):
+            same_column(a.to_arrow(), want[name], name)
+
+
+def test_zstd_lineitem_shape_and_corrupt_frames(ctx, tmp_path):
+    from dfgpu.parquet import ParquetFile
+    import dfgpu
+    t = big_table(400000)
+    path = str(tmp_path / "li.parquet")
+    pq.write_table(t, path, compression="zstd", row_group_size=100000)
+    want = pq.read_table(path)
+    f = ParquetFile(ctx, path=path, stage_on_device=True)
+    for name, a in zip(f.column_names(), f.read()):
+        same_column(a.to_arrow(), want[name], name)
+    f.close()
+    # flip bytes inside the first column chunk's compressed pages: an error (or, when the damage happens to decode, different values), never a fault
+    raw = bytearray(open(path, "rb").read())
+    md = pq.ParquetFile(path).metadata.row_group(0).column(0)
+    start = md.dictionary_page_offset or md.data_page_offset
+    for k in range(60, min(4000, md.total_compressed_size), 97):
+        raw[start + k] ^= 0x5A
+    bad = str(tmp_path / "bad.parquet"); open(bad, "wb").write(bytes(raw))
+    g = ParquetFile(ctx, path=bad, stage_on_device=True)
+    try:
+        g.read(columns=[0])
+    except dfgpu.DfgpuError:
+        pass
