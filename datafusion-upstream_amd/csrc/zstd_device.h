@@ -14,10 +14,11 @@ namespace dfgpu {
 namespace zs {
 
 struct FseEnt { uint16_t base; uint8_t nbits; uint8_t sym; };
+struct SeqEnt { uint16_t base; uint8_t nbits; uint8_t addbits; uint32_t value; };      // sequence tables: the code's base value and number of extra bits ride in the entry -- one LDS read per state
 constexpr int ZS_HUF_LOG = 11, ZS_LL_LOG = 9, ZS_ML_LOG = 9, ZS_OF_LOG = 8, ZS_BLOCK_MAX = 128 * 1024;
-struct Lds {                              // ~10.5 KB per wave
+struct Lds {                              // ~17 KB per wave
   uint16_t huf[1 << ZS_HUF_LOG];          // sym | nbits << 8
-  FseEnt ll[1 << ZS_LL_LOG], ml[1 << ZS_ML_LOG], of[1 << ZS_OF_LOG], wt[64];
+  SeqEnt ll[1 << ZS_LL_LOG], ml[1 << ZS_ML_LOG], of[1 << ZS_OF_LOG]; FseEnt tmp[1 << ZS_LL_LOG], wt[64];
   int16_t norm[256]; uint16_t next[256]; uint8_t weight[256];
   int32_t ll_log, ml_log, of_log, huf_log, huf_ok;
 };
@@ -33,26 +34,30 @@ __device__ inline uint32_t bits_at(const uint8_t* s, int64_t pos, int n) {
   if (pos < 0) { const int m = n + (int)pos; if (m <= 0) return 0; return (uint32_t)((ld64(s) & ((1ull << m) - 1ull)) << (-(int)pos)); }
   return (uint32_t)((ld64(s + (pos >> 3)) >> (pos & 7)) & ((1ull << n) - 1ull));
 }
-// backward stream: unread bits are [0, bit).  c holds bits [cb, cb + 64) of which [cb, cb + 57) are used, so a refill (one unaligned 8-byte load, issued together with a
-// load 256 bytes further down the stream that only warms the cache) serves ~57 bits of reads; bits below 0 read as zero (the last reads of a stream may run out)
-struct Back { const uint8_t* s; int64_t bit, cb; uint64_t c, sink; };
-__device__ inline void back_fill(Back* b, int64_t top) {            // make [top - 57, top) readable
-  const int64_t cb = top - 57; b->cb = cb;
-  asm volatile("" :: "v"(b->sink));                                  // the cache-warming load of the previous refill has to be issued, nothing more
-  if (cb >= 0) b->c = ld64(b->s + (cb >> 3)) >> (cb & 7);
-  else { const int64_t neg = -cb; b->c = neg >= 64 ? 0ull : (ld64(b->s) << neg); }
-  if (cb >= 2048 + 64) b->sink = ld64(b->s + (cb >> 3) - 256);
-}
+// backward stream: unread bits are [0, bit) (bit 0 = LSB of the stream's first byte).  The reader keeps the two 8-byte-aligned words around the read position in registers
+// (hi = word w, lo = word w - 1: 128 bits) and the word below them (nx = word w - 2) already loaded: when the position leaves `lo`, the words shift down and the load of the
+// next one is only ISSUED -- it has a whole word of reads (two or more sequences) to arrive, so a refill never waits on memory.  Words below the stream's first byte read as
+// zero (the format lets the last reads of a stream run out).
+struct Back { const uint64_t* q; int64_t bit; int64_t w; int64_t lead; uint64_t hi, lo, nx; };       // q: aligned base, lead: bits of q[0] in front of the stream, w: index of `hi`
+__device__ inline uint64_t back_word(const Back* b, int64_t w) { if (w < 0) return 0ull; const uint64_t v = b->q[w]; return w == 0 && b->lead ? (v >> b->lead) << b->lead : v; }
 __device__ inline bool back_init(Back* b, const uint8_t* s, uint32_t len) {
   if (!len) return false; const uint8_t last = s[len - 1]; if (!last) return false;
-  b->s = s; b->bit = (int64_t)(len - 1) * 8 + (31 - __clz((int)last)); b->sink = 0; back_fill(b, b->bit); return true;
+  const uintptr_t a = (uintptr_t)s; b->q = (const uint64_t*)(a & ~(uintptr_t)7); b->lead = (int64_t)(a & 7) * 8;
+  b->bit = b->lead + (int64_t)(len - 1) * 8 + (31 - __clz((int)last));           // positions are kept relative to q[0]: the stream's bit 0 is at `lead`
+  b->w = b->bit >> 6; b->hi = back_word(b, b->w); b->lo = back_word(b, b->w - 1); b->nx = back_word(b, b->w - 2);
+  return true;
 }
-__device__ inline uint32_t back_read(Back* b, int n) {              // n <= 32
-  if (n <= 0) return 0;
-  if (b->bit - n < b->cb) back_fill(b, b->bit);
-  b->bit -= n; return (uint32_t)((b->c >> (b->bit - b->cb)) & ((1ull << n) - 1ull));
+__device__ inline uint32_t back_get(Back* b, int64_t pos, int n) {    // bits [pos, pos + n), pos + n <= bit, n <= 32; positions below `lead` are zero
+  while (pos < (b->w - 1) * 64) { b->hi = b->lo; b->lo = b->nx; b->w -= 1; b->nx = back_word(b, b->w - 2); }
+  const int64_t rel = pos - (b->w - 1) * 64;                          // 0 .. 127 inside lo:hi
+  uint64_t v;
+  if (rel >= 64) v = b->hi >> (rel - 64);
+  else v = rel ? (b->lo >> rel) | (b->hi << (64 - rel)) : b->lo;
+  return (uint32_t)(v & ((1ull << n) - 1ull));
 }
-__device__ inline uint32_t back_peek(Back* b, int n) { if (b->bit - n < b->cb) back_fill(b, b->bit); return (uint32_t)((b->c >> (b->bit - n - b->cb)) & ((1ull << n) - 1ull)); }
+__device__ inline uint32_t back_read(Back* b, int n) { if (n <= 0) return 0; b->bit -= n; return back_get(b, b->bit, n); }
+__device__ inline uint32_t back_peek(Back* b, int n) { return back_get(b, b->bit - n, n); }
+__device__ inline int64_t back_left(const Back* b) { return b->bit - b->lead; }      // unread bits; negative = the stream ran out
 
 // FSE table description (forward bits) -> norm[]; returns bytes consumed, 0 on error
 __device__ inline uint32_t fse_read_norm(const uint8_t* s, uint32_t len, int max_log, int max_sym, int16_t* norm, int* out_log, int* out_nsym) {
@@ -106,14 +111,14 @@ __device__ inline uint32_t huf_read_tree(Lds* L, const uint8_t* s, uint32_t len)
     int al = 0, nsym = 0; const uint32_t h = fse_read_norm(s + 1, hb, 6, 255, L->norm, &al, &nsym); if (!h || h >= hb) return 0;
     fse_build(L->wt, L->norm, nsym, al, L->next);
     Back b; if (!back_init(&b, s + 1 + h, hb - h)) return 0;
-    uint32_t s1 = back_read(&b, al), s2 = back_read(&b, al); if (b.bit < 0) return 0;
+    uint32_t s1 = back_read(&b, al), s2 = back_read(&b, al); if (back_left(&b) < 0) return 0;
     for (;;) {
       if (nw > 253) return 0;
       L->weight[nw++] = L->wt[s1].sym; s1 = L->wt[s1].base + back_read(&b, L->wt[s1].nbits);
-      if (b.bit < 0) { L->weight[nw++] = L->wt[s2].sym; break; }
+      if (back_left(&b) < 0) { L->weight[nw++] = L->wt[s2].sym; break; }
       if (nw > 253) return 0;
       L->weight[nw++] = L->wt[s2].sym; s2 = L->wt[s2].base + back_read(&b, L->wt[s2].nbits);
-      if (b.bit < 0) { L->weight[nw++] = L->wt[s1].sym; break; }
+      if (back_left(&b) < 0) { L->weight[nw++] = L->wt[s1].sym; break; }
     }
   }
   uint32_t total = 0; for (int i = 0; i < nw; i++) { if (L->weight[i] > ZS_HUF_LOG) return 0; if (L->weight[i]) total += 1u << (L->weight[i] - 1); }
@@ -133,15 +138,21 @@ __device__ inline uint32_t huf_read_tree(Lds* L, const uint8_t* s, uint32_t len)
 __device__ inline bool huf_stream(const Lds* L, const uint8_t* s, uint32_t len, uint8_t* out, uint32_t n) {
   Back b; if (!back_init(&b, s, len)) return false; const int hl = L->huf_log;
   for (uint32_t i = 0; i < n; i++) { const uint16_t e = L->huf[back_peek(&b, hl)]; out[i] = (uint8_t)e; b.bit -= e >> 8; }
-  return b.bit == 0;
+  return back_left(&b) == 0;
 }
 
-// one of the three sequence tables: mode 0 predefined, 1 RLE, 2 FSE description, 3 repeat; advances *p.  Serial: one lane.
-__device__ inline bool seq_table(Lds* L, int mode, const uint8_t** p, const uint8_t* end, FseEnt* t, int32_t* log, const int16_t* def, int def_n, int def_log, int max_log, int max_sym) {
-  if (mode == 0) { for (int i = 0; i < def_n; i++) L->norm[i] = def[i]; fse_build(t, L->norm, def_n, def_log, L->next); *log = def_log; return true; }
-  if (mode == 1) { if (*p >= end) return false; if (**p > max_sym) return false; fse_rle(t, **p); (*p)++; *log = 0; return true; }
-  if (mode == 2) { int al = 0, ns = 0; const uint32_t h = fse_read_norm(*p, (uint32_t)(end - *p), max_log, max_sym, L->norm, &al, &ns); if (!h) return false; fse_build(t, L->norm, ns, al, L->next); *log = al; *p += h; return true; }
-  return *log >= 0;                       // repeat: a table must exist
+// one of the three sequence tables (kind 0 literal lengths, 1 offsets, 2 match lengths): mode 0 predefined, 1 RLE, 2 FSE description, 3 repeat; advances *p.  Serial: one lane.
+__device__ inline bool seq_table(Lds* L, int kind, int mode, const uint8_t** p, const uint8_t* end, SeqEnt* t, int32_t* log, const int16_t* def, int def_n, int def_log, int max_log, int max_sym) {
+  int al;
+  if (mode == 0) { for (int i = 0; i < def_n; i++) L->norm[i] = def[i]; fse_build(L->tmp, L->norm, def_n, def_log, L->next); al = def_log; }
+  else if (mode == 1) { if (*p >= end || **p > max_sym) return false; fse_rle(L->tmp, **p); (*p)++; al = 0; }
+  else if (mode == 2) { int ns = 0; const uint32_t h = fse_read_norm(*p, (uint32_t)(end - *p), max_log, max_sym, L->norm, &al, &ns); if (!h) return false; fse_build(L->tmp, L->norm, ns, al, L->next); *p += h; }
+  else return *log >= 0;                  // repeat: a table must exist
+  for (int u = 0; u < (1 << al); u++) { const FseEnt e = L->tmp[u]; if (e.sym > max_sym) return false;
+    SeqEnt o; o.base = e.base; o.nbits = e.nbits;
+    if (kind == 1) { o.addbits = e.sym; o.value = 1u << e.sym; } else if (kind == 0) { o.addbits = ZS_LL_BITS[e.sym]; o.value = ZS_LL_BASE[e.sym]; } else { o.addbits = ZS_ML_BITS[e.sym]; o.value = ZS_ML_BASE[e.sym]; }
+    t[u] = o; }
+  *log = al; return true;
 }
 
 constexpr uint32_t ZS_LIT_LDS = 65536;
@@ -159,23 +170,52 @@ __device__ inline bool decode_frame(Lds* L, uint8_t* ring, uint8_t* lit_lds, con
   if (did) return false;                                     // dictionaries are not part of a Parquet page
   const uint32_t fcs_bytes = fcs_flag == 0 ? (single ? 1u : 0u) : fcs_flag == 1 ? 2u : fcs_flag == 2 ? 4u : 8u;
   p += fcs_bytes; if (p > csize) return false;
-  uint32_t rep1 = 1, rep2 = 4, rep3 = 8, out = 0;
+  uint32_t rep1 = 1, rep2 = 4, rep3 = 8, out = 0, fenced = 0;
+#ifdef ZS_PROFILE
+  long long t_lit = 0, t_tab = 0, t_seq = 0, t_mark = wall_clock64();        // -DZS_PROFILE: time per phase of job 0, printed by dfgpu_parquet_read
+#define ZS_T(acc) { const long long now_ = wall_clock64(); acc += now_ - t_mark; t_mark = now_; }
+#else
+#define ZS_T(acc)
+#endif
   __shared__ uint32_t sh_bad, sh_used; __shared__ const uint8_t* sh_ptr;
   if (lane == 0) { L->ll_log = L->ml_log = L->of_log = -1; L->huf_ok = 0; }
   __syncthreads();
-  auto put_copy = [&](const uint8_t* from, uint32_t n) {      // n bytes from `from` (input or literal scratch) to the output
-    for (uint32_t i = lane; i < n; i += 64) { const uint8_t v = from[i]; ring[(out + i) & RM] = v; dst[out + i] = v; }
-    out += n;
+  // Output goes to the LDS ring only; the ring is copied to HBM a few KB at a time with 16-byte stores (no byte stores, and no store between the loads of the bit reader).
+  // Measured with -DZS_PROFILE on 1 MB pages of sorted Int64 keys (one sequence per value): 128 ms in the sequence loop, ~0.5-1 us per sequence, the same with per-sequence
+  // stores, with literals in HBM, with table constants in global memory: what a sequence costs is the chain of dependent LDS round trips (state -> entry -> bits -> literal
+  // -> match), which this one-wave-per-page structure does not shorten.
+  uint32_t flushed = 0;
+  const bool dst16 = ((uintptr_t)dst & 15) == 0;
+  auto flush = [&](uint32_t upto, bool all) {                  // ring[flushed, upto) -> dst; without `all` only whole 16-byte groups leave
+    __builtin_amdgcn_wave_barrier();
+    uint32_t a = flushed;
+    if (!dst16) { if (all || upto - a >= 4096) { for (uint32_t q = a + lane; q < upto; q += 64) dst[q] = ring[q & RM]; flushed = upto; } return; }
+    const uint32_t a16 = (a + 15u) & ~15u, e16 = upto & ~15u;
+    if (a16 > a) { const uint32_t h = a16 < upto ? a16 : upto; for (uint32_t q = a + lane; q < h; q += 64) dst[q] = ring[q & RM]; a = h; }
+    if (e16 > a) { for (uint32_t q = a + lane * 16; q < e16; q += 1024) *(uint4*)(dst + q) = *(const uint4*)(ring + (q & RM)); a = e16; }
+    if (all && upto > a) { for (uint32_t q = a + lane; q < upto; q += 64) dst[q] = ring[q & RM]; a = upto; }
+    flushed = a;
+  };
+  constexpr uint32_t CH = 8192;                                // at most this much is written between two looks at the ring's fill
+  auto room = [&](uint32_t c) { if (out + c - flushed > ZS_RING - 64) flush(out, false); };
+  auto put_copy = [&](const uint8_t* from, uint32_t n) {      // n bytes from `from` (input or literal buffer) to the output
+    while (n) { const uint32_t c = n < CH ? n : CH; room(c);
+      for (uint32_t i = lane; i < c; i += 64) ring[(out + i) & RM] = from[i];
+      out += c; from += c; n -= c; }
+  };
+  auto put_fill = [&](uint8_t v, uint32_t n) {
+    while (n) { const uint32_t c = n < CH ? n : CH; room(c); for (uint32_t i = lane; i < c; i += 64) ring[(out + i) & RM] = v; out += c; n -= c; }
   };
   for (;;) {
     if (p + 3 > csize) return false;
     const uint32_t bh = (uint32_t)src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16); p += 3;
     const uint32_t last = bh & 1, btype = (bh >> 1) & 3, bsize = bh >> 3;
     if (btype == 0) { if (p + bsize > csize || out + bsize > usize) return false; put_copy(src + p, bsize); p += bsize; }
-    else if (btype == 1) { if (p + 1 > csize || out + bsize > usize) return false; const uint8_t v = src[p]; for (uint32_t i = lane; i < bsize; i += 64) { ring[(out + i) & RM] = v; dst[out + i] = v; } out += bsize; p += 1; }
+    else if (btype == 1) { if (p + 1 > csize || out + bsize > usize) return false; put_fill(src[p], bsize); p += 1; }
     else if (btype == 2) {
       if (bsize > (uint32_t)ZS_BLOCK_MAX || p + bsize > csize || bsize < 2) return false;
       const uint8_t* b = src + p; const uint8_t* const bend = b + bsize; p += bsize;
+      ZS_T(t_tab)
       // ---- literals section
       const uint32_t lt = b[0] & 3, sf = (b[0] >> 2) & 3; uint32_t regen = 0, comp = 0, hdr = 0, streams = 1;
       if (lt < 2) {
@@ -219,6 +259,7 @@ __device__ inline bool decode_frame(Lds* L, uint8_t* ring, uint8_t* lit_lds, con
         if (sh_bad) return false;
       }
       __syncthreads();                                      // literals written by some lanes are read by all
+      ZS_T(t_lit)
       // ---- sequences section
       if (b >= bend) return false;
       uint32_t nseq = b[0]; b += 1;
@@ -227,25 +268,25 @@ __device__ inline bool decode_frame(Lds* L, uint8_t* ring, uint8_t* lit_lds, con
       if (nseq) {
         if (b >= bend) return false;
         const uint32_t modes = b[0]; b += 1; if (modes & 3) return false;
-        if (lane == 0) { const uint8_t* q = b; bool ok = seq_table(L, (modes >> 6) & 3, &q, bend, L->ll, &L->ll_log, ZS_LL_DEF, 36, 6, ZS_LL_LOG, 35);
-          ok = ok && seq_table(L, (modes >> 4) & 3, &q, bend, L->of, &L->of_log, ZS_OF_DEF, 29, 5, ZS_OF_LOG, 31);
-          ok = ok && seq_table(L, (modes >> 2) & 3, &q, bend, L->ml, &L->ml_log, ZS_ML_DEF, 53, 6, ZS_ML_LOG, 52);
+        if (lane == 0) { const uint8_t* q = b; bool ok = seq_table(L, 0, (modes >> 6) & 3, &q, bend, L->ll, &L->ll_log, ZS_LL_DEF, 36, 6, ZS_LL_LOG, 35);
+          ok = ok && seq_table(L, 1, (modes >> 4) & 3, &q, bend, L->of, &L->of_log, ZS_OF_DEF, 29, 5, ZS_OF_LOG, 31);
+          ok = ok && seq_table(L, 2, (modes >> 2) & 3, &q, bend, L->ml, &L->ml_log, ZS_ML_DEF, 53, 6, ZS_ML_LOG, 52);
           sh_bad = ok ? 0u : 1u; sh_ptr = q; }
         __syncthreads();
         if (sh_bad) return false;
         b = sh_ptr;
         __syncthreads();
+        ZS_T(t_tab)
         Back s; if (b >= bend || !back_init(&s, b, (uint32_t)(bend - b))) return false;
         uint32_t sl = back_read(&s, L->ll_log), so = back_read(&s, L->of_log), sm = back_read(&s, L->ml_log);
-        if (s.bit < 0) return false;
+        if (back_left(&s) < 0) return false;
         for (uint32_t i = 0; i < nseq; i++) {
-          const FseEnt el = L->ll[sl], eo = L->of[so], em = L->ml[sm];
-          if (el.sym > 35 || em.sym > 52 || eo.sym > 31) return false;
-          const uint32_t ov = (1u << eo.sym) + back_read(&s, eo.sym);
-          const uint32_t mlen = ZS_ML_BASE[em.sym] + back_read(&s, ZS_ML_BITS[em.sym]);
-          const uint32_t llen = ZS_LL_BASE[el.sym] + back_read(&s, ZS_LL_BITS[el.sym]);
+          const SeqEnt el = L->ll[sl], eo = L->of[so], em = L->ml[sm];
+          const uint32_t ov = eo.value + back_read(&s, eo.addbits);
+          const uint32_t mlen = em.value + back_read(&s, em.addbits);
+          const uint32_t llen = el.value + back_read(&s, el.addbits);
           if (i + 1 < nseq) { sl = el.base + back_read(&s, el.nbits); sm = em.base + back_read(&s, em.nbits); so = eo.base + back_read(&s, eo.nbits); }
-          if (s.bit < 0) return false;
+          if (back_left(&s) < 0) return false;
           uint32_t off;
           if (ov > 3) { off = ov - 3; rep3 = rep2; rep2 = rep1; rep1 = off; }
           else { const uint32_t idx = ov + (llen == 0 ? 1u : 0u);
@@ -256,20 +297,23 @@ __device__ inline bool decode_frame(Lds* L, uint8_t* ring, uint8_t* lit_lds, con
           if (lpos + llen > regen || out + llen + mlen > usize || off > out + llen) return false;
           if (llen) { put_copy(lsrc + lpos, llen); lpos += llen; }
           __builtin_amdgcn_wave_barrier();
-          if (off + mlen <= ZS_RING) {            // source [out - off, out) and everything this match overwrites stay inside the ring
-            const uint32_t from = out - off;
-            if (off >= mlen) { for (uint32_t k = lane; k < mlen; k += 64) { const uint8_t v = ring[(from + k) & RM]; ring[(out + k) & RM] = v; dst[out + k] = v; } }
-            else for (uint32_t k = lane; k < mlen; k += 64) { const uint8_t v = ring[(from + k % off) & RM]; __builtin_amdgcn_wave_barrier(); ring[(out + k) & RM] = v; dst[out + k] = v; }
-          } else {
-            __threadfence_block();                // this wave's earlier stores have reached the cache the loads below read
-            const uint8_t* from = dst + out - off;
-            if (off >= mlen) { for (uint32_t k = lane; k < mlen; k += 64) { const uint8_t v = from[k]; ring[(out + k) & RM] = v; dst[out + k] = v; } }
-            else for (uint32_t k = lane; k < mlen; k += 64) { const uint8_t v = from[k % off]; ring[(out + k) & RM] = v; dst[out + k] = v; }
+          if (off + CH <= ZS_RING) {              // the source of every chunk lies inside the ring
+            uint32_t n = mlen;
+            while (n) { const uint32_t c = n < CH ? n : CH; room(c); const uint32_t from = out - off;
+              if (off >= c) { for (uint32_t k = lane; k < c; k += 64) ring[(out + k) & RM] = ring[(from + k) & RM]; }
+              else for (uint32_t k = lane; k < c; k += 64) { const uint8_t v = ring[(from + k % off) & RM]; __builtin_amdgcn_wave_barrier(); ring[(out + k) & RM] = v; }
+              out += c; n -= c; __builtin_amdgcn_wave_barrier(); }
+          } else {                                // further back than the ring: everything written so far leaves for HBM, one wait, then the source is read there
+            if (out - off + (mlen < off ? mlen : off) > fenced) { flush(out, true); __threadfence_block(); fenced = out; }      // one wait covers everything written so far
+            const uint32_t o0 = out; uint32_t n = mlen, done = 0;                    // source positions are all in front of o0: nothing this match writes is read back
+            while (n) { const uint32_t c = n < CH ? n : CH; room(c);
+              for (uint32_t k = lane; k < c; k += 64) { const uint32_t j = done + k; ring[(out + k) & RM] = dst[o0 - off + (off >= mlen ? j : j % off)]; }
+              out += c; done += c; n -= c; }
           }
-          out += mlen;
           __builtin_amdgcn_wave_barrier();
         }
-        if (s.bit != 0) return false;
+        if (back_left(&s) != 0) return false;
+        ZS_T(t_seq)
       }
       const uint32_t restl = regen - lpos; if (out + restl > usize) return false;
       put_copy(lsrc + lpos, restl);
@@ -277,6 +321,10 @@ __device__ inline bool decode_frame(Lds* L, uint8_t* ring, uint8_t* lit_lds, con
     } else return false;
     if (last) break;
   }
+  flush(out, true);
+#ifdef ZS_PROFILE
+  if (lane == 0) { long long* d = (long long*)lit_hbm; d[0] = t_lit; d[1] = t_tab; d[2] = t_seq; d[3] = (long long)usize; }
+#endif
   return out == usize;
 }
 
