@@ -988,7 +988,7 @@ dfgpu_status dfgpu_parquet_read(dfgpu_ctx* ctx, dfgpu_parquet* f, int32_t first_
       hipLaunchKernelGGL(k_pq_zstd, dim3((unsigned)zjobs.size()), dim3(64), 0, ctx->stream, (const SnJob*)dz->ptr, (uint8_t*)zlit->ptr, ctx->d_flags);
       KERNEL_CHECK();
 #ifdef ZS_PROFILE
-      { long long t[4]; HIP_CHECK(hipMemcpy(t, zlit->ptr, 32, hipMemcpyDeviceToHost)); fprintf(stderr, "zstd job0: literals %.2f ms, tables/headers %.2f ms, sequences %.2f ms, usize %lld, jobs %zu\n", t[0] / 1e5, t[1] / 1e5, t[2] / 1e5, t[3], zjobs.size()); }
+      { long long t[10]; HIP_CHECK(hipMemcpy(t, zlit->ptr, 80, hipMemcpyDeviceToHost)); fprintf(stderr, "zstd job0: literals %.2f ms, tables/headers %.2f ms, sequences %.2f ms (decode %.2f, literal copies %.2f, match copies %.2f; %lld sequences, %lld overlapping, %lld far), usize %lld, jobs %zu\n", t[0] / 1e5, t[1] / 1e5, t[2] / 1e5, t[4] / 1e5, t[5] / 1e5, t[6] / 1e5, t[7], t[8], t[9], t[3], zjobs.size()); }
 #endif
     }
     if (!jobs.empty()) {                          // every compressed page of the read in one launch: the pages are the parallelism
