@@ -50,12 +50,15 @@ CONFIGS = {
     "dict_snappy_small_pages": dict(use_dictionary=True, compression="snappy", data_page_size=512, row_group_size=700),
     "dict_fallback_snappy": dict(use_dictionary=True, compression="snappy", dictionary_pagesize_limit=2048, data_page_size=4096),
     "decimal_as_integer": dict(use_dictionary=False, compression="snappy", store_decimal_as_integer=True),
+    "dict_zstd_v1": dict(use_dictionary=True, compression="zstd", data_page_version="1.0"),                 # the codec DataFusion's own writer defaults to
+    "plain_zstd_v2": dict(use_dictionary=False, compression="zstd", compression_level=9, data_page_version="2.0"),
 }
 
 if __name__ == "__main__":
     os.makedirs(HERE, exist_ok=True)
     for name, kw in CONFIGS.items():
-        pq.write_table(table(2500), os.path.join(HERE, name + ".parquet"), **kw)
+        if not os.path.exists(os.path.join(HERE, name + ".parquet")):          # fixtures already committed stay byte for byte what they were
+            pq.write_table(table(2500), os.path.join(HERE, name + ".parquet"), **kw)
     pq.write_table(table(1500, seed=11, null_frac=0), os.path.join(HERE, "no_nulls_dict_snappy.parquet"), use_dictionary=True, compression="snappy")
     pq.write_table(table(10).slice(0, 0), os.path.join(HERE, "empty.parquet"))
     t = table(64, seed=3)
