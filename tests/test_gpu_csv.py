@@ -186,3 +186,17 @@ def test_csv_exec_plan_filter_aggregate(ctx):
     key = [("k", "ascending"), ("qty", "ascending"), ("d", "ascending"), ("flag", "ascending")]
     rows = pa.concat_tables(batches).sort_by(key)
     assert rows.equals(reference_read(data, [("k", I64), ("flag", S), ("qty", I64), ("d", D32)]).sort_by(key))
+
+
+def test_csv_exec_edge_files(ctx):
+    """Header only, empty image, one record without a line feed, more partitions than pieces: CsvExec yields the rows once, or none."""
+    from dfgpu import capi, physical_plan as ops
+    sch = [("a", capi.INT64, 0, 0), ("b", capi.UTF8, 0, 0)]
+    tc = ops.TaskContext(ctx, 8192)
+    for data, rows in ((b"a,b\n", 0), (b"", 0), (b"a,b\n1,x", 1), (b"a,b\n1,x\n2,y\n", 2)):
+        for parts in (1, 3):
+            scan = ops.CsvExec(data, sch, partitions=parts, batch_bytes=4)
+            out = [b.to_arrow() for b in ops.CoalescePartitionsExec(scan).execute(0, tc)] if parts > 1 else [b.to_arrow() for b in scan.execute(0, tc)]
+            assert sum(b.num_rows for b in out) == rows, (data, parts)
+    got = pa.concat_tables([b.to_arrow() for b in ops.CsvExec(b"a,b\n1,x\n2,y\n", sch, batch_bytes=4).execute(0, tc)])
+    assert got["a"].to_pylist() == [1, 2] and got["b"].to_pylist() == ["x", "y"]

@@ -101,3 +101,27 @@ def test_ordered_aggregate_keeps_only_open_groups(ctx):
     sel = t.filter(t["keep"])
     ref = sel.group_by("a", use_threads=False).aggregate([("v", "sum")])
     assert whole["a"].combine_chunks().equals(ref["a"].combine_chunks()) and whole["s"].combine_chunks().equals(ref["v_sum"].combine_chunks())
+
+
+@pytest.mark.gpu
+def test_ordered_aggregate_edge_inputs(ctx):
+    """Empty input, empty batches between full ones, a single group spanning every batch, one-row batches: the schedule still follows the oracle."""
+    from dfgpu import capi, physical_plan as ops
+    C, F = ops.Column, ops.Field
+    sch_t = pa.table({"a": pa.array([], pa.int64()), "v": pa.array([], pa.int64())})
+
+    def run(batches, order="Sorted"):
+        scan = ops.MemoryExec([[ops.batch_from_arrow(ctx, b) for b in batches]], ops.batch_from_arrow(ctx, sch_t).schema)
+        agg = ops.AggregateExec("Single", [(C("a", 0), "a")], [ops.AggregateFunctionExpr("SUM", C("v", 1), "s", input_field=F("v", capi.INT64))], scan, input_order_mode=order)
+        return [b.to_arrow() for b in agg.execute(0, ops.TaskContext(ctx, 8192))]
+    mk = lambda a: pa.table({"a": pa.array(a, pa.int64()), "v": pa.array([1] * len(a), pa.int64())})
+    assert run([]) == [] and run([sch_t]) == []
+    cases = [[mk([5, 5]), sch_t, mk([5]), mk([5, 5, 5])],                       # one group throughout: nothing leaves before the end
+             [mk([1]), mk([2]), mk([3])], [mk([1, 2, 3]), sch_t, sch_t, mk([3, 4])], [mk([7])]]
+    for batches in cases:
+        got = run(batches)
+        want = po.group_ordering_emits([[b["a"].combine_chunks()] for b in batches if b.num_rows])
+        assert [b.num_rows for b in got] == want, (batches, want)
+        whole = pa.concat_tables(got)
+        ref = pa.concat_tables(batches).group_by("a", use_threads=False).aggregate([("v", "sum")])
+        assert whole["a"].combine_chunks().equals(ref["a"].combine_chunks()) and whole["s"].combine_chunks().equals(ref["v_sum"].combine_chunks())
