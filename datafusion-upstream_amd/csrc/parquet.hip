@@ -54,7 +54,7 @@ struct TR {
 
 enum { PT_BOOLEAN = 0, PT_INT32 = 1, PT_INT64 = 2, PT_INT96 = 3, PT_FLOAT = 4, PT_DOUBLE = 5, PT_BYTE_ARRAY = 6, PT_FLBA = 7 };
 enum { ENC_PLAIN = 0, ENC_PLAIN_DICT = 2, ENC_RLE = 3, ENC_BIT_PACKED = 4, ENC_RLE_DICT = 8 };
-enum { CODEC_NONE = 0, CODEC_SNAPPY = 1, CODEC_ZSTD = 6 };
+enum { CODEC_NONE = 0, CODEC_SNAPPY = 1, CODEC_ZSTD = 6, CODEC_LZ4_RAW = 7 };
 enum { PG_DATA = 0, PG_INDEX = 1, PG_DICT = 2, PG_DATA_V2 = 3 };
 
 struct Leaf {
@@ -764,7 +764,8 @@ __global__ void __launch_bounds__(64) k_pq_zstd(const SnJob* __restrict__ jobs, 
   __shared__ zs::Lds L; __shared__ __attribute__((aligned(16))) uint8_t ring[zs::ZS_RING]; __shared__ __attribute__((aligned(16))) uint8_t litl[zs::ZS_LIT_LDS];
   const SnJob jb = jobs[blockIdx.x]; const uint32_t lane = threadIdx.x;
   if (jb.raw) { for (uint32_t i = lane; i < jb.usize; i += 64) jb.dst[i] = jb.src[i]; return; }
-  const bool ok = zs::decode_frame(&L, ring, litl, jb.src, jb.csize, jb.dst, jb.usize, lit + (size_t)blockIdx.x * ZS_LIT, lane);
+  const bool ok = jb.codec == CODEC_LZ4_RAW ? zs::lz4_decode(ring, litl, jb.src, jb.csize, jb.dst, jb.usize, lane)
+                                            : zs::decode_frame(&L, ring, litl, jb.src, jb.csize, jb.dst, jb.usize, lit + (size_t)blockIdx.x * ZS_LIT, lane);
   if (!ok && lane == 0) atomicOr(flags, DFGPU_FLAG_OOB);
 }
 
@@ -781,7 +782,7 @@ static void plan_column(dfgpu_ctx* ctx, dfgpu_parquet* f, int leaf_idx, int rg0,
   int& wp = cr.wp; wp = leaf.phys == PT_INT32 || leaf.phys == PT_FLOAT ? 4 : leaf.phys == PT_INT64 || leaf.phys == PT_DOUBLE ? 8 : leaf.phys == PT_FLBA ? leaf.type_len : 0;
   for (int g = rg0; g < rg0 + nrg; g++) {
     const RowGroup& rg = f->rgs[(size_t)g]; const Chunk& ch = rg.cols[(size_t)leaf_idx];
-    if (ch.codec != CODEC_NONE && ch.codec != CODEC_SNAPPY && ch.codec != CODEC_ZSTD) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: Parquet compression codec %d of column '%s' (UNCOMPRESSED, SNAPPY and ZSTD are decoded on the device)", ch.codec, leaf.name.c_str());
+    if (ch.codec != CODEC_NONE && ch.codec != CODEC_SNAPPY && ch.codec != CODEC_ZSTD && ch.codec != CODEC_LZ4_RAW) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: Parquet compression codec %d of column '%s' (UNCOMPRESSED, SNAPPY, ZSTD and LZ4_RAW are decoded on the device)", ch.codec, leaf.name.c_str());
     if (ch.num_values != rg.rows) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: Parquet column '%s' holds %lld values for %lld rows (repeated values)", leaf.name.c_str(), (long long)ch.num_values, (long long)rg.rows);
     if (ch.num_values == 0) continue;                       // a row group without rows: nothing to walk
     int64_t start = ch.dict_off > 0 && ch.dict_off < ch.data_off ? ch.dict_off : ch.data_off;
@@ -979,7 +980,7 @@ dfgpu_status dfgpu_parquet_read(dfgpu_ctx* ctx, dfgpu_parquet* f, int32_t first_
       if (columns[i] < 0 || (size_t)columns[i] >= f->leaves.size()) fail(DFGPU_INVALID_ARGUMENT, "parquet_read: column %d of %zu", columns[i], f->leaves.size());
       plan_column(ctx, f, columns[i], first_row_group, num_row_groups, reads[(size_t)i], jobs);
     }
-    std::vector<SnJob> zjobs; { std::vector<SnJob> sj; for (auto& j : jobs) (j.codec == CODEC_ZSTD ? zjobs : sj).push_back(j); jobs.swap(sj); }
+    std::vector<SnJob> zjobs; { std::vector<SnJob> sj; for (auto& j : jobs) (j.codec == CODEC_ZSTD || j.codec == CODEC_LZ4_RAW ? zjobs : sj).push_back(j); jobs.swap(sj); }
     BufferPtr zlit;
     if (!zjobs.empty()) {                         // Zstandard: a frame is sequential, the pages of the read are the parallelism -- one wave each
       std::stable_sort(zjobs.begin(), zjobs.end(), [](const SnJob& x, const SnJob& y) { return x.usize > y.usize; });          // the longest pages start first

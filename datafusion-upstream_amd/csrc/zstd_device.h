@@ -364,5 +364,71 @@ __device__ inline bool decode_frame(Lds* L, uint8_t* ring, uint8_t* lit_lds, con
   return out == usize;
 }
 
+
+// ---- LZ4 block format (Parquet codec LZ4_RAW): token (literal length : match length - 4), extension bytes of 255, literals, 2-byte offset.  One wave per page like the
+// Zstandard frames above and for the same reason (every match may reach back to the start of the page); the input is parsed out of a 16 KB LDS window, output goes to
+// the same kind of LDS ring, flushed to HBM in 16-byte stores.
+__device__ inline bool lz4_decode(uint8_t* ring, uint8_t* win, const uint8_t* src, uint32_t csize, uint8_t* dst, uint32_t usize, uint32_t lane) {
+  constexpr uint32_t RM = ZS_RING - 1, WIN = 16384, CH = 8192;
+  uint32_t out = 0, flushed = 0, fenced = 0, ip = 0, wbase = 0, wlen = 0;
+  const bool dst16 = ((uintptr_t)dst & 15) == 0;
+  auto flush = [&](uint32_t upto, bool all) {
+    __builtin_amdgcn_wave_barrier();
+    uint32_t a = flushed;
+    if (!dst16) { if (all || upto - a >= 4096) { for (uint32_t q = a + lane; q < upto; q += 64) dst[q] = ring[q & RM]; flushed = upto; } return; }
+    const uint32_t a16 = (a + 15u) & ~15u, e16 = upto & ~15u;
+    if (a16 > a) { const uint32_t h = a16 < upto ? a16 : upto; for (uint32_t q = a + lane; q < h; q += 64) dst[q] = ring[q & RM]; a = h; }
+    if (e16 > a) { for (uint32_t q = a + lane * 16; q < e16; q += 1024) *(uint4*)(dst + q) = *(const uint4*)(ring + (q & RM)); a = e16; }
+    if (all && upto > a) { for (uint32_t q = a + lane; q < upto; q += 64) dst[q] = ring[q & RM]; a = upto; }
+    flushed = a;
+  };
+  auto room = [&](uint32_t c) { if (out + c - flushed > ZS_RING - 64) flush(out, false); };
+  auto need = [&](uint32_t n) {                    // input [ip, ip + n) readable from the window (n <= WIN)
+    if (ip + n > wbase + wlen) { __builtin_amdgcn_wave_barrier(); wbase = ip; wlen = csize - ip < WIN ? csize - ip : WIN;
+      for (uint32_t i = lane; i < wlen; i += 64) win[i] = src[ip + i];
+      __builtin_amdgcn_wave_barrier(); }
+  };
+  if (!csize) return usize == 0;
+  for (;;) {
+    if (ip >= csize) return false;
+    need(csize - ip < 64 ? csize - ip : 64);
+    const uint32_t token = win[ip - wbase]; ip += 1;
+    uint32_t ll = token >> 4;
+    if (ll == 15) { for (;;) { if (ip >= csize) return false; need(1); const uint32_t b = win[ip - wbase]; ip += 1; ll += b; if (b != 255) break; } }
+    if (ip + ll > csize || out + ll > usize) return false;
+    { uint32_t n = ll, at = ip;                      // literals: short ones out of the window, long ones straight from the page
+      while (n) { const uint32_t c = n < CH ? n : CH; room(c);
+        if (at >= wbase && at + c <= wbase + wlen) { for (uint32_t i = lane; i < c; i += 64) ring[(out + i) & RM] = win[at - wbase + i]; }
+        else for (uint32_t i = lane; i < c; i += 64) ring[(out + i) & RM] = src[at + i];
+        out += c; at += c; n -= c; } }
+    ip += ll;
+    if (ip >= csize) break;                          // the last sequence is literals only
+    if (ip + 2 > csize) return false;
+    need(2);
+    const uint32_t off = (uint32_t)win[ip - wbase] | ((uint32_t)win[ip - wbase + 1] << 8); ip += 2;
+    uint32_t ml = token & 15;
+    if (ml == 15) { for (;;) { if (ip >= csize) return false; need(1); const uint32_t b = win[ip - wbase]; ip += 1; ml += b; if (b != 255) break; } }
+    ml += 4;
+    if (!off || off > out || out + ml > usize) return false;
+    __builtin_amdgcn_wave_barrier();
+    if (off + CH <= ZS_RING) {
+      uint32_t n = ml;
+      while (n) { const uint32_t c = n < CH ? n : CH; room(c); const uint32_t from = out - off;
+        if (off >= c) { for (uint32_t k = lane; k < c; k += 64) ring[(out + k) & RM] = ring[(from + k) & RM]; }
+        else for (uint32_t k = lane; k < c; k += 64) { const uint8_t v = ring[(from + k % off) & RM]; __builtin_amdgcn_wave_barrier(); ring[(out + k) & RM] = v; }
+        out += c; n -= c; __builtin_amdgcn_wave_barrier(); }
+    } else {
+      if (out - off + (ml < off ? ml : off) > fenced) { flush(out, true); __threadfence_block(); fenced = out; }
+      const uint32_t o0 = out; uint32_t n = ml, done = 0;
+      while (n) { const uint32_t c = n < CH ? n : CH; room(c);
+        for (uint32_t k = lane; k < c; k += 64) { const uint32_t j = done + k; ring[(out + k) & RM] = dst[o0 - off + (off >= ml ? j : j % off)]; }
+        out += c; done += c; n -= c; }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  flush(out, true);
+  return out == usize;
+}
+
 }  // namespace zs
 }  // namespace dfgpu

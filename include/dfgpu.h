@@ -412,7 +412,7 @@ DFGPU_API dfgpu_status dfgpu_exchange(dfgpu_ctx *ctx, dfgpu_comm *comm, const df
 /* ------------------------------------------------------------------ scan: Parquet column chunks -> Arrow columns in HBM */
 /* ≙ what ParquetExec's stream does per row group (core/src/datasource/physical_plan/parquet/mod.rs: ParquetOpener::open :417-560 ->
  * ParquetRecordBatchStreamBuilder of the `parquet` crate (arrow-rs 50, not part of the reference tree) -> RecordBatches), for flat schemas:
- * the footer and the page headers are parsed on the host, pages are decompressed (UNCOMPRESSED, SNAPPY, ZSTD) and decoded (PLAIN, PLAIN_DICTIONARY /
+ * the footer and the page headers are parsed on the host, pages are decompressed (UNCOMPRESSED, SNAPPY, ZSTD, LZ4_RAW) and decoded (PLAIN, PLAIN_DICTIONARY /
  * RLE_DICTIONARY, RLE definition levels; data pages v1 and v2) by device kernels.  Column types follow the crate's parquet -> arrow rules:
  * BOOLEAN, INT32 / INT64 with their INT(8..64, signed / unsigned), DATE and DECIMAL annotations, FLOAT, DOUBLE, BYTE_ARRAY (STRING / UTF8),
  * FIXED_LEN_BYTE_ARRAY (DECIMAL, <= 16 bytes).  Other columns (nested, INT96, timestamps, binary) report type 0 and fail to read with

@@ -253,3 +253,18 @@ def test_zstd_lineitem_shape_and_corrupt_frames(ctx, tmp_path):
         g.read(columns=[0])
     except dfgpu.DfgpuError:
         pass
+
+
+@pytest.mark.parametrize("kw", [dict(use_dictionary=False), dict(use_dictionary=True, data_page_version="2.0")], ids=["plain", "dict-v2"])
+def test_lz4_raw_pages_equal_pyarrow(ctx, tmp_path, kw):
+    """LZ4_RAW (what pyarrow writes for compression="lz4"): tokens with extended literal and match lengths (incompressible 1 MB pages, constant columns), overlapping matches,
+    references beyond the LDS ring -- bit-exact against pyarrow on the same file."""
+    from dfgpu.parquet import ParquetFile
+    t = _pattern_table(300000)
+    path = str(tmp_path / "l.parquet")
+    pq.write_table(t, path, compression="lz4", row_group_size=200000, data_page_size=1 << 20, **kw)
+    want = pq.read_table(path)
+    for staged in (True, False):
+        f = ParquetFile(ctx, path=path, stage_on_device=staged, utf8_dictionary=False)
+        for name, a in zip(f.column_names(), f.read()):
+            same_column(a.to_arrow(), want[name], name)
