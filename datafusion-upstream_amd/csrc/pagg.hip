@@ -434,7 +434,7 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
         for (int shift = 0; shift < fb; shift += dbits) {
           const int bits = fb - shift < dbits ? fb - shift : dbits;
           RpCols rc{}; rc.n = 1; rc.c[0] = RpCol{ nullptr, wb, 8, RP_HASHKEY, 0 };
-          (void)rp_partition(ctx, RpHashDigit{ wa, shift + jb, (1u << bits) - 1u }, m, 1u << bits, rc, true, ctx->d_scratch64 + 9, "pa_order_hist", "pa_order_scan", "pa_order_scatter");
+          (void)rp_partition(ctx, RpHashDigit{ wa, shift + jb, (1u << bits) - 1u }, m, 1u << bits, rc, true, ctx->d_scratch64 + 9, "pa_order_hist", "pa_order_scan", "pa_order_scatter", false);
           std::swap(wa, wb);
         }
         hipLaunchKernelGGL(k_pa_perm_of_words, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)wa, m, jb, (uint32_t*)perm->ptr);

@@ -285,12 +285,12 @@ struct RpResult { uint32_t P = 0; int64_t ntiles = 0; BufferPtr starts; };     /
 // d_total: device u64 that receives the number of rows moved.  timer names: <prefix>_hist / _scan / _scatter.
 template <typename H>
 static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const RpCols& cols, bool stable, uint64_t* d_total,
-                             const char* t_hist, const char* t_scan, const char* t_scatter) {
+                             const char* t_hist, const char* t_scan, const char* t_scatter, bool want_starts = true) {
   if (P < 1 || P > RP_MAX_P) fail(DFGPU_INTERNAL, "rp_partition: %u partitions (1..%u supported)", P, RP_MAX_P);
   if (stable && P > RP_MAX_STABLE_P) fail(DFGPU_INTERNAL, "rp_partition: stable order supports up to %u partitions, got %u", RP_MAX_STABLE_P, P);
   if (n > 0xFFFFFFF0ll) fail(DFGPU_NOT_IMPLEMENTED, "partitioning above 2^32-16 rows");
   RpResult r; r.P = P;
-  r.starts = alloc_buffer(ctx, (size_t)(P + 1) * 4);
+  if (want_starts) r.starts = alloc_buffer(ctx, (size_t)(P + 1) * 4);       // the passes of a sort only need the rows moved
   const bool big = P > 512 && P <= 2048 && !stable;        // 8192-row tiles halve the count matrix; 4096-row tiles give more workgroups per CU (and leave LDS for P > 2048)
   const bool small_wg = stable && P > 16;                  // stable with many partitions: 256-thread workgroups (the count table is 64 P bytes) keep several on a CU;
   const int nt = small_wg ? 256 : big ? 1024 : 512, tile = nt * RP_R;      // few partitions want the longer runs of a 4096-row tile
@@ -307,7 +307,7 @@ static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const 
       hipLaunchKernelGGL((k_rp_hist<512, H>), dim3((unsigned)nh), dim3(512), hl, ctx->stream, hs, n, P, ntiles, G, (uint32_t*)counts->ptr); }
     KERNEL_CHECK(); }
   { KernelTimer kt_(ctx, t_scan); exclusive_scan_u32_inplace32(ctx, (uint32_t*)counts->ptr, (int64_t)P * ntiles, d_total); }
-  hipLaunchKernelGGL(k_rp_starts, dim3((P + 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)counts->ptr, ntiles, P, (const uint64_t*)d_total, (uint32_t*)r.starts->ptr);
+  if (want_starts) hipLaunchKernelGGL(k_rp_starts, dim3((P + 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)counts->ptr, ntiles, P, (const uint64_t*)d_total, (uint32_t*)r.starts->ptr);
   KERNEL_CHECK();
   if (n) { KernelTimer kt_(ctx, t_scatter);
     const unsigned grid = (unsigned)(((ntiles + 7) / 8) * 8);

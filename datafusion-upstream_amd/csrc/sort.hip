@@ -417,7 +417,7 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
             if (word) { rc.n = 1; rc.c[0] = RpCol{ nullptr, kb, 8, RP_HASHKEY, 0 }; }       // the whole record is the word the digit is read from
             else { rc.n = last ? 1 : 2; rc.c[0] = RpCol{ va, vb, 4, RP_RAW, 0 };
               if (!last) rc.c[1] = RpCol{ nullptr, kb, 8, RP_HASHKEY, 0 }; }                // the last pass only needs the row ids
-            (void)rp_partition(ctx, RpHashDigit{ ka, shift + (word ? ib : 0), (1u << bits) - 1u }, n, 1u << bits, rc, true, ctx->d_scratch64 + 9, "sort_pass_hist", "sort_pass_scan", "sort_pass_scatter");
+            (void)rp_partition(ctx, RpHashDigit{ ka, shift + (word ? ib : 0), (1u << bits) - 1u }, n, 1u << bits, rc, true, ctx->d_scratch64 + 9, "sort_pass_hist", "sort_pass_scan", "sort_pass_scatter", false);
             std::swap(ka, kb); std::swap(va, vb);
           }
           if (word) {
