@@ -764,9 +764,16 @@ __global__ void __launch_bounds__(64) k_pq_zstd(const SnJob* __restrict__ jobs, 
   __shared__ zs::Lds L; __shared__ __attribute__((aligned(16))) uint8_t ring[zs::ZS_RING]; __shared__ __attribute__((aligned(16))) uint8_t litl[zs::ZS_LIT_LDS];
   const SnJob jb = jobs[blockIdx.x]; const uint32_t lane = threadIdx.x;
   if (jb.raw) { for (uint32_t i = lane; i < jb.usize; i += 64) jb.dst[i] = jb.src[i]; return; }
-  const bool ok = jb.codec == CODEC_LZ4_RAW ? zs::lz4_decode(ring, litl, jb.src, jb.csize, jb.dst, jb.usize, lane)
-                                            : zs::decode_frame(&L, ring, litl, jb.src, jb.csize, jb.dst, jb.usize, lit + (size_t)blockIdx.x * ZS_LIT, lane);
+  const bool ok = zs::decode_frame(&L, ring, litl, jb.src, jb.csize, jb.dst, jb.usize, lit + (size_t)blockIdx.x * ZS_LIT, lane);
   if (!ok && lane == 0) atomicOr(flags, DFGPU_FLAG_OOB);
+}
+
+// LZ4_RAW pages: a kernel of their own (sharing k_pq_zstd cost the Zstandard path a third of its speed: register pressure)
+__global__ void __launch_bounds__(64) k_pq_lz4(const SnJob* __restrict__ jobs, uint32_t* flags) {
+  __shared__ __attribute__((aligned(16))) uint8_t ring[zs::ZS_RING]; __shared__ __attribute__((aligned(16))) uint8_t win[16384];
+  const SnJob jb = jobs[blockIdx.x]; const uint32_t lane = threadIdx.x;
+  if (jb.raw) { for (uint32_t i = lane; i < jb.usize; i += 64) jb.dst[i] = jb.src[i]; return; }
+  if (!zs::lz4_decode(ring, win, jb.src, jb.csize, jb.dst, jb.usize, lane) && lane == 0) atomicOr(flags, DFGPU_FLAG_OOB);
 }
 
 static void plan_column(dfgpu_ctx* ctx, dfgpu_parquet* f, int leaf_idx, int rg0, int nrg, ColumnRead& cr, std::vector<SnJob>& jobs) {
@@ -980,7 +987,14 @@ dfgpu_status dfgpu_parquet_read(dfgpu_ctx* ctx, dfgpu_parquet* f, int32_t first_
       if (columns[i] < 0 || (size_t)columns[i] >= f->leaves.size()) fail(DFGPU_INVALID_ARGUMENT, "parquet_read: column %d of %zu", columns[i], f->leaves.size());
       plan_column(ctx, f, columns[i], first_row_group, num_row_groups, reads[(size_t)i], jobs);
     }
-    std::vector<SnJob> zjobs; { std::vector<SnJob> sj; for (auto& j : jobs) (j.codec == CODEC_ZSTD || j.codec == CODEC_LZ4_RAW ? zjobs : sj).push_back(j); jobs.swap(sj); }
+    std::vector<SnJob> zjobs, ljobs; { std::vector<SnJob> sj; for (auto& j : jobs) (j.codec == CODEC_ZSTD ? zjobs : j.codec == CODEC_LZ4_RAW ? ljobs : sj).push_back(j); jobs.swap(sj); }
+    if (!ljobs.empty()) {
+      std::stable_sort(ljobs.begin(), ljobs.end(), [](const SnJob& x, const SnJob& y) { return x.usize > y.usize; });
+      BufferPtr dl = upload(ctx, ljobs);
+      KernelTimer kt(ctx, "pq_lz4");
+      hipLaunchKernelGGL(k_pq_lz4, dim3((unsigned)ljobs.size()), dim3(64), 0, ctx->stream, (const SnJob*)dl->ptr, ctx->d_flags);
+      KERNEL_CHECK();
+    }
     BufferPtr zlit;
     if (!zjobs.empty()) {                         // Zstandard: a frame is sequential, the pages of the read are the parallelism -- one wave each
       std::stable_sort(zjobs.begin(), zjobs.end(), [](const SnJob& x, const SnJob& y) { return x.usize > y.usize; });          // the longest pages start first
@@ -989,7 +1003,7 @@ dfgpu_status dfgpu_parquet_read(dfgpu_ctx* ctx, dfgpu_parquet* f, int32_t first_
       hipLaunchKernelGGL(k_pq_zstd, dim3((unsigned)zjobs.size()), dim3(64), 0, ctx->stream, (const SnJob*)dz->ptr, (uint8_t*)zlit->ptr, ctx->d_flags);
       KERNEL_CHECK();
 #ifdef ZS_PROFILE
-      { long long t[10]; HIP_CHECK(hipMemcpy(t, zlit->ptr, 80, hipMemcpyDeviceToHost)); fprintf(stderr, "zstd job0: literals %.2f ms, tables/headers %.2f ms, sequences %.2f ms (decode %.2f, literal copies %.2f, match copies %.2f; %lld sequences, %lld overlapping, %lld far), usize %lld, jobs %zu\n", t[0] / 1e5, t[1] / 1e5, t[2] / 1e5, t[4] / 1e5, t[5] / 1e5, t[6] / 1e5, t[7], t[8], t[9], t[3], zjobs.size()); }
+      { long long t[4]; HIP_CHECK(hipMemcpy(t, zlit->ptr, 32, hipMemcpyDeviceToHost)); fprintf(stderr, "zstd job0: literals %.2f ms, tables/headers %.2f ms, sequences %.2f ms, usize %lld, jobs %zu\n", t[0] / 1e5, t[1] / 1e5, t[2] / 1e5, t[3], zjobs.size()); }
 #endif
     }
     if (!jobs.empty()) {                          // every compressed page of the read in one launch: the pages are the parallelism

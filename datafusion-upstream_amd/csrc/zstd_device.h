@@ -59,25 +59,6 @@ __device__ inline uint32_t back_read(Back* b, int n) { if (n <= 0) return 0; b->
 __device__ inline uint32_t back_peek(Back* b, int n) { return back_get(b, b->bit - n, n); }
 __device__ inline int64_t back_left(const Back* b) { return b->bit - b->lead; }      // unread bits; negative = the stream ran out
 
-// The sequence stream's reader: the same three words, but the window is moved at most once per GROUP of reads (sb_ensure, n <= 64: the three extra-bit fields, then the
-// three state updates) by a plain `if`, so the load of the next word is not needed before the next move, and a read is a shift and a mask with no branch in it.
-struct SeqBits { const uint64_t* q; int64_t lead, bit, base, w; uint64_t hi, lo, nx; };        // base = 64 * (w - 1): position of lo's bit 0
-__device__ inline uint64_t sb_word(const SeqBits* b, int64_t w) { if (w < 0) return 0ull; const uint64_t v = b->q[w]; return w == 0 && b->lead ? (v >> b->lead) << b->lead : v; }
-__device__ inline bool sb_init(SeqBits* b, const uint8_t* s, uint32_t len) {
-  if (!len) return false; const uint8_t last = s[len - 1]; if (!last) return false;
-  const uintptr_t a = (uintptr_t)s; b->q = (const uint64_t*)(a & ~(uintptr_t)7); b->lead = (int64_t)(a & 7) * 8;
-  b->bit = b->lead + (int64_t)(len - 1) * 8 + (31 - __clz((int)last));
-  b->w = b->bit >> 6; b->base = (b->w - 1) * 64; b->hi = sb_word(b, b->w); b->lo = sb_word(b, b->w - 1); b->nx = sb_word(b, b->w - 2);
-  return true;
-}
-__device__ inline void sb_ensure(SeqBits* b, int n) { if (b->bit - n < b->base) { b->hi = b->lo; b->lo = b->nx; b->w -= 1; b->base -= 64; b->nx = sb_word(b, b->w - 2); } }
-__device__ inline uint32_t sb_take(SeqBits* b, uint32_t n) {        // n <= 32 bits below the cursor, inside the window (sb_ensure)
-  b->bit -= n; const uint32_t rel = (uint32_t)(b->bit - b->base);
-  const uint64_t v = rel >= 64 ? b->hi >> (rel - 64) : (rel ? (b->lo >> rel) | (b->hi << (64 - rel)) : b->lo);
-  return n >= 32 ? (uint32_t)v : (uint32_t)v & ((1u << n) - 1u);
-}
-__device__ inline int64_t sb_left(const SeqBits* b) { return b->bit - b->lead; }
-
 // FSE table description (forward bits) -> norm[]; returns bytes consumed, 0 on error
 __device__ inline uint32_t fse_read_norm(const uint8_t* s, uint32_t len, int max_log, int max_sym, int16_t* norm, int* out_log, int* out_nsym) {
   if (len < 1) return 0;
@@ -191,7 +172,7 @@ __device__ inline bool decode_frame(Lds* L, uint8_t* ring, uint8_t* lit_lds, con
   p += fcs_bytes; if (p > csize) return false;
   uint32_t rep1 = 1, rep2 = 4, rep3 = 8, out = 0, fenced = 0;
 #ifdef ZS_PROFILE
-  long long t_lit = 0, t_tab = 0, t_seq = 0, t_dec = 0, t_cl = 0, t_cm = 0, t_mark = wall_clock64(); unsigned long long n_sq = 0, n_ov = 0, n_far = 0;        // -DZS_PROFILE: time per phase of job 0, printed by dfgpu_parquet_read
+  long long t_lit = 0, t_tab = 0, t_seq = 0, t_mark = wall_clock64();        // -DZS_PROFILE: time per phase of job 0, printed by dfgpu_parquet_read
 #define ZS_T(acc) { const long long now_ = wall_clock64(); acc += now_ - t_mark; t_mark = now_; }
 #else
 #define ZS_T(acc)
@@ -200,10 +181,10 @@ __device__ inline bool decode_frame(Lds* L, uint8_t* ring, uint8_t* lit_lds, con
   if (lane == 0) { L->ll_log = L->ml_log = L->of_log = -1; L->huf_ok = 0; }
   __syncthreads();
   // Output goes to the LDS ring only; the ring is copied to HBM a few KB at a time with 16-byte stores (no byte stores, and no store between the loads of the bit reader).
-  // Measured with -DZS_PROFILE on a 1 MB page of sorted Int64 keys (131 462 sequences, one per value, 28 overlapping, none beyond the ring): 128 ms in the sequence loop,
-  // ~1 us per sequence, split evenly over decoding the sequence, copying its literals and copying its match (each ~0.3-0.5 us with the timer reads), and the same with
-  // per-sequence stores, with literals in HBM, with table constants in global memory, with the reader on the scalar unit: a lone wave per CU running a chain of dependent
-  // short operations; this one-wave-per-page structure does not shorten that chain.
+  // Measured with -DZS_PROFILE on a 1 MB page of sorted Int64 keys (131 462 sequences, one per value): ~128 ms in the sequence loop, ~1 us per sequence, split evenly over
+  // decoding the sequence, copying its literals and copying its match, and the same with per-sequence stores, with literals in HBM, with table constants in global memory:
+  // the compiler keeps the (uniform) parse on the vector unit behind exec masks -- ~1000 instructions per sequence on a lone wave.  Variants tried and dropped because they
+  // were slower on the device: a reader with one window move per group of reads and v_readfirstlane on everything loaded (129 ms), LZ4 sharing this kernel (159 ms).
   uint32_t flushed = 0;
   const bool dst16 = ((uintptr_t)dst & 15) == 0;
   auto flush = [&](uint32_t upto, bool all) {                  // ring[flushed, upto) -> dst; without `all` only whole 16-byte groups leave
@@ -222,11 +203,6 @@ __device__ inline bool decode_frame(Lds* L, uint8_t* ring, uint8_t* lit_lds, con
     while (n) { const uint32_t c = n < CH ? n : CH; room(c);
       for (uint32_t i = lane; i < c; i += 64) ring[(out + i) & RM] = from[i];
       out += c; from += c; n -= c; }
-  };
-  auto put_lit = [&](uint32_t at, uint32_t n) {               // literals that sit in the LDS literal buffer: LDS -> LDS (a pointer that may be LDS or HBM makes every access a flat one)
-    while (n) { const uint32_t c = n < CH ? n : CH; room(c);
-      for (uint32_t i = lane; i < c; i += 64) ring[(out + i) & RM] = lit_lds[at + i];
-      out += c; at += c; n -= c; }
   };
   auto put_fill = [&](uint8_t v, uint32_t n) {
     while (n) { const uint32_t c = n < CH ? n : CH; room(c); for (uint32_t i = lane; i < c; i += 64) ring[(out + i) & RM] = v; out += c; n -= c; }
@@ -256,7 +232,7 @@ __device__ inline bool decode_frame(Lds* L, uint8_t* ring, uint8_t* lit_lds, con
         else { regen = (uint32_t)(h >> 4) & 0x3FFFF; comp = (uint32_t)(h >> 22) & 0x3FFFF; hdr = 5; streams = 4; }
       }
       if (regen > (uint32_t)ZS_BLOCK_MAX || b + hdr > bend) return false;
-      const bool lit_in_lds = regen <= ZS_LIT_LDS; uint8_t* const lit = lit_in_lds ? lit_lds : lit_hbm;
+      uint8_t* const lit = regen <= ZS_LIT_LDS ? lit_lds : lit_hbm;
       const uint8_t* lsrc = lit; b += hdr;
       if (lt == 0) { if (b + regen > bend) return false; if (regen <= ZS_LIT_LDS) { for (uint32_t i = lane; i < regen; i += 64) lit[i] = b[i]; } else lsrc = b; b += regen; }      // raw: staged in LDS, or read in place
       else if (lt == 1) { if (b + 1 > bend) return false; const uint8_t v = b[0]; for (uint32_t i = lane; i < regen; i += 64) lit[i] = v; b += 1; }
@@ -302,21 +278,16 @@ __device__ inline bool decode_frame(Lds* L, uint8_t* ring, uint8_t* lit_lds, con
         b = sh_ptr;
         __syncthreads();
         ZS_T(t_tab)
-        SeqBits s; if (b >= bend || !sb_init(&s, b, (uint32_t)(bend - b))) return false;
-        sb_ensure(&s, 32);
-        uint32_t sl = sb_take(&s, (uint32_t)L->ll_log), so = sb_take(&s, (uint32_t)L->of_log), sm = sb_take(&s, (uint32_t)L->ml_log);
-        if (sb_left(&s) < 0) return false;
+        Back s; if (b >= bend || !back_init(&s, b, (uint32_t)(bend - b))) return false;
+        uint32_t sl = back_read(&s, L->ll_log), so = back_read(&s, L->of_log), sm = back_read(&s, L->ml_log);
+        if (back_left(&s) < 0) return false;
         for (uint32_t i = 0; i < nseq; i++) {
           const SeqEnt el = L->ll[sl], eo = L->of[so], em = L->ml[sm];
-          sb_ensure(&s, 64);                    // offset <= 31 extra bits, match and literal lengths <= 16 each
-          const uint32_t ov = eo.value + sb_take(&s, eo.addbits);
-          const uint32_t mlen = em.value + sb_take(&s, em.addbits);
-          const uint32_t llen = el.value + sb_take(&s, el.addbits);
-          if (i + 1 < nseq) { sb_ensure(&s, 32); sl = el.base + sb_take(&s, el.nbits); sm = em.base + sb_take(&s, em.nbits); so = eo.base + sb_take(&s, eo.nbits); }
-          if (sb_left(&s) < 0) return false;
-#ifdef ZS_PROFILE
-          { const long long now_ = wall_clock64(); t_dec += now_ - t_mark; t_mark = now_; n_sq++; }
-#endif
+          const uint32_t ov = eo.value + back_read(&s, eo.addbits);
+          const uint32_t mlen = em.value + back_read(&s, em.addbits);
+          const uint32_t llen = el.value + back_read(&s, el.addbits);
+          if (i + 1 < nseq) { sl = el.base + back_read(&s, el.nbits); sm = em.base + back_read(&s, em.nbits); so = eo.base + back_read(&s, eo.nbits); }
+          if (back_left(&s) < 0) return false;
           uint32_t off;
           if (ov > 3) { off = ov - 3; rep3 = rep2; rep2 = rep1; rep1 = off; }
           else { const uint32_t idx = ov + (llen == 0 ? 1u : 0u);
@@ -325,11 +296,8 @@ __device__ inline bool decode_frame(Lds* L, uint8_t* ring, uint8_t* lit_lds, con
             else if (idx == 3) { off = rep3; rep3 = rep2; rep2 = rep1; rep1 = off; }
             else { off = rep1 - 1; if (!off) return false; rep3 = rep2; rep2 = rep1; rep1 = off; } }
           if (lpos + llen > regen || out + llen + mlen > usize || off > out + llen) return false;
-          if (llen) { if (lit_in_lds) put_lit(lpos, llen); else put_copy(lsrc + lpos, llen); lpos += llen; }
+          if (llen) { put_copy(lsrc + lpos, llen); lpos += llen; }
           __builtin_amdgcn_wave_barrier();
-#ifdef ZS_PROFILE
-          { const long long now_ = wall_clock64(); t_cl += now_ - t_mark; t_mark = now_; if (off < mlen) n_ov++; if (off + CH > ZS_RING) n_far++; }
-#endif
           if (off + CH <= ZS_RING) {              // the source of every chunk lies inside the ring
             uint32_t n = mlen;
             while (n) { const uint32_t c = n < CH ? n : CH; room(c); const uint32_t from = out - off;
@@ -344,22 +312,19 @@ __device__ inline bool decode_frame(Lds* L, uint8_t* ring, uint8_t* lit_lds, con
               out += c; done += c; n -= c; }
           }
           __builtin_amdgcn_wave_barrier();
-#ifdef ZS_PROFILE
-          { const long long now_ = wall_clock64(); t_cm += now_ - t_mark; t_mark = now_; }
-#endif
         }
-        if (sb_left(&s) != 0) return false;
+        if (back_left(&s) != 0) return false;
         ZS_T(t_seq)
       }
       const uint32_t restl = regen - lpos; if (out + restl > usize) return false;
-      if (lit_in_lds) put_lit(lpos, restl); else put_copy(lsrc + lpos, restl);
+      put_copy(lsrc + lpos, restl);
       __syncthreads();
     } else return false;
     if (last) break;
   }
   flush(out, true);
 #ifdef ZS_PROFILE
-  if (lane == 0) { long long* d = (long long*)lit_hbm; d[0] = t_lit; d[1] = t_tab; d[2] = t_seq; d[3] = (long long)usize; d[4] = t_dec; d[5] = t_cl; d[6] = t_cm; d[7] = (long long)n_sq; d[8] = (long long)n_ov; d[9] = (long long)n_far; }
+  if (lane == 0) { long long* d = (long long*)lit_hbm; d[0] = t_lit; d[1] = t_tab; d[2] = t_seq; d[3] = (long long)usize; }
 #endif
   return out == usize;
 }
