@@ -986,8 +986,29 @@ dfgpu_status dfgpu_jit_selftest(const char* arch, char* log, int64_t log_cap) {
   return DFGPU_OK;
 }
 
+// merge_batch of states that carry group i in row i (ids 0 .. total-1, flagged as the identity) into an accumulator that holds nothing yet -- the partial rows of a first,
+// fully pre-aggregated batch (AggregateExec::merge_partial): the states ARE the accumulator's new contents, so they are copied in instead of being added row by row
+static bool acc_adopt_identity(dfgpu_ctx* ctx, dfgpu_acc* a, const dfgpu_array* const* st, int32_t nst, const dfgpu_array* gids, const dfgpu_array* filt, int64_t total) {
+  if (a->n != 0 || filt || !gids || !gids->identity || gids->length != total || total <= 0) return false;
+  if (a->kind == DFGPU_AGG_AVG) return false;            // its `seen` is count > 0 per group: left to the row-by-row merge
+  const int want = 1; if (nst != want) return false;
+  for (int i = 0; i < nst; i++) if (!st[i] || st[i]->validity || st[i]->length != total || st[i]->type == DFGPU_DICTIONARY || !st[i]->values) return false;
+  const dfgpu_array* vals = a->kind == DFGPU_AGG_COUNT ? nullptr : st[nst - 1];
+  if (a->kind == DFGPU_AGG_COUNT && st[0]->type != DFGPU_INT64) return false;
+  if (a->kind == DFGPU_AGG_AVG && st[0]->type != DFGPU_UINT64) return false;
+  if (vals && (vals->type != a->state_type || type_width(vals->type) != a->width)) return false;
+  a->vals = alloc_buffer(ctx, (size_t)total * a->width); a->counts = alloc_buffer(ctx, (size_t)total * 8); a->seen = alloc_buffer(ctx, (size_t)total); a->cap = total;
+  if (vals) HIP_CHECK(hipMemcpyAsync(a->vals->ptr, vals->values->ptr, (size_t)total * a->width, hipMemcpyDeviceToDevice, ctx->stream));
+  else HIP_CHECK(hipMemsetAsync(a->vals->ptr, 0, (size_t)total * a->width, ctx->stream));
+  if (a->kind == DFGPU_AGG_COUNT || a->kind == DFGPU_AGG_AVG) HIP_CHECK(hipMemcpyAsync(a->counts->ptr, st[0]->values->ptr, (size_t)total * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  else HIP_CHECK(hipMemsetAsync(a->counts->ptr, 0, (size_t)total * 8, ctx->stream));
+  HIP_CHECK(hipMemsetAsync(a->seen->ptr, 1, (size_t)total, ctx->stream));
+  a->n = total;
+  return true;
+}
 dfgpu_status dfgpu_acc_merge_batch(dfgpu_ctx* ctx, dfgpu_acc* a, const dfgpu_array* const* st, int32_t nst, const dfgpu_array* gids, const dfgpu_array* filt, int64_t total) {
   if (!a || !st) return DFGPU_INVALID_ARGUMENT;
+  { bool adopted = false; dfgpu_status rc = guard(ctx, [&] { adopted = acc_adopt_identity(ctx, a, st, nst, gids, filt, total); }); if (rc != DFGPU_OK || adopted) return rc; }
   if (a->kind == DFGPU_AGG_COUNT) {         // count.rs:135-170: add the partial counts (never null)
     return guard(ctx, [&] {
       if (nst != 1 || st[0]->type != DFGPU_INT64) fail(DFGPU_INVALID_ARGUMENT, "COUNT merge expects one Int64 state");

@@ -116,6 +116,13 @@ uint64_t read_scratch(dfgpu_ctx* ctx, int slot) {
   HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return ctx->h_pinned[slot];
 }
+// several consecutive slots with ONE copy and one wait; returns a pointer to the pinned copies (valid until the next read-back)
+const uint64_t* read_scratch_range(dfgpu_ctx* ctx, int first, int count) {
+  ctx->count_sync((std::string("sync:count") + std::to_string(first) + ".." + std::to_string(first + count - 1)).c_str());
+  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + first, ctx->d_scratch64 + first, (size_t)count * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return ctx->h_pinned + first;
+}
 void zero_scratch(dfgpu_ctx* ctx) { HIP_CHECK(hipMemsetAsync(ctx->d_scratch64, 0, 64 * 8, ctx->stream)); }
 
 ColView make_view(const dfgpu_array* a) {

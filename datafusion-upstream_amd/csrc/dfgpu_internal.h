@@ -150,6 +150,7 @@ struct ArrayHolder {   // RAII release on exception paths
 void check_flags(dfgpu_ctx* ctx, const char* what);
 void flush_flags(dfgpu_ctx* ctx);                          // the deferred check, now
 uint64_t read_scratch(dfgpu_ctx* ctx, int slot);          // sync + D2H of d_scratch64[slot]
+const uint64_t* read_scratch_range(dfgpu_ctx* ctx, int first, int count);      // the same for `count` consecutive slots: one copy, one wait
 void zero_scratch(dfgpu_ctx* ctx);
 
 // Device view of a column passed to kernels by value.

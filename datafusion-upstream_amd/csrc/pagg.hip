@@ -407,11 +407,12 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
                          items ? (const uint32_t*)items->ptr : nullptr, (uint32_t)P, cbits, (uint32_t)slice, (uint64_t*)orec->ptr, rs, (uint32_t*)ofirst->ptr, (unsigned long long*)(ctx->d_scratch64 + 12),
                          two_level ? (uint32_t)P1 : 0u, (uint32_t)P2, (uint32_t*)(ctx->d_scratch64 + 11));
       KERNEL_CHECK(); }
-    const int64_t m = (int64_t)read_scratch(ctx, 12);
-    if (two_level && (uint32_t)read_scratch(ctx, 11) != 0) fail(DFGPU_INTERNAL, "agg_preaggregate: the two-level partition left rows out of partition order");
+    const uint64_t* back = read_scratch_range(ctx, 11, 4);          // [0] rows out of order, [1] partial rows written, [3] tables flushed early: one read-back
+    const int64_t m = (int64_t)back[1]; const uint64_t early = back[3];
+    if (two_level && (uint32_t)back[0] != 0) fail(DFGPU_INTERNAL, "agg_preaggregate: the two-level partition left rows out of partition order");
     // every key left in exactly one partial row unless a hot partition was cut into slices or a table overflowed mid-partition: the plan layer then
     // needs no hash table to number the groups of a first batch (option "agg_preaggregate_distinct", read only)
-    ctx->pa_last_distinct = n_slices == 1 && key->type != DFGPU_DICTIONARY && read_scratch(ctx, 14) == 0;          // dictionary codes: two codes may carry one value
+    ctx->pa_last_distinct = n_slices == 1 && key->type != DFGPU_DICTIONARY && early == 0;          // dictionary codes: two codes may carry one value
     pkey.reset(); prow.reset(); pval.clear();
     // ---- partial rows in first-seen order of their groups
     BufferPtr perm = alloc_buffer(ctx, (size_t)(m + 1) * 4);
