@@ -597,3 +597,71 @@ def group_ordering_emits(batches: Sequence[Sequence], order_indices: Optional[Se
     if len(seen) > 0:
         emits.append(len(seen))                                         # input_done: EmitTo::All
     return emits
+
+
+# ------------------------------------------------------------------ CSV records (arrow-csv, arrow-rs 50 -- not part of the reference tree; restated from its documented rules)
+def csv_records(data: bytes, delimiter: str = ",", quote: str = '"', has_header: bool = True):
+    """Records of a delimited text image as lists of (text, quoted) fields: RFC 4180 quoting (a doubled quote inside quotes is one quote; delimiters and line feeds inside
+    quotes are data), LF or CRLF record ends, blank lines skipped, a last record without a line feed counts.  Plain Python, byte by byte: small inputs only."""
+    d, q = ord(delimiter), ord(quote)
+    recs, fields, cur, quoted, inside = [], [], bytearray(), False, False
+
+    def end_field():
+        nonlocal cur, quoted
+        fields.append((bytes(cur).decode("utf-8"), quoted)); cur = bytearray(); quoted = False
+
+    def end_record():
+        nonlocal fields
+        if cur and cur[-1] == 0x0D and not quoted:               # CRLF
+            cur.pop()
+        if cur or quoted or fields:                               # a blank line is no record
+            end_field(); recs.append(fields)
+        fields = []
+    i, n = 0, len(data)
+    while i < n:
+        c = data[i]
+        if inside:
+            if c == q and i + 1 < n and data[i + 1] == q:
+                cur.append(q); i += 1
+            elif c == q:
+                inside = False
+            else:
+                cur.append(c)
+        elif c == q and not cur and not quoted:
+            inside = quoted = True
+        elif c == d:
+            end_field()
+        elif c == 0x0A:
+            end_record()
+        else:
+            cur.append(c)
+        i += 1
+    end_record()
+    return recs[1:] if has_header and recs else recs
+
+
+def csv_column(records, index: int, pa_type):
+    """Column `index` of csv_records() under the caller's schema: an empty unquoted-or-quoted field of a non-string column is NULL, of a string column the empty string."""
+    import decimal
+    out = []
+    for r in records:
+        text, _ = r[index]
+        if pa.types.is_string(pa_type):
+            out.append(text)
+        elif text == "":
+            out.append(None)
+        elif pa.types.is_boolean(pa_type):
+            out.append({"true": True, "false": False}[text.lower()])
+        elif pa.types.is_integer(pa_type):
+            out.append(int(text))
+        elif pa.types.is_floating(pa_type):
+            out.append(float(text))
+        elif pa.types.is_date32(pa_type):
+            import datetime
+            out.append(datetime.date.fromisoformat(text))
+        elif pa.types.is_decimal(pa_type):
+            q = decimal.Decimal(text)
+            out.append(q.quantize(decimal.Decimal(1).scaleb(-pa_type.scale), rounding=decimal.ROUND_DOWN))
+        else:
+            raise OracleError(f"csv_column: type {pa_type}")
+    return pa.array(out, type=pa_type)
