@@ -160,7 +160,7 @@ PROTOTYPES = {
     "dfgpu_comm_world": (C.c_int32, [_P]),
     "dfgpu_exchange": (C.c_int32, [_P, _P, _PP, C.c_int32, _PP, C.c_int32, _P, _PP, C.POINTER(C.c_int64)]),
     "dfgpu_partition_columns": (C.c_int32, [_P, _PP, C.c_int32, C.c_int32, _PP, C.c_int32, _P, _PP, _PP, C.POINTER(C.c_int64)]),
-    "dfgpu_csv_read": (C.c_int32, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, _PP, C.POINTER(C.c_int64)]),
+    "dfgpu_csv_read": (C.c_int32, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, _PP, C.POINTER(C.c_int64)]),
     "dfgpu_parquet_open": (C.c_int32, [_P, _P, C.c_int64, _P, _PP]),
     "dfgpu_parquet_open_file": (C.c_int32, [_P, C.c_char_p, C.c_int32, _PP]),
     "dfgpu_parquet_close": (None, [_P]),
@@ -184,7 +184,7 @@ PROTOTYPES.update({
     "dfgpu_plan_sort_merge_join": (C.c_int32, [_P, _P, _PP, _PP, C.c_int32, _P, C.c_int32, C.c_int32, _PP]),
     "dfgpu_plan_nested_loop_join": (C.c_int32, [_P, _P, _P, _I32P, _I32P, C.c_int32, C.c_int32, _PP]),
     "dfgpu_plan_parquet": (C.c_int32, [_P, _I32P, C.c_int32, C.c_int32, C.c_int32, _PP]),
-    "dfgpu_plan_csv": (C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), _I32P, C.c_int32, _I32P, C.c_int32, C.c_int32, C.c_int64, _PP]),
+    "dfgpu_plan_csv": (C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), _I32P, C.c_int32, _I32P, C.c_int32, C.c_int32, C.c_int64, _PP]),
     "dfgpu_plan_parquet_prune": (C.c_int32, [_P, C.c_int32, C.c_int64, C.c_int64]),
     "dfgpu_plan_parquet_pruned": (C.c_int64, [_P]),
     "dfgpu_batch_new": (C.c_int32, [_CPP, _PP, C.c_int32, _PP]),

@@ -22,16 +22,24 @@ __device__ inline void csv_load16(const uint8_t* __restrict__ d, int64_t n, int6
 #pragma unroll
   for (int k = 0; k < 16; k++) b[k] = p + k < n ? d[p + k] : (uint8_t)0;
 }
+// escape character (CsvExec::escape, csv.rs:59; csv-core: inside quoted fields `escape` + any byte is that byte): a quote preceded by an odd run of escape characters is data.
+// Quotes are sparse and such runs short: every quote of a lane looks back over the bytes in front of it.
+__device__ inline uint32_t csv_real_quotes(const uint8_t* __restrict__ d, int64_t p, uint32_t q, int esc) {
+  if (esc < 0 || !q) return q;
+  uint32_t out = q;
+  for (uint32_t m = q; m; m &= m - 1) { const int k = __ffs((int)m) - 1; int64_t i = p + k; uint32_t run = 0; while (i > 0 && d[i - 1] == (uint8_t)esc) { run++; i--; } if (run & 1u) out &= ~(1u << k); }
+  return out;
+}
 __device__ inline uint32_t csv_mask16(const uint8_t* b, uint8_t c) { uint32_t m = 0;
 #pragma unroll
   for (int k = 0; k < 16; k++) m |= (uint32_t)(b[k] == c) << k;
   return m; }
 
 // quote characters per 1 KB block (their parity decides which line feeds are real)
-__global__ void __launch_bounds__(BLOCK) k_csv_quotes(const uint8_t* __restrict__ d, int64_t n, uint8_t quote, int64_t nblk, uint32_t* __restrict__ counts) {
+__global__ void __launch_bounds__(BLOCK) k_csv_quotes(const uint8_t* __restrict__ d, int64_t n, uint8_t quote, int esc, int64_t nblk, uint32_t* __restrict__ counts) {
   const int64_t blk = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); if (blk >= nblk) return;
   alignas(16) uint8_t b[16]; csv_load16(d, n, blk * CSV_BLK + lane_id() * 16, b);
-  uint32_t c = (uint32_t)__popc(csv_mask16(b, quote));
+  uint32_t c = (uint32_t)__popc(csv_real_quotes(d, blk * CSV_BLK + lane_id() * 16, csv_mask16(b, quote), esc));
 #pragma unroll
   for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o, 64);
   if (lane_id() == 0) counts[blk] = c;
@@ -39,11 +47,11 @@ __global__ void __launch_bounds__(BLOCK) k_csv_quotes(const uint8_t* __restrict_
 // bit i of `rows` = byte i ends a record: a line feed outside quotes that does not close a blank line (nothing, or a lone carriage return, since the previous line feed:
 // arrow-csv skips blank lines), or the last byte of the image when that is not a line feed.  One wave per 1 KB, no LDS: prefix parity inside the lane's 16 bits by
 // shift-xor, across lanes by a ballot of the lanes' parities.
-__global__ void __launch_bounds__(BLOCK) k_csv_rows(const uint8_t* __restrict__ d, int64_t n, uint8_t quote, int64_t nblk, const uint64_t* __restrict__ before, uint16_t* __restrict__ rows, uint32_t* flags) {
+__global__ void __launch_bounds__(BLOCK) k_csv_rows(const uint8_t* __restrict__ d, int64_t n, uint8_t quote, int esc, int64_t nblk, const uint64_t* __restrict__ before, uint16_t* __restrict__ rows, uint32_t* flags) {
   const int64_t blk = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); if (blk >= nblk) return;
   const int64_t p = blk * CSV_BLK + lane_id() * 16;
   alignas(16) uint8_t b[16]; csv_load16(d, n, p, b);
-  const uint32_t q = csv_mask16(b, quote), nl = csv_mask16(b, '\n'), cr = csv_mask16(b, '\r');
+  const uint32_t q = csv_real_quotes(d, p, csv_mask16(b, quote), esc), nl = csv_mask16(b, '\n'), cr = csv_mask16(b, '\r');
   uint32_t incl = q; incl ^= incl << 1; incl ^= incl << 2; incl ^= incl << 4; incl ^= incl << 8; incl &= 0xFFFFu;     // bit k = parity of quotes in bytes 0..k of the lane
   const uint32_t lane_par = (uint32_t)__popc(q) & 1u;
   const uint32_t in0 = ((uint32_t)(before[blk] & 1) + (uint32_t)__popcll(ballot64(lane_par != 0) & lanemask_lt())) & 1u;       // inside quotes in front of the lane's first byte
@@ -63,7 +71,7 @@ __global__ void __launch_bounds__(BLOCK) k_csv_rows(const uint8_t* __restrict__ 
 
 struct CsvField { uint32_t start, len; };      // len bit 31: the field was quoted (content excludes the outer quotes; doubled quotes still doubled)
 // one lane per record: fields wanted[k] (ascending file column indices) -> out[k * nrows + row]
-__global__ void __launch_bounds__(BLOCK) k_csv_fields(const uint8_t* __restrict__ d, const uint32_t* __restrict__ ends, int64_t first_row, int64_t nrows, uint8_t delim, uint8_t quote,
+__global__ void __launch_bounds__(BLOCK) k_csv_fields(const uint8_t* __restrict__ d, const uint32_t* __restrict__ ends, int64_t first_row, int64_t nrows, uint8_t delim, uint8_t quote, int esc,
                                                       const int32_t* __restrict__ wanted, int32_t nwanted, int32_t ncols_file, CsvField* __restrict__ out, uint32_t* flags) {
   const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (r >= nrows) return;
   const int64_t fr = first_row + r;
@@ -74,7 +82,7 @@ __global__ void __launch_bounds__(BLOCK) k_csv_fields(const uint8_t* __restrict_
     uint32_t s = p, len; bool quoted = false;
     if (p < e && d[p] == quote) {
       quoted = true; s = ++p;
-      for (;;) { if (p >= e) { bad = true; break; } if (d[p] == quote) { if (p + 1 < e && d[p + 1] == quote) { p += 2; continue; } break; } p++; }
+      for (;;) { if (p >= e) { bad = true; break; } if (esc >= 0 && d[p] == (uint8_t)esc && p + 1 < e) { p += 2; continue; } if (d[p] == quote) { if (p + 1 < e && d[p + 1] == quote) { p += 2; continue; } break; } p++; }
       len = p - s; if (!bad) p++;                                   // past the closing quote
       if (!bad && p < e && d[p] != delim) bad = true;
     } else { while (p < e && d[p] != delim) p++; len = p - s; }
@@ -219,16 +227,16 @@ __global__ void __launch_bounds__(BLOCK) k_csv_parse_f64(const uint8_t* __restri
   if (bad) atomicOr(flags, DFGPU_FLAG_CAST);
 }
 // Utf8: byte length after collapsing doubled quotes, then the copy
-__global__ void __launch_bounds__(BLOCK) k_csv_str_len(const uint8_t* __restrict__ d, const CsvField* __restrict__ f, int64_t n, uint8_t quote, uint32_t* __restrict__ lens) {
+__global__ void __launch_bounds__(BLOCK) k_csv_str_len(const uint8_t* __restrict__ d, const CsvField* __restrict__ f, int64_t n, uint8_t quote, int esc, uint32_t* __restrict__ lens) {
   const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (r >= n) return;
   const uint32_t raw = f[r].len, len = raw & 0x7FFFFFFFu; uint32_t out = len;
-  if (raw >> 31) { const uint8_t* s = d + f[r].start; for (uint32_t i = 0; i + 1 < len; i++) if (s[i] == quote && s[i + 1] == quote) { out--; i++; } }
+  if (raw >> 31) { const uint8_t* s = d + f[r].start; for (uint32_t i = 0; i + 1 < len; i++) if ((s[i] == quote && s[i + 1] == quote) || (esc >= 0 && s[i] == (uint8_t)esc)) { out--; i++; } }      // a doubled quote, or escape + byte, is one byte
   lens[r] = out;
 }
-__global__ void __launch_bounds__(BLOCK) k_csv_str_copy(const uint8_t* __restrict__ d, const CsvField* __restrict__ f, int64_t n, uint8_t quote, const int32_t* __restrict__ offsets, uint8_t* __restrict__ out) {
+__global__ void __launch_bounds__(BLOCK) k_csv_str_copy(const uint8_t* __restrict__ d, const CsvField* __restrict__ f, int64_t n, uint8_t quote, int esc, const int32_t* __restrict__ offsets, uint8_t* __restrict__ out) {
   const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (r >= n) return;
   const uint32_t raw = f[r].len, len = raw & 0x7FFFFFFFu; const uint8_t* s = d + f[r].start; uint8_t* o = out + offsets[r];
-  if (raw >> 31) { for (uint32_t i = 0; i < len; i++) { *o++ = s[i]; if (s[i] == quote && i + 1 < len && s[i + 1] == quote) i++; } }
+  if (raw >> 31) { for (uint32_t i = 0; i < len; i++) { if (esc >= 0 && s[i] == (uint8_t)esc && i + 1 < len) { *o++ = s[++i]; continue; } *o++ = s[i]; if (s[i] == quote && i + 1 < len && s[i + 1] == quote) i++; } }
   else for (uint32_t i = 0; i < len; i++) o[i] = s[i];
 }
 __global__ void k_csv_set_i32(int32_t* p, int32_t v) { *p = v; }
@@ -236,7 +244,7 @@ __global__ void k_csv_set_i32(int32_t* p, int32_t v) { *p = v; }
 }  // namespace dfgpu
 using namespace dfgpu;
 
-extern "C" dfgpu_status dfgpu_csv_read(dfgpu_ctx* ctx, const uint8_t* bytes, int64_t len, int32_t bytes_on_device, int32_t delimiter, int32_t quote, int32_t has_header, int32_t ncols_file,
+extern "C" dfgpu_status dfgpu_csv_read(dfgpu_ctx* ctx, const uint8_t* bytes, int64_t len, int32_t bytes_on_device, int32_t delimiter, int32_t quote, int32_t escape, int32_t has_header, int32_t ncols_file,
                                        const int32_t* columns, const int32_t* types /* 3 per projected column: type, precision, scale */, int32_t ncols, dfgpu_array** out, int64_t* out_rows) {
   return guard(ctx, [&] {
     if (!bytes || len < 0 || !out || ncols < 1 || !columns || !types || ncols_file < 1) fail(DFGPU_INVALID_ARGUMENT, "csv_read: bad argument");
@@ -246,7 +254,7 @@ extern "C" dfgpu_status dfgpu_csv_read(dfgpu_ctx* ctx, const uint8_t* bytes, int
     HIP_CHECK(hipSetDevice(ctx->device));
     BufferPtr img; const uint8_t* d = bytes;
     if (!bytes_on_device) { img = alloc_buffer(ctx, (size_t)len + 64); if (len) HIP_CHECK(hipMemcpyAsync(img->ptr, bytes, (size_t)len, hipMemcpyHostToDevice, ctx->stream)); d = (const uint8_t*)img->ptr; }
-    const uint8_t dl = (uint8_t)delimiter, qt = (uint8_t)quote;
+    const uint8_t dl = (uint8_t)delimiter, qt = (uint8_t)quote; const int esc = escape > 0 && escape < 256 && escape != quote ? escape : -1;
     // ---- records
     const int64_t nblk = (len + CSV_BLK - 1) / CSV_BLK;
     ArrayHolder ends;
@@ -254,9 +262,9 @@ extern "C" dfgpu_status dfgpu_csv_read(dfgpu_ctx* ctx, const uint8_t* bytes, int
       BufferPtr qc = alloc_buffer(ctx, (size_t)(nblk + 1) * 4), qb = alloc_buffer(ctx, (size_t)(nblk + 1) * 8), bits = alloc_buffer(ctx, (size_t)nblk * (CSV_BLK / 8) + 16, true);
       if (nblk) {
         const dim3 g(grid_for(nblk, BLOCK / 64));
-        hipLaunchKernelGGL(k_csv_quotes, g, dim3(BLOCK), 0, ctx->stream, d, len, qt, nblk, (uint32_t*)qc->ptr);
+        hipLaunchKernelGGL(k_csv_quotes, g, dim3(BLOCK), 0, ctx->stream, d, len, qt, esc, nblk, (uint32_t*)qc->ptr);
         exclusive_scan_u32(ctx, (const uint32_t*)qc->ptr, (uint64_t*)qb->ptr, nblk, nullptr);
-        hipLaunchKernelGGL(k_csv_rows, g, dim3(BLOCK), 0, ctx->stream, d, len, qt, nblk, (const uint64_t*)qb->ptr, (uint16_t*)bits->ptr, ctx->d_flags);
+        hipLaunchKernelGGL(k_csv_rows, g, dim3(BLOCK), 0, ctx->stream, d, len, qt, esc, nblk, (const uint64_t*)qb->ptr, (uint16_t*)bits->ptr, ctx->d_flags);
         KERNEL_CHECK();
       }
       ends.a = mask_to_indices_impl(ctx, (const uint64_t*)bits->ptr, len); }
@@ -266,7 +274,7 @@ extern "C" dfgpu_status dfgpu_csv_read(dfgpu_ctx* ctx, const uint8_t* bytes, int
     BufferPtr fields = alloc_buffer(ctx, std::max<size_t>((size_t)ncols * (size_t)nrows * sizeof(CsvField), 16));
     BufferPtr want = alloc_buffer(ctx, (size_t)ncols * 4 + 16); HIP_CHECK(hipMemcpyAsync(want->ptr, columns, (size_t)ncols * 4, hipMemcpyHostToDevice, ctx->stream));
     if (nrows) { KernelTimer kt(ctx, "csv_fields");
-      hipLaunchKernelGGL(k_csv_fields, dim3(grid_for(nrows, BLOCK)), dim3(BLOCK), 0, ctx->stream, d, (const uint32_t*)ends.get()->values->ptr, first, nrows, dl, qt, (const int32_t*)want->ptr, ncols, ncols_file, (CsvField*)fields->ptr, ctx->d_flags);
+      hipLaunchKernelGGL(k_csv_fields, dim3(grid_for(nrows, BLOCK)), dim3(BLOCK), 0, ctx->stream, d, (const uint32_t*)ends.get()->values->ptr, first, nrows, dl, qt, esc, (const int32_t*)want->ptr, ncols, ncols_file, (CsvField*)fields->ptr, ctx->d_flags);
       KERNEL_CHECK(); }
     // ---- values
     std::vector<ArrayHolder> res((size_t)ncols);
@@ -277,14 +285,14 @@ extern "C" dfgpu_status dfgpu_csv_read(dfgpu_ctx* ctx, const uint8_t* bytes, int
         ArrayHolder a(new_array(ctx, DFGPU_UTF8, nrows)); BufferPtr off = alloc_buffer(ctx, (size_t)(nrows + 1) * 4 + 16);
         uint64_t tot = 0;
         if (nrows) {
-          hipLaunchKernelGGL(k_csv_str_len, g, dim3(BLOCK), 0, ctx->stream, d, f, nrows, qt, (uint32_t*)off->ptr);
+          hipLaunchKernelGGL(k_csv_str_len, g, dim3(BLOCK), 0, ctx->stream, d, f, nrows, qt, esc, (uint32_t*)off->ptr);
           exclusive_scan_u32_inplace32(ctx, (uint32_t*)off->ptr, nrows, ctx->d_scratch64 + 41);
           tot = read_scratch(ctx, 41);
           if (tot > 0x7FFFFFFFull) fail(DFGPU_EXECUTION, "Arrow error: a Utf8 CSV column of %llu bytes overflows int32 offsets -- read a smaller byte range", (unsigned long long)tot);
         }
         hipLaunchKernelGGL(k_csv_set_i32, dim3(1), dim3(1), 0, ctx->stream, (int32_t*)off->ptr + nrows, (int32_t)tot);
         BufferPtr ch = alloc_buffer(ctx, std::max<size_t>((size_t)tot, 16));
-        if (nrows && tot) hipLaunchKernelGGL(k_csv_str_copy, g, dim3(BLOCK), 0, ctx->stream, d, f, nrows, qt, (const int32_t*)off->ptr, (uint8_t*)ch->ptr);
+        if (nrows && tot) hipLaunchKernelGGL(k_csv_str_copy, g, dim3(BLOCK), 0, ctx->stream, d, f, nrows, qt, esc, (const int32_t*)off->ptr, (uint8_t*)ch->ptr);
         a.get()->offsets = off; a.get()->values = ch; a.get()->values_bytes = (int64_t)tot; a.get()->null_count = 0;
         res[(size_t)c].a = a.release();
       } else {

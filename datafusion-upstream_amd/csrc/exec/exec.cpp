@@ -349,7 +349,7 @@ struct ParquetExec : Plan {
 // once, at plan time, into pieces of about `batch_bytes` that end on a record boundary outside quotes, the pieces are dealt to the partitions in contiguous runs and
 // every piece is one batch parsed on the device (dfgpu_csv_read).  The caller keeps the image alive while the plan lives.
 struct CsvExec : Plan {
-  const uint8_t* bytes = nullptr; int64_t len = 0; int32_t delim = ',', quote = '"', ncols_file = 0; bool header = true;
+  const uint8_t* bytes = nullptr; int64_t len = 0; int32_t delim = ',', quote = '"', escape = 0, ncols_file = 0; bool header = true;
   std::vector<int32_t> proj, types; SchemaPtr sch; int nparts = 1; std::vector<int64_t> cuts;      // piece i = [cuts[i], cuts[i + 1])
   const char* name() const override { return "CsvExec"; }
   PlanPtr fresh() const override { return shared_from_this(); }
@@ -357,7 +357,7 @@ struct CsvExec : Plan {
   int partitions() const override { return nparts; }
   void cut(int64_t batch_bytes) {
     cuts.assign(1, 0); bool inside = false; int64_t next = batch_bytes;
-    for (int64_t i = 0; i < len; i++) { const uint8_t c = bytes[i]; if (c == (uint8_t)quote) inside = !inside; else if (c == '\n' && !inside && i + 1 >= next && i + 1 < len) { cuts.push_back(i + 1); next = i + 1 + batch_bytes; } }
+    for (int64_t i = 0; i < len; i++) { const uint8_t c = bytes[i]; if (escape > 0 && c == (uint8_t)escape && inside && i + 1 < len) { i++; continue; } if (c == (uint8_t)quote) inside = !inside; else if (c == '\n' && !inside && i + 1 >= next && i + 1 < len) { cuts.push_back(i + 1); next = i + 1 + batch_bytes; } }
     cuts.push_back(len);
   }
   struct S : Stream {
@@ -366,7 +366,7 @@ struct CsvExec : Plan {
     bool next(Batch& out) override {
       if (next_piece >= end_piece) return false;
       const int i = next_piece++; std::vector<dfgpu_array*> cols(op->proj.size(), nullptr); int64_t rows = 0;
-      tc.check(dfgpu_csv_read(tc.ctx, op->bytes + op->cuts[(size_t)i], op->cuts[(size_t)i + 1] - op->cuts[(size_t)i], 0, op->delim, op->quote, i == 0 && op->header ? 1 : 0, op->ncols_file,
+      tc.check(dfgpu_csv_read(tc.ctx, op->bytes + op->cuts[(size_t)i], op->cuts[(size_t)i + 1] - op->cuts[(size_t)i], 0, op->delim, op->quote, op->escape, i == 0 && op->header ? 1 : 0, op->ncols_file,
                               op->proj.data(), op->types.data(), (int32_t)op->proj.size(), cols.data(), &rows));
       Batch b; b.schema = op->sch; b.base_rows = rows;
       for (auto* a : cols) b.cols.push_back(col_of(ArrayRef::adopt(a)));
@@ -1722,11 +1722,11 @@ dfgpu_status dfgpu_plan_parquet(dfgpu_parquet* file, const int32_t* columns, int
     *out = new dfgpu_plan{n};
   });
 }
-dfgpu_status dfgpu_plan_csv(const uint8_t* bytes, int64_t len, int32_t delimiter, int32_t quote, int32_t has_header, const char* const* names, const int32_t* types, int32_t ncols_file,
+dfgpu_status dfgpu_plan_csv(const uint8_t* bytes, int64_t len, int32_t delimiter, int32_t quote, int32_t escape, int32_t has_header, const char* const* names, const int32_t* types, int32_t ncols_file,
                             const int32_t* columns, int32_t ncols, int32_t npartitions, int64_t batch_bytes, dfgpu_plan** out) {
   return guard([&] {
     if ((!bytes && len) || len < 0 || !out || !names || !types || ncols_file < 1 || ncols < 1 || !columns || npartitions < 1) fail(DFGPU_INVALID_ARGUMENT, "plan_csv: bad argument");
-    auto n = std::make_shared<CsvExec>(); n->bytes = bytes; n->len = len; n->delim = delimiter; n->quote = quote; n->header = has_header != 0; n->ncols_file = ncols_file; n->nparts = npartitions;
+    auto n = std::make_shared<CsvExec>(); n->bytes = bytes; n->len = len; n->delim = delimiter; n->quote = quote; n->escape = escape; n->header = has_header != 0; n->ncols_file = ncols_file; n->nparts = npartitions;
     n->sch = std::make_shared<Schema>();
     for (int32_t i = 0; i < ncols; i++) {
       const int32_t c = columns[i];

@@ -433,11 +433,11 @@ class CsvExec(ExecutionPlan):
     [(name, DFGPU type, precision, scale)] of every file column.  The image is cut at record boundaries into pieces of ~batch_bytes, one batch each, dealt to
     `partitions` in contiguous runs (the reference's byte-range file groups, csv.rs:362-420)."""
 
-    def __init__(self, data: bytes, file_schema, projection=None, partitions: int = 1, has_header: bool = True, delimiter: str = ",", quote: str = '"', batch_bytes: int = 0):
+    def __init__(self, data: bytes, file_schema, projection=None, partitions: int = 1, has_header: bool = True, delimiter: str = ",", quote: str = '"', batch_bytes: int = 0, escape: Optional[str] = None):
         names = [f[0] for f in file_schema]
         self.data, self.file_schema = bytes(data) if not isinstance(data, bytes) else data, [tuple(f) for f in file_schema]
         self.projection = sorted(range(len(names)) if projection is None else [names.index(c) if isinstance(c, str) else int(c) for c in projection])
-        self.partitions, self.has_header, self.delimiter, self.quote, self.batch_bytes = partitions, has_header, delimiter, quote, batch_bytes
+        self.partitions, self.has_header, self.delimiter, self.quote, self.batch_bytes, self.escape = partitions, has_header, delimiter, quote, batch_bytes, escape
 
     def output_partitioning(self):
         return Partitioning.UnknownPartitioning(self.partitions)
@@ -450,7 +450,7 @@ class CsvExec(ExecutionPlan):
         names = (C.c_char_p * n)(*[f[0].encode() for f in self.file_schema])
         types = (C.c_int32 * (3 * n))(*[v for f in self.file_schema for v in f[1:4]])
         idx = (C.c_int32 * len(self.projection))(*self.projection)
-        _check(_lib().dfgpu_plan_csv(C.cast(C.c_char_p(self.data), C.c_void_p), len(self.data), ord(self.delimiter), ord(self.quote), 1 if self.has_header else 0, names, types, n,
+        _check(_lib().dfgpu_plan_csv(C.cast(C.c_char_p(self.data), C.c_void_p), len(self.data), ord(self.delimiter), ord(self.quote), ord(self.escape) if self.escape else 0, 1 if self.has_header else 0, names, types, n,
                                      idx, len(self.projection), self.partitions, self.batch_bytes, C.byref(out)))
         return self._new(out)
 

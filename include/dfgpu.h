@@ -449,8 +449,9 @@ DFGPU_API dfgpu_status dfgpu_parquet_read(dfgpu_ctx *ctx, dfgpu_parquet *file, i
  * of the wanted file columns, `types` = (DFGPU_* type, precision, scale) per wanted column -- Int8 .. UInt64, Float64 (inputs of up to 15 significant digits and exponents of
  * at most 22: the exactly rounded path; longer ones raise an error instead of a guess), Boolean, Date32 (YYYY-MM-DD), Decimal128, Utf8.  A field that does not parse as its
  * column's type, a record with too few fields or broken quoting fail the call with DFGPU_EXECUTION.  `bytes` is the file image in host memory, or already in HBM
- * (bytes_on_device = 1); at most 4 GB per call.  has_header = 1 skips the first record.  out_rows (optional) = records read. */
-DFGPU_API dfgpu_status dfgpu_csv_read(dfgpu_ctx *ctx, const uint8_t *bytes, int64_t len, int32_t bytes_on_device, int32_t delimiter, int32_t quote, int32_t has_header, int32_t ncols_file,
+ * (bytes_on_device = 1); at most 4 GB per call.  escape (0 = none; CsvExec::escape, csv.rs:59, :304): inside a quoted field `escape` followed by any byte stands for that byte.
+ * has_header = 1 skips the first record.  out_rows (optional) = records read. */
+DFGPU_API dfgpu_status dfgpu_csv_read(dfgpu_ctx *ctx, const uint8_t *bytes, int64_t len, int32_t bytes_on_device, int32_t delimiter, int32_t quote, int32_t escape, int32_t has_header, int32_t ncols_file,
                                       const int32_t *columns, const int32_t *types, int32_t ncols, dfgpu_array **out, int64_t *out_rows);
 
 #ifdef __cplusplus

@@ -68,7 +68,7 @@ DFGPU_API dfgpu_status dfgpu_plan_parquet(dfgpu_parquet *file, const int32_t *co
  * schema: names[ncols_file], types[3 * ncols_file] = (DFGPU type, precision, scale) of EVERY file column, columns[ncols] = the projection (ascending file column
  * indices).  The image is cut at record boundaries into pieces of about batch_bytes (0 = 256 MiB; <= 4 GB) -- one batch each, parsed on the device by
  * dfgpu_csv_read -- and the pieces are dealt to npartitions in contiguous runs (the byte-range file groups of FileScanConfig, csv.rs:362-420). */
-DFGPU_API dfgpu_status dfgpu_plan_csv(const uint8_t *bytes, int64_t len, int32_t delimiter, int32_t quote, int32_t has_header, const char *const *names, const int32_t *types,
+DFGPU_API dfgpu_status dfgpu_plan_csv(const uint8_t *bytes, int64_t len, int32_t delimiter, int32_t quote, int32_t escape, int32_t has_header, const char *const *names, const int32_t *types,
                                       int32_t ncols_file, const int32_t *columns, int32_t ncols, int32_t npartitions, int64_t batch_bytes, dfgpu_plan **out);
 DFGPU_API dfgpu_status dfgpu_plan_parquet_prune(dfgpu_plan *parquet_exec, int32_t column, int64_t min_value, int64_t max_value);
 DFGPU_API int64_t dfgpu_plan_parquet_pruned(const dfgpu_plan *parquet_exec);

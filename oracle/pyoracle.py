@@ -600,10 +600,10 @@ def group_ordering_emits(batches: Sequence[Sequence], order_indices: Optional[Se
 
 
 # ------------------------------------------------------------------ CSV records (arrow-csv, arrow-rs 50 -- not part of the reference tree; restated from its documented rules)
-def csv_records(data: bytes, delimiter: str = ",", quote: str = '"', has_header: bool = True):
+def csv_records(data: bytes, delimiter: str = ",", quote: str = '"', has_header: bool = True, escape: Optional[str] = None):
     """Records of a delimited text image as lists of (text, quoted) fields: RFC 4180 quoting (a doubled quote inside quotes is one quote; delimiters and line feeds inside
     quotes are data), LF or CRLF record ends, blank lines skipped, a last record without a line feed counts.  Plain Python, byte by byte: small inputs only."""
-    d, q = ord(delimiter), ord(quote)
+    d, q, esc = ord(delimiter), ord(quote), (ord(escape) if escape else -1)
     recs, fields, cur, quoted, inside = [], [], bytearray(), False, False
 
     def end_field():
@@ -621,7 +621,9 @@ def csv_records(data: bytes, delimiter: str = ",", quote: str = '"', has_header:
     while i < n:
         c = data[i]
         if inside:
-            if c == q and i + 1 < n and data[i + 1] == q:
+            if c == esc and i + 1 < n:                             # CsvExec::escape: inside quotes, escape + byte is that byte
+                cur.append(data[i + 1]); i += 1
+            elif c == q and i + 1 < n and data[i + 1] == q:
                 cur.append(q); i += 1
             elif c == q:
                 inside = False

@@ -49,10 +49,10 @@ extern "C" {
     pub fn dfgpu_parquet_read(ctx: *mut dfgpu_ctx, file: *mut dfgpu_parquet, first_row_group: i32, num_row_groups: i32, columns: *const i32, ncols: i32, out: *mut *mut dfgpu_array) -> i32;
     // ---- include/dfgpu_exec.h
     pub fn dfgpu_sort_to_indices_keys(ctx: *mut dfgpu_ctx, cols: *const *const dfgpu_array, descending: *const u8, nulls_first: *const u8, k: i32, fetch: i64, out: *mut *mut dfgpu_array, out_sorted: *mut *mut dfgpu_array) -> i32;
-    pub fn dfgpu_csv_read(ctx: *mut dfgpu_ctx, bytes: *const u8, len: i64, bytes_on_device: i32, delimiter: i32, quote: i32, has_header: i32, ncols_file: i32, columns: *const i32, types: *const i32, ncols: i32, out: *mut *mut dfgpu_array, out_rows: *mut i64) -> i32;
+    pub fn dfgpu_csv_read(ctx: *mut dfgpu_ctx, bytes: *const u8, len: i64, bytes_on_device: i32, delimiter: i32, quote: i32, escape: i32, has_header: i32, ncols_file: i32, columns: *const i32, types: *const i32, ncols: i32, out: *mut *mut dfgpu_array, out_rows: *mut i64) -> i32;
     pub fn dfgpu_plan_aggregate_input_order(aggregate: *mut dfgpu_plan, input_order_mode: i32, order_indices: *const i32, n: i32) -> i32;
     pub fn dfgpu_plan_parquet(file: *mut dfgpu_parquet, columns: *const i32, ncols: i32, npartitions: i32, row_groups_per_batch: i32, out: *mut *mut dfgpu_plan) -> i32;
-    pub fn dfgpu_plan_csv(bytes: *const u8, len: i64, delimiter: i32, quote: i32, has_header: i32, names: *const *const c_char, types: *const i32, ncols_file: i32, columns: *const i32, ncols: i32, npartitions: i32, batch_bytes: i64, out: *mut *mut dfgpu_plan) -> i32;
+    pub fn dfgpu_plan_csv(bytes: *const u8, len: i64, delimiter: i32, quote: i32, escape: i32, has_header: i32, names: *const *const c_char, types: *const i32, ncols_file: i32, columns: *const i32, ncols: i32, npartitions: i32, batch_bytes: i64, out: *mut *mut dfgpu_plan) -> i32;
     pub fn dfgpu_plan_parquet_prune(parquet_exec: *mut dfgpu_plan, column: i32, min_value: i64, max_value: i64) -> i32;
     pub fn dfgpu_plan_nested_loop_join(left: *const dfgpu_plan, right: *const dfgpu_plan, filter: *const dfgpu_expr, filter_sides: *const i32, filter_indices: *const i32,
                                        nfilter_cols: i32, join_type: i32, out: *mut *mut dfgpu_plan) -> i32;

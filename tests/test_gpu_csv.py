@@ -54,27 +54,27 @@ def dfgpu_schema(fields):
     return out
 
 
-def reference_read(data: bytes, fields, delimiter=",", has_header=True, include=None):
+def reference_read(data: bytes, fields, delimiter=",", has_header=True, include=None, escape=None):
     ro = pcsv.ReadOptions(column_names=None if has_header else [n for n, _ in fields])
-    po = pcsv.ParseOptions(delimiter=delimiter, newlines_in_values=True)
+    po = pcsv.ParseOptions(delimiter=delimiter, newlines_in_values=True, escape_char=escape or False)
     co = pcsv.ConvertOptions(column_types=dict(fields), null_values=[""], strings_can_be_null=False, quoted_strings_can_be_null=False, true_values=["true", "TRUE", "True"], false_values=["false", "FALSE", "False"],
                              include_columns=include)
     return pcsv.read_csv(io.BytesIO(data), read_options=ro, parse_options=po, convert_options=co)
 
 
-def check(ctx, data: bytes, fields, delimiter=",", has_header=True, projection=None, on_device=False):
+def check(ctx, data: bytes, fields, delimiter=",", has_header=True, projection=None, on_device=False, escape=None):
     from dfgpu.csv import read_csv
     import torch
     names = [n for n, _ in fields]
-    want = reference_read(data, fields, delimiter, has_header, include=None if projection is None else sorted(projection, key=names.index))
+    want = reference_read(data, fields, delimiter, has_header, include=None if projection is None else sorted(projection, key=names.index), escape=escape)
     src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda() if on_device else data
-    got = read_csv(ctx, src, dfgpu_schema(fields), projection=projection, delimiter=delimiter, has_header=has_header, on_device=on_device)
+    got = read_csv(ctx, src, dfgpu_schema(fields), projection=projection, delimiter=delimiter, has_header=has_header, on_device=on_device, escape=escape)
     assert len(got) == want.num_columns
     for a, name in zip(got, want.column_names):
         same_column(a.to_arrow(), want[name], name)
     if len(data) <= 65536:                  # small inputs: also against the oracle's restatement of the record rules (plain Python; pinned on pyarrow in test_oracle_csv.py)
         from oracle import pyoracle as po
-        recs = po.csv_records(data, delimiter, has_header=has_header)
+        recs = po.csv_records(data, delimiter, has_header=has_header, escape=escape)
         for a, name in zip(got, want.column_names):
             same_column(a.to_arrow(), po.csv_column(recs, names.index(name), dict(fields)[name]), name + " (oracle)")
     return want.num_rows
@@ -205,3 +205,24 @@ def test_csv_exec_edge_files(ctx):
             assert sum(b.num_rows for b in out) == rows, (data, parts)
     got = pa.concat_tables([b.to_arrow() for b in ops.CsvExec(b"a,b\n1,x\n2,y\n", sch, batch_bytes=4).execute(0, tc)])
     assert got["a"].to_pylist() == [1, 2] and got["b"].to_pylist() == ["x", "y"]
+
+
+def test_escape_character(ctx):
+    """CsvExec::escape (csv.rs:59, :304): the reference's escape.csv (core/tests/data, quotes escaped by a backslash) and generated records with escaped quotes, escaped
+    backslashes, an escaped quote in front of the closing quote, escapes next to doubled quotes, and escapes across the 1 KB blocks of the record pass."""
+    from dfgpu import physical_plan as ops, capi
+    data = open(os.path.join(HERE, "data_escape.csv"), "rb").read()
+    fields = [("c1", S), ("c2", S)]
+    assert check(ctx, data, fields, escape="\\") == 10
+    rows = [b'1,"a\\"b",x', b'2,"back\\\\slash",y', b'3,"ends with quote\\"",z', b'4,"both \\" and """,w', b'5,"line\nfeed \\" inside",v', b'6,plain,u']
+    rows += [b'%d,"%s\\"%s",t' % (i, b"p" * (i % 700), b"q" * (i % 13)) for i in range(7, 400)]
+    data = b"k,s,t\n" + b"\n".join(rows) + b"\n"
+    fields = [("k", I64), ("s", S), ("t", S)]
+    assert check(ctx, data, fields, escape="\\") == len(rows)
+    check(ctx, data, fields, escape="\\", on_device=True, projection=["s"])
+    # through CsvExec, cut into small pieces
+    sch = [("k", capi.INT64, 0, 0), ("s", capi.UTF8, 0, 0), ("t", capi.UTF8, 0, 0)]
+    tc = ops.TaskContext(ctx, 8192)
+    out = pa.concat_tables([b.to_arrow() for b in ops.CsvExec(data, sch, batch_bytes=4096, escape="\\").execute(0, tc)])
+    want = reference_read(data, fields, escape="\\")
+    assert out["s"].combine_chunks().equals(want["s"].combine_chunks()) and out["k"].combine_chunks().equals(want["k"].combine_chunks())

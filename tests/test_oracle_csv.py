@@ -41,3 +41,11 @@ def test_quoting_crlf_blank_lines_and_missing_final_newline():
             data = b"k,s,f" + eol + eol.join(rows) + tail
             columns_equal(data, fields)
             columns_equal(eol + data + eol + eol, fields)
+
+
+def test_escape_csv_file():
+    data = open(os.path.join(HERE, "data_escape.csv"), "rb").read()
+    want = reference_read(data, [("c1", pa.string()), ("c2", pa.string())], escape="\\")
+    recs = po.csv_records(data, escape="\\")
+    assert po.csv_column(recs, 0, pa.string()).equals(want["c1"].combine_chunks()) and po.csv_column(recs, 1, pa.string()).equals(want["c2"].combine_chunks())
+    assert recs[0][1][0] == 'value"0'
