@@ -377,7 +377,7 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
       RpCols c2{}; c2.n = 2 + plan.n_acc;
       c2.c[0] = RpCol{ pkey->ptr, pkey2->ptr, 8, RP_RAW, 0 }; c2.c[1] = RpCol{ prow->ptr, prow2->ptr, 4, RP_RAW, 0 };
       for (int c = 0; c < plan.n_acc; c++) { pval2[(size_t)c] = alloc_buffer(ctx, (size_t)n * 8); c2.c[2 + c] = RpCol{ pval[(size_t)c]->ptr, pval2[(size_t)c]->ptr, 8, RP_RAW, 0 }; }
-      (void)rp_partition(ctx, RpHashU64Low{ (const uint64_t*)pkey->ptr }, m1, (uint32_t)P2, c2, true, ctx->d_scratch64 + 10, "pa_hist2", "pa_scan2", "pa_scatter2");
+      (void)rp_partition(ctx, RpHashU64Low{ (const uint64_t*)pkey->ptr }, m1, (uint32_t)P2, c2, true, ctx->d_scratch64 + 10, "pa_hist2", "pa_scan2", "pa_scatter2", true, true);
       pkey = pkey2; prow = prow2; for (int c = 0; c < plan.n_acc; c++) { pval[(size_t)c] = pval2[(size_t)c]; plan.val[c] = (const uint64_t*)pval[(size_t)c]->ptr; }
       HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 11, 0, 8, ctx->stream));
       r.starts = alloc_buffer(ctx, (size_t)(P + 1) * 4); r.P = (uint32_t)P;

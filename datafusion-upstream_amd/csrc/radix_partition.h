@@ -285,14 +285,15 @@ struct RpResult { uint32_t P = 0; int64_t ntiles = 0; BufferPtr starts; };     /
 // d_total: device u64 that receives the number of rows moved.  timer names: <prefix>_hist / _scan / _scatter.
 template <typename H>
 static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const RpCols& cols, bool stable, uint64_t* d_total,
-                             const char* t_hist, const char* t_scan, const char* t_scatter, bool want_starts = true) {
+                             const char* t_hist, const char* t_scan, const char* t_scatter, bool want_starts = true, bool wide_rows = false) {
   if (P < 1 || P > RP_MAX_P) fail(DFGPU_INTERNAL, "rp_partition: %u partitions (1..%u supported)", P, RP_MAX_P);
   if (stable && P > RP_MAX_STABLE_P) fail(DFGPU_INTERNAL, "rp_partition: stable order supports up to %u partitions, got %u", RP_MAX_STABLE_P, P);
   if (n > 0xFFFFFFF0ll) fail(DFGPU_NOT_IMPLEMENTED, "partitioning above 2^32-16 rows");
   RpResult r; r.P = P;
   if (want_starts) r.starts = alloc_buffer(ctx, (size_t)(P + 1) * 4);       // the passes of a sort only need the rows moved
   const bool big = P > 512 && P <= 2048 && !stable;        // 8192-row tiles halve the count matrix; 4096-row tiles give more workgroups per CU (and leave LDS for P > 2048)
-  const bool small_wg = stable && P > 16;                  // stable with many partitions: 256-thread workgroups (the count table is 64 P bytes) keep several on a CU;
+  const bool small_wg = stable && P > 16 && !wide_rows;    // wide_rows: several columns move per row (the aggregation's second level: 20 B) -- there the 4096-row tile's longer runs win (1.65 -> 1.44 ms),
+                                                           // while the sort's single 8-byte column is faster with more workgroups per CU (3.2 against 3.7 ms)                  // stable with many partitions: 256-thread workgroups (the count table is 64 P bytes) keep several on a CU;
   const int nt = small_wg ? 256 : big ? 1024 : 512, tile = nt * RP_R;      // few partitions want the longer runs of a 4096-row tile
   const int64_t ntiles = n ? (n + tile - 1) / tile : 1; r.ntiles = ntiles;
   int G = P <= 2048 ? RP_G : 4; while (G > 1 && (ntiles + G - 1) / G < 1024) G >>= 1;      // a small input still wants ~1000 histogram workgroups (a few dozen of them counting 16 tiles each was 0.04 ms per sort pass of 1 M rows)
