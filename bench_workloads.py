@@ -324,31 +324,34 @@ def run(args, ctx=None, emit=True):
         torch.cuda.synchronize()
         batch = ops.RecordBatch.from_arrays(ctx, ["l_orderkey", "l_extendedprice", "l_discount", "l_shipdate"],
                                             [ctx.wrap_tensor(l_orderkey, capi.INT64), ctx.wrap_tensor(price, capi.DECIMAL128, 15, 2), ctx.wrap_tensor(disc, capi.DECIMAL128, 15, 2), ctx.wrap_tensor(sdate, capi.DATE32)])
-        nparts = 8
-        plan = ops.RepartitionExec(ops.MemoryExec([[batch]], batch.schema), ops.Partitioning.Hash([C("l_orderkey", 0)], nparts))
+        for nparts in ((8, 64) if not __import__("os").environ.get("DFGPU_BENCH_NPARTS") else (int(__import__("os").environ["DFGPU_BENCH_NPARTS"]),)):                      # 8: one node's GPUs; 64: a target_partitions-sized fan-out (the LDS-staged stable scatter)
+            if want and "partition" not in want and not any(w in "partition_hash_%d" % nparts for w in want):
+                continue
+            plan = ops.RepartitionExec(ops.MemoryExec([[batch]], batch.schema), ops.Partitioning.Hash([C("l_orderkey", 0)], nparts))
 
-        def timed_partition():
-            def step():
-                p2 = ops.with_fresh_state(plan); rows = 0
-                with ctx.deferred_flags():
-                    for d in range(nparts):
-                        for b in p2.execute(d, tc):
-                            b.columns; rows += b.num_rows
-                ctx.synchronize()
-                return rows
-            for _ in range(max(args.warmup, 1)):
-                step()
-            ctx.profile_enable(True); ctx.profile_read(); step(); pr = ctx.profile_read(); ctx.profile_enable(False)
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                rows = step()
-            dt = (time.perf_counter() - t0) / args.steps
-            kern = {k: round(v[1], 3) for k, v in sorted(pr.items(), key=lambda kv: -kv[1][1]) if not k.startswith("sync:")}
-            return dt, rows, kern, sum(v[0] for k, v in pr.items() if k.startswith("sync:"))
-        dt, rows, kern, syncs = timed_partition()
-        assert rows == n
-        report("partition_hash_8", dt, n, rows, 2 * (8 + 16 + 16 + 4), kern, syncs, {"partitions": nparts})
-        del price, disc, sdate, batch, plan
+            def timed_partition():
+                def step():
+                    p2 = ops.with_fresh_state(plan); rows = 0
+                    with ctx.deferred_flags():
+                        for d in range(nparts):
+                            for b in p2.execute(d, tc):
+                                b.columns; rows += b.num_rows
+                    ctx.synchronize()
+                    return rows
+                for _ in range(max(args.warmup, 1)):
+                    step()
+                ctx.profile_enable(True); ctx.profile_read(); step(); pr = ctx.profile_read(); ctx.profile_enable(False)
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    rows = step()
+                dt = (time.perf_counter() - t0) / args.steps
+                kern = {k: round(v[1], 3) for k, v in sorted(pr.items(), key=lambda kv: -kv[1][1]) if not k.startswith("sync:")}
+                return dt, rows, kern, sum(v[0] for k, v in pr.items() if k.startswith("sync:"))
+            dt, rows, kern, syncs = timed_partition()
+            assert rows == n
+            report("partition_hash_%d" % nparts, dt, n, rows, 2 * (8 + 16 + 16 + 4), kern, syncs, {"partitions": nparts})
+            del plan
+        del price, disc, sdate, batch
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ ParquetExec: lineitem-shaped file (written by pyarrow here) -> columns in HBM

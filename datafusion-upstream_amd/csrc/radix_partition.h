@@ -215,16 +215,16 @@ __global__ void __launch_bounds__(NT) k_rp_scatter(H hs, int64_t n, uint32_t P, 
 // offset, the counts of its partition in the (slab, wave) pieces in front of it (a small LDS table) and its rank among the lanes of its wave (ballots); each lane
 // then copies its row's columns straight from source to slot.  A wave's 64 rows land in at most P runs of consecutive slots (~64 / P rows each), reads are fully
 // coalesced, 16-byte columns move in one piece.  Stable by construction.
-template <int NT, typename H>
+template <int NT, int DP, typename H>          // DP: most partitions this instance takes (16 or 256: the (slab, wave, partition) count table is DP wide)
 __global__ void __launch_bounds__(NT) k_rp_scatter_direct(H hs, int64_t n, uint32_t P, int64_t ntiles, const uint32_t* goff, RpCols cols) {
   constexpr int TILE = NT * RP_R, NW = NT / WAVE;
-  __shared__ uint16_t wcnt[RP_R * NW * 16]; __shared__ uint32_t tbase[16]; __shared__ RpCol scol[RP_MAX_COLS];
+  __shared__ uint16_t wcnt[RP_R * NW * DP]; __shared__ uint32_t tbase[DP]; __shared__ RpCol scol[RP_MAX_COLS];
 #pragma unroll
   for (int c = 0; c < RP_MAX_COLS; c++) if ((int)threadIdx.x == c) scol[c] = cols.c[c];
   const int64_t per = (ntiles + 7) / 8, t = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (t >= ntiles || (int64_t)(blockIdx.x >> 3) >= per) return;
   const int64_t base = t * (int64_t)TILE; const int wave = threadIdx.x >> 6;
-  for (int x = threadIdx.x; x < RP_R * NW * 16; x += NT) wcnt[x] = 0;
+  for (int x = threadIdx.x; x < RP_R * NW * DP; x += NT) wcnt[x] = 0;
   if (threadIdx.x < P) tbase[threadIdx.x] = goff[(int64_t)threadIdx.x * ntiles + t];
   __syncthreads();
   uint32_t pid[RP_R], rk[RP_R]; bool on[RP_R]; uint64_t hk[RP_R];
@@ -235,14 +235,14 @@ __global__ void __launch_bounds__(NT) k_rp_scatter_direct(H hs, int64_t n, uint3
     uint64_t peers = ballot64(on[q]);
     for (uint32_t b = 1; b < P; b <<= 1) { uint64_t mb = ballot64((pid[q] & b) != 0); peers &= (pid[q] & b) ? mb : ~mb; }
     rk[q] = (uint32_t)__popcll(peers & lanemask_lt());
-    if (on[q] && rk[q] == 0) wcnt[((size_t)q * NW + wave) * 16 + pid[q]] = (uint16_t)__popcll(peers);
+    if (on[q] && rk[q] == 0) wcnt[((size_t)q * NW + wave) * DP + pid[q]] = (uint16_t)__popcll(peers);
   }
   __syncthreads();
-  if (threadIdx.x < P) { uint32_t run = 0; for (int x = 0; x < RP_R * NW; x++) { uint16_t c = wcnt[(size_t)x * 16 + threadIdx.x]; wcnt[(size_t)x * 16 + threadIdx.x] = (uint16_t)run; run += c; } }
+  if (threadIdx.x < P) { uint32_t run = 0; for (int x = 0; x < RP_R * NW; x++) { uint16_t c = wcnt[(size_t)x * DP + threadIdx.x]; wcnt[(size_t)x * DP + threadIdx.x] = (uint16_t)run; run += c; } }
   __syncthreads();
   int64_t pos[RP_R];
 #pragma unroll
-  for (int q = 0; q < RP_R; q++) pos[q] = on[q] ? (int64_t)(tbase[pid[q]] + (uint32_t)wcnt[((size_t)q * NW + wave) * 16 + pid[q]] + rk[q]) : 0;
+  for (int q = 0; q < RP_R; q++) pos[q] = on[q] ? (int64_t)(tbase[pid[q]] + (uint32_t)wcnt[((size_t)q * NW + wave) * DP + pid[q]] + rk[q]) : 0;
   if (cols.rowid_dst) {
 #pragma unroll
     for (int q = 0; q < RP_R; q++) if (on[q]) cols.rowid_dst[pos[q]] = (uint32_t)(base + (int64_t)q * NT + threadIdx.x);
@@ -292,7 +292,12 @@ static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const 
   RpResult r; r.P = P;
   if (want_starts) r.starts = alloc_buffer(ctx, (size_t)(P + 1) * 4);       // the passes of a sort only need the rows moved
   const bool big = P > 512 && P <= 2048 && !stable;        // 8192-row tiles halve the count matrix; 4096-row tiles give more workgroups per CU (and leave LDS for P > 2048)
-  const bool small_wg = stable && P > 16 && !wide_rows;    // wide_rows: several columns move per row (the aggregation's second level: 20 B) -- there the 4096-row tile's longer runs win (1.65 -> 1.44 ms),
+  // the LDS-free scatter: always for <= 16 partitions; up to 256 when a row is one column (a sort pass: 3.0 against 3.2 ms per 100 M rows) or holds a 16-byte column (the staged
+  // scatter moves those as two halves: 600 M rows x 44 B into 64 / 128 / 256: 16.9 / 18.0 / 22.5 ms against 22.8 / 23.9 / 25.9); rows of several narrow columns (the aggregation's
+  // (key, row, value): 2.7 against 1.4 ms) stay with the staged one
+  bool wide16 = false; for (int c = 0; c < cols.n; c++) wide16 |= cols.c[c].width == 16;
+  const bool direct = stable && !cols.pack12_dst && (P <= 16 || (P <= 256 && !wide_rows && (cols.n <= 1 || wide16)));
+  const bool small_wg = stable && P > 16 && !wide_rows && !direct;    // wide_rows: several columns move per row (the aggregation's second level: 20 B) -- there the 4096-row tile's longer runs win (1.65 -> 1.44 ms),
                                                            // while the sort's single 8-byte column is faster with more workgroups per CU (3.2 against 3.7 ms)                  // stable with many partitions: 256-thread workgroups (the count table is 64 P bytes) keep several on a CU;
   const int nt = small_wg ? 256 : big ? 1024 : 512, tile = nt * RP_R;      // few partitions want the longer runs of a 4096-row tile
   const int64_t ntiles = n ? (n + tile - 1) / tile : 1; r.ntiles = ntiles;
@@ -314,7 +319,8 @@ static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const 
     const unsigned grid = (unsigned)(((ntiles + 7) / 8) * 8);
 #define RP_LAUNCH(NT_, ST_) { static bool once = false; if (!once) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_scatter<NT_, ST_, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); once = true; } \
       hipLaunchKernelGGL((k_rp_scatter<NT_, ST_, H>), dim3(grid), dim3(NT_), rp_scatter_lds<NT_>(P, ST_), ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols); }
-    if (stable && P <= 16 && !cols.pack12_dst && !small_wg) hipLaunchKernelGGL((k_rp_scatter_direct<512, H>), dim3(grid), dim3(512), 0, ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols);
+    if (direct && P <= 16) hipLaunchKernelGGL((k_rp_scatter_direct<512, 16, H>), dim3(grid), dim3(512), 0, ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols);
+    else if (direct) hipLaunchKernelGGL((k_rp_scatter_direct<512, 256, H>), dim3(grid), dim3(512), 0, ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols);
     else if (small_wg) RP_LAUNCH(256, true) else if (stable) RP_LAUNCH(512, true) else if (big) RP_LAUNCH(1024, false) else RP_LAUNCH(512, false)
 #undef RP_LAUNCH
     KERNEL_CHECK(); }
