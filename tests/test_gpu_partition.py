@@ -36,15 +36,21 @@ def test_partition_columns_equal_take_through_oracle_indices(ctx, nparts, n):
             assert o is None                             # nullable / Utf8 / lazy: through the indices
 
 
-def test_partition_columns_with_fused_selection(ctx):
-    n, nparts = 50000, 8
+@pytest.mark.parametrize("wide", [False, True], ids=["narrow-columns", "with-decimal128"])
+@pytest.mark.parametrize("nparts", [8, 64, 200])
+def test_partition_columns_with_fused_selection(ctx, nparts, wide):
+    """Selection fused into the partition pass, through both scatters: the LDS-free one (<= 16 partitions, or <= 256 when a 16-byte column moves) and the LDS-staged one."""
+    import decimal
+    n = 50000
     key = pa.array(RNG.integers(0, 10**9, n)); v = pa.array(RNG.integers(0, 10**6, n)); mask = RNG.random(n) < 0.3
-    outs, idx, counts = ctx.partition_columns([ctx.from_arrow(key)], nparts, [ctx.from_arrow(v)], mask=ctx.from_arrow(pa.array(mask)))
+    extra = [pa.array([decimal.Decimal(int(x)).scaleb(-2) for x in RNG.integers(-10**12, 10**12, n)], type=pa.decimal128(15, 2))] if wide else [pa.array(RNG.integers(0, 100, n).astype(np.int8))]
+    outs, idx, counts = ctx.partition_columns([ctx.from_arrow(key)], nparts, [ctx.from_arrow(v), ctx.from_arrow(extra[0])], mask=ctx.from_arrow(pa.array(mask)))
     sel = np.flatnonzero(mask)
     oidx, ocounts = po.hash_partition([key.take(pa.array(sel))], nparts)
     assert counts == ocounts.tolist()
     assert np.array_equal(idx.to_numpy(), sel[oidx])      # original row numbers of the selected rows
     assert outs[0].to_arrow().equals(v.take(pa.array(sel[oidx])))
+    assert outs[1].to_arrow().equals(extra[0].take(pa.array(sel[oidx])))
 
 
 def test_repartition_exec_uses_the_one_pass_kernels_and_conserves_rows(ctx, task_ctx):
