@@ -4,12 +4,14 @@
 
 namespace dfgpu {
 // radix-partitioned build side (pjoin.hip): (key widened to 64 bits, original build row) grouped by partition of the key hash, sized so
-// that one partition's open-addressing table fits the 160 KB LDS of a CU
+// that one partition's open-addressing table fits 64 KB of LDS (two workgroups per CU; 128 KB at most)
 struct PartitionedBuild {
   uint32_t P = 0; int sbits = 0;            // partitions; log2 of the LDS table slots
   int64_t rows = 0;                         // selected, non-NULL build rows
-  BufferPtr recs;                           // RpRec12 {key lo, key hi, build row}[rows], partition-major
-  BufferPtr starts;                         // u32[P + 1]
+  BufferPtr recs;                           // RpRec12 {key lo, key hi, ref}[..], partition-major: ref = build row (unique keys) or group number (dups)
+  BufferPtr starts;                         // u32[P + 1] over recs
+  bool dups = false;                        // a build key repeats: recs holds one record per DISTINCT key, the rows of a key are a CSR
+  BufferPtr grp_start, grp_cnt, csr_rows;   // u32[groups] into csr_rows / rows of the group; u32[rows] build rows, ascending inside a group
 };
 }  // namespace dfgpu
 

@@ -1,40 +1,171 @@
-// pjoin.hip -- radix-partitioned hash join for unsorted / sparse integer keys: build + probe of every partition out of LDS.
+// pjoin.hip -- radix-partitioned hash join for unsorted integer keys: build + probe of every partition out of LDS.
 //
 // Reference semantics: JoinHashMap build + lookup_join_hashmap (physical-plan/src/joins/utils.rs:121-229, hash_join.rs:1024-1118);
-// the (build, probe) pairs come back ordered by probe row exactly as the reference emits them.
+// the (build, probe) pairs come back ordered by probe row, then build row, exactly as the reference emits them.
 //
 // Why: the global open-addressing table of join.hip costs every probe row a random 64-B sector out of a table far larger than L2
-// (150 M probes of a 15 M-row build: ~53 G sectors/s on MI355X whatever the table's size beyond L2, i.e. >= 2.8 ms, measured 4.5 ms with
-// the key verification; profiles/experiments/random_gather_microbench.hip).  Here both sides are split by hash bits (radix_partition.h:
-// one pass, LDS-staged write combining) into P partitions of <= 16 K build rows, so that one partition's table -- 32 K four-byte slots
-// (tag : 17 | partition-local build row : 14) -- sits in the 160 KB LDS of a CU.  One workgroup per partition builds the table from the
-// partition's (key, row) records and streams the partition's probe rows against it; a tag match is verified against the build record
-// (exact: full 64-bit key compare), which for a hit also yields the original build row.
+// (150 M probes of a 15 M-row build: ~53 G sectors/s on MI355X whatever the table's size beyond L2, i.e. >= 2.8 ms).  Here both sides are
+// split by hash bits into P <= 2048 partitions so that one partition's table -- 16 K four-byte slots (tag : 17 | partition-local index : 14)
+// -- sits in 64 KB of LDS, two workgroups per CU.
 //
-// Order: partitioning destroys probe order, so a hit stores found[probe row] = build row (4-byte scatter into an array pre-set to NONE) and an
-// order-preserving compaction of found[] emits the pairs: output order is a function of the input only.  (Tried instead: hits written out
-// per partition, re-partitioned by probe-row range and ranked inside LDS per range -- 1.29 ms against 0.95 ms for 30 M hits out of 150 M rows.)
-// Build keys must be unique (every PK-FK join); a repeated build key, a partition beyond the table's capacity (adversarial hash skew) or an
-// unsupported key type leave the table to join.hip's general path.
+// Round 3 pipeline (profiles/experiments/pjoin2_microbench.hip holds the measurements that chose it; 15 M x 150 M rows, 20 % match):
+//   partition   k_pj_hist     per chunk of 16 tiles (8192 rows each): LDS histogram in u16 counters with the next tile's keys in flight; writes
+//                             pre[tile][p] = rows of partition p in the chunk's tiles in front of this tile (TILE-major: a tile reads its 2048
+//                             offsets as 8 KB of coalesced loads -- the partition-major matrix cost 2048 separate 64-B lines per tile) and
+//                             tot[chunk][p]; no device-wide scan of the 37 M-cell matrix, only the 2 M chunk totals are prefixed (0.49 -> 0.30 ms)
+//               k_pj_scatter  counting sort of the tile in LDS, staged in two rounds of half a tile (64 KB of LDS: two workgroups per CU, one
+//                             loading while the other writes), 12-byte records (key, row) written as runs (1.21 -> 0.82 ms)
+//   join        k_pj_join     one workgroup per partition; every wave owns a contiguous range of probe-row chunks = a contiguous slice of the
+//                             partition's records (tiles lie in row order inside a partition) and emits its hits (probe row, build ref) in
+//                             record order behind the slice's first record: no barrier in the probe loop, no found[probe row] scatter (that
+//                             random 4-byte store cost 0.85 ms of sector read-modify-write per 30 M hits); hstart[p][c] = first hit of chunk c
+//   restore     k_pj_restore  one workgroup per chunk of 2^14 probe rows gathers the chunk's hits from the 2048 partition lists (runs of
+//                             consecutive hits), ranks them by probe row through a bitmap of the chunk's rows (at most one hit per probe row:
+//                             repeated build keys travel as ONE group reference) and writes the pairs in probe order through an LDS window
+// Repeated build keys (foreign-key builds): k_pj_groups numbers the distinct keys of every partition and lays the build rows out as a CSR
+// (rows of a key ascending); the LDS tables then hold one entry per distinct key, a hit carries the group, and k_pj_expand emits the group's
+// rows after the order has been restored -- pairs and their order identical to the general path.
 #include "join_table.h"
 #include "radix_partition.h"
 
 namespace dfgpu {
 
 constexpr uint32_t PJ_EMPTY = 0xFFFFFFFFu;
-constexpr int PJ_IDX_BITS = 14;                       // partition-local build row
+constexpr int PJ_IDX_BITS = 14;                       // partition-local record
 constexpr uint32_t PJ_IDX_MASK = (1u << PJ_IDX_BITS) - 1u;
 constexpr uint32_t PJ_TAG_MASK = (1u << (31 - PJ_IDX_BITS)) - 1u;       // 17 bits: an entry never has its top bit set, PJ_EMPTY always has
 constexpr uint32_t PJ_MAX_PART_ROWS = PJ_IDX_MASK - 1;      // keeps (tag, idx) != PJ_EMPTY
-constexpr int PJ_MAX_SBITS = 15;                      // 32 K slots x 4 B = 128 KB
-constexpr int PJ_NT = 1024;                           // one workgroup per CU while a 128 KB table is resident
-constexpr int PJ_U = 4;                               // probe rows per lane in flight
+constexpr int PJ_MAX_SBITS = 15;                      // 32 K slots x 4 B = 128 KB (one workgroup per CU); 14 = two per CU
+constexpr int PJ_NT = 1024, PJ_R = 8, PJ_TILE = PJ_NT * PJ_R, PJ_G = 16, PJ_NW = PJ_NT / WAVE;
+constexpr uint32_t PJ_MAX_P = 2048;                   // two partitions per thread in the offset loops
+constexpr int PJ_CHS = 14;                            // restore chunk = 2^14 probe rows = two tiles
+constexpr int PJ_U = 4;                               // probe records per lane in flight
+constexpr uint32_t PJ_DUP_MAX_ROWS = 8192;            // repeated keys: a partition's records, slot counters and CSR cursors share 96 KB of LDS
+constexpr uint32_t PJ_MAX_GROUP = 256;                // rows of one key a single thread puts in order
 
-// ---- build side check: one workgroup per partition inserts the partition's keys into the LDS table exactly as the probe kernel will;
-// reports a repeated key ([1]) or an over-full partition ([2]) and the largest partition ([0])
-// Slots are read four at a time (one ds_read_b128 per step of a walk): a key's home is the first slot of the 4-slot group its hash selects and
-// it sits in the first free slot from there on, so a lookup that walks group by group may stop at the first EMPTY it sees.
-__device__ inline uint64_t pj_key(const RpRec12& r) { return (uint64_t)r.lo | ((uint64_t)r.hi << 32); }
+struct PjOffsets { BufferPtr pre, cpre, pstart; int64_t ntiles = 0, nchunks = 0; };      // pre [ntiles][P], cpre [nchunks][P], pstart [P + 1]
+
+// ---------------------------------------------------------------------------------------------------------------- partition
+template <typename H>
+__global__ void __launch_bounds__(PJ_NT) k_pj_hist(H hs, int64_t n, uint32_t P, int64_t ntiles, uint32_t* pre /*[ntiles][P]*/, uint32_t* tot /*[nchunks][P]*/) {
+  extern __shared__ uint32_t pj_lds[];        // [P][G] u16, two counters per word
+  const int64_t t0 = (int64_t)blockIdx.x * PJ_G;
+  for (int x = threadIdx.x; x < (int)P * PJ_G / 2; x += PJ_NT) pj_lds[x] = 0;
+  // counter index of every row of a tile (0xFFFFFFFF: not selected); the next tile's keys are loaded and hashed before this tile's LDS atomics issue
+  auto tile_counters = [&](int g, uint32_t* c) {
+    const int64_t base = (t0 + g) * (int64_t)PJ_TILE;
+#pragma unroll
+    for (int q = 0; q < PJ_R; q++) { const int64_t i = base + (int64_t)q * PJ_NT + threadIdx.x; uint32_t pid = 0; uint64_t hk; c[q] = (i < n && hs(i, P, &pid, &hk)) ? pid * PJ_G + g : 0xFFFFFFFFu; }
+  };
+  uint32_t cn[PJ_R];
+  tile_counters(0, cn);
+  __syncthreads();
+  for (int g = 0; g < PJ_G; g++) {
+    if ((t0 + g) * (int64_t)PJ_TILE >= n) break;
+    uint32_t c[PJ_R];
+#pragma unroll
+    for (int q = 0; q < PJ_R; q++) c[q] = cn[q];
+    if (g + 1 < PJ_G) tile_counters(g + 1, cn);
+#pragma unroll
+    for (int q = 0; q < PJ_R; q++) if (c[q] != 0xFFFFFFFFu) atomicAdd(&pj_lds[c[q] >> 1], 1u << ((c[q] & 1) * 16));      // <= 8192 per counter: no carry
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < (int)P; p += PJ_NT) {
+    const uint4* s = (const uint4*)(pj_lds + p * (PJ_G / 2)); const uint4 a = s[0], b = s[1];
+    const uint32_t w[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w }; uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (t0 + 2 * j < ntiles) pre[(t0 + 2 * j) * (int64_t)P + p] = sum;
+      sum += w[j] & 0xFFFFu;
+      if (t0 + 2 * j + 1 < ntiles) pre[(t0 + 2 * j + 1) * (int64_t)P + p] = sum;
+      sum += w[j] >> 16;
+    }
+    tot[(int64_t)blockIdx.x * P + p] = sum;
+  }
+}
+// within-partition exclusive prefix of the chunk totals, in place (chunk-major storage), and the partition totals: 64 partitions per workgroup, one wave per range of chunks
+__global__ void __launch_bounds__(PJ_NT) k_pj_chunk_prefix(uint32_t* tot /*[nchunks][P]*/, int64_t nchunks, uint32_t P, uint32_t* ptot /*[P]*/) {
+  __shared__ uint32_t part[PJ_NW][WAVE];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63; const uint32_t p = blockIdx.x * 64 + lane;
+  const int64_t per = (nchunks + PJ_NW - 1) / PJ_NW, c0 = wave * per, c1 = c0 + per < nchunks ? c0 + per : nchunks;
+  uint32_t s = 0;
+  if (p < P) for (int64_t c = c0; c < c1; c++) s += tot[c * P + p];
+  part[wave][lane] = s;
+  __syncthreads();
+  uint32_t run = 0; for (int w = 0; w < wave; w++) run += part[w][lane];
+  if (wave == PJ_NW - 1 && p < P) ptot[p] = run + s;
+  if (p < P) for (int64_t c = c0; c < c1; c++) { const uint32_t v = tot[c * P + p]; tot[c * P + p] = run; run += v; }
+}
+// pstart[p] = exclusive scan of ptot (P <= 2048, one workgroup), pstart[P] = rows moved (also -> *d_total)
+__global__ void __launch_bounds__(PJ_NT) k_pj_pstart(const uint32_t* ptot, uint32_t P, uint32_t* pstart, uint64_t* d_total) {
+  __shared__ uint32_t wsum[PJ_NW];
+  const uint32_t a = threadIdx.x * 2 < P ? ptot[threadIdx.x * 2] : 0, b = threadIdx.x * 2 + 1 < P ? ptot[threadIdx.x * 2 + 1] : 0, s = a + b;
+  const uint32_t inc = wave_inclusive_sum(s);
+  if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  uint32_t run = inc - s, tot = 0; for (int w = 0; w < PJ_NW; w++) { if (w < (int)(threadIdx.x >> 6)) run += wsum[w]; tot += wsum[w]; }
+  if (threadIdx.x * 2 < P) pstart[threadIdx.x * 2] = run;
+  if (threadIdx.x * 2 + 1 < P) pstart[threadIdx.x * 2 + 1] = run + a;
+  if (threadIdx.x == 0) { pstart[P] = tot; if (d_total) *d_total = tot; }
+}
+// LDS-staged scatter of (key, row) records; staging in two rounds of half the sorted tile: 8 P + 6 TILE bytes of LDS, two workgroups per CU.
+// blockIdx -> tile: XCD x (= blockIdx & 7 under round-robin placement; speed only) works on a contiguous range of tiles, so the tiles in flight on one
+// XCD are neighbours and their runs of a partition complete each other's cache lines inside that XCD's L2.
+template <typename H>
+__global__ void __launch_bounds__(PJ_NT, 8) k_pj_scatter(H hs, int64_t n, uint32_t P, int64_t ntiles, const uint32_t* pre, const uint32_t* cpre, const uint32_t* pstart, RpRec12* out) {
+  extern __shared__ uint32_t pj_lds[];
+  constexpr int PIECE = PJ_TILE / 2;
+  uint32_t* cnt = pj_lds; uint32_t* delta = pj_lds + P; uint16_t* spid = (uint16_t*)(pj_lds + 2 * P); uint16_t* slidx = spid + PIECE;
+  uint64_t* skey = (uint64_t*)(((uintptr_t)(slidx + PIECE) + 7) & ~(uintptr_t)7);
+  __shared__ uint32_t wsum[PJ_NW]; __shared__ uint32_t moved_sh;
+  constexpr int PER = (int)PJ_MAX_P / PJ_NT;
+  const int64_t per = (ntiles + 7) / 8, t = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (t >= ntiles || (int64_t)(blockIdx.x >> 3) >= per) return;
+  const int64_t base = t * (int64_t)PJ_TILE, chunk = t / PJ_G;
+  uint64_t k[PJ_R]; uint32_t pid[PJ_R], rk[PJ_R]; bool on[PJ_R]; uint32_t gc[PER];
+#pragma unroll
+  for (int q = 0; q < PJ_R; q++) { const int64_t i = base + (int64_t)q * PJ_NT + threadIdx.x; pid[q] = 0; k[q] = 0; on[q] = i < n && hs(i, P, &pid[q], &k[q]); }
+#pragma unroll
+  for (int j = 0; j < PER; j++) { const int p = threadIdx.x * PER + j; gc[j] = p < (int)P ? pre[t * (int64_t)P + p] + cpre[chunk * (int64_t)P + p] + pstart[p] : 0; }
+  for (int p = threadIdx.x; p < (int)P; p += PJ_NT) cnt[p] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < PJ_R; q++) rk[q] = on[q] ? atomicAdd(&cnt[pid[q]], 1u) : 0;
+  __syncthreads();
+  {
+    uint32_t loc[PER]; uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) { const int p = threadIdx.x * PER + j; loc[j] = p < (int)P ? cnt[p] : 0; s += loc[j]; }
+    const uint32_t inc = wave_inclusive_sum(s);
+    if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t run = inc - s; for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wsum[w];
+#pragma unroll
+    for (int j = 0; j < PER; j++) { const int p = threadIdx.x * PER + j; if (p < (int)P) { cnt[p] = run; delta[p] = gc[j] - run; run += loc[j]; } }      // mod 2^32: slot = delta + sorted position
+    if (threadIdx.x == PJ_NT - 1) moved_sh = run;
+  }
+  __syncthreads();
+  const uint32_t moved = moved_sh;
+  uint32_t spos[PJ_R];
+#pragma unroll
+  for (int q = 0; q < PJ_R; q++) spos[q] = on[q] ? cnt[pid[q]] + rk[q] : 0xFFFFFFFFu;
+#pragma unroll 1
+  for (int h = 0; h < 2; h++) {
+    const uint32_t lo = (uint32_t)h * PIECE;
+    if (lo >= moved) break;
+    if (h) __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PJ_R; q++) { const uint32_t s = spos[q] - lo; if (s < (uint32_t)PIECE) { spid[s] = (uint16_t)pid[q]; slidx[s] = (uint16_t)(q * PJ_NT + threadIdx.x); skey[s] = k[q]; } }
+    __syncthreads();
+    const uint32_t m = moved - lo < (uint32_t)PIECE ? moved - lo : (uint32_t)PIECE;
+    for (uint32_t i = threadIdx.x; i < m; i += PJ_NT) {
+      const uint32_t pos = delta[spid[i]] + lo + i; const uint64_t v = skey[i];
+      out[pos] = RpRec12{ (uint32_t)v, (uint32_t)(v >> 32), (uint32_t)(base + slidx[i]) };
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- LDS tables
 // slot group and tag of a key inside its partition: three 32-bit multiplies (the partition was chosen by mix64's top bits; the walk is
 // issue bound, 64-bit multiplies per probe row cost as much as the walk itself).  Collisions only cost a verification.
 __device__ inline void pj_hash(uint32_t lo, uint32_t hi, uint32_t M, int sbits, uint32_t* group, uint32_t* tagsh) {
@@ -45,22 +176,14 @@ __device__ inline void pj_hash(uint32_t lo, uint32_t hi, uint32_t M, int sbits, 
 }
 // Slots are read four at a time (one ds_read_b128 per step of a walk): a key's home is the first slot of the 4-slot group its hash selects and
 // it sits in the first free slot from there on, so a lookup that walks group by group may stop at the first EMPTY it sees.
-__device__ inline void pj_build_table(uint32_t* tab, uint32_t M, int sbits, const RpRec12* brec, uint32_t nb, unsigned long long* flags) {
-  for (uint32_t j0 = threadIdx.x; j0 < nb; j0 += PJ_NT * 4) {
-    RpRec12 k[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) { uint32_t j = j0 + u * PJ_NT; k[u] = brec[j < nb ? j : nb - 1]; }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      uint32_t j = j0 + u * PJ_NT; if (j >= nb) break;
-      uint32_t s, tagsh; pj_hash(k[u].lo, k[u].hi, M, sbits, &s, &tagsh); const uint32_t ent = tagsh | j;
-      for (;;) {
-        uint32_t old = atomicCAS(&tab[s], PJ_EMPTY, ent);
-        if (old == PJ_EMPTY) break;
-        if ((old & ~PJ_IDX_MASK) == tagsh) { RpRec12 o = brec[old & PJ_IDX_MASK]; if (o.lo == k[u].lo && o.hi == k[u].hi) { if (flags) flags[1] = 1ull; break; } }     // the key is in the table already
-        s = (s + 1) & M;
-      }
-    }
+// Inserts record j of `rec` (nb <= PJ_MAX_PART_ROWS); *found_slot (optional): the slot that holds the key afterwards, *inserted: this call put it there.
+__device__ inline void pj_insert(uint32_t* tab, uint32_t M, int sbits, const RpRec12* rec, uint32_t j, const RpRec12 kj, uint32_t* found_slot, bool* inserted) {
+  uint32_t s, tagsh; pj_hash(kj.lo, kj.hi, M, sbits, &s, &tagsh); const uint32_t ent = tagsh | j;
+  for (;;) {
+    const uint32_t old = atomicCAS(&tab[s], PJ_EMPTY, ent);
+    if (old == PJ_EMPTY) { *found_slot = s; *inserted = true; return; }
+    if ((old & ~PJ_IDX_MASK) == tagsh) { const RpRec12 o = rec[old & PJ_IDX_MASK]; if (o.lo == kj.lo && o.hi == kj.hi) { *found_slot = s; *inserted = false; return; } }     // the key is in the table already
+    s = (s + 1) & M;
   }
 }
 // one 4-slot group of a walk: true = the walk ends here, with *cand = the first slot whose tag matches (PJ_EMPTY if an EMPTY came first)
@@ -75,116 +198,257 @@ __device__ inline bool pj_group(const uint4 v, uint32_t tagsh, uint32_t s, uint3
   *cand = (code & 2u) ? val : PJ_EMPTY; *pos = s + j;
   return code != 0;
 }
-__global__ void __launch_bounds__(PJ_NT) k_pj_check(const RpRec12* brec, const uint32_t* bstart, unsigned long long* flags) {
-  extern __shared__ uint32_t pj_tab[];
+
+// ---- build side check: one workgroup per partition inserts the partition's keys into the LDS table exactly as the probe kernel will.
+// flags: [0] largest partition, [1] a key repeats, [2] a partition is beyond the table's capacity, [4] most distinct keys in one partition; ndist[p] = distinct keys of partition p
+__global__ void __launch_bounds__(PJ_NT) k_pj_check(const RpRec12* brec, const uint32_t* bstart, unsigned long long* flags, uint32_t* ndist) {
+  extern __shared__ uint32_t pj_lds[];
+  __shared__ uint32_t nd_sh;
   const uint32_t b0 = bstart[blockIdx.x], nb = bstart[blockIdx.x + 1] - b0;
-  if (threadIdx.x == 0) atomicMax(&flags[0], (unsigned long long)nb);
-  if (nb > PJ_MAX_PART_ROWS) { if (threadIdx.x == 0) flags[2] = 1ull; return; }
+  if (threadIdx.x == 0) { atomicMax(&flags[0], (unsigned long long)nb); nd_sh = 0; }
+  if (nb > PJ_MAX_PART_ROWS) { if (threadIdx.x == 0) { flags[2] = 1ull; ndist[blockIdx.x] = nb; } return; }
   int sbits = 6; while ((1u << sbits) < 2 * nb && sbits < PJ_MAX_SBITS) sbits++;
-  if ((1u << sbits) < nb + nb / 8 + 4) { if (threadIdx.x == 0) flags[2] = 1ull; return; }
+  if ((1u << sbits) < nb + nb / 8 + 4) { if (threadIdx.x == 0) { flags[2] = 1ull; ndist[blockIdx.x] = nb; } return; }
   const uint32_t S = 1u << sbits;
-  for (uint32_t s = threadIdx.x; s < S; s += PJ_NT) pj_tab[s] = PJ_EMPTY;
+  for (uint32_t s = threadIdx.x; s < S; s += PJ_NT) pj_lds[s] = PJ_EMPTY;
   __syncthreads();
-  pj_build_table(pj_tab, S - 1, sbits, brec + b0, nb, flags);
+  uint32_t mine = 0;
+  for (uint32_t j = threadIdx.x; j < nb; j += PJ_NT) { uint32_t fs; bool ins; pj_insert(pj_lds, S - 1, sbits, brec + b0, j, brec[b0 + j], &fs, &ins); mine += ins; }
+  mine = wave_sum(mine);
+  if (lane_id() == 0 && mine) atomicAdd(&nd_sh, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) { const uint32_t nd = nd_sh; ndist[blockIdx.x] = nd; if (nd != nb) flags[1] = 1ull; atomicMax(&flags[4], (unsigned long long)nd); }
 }
 
-// ---- probe: one workgroup per partition
-__global__ void __launch_bounds__(PJ_NT) k_pj_join(const RpRec12* brec, const uint32_t* bstart, const RpRec12* prec, const uint32_t* pstart, int sbits, uint32_t* found) {
-  extern __shared__ uint4 tab4[];                      // 16-byte aligned: one ds_read_b128 per group
-  uint32_t* const pj_tab = (uint32_t*)tab4;
+// ---- repeated build keys: the distinct keys of a partition become groups (numbered in slot order), the partition's build rows a CSR.
+// grec[gstart_p + g] = (key, global group number) -- what the LDS tables of the probe are built from; grp_start / grp_cnt index csr_rows
+__global__ void __launch_bounds__(PJ_NT) k_pj_groups(const RpRec12* brec, const uint32_t* bstart, const uint32_t* gbase /*[P + 1] exclusive scan of ndist*/, RpRec12* grec, uint32_t* grp_start, uint32_t* grp_cnt,
+                                                     uint32_t* csr_rows, unsigned long long* flags) {
+  extern __shared__ uint32_t pj_lds[];
+  constexpr int SB = 14; constexpr uint32_t S = 1u << SB, M = S - 1;
+  uint32_t* tab = pj_lds; uint16_t* scnt = (uint16_t*)(pj_lds + S);       // rows of the key in slot s, then its CSR start inside the partition
+  __shared__ uint32_t wsum[2][PJ_NW];
+  const int p = blockIdx.x; const uint32_t b0 = bstart[p], nb = bstart[p + 1] - b0;       // nb <= PJ_DUP_MAX_ROWS (host checked)
+  for (uint32_t s = threadIdx.x; s < S; s += PJ_NT) tab[s] = PJ_EMPTY;
+  for (uint32_t s = threadIdx.x; s < S / 2; s += PJ_NT) ((uint32_t*)scnt)[s] = 0;
+  __syncthreads();
+  constexpr int RPT = (int)PJ_DUP_MAX_ROWS / PJ_NT;
+  uint16_t slot[RPT], ord[RPT]; uint32_t row[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; r++) {
+    const uint32_t j = threadIdx.x + r * PJ_NT; slot[r] = 0; ord[r] = 0; row[r] = 0;
+    if (j < nb) {
+      const RpRec12 kj = brec[b0 + j]; uint32_t fs; bool ins; pj_insert(tab, M, SB, brec + b0, j, kj, &fs, &ins);
+      slot[r] = (uint16_t)fs; row[r] = kj.row;
+      // ordinal inside the group: a 16-bit counter of a 32-bit LDS word
+      const uint32_t old = atomicAdd((uint32_t*)scnt + (fs >> 1), 1u << ((fs & 1) * 16)); ord[r] = (uint16_t)(old >> ((fs & 1) * 16));
+    }
+  }
+  __syncthreads();
+  // slot order -> group numbers and CSR starts: thread t owns slots [16 t, 16 t + 16)
+  constexpr int SPT = (int)(S / PJ_NT); uint32_t c[SPT]; uint32_t ng = 0, nr = 0;
+#pragma unroll
+  for (int x = 0; x < SPT; x++) { const uint32_t s = threadIdx.x * SPT + x; c[x] = tab[s] != PJ_EMPTY ? scnt[s] : 0; ng += c[x] != 0; nr += c[x]; }
+  const uint32_t ig = wave_inclusive_sum(ng), ir = wave_inclusive_sum(nr);
+  if (lane_id() == 63) { wsum[0][threadIdx.x >> 6] = ig; wsum[1][threadIdx.x >> 6] = ir; }
+  __syncthreads();
+  uint32_t g = ig - ng, st = ir - nr; for (int w = 0; w < (int)(threadIdx.x >> 6); w++) { g += wsum[0][w]; st += wsum[1][w]; }
+  const uint32_t g0 = gbase[p]; uint32_t big = 0;
+#pragma unroll
+  for (int x = 0; x < SPT; x++) if (c[x]) {
+    const uint32_t s = threadIdx.x * SPT + x; const RpRec12 rep = brec[b0 + (tab[s] & PJ_IDX_MASK)];
+    grec[g0 + g] = RpRec12{ rep.lo, rep.hi, g0 + g }; grp_start[g0 + g] = b0 + st; grp_cnt[g0 + g] = c[x];
+    scnt[s] = (uint16_t)st; big |= c[x] > PJ_MAX_GROUP;
+    g++; st += c[x];
+  }
+  if (big) flags[5] = 1ull;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RPT; r++) { const uint32_t j = threadIdx.x + r * PJ_NT; if (j < nb) csr_rows[b0 + scnt[slot[r]] + ord[r]] = row[r]; }
+}
+// rows of a group in ascending order (the LDS atomics above hand the ordinals out in arrival order): one thread per group, insertion sort
+__global__ void __launch_bounds__(BLOCK) k_pj_sort_groups(const uint32_t* grp_start, const uint32_t* grp_cnt, int64_t ngroups, uint32_t* csr_rows) {
+  const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (g >= ngroups) return;
+  const uint32_t c = grp_cnt[g]; if (c < 2 || c > PJ_MAX_GROUP) return;
+  uint32_t* r = csr_rows + grp_start[g];
+  for (uint32_t i = 1; i < c; i++) { const uint32_t v = r[i]; uint32_t j = i; while (j && r[j - 1] > v) { r[j] = r[j - 1]; j--; } r[j] = v; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- probe
+// One workgroup per partition: LDS table from the partition's build records (or group records), then every wave streams its slice of the partition's
+// probe records: wave w owns the chunks [w K, (w + 1) K) of 2^PJ_CHS probe rows; tiles lie in row order inside a partition and chunk bounds are tile
+// bounds, so the slice is the contiguous record range between two offsets of the partition pass.  Hits leave in record order behind the slice's first
+// record (hits <= records): hits[pstart[p] + o] = (probe row << 32 | ref), hstart[p][c] = o of chunk c's first hit, send[p][w] = end of wave w's hits.
+__global__ void __launch_bounds__(PJ_NT, 8) k_pj_join(const RpRec12* brec, const uint32_t* bstart, const RpRec12* prec, const uint32_t* pstart, int sbits, int NC, uint32_t P,
+                                                     const uint32_t* pre, const uint32_t* cpre, int64_t ntiles, uint64_t* hits, uint32_t* hstart /*[P][NC]*/, uint32_t* send /*[P][PJ_NW]*/) {
+  extern __shared__ uint4 pj_tab4[];                   // 16-byte aligned: one ds_read_b128 per group
+  uint32_t* const tab = (uint32_t*)pj_tab4;
   const uint32_t S = 1u << sbits, M = S - 1;
-  const int p = blockIdx.x;
-  const uint32_t q0 = pstart[p], q1 = pstart[p + 1];
-  if (q0 == q1) return;
-  for (uint32_t s = threadIdx.x; s < S; s += PJ_NT) pj_tab[s] = PJ_EMPTY;
+  const int p = blockIdx.x; const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (uint32_t s = threadIdx.x; s < S; s += PJ_NT) tab[s] = PJ_EMPTY;
   __syncthreads();
   const uint32_t b0 = bstart[p], nb = bstart[p + 1] - b0;
   const RpRec12* br = brec + b0;
-  pj_build_table(pj_tab, M, sbits, br, nb, nullptr);
+  for (uint32_t j = threadIdx.x; j < nb; j += PJ_NT) { uint32_t fs; bool ins; pj_insert(tab, M, sbits, br, j, br[j], &fs, &ins); }
   __syncthreads();
-  // PJ_U rows per lane and step.  Vector-memory loads return in issue order, so the records are fetched TWO steps ahead and a step
-  // issues its loads as [verification of this step's hits (L2), records of step + 2 (HBM)]: the verification never waits behind an HBM
-  // fetch of the same step, and a step's records have had a whole step to arrive.
-  RpRec12 rc[PJ_U], rn[PJ_U], rnn[PJ_U];
-  uint32_t i0 = q0 + threadIdx.x;
+  const uint32_t q0 = pstart[p], q1 = pstart[p + 1];
+  const int K = (NC + PJ_NW - 1) / PJ_NW, ca = wave * K, cb = ca + K < NC ? ca + K : NC;
+  uint32_t* const hs = hstart + (size_t)p * NC;
+  if (ca >= NC) { if (lane == 0) send[(size_t)p * PJ_NW + wave] = q1 - q0; return; }
+  // first record of chunk c in this partition = offset of tile c << (PJ_CHS - 13)
+  auto rec_of_chunk = [&](int c) -> uint32_t { const int64_t t = (int64_t)c << (PJ_CHS - 13); if (t >= ntiles) return q1; return q0 + pre[t * (int64_t)P + p] + cpre[(t / PJ_G) * (int64_t)P + p]; };
+  const uint32_t r0 = rec_of_chunk(ca), r1 = cb < NC ? rec_of_chunk(cb) : q1;
+  uint32_t run = r0 - q0;
+  int clast = ca - 1;           // wave-uniform: the last chunk whose start has been written
+  for (uint32_t i0 = r0 + lane; i0 - lane < r1; i0 += WAVE * PJ_U) {
+    RpRec12 rc[PJ_U]; bool on[PJ_U];
 #pragma unroll
-  for (int u = 0; u < PJ_U; u++) { uint32_t i = i0 + u * PJ_NT; rn[u] = prec[i < q1 ? i : q1 - 1]; }
+    for (int u = 0; u < PJ_U; u++) { const uint32_t i = i0 + u * WAVE; on[u] = i < r1; rc[u] = prec[on[u] ? i : r1 - 1]; }
+    // first group of every row: PJ_U independent 16-byte LDS reads, straight-line; the few rows whose first group is full of other keys go on in the loop below
+    uint32_t s[PJ_U], tagsh[PJ_U], cand[PJ_U], pos[PJ_U]; uint4 v[PJ_U]; bool walking[PJ_U]; bool more = false;
 #pragma unroll
-  for (int u = 0; u < PJ_U; u++) { uint32_t i = i0 + (PJ_U + u) * PJ_NT; rnn[u] = prec[i < q1 ? i : q1 - 1]; }
-  for (; i0 < q1; i0 += PJ_NT * PJ_U) {
-    uint32_t cand[PJ_U], pos[PJ_U]; bool on[PJ_U];
-#pragma unroll
-    for (int u = 0; u < PJ_U; u++) { rc[u] = rn[u]; rn[u] = rnn[u]; on[u] = i0 + u * PJ_NT < q1; }
-    // first group of every row: PJ_U independent 16-byte LDS reads, straight-line; the few rows whose first group is full of other
-    // keys (no EMPTY, no tag match) go on in the loop below
-    uint32_t s[PJ_U], tagsh[PJ_U]; uint4 v[PJ_U]; bool more = false;
-#pragma unroll
-    for (int u = 0; u < PJ_U; u++) { pj_hash(rc[u].lo, rc[u].hi, M, sbits, &s[u], &tagsh[u]); v[u] = tab4[s[u] >> 2]; }
-    bool walking[PJ_U];
+    for (int u = 0; u < PJ_U; u++) { pj_hash(rc[u].lo, rc[u].hi, M, sbits, &s[u], &tagsh[u]); v[u] = pj_tab4[s[u] >> 2]; }
 #pragma unroll
     for (int u = 0; u < PJ_U; u++) { const bool done = pj_group(v[u], tagsh[u], s[u], &cand[u], &pos[u]); walking[u] = on[u] & !done; cand[u] = on[u] ? cand[u] : PJ_EMPTY; more |= walking[u]; }
     while (__ballot(more)) {
       more = false;
 #pragma unroll
-      for (int u = 0; u < PJ_U; u++) if (walking[u]) {
-        s[u] = (s[u] + 4) & M;
-        walking[u] = !pj_group(tab4[s[u] >> 2], tagsh[u], s[u], &cand[u], &pos[u]); more |= walking[u];
-      }
+      for (int u = 0; u < PJ_U; u++) if (walking[u]) { s[u] = (s[u] + 4) & M; walking[u] = !pj_group(pj_tab4[s[u] >> 2], tagsh[u], s[u], &cand[u], &pos[u]); more |= walking[u]; }
     }
     RpRec12 vb[PJ_U];
 #pragma unroll
     for (int u = 0; u < PJ_U; u++) { vb[u] = RpRec12{0, 0, 0}; if (cand[u] != PJ_EMPTY) vb[u] = br[cand[u] & PJ_IDX_MASK]; }
-    __builtin_amdgcn_sched_barrier(0);                 // keep the verification loads ahead of the record fetch below
-    const uint32_t i2 = i0 + 2 * PJ_NT * PJ_U;
-#pragma unroll
-    for (int u = 0; u < PJ_U; u++) { uint32_t i = i2 + u * PJ_NT; rnn[u] = prec[i < q1 ? i : q1 - 1]; }
-    __builtin_amdgcn_sched_barrier(0);
+    uint32_t href[PJ_U]; bool hit[PJ_U];
 #pragma unroll
     for (int u = 0; u < PJ_U; u++) {
+      hit[u] = false; href[u] = 0;
       if (cand[u] == PJ_EMPTY) continue;
-      if (vb[u].lo == rc[u].lo && vb[u].hi == rc[u].hi) { found[rc[u].row] = vb[u].row; continue; }
+      if (vb[u].lo == rc[u].lo && vb[u].hi == rc[u].hi) { hit[u] = true; href[u] = vb[u].row; continue; }
       // a different key with the same 17-bit tag (2^-17 per occupied slot passed): keep walking, verifying every tag match
-      uint32_t s1 = (pos[u] + 1) & M, c = pj_tab[s1];
+      uint32_t s1 = (pos[u] + 1) & M, c = tab[s1];
       while (c != PJ_EMPTY) {
-        if ((c & ~PJ_IDX_MASK) == tagsh[u]) { RpRec12 w = br[c & PJ_IDX_MASK]; if (w.lo == rc[u].lo && w.hi == rc[u].hi) { found[rc[u].row] = w.row; break; } }
-        s1 = (s1 + 1) & M; c = pj_tab[s1];
+        if ((c & ~PJ_IDX_MASK) == tagsh[u]) { const RpRec12 w = br[c & PJ_IDX_MASK]; if (w.lo == rc[u].lo && w.hi == rc[u].hi) { hit[u] = true; href[u] = w.row; break; } }
+        s1 = (s1 + 1) & M; c = tab[s1];
       }
+    }
+#pragma unroll
+    for (int u = 0; u < PJ_U; u++) {
+      const uint64_t b = __ballot(hit[u]);
+      const uint32_t o = run + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+      if (hit[u]) hits[(size_t)q0 + o] = ((uint64_t)rc[u].row << 32) | href[u];
+      // the first record of a chunk writes the start of every chunk since the previous record's
+      const int c = on[u] ? (int)(rc[u].row >> PJ_CHS) : cb;
+      int cp = __shfl_up(c, 1, 64); if (lane == 0) cp = clast;
+      if (on[u] && c != cp) for (int x = cp + 1; x <= c; x++) hs[x] = o;
+      clast = __shfl(c, 63, 64);
+      if (clast >= cb) { const uint64_t onb = __ballot(on[u]); clast = onb ? __shfl(c, 63 - __clzll((long long)onb), 64) : cp; clast = __shfl(clast, 0, 64); }
+      run += (uint32_t)__popcll(b);
+    }
+  }
+  if (lane == 0) { for (int x = clast + 1; x < cb; x++) hs[x] = run; send[(size_t)p * PJ_NW + wave] = run; }
+}
+// hstart [P][NC] -> hT [NC][P] (starts) + lT [NC][P] (lengths: next start, or the owning wave's end, minus start); hits per chunk by atomics
+__global__ void __launch_bounds__(PJ_NT) k_pj_transpose(const uint32_t* hstart, const uint32_t* send, int P, int NC, uint32_t* hT, uint16_t* lT, uint32_t* ctot) {
+  __shared__ uint32_t ts[32][33], tl[32][33];
+  const int c0 = blockIdx.x * 32, p0 = blockIdx.y * 32; const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int K = (NC + PJ_NW - 1) / PJ_NW;
+  { const int p = p0 + ty, c = c0 + tx;
+    if (p < P && c < NC) { const uint32_t a = hstart[(size_t)p * NC + c]; const bool last = (c + 1) % K == 0 || c + 1 == NC; const uint32_t b = last ? send[(size_t)p * PJ_NW + c / K] : hstart[(size_t)p * NC + c + 1]; ts[ty][tx] = a; tl[ty][tx] = b - a; }
+    else { ts[ty][tx] = 0; tl[ty][tx] = 0; } }
+  __syncthreads();
+  { const int c = c0 + ty, p = p0 + tx;
+    uint32_t l = tl[tx][ty];
+    if (c < NC && p < P) { hT[(size_t)c * P + p] = ts[tx][ty]; lT[(size_t)c * P + p] = (uint16_t)l; }       // l <= 2^PJ_CHS
+#pragma unroll
+    for (int d = 16; d > 0; d >>= 1) l += __shfl_xor(l, d, 64);
+    if (tx == 0 && c < NC && l) atomicAdd(&ctot[c], l); }
+}
+// restore probe order: one workgroup per chunk of 2^PJ_CHS probe rows.  Hit i of the chunk is found in its partition's list by a search over the prefix of
+// the 2048 run lengths; every probe row has at most one hit, so its rank among the chunk's hits = set bits below it in a bitmap of the chunk's rows.  The
+// hits leave through an LDS window of WIN ranks (a chunk usually fits one window: its hits then stay in registers between the two passes).
+constexpr int PJ_K6 = 6, PJ_WIN = PJ_NT * PJ_K6;
+template <bool GROUPS>
+__global__ void __launch_bounds__(PJ_NT) k_pj_restore(const uint64_t* hits, const uint32_t* pstart, const uint32_t* hT, const uint16_t* lT, int P, int NC, const uint32_t* coff,
+                                                     uint32_t* out_probe, uint64_t* out_build, uint32_t* out_ref) {
+  constexpr int NWORDS = 1 << (PJ_CHS - 5);
+  __shared__ uint32_t bits[NWORDS]; __shared__ uint32_t pref[NWORDS]; __shared__ uint32_t rsrc[PJ_MAX_P]; __shared__ uint32_t roff[PJ_MAX_P + 1]; __shared__ uint32_t wsum[PJ_NW]; __shared__ uint64_t stage[PJ_WIN];
+  const int64_t per = (NC + 7) / 8, cc = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (cc >= NC || (int64_t)(blockIdx.x >> 3) >= per) return;
+  const int c = (int)cc; const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int x = threadIdx.x; x < NWORDS; x += PJ_NT) bits[x] = 0;
+  uint32_t tot;
+  { constexpr int PER = (int)PJ_MAX_P / PJ_NT; uint32_t len[PER]; uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) { const int p = threadIdx.x * PER + j; len[j] = 0; if (p < P) { len[j] = lT[(size_t)c * P + p]; rsrc[p] = pstart[p] + hT[(size_t)c * P + p]; } s += len[j]; }
+    const uint32_t inc = wave_inclusive_sum(s);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - s; tot = 0; for (int w = 0; w < PJ_NW; w++) { if (w < wave) run += wsum[w]; tot += wsum[w]; }
+#pragma unroll
+    for (int j = 0; j < PER; j++) { const int p = threadIdx.x * PER + j; if (p < P) roff[p] = run; run += len[j]; }
+    if (threadIdx.x == 0) roff[P] = tot; }
+  __syncthreads();
+  auto src_of = [&](uint32_t i) -> size_t { int lo = 0, hi = P;      // last run with roff <= i (empty runs share their successor's offset)
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (roff[mid] <= i) lo = mid; else hi = mid; }
+    return (size_t)rsrc[lo] + (i - roff[lo]); };
+  constexpr uint32_t rmask = (1u << PJ_CHS) - 1u;
+  const bool one = tot <= (uint32_t)PJ_WIN;
+  uint64_t hv[PJ_K6];
+  for (uint32_t i0 = 0; i0 < tot; i0 += PJ_WIN) {
+    size_t a[PJ_K6];
+#pragma unroll
+    for (int k = 0; k < PJ_K6; k++) { const uint32_t i = i0 + k * PJ_NT + threadIdx.x; a[k] = i < tot ? src_of(i) : (size_t)0; }
+#pragma unroll
+    for (int k = 0; k < PJ_K6; k++) { const uint32_t i = i0 + k * PJ_NT + threadIdx.x; hv[k] = i < tot ? hits[a[k]] : ~0ull; }
+#pragma unroll
+    for (int k = 0; k < PJ_K6; k++) if (hv[k] != ~0ull) { const uint32_t rr = (uint32_t)(hv[k] >> 32) & rmask; atomicOr(&bits[rr >> 5], 1u << (rr & 31)); }
+  }
+  __syncthreads();
+  { const uint32_t cw = threadIdx.x < (unsigned)NWORDS ? __popc(bits[threadIdx.x]) : 0; const uint32_t inc2 = wave_inclusive_sum(cw);
+    __syncthreads();
+    if (lane == 63) wsum[wave] = inc2;
+    __syncthreads();
+    uint32_t r2 = inc2 - cw; for (int w = 0; w < wave; w++) r2 += wsum[w];
+    if (threadIdx.x < (unsigned)NWORDS) pref[threadIdx.x] = r2; }
+  __syncthreads();
+  const uint32_t o0 = coff[c];
+  for (uint32_t lo = 0; lo < tot; lo += PJ_WIN) {            // window of ranks [lo, lo + WIN)
+    if (lo) __syncthreads();
+    if (one) {
+#pragma unroll
+      for (int k = 0; k < PJ_K6; k++) if (hv[k] != ~0ull) { const uint32_t rr = (uint32_t)(hv[k] >> 32) & rmask; stage[pref[rr >> 5] + __popc(bits[rr >> 5] & ((1u << (rr & 31)) - 1u))] = hv[k]; }
+    } else {
+      for (uint32_t i0 = 0; i0 < tot; i0 += PJ_WIN) {
+        size_t a[PJ_K6]; uint64_t h2[PJ_K6];
+#pragma unroll
+        for (int k = 0; k < PJ_K6; k++) { const uint32_t i = i0 + k * PJ_NT + threadIdx.x; a[k] = i < tot ? src_of(i) : (size_t)0; }
+#pragma unroll
+        for (int k = 0; k < PJ_K6; k++) { const uint32_t i = i0 + k * PJ_NT + threadIdx.x; h2[k] = i < tot ? hits[a[k]] : ~0ull; }
+#pragma unroll
+        for (int k = 0; k < PJ_K6; k++) if (h2[k] != ~0ull) { const uint32_t rr = (uint32_t)(h2[k] >> 32) & rmask; const uint32_t rk = pref[rr >> 5] + __popc(bits[rr >> 5] & ((1u << (rr & 31)) - 1u)) - lo; if (rk < (uint32_t)PJ_WIN) stage[rk] = h2[k]; }
+      }
+    }
+    __syncthreads();
+    const uint32_t m = tot - lo < (uint32_t)PJ_WIN ? tot - lo : (uint32_t)PJ_WIN;
+    for (uint32_t i = threadIdx.x; i < m; i += PJ_NT) {
+      const uint64_t v = stage[i]; out_probe[o0 + lo + i] = (uint32_t)(v >> 32);
+      if (GROUPS) out_ref[o0 + lo + i] = (uint32_t)v; else out_build[o0 + lo + i] = (uint32_t)v;
     }
   }
 }
-
-// ---- order-preserving compaction of found[]: 4096 rows per workgroup, 16 consecutive rows per lane; the hits of a workgroup are staged in
-// LDS in row order and leave with consecutive lanes writing consecutive output slots
-__global__ void __launch_bounds__(BLOCK) k_pj_found_count(const uint32_t* found, int64_t n, uint32_t* counts) {
-  int64_t base = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * 16; uint32_t c = 0;
-  if (base + 16 <= n) { const uint4* p = (const uint4*)(found + base);
-#pragma unroll
-    for (int q = 0; q < 4; q++) { uint4 v = p[q]; c += (v.x != PJ_EMPTY) + (v.y != PJ_EMPTY) + (v.z != PJ_EMPTY) + (v.w != PJ_EMPTY); } }
-  else for (int64_t i = base; i < n; i++) c += found[i] != PJ_EMPTY;
-  __shared__ uint32_t lds[BLOCK / WAVE];
-  uint32_t tot; (void)block_exclusive_sum<uint32_t>(c, lds, &tot);
-  if (threadIdx.x == 0) counts[blockIdx.x] = tot;
+// repeated build keys: every matched probe row emits its group's rows in build order (the general path's k_probe_expand over the partitioned CSR)
+__global__ void __launch_bounds__(BLOCK) k_pj_group_counts(const uint32_t* ref, int64_t m, const uint32_t* grp_cnt, uint32_t* cnt) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < m) cnt[i] = grp_cnt[ref[i]];
 }
-__global__ void __launch_bounds__(BLOCK) k_pj_found_write(const uint32_t* found, int64_t n, const uint32_t* offs, uint32_t* out_probe, uint64_t* out_build) {
-  __shared__ uint32_t sp[4096], sb[4096]; __shared__ uint32_t lds[BLOCK / WAVE];
-  int64_t base = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * 16; uint32_t v[16]; uint32_t c = 0;
-  if (base + 16 <= n) { const uint4* p = (const uint4*)(found + base);
-#pragma unroll
-    for (int q = 0; q < 4; q++) { uint4 x = p[q]; v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w; } }
-  else {
-#pragma unroll
-    for (int q = 0; q < 16; q++) v[q] = base + q < n ? found[base + q] : PJ_EMPTY; }
-#pragma unroll
-  for (int q = 0; q < 16; q++) c += v[q] != PJ_EMPTY;
-  uint32_t tot; uint32_t ex = block_exclusive_sum<uint32_t>(c, lds, &tot);
-#pragma unroll
-  for (int q = 0; q < 16; q++) if (v[q] != PJ_EMPTY) { sp[ex] = (uint32_t)(base + q); sb[ex] = v[q]; ex++; }
-  __syncthreads();
-  const uint32_t o = offs[blockIdx.x];
-  for (uint32_t i = threadIdx.x; i < tot; i += BLOCK) { out_probe[o + i] = sp[i]; out_build[o + i] = sb[i]; }
+__global__ void __launch_bounds__(BLOCK) k_pj_expand(const uint32_t* rows, const uint32_t* ref, const uint64_t* offsets, int64_t m, const uint32_t* grp_start, const uint32_t* grp_cnt, const uint32_t* csr_rows,
+                                                    uint64_t* out_build, uint32_t* out_probe) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i >= m) return;
+  const uint32_t g = ref[i], c = grp_cnt[g], st = grp_start[g], j = rows[i]; const uint64_t o = offsets[i];
+  for (uint32_t k = 0; k < c; k++) { out_build[o + k] = csr_rows[st + k]; out_probe[o + k] = j; }
 }
 
-static void pj_set_lds_limit(const void* fn) { HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); }
+// ---------------------------------------------------------------------------------------------------------------- host
+static void pj_set_lds(const void* fn, size_t bytes) { if (bytes > 48 * 1024) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); }     // per device, per call: cheap and free of process-wide state
 
 static bool pj_key_type_ok(const dfgpu_array* a) {
   switch (a->type) {
@@ -194,10 +458,32 @@ static bool pj_key_type_ok(const dfgpu_array* a) {
   }
 }
 
-// partition the rows of an integer key column (selected and non-NULL ones) by rp_pid(mix64(widened key))
-static RpResult pj_partition(dfgpu_ctx* ctx, const dfgpu_array* key, const uint64_t* mask, uint32_t P, const RpCols& cols, uint64_t* d_total, const char* th, const char* ts, const char* tw) {
+// partition the selected, non-NULL rows of an integer key column by rp_pid(mix64(widened key)) into 12-byte (key, row) records
+template <typename H>
+static PjOffsets pj_partition_t(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, RpRec12* recs, uint64_t* d_total, const char* th, const char* ts, const char* tw) {
+  PjOffsets o; o.ntiles = n ? (n + PJ_TILE - 1) / PJ_TILE : 1; o.nchunks = (o.ntiles + PJ_G - 1) / PJ_G;
+  o.pre = alloc_buffer(ctx, (size_t)o.ntiles * P * 4); o.cpre = alloc_buffer(ctx, (size_t)o.nchunks * P * 4); o.pstart = alloc_buffer(ctx, (size_t)(P + 1) * 4);
+  BufferPtr ptot = alloc_buffer(ctx, (size_t)P * 4);
+  { KernelTimer kt_(ctx, th);
+    const size_t lds = (size_t)P * PJ_G * 2;
+    pj_set_lds((const void*)k_pj_hist<H>, lds);
+    hipLaunchKernelGGL((k_pj_hist<H>), dim3((unsigned)o.nchunks), dim3(PJ_NT), lds, ctx->stream, hs, n, P, o.ntiles, (uint32_t*)o.pre->ptr, (uint32_t*)o.cpre->ptr);
+    KERNEL_CHECK(); }
+  { KernelTimer kt_(ctx, ts);
+    hipLaunchKernelGGL(k_pj_chunk_prefix, dim3((P + 63) / 64), dim3(PJ_NT), 0, ctx->stream, (uint32_t*)o.cpre->ptr, o.nchunks, P, (uint32_t*)ptot->ptr);
+    hipLaunchKernelGGL(k_pj_pstart, dim3(1), dim3(PJ_NT), 0, ctx->stream, (const uint32_t*)ptot->ptr, P, (uint32_t*)o.pstart->ptr, d_total);
+    KERNEL_CHECK(); }
+  if (n) { KernelTimer kt_(ctx, tw);
+    const size_t lds = (size_t)P * 8 + (size_t)PJ_TILE / 2 * 12 + 16;
+    pj_set_lds((const void*)k_pj_scatter<H>, lds);
+    hipLaunchKernelGGL((k_pj_scatter<H>), dim3((unsigned)(((o.ntiles + 7) / 8) * 8)), dim3(PJ_NT), lds, ctx->stream, hs, n, P, o.ntiles, (const uint32_t*)o.pre->ptr, (const uint32_t*)o.cpre->ptr,
+                       (const uint32_t*)o.pstart->ptr, recs);
+    KERNEL_CHECK(); }
+  return o;
+}
+static PjOffsets pj_partition(dfgpu_ctx* ctx, const dfgpu_array* key, const uint64_t* mask, uint32_t P, RpRec12* recs, uint64_t* d_total, const char* th, const char* ts, const char* tw) {
   const uint64_t* valid = key->validity ? (const uint64_t*)key->validity->ptr : nullptr; const int64_t n = key->length;
-#define PJ_PART(T) return rp_partition(ctx, RpHashInt<T>{ (const T*)key->values->ptr, valid, mask }, n, P, cols, false, d_total, th, ts, tw)
+#define PJ_PART(T) return pj_partition_t(ctx, RpHashInt<T>{ (const T*)key->values->ptr, valid, mask }, n, P, recs, d_total, th, ts, tw)
   switch (key->type) {
     case DFGPU_INT8: PJ_PART(int8_t); case DFGPU_INT16: PJ_PART(int16_t); case DFGPU_INT32: case DFGPU_DATE32: PJ_PART(int32_t);
     case DFGPU_UINT8: PJ_PART(uint8_t); case DFGPU_UINT16: PJ_PART(uint16_t); case DFGPU_UINT32: PJ_PART(uint32_t);
@@ -212,64 +498,108 @@ bool pj_build(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   if (n < ctx->join_partitioned_min_build || n > 0xFFFFFFF0ll) return false;
   const dfgpu_array* key0 = t->keys[0];
   if (!pj_key_type_ok(key0)) return false;
-  int64_t per = ctx->join_partition_rows; if (per < 16) per = 16; if (per > 14000) per = 14000;
+  int64_t cap = ctx->join_partition_rows; if (cap < 16) cap = 16; if (cap > 14000) cap = 14000;
+  const int64_t per = std::min<int64_t>(cap, 7300);      // <= 8192 keys: a 64 KB table at load <= 1/2, two workgroups per CU
   int64_t P64 = (n + per - 1) / per; if (P64 < 1) P64 = 1;
-  if (P64 > ctx->num_cus && P64 <= 2048) P64 = std::min<int64_t>(2048, (P64 + ctx->num_cus - 1) / ctx->num_cus * ctx->num_cus);      // whole rounds of one workgroup per CU
-  if (P64 > 2048) return false;                        // larger builds: finer partitions cost more than the general path saves
+  if (P64 > PJ_MAX_P) { if ((n + PJ_MAX_P - 1) / PJ_MAX_P > cap) return false; P64 = PJ_MAX_P; }       // up to `cap` rows per partition: 128 KB tables, one workgroup per CU
+  else if (P64 > 2 * ctx->num_cus) P64 = std::min<int64_t>(PJ_MAX_P, (P64 + 2 * ctx->num_cus - 1) / (2 * ctx->num_cus) * (2 * ctx->num_cus));      // whole rounds of two workgroups per CU
   auto part = std::make_unique<PartitionedBuild>();
   part->P = (uint32_t)P64;
-  BufferPtr recs = alloc_buffer(ctx, (size_t)n * 12);
-  RpCols cols{}; cols.n = 1; cols.pack12_dst = (RpRec12*)recs->ptr;
-  cols.c[0] = RpCol{ key0->values->ptr, nullptr, 8, RP_HASHKEY, key0->type };
+  BufferPtr recs = alloc_buffer(ctx, (size_t)(n + 1) * 12), ndist = alloc_buffer(ctx, (size_t)(P64 + 1) * 4);
   zero_scratch(ctx);
-  RpResult r = pj_partition(ctx, key0, t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr, part->P, cols, ctx->d_scratch64 + 3, "pj_build_hist", "pj_build_scan", "pj_build_scatter");
+  PjOffsets off = pj_partition(ctx, key0, t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr, part->P, (RpRec12*)recs->ptr, ctx->d_scratch64 + 3, "pj_build_hist", "pj_build_scan", "pj_build_scatter");
   { KernelTimer kt_(ctx, "pj_build_check");
-    static bool once = false; if (!once) { pj_set_lds_limit((const void*)k_pj_check); once = true; }
-    hipLaunchKernelGGL(k_pj_check, dim3(part->P), dim3(PJ_NT), (size_t)(1u << PJ_MAX_SBITS) * 4, ctx->stream, (const RpRec12*)recs->ptr, (const uint32_t*)r.starts->ptr, (unsigned long long*)ctx->d_scratch64);
+    const size_t lds = (size_t)(1u << PJ_MAX_SBITS) * 4;
+    pj_set_lds((const void*)k_pj_check, lds);
+    hipLaunchKernelGGL(k_pj_check, dim3(part->P), dim3(PJ_NT), lds, ctx->stream, (const RpRec12*)recs->ptr, (const uint32_t*)off.pstart->ptr, (unsigned long long*)ctx->d_scratch64, (uint32_t*)ndist->ptr);
     KERNEL_CHECK(); }
-  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned, ctx->d_scratch64, 32, hipMemcpyDeviceToHost, ctx->stream));
+  const uint64_t* h = read_scratch_range(ctx, 0, 6);
   ctx->count_sync("sync:pj_build_check");
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  const uint64_t max_rows = ctx->h_pinned[0], dup = ctx->h_pinned[1], over = ctx->h_pinned[2], moved = ctx->h_pinned[3];
-  if (dup || over) return false;
-  int sbits = 6; while ((1ull << sbits) < 2 * max_rows && sbits < PJ_MAX_SBITS) sbits++;
-  part->sbits = sbits; part->rows = (int64_t)moved; part->recs = recs; part->starts = r.starts;
+  const uint64_t max_rows = h[0], dup = h[1], over = h[2], moved = h[3], max_dist = h[4];
+  if (over) return false;
+  part->rows = (int64_t)moved; part->starts = off.pstart; part->recs = recs;
+  uint64_t max_keys = max_rows;
+  if (dup) {
+    if (max_rows > PJ_DUP_MAX_ROWS) return false;        // the CSR kernel keeps a partition's records, counters and cursors in LDS
+    KernelTimer kt_(ctx, "pj_build_groups");
+    exclusive_scan_u32_inplace32(ctx, (uint32_t*)ndist->ptr, (int64_t)P64 + 1, ctx->d_scratch64 + 6);     // ndist[P] is scratch: its exclusive prefix is the total
+    BufferPtr grec = alloc_buffer(ctx, (size_t)(moved + 1) * 12), gstart = alloc_buffer(ctx, (size_t)(moved + 1) * 4), gcnt = alloc_buffer(ctx, (size_t)(moved + 1) * 4), csr = alloc_buffer(ctx, (size_t)(moved + 1) * 4);
+    const size_t lds = (size_t)(1u << 14) * 4 + (size_t)(1u << 14) * 2;
+    pj_set_lds((const void*)k_pj_groups, lds);
+    hipLaunchKernelGGL(k_pj_groups, dim3(part->P), dim3(PJ_NT), lds, ctx->stream, (const RpRec12*)recs->ptr, (const uint32_t*)off.pstart->ptr, (const uint32_t*)ndist->ptr, (RpRec12*)grec->ptr, (uint32_t*)gstart->ptr,
+                       (uint32_t*)gcnt->ptr, (uint32_t*)csr->ptr, (unsigned long long*)ctx->d_scratch64);
+    KERNEL_CHECK();
+    // total groups = ndist[P] after the scan; read it together with the big-group flag
+    HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 8, (const uint32_t*)ndist->ptr + P64, 4, hipMemcpyDeviceToHost, ctx->stream));
+    const uint64_t big = read_scratch(ctx, 5);
+    const int64_t ng = (int64_t)(uint32_t)ctx->h_pinned[8];
+    if (big) return false;                               // a key with more rows than one thread sorts: the general path's CSR
+    if (ng) hipLaunchKernelGGL(k_pj_sort_groups, dim3(grid_for(ng, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)gstart->ptr, (const uint32_t*)gcnt->ptr, ng, (uint32_t*)csr->ptr);
+    KERNEL_CHECK();
+    part->dups = true; part->recs = grec; part->grp_start = gstart; part->grp_cnt = gcnt; part->csr_rows = csr; part->starts = ndist;       // ndist = group offsets of the partitions
+    max_keys = max_dist;
+    t->mem += (int64_t)moved * 24;
+  }
+  int sbits = 6; while ((1ull << sbits) < 2 * max_keys && sbits < PJ_MAX_SBITS) sbits++;
+  part->sbits = sbits;
   t->part = std::move(part);
-  t->unique = true;
+  t->unique = !dup;
   t->mem += (int64_t)n * 12 + (int64_t)(P64 + 1) * 4;
   return true;
 }
 
 bool pj_probe_eligible(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* probe_key, int64_t n) {
-  if (!t->part || !ctx->join_partitioned || n < ctx->join_partitioned_min_probe || n > 0xFFFF0000ll) return false;      // 32-bit slot arithmetic with two steps of look-ahead
+  if (!t->part || !ctx->join_partitioned || n < ctx->join_partitioned_min_probe || n > 0xFFFF0000ll) return false;
   return probe_key->type == t->keys[0]->type;          // same physical integer type, no dictionary
 }
 
 void pj_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* pk, const uint64_t* mask, dfgpu_array** out_build, dfgpu_array** out_probe) {
   const PartitionedBuild& part = *t->part;
-  const int64_t n = pk->length;
-  BufferPtr recs = alloc_buffer(ctx, (size_t)n * 12), found = alloc_buffer(ctx, (size_t)n * 4);
-  RpCols cols{}; cols.n = 1; cols.pack12_dst = (RpRec12*)recs->ptr;
-  cols.c[0] = RpCol{ pk->values->ptr, nullptr, 8, RP_HASHKEY, pk->type };
-  RpResult r = pj_partition(ctx, pk, mask, part.P, cols, ctx->d_scratch64 + 9, "pj_probe_hist", "pj_probe_scan", "pj_probe_scatter");
+  const int64_t n = pk->length; const uint32_t P = part.P;
+  const int NC = (int)((n + (1ll << PJ_CHS) - 1) >> PJ_CHS);
+  BufferPtr recs = alloc_buffer(ctx, (size_t)(n + 1) * 12);
+  PjOffsets off = pj_partition(ctx, pk, mask, P, (RpRec12*)recs->ptr, ctx->d_scratch64 + 9, "pj_probe_hist", "pj_probe_scan", "pj_probe_scatter");
+  BufferPtr hits = alloc_buffer(ctx, (size_t)(n + 1) * 8), hstart = alloc_buffer(ctx, (size_t)P * NC * 4 + 4), send = alloc_buffer(ctx, (size_t)P * PJ_NW * 4);
   { KernelTimer kt_(ctx, "pj_join");
-    HIP_CHECK(hipMemsetAsync(found->ptr, 0xFF, (size_t)n * 4, ctx->stream));
-    static bool once = false; if (!once) { pj_set_lds_limit((const void*)k_pj_join); once = true; }
-    hipLaunchKernelGGL(k_pj_join, dim3(part.P), dim3(PJ_NT), (size_t)(1u << part.sbits) * 4, ctx->stream, (const RpRec12*)part.recs->ptr, (const uint32_t*)part.starts->ptr,
-                       (const RpRec12*)recs->ptr, (const uint32_t*)r.starts->ptr, part.sbits, (uint32_t*)found->ptr);
+    const size_t lds = (size_t)(1u << part.sbits) * 4;
+    pj_set_lds((const void*)k_pj_join, lds);
+    hipLaunchKernelGGL(k_pj_join, dim3(P), dim3(PJ_NT), lds, ctx->stream, (const RpRec12*)part.recs->ptr, (const uint32_t*)part.starts->ptr, (const RpRec12*)recs->ptr, (const uint32_t*)off.pstart->ptr,
+                       part.sbits, NC, P, (const uint32_t*)off.pre->ptr, (const uint32_t*)off.cpre->ptr, off.ntiles, (uint64_t*)hits->ptr, (uint32_t*)hstart->ptr, (uint32_t*)send->ptr);
     KERNEL_CHECK(); }
-  recs.reset();
+  recs.reset(); off.pre.reset(); off.cpre.reset();
   KernelTimer kt_(ctx, "pj_compact");
-  const int64_t nb = (n + 4095) / 4096;
-  BufferPtr counts = alloc_buffer(ctx, (size_t)nb * 4);
-  hipLaunchKernelGGL(k_pj_found_count, dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)found->ptr, n, (uint32_t*)counts->ptr);
-  exclusive_scan_u32_inplace32(ctx, (uint32_t*)counts->ptr, nb, ctx->d_scratch64 + 10);
+  BufferPtr hT = alloc_buffer(ctx, (size_t)P * NC * 4 + 4), lT = alloc_buffer(ctx, (size_t)P * NC * 2 + 4), coff = alloc_buffer(ctx, (size_t)(NC + 1) * 4, true);
+  hipLaunchKernelGGL(k_pj_transpose, dim3((NC + 31) / 32, (P + 31) / 32), dim3(PJ_NT), 0, ctx->stream, (const uint32_t*)hstart->ptr, (const uint32_t*)send->ptr, (int)P, NC, (uint32_t*)hT->ptr, (uint16_t*)lT->ptr, (uint32_t*)coff->ptr);
+  exclusive_scan_u32_inplace32(ctx, (uint32_t*)coff->ptr, (int64_t)NC + 1, ctx->d_scratch64 + 10);
   KERNEL_CHECK();
-  const int64_t total = (int64_t)read_scratch(ctx, 10);
+  hstart.reset(); send.reset();
+  const int64_t m = (int64_t)read_scratch(ctx, 10);        // matched probe rows
+  const unsigned rgrid = (unsigned)(((NC + 7) / 8) * 8);
+  if (!part.dups) {
+    ArrayHolder ob(new_fixed(ctx, DFGPU_UINT64, m)), op(new_fixed(ctx, DFGPU_UINT32, m));
+    if (m) hipLaunchKernelGGL((k_pj_restore<false>), dim3(rgrid), dim3(PJ_NT), 0, ctx->stream, (const uint64_t*)hits->ptr, (const uint32_t*)off.pstart->ptr, (const uint32_t*)hT->ptr, (const uint16_t*)lT->ptr, (int)P, NC,
+                                  (const uint32_t*)coff->ptr, (uint32_t*)op.get()->values->ptr, (uint64_t*)ob.get()->values->ptr, (uint32_t*)nullptr);
+    KERNEL_CHECK();
+    op.get()->identity = m == n;
+    *out_build = ob.release(); *out_probe = op.release();
+    return;
+  }
+  // repeated build keys: restore the order of the (probe row, group) matches, then every match emits its group
+  BufferPtr rows = alloc_buffer(ctx, (size_t)(m + 1) * 4), ref = alloc_buffer(ctx, (size_t)(m + 1) * 4), cnt = alloc_buffer(ctx, (size_t)(m + 1) * 4), offs = alloc_buffer(ctx, (size_t)(m + 1) * 8);
+  int64_t total = 0;
+  if (m) {
+    hipLaunchKernelGGL((k_pj_restore<true>), dim3(rgrid), dim3(PJ_NT), 0, ctx->stream, (const uint64_t*)hits->ptr, (const uint32_t*)off.pstart->ptr, (const uint32_t*)hT->ptr, (const uint16_t*)lT->ptr, (int)P, NC,
+                       (const uint32_t*)coff->ptr, (uint32_t*)rows->ptr, (uint64_t*)nullptr, (uint32_t*)ref->ptr);
+    hipLaunchKernelGGL(k_pj_group_counts, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)ref->ptr, m, (const uint32_t*)part.grp_cnt->ptr, (uint32_t*)cnt->ptr);
+    KERNEL_CHECK();
+    exclusive_scan_u32(ctx, (const uint32_t*)cnt->ptr, (uint64_t*)offs->ptr, m, ctx->d_scratch64 + 8);
+    total = (int64_t)read_scratch(ctx, 8);
+  }
+  if (total > 0xFFFFFFF0ll) fail(DFGPU_RESOURCES_EXHAUSTED, "join output of %lld rows for one probe batch; split the probe batch", (long long)total);
   ArrayHolder ob(new_fixed(ctx, DFGPU_UINT64, total)), op(new_fixed(ctx, DFGPU_UINT32, total));
-  if (total) hipLaunchKernelGGL(k_pj_found_write, dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)found->ptr, n, (const uint32_t*)counts->ptr, (uint32_t*)op.get()->values->ptr, (uint64_t*)ob.get()->values->ptr);
+  if (total) hipLaunchKernelGGL(k_pj_expand, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)rows->ptr, (const uint32_t*)ref->ptr, (const uint64_t*)offs->ptr, m, (const uint32_t*)part.grp_start->ptr,
+                                (const uint32_t*)part.grp_cnt->ptr, (const uint32_t*)part.csr_rows->ptr, (uint64_t*)ob.get()->values->ptr, (uint32_t*)op.get()->values->ptr);
   KERNEL_CHECK();
-  op.get()->identity = total == n;
   *out_build = ob.release(); *out_probe = op.release();
 }
 

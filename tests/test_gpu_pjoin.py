@@ -132,21 +132,39 @@ def test_dense_domain_keeps_the_bitmap_path(ctx):
         assert "pj_join" not in f.kernels()
 
 
-def test_repeated_build_keys_fall_back(ctx):
+def test_repeated_build_keys_take_the_partitioned_path(ctx):
+    """one repeated key: the distinct keys of every partition become groups, the rows of a key a CSR (k_pj_groups); pairs in probe order, then build order"""
     b = unique_keys(30000); b[1234] = b[77]; p = probe_keys(b, 80000, 0.5)
     with forced(ctx, 100) as f:
         check(ctx, b, p)
         ran = f.kernels()
-        assert "pj_build_check" in ran and "pj_join" not in ran
+        assert "pj_build_check" in ran and "pj_build_groups" in ran and "pj_join" in ran and "k_probe_match_hash" not in ran, ran
+
+
+@pytest.mark.parametrize("nb,npr,distinct,per", [(60000, 200000, 9000, 128), (40000, 100000, 39000, 64), (50000, 150000, 500, 12800), (3000, 50000, 1, 12800), (200000, 300000, 40000, 256)],
+                         ids=["fk7", "few-dups", "100-per-key", "one-key", "fk5-2048-partitions"])
+def test_foreign_key_builds(ctx, nb, npr, distinct, per):
+    """a build side whose keys repeat (a foreign key): every match emits its key's rows in build input order; masks and NULLs on both sides"""
+    keys = unique_keys(distinct)
+    b = keys[RNG.integers(0, distinct, nb)]
+    p = probe_keys(keys, npr, 0.4)
+    with forced(ctx, per) as f:
+        m = check(ctx, b, p, bmask=RNG.random(nb) < 0.8, pmask=RNG.random(npr) < 0.7, bnull=RNG.random(nb) < 0.05, pnull=RNG.random(npr) < 0.05)
+        ran = f.kernels()
+    assert m > 0
+    if distinct >= 500:                 # few rows per key: the partitioned CSR; a key with more rows than PJ_MAX_GROUP leaves the build to the general path
+        assert "pj_join" in ran and "pj_build_groups" in ran, ran
+    else:
+        assert "pj_join" not in ran
 
 
 def test_overfull_partition_falls_back(ctx):
-    """20 000 distinct keys whose hash lands in partition 0 of 2: beyond the 16 382 rows an LDS table indexes -> general path, same pairs"""
+    """20 000 distinct keys whose hash lands in partition 0 of 3 (7300 rows per partition are planned): beyond the 16 382 rows an LDS table indexes -> general path, same pairs"""
     ks = []
     x = 1
     while len(ks) < 20000:
         x += 1
-        if (mix64(x * 7919) >> 32) * 2 >> 32 == 0:
+        if (mix64(x * 7919) >> 32) * 3 >> 32 == 0:
             ks.append(x * 7919)
     b = np.array(ks, dtype=np.int64)[RNG.permutation(len(ks))]          # range / rows ~ 16 000: too sparse for the bitmap path
     p = probe_keys(b, 60000, 0.5)
