@@ -48,10 +48,62 @@ def wrap_dict(ctx, capi, keys, dictionary, key_type):
     return ctx.wrap_device(d, keepalive=(keys, dictionary, dd))
 
 
+LAST_OUT = [None]          # batches of the most recent plan step: what the result checks read (outside the timed region)
+
+
+def result_columns(batches):
+    """result batches -> one list of numpy columns: Decimal128 as Python ints (unscaled), dictionaries / strings as Python strings, the rest as numpy arrays"""
+    import numpy as np
+    import pyarrow as pa
+    if not batches:
+        return []
+    cols = []
+    for i in range(batches[0].num_columns):
+        a = pa.concat_arrays([b.columns[i].to_arrow() for b in batches]) if len(batches) > 1 else batches[0].columns[i].to_arrow()
+        if pa.types.is_dictionary(a.type):
+            a = a.cast(a.type.value_type)
+        if pa.types.is_decimal(a.type):
+            raw = np.frombuffer(a.buffers()[1], dtype=np.uint64, count=2 * len(a), offset=a.offset * 16).reshape(-1, 2)
+            cols.append(([int(lo) | (int(hi) << 64) for lo, hi in raw.tolist()], a.type.scale))
+        elif pa.types.is_string(a.type) or pa.types.is_large_string(a.type):
+            cols.append(a.to_pylist())
+        elif pa.types.is_date32(a.type):
+            cols.append(np.asarray(a.cast(pa.int32())))
+        else:
+            cols.append(np.asarray(a))
+    return cols
+
+
+M64 = (1 << 64) - 1
+
+
+class _DevView:
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def dev_tensor(torch, arr, typestr, cols=1):
+    """a dfgpu Array's values buffer as a torch tensor over the same HBM (no copy; `arr` must stay alive while the tensor is used)"""
+    d = arr.describe()
+    return torch.as_tensor(_DevView(d.values, (d.length,) if cols == 1 else (d.length, cols), typestr), device="cuda")
+
+
+def wrap64(x):
+    """Python int (possibly negative / wider than 64 bits) -> its low 64 bits, what a wrapping Int64 torch sum holds"""
+    return int(x) & M64
+
+
+def check(name, ok, detail):
+    """every workload's result of the last timed step against a plain-torch recomputation over the same tensors: asserted, and reported in the JSON line"""
+    assert ok, f"{name}: result differs from the torch recomputation: {detail}"
+    return {"ok": True, "what": detail}
+
+
 def time_plan(ctx, ops, tc, template, steps, warmup):
     def step():
         out = [b for b in ops.with_fresh_state(template).execute(0, tc)]
         ctx.synchronize()
+        LAST_OUT[0] = out
         return sum(b.num_rows for b in out)
     breakdown = None
     for w in range(max(warmup, 1)):
@@ -84,6 +136,7 @@ def main():
 def run(args, ctx=None, emit=True):
     """args: .sf .steps .warmup .only (comma separated workload names, "" = all).  Returns the list of result dicts (bench.py nests them
     in its JSON line); emit = also print one JSON line per workload."""
+    import numpy as np
     import pyarrow as pa
     import torch
     import dfgpu
@@ -155,7 +208,38 @@ def run(args, ctx=None, emit=True):
         agg = ops.AggregateExec("Single", [(C("l_returnflag", 5), "l_returnflag"), (C("l_linestatus", 6), "l_linestatus")], aggs, proj)
         plan = ops.SortExec([ops.PhysicalSortExpr(C("l_returnflag", 0), False, False), ops.PhysicalSortExpr(C("l_linestatus", 1), False, False)], agg)
         dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan, args.steps, args.warmup)
-        report(name, dt, n, rows, bpr, kern, syncs)
+        # result check: 6 groups (l_returnflag, l_linestatus) in key order; sums / counts against torch index_add over the same tensors
+        res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
+        sel = shipdate <= 10471
+        gid = (rf.to(torch.int64) * 2 + ls.to(torch.int64))[sel]
+        gmask = [gid == k for k in range(6)]               # six groups: masked sums (an index_add of 6e8 rows into six words serialises on its atomics)
+        cnt = torch.stack([m.sum() for m in gmask])
+        got_keys = list(zip(res[0], res[1])); exp_keys = [(a, b) for a in ("A", "N", "R") for b in ("F", "O")]
+        ok = got_keys == exp_keys and [int(x) for x in res[9]] == cnt.tolist()
+        if money == "decimal":
+            q, pr, di, tx = (cols[k][:, 0][sel] for k in ("l_quantity", "l_extendedprice", "l_discount", "l_tax"))
+            acc = lambda v: [int(v[m].sum().item()) for m in gmask]
+            dp = pr * (100 - di)
+            expect = [acc(q), acc(pr), acc(dp), acc(dp * (100 + tx))]
+            for ci, w in zip((2, 3, 4, 5), expect):
+                ok = ok and [wrap64(v) for v in res[ci][0]] == [wrap64(v) for v in w]
+            for ci, w in zip((6, 7, 8), (expect[0], expect[1], acc(di))):            # AVG = SUM / COUNT, Decimal128 result: compared as a ratio to 1e-9
+                sc = 10 ** res[ci][1]
+                ok = ok and all(abs(g / sc - (wv / 100) / c) <= 1e-9 * abs((wv / 100) / c) + 10 / sc for g, wv, c in zip(res[ci][0], w, cnt.tolist()))
+            what = "6 groups in key order: COUNT(*), wrapping Int64 (low word of Decimal128) SUM(qty), SUM(price), SUM(disc_price), SUM(charge) exact; 3 AVGs to 1e-9"
+        else:
+            q, pr, di, tx = (cols[k][sel] for k in ("l_quantity", "l_extendedprice", "l_discount", "l_tax"))
+            acc = lambda v: [float(v[m].sum().item()) for m in gmask]
+            dp = pr * (1.0 - di)
+            expect = [acc(q), acc(pr), acc(dp), acc(dp * (1.0 + tx))]
+            close = lambda g, w: abs(g - w) <= 1e-9 * abs(w)
+            for ci, w in zip((2, 3, 4, 5), expect):
+                ok = ok and all(close(float(g), wv) for g, wv in zip(res[ci], w))
+            for ci, w in zip((6, 7, 8), (expect[0], expect[1], acc(di))):
+                ok = ok and all(close(float(g), wv / c) for g, wv, c in zip(res[ci], w, cnt.tolist()))
+            what = "6 groups in key order: COUNT(*) exact; Float64 SUMs and AVGs within 1e-9 relative of torch index_add"
+        del sel, gid, gmask, q, pr, di, tx, dp
+        report(name, dt, n, rows, bpr, kern, syncs, {"result_check": check(name, ok, what)})
         del cols, rf, ls, shipdate, arrays, batch, src, plan
         torch.cuda.empty_cache()
 
@@ -168,7 +252,13 @@ def run(args, ctx=None, emit=True):
         sub = ops.AggregateExec("Single", [(C("l_orderkey", 0), "l_orderkey")], [ops.AggregateFunctionExpr("SUM", C("l_quantity", 1), "SUM(l_quantity)", input_field=F("q", capi.DECIMAL128, 15, 2))], src)
         plan = ops.CoalesceBatchesExec(ops.FilterExec(B(C("SUM(l_quantity)", 1), ">", L(decimal.Decimal(300), pa.decimal128(25, 2))), sub), 8192)
         dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan, args.steps, args.warmup)
-        report("q18_groups", dt, n, rows, 8 + 16, kern, syncs, {"groups": n_orders})
+        res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
+        kk = l_orderkey - 1; oidx = (kk // 32) * 8 + (kk % 32); del kk
+        sums = torch.zeros(n_orders, dtype=torch.int64, device="cuda").index_add_(0, oidx, qty[:, 0]); big = sums > 30000
+        ok = rows == int(big.sum().item()) and wrap64(sum(int(x) for x in res[0])) == wrap64(int(((torch.nonzero(big).flatten() // 8) * 32 + torch.nonzero(big).flatten() % 8 + 1).sum().item())) and \
+            wrap64(sum(res[1][0])) == wrap64(int(sums[big].sum().item()))
+        del oidx, sums, big
+        report("q18_groups", dt, n, rows, 8 + 16, kern, syncs, {"groups": n_orders, "result_check": check("q18_groups", ok, "rows with SUM(l_quantity) > 300, wrapping sums of their keys and of their sums == torch index_add per order")})
         del qty, batch, src, plan
         torch.cuda.empty_cache()
 
@@ -216,7 +306,18 @@ def run(args, ctx=None, emit=True):
         rows_in = n + n_orders + n_cust + n_supp + 30
         dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan, args.steps, args.warmup)
         bytes_total = n * (8 + 8 + 16 + 16) + n_orders * (8 + 8 + 4) + n_cust * 16 + n_supp * 16
-        report("q5", dt, rows_in, rows, round(bytes_total / rows_in, 2), kern, syncs)
+        # result check: revenue per ASIA nation (n_regionkey = n_nationkey % 5 == 2), descending, against torch gathers over the dense keys
+        res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
+        o_ok = (o_orderdate >= 8766) & (o_orderdate < 9131)
+        o_nat = c_nationkey[o_custkey - 1]
+        kk = l_orderkey - 1; oidx = (kk // 32) * 8 + (kk % 32); del kk
+        s_nat = s_nationkey[l_suppkey - 1]
+        lsel = o_ok[oidx] & (s_nat == o_nat[oidx]) & (s_nat % 5 == 2)
+        rev = torch.zeros(25, dtype=torch.int64, device="cuda").index_add_(0, s_nat[lsel], (price[:, 0] * (100 - disc[:, 0]))[lsel]).tolist()
+        expect = sorted(((r, f"NATION{i:02d}") for i, r in enumerate(rev) if i % 5 == 2 and r), key=lambda t: -t[0])
+        ok = [(wrap64(v), nm) for v, nm in zip(res[1][0], res[0])] == [(wrap64(r), nm) for r, nm in expect]
+        del o_ok, o_nat, oidx, s_nat, lsel
+        report("q5", dt, rows_in, rows, round(bytes_total / rows_in, 2), kern, syncs, {"result_check": check("q5", ok, "SUM(l_extendedprice * (1 - l_discount)) per ASIA nation, order included, == torch gathers + index_add (exact, low word of Decimal128)")})
         del customer, orders, line, supplier, plan, price, disc, l_suppkey, o_custkey, o_orderdate, o_orderkey
         torch.cuda.empty_cache()
 
@@ -249,7 +350,17 @@ def run(args, ctx=None, emit=True):
         rows_in = 2 * n + n_orders + n_cust
         dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan, args.steps, args.warmup)
         bytes_total = 2 * n * (8 + 16) + n_orders * (8 + 8 + 16 + 4) + n_cust * 8
-        report("q18", dt, rows_in, rows, round(bytes_total / rows_in, 2), kern, syncs)
+        # result check: one row per order whose lineitems sum to > 300, ordered by o_totalprice DESC, o_orderdate
+        res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
+        kk = l_orderkey - 1; oidx = (kk // 32) * 8 + (kk % 32); del kk
+        sums = torch.zeros(n_orders, dtype=torch.int64, device="cuda").index_add_(0, oidx, qty[:, 0]); big = torch.nonzero(sums > 30000).flatten()
+        tp, od = o_totalprice[:, 0][big], o_orderdate[big].to(torch.int64)
+        order = torch.argsort((tp.max() - tp) * 4096 + (od - 8035), stable=True)
+        big = big[order]
+        ok = rows == big.numel() and np.array_equal(np.asarray(res[1]).astype(np.int64), o_orderkey[big].cpu().numpy()) and np.array_equal(np.asarray(res[0]).astype(np.int64), o_custkey[big].cpu().numpy()) and \
+            [wrap64(v) for v in res[4][0]] == [wrap64(v) for v in sums[big].tolist()] and [wrap64(v) for v in res[3][0]] == [wrap64(v) for v in o_totalprice[:, 0][big].tolist()]
+        del oidx, sums, big, tp, od, order
+        report("q18", dt, rows_in, rows, round(bytes_total / rows_in, 2), kern, syncs, {"result_check": check("q18", ok, "every result row (c_custkey, o_orderkey, o_totalprice, SUM(l_quantity)) in output order == torch index_add + stable argsort")})
         del customer, orders, line, plan, qty, o_totalprice, o_custkey, o_orderdate, o_orderkey
         torch.cuda.empty_cache()
 
@@ -266,8 +377,27 @@ def run(args, ctx=None, emit=True):
         j = ops.HashJoinExec(ops.MemoryExec([[left]], left.schema), ops.MemoryExec([[right]], right.schema), [(C("k", 0), C("k", 0))], None, "Inner", "CollectLeft")
         plan = ops.AggregateExec("Single", [], [ops.AggregateFunctionExpr("SUM", C("v", 2), "s", input_field=F("v", capi.INT64)), ops.AggregateFunctionExpr("COUNT", None, "c")], j)
         dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan, args.steps, args.warmup)
-        report("hash_join_sparse_keys", dt, nb + npr, rows, round((nb * 8 + npr * 16) / (nb + npr), 2), kern, syncs, {"build_rows": nb, "probe_rows": npr, "match_fraction": 0.2})
-        del bk, pk, pv, left, right, plan
+        res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
+        sb = torch.sort(bk).values; pos = torch.searchsorted(sb, pk).clamp_(max=nb - 1); hit = sb[pos] == pk         # build keys are distinct (62-bit random): a match is one pair
+        ok = int(res[1][0]) == int(hit.sum().item()) and wrap64(int(res[0][0])) == wrap64(int(pv[hit].sum().item()))
+        del sb, pos, hit
+        report("hash_join_sparse_keys", dt, nb + npr, rows, round((nb * 8 + npr * 16) / (nb + npr), 2), kern, syncs, {"build_rows": nb, "probe_rows": npr, "match_fraction": 0.2,
+               "result_check": check("hash_join_sparse_keys", ok, "COUNT(*) and SUM(v) over the join output == torch sort + searchsorted over the same keys")})
+        # the same join with a foreign-key build side: every build key five times (75 M build rows at SF100 would leave the 2048-partition range: 3 M distinct keys x 5)
+        nd = nb // 5
+        bk5 = bk[:nd].repeat(5)[torch.randperm(nd * 5, generator=g, device="cuda")]
+        torch.cuda.synchronize()
+        left5 = ops.RecordBatch.from_arrays(ctx, ["k"], [ctx.wrap_tensor(bk5, capi.INT64)])
+        j5 = ops.HashJoinExec(ops.MemoryExec([[left5]], left5.schema), ops.MemoryExec([[right]], right.schema), [(C("k", 0), C("k", 0))], None, "Inner", "CollectLeft")
+        plan5 = ops.AggregateExec("Single", [], [ops.AggregateFunctionExpr("SUM", C("v", 2), "s", input_field=F("v", capi.INT64)), ops.AggregateFunctionExpr("COUNT", None, "c")], j5)
+        dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan5, args.steps, args.warmup)
+        res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
+        sb = torch.sort(bk[:nd]).values; pos = torch.searchsorted(sb, pk).clamp_(max=nd - 1); hit = sb[pos] == pk
+        ok = int(res[1][0]) == 5 * int(hit.sum().item()) and wrap64(int(res[0][0])) == wrap64(5 * int(pv[hit].sum().item()))
+        del sb, pos, hit
+        report("hash_join_sparse_keys_fk5", dt, nd * 5 + npr, rows, round((nd * 5 * 8 + npr * 16) / (nd * 5 + npr), 2), kern, syncs, {"build_rows": nd * 5, "probe_rows": npr, "rows_per_build_key": 5,
+               "result_check": check("hash_join_sparse_keys_fk5", ok, "COUNT(*) and SUM(v) over the join output (5 pairs per matching probe row) == torch")})
+        del bk, pk, pv, left, right, plan, bk5, left5, j5, plan5
         torch.cuda.empty_cache()
     if not want or "groupby_int64" in want:
         ng = int(1_000_000 * args.sf)
@@ -280,7 +410,14 @@ def run(args, ctx=None, emit=True):
                                     ops.MemoryExec([[b]], b.schema))
             plan = ops.SortExec([ops.PhysicalSortExpr(C("s", 1), True, True), ops.PhysicalSortExpr(C("k", 0), False, False)], agg, fetch=10)
             dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan, args.steps, args.warmup)
-            report(f"groupby_int64_unclustered_{total}", dt, ng, rows, 16, kern, syncs, {"cardinality": total})
+            res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
+            kid = keys // 7919
+            sums = torch.zeros(total, dtype=torch.int64, device="cuda").index_add_(0, kid, val); cnts = torch.zeros(total, dtype=torch.int64, device="cuda").index_add_(0, kid, torch.ones_like(val))
+            top = torch.argsort(sums * (2 * total) + (total - 1 - torch.arange(total, device="cuda")), descending=True)[:10]       # s DESC, k ASC
+            ok = np.array_equal(np.asarray(res[0]).astype(np.int64), (top * 7919).cpu().numpy()) and np.array_equal(np.asarray(res[1]).astype(np.int64), sums[top].cpu().numpy()) and \
+                np.array_equal(np.asarray(res[2]).astype(np.int64), cnts[top].cpu().numpy())
+            del kid, sums, cnts, top
+            report(f"groupby_int64_unclustered_{total}", dt, ng, rows, 16, kern, syncs, {"cardinality": total, "result_check": check(f"groupby_int64_unclustered_{total}", ok, "the 10 result rows (k, SUM, COUNT) in order == torch index_add + argsort")})
             del keys, val, b, agg, plan
             torch.cuda.empty_cache()
 
@@ -302,6 +439,7 @@ def run(args, ctx=None, emit=True):
                     for b in out:
                         b.columns                        # the sorted columns, not only the order
                 ctx.synchronize()
+                LAST_OUT[0] = out
                 return sum(b.num_rows for b in out)
             for _ in range(max(args.warmup, 1)):
                 step()
@@ -313,7 +451,16 @@ def run(args, ctx=None, emit=True):
             kern = {k: round(v[1], 3) for k, v in sorted(p.items(), key=lambda kv: -kv[1][1]) if not k.startswith("sync:")}
             return dt, rows, kern, sum(v[0] for k, v in p.items() if k.startswith("sync:"))
         dt, rows, kern, syncs = timed_sort()
-        report("sort", dt, ns, rows, 2 * (8 + 16 + 4), kern, syncs, {"sort_keys": "Decimal128 DESC NULLS FIRST, Date32 ASC NULLS LAST"})
+        # result check: the whole permutation against a stable torch sort of the composite key (both sorts are stable: ties keep input order)
+        outb = LAST_OUT[0]; LAST_OUT[0] = None
+        comp = (price[:, 0].max() - price[:, 0]) * 4096 + (sdate.to(torch.int64) - 8035)
+        perm = torch.sort(comp, stable=True).indices; del comp
+        got_key = torch.cat([dev_tensor(torch, b.columns[0], "<i8") for b in outb])
+        got_date = torch.cat([dev_tensor(torch, b.columns[2], "<i4") for b in outb])
+        ok = rows == ns and bool(torch.equal(got_key, okey[perm])) and bool(torch.equal(got_date, sdate[perm]))
+        del perm, got_key, got_date, outb
+        report("sort", dt, ns, rows, 2 * (8 + 16 + 4), kern, syncs, {"sort_keys": "Decimal128 DESC NULLS FIRST, Date32 ASC NULLS LAST",
+               "result_check": check("sort", ok, "l_orderkey and l_shipdate of every output row == the input gathered through a stable torch sort of the composite key")})
         del price, sdate, okey, batch, plan
         torch.cuda.empty_cache()
 
@@ -331,12 +478,13 @@ def run(args, ctx=None, emit=True):
 
             def timed_partition():
                 def step():
-                    p2 = ops.with_fresh_state(plan); rows = 0
+                    p2 = ops.with_fresh_state(plan); rows = 0; keep = []
                     with ctx.deferred_flags():
                         for d in range(nparts):
                             for b in p2.execute(d, tc):
-                                b.columns; rows += b.num_rows
+                                b.columns; rows += b.num_rows; keep.append((d, b))
                     ctx.synchronize()
+                    LAST_OUT[0] = keep
                     return rows
                 for _ in range(max(args.warmup, 1)):
                     step()
@@ -349,7 +497,22 @@ def run(args, ctx=None, emit=True):
                 return dt, rows, kern, sum(v[0] for k, v in pr.items() if k.startswith("sync:"))
             dt, rows, kern, syncs = timed_partition()
             assert rows == n
-            report("partition_hash_%d" % nparts, dt, n, rows, 2 * (8 + 16 + 16 + 4), kern, syncs, {"partitions": nparts})
+            # result check: rows conserved (count, wrapping sums of key / price / date), and no key in two partitions: owner[order index] is written by every
+            # partition for its rows and read back -- a key that two partitions hold fails the read-back of the one that wrote first
+            keep = LAST_OUT[0]; LAST_OUT[0] = None
+            owner = torch.full((n_orders,), -1, dtype=torch.int8, device="cuda"); sk = sp = sd = 0; parts = []
+            for d, b in keep:
+                if not b.num_rows:
+                    continue
+                kd = dev_tensor(torch, b.columns[0], "<i8"); kk = kd - 1; oi = (kk // 32) * 8 + (kk % 32)
+                owner[oi] = d; parts.append((d, oi)); sk += int(kd.sum().item())
+                sp += int(dev_tensor(torch, b.columns[1], "<i8", 2)[:, 0].sum().item()); sd += int(dev_tensor(torch, b.columns[3], "<i4").to(torch.int64).sum().item())
+                del kd, kk
+            ok = all(bool((owner[oi] == d).all().item()) for d, oi in parts)
+            ok = ok and wrap64(sk) == wrap64(int(l_orderkey.sum().item())) and wrap64(sp) == wrap64(int(price[:, 0].sum().item())) and sd == int(sdate.to(torch.int64).sum().item())
+            del keep, owner, parts
+            report("partition_hash_%d" % nparts, dt, n, rows, 2 * (8 + 16 + 16 + 4), kern, syncs, {"partitions": nparts,
+                   "result_check": check("partition_hash_%d" % nparts, ok, "row count and wrapping column sums conserved; every l_orderkey value lives in exactly one output partition")})
             del plan
         del price, disc, sdate, batch
         torch.cuda.empty_cache()
@@ -373,6 +536,17 @@ def run(args, ctx=None, emit=True):
                           "l_discount": dec(0, 11), "l_shipdate": pa.array(rng.integers(8035, 10560, nr).astype(np.int32), type=pa.date32()),
                           "l_returnflag": pick(["A", "N", "R"]), "l_linestatus": pick(["F", "O"]), "l_shipmode": pick(["AIR", "FOB", "MAIL", "RAIL", "REG AIR", "SHIP", "TRUCK"])})
         decoded = nr * (8 + 3 * 16 + 4 + 3 * 4)
+
+        def scan_check(cols, tab):
+            """decoded device columns (Array objects) against the source table, column by column"""
+            for i, c in enumerate(cols):
+                a = c.to_arrow()
+                if pa.types.is_dictionary(a.type):
+                    a = a.cast(a.type.value_type)
+                w = tab.column(i).combine_chunks().slice(0, len(a))
+                if len(a) != len(w) or not a.equals(w.cast(a.type)):
+                    return False
+            return True
         for label, kw in (("snappy_dict", dict(compression="snappy", use_dictionary=True)), ("zstd_dict", dict(compression="zstd", use_dictionary=True)), ("plain", dict(compression="none", use_dictionary=False))):
             name = "parquet_scan_" + label
             if want and not any(w in name for w in want):
@@ -386,6 +560,7 @@ def run(args, ctx=None, emit=True):
                 def step():
                     cols = f.read()
                     ctx.synchronize()
+                    LAST_OUT[0] = cols
                     return len(cols[0])
                 for _ in range(max(args.warmup, 1)):
                     step()
@@ -394,6 +569,7 @@ def run(args, ctx=None, emit=True):
                 for _ in range(args.steps):
                     rows = step()
                 dt = (time.perf_counter() - t0) / args.steps
+                scan_ok = scan_check(LAST_OUT[0], table); LAST_OUT[0] = None
                 kern = {k: round(v[1], 3) for k, v in sorted(pr.items(), key=lambda kv: -kv[1][1]) if not k.startswith("sync:")}
                 syncs = sum(v[0] for k, v in pr.items() if k.startswith("sync:"))
                 f.close()
@@ -405,7 +581,8 @@ def run(args, ctx=None, emit=True):
             assert rows == nr
             report(name, dt, nr, rows, decoded // nr, kern, syncs, {"file_bytes": fbytes, "decoded_bytes": decoded, "row_groups": (nr + (1 << 20) - 1) >> 20, "decoded_GBps": round(decoded / dt / 1e9, 1),
                                                                     "file_GBps": round(fbytes / dt / 1e9, 1), "from_host_image_ms": round(dth * 1e3, 1), "from_host_image_decoded_GBps": round(decoded / dth / 1e9, 2),
-                                                                    "columns": "Int64 key, 3 x Decimal128(15,2) (FIXED_LEN_BYTE_ARRAY), Date32, 3 x Utf8 kept as Dictionary(Int32, Utf8)"})
+                                                                    "columns": "Int64 key, 3 x Decimal128(15,2) (FIXED_LEN_BYTE_ARRAY), Date32, 3 x Utf8 kept as Dictionary(Int32, Utf8)",
+                                                                    "result_check": check(name, scan_ok, "every decoded column == the pyarrow table the file was written from (values compared after the D2H copy)")})
         # ---- CsvExec's per-file work: the same table as text (written by pyarrow.csv), image resident in HBM -> columns in HBM
         if not want or any(w in "csv_scan" for w in want):
             import io
@@ -421,6 +598,7 @@ def run(args, ctx=None, emit=True):
             def step():
                 cols = read_csv(ctx, dimg, sch, on_device=True)
                 ctx.synchronize()
+                LAST_OUT[0] = cols
                 return len(cols[0])
             for _ in range(max(args.warmup, 1)):
                 step()
@@ -432,8 +610,10 @@ def run(args, ctx=None, emit=True):
             kern = {k: round(v[1], 3) for k, v in sorted(pr.items(), key=lambda kv: -kv[1][1]) if not k.startswith("sync:")}
             syncs = sum(v[0] for k, v in pr.items() if k.startswith("sync:"))
             assert rows == nc
+            csv_ok = scan_check(LAST_OUT[0], table.slice(0, nc)); LAST_OUT[0] = None
             report("csv_scan", dt, nc, rows, len(img) // nc, kern, syncs, {"file_bytes": len(img), "file_GBps": round(len(img) / dt / 1e9, 1),
-                                                                                    "columns": "Int64 key, 3 x Decimal128(15,2), Date32, 3 x Utf8; text written by pyarrow.csv, image resident in HBM"})
+                                                                                    "columns": "Int64 key, 3 x Decimal128(15,2), Date32, 3 x Utf8; text written by pyarrow.csv, image resident in HBM",
+                                                                                    "result_check": check("csv_scan", csv_ok, "every parsed column == the pyarrow table the text was written from")})
             del dimg, img
         del table
 
@@ -466,7 +646,22 @@ def run(args, ctx=None, emit=True):
         having = ops.FilterExec(B(C("c", 2), ">", L(3, pa.int64())), agg)
         plan = ops.SortExec([ops.PhysicalSortExpr(C("l", 1), True, True), ops.PhysicalSortExpr(C("k", 0), False, False)], having, fetch=25)
         dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan, args.steps, args.warmup)
-        report(name, dt, nrows, rows, 4 + 4 + 8, kern, syncs, {"cardinality": card})
+        # result check: AVG / COUNT / MAX per key with torch index_add / scatter_reduce, HAVING c > 3, top 25 by (avg DESC, key ASC)
+        res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
+        nz = ids != 0; idl = ids[nz].to(torch.int64)
+        cs = torch.zeros(card, dtype=torch.int64, device="cuda").index_add_(0, idl, torch.ones_like(idl))
+        ls_ = torch.zeros(card, dtype=torch.int64, device="cuda").index_add_(0, idl, length[nz].to(torch.int64))
+        mx = torch.full((card,), -1, dtype=torch.int64, device="cuda").scatter_reduce_(0, idl, w[nz], reduce="amax")
+        have = torch.nonzero(cs > 3).flatten()
+        avg = ls_[have].to(torch.float64) / cs[have].to(torch.float64)
+        kth = torch.topk(avg, min(25, avg.numel())).values[-1] if avg.numel() else None
+        cand = have[avg >= kth].tolist() if kth is not None else []                  # everything tied with the 25th average takes part in the key tie-break
+        cand.sort(key=lambda k: (-(ls_[k].item() / cs[k].item()), words[k].as_py()))
+        expect = [(words[k].as_py(), ls_[k].item() / cs[k].item(), int(cs[k].item()), int(mx[k].item())) for k in cand[:25]]
+        got = [(k, float(a), int(c_), int(m)) for k, a, c_, m in zip(res[0], res[1], res[2], res[3])]
+        ok = len(got) == len(expect) and all(g[0] == w_[0] and abs(g[1] - w_[1]) <= 1e-9 * abs(w_[1]) and g[2:] == w_[2:] for g, w_ in zip(got, expect))
+        del nz, idl, cs, ls_, mx, have, avg
+        report(name, dt, nrows, rows, 4 + 4 + 8, kern, syncs, {"cardinality": card, "result_check": check(name, ok, "the 25 result rows (key, AVG, COUNT, MAX) in order == torch index_add / scatter_reduce + HAVING + top 25")})
         del ids, length, w, batch, src, plan, dictionary
         torch.cuda.empty_cache()
     return out

@@ -201,7 +201,8 @@ __device__ inline bool pj_group(const uint4 v, uint32_t tagsh, uint32_t s, uint3
 
 // ---- build side check: one workgroup per partition inserts the partition's keys into the LDS table exactly as the probe kernel will.
 // flags: [0] largest partition, [1] a key repeats, [2] a partition is beyond the table's capacity, [4] most distinct keys in one partition; ndist[p] = distinct keys of partition p
-__global__ void __launch_bounds__(PJ_NT) k_pj_check(const RpRec12* brec, const uint32_t* bstart, unsigned long long* flags, uint32_t* ndist) {
+// max_sbits: the table the launch has LDS for; a partition that needs a larger one raises flags[6] (the host launches again with 128 KB)
+__global__ void __launch_bounds__(PJ_NT) k_pj_check(const RpRec12* brec, const uint32_t* bstart, int max_sbits, unsigned long long* flags, uint32_t* ndist) {
   extern __shared__ uint32_t pj_lds[];
   __shared__ uint32_t nd_sh;
   const uint32_t b0 = bstart[blockIdx.x], nb = bstart[blockIdx.x + 1] - b0;
@@ -209,6 +210,7 @@ __global__ void __launch_bounds__(PJ_NT) k_pj_check(const RpRec12* brec, const u
   if (nb > PJ_MAX_PART_ROWS) { if (threadIdx.x == 0) { flags[2] = 1ull; ndist[blockIdx.x] = nb; } return; }
   int sbits = 6; while ((1u << sbits) < 2 * nb && sbits < PJ_MAX_SBITS) sbits++;
   if ((1u << sbits) < nb + nb / 8 + 4) { if (threadIdx.x == 0) { flags[2] = 1ull; ndist[blockIdx.x] = nb; } return; }
+  if (sbits > max_sbits) { if (threadIdx.x == 0) flags[6] = 1ull; return; }
   const uint32_t S = 1u << sbits;
   for (uint32_t s = threadIdx.x; s < S; s += PJ_NT) pj_lds[s] = PJ_EMPTY;
   __syncthreads();
@@ -508,14 +510,19 @@ bool pj_build(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   BufferPtr recs = alloc_buffer(ctx, (size_t)(n + 1) * 12), ndist = alloc_buffer(ctx, (size_t)(P64 + 1) * 4);
   zero_scratch(ctx);
   PjOffsets off = pj_partition(ctx, key0, t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr, part->P, (RpRec12*)recs->ptr, ctx->d_scratch64 + 3, "pj_build_hist", "pj_build_scan", "pj_build_scatter");
-  { KernelTimer kt_(ctx, "pj_build_check");
-    const size_t lds = (size_t)(1u << PJ_MAX_SBITS) * 4;
-    pj_set_lds((const void*)k_pj_check, lds);
-    hipLaunchKernelGGL(k_pj_check, dim3(part->P), dim3(PJ_NT), lds, ctx->stream, (const RpRec12*)recs->ptr, (const uint32_t*)off.pstart->ptr, (unsigned long long*)ctx->d_scratch64, (uint32_t*)ndist->ptr);
-    KERNEL_CHECK(); }
-  const uint64_t* h = read_scratch_range(ctx, 0, 6);
-  ctx->count_sync("sync:pj_build_check");
-  const uint64_t max_rows = h[0], dup = h[1], over = h[2], moved = h[3], max_dist = h[4];
+  uint64_t max_rows = 0, dup = 0, over = 0, moved = 0, max_dist = 0;
+  for (int max_sbits = (n + P64 - 1) / P64 <= 7500 ? 14 : PJ_MAX_SBITS;; max_sbits = PJ_MAX_SBITS) {      // 64 KB of LDS (two workgroups per CU) when the average partition leaves room for its spread
+    { KernelTimer kt_(ctx, "pj_build_check");
+      const size_t lds = (size_t)(1u << max_sbits) * 4;
+      pj_set_lds((const void*)k_pj_check, lds);
+      hipLaunchKernelGGL(k_pj_check, dim3(part->P), dim3(PJ_NT), lds, ctx->stream, (const RpRec12*)recs->ptr, (const uint32_t*)off.pstart->ptr, max_sbits, (unsigned long long*)ctx->d_scratch64, (uint32_t*)ndist->ptr);
+      KERNEL_CHECK(); }
+    const uint64_t* h = read_scratch_range(ctx, 0, 7);
+    ctx->count_sync("sync:pj_build_check");
+    max_rows = h[0]; dup = h[1]; over = h[2]; moved = h[3]; max_dist = h[4];
+    if (!h[6] || max_sbits == PJ_MAX_SBITS) break;
+    HIP_CHECK(hipMemsetAsync(ctx->d_scratch64, 0, 24, ctx->stream)); HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 4, 0, 24, ctx->stream));       // a partition beyond 8192 rows: once more with the 128 KB table (slot 3, the rows moved, stays)
+  }
   if (over) return false;
   part->rows = (int64_t)moved; part->starts = off.pstart; part->recs = recs;
   uint64_t max_keys = max_rows;
