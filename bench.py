@@ -108,12 +108,37 @@ def parse_args():
     ap.add_argument("--no-workloads", action="store_true", help="N = 1: skip the nested other plan shapes (bench_workloads.py)")
     ap.add_argument("--workloads", default="q1_decimal,q1_float64,q5,q18,hash_join,groupby_int64,sort,partition,parquet_scan,csv_scan,clickbench_uniform_1000000,clickbench_zipf_1000000",
                     help="N = 1: which plan shapes of bench_workloads.py to nest under \"workloads\"")
+    ap.add_argument("--collective-deadline", type=float, default=180.0, help="N > 1: seconds without progress (no exchange started, no step finished) after which a rank reports where it stands and exits with code 3 instead of hanging the job")
     ap.add_argument("--native-exchange", action="store_true", help="N > 1 workloads: ShuffleExec through the C entry point dfgpu_exchange (RCCL inside libdfgpu.so) instead of torch.distributed collectives")
     ap.add_argument("--plan", choices=["colocated", "broadcast", "shuffle"], default="shuffle",
                     help="N > 1: colocated = customer build side broadcast, orders-lineitem join and aggregation partition-local (the shards are co-partitioned on "
                          "the order key, as TPC-H files are); broadcast = both build sides all-gathered (CollectLeft), partial aggregates shuffled; "
                          "shuffle = the reference's fully partitioned plan (hash repartition of every join / aggregate input)")
     return ap.parse_args()
+
+
+class Watchdog:
+    """N > 1: a rank stuck in a collective (a peer died, a lane mismatch) would otherwise hang the whole job until the driver's limit.  The main thread
+    reports every exchange it starts and every step it finishes; a daemon thread exits the process (os._exit: no re-exec, no cleanup that could block
+    on the GPU) with a line that says which rank stopped where once nothing has moved for `deadline` seconds."""
+
+    def __init__(self, rank, deadline):
+        import threading
+        self.rank, self.deadline, self.phase, self.t, self.armed = rank, deadline, "start", time.time(), False
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def beat(self, phase):
+        self.phase, self.t = phase, time.time()
+
+    def arm(self, on, phase=""):
+        self.armed = on; self.beat(phase or self.phase)
+
+    def _run(self):
+        while True:
+            time.sleep(1.0)
+            if self.armed and time.time() - self.t > self.deadline:
+                sys.stderr.write(json.dumps({"watchdog": "no progress", "rank": self.rank, "seconds": round(time.time() - self.t, 1), "last": self.phase}) + "\n"); sys.stderr.flush()
+                os._exit(3)
 
 
 def main():
@@ -153,6 +178,14 @@ def main():
     torch.cuda.synchronize()
 
     result_rows, last_out = [0], [None]
+    ranks_seen = 1
+    wd = None
+    if world > 1:
+        t = torch.ones(1, dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        ranks_seen = int(t.item())                      # every rank of the launch takes part in the collectives (reported in the JSON line)
+        wd = Watchdog(rank, args.collective_deadline)
+        exchange.PROGRESS = wd.beat
 
     PLANS = {"colocated": tpch.q3_colocated_plan, "broadcast": tpch.q3_broadcast_plan, "shuffle": tpch.q3_distributed_plan}
     Q3_OUTPUT = ["l_orderkey", "revenue", "o_orderdate", "o_shippriority"]
@@ -176,6 +209,7 @@ def main():
             plan = ops.with_fresh_state(template)
             out = [b for b in plan.execute(0, tc)]
         else:
+            wd.arm(True, "Q3 step (%s plan)" % args.plan)
             plan = staged if staged is not None else PLANS[args.plan](tables, batch_size=8192)
             with ctx.deferred_flags():          # one error-flag read-back for the rank's plan + gather instead of one per materialised column
                 local = [b for b in plan.execute(0, tc)]
@@ -186,6 +220,8 @@ def main():
                 final_slot.replace([[gathered]])
                 out = [b for b in ops.with_fresh_state(final_plan).execute(0, tc)]
         ctx.synchronize()
+        if wd is not None:
+            wd.arm(False, "Q3 step done")
         result_rows[0] = sum(b.num_rows for b in out)
         last_out[0] = out
 
@@ -323,6 +359,7 @@ def main():
                 continue
             st2 = tpch.Q3ColocatedStaged(tables, batch_size=8192) if name == "colocated" else None
             def step2():
+                wd.arm(True, "Q3 step (%s plan)" % name)
                 plan = st2 if st2 is not None else PLANS[name](tables, batch_size=8192)
                 with ctx.deferred_flags():
                     local = [b for b in plan.execute(0, tc)]
@@ -332,6 +369,7 @@ def main():
                     final_slot.replace([[gathered]])
                     [b for b in ops.with_fresh_state(final_plan).execute(0, tc)]
                 ctx.synchronize()
+                wd.arm(False)
             step2(); barrier(); t1 = time.perf_counter()
             for _ in range(args.steps):
                 step2()
@@ -352,6 +390,7 @@ def main():
 
             def run_dist(name, build, outputs, sort_keys, fetch, rows_local, checksum):
                 def stepd():
+                    wd.arm(True, "workload %s step" % name)
                     plan = build()
                     with ctx.deferred_flags():
                         local = [b for b in plan.execute(0, tc)]
@@ -361,6 +400,7 @@ def main():
                     if rank == 0 and gathered.num_rows:
                         res = [b for b in ops.SortExec(sort_keys, ops.MemoryExec([[gathered]], gathered.schema), fetch=fetch).execute(0, tc)]
                     ctx.synchronize()
+                    wd.arm(False)
                     return plan, res
                 for _ in range(max(1, args.warmup)):
                     stepd()
@@ -450,6 +490,9 @@ def main():
             if dist_workloads:
                 line["workloads"] = dist_workloads
             line["config"]["plan"] = args.plan
+            line["ranks_seen"] = ranks_seen
+            line["config"]["exchange_path"] = ("dfgpu_exchange (C ABI, RCCL grouped send / recv inside libdfgpu.so)" if args.native_exchange else "exchange.py over torch.distributed (%s): one metadata all-gather + one all-to-all(v) per exchange" % args.backend) + \
+                "; Q3's own plans always use the torch.distributed path, --native-exchange switches the Q5 / ClickBench workloads"
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -50,6 +50,8 @@ __global__ void __launch_bounds__(BLOCK) k_bytes_to_bits(const uint8_t* in, int6
   if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) bits[i >> 6] = m;
 }
 
+__global__ void __launch_bounds__(BLOCK) k_offsets_to_lengths(const int32_t* off, int64_t n, int32_t* len) { int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < n) len[i] = off[i + 1] - off[i]; }
+
 }  // namespace dfgpu
 using namespace dfgpu;
 
@@ -94,106 +96,183 @@ dfgpu_status dfgpu_exchange(dfgpu_ctx* ctx, dfgpu_comm* comm, const dfgpu_array*
     if (ncols > MAXC) fail(DFGPU_NOT_IMPLEMENTED, "exchange of more than %d columns", MAXC);
     const bool have = cols != nullptr && keys != nullptr;          // a rank whose input produced no batch still takes part: it learns the column types from the others
     const int64_t n = have ? keys[0]->length : 0;
-    // ---- 1. every column grouped by destination rank in one pass
-    std::vector<ArrayHolder> gh((size_t)ncols), vbytes((size_t)ncols); ArrayHolder idx_h; std::vector<int64_t> send_rows((size_t)W, 0);
-    if (have) {
-      for (int32_t c = 0; c < ncols; c++) {
-        const dfgpu_array* a = cols[c];
-        if (!a || a->length != n) fail(DFGPU_INVALID_ARGUMENT, "exchange: column %d is missing or differs in length from the keys (%lld rows, type %d; keys hold %lld)", c, a ? (long long)a->length : -1ll, a ? a->type : 0, (long long)n);
-        if (a->type == DFGPU_DICTIONARY || a->type == DFGPU_UTF8 || a->type == DFGPU_BOOL || !type_width(a->type))
-          fail(DFGPU_NOT_IMPLEMENTED, "exchange of column %d (type %d): fixed-width columns only; cast dictionary / Utf8 columns or use the host-side exchange", c, a->type);
-      }
-      // a nullable column = its values (validity detached) + the validity as one byte per row, both partitioned like any other column
-      std::vector<const dfgpu_array*> pcols; std::vector<ArrayHolder> tmp; std::vector<int> lane_col, lane_is_valid;
-      for (int32_t c = 0; c < ncols; c++) {
-        const dfgpu_array* a = cols[c];
-        if (a->validity) {
-          ArrayHolder data(new_array(ctx, a->type, n, a->precision, a->scale)); data.get()->values = a->values; data.get()->null_count = 0;
-          ArrayHolder vb(new_fixed(ctx, DFGPU_UINT8, n));
-          if (n) hipLaunchKernelGGL(k_bits_to_bytes, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)a->validity->ptr, n, (uint8_t*)vb.get()->values->ptr);
+    // ---- 1. every column grouped by destination rank: fixed-width columns without NULLs in the partition pass itself, every other column (NULLs, Utf8,
+    // Boolean, dictionary) by a take through the pass's row numbers.  A failure here must not keep this rank away from the collective below (its peers
+    // would wait in it for ever): it is caught, travels as a status word, and every rank fails together.
+    std::vector<ArrayHolder> gh((size_t)ncols); std::vector<int64_t> send_rows((size_t)W, 0);
+    std::vector<std::vector<int64_t>> ubytes((size_t)ncols);                       // Utf8 columns: value bytes per destination
+    std::vector<BufferPtr> ulen((size_t)ncols), vbytes((size_t)ncols), bbytes((size_t)ncols);      // Utf8 lengths (int32 per row), validity / Boolean values as one byte per row
+    int64_t local_status = DFGPU_OK; std::string local_err;
+    auto lane_type = [](const dfgpu_array* a) { return a->type == DFGPU_DICTIONARY ? a->dictionary->type : a->type; };
+    try {
+      if (have) {
+        std::vector<ArrayHolder> plain((size_t)ncols);             // dictionary columns travel as their values
+        std::vector<const dfgpu_array*> src((size_t)ncols);
+        for (int32_t c = 0; c < ncols; c++) {
+          const dfgpu_array* a = cols[c];
+          if (!a || a->length != n) fail(DFGPU_INVALID_ARGUMENT, "exchange: column %d is missing or differs in length from the keys (%lld rows, type %d; keys hold %lld)", c, a ? (long long)a->length : -1ll, a ? a->type : 0, (long long)n);
+          const int32_t lt = lane_type(a);
+          if (lt != DFGPU_UTF8 && lt != DFGPU_BOOL && !type_width(lt)) fail(DFGPU_NOT_IMPLEMENTED, "exchange of column %d (type %d)", c, lt);
+          if (a->type == DFGPU_DICTIONARY) {        // decode: take(dictionary values, keys) -- a NULL key or a NULL dictionary entry is a NULL cell
+            ArrayHolder kv(new_array(ctx, a->key_type, n)); kv.get()->values = a->values; kv.get()->validity = a->validity; kv.get()->null_count = a->validity ? -1 : 0;
+            const dfgpu_array* kidx = kv.get(); ArrayHolder k32;
+            if (type_width(a->key_type) < 4) { dfgpu_array* w = nullptr; dfgpu_status st = dfgpu_cast(ctx, kv.get(), DFGPU_INT32, 0, 0, &w); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str()); k32.a = w; kidx = w; }
+            dfgpu_array* v = nullptr; dfgpu_status st = dfgpu_take(ctx, a->dictionary, kidx, &v); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str());
+            plain[(size_t)c].a = v; a = v;
+          }
+          src[(size_t)c] = a;
+        }
+        std::vector<dfgpu_array*> grouped((size_t)ncols, nullptr); dfgpu_array* idx = nullptr;
+        dfgpu_status st = dfgpu_partition_columns(ctx, keys, nkeys, W, src.data(), ncols, opt_mask, grouped.data(), &idx, send_rows.data());
+        ArrayHolder idx_h(idx);
+        for (int32_t c = 0; c < ncols; c++) gh[(size_t)c].a = grouped[(size_t)c];
+        if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str());
+        int64_t sent = 0; for (int32_t p = 0; p < W; p++) sent += send_rows[(size_t)p];
+        std::vector<int> utf;
+        for (int32_t c = 0; c < ncols; c++) {
+          if (!gh[(size_t)c].get()) { dfgpu_array* g = nullptr; st = dfgpu_take(ctx, src[(size_t)c], idx, &g); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str()); gh[(size_t)c].a = g; }
+          const dfgpu_array* g = gh[(size_t)c].get();
+          if (g->validity) { vbytes[(size_t)c] = alloc_buffer(ctx, (size_t)sent + 1); if (sent) hipLaunchKernelGGL(k_bits_to_bytes, dim3(grid_for(sent, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)g->validity->ptr, sent, (uint8_t*)vbytes[(size_t)c]->ptr); }
+          if (g->type == DFGPU_BOOL) { bbytes[(size_t)c] = alloc_buffer(ctx, (size_t)sent + 1); if (sent) hipLaunchKernelGGL(k_bits_to_bytes, dim3(grid_for(sent, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)g->values->ptr, sent, (uint8_t*)bbytes[(size_t)c]->ptr); }
+          if (g->type == DFGPU_UTF8) { ulen[(size_t)c] = alloc_buffer(ctx, (size_t)(sent + 1) * 4); if (sent) hipLaunchKernelGGL(k_offsets_to_lengths, dim3(grid_for(sent, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const int32_t*)g->offsets->ptr, sent, (int32_t*)ulen[(size_t)c]->ptr); utf.push_back(c); }
           KERNEL_CHECK();
-          pcols.push_back(data.get()); lane_col.push_back(c); lane_is_valid.push_back(0); tmp.push_back(std::move(data));
-          pcols.push_back(vb.get()); lane_col.push_back(c); lane_is_valid.push_back(1); tmp.push_back(std::move(vb));
-        } else { pcols.push_back(a); lane_col.push_back(c); lane_is_valid.push_back(0); }
+        }
+        if (!utf.empty()) {        // value bytes per destination = differences of the grouped offsets at the destination bounds: one small read-back for all Utf8 columns
+          std::vector<int32_t> bounds(utf.size() * (size_t)(W + 1), 0);
+          if (sent) {
+            for (size_t u = 0; u < utf.size(); u++) { int64_t row = 0; const int32_t* off = (const int32_t*)gh[(size_t)utf[u]].get()->offsets->ptr;
+              for (int32_t p = 0; p <= W; p++) { HIP_CHECK(hipMemcpyAsync(&bounds[u * (size_t)(W + 1) + (size_t)p], off + row, 4, hipMemcpyDeviceToHost, ctx->stream)); if (p < W) row += send_rows[(size_t)p]; } }
+            ctx->count_sync("sync:exchange_utf8_bounds");
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+          }
+          for (size_t u = 0; u < utf.size(); u++) { auto& ub = ubytes[(size_t)utf[u]]; ub.assign((size_t)W, 0); for (int32_t p = 0; p < W; p++) ub[(size_t)p] = (int64_t)bounds[u * (size_t)(W + 1) + (size_t)p + 1] - bounds[u * (size_t)(W + 1) + (size_t)p]; }
+        }
       }
-      std::vector<dfgpu_array*> grouped(pcols.size(), nullptr); dfgpu_array* idx = nullptr;
-      dfgpu_status st = dfgpu_partition_columns(ctx, keys, nkeys, W, pcols.data(), (int32_t)pcols.size(), opt_mask, grouped.data(), &idx, send_rows.data());
-      idx_h.a = idx;
-      for (size_t l = 0; l < grouped.size(); l++) { if (st == DFGPU_OK && !grouped[l]) st = DFGPU_INTERNAL; (lane_is_valid[l] ? vbytes : gh)[(size_t)lane_col[l]].a = grouped[l]; }
-      if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str());
-    }
-    // ---- 2. what the ranks must agree on, in one small all-gather: the row-count matrix, the column types, which columns are nullable anywhere
-    const int64_t ML = W + 1 + 4 * MAXC;
+    } catch (const Error& e) { local_status = e.code ? e.code : DFGPU_INTERNAL; local_err = e.msg; std::fill(send_rows.begin(), send_rows.end(), 0); }
+    // ---- 2. what the ranks must agree on, in one small all-gather: the status word, the row-count matrix, the column types, which columns are nullable
+    // anywhere, the Utf8 byte counts
+    const int64_t ML = W + 2 + 4 * (int64_t)ncols + (int64_t)ncols * W;
     std::vector<int64_t> mine((size_t)ML, 0), all((size_t)ML * W, 0);
-    for (int32_t p = 0; p < W; p++) mine[(size_t)p] = send_rows[(size_t)p];
-    mine[(size_t)W] = have ? ncols : 0;
-    if (have) for (int32_t c = 0; c < ncols; c++) { const dfgpu_array* a = cols[c]; int64_t* f = &mine[(size_t)W + 1 + 4 * (size_t)c]; f[0] = a->type; f[1] = a->precision; f[2] = a->scale; f[3] = a->validity ? 1 : 0; }
-    if (comm->custom) { if (comm->vt.all_gather_host(comm->vt.user, mine.data(), ML * 8, all.data()) != 0) fail(DFGPU_EXECUTION, "exchange: the transport's all_gather_host failed"); }
-    else {
-      BufferPtr ds = alloc_buffer(ctx, (size_t)ML * 8), dr = alloc_buffer(ctx, (size_t)ML * W * 8);
-      HIP_CHECK(hipMemcpyAsync(ds->ptr, mine.data(), (size_t)ML * 8, hipMemcpyHostToDevice, ctx->stream));
-      nccl_check(rccl().AllGather(ds->ptr, dr->ptr, (size_t)ML * 8, 1 /* ncclUint8 */, comm->nccl, ctx->stream), "ncclAllGather");
-      HIP_CHECK(hipMemcpyAsync(all.data(), dr->ptr, (size_t)ML * W * 8, hipMemcpyDeviceToHost, ctx->stream));
+    auto gather = [&](std::vector<int64_t>& m, std::vector<int64_t>& a, int64_t len, const char* what) {
+      if (comm->custom) { if (comm->vt.all_gather_host(comm->vt.user, m.data(), len * 8, a.data()) != 0) fail(DFGPU_EXECUTION, "exchange: the transport's all_gather_host failed (%s)", what); return; }
+      BufferPtr ds = alloc_buffer(ctx, (size_t)len * 8), dr = alloc_buffer(ctx, (size_t)len * W * 8);
+      HIP_CHECK(hipMemcpyAsync(ds->ptr, m.data(), (size_t)len * 8, hipMemcpyHostToDevice, ctx->stream));
+      nccl_check(rccl().AllGather(ds->ptr, dr->ptr, (size_t)len * 8, 1 /* ncclUint8 */, comm->nccl, ctx->stream), "ncclAllGather");
+      HIP_CHECK(hipMemcpyAsync(a.data(), dr->ptr, (size_t)len * W * 8, hipMemcpyDeviceToHost, ctx->stream));
       ctx->count_sync("sync:exchange_counts");
       HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    };
+    const size_t O_NCOLS = (size_t)W, O_STATUS = (size_t)W + 1, O_META = (size_t)W + 2, O_UB = O_META + 4 * (size_t)ncols;
+    for (int32_t p = 0; p < W; p++) mine[(size_t)p] = send_rows[(size_t)p];
+    mine[O_NCOLS] = have && local_status == DFGPU_OK ? ncols : 0; mine[O_STATUS] = local_status;
+    if (have && local_status == DFGPU_OK) for (int32_t c = 0; c < ncols; c++) {
+      const dfgpu_array* g = gh[(size_t)c].get(); int64_t* f = &mine[O_META + 4 * (size_t)c]; f[0] = g->type; f[1] = g->precision; f[2] = g->scale; f[3] = g->validity ? 1 : 0;
+      if (!ubytes[(size_t)c].empty()) for (int32_t p = 0; p < W; p++) mine[O_UB + (size_t)c * W + (size_t)p] = ubytes[(size_t)c][(size_t)p];
     }
-    const int64_t* ref = nullptr;                      // the first rank that holds a schema
-    for (int32_t s2 = 0; s2 < W && !ref; s2++) if (all[(size_t)s2 * ML + W] > 0) ref = &all[(size_t)s2 * ML];
+    gather(mine, all, ML, "row counts");
     for (int32_t c = 0; c < ncols; c++) out_cols[c] = nullptr;
     if (out_counts) for (int32_t p = 0; p < 2 * W; p++) out_counts[p] = 0;
+    for (int32_t s2 = 0; s2 < W; s2++) if (all[(size_t)s2 * ML + O_STATUS] != DFGPU_OK) {        // every rank leaves here, none enters the data collective
+      if (s2 == comm->rank) fail((dfgpu_status)local_status, "%s", local_err.c_str());
+      fail((dfgpu_status)all[(size_t)s2 * ML + O_STATUS], "exchange: rank %d failed before the collective (status %lld); nothing was exchanged", s2, (long long)all[(size_t)s2 * ML + O_STATUS]);
+    }
+    const int64_t* ref = nullptr;                      // the first rank that holds a schema
+    for (int32_t s2 = 0; s2 < W && !ref; s2++) if (all[(size_t)s2 * ML + O_NCOLS] > 0) ref = &all[(size_t)s2 * ML];
     if (!ref) return;                                  // nobody has rows: nothing moves, out_cols stay NULL
-    if (ref[W] != ncols) fail(DFGPU_INVALID_ARGUMENT, "exchange: this rank passes %d columns, another one %lld", ncols, (long long)ref[W]);
+    if (ref[O_NCOLS] != ncols) fail(DFGPU_INVALID_ARGUMENT, "exchange: this rank passes %d columns, another one %lld", ncols, (long long)ref[O_NCOLS]);
     std::vector<int64_t> recv_rows((size_t)W, 0); int64_t total = 0, sent = 0;
     for (int32_t s2 = 0; s2 < W; s2++) { recv_rows[(size_t)s2] = all[(size_t)s2 * ML + comm->rank]; total += recv_rows[(size_t)s2]; }
     for (int32_t p = 0; p < W; p++) sent += send_rows[(size_t)p];
-    if (total > 0xFFFFFFF0ll) fail(DFGPU_RESOURCES_EXHAUSTED, "exchange: %lld rows arrive at rank %d; more ranks or smaller batches", (long long)total, comm->rank);
     struct Meta { int32_t type, precision, scale; bool nullable; }; std::vector<Meta> meta((size_t)ncols);
+    int64_t agree = total > 0xFFFFFFF0ll ? DFGPU_RESOURCES_EXHAUSTED : DFGPU_OK;           // every rank checks every rank's view: the same verdict everywhere
+    for (int32_t r2 = 0; r2 < W; r2++) { int64_t t2 = 0; for (int32_t s2 = 0; s2 < W; s2++) t2 += all[(size_t)s2 * ML + (size_t)r2]; if (t2 > 0xFFFFFFF0ll) agree = DFGPU_RESOURCES_EXHAUSTED; }
+    if (agree != DFGPU_OK) fail(DFGPU_RESOURCES_EXHAUSTED, "exchange: more than 2^32-16 rows arrive at one rank; more ranks or smaller batches");
     for (int32_t c = 0; c < ncols; c++) {
-      const int64_t* f = ref + W + 1 + 4 * c; meta[(size_t)c] = Meta{ (int32_t)f[0], (int32_t)f[1], (int32_t)f[2], false };
-      for (int32_t s2 = 0; s2 < W; s2++) { const int64_t* g = &all[(size_t)s2 * ML]; if (g[W] > 0) { if (g[W + 1 + 4 * c] != f[0]) fail(DFGPU_INVALID_ARGUMENT, "exchange: column %d has type %lld on one rank and %lld on another", c, (long long)f[0], (long long)g[W + 1 + 4 * c]); meta[(size_t)c].nullable |= g[W + 4 + 4 * c] != 0; } }
+      const int64_t* f = ref + O_META + 4 * (size_t)c; meta[(size_t)c] = Meta{ (int32_t)f[0], (int32_t)f[1], (int32_t)f[2], false };
+      for (int32_t s2 = 0; s2 < W; s2++) { const int64_t* g = &all[(size_t)s2 * ML]; if (g[O_NCOLS] > 0) { if (g[O_META + 4 * (size_t)c] != f[0]) fail(DFGPU_INVALID_ARGUMENT, "exchange: column %d has type %lld on one rank and %lld on another", c, (long long)f[0], (long long)g[O_META + 4 * (size_t)c]); meta[(size_t)c].nullable |= g[O_META + 4 * (size_t)c + 3] != 0; } }
     }
-    // ---- 3. one grouped collective over every lane (values of every column, validity bytes of the columns that are nullable anywhere)
-    std::vector<ArrayHolder> recv((size_t)ncols), recv_valid((size_t)ncols);
-    auto offsets = [&](int64_t w, std::vector<int64_t>& so, std::vector<int64_t>& sb, std::vector<int64_t>& ro, std::vector<int64_t>& rb) {
-      so.assign((size_t)W, 0); sb.assign((size_t)W, 0); ro.assign((size_t)W, 0); rb.assign((size_t)W, 0); int64_t a = 0, b = 0;
-      for (int32_t p = 0; p < W; p++) { so[(size_t)p] = a * w; sb[(size_t)p] = send_rows[(size_t)p] * w; a += send_rows[(size_t)p]; ro[(size_t)p] = b * w; rb[(size_t)p] = recv_rows[(size_t)p] * w; b += recv_rows[(size_t)p]; }
-    };
-    { KernelTimer kt_(ctx, "exchange_all_to_all");
-      if (comm->custom) HIP_CHECK(hipStreamSynchronize(ctx->stream));            // the callbacks read the send buffers outside this stream
-      else nccl_check(rccl().GroupStart(), "ncclGroupStart");
-      BufferPtr ones;
-      auto move = [&](const uint8_t* sp, uint8_t* rp, int64_t w) {
-        std::vector<int64_t> so, sb, ro, rb; offsets(w, so, sb, ro, rb);
-        if (comm->custom) { if (comm->vt.all_to_all_v(comm->vt.user, sp, so.data(), sb.data(), rp, ro.data(), rb.data()) != 0) fail(DFGPU_EXECUTION, "exchange: the transport's all_to_all_v failed"); return; }
-        for (int32_t p = 0; p < W; p++) {
-          if (sb[(size_t)p]) nccl_check(rccl().Send(sp + so[(size_t)p], (size_t)sb[(size_t)p], 1, p, comm->nccl, ctx->stream), "ncclSend");
-          if (rb[(size_t)p]) nccl_check(rccl().Recv(rp + ro[(size_t)p], (size_t)rb[(size_t)p], 1, p, comm->nccl, ctx->stream), "ncclRecv");
-        }
-      };
+    // ---- 3. the lanes: per column its values (fixed width), or its Boolean bytes, or its Utf8 lengths + value bytes; plus validity bytes where nullable anywhere.
+    // Every receive buffer exists BEFORE the grouped collective starts; a rank that cannot allocate says so in a second status round (only paid when the
+    // ctx runs under a memory limit, where ResourcesExhausted is an expected answer), so that no rank enters the group alone.
+    struct Lane { const uint8_t* sp; uint8_t* rp; std::vector<int64_t> sb, rb; };
+    std::vector<Lane> lanes; std::vector<BufferPtr> keep;
+    std::vector<BufferPtr> r_vals((size_t)ncols), r_len((size_t)ncols), r_valid((size_t)ncols); std::vector<int64_t> r_bytes((size_t)ncols, 0);
+    BufferPtr ones; int64_t alloc_status = DFGPU_OK; std::string alloc_err;
+    auto fixed_lane = [&](const void* sp, void* rp, int64_t w) { Lane l{ (const uint8_t*)sp, (uint8_t*)rp, std::vector<int64_t>((size_t)W), std::vector<int64_t>((size_t)W) }; for (int32_t p = 0; p < W; p++) { l.sb[(size_t)p] = send_rows[(size_t)p] * w; l.rb[(size_t)p] = recv_rows[(size_t)p] * w; } lanes.push_back(std::move(l)); };
+    try {
       for (int32_t c = 0; c < ncols; c++) {
-        const Meta& m = meta[(size_t)c]; const int64_t w = type_width(m.type);
-        recv[(size_t)c].a = new_fixed(ctx, m.type, total, m.precision, m.scale);
-        move(gh[(size_t)c].get() ? (const uint8_t*)gh[(size_t)c].get()->values->ptr : nullptr, (uint8_t*)recv[(size_t)c].get()->values->ptr, w);
-        if (!m.nullable) continue;
-        recv_valid[(size_t)c].a = new_fixed(ctx, DFGPU_UINT8, total);
-        const uint8_t* vp = vbytes[(size_t)c].get() ? (const uint8_t*)vbytes[(size_t)c].get()->values->ptr : nullptr;
-        if (!vp && sent) {          // nullable on another rank only: this rank's rows are all valid
-          if (!ones) { ones = alloc_buffer(ctx, (size_t)sent); HIP_CHECK(hipMemsetAsync(ones->ptr, 1, (size_t)sent, ctx->stream)); if (comm->custom) HIP_CHECK(hipStreamSynchronize(ctx->stream)); }
-          vp = (const uint8_t*)ones->ptr;
+        const Meta& m = meta[(size_t)c]; const dfgpu_array* g = gh[(size_t)c].get();
+        if (m.type == DFGPU_UTF8) {
+          r_len[(size_t)c] = alloc_buffer(ctx, (size_t)(total + 1) * 4);
+          fixed_lane(g ? ulen[(size_t)c]->ptr : nullptr, r_len[(size_t)c]->ptr, 4);
+          Lane l{ g ? (const uint8_t*)g->values->ptr : nullptr, nullptr, std::vector<int64_t>((size_t)W, 0), std::vector<int64_t>((size_t)W, 0) };
+          for (int32_t p = 0; p < W; p++) { l.sb[(size_t)p] = ubytes[(size_t)c].empty() ? 0 : ubytes[(size_t)c][(size_t)p]; l.rb[(size_t)p] = all[(size_t)p * ML + O_UB + (size_t)c * W + (size_t)comm->rank]; r_bytes[(size_t)c] += l.rb[(size_t)p]; }
+          if (r_bytes[(size_t)c] > 0x7FFFFFF0ll) fail(DFGPU_RESOURCES_EXHAUSTED, "exchange: %lld bytes of column %d arrive at rank %d: beyond Utf8's 32-bit offsets", (long long)r_bytes[(size_t)c], c, comm->rank);
+          r_vals[(size_t)c] = alloc_buffer(ctx, (size_t)r_bytes[(size_t)c] + 8); l.rp = (uint8_t*)r_vals[(size_t)c]->ptr;
+          lanes.push_back(std::move(l));
+        } else if (m.type == DFGPU_BOOL) {
+          r_vals[(size_t)c] = alloc_buffer(ctx, (size_t)total + 1);
+          fixed_lane(g ? bbytes[(size_t)c]->ptr : nullptr, r_vals[(size_t)c]->ptr, 1);
+        } else {
+          const int64_t w = type_width(m.type);
+          r_vals[(size_t)c] = alloc_buffer(ctx, (size_t)total * w + 8);
+          fixed_lane(g ? g->values->ptr : nullptr, r_vals[(size_t)c]->ptr, w);
         }
-        move(vp, (uint8_t*)recv_valid[(size_t)c].get()->values->ptr, 1);
+        if (!m.nullable) continue;
+        r_valid[(size_t)c] = alloc_buffer(ctx, (size_t)total + 1);
+        const void* vp = vbytes[(size_t)c] ? vbytes[(size_t)c]->ptr : nullptr;
+        if (!vp && sent) {          // nullable on another rank only: this rank's rows are all valid
+          if (!ones) { ones = alloc_buffer(ctx, (size_t)sent); HIP_CHECK(hipMemsetAsync(ones->ptr, 1, (size_t)sent, ctx->stream)); }
+          vp = ones->ptr;
+        }
+        fixed_lane(vp, r_valid[(size_t)c]->ptr, 1);
       }
-      if (!comm->custom) nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+    } catch (const Error& e) { alloc_status = e.code ? e.code : DFGPU_INTERNAL; alloc_err = e.msg; }
+    if (ctx->memory_limit > 0) {
+      std::vector<int64_t> m2(1, alloc_status), a2((size_t)W, 0);
+      gather(m2, a2, 1, "allocation status");
+      for (int32_t s2 = 0; s2 < W; s2++) if (a2[(size_t)s2] != DFGPU_OK) {
+        if (s2 == comm->rank) fail((dfgpu_status)alloc_status, "%s", alloc_err.c_str());
+        fail((dfgpu_status)a2[(size_t)s2], "exchange: rank %d could not allocate its receive buffers (status %lld); nothing was exchanged", s2, (long long)a2[(size_t)s2]);
+      }
+    } else if (alloc_status != DFGPU_OK) fail((dfgpu_status)alloc_status, "%s", alloc_err.c_str());
+    // ---- 4. one grouped collective over every lane
+    { KernelTimer kt_(ctx, "exchange_all_to_all");
+      struct Group { bool open = false; ~Group() { if (open) (void)rccl().GroupEnd(); } } group;       // an error between Start and End still closes the group: the communicator stays usable
+      if (comm->custom) HIP_CHECK(hipStreamSynchronize(ctx->stream));            // the callbacks read the send buffers outside this stream
+      else { nccl_check(rccl().GroupStart(), "ncclGroupStart"); group.open = true; }
+      for (size_t li = 0; li < lanes.size(); li++) {
+        const Lane& l = lanes[li];
+        std::vector<int64_t> so((size_t)W, 0), ro((size_t)W, 0); int64_t a = 0, b2 = 0;
+        for (int32_t p = 0; p < W; p++) { so[(size_t)p] = a; a += l.sb[(size_t)p]; ro[(size_t)p] = b2; b2 += l.rb[(size_t)p]; }
+        if (comm->custom) { if (comm->vt.all_to_all_v(comm->vt.user, l.sp, so.data(), l.sb.data(), l.rp, ro.data(), l.rb.data()) != 0) fail(DFGPU_EXECUTION, "exchange: the transport's all_to_all_v failed on lane %zu", li); continue; }
+        for (int32_t p = 0; p < W; p++) {
+          if (l.sb[(size_t)p]) nccl_check(rccl().Send(l.sp + so[(size_t)p], (size_t)l.sb[(size_t)p], 1, p, comm->nccl, ctx->stream), "ncclSend");
+          if (l.rb[(size_t)p]) nccl_check(rccl().Recv(l.rp + ro[(size_t)p], (size_t)l.rb[(size_t)p], 1, p, comm->nccl, ctx->stream), "ncclRecv");
+        }
+      }
+      if (group.open) { group.open = false; nccl_check(rccl().GroupEnd(), "ncclGroupEnd"); }
     }
-    // ---- 4. validity bytes -> bitmaps
+    // ---- 5. the received lanes become arrays: validity bytes -> bitmaps, Boolean bytes -> bits, Utf8 lengths -> offsets
     for (int32_t c = 0; c < ncols; c++) {
-      dfgpu_array* o = recv[(size_t)c].release();
-      if (meta[(size_t)c].nullable) {
-        o->validity = alloc_buffer(ctx, bitmap_bytes(total), true); o->null_count = -1;
-        if (total) hipLaunchKernelGGL(k_bytes_to_bits, dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint8_t*)recv_valid[(size_t)c].get()->values->ptr, total, (uint64_t*)o->validity->ptr);
-        KERNEL_CHECK();
+      const Meta& m = meta[(size_t)c];
+      ArrayHolder o(new_array(ctx, m.type, total, m.precision, m.scale));
+      if (m.type == DFGPU_UTF8) {
+        o.get()->offsets = alloc_buffer(ctx, (size_t)(total + 1) * 4); o.get()->values = r_vals[(size_t)c]; o.get()->values_bytes = r_bytes[(size_t)c];
+        HIP_CHECK(hipMemsetAsync((uint8_t*)r_len[(size_t)c]->ptr + (size_t)total * 4, 0, 4, ctx->stream));
+        exclusive_scan_u32_inplace32(ctx, (uint32_t*)r_len[(size_t)c]->ptr, total + 1, nullptr);
+        o.get()->offsets = r_len[(size_t)c];
+      } else if (m.type == DFGPU_BOOL) {
+        o.get()->values = alloc_buffer(ctx, bitmap_bytes(total), true);
+        if (total) hipLaunchKernelGGL(k_bytes_to_bits, dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint8_t*)r_vals[(size_t)c]->ptr, total, (uint64_t*)o.get()->values->ptr);
+      } else o.get()->values = r_vals[(size_t)c];
+      o.get()->null_count = 0;
+      if (m.nullable) {
+        o.get()->validity = alloc_buffer(ctx, bitmap_bytes(total), true); o.get()->null_count = -1;
+        if (total) hipLaunchKernelGGL(k_bytes_to_bits, dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint8_t*)r_valid[(size_t)c]->ptr, total, (uint64_t*)o.get()->validity->ptr);
       }
-      out_cols[c] = o;
+      KERNEL_CHECK();
+      out_cols[c] = o.release();
     }
     if (out_counts) for (int32_t p = 0; p < W; p++) { out_counts[p] = send_rows[(size_t)p]; out_counts[W + p] = recv_rows[(size_t)p]; }
   });

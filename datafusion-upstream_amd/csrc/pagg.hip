@@ -294,7 +294,7 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     const bool verdict_only = out_keys == nullptr;         // would this batch be taken?  (key column + selection only; see include/dfgpu.h)
     if (!keys || (!verdict_only && n_aggs && (!kinds || !values || !out_states))) fail(DFGPU_INVALID_ARGUMENT, "agg_preaggregate: null argument");
     if (verdict_only) n_aggs = 0;
-    auto skip = [&](const char* why) { fail(DFGPU_NOT_IMPLEMENTED, "agg_preaggregate: %s", why); };
+    auto skip = [&](const char* why) { ctx->pa_sample_key = nullptr; fail(DFGPU_NOT_IMPLEMENTED, "agg_preaggregate: %s", why); };      // a skipped batch's sample must not answer for the next batch at a recycled address
     if (!ctx->agg_partitioned) skip("switched off (option agg_partitioned)");
     if (nkeys != 1) skip("one key column");
     const dfgpu_array* key = keys[0]; const int64_t n = key->length;
@@ -396,7 +396,7 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     int64_t slice = (n / P + 1) * 3 / 2; if (slice < 65536) slice = 65536;          // uniform keys never split (a partition is within a percent of the average) if (slice > 0x7FFFFFFF) slice = 0x7FFFFFFF;
     const int64_t n_slices = max_len ? (max_len + slice - 1) / slice : 1;
     { KernelTimer kt_(ctx, "pa_aggregate");
-      static bool once = false; if (!once) { HIP_CHECK(hipFuncSetAttribute((const void*)k_pa_aggregate, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); once = true; }
+      HIP_CHECK(hipFuncSetAttribute((const void*)k_pa_aggregate, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));      // per device: set on every call, no process-wide flag
       BufferPtr items; unsigned grid = (unsigned)P;
       if (n_slices > 1) {            // sum over partitions of ceil(len / slice) <= P + n / slice
         items = alloc_buffer(ctx, (size_t)(P + 1) * 4);

@@ -821,7 +821,7 @@ static void plan_column(dfgpu_ctx* ctx, dfgpu_parquet* f, int leaf_idx, int rg0,
           if (lvl) jobs.push_back({src, ubase, (uint32_t)lvl, (uint32_t)lvl, 1, ch.codec});
           if (h.usize - lvl > 0) jobs.push_back({src + lvl, ubase + lvl, (uint32_t)(h.csize - lvl), (uint32_t)(h.usize - lvl), 0, ch.codec});
           data = ubase; ubase += ((int64_t)h.usize + 31) & ~15ll;
-        }
+        } else if (h.csize != h.usize) fail(DFGPU_EXECUTION, "Parquet error: uncompressed v2 page of '%s' with different sizes", leaf.name.c_str());      // decoded in place: only csize bytes were bounds-checked
       } else if (h.csize != h.usize) fail(DFGPU_EXECUTION, "Parquet error: uncompressed page of '%s' with different sizes", leaf.name.c_str());
       if (h.type == PG_DICT) {
         if (h.enc != ENC_PLAIN && h.enc != ENC_PLAIN_DICT) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: dictionary page encoding %d", h.enc);

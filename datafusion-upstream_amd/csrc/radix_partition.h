@@ -306,10 +306,10 @@ static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const 
   const size_t hl = (size_t)P * G * 4;
   const int64_t nh = (ntiles + G - 1) / G;
   { KernelTimer kt_(ctx, t_hist);
-    if (big) { static bool once = false; if (!once) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_hist<1024, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); once = true; }
+    if (big) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_hist<1024, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
       hipLaunchKernelGGL((k_rp_hist<1024, H>), dim3((unsigned)nh), dim3(1024), hl, ctx->stream, hs, n, P, ntiles, G, (uint32_t*)counts->ptr); }
     else if (small_wg) hipLaunchKernelGGL((k_rp_hist<256, H>), dim3((unsigned)nh), dim3(256), hl, ctx->stream, hs, n, P, ntiles, G, (uint32_t*)counts->ptr);
-    else { static bool once = false; if (!once) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_hist<512, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); once = true; }
+    else { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_hist<512, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
       hipLaunchKernelGGL((k_rp_hist<512, H>), dim3((unsigned)nh), dim3(512), hl, ctx->stream, hs, n, P, ntiles, G, (uint32_t*)counts->ptr); }
     KERNEL_CHECK(); }
   { KernelTimer kt_(ctx, t_scan); exclusive_scan_u32_inplace32(ctx, (uint32_t*)counts->ptr, (int64_t)P * ntiles, d_total); }
@@ -317,7 +317,7 @@ static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const 
   KERNEL_CHECK();
   if (n) { KernelTimer kt_(ctx, t_scatter);
     const unsigned grid = (unsigned)(((ntiles + 7) / 8) * 8);
-#define RP_LAUNCH(NT_, ST_) { static bool once = false; if (!once) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_scatter<NT_, ST_, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); once = true; } \
+#define RP_LAUNCH(NT_, ST_) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_scatter<NT_, ST_, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); \
       hipLaunchKernelGGL((k_rp_scatter<NT_, ST_, H>), dim3(grid), dim3(NT_), rp_scatter_lds<NT_>(P, ST_), ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols); }
     if (direct && P <= 16) hipLaunchKernelGGL((k_rp_scatter_direct<512, 16, H>), dim3(grid), dim3(512), 0, ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols);
     else if (direct) hipLaunchKernelGGL((k_rp_scatter_direct<512, 256, H>), dim3(grid), dim3(512), 0, ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols);

@@ -116,6 +116,7 @@ def _exchange_meta(counts: Sequence[int], fields, has_valid: Sequence[int], grou
     dev = "cuda" if _is_nccl(group) else "cpu"
     mine = torch.tensor(row, dtype=torch.int64, device=dev)
     allm = torch.empty((world, mine.numel()), dtype=torch.int64, device=dev)      # also at world 1: the RCCL path is the one a 1-rank test covers
+    _beat("exchange metadata all-gather (%d columns)" % ncols)
     dist.all_gather_into_tensor(allm, mine, group=group) if _is_nccl(group) else dist.all_gather(list(allm.unbind(0)), mine, group=group)
     m = allm.cpu().tolist()                                     # the one host round trip of an exchange
     all_counts = [r[:world] for r in m]
@@ -246,6 +247,7 @@ def _exchange_batches(ctx, schema, parts, group, names, broadcast):
         if segs:
             torch.cat(segs, out=pad[:recv_sizes[rank]])
         out = torch.empty((world, stride), dtype=torch.uint8, device="cuda" if nccl else "cpu")
+        _beat("broadcast data all-gather (%d bytes per rank)" % stride)
         if nccl:
             dist.all_gather_into_tensor(out, pad, group=group)
         else:
@@ -330,6 +332,7 @@ class Comm:
             return
         self.kind = "callbacks"
         world, rank = self.world, self.rank
+        self.fail_lane, self._lane = None, 0            # tests: make the transport refuse one lane of the next exchange
 
         def all_gather_host(user, send, nbytes, recv):
             try:
@@ -345,6 +348,9 @@ class Comm:
 
         def all_to_all_v(user, send, so, sb, recv, ro, rb):
             try:
+                lane = self._lane; self._lane += 1
+                if self.fail_lane is not None and lane == self.fail_lane:
+                    return 1
                 so, sb, ro, rb = ([int(a[i]) for i in range(world)] for a in (so, sb, ro, rb))
                 tot_s, tot_r = so[-1] + sb[-1], ro[-1] + rb[-1]
                 sd = torch.as_tensor(_DevicePtr(send, tot_s, None), device="cuda") if tot_s else torch.empty(0, dtype=torch.uint8, device="cuda")
@@ -385,6 +391,8 @@ class Comm:
         ch = (C.c_void_p * max(1, ncols))(*[c.h for c in (cols or [])])
         out = (C.c_void_p * ncols)()
         counts = (C.c_int64 * (2 * self.world))()
+        self._lane = 0
+        _beat("dfgpu_exchange (%s transport, %d columns)" % (self.kind, ncols))
         self.ctx.check(self.lib.dfgpu_exchange(self.ctx.h, self.h, kh if keys else None, len(keys or []), ch if cols else None, ncols, mask.h if mask is not None else None, out, counts))
         arrays = [Array(self.ctx, C.c_void_p(out[i])) for i in range(ncols)] if out[0] else None
         return arrays, list(counts[:self.world]), list(counts[self.world:])
@@ -397,6 +405,14 @@ def gather_batches(ctx, schema, batch, dst: int = 0, group=None, names: Optional
     parts = [None] * world
     parts[dst] = batch
     return exchange_batches(ctx, schema, parts, group, names=names)
+
+
+PROGRESS = None         # bench.py's watchdog: called with a label before every collective, so that a stalled job can say where it stopped
+
+
+def _beat(what):
+    if PROGRESS is not None:
+        PROGRESS(what)
 
 
 TIMING = False          # bench.py: bracket every ShuffleExec's collectives with events on torch's current stream (the ctx stream in the bench)

@@ -401,11 +401,15 @@ DFGPU_API int32_t dfgpu_comm_world(const dfgpu_comm *comm);
 /* ≙ RepartitionExec with Partitioning::Hash(keys, world) between processes (repartition/mod.rs:442-580, :684-760 -- the in-process channels
  * become an all-to-all): every rank hash-partitions its rows (create_hashes % world, identical on all ranks; dfgpu_partition_columns), the
  * row-count matrix is exchanged, then ONE grouped collective moves every column buffer.  out_cols[c] = the rows of column c this rank owns
- * afterwards, ordered by source rank (row i of every column belongs to one row).  Fixed-width columns, with or without NULLs; dictionary /
- * Utf8 columns return DFGPU_NOT_IMPLEMENTED (cast them first).  opt_mask: unselected rows are not sent.  out_counts (optional, 2 * world):
- * rows sent to / received from every rank.  Collective: every rank of the communicator must call it with the same number of columns; a rank
- * whose input produced no batch passes keys = cols = NULL and learns the column types from the others (out_cols stay NULL when no rank had
- * rows).  A column that is nullable on any rank arrives with a validity bitmap on every rank. */
+ * afterwards, ordered by source rank (row i of every column belongs to one row).  Any column type RepartitionExec moves: fixed width, Boolean,
+ * Utf8 (lengths + value bytes as two lanes) and dictionary-encoded columns (sent as their values), with or without NULLs.  opt_mask: unselected
+ * rows are not sent.  out_counts (optional, 2 * world): rows sent to / received from every rank.  Collective: every rank of the communicator must
+ * call it with the same number of columns; a rank whose input produced no batch passes keys = cols = NULL and learns the column types from the
+ * others (out_cols stay NULL when no rank had rows).  A column that is nullable on any rank arrives with a validity bitmap on every rank.
+ * Failure is collective too: a rank whose local step fails (bad argument, allocation) still joins the metadata all-gather with a status word, and
+ * EVERY rank returns an error without entering the data collective -- no rank is left waiting.  Under a ctx memory limit the receive-buffer
+ * allocation is agreed on in a second status round.  A transport error inside the data collective closes the RCCL group before it is reported,
+ * so the communicator stays usable. */
 DFGPU_API dfgpu_status dfgpu_exchange(dfgpu_ctx *ctx, dfgpu_comm *comm, const dfgpu_array *const *keys, int32_t nkeys, const dfgpu_array *const *cols, int32_t ncols,
                                       const dfgpu_array *opt_mask, dfgpu_array **out_cols, int64_t *out_counts);
 

@@ -1,0 +1,142 @@
+"""-m gpu: dfgpu_exchange (the C entry point, csrc/exchange.hip) over the caller-provided transport with 2 and 3 ranks on ONE GPU (gloo, staged
+through the host; RCCL refuses two ranks on one device): Utf8, nullable Utf8, Boolean, dictionary and nullable Decimal128 lanes travel natively;
+a rank without rows takes part; a rank that fails alone before the collective makes EVERY rank fail (status word in the metadata all-gather) instead
+of leaving its peers waiting; a transport error on one lane leaves the communicator usable for the next call."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tables(rank, world):
+    import decimal
+    import pyarrow as pa
+    rng = np.random.default_rng(100 + rank)
+    n = 0 if (world == 3 and rank == 2) else 4000 + 500 * rank           # world 3: the last rank has no rows at all
+    keys = rng.integers(0, 700, n).astype(np.int64)
+    words = [f"w{int(k) % 97}-{'x' * int(k % 7)}" for k in keys]
+    s_null = pa.array(words, mask=(rng.random(n) < 0.2) if rank == 0 else None)      # nullable on rank 0 only: every rank must receive a bitmap
+    s_plain = pa.array([w[::-1] for w in words])
+    flag = pa.array((keys % 3 == 0), mask=rng.random(n) < 0.1)
+    dic = pa.DictionaryArray.from_arrays(pa.array((keys % 5).astype(np.int32)), pa.array(["alpha", "beta", "", "delta", "epsilon-long-value"]))
+    dec = pa.array([decimal.Decimal(int(k) * 37 - 5000).scaleb(-2) for k in keys], type=pa.decimal128(15, 2), mask=rng.random(n) < 0.15)
+    return pa.table({"k": pa.array(keys), "s_null": s_null, "s_plain": s_plain, "flag": flag, "dic": dic, "dec": dec})
+
+
+def _rows(table):
+    cols = [c.combine_chunks() for c in table.columns]
+    cols = [c.cast(c.type.value_type) if hasattr(c.type, "value_type") else c for c in cols]
+    return list(zip(*[c.to_pylist() for c in cols]))
+
+
+def _worker(rank, world, port, q, scenario):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        import faulthandler
+        faulthandler.dump_traceback_later(120, exit=True)      # a rank stuck in a collective must not hold the GPU box
+        import pyarrow as pa
+        import torch
+        import torch.distributed as dist
+        import dfgpu
+        from dfgpu import capi, exchange
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ctx = dfgpu.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        comm = exchange.Comm(ctx, force_callbacks=True)
+        t = _tables(rank, world)
+        arrays = [ctx.from_arrow(c.combine_chunks()) for c in t.columns] if t.num_rows else None
+
+        def run():
+            got, sent, recv = comm.exchange([arrays[0]] if arrays else None, arrays, t.num_columns)
+            if got is None:
+                return []
+            return _rows(pa.table({name: a.to_arrow() for name, a in zip(t.column_names, got)}))
+
+        out = {"mine": _rows(t)}
+        if scenario == "lanes":
+            out["got"] = run()
+        elif scenario == "transport_error":
+            comm.fail_lane = 3                           # every rank's callback refuses the fourth lane of the next call (no rank enters that collective alone)
+            try:
+                run(); out["first"] = "no error"
+            except capi.DfgpuError as e:
+                out["first"] = str(e)
+            comm.fail_lane = None
+            out["got"] = run()                           # the communicator is still usable
+        elif scenario == "rank_fails_alone":
+            if rank == 1:                                # a column shorter than the keys: a local argument error BEFORE the collective
+                bad = list(arrays); bad[2] = bad[2].slice(0, len(bad[2]) - 1)
+                try:
+                    comm.exchange([arrays[0]], bad, t.num_columns); out["first"] = "no error"
+                except capi.DfgpuError as e:
+                    out["first"] = str(e)
+            else:
+                try:
+                    run(); out["first"] = "no error"
+                except capi.DfgpuError as e:
+                    out["first"] = str(e)
+            out["got"] = run()
+        q.put((rank, out))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def _launch(world, scenario):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 28100 + (os.getpid() % 800) + world + {"lanes": 0, "transport_error": 10, "rank_fails_alone": 20}[scenario]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, scenario)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=150) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        assert isinstance(results[r], dict), results[r]
+    return results
+
+
+def _check_exchange(results, world):
+    everything = [row for r in range(world) for row in results[r]["mine"]]
+    arrived = [row for r in range(world) for row in results[r]["got"]]
+    assert sorted(arrived, key=repr) == sorted(everything, key=repr), "every row arrives exactly once, every cell intact (NULLs, empty strings, Booleans, decimals)"
+    owner = {}
+    for r in range(world):
+        for row in results[r]["got"]:
+            assert owner.setdefault(row[0], r) == r, "equal keys must land on one rank"
+    # rows of one source keep their order inside a destination (rows arrive ordered by source rank, RepartitionExec's per-input order)
+    for r in range(world):
+        pos = 0
+        for src in range(world):
+            mine = [row for row in results[src]["mine"] if owner.get(row[0]) == r]
+            assert results[r]["got"][pos:pos + len(mine)] == mine
+            pos += len(mine)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_exchange_moves_utf8_boolean_dictionary_and_nullable_lanes(world):
+    _check_exchange(_launch(world, "lanes"), world)
+
+
+def test_transport_error_leaves_the_communicator_usable():
+    res = _launch(2, "transport_error")
+    for r in range(2):
+        assert "all_to_all_v failed on lane 3" in res[r]["first"], res[r]["first"]
+    _check_exchange(res, 2)
+
+
+def test_a_rank_that_fails_alone_fails_every_rank_and_nothing_hangs():
+    res = _launch(3, "rank_fails_alone")
+    assert "differs in length" in res[1]["first"], res[1]["first"]
+    for r in (0, 2):
+        assert "rank 1 failed before the collective" in res[r]["first"], res[r]["first"]
+    _check_exchange(res, 3)
