@@ -20,6 +20,7 @@ Extra objects in the JSON line:
 Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N
 """
 import argparse
+import gc
 import json
 import os
 import statistics
@@ -244,6 +245,7 @@ def main():
         return p
 
     breakdown = None
+    gc.collect(); gc.disable()          # the timed region must not contain a cyclic-GC pass of the Python wrappers (bench_workloads.py: one such pass cost a single step 65 ms)
     for w in range(args.warmup):
         if w == args.warmup - 1:
             breakdown = profiled_step()
@@ -265,6 +267,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     prof, _ = split_syncs(ctx.profile_read())
     ctx.profile_enable(False)
     if breakdown is None:
@@ -349,7 +352,7 @@ def main():
             del template, tables, tensors
             torch.cuda.empty_cache()
             res = bench_workloads.run(_ap.Namespace(sf=args.sf, steps=3, warmup=2, only=args.workloads), ctx=ctx, emit=False)
-            workloads = {r["workload"]: {k: r[k] for k in ("input_rows", "result_rows", "ms_per_step", "rows_per_s", "algorithmic_GBps", "frac_of_hbm_peak", "algorithmic_bytes_per_row", "roofline", "host_syncs_per_step", "result_check") if k in r}
+            workloads = {r["workload"]: {k: r[k] for k in ("input_rows", "result_rows", "ms_per_step", "rows_per_s", "algorithmic_GBps", "frac_of_hbm_peak", "algorithmic_bytes_per_row", "roofline", "host_syncs_per_step", "result_check", "step_ms", "memory_GB") if k in r}
                          | {"kernel_ms_per_step": dict(list(r["kernel_ms_per_step"].items())[:8])} | {k: r[k] for k in r if k in ("cardinality", "build_rows", "probe_rows", "rows_per_build_key", "partitions", "exchange", "file_bytes", "decoded_bytes", "decoded_GBps", "file_GBps", "from_host_image_ms", "from_host_image_decoded_GBps", "row_groups")} for r in res}
     else:
         # the other two distribution plans, after the timed region (every rank takes part: they hold collectives)

@@ -21,6 +21,7 @@ This is NOT the driver's bench contract (bench.py is); it exists so that DESIGN.
 """
 import argparse
 import decimal
+import gc
 import json
 import os
 import sys
@@ -48,6 +49,8 @@ def wrap_dict(ctx, capi, keys, dictionary, key_type):
     return ctx.wrap_device(d, keepalive=(keys, dictionary, dd))
 
 
+KEEP = [False]             # True only while the last timed step runs: that step's output is what the result check reads
+STEP_MS = [None]           # wall time of every timed step of the most recent workload (reported next to the mean)
 LAST_OUT = [None]          # batches of the most recent plan step: what the result checks read (outside the timed region)
 
 
@@ -103,9 +106,10 @@ def time_plan(ctx, ops, tc, template, steps, warmup):
     def step():
         out = [b for b in ops.with_fresh_state(template).execute(0, tc)]
         ctx.synchronize()
-        LAST_OUT[0] = out
+        LAST_OUT[0] = out if KEEP[0] else None
         return sum(b.num_rows for b in out)
     breakdown = None
+    gc.collect(); gc.disable()          # no cyclic-GC pass between here and the end of the timed loop (one landed in a single partition step: 82 ms against 17)
     for w in range(max(warmup, 1)):
         if w == max(warmup, 1) - 1:
             ctx.profile_select(None); ctx.profile_enable(True); ctx.profile_read()
@@ -114,10 +118,14 @@ def time_plan(ctx, ops, tc, template, steps, warmup):
         else:
             step()
     ctx.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        rows = step()
+    t0 = time.perf_counter(); per = []
+    for it in range(steps):
+        KEEP[0] = it == steps - 1
+        t1 = time.perf_counter(); rows = step(); per.append(round((time.perf_counter() - t1) * 1e3, 3))
+    KEEP[0] = False
     dt = (time.perf_counter() - t0) / steps
+    gc.enable()
+    STEP_MS[0] = per
     kern = {k: round(v[1], 3) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][1]) if not k.startswith("sync:")}
     syncs = sum(v[0] for k, v in breakdown.items() if k.startswith("sync:"))
     return dt, rows, kern, syncs
@@ -162,6 +170,12 @@ def run(args, ctx=None, emit=True):
                 "algorithmic_bytes_per_row": bytes_per_row, "kernel_ms_per_step": kern, "host_syncs_per_step": syncs}
         if extra:
             line.update(extra)
+        if STEP_MS[0]:
+            line["step_ms"] = STEP_MS[0]; STEP_MS[0] = None
+        KEEP[0] = False
+        live0 = ctx.get_option("live_bytes"); gc.collect()            # device arrays held only by reference cycles of the Python wrappers go back here, not in the middle of a later step
+        line["memory_GB"] = {"dfgpu_live_before_gc": round(live0 / 1e9, 2), "dfgpu_live": round(ctx.get_option("live_bytes") / 1e9, 2), "dfgpu_cached": round(ctx.get_option("cached_bytes") / 1e9, 2), "torch_reserved": round(torch.cuda.memory_reserved() / 1e9, 2)}
+        ctx.set_option("trim_cache", 1)
         if kern:
             dk = next(iter(kern))
             line["roofline"] = {"bound": "hbm", "kernel": dk, "kernel_ms_per_step": kern[dk], "frac": line["frac_of_hbm_peak"], "unit": "GB/s", "achieved": line["algorithmic_GBps"], "peak": HBM_PEAK_GBS,
@@ -439,15 +453,18 @@ def run(args, ctx=None, emit=True):
                     for b in out:
                         b.columns                        # the sorted columns, not only the order
                 ctx.synchronize()
-                LAST_OUT[0] = out
+                LAST_OUT[0] = out if KEEP[0] else None
                 return sum(b.num_rows for b in out)
+            gc.collect(); gc.disable()
             for _ in range(max(args.warmup, 1)):
                 step()
             ctx.profile_enable(True); ctx.profile_read(); step(); p = ctx.profile_read(); ctx.profile_enable(False)
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                rows = step()
+            t0 = time.perf_counter(); per = []
+            for it in range(args.steps):
+                KEEP[0] = it == args.steps - 1
+                t1 = time.perf_counter(); rows = step(); per.append(round((time.perf_counter() - t1) * 1e3, 3))
             dt = (time.perf_counter() - t0) / args.steps
+            gc.enable(); STEP_MS[0] = per
             kern = {k: round(v[1], 3) for k, v in sorted(p.items(), key=lambda kv: -kv[1][1]) if not k.startswith("sync:")}
             return dt, rows, kern, sum(v[0] for k, v in p.items() if k.startswith("sync:"))
         dt, rows, kern, syncs = timed_sort()
@@ -484,15 +501,18 @@ def run(args, ctx=None, emit=True):
                             for b in p2.execute(d, tc):
                                 b.columns; rows += b.num_rows; keep.append((d, b))
                     ctx.synchronize()
-                    LAST_OUT[0] = keep
+                    LAST_OUT[0] = keep if KEEP[0] else None
                     return rows
+                gc.collect(); gc.disable()
                 for _ in range(max(args.warmup, 1)):
                     step()
                 ctx.profile_enable(True); ctx.profile_read(); step(); pr = ctx.profile_read(); ctx.profile_enable(False)
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    rows = step()
+                t0 = time.perf_counter(); per = []
+                for it in range(args.steps):
+                    KEEP[0] = it == args.steps - 1
+                    t1 = time.perf_counter(); rows = step(); per.append(round((time.perf_counter() - t1) * 1e3, 3))
                 dt = (time.perf_counter() - t0) / args.steps
+                gc.enable(); STEP_MS[0] = per
                 kern = {k: round(v[1], 3) for k, v in sorted(pr.items(), key=lambda kv: -kv[1][1]) if not k.startswith("sync:")}
                 return dt, rows, kern, sum(v[0] for k, v in pr.items() if k.startswith("sync:"))
             dt, rows, kern, syncs = timed_partition()
@@ -560,15 +580,18 @@ def run(args, ctx=None, emit=True):
                 def step():
                     cols = f.read()
                     ctx.synchronize()
-                    LAST_OUT[0] = cols
+                    LAST_OUT[0] = cols if KEEP[0] else None
                     return len(cols[0])
+                gc.collect(); gc.disable()
                 for _ in range(max(args.warmup, 1)):
                     step()
                 ctx.profile_enable(True); ctx.profile_read(); step(); pr = ctx.profile_read(); ctx.profile_enable(False)
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    rows = step()
+                t0 = time.perf_counter(); per = []
+                for it in range(args.steps):
+                    KEEP[0] = it == args.steps - 1
+                    t1 = time.perf_counter(); rows = step(); per.append(round((time.perf_counter() - t1) * 1e3, 3))
                 dt = (time.perf_counter() - t0) / args.steps
+                gc.enable(); STEP_MS[0] = per
                 scan_ok = scan_check(LAST_OUT[0], table); LAST_OUT[0] = None
                 kern = {k: round(v[1], 3) for k, v in sorted(pr.items(), key=lambda kv: -kv[1][1]) if not k.startswith("sync:")}
                 syncs = sum(v[0] for k, v in pr.items() if k.startswith("sync:"))
@@ -598,15 +621,18 @@ def run(args, ctx=None, emit=True):
             def step():
                 cols = read_csv(ctx, dimg, sch, on_device=True)
                 ctx.synchronize()
-                LAST_OUT[0] = cols
+                LAST_OUT[0] = cols if KEEP[0] else None
                 return len(cols[0])
+            gc.collect(); gc.disable()
             for _ in range(max(args.warmup, 1)):
                 step()
             ctx.profile_enable(True); ctx.profile_read(); step(); pr = ctx.profile_read(); ctx.profile_enable(False)
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                rows = step()
+            t0 = time.perf_counter(); per = []
+            for it in range(args.steps):
+                KEEP[0] = it == args.steps - 1
+                t1 = time.perf_counter(); rows = step(); per.append(round((time.perf_counter() - t1) * 1e3, 3))
             dt = (time.perf_counter() - t0) / args.steps
+            gc.enable(); STEP_MS[0] = per
             kern = {k: round(v[1], 3) for k, v in sorted(pr.items(), key=lambda kv: -kv[1][1]) if not k.startswith("sync:")}
             syncs = sum(v[0] for k, v in pr.items() if k.startswith("sync:"))
             assert rows == nc

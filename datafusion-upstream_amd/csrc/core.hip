@@ -302,6 +302,10 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "fused_aggregate_min_rows") ctx->fused_aggregate_min_rows = value;
     else if (k == "sort_packed_keys") ctx->sort_packed_keys = value != 0;
     else if (k == "memory_limit") ctx->memory_limit = value;
+    else if (k == "trim_cache") {        // give the freed blocks the ctx keeps for reuse back to the driver (≙ MemoryPool::shrink): after the stream has drained, so no kernel still reads them
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      std::lock_guard<std::mutex> l(*ctx->alloc_mu); for (auto& x : *ctx->free_blocks) (void)hipFree(x.second); ctx->free_blocks->clear(); ctx->cached_bytes = 0;
+    }
     else if (k == "agg_spill_state_bytes") ctx->agg_spill_state_bytes = value;
     else if (k == "agg_spill_ranges") { if (value < 1 || value > 4096) fail(DFGPU_INVALID_ARGUMENT, "agg_spill_ranges: 1 .. 4096"); ctx->agg_spill_ranges = value; }
     else if (k == "collect_metrics") ctx->collect_metrics = value != 0;
@@ -340,6 +344,7 @@ dfgpu_status dfgpu_ctx_get_option(dfgpu_ctx* ctx, const char* key, int64_t* out)
     else if (k == "agg_preaggregate_distinct") *out = ctx->pa_last_distinct;      // read only
     else if (k == "live_bytes") *out = (int64_t)ctx->live_bytes;              // read only: device bytes held by live buffers of this ctx
     else if (k == "cached_bytes") *out = (int64_t)ctx->cached_bytes;          // read only: freed blocks kept for reuse
+    else if (k == "live_bytes") *out = (int64_t)ctx->live_bytes;              // read only: device memory the ctx's arrays hold right now
     else if (k == "agg_partitioned") *out = ctx->agg_partitioned;
     else if (k == "agg_partitioned_force") *out = ctx->agg_partitioned_force;
     else if (k == "agg_partitioned_min_rows") *out = ctx->agg_partitioned_min_rows;
