@@ -379,7 +379,8 @@ def run(args, ctx=None, emit=True):
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ general-case operators: keys that are neither clustered nor dense
-    if not want or "hash_join" in want:
+    if not want or "hash_join" in want or "hash_join_plain" in want or "hash_join_fk5" in want:          # hash_join = both variants; _plain / _fk5 = one of them (profiling passes)
+        do_plain, do_fk5 = (not want or "hash_join" in want or "hash_join_plain" in want), (not want or "hash_join" in want or "hash_join_fk5" in want)
         nb, npr = int(150_000 * args.sf), int(1_500_000 * args.sf)
         bk = torch.randint(0, 2**62, (nb,), generator=g, device="cuda", dtype=torch.int64)
         pk = torch.cat([bk[torch.randint(0, nb, (npr // 5,), generator=g, device="cuda")], torch.randint(0, 2**62, (npr - npr // 5,), generator=g, device="cuda", dtype=torch.int64)])
@@ -390,28 +391,30 @@ def run(args, ctx=None, emit=True):
         right = ops.RecordBatch.from_arrays(ctx, ["k", "v"], [ctx.wrap_tensor(pk, capi.INT64), ctx.wrap_tensor(pv, capi.INT64)])
         j = ops.HashJoinExec(ops.MemoryExec([[left]], left.schema), ops.MemoryExec([[right]], right.schema), [(C("k", 0), C("k", 0))], None, "Inner", "CollectLeft")
         plan = ops.AggregateExec("Single", [], [ops.AggregateFunctionExpr("SUM", C("v", 2), "s", input_field=F("v", capi.INT64)), ops.AggregateFunctionExpr("COUNT", None, "c")], j)
-        dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan, args.steps, args.warmup)
-        res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
-        sb = torch.sort(bk).values; pos = torch.searchsorted(sb, pk).clamp_(max=nb - 1); hit = sb[pos] == pk         # build keys are distinct (62-bit random): a match is one pair
-        ok = int(res[1][0]) == int(hit.sum().item()) and wrap64(int(res[0][0])) == wrap64(int(pv[hit].sum().item()))
-        del sb, pos, hit
-        report("hash_join_sparse_keys", dt, nb + npr, rows, round((nb * 8 + npr * 16) / (nb + npr), 2), kern, syncs, {"build_rows": nb, "probe_rows": npr, "match_fraction": 0.2,
-               "result_check": check("hash_join_sparse_keys", ok, "COUNT(*) and SUM(v) over the join output == torch sort + searchsorted over the same keys")})
+        if do_plain:
+            dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan, args.steps, args.warmup)
+            res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
+            sb = torch.sort(bk).values; pos = torch.searchsorted(sb, pk).clamp_(max=nb - 1); hit = sb[pos] == pk         # build keys are distinct (62-bit random): a match is one pair
+            ok = int(res[1][0]) == int(hit.sum().item()) and wrap64(int(res[0][0])) == wrap64(int(pv[hit].sum().item()))
+            del sb, pos, hit
+            report("hash_join_sparse_keys", dt, nb + npr, rows, round((nb * 8 + npr * 16) / (nb + npr), 2), kern, syncs, {"build_rows": nb, "probe_rows": npr, "match_fraction": 0.2,
+                   "result_check": check("hash_join_sparse_keys", ok, "COUNT(*) and SUM(v) over the join output == torch sort + searchsorted over the same keys")})
         # the same join with a foreign-key build side: every build key five times (75 M build rows at SF100 would leave the 2048-partition range: 3 M distinct keys x 5)
-        nd = nb // 5
-        bk5 = bk[:nd].repeat(5)[torch.randperm(nd * 5, generator=g, device="cuda")]
-        torch.cuda.synchronize()
-        left5 = ops.RecordBatch.from_arrays(ctx, ["k"], [ctx.wrap_tensor(bk5, capi.INT64)])
-        j5 = ops.HashJoinExec(ops.MemoryExec([[left5]], left5.schema), ops.MemoryExec([[right]], right.schema), [(C("k", 0), C("k", 0))], None, "Inner", "CollectLeft")
-        plan5 = ops.AggregateExec("Single", [], [ops.AggregateFunctionExpr("SUM", C("v", 2), "s", input_field=F("v", capi.INT64)), ops.AggregateFunctionExpr("COUNT", None, "c")], j5)
-        dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan5, args.steps, args.warmup)
-        res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
-        sb = torch.sort(bk[:nd]).values; pos = torch.searchsorted(sb, pk).clamp_(max=nd - 1); hit = sb[pos] == pk
-        ok = int(res[1][0]) == 5 * int(hit.sum().item()) and wrap64(int(res[0][0])) == wrap64(5 * int(pv[hit].sum().item()))
-        del sb, pos, hit
-        report("hash_join_sparse_keys_fk5", dt, nd * 5 + npr, rows, round((nd * 5 * 8 + npr * 16) / (nd * 5 + npr), 2), kern, syncs, {"build_rows": nd * 5, "probe_rows": npr, "rows_per_build_key": 5,
-               "result_check": check("hash_join_sparse_keys_fk5", ok, "COUNT(*) and SUM(v) over the join output (5 pairs per matching probe row) == torch")})
-        del bk, pk, pv, left, right, plan, bk5, left5, j5, plan5
+        if do_fk5:
+            nd = nb // 5
+            bk5 = bk[:nd].repeat(5)[torch.randperm(nd * 5, generator=g, device="cuda")]
+            torch.cuda.synchronize()
+            left5 = ops.RecordBatch.from_arrays(ctx, ["k"], [ctx.wrap_tensor(bk5, capi.INT64)])
+            j5 = ops.HashJoinExec(ops.MemoryExec([[left5]], left5.schema), ops.MemoryExec([[right]], right.schema), [(C("k", 0), C("k", 0))], None, "Inner", "CollectLeft")
+            plan5 = ops.AggregateExec("Single", [], [ops.AggregateFunctionExpr("SUM", C("v", 2), "s", input_field=F("v", capi.INT64)), ops.AggregateFunctionExpr("COUNT", None, "c")], j5)
+            dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan5, args.steps, args.warmup)
+            res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
+            sb = torch.sort(bk[:nd]).values; pos = torch.searchsorted(sb, pk).clamp_(max=nd - 1); hit = sb[pos] == pk
+            ok = int(res[1][0]) == 5 * int(hit.sum().item()) and wrap64(int(res[0][0])) == wrap64(5 * int(pv[hit].sum().item()))
+            del sb, pos, hit
+            report("hash_join_sparse_keys_fk5", dt, nd * 5 + npr, rows, round((nd * 5 * 8 + npr * 16) / (nd * 5 + npr), 2), kern, syncs, {"build_rows": nd * 5, "probe_rows": npr, "rows_per_build_key": 5,
+                   "result_check": check("hash_join_sparse_keys_fk5", ok, "COUNT(*) and SUM(v) over the join output (5 pairs per matching probe row) == torch")})
+        del bk, pk, pv, left, right, plan
         torch.cuda.empty_cache()
     if not want or "groupby_int64" in want:
         ng = int(1_000_000 * args.sf)
