@@ -107,7 +107,7 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--no-workloads", action="store_true", help="N = 1: skip the nested other plan shapes (bench_workloads.py)")
-    ap.add_argument("--workloads", default="q1_decimal,q1_float64,q5,q18,hash_join,groupby_int64,sort,partition,parquet_scan,csv_scan,clickbench_uniform_1000000,clickbench_zipf_1000000",
+    ap.add_argument("--workloads", default="q1_decimal,q1_float64,q5,q18,hash_join,groupby_int64,groupby_decimal_3key,sort,partition,parquet_scan,csv_scan,clickbench_uniform_1000000,clickbench_zipf_1000000",
                     help="N = 1: which plan shapes of bench_workloads.py to nest under \"workloads\"")
     ap.add_argument("--collective-deadline", type=float, default=180.0, help="N > 1: seconds without progress (no exchange started, no step finished) after which a rank reports where it stands and exits with code 3 instead of hanging the job")
     ap.add_argument("--native-exchange", action="store_true", help="N > 1 workloads: ShuffleExec through the C entry point dfgpu_exchange (RCCL inside libdfgpu.so) instead of torch.distributed collectives")

@@ -438,6 +438,29 @@ def run(args, ctx=None, emit=True):
             del keys, val, b, agg, plan
             torch.cuda.empty_cache()
 
+    # ------------------------------------------------------------------ TPC-H-typed group-by: three key columns (Int64, Date32, Int32), SUM over Decimal128, 1 M groups
+    if not want or "groupby_decimal_3key" in want:
+        ng, total = int(1_000_000 * args.sf), max(1000, int(10_000 * args.sf))
+        gidc = torch.randint(0, total, (ng,), generator=g, device="cuda", dtype=torch.int64)
+        k0 = gidc * 7919; k1 = (8035 + gidc % 2400).to(torch.int32); k2 = (gidc % 3).to(torch.int32)
+        val = dec_tensor(torch, ng, 90000, 10494951, g)
+        torch.cuda.synchronize()
+        b = ops.RecordBatch.from_arrays(ctx, ["k", "d", "p", "v"], [ctx.wrap_tensor(k0, capi.INT64), ctx.wrap_tensor(k1, capi.DATE32), ctx.wrap_tensor(k2, capi.INT32), ctx.wrap_tensor(val, capi.DECIMAL128, 15, 2)])
+        agg = ops.AggregateExec("Single", [(C("k", 0), "k"), (C("d", 1), "d"), (C("p", 2), "p")],
+                                [ops.AggregateFunctionExpr("SUM", C("v", 3), "s", input_field=F("v", capi.DECIMAL128, 15, 2)), ops.AggregateFunctionExpr("COUNT", None, "c")], ops.MemoryExec([[b]], b.schema))
+        plan = ops.SortExec([ops.PhysicalSortExpr(C("s", 3), True, True), ops.PhysicalSortExpr(C("k", 0), False, False)], agg, fetch=10)
+        dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan, args.steps, args.warmup)
+        res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
+        sums = torch.zeros(total, dtype=torch.int64, device="cuda").index_add_(0, gidc, val[:, 0]); cnts = torch.zeros(total, dtype=torch.int64, device="cuda").index_add_(0, gidc, torch.ones_like(gidc))
+        top = torch.argsort(sums * (2 * total) + (total - 1 - torch.arange(total, device="cuda")), descending=True)[:10]       # s DESC, k ASC
+        ok = np.array_equal(np.asarray(res[0]).astype(np.int64), (top * 7919).cpu().numpy()) and np.array_equal(np.asarray(res[1]).astype(np.int64), (8035 + top % 2400).cpu().numpy()) and \
+            np.array_equal(np.asarray(res[2]).astype(np.int64), (top % 3).cpu().numpy()) and [wrap64(x) for x in res[3][0]] == [wrap64(x) for x in sums[top].tolist()] and \
+            np.array_equal(np.asarray(res[4]).astype(np.int64), cnts[top].cpu().numpy())
+        del sums, cnts, top
+        report("groupby_decimal_3key", dt, ng, rows, 8 + 4 + 4 + 16, kern, syncs, {"cardinality": total, "result_check": check("groupby_decimal_3key", ok, "the 10 result rows (k, d, p, SUM Decimal128, COUNT) in order == torch index_add + argsort")})
+        del gidc, k0, k1, k2, val, b, agg, plan
+        torch.cuda.empty_cache()
+
     # ------------------------------------------------------------------ SortExec at scale: ORDER BY l_extendedprice DESC, l_shipdate over 1 M x sf rows, 3 columns out
     if not want or "sort" in want:
         ns = int(1_000_000 * args.sf)

@@ -59,7 +59,7 @@ __device__ inline int64_t key_at(const void* keys, int32_t key_type, int64_t i) 
   switch (key_type) {
     case DFGPU_INT8: return ((const int8_t*)keys)[i];
     case DFGPU_INT16: return ((const int16_t*)keys)[i];
-    case DFGPU_INT32: return ((const int32_t*)keys)[i];
+    case DFGPU_INT32: case DFGPU_DATE32: return ((const int32_t*)keys)[i];      // Date32 is a 4-byte value: without its own case it fell to the 8-byte default and read past the column
     case DFGPU_INT64: return ((const int64_t*)keys)[i];
     case DFGPU_UINT8: return ((const uint8_t*)keys)[i];
     case DFGPU_UINT16: return ((const uint16_t*)keys)[i];

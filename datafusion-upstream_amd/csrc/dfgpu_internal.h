@@ -53,6 +53,8 @@ struct dfgpu_ctx {
   bool agg_partitioned = true, agg_partitioned_force = false; int64_t agg_partitioned_min_rows = 1 << 22;      // partitioned pre-aggregation (pagg.hip)
   bool pa_last_distinct = false;    // the last dfgpu_agg_preaggregate call emitted every key once
   const void* pa_sample_key = nullptr; const void* pa_sample_mask = nullptr; int64_t pa_sample_n = 0; uint64_t pa_sample[3] = {0, 0, 0};   // sample of a verdict-only dfgpu_agg_preaggregate call
+  // 2..4 key columns packed into one u64 by that verdict-only call (kept for the call that follows on the same columns): key = sum((v - min + nullable) * stride), 0 in a nullable column's digit = NULL
+  std::shared_ptr<dfgpu::Buffer> pa_pack; int pa_pack_n = 0; int64_t pa_pack_min[4] = {0, 0, 0, 0}; uint64_t pa_pack_stride[4] = {0, 0, 0, 0}, pa_pack_range[4] = {0, 0, 0, 0}; bool pa_pack_nullable[4] = {false, false, false, false};
   // row selection of the running operator (dfgpu_ctx_set_row_selection): expression kernels evaluate every row of full-length
   // columns but raise errors only for selected rows
   std::shared_ptr<dfgpu::Buffer> row_selection; int64_t row_selection_len = 0;

@@ -1157,11 +1157,12 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
   }
   // dfgpu_agg_preaggregate over one batch, then intern + merge_batch of its partial rows.  false = shape not taken, nothing accumulated.
   template <typename Ensure>
-  bool preaggregate(const TaskContext& tc, Batch& b, const std::vector<bool>& deferred, Ensure&& ensure, const dfgpu_array* key, const ArrayRef& mask, GroupsRef& groups, std::vector<AccRef>& accs, ArrayRef* pending) const {
+  bool preaggregate(const TaskContext& tc, Batch& b, const std::vector<bool>& deferred, Ensure&& ensure, const std::vector<const dfgpu_array*>& keyv, const ArrayRef& mask, GroupsRef& groups, std::vector<AccRef>& accs, ArrayRef* pending) const {
+    const int32_t nk = (int32_t)keyv.size();
     std::vector<ArrayRef> vals(aggs.size()); std::vector<const dfgpu_array*> vp; std::vector<int32_t> kinds;
     for (auto& a : aggs) if (a.filter) return false;
     // the key column decides (type, clustering, number of groups): ask before any computed argument is evaluated for it
-    dfgpu_status v0 = dfgpu_agg_preaggregate(tc.ctx, &key, 1, nullptr, nullptr, 0, mask.a, nullptr, nullptr);
+    dfgpu_status v0 = dfgpu_agg_preaggregate(tc.ctx, keyv.data(), nk, nullptr, nullptr, 0, mask.a, nullptr, nullptr);
     if (v0 == DFGPU_NOT_IMPLEMENTED) return false;
     tc.check(v0);
     for (size_t i = 0; i < aggs.size(); i++) {
@@ -1171,22 +1172,23 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
       }
       vp.push_back(vals[i].a); kinds.push_back(aggs[i].kind);
     }
-    std::vector<dfgpu_array*> st(aggs.size() * 2 + 2, nullptr); dfgpu_array* pk = nullptr;
-    dfgpu_status rc = dfgpu_agg_preaggregate(tc.ctx, &key, 1, kinds.data(), vp.data(), (int32_t)aggs.size(), mask.a, &pk, st.data());
+    std::vector<dfgpu_array*> st(aggs.size() * 2 + 2, nullptr); dfgpu_array* pk[4] = { nullptr, nullptr, nullptr, nullptr };
+    dfgpu_status rc = dfgpu_agg_preaggregate(tc.ctx, keyv.data(), nk, kinds.data(), vp.data(), (int32_t)aggs.size(), mask.a, pk, st.data());
     if (rc == DFGPU_NOT_IMPLEMENTED) return false;
     tc.check(rc);
-    ArrayRef pkeys = ArrayRef::adopt(pk); std::vector<ArrayRef> states; for (auto* x : st) states.push_back(ArrayRef::adopt(x));
+    std::vector<ArrayRef> pkeyv; for (int32_t c = 0; c < nk; c++) pkeyv.push_back(ArrayRef::adopt(pk[c]));
+    const ArrayRef& pkeys = pkeyv[0]; std::vector<ArrayRef> states; for (auto* x : st) states.push_back(ArrayRef::adopt(x));
     // A FIRST batch whose partial rows hold every key once (in first-seen order) needs no hash table to number its groups: ids are 0, 1, ..; the keys wait
     // in `pending` and are interned only if another batch follows (merge_partial with pending == nullptr), else they are emitted as they are.
     int64_t distinct = 0, fs = 1; dfgpu_ctx_get_option(tc.ctx, "agg_preaggregate_distinct", &distinct); dfgpu_ctx_get_option(tc.ctx, "first_seen_group_order", &fs); distinct = distinct && fs;
-    if (pending && distinct && dfgpu_groups_len(groups.g) == 0 && !*pending) { *pending = pkeys; merge_partial(tc, ArrayRef(), states, pkeys.len(), groups, accs); return true; }
-    merge_partial(tc, pkeys, states, 0, groups, accs);
+    if (nk == 1 && pending && distinct && dfgpu_groups_len(groups.g) == 0 && !*pending) { *pending = pkeys; merge_partial(tc, {}, states, pkeys.len(), groups, accs); return true; }
+    merge_partial(tc, pkeyv, states, 0, groups, accs);
     return true;
   }
   // intern the partial rows' keys (or take ids 0 .. n-1 when `keys` is empty) and merge their states
-  void merge_partial(const TaskContext& tc, const ArrayRef& keys, const std::vector<ArrayRef>& states, int64_t n_ids, GroupsRef& groups, std::vector<AccRef>& accs) const {
+  void merge_partial(const TaskContext& tc, const std::vector<ArrayRef>& keys, const std::vector<ArrayRef>& states, int64_t n_ids, GroupsRef& groups, std::vector<AccRef>& accs) const {
     dfgpu_array* ids = nullptr; int64_t total;
-    if (keys) { const dfgpu_array* kp = keys.a; tc.check(dfgpu_groups_intern(tc.ctx, groups.g, &kp, 1, nullptr, &ids)); total = dfgpu_groups_len(groups.g); }
+    if (!keys.empty()) { std::vector<const dfgpu_array*> kp; for (auto& k : keys) kp.push_back(k.a); tc.check(dfgpu_groups_intern(tc.ctx, groups.g, kp.data(), (int32_t)kp.size(), nullptr, &ids)); total = dfgpu_groups_len(groups.g); }
     else { tc.check(dfgpu_array_iota(tc.ctx, n_ids, &ids)); total = n_ids; }
     ArrayRef gids = ArrayRef::adopt(ids);
     for (size_t i = 0; i < aggs.size(); i++) {
@@ -1313,7 +1315,7 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
         }
         // A large batch of high-cardinality keys is first reduced to one row per group partition by partition out of LDS (the Partial stage
         // of a two-phase plan, applied inside the operator): its partial rows are then interned and MERGED like the Final stage does.
-        if (!specials && !merging() && gp.size() == 1 && b.base_rows >= preagg_min_rows && preaggregate(tc, b, deferred, ensure, gp[0], mask, groups, accs, S.spill ? nullptr : &pending)) return;
+        if (!specials && !merging() && gp.size() >= 1 && gp.size() <= 4 && b.base_rows >= preagg_min_rows && preaggregate(tc, b, deferred, ensure, gp, mask, groups, accs, S.spill ? nullptr : &pending)) return;
         dfgpu_array* ids = nullptr; tc.check(specials || order_mode == 1 ? dfgpu_groups_intern(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids) : dfgpu_groups_intern_deferred(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids)); gids = ArrayRef::adopt(ids);      // deferred ids: only the accumulators read them
         total = dfgpu_groups_len(groups.g);
         if (order_mode == 1 && !specials) note_sort_prefix(S, gp, gids, mask);

@@ -24,9 +24,10 @@ namespace dfgpu {
 constexpr uint64_t PA_EMPTY = ~0ull;
 constexpr int PA_NT = 1024;
 constexpr int PA_MAX_AGGS = 6;
-enum { PA_SUM_I64 = 0, PA_SUM_F64 = 1, PA_MIN_I64 = 2, PA_MAX_I64 = 3, PA_MIN_U64 = 4, PA_MAX_U64 = 5, PA_MIN_F64 = 6, PA_MAX_F64 = 7, PA_NONE = 8 };
+enum { PA_SUM_I64 = 0, PA_SUM_F64 = 1, PA_MIN_I64 = 2, PA_MAX_I64 = 3, PA_MIN_U64 = 4, PA_MAX_U64 = 5, PA_MIN_F64 = 6, PA_MAX_F64 = 7, PA_NONE = 8,
+       PA_SUM_I128_LO = 9, PA_SUM_I128_HI = 10, PA_SUM_I128_SX = 11 };      // SX: the high word is the sign extension of the low one (Decimal128 of precision <= 18 moves 8 bytes per row through the partition)      // Decimal128 SUM / AVG: two neighbouring cells, the low add's returned value gives the carry (exact mod 2^128, as acc.hip does in HBM)
 
-struct PaPlan { int32_t n_acc; int32_t op[PA_MAX_AGGS]; const uint64_t* val[PA_MAX_AGGS]; uint64_t* out[PA_MAX_AGGS]; };
+struct PaPlan { int32_t n_acc; int32_t op[PA_MAX_AGGS]; const uint64_t* val[PA_MAX_AGGS]; int32_t vstride[PA_MAX_AGGS]; uint64_t* out[PA_MAX_AGGS]; int32_t has_i128; };      // val[a][i * vstride[a]]: a Decimal128 column is two cells of stride 2
 
 __device__ inline uint64_t pa_identity(int op) {
   switch (op) {
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
   const int na = plan_arg.n_acc;
   { const uint32_t i = q0 + threadIdx.x, ic = i < q1 ? i : q1 - 1; kn = pkey[ic]; rn = prow[ic];
 #pragma unroll
-    for (int a = 0; a < PA_MAX_AGGS; a++) vn[a] = a < na ? plan_arg.val[a][ic] : 0; }
+    for (int a = 0; a < PA_MAX_AGGS; a++) vn[a] = a < na ? plan_arg.val[a][(size_t)ic * plan_arg.vstride[a]] : 0; }
   for (uint32_t i0 = q0; i0 < q1; i0 += PA_NT) {
     if (nfilled + PA_NT > C - C / 8) { __syncthreads(); flush(); reset(); if (threadIdx.x == 0) atomicAdd(cursor + 2, 1ull); __syncthreads(); }      // nfilled is only written between barriers: uniform
     const uint32_t i = i0 + threadIdx.x; const bool on = i < q1;
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
     for (int a = 0; a < PA_MAX_AGGS; a++) v[a] = vn[a];
     { const uint32_t i2 = i + PA_NT, ic = i2 < q1 ? i2 : q1 - 1; kn = pkey[ic]; rn = prow[ic];
 #pragma unroll
-      for (int a = 0; a < PA_MAX_AGGS; a++) vn[a] = a < na ? plan_arg.val[a][ic] : 0; }
+      for (int a = 0; a < PA_MAX_AGGS; a++) vn[a] = a < na ? plan_arg.val[a][(size_t)ic * plan_arg.vstride[a]] : 0; }
     // Skewed keys: when at least 16 lanes of a wave carry the key of its first active lane, those lanes are combined in registers (shuffles) and the leader
     // alone touches the table: one LDS atomic per state instead of one per row on a slot every wave of the workgroup is hammering.
     uint32_t cntv = 1; uint32_t rowv = row; bool mine = on;
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
       const uint32_t k0lo = (uint32_t)__shfl((int)(uint32_t)k, lead, 64), k0hi = (uint32_t)__shfl((int)(uint32_t)(k >> 32), lead, 64);
       const bool member = on && (uint32_t)k == k0lo && (uint32_t)(k >> 32) == k0hi;
       const uint64_t mem = ballot64(member);
-      if (__popcll(mem) >= 16) {
+      if (__popcll(mem) >= 16 && !plan_arg.has_i128) {
         uint32_t r = member ? row : 0xFFFFFFFFu;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)r, d, 64); r = o < r ? o : r; }
@@ -193,7 +194,20 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
       if (rowv < first[s]) atomicMin(&first[s], rowv);           // a stale read only costs a redundant atomic
       atomicAdd(&cnt[s], cntv);
 #pragma unroll
-      for (int a = 0; a < PA_MAX_AGGS; a++) if (a < na) pa_apply(plan_arg.op[a], &acc[(size_t)a * C1 + s], v[a]);
+      for (int a = 0; a < PA_MAX_AGGS; a++) if (a < na) {
+        const int op = plan_arg.op[a];
+        if (op == PA_SUM_I128_LO && plan_arg.op[a + 1 < PA_MAX_AGGS ? a + 1 : a] == PA_SUM_I128_SX) {            // value = sign-extended 64 bits
+          const int ah = a + 1 < PA_MAX_AGGS ? a + 1 : a;
+          const unsigned long long lo = v[a], old = atomicAdd(&acc[(size_t)a * C1 + s], lo);
+          const unsigned long long hi = (unsigned long long)((long long)lo >> 63) + (unsigned long long)(old + lo < old);
+          if (hi) atomicAdd(&acc[(size_t)ah * C1 + s], hi);
+        } else if (op == PA_SUM_I128_LO) {            // a + 1 is the high word's cell
+          const int ah = a + 1 < PA_MAX_AGGS ? a + 1 : a;      // a LO cell is never the last one (the host lays pairs out); the clamp keeps the unrolled index in range
+          const unsigned long long lo = v[a], old = atomicAdd(&acc[(size_t)a * C1 + s], lo);
+          const unsigned long long hi = v[ah] + (unsigned long long)(old + lo < old);
+          if (hi) atomicAdd(&acc[(size_t)ah * C1 + s], hi);
+        } else if (op != PA_SUM_I128_HI && op != PA_SUM_I128_SX) pa_apply(op, &acc[(size_t)a * C1 + s], v[a]);
+      }
     }
     uint64_t fb = ballot64(fresh);
     if (lane == 0 && fb) atomicAdd(&nfilled, (uint32_t)__popcll(fb));
@@ -266,7 +280,7 @@ __global__ void __launch_bounds__(BLOCK) k_pa_perm_of_words(const uint64_t* __re
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < m) perm[i] = (uint32_t)(words[i] & ((1ull << jb) - 1ull));
 }
 // every output column of the partial rows in one pass over the permutation: a row's record (key, count, cells) is one or two 32-byte reads
-struct PaEmit { int32_t n; int32_t word[2 + 2 * PA_MAX_AGGS]; void* dst[2 + 2 * PA_MAX_AGGS]; int32_t narrow[2 + 2 * PA_MAX_AGGS]; };      // narrow: store the low 32 bits
+struct PaEmit { int32_t n; int32_t word[2 + 2 * PA_MAX_AGGS]; void* dst[2 + 2 * PA_MAX_AGGS]; int32_t narrow[2 + 2 * PA_MAX_AGGS]; int32_t dstride[2 + 2 * PA_MAX_AGGS], doff[2 + 2 * PA_MAX_AGGS]; };      // narrow: store the low 32 bits; dst[i * dstride + doff]
 template <int RS>
 __global__ void __launch_bounds__(BLOCK) k_pa_emit(PaEmit e, const uint64_t* __restrict__ recs, const uint32_t* __restrict__ perm, int64_t m) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i >= m) return;
@@ -279,8 +293,42 @@ __global__ void __launch_bounds__(BLOCK) k_pa_emit(PaEmit e, const uint64_t* __r
     uint64_t x = 0;
 #pragma unroll
     for (int w = 0; w < RS; w++) if (e.word[c] == w) x = v[w];
-    if (e.narrow[c]) ((uint32_t*)e.dst[c])[i] = (uint32_t)x; else ((uint64_t*)e.dst[c])[i] = x;
+    if (e.narrow[c]) ((uint32_t*)e.dst[c])[i] = (uint32_t)x; else ((uint64_t*)e.dst[c])[(size_t)i * e.dstride[c] + e.doff[c]] = x;
   }
+}
+
+// ---- 2..4 integer key columns -> one u64: key = sum over columns of (value - min + (nullable ? 1 : 0)) * stride; digit 0 of a nullable column = NULL (its own group,
+// group_values/row.rs:94-146 treats NULL as a value).  The ranges multiply to < 2^62, so the packed key never equals PA_EMPTY.
+struct PaPackCols { int32_t n; const void* v[4]; const uint64_t* valid[4]; int32_t type[4]; long long mn[4]; unsigned long long stride[4], range[4]; int32_t nullable[4]; };
+// One row per thread and step.  Measured per 100 M rows x 3 key columns (both kernels together): this form 1.67 ms; four rows per thread, consecutive rows 1.92 ms,
+// lane-contiguous rows 1.94 ms -- neither unrolled form helped, so the simple one stays (the per-element type switch of key_at is the suspect, not measured apart).
+__global__ void __launch_bounds__(BLOCK) k_pa_cols_minmax(PaPackCols pc, const uint64_t* mask, int64_t n, long long* mm /*[2 * n] min, max*/) {
+  long long lo[4] = { INT64_MAX, INT64_MAX, INT64_MAX, INT64_MAX }, hi[4] = { INT64_MIN, INT64_MIN, INT64_MIN, INT64_MIN };
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    if (mask && !bit_get(mask, i)) continue;
+#pragma unroll
+    for (int c = 0; c < 4; c++) if (c < pc.n && valid_at(pc.valid[c], i)) { const long long x = key_at(pc.v[c], pc.type[c], i); lo[c] = x < lo[c] ? x : lo[c]; hi[c] = x > hi[c] ? x : hi[c]; }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; c++) if (c < pc.n) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const long long a = __shfl_xor(lo[c], d, 64), b = __shfl_xor(hi[c], d, 64); lo[c] = a < lo[c] ? a : lo[c]; hi[c] = b > hi[c] ? b : hi[c]; }
+    if (lane_id() == 0 && lo[c] <= hi[c]) { atomicMin(&mm[2 * c], lo[c]); atomicMax(&mm[2 * c + 1], hi[c]); }       // one pair per wave
+  }
+}
+__global__ void __launch_bounds__(BLOCK) k_pa_pack(PaPackCols pc, int64_t n, uint64_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i >= n) return;
+  unsigned long long k = 0;
+#pragma unroll
+  for (int c = 0; c < 4; c++) if (c < pc.n) { const bool ok = valid_at(pc.valid[c], i); const unsigned long long dgt = ok ? (unsigned long long)(key_at(pc.v[c], pc.type[c], i) - pc.mn[c]) + (unsigned long long)pc.nullable[c] : 0ull; k += dgt * pc.stride[c]; }
+  out[i] = k;
+}
+// packed keys of the partial rows -> column c of the group keys (values as 64-bit patterns narrowed by the caller's type width; validity word by word)
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_pa_unpack(const uint64_t* packed, int64_t m, unsigned long long stride, unsigned long long range, long long mn, int nullable, T* out, uint64_t* valid) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; bool ok = true; 
+  if (i < m) { const unsigned long long dgt = (packed[i] / stride) % range; ok = !nullable || dgt != 0; out[i] = ok ? (T)((long long)(dgt - (unsigned long long)nullable) + mn) : (T)0; }
+  if (valid) { const uint64_t b = ballot64(i < m && ok); if (lane_id() == 0 && i < ((m + 63) / 64) * 64) valid[i >> 6] = b; }
 }
 
 static bool pa_key_type_ok(int32_t t) { return t == DFGPU_INT64 || t == DFGPU_UINT64 || t == DFGPU_INT32 || t == DFGPU_UINT32 || t == DFGPU_DATE32; }
@@ -294,53 +342,103 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     const bool verdict_only = out_keys == nullptr;         // would this batch be taken?  (key column + selection only; see include/dfgpu.h)
     if (!keys || (!verdict_only && n_aggs && (!kinds || !values || !out_states))) fail(DFGPU_INVALID_ARGUMENT, "agg_preaggregate: null argument");
     if (verdict_only) n_aggs = 0;
-    auto skip = [&](const char* why) { ctx->pa_sample_key = nullptr; fail(DFGPU_NOT_IMPLEMENTED, "agg_preaggregate: %s", why); };      // a skipped batch's sample must not answer for the next batch at a recycled address
+    auto skip = [&](const char* why) { ctx->pa_sample_key = nullptr; ctx->pa_pack.reset(); fail(DFGPU_NOT_IMPLEMENTED, "agg_preaggregate: %s", why); };      // a skipped batch's sample must not answer for the next batch at a recycled address
     if (!ctx->agg_partitioned) skip("switched off (option agg_partitioned)");
-    if (nkeys != 1) skip("one key column");
+    if (nkeys < 1 || nkeys > 4) skip("one to four key columns");
     const dfgpu_array* key = keys[0]; const int64_t n = key->length;
     // A dictionary key column is pre-aggregated by its CODES: codes with equal dictionary values leave as separate partial rows, which
     // interning the emitted dictionary array merges (dictionary keys intern by value).
-    const int32_t ktype = key->type == DFGPU_DICTIONARY ? key->key_type : key->type;
-    if (!pa_key_type_ok(ktype) || key->validity) skip("a 4- or 8-byte integer key column (or dictionary codes of that width) without NULLs");
+    const bool is_dict = nkeys == 1 && key->type == DFGPU_DICTIONARY;
+    // Several key columns, or one with NULLs, travel as ONE packed u64 (value ranges multiplied out, NULL = digit 0 of its column): the partial rows' keys are unpacked again
+    const bool packed_keys = nkeys > 1 || (!is_dict && key->validity);
+    auto plain_int = [](int32_t t) { switch (t) { case DFGPU_INT8: case DFGPU_INT16: case DFGPU_INT32: case DFGPU_INT64: case DFGPU_DATE32: case DFGPU_UINT8: case DFGPU_UINT16: case DFGPU_UINT32: case DFGPU_UINT64: return true; default: return false; } };
+    if (packed_keys) { for (int c = 0; c < nkeys; c++) if (!keys[c] || !plain_int(keys[c]->type) || keys[c]->length != n) skip("integer / Date32 key columns (not dictionary-encoded) when there are several or one carries NULLs"); }
+    int32_t ktype = is_dict ? key->key_type : key->type;
+    if (!packed_keys && (!pa_key_type_ok(ktype) || key->validity)) skip("a 4- or 8-byte integer key column (or dictionary codes of that width)");
     if (n < ctx->agg_partitioned_min_rows || n > 0xFFFF0000ll) skip("batch below agg_partitioned_min_rows");
     if (n_aggs > 16) skip("at most 16 aggregates");
     // accumulator plan: one 8-byte LDS cell per SUM / MIN / MAX; COUNT and AVG counts come from the row count (value columns carry no NULLs)
-    PaPlan plan{}; int cell_of[16]; const dfgpu_array* cell_src[PA_MAX_AGGS];
+    PaPlan plan{}; int cell_of[16]; const dfgpu_array* cell_src[PA_MAX_AGGS]; int cell_word[PA_MAX_AGGS];      // cell c reads word cell_word[c] of its source's rows
     for (int i = 0; i < n_aggs; i++) {
       const dfgpu_array* v = values[i]; cell_of[i] = -1;
       if (v && (v->validity || v->length != n || v->type == DFGPU_DICTIONARY)) skip("value columns without NULLs");
       if (kinds[i] == DFGPU_AGG_COUNT) continue;
       if (!v) skip("aggregate without an argument");
       int op = PA_NONE;
-      const bool i64 = v->type == DFGPU_INT64, u64 = v->type == DFGPU_UINT64, f64 = v->type == DFGPU_FLOAT64;
-      if (!i64 && !u64 && !f64) skip("Int64 / UInt64 / Float64 aggregate arguments");
+      const bool i64 = v->type == DFGPU_INT64, u64 = v->type == DFGPU_UINT64, f64 = v->type == DFGPU_FLOAT64, d128 = v->type == DFGPU_DECIMAL128;
+      if (!i64 && !u64 && !f64 && !d128) skip("Int64 / UInt64 / Float64 / Decimal128 aggregate arguments");
       switch (kinds[i]) {
-        case DFGPU_AGG_SUM: op = f64 ? PA_SUM_F64 : PA_SUM_I64; break;
-        case DFGPU_AGG_AVG: if (!f64) skip("AVG over Float64"); op = PA_SUM_F64; break;
-        case DFGPU_AGG_MIN: if (f64) skip("MIN over Float64 (NaN order)"); op = i64 ? PA_MIN_I64 : PA_MIN_U64; break;
-        case DFGPU_AGG_MAX: if (f64) skip("MAX over Float64 (NaN order)"); op = i64 ? PA_MAX_I64 : PA_MAX_U64; break;
+        case DFGPU_AGG_SUM: op = d128 ? PA_SUM_I128_LO : f64 ? PA_SUM_F64 : PA_SUM_I64; break;
+        case DFGPU_AGG_AVG: if (!f64 && !d128) skip("AVG over Float64 / Decimal128"); op = d128 ? PA_SUM_I128_LO : PA_SUM_F64; break;
+        case DFGPU_AGG_MIN: if (f64 || d128) skip("MIN over Float64 (NaN order) / Decimal128"); op = i64 ? PA_MIN_I64 : PA_MIN_U64; break;
+        case DFGPU_AGG_MAX: if (f64 || d128) skip("MAX over Float64 (NaN order) / Decimal128"); op = i64 ? PA_MAX_I64 : PA_MAX_U64; break;
         default: skip("SUM / AVG / COUNT / MIN / MAX");
       }
       int c = -1; for (int j = 0; j < plan.n_acc; j++) if (plan.op[j] == op && cell_src[j] == v) c = j;          // SUM(x) and AVG(x) share a cell
-      if (c < 0) { if (plan.n_acc == PA_MAX_AGGS) skip("at most 6 distinct accumulator cells"); c = plan.n_acc++; plan.op[c] = op; cell_src[c] = v; }
+      if (c < 0) {
+        const int need = d128 ? 2 : 1;
+        if (plan.n_acc + need > PA_MAX_AGGS) skip("at most 6 accumulator cells (a Decimal128 sum takes two)");
+        c = plan.n_acc; plan.n_acc += need; plan.op[c] = op; cell_src[c] = v; cell_word[c] = 0;
+        if (d128) { const bool fits64 = v->precision > 0 && v->precision <= 18;      // |unscaled value| < 10^18 < 2^63: the high word carries no information
+          plan.op[c + 1] = fits64 ? PA_SUM_I128_SX : PA_SUM_I128_HI; cell_src[c + 1] = v; cell_word[c + 1] = fits64 ? 0 : 1; plan.has_i128 = 1; }
+      }
       cell_of[i] = c;
     }
+    // the distinct value columns the partition moves (a Decimal128 column once, 16 bytes wide)
+    const dfgpu_array* srcs[PA_MAX_AGGS]; int n_src = 0, src_of[PA_MAX_AGGS];
+    for (int c = 0; c < plan.n_acc; c++) { int j = -1; for (int q = 0; q < n_src; q++) if (srcs[q] == cell_src[c]) j = q; if (j < 0) { j = n_src; srcs[n_src++] = cell_src[c]; } src_of[c] = j; }
     const uint64_t* mk = nullptr; BufferPtr mask = effective_mask(ctx, opt_mask, n); if (mask) mk = (const uint64_t*)mask->ptr;
     // ---- sample: clustered? how many groups?  (a verdict-only call leaves its sample for the call that follows on the same column)
     const int64_t s = n < (1 << 19) ? n : (1 << 19), stride = n / s; const uint64_t cap = 1ull << 21;
-    if (ctx->pa_sample_key == key->values->ptr && ctx->pa_sample_n == n && ctx->pa_sample_mask == (const void*)mk) { for (int q = 0; q < 3; q++) ctx->h_pinned[q] = ctx->pa_sample[q]; ctx->pa_sample_key = nullptr; }
+    const void* ident = keys[0]->values->ptr;           // what the verdict-only call and the call that follows share
+    const bool cached = ctx->pa_sample_key == ident && ctx->pa_sample_n == n && ctx->pa_sample_mask == (const void*)mk && (!packed_keys || (ctx->pa_pack && ctx->pa_pack_n == nkeys));
+    BufferPtr packed; PaPackCols pc{};
+    if (packed_keys) {
+      pc.n = nkeys; for (int c = 0; c < nkeys; c++) { pc.v[c] = keys[c]->values->ptr; pc.valid[c] = keys[c]->validity ? (const uint64_t*)keys[c]->validity->ptr : nullptr; pc.type[c] = keys[c]->type == DFGPU_DATE32 ? DFGPU_INT32 : keys[c]->type; pc.nullable[c] = keys[c]->validity ? 1 : 0;
+        const int w = type_width(keys[c]->type); if (w != 1 && w != 2 && w != 4 && w != 8) fail(DFGPU_INTERNAL, "agg_preaggregate: key column %d of type %d has no integer width", c, keys[c]->type); }      // the kernels read w bytes per row: checked here, not assumed there
+      if (cached) { packed = ctx->pa_pack; for (int c = 0; c < nkeys; c++) { pc.mn[c] = ctx->pa_pack_min[c]; pc.stride[c] = ctx->pa_pack_stride[c]; pc.range[c] = ctx->pa_pack_range[c]; } }
+      else {
+        long long init[8]; for (int c = 0; c < 4; c++) { init[2 * c] = INT64_MAX; init[2 * c + 1] = INT64_MIN; }
+        HIP_CHECK(hipMemcpyAsync(ctx->d_scratch64 + 16, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+        { KernelTimer kt_(ctx, "pa_pack");
+          hipLaunchKernelGGL(k_pa_cols_minmax, dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 8)), dim3(BLOCK), 0, ctx->stream, pc, mk, n, (long long*)(ctx->d_scratch64 + 16));
+          KERNEL_CHECK(); }
+        const uint64_t* mm = read_scratch_range(ctx, 16, 8);
+        ctx->count_sync("sync:pa_pack_ranges");
+        unsigned __int128 prod = 1;
+        for (int c = nkeys - 1; c >= 0; c--) {
+          long long lo = (long long)mm[2 * c], hi = (long long)mm[2 * c + 1]; if (lo > hi) lo = hi = 0;              // a column of NULLs only
+          const unsigned __int128 range = (unsigned __int128)((unsigned long long)hi - (unsigned long long)lo) + 1 + (unsigned)pc.nullable[c];
+          if (range > ((unsigned __int128)1 << 62)) { prod = (unsigned __int128)1 << 100; break; }
+          pc.mn[c] = lo; pc.range[c] = (unsigned long long)range; pc.stride[c] = (unsigned long long)prod; prod *= range;
+          if (prod > ((unsigned __int128)1 << 62)) break;
+        }
+        if (prod > ((unsigned __int128)1 << 62)) skip("key value ranges multiply beyond 2^62 (no packed key)");
+        packed = alloc_buffer(ctx, (size_t)n * 8);
+        { KernelTimer kt_(ctx, "pa_pack");
+          hipLaunchKernelGGL(k_pa_pack, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, pc, n, (uint64_t*)packed->ptr);
+          KERNEL_CHECK(); }
+      }
+      ktype = DFGPU_UINT64;
+    }
+    const void* kptr = packed_keys ? packed->ptr : key->values->ptr;
+    if (cached) { for (int q = 0; q < 3; q++) ctx->h_pinned[q] = ctx->pa_sample[q]; ctx->pa_sample_key = nullptr; ctx->pa_pack.reset(); }
     else {
     BufferPtr table = alloc_buffer(ctx, cap * 8); HIP_CHECK(hipMemsetAsync(table->ptr, 0xFF, cap * 8, ctx->stream));
     zero_scratch(ctx);
     { KernelTimer kt_(ctx, "pa_sample");
-#define PA_SAMPLE(T) hipLaunchKernelGGL((k_pa_sample<T>), dim3(grid_for(s, BLOCK * 8, 256)), dim3(BLOCK), 0, ctx->stream, (const T*)key->values->ptr, mk, n, s, stride, (unsigned long long*)table->ptr, cap - 1, (unsigned long long*)ctx->d_scratch64)
+#define PA_SAMPLE(T) hipLaunchKernelGGL((k_pa_sample<T>), dim3(grid_for(s, BLOCK * 8, 256)), dim3(BLOCK), 0, ctx->stream, (const T*)kptr, mk, n, s, stride, (unsigned long long*)table->ptr, cap - 1, (unsigned long long*)ctx->d_scratch64)
       switch (ktype) { case DFGPU_INT64: PA_SAMPLE(int64_t); break; case DFGPU_UINT64: PA_SAMPLE(uint64_t); break; case DFGPU_UINT32: PA_SAMPLE(uint32_t); break; default: PA_SAMPLE(int32_t); break; }
 #undef PA_SAMPLE
       KERNEL_CHECK(); }
     HIP_CHECK(hipMemcpyAsync(ctx->h_pinned, ctx->d_scratch64, 24, hipMemcpyDeviceToHost, ctx->stream));
     ctx->count_sync("sync:pa_sample");
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (verdict_only) { ctx->pa_sample_key = key->values->ptr; ctx->pa_sample_n = n; ctx->pa_sample_mask = (const void*)mk; for (int q = 0; q < 3; q++) ctx->pa_sample[q] = ctx->h_pinned[q]; }
+    if (verdict_only) {
+      ctx->pa_sample_key = ident; ctx->pa_sample_n = n; ctx->pa_sample_mask = (const void*)mk; for (int q = 0; q < 3; q++) ctx->pa_sample[q] = ctx->h_pinned[q];
+      ctx->pa_pack = packed; ctx->pa_pack_n = packed_keys ? nkeys : 0;
+      for (int c = 0; c < nkeys && packed_keys; c++) { ctx->pa_pack_min[c] = pc.mn[c]; ctx->pa_pack_stride[c] = pc.stride[c]; ctx->pa_pack_range[c] = pc.range[c]; ctx->pa_pack_nullable[c] = pc.nullable[c] != 0; }
+    }
     }
     const double d = (double)ctx->h_pinned[0], nondec = (double)ctx->h_pinned[1], pairs = (double)ctx->h_pinned[2], ss = pairs + 1;
     if (pairs > 0 && nondec >= 0.98 * pairs && !ctx->agg_partitioned_force) skip("keys arrive clustered (run numbering is cheaper)");
@@ -363,22 +461,28 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     if (two_level) { P2 = P > 2048 * 128 ? 256 : 128; P1 = (P + P2 - 1) / P2; if (P1 < 16) P1 = 16; if (P1 > 2048) P1 = 2048; P = P1 * P2; }
     else { if (P > n / 2048 + 1) P = n / 2048 + 1; if (P > ctx->num_cus) P = std::min<int64_t>(2048, (P + ctx->num_cus - 1) / ctx->num_cus * ctx->num_cus); P1 = P; }
     // ---- partition (key, row, value cells)
-    BufferPtr pkey = alloc_buffer(ctx, (size_t)n * 8), prow = alloc_buffer(ctx, (size_t)n * 4); std::vector<BufferPtr> pval((size_t)plan.n_acc);
-    RpCols cols{}; cols.n = 1 + plan.n_acc; cols.rowid_dst = (uint32_t*)prow->ptr;
-    cols.c[0] = RpCol{ key->values->ptr, pkey->ptr, 8, RP_HASHKEY, ktype };
-    for (int c = 0; c < plan.n_acc; c++) { pval[(size_t)c] = alloc_buffer(ctx, (size_t)n * 8); cols.c[1 + c] = RpCol{ cell_src[c]->values->ptr, pval[(size_t)c]->ptr, 8, RP_RAW, 0 }; plan.val[c] = (const uint64_t*)pval[(size_t)c]->ptr; }
+    BufferPtr pkey = alloc_buffer(ctx, (size_t)n * 8), prow = alloc_buffer(ctx, (size_t)n * 4); std::vector<BufferPtr> pval((size_t)n_src);
+    RpCols cols{}; cols.n = 1 + n_src; cols.rowid_dst = (uint32_t*)prow->ptr;
+    cols.c[0] = RpCol{ kptr, pkey->ptr, 8, RP_HASHKEY, ktype };
+    auto lo16 = [&](int j) { return srcs[j]->type == DFGPU_DECIMAL128 && srcs[j]->precision > 0 && srcs[j]->precision <= 18; };
+    auto src_width = [&](int j) { return srcs[j]->type == DFGPU_DECIMAL128 && !lo16(j) ? 16 : 8; };
+    for (int j = 0; j < n_src; j++) { pval[(size_t)j] = alloc_buffer(ctx, (size_t)n * (size_t)src_width(j)); cols.c[1 + j] = RpCol{ srcs[j]->values->ptr, pval[(size_t)j]->ptr, 8 * (src_width(j) / 8), lo16(j) ? RP_LO16 : RP_RAW, 0 }; }
+    auto bind_cells = [&]() { for (int c = 0; c < plan.n_acc; c++) { const int j = src_of[c]; plan.vstride[c] = src_width(j) / 8; plan.val[c] = (const uint64_t*)pval[(size_t)j]->ptr + cell_word[c]; } };
+    bind_cells();
     RpResult r;
-#define PA_PART(T) r = rp_partition(ctx, RpHashInt<T>{ (const T*)key->values->ptr, nullptr, mk }, n, (uint32_t)P1, cols, false, ctx->d_scratch64 + 9, "pa_hist", "pa_scan", "pa_scatter")
+#define PA_PART(T) r = rp_partition(ctx, RpHashInt<T>{ (const T*)kptr, nullptr, mk }, n, (uint32_t)P1, cols, false, ctx->d_scratch64 + 9, "pa_hist", "pa_scan", "pa_scatter")
     switch (ktype) { case DFGPU_INT64: case DFGPU_UINT64: PA_PART(int64_t); break; case DFGPU_UINT32: PA_PART(uint32_t); break; default: PA_PART(int32_t); break; }
 #undef PA_PART
+    packed.reset();
     if (two_level) {
       const int64_t m1 = mk ? (int64_t)read_scratch(ctx, 9) : n;          // rows the selection kept
-      BufferPtr pkey2 = alloc_buffer(ctx, (size_t)n * 8), prow2 = alloc_buffer(ctx, (size_t)n * 4); std::vector<BufferPtr> pval2((size_t)plan.n_acc);
-      RpCols c2{}; c2.n = 2 + plan.n_acc;
+      BufferPtr pkey2 = alloc_buffer(ctx, (size_t)n * 8), prow2 = alloc_buffer(ctx, (size_t)n * 4); std::vector<BufferPtr> pval2((size_t)n_src);
+      RpCols c2{}; c2.n = 2 + n_src;
       c2.c[0] = RpCol{ pkey->ptr, pkey2->ptr, 8, RP_RAW, 0 }; c2.c[1] = RpCol{ prow->ptr, prow2->ptr, 4, RP_RAW, 0 };
-      for (int c = 0; c < plan.n_acc; c++) { pval2[(size_t)c] = alloc_buffer(ctx, (size_t)n * 8); c2.c[2 + c] = RpCol{ pval[(size_t)c]->ptr, pval2[(size_t)c]->ptr, 8, RP_RAW, 0 }; }
+      for (int j = 0; j < n_src; j++) { pval2[(size_t)j] = alloc_buffer(ctx, (size_t)n * (size_t)src_width(j)); c2.c[2 + j] = RpCol{ pval[(size_t)j]->ptr, pval2[(size_t)j]->ptr, src_width(j), RP_RAW, 0 }; }
       (void)rp_partition(ctx, RpHashU64Low{ (const uint64_t*)pkey->ptr }, m1, (uint32_t)P2, c2, true, ctx->d_scratch64 + 10, "pa_hist2", "pa_scan2", "pa_scatter2", true, true);
-      pkey = pkey2; prow = prow2; for (int c = 0; c < plan.n_acc; c++) { pval[(size_t)c] = pval2[(size_t)c]; plan.val[c] = (const uint64_t*)pval[(size_t)c]->ptr; }
+      pkey = pkey2; prow = prow2; for (int j = 0; j < n_src; j++) pval[(size_t)j] = pval2[(size_t)j];
+      bind_cells();
       HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 11, 0, 8, ctx->stream));
       r.starts = alloc_buffer(ctx, (size_t)(P + 1) * 4); r.P = (uint32_t)P;
       { KernelTimer kt_(ctx, "pa_bounds");
@@ -412,7 +516,7 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     if (two_level && (uint32_t)back[0] != 0) fail(DFGPU_INTERNAL, "agg_preaggregate: the two-level partition left rows out of partition order");
     // every key left in exactly one partial row unless a hot partition was cut into slices or a table overflowed mid-partition: the plan layer then
     // needs no hash table to number the groups of a first batch (option "agg_preaggregate_distinct", read only)
-    ctx->pa_last_distinct = n_slices == 1 && key->type != DFGPU_DICTIONARY && early == 0;          // dictionary codes: two codes may carry one value
+    ctx->pa_last_distinct = n_slices == 1 && !is_dict && early == 0;          // dictionary codes: two codes may carry one value
     pkey.reset(); prow.reset(); pval.clear();
     // ---- partial rows in first-seen order of their groups
     BufferPtr perm = alloc_buffer(ctx, (size_t)(m + 1) * 4);
@@ -447,22 +551,39 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     KernelTimer kt_(ctx, "pa_emit");
     const uint32_t* pp = (const uint32_t*)perm->ptr; dim3 grid(grid_for(m, BLOCK));
     ArrayHolder ok(new_fixed(ctx, ktype, m));
-    PaEmit em{}; auto add = [&](int word, void* dst, int narrow) { em.word[em.n] = word; em.dst[em.n] = dst; em.narrow[em.n] = narrow; em.n++; };
+    PaEmit em{}; auto add = [&](int word, void* dst, int narrow, int dstride = 1, int doff = 0) { em.word[em.n] = word; em.dst[em.n] = dst; em.narrow[em.n] = narrow; em.dstride[em.n] = dstride; em.doff[em.n] = doff; em.n++; };
     add(0, ok.get()->values->ptr, (ktype == DFGPU_INT64 || ktype == DFGPU_UINT64) ? 0 : 1);
     std::vector<ArrayHolder> st((size_t)n_aggs * 2);
     for (int i = 0; i < n_aggs; i++) {
       auto counts_as = [&](int32_t type) { dfgpu_array* a = new_fixed(ctx, type, m); add(1, a->values->ptr, 0); return a; };
       auto cell_as = [&](int32_t type) { dfgpu_array* a = new_fixed(ctx, type, m); add(2 + cell_of[i], a->values->ptr, 0); return a; };
+      // Decimal128 sums: state type Decimal128(min(38, p + 10), s) (sum.rs:75-86, average.rs:96-110); the two cells interleave into 16-byte values
+      auto dec_as = [&]() { const dfgpu_array* v = values[i]; dfgpu_array* a = new_fixed(ctx, DFGPU_DECIMAL128, m, std::min(38, v->precision + 10), v->scale); add(2 + cell_of[i], a->values->ptr, 0, 2, 0); add(3 + cell_of[i], a->values->ptr, 0, 2, 1); return a; };
+      const bool d128 = values[i] && values[i]->type == DFGPU_DECIMAL128;
       if (kinds[i] == DFGPU_AGG_COUNT) st[(size_t)2 * i].a = counts_as(DFGPU_INT64);                                                       // count.rs: Int64 state
-      else if (kinds[i] == DFGPU_AGG_AVG) { st[(size_t)2 * i].a = counts_as(DFGPU_UINT64); st[(size_t)2 * i + 1].a = cell_as(DFGPU_FLOAT64); }   // average.rs:392-430: (counts, sums)
+      else if (kinds[i] == DFGPU_AGG_AVG) { st[(size_t)2 * i].a = counts_as(DFGPU_UINT64); st[(size_t)2 * i + 1].a = d128 ? dec_as() : cell_as(DFGPU_FLOAT64); }   // average.rs:392-430: (counts, sums)
+      else if (d128) st[(size_t)2 * i].a = dec_as();
       else st[(size_t)2 * i].a = cell_as(values[i]->type);          // SUM / MIN / MAX of an 8-byte type: state type == input type (sum.rs:75-86, min_max.rs:102-139)
+      if (em.n > 2 + 2 * PA_MAX_AGGS) fail(DFGPU_NOT_IMPLEMENTED, "agg_preaggregate: more output columns than one emit pass writes");
     }
     if (m) { if (rs == 4) hipLaunchKernelGGL(k_pa_emit<4>, grid, dim3(BLOCK), 0, ctx->stream, em, (const uint64_t*)orec->ptr, pp, m); else hipLaunchKernelGGL(k_pa_emit<8>, grid, dim3(BLOCK), 0, ctx->stream, em, (const uint64_t*)orec->ptr, pp, m); }
     KERNEL_CHECK();
-    if (key->type == DFGPU_DICTIONARY) {           // DictionaryArray::try_new(codes, the input's dictionary)
+    if (is_dict) {           // DictionaryArray::try_new(codes, the input's dictionary)
       dfgpu_array* d = nullptr; dfgpu_status st2 = dfgpu_array_make_dictionary(ctx, ok.get(), key->dictionary, &d);
       if (st2 != DFGPU_OK) fail(st2, "%s", ctx->err.c_str());
       out_keys[0] = d;
+    } else if (packed_keys) {  // the packed keys of the partial rows back into their columns (NULL digits -> validity)
+      std::vector<ArrayHolder> kc((size_t)nkeys);
+      for (int c = 0; c < nkeys; c++) {
+        kc[(size_t)c].a = new_fixed(ctx, keys[c]->type, m, 0, 0, pc.nullable[c] != 0);
+        uint64_t* vb = pc.nullable[c] ? (uint64_t*)kc[(size_t)c].get()->validity->ptr : nullptr; void* dst = kc[(size_t)c].get()->values->ptr;
+#define PA_UNPACK(T) hipLaunchKernelGGL((k_pa_unpack<T>), dim3(grid_for(((m + 63) / 64) * 64, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)ok.get()->values->ptr, m, pc.stride[c], pc.range[c], pc.mn[c], pc.nullable[c], (T*)dst, vb)
+        if (m) switch (type_width(keys[c]->type)) { case 1: PA_UNPACK(uint8_t); break; case 2: PA_UNPACK(uint16_t); break; case 4: PA_UNPACK(uint32_t); break; default: PA_UNPACK(uint64_t); break; }
+#undef PA_UNPACK
+        kc[(size_t)c].get()->null_count = pc.nullable[c] ? -1 : 0;
+      }
+      KERNEL_CHECK();
+      for (int c = 0; c < nkeys; c++) out_keys[c] = kc[(size_t)c].release();
     } else out_keys[0] = ok.release();
     for (int i = 0; i < n_aggs; i++) { out_states[2 * i] = st[(size_t)2 * i].release(); out_states[2 * i + 1] = st[(size_t)2 * i + 1].release(); }
   });

@@ -59,7 +59,7 @@ struct RpHashDigit {      // partition = one digit of a 64-bit word (the LSD pas
 };
 
 // columns moved by the scatter
-enum { RP_RAW = 0, RP_KEY64 = 2, RP_HASHKEY = 3 };
+enum { RP_RAW = 0, RP_KEY64 = 2, RP_HASHKEY = 3, RP_LO16 = 4 };      // LO16: src holds 16-byte elements (Decimal128), the low 8 bytes move (width 8 on the destination side)
 struct RpCol { const void* src; void* dst; int32_t width; int32_t kind; int32_t type; };   // RAW: width bytes per row (1, 2, 4, 8, 16); KEY64: src integer column of `type`, dst u64; HASHKEY: dst u64 = the 64-bit key the hasher produced for the row
 // rowid_dst (optional): the original row number of every moved row (rides along with the first column's round).
 // pack12_dst (optional; column 0 must be 8 bytes wide): column 0 and the row number leave as ONE array of 12-byte records
@@ -172,6 +172,7 @@ __global__ void __launch_bounds__(NT) k_rp_scatter(H hs, int64_t n, uint32_t P, 
       // the width switch sits outside the unrolled row loop: one load shape per column, RP_R loads in flight
 #define RP_GATHER(EXPR) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) { const int64_t i = i0 + (int64_t)q * QS; stage[spos[q]] = (uint64_t)(EXPR); } }
       if (col.kind == RP_HASHKEY) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) stage[spos[q]] = hk[q]; }
+      else if (col.kind == RP_LO16) RP_GATHER(((const uint64_t*)col.src)[2 * i])
       else if (col.kind == RP_KEY64) switch (col.type) {            // widened exactly as key_at() does
         case DFGPU_INT8: RP_GATHER((int64_t)((const int8_t*)col.src)[i]) break;
         case DFGPU_INT16: RP_GATHER((int64_t)((const int16_t*)col.src)[i]) break;
@@ -252,6 +253,7 @@ __global__ void __launch_bounds__(NT) k_rp_scatter_direct(H hs, int64_t n, uint3
     const RpCol col = scol[c];
 #define RP_MOVE(DT, EXPR) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) { const int64_t i = i0 + (int64_t)q * NT; ((DT*)col.dst)[pos[q]] = (DT)(EXPR); } }
     if (col.kind == RP_HASHKEY) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) ((uint64_t*)col.dst)[pos[q]] = hk[q]; }
+    else if (col.kind == RP_LO16) RP_MOVE(uint64_t, ((const uint64_t*)col.src)[2 * i])
     else if (col.kind == RP_KEY64) switch (col.type) {
       case DFGPU_INT8: RP_MOVE(uint64_t, (int64_t)((const int8_t*)col.src)[i]) break;
       case DFGPU_INT16: RP_MOVE(uint64_t, (int64_t)((const int16_t*)col.src)[i]) break;

@@ -329,14 +329,16 @@ DFGPU_API dfgpu_status dfgpu_jit_selftest(const char *arch, char *log, int64_t l
 DFGPU_API dfgpu_status dfgpu_acc_merge_batch(dfgpu_ctx *ctx, dfgpu_acc *a, const dfgpu_array *const *states, int32_t nstates,
                                              const dfgpu_array *group_ids, const dfgpu_array *opt_filter, int64_t total_num_groups);
 /* Partial aggregation of ONE batch ahead of intern / merge_batch (≙ AggregateMode::Partial applied inside the operator, aggregates/mod.rs:64-100,
- * row_hash.rs:524-613): the batch is reduced to one row per group -- out_keys[0] = the group keys (type of keys[0]) in first-seen order of
+ * row_hash.rs:524-613): the batch is reduced to one row per group -- out_keys[c] = column c of the group keys (type of keys[c]) in first-seen order of
  * their groups, out_states[2 i], out_states[2 i + 1] = the state arrays of aggregate i exactly as dfgpu_acc_state returns them (COUNT: Int64;
  * SUM / MIN / MAX: one array; AVG: UInt64 counts, sums; the second entry is NULL unless AVG).  The caller interns out_keys and calls
  * dfgpu_acc_merge_batch with the states: results equal updating the accumulators with the batch row by row (Float64 sums within 1e-9
  * relative: the additions are reassociated).  Rows are hash-partitioned on the key so that every partition's groups fit one LDS table
  * (csrc/pagg.hip); a key may come back in more than one row when a partition held more groups than the table -- the merge adds them up.
- * Taken for one 4- / 8-byte integer key column without NULLs, SUM / MIN / MAX over Int64 / UInt64, SUM / AVG over Float64, COUNT, value
- * columns without NULLs, no per-aggregate filter, a batch of >= option "agg_partitioned_min_rows" rows whose keys are neither clustered
+ * Taken for one 4- / 8-byte integer key column (or dictionary codes of that width), or for 1..4 integer / Date32 key columns with or without NULLs
+ * whose value ranges multiply to < 2^62 (they travel as ONE packed 64-bit key, NULL = a value of its own, and are unpacked again: out_keys[0 ..
+ * nkeys)); SUM / MIN / MAX over Int64 / UInt64, SUM / AVG over Float64 and over Decimal128 (exact 128-bit sums; state Decimal128(min(38, p + 10), s)),
+ * COUNT, value columns without NULLs, no per-aggregate filter, a batch of >= option "agg_partitioned_min_rows" rows whose keys are neither clustered
  * nor few (a sample decides); any other shape returns DFGPU_NOT_IMPLEMENTED and the caller updates the accumulators the ordinary way.
  * values[i] may be NULL for COUNT(*).  opt_mask: BOOL selection, unselected rows do not take part.
  * out_keys == NULL asks for the verdict only (DFGPU_OK = a following call with the same key column and selection will be taken, as far as the

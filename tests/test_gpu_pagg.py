@@ -141,8 +141,10 @@ def test_sample_declines_clustered_few_and_unsupported_shapes(ctx):
         for key in (np.sort(RNG.integers(0, 50000, n)), RNG.integers(0, 100, n)):          # clustered; few groups
             with pytest.raises(dfgpu.DfgpuError):
                 dfgpu.agg_preaggregate(ctx, ctx.from_arrow(pa.array(key.astype(np.int64))), [0], [v])
-        with pytest.raises(dfgpu.DfgpuError):                                                # nullable key
-            dfgpu.agg_preaggregate(ctx, ctx.from_arrow(pa.array(RNG.integers(0, 50000, n), mask=RNG.random(n) < 0.1)), [0], [v])
+        with pytest.raises(dfgpu.DfgpuError):                                                # a Float64 key cannot be packed
+            dfgpu.agg_preaggregate(ctx, ctx.from_arrow(pa.array(RNG.random(n))), [0], [v])
+        pk, _ = dfgpu.agg_preaggregate(ctx, ctx.from_arrow(pa.array(RNG.integers(0, 50000, n), mask=RNG.random(n) < 0.1)), [0], [v])     # a nullable key is taken since round 3 (NULL = a group of its own)
+        assert len(pk) >= 49000 and pk.null_count == 1
         pk, _ = dfgpu.agg_preaggregate(ctx, ctx.from_arrow(pa.array(RNG.integers(0, 50000, n).astype(np.int64))), [0], [v])     # taken
         assert len(pk) >= 49000
 
@@ -211,3 +213,109 @@ def test_first_batch_keeps_its_keys_out_of_the_hash_table_until_a_second_batch_a
         res.append([pa.concat_arrays([c[i] for c in cols]) for i in range(4)])
     for a, b in zip(*res):
         assert a.equals(b)
+
+
+# ---------------------------------------------------------------------------------------------- round 3: TPC-H shapes -- several key columns, NULL keys, Decimal128 sums
+def run_device_multi(ctx, keys, aggs, mask=None):
+    import dfgpu
+    kd = [ctx.from_arrow(k) for k in keys]
+    vals = [ctx.from_arrow(v) if v is not None else None for _, v in aggs]
+    pk, states = dfgpu.agg_preaggregate(ctx, kd, [KIND[k] for k, _ in aggs], vals, mask=ctx.from_arrow(pa.array(mask)) if mask is not None else None)
+    gv = dfgpu.GroupValues(ctx, len(keys))
+    gids = gv.intern(pk)
+    out = []
+    for (k, v), st in zip(aggs, states):
+        if v is None:
+            acc = dfgpu.GroupsAccumulator(ctx, KIND[k], dfgpu.capi.INT64)
+        elif pa.types.is_decimal(v.type):
+            acc = dfgpu.GroupsAccumulator(ctx, KIND[k], dfgpu.capi.DECIMAL128, v.type.precision, v.type.scale)
+        else:
+            acc = dfgpu.GroupsAccumulator(ctx, KIND[k], {pa.int64(): dfgpu.capi.INT64, pa.uint64(): dfgpu.capi.UINT64, pa.float64(): dfgpu.capi.FLOAT64}[v.type])
+        acc.merge_batch(st, gids, None, len(gv))
+        out.append(acc.evaluate().to_arrow())
+    return [a.to_arrow() for a in gv.emit()], out, len(pk[0])
+
+
+def run_oracle_multi(keys, aggs, mask=None):
+    if mask is not None:
+        m = pa.array(mask); keys = [k.filter(m) for k in keys]; aggs = [(k, v.filter(m) if v is not None else None) for k, v in aggs]
+    og = po.Groups([k.type for k in keys]); gids = og.intern(keys)
+    out = []
+    for k, v in aggs:
+        acc = po.Acc(k, pa.int64() if v is None else v.type)
+        acc.update_batch(v, gids, None, len(og))
+        out.append(acc.evaluate())
+    return og.emit(), out
+
+
+def dec_array(values, precision=15, scale=2):
+    import decimal
+    return pa.array([decimal.Decimal(int(x)).scaleb(-scale) for x in values], type=pa.decimal128(precision, scale))
+
+
+def compare_multi(gk, got, wk, want):
+    assert len(gk) == len(wk)
+    for a, b in zip(gk, wk):
+        assert a.type == b.type and a.equals(b)          # same groups, same first-seen order, NULL keys where the oracle has them
+    for g, w in zip(got, want):
+        assert g.type == w.type and g.equals(w), (g.type, w.type)
+
+
+@pytest.mark.parametrize("n,groups", [(300000, 20000), (120000, 110000), (400000, 300)], ids=["15-rows-per-group", "mostly-distinct", "hot-groups"])
+def test_three_key_columns_decimal_sum_avg_count(ctx, n, groups):
+    """GROUP BY (Int64, Date32, Int32) with SUM / AVG over Decimal128(15,2) and COUNT(*): Q3's aggregate shape.  Values of both signs: the
+    128-bit sum is two LDS cells, the low add's returned value carries into the high one."""
+    gid = RNG.integers(0, groups, n)
+    k0 = pa.array((gid * 7919 - 3_000_000).astype(np.int64)); k1 = pa.array((8000 + gid % 2400).astype(np.int32)).cast(pa.date32()); k2 = pa.array((gid % 3 - 1).astype(np.int32))
+    v = dec_array(RNG.integers(-10**14, 10**14, n)); w = dec_array(RNG.integers(0, 10**6, n), 38, 4)
+    aggs = [("SUM", v), ("AVG", v), ("COUNT", None), ("SUM", w)]
+    with forced(ctx) as f:
+        gk, got, m = run_device_multi(ctx, [k0, k1, k2], aggs)
+        ran = f.kernels()
+    assert "pa_aggregate" in ran and "pa_pack" in ran, ran
+    wk, want = run_oracle_multi([k0, k1, k2], aggs)
+    compare_multi(gk, got, wk, want)
+    assert m >= len(wk[0])
+
+
+def test_nullable_key_columns_and_selection(ctx):
+    """NULL is a group of its own in every key column (group_values/row.rs:94-146); a fused selection drops rows before they are grouped"""
+    n = 200000
+    a = RNG.integers(0, 5000, n).astype(np.int64); b = RNG.integers(-50, 50, n).astype(np.int32)
+    k0 = pa.array(a, mask=RNG.random(n) < 0.05); k1 = pa.array(b, mask=RNG.random(n) < 0.1)
+    v = pa.array(RNG.integers(-10**9, 10**9, n).astype(np.int64)); d = dec_array(RNG.integers(-10**12, 10**12, n))
+    aggs = [("SUM", v), ("MIN", v), ("MAX", v), ("SUM", d), ("COUNT", None)]
+    mask = RNG.random(n) < 0.7
+    with forced(ctx) as f:
+        gk, got, _ = run_device_multi(ctx, [k0, k1], aggs, mask=mask)
+        assert "pa_aggregate" in f.kernels()
+    wk, want = run_oracle_multi([k0, k1], aggs, mask=mask)
+    compare_multi(gk, got, wk, want)
+
+
+def test_one_nullable_key_column(ctx):
+    n = 150000
+    k = pa.array(RNG.integers(0, 9000, n).astype(np.int32), mask=RNG.random(n) < 0.03)
+    v = pa.array(RNG.random(n)); c = pa.array(RNG.integers(0, 100, n).astype(np.int64))
+    aggs = [("SUM", c), ("AVG", v), ("COUNT", None)]
+    with forced(ctx) as f:
+        gk, got, _ = run_device_multi(ctx, [k], aggs)
+        assert "pa_aggregate" in f.kernels()
+    wk, want = run_oracle_multi([k], aggs)
+    assert gk[0].equals(wk[0])
+    for g, w in zip(got, want):
+        if pa.types.is_floating(g.type):
+            assert np.allclose(g.to_numpy(zero_copy_only=False), w.to_numpy(zero_copy_only=False), rtol=FLOAT_RTOL, atol=0.0)
+        else:
+            assert g.equals(w)
+
+
+def test_key_ranges_too_wide_to_pack_decline(ctx):
+    """two Int64 columns spanning 2^62 each cannot share one 64-bit key: NotImplemented, the caller groups the ordinary way"""
+    import dfgpu
+    n = 100000
+    k0 = pa.array(RNG.integers(-(1 << 61), 1 << 61, n).astype(np.int64)); k1 = pa.array(RNG.integers(-(1 << 61), 1 << 61, n).astype(np.int64))
+    with forced(ctx):
+        with pytest.raises(dfgpu.capi.DfgpuError) as e:
+            run_device_multi(ctx, [k0, k1], [("COUNT", None)])
+    assert "multiply beyond" in str(e.value)

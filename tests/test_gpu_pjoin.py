@@ -189,3 +189,21 @@ def test_two_packed_key_columns_take_the_partitioned_path(ctx):
     want = po.hash_join([[pa.array(b0), pa.array(b1)]], [[pa.array(p0), pa.array(p1)]], "Inner", False, batch_size=1 << 40)
     assert np.array_equal(bi.to_numpy().astype(np.int64), want.build_idx) and np.array_equal(pi.to_numpy().astype(np.int64), want.probe_idx)
     assert "pj_join" in ran
+
+
+def test_packed_join_keys_with_a_date32_column(ctx):
+    """(Int64, Date32) join keys packed into one Int64 (join.hip k_pack_keys): a Date32 column is 4 bytes per row.  Regression for round 3: key_at() had no
+    Date32 case and read 8 bytes per row from it (out of bounds, garbage ranges -- the pack was then refused for the wrong reason)."""
+    import dfgpu
+    nb, npr = 40000, 120000
+    bk = unique_keys(nb, np.int64, 0, 10**6); bd = (9000 + (bk % 1500)).astype(np.int32)
+    hit = RNG.random(npr) < 0.5; pick = RNG.integers(0, nb, npr)
+    pk = np.where(hit, bk[pick], RNG.integers(0, 10**6, npr)).astype(np.int64); pd = np.where(hit, bd[pick], RNG.integers(9000, 10500, npr)).astype(np.int32)
+    arr = lambda k, d: [pa.array(k), pa.array(d).cast(pa.date32())]
+    with forced(ctx, 256) as f:
+        t = dfgpu.JoinTable(ctx, [ctx.from_arrow(a) for a in arr(bk, bd)])
+        bi, pi = t.probe([ctx.from_arrow(a) for a in arr(pk, pd)])
+        ran = f.kernels()
+    want = po.hash_join([arr(bk, bd)], [arr(pk, pd)], "Inner", False, batch_size=1 << 40)
+    assert np.array_equal(bi.to_numpy().astype(np.int64), want.build_idx) and np.array_equal(pi.to_numpy().astype(np.int64), want.probe_idx)
+    assert "k_pack_keys" in ran, ran              # the ranges (10^6 x 1500) fit: the packed single-key paths serve the join
