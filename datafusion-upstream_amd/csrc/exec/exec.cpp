@@ -853,24 +853,27 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
 // buffered rows in buffered order, an unmatched streamed row of an outer join in its own place with NULLs (join_partial :968-1060).  For sorted inputs that
 // is exactly: probe the streamed rows against a table of the buffered rows (pairs come out by streamed row, then buffered input order), then -- for Left /
 // Right -- a stable re-order of matched + unmatched rows by streamed row.  The device does that instead of a two-cursor merge: one build, one probe and
-// one stable sort over whole partitions.  Inner, Left, Right, LeftSemi, LeftAnti without a JoinFilter; Full (its NULL-joined buffered rows interleave with
-// the streamed output batch by batch), RightSemi (refused by the reference too, :107-111), RightAnti and filters answer NotImplemented.
+// one stable sort over whole partitions.  Inner, Left, Right, LeftSemi, LeftAnti, RightAnti (streamed side = right, :164) and Full without a JoinFilter.
+// Full = the Left join's rows in streamed order, then one batch of the buffered rows no streamed row matched, NULL-joined (the reference interleaves those
+// batch by batch as its buffered cursor advances, :1001-1077; its two Full tests, :2094-2121 and :2451-2497, compare sorted rows, and so do ours).
+// RightSemi (refused by the reference too, :107-111) and JoinFilters answer NotImplemented.
 struct SortMergeJoinExec : Plan {
   PlanPtr left, right; std::vector<ExprPtr> on_l, on_r; int join_type = 0; bool null_equals_null = false;
   PlanPtr fresh() const override { auto j = std::make_shared<SortMergeJoinExec>(); j->left = left->fresh(); j->right = right->fresh(); j->on_l = on_l; j->on_r = on_r; j->join_type = join_type; j->null_equals_null = null_equals_null; return j; }
   std::vector<std::shared_ptr<const Plan>> children() const override { return {left, right}; }
   const char* name() const override { return "SortMergeJoinExec"; }
   bool left_only() const { return join_type == DFGPU_JOIN_LEFT_SEMI || join_type == DFGPU_JOIN_LEFT_ANTI; }
+  bool right_only() const { return join_type == DFGPU_JOIN_RIGHT_ANTI; }
   SchemaPtr schema() const override {
     auto s = std::make_shared<Schema>(); auto l = left->schema(), r = right->schema();
-    if (l) s->f.insert(s->f.end(), l->f.begin(), l->f.end());
+    if (!right_only() && l) s->f.insert(s->f.end(), l->f.begin(), l->f.end());
     if (!left_only() && r) s->f.insert(s->f.end(), r->f.begin(), r->f.end());
     return s;
   }
   int partitions() const override { return left->partitions(); }
   std::unique_ptr<Stream> execute(int p, const TaskContext& tc) const override {
     if (left->partitions() != right->partitions()) fail(DFGPU_INTERNAL, "Invalid SortMergeJoinExec, partition count mismatch %d!=%d, consider using RepartitionExec", left->partitions(), right->partitions());   // :294-300
-    const bool stream_left = join_type != DFGPU_JOIN_RIGHT;
+    const bool stream_left = join_type != DFGPU_JOIN_RIGHT && join_type != DFGPU_JOIN_RIGHT_ANTI;      // :160-175
     auto collect = [&](const PlanPtr& side, Batch* out) {
       std::vector<Batch> in; drain(side, p, tc, in);
       if (!concat_batches(tc, in, out)) { out->schema = side->schema(); out->base_rows = 0; for (auto& f : out->schema->f) { dfgpu_array* nn = nullptr; tc.check(dfgpu_array_new_null(tc.ctx, f.type, f.precision, f.scale, 0, &nn)); out->cols.push_back(col_of(ArrayRef::adopt(nn))); } }
@@ -880,16 +883,20 @@ struct SortMergeJoinExec : Plan {
     const auto& on_s = stream_left ? on_l : on_r; const auto& on_b = stream_left ? on_r : on_l;
     std::vector<Batch> outv;
     SpanGuard join_span(tc, met.get(), 2);
-    ArrayRef bidx, sidx;
+    ArrayRef bidx, sidx, unmatched_b;            // unmatched_b (Full): buffered rows no streamed row matched
     {
       std::vector<ArrayRef> bk, sk; std::vector<const dfgpu_array*> bp, sp;
       for (auto& e : on_b) { bk.push_back(into_array(tc, e->eval(tc, bb), bb.base_rows)); bp.push_back(bk.back().a); }
       for (auto& e : on_s) { sk.push_back(into_array(tc, e->eval(tc, sb), sb.base_rows)); sp.push_back(sk.back().a); }
       JoinTableRef table; tc.check(dfgpu_join_build(tc.ctx, bp.data(), (int32_t)bp.size(), nullptr, null_equals_null ? 1 : 0, &table.t));
       dfgpu_array *b = nullptr, *s = nullptr; tc.check(dfgpu_join_probe(tc.ctx, table.t, sp.data(), (int32_t)sp.size(), nullptr, &b, &s)); bidx = ArrayRef::adopt(b); sidx = ArrayRef::adopt(s);
+      if (join_type == DFGPU_JOIN_FULL) {        // the table indexes the buffered side: its unvisited rows are what the Full join adds (≙ the visited bitmap of a HashJoinExec Full join)
+        tc.check(dfgpu_join_mark_visited(tc.ctx, table.t, bidx.a));
+        dfgpu_array* u = nullptr; tc.check(dfgpu_join_final_indices(tc.ctx, table.t, DFGPU_JOIN_LEFT_ANTI, &u)); unmatched_b = ArrayRef::adopt(u);
+      }
     }
     if (join_type != DFGPU_JOIN_INNER) {
-      const int as = (join_type == DFGPU_JOIN_LEFT || join_type == DFGPU_JOIN_RIGHT) ? DFGPU_JOIN_RIGHT : join_type == DFGPU_JOIN_LEFT_SEMI ? DFGPU_JOIN_RIGHT_SEMI : DFGPU_JOIN_RIGHT_ANTI;
+      const int as = (join_type == DFGPU_JOIN_LEFT || join_type == DFGPU_JOIN_RIGHT || join_type == DFGPU_JOIN_FULL) ? DFGPU_JOIN_RIGHT : join_type == DFGPU_JOIN_LEFT_SEMI ? DFGPU_JOIN_RIGHT_SEMI : DFGPU_JOIN_RIGHT_ANTI;
       dfgpu_array *b2 = nullptr, *s2 = nullptr; tc.check(dfgpu_join_adjust_indices(tc.ctx, bidx.a, sidx.a, 0, sb.base_rows, as, &b2, &s2)); bidx = ArrayRef::adopt(b2); sidx = ArrayRef::adopt(s2);
       if (as == DFGPU_JOIN_RIGHT && sidx.len()) {         // unmatched streamed rows back into their places: stable order by streamed row
         const dfgpu_array* kp = sidx.a; uint8_t no = 0; dfgpu_array* perm = nullptr;
@@ -898,9 +905,16 @@ struct SortMergeJoinExec : Plan {
       }
     }
     Batch o; o.schema = schema(); o.base_rows = sidx.len(); MemoPtr memo = std::make_shared<TakeMemo>();
-    for (auto& c : lb.cols) o.cols.push_back(col_take(c, stream_left ? sidx : bidx, memo));
+    if (!right_only()) for (auto& c : lb.cols) o.cols.push_back(col_take(c, stream_left ? sidx : bidx, memo));
     if (!left_only()) for (auto& c : rb.cols) o.cols.push_back(col_take(c, stream_left ? bidx : sidx, memo));
     if (o.base_rows > 0) outv.push_back(std::move(o));
+    if (unmatched_b && unmatched_b.len() > 0) {      // Full: streamed (left) columns NULL, buffered (right) columns from the unmatched rows
+      const int64_t m = unmatched_b.len(); dfgpu_array* nn = nullptr; tc.check(dfgpu_array_new_null(tc.ctx, DFGPU_UINT32, 0, 0, m, &nn)); ArrayRef nulls = ArrayRef::adopt(nn);
+      Batch u; u.schema = schema(); u.base_rows = m; MemoPtr memo2 = std::make_shared<TakeMemo>();
+      for (auto& c : lb.cols) u.cols.push_back(col_take(c, nulls, memo2));
+      for (auto& c : rb.cols) u.cols.push_back(col_take(c, unmatched_b, memo2));
+      outv.push_back(std::move(u));
+    }
     return std::unique_ptr<Stream>(new VecStream(std::move(outv)));
   }
 };
@@ -1783,7 +1797,7 @@ dfgpu_status dfgpu_plan_sort_merge_join(const dfgpu_plan* left, const dfgpu_plan
   return guard([&] {
     if (non < 1) fail(DFGPU_EXECUTION, "Plan error: On constraints in SortMergeJoinExec should be non-empty");       // sort_merge_join.rs:116-120
     if (join_type == DFGPU_JOIN_RIGHT_SEMI) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: SortMergeJoinExec does not support JoinType::RightSemi");       // :107-111
-    if (join_type == DFGPU_JOIN_FULL || join_type == DFGPU_JOIN_RIGHT_ANTI || join_type < 0 || join_type > DFGPU_JOIN_RIGHT_ANTI) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: SortMergeJoinExec join type %d on the device (Inner, Left, Right, LeftSemi, LeftAnti are)", join_type);
+    if (join_type < 0 || join_type > DFGPU_JOIN_RIGHT_ANTI) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: SortMergeJoinExec join type %d on the device", join_type);
     if (filter) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: SortMergeJoinExec with a JoinFilter on the device");
     auto j = std::make_shared<SortMergeJoinExec>(); j->left = pl(left); j->right = pl(right);
     for (int i = 0; i < non; i++) { j->on_l.push_back(ex(on_left[i])); j->on_r.push_back(ex(on_right[i])); }

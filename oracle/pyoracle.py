@@ -475,8 +475,18 @@ def sort_merge_join(left_cols, right_cols, on, join_type: str, descending: bool 
     streamed key against the buffered head under the sort options (a NULL never equals unless null_equals_null; NULLs order by nulls_first); join_partial (:968-1060)
     emits, per streamed row: Equal -> the pairs with every buffered row of the equal-key run (Inner / Left / Right), or the streamed row once (LeftSemi); Less ->
     the streamed row with NULLs (Left / Right) or alone (LeftAnti); Greater -> the buffered cursor advances."""
+    if join_type == "RightAnti":          # streamed side = right (:164): the right rows no left row matches, in right order = LeftAnti with the sides exchanged
+        return sort_merge_join(right_cols, left_cols, [(r, l) for l, r in on], "LeftAnti", descending, nulls_first, null_equals_null)
+    if join_type == "Full":               # streamed side = left (:169): the Left join's rows, plus every buffered (right) row no streamed row matched, NULL-joined.  The reference emits
+        # those as its buffered cursor passes them (:1001-1077); its tests compare sorted rows (:2121, :2497), so the restatement appends them: a MULTISET contract
+        out = sort_merge_join(left_cols, right_cols, on, "Left", descending, nulls_first, null_equals_null)
+        lonely = sort_merge_join(right_cols, left_cols, [(r, l) for l, r in on], "LeftAnti", descending, nulls_first, null_equals_null)
+        m = len(lonely[0]) if lonely else 0
+        left_nulls = [pa.nulls(m, type=c.type) for c in left_cols]
+        parts = [pa.concat_arrays([a, b]) for a, b in zip(out, left_nulls + lonely)]
+        return parts
     if join_type not in ("Inner", "Left", "Right", "LeftSemi", "LeftAnti"):
-        raise OracleError("sort_merge_join restates Inner, Left, Right, LeftSemi, LeftAnti")
+        raise OracleError("sort_merge_join restates Inner, Left, Right, LeftSemi, LeftAnti, RightAnti, Full")
     stream_left = join_type != "Right"
     scols, bcols = (left_cols, right_cols) if stream_left else (right_cols, left_cols)
     skey = [scols[l if stream_left else r].to_pylist() for l, r in on]

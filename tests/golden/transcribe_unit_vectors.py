@@ -173,6 +173,15 @@ smj = [
 ]
 
 S = "datafusion/physical-plan/src/sorts/sort.rs:"
+# JoinType::Full: the reference's two tests compare SORTED rows (assert_batches_sorted_eq), so "expected" is a multiset here ("sorted": True)
+smj_full = [
+    {"name": "join_full_one", "ref": SM + "2094-2121", "join_type": "Full", "sorted": True, "left": T3([1, 2, 3], [4, 5, 7], [7, 8, 9]), "right": T3([10, 20, 30], [4, 5, 6], [70, 80, 90]), "on": [[1, 1]],
+     "expected": [[N, N, N, 30, 6, 90], [1, 4, 7, 10, 4, 70], [2, 5, 8, 20, 5, 80], [3, 7, 9, N, N, N]]},
+    {"name": "join_full_multiple_batches", "ref": SM + "2451-2497", "join_type": "Full", "sorted": True, "left_batches": [3, 4], "right_batches": [3, 2],
+     "left": T3([0, 1, 2, 3, 4, 5, 6], [3, 4, 5, 6, 6, 7, 9], [4, 5, 6, 7, 8, 9, 9]), "right": T3([0, 10, 20, 30, 40], [2, 4, 6, 6, 8], [50, 60, 70, 80, 90]), "on": [[1, 1]],
+     "expected": [[N, N, N, 0, 2, 50], [N, N, N, 40, 8, 90], [0, 3, 4, N, N, N], [1, 4, 5, 10, 4, 60], [2, 5, 6, N, N, N], [3, 6, 7, 20, 6, 70], [3, 6, 7, 30, 6, 80], [4, 6, 8, 20, 6, 70],
+                  [4, 6, 8, 30, 6, 80], [5, 7, 9, N, N, N], [6, 9, 9, N, N, N]]},
+]
 sort = [
     {"name": "test_in_mem_sort", "ref": S + "1022-1049 (test::scan_partitioned(4): 4 partitions of make_partition(100), column i = 0..100)", "type": "int32",
      "partitions": [list(range(100))] * 4, "descending": False, "nulls_first": True, "expected_rows": 400, "expected_batches": 1},
@@ -185,6 +194,6 @@ repartition = [
     {"name": "many_to_many_round_robin", "ref": R + "989-1007", "inputs": [50, 50, 50], "scheme": "RoundRobinBatch", "n": 5, "expected_batches": [30, 30, 30, 30, 30]},
     {"name": "many_to_many_hash_partition", "ref": R + "1010-1033", "inputs": [50, 50, 50], "scheme": "Hash", "n": 8, "expected_total_rows": 8 * 50 * 3},
 ]
-json.dump({"binary": cases, "in_list": in_list, "nested_loop_join": nlj, "sort_merge_join": smj, "sort": sort, "repartition": {"batch": {"ref": R + "1440-1447 create_batch", "type": "uint32", "column": "c0", "values": [1, 2, 3, 4, 5, 6, 7, 8]}, "cases": repartition}},
+json.dump({"binary": cases, "in_list": in_list, "nested_loop_join": nlj, "sort_merge_join": smj, "sort_merge_join_full": smj_full, "sort": sort, "repartition": {"batch": {"ref": R + "1440-1447 create_batch", "type": "uint32", "column": "c0", "values": [1, 2, 3, 4, 5, 6, 7, 8]}, "cases": repartition}},
           open(__file__.rsplit("/", 1)[0] + "/unit_vectors.json", "w"), indent=1)
 print(len(cases), "binary cases,", len(in_list), "in_list cases")

@@ -8,6 +8,8 @@ import pytest
 from helpers import load_golden
 
 SMJ = load_golden("unit_vectors.json")["sort_merge_join"]
+SMJ_FULL = load_golden("unit_vectors.json")["sort_merge_join_full"]          # the reference compares sorted rows for JoinType::Full
+skey = lambda r: [(-1, 0) if v is None else (0, v) for v in r]
 
 
 def cols(vals):
@@ -25,6 +27,13 @@ def test_oracle_sort_merge_join_reference_cases(case):
     got = po.sort_merge_join(cols(case["left"]), cols(case["right"]), [tuple(x) for x in case["on"]], case["join_type"], case.get("descending", False), case.get("nulls_first", True),
                              case.get("null_equals_null", False))
     assert rows(got) == case["expected"]
+
+
+@pytest.mark.parametrize("case", SMJ_FULL, ids=[c["name"] for c in SMJ_FULL])
+def test_oracle_sort_merge_join_full_reference_cases(case):
+    from oracle import pyoracle as po
+    got = po.sort_merge_join(cols(case["left"]), cols(case["right"]), [tuple(x) for x in case["on"]], "Full")
+    assert sorted(rows(got), key=skey) == sorted(case["expected"], key=skey)
 
 
 def device_join(ctx, left_batches, right_batches, on, jt, nen=False, lnames=("a1", "b1", "c1"), rnames=("a2", "b2", "c2")):
@@ -56,7 +65,16 @@ def test_device_sort_merge_join_reference_cases(ctx, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("jt", ["Inner", "Left", "Right", "LeftSemi", "LeftAnti"])
+@pytest.mark.parametrize("case", SMJ_FULL, ids=[c["name"] for c in SMJ_FULL])
+def test_device_sort_merge_join_full_reference_cases(ctx, case):
+    l, r = cols(case["left"]), cols(case["right"])
+    lb = split(l, case["left_batches"]) if "left_batches" in case else [l]
+    rb = split(r, case["right_batches"]) if "right_batches" in case else [r]
+    assert sorted(device_join(ctx, lb, rb, case["on"], "Full"), key=skey) == sorted(case["expected"], key=skey)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("jt", ["Inner", "Left", "Right", "LeftSemi", "LeftAnti", "RightAnti", "Full"])
 @pytest.mark.parametrize("seed,nl,nr,nen", [(1, 300, 200, False), (2, 50, 400, True), (3, 1, 1, False), (4, 257, 0, False)])
 def test_device_sort_merge_join_equals_oracle_on_sorted_inputs(ctx, jt, seed, nl, nr, nen):
     from oracle import pyoracle as po
@@ -68,14 +86,17 @@ def test_device_sort_merge_join_equals_oracle_on_sorted_inputs(ctx, jt, seed, nl
         return [pa.array(np.arange(n, dtype=np.int32)), pa.array(k, mask=mask), pa.array(rng.integers(0, 1000, n).astype(np.int32))]
     l, r = side(nl), side(nr)
     want = rows(po.sort_merge_join(l, r, [(1, 1)], jt, False, False, nen))
-    assert device_join(ctx, [l], [r], [(1, 1)], jt, nen) == want
+    got = device_join(ctx, [l], [r], [(1, 1)], jt, nen)
+    if jt == "Full":                     # multiset contract (see the oracle's note): sorted rows
+        got, want = sorted(got, key=skey), sorted(want, key=skey)
+    assert got == want
 
 
 @pytest.mark.gpu
 def test_device_sort_merge_join_refuses_what_it_does_not_cover(ctx):
     import dfgpu
     l = cols([[1], [1], [1]])
-    for jt in ("Full", "RightSemi", "RightAnti"):
+    for jt in ("RightSemi",):
         with pytest.raises(dfgpu.DfgpuError) as e:
             device_join(ctx, [l], [l], [(1, 1)], jt)
         assert e.value.kind == "NotImplemented"
