@@ -312,6 +312,7 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "agg_partitioned") ctx->agg_partitioned = value != 0;
     else if (k == "agg_partitioned_force") ctx->agg_partitioned_force = value != 0;
     else if (k == "agg_partitioned_min_rows") ctx->agg_partitioned_min_rows = value;
+    else if (k == "agg_pack_estimate_min_rows") ctx->agg_pack_estimate_min_rows = value;
     else if (k == "join_partitioned") ctx->join_partitioned = value != 0;
     else if (k == "join_partitioned_min_build") ctx->join_partitioned_min_build = value;
     else if (k == "join_partitioned_min_probe") ctx->join_partitioned_min_probe = value;
@@ -348,6 +349,7 @@ dfgpu_status dfgpu_ctx_get_option(dfgpu_ctx* ctx, const char* key, int64_t* out)
     else if (k == "agg_partitioned") *out = ctx->agg_partitioned;
     else if (k == "agg_partitioned_force") *out = ctx->agg_partitioned_force;
     else if (k == "agg_partitioned_min_rows") *out = ctx->agg_partitioned_min_rows;
+    else if (k == "agg_pack_estimate_min_rows") *out = ctx->agg_pack_estimate_min_rows;
     else if (k == "join_partitioned") *out = ctx->join_partitioned;
     else if (k == "join_partitioned_min_build") *out = ctx->join_partitioned_min_build;
     else if (k == "join_partitioned_min_probe") *out = ctx->join_partitioned_min_probe;

@@ -51,6 +51,7 @@ struct dfgpu_ctx {
   int64_t fused_aggregate_min_rows = 1 << 20;
   bool sort_packed_keys = true;     // large sorts over fixed-width keys: range-packed u64 keys + stable one-pass partition per digit (sort.hip)
   bool agg_partitioned = true, agg_partitioned_force = false; int64_t agg_partitioned_min_rows = 1 << 22;      // partitioned pre-aggregation (pagg.hip)
+  int64_t agg_pack_estimate_min_rows = 1 << 22;   // packed group keys: batches of at least this many rows take their value ranges from a sample (checked row by row while packing)
   bool pa_last_distinct = false;    // the last dfgpu_agg_preaggregate call emitted every key once
   const void* pa_sample_key = nullptr; const void* pa_sample_mask = nullptr; int64_t pa_sample_n = 0; uint64_t pa_sample[3] = {0, 0, 0};   // sample of a verdict-only dfgpu_agg_preaggregate call
   // 2..4 key columns packed into one u64 by that verdict-only call (kept for the call that follows on the same columns): key = sum((v - min + nullable) * stride), 0 in a nullable column's digit = NULL

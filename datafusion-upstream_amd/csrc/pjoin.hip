@@ -39,6 +39,7 @@ constexpr int PJ_MAX_SBITS = 15;                      // 32 K slots x 4 B = 128 
 constexpr int PJ_NT = 1024, PJ_R = 8, PJ_TILE = PJ_NT * PJ_R, PJ_G = 16, PJ_NW = PJ_NT / WAVE;
 constexpr uint32_t PJ_MAX_P = 2048;                   // two partitions per thread in the offset loops
 constexpr int PJ_CHS = 14;                            // restore chunk = 2^14 probe rows = two tiles
+static_assert(PJ_TILE == 1 << 13 && PJ_CHS >= 13, "k_pj_join turns a chunk into its first tile by a shift");
 constexpr int PJ_U = 4;                               // probe records per lane in flight
 constexpr uint32_t PJ_DUP_MAX_ROWS = 8192;            // repeated keys: a partition's records, slot counters and CSR cursors share 96 KB of LDS
 constexpr uint32_t PJ_MAX_GROUP = 256;                // rows of one key a single thread puts in order

@@ -319,3 +319,25 @@ def test_key_ranges_too_wide_to_pack_decline(ctx):
         with pytest.raises(dfgpu.capi.DfgpuError) as e:
             run_device_multi(ctx, [k0, k1], [("COUNT", None)])
     assert "multiply beyond" in str(e.value)
+
+
+@pytest.mark.parametrize("outlier", [False, True], ids=["ranges-hold", "outlier-forces-exact-ranges"])
+def test_packed_key_ranges_from_a_sample(ctx, outlier):
+    """large batches take the key columns' value ranges from every step-th row (widened) and check every row while packing; a value outside them makes the
+    pack run again with exact ranges (sync:pa_pack_outside in the profile).  Either way groups, order and sums equal the oracle's."""
+    n = 200000
+    a = RNG.integers(1000, 6000, n).astype(np.int64); b = RNG.integers(0, 40, n).astype(np.int32)
+    if outlier:
+        a[12345] = 10**9; b[777] = -1000                  # odd rows (the sample takes every second row), far outside the widened estimate, exact ranges still pack (2^30 x 2^10)
+    v = pa.array(RNG.integers(-1000, 1000, n).astype(np.int64))
+    aggs = [("SUM", v), ("COUNT", None)]
+    saved = ctx.get_option("agg_pack_estimate_min_rows"); ctx.set_option("agg_pack_estimate_min_rows", 1)
+    try:
+        with forced(ctx) as f:
+            gk, got, _ = run_device_multi(ctx, [pa.array(a), pa.array(b)], aggs)
+            ran = f.kernels()
+    finally:
+        ctx.set_option("agg_pack_estimate_min_rows", saved)
+    assert ("sync:pa_pack_outside" in ran) == outlier, ran
+    wk, want = run_oracle_multi([pa.array(a), pa.array(b)], aggs)
+    compare_multi(gk, got, wk, want)
