@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(PJ_NT) k_pj_transpose(const uint32_t* hstart, 
 // restore probe order: one workgroup per chunk of 2^PJ_CHS probe rows.  Hit i of the chunk is found in its partition's list by a search over the prefix of
 // the 2048 run lengths; every probe row has at most one hit, so its rank among the chunk's hits = set bits below it in a bitmap of the chunk's rows.  The
 // hits leave through an LDS window of WIN ranks (a chunk usually fits one window: its hits then stay in registers between the two passes).
-constexpr int PJ_K6 = 6, PJ_WIN = PJ_NT * PJ_K6;
+constexpr int PJ_K6 = 6, PJ_WIN = PJ_NT * PJ_K6;      // tried: 512 threads x 8 hits (32 KB window, three workgroups per CU instead of two): 0.393 against 0.396 ms -- not the limiter
 template <bool GROUPS>
 __global__ void __launch_bounds__(PJ_NT) k_pj_restore(const uint64_t* hits, const uint32_t* pstart, const uint32_t* hT, const uint16_t* lT, int P, int NC, const uint32_t* coff,
                                                      uint32_t* out_probe, uint64_t* out_build, uint32_t* out_ref) {
