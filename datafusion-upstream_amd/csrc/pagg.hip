@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(PA_NT) k_pa_items(const uint32_t* pstart, uint
 }
 // two-level partition: fine partition = (low hash bits -> P2) * P1 + (high hash bits -> P1)
 __device__ inline uint32_t pa_fine_pid(uint64_t k, uint32_t P1, uint32_t P2) { uint64_t h = mix64(k); return (uint32_t)(((h & 0xFFFFFFFFull) * (uint64_t)P2) >> 32) * P1 + rp_pid(h, P1); }
+template <bool I128>          // I128: the plan holds Decimal128 cell pairs / strided value columns; the plain instantiation is the round-2 kernel (the extra branches cost it 6 %)
 __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, const uint32_t* prow, PaPlan plan_arg, const uint32_t* pstart, const uint32_t* item_start, uint32_t P, int cbits, uint32_t slice,
                                                       uint64_t* orec /* records of `rs` words: key, count, accumulator cells */, int rs, uint32_t* ofirst, unsigned long long* cursor /*[0] rows written, [2] tables flushed before their partition ended*/,
                                                       uint32_t P1, uint32_t P2, uint32_t* misplaced /* two-level partition (P1 != 0): set when a row sits in a partition its key does not hash to */) {
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
   const int na = plan_arg.n_acc;
   { const uint32_t i = q0 + threadIdx.x, ic = i < q1 ? i : q1 - 1; kn = pkey[ic]; rn = prow[ic];
 #pragma unroll
-    for (int a = 0; a < PA_MAX_AGGS; a++) vn[a] = a < na ? plan_arg.val[a][(size_t)ic * plan_arg.vstride[a]] : 0; }
+    for (int a = 0; a < PA_MAX_AGGS; a++) vn[a] = a < na ? plan_arg.val[a][I128 ? (size_t)ic * plan_arg.vstride[a] : (size_t)ic] : 0; }
   for (uint32_t i0 = q0; i0 < q1; i0 += PA_NT) {
     if (nfilled + PA_NT > C - C / 8) { __syncthreads(); flush(); reset(); if (threadIdx.x == 0) atomicAdd(cursor + 2, 1ull); __syncthreads(); }      // nfilled is only written between barriers: uniform
     const uint32_t i = i0 + threadIdx.x; const bool on = i < q1;
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
     for (int a = 0; a < PA_MAX_AGGS; a++) v[a] = vn[a];
     { const uint32_t i2 = i + PA_NT, ic = i2 < q1 ? i2 : q1 - 1; kn = pkey[ic]; rn = prow[ic];
 #pragma unroll
-      for (int a = 0; a < PA_MAX_AGGS; a++) vn[a] = a < na ? plan_arg.val[a][(size_t)ic * plan_arg.vstride[a]] : 0; }
+      for (int a = 0; a < PA_MAX_AGGS; a++) vn[a] = a < na ? plan_arg.val[a][I128 ? (size_t)ic * plan_arg.vstride[a] : (size_t)ic] : 0; }
     // Skewed keys: when at least 16 lanes of a wave carry the key of its first active lane, those lanes are combined in registers (shuffles) and the leader
     // alone touches the table: one LDS atomic per state instead of one per row on a slot every wave of the workgroup is hammering.
     uint32_t cntv = 1; uint32_t rowv = row; bool mine = on;
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
       const uint32_t k0lo = (uint32_t)__shfl((int)(uint32_t)k, lead, 64), k0hi = (uint32_t)__shfl((int)(uint32_t)(k >> 32), lead, 64);
       const bool member = on && (uint32_t)k == k0lo && (uint32_t)(k >> 32) == k0hi;
       const uint64_t mem = ballot64(member);
-      if (__popcll(mem) >= 16 && !plan_arg.has_i128) {
+      if (__popcll(mem) >= 16 && !I128) {
         uint32_t r = member ? row : 0xFFFFFFFFu;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)r, d, 64); r = o < r ? o : r; }
@@ -196,7 +197,8 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
 #pragma unroll
       for (int a = 0; a < PA_MAX_AGGS; a++) if (a < na) {
         const int op = plan_arg.op[a];
-        if (op == PA_SUM_I128_LO && plan_arg.op[a + 1 < PA_MAX_AGGS ? a + 1 : a] == PA_SUM_I128_SX) {            // value = sign-extended 64 bits
+        if (!I128) pa_apply(op, &acc[(size_t)a * C1 + s], v[a]);
+        else if (op == PA_SUM_I128_LO && plan_arg.op[a + 1 < PA_MAX_AGGS ? a + 1 : a] == PA_SUM_I128_SX) {            // value = sign-extended 64 bits
           const int ah = a + 1 < PA_MAX_AGGS ? a + 1 : a;
           const unsigned long long lo = v[a], old = atomicAdd(&acc[(size_t)a * C1 + s], lo);
           const unsigned long long hi = (unsigned long long)((long long)lo >> 63) + (unsigned long long)(old + lo < old);
@@ -521,14 +523,17 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     int64_t slice = (n / P + 1) * 3 / 2; if (slice < 65536) slice = 65536;          // uniform keys never split (a partition is within a percent of the average) if (slice > 0x7FFFFFFF) slice = 0x7FFFFFFF;
     const int64_t n_slices = max_len ? (max_len + slice - 1) / slice : 1;
     { KernelTimer kt_(ctx, "pa_aggregate");
-      HIP_CHECK(hipFuncSetAttribute((const void*)k_pa_aggregate, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));      // per device: set on every call, no process-wide flag
+      HIP_CHECK(hipFuncSetAttribute(plan.has_i128 ? (const void*)k_pa_aggregate<true> : (const void*)k_pa_aggregate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));      // per device: set on every call, no process-wide flag
       BufferPtr items; unsigned grid = (unsigned)P;
       if (n_slices > 1) {            // sum over partitions of ceil(len / slice) <= P + n / slice
         items = alloc_buffer(ctx, (size_t)(P + 1) * 4);
         hipLaunchKernelGGL(k_pa_items, dim3(1), dim3(PA_NT), 0, ctx->stream, (const uint32_t*)r.starts->ptr, (uint32_t)P, (uint32_t)slice, (uint32_t*)items->ptr);
         grid = (unsigned)(P + n / slice + 1);
       }
-      hipLaunchKernelGGL(k_pa_aggregate, dim3(grid), dim3(PA_NT), (((size_t)1 << cbits) + 1) * cell_bytes, ctx->stream, (const uint64_t*)pkey->ptr, (const uint32_t*)prow->ptr, plan, (const uint32_t*)r.starts->ptr,
+      if (plan.has_i128) hipLaunchKernelGGL(k_pa_aggregate<true>, dim3(grid), dim3(PA_NT), (((size_t)1 << cbits) + 1) * cell_bytes, ctx->stream, (const uint64_t*)pkey->ptr, (const uint32_t*)prow->ptr, plan, (const uint32_t*)r.starts->ptr,
+                         items ? (const uint32_t*)items->ptr : nullptr, (uint32_t)P, cbits, (uint32_t)slice, (uint64_t*)orec->ptr, rs, (uint32_t*)ofirst->ptr, (unsigned long long*)(ctx->d_scratch64 + 12),
+                         two_level ? (uint32_t)P1 : 0u, (uint32_t)P2, (uint32_t*)(ctx->d_scratch64 + 11));
+      else hipLaunchKernelGGL(k_pa_aggregate<false>, dim3(grid), dim3(PA_NT), (((size_t)1 << cbits) + 1) * cell_bytes, ctx->stream, (const uint64_t*)pkey->ptr, (const uint32_t*)prow->ptr, plan, (const uint32_t*)r.starts->ptr,
                          items ? (const uint32_t*)items->ptr : nullptr, (uint32_t)P, cbits, (uint32_t)slice, (uint64_t*)orec->ptr, rs, (uint32_t*)ofirst->ptr, (unsigned long long*)(ctx->d_scratch64 + 12),
                          two_level ? (uint32_t)P1 : 0u, (uint32_t)P2, (uint32_t*)(ctx->d_scratch64 + 11));
       KERNEL_CHECK(); }

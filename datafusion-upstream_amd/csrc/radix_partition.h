@@ -91,7 +91,7 @@ template <int NT> static inline size_t rp_scatter_lds(uint32_t P, bool stable) {
   return (size_t)P * 8 + (size_t)NT * RP_R * 4 + 8 + (size_t)NT * RP_R * 8 + (stable ? (size_t)(NT / WAVE) * P * 2 : 0);
 }
 
-template <int NT, bool STABLE, typename H>
+template <int NT, bool STABLE, typename H, bool LO16 = false>          // LO16: some column is RP_LO16 (an instantiation of its own: the extra branch in the column loop cost the others 10 %)
 __global__ void __launch_bounds__(NT) k_rp_scatter(H hs, int64_t n, uint32_t P, int64_t ntiles, const uint32_t* goff, RpCols cols) {
   extern __shared__ uint32_t rp_lds[];
   constexpr int TILE = NT * RP_R, NW = NT / WAVE;
@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(NT) k_rp_scatter(H hs, int64_t n, uint32_t P, 
       // the width switch sits outside the unrolled row loop: one load shape per column, RP_R loads in flight
 #define RP_GATHER(EXPR) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) { const int64_t i = i0 + (int64_t)q * QS; stage[spos[q]] = (uint64_t)(EXPR); } }
       if (col.kind == RP_HASHKEY) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) stage[spos[q]] = hk[q]; }
-      else if (col.kind == RP_LO16) RP_GATHER(((const uint64_t*)col.src)[2 * i])
+      else if (LO16 && col.kind == RP_LO16) RP_GATHER(((const uint64_t*)col.src)[2 * i])
       else if (col.kind == RP_KEY64) switch (col.type) {            // widened exactly as key_at() does
         case DFGPU_INT8: RP_GATHER((int64_t)((const int8_t*)col.src)[i]) break;
         case DFGPU_INT16: RP_GATHER((int64_t)((const int16_t*)col.src)[i]) break;
@@ -253,7 +253,6 @@ __global__ void __launch_bounds__(NT) k_rp_scatter_direct(H hs, int64_t n, uint3
     const RpCol col = scol[c];
 #define RP_MOVE(DT, EXPR) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) { const int64_t i = i0 + (int64_t)q * NT; ((DT*)col.dst)[pos[q]] = (DT)(EXPR); } }
     if (col.kind == RP_HASHKEY) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) ((uint64_t*)col.dst)[pos[q]] = hk[q]; }
-    else if (col.kind == RP_LO16) RP_MOVE(uint64_t, ((const uint64_t*)col.src)[2 * i])
     else if (col.kind == RP_KEY64) switch (col.type) {
       case DFGPU_INT8: RP_MOVE(uint64_t, (int64_t)((const int8_t*)col.src)[i]) break;
       case DFGPU_INT16: RP_MOVE(uint64_t, (int64_t)((const int16_t*)col.src)[i]) break;
@@ -297,8 +296,8 @@ static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const 
   // the LDS-free scatter: always for <= 16 partitions; up to 256 when a row is one column (a sort pass: 3.0 against 3.2 ms per 100 M rows) or holds a 16-byte column (the staged
   // scatter moves those as two halves: 600 M rows x 44 B into 64 / 128 / 256: 16.9 / 18.0 / 22.5 ms against 22.8 / 23.9 / 25.9); rows of several narrow columns (the aggregation's
   // (key, row, value): 2.7 against 1.4 ms) stay with the staged one
-  bool wide16 = false; for (int c = 0; c < cols.n; c++) wide16 |= cols.c[c].width == 16;
-  const bool direct = stable && !cols.pack12_dst && (P <= 16 || (P <= 256 && !wide_rows && (cols.n <= 1 || wide16)));
+  bool wide16 = false, lo16 = false; for (int c = 0; c < cols.n; c++) { wide16 |= cols.c[c].width == 16; lo16 |= cols.c[c].kind == RP_LO16; }
+  const bool direct = stable && !cols.pack12_dst && !lo16 && (P <= 16 || (P <= 256 && !wide_rows && (cols.n <= 1 || wide16)));
   const bool small_wg = stable && P > 16 && !wide_rows && !direct;    // wide_rows: several columns move per row (the aggregation's second level: 20 B) -- there the 4096-row tile's longer runs win (1.65 -> 1.44 ms),
                                                            // while the sort's single 8-byte column is faster with more workgroups per CU (3.2 against 3.7 ms)                  // stable with many partitions: 256-thread workgroups (the count table is 64 P bytes) keep several on a CU;
   const int nt = small_wg ? 256 : big ? 1024 : 512, tile = nt * RP_R;      // few partitions want the longer runs of a 4096-row tile
@@ -319,8 +318,10 @@ static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const 
   KERNEL_CHECK();
   if (n) { KernelTimer kt_(ctx, t_scatter);
     const unsigned grid = (unsigned)(((ntiles + 7) / 8) * 8);
-#define RP_LAUNCH(NT_, ST_) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_scatter<NT_, ST_, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); \
-      hipLaunchKernelGGL((k_rp_scatter<NT_, ST_, H>), dim3(grid), dim3(NT_), rp_scatter_lds<NT_>(P, ST_), ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols); }
+#define RP_LAUNCH(NT_, ST_) { if (lo16) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_scatter<NT_, ST_, H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); \
+      hipLaunchKernelGGL((k_rp_scatter<NT_, ST_, H, true>), dim3(grid), dim3(NT_), rp_scatter_lds<NT_>(P, ST_), ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols); } else { \
+      HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_scatter<NT_, ST_, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)); \
+      hipLaunchKernelGGL((k_rp_scatter<NT_, ST_, H>), dim3(grid), dim3(NT_), rp_scatter_lds<NT_>(P, ST_), ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols); } }
     if (direct && P <= 16) hipLaunchKernelGGL((k_rp_scatter_direct<512, 16, H>), dim3(grid), dim3(512), 0, ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols);
     else if (direct) hipLaunchKernelGGL((k_rp_scatter_direct<512, 256, H>), dim3(grid), dim3(512), 0, ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols);
     else if (small_wg) RP_LAUNCH(256, true) else if (stable) RP_LAUNCH(512, true) else if (big) RP_LAUNCH(1024, false) else RP_LAUNCH(512, false)
