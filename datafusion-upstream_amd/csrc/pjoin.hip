@@ -443,11 +443,30 @@ __global__ void __launch_bounds__(PJ_NT) k_pj_restore(const uint64_t* hits, cons
 __global__ void __launch_bounds__(BLOCK) k_pj_group_counts(const uint32_t* ref, int64_t m, const uint32_t* grp_cnt, uint32_t* cnt) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < m) cnt[i] = grp_cnt[ref[i]];
 }
+// Load-balanced: a wave owns 64 consecutive matches; its pairs [offsets[first], offsets[last] + cnt[last]) are consecutive in the output, so the lanes walk that range 64 pairs
+// at a time (consecutive lanes -> consecutive output slots) and find their match by a 6-step search over the wave's 64 offsets held in registers (shuffles).  One thread per match
+// with a loop over its group wrote `count`-strided runs: 0.8 ms for 30 M pairs of 5-row groups against 0.25 ms.
 __global__ void __launch_bounds__(BLOCK) k_pj_expand(const uint32_t* rows, const uint32_t* ref, const uint64_t* offsets, int64_t m, const uint32_t* grp_start, const uint32_t* grp_cnt, const uint32_t* csr_rows,
                                                     uint64_t* out_build, uint32_t* out_probe) {
-  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i >= m) return;
-  const uint32_t g = ref[i], c = grp_cnt[g], st = grp_start[g], j = rows[i]; const uint64_t o = offsets[i];
-  for (uint32_t k = 0; k < c; k++) { out_build[o + k] = csr_rows[st + k]; out_probe[o + k] = j; }
+  const int lane = lane_id(); const int64_t w0 = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) - lane;      // first match of this wave
+  if (w0 >= m) return;
+  const int64_t i = w0 + lane; const bool on = i < m;
+  const uint32_t g = on ? ref[i] : 0u, c = on ? grp_cnt[g] : 0u, st = on ? grp_start[g] : 0u, j = on ? rows[i] : 0u;
+  const uint64_t o = on ? offsets[i] : 0ull;
+  const uint64_t base = __shfl((long long)o, 0, 64);                                   // offsets are non-decreasing: lane 0 holds the wave's first pair
+  const uint32_t rel = (uint32_t)(o - base);                                            // a wave's pairs fit 32 bits (64 matches x group size)
+  const int last = 63 - __clzll((long long)ballot64(on));
+  const uint32_t total = (uint32_t)__shfl((int)(rel + c), last, 64);
+  for (uint32_t k0 = 0; k0 < total; k0 += WAVE) {
+    const uint32_t k = k0 + lane;
+    // the match whose pair range holds k: the last lane with rel <= k (lanes past `last` hold rel = 0 and c = 0: clamp the search to [0, last])
+    int lo = 0, hi = last;
+#pragma unroll
+    for (int step = 0; step < 6; step++) { const int mid = (lo + hi + 1) >> 1; const uint32_t r = (uint32_t)__shfl((int)rel, mid, 64); if (r <= k) lo = mid; else hi = mid - 1; }
+    // groups of zero rows cannot occur (a match has >= 1 row), so rel is strictly increasing over the active lanes and lo is exact
+    const uint32_t r0 = (uint32_t)__shfl((int)rel, lo, 64), s0 = (uint32_t)__shfl((int)st, lo, 64), p0 = (uint32_t)__shfl((int)j, lo, 64);
+    if (k < total) { out_build[base + k] = csr_rows[s0 + (k - r0)]; out_probe[base + k] = p0; }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- host
