@@ -214,12 +214,29 @@ __global__ void __launch_bounds__(BLOCK) k_probe_lookup(KeySet bks, KeySet pks, 
   else { out_slot[i] = (uint32_t)s; out_cnt[i] = found ? slot_count[s] : 0; }
 }
 // ---- probe pass 3 (repeated build keys): every matched probe row emits its key group in build input order
+// Load-balanced (the same walk as k_pj_expand, pjoin.hip): a wave owns 64 consecutive matches, whose pairs are consecutive in the output; the lanes take 64 pairs at a time and find
+// the match a pair belongs to by a 6-step search over the wave's offsets (shuffles).  A thread per match looping over its run writes count-strided and a hot key serialises a wave.
 __global__ void __launch_bounds__(BLOCK) k_probe_expand(const uint32_t* rows, const uint32_t* slot_of, const uint32_t* cnt, const uint64_t* offsets, int64_t m,
                                                         const uint32_t* slot_start, const uint32_t* csr_rows, uint64_t* out_build, uint32_t* out_probe) {
-  int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= m) return;
-  uint32_t c = cnt[i], st = slot_start[slot_of[i]], j = rows[i]; uint64_t o = offsets[i];
-  for (uint32_t k = 0; k < c; k++) { out_build[o + k] = csr_rows ? csr_rows[st + k] : st + k; out_probe[o + k] = j; }      // csr_rows == null: the run is contiguous (rank_runs)
+  const int lane = lane_id(); const int64_t w0 = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) - lane;
+  if (w0 >= m) return;
+  const int64_t i = w0 + lane; const bool on = i < m;
+  const uint32_t c = on ? cnt[i] : 0u, st = on ? slot_start[slot_of[i]] : 0u, j = on ? rows[i] : 0u;
+  const uint64_t o = on ? offsets[i] : 0ull;
+  const uint64_t base = (uint64_t)__shfl((long long)o, 0, 64);
+  const uint64_t rel = o - base;
+  const int last = 63 - __clzll((long long)ballot64(on));
+  const uint64_t total = (uint64_t)__shfl((long long)(rel + c), last, 64);
+  for (uint64_t k0 = 0; k0 < total; k0 += WAVE) {
+    const uint64_t k = k0 + lane;
+    // the last lane in [0, last] with rel <= k and a non-empty run: runs of zero pairs (cnt 0 never reaches here, but keep the search right) share rel with their successor, and
+    // "last lane with rel <= k" then lands on the successor, which is the one that owns k
+    int lo = 0, hi = last;
+#pragma unroll
+    for (int step = 0; step < 6; step++) { const int mid = (lo + hi + 1) >> 1; const uint64_t r = (uint64_t)__shfl((long long)rel, mid, 64); if (r <= k) lo = mid; else hi = mid - 1; }
+    const uint64_t r0 = (uint64_t)__shfl((long long)rel, lo, 64); const uint32_t s0 = (uint32_t)__shfl((int)st, lo, 64), p0 = (uint32_t)__shfl((int)j, lo, 64);
+    if (k < total) { const uint32_t at = s0 + (uint32_t)(k - r0); out_build[base + k] = csr_rows ? csr_rows[at] : at; out_probe[base + k] = p0; }      // csr_rows == null: the run is contiguous (rank_runs)
+  }
 }
 // ---- membership bitmap of the build keys
 template <typename T>
