@@ -102,7 +102,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sf", type=float, default=100.0, help="TPC-H scale factor of the whole job")
-    ap.add_argument("--cpu-sf", type=float, default=10.0, help="scale factor of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sf", type=float, default=30.0, help="scale factor of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -456,7 +456,7 @@ def main():
         n_in = tpch.total_input_rows(host)
         seg, times = tpch.SEGMENTS.index(tpch.Q3_SEGMENT), []
         po.tpch_q3(host, seg, tpch.Q3_DATE, cores, 8192)                  # warm-up (page faults)
-        for _ in range(3):
+        for _ in range(5):
             t1 = time.perf_counter()
             res = po.tpch_q3(host, seg, tpch.Q3_DATE, cores, 8192)
             times.append(time.perf_counter() - t1)
@@ -467,7 +467,7 @@ def main():
             model = "unknown"
         cpu_baseline = {"value": round(n_in / med, 1), "unit": "rows/s", "cores": cores, "cpu_model": model, "kind": "port",
                         "sample": f"oracle/dfo_tpch.c restatement of DataFusion 36 CPU operators (Q3 plan, target_partitions={cores}, batch_size=8192) on synthetic SF{cpu_sf:g} "
-                                  f"({n_in} input rows, {len(res['l_orderkey'])} result rows); 1 warm-up + 3 runs, median {med:.3f}s, min {min(times):.3f}s",
+                                  f"({n_in} input rows, {len(res['l_orderkey'])} result rows); 1 warm-up + 5 runs ({sum(times):.2f}s timed), median {med:.3f}s, min {min(times):.3f}s",
                         "min_value": round(n_in / min(times), 1)}
         # a second, INDEPENDENT CPU number (not the reference, not the oracle): the same query through pyarrow's Acero engine
         try:

@@ -26,6 +26,7 @@ static void ctx_unref(dfgpu_ctx* c) {
   if (c->d_flags) (void)hipFree(c->d_flags);
   if (c->d_scratch64) (void)hipFree(c->d_scratch64);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete r; delete c;
 }

@@ -38,6 +38,7 @@ struct dfgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t copy_stream = nullptr;   // host -> device staging of the Parquet reader (created on first use): copies of the next column chunks run beside the decode kernels on `stream`
   std::string err;
   bool force_hash_collisions = false;
   bool first_seen_group_order = true;

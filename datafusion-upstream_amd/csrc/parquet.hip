@@ -170,7 +170,8 @@ struct dfgpu_parquet {
   const uint8_t* dev = nullptr; BufferPtr dev_owned;  // the file image in HBM (caller's, or staged by open_file)
   std::vector<Leaf> leaves; std::vector<RowGroup> rgs; int64_t num_rows = 0; std::string created_by;
   bool utf8_dictionary = true;
-  ~dfgpu_parquet() { if (map) munmap(map, map_len); }
+  bool registered = false;                            // open_file without device staging: the mapping is page-locked, so column chunks cross PCIe by DMA from where they lie
+  ~dfgpu_parquet() { if (registered) (void)hipHostUnregister(map); if (map) munmap(map, map_len); }
 };
 
 namespace dfgpu {
@@ -244,7 +245,7 @@ static void parse_footer(dfgpu_parquet* f) {
 }
 
 // ================================================================================ device side
-constexpr int PQ_NT = 256, PQ_TILE = 2048, PQ_MAXR = 256, PQ_WIN = 8192;
+constexpr int PQ_NT = 256, PQ_TILE = 2048, PQ_MAXR = 256;
 enum { MODE_FIXED = 0, MODE_KEYS = 1, MODE_STRING = 2 };
 enum { CONV_COPY4 = 0, CONV_COPY8 = 1, CONV_4TO1 = 2, CONV_4TO2 = 3, CONV_I32_DEC = 4, CONV_I64_DEC = 5, CONV_FLBA_DEC = 6, CONV_BOOL = 7 };
 
@@ -253,10 +254,12 @@ struct PqPage {
   int64_t row_start;
   uint32_t size; int32_t num_values; int32_t dict_enc; int32_t lvl_mode /*0 none, 1 u32-length prefixed (v1), 2 lvl_len bytes (v2)*/; int32_t lvl_len; int32_t decode_levels;
   int32_t dict_base, dict_count;
+  uint32_t str_base;                                  // PLAIN byte arrays: first slot of this page in PqCol::str_pos, its index in PqCol::str_cnt is the page's own
 };
 struct PqCol {
   int32_t mode, conv, wp, wo;
   void* out; uint8_t* vbytes; uint32_t* slen; uint64_t* ssrc; const int32_t* dict_offsets; const uint8_t* dict_chars;
+  const uint32_t* str_pos; const uint32_t* str_cnt;   // PLAIN byte arrays: where each value's bytes start in its page, values found per page (k_pq_str_walk)
 };
 
 __device__ inline uint32_t ld32u(const uint8_t* p) {
@@ -347,8 +350,7 @@ __device__ inline bool rle_fill(RleState& s, RunTable& t, uint32_t want, uint32_
 __global__ void __launch_bounds__(PQ_NT) k_pq_decode(const PqPage* __restrict__ pages, PqCol col, uint32_t* flags) {
   __shared__ RleState lv, ix; __shared__ RunTable rt;
   __shared__ uint32_t vals[PQ_TILE]; __shared__ uint16_t pos16[PQ_TILE];
-  __shared__ uint32_t str_off[PQ_TILE], str_len[PQ_TILE];
-  __shared__ uint8_t win[PQ_WIN]; __shared__ uint32_t wstate[4];     // walk cursor, strings found, bad
+  __shared__ uint32_t wstate[4];                        // [0] offset of the values in the page, [2] bad
   __shared__ uint32_t scan_lds[4]; __shared__ const uint8_t* s_vptr;
   const PqPage pg = pages[blockIdx.x];
   const int tid = threadIdx.x;
@@ -382,27 +384,8 @@ __global__ void __launch_bounds__(PQ_NT) k_pq_decode(const PqPage* __restrict__ 
     if (pg.dict_enc) {
       if (nn && !rle_fill(ix, rt, nn, vals)) { bad = true; break; }
     } else if (col.mode == MODE_STRING) {
-      // PLAIN byte arrays: u32 length + bytes, back to back.  One lane walks the headers out of an LDS window of the stream.
-      if (tid == 0) wstate[1] = 0;
-      __syncthreads();
-      while (wstate[1] < nn) {
-        uint32_t wb = wstate[0], wl = min((uint32_t)PQ_WIN, pg.size - wb);
-        for (uint32_t i = tid; i < wl; i += PQ_NT) win[i] = pg.data[wb + i];
-        __syncthreads();
-        if (tid == 0) {
-          uint32_t cur = wb, found = wstate[1];
-          while (found < nn && cur + 4 <= wb + wl) {
-            const uint8_t* h = win + (cur - wb); uint32_t L = (uint32_t)h[0] | ((uint32_t)h[1] << 8) | ((uint32_t)h[2] << 16) | ((uint32_t)h[3] << 24);
-            if ((uint64_t)cur + 4 + L > pg.size) { wstate[2] = 1; break; }
-            str_off[found] = cur + 4; str_len[found] = L; found++; cur += 4 + L;
-          }
-          if (cur == wb && found < nn) wstate[2] = 1;          // no header fits: the stream ended early
-          wstate[0] = cur; wstate[1] = found;
-        }
-        __syncthreads();
-        if (wstate[2]) break;
-      }
-      if (wstate[2]) { bad = true; break; }
+      // PLAIN byte arrays: k_pq_str_walk has found where every value starts; fewer values than the levels ask for = the stream ended early
+      if ((uint64_t)consumed + nn > col.str_cnt[blockIdx.x]) { bad = true; break; }
     } else if (col.conv == CONV_BOOL) {
       if ((uint64_t)(consumed + nn + 7) / 8 > vbytes_avail) { bad = true; break; }
     } else if ((uint64_t)(consumed + nn) * (uint32_t)col.wp > vbytes_avail) { bad = true; break; }
@@ -421,7 +404,7 @@ __global__ void __launch_bounds__(PQ_NT) k_pq_decode(const PqPage* __restrict__ 
         uint32_t L = 0; uint64_t src = 0;
         if (valid) {
           if (pg.dict_enc) { int32_t k = (int32_t)idx + pg.dict_base; int32_t o = col.dict_offsets[k]; L = (uint32_t)(col.dict_offsets[k + 1] - o); src = (uint64_t)(uintptr_t)(col.dict_chars + o); }
-          else { L = str_len[p16]; src = (uint64_t)(uintptr_t)(pg.data + str_off[p16]); }
+          else { const uint32_t at = col.str_pos[pg.str_base + consumed + p16]; L = ld32u(pg.data + at - 4); src = (uint64_t)(uintptr_t)(pg.data + at); }
         }
         col.slen[row] = L; col.ssrc[row] = src;
       }
@@ -430,6 +413,101 @@ __global__ void __launch_bounds__(PQ_NT) k_pq_decode(const PqPage* __restrict__ 
     __syncthreads();
   }
   if (bad || lv.bad || ix.bad) { if (tid == 0) atomicOr(flags, DFGPU_FLAG_OOB); }
+}
+
+// PLAIN byte arrays (u32 length + bytes, back to back) are a linked list: where value i starts is known only after value i - 1.  One lane walking a 1 MB page of short strings
+// takes ~70 000 dependent loads.  Here the page goes through LDS in windows of PQ_WIN bytes (read once, coalesced); a window is cut into one segment per lane and every lane walks
+// its own: lane 0 from the position the previous window ended on, the others from a GUESS -- the first position of the segment from which PQ_CHAIN headers in a row stay inside the
+// page (text bytes read as a length point far outside; the byte before a header reads as a small length, which is why one or three in a row are not enough).  The guesses are then
+// checked against the true path, all lanes at once: a walk stands if it started on the position its predecessor's walk ended on; a lane whose guess was wrong walks again from
+// there, and its successor looks again.  So the result never depends on a guess being right; only the time does.
+// Counts are scanned and the lanes walk once more, out of LDS, to write where each value's bytes start.
+// Tried on the way: the same scheme straight from global memory with 256 segments per 1 MB page (1.85 ms for 36 M values: every hop re-fetches its 128-byte line, the lanes' lines
+// do not fit L1) and with 1024 (3.0 ms: they do not fit L2 either).
+constexpr int PQ_WIN = 65536, PQ_SUB = PQ_WIN / PQ_NT, PQ_CHAIN = 8; constexpr uint32_t PQ_NOPOS = 0xFFFFFFFFu;
+static_assert(PQ_SUB >= 64 && PQ_SUB * PQ_NT == PQ_WIN, "one segment per lane");
+// word w of the window lives at LDS word w + w / 64: the lanes' segments are 64 words apart, which unpadded is one bank for the whole wave
+__device__ inline uint32_t pq_win_at(uint32_t w) { return w + (w >> 6); }
+// a length prefix at page offset p, read from the window (win holds the page's bytes from offset wb on, whole words, one word more than the window)
+__device__ inline bool pq_str_hdr(const uint32_t* win, uint32_t wb, uint32_t wend, uint32_t size, uint32_t p, uint32_t& next) {
+  if (p >= wend || (uint64_t)p + 4 > size) return false;             // wend: headers from here on belong to the next window
+  const uint32_t r = p - wb, w = r >> 2, lo = win[pq_win_at(w)], sh = r & 3;
+  const uint32_t L = sh ? __builtin_amdgcn_alignbyte(win[pq_win_at(w + 1)], lo, sh) : lo;
+  if ((uint64_t)p + 4 + L > size) return false;
+  next = p + 4 + L; return true;
+}
+__global__ void __launch_bounds__(PQ_NT) k_pq_str_walk(const PqPage* __restrict__ pages, uint32_t* __restrict__ str_pos, uint32_t* __restrict__ str_cnt) {
+  __shared__ __attribute__((aligned(16))) uint32_t win[PQ_WIN / 4 + PQ_WIN / 256 + 8];
+  __shared__ uint32_t s_exit[PQ_NT], s_wave[PQ_NT / WAVE], s_next; __shared__ uint8_t s_stale[PQ_NT];
+  const PqPage pg = pages[blockIdx.x]; const int t = threadIdx.x;
+  uint32_t vstart = 0; bool bad = false;
+  if (pg.lvl_mode == 1) { if (pg.size < 4) bad = true; else { const uint32_t L = ld32u(pg.data); if (L > pg.size - 4) bad = true; else vstart = 4 + L; } }
+  else if (pg.lvl_mode == 2) { if ((uint32_t)pg.lvl_len > pg.size) bad = true; else vstart = (uint32_t)pg.lvl_len; }
+  if (bad || pg.dict_enc || pg.num_values <= 0) { if (t == 0) str_cnt[blockIdx.x] = 0; return; }        // block-uniform; k_pq_decode reports a bad page itself
+  // positions below are byte offsets from `words`, the word at or below the page's first byte (a page need not start on a word): page offset + mis
+  const uint32_t* words = (const uint32_t*)((uintptr_t)pg.data & ~(uintptr_t)3); const uint32_t mis = (uint32_t)((uintptr_t)pg.data & 3);
+  const uint32_t size = pg.size + mis, want = (uint32_t)pg.num_values;
+  uint32_t cur = vstart + mis, found = 0;                                                                 // block-uniform: the true path's position, values written so far
+  while (cur < size && found < want) {
+    const uint32_t wb = cur & ~3u, wend = (uint32_t)min((uint64_t)wb + PQ_WIN, (uint64_t)size);             // window [wb, wend)
+    const uint32_t nwords = (wend - wb + 3) / 4 + 1;                                                       // one more: a header may straddle the last word (buffers are padded by 16 bytes)
+    __syncthreads();
+    for (uint32_t i = t; i < nwords; i += PQ_NT) win[pq_win_at(i)] = words[(wb >> 2) + i];
+    const uint32_t s0 = max(cur, wb + (uint32_t)t * PQ_SUB), s1 = min(wend, wb + (uint32_t)(t + 1) * PQ_SUB);
+    __syncthreads();
+    uint32_t entry = PQ_NOPOS, exitp = PQ_NOPOS, cnt = 0;                                                 // exit NOPOS: the list ends inside the segment
+    if (s0 < s1) {
+      if (t == 0) entry = cur;
+      else for (uint32_t p = s0; p < s1; p++) {
+        // the chain may leave the window (one long value does), and then goes on in global memory: accepting it for what it saw inside is not enough -- five-byte values
+        // ("A", "N", "R" with their prefixes) read one byte early as a length of 0x14100 + 4, a multiple of five, which lands on the same wrong phase 82 KB further on
+        uint32_t q = p, nx; int h = 0;
+        while (h < PQ_CHAIN && q != size) {
+          if (q < wend) { if (!pq_str_hdr(win, wb, wend, size, q, nx)) break; }
+          else { if ((uint64_t)q + 4 > size) break; const uint32_t L = ld32u((const uint8_t*)words + q); if ((uint64_t)q + 4 + L > size) break; nx = q + 4 + L; }
+          q = nx; h++;
+        }
+        if (h == PQ_CHAIN || (h > 0 && q == size)) { entry = p; break; }
+      }
+      if (entry != PQ_NOPOS) { uint32_t c = entry, nx; while (c < s1 && pq_str_hdr(win, wb, wend, size, c, nx)) { cnt++; c = nx; } if (c >= s1) exitp = c; }
+    }
+    s_exit[t] = exitp;
+    __syncthreads();
+    // Repair, all lanes at once: a lane's walk stands if it started where its predecessor's walk arrives.  One that did not walks again from there (or lets a value that jumps
+    // over its whole segment pass through) -- but only when the predecessor itself stands: starting from a wrong walk's exit would carry the error down the window, one
+    // segment per round (tried: 11 ms).  The first lane that does not stand always has a standing predecessor, so every round settles at least one more segment; isolated
+    // wrong guesses, the usual case, all settle in the first.
+    const int tl = (int)((wend - 1 - wb) / PQ_SUB);                                                       // the last segment with bytes
+    uint32_t from = t == 0 ? cur : entry != PQ_NOPOS ? entry : 0xFFFFFFFEu;                               // the arrival this lane's (entry, cnt, exit) were computed for
+    for (;;) {
+      const uint32_t arrive = t == 0 ? cur : s_exit[t - 1];
+      const bool stale = t > 0 && t <= tl && from != arrive;
+      s_stale[t] = stale ? 1 : 0;
+      if (!__syncthreads_or(stale ? 1 : 0)) break;
+      if (stale && !s_stale[t - 1]) {
+        from = arrive; entry = PQ_NOPOS; cnt = 0; exitp = arrive;                                        // the list is over (NOPOS), or jumps over this segment
+        if (arrive < s1) { entry = arrive; exitp = PQ_NOPOS; uint32_t c = arrive, nx; while (c < s1 && pq_str_hdr(win, wb, wend, size, c, nx)) { cnt++; c = nx; } if (c >= s1) exitp = c; }
+        s_exit[t] = exitp;
+      }
+      __syncthreads();
+    }
+    if (t == tl) s_next = exitp;
+    const uint32_t inc = wave_inclusive_sum(cnt);
+    if (lane_id() == WAVE - 1) s_wave[t >> 6] = inc;
+    __syncthreads();
+    uint32_t base = found + inc - cnt, total = 0;
+#pragma unroll
+    for (int w = 0; w < PQ_NT / WAVE; w++) { const uint32_t x = s_wave[w]; if (w < (t >> 6)) base += x; total += x; }
+    if (entry != PQ_NOPOS) {
+      uint32_t c = entry, nx;
+      for (uint32_t j = 0; j < cnt && base + j < want; j++) { pq_str_hdr(win, wb, wend, size, c, nx); str_pos[pg.str_base + base + j] = c + 4 - mis; c = nx; }      // a page holds at most num_values values
+    }
+    found += total;
+    const uint32_t nxt = s_next;
+    if (nxt == PQ_NOPOS || total == 0) break;                                                             // the list ended (a length that leaves the page, or fewer than 4 bytes left)
+    cur = nxt;
+  }
+  if (t == 0) str_cnt[blockIdx.x] = min(found, want);
 }
 
 // PLAIN fixed-width pages without levels: (page, slice of 8192 values)
@@ -729,6 +807,21 @@ static StrOut finish_strings(dfgpu_ctx* ctx, int64_t n, BufferPtr offsets, Buffe
 
 static void launch_decode(dfgpu_ctx* ctx, const std::vector<PqPage>& pages, const PqCol& col, bool wide_ok) {
   if (pages.empty()) return;
+  if (col.mode == MODE_STRING) {                 // every page goes through k_pq_decode; the PLAIN ones get their values' positions from k_pq_str_walk first
+    std::vector<PqPage> pg(pages); uint64_t slots = 0; bool any_plain = false;
+    for (auto& p : pg) { p.str_base = (uint32_t)slots; if (!p.dict_enc) { slots += (uint64_t)std::max(p.num_values, 0); any_plain = true; } }
+    if (slots > 0xFFFFFFF0ull) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: more than 2^32 PLAIN byte-array values in one Parquet read");
+    BufferPtr dpg = upload(ctx, pg), pos, cnt; PqCol c2 = col;
+    if (any_plain) {
+      pos = alloc_buffer(ctx, (size_t)slots * 4 + 16); cnt = alloc_buffer(ctx, pg.size() * 4 + 16);
+      KernelTimer kt(ctx, "pq_str_walk");
+      hipLaunchKernelGGL(k_pq_str_walk, dim3((unsigned)pg.size()), dim3(PQ_NT), 0, ctx->stream, (const PqPage*)dpg->ptr, (uint32_t*)pos->ptr, (uint32_t*)cnt->ptr); KERNEL_CHECK();
+      c2.str_pos = (const uint32_t*)pos->ptr; c2.str_cnt = (const uint32_t*)cnt->ptr;
+    }
+    KernelTimer kt(ctx, "pq_decode");
+    hipLaunchKernelGGL(k_pq_decode, dim3((unsigned)pg.size()), dim3(PQ_NT), 0, ctx->stream, (const PqPage*)dpg->ptr, c2, ctx->d_flags); KERNEL_CHECK();
+    return;                                       // pos / cnt go back to the stream-ordered cache behind the kernel
+  }
   BufferPtr dpages = upload(ctx, pages);
   std::vector<PqPage> slow; std::vector<PqSlice> slices; std::vector<uint32_t> slow_idx;
   for (size_t i = 0; i < pages.size(); i++) {
@@ -755,6 +848,9 @@ static BufferPtr bytes_to_validity(dfgpu_ctx* ctx, const BufferPtr& vbytes, int6
 // One column of one read: the host's walk over the page headers (plan_column; stages the chunks, lists the Snappy jobs of ALL columns so that one
 // launch decompresses every page of the read) and the decode launches (decode_column).
 struct ColumnRead {
+  hipEvent_t copied = nullptr;                        // host image: recorded on the copy stream behind this column's last chunk
+  ColumnRead() = default; ColumnRead(const ColumnRead&) = delete; ColumnRead& operator=(const ColumnRead&) = delete;
+  ~ColumnRead() { if (copied) (void)hipEventDestroy(copied); }
   int leaf_idx = 0; int64_t total_rows = 0; std::vector<PqPage> pages, dict_str_pages; std::vector<BufferPtr> keep;
   bool any_levels = false, all_dict = true; int32_t dict_total = 0; int wp = 0;
 };
@@ -787,6 +883,7 @@ static void plan_column(dfgpu_ctx* ctx, dfgpu_parquet* f, int leaf_idx, int rg0,
   bool& any_levels = cr.any_levels; bool& all_dict = cr.all_dict; int64_t row = 0; int32_t& dict_total = cr.dict_total;
   cr.leaf_idx = leaf_idx; cr.total_rows = total_rows;
   int& wp = cr.wp; wp = leaf.phys == PT_INT32 || leaf.phys == PT_FLOAT ? 4 : leaf.phys == PT_INT64 || leaf.phys == PT_DOUBLE ? 8 : leaf.phys == PT_FLBA ? leaf.type_len : 0;
+  bool staged = false;
   for (int g = rg0; g < rg0 + nrg; g++) {
     const RowGroup& rg = f->rgs[(size_t)g]; const Chunk& ch = rg.cols[(size_t)leaf_idx];
     if (ch.codec != CODEC_NONE && ch.codec != CODEC_SNAPPY && ch.codec != CODEC_ZSTD && ch.codec != CODEC_LZ4_RAW) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: Parquet compression codec %d of column '%s' (UNCOMPRESSED, SNAPPY, ZSTD and LZ4_RAW are decoded on the device)", ch.codec, leaf.name.c_str());
@@ -796,7 +893,7 @@ static void plan_column(dfgpu_ctx* ctx, dfgpu_parquet* f, int leaf_idx, int rg0,
     if (start < 4 || ch.total_comp < 0 || start + ch.total_comp > f->len) fail(DFGPU_EXECUTION, "Parquet error: column chunk of '%s' lies outside the file", leaf.name.c_str());
     const uint8_t* dsrc;
     if (f->dev) dsrc = f->dev + start;
-    else { BufferPtr st = alloc_buffer(ctx, (size_t)ch.total_comp + 16); HIP_CHECK(hipMemcpyAsync(st->ptr, f->host + start, (size_t)ch.total_comp, hipMemcpyHostToDevice, ctx->stream)); keep.push_back(st); dsrc = (const uint8_t*)st->ptr; }
+    else { BufferPtr st = alloc_buffer(ctx, (size_t)ch.total_comp + 16); HIP_CHECK(hipMemcpyAsync(st->ptr, f->host + start, (size_t)ch.total_comp, hipMemcpyHostToDevice, ctx->copy_stream)); keep.push_back(st); dsrc = (const uint8_t*)st->ptr; staged = true; }
     // page headers (host), sizes of the uncompressed images
     struct P { PageHdr h; int64_t payload; }; std::vector<P> ps; int64_t pos = start, seen = 0, ubytes = 0;
     while (seen < ch.num_values) {
@@ -846,6 +943,7 @@ static void plan_column(dfgpu_ctx* ctx, dfgpu_parquet* f, int leaf_idx, int rg0,
     }
   }
   if (row != total_rows) fail(DFGPU_EXECUTION, "Parquet error: pages of '%s' hold %lld values for %lld rows", leaf.name.c_str(), (long long)row, (long long)total_rows);
+  if (staged) { HIP_CHECK(hipEventCreateWithFlags(&cr.copied, hipEventDisableTiming)); HIP_CHECK(hipEventRecord(cr.copied, ctx->copy_stream)); }
 }
 static dfgpu_array* decode_column(dfgpu_ctx* ctx, dfgpu_parquet* f, ColumnRead& cr) {
   const Leaf& leaf = f->leaves[(size_t)cr.leaf_idx]; const bool is_str = leaf.arrow == DFGPU_UTF8;
@@ -922,7 +1020,8 @@ dfgpu_status dfgpu_parquet_open_file(dfgpu_ctx* ctx, const char* path, int32_t s
     if (!path || !out) fail(DFGPU_INVALID_ARGUMENT, "parquet_open_file: null argument");
     int fd = open(path, O_RDONLY); if (fd < 0) fail(DFGPU_EXECUTION, "Object Store error: cannot open %s", path);
     struct stat st; if (fstat(fd, &st) != 0 || st.st_size < 12) { close(fd); fail(DFGPU_EXECUTION, "Parquet error: Invalid Parquet file. Size is smaller than footer"); }
-    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0); close(fd);
+    // host image: a private writable mapping (never written) can be page-locked, a read-only one cannot
+    void* m = mmap(nullptr, (size_t)st.st_size, stage_on_device ? PROT_READ : PROT_READ | PROT_WRITE, MAP_PRIVATE, fd, 0); close(fd);
     if (m == MAP_FAILED) fail(DFGPU_EXECUTION, "Object Store error: cannot map %s", path);
     std::unique_ptr<dfgpu_parquet> f(new dfgpu_parquet()); f->map = m; f->map_len = (size_t)st.st_size; f->host = (const uint8_t*)m; f->len = st.st_size;
     parse_footer(f.get());
@@ -931,6 +1030,11 @@ dfgpu_status dfgpu_parquet_open_file(dfgpu_ctx* ctx, const char* path, int32_t s
       HIP_CHECK(hipSetDevice(ctx->device));
       f->dev_owned = alloc_buffer(ctx, (size_t)f->len + 16); HIP_CHECK(hipMemcpyAsync(f->dev_owned->ptr, f->host, (size_t)f->len, hipMemcpyHostToDevice, ctx->stream)); HIP_CHECK(hipStreamSynchronize(ctx->stream));
       f->dev = (const uint8_t*)f->dev_owned->ptr;
+    } else if (ctx) {
+      // page-lock the image once: column chunks then move by DMA (~55 GB/s over PCIe 5 x16) and asynchronously; from pageable memory every copy goes through the runtime's bounce
+      // buffer and holds the calling thread.  A mapping that cannot be locked (RLIMIT_MEMLOCK, a filesystem that refuses) is read as before.
+      HIP_CHECK(hipSetDevice(ctx->device));
+      if (hipHostRegister(m, (size_t)st.st_size, hipHostRegisterDefault) == hipSuccess) f->registered = true; else (void)hipGetLastError();
     }
     *out = f.release();
   });
@@ -983,10 +1087,22 @@ dfgpu_status dfgpu_parquet_read(dfgpu_ctx* ctx, dfgpu_parquet* f, int32_t first_
     if (first_row_group < 0 || num_row_groups < 0 || (size_t)first_row_group + (size_t)num_row_groups > f->rgs.size()) fail(DFGPU_INVALID_ARGUMENT, "parquet_read: row groups [%d, %d) of %zu", first_row_group, first_row_group + num_row_groups, f->rgs.size());
     HIP_CHECK(hipSetDevice(ctx->device));
     std::vector<ArrayHolder> res; std::vector<ColumnRead> reads((size_t)ncols); std::vector<SnJob> jobs;
-    for (int32_t i = 0; i < ncols; i++) {
-      if (columns[i] < 0 || (size_t)columns[i] >= f->leaves.size()) fail(DFGPU_INVALID_ARGUMENT, "parquet_read: column %d of %zu", columns[i], f->leaves.size());
-      plan_column(ctx, f, columns[i], first_row_group, num_row_groups, reads[(size_t)i], jobs);
+    // A file image in host memory: the column chunks cross PCIe on the copy stream, one event per column, while `stream` decodes the columns that have arrived (ParquetExec's reader
+    // fetches the projected chunks' byte ranges ahead of the decoder the same way, parquet/mod.rs ParquetOpener -> AsyncFileReader::get_byte_ranges).  The staging buffers come from
+    // the stream-ordered cache of `stream`, so the copies start behind everything `stream` has been given so far; an error on the way waits for the copies before the buffers go back.
+    struct CopyDrain { dfgpu_ctx* c; bool armed = true; ~CopyDrain() { if (armed && c->copy_stream) (void)hipStreamSynchronize(c->copy_stream); } } drain{ctx};
+    if (!f->dev) {
+      if (!ctx->copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+      hipEvent_t e0; HIP_CHECK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+      hipError_t e1 = hipEventRecord(e0, ctx->stream), e2 = e1 == hipSuccess ? hipStreamWaitEvent(ctx->copy_stream, e0, 0) : e1; (void)hipEventDestroy(e0); HIP_CHECK(e2);
     }
+    // byte-array columns first: their decode is the long one (a walk over length prefixes), so it should start while the fixed-width chunks are still on the wire
+    std::vector<int32_t> order; order.reserve((size_t)ncols);
+    for (int32_t i = 0; i < ncols; i++) if (columns[i] < 0 || (size_t)columns[i] >= f->leaves.size()) fail(DFGPU_INVALID_ARGUMENT, "parquet_read: column %d of %zu", columns[i], f->leaves.size());
+    for (int pass = 0; pass < 2; pass++) for (int32_t i = 0; i < ncols; i++) if ((f->leaves[(size_t)columns[i]].arrow == DFGPU_UTF8) == (pass == 0)) order.push_back(i);
+    for (int32_t i : order) plan_column(ctx, f, columns[i], first_row_group, num_row_groups, reads[(size_t)i], jobs);
+    const bool compressed = !jobs.empty();
+    if (compressed) for (int32_t i = 0; i < ncols; i++) if (reads[(size_t)i].copied) HIP_CHECK(hipStreamWaitEvent(ctx->stream, reads[(size_t)i].copied, 0));      // the decompressors take every page of the read in one launch
     std::vector<SnJob> zjobs, ljobs; { std::vector<SnJob> sj; for (auto& j : jobs) (j.codec == CODEC_ZSTD ? zjobs : j.codec == CODEC_LZ4_RAW ? ljobs : sj).push_back(j); jobs.swap(sj); }
     if (!ljobs.empty()) {
       std::stable_sort(ljobs.begin(), ljobs.end(), [](const SnJob& x, const SnJob& y) { return x.usize > y.usize; });
@@ -1018,7 +1134,12 @@ dfgpu_status dfgpu_parquet_read(dfgpu_ctx* ctx, dfgpu_parquet* f, int32_t first_
         hipLaunchKernelGGL(k_pq_snappy, dim3((unsigned)jobs.size()), dim3(64), 0, ctx->stream, (const SnJob*)dj->ptr, (const SnBlk*)nullptr, (uint32_t*)bad->ptr, ctx->d_flags); }
       KERNEL_CHECK();
     }
-    for (int32_t i = 0; i < ncols; i++) res.emplace_back(decode_column(ctx, f, reads[(size_t)i]));
+    res.resize((size_t)ncols);
+    for (int32_t i : order) {
+      if (!compressed && reads[(size_t)i].copied) HIP_CHECK(hipStreamWaitEvent(ctx->stream, reads[(size_t)i].copied, 0));
+      res[(size_t)i].a = decode_column(ctx, f, reads[(size_t)i]);
+    }
+    drain.armed = false;                       // every copy is ordered before a kernel of `stream` from here on
     // the staged / decompressed bytes (reads[].keep) outlive the kernels: frees are stream ordered through the caching allocator
     check_flags(ctx, "Parquet page decode (malformed page, run or dictionary index)");
     for (int32_t i = 0; i < ncols; i++) out[i] = res[(size_t)i].release();

@@ -268,3 +268,41 @@ def test_lz4_raw_pages_equal_pyarrow(ctx, tmp_path, kw):
         f = ParquetFile(ctx, path=path, stage_on_device=staged, utf8_dictionary=False)
         for name, a in zip(f.column_names(), f.read()):
             same_column(a.to_arrow(), want[name], name)
+
+
+def _plain_strings_case(kind, n, rng):
+    if kind == "short":                      # the TPC-H shape: the byte before a length prefix reads as a small length too
+        words = ["MAIL", "RAIL", "SHIP", "TRUCK", "AIR", "REG AIR", "FOB", "DELIVER IN PERSON", "COLLECT COD", "NONE", "TAKE BACK RETURN", ""]
+        return [words[i] for i in rng.integers(0, len(words), n)]
+    if kind == "looks_like_prefixes":        # values made of bytes that read as plausible length prefixes: every guess of the parallel walk can be wrong, the result may not be
+        alphabet = ["\x01\x00\x00\x00", "\x04\x00\x00\x00\x00", "\x00\x00\x00\x00", "\x02\x00\x00\x00ab", "\x00", "\x03\x00\x00"]
+        return ["".join(alphabet[j] for j in rng.integers(0, len(alphabet), int(k))) for k in rng.integers(0, 9, n)]
+    if kind == "long":                       # values longer than a segment, longer than a window (64 KB), and tiny ones between them
+        lens = rng.choice([0, 1, 3, 200, 300, 5000, 70_000, 140_000], n, p=[.2, .2, .2, .15, .15, .07, .02, .01])
+        return [chr(97 + int(i) % 26) * int(L) for i, L in enumerate(lens)]
+    raise AssertionError(kind)
+
+
+@pytest.mark.parametrize("version", ["1.0", "2.0"], ids=["v1-pages", "v2-pages"])
+@pytest.mark.parametrize("nulls", [False, True], ids=["required", "nullable"])
+@pytest.mark.parametrize("kind", ["short", "looks_like_prefixes", "long"])
+def test_plain_byte_arrays_walked_in_parallel(ctx, tmp_path, kind, nulls, version):
+    """PLAIN BYTE_ARRAY pages (k_pq_str_walk): each lane walks a segment of the page from a guessed value boundary, the guesses are checked against the true path.  Short
+    strings (guesses right), strings whose bytes look like length prefixes (guesses wrong), strings longer than a segment / the LDS window (segments jumped over), with and
+    without NULLs, both page versions, pages of 64 KB..1 MB, host and device image."""
+    from dfgpu.parquet import ParquetFile
+    rng = np.random.default_rng(hash((kind, nulls, version)) % 2**32)
+    n = 6_000 if kind == "long" else 250_000
+    vals = _plain_strings_case(kind, n, rng)
+    mask = rng.random(n) < 0.3 if nulls else None
+    t = pa.table({"s": pa.array(vals, type=pa.string(), mask=mask), "i": pa.array(np.arange(n))})
+    for page in (1 << 16, 1 << 20):
+        path = str(tmp_path / f"{kind}_{page}.parquet")
+        pq.write_table(t, path, compression="none", use_dictionary=False, data_page_version=version, data_page_size=page, row_group_size=100_000)
+        for staged in (False, True):
+            f = ParquetFile(ctx, path=path, stage_on_device=staged, utf8_dictionary=False)
+            got = f.read()
+            same_column(got[0].to_arrow(), t["s"], f"{kind} page={page} staged={staged}")
+            same_column(got[1].to_arrow(), t["i"])
+            f.close()
+    ctx.synchronize()
