@@ -181,7 +181,7 @@ _CPP = C.POINTER(C.c_char_p)
 _I32P = C.POINTER(C.c_int32)
 PROTOTYPES.update({
     "dfgpu_exec_last_error": (C.c_char_p, []),
-    "dfgpu_plan_sort_merge_join": (C.c_int32, [_P, _P, _PP, _PP, C.c_int32, _P, C.c_int32, C.c_int32, _PP]),
+    "dfgpu_plan_sort_merge_join": (C.c_int32, [_P, _P, _PP, _PP, C.c_int32, _P, _I32P, _I32P, C.c_int32, C.c_int32, C.c_int32, _PP]),
     "dfgpu_plan_nested_loop_join": (C.c_int32, [_P, _P, _P, _I32P, _I32P, C.c_int32, C.c_int32, _PP]),
     "dfgpu_plan_parquet": (C.c_int32, [_P, _I32P, C.c_int32, C.c_int32, C.c_int32, _PP]),
     "dfgpu_plan_csv": (C.c_int32, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), _I32P, C.c_int32, _I32P, C.c_int32, C.c_int32, C.c_int64, _PP]),

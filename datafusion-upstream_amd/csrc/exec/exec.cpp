@@ -859,7 +859,8 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
 // RightSemi (refused by the reference too, :107-111) and JoinFilters answer NotImplemented.
 struct SortMergeJoinExec : Plan {
   PlanPtr left, right; std::vector<ExprPtr> on_l, on_r; int join_type = 0; bool null_equals_null = false;
-  PlanPtr fresh() const override { auto j = std::make_shared<SortMergeJoinExec>(); j->left = left->fresh(); j->right = right->fresh(); j->on_l = on_l; j->on_r = on_r; j->join_type = join_type; j->null_equals_null = null_equals_null; return j; }
+  ExprPtr filter; std::vector<int> f_side, f_index;          // JoinFilter: column i of the intermediate batch = column f_index[i] of side f_side[i] (0 left, 1 right)
+  PlanPtr fresh() const override { auto j = std::make_shared<SortMergeJoinExec>(); j->left = left->fresh(); j->right = right->fresh(); j->on_l = on_l; j->on_r = on_r; j->join_type = join_type; j->null_equals_null = null_equals_null; j->filter = filter; j->f_side = f_side; j->f_index = f_index; return j; }
   std::vector<std::shared_ptr<const Plan>> children() const override { return {left, right}; }
   const char* name() const override { return "SortMergeJoinExec"; }
   bool left_only() const { return join_type == DFGPU_JOIN_LEFT_SEMI || join_type == DFGPU_JOIN_LEFT_ANTI; }
@@ -895,7 +896,40 @@ struct SortMergeJoinExec : Plan {
         dfgpu_array* u = nullptr; tc.check(dfgpu_join_final_indices(tc.ctx, table.t, DFGPU_JOIN_LEFT_ANTI, &u)); unmatched_b = ArrayRef::adopt(u);
       }
     }
-    if (join_type != DFGPU_JOIN_INNER) {
+    // JoinFilter (:1156-1300), as the reference applies it: over the joined PAIRS of a chunk.  A pair that passes is an output row.  For Left / Right / Full a pair that fails is
+    // ALSO an output row -- its streamed row joined with NULLs (one per failing pair, not one per streamed row without a passing pair: sort_merge_join.slt:137-147 holds the
+    // reference to exactly that), and for Full a second one, NULLs joined with its buffered row.  Buffered rows count as joined by their key match alone.
+    ArrayRef fail_b, fail_s; const int64_t npairs = sidx.len();
+    if (filter && npairs) {
+      Batch inter; inter.schema = std::make_shared<Schema>(); inter.base_rows = npairs;
+      for (size_t i = 0; i < f_side.size(); i++) {
+        const bool from_left = f_side[i] == 0; Batch& side = from_left ? lb : rb;
+        Col t = col_take(side.cols.at((size_t)f_index[i]), from_left == stream_left ? sidx : bidx); inter.cols.push_back(col_of(col_get(tc, t))); inter.schema->f.push_back(Field{"x"});
+      }
+      ArrayRef m = known_mask(tc, into_array(tc, filter->eval(tc, inter), npairs));
+      auto pick = [&](const ArrayRef& a, const ArrayRef& mask) { dfgpu_array* o = nullptr; tc.check(dfgpu_filter(tc.ctx, a.a, mask.a, &o)); return ArrayRef::adopt(o); };
+      if (join_type != DFGPU_JOIN_INNER) { dfgpu_array* nm = nullptr; tc.check(dfgpu_not(tc.ctx, m.a, &nm)); ArrayRef notm = ArrayRef::adopt(nm); fail_b = pick(bidx, notm); fail_s = pick(sidx, notm); }
+      ArrayRef pb = pick(bidx, m), ps = pick(sidx, m);
+      if (join_type == DFGPU_JOIN_INNER) { bidx = pb; sidx = ps; }
+      else {
+        // streamed rows without a key match, from the index algebra over ALL key pairs; then passing pairs + failing pairs (buffered side NULL) + those rows
+        dfgpu_array *b2 = nullptr, *s2 = nullptr; tc.check(dfgpu_join_adjust_indices(tc.ctx, bidx.a, sidx.a, 0, sb.base_rows, DFGPU_JOIN_RIGHT, &b2, &s2)); ArrayRef ab = ArrayRef::adopt(b2), as_ = ArrayRef::adopt(s2);
+        dfgpu_array *ub = nullptr, *us = nullptr; tc.check(dfgpu_array_slice(tc.ctx, ab.a, npairs, ab.len() - npairs, &ub)); ArrayRef unb = ArrayRef::adopt(ub);
+        tc.check(dfgpu_array_slice(tc.ctx, as_.a, npairs, as_.len() - npairs, &us)); ArrayRef uns = ArrayRef::adopt(us);
+        dfgpu_array* nn = nullptr; tc.check(dfgpu_array_new_null(tc.ctx, DFGPU_UINT64, 0, 0, fail_s.len(), &nn)); ArrayRef fnull = ArrayRef::adopt(nn);
+        std::vector<ArrayRef> bv, sv;
+        if (pb.len()) { bv.push_back(pb); sv.push_back(ps); }
+        if (fail_s.len()) { bv.push_back(fnull); sv.push_back(fail_s); }
+        if (unb.len()) { bv.push_back(unb); sv.push_back(uns); }
+        if (bv.empty()) { bidx = pb; sidx = ps; } else if (bv.size() == 1) { bidx = bv[0]; sidx = sv[0]; } else { bidx = concat_arrays(tc, bv); sidx = concat_arrays(tc, sv); }
+        if (sidx.len()) {                                  // back into streamed order, a row's passing pairs before its NULL-joined ones (stable)
+          const dfgpu_array* kp = sidx.a; uint8_t no = 0; dfgpu_array* perm = nullptr;
+          tc.check(dfgpu_sort_to_indices(tc.ctx, &kp, &no, &no, 1, -1, &perm)); ArrayRef pm = ArrayRef::adopt(perm);
+          bidx = take(tc, bidx, pm); sidx = take(tc, sidx, pm);
+        }
+      }
+    }
+    if (join_type != DFGPU_JOIN_INNER && !(filter && npairs)) {
       const int as = (join_type == DFGPU_JOIN_LEFT || join_type == DFGPU_JOIN_RIGHT || join_type == DFGPU_JOIN_FULL) ? DFGPU_JOIN_RIGHT : join_type == DFGPU_JOIN_LEFT_SEMI ? DFGPU_JOIN_RIGHT_SEMI : DFGPU_JOIN_RIGHT_ANTI;
       dfgpu_array *b2 = nullptr, *s2 = nullptr; tc.check(dfgpu_join_adjust_indices(tc.ctx, bidx.a, sidx.a, 0, sb.base_rows, as, &b2, &s2)); bidx = ArrayRef::adopt(b2); sidx = ArrayRef::adopt(s2);
       if (as == DFGPU_JOIN_RIGHT && sidx.len()) {         // unmatched streamed rows back into their places: stable order by streamed row
@@ -908,6 +942,13 @@ struct SortMergeJoinExec : Plan {
     if (!right_only()) for (auto& c : lb.cols) o.cols.push_back(col_take(c, stream_left ? sidx : bidx, memo));
     if (!left_only()) for (auto& c : rb.cols) o.cols.push_back(col_take(c, stream_left ? bidx : sidx, memo));
     if (o.base_rows > 0) outv.push_back(std::move(o));
+    if (join_type == DFGPU_JOIN_FULL && fail_b && fail_b.len() > 0) {      // Full with a filter: NULLs joined with the buffered row of every failing pair (:1262-1300)
+      const int64_t m = fail_b.len(); dfgpu_array* nn = nullptr; tc.check(dfgpu_array_new_null(tc.ctx, DFGPU_UINT32, 0, 0, m, &nn)); ArrayRef nulls = ArrayRef::adopt(nn);
+      Batch u; u.schema = schema(); u.base_rows = m; MemoPtr memo2 = std::make_shared<TakeMemo>();
+      for (auto& c : lb.cols) u.cols.push_back(col_take(c, nulls, memo2));
+      for (auto& c : rb.cols) u.cols.push_back(col_take(c, fail_b, memo2));
+      outv.push_back(std::move(u));
+    }
     if (unmatched_b && unmatched_b.len() > 0) {      // Full: streamed (left) columns NULL, buffered (right) columns from the unmatched rows
       const int64_t m = unmatched_b.len(); dfgpu_array* nn = nullptr; tc.check(dfgpu_array_new_null(tc.ctx, DFGPU_UINT32, 0, 0, m, &nn)); ArrayRef nulls = ArrayRef::adopt(nn);
       Batch u; u.schema = schema(); u.base_rows = m; MemoPtr memo2 = std::make_shared<TakeMemo>();
@@ -1793,13 +1834,16 @@ dfgpu_status dfgpu_plan_hash_join(const dfgpu_plan* left, const dfgpu_plan* righ
   });
 }
 dfgpu_status dfgpu_plan_sort_merge_join(const dfgpu_plan* left, const dfgpu_plan* right, const dfgpu_expr* const* on_left, const dfgpu_expr* const* on_right, int32_t non, const dfgpu_expr* filter,
-                                        int32_t join_type, int32_t null_equals_null, dfgpu_plan** out) {
+                                        const int32_t* fs, const int32_t* fi, int32_t nf, int32_t join_type, int32_t null_equals_null, dfgpu_plan** out) {
   return guard([&] {
     if (non < 1) fail(DFGPU_EXECUTION, "Plan error: On constraints in SortMergeJoinExec should be non-empty");       // sort_merge_join.rs:116-120
     if (join_type == DFGPU_JOIN_RIGHT_SEMI) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: SortMergeJoinExec does not support JoinType::RightSemi");       // :107-111
     if (join_type < 0 || join_type > DFGPU_JOIN_RIGHT_ANTI) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: SortMergeJoinExec join type %d on the device", join_type);
-    if (filter) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: SortMergeJoinExec with a JoinFilter on the device");
+    if (filter && (join_type == DFGPU_JOIN_LEFT_SEMI || join_type == DFGPU_JOIN_LEFT_ANTI || join_type == DFGPU_JOIN_RIGHT_ANTI))
+      fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: SortMergeJoinExec %s with a JoinFilter on the device (Inner, Left, Right and Full take one)", join_type == DFGPU_JOIN_LEFT_SEMI ? "LeftSemi" : join_type == DFGPU_JOIN_LEFT_ANTI ? "LeftAnti" : "RightAnti");
+    if (filter && nf > 0 && (!fs || !fi)) fail(DFGPU_INVALID_ARGUMENT, "sort_merge_join: JoinFilter without column indices");
     auto j = std::make_shared<SortMergeJoinExec>(); j->left = pl(left); j->right = pl(right);
+    if (filter) { j->filter = ex(filter); for (int i = 0; i < nf; i++) { j->f_side.push_back(fs[i]); j->f_index.push_back(fi[i]); } }
     for (int i = 0; i < non; i++) { j->on_l.push_back(ex(on_left[i])); j->on_r.push_back(ex(on_right[i])); }
     j->join_type = join_type; j->null_equals_null = null_equals_null != 0;
     *out = new dfgpu_plan{j};

@@ -627,10 +627,14 @@ class SortMergeJoinExec(ExecutionPlan):
 
     def _build(self, context):
         ctx = context.ctx
+        f = self.filter
+        nf = len(f.column_indices) if f else 0
+        sides = (C.c_int32 * max(1, nf))(*([0 if s == "left" else 1 for s, _ in f.column_indices] if f else [0]))
+        idx = (C.c_int32 * max(1, nf))(*([i for _, i in f.column_indices] if f else [0]))
         out = C.c_void_p()
         _check(_lib().dfgpu_plan_sort_merge_join(_child_handle(self.left, context).h, _child_handle(self.right, context).h,
                                                  _ptrs([l.handle(ctx).h for l, _ in self.on]), _ptrs([r.handle(ctx).h for _, r in self.on]), len(self.on),
-                                                 self.filter.expression.handle(ctx).h if self.filter else None, JOIN_TYPES[self.join_type], int(self.null_equals_null), C.byref(out)))
+                                                 f.expression.handle(ctx).h if f else None, sides, idx, nf, JOIN_TYPES[self.join_type], int(self.null_equals_null), C.byref(out)))
         return self._new(out)
 
 

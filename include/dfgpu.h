@@ -425,7 +425,11 @@ DFGPU_API dfgpu_status dfgpu_exchange(dfgpu_ctx *ctx, dfgpu_comm *comm, const df
  * DFGPU_NOT_IMPLEMENTED -- the file's other columns stay readable (projection).
  * dfgpu_parquet_open: `file_bytes` is the whole file in host memory (kept by the caller until close); `device_bytes` (optional) is the same image
  * already resident in HBM (a GPUDirect read, or a cached file) -- pages are then decoded in place, otherwise each column chunk read is copied
- * to the device first.  dfgpu_parquet_open_file maps `path` (stage_on_device = 1 also copies the image to HBM once).
+ * to the device first, on a copy stream of the context's own, one event per column: the decode kernels of a column start when its chunks have
+ * arrived, while the next columns are still on the wire (≙ the byte-range prefetch of ParquetOpener's AsyncFileReader).  These copies run at PCIe
+ * speed and beside the kernels only from page-locked memory: dfgpu_parquet_open_file maps `path` and page-locks the mapping (stage_on_device = 1
+ * copies the image to HBM once instead); a caller of dfgpu_parquet_open who wants the same passes page-locked `file_bytes` (hipHostMalloc /
+ * hipHostRegister) -- pageable memory works, through the runtime's bounce buffer.
  * Option "utf8_dictionary" (default 1): Utf8 columns are handed over as Dictionary(Int32, Utf8) -- the page indices plus the row group's base in
  * the concatenated dictionaries; nothing is expanded, and dictionary predicates / the canonical-id group-by take the column as it is.  Chunks that
  * fell back to PLAIN pages get identity keys, so the column type is the same in every batch.  0 = plain Utf8 columns, as the reference decodes. */

@@ -85,10 +85,13 @@ DFGPU_API dfgpu_status dfgpu_plan_hash_join(const dfgpu_plan *left, const dfgpu_
                                             int32_t join_type, int32_t mode, int32_t null_equals_null, dfgpu_plan **out);
 /* SortMergeJoinExec::try_new(left, right, on, filter, join_type, sort_options, null_equals_null) (joins/sort_merge_join.rs:95-160): inputs sorted on the keys and
  * partitioned alike; output rows in streamed-side order (left; right for JoinType::Right), each with its matches in buffered order, unmatched outer rows in place.
- * Inner, Left, Right, LeftSemi, LeftAnti; Full / RightAnti / a JoinFilter answer DFGPU_NOT_IMPLEMENTED, RightSemi is refused as the reference refuses it.  The sort
- * options do not enter: row order follows the inputs' own order. */
+ * Inner, Left, Right, Full, LeftSemi, LeftAnti, RightAnti; RightSemi is refused as the reference refuses it.  Full adds the buffered rows no streamed row matched as a
+ * last batch.  JoinFilter as for dfgpu_plan_hash_join, for Inner / Left / Right / Full, with the reference's own semantics (:1156-1300): it is applied to the joined pairs,
+ * and an outer join emits every FAILING pair NULL-joined (once for the streamed side; for Full once more for the buffered side) -- sort_merge_join.slt:137-147 pins this.
+ * LeftSemi / LeftAnti / RightAnti with a filter answer DFGPU_NOT_IMPLEMENTED.  The sort options do not enter: row order follows the inputs' own order. */
 DFGPU_API dfgpu_status dfgpu_plan_sort_merge_join(const dfgpu_plan *left, const dfgpu_plan *right, const dfgpu_expr *const *on_left, const dfgpu_expr *const *on_right, int32_t non,
-                                                  const dfgpu_expr *filter, int32_t join_type, int32_t null_equals_null, dfgpu_plan **out);
+                                                  const dfgpu_expr *filter, const int32_t *filter_sides, const int32_t *filter_indices, int32_t nfilter_cols,
+                                                  int32_t join_type, int32_t null_equals_null, dfgpu_plan **out);
 /* NestedLoopJoinExec::try_new(left, right, filter, join_type) (joins/nested_loop_join.rs:102-127): no equi-join keys; the side named by left_is_build_side
  * (:373-378) is collected, the other side streams and decides the output partitioning.  JoinFilter as for dfgpu_plan_hash_join (NULL = cross join). */
 DFGPU_API dfgpu_status dfgpu_plan_nested_loop_join(const dfgpu_plan *left, const dfgpu_plan *right, const dfgpu_expr *filter, const int32_t *filter_sides, const int32_t *filter_indices,

@@ -469,18 +469,29 @@ def nested_loop_join(left_batches, right_batches, filter_cols, filter_fn, join_t
 
 
 # ------------------------------------------------------------------ SortMergeJoinExec (joins/sort_merge_join.rs), small inputs only: a two-cursor merge in plain Python
-def sort_merge_join(left_cols, right_cols, on, join_type: str, descending: bool = False, nulls_first: bool = True, null_equals_null: bool = False):          # SortOptions::default(): ascending, nulls first
+def sort_merge_join(left_cols, right_cols, on, join_type: str, descending: bool = False, nulls_first: bool = True, null_equals_null: bool = False, filter=None):          # SortOptions::default(): ascending, nulls first
     """left_cols / right_cols: lists of pyarrow arrays (one sorted partition each); on: [(left column index, right column index)].  Returns the output columns.
+    filter (Inner / Left / Right / Full): f(left_row, right_row) -> True / False / None over the two rows' values, the JoinFilter as freeze_streamed applies it
+    (:1156-1300): to the joined PAIRS.  A passing pair is a row; under Left / Right / Full a failing pair (False or NULL) is ALSO a row -- its streamed row NULL-joined,
+    one per failing pair -- and under Full a second one, NULLs joined with its buffered row; buffered rows count as joined by their key match alone
+    (sort_merge_join.slt:75-155 pins all of this).  With a filter the row ORDER is not part of the contract (the reference pushes the three kinds chunk by chunk, its
+    tests sort): here failing pairs follow in place, the buffered-side rows of Full at the end.
     Follows SMJStream (:590-1330) without a filter: the streamed side (left; right for JoinType::Right) advances row by row; compare_join_arrays (:1361-1456) orders the
     streamed key against the buffered head under the sort options (a NULL never equals unless null_equals_null; NULLs order by nulls_first); join_partial (:968-1060)
     emits, per streamed row: Equal -> the pairs with every buffered row of the equal-key run (Inner / Left / Right), or the streamed row once (LeftSemi); Less ->
     the streamed row with NULLs (Left / Right) or alone (LeftAnti); Greater -> the buffered cursor advances."""
+    if filter is not None and join_type not in ("Inner", "Left", "Right", "Full"):
+        raise OracleError("sort_merge_join restates the JoinFilter for Inner, Left, Right, Full")
     if join_type == "RightAnti":          # streamed side = right (:164): the right rows no left row matches, in right order = LeftAnti with the sides exchanged
         return sort_merge_join(right_cols, left_cols, [(r, l) for l, r in on], "LeftAnti", descending, nulls_first, null_equals_null)
     if join_type == "Full":               # streamed side = left (:169): the Left join's rows, plus every buffered (right) row no streamed row matched, NULL-joined.  The reference emits
         # those as its buffered cursor passes them (:1001-1077); its tests compare sorted rows (:2121, :2497), so the restatement appends them: a MULTISET contract
-        out = sort_merge_join(left_cols, right_cols, on, "Left", descending, nulls_first, null_equals_null)
+        failed = []               # buffered rows of the pairs the filter failed: NULL-joined once per pair (:1262-1300)
+        out = sort_merge_join(left_cols, right_cols, on, "Left", descending, nulls_first, null_equals_null, filter=(filter, failed) if filter is not None else None)
         lonely = sort_merge_join(right_cols, left_cols, [(r, l) for l, r in on], "LeftAnti", descending, nulls_first, null_equals_null)
+        if failed:
+            fi = pa.array(failed, type=pa.int64())
+            lonely = [pa.concat_arrays([c.take(fi), d]) for c, d in zip(right_cols, lonely)]
         m = len(lonely[0]) if lonely else 0
         left_nulls = [pa.nulls(m, type=c.type) for c in left_cols]
         parts = [pa.concat_arrays([a, b]) for a, b in zip(out, left_nulls + lonely)]
@@ -537,6 +548,21 @@ def sort_merge_join(left_cols, right_cols, on, join_type: str, descending: bool 
             si.append(i); bi.append(None)
         elif join_type == "LeftAnti":
             si.append(i); bi.append(None)
+    if filter is not None:
+        fn, failed = filter if isinstance(filter, tuple) else (filter, None)
+        srows = list(zip(*[c.to_pylist() for c in scols])); brows = list(zip(*[c.to_pylist() for c in bcols]))
+        s2, b2 = [], []
+        for i, j in zip(si, bi):
+            if j is None:
+                s2.append(i); b2.append(None); continue
+            ok = fn(srows[i], brows[j]) if stream_left else fn(brows[j], srows[i])
+            if ok:                        # True; False and NULL fail alike (prep_null_mask_filter, :1209-1214)
+                s2.append(i); b2.append(j)
+            elif join_type != "Inner":
+                s2.append(i); b2.append(None)
+                if failed is not None:
+                    failed.append(j)
+        si, bi = s2, b2
     take = lambda arr, idx: arr.take(pa.array(idx, type=pa.int64()))
     lidx, ridx = (si, bi) if stream_left else (bi, si)
     out = [take(c, lidx) for c in left_cols]

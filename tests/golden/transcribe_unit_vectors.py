@@ -182,6 +182,51 @@ smj_full = [
      "expected": [[N, N, N, 0, 2, 50], [N, N, N, 40, 8, 90], [0, 3, 4, N, N, N], [1, 4, 5, 10, 4, 60], [2, 5, 6, N, N, N], [3, 6, 7, 20, 6, 70], [3, 6, 7, 30, 6, 80], [4, 6, 8, 20, 6, 70],
                   [4, 6, 8, 30, 6, 80], [5, 7, 9, N, N, N], [6, 9, 9, N, N, N]]},
 ]
+# JoinFilter: sqllogictest/test_files/sort_merge_join.slt (prefer_hash_join = false).  Tables as the file creates them (INT columns widened to Int64, which is what the
+# planner's CAST in the file's own EXPLAIN output does before the arithmetic); "filter" is the ON clause's non-equi part as a small tree over ["l", i] / ["r", i] = column i
+# of the left / right table; "project" = the SELECT list as indices into left columns ++ right columns; rows compared sorted (the file says rowsort).
+SLT = "datafusion/sqllogictest/test_files/sort_merge_join.slt:"
+TA1 = {"types": ["utf8", "int64"], "columns": [["Alice", "Alice", "Bob"], [50, 100, 1]]}
+TA2 = {"types": ["utf8", "int64"], "columns": [["Alice", "Alice"], [2, 1]]}
+TB1 = {"types": ["int64", "utf8", "int64"], "columns": [[11, 22, 33, 44], ["a", "b", "c", "d"], [1, 2, 3, 4]]}
+TB2 = {"types": ["int64", "utf8", "int64"], "columns": [[11, 22, 44, 55], ["z", "y", "x", "w"], [3, 1, 3, 3]]}
+L, Rr = (lambda i: ["l", i]), (lambda i: ["r", i])
+A = "Alice"
+smj_filter = [
+    {"name": "inner_times_50", "ref": SLT + "51-56", "join_type": "Inner", "left": TA1, "right": TA2, "on": [[0, 0]], "filter": ["<=", ["*", Rr(1), 50], L(1)],
+     "expected": [[A, 100, A, 1], [A, 100, A, 2], [A, 50, A, 1]]},
+    {"name": "inner_less", "ref": SLT + "58-64", "join_type": "Inner", "left": TA1, "right": TA2, "on": [[0, 0]], "filter": ["<", Rr(1), L(1)],
+     "expected": [[A, 100, A, 1], [A, 100, A, 2], [A, 50, A, 1], [A, 50, A, 2]]},
+    {"name": "inner_none_pass", "ref": SLT + "66-68", "join_type": "Inner", "left": TA1, "right": TA2, "on": [[0, 0]], "filter": [">", Rr(1), L(1)], "expected": []},
+    {"name": "left_times_50", "ref": SLT + "81-88", "join_type": "Left", "left": TA1, "right": TA2, "on": [[0, 0]], "filter": ["<=", ["*", Rr(1), 50], L(1)],
+     "expected": [[A, 100, A, 1], [A, 100, A, 2], [A, 50, A, 1], [A, 50, N, N], ["Bob", 1, N, N]]},
+    {"name": "left_less", "ref": SLT + "90-97", "join_type": "Left", "left": TA1, "right": TA2, "on": [[0, 0]], "filter": ["<", Rr(1), L(1)],
+     "expected": [[A, 100, A, 1], [A, 100, A, 2], [A, 50, A, 1], [A, 50, A, 2], ["Bob", 1, N, N]]},
+    {"name": "right_times_50", "ref": SLT + "109-115", "join_type": "Right", "left": TA1, "right": TA2, "on": [[0, 0]], "filter": ["<=", ["*", Rr(1), 50], L(1)],
+     "expected": [[A, 100, A, 1], [A, 100, A, 2], [A, 50, A, 1], [N, N, A, 2]]},
+    {"name": "right_greater", "ref": SLT + "117-123", "join_type": "Right", "left": TA1, "right": TA2, "on": [[0, 0]], "filter": [">", L(1), Rr(1)],
+     "expected": [[A, 100, A, 1], [A, 100, A, 2], [A, 50, A, 1], [A, 50, A, 2]]},
+    {"name": "full_times_50", "ref": SLT + "136-146", "join_type": "Full", "left": TA1, "right": TA2, "on": [[0, 0]], "filter": [">", ["*", Rr(1), 50], L(1)],
+     "expected": [[A, 100, N, N], [A, 100, N, N], [A, 50, A, 2], [A, 50, N, N], ["Bob", 1, N, N], [N, N, A, 1], [N, N, A, 1], [N, N, A, 2]]},
+    {"name": "full_plus_50", "ref": SLT + "148-157", "join_type": "Full", "left": TA1, "right": TA2, "on": [[0, 0]], "filter": [">", L(1), ["+", Rr(1), 50]],
+     "expected": [[A, 100, A, 1], [A, 100, A, 2], [A, 50, N, N], [A, 50, N, N], ["Bob", 1, N, N], [N, N, A, 1], [N, N, A, 2]]},
+    {"name": "inner_int_ge", "ref": SLT + "180-185", "join_type": "Inner", "left": TB1, "right": TB2, "on": [[0, 0]], "filter": [">=", L(2), Rr(2)], "project": [0, 2, 5],
+     "expected": [[22, 2, 1], [44, 4, 3]]},
+    {"name": "equijoin_multiple_condition_ordering", "ref": SLT + "187-193", "join_type": "Inner", "left": TB1, "right": TB2, "on": [[0, 0]], "filter": ["!=", L(1), Rr(1)], "project": [0, 1, 4],
+     "expected": [[11, "a", "z"], [22, "b", "y"], [44, "d", "x"]]},
+    {"name": "equijoin_right_and_condition_from_left", "ref": SLT + "195-202", "join_type": "Right", "left": TB1, "right": TB2, "on": [[0, 0]], "filter": [">=", L(0), 22], "project": [0, 1, 4],
+     "expected": [[22, "b", "y"], [44, "d", "x"], [N, N, "w"], [N, N, "z"]]},
+    {"name": "equijoin_left_and_condition_from_left", "ref": SLT + "204-211", "join_type": "Left", "left": TB1, "right": TB2, "on": [[0, 0]], "filter": [">=", L(0), 44], "project": [0, 1, 4],
+     "expected": [[11, "a", N], [22, "b", N], [33, "c", N], [44, "d", "x"]]},
+    {"name": "equijoin_left_and_condition_from_both", "ref": SLT + "213-220", "join_type": "Left", "left": TB1, "right": TB2, "on": [[0, 0]], "filter": [">=", L(2), Rr(2)], "project": [0, 2, 5],
+     "expected": [[11, 1, N], [22, 2, 1], [33, 3, N], [44, 4, 3]]},
+    {"name": "equijoin_right_and_condition_from_right", "ref": SLT + "222-229", "join_type": "Right", "left": TB1, "right": TB2, "on": [[0, 0]], "filter": [">=", Rr(0), 22], "project": [0, 1, 4],
+     "expected": [[22, "b", "y"], [44, "d", "x"], [N, N, "w"], [N, N, "z"]]},
+    {"name": "equijoin_right_and_condition_from_both", "ref": SLT + "231-238", "join_type": "Right", "left": TB1, "right": TB2, "on": [[0, 0]], "filter": ["<=", Rr(2), L(2)], "project": [2, 5, 3],
+     "expected": [[2, 1, 22], [4, 3, 44], [N, 3, 11], [N, 3, 55]]},
+    {"name": "equijoin_full_and_condition_from_both", "ref": SLT + "250-259", "join_type": "Full", "left": TB1, "right": TB2, "on": [[0, 0]], "filter": ["<=", Rr(2), L(2)],
+     "expected": [[11, "a", 1, N, N, N], [22, "b", 2, 22, "y", 1], [33, "c", 3, N, N, N], [44, "d", 4, 44, "x", 3], [N, N, N, 11, "z", 3], [N, N, N, 55, "w", 3]]},
+]
 sort = [
     {"name": "test_in_mem_sort", "ref": S + "1022-1049 (test::scan_partitioned(4): 4 partitions of make_partition(100), column i = 0..100)", "type": "int32",
      "partitions": [list(range(100))] * 4, "descending": False, "nulls_first": True, "expected_rows": 400, "expected_batches": 1},
@@ -194,6 +239,6 @@ repartition = [
     {"name": "many_to_many_round_robin", "ref": R + "989-1007", "inputs": [50, 50, 50], "scheme": "RoundRobinBatch", "n": 5, "expected_batches": [30, 30, 30, 30, 30]},
     {"name": "many_to_many_hash_partition", "ref": R + "1010-1033", "inputs": [50, 50, 50], "scheme": "Hash", "n": 8, "expected_total_rows": 8 * 50 * 3},
 ]
-json.dump({"binary": cases, "in_list": in_list, "nested_loop_join": nlj, "sort_merge_join": smj, "sort_merge_join_full": smj_full, "sort": sort, "repartition": {"batch": {"ref": R + "1440-1447 create_batch", "type": "uint32", "column": "c0", "values": [1, 2, 3, 4, 5, 6, 7, 8]}, "cases": repartition}},
+json.dump({"binary": cases, "in_list": in_list, "nested_loop_join": nlj, "sort_merge_join": smj, "sort_merge_join_full": smj_full, "sort_merge_join_filter": smj_filter, "sort": sort, "repartition": {"batch": {"ref": R + "1440-1447 create_batch", "type": "uint32", "column": "c0", "values": [1, 2, 3, 4, 5, 6, 7, 8]}, "cases": repartition}},
           open(__file__.rsplit("/", 1)[0] + "/unit_vectors.json", "w"), indent=1)
 print(len(cases), "binary cases,", len(in_list), "in_list cases")
