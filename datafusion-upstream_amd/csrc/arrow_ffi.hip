@@ -84,11 +84,21 @@ static void export_one(dfgpu_ctx* ctx, const dfgpu_array* a, struct ArrowArray* 
   int64_t n = a->length;
   int32_t vt = a->type == DFGPU_DICTIONARY ? a->key_type : a->type;
   size_t vbytes = a->type == DFGPU_UTF8 ? (size_t)a->values_bytes : (vt == DFGPU_BOOL ? (size_t)(n + 7) / 8 : (size_t)n * type_width(vt));
-  void* hv = calloc(1, vbytes + 64); pr->bufs.push_back(hv);
-  uint8_t* hval = nullptr; int32_t* hoff = nullptr;
+  uint8_t* hval = nullptr; int32_t* hoff = nullptr; void* hv = nullptr;
   if (a->validity) { hval = (uint8_t*)calloc(1, (size_t)(n + 7) / 8 + 64); pr->bufs.push_back(hval); }
   if (a->type == DFGPU_UTF8) { hoff = (int32_t*)calloc((size_t)n + 1 + 16, 4); pr->bufs.push_back(hoff); }
-  dfgpu_status st = dfgpu_array_export_host(ctx, a, hv, hval, hoff);
+  dfgpu_status st;
+  if (a->type == DFGPU_UTF8) {
+    // the bytes of THIS array are offsets[0] .. offsets[n] of its value buffer (a slice shares its parent's buffer; values_bytes is the parent's): offsets first, then that range
+    st = dfgpu_array_export_host(ctx, a, nullptr, hval, hoff);
+    const int32_t first = n ? hoff[0] : 0, last = n ? hoff[n] : 0;
+    vbytes = (size_t)(last - first); hv = calloc(1, vbytes + 64); pr->bufs.push_back(hv);
+    if (st == DFGPU_OK && vbytes) { if (hipMemcpy(hv, (const char*)a->values->ptr + first, vbytes, hipMemcpyDeviceToHost) != hipSuccess) { st = DFGPU_INTERNAL; ctx->err = "export_arrow: copy of string bytes failed"; } }
+    for (int64_t i = 0; i <= n && first; i++) hoff[i] -= first;
+  } else {
+    hv = calloc(1, vbytes + 64); pr->bufs.push_back(hv);
+    st = dfgpu_array_export_host(ctx, a, hv, hval, hoff);
+  }
   if (st != DFGPU_OK) { for (void* b : pr->bufs) free(b); delete pr; fail(st, "%s", ctx->err.c_str()); }
   int64_t nulls = 0;
   if (hval) { for (int64_t i = 0; i < n; i++) nulls += !((hval[i >> 3] >> (i & 7)) & 1); if (n & 7) hval[(n - 1) >> 3] &= (uint8_t)((1u << (n & 7)) - 1); }

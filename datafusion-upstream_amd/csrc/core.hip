@@ -188,9 +188,32 @@ static void or_bits(dfgpu_ctx* ctx, uint64_t* dst, int64_t dst_off, const uint64
   hipLaunchKernelGGL(k_or_bits, dim3(grid_for(words, BLOCK)), dim3(BLOCK), 0, ctx->stream, dst, dst_off, src, n);
   KERNEL_CHECK();
 }
-__global__ void k_rebase_offsets(const int32_t* src, int32_t* dst, int64_t n, int32_t delta) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = src[i] + delta;
+// concat of Utf8 arrays.  An input's bytes are offsets[0] .. offsets[len] of its value buffer: a slice starts above 0, and values_bytes (what the host knows) is only an upper
+// bound of the end.  Copying values_bytes per input and shifting the offsets by a running sum of them (what this did before) leaves a gap between two inputs, and the shared
+// offset entry between them cannot say so: the last string of the first input swallowed the gap.  The bases are therefore computed on the device from the offsets themselves.
+struct Utf8Part { const int32_t* offsets; const uint8_t* values; int64_t len; int64_t row; };
+__global__ void k_concat_utf8_bases(const Utf8Part* parts, int n, int32_t* first, int32_t* base) {      // one thread: n is the number of batches, not of rows
+  if (blockIdx.x || threadIdx.x) return;
+  int64_t run = 0;
+  for (int i = 0; i < n; i++) { const int32_t f = parts[i].len ? parts[i].offsets[0] : 0, l = parts[i].len ? parts[i].offsets[parts[i].len] : 0; first[i] = f; base[i] = (int32_t)run; run += l - f; }
+  base[n] = (int32_t)run;
+}
+__global__ void __launch_bounds__(BLOCK) k_concat_utf8_part(const Utf8Part* parts, int i, const int32_t* first, const int32_t* base, int32_t* out_offsets, uint8_t* out_values) {
+  const Utf8Part p = parts[i]; const int32_t f = first[i], b = base[i]; const int64_t used = (int64_t)base[i + 1] - b;
+  const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x, stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t k = t; k <= p.len; k += stride) out_offsets[p.row + k] = p.offsets[k] - f + b;           // entry row + len == the next part's entry row: both write the same value
+  // 16 output bytes per step, aligned in the output; the source is read byte-wise (its alignment relative to the output is arbitrary)
+  uint8_t* dst = out_values + b; const uint8_t* src = p.values + f;
+  const int64_t head = min(used, (int64_t)((16 - ((uintptr_t)dst & 15)) & 15));
+  for (int64_t k = t; k < head; k += stride) dst[k] = src[k];
+  const int64_t chunks = (used - head) >> 4;
+  for (int64_t c = t; c < chunks; c += stride) {
+    const uint8_t* q = src + head + (c << 4); uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) w[j] = (uint32_t)q[4 * j] | ((uint32_t)q[4 * j + 1] << 8) | ((uint32_t)q[4 * j + 2] << 16) | ((uint32_t)q[4 * j + 3] << 24);
+    *(uint4*)(dst + head + (c << 4)) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  for (int64_t k = head + (chunks << 4) + t; k < used; k += stride) dst[k] = src[k];
 }
 __global__ void k_popcount(const uint64_t* bits, int64_t n, unsigned long long* total) {
   int64_t nw = (n + 63) >> 6; unsigned long long c = 0;
@@ -308,6 +331,8 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
       std::lock_guard<std::mutex> l(*ctx->alloc_mu); for (auto& x : *ctx->free_blocks) (void)hipFree(x.second); ctx->free_blocks->clear(); ctx->cached_bytes = 0;
     }
     else if (k == "agg_spill_state_bytes") ctx->agg_spill_state_bytes = value;
+    else if (k == "sort_spill_bytes") ctx->sort_spill_bytes = value;
+    else if (k == "sort_spill_ranges") { if (value < 1 || value > 4096) fail(DFGPU_INVALID_ARGUMENT, "sort_spill_ranges: 1 .. 4096"); ctx->sort_spill_ranges = value; }
     else if (k == "agg_spill_ranges") { if (value < 1 || value > 4096) fail(DFGPU_INVALID_ARGUMENT, "agg_spill_ranges: 1 .. 4096"); ctx->agg_spill_ranges = value; }
     else if (k == "collect_metrics") ctx->collect_metrics = value != 0;
     else if (k == "agg_partitioned") ctx->agg_partitioned = value != 0;
@@ -341,6 +366,8 @@ dfgpu_status dfgpu_ctx_get_option(dfgpu_ctx* ctx, const char* key, int64_t* out)
     else if (k == "sort_packed_keys") *out = ctx->sort_packed_keys;
     else if (k == "memory_limit") *out = ctx->memory_limit;
     else if (k == "agg_spill_state_bytes") *out = ctx->agg_spill_state_bytes;
+    else if (k == "sort_spill_bytes") *out = ctx->sort_spill_bytes;
+    else if (k == "sort_spill_ranges") *out = ctx->sort_spill_ranges;
     else if (k == "agg_spill_ranges") *out = ctx->agg_spill_ranges;
     else if (k == "collect_metrics") *out = ctx->collect_metrics;
     else if (k == "agg_preaggregate_distinct") *out = ctx->pa_last_distinct;      // read only
@@ -572,20 +599,30 @@ dfgpu_status dfgpu_concat(dfgpu_ctx* ctx, const dfgpu_array* const* arrays, int3
     else if (vt == DFGPU_BOOL) o->values = alloc_buffer(ctx, bitmap_bytes(total), true);
     else o->values = alloc_buffer(ctx, (size_t)total * w);
     if (any_validity) o->validity = alloc_buffer(ctx, bitmap_bytes(total), true); else o->null_count = 0;
-    int64_t row = 0, byte = 0;
+    int64_t row = 0;
+    BufferPtr dparts, dbases;
+    if (f->type == DFGPU_UTF8) {               // o->values_bytes stays the upper bound sum(values_bytes): the exact total is offsets[total], known to the device
+      if (total_bytes > 0x7FFFFFF0ll) fail(DFGPU_NOT_IMPLEMENTED, "concat of Utf8 columns above 2^31 bytes");
+      std::vector<Utf8Part> parts; int64_t r = 0;
+      for (int i = 0; i < n; i++) { parts.push_back(Utf8Part{arrays[i]->length ? (const int32_t*)arrays[i]->offsets->ptr : nullptr, arrays[i]->values ? (const uint8_t*)arrays[i]->values->ptr : nullptr, arrays[i]->length, r}); r += arrays[i]->length; }
+      dparts = alloc_buffer(ctx, parts.size() * sizeof(Utf8Part)); dbases = alloc_buffer(ctx, (size_t)(2 * n + 2) * 4);
+      HIP_CHECK(hipMemcpyAsync(dparts->ptr, parts.data(), parts.size() * sizeof(Utf8Part), hipMemcpyHostToDevice, ctx->stream));
+      HIP_CHECK(hipStreamSynchronize(ctx->stream));          // `parts` is a pageable host vector about to go out of scope
+      int32_t* first = (int32_t*)dbases->ptr; int32_t* base = first + n;
+      hipLaunchKernelGGL(k_concat_utf8_bases, dim3(1), dim3(1), 0, ctx->stream, (const Utf8Part*)dparts->ptr, n, first, base);
+      for (int i = 0; i < n; i++) if (arrays[i]->length)
+        hipLaunchKernelGGL(k_concat_utf8_part, dim3(grid_for(std::max<int64_t>(arrays[i]->length + 1, arrays[i]->values_bytes / 16 + 1), BLOCK, 2048)), dim3(BLOCK), 0, ctx->stream,
+                           (const Utf8Part*)dparts->ptr, i, (const int32_t*)first, (const int32_t*)base, (int32_t*)o->offsets->ptr, (uint8_t*)o->values->ptr);
+      KERNEL_CHECK();
+    }
     for (int i = 0; i < n; i++) {
       const dfgpu_array* a = arrays[i];
       if (a->length == 0) continue;
       if (f->type == DFGPU_UTF8) {
-        if (a->values_bytes) HIP_CHECK(hipMemcpyAsync((char*)o->values->ptr + byte, a->values->ptr, (size_t)a->values_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-        // offsets of a slice may not start at 0: rebase by (byte - first offset) on device
-        hipLaunchKernelGGL(k_rebase_offsets, dim3(grid_for(a->length + 1, BLOCK)), dim3(BLOCK), 0, ctx->stream,
-                           (const int32_t*)a->offsets->ptr, (int32_t*)o->offsets->ptr + row, a->length + 1, (int32_t)byte);
-        KERNEL_CHECK();
       } else if (vt == DFGPU_BOOL) or_bits(ctx, (uint64_t*)o->values->ptr, row, (const uint64_t*)a->values->ptr, a->length);
       else HIP_CHECK(hipMemcpyAsync((char*)o->values->ptr + (size_t)row * w, a->values->ptr, (size_t)a->length * w, hipMemcpyDeviceToDevice, ctx->stream));
       if (any_validity) or_bits(ctx, (uint64_t*)o->validity->ptr, row, a->validity ? (const uint64_t*)a->validity->ptr : nullptr, a->length);
-      row += a->length; byte += a->values_bytes;
+      row += a->length;
     }
     if (f->dictionary) { o->dictionary = f->dictionary; dfgpu_array_retain(f->dictionary); }
     *out = h.release();

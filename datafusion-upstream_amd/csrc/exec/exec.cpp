@@ -240,6 +240,7 @@ using PlanPtr = std::shared_ptr<const Plan>;
 // operator enqueued (dfgpu_span_*), resolved when the metrics are read; elapsed_compute excludes the children's spans.
 struct Metrics {
   std::mutex mu; int64_t output_rows = 0, output_batches = 0;
+  int64_t spill_count = 0, spilled_bytes = 0, spilled_rows = 0;        // SortExec (sorts/sort.rs:229-231, 306-312)
   struct Open { dfgpu_ctx* c; int64_t id; int which; };        // which: 0 inclusive compute, 1 build, 2 join, 3 repartition
   std::vector<Open> open; int64_t ns[4] = {0, 0, 0, 0};
   void resolve() {
@@ -1147,6 +1148,14 @@ struct CountDistinct {
   }
 };
 
+// what a spill keeps in host memory: Arrow arrays (dfgpu_array_export_arrow), one piece per key range of a sorted run (AggregateExec's state, SortExec's input)
+struct HostColumn { ArrowArray a{}; ArrowSchema s{}; bool live = false;
+  HostColumn() = default; HostColumn(const HostColumn&) = delete; HostColumn& operator=(const HostColumn&) = delete;
+  HostColumn(HostColumn&& o) noexcept : a(o.a), s(o.s), live(o.live) { o.live = false; }
+  ~HostColumn() { if (live) { if (a.release) a.release(&a); if (s.release) s.release(&s); } } };
+struct SpillPiece { std::vector<HostColumn> cols; int64_t rows = 0; };
+struct SpillRun { std::vector<SpillPiece> pieces; };
+
 struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggregateStream row_hash.rs:423-662
   int mode; std::vector<ExprPtr> gexprs; std::vector<std::string> gnames; std::vector<AggExpr> aggs; PlanPtr input; mutable SchemaPtr sch; mutable std::mutex mu;
   // PhysicalGroupBy grouping sets (aggregates/mod.rs:103-160): sets[s][i] != 0 = key i is replaced by null_exprs[i] in set s; empty = the single set of all keys
@@ -1440,12 +1449,6 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
   // GroupOrdering::Full.  Here a spill is the sorted state batch cut into key RANGES (splitter keys fixed at the first spill, so every spill and the remainder are cut at
   // the same keys) and copied to host memory as Arrow arrays; at the end range r of every spill and of the remainder is brought back, merged (merge_batch) in a fresh
   // table, ordered by key and emitted -- ranges in key order, so the output is in key order like the reference's, and the device only ever holds one range's groups.
-  struct HostColumn { ArrowArray a{}; ArrowSchema s{}; bool live = false;
-    HostColumn() = default; HostColumn(const HostColumn&) = delete; HostColumn& operator=(const HostColumn&) = delete;
-    HostColumn(HostColumn&& o) noexcept : a(o.a), s(o.s), live(o.live) { o.live = false; }
-    ~HostColumn() { if (live) { if (a.release) a.release(&a); if (s.release) s.release(&s); } } };
-  struct SpillPiece { std::vector<HostColumn> cols; int64_t rows = 0; };
-  struct SpillRun { std::vector<SpillPiece> pieces; };
   struct SpillState { std::vector<SpillRun> runs; std::vector<ArrayRef> splitters; int64_t limit = 0, ranges = 16, spilled_rows = 0, spilled_bytes = 0; };
   int64_t state_bytes(const AggState& S) const { int64_t b = S.groups.g ? dfgpu_groups_size(S.groups.g) : 0; for (auto& a : S.accs) if (a.a) b += dfgpu_acc_size(a.a); return b; }
   void new_accs(AggState& S) const {
@@ -1636,9 +1639,102 @@ struct SortExec : Plan {          // sorts/sort.rs:719-733; sort_batch :584-609
   const char* name() const override { return "SortExec"; }
   SchemaPtr schema() const override { return input->schema(); }
   int partitions() const override { return preserve ? input->partitions() : 1; }
+  // ---- spill (ExternalSorter, sorts/sort.rs:208-400).  The reference keeps the input batches in memory until the reservation fails, then sorts them and writes the sorted run
+  // to an IPC file; at the end the runs and the batches still in memory go through the streaming merge.  Here, with the context option "sort_spill_bytes" > 0 (and no fetch:
+  // a TopK keeps `fetch` rows, it never spills), the batches are kept until they exceed that many bytes; then they are sorted, the sorted run is cut at SPLITTER keys
+  // ("sort_spill_ranges" - 1 rows of the first run at equal distances, the same keys for every later run) and the pieces are copied to host memory as Arrow arrays.  At the
+  // end range r of every run is brought back, concatenated in run order and sorted once more (stable: equal keys keep their arrival order, as in the in-memory sort); the
+  // ranges come out in key order, one batch each, so the result is the sorted input and the device never holds more than the budget plus one range.
+  struct Spilled : Stream {
+    const SortExec* op; TaskContext tc; std::vector<SpillRun> runs; size_t r = 0;
+    Spilled(const SortExec* o, TaskContext t, std::vector<SpillRun> rs) : op(o), tc(t), runs(std::move(rs)) {}
+    bool next(Batch& out) override {
+      const size_t R = runs.empty() ? 0 : runs[0].pieces.size();
+      for (; r < R; r++) {
+        std::vector<Batch> parts;
+        for (auto& run : runs) { SpillPiece& pc = run.pieces[r]; if (pc.rows <= 0) continue;
+          Batch b; b.schema = op->schema(); b.base_rows = pc.rows;
+          for (auto& h : pc.cols) { dfgpu_array* a = nullptr; tc.check(dfgpu_array_import_arrow(tc.ctx, &h.a, &h.s, &a)); b.cols.push_back(col_of(ArrayRef::adopt(a))); }
+          pc.cols.clear(); parts.push_back(std::move(b)); }
+        Batch all; if (parts.empty() || !concat_batches(tc, parts, &all) || all.base_rows <= 0) continue;
+        parts.clear();
+        std::vector<ArrayRef> keys; std::vector<const dfgpu_array*> kp;
+        for (auto& e : op->exprs) { keys.push_back(into_array(tc, e->eval(tc, all), all.base_rows)); kp.push_back(keys.back().a); }
+        out = sorted_batch(tc, all, op->exprs, kp, op->desc, op->nulls_first, -1); r++; return true;
+      }
+      return false;
+    }
+  };
+  // first row of every range in a batch sorted on `keys` (ranges + 1 entries): splitters and rows are concatenated, splitters first, and ranked by the stable sort -- a splitter
+  // lands in front of the rows equal to it, so (its rank - its own number) rows are strictly before it
+  std::vector<int64_t> range_bounds(const TaskContext& tc, std::vector<ArrayRef>& splitters, const std::vector<ArrayRef>& keys, int64_t K) const {
+    const int64_t rows = keys[0].len(); const size_t nk = keys.size();
+    if (splitters.empty()) {
+      std::vector<uint32_t> at; for (int64_t j = 1; j < K; j++) at.push_back((uint32_t)(rows * j / K));
+      if (at.empty()) at.push_back(0);               // one range: a splitter in front of everything keeps the code below uniform (range 0 is empty, range 1 is the run)
+      dfgpu_array_desc d{}; d.type = DFGPU_UINT32; d.length = (int64_t)at.size(); d.values = at.data(); dfgpu_array* ia = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &d, &ia)); ArrayRef ix = ArrayRef::adopt(ia);
+      for (size_t k = 0; k < nk; k++) splitters.push_back(take(tc, keys[k], ix));
+    }
+    const int64_t ns = splitters[0].len();
+    std::vector<ArrayRef> both; std::vector<const dfgpu_array*> bp;
+    for (size_t k = 0; k < nk; k++) { const dfgpu_array* two[2] = { splitters[k].a, keys[k].a }; dfgpu_array* c = nullptr; tc.check(dfgpu_concat(tc.ctx, two, 2, &c)); both.push_back(ArrayRef::adopt(c)); bp.push_back(both.back().a); }
+    dfgpu_array* idx = nullptr; tc.check(dfgpu_sort_to_indices(tc.ctx, bp.data(), desc.data(), nulls_first.data(), (int32_t)nk, -1, &idx)); ArrayRef order = ArrayRef::adopt(idx);
+    uint32_t nsv = (uint32_t)ns; dfgpu_array_desc ld{}; ld.type = DFGPU_UINT32; ld.length = 1; ld.values = &nsv; dfgpu_array* la = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &ld, &la)); ArrayRef lit = ArrayRef::adopt(la);
+    dfgpu_array* m = nullptr; tc.check(dfgpu_binary(tc.ctx, DFGPU_OP_LT, order.a, 0, lit.a, 1, &m)); ArrayRef is_split = ArrayRef::adopt(m);
+    ArrayRef pos = mask_indices(tc, is_split);
+    if (pos.len() != ns) fail(DFGPU_INTERNAL, "SortExec spill: %lld splitter positions for %lld splitters", (long long)pos.len(), (long long)ns);
+    std::vector<uint32_t> hp((size_t)ns); tc.check(dfgpu_array_export_host(tc.ctx, pos.a, hp.data(), nullptr, nullptr));
+    std::vector<int64_t> bounds; bounds.push_back(0);
+    for (int64_t j = 0; j < ns; j++) bounds.push_back((int64_t)hp[(size_t)j] - j);      // the splitters are sorted among themselves (rows of a sorted run) and the sort is stable
+    bounds.push_back(rows);
+    return bounds;
+  }
+  static int64_t batch_bytes(const Batch& b) {
+    int64_t t = 0;
+    for (auto& c : b.cols) { dfgpu_array_desc d; if (!c.arr.a) continue; dfgpu_array_describe(c.arr.a, &d);
+      const int64_t w = d.type == DFGPU_UTF8 ? 4 : d.type == DFGPU_DICTIONARY ? 4 : d.type == DFGPU_BOOL ? 1 : d.type == DFGPU_DECIMAL128 ? 16 : d.type == DFGPU_INT32 || d.type == DFGPU_UINT32 || d.type == DFGPU_DATE32 || d.type == DFGPU_FLOAT32 ? 4 : d.type == DFGPU_INT8 || d.type == DFGPU_UINT8 ? 1 : d.type == DFGPU_INT16 || d.type == DFGPU_UINT16 ? 2 : 8;
+      t += d.length * w + (d.type == DFGPU_UTF8 ? d.values_bytes : 0) + (d.validity ? (d.length + 7) / 8 : 0); }
+    return t;
+  }
+  void spill_run(const TaskContext& tc, std::vector<Batch>& mem, std::vector<SpillRun>& runs, std::vector<ArrayRef>& splitters, int64_t K) const {
+    Batch all; if (mem.empty() || !concat_batches(tc, mem, &all) || all.base_rows <= 0) { mem.clear(); return; }
+    mem.clear();
+    Batch sorted;
+    { std::vector<ArrayRef> keys; std::vector<const dfgpu_array*> kp;
+      for (auto& e : exprs) { keys.push_back(into_array(tc, e->eval(tc, all), all.base_rows)); kp.push_back(keys.back().a); }
+      sorted = sorted_batch(tc, all, exprs, kp, desc, nulls_first, -1); all = Batch(); }
+    std::vector<ArrayRef> cols; for (auto& c : sorted.cols) cols.push_back(col_get(tc, c));
+    Batch view; view.schema = sorted.schema; view.base_rows = sorted.base_rows; for (auto& c : cols) view.cols.push_back(col_of(c));
+    std::vector<ArrayRef> skeys; for (auto& e : exprs) skeys.push_back(into_array(tc, e->eval(tc, view), view.base_rows));
+    std::vector<int64_t> bounds = range_bounds(tc, splitters, skeys, K);
+    SpillRun run; run.pieces.resize(bounds.size() - 1); int64_t bytes = 0;
+    for (size_t r = 0; r + 1 < bounds.size(); r++) {
+      const int64_t lo = bounds[r], len = bounds[r + 1] - bounds[r]; run.pieces[r].rows = len; if (len <= 0) continue;
+      for (auto& c : cols) { dfgpu_array* sl = nullptr; tc.check(dfgpu_array_slice(tc.ctx, c.a, lo, len, &sl)); ArrayRef piece = ArrayRef::adopt(sl);
+        run.pieces[r].cols.emplace_back(); HostColumn& h = run.pieces[r].cols.back(); tc.check(dfgpu_array_export_arrow(tc.ctx, piece.a, &h.a, &h.s)); h.live = true; }
+    }
+    bytes = batch_bytes(view);
+    { std::lock_guard<std::mutex> l(met->mu); met->spill_count++; met->spilled_rows += view.base_rows; met->spilled_bytes += bytes; }
+    runs.push_back(std::move(run));
+  }
   std::unique_ptr<Stream> execute(int partition, const TaskContext& tc) const override {
+    int64_t budget = 0, K = 16; dfgpu_ctx_get_option(tc.ctx, "sort_spill_bytes", &budget); dfgpu_ctx_get_option(tc.ctx, "sort_spill_ranges", &K);
     std::vector<Batch> in;
-    if (preserve) drain(input, partition, tc, in); else for (int p = 0; p < input->partitions(); p++) drain(input, p, tc, in);
+    if (budget > 0 && fetch < 0 && !exprs.empty()) {
+      std::vector<SpillRun> runs; std::vector<ArrayRef> splitters; int64_t held = 0;
+      auto pull = [&](int p) {
+        auto s = input->run(p, tc); Batch b;
+        while (s->next(b)) { Batch m = materialize(tc, b); for (auto& c : m.cols) c = col_of(col_get(tc, c)); held += batch_bytes(m); in.push_back(std::move(m)); b = Batch();
+          if (held > budget) { spill_run(tc, in, runs, splitters, K); held = 0; } }
+      };
+      if (preserve) pull(partition); else for (int p = 0; p < input->partitions(); p++) pull(p);
+      if (!runs.empty()) {                               // what is still in memory becomes the last run (sort.rs:283-313 merges it with the spills the same way)
+        spill_run(tc, in, runs, splitters, K);
+        return std::unique_ptr<Stream>(new Spilled(this, tc, std::move(runs)));
+      }
+    } else {
+      if (preserve) drain(input, partition, tc, in); else for (int p = 0; p < input->partitions(); p++) drain(input, p, tc, in);
+    }
     std::vector<Batch> outv; Batch b;
     if (!in.empty() && concat_batches(tc, in, &b) && b.base_rows > 0) {
       std::vector<ArrayRef> keys; std::vector<const dfgpu_array*> kp;
@@ -1936,6 +2032,7 @@ static void metrics_lines(const std::shared_ptr<const Plan>& p, int depth, std::
   char line[512]; int k = snprintf(line, sizeof line, "%d %s output_rows=%lld output_batches=%lld elapsed_compute=%lld", depth, p->name(), (long long)m.output_rows, (long long)m.output_batches, (long long)self);
   if (!strcmp(p->name(), "HashJoinExec")) k += snprintf(line + k, sizeof line - (size_t)k, " build_time=%lld join_time=%lld", (long long)m.ns[1], (long long)m.ns[2]);
   if (!strcmp(p->name(), "RepartitionExec")) k += snprintf(line + k, sizeof line - (size_t)k, " repartition_time=%lld", (long long)m.ns[3]);
+  if (!strcmp(p->name(), "SortExec")) k += snprintf(line + k, sizeof line - (size_t)k, " spill_count=%lld spilled_bytes=%lld spilled_rows=%lld", (long long)m.spill_count, (long long)m.spilled_bytes, (long long)m.spilled_rows);
   out += line; out += "\n"; out += below;
   if (inclusive_out) *inclusive_out = m.ns[0];
   (void)inclusive;
