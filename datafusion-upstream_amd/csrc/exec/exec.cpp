@@ -1746,10 +1746,13 @@ struct SortExec : Plan {          // sorts/sort.rs:719-733; sort_batch :584-609
 };
 
 // ------------------------------------------------------------------ SortPreservingMergeExec
-// sorts/sort_preserving_merge.rs:67-120, execute :186-247; streaming_merge / loser tree (sorts/merge.rs:38-110) picks, among
-// streams whose heads compare equal, the lower stream index.  On the device the k sorted input partitions are concatenated in
-// partition order and ranked by the STABLE radix sort of dfgpu_sort_to_indices: for inputs that are sorted on `exprs` (the
-// operator's precondition) that is the same row order as the k-way merge, ties included, in one pass over whole partitions.
+// sorts/sort_preserving_merge.rs:67-120, execute :186-247; streaming_merge / loser tree (sorts/merge.rs:38-110) picks, among streams whose heads compare equal, the lower
+// stream index, and holds one batch per input.  On the device a merge step works on whole CHUNKS: every input is loaded up to its share of "spm_merge_rows" rows (a ctx option,
+// 2^25 by default); the loaded rows of all inputs are concatenated in input order and ranked by the stable radix sort of dfgpu_sort_to_indices, which for sorted inputs IS the
+// k-way merge order, ties included.  If every input ended inside its chunk that is the whole answer, in one pass (the usual in-memory case).  Otherwise only the rows that
+// no unloaded row can precede may leave: the bound is the smallest (last loaded key, input index) among the inputs that have more to deliver; a copy of that row is put into
+// the concatenation right behind its own input, so the stable sort ranks it behind every loaded row that precedes the first unloaded one and in front of all others -- the rows
+// ranked before it are emitted, the rest of each input (a suffix: the inputs are sorted) stays loaded, and the input that set the bound, now empty, loads its next chunk.
 struct SortPreservingMergeExec : Plan {
   std::vector<ExprPtr> exprs; std::vector<uint8_t> desc, nulls_first; int64_t fetch; PlanPtr input;
   PlanPtr fresh() const override { auto s = std::make_shared<SortPreservingMergeExec>(); s->exprs = exprs; s->desc = desc; s->nulls_first = nulls_first; s->fetch = fetch; s->input = input->fresh(); return s; }
@@ -1757,20 +1760,101 @@ struct SortPreservingMergeExec : Plan {
   const char* name() const override { return "SortPreservingMergeExec"; }
   SchemaPtr schema() const override { return input->schema(); }
   int partitions() const override { return 1; }
+  struct Merge : Stream {
+    const SortPreservingMergeExec* op; TaskContext tc;
+    struct In { std::unique_ptr<Stream> s; std::vector<Batch> loaded; int64_t rows = 0; Batch ahead; bool has_ahead = false, done = false; };
+    std::vector<In> in; int64_t share = 1, emitted = 0; bool finished = false;
+    Merge(const SortPreservingMergeExec* o, TaskContext t) : op(o), tc(t) {
+      const int np = o->input->partitions(); int64_t budget = 0; dfgpu_ctx_get_option(tc.ctx, "spm_merge_rows", &budget); if (budget <= 0) budget = (int64_t)1 << 25;
+      share = std::max<int64_t>(1, budget / np);
+      in.resize((size_t)np); for (int p = 0; p < np; p++) in[(size_t)p].s = o->input->run(p, tc);
+    }
+    // one batch ahead, so that an input whose last batch has been loaded is known to be done (≙ the merge's cursors: `is_finished`)
+    bool pull(In& x, Batch* b) {
+      if (x.has_ahead) { *b = std::move(x.ahead); x.has_ahead = false; return true; }
+      if (x.done) return false;
+      Batch t; while (x.s->next(t)) { Batch m = materialize(tc, t); if (m.base_rows > 0) { *b = std::move(m); return true; } }
+      x.done = true; return false;
+    }
+    void fill(In& x) {
+      Batch b;
+      while (x.rows < share && pull(x, &b)) { x.rows += b.base_rows; x.loaded.push_back(std::move(b)); }
+      if (!x.done && !x.has_ahead) { Batch n; if (pull(x, &n)) { x.ahead = std::move(n); x.has_ahead = true; } }
+    }
+    bool more(const In& x) const { return x.has_ahead || !x.done; }
+    Batch one(In& x) { Batch o; if (x.loaded.size() == 1) o = std::move(x.loaded[0]); else concat_batches(tc, x.loaded, &o); x.loaded.clear(); for (auto& c : o.cols) c = col_of(col_get(tc, c)); return o; }
+    static Batch rows_of(const TaskContext& tc, const Batch& b, int64_t off, int64_t len) {
+      Batch o; o.schema = b.schema; o.base_rows = len;
+      for (auto& c : b.cols) { dfgpu_array* sl = nullptr; tc.check(dfgpu_array_slice(tc.ctx, c.arr.a, off, len, &sl)); o.cols.push_back(col_of(ArrayRef::adopt(sl))); }
+      return o;
+    }
+    ArrayRef order_of(Batch& all, int64_t limit) {
+      std::vector<ArrayRef> keys; std::vector<const dfgpu_array*> kp;
+      for (auto& e : op->exprs) { keys.push_back(into_array(tc, e->eval(tc, all), all.base_rows)); kp.push_back(keys.back().a); }
+      dfgpu_array* idx = nullptr; tc.check(dfgpu_sort_to_indices(tc.ctx, kp.data(), op->desc.data(), op->nulls_first.data(), (int32_t)kp.size(), limit, &idx)); return ArrayRef::adopt(idx);
+    }
+    Batch gather(const Batch& all, const ArrayRef& ix) { Batch o; o.schema = all.schema; o.base_rows = ix.len(); for (auto& c : all.cols) o.cols.push_back(col_of(take(tc, c.arr, ix))); return o; }
+    bool next(Batch& out) override {
+      while (!finished) {
+        for (auto& x : in) if (x.rows == 0) fill(x);
+        std::vector<size_t> act; for (size_t p = 0; p < in.size(); p++) if (in[p].rows > 0) act.push_back(p);
+        if (act.empty()) { finished = true; break; }
+        const int64_t left = op->fetch >= 0 ? op->fetch - emitted : -1;
+        if (left == 0) { finished = true; break; }
+        std::vector<Batch> parts; std::vector<int64_t> off; int64_t total = 0;
+        for (size_t p : act) { parts.push_back(one(in[p])); in[p].loaded.clear(); off.push_back(total); total += parts.back().base_rows; }
+        bool bounded = false; for (size_t p : act) bounded |= more(in[p]);
+        if (!bounded) {                                    // every input ended inside its chunk: what is loaded is all there is
+          Batch all; if (parts.size() == 1) all = std::move(parts[0]); else concat_batches(tc, parts, &all);
+          for (size_t p : act) in[p].rows = 0;
+          ArrayRef ix = order_of(all, left);
+          out = gather(all, ix); emitted += out.base_rows; finished = true;
+          if (out.base_rows > 0) return true;
+          break;
+        }
+        // the bound: the smallest (last loaded row, input index) among the inputs with more to come -- ranked by the same stable sort over those rows, in input order
+        size_t bi = 0;
+        { std::vector<Batch> lasts; std::vector<size_t> who;
+          for (size_t k = 0; k < act.size(); k++) if (more(in[act[k]])) { lasts.push_back(rows_of(tc, parts[k], parts[k].base_rows - 1, 1)); who.push_back(k); }
+          if (who.size() == 1) bi = who[0];
+          else { Batch lb; concat_batches(tc, lasts, &lb); ArrayRef o1 = order_of(lb, 1); uint32_t first = 0; tc.check(dfgpu_array_export_host(tc.ctx, o1.a, &first, nullptr, nullptr)); bi = who.at(first); } }
+        // concatenation: inputs in order, the bound row's copy right behind its own input
+        std::vector<Batch> seq; int64_t sentinel = -1, at = 0; std::vector<int64_t> start(act.size());
+        for (size_t k = 0; k < act.size(); k++) { start[k] = at; at += parts[k].base_rows; seq.push_back(parts[k]); if (k == bi) { sentinel = at; at += 1; seq.push_back(rows_of(tc, parts[k], parts[k].base_rows - 1, 1)); } }
+        Batch all; concat_batches(tc, seq, &all); seq.clear();
+        ArrayRef ix = order_of(all, -1);
+        // where the copy landed = how many rows may leave
+        uint32_t sv = (uint32_t)sentinel; dfgpu_array_desc ld{}; ld.type = DFGPU_UINT32; ld.length = 1; ld.values = &sv; dfgpu_array* la = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &ld, &la)); ArrayRef lit = ArrayRef::adopt(la);
+        dfgpu_array* m = nullptr; tc.check(dfgpu_binary(tc.ctx, DFGPU_OP_EQ, ix.a, 0, lit.a, 1, &m)); ArrayRef is_s = ArrayRef::adopt(m);
+        ArrayRef where = mask_indices(tc, is_s); if (where.len() != 1) fail(DFGPU_INTERNAL, "SortPreservingMergeExec: the bound row was ranked %lld times", (long long)where.len());
+        uint32_t cut = 0; tc.check(dfgpu_array_export_host(tc.ctx, where.a, &cut, nullptr, nullptr));
+        dfgpu_array* hd = nullptr; tc.check(dfgpu_array_slice(tc.ctx, ix.a, 0, (int64_t)cut, &hd)); ArrayRef head = ArrayRef::adopt(hd);
+        // rows leaving per input: an input's emitted rows are a prefix of it (it is sorted); the prefix length is the number of its rows ranked before the cut
+        std::vector<int64_t> gone(act.size(), 0);
+        { const dfgpu_array* pk = ix.a; uint8_t no = 0; dfgpu_array* rk = nullptr; tc.check(dfgpu_sort_to_indices(tc.ctx, &pk, &no, &no, 1, -1, &rk)); ArrayRef rank = ArrayRef::adopt(rk);      // argsort of a permutation = its inverse: rank[i] = position of row i
+          uint32_t cv = cut; dfgpu_array_desc cd{}; cd.type = DFGPU_UINT32; cd.length = 1; cd.values = &cv; dfgpu_array* ca = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &cd, &ca)); ArrayRef clit = ArrayRef::adopt(ca);
+          dfgpu_array* bm = nullptr; tc.check(dfgpu_binary(tc.ctx, DFGPU_OP_LT, rank.a, 0, clit.a, 1, &bm)); ArrayRef before = ArrayRef::adopt(bm);
+          for (size_t k = 0; k < act.size(); k++) { dfgpu_array* sl = nullptr; tc.check(dfgpu_array_slice(tc.ctx, before.a, start[k], parts[k].base_rows, &sl)); ArrayRef part = ArrayRef::adopt(sl); tc.check(dfgpu_mask_count(tc.ctx, part.a, &gone[k])); } }
+        Batch o = gather(all, head);
+        for (size_t k = 0; k < act.size(); k++) {
+          In& x = in[act[k]]; const int64_t keep = parts[k].base_rows - gone[k];
+          if (k == bi && keep != 0) fail(DFGPU_INTERNAL, "SortPreservingMergeExec: %lld rows of the bounding input stayed behind", (long long)keep);
+          x.rows = keep; if (keep > 0) x.loaded.push_back(rows_of(tc, parts[k], gone[k], keep));
+        }
+        if (left >= 0 && o.base_rows > left) { o = rows_of(tc, o, 0, left); }
+        emitted += o.base_rows;
+        if (o.base_rows > 0) { out = std::move(o); return true; }
+      }
+      return false;
+    }
+  };
   std::unique_ptr<Stream> execute(int partition, const TaskContext& tc) const override {
     if (partition != 0) fail(DFGPU_INTERNAL, "SortPreservingMergeExec invalid partition %d", partition);
     int np = input->partitions();
     if (np == 0) fail(DFGPU_INTERNAL, "SortPreservingMergeExec requires at least one input partition");
     if (np == 1) return input->run(0, tc);              // bypass (:213-218)
     if (exprs.empty()) fail(DFGPU_INTERNAL, "Sort expressions cannot be empty for streaming merge");      // sorts/streaming_merge.rs
-    std::vector<Batch> in; for (int p = 0; p < np; p++) drain(input, p, tc, in);
-    std::vector<Batch> outv; Batch b;
-    if (!in.empty() && concat_batches(tc, in, &b) && b.base_rows > 0) {
-      std::vector<ArrayRef> keys; std::vector<const dfgpu_array*> kp;
-      for (auto& e : exprs) { keys.push_back(into_array(tc, e->eval(tc, b), b.base_rows)); kp.push_back(keys.back().a); }
-      outv.push_back(sorted_batch(tc, b, exprs, kp, desc, nulls_first, fetch));
-    }
-    return std::unique_ptr<Stream>(new VecStream(std::move(outv)));
+    return std::unique_ptr<Stream>(new Merge(this, tc));
   }
 };
 

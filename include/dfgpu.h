@@ -112,6 +112,7 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
  * row_hash.rs:667-705) or emits early (Partial, :720-733) -- the reservation a MemoryPool would grant the operator; "agg_spill_ranges" (16) == key ranges a spill is cut into;
  * "sort_spill_bytes" (0 = never) == bytes of input SortExec keeps on the device before it sorts them and spills the sorted run to host memory (ExternalSorter,
  * sorts/sort.rs:283-313; not with a fetch); "sort_spill_ranges" (16) == key ranges a run is cut into -- the merge brings one range of every run back at a time;
+ * "spm_merge_rows" (2^25) == rows SortPreservingMergeExec loads over all its inputs per merge step (an input that ends inside its share needs no further step);
  * "collect_metrics" (1/0) == the plan layer records per-operator metrics (dfgpu_plan_metrics);
  * "defer_flag_checks" (1 = enter / 0 = leave a deferred region, nests) == kernel error flags (overflow, divide by zero,
  * cast range, index bounds -- the ArrowError cases of arrow-arith / arrow-cast / arrow-select) are normally checked by the

@@ -310,3 +310,41 @@ def test_lent_device_memory_outlives_its_python_owner_until_the_plan_is_gone(ctx
     del plan, junk
     gc.collect()
     assert device.lent_memory_owners() == before
+
+
+@pytest.mark.parametrize("fetch", [None, 0, 1, 777, 10**9])
+@pytest.mark.parametrize("budget", [64, 1000, 50_000])
+def test_sort_preserving_merge_in_bounded_steps(ctx, task_ctx, budget, fetch):
+    """The k-way merge with `spm_merge_rows` far below the input (sorts/merge.rs:38-110 holds one batch per stream; here one chunk per stream): 7 sorted partitions of
+    uneven length in batches of uneven size, one of them empty, keys with long runs of ties across and inside partitions, NULL keys, a descending second key.  The output is
+    the rows of the stable sort of the partitions concatenated in partition order -- ties: lower partition first, then arrival order (the `src` column shows both) -- which is
+    what the merge's tie rule (lower stream index) produces, checked against an independent numpy model; with the default budget the same plan takes one step."""
+    from dfgpu import physical_plan as ops
+    rng = np.random.default_rng(budget)
+    parts, model = [], []
+    for p, n in enumerate([5000, 1, 0, 12345, 300, 7000, 2500]):
+        k = np.sort(rng.integers(0, 40, n)); null = rng.random(n) < 0.03
+        v = rng.integers(0, 5, n)
+        # sorted on (k ASC NULLS FIRST, v DESC): NULL keys first, then by k, v descending inside a key
+        o = np.lexsort((-v, k, ~null)); k, v, null = k[o], v[o], null[o]
+        t = pa.table({"k": pa.array(k, mask=null), "v": pa.array(v), "src": pa.array(np.arange(n) + p * 10**6)})
+        cuts = [0] + sorted(set(rng.integers(0, n + 1, 6).tolist())) + [n] if n else [0, 0]
+        parts.append([t.slice(a, b - a) for a, b in zip(cuts[:-1], cuts[1:])])
+        model += [((0, 0) if null[i] else (1, int(k[i])), -int(v[i]), p, i) for i in range(n)]
+    schema = ops.batch_from_arrow(ctx, parts[0][0]).schema
+    src = ops.MemoryExec([[ops.batch_from_arrow(ctx, b) for b in bs] for bs in parts], schema)
+    keys = [ops.PhysicalSortExpr(ops.Column("k", 0), False, True), ops.PhysicalSortExpr(ops.Column("v", 1), True, False)]
+    want = [p * 10**6 + i for _, _, p, i in sorted(model)]
+    if fetch is not None:
+        want = want[:fetch]
+    ctx.set_option("spm_merge_rows", budget)
+    try:
+        out = [b.to_arrow() for b in ops.SortPreservingMergeExec(keys, src, fetch=fetch).execute(0, task_ctx)]
+    finally:
+        ctx.set_option("spm_merge_rows", 1 << 25)
+    got = pa.concat_tables(out)["src"].to_pylist() if out else []
+    assert got == want
+    if fetch is None and budget < 50_000:
+        assert len(out) > 3, "several merge steps"
+    one = pa.concat_tables([b.to_arrow() for b in ops.SortPreservingMergeExec(keys, src, fetch=fetch).execute(0, task_ctx)]) if want else None
+    assert (one["src"].to_pylist() if one is not None else []) == want
