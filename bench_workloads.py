@@ -379,8 +379,9 @@ def run(args, ctx=None, emit=True):
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ general-case operators: keys that are neither clustered nor dense
-    if not want or "hash_join" in want or "hash_join_plain" in want or "hash_join_fk5" in want:          # hash_join = both variants; _plain / _fk5 = one of them (profiling passes)
+    if not want or "hash_join" in want or "hash_join_plain" in want or "hash_join_fk5" in want or "hash_join_two_keys" in want:          # hash_join = every variant; _plain / _fk5 / _two_keys = one of them (profiling passes)
         do_plain, do_fk5 = (not want or "hash_join" in want or "hash_join_plain" in want), (not want or "hash_join" in want or "hash_join_fk5" in want)
+        do_two = not want or "hash_join" in want or "hash_join_two_keys" in want
         nb, npr = int(150_000 * args.sf), int(1_500_000 * args.sf)
         bk = torch.randint(0, 2**62, (nb,), generator=g, device="cuda", dtype=torch.int64)
         pk = torch.cat([bk[torch.randint(0, nb, (npr // 5,), generator=g, device="cuda")], torch.randint(0, 2**62, (npr - npr // 5,), generator=g, device="cuda", dtype=torch.int64)])
@@ -414,6 +415,35 @@ def run(args, ctx=None, emit=True):
             del sb, pos, hit
             report("hash_join_sparse_keys_fk5", dt, nd * 5 + npr, rows, round((nd * 5 * 8 + npr * 16) / (nd * 5 + npr), 2), kern, syncs, {"build_rows": nd * 5, "probe_rows": npr, "rows_per_build_key": 5,
                    "result_check": check("hash_join_sparse_keys_fk5", ok, "COUNT(*) and SUM(v) over the join output (5 pairs per matching probe row) == torch")})
+        # the same join on TWO Int64 key columns whose ranges do not pack into one word: the partitioned join's hashed mode (64-bit keyset hashes through the LDS tables, every
+        # emitted pair verified in the columns); next to it the same plan with that mode off = the global open-addressing table it replaces
+        if do_two:
+            bk1 = torch.randint(0, 2**62, (nb,), generator=g, device="cuda", dtype=torch.int64)
+            src = torch.randint(0, nb, (npr,), generator=g, device="cuda")
+            hit2 = torch.rand(npr, generator=g, device="cuda") < 0.2
+            pk0 = torch.where(hit2, bk[src], torch.randint(0, 2**62, (npr,), generator=g, device="cuda", dtype=torch.int64))
+            pk1 = torch.where(torch.rand(npr, generator=g, device="cuda") < 0.95, bk1[src], pk0)          # 5 % of the first-column matches differ in the second column
+            hit2 = hit2 & (pk1 == bk1[src])
+            del src
+            torch.cuda.synchronize()
+            left2 = ops.RecordBatch.from_arrays(ctx, ["k", "j"], [ctx.wrap_tensor(bk, capi.INT64), ctx.wrap_tensor(bk1, capi.INT64)])
+            right2 = ops.RecordBatch.from_arrays(ctx, ["k", "j", "v"], [ctx.wrap_tensor(pk0, capi.INT64), ctx.wrap_tensor(pk1, capi.INT64), ctx.wrap_tensor(pv, capi.INT64)])
+            j2k = ops.HashJoinExec(ops.MemoryExec([[left2]], left2.schema), ops.MemoryExec([[right2]], right2.schema), [(C("k", 0), C("k", 0)), (C("j", 1), C("j", 1))], None, "Inner", "CollectLeft")
+            plan2 = ops.AggregateExec("Single", [], [ops.AggregateFunctionExpr("SUM", C("v", 4), "s", input_field=F("v", capi.INT64)), ops.AggregateFunctionExpr("COUNT", None, "c")], j2k)
+            dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan2, args.steps, args.warmup)
+            res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
+            ok = int(res[1][0]) == int(hit2.sum().item()) and wrap64(int(res[0][0])) == wrap64(int(pv[hit2].sum().item()))
+            ctx.set_option("join_partitioned_hashed", 0)
+            try:
+                dt0, _, kern0, _ = time_plan(ctx, ops, tc, plan2, args.steps, args.warmup)
+                res0 = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
+            finally:
+                ctx.set_option("join_partitioned_hashed", 1)
+            ok = ok and int(res0[1][0]) == int(res[1][0]) and wrap64(int(res0[0][0])) == wrap64(int(res[0][0]))
+            report("hash_join_two_keys", dt, nb + npr, rows, round((nb * 16 + npr * 24) / (nb + npr), 2), kern, syncs, {"build_rows": nb, "probe_rows": npr, "match_fraction": round(float(hit2.float().mean().item()), 3),
+                   "global_table_ms_per_step": round(dt0 * 1e3, 3), "global_table_kernel_ms_per_step": kern0,
+                   "result_check": check("hash_join_two_keys", ok, "COUNT(*) and SUM(v) over the join output == the matches by construction (torch), and == the same plan through the global table")})
+            del bk1, pk0, pk1, hit2, left2, right2, j2k, plan2
         del bk, pk, pv, left, right, plan
         torch.cuda.empty_cache()
     if not want or "groupby_int64" in want:

@@ -26,6 +26,7 @@ static void ctx_unref(dfgpu_ctx* c) {
   if (c->d_flags) (void)hipFree(c->d_flags);
   if (c->d_scratch64) (void)hipFree(c->d_scratch64);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  for (auto& sp : c->spans) if (sp.start) { (void)hipEventDestroy(sp.start); (void)hipEventDestroy(sp.stop); }      // spans nobody resolved
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete r; delete c;
@@ -343,6 +344,8 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "join_partitioned") ctx->join_partitioned = value != 0;
     else if (k == "join_partitioned_min_build") ctx->join_partitioned_min_build = value;
     else if (k == "join_partitioned_min_probe") ctx->join_partitioned_min_probe = value;
+    else if (k == "join_partitioned_hashed") ctx->join_partitioned_hashed = value != 0;
+    else if (k == "join_partitioned_hash_mask") ctx->join_partitioned_hash_mask = value <= 0 ? ~0ull : (uint64_t)value;
     else if (k == "join_partition_rows") ctx->join_partition_rows = value;
     else if (k == "defer_flag_checks") {            // nests: +1 enters a deferred region, 0 leaves it and raises what the region deferred
       if (value) ctx->defer_flag_checks++;
@@ -383,6 +386,8 @@ dfgpu_status dfgpu_ctx_get_option(dfgpu_ctx* ctx, const char* key, int64_t* out)
     else if (k == "join_partitioned") *out = ctx->join_partitioned;
     else if (k == "join_partitioned_min_build") *out = ctx->join_partitioned_min_build;
     else if (k == "join_partitioned_min_probe") *out = ctx->join_partitioned_min_probe;
+    else if (k == "join_partitioned_hashed") *out = ctx->join_partitioned_hashed ? 1 : 0;
+    else if (k == "join_partitioned_hash_mask") *out = ctx->join_partitioned_hash_mask == ~0ull ? 0 : (int64_t)ctx->join_partitioned_hash_mask;
     else if (k == "join_partition_rows") *out = ctx->join_partition_rows;
     else if (k == "defer_flag_checks") *out = ctx->defer_flag_checks;
     else fail(DFGPU_INVALID_ARGUMENT, "unknown option '%s'", k.c_str());
@@ -402,29 +407,38 @@ dfgpu_status dfgpu_mask_count(dfgpu_ctx* ctx, const dfgpu_array* mask, int64_t* 
     *out = mask->length ? count_set_bits(ctx, (const uint64_t*)m->ptr, mask->length) : 0;
   });
 }
+// A span id outlives the call that made it (the plan layer resolves them when metrics are read, or when the plan goes away): every entry point first asks the registry
+// whether the ctx still exists, and the table is guarded -- a plan's partitions meter concurrently.  Events of spans nobody resolved are destroyed with the ctx.
 dfgpu_status dfgpu_span_begin(dfgpu_ctx* ctx, int64_t* out_span) {
+  if (!ctx || !refs_of(ctx)) return DFGPU_INVALID_ARGUMENT;
   return guard(ctx, [&] {
     if (!out_span) fail(DFGPU_INVALID_ARGUMENT, "span_begin: null argument");
     dfgpu_ctx::Span sp; HIP_CHECK(hipEventCreate(&sp.start)); HIP_CHECK(hipEventCreate(&sp.stop));
     HIP_CHECK(hipEventRecord(sp.start, ctx->stream));
+    std::lock_guard<std::mutex> l(ctx->span_mu);
     size_t k = 0; for (; k < ctx->spans.size(); k++) if (!ctx->spans[k].start) break;
     if (k == ctx->spans.size()) ctx->spans.push_back(sp); else ctx->spans[k] = sp;
     *out_span = (int64_t)k;
   });
 }
 dfgpu_status dfgpu_span_end(dfgpu_ctx* ctx, int64_t span) {
+  if (!ctx || !refs_of(ctx)) return DFGPU_INVALID_ARGUMENT;
   return guard(ctx, [&] {
+    std::lock_guard<std::mutex> l(ctx->span_mu);
     if (span < 0 || (size_t)span >= ctx->spans.size() || !ctx->spans[(size_t)span].start) fail(DFGPU_INVALID_ARGUMENT, "span_end: unknown span");
     HIP_CHECK(hipEventRecord(ctx->spans[(size_t)span].stop, ctx->stream));
   });
 }
 dfgpu_status dfgpu_span_elapsed_ns(dfgpu_ctx* ctx, int64_t span, int64_t* out_ns) {
+  if (!ctx || !refs_of(ctx)) return DFGPU_INVALID_ARGUMENT;
   return guard(ctx, [&] {
-    if (!out_ns || span < 0 || (size_t)span >= ctx->spans.size() || !ctx->spans[(size_t)span].start) fail(DFGPU_INVALID_ARGUMENT, "span_elapsed: unknown span");
-    dfgpu_ctx::Span& sp = ctx->spans[(size_t)span];
-    HIP_CHECK(hipEventSynchronize(sp.stop));
-    float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, sp.start, sp.stop));
-    (void)hipEventDestroy(sp.start); (void)hipEventDestroy(sp.stop); sp.start = sp.stop = nullptr;
+    dfgpu_ctx::Span sp;
+    { std::lock_guard<std::mutex> l(ctx->span_mu);
+      if (!out_ns || span < 0 || (size_t)span >= ctx->spans.size() || !ctx->spans[(size_t)span].start) fail(DFGPU_INVALID_ARGUMENT, "span_elapsed: unknown span");
+      sp = ctx->spans[(size_t)span]; ctx->spans[(size_t)span].start = ctx->spans[(size_t)span].stop = nullptr; }      // the slot is free again; the events are this call's
+    hipError_t e = hipEventSynchronize(sp.stop); float ms = 0; if (e == hipSuccess) e = hipEventElapsedTime(&ms, sp.start, sp.stop);
+    (void)hipEventDestroy(sp.start); (void)hipEventDestroy(sp.stop);
+    HIP_CHECK(e);
     *out_ns = (int64_t)((double)ms * 1e6);
   });
 }

@@ -48,6 +48,8 @@ struct dfgpu_ctx {
   bool group_dictionary_canon = true;
   bool join_swap_small_semi = true;
   // radix-partitioned hash join (pjoin.hip): on/off, smallest build / probe batch that takes it, build rows per partition (<= 14000)
+  uint64_t join_partitioned_hash_mask = ~0ull;       // tests: AND-ed onto the key hashes of the hashed mode, so that different keys collide
+  bool join_partitioned_hashed = true;       // builds the integer mode of the partitioned join does not take (several key columns that do not pack, Utf8 / dictionary keys, null_equals_null) go through it on 64-bit key hashes
   bool join_partitioned = true; int64_t join_partitioned_min_build = 1 << 20, join_partitioned_min_probe = 1 << 22, join_partition_rows = 14000;
   int64_t fused_aggregate_min_rows = 1 << 20;
   bool sort_packed_keys = true;     // large sorts over fixed-width keys: range-packed u64 keys + stable one-pass partition per digit (sort.hip)
@@ -80,6 +82,7 @@ struct dfgpu_ctx {
   bool collect_metrics = false;     // the plan layer meters its operators (device-time spans + row counts)
   struct Span { hipEvent_t start = nullptr, stop = nullptr; };
   std::vector<Span> spans;          // dfgpu_span_*
+  std::mutex span_mu;               // a plan's partitions share one ctx and meter concurrently
   bool profile = false; std::string profile_only;
   std::vector<std::pair<std::string, int64_t>> sync_counts;   // host<->stream synchronisation points by cause (profiling only)
   void count_sync(const char* why) { if (!profile) return; for (auto& kv : sync_counts) if (kv.first == why) { kv.second++; return; } sync_counts.emplace_back(why, 1); }

@@ -248,6 +248,7 @@ struct Metrics {
     for (auto& o : open) { int64_t t = 0; if (dfgpu_span_elapsed_ns(o.c, o.id, &t) == DFGPU_OK) ns[o.which] += t; }
     open.clear();
   }
+  ~Metrics() { resolve(); }          // a plan whose metrics nobody read gives its spans' events back (dfgpu_span_* refuse a ctx that is gone)
 };
 struct SpanGuard {
   dfgpu_ctx* c = nullptr; int64_t id = -1; Metrics* m = nullptr; int which = 0;

@@ -638,7 +638,7 @@ dfgpu_status dfgpu_join_build(dfgpu_ctx* ctx, const dfgpu_array* const* keys, in
     t->mem = (int64_t)bitmap_bytes(n);
     // order of preference: rank index (clustered keys: no table at all), radix-partitioned LDS tables (large builds on unsorted keys
     // whose domain is too sparse for the membership bitmap in front of the general table), general open-addressing table
-    if (!build_rank_index(ctx, t.get()) && !(pj_domain_is_sparse(ctx, t.get()) && pj_build(ctx, t.get()))) build_hash_table(ctx, t.get(), true);
+    if (!build_rank_index(ctx, t.get()) && !((pj_domain_is_sparse(ctx, t.get()) || pj_hashed_candidate(ctx, t.get())) && pj_build(ctx, t.get()))) build_hash_table(ctx, t.get(), true);
     *out = t.release();
   });
 }
@@ -663,8 +663,8 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
     int64_t nw = (n + 63) / 64;
     const uint64_t* mk = mask ? (const uint64_t*)mask->ptr : nullptr;
     int nen = t->null_equals_null ? 1 : 0, fz = ctx->force_hash_collisions ? 1 : 0;
-    if (nkeys == 1 && pj_probe_eligible(ctx, t, probe_keys[0], n)) {        // large batch against a partitioned build: partition by partition out of LDS
-      pj_probe(ctx, t, probe_keys[0], mk, out_build_idx, out_probe_idx);
+    if (pj_probe_eligible(ctx, t, probe_keys, nkeys, n)) {        // large batch against a partitioned build: partition by partition out of LDS
+      pj_probe(ctx, t, probe_keys, nkeys, mk, out_build_idx, out_probe_idx);
       check_flags(ctx, "join_probe");
       return;
     }

@@ -10,6 +10,7 @@ struct PartitionedBuild {
   int64_t rows = 0;                         // selected, non-NULL build rows
   BufferPtr recs;                           // RpRec12 {key lo, key hi, ref}[..], partition-major: ref = build row (unique keys) or group number (dups)
   BufferPtr starts;                         // u32[P + 1] over recs
+  bool hashed = false;                      // record keys are keyset hashes of the key columns (any number, any type, NULLs under null_equals_null): a match is a candidate, verified against the columns
   bool dups = false;                        // a build key repeats: recs holds one record per DISTINCT key, the rows of a key are a CSR
   BufferPtr grp_start, grp_cnt, csr_rows;   // u32[groups] into csr_rows / rows of the group; u32[rows] build rows, ascending inside a group
 };
@@ -54,6 +55,7 @@ struct dfgpu_join_table {
 namespace dfgpu {
 // pjoin.hip
 bool pj_build(dfgpu_ctx* ctx, dfgpu_join_table* t);      // false = shape not taken (nothing kept)
-bool pj_probe_eligible(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* probe_key, int64_t n);
-void pj_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* probe_key, const uint64_t* mask, dfgpu_array** out_build, dfgpu_array** out_probe);
+bool pj_probe_eligible(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* probe_keys, int32_t nkeys, int64_t n);
+void pj_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* probe_keys, int32_t nkeys, const uint64_t* mask, dfgpu_array** out_build, dfgpu_array** out_probe);
+bool pj_hashed_candidate(dfgpu_ctx* ctx, const dfgpu_join_table* t);      // a build the integer mode does not take, large enough for the partitioned path
 }  // namespace dfgpu

@@ -514,12 +514,38 @@ static PjOffsets pj_partition(dfgpu_ctx* ctx, const dfgpu_array* key, const uint
 #undef PJ_PART
 }
 
+// Hashed mode: the key columns are anything keyset_hash takes (several columns, Utf8, dictionaries, NULLs that match under null_equals_null).  The record key is the
+// 64-bit keyset hash; everything downstream -- partition, LDS tables, groups of repeated keys -- compares record keys, so two different key values with one hash are simply
+// rows of one "key" there.  That is sorted out at the end: k_pj_verify compares every emitted pair in the columns themselves and the pairs that fail are dropped.
+struct PjHashKeys {
+  KeySet ks; const uint64_t* mask; int null_eq; uint64_t hmask;        // hmask: all ones; fewer bits (option "join_partitioned_hash_mask", tests) make different keys share a hash
+  __device__ inline bool operator()(int64_t i, uint32_t P, uint32_t* pid, uint64_t* key) const {
+    bool an; const uint64_t h = keyset_hash(ks, i, 0, &an) & hmask;
+    *key = h; *pid = rp_pid(mix64(h), P);
+    return (!mask || bit_get(mask, i)) && (!an || null_eq);
+  }
+};
+__global__ void __launch_bounds__(BLOCK) k_pj_verify(KeySet bks, KeySet pks, const uint64_t* __restrict__ bidx, const uint32_t* __restrict__ pidx, int64_t m, int null_eq, uint64_t* __restrict__ keep, unsigned long long* nfail) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const bool ok = i < m && keyset_equal(bks, (int64_t)bidx[i], pks, (int64_t)pidx[i], null_eq != 0);
+  const uint64_t w = ballot64(ok);
+  if (lane_id() == 0 && i < m) { keep[i >> 6] = w; const int live = (int)min((int64_t)64, m - i); const int bad = live - __popcll(w); if (bad) atomicAdd(nfail, (unsigned long long)bad); }
+}
+static PjOffsets pj_partition_keys(dfgpu_ctx* ctx, const KeySet& ks, int64_t n, const uint64_t* mask, bool null_eq, uint32_t P, RpRec12* recs, uint64_t* d_total, const char* th, const char* ts, const char* tw) {
+  return pj_partition_t(ctx, PjHashKeys{ ks, mask, null_eq ? 1 : 0, ctx->join_partitioned_hash_mask }, n, P, recs, d_total, th, ts, tw);
+}
+bool pj_hashed_candidate(dfgpu_ctx* ctx, const dfgpu_join_table* t) {
+  if (!ctx->join_partitioned || !ctx->join_partitioned_hashed || ctx->force_hash_collisions || t->n_build < ctx->join_partitioned_min_build) return false;
+  return !(t->nkeys == 1 && !t->null_equals_null && pj_key_type_ok(t->keys[0]));      // those are the integer mode's (which asks pj_domain_is_sparse first)
+}
+
 bool pj_build(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   const int64_t n = t->n_build;
-  if (!ctx->join_partitioned || ctx->force_hash_collisions || t->nkeys != 1 || t->null_equals_null) return false;
+  if (!ctx->join_partitioned || ctx->force_hash_collisions) return false;
   if (n < ctx->join_partitioned_min_build || n > 0xFFFFFFF0ll) return false;
   const dfgpu_array* key0 = t->keys[0];
-  if (!pj_key_type_ok(key0)) return false;
+  const bool hashed = !(t->nkeys == 1 && !t->null_equals_null && pj_key_type_ok(key0));
+  if (hashed && !ctx->join_partitioned_hashed) return false;
   int64_t cap = ctx->join_partition_rows; if (cap < 16) cap = 16; if (cap > 14000) cap = 14000;
   const int64_t per = std::min<int64_t>(cap, 7300);      // <= 8192 keys: a 64 KB table at load <= 1/2, two workgroups per CU
   int64_t P64 = (n + per - 1) / per; if (P64 < 1) P64 = 1;
@@ -529,7 +555,10 @@ bool pj_build(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   part->P = (uint32_t)P64;
   BufferPtr recs = alloc_buffer(ctx, (size_t)(n + 1) * 12), ndist = alloc_buffer(ctx, (size_t)(P64 + 1) * 4);
   zero_scratch(ctx);
-  PjOffsets off = pj_partition(ctx, key0, t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr, part->P, (RpRec12*)recs->ptr, ctx->d_scratch64 + 3, "pj_build_hist", "pj_build_scan", "pj_build_scatter");
+  const uint64_t* bmask = t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr;
+  part->hashed = hashed;
+  PjOffsets off = hashed ? pj_partition_keys(ctx, t->ks, n, bmask, t->null_equals_null, part->P, (RpRec12*)recs->ptr, ctx->d_scratch64 + 3, "pj_build_hist", "pj_build_scan", "pj_build_scatter")
+                         : pj_partition(ctx, key0, bmask, part->P, (RpRec12*)recs->ptr, ctx->d_scratch64 + 3, "pj_build_hist", "pj_build_scan", "pj_build_scatter");
   uint64_t max_rows = 0, dup = 0, over = 0, moved = 0, max_dist = 0;
   for (int max_sbits = (n + P64 - 1) / P64 <= 7500 ? 14 : PJ_MAX_SBITS;; max_sbits = PJ_MAX_SBITS) {      // 64 KB of LDS (two workgroups per CU) when the average partition leaves room for its spread
     { KernelTimer kt_(ctx, "pj_build_check");
@@ -575,17 +604,37 @@ bool pj_build(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   return true;
 }
 
-bool pj_probe_eligible(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* probe_key, int64_t n) {
+bool pj_probe_eligible(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* probe_keys, int32_t nkeys, int64_t n) {
   if (!t->part || !ctx->join_partitioned || n < ctx->join_partitioned_min_probe || n > 0xFFFF0000ll) return false;
-  return probe_key->type == t->keys[0]->type;          // same physical integer type, no dictionary
+  if (t->part->hashed) return nkeys == t->nkeys;       // the caller has checked the column types against the build's; dictionaries hash by value
+  return nkeys == 1 && probe_keys[0]->type == t->keys[0]->type;          // same physical integer type, no dictionary
 }
 
-void pj_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* pk, const uint64_t* mask, dfgpu_array** out_build, dfgpu_array** out_probe) {
+// hashed mode: drop the pairs whose columns differ (two key values with one 64-bit hash; none on ordinary data -- the count decides whether anything is compacted)
+static void pj_verify(dfgpu_ctx* ctx, const dfgpu_join_table* t, const KeySet& pks, ArrayHolder& ob, ArrayHolder& op) {
+  const int64_t m = ob.get()->length; if (!m) return;
+  KernelTimer kt_(ctx, "pj_verify");
+  BufferPtr keep = alloc_buffer(ctx, bitmap_bytes(m));
+  HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 11, 0, 8, ctx->stream));
+  hipLaunchKernelGGL(k_pj_verify, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, t->ks, pks, (const uint64_t*)ob.get()->values->ptr, (const uint32_t*)op.get()->values->ptr, m, t->null_equals_null ? 1 : 0,
+                     (uint64_t*)keep->ptr, (unsigned long long*)(ctx->d_scratch64 + 11));
+  KERNEL_CHECK();
+  const uint64_t bad = read_scratch(ctx, 11);
+  ctx->count_sync("sync:pj_verify");
+  if (!bad) return;
+  ArrayHolder idx(mask_to_indices_impl(ctx, (const uint64_t*)keep->ptr, m));
+  ArrayHolder nb(take_impl(ctx, ob.get(), idx.get()->values->ptr, 4, nullptr, idx.get()->length)), np(take_impl(ctx, op.get(), idx.get()->values->ptr, 4, nullptr, idx.get()->length));
+  dfgpu_array_release(ob.a); ob.a = nb.release(); dfgpu_array_release(op.a); op.a = np.release();
+}
+void pj_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* probe_keys, int32_t nkeys, const uint64_t* mask, dfgpu_array** out_build, dfgpu_array** out_probe) {
   const PartitionedBuild& part = *t->part;
+  const dfgpu_array* pk = probe_keys[0];
+  const KeySet pks = part.hashed ? make_keyset(probe_keys, nkeys) : KeySet{};
   const int64_t n = pk->length; const uint32_t P = part.P;
   const int NC = (int)((n + (1ll << PJ_CHS) - 1) >> PJ_CHS);
   BufferPtr recs = alloc_buffer(ctx, (size_t)(n + 1) * 12);
-  PjOffsets off = pj_partition(ctx, pk, mask, P, (RpRec12*)recs->ptr, ctx->d_scratch64 + 9, "pj_probe_hist", "pj_probe_scan", "pj_probe_scatter");
+  PjOffsets off = part.hashed ? pj_partition_keys(ctx, pks, n, mask, t->null_equals_null, P, (RpRec12*)recs->ptr, ctx->d_scratch64 + 9, "pj_probe_hist", "pj_probe_scan", "pj_probe_scatter")
+                              : pj_partition(ctx, pk, mask, P, (RpRec12*)recs->ptr, ctx->d_scratch64 + 9, "pj_probe_hist", "pj_probe_scan", "pj_probe_scatter");
   BufferPtr hits = alloc_buffer(ctx, (size_t)(n + 1) * 8), hstart = alloc_buffer(ctx, (size_t)P * NC * 4 + 4), send = alloc_buffer(ctx, (size_t)P * PJ_NW * 4);
   { KernelTimer kt_(ctx, "pj_join");
     const size_t lds = (size_t)(1u << part.sbits) * 4;
@@ -594,7 +643,7 @@ void pj_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* pk, 
                        part.sbits, NC, P, (const uint32_t*)off.pre->ptr, (const uint32_t*)off.cpre->ptr, off.ntiles, (uint64_t*)hits->ptr, (uint32_t*)hstart->ptr, (uint32_t*)send->ptr);
     KERNEL_CHECK(); }
   recs.reset(); off.pre.reset(); off.cpre.reset();
-  KernelTimer kt_(ctx, "pj_compact");
+  std::unique_ptr<KernelTimer> kt_(new KernelTimer(ctx, "pj_compact"));       // ends before the verification of the hashed mode, which has a timer of its own
   BufferPtr hT = alloc_buffer(ctx, (size_t)P * NC * 4 + 4), lT = alloc_buffer(ctx, (size_t)P * NC * 2 + 4), coff = alloc_buffer(ctx, (size_t)(NC + 1) * 4, true);
   hipLaunchKernelGGL(k_pj_transpose, dim3((NC + 31) / 32, (P + 31) / 32), dim3(PJ_NT), 0, ctx->stream, (const uint32_t*)hstart->ptr, (const uint32_t*)send->ptr, (int)P, NC, (uint32_t*)hT->ptr, (uint16_t*)lT->ptr, (uint32_t*)coff->ptr);
   exclusive_scan_u32_inplace32(ctx, (uint32_t*)coff->ptr, (int64_t)NC + 1, ctx->d_scratch64 + 10);
@@ -607,7 +656,9 @@ void pj_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* pk, 
     if (m) hipLaunchKernelGGL((k_pj_restore<false>), dim3(rgrid), dim3(PJ_NT), 0, ctx->stream, (const uint64_t*)hits->ptr, (const uint32_t*)off.pstart->ptr, (const uint32_t*)hT->ptr, (const uint16_t*)lT->ptr, (int)P, NC,
                                   (const uint32_t*)coff->ptr, (uint32_t*)op.get()->values->ptr, (uint64_t*)ob.get()->values->ptr, (uint32_t*)nullptr);
     KERNEL_CHECK();
-    op.get()->identity = m == n;
+    kt_.reset();
+    if (part.hashed) pj_verify(ctx, t, pks, ob, op);
+    op.get()->identity = op.get()->length == n;
     *out_build = ob.release(); *out_probe = op.release();
     return;
   }
@@ -627,6 +678,8 @@ void pj_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* pk, 
   if (total) hipLaunchKernelGGL(k_pj_expand, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)rows->ptr, (const uint32_t*)ref->ptr, (const uint64_t*)offs->ptr, m, (const uint32_t*)part.grp_start->ptr,
                                 (const uint32_t*)part.grp_cnt->ptr, (const uint32_t*)part.csr_rows->ptr, (uint64_t*)ob.get()->values->ptr, (uint32_t*)op.get()->values->ptr);
   KERNEL_CHECK();
+  kt_.reset();
+  if (part.hashed) pj_verify(ctx, t, pks, ob, op);
   *out_build = ob.release(); *out_probe = op.release();
 }
 

@@ -207,3 +207,101 @@ def test_packed_join_keys_with_a_date32_column(ctx):
     want = po.hash_join([arr(bk, bd)], [arr(pk, pd)], "Inner", False, batch_size=1 << 40)
     assert np.array_equal(bi.to_numpy().astype(np.int64), want.build_idx) and np.array_equal(pi.to_numpy().astype(np.int64), want.probe_idx)
     assert "k_pack_keys" in ran, ran              # the ranges (10^6 x 1500) fit: the packed single-key paths serve the join
+
+
+# ------------------------------------------------------------------ hashed mode: key columns the integer mode does not take travel as 64-bit keyset hashes, pairs are verified in the columns
+def _hashed_case(kind, nb, npr, rng):
+    """-> (build key columns, probe key columns) as pyarrow arrays; about a third of the probe rows match, keys repeat on the build side in some cases"""
+    words = np.array([f"k{i:07d}" + "x" * (i % 5) for i in range(nb)], dtype=object)
+    if kind == "utf8":
+        b = [pa.array(words[rng.permutation(nb)], pa.utf8())]
+        p = [pa.array(np.where(rng.random(npr) < 0.3, words[rng.integers(0, nb, npr)], np.array([f"q{i}" for i in range(npr)], dtype=object)), pa.utf8())]
+    elif kind == "utf8_nullable_dups":                # every key twice on the build side, NULLs on both sides (never a match)
+        base = words[: nb // 2]
+        b = [pa.array(np.concatenate([base, base])[rng.permutation(2 * (nb // 2))], pa.utf8(), mask=rng.random(2 * (nb // 2)) < 0.05)]
+        p = [pa.array(np.where(rng.random(npr) < 0.3, base[rng.integers(0, len(base), npr)], "none"), pa.utf8(), mask=rng.random(npr) < 0.05)]
+    elif kind == "two_wide_ints":                     # ranges multiply far beyond 2^40: no packing
+        k0 = rng.integers(-(1 << 60), 1 << 60, nb); k1 = rng.integers(-(1 << 60), 1 << 60, nb)
+        pick = rng.integers(0, nb, npr); hit = rng.random(npr) < 0.3
+        b = [pa.array(k0), pa.array(k1)]
+        p = [pa.array(np.where(hit, k0[pick], rng.integers(0, 1 << 60, npr))), pa.array(np.where(rng.random(npr) < 0.9, k1[pick], 7))]      # some rows match in the first column only
+    elif kind == "int_and_utf8":
+        k0 = rng.integers(0, 50, nb); pick = rng.integers(0, nb, npr); hit = rng.random(npr) < 0.3
+        b = [pa.array(k0), pa.array(words, pa.utf8())]
+        p = [pa.array(np.where(hit, k0[pick], -1)), pa.array(words[pick], pa.utf8())]
+    elif kind == "dictionary":
+        d = pa.array([f"d{i}" for i in range(4000)], pa.utf8())
+        b = [pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, 4000, nb).astype(np.int32)), d)]
+        p = [pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, 4000, npr).astype(np.int32)), d)]      # ~nb / 4000 build rows per key
+    else:
+        raise AssertionError(kind)
+    return b, p
+
+
+def _check_hashed(ctx, b, p, nen=False, bmask=None, pmask=None):
+    import dfgpu
+    table = dfgpu.JoinTable(ctx, [ctx.from_arrow(c) for c in b], mask=ctx.from_arrow(pa.array(bmask)) if bmask is not None else None, null_equals_null=nen)
+    bi, pi = table.probe([ctx.from_arrow(c) for c in p], mask=ctx.from_arrow(pa.array(pmask)) if pmask is not None else None)
+    bsel = np.arange(len(b[0])) if bmask is None else np.flatnonzero(bmask)
+    psel = np.arange(len(p[0])) if pmask is None else np.flatnonzero(pmask)
+    plain = lambda c: c.cast(c.type.value_type) if pa.types.is_dictionary(c.type) else c
+    want = po.hash_join([[plain(c).take(pa.array(bsel)) for c in b]], [[plain(c).take(pa.array(psel)) for c in p]], "Inner", nen, batch_size=1 << 40)
+    assert np.array_equal(bi.to_numpy().astype(np.int64), bsel[want.build_idx])
+    assert np.array_equal(pi.to_numpy().astype(np.int64), psel[want.probe_idx])
+    return len(want.probe_idx)
+
+
+@pytest.mark.parametrize("per", [64, 12800])
+@pytest.mark.parametrize("kind", ["utf8", "utf8_nullable_dups", "two_wide_ints", "int_and_utf8", "dictionary"])
+def test_hashed_keys_take_the_partitioned_path(ctx, kind, per):
+    rng = np.random.default_rng(len(kind) * 1000 + per)
+    b, p = _hashed_case(kind, 40_000, 150_000, rng)
+    if kind == "dictionary" and per == 64:
+        pytest.skip("groups of ~10 rows per key in partitions of 64 rows: the build declines (covered by the fall-back test)")
+    with forced(ctx, per) as f:
+        m = _check_hashed(ctx, b, p)
+        ks = f.kernels()
+    assert m > 0 and "pj_join" in ks and "pj_verify" in ks, ks
+
+
+def test_hashed_keys_with_masks_and_null_equals_null(ctx):
+    """null_equals_null: NULL keys hash (keyset_hash leaves the running hash unchanged for a NULL cell) and match each other; one Int64 key column with NULLs on both
+    sides, which the integer mode refuses; fused selections on both sides."""
+    rng = np.random.default_rng(77)
+    nb, npr = 30_000, 100_000
+    k = unique_keys(nb); bnull = rng.random(nb) < 0.001            # a few NULL build keys: they form one group of ~30 rows
+    pk = probe_keys(k, npr, 0.3); pnull = rng.random(npr) < 0.01
+    b = [pa.array(k, mask=bnull)]; p = [pa.array(pk, mask=pnull)]
+    with forced(ctx, 12800) as f:
+        m = _check_hashed(ctx, b, p, nen=True, bmask=rng.random(nb) < 0.9, pmask=rng.random(npr) < 0.8)
+        ks = f.kernels()
+    assert m > 0 and "pj_join" in ks and "pj_verify" in ks and "pj_build_groups" in ks, ks
+
+
+@pytest.mark.parametrize("bits", [12, 16])
+def test_hashed_keys_that_share_a_hash_are_told_apart(ctx, bits):
+    """`join_partitioned_hash_mask` leaves `bits` bits of every key hash, so thousands of different keys share one: the tables, the groups and the expansion treat them as
+    one key, the verification against the columns drops the wrong pairs -- the result is still the oracle's, in order."""
+    rng = np.random.default_rng(bits)
+    b, p = _hashed_case("utf8", 30_000, 100_000, rng)
+    ctx.set_option("join_partitioned_hash_mask", (1 << bits) - 1)
+    try:
+        with forced(ctx, 12800) as f:
+            m = _check_hashed(ctx, b, p)
+            ks = f.kernels()
+    finally:
+        ctx.set_option("join_partitioned_hash_mask", 0)
+    assert m > 0 and "pj_verify" in ks and "pj_build_groups" in ks, ks
+
+
+def test_hashed_mode_can_be_switched_off_and_small_builds_do_not_take_it(ctx):
+    rng = np.random.default_rng(5)
+    b, p = _hashed_case("utf8", 20_000, 60_000, rng)
+    with forced(ctx, 12800) as f:
+        ctx.set_option("join_partitioned_hashed", 0)
+        try:
+            _check_hashed(ctx, b, p)
+            assert "pj_join" not in f.kernels()
+        finally:
+            ctx.set_option("join_partitioned_hashed", 1)
+    _check_hashed(ctx, b, p)                                        # default thresholds: 20 000 rows stay with the general table
