@@ -108,6 +108,8 @@ PROTOTYPES = {
     "dfgpu_array_null_count": (C.c_int64, [_P, _P]),
     "dfgpu_array_slice": (C.c_int32, [_P, _P, C.c_int64, C.c_int64, _PP]),
     "dfgpu_concat": (C.c_int32, [_P, _PP, C.c_int32, _PP]),
+    "dfgpu_list_from_counts": (C.c_int32, [_P, _P, _P, _PP]),
+    "dfgpu_list_flatten": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _PP, _PP]),
     "dfgpu_array_new_null": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _PP]),
     "dfgpu_array_new_zeros": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _PP]),
     "dfgpu_array_make_dictionary": (C.c_int32, [_P, _P, _P, _PP]),

@@ -283,6 +283,26 @@ static dfgpu_array* import_desc(dfgpu_ctx* ctx, const dfgpu_array_desc* d, bool 
 
 using namespace dfgpu;
 
+namespace dfgpu {
+// ---- lists of fixed-width values in the Utf8 layout (the List<T> state of COUNT(DISTINCT), physical-expr/src/aggregate/count_distinct/native.rs state()): offsets are BYTE
+// offsets into the packed values, so take / concat / slice / partition / exchange / Arrow export move such a column as they move strings.
+__global__ void __launch_bounds__(BLOCK) k_list_lens(const int64_t* counts, int64_t n, uint32_t w, uint32_t* lens, uint32_t* flags) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i > n) return;
+  if (i == n) { lens[i] = 0; return; }
+  const int64_t c = counts[i];
+  if (c < 0 || c > (int64_t)(0x7FFFFFF0u / w)) { atomicOr(flags, DFGPU_FLAG_OOB); lens[i] = 0; } else lens[i] = (uint32_t)c * w;
+}
+// element e of the flattened list (byte first + e * w) belongs to the row whose [offsets[r], offsets[r + 1]) holds it
+__global__ void __launch_bounds__(BLOCK) k_list_row_of(const int32_t* offsets, int64_t n, int64_t ne, uint32_t w, uint32_t* row_of) {
+  const int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (e >= ne) return;
+  const int64_t at = (int64_t)offsets[0] + e * w;
+  int64_t lo = 0, hi = n - 1;                            // the last row with offsets[r] <= at (rows of no elements share their offset with the next: the last one wins only if it holds `at`)
+  while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if ((int64_t)offsets[mid] <= at) lo = mid; else hi = mid - 1; }
+  row_of[e] = (uint32_t)lo;
+}
+}  // namespace dfgpu
+
 extern "C" {
 
 const char* dfgpu_version(void) { return "dfgpu 0.1 (gfx950)"; }
@@ -642,6 +662,43 @@ dfgpu_status dfgpu_concat(dfgpu_ctx* ctx, const dfgpu_array* const* arrays, int3
     }
     if (f->dictionary) { o->dictionary = f->dictionary; dfgpu_array_retain(f->dictionary); }
     *out = h.release();
+  });
+}
+
+/* see include/dfgpu.h */
+dfgpu_status dfgpu_list_from_counts(dfgpu_ctx* ctx, const dfgpu_array* counts, const dfgpu_array* values, dfgpu_array** out) {
+  return guard(ctx, [&] {
+    if (!counts || !values || !out) fail(DFGPU_INVALID_ARGUMENT, "list_from_counts: null argument");
+    if (counts->type != DFGPU_INT64) fail(DFGPU_INVALID_ARGUMENT, "list_from_counts: counts must be Int64");
+    if (values->type == DFGPU_UTF8 || values->type == DFGPU_DICTIONARY || values->type == DFGPU_BOOL) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: lists of type %d values on the device (fixed-width values only)", values->type);
+    const int w = type_width(values->type); const int64_t n = counts->length, bytes = values->length * w;
+    if (bytes > 0x7FFFFFF0ll) fail(DFGPU_NOT_IMPLEMENTED, "list_from_counts: %lld bytes of values exceed 32-bit offsets", (long long)bytes);
+    ArrayHolder h(new_array(ctx, DFGPU_UTF8, n)); dfgpu_array* o = h.get();
+    o->offsets = alloc_buffer(ctx, (size_t)(n + 1) * 4 + 16); o->values = values->values ? values->values : alloc_buffer(ctx, 16); o->values_bytes = bytes; o->null_count = 0;
+    hipLaunchKernelGGL(k_list_lens, dim3(grid_for(n + 1, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const int64_t*)counts->values->ptr, n, (uint32_t)w, (uint32_t*)o->offsets->ptr, ctx->d_flags);
+    exclusive_scan_u32_inplace32(ctx, (uint32_t*)o->offsets->ptr, n + 1, ctx->d_scratch64 + 13);
+    KERNEL_CHECK();
+    if ((int64_t)read_scratch(ctx, 13) != bytes) fail(DFGPU_INVALID_ARGUMENT, "list_from_counts: the counts add up to %lld bytes, the values hold %lld", (long long)read_scratch(ctx, 13), (long long)bytes);
+    check_flags(ctx, "list_from_counts");
+    *out = h.release();
+  });
+}
+dfgpu_status dfgpu_list_flatten(dfgpu_ctx* ctx, const dfgpu_array* list, int32_t value_type, int32_t precision, int32_t scale, dfgpu_array** out_values, dfgpu_array** out_row_of) {
+  return guard(ctx, [&] {
+    if (!list || !out_values || !out_row_of) fail(DFGPU_INVALID_ARGUMENT, "list_flatten: null argument");
+    if (list->type != DFGPU_UTF8) fail(DFGPU_INVALID_ARGUMENT, "list_flatten: a list column travels in the Utf8 layout, got type %d", list->type);
+    if (value_type == DFGPU_UTF8 || value_type == DFGPU_DICTIONARY || value_type == DFGPU_BOOL || value_type < DFGPU_INT8) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: lists of type %d values on the device", value_type);
+    const int w = type_width(value_type); const int64_t n = list->length;
+    int32_t ends[2] = {0, 0};
+    if (n) { HIP_CHECK(hipMemcpyAsync(&ends[0], list->offsets->ptr, 4, hipMemcpyDeviceToHost, ctx->stream)); HIP_CHECK(hipMemcpyAsync(&ends[1], (const int32_t*)list->offsets->ptr + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+      ctx->count_sync("sync:list_flatten"); HIP_CHECK(hipStreamSynchronize(ctx->stream)); }
+    const int64_t bytes = (int64_t)ends[1] - ends[0];
+    if (bytes < 0 || bytes % w) fail(DFGPU_EXECUTION, "list_flatten: %lld bytes of list values are not a whole number of %d-byte values", (long long)bytes, w);
+    const int64_t ne = bytes / w;
+    ArrayHolder v(new_fixed(ctx, value_type, ne)), r(new_fixed(ctx, DFGPU_UINT32, ne)); v.get()->precision = precision; v.get()->scale = scale;
+    if (ne) { HIP_CHECK(hipMemcpyAsync(v.get()->values->ptr, (const char*)list->values->ptr + ends[0], (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_list_row_of, dim3(grid_for(ne, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const int32_t*)list->offsets->ptr, n, ne, (uint32_t)w, (uint32_t*)r.get()->values->ptr); KERNEL_CHECK(); }
+    *out_values = v.release(); *out_row_of = r.release();
   });
 }
 

@@ -1125,8 +1125,8 @@ struct StringMinMax {
   }
 };
 // COUNT(DISTINCT x) (physical-expr/src/aggregate/count_distinct/: a set of values per group): the (group id, value) pairs are interned in a GroupValues of their own;
-// every NEW pair adds one to its group's count.  The reference's Partial state is a List per group, which the flat state arrays here do not carry: Single /
-// SinglePartitioned only (the planner's SingleDistinctToGroupBy rewrite covers the partitioned form with ordinary aggregates).
+// every NEW pair adds one to its group's count.  Partial emits the reference's state -- one List of distinct values per group -- in the Utf8 layout (state()), Final /
+// FinalPartitioned merge such lists (merge()); fixed-width argument types (Utf8 arguments: Single / SinglePartitioned only).
 struct CountDistinct {
   GroupsRef pairs; AccRef cnt;
   void init(const TaskContext& tc) { tc.check(dfgpu_groups_new(tc.ctx, 2, &pairs.g)); tc.check(dfgpu_acc_new(tc.ctx, DFGPU_AGG_COUNT, DFGPU_INT64, 0, 0, &cnt.a)); }
@@ -1146,6 +1146,26 @@ struct CountDistinct {
     dfgpu_array_desc ed{}; ed.type = DFGPU_UINT32; ed.values = &ed; dfgpu_array* e = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &ed, &e)); ArrayRef empty_ids = ArrayRef::adopt(e);
     tc.check(dfgpu_acc_update_batch(tc.ctx, cnt.a, nullptr, empty_ids.a, nullptr, total));
     dfgpu_array* v = nullptr; tc.check(dfgpu_acc_evaluate(tc.ctx, cnt.a, &v)); return ArrayRef::adopt(v);
+  }
+  // state() (count_distinct/native.rs:97-110: one List of the group's distinct values): the interned (group, value) pairs ordered by group -- stable, so a group's values
+  // stay in first-seen order -- and cut by the groups' counts.  The list column travels in the Utf8 layout (dfgpu_list_from_counts).
+  ArrayRef state(const TaskContext& tc, int64_t total, int32_t value_type) {
+    ArrayRef counts = emit(tc, total);
+    const int64_t np = dfgpu_groups_len(pairs.g);
+    ArrayRef vals;
+    if (np > 0) {
+      dfgpu_array* keys[2] = { nullptr, nullptr }; tc.check(dfgpu_groups_emit(tc.ctx, pairs.g, keys)); ArrayRef k0 = ArrayRef::adopt(keys[0]), k1 = ArrayRef::adopt(keys[1]);
+      const dfgpu_array* kp = k0.a; uint8_t no = 0; dfgpu_array* perm = nullptr; tc.check(dfgpu_sort_to_indices(tc.ctx, &kp, &no, &no, 1, -1, &perm)); ArrayRef pm = ArrayRef::adopt(perm);
+      vals = take(tc, k1, pm);
+    } else { dfgpu_array* z = nullptr; tc.check(dfgpu_array_new_zeros(tc.ctx, value_type, 0, 0, 0, &z)); vals = ArrayRef::adopt(z); }
+    dfgpu_array* l = nullptr; tc.check(dfgpu_list_from_counts(tc.ctx, counts.a, vals.a, &l)); return ArrayRef::adopt(l);
+  }
+  // merge_batch (native.rs:131-150: every value of every incoming list is inserted into its group's set): the lists flattened, each value with the group id of its row
+  void merge(const TaskContext& tc, const ArrayRef& g_in, const ArrayRef& lists, const ArrayRef& row_mask, int64_t total, int32_t value_type, int32_t precision, int32_t scale) {
+    dfgpu_array *v = nullptr, *r = nullptr; tc.check(dfgpu_list_flatten(tc.ctx, lists.a, value_type, precision, scale, &v, &r)); ArrayRef vals = ArrayRef::adopt(v), row_of = ArrayRef::adopt(r);
+    if (vals.len() == 0) return;                        // nothing to insert; emit() grows the counts to `total` groups
+    ArrayRef ge = take(tc, g_in, row_of), fe; if (row_mask) fe = take(tc, row_mask, row_of);
+    update(tc, ge, vals, fe, total);
   }
 };
 
@@ -1393,6 +1413,9 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
         if (merging() && is_string_minmax(i)) {           // the state column is the value (min_max.rs state())
           ArrayRef stv = b.column(tc, (int)col); col += 1;
           smm[i].update(tc, gids, stv, mask);              // rows a fused selection dropped carry no state
+        } else if (merging() && aggs[i].kind == DFGPU_AGG_COUNT_DISTINCT) {      // the state column is the list of the group's distinct values
+          ArrayRef stv = b.column(tc, (int)col); col += 1;
+          cds[i].merge(tc, gids, stv, mask, total, aggs[i].type, aggs[i].precision, aggs[i].scale);
         } else if (merging()) {
           int nst = aggs[i].kind == DFGPU_AGG_AVG ? 2 : 1; const dfgpu_array* st[2];
           for (int k = 0; k < nst; k++) st[k] = b.column(tc, (int)(col + (size_t)k)).a;
@@ -1433,7 +1456,7 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
       dfgpu_array_desc ed{}; ed.type = DFGPU_UINT32; ed.values = &ed; dfgpu_array* e = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &ed, &e)); ArrayRef empty_ids = ArrayRef::adopt(e);
       for (size_t i = 0; i < aggs.size(); i++) {
         if (is_string_minmax(i)) { o.cols.push_back(col_of(smm[i].emit(tc, total))); continue; }          // state and final value are the same column
-        if (aggs[i].kind == DFGPU_AGG_COUNT_DISTINCT) { o.cols.push_back(col_of(cds[i].emit(tc, total))); continue; }
+        if (aggs[i].kind == DFGPU_AGG_COUNT_DISTINCT) { o.cols.push_back(col_of(as_state ? cds[i].state(tc, total, aggs[i].type) : cds[i].emit(tc, total))); continue; }
         tc.check(dfgpu_acc_update_batch(tc.ctx, accs[i].a, nullptr, empty_ids.a, nullptr, total));      // zero-row update: grow the state to `total` groups
         if (as_state) { dfgpu_array* st[2] = {nullptr, nullptr}; int32_t n = 0; tc.check(dfgpu_acc_state(tc.ctx, accs[i].a, st, &n)); for (int k = 0; k < n; k++) o.cols.push_back(col_of(ArrayRef::adopt(st[k]))); }
         else { dfgpu_array* v = nullptr; tc.check(dfgpu_acc_evaluate(tc.ctx, accs[i].a, &v)); o.cols.push_back(col_of(ArrayRef::adopt(v))); }
@@ -2048,7 +2071,8 @@ dfgpu_status dfgpu_plan_aggregate(int32_t mode, const dfgpu_expr* const* gexprs,
       AggExpr x; x.kind = kinds[i]; if (args && args[i]) x.arg = args[i]->e; if (filters && filters[i]) x.filter = filters[i]->e; x.name = names[i] ? names[i] : "";
       x.type = types[3 * i]; x.precision = types[3 * i + 1]; x.scale = types[3 * i + 2];
       if (x.kind < DFGPU_AGG_SUM || x.kind > DFGPU_AGG_COUNT_DISTINCT) fail(DFGPU_NOT_IMPLEMENTED, "aggregate kind %d has no GroupsAccumulator on device", x.kind);
-      if (x.kind == DFGPU_AGG_COUNT_DISTINCT && mode != 3 && mode != 4) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: COUNT(DISTINCT) in AggregateMode %d on the device (its Partial state is a List per group); Single / SinglePartitioned are", mode);
+      if (x.kind == DFGPU_AGG_COUNT_DISTINCT && mode != 3 && mode != 4 && (x.type == DFGPU_UTF8 || x.type == DFGPU_DICTIONARY || x.type == DFGPU_BOOL))
+        fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: COUNT(DISTINCT) over a type %d argument in AggregateMode %d on the device (its Partial state is a List per group, carried for fixed-width values); Single / SinglePartitioned are", x.type, mode);
       if (!x.arg && x.kind != DFGPU_AGG_COUNT && mode != 1 && mode != 2) fail(DFGPU_INVALID_ARGUMENT, "aggregate %s needs an argument", x.name.c_str());
       a->aggs.push_back(std::move(x));
     }

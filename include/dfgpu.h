@@ -179,6 +179,12 @@ DFGPU_API int64_t dfgpu_array_null_count(dfgpu_ctx *ctx, const dfgpu_array *a); 
 DFGPU_API dfgpu_status dfgpu_array_slice(dfgpu_ctx *ctx, const dfgpu_array *a, int64_t offset, int64_t length, dfgpu_array **out);
 /* concat_batches per column (hash_join.rs:764, coalesce_batches.rs:198-260, sorts/sort.rs:505). */
 DFGPU_API dfgpu_status dfgpu_concat(dfgpu_ctx *ctx, const dfgpu_array *const *arrays, int32_t n, dfgpu_array **out);
+/* Lists of fixed-width values (the List<T> state column of COUNT(DISTINCT), physical-expr/src/aggregate/count_distinct/native.rs:state()) travel in the Utf8 layout:
+ * offsets are BYTE offsets into the packed values, so every operation that moves a Utf8 column (take, filter, concat, slice, partition, exchange, Arrow export) moves a
+ * list column; an Arrow ListArray is the same buffers with the offsets divided by the value width.  dfgpu_list_from_counts: row i gets the next counts[i] (Int64) values;
+ * dfgpu_list_flatten: the values of all rows back to back (typed value_type) and, per value, the row it belongs to (UInt32) -- what merging such a state needs. */
+DFGPU_API dfgpu_status dfgpu_list_from_counts(dfgpu_ctx *ctx, const dfgpu_array *counts, const dfgpu_array *values, dfgpu_array **out);
+DFGPU_API dfgpu_status dfgpu_list_flatten(dfgpu_ctx *ctx, const dfgpu_array *list, int32_t value_type, int32_t precision, int32_t scale, dfgpu_array **out_values, dfgpu_array **out_row_of);
 /* fixed-width column of `length` zeros, no validity (e.g. the single group id of an AggregateExec without GROUP BY) */
 DFGPU_API dfgpu_status dfgpu_array_new_zeros(dfgpu_ctx *ctx, int32_t type, int32_t precision, int32_t scale, int64_t length, dfgpu_array **out);
 /* DictionaryArray::try_new(keys, values) without copying: an integer array of codes (its validity = NULL codes) over a values array.

@@ -96,7 +96,9 @@ DFGPU_API dfgpu_status dfgpu_plan_sort_merge_join(const dfgpu_plan *left, const 
  * (:373-378) is collected, the other side streams and decides the output partitioning.  JoinFilter as for dfgpu_plan_hash_join (NULL = cross join). */
 DFGPU_API dfgpu_status dfgpu_plan_nested_loop_join(const dfgpu_plan *left, const dfgpu_plan *right, const dfgpu_expr *filter, const int32_t *filter_sides, const int32_t *filter_indices,
                                                    int32_t nfilter_cols, int32_t join_type, dfgpu_plan **out);
-/* Aggregate kinds of the plan layer beyond DFGPU_AGG_* (include/dfgpu.h): COUNT(DISTINCT x) (aggregate/count_distinct/) -- Single / SinglePartitioned modes only.  MIN / MAX
+/* Aggregate kinds of the plan layer beyond DFGPU_AGG_* (include/dfgpu.h): COUNT(DISTINCT x) (aggregate/count_distinct/) -- every mode for fixed-width arguments: the Partial state is the reference's List of distinct values per group, carried in the
+ * Utf8 layout (dfgpu_list_from_counts / dfgpu_list_flatten, include/dfgpu.h; a ListArray is the same buffers with the offsets divided by the value width); Utf8 arguments in Single /
+ * SinglePartitioned modes only.  MIN / MAX
  * over Utf8 (input type DFGPU_UTF8) are also served by the plan layer, in every mode. */
 enum { DFGPU_AGG_COUNT_DISTINCT = 5 };
 /* AggregateExec::try_new(mode, group_by, aggr_expr, input): mode 0 Partial, 1 Final, 2 FinalPartitioned, 3 Single,

@@ -79,9 +79,9 @@ def test_device_equals_models_on_random_batches(ctx, mode):
         batches.append(pa.table({"k": pa.array(rng.integers(0, 40, n).astype(np.int64), mask=rng.random(n) < 0.05),
                                  "s": pa.array(words[rng.integers(0, 60, n)], mask=rng.random(n) < 0.3),
                                  "v": pa.array(rng.integers(0, 25, n).astype(np.int64), mask=rng.random(n) < 0.2)}))
-    aggs = [("MIN", "s", capi.UTF8), ("MAX", "s", capi.UTF8), ("COUNT", "v", capi.INT64)]
+    aggs = [("MIN", "s", capi.UTF8), ("MAX", "s", capi.UTF8), ("COUNT", "v", capi.INT64), ("COUNT DISTINCT", "v", capi.INT64)]
     if mode == "Single":
-        aggs += [("COUNT DISTINCT", "v", capi.INT64), ("COUNT DISTINCT", "s", capi.UTF8)]
+        aggs += [("COUNT DISTINCT", "s", capi.UTF8)]
     out = agg_plan(ctx, batches, ["k"], aggs, mode)
     allt = pa.concat_tables(batches)
     og = po.Groups([pa.int64()]); gids = og.intern([allt["k"].combine_chunks()]); total = len(og)
@@ -89,16 +89,122 @@ def test_device_equals_models_on_random_batches(ctx, mode):
     s, v = allt["s"].combine_chunks(), allt["v"].combine_chunks()
     assert out.column(1).combine_chunks().equals(po.string_min_max(s, gids, total, False))
     assert out.column(2).combine_chunks().equals(po.string_min_max(s, gids, total, True))
+    assert out.column(4).combine_chunks().equals(po.count_distinct(v, gids, total))        # PartialFinal: through the List state of the Partial stage
     if mode == "Single":
-        assert out.column(4).combine_chunks().equals(po.count_distinct(v, gids, total))
         assert out.column(5).combine_chunks().equals(po.count_distinct(s, gids, total))
 
 
 @pytest.mark.gpu
-def test_device_refuses_count_distinct_in_partial_mode(ctx):
+def test_device_refuses_count_distinct_over_strings_in_partial_mode(ctx):
     import dfgpu
     from dfgpu import capi
-    t = pa.table({"k": pa.array([1, 2], type=pa.int64()), "v": pa.array([1, 1], type=pa.int64())})
+    t = pa.table({"k": pa.array([1, 2], type=pa.int64()), "v": pa.array(["a", "a"])})
     with pytest.raises(dfgpu.DfgpuError) as e:
-        agg_plan(ctx, [t], ["k"], [("COUNT DISTINCT", "v", capi.INT64)], "PartialFinal")
+        agg_plan(ctx, [t], ["k"], [("COUNT DISTINCT", "v", capi.UTF8)], "PartialFinal")
     assert e.value.kind == "NotImplemented"
+
+
+def lists_of(col: pa.Array, dtype):
+    """a list column as it travels on the device (Utf8 layout: byte offsets into the packed values) -> Python lists"""
+    col = col.combine_chunks() if isinstance(col, pa.ChunkedArray) else col
+    off = np.frombuffer(col.buffers()[1], dtype=np.int32)[col.offset: col.offset + len(col) + 1]
+    data = np.frombuffer(col.buffers()[2], dtype=np.uint8) if col.buffers()[2] is not None else np.zeros(0, np.uint8)
+    return [np.frombuffer(data[off[i]: off[i + 1]].tobytes(), dtype=dtype).tolist() for i in range(len(col))]
+
+
+def partial_and_final(ctx, table, keys, col, typ, batches=1):
+    """-> (the Partial stage's state lists, the Final stage's counts) of COUNT(DISTINCT col)"""
+    from dfgpu import physical_plan as ops
+    n = table.num_rows; step = max(1, (n + batches - 1) // batches)
+    bs = [ops.batch_from_arrow(ctx, table.slice(o, step)) for o in range(0, max(n, 1), step)]
+    src = ops.MemoryExec([bs], bs[0].schema)
+    names = table.column_names; C, F = ops.Column, ops.Field
+    agg = lambda: [ops.AggregateFunctionExpr("COUNT DISTINCT", C(col, names.index(col)), "cd", input_field=F(col, typ))]
+    gb = [(C(k, names.index(k)), k) for k in keys]
+    partial = ops.AggregateExec("Partial", gb, agg(), src)
+    tc = ops.TaskContext(ctx, 8192)
+    st = pa.concat_tables([b.to_arrow() for b in partial.execute(0, tc)])
+    final = ops.AggregateExec("Final", [(C(k, i), k) for i, k in enumerate(keys)], agg(), ops.AggregateExec("Partial", gb, agg(), src))
+    out = pa.concat_tables([b.to_arrow() for b in final.execute(0, tc)])
+    return st, out
+
+
+REF = "physical-expr/src/aggregate/count_distinct/mod.rs"
+NUMERIC = [1, 1, None, 3, 2, None, 2, 3, 1]                    # test_count_distinct_update_batch_numeric (:305-331): state sorted == [1, 2, 3], result 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pat,npt,code", [(pa.int8(), np.int8, "INT8"), (pa.int16(), np.int16, "INT16"), (pa.int32(), np.int32, "INT32"), (pa.int64(), np.int64, "INT64"), (pa.uint8(), np.uint8, "UINT8"),
+                                          (pa.uint16(), np.uint16, "UINT16"), (pa.uint32(), np.uint32, "UINT32"), (pa.uint64(), np.uint64, "UINT64")], ids=lambda x: str(x) if isinstance(x, pa.DataType) else "")
+def test_count_distinct_state_and_result_reference_numeric(ctx, pat, npt, code):
+    """count_distinct_update_batch_i8 .. u64 (mod.rs:482-520): the accumulator's state is ONE list holding the distinct values (compared sorted, as the reference does), the result 3"""
+    from dfgpu import capi
+    st, out = partial_and_final(ctx, pa.table({"v": pa.array(NUMERIC, type=pat)}), [], "v", getattr(capi, code))
+    assert [sorted(x) for x in lists_of(st.column(0), npt)] == [[1, 2, 3]]
+    assert out.column(0).to_pylist() == [3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pat,npt,code,sub", [(pa.float32(), np.float32, "FLOAT32", 1.0e-40), (pa.float64(), np.float64, "FLOAT64", 1.0e-308)], ids=["f32", "f64"])
+def test_count_distinct_state_and_result_reference_floating_point(ctx, pat, npt, code, sub):
+    """test_count_distinct_update_batch_floating_point (mod.rs:398-450): infinities, a subnormal, NaN twice (one value: Hashable compares bit patterns) -> 8 distinct"""
+    from dfgpu import capi
+    inf, nan = float("inf"), float("nan")
+    vals = [inf, nan, 1.0, sub, 1.0, inf, None, 3.0, -4.5, 2.0, None, 2.0, 3.0, -inf, 1.0, nan, -inf]
+    st, out = partial_and_final(ctx, pa.table({"v": pa.array(vals, type=pat)}), [], "v", getattr(capi, code))
+    got = sorted(lists_of(st.column(0), npt)[0], key=lambda x: (np.isnan(x), x))
+    want = [-inf, -4.5, float(npt(sub)), 1.0, 2.0, 3.0, inf]
+    assert got[:-1] == want and np.isnan(got[-1])
+    assert out.column(0).to_pylist() == [8]
+
+
+@pytest.mark.gpu
+def test_count_distinct_state_of_nulls_and_of_nothing(ctx):
+    """count_distinct_update_batch_all_nulls / _empty (mod.rs:583-608): an empty list, result 0; count_distinct_update / _with_nulls (:611-680): -1, 5, 2 -> 3; NULLs do not count"""
+    from dfgpu import capi
+    st, out = partial_and_final(ctx, pa.table({"v": pa.array([None, None, None, None], type=pa.int32())}), [], "v", capi.INT32)
+    assert lists_of(st.column(0), np.int32) == [[]] and out.column(0).to_pylist() == [0]
+    st, out = partial_and_final(ctx, pa.table({"v": pa.array([], type=pa.int32())}), [], "v", capi.INT32)
+    assert lists_of(st.column(0), np.int32) == [[]] and out.column(0).to_pylist() == [0]
+    st, out = partial_and_final(ctx, pa.table({"v": pa.array([-1, 5, -1, 5, -1, -1, 2], type=pa.int32())}), [], "v", capi.INT32, batches=7)      # run_update: one row per update_batch
+    assert [sorted(x) for x in lists_of(st.column(0), np.int32)] == [[-1, 2, 5]] and out.column(0).to_pylist() == [3]
+    st, out = partial_and_final(ctx, pa.table({"v": pa.array([1, 1, 2, 1, None, None], type=pa.uint64())}), [], "v", capi.UINT64, batches=6)
+    assert [sorted(x) for x in lists_of(st.column(0), np.uint64)] == [[1, 2]] and out.column(0).to_pylist() == [2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("parts", [1, 3])
+def test_count_distinct_partial_states_through_repartition_into_final(ctx, parts):
+    """Partial -> RepartitionExec(Hash on the group key) -> CoalesceBatchesExec -> FinalPartitioned: the list states are taken, partitioned and concatenated as columns like
+    any other; per-group lists of the Partial stage hold exactly the group's distinct values in first-seen order; the counts equal the model's and the Single mode's;
+    Decimal128 values (16 bytes wide) and a second, plain aggregate next to it."""
+    import decimal
+    from dfgpu import capi, physical_plan as ops
+    rng = np.random.default_rng(parts)
+    n = 30_000
+    k = rng.integers(0, 300, n).astype(np.int64); v = rng.integers(0, 40, n)
+    t = pa.table({"k": pa.array(k, mask=rng.random(n) < 0.02), "v": pa.array(v, mask=rng.random(n) < 0.2), "d": pa.array([decimal.Decimal(int(x) * 7 - 100).scaleb(-2) for x in v], type=pa.decimal128(15, 2), mask=rng.random(n) < 0.1)})
+    batches = [t.slice(o, 4096) for o in range(0, n, 4096)]
+    C, F = ops.Column, ops.Field
+    bs = [[ops.batch_from_arrow(ctx, b) for b in batches[p::parts]] for p in range(parts)]
+    src = ops.MemoryExec(bs, bs[0][0].schema)
+    aggs = lambda: [ops.AggregateFunctionExpr("COUNT DISTINCT", C("v", 1), "cv", input_field=F("v", capi.INT64)), ops.AggregateFunctionExpr("SUM", C("v", 1), "sv", input_field=F("v", capi.INT64)),
+                    ops.AggregateFunctionExpr("COUNT DISTINCT", C("d", 2), "cd", input_field=F("d", capi.DECIMAL128, 15, 2))]
+    partial = ops.AggregateExec("Partial", [(C("k", 0), "k")], aggs(), src)
+    tc = ops.TaskContext(ctx, 8192)
+    # the Partial stage alone (partition 0): lists == the distinct values of each group, first-seen order
+    st = pa.concat_tables([b.to_arrow() for b in partial.execute(0, tc)])
+    seen = pa.concat_tables(batches[0::parts])
+    og = po.Groups([pa.int64()]); gids = og.intern([seen["k"].combine_chunks()])
+    want = [[] for _ in range(len(og))]
+    for g, x in zip(np.asarray(gids).tolist(), seen["v"].to_pylist()):
+        if x is not None and x not in want[g]:
+            want[g].append(x)
+    assert st.column(0).combine_chunks().equals(og.emit()[0]) and lists_of(st.column(1), np.int64) == want
+    plan = ops.AggregateExec("FinalPartitioned", [(C("k", 0), "k")], aggs(),
+                             ops.CoalesceBatchesExec(ops.RepartitionExec(ops.AggregateExec("Partial", [(C("k", 0), "k")], aggs(), src), ops.Partitioning.Hash([C("k", 0)], 4)), 8192))
+    out = pa.concat_tables([b.to_arrow() for p in range(4) for b in plan.execute(p, tc)]).sort_by([("k", "ascending")])
+    single = pa.concat_tables([b.to_arrow() for b in ops.AggregateExec("Single", [(C("k", 0), "k")], aggs(), ops.MemoryExec([[x for p in bs for x in p]], bs[0][0].schema)).execute(0, tc)]).sort_by([("k", "ascending")])
+    assert out.equals(single)
+    ref = t.group_by("k", use_threads=False).aggregate([("v", "count_distinct"), ("v", "sum"), ("d", "count_distinct")]).sort_by([("k", "ascending")])
+    assert out["cv"].to_pylist() == ref["v_count_distinct"].to_pylist() and out["cd"].to_pylist() == ref["d_count_distinct"].to_pylist() and out["sv"].to_pylist() == ref["v_sum"].to_pylist()
