@@ -108,6 +108,7 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
  * AggregateExec pre-aggregate large batches of high-cardinality unclustered keys partition by partition out of LDS (dfgpu_agg_preaggregate);
  * "agg_preaggregate_distinct" (read only) == 1 when the last dfgpu_agg_preaggregate call on this ctx emitted every key in exactly one partial row;
  * "sort_packed_keys" (1/0) == let sort_to_indices sort large inputs over fixed-width keys through range-packed 64-bit keys (identical indices);
+ * "sort_estimate_ranges" (1/0) == from 2^22 rows on, take those ranges from a sample and check them while packing (a miss repeats the step with exact ranges; identical indices);
  * "memory_limit" (bytes, 0 = none) == live device memory this ctx may hold; an allocation beyond it fails with DFGPU_RESOURCES_EXHAUSTED and the
  * message of MemoryPool::try_grow (≙ RuntimeConfig::with_memory_limit, execution/src/runtime_env.rs); "live_bytes" / "cached_bytes" (read only);
  * "agg_spill_state_bytes" (0 = never) == the state size (group table + accumulators) above which AggregateExec spills to host memory (non-Partial modes,

@@ -203,3 +203,31 @@ def test_sort_exec_uses_sorted_key_columns(ctx):
     out = pa.concat_tables([b.to_arrow() for b in plan.execute(0, ops.TaskContext(ctx, 8192))])
     order = po.lexsort_to_indices([t["price"].combine_chunks(), t["d"].combine_chunks()], [True, False], [True, False])
     assert out.equals(t.take(pa.array(order)))
+
+
+@pytest.mark.parametrize("shape", ["ranges_hold", "outliers_outside_the_sample", "column_valid_only_off_the_sample", "estimate_off"])
+def test_packed_sort_key_ranges_from_a_sample(ctx, shape):
+    """From 2^22 rows on, the packed-key sort takes the value ranges from a sample (every n / 2^19-th row, widened), the encode pass checks every value against them and a
+    miss costs the exact pass: a few extreme values on rows the sample does not visit; a column that is NULL wherever the sample looks.  The indices are numpy's stable
+    lexsort either way, and the profile shows which passes ran."""
+    rng = np.random.default_rng(17)
+    n = (1 << 22) + 4321
+    step = max(2, n >> 19)
+    a = rng.integers(1000, 2000, n).astype(np.int64); b = rng.integers(0, 7, n).astype(np.int32)
+    mask_b = None
+    if shape == "outliers_outside_the_sample":
+        a[step + 1] = -(10**12); a[5 * step + 3] = 10**12            # rows the strided sample does not visit
+    if shape == "column_valid_only_off_the_sample":
+        mask_b = (np.arange(n) % step) == 0                            # NULL on every sampled row
+    if shape == "estimate_off":
+        ctx.set_option("sort_estimate_ranges", 0)
+    cols = [pa.array(a), pa.array(b, mask=mask_b)]
+    ctx.profile_select(None); ctx.profile_enable(True); ctx.profile_read()
+    try:
+        got = ctx.sort_to_indices([ctx.from_arrow(c) for c in cols], [True, False], [True, False]).to_numpy()
+        ks = set(ctx.profile_read())
+    finally:
+        ctx.profile_enable(False); ctx.set_option("sort_estimate_ranges", 1)
+    assert np.array_equal(got, po.lexsort_to_indices(cols, [True, False], [True, False]))
+    assert ("sort_key_sample" in ks) == (shape != "estimate_off")
+    assert ("sort_key_ranges" in ks) == (shape != "ranges_hold")
