@@ -379,6 +379,33 @@ def run(args, ctx=None, emit=True):
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ general-case operators: keys that are neither clustered nor dense
+    # ------------------------------------------------------------------ unique build keys over a dense domain, in no order (a primary-key side after a hash repartition -- the N > 1 shuffle plan's builds)
+    if not want or "hash_join" in want or "hash_join_dense_unsorted" in want:
+        nbd, npd = int(150_000 * args.sf), int(1_500_000 * args.sf)
+        bkd = torch.randperm(nbd * 4, generator=g, device="cuda")[:nbd].to(torch.int64) + 1
+        pkd = torch.randint(1, nbd * 4 + 1, (npd,), generator=g, device="cuda", dtype=torch.int64)
+        pvd = torch.randint(0, 10**6, (npd,), generator=g, device="cuda", dtype=torch.int64)
+        torch.cuda.synchronize()
+        leftd = ops.RecordBatch.from_arrays(ctx, ["k"], [ctx.wrap_tensor(bkd, capi.INT64)])
+        rightd = ops.RecordBatch.from_arrays(ctx, ["k", "v"], [ctx.wrap_tensor(pkd, capi.INT64), ctx.wrap_tensor(pvd, capi.INT64)])
+        jd = ops.HashJoinExec(ops.MemoryExec([[leftd]], leftd.schema), ops.MemoryExec([[rightd]], rightd.schema), [(C("k", 0), C("k", 0))], None, "Inner", "CollectLeft")
+        pland = ops.AggregateExec("Single", [], [ops.AggregateFunctionExpr("SUM", C("v", 2), "s", input_field=F("v", capi.INT64)), ops.AggregateFunctionExpr("COUNT", None, "c")], jd)
+        dt, rows, kern, syncs = time_plan(ctx, ops, tc, pland, args.steps, args.warmup)
+        res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
+        member = torch.zeros(nbd * 4 + 2, dtype=torch.bool, device="cuda"); member[bkd] = True; hitd = member[pkd]
+        ok = int(res[1][0]) == int(hitd.sum().item()) and wrap64(int(res[0][0])) == wrap64(int(pvd[hitd].sum().item()))
+        ctx.set_option("join_rank_index_unsorted", 0)
+        try:
+            dt0, _, kern0, _ = time_plan(ctx, ops, tc, pland, args.steps, args.warmup)
+            res0 = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
+        finally:
+            ctx.set_option("join_rank_index_unsorted", 1)
+        ok = ok and int(res0[1][0]) == int(res[1][0]) and wrap64(int(res0[0][0])) == wrap64(int(res[0][0]))
+        report("hash_join_dense_unsorted", dt, nbd + npd, rows, round((nbd * 8 + npd * 16) / (nbd + npd), 2), kern, syncs, {"build_rows": nbd, "probe_rows": npd, "match_fraction": 0.25,
+               "hash_table_ms_per_step": round(dt0 * 1e3, 3), "hash_table_kernel_ms_per_step": kern0,
+               "result_check": check("hash_join_dense_unsorted", ok, "COUNT(*) and SUM(v) over the join output == a torch membership table over the same keys, and == the same plan through the bitmap + hash table")})
+        del bkd, pkd, pvd, leftd, rightd, jd, pland, member, hitd
+        torch.cuda.empty_cache()
     if not want or "hash_join" in want or "hash_join_plain" in want or "hash_join_fk5" in want or "hash_join_two_keys" in want:          # hash_join = every variant; _plain / _fk5 / _two_keys = one of them (profiling passes)
         do_plain, do_fk5 = (not want or "hash_join" in want or "hash_join_plain" in want), (not want or "hash_join" in want or "hash_join_fk5" in want)
         do_two = not want or "hash_join" in want or "hash_join_two_keys" in want

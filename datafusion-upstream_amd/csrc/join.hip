@@ -270,6 +270,23 @@ __global__ void __launch_bounds__(BLOCK) k_check_increasing(const T* keys, int64
   if (ballot64(dup) && lane_id() == 0) out[3] = 1ull;
   if (blockIdx.x == 0 && threadIdx.x == 0) { out[1] = (unsigned long long)(long long)keys[0]; out[2] = (unsigned long long)(long long)keys[n - 1]; }   // one read-back for all of them
 }
+// ---- rank index over UNSORTED unique keys (a key column after a hash repartition, a filtered dimension table in arrival order): the membership bitmap still ranks the
+// keys; one more array, rank -> build row, takes the place of the sort order.  Setting the bits finds repeated keys (the bit is already there).
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_key_setbits_unique(const T* keys, const uint64_t* mask, int64_t n, int64_t kmin, uint64_t* bitmap, unsigned long long* dup) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n || (mask && !bit_get(mask, i))) return;
+  const uint64_t d = (uint64_t)((int64_t)keys[i] - kmin), bit = 1ull << (d & 63);
+  const unsigned long long old = atomicOr((unsigned long long*)&bitmap[d >> 6], (unsigned long long)bit);
+  if (old & bit) *dup = 1ull;
+}
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_rank_rows(const T* keys, const uint64_t* mask, int64_t n, int64_t kmin, const uint64_t* bitmap, const uint32_t* prefix, uint32_t* row_of_rank) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n || (mask && !bit_get(mask, i))) return;
+  const uint64_t d = (uint64_t)((int64_t)keys[i] - kmin);
+  row_of_rank[prefix[d >> 6] + (uint32_t)__popcll(bitmap[d >> 6] & ((1ull << (d & 63)) - 1ull))] = (uint32_t)i;
+}
 // heads bit i = row i starts a run of equal keys
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_key_run_heads(const T* keys, int64_t n, uint64_t* heads) {
@@ -559,12 +576,62 @@ __global__ void __launch_bounds__(BLOCK) k_key_minmax_masked(const T* keys, cons
     if (lo <= hi) { atomicMin(mn, lo); atomicMax(mx, hi); }
   }
 }
+// Rank index over unsorted unique keys (see k_key_setbits_unique).  Tried after build_rank_index found the keys unsorted: min / max of the selected keys, a domain of at most
+// 64 slots per key (bitmap + prefix <= 12 bytes per build row), the bits set with repeat detection, then rank -> row.  false = not taken, nothing kept.
+static bool build_rank_index_unsorted(dfgpu_ctx* ctx, dfgpu_join_table* t) {
+  const int64_t n = t->n_build;
+  if (!ctx->join_rank_index || !ctx->join_rank_index_unsorted || ctx->force_hash_collisions || n < 2 || n > 0xFFFFFFF0ll || t->nkeys != 1 || t->null_equals_null) return false;
+  const dfgpu_array* key0 = t->keys[0];
+  if (key0->type == DFGPU_DICTIONARY || !int_key_type(key0->type) || key0->validity) return false;
+  KernelTimer kt_(ctx, "join_build_rank");
+  const uint64_t* mk = t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr;
+  long long init[2] = { INT64_MAX, INT64_MIN };
+  HIP_CHECK(hipMemcpyAsync(ctx->d_scratch64 + 4, init, 16, hipMemcpyHostToDevice, ctx->stream));
+  DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_minmax_masked<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 4)), dim3(BLOCK), 0, ctx->stream, (const T*)key0->values->ptr,
+                                                        (const uint64_t*)nullptr, mk, n, (long long*)(ctx->d_scratch64 + 4), (long long*)(ctx->d_scratch64 + 5)));
+  KERNEL_CHECK();
+  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 4, ctx->d_scratch64 + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
+  ctx->count_sync("sync:rank_index_range");
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  const long long lo = (long long)ctx->h_pinned[4], hi = (long long)ctx->h_pinned[5];
+  t->have_minmax = true; t->sel_min = lo; t->sel_max = hi;
+  if (lo > hi) return false;                               // no selected row
+  const uint64_t range = (uint64_t)hi - (uint64_t)lo + 1;
+  if (range == 0 || range > (1ull << 32) || range > (uint64_t)n * 64 + 65536) return false;
+  const int64_t nw = (int64_t)((range + 63) / 64);
+  BufferPtr bitmap = alloc_buffer(ctx, bitmap_bytes((int64_t)range));
+  HIP_CHECK(hipMemsetAsync(bitmap->ptr, 0, bitmap_bytes((int64_t)range), ctx->stream));
+  HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 6, 0, 8, ctx->stream));
+  DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_setbits_unique<T>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const T*)key0->values->ptr, mk, n, (int64_t)lo, (uint64_t*)bitmap->ptr,
+                                                        (unsigned long long*)(ctx->d_scratch64 + 6)));
+  BufferPtr prefix = alloc_buffer(ctx, (size_t)nw * 4);
+  hipLaunchKernelGGL(k_popc_words, dim3(grid_for(nw, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)bitmap->ptr, nw, (uint32_t*)prefix->ptr);
+  exclusive_scan_u32_inplace32(ctx, (uint32_t*)prefix->ptr, nw, ctx->d_scratch64 + 7);
+  KERNEL_CHECK();
+  const uint64_t* hsc = read_scratch_range(ctx, 6, 2);
+  ctx->count_sync("sync:rank_index_unique");
+  if (hsc[0] != 0) return false;                           // a key repeats: the hash paths keep their CSR
+  const int64_t nsel = (int64_t)hsc[1];
+  ArrayHolder rows(new_fixed(ctx, DFGPU_UINT32, nsel));
+  DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_rank_rows<T>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const T*)key0->values->ptr, mk, n, (int64_t)lo, (const uint64_t*)bitmap->ptr,
+                                                        (const uint32_t*)prefix->ptr, (uint32_t*)rows.get()->values->ptr));
+  KERNEL_CHECK();
+  t->key_min = lo; t->range = range; t->rank_mode = true; t->unique = true; t->rank_runs = false; t->rank_identity = false;
+  t->bitmap = bitmap; t->rank_prefix = prefix; t->sel_rows = rows.release();
+  t->mem += (int64_t)bitmap_bytes((int64_t)range) + nw * 4 + nsel * 4;
+  return true;
+}
 static bool pj_domain_is_sparse(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   int64_t n = t->n_build;
   if (!ctx->join_partitioned || ctx->force_hash_collisions || t->nkeys != 1 || t->null_equals_null || n < ctx->join_partitioned_min_build) return false;
   const dfgpu_array* key0 = t->keys[0];
   if (key0->type == DFGPU_UINT64) return true;
   if (key0->type == DFGPU_DICTIONARY || !int_key_type(key0->type)) return false;
+  if (t->have_minmax && !key0->validity) {                 // build_rank_index_unsorted has been here (it takes columns without NULLs only)
+    if (t->sel_min > t->sel_max) return false;
+    const uint64_t range = (uint64_t)t->sel_max - (uint64_t)t->sel_min + 1;
+    return range == 0 || range > (1ull << 32) || range > (uint64_t)n * 256;
+  }
   long long init[2] = { INT64_MAX, INT64_MIN };
   HIP_CHECK(hipMemcpyAsync(ctx->d_scratch64 + 4, init, 16, hipMemcpyHostToDevice, ctx->stream));
   DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_minmax_masked<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 4)), dim3(BLOCK), 0, ctx->stream, (const T*)key0->values->ptr,
@@ -638,7 +705,7 @@ dfgpu_status dfgpu_join_build(dfgpu_ctx* ctx, const dfgpu_array* const* keys, in
     t->mem = (int64_t)bitmap_bytes(n);
     // order of preference: rank index (clustered keys: no table at all), radix-partitioned LDS tables (large builds on unsorted keys
     // whose domain is too sparse for the membership bitmap in front of the general table), general open-addressing table
-    if (!build_rank_index(ctx, t.get()) && !((pj_domain_is_sparse(ctx, t.get()) || pj_hashed_candidate(ctx, t.get())) && pj_build(ctx, t.get()))) build_hash_table(ctx, t.get(), true);
+    if (!build_rank_index(ctx, t.get()) && !build_rank_index_unsorted(ctx, t.get()) && !((pj_domain_is_sparse(ctx, t.get()) || pj_hashed_candidate(ctx, t.get())) && pj_build(ctx, t.get()))) build_hash_table(ctx, t.get(), true);
     *out = t.release();
   });
 }

@@ -46,6 +46,7 @@ struct dfgpu_join_table {
   // column as its only key; probes pack their tuples with the same parameters (a component outside the build range = NULL = no match).
   int pack_n = 0; int32_t pack_types[dfgpu::MAX_KEYS] = {0}; int64_t pack_min[dfgpu::MAX_KEYS] = {0}; uint64_t pack_range[dfgpu::MAX_KEYS] = {0}, pack_stride[dfgpu::MAX_KEYS] = {0};
   dfgpu::BufferPtr rank_prefix;  // u32[range / 64]   set bits before each bitmap word
+  bool have_minmax = false; long long sel_min = 0, sel_max = 0;      // min / max of the selected build keys, once some builder has computed them
   dfgpu_array* sel_rows = nullptr;   // u32[selected] ascending build rows (masked builds only)
   std::unique_ptr<dfgpu::PartitionedBuild> part;   // set = probes of large batches run partition by partition out of LDS (pjoin.hip)
   int64_t mem = 0;

@@ -26,7 +26,8 @@ class forced:
     """ctx options that send small inputs down the partitioned path"""
 
     def __init__(self, ctx, rows_per_partition=12800, on=1):
-        self.ctx, self.opts = ctx, {"join_partitioned": on, "join_partitioned_min_build": 1, "join_partitioned_min_probe": 1, "join_partition_rows": rows_per_partition}
+        self.ctx, self.opts = ctx, {"join_partitioned": on, "join_partitioned_min_build": 1, "join_partitioned_min_probe": 1, "join_partition_rows": rows_per_partition,
+                                    "join_rank_index_unsorted": 0}          # unique keys over a dense domain (the narrow integer types here) would take the rank index first
 
     def __enter__(self):
         self.saved = {k: self.ctx.get_option(k) for k in self.opts}
@@ -305,3 +306,43 @@ def test_hashed_mode_can_be_switched_off_and_small_builds_do_not_take_it(ctx):
         finally:
             ctx.set_option("join_partitioned_hashed", 1)
     _check_hashed(ctx, b, p)                                        # default thresholds: 20 000 rows stay with the general table
+
+
+# ------------------------------------------------------------------ rank index over UNSORTED unique keys (join.hip build_rank_index_unsorted)
+@pytest.mark.parametrize("shape", ["permutation", "one_in_five_masked", "int32_negative_range", "a_key_repeats", "domain_too_wide"])
+def test_rank_index_over_unsorted_unique_keys(ctx, shape):
+    """Unique integer build keys over a dense domain in any order (a primary-key column after a hash repartition): the membership bitmap ranks the keys and one array maps
+    rank -> build row; no hash table is built.  A repeated key (found while the bits are set) or a domain of more than 64 slots per key leaves the build to the hash paths.
+    Pairs are the oracle's, in order, either way."""
+    rng = np.random.default_rng(len(shape))
+    nb, npr = 200_000, 600_000
+    typ, bmask = None, None
+    if shape == "permutation":
+        b = rng.permutation(nb).astype(np.int64) + 1000
+    elif shape == "one_in_five_masked":
+        b = (rng.permutation(nb * 5)[:nb]).astype(np.int64); bmask = rng.random(nb) < 0.7
+    elif shape == "int32_negative_range":
+        b = (rng.permutation(nb * 2)[:nb] - nb).astype(np.int32); typ = pa.int32()
+    elif shape == "a_key_repeats":
+        b = rng.permutation(nb).astype(np.int64); b[777] = b[5]
+    else:
+        b = (rng.permutation(nb) * 1000).astype(np.int64)
+    lo, hi = int(b.min()), int(b.max())
+    p = rng.integers(lo - 50, hi + 50, npr).astype(b.dtype)
+    ctx.profile_select(None); ctx.profile_enable(True); ctx.profile_read()
+    try:
+        m = check(ctx, b, p, bmask=bmask, pmask=rng.random(npr) < 0.9, typ=typ)
+        ks = set(ctx.profile_read())
+    finally:
+        ctx.profile_enable(False)
+    assert m > 0
+    taken = shape in ("permutation", "one_in_five_masked", "int32_negative_range")
+    assert ("k_probe_lookup_rank" in ks) == taken and ("k_join_build" in ks) == (not taken), ks
+    if taken:                                   # switched off, the same build takes a hash table and gives the same pairs
+        ctx.set_option("join_rank_index_unsorted", 0)
+        try:
+            ctx.profile_enable(True); ctx.profile_read()
+            check(ctx, b, p, bmask=bmask, typ=typ)
+            assert "k_join_build" in set(ctx.profile_read())
+        finally:
+            ctx.profile_enable(False); ctx.set_option("join_rank_index_unsorted", 1)
