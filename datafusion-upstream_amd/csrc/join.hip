@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(BLOCK) k_key_minmax_masked(const T* keys, cons
   }
 }
 // Rank index over unsorted unique keys (see k_key_setbits_unique).  Tried after build_rank_index found the keys unsorted: min / max of the selected keys, a domain of at most
-// 64 slots per key (bitmap + prefix <= 12 bytes per build row), the bits set with repeat detection, then rank -> row.  false = not taken, nothing kept.
+// 256 slots per key (bitmap + prefix <= 48 bytes per build row; an eighth of a hash-partitioned TPC-H key column is 1 in 64), the bits set with repeat detection, then rank -> row.  false = not taken, nothing kept.
 static bool build_rank_index_unsorted(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   const int64_t n = t->n_build;
   if (!ctx->join_rank_index || !ctx->join_rank_index_unsorted || ctx->force_hash_collisions || n < 2 || n > 0xFFFFFFF0ll || t->nkeys != 1 || t->null_equals_null) return false;
@@ -597,7 +597,7 @@ static bool build_rank_index_unsorted(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   t->have_minmax = true; t->sel_min = lo; t->sel_max = hi;
   if (lo > hi) return false;                               // no selected row
   const uint64_t range = (uint64_t)hi - (uint64_t)lo + 1;
-  if (range == 0 || range > (1ull << 32) || range > (uint64_t)n * 64 + 65536) return false;
+  if (range == 0 || range > (1ull << 32) || range > (uint64_t)n * 256 + 65536) return false;       // sparser domains are the partitioned join's (pj_domain_is_sparse draws the same line)
   const int64_t nw = (int64_t)((range + 63) / 64);
   BufferPtr bitmap = alloc_buffer(ctx, bitmap_bytes((int64_t)range));
   HIP_CHECK(hipMemsetAsync(bitmap->ptr, 0, bitmap_bytes((int64_t)range), ctx->stream));

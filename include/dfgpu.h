@@ -89,7 +89,7 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
  * "first_seen_group_order" (1/0) == group ids in first-seen order (group_values/primitive.rs:137-141);
  * "join_rank_index" (1/0) == let join_build replace the hash table by a bitmap rank index when the single integer key
  * column is strictly increasing (results identical either way; the switch exists for A/B tests);
- * "join_rank_index_unsorted" (1/0) == the same index for UNIQUE integer keys over a dense domain (<= 64 slots per key) in any order -- a primary-key column after a hash
+ * "join_rank_index_unsorted" (1/0) == the same index for UNIQUE integer keys over a dense domain (<= 256 slots per key) in any order -- a primary-key column after a hash
  * repartition: one more array maps rank -> build row (results identical);
  * "join_key_packing" (1/0) == let join_build pack 2..4 integer key columns with small value ranges into one Int64 key (tuple
  * equality == packed equality), so that the single-key paths apply; results identical;

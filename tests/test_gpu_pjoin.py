@@ -312,7 +312,7 @@ def test_hashed_mode_can_be_switched_off_and_small_builds_do_not_take_it(ctx):
 @pytest.mark.parametrize("shape", ["permutation", "one_in_five_masked", "int32_negative_range", "a_key_repeats", "domain_too_wide"])
 def test_rank_index_over_unsorted_unique_keys(ctx, shape):
     """Unique integer build keys over a dense domain in any order (a primary-key column after a hash repartition): the membership bitmap ranks the keys and one array maps
-    rank -> build row; no hash table is built.  A repeated key (found while the bits are set) or a domain of more than 64 slots per key leaves the build to the hash paths.
+    rank -> build row; no hash table is built.  A repeated key (found while the bits are set) or a domain of more than 256 slots per key leaves the build to the hash paths.
     Pairs are the oracle's, in order, either way."""
     rng = np.random.default_rng(len(shape))
     nb, npr = 200_000, 600_000
