@@ -88,7 +88,8 @@ DFGPU_API dfgpu_status dfgpu_plan_hash_join(const dfgpu_plan *left, const dfgpu_
  * Inner, Left, Right, Full, LeftSemi, LeftAnti, RightAnti; RightSemi is refused as the reference refuses it.  Full adds the buffered rows no streamed row matched as a
  * last batch.  JoinFilter as for dfgpu_plan_hash_join, for Inner / Left / Right / Full, with the reference's own semantics (:1156-1300): it is applied to the joined pairs,
  * and an outer join emits every FAILING pair NULL-joined (once for the streamed side; for Full once more for the buffered side) -- sort_merge_join.slt:137-147 pins this.
- * LeftSemi / LeftAnti / RightAnti with a filter answer DFGPU_NOT_IMPLEMENTED.  The sort options do not enter: row order follows the inputs' own order. */
+ * LeftSemi / LeftAnti / RightAnti with a filter answer DFGPU_NOT_IMPLEMENTED (the reference's freeze_streamed builds no buffered columns for them, :1133-1135, so a filter over the
+ * buffered side has nothing to be evaluated on there either).  The sort options do not enter: row order follows the inputs' own order. */
 DFGPU_API dfgpu_status dfgpu_plan_sort_merge_join(const dfgpu_plan *left, const dfgpu_plan *right, const dfgpu_expr *const *on_left, const dfgpu_expr *const *on_right, int32_t non,
                                                   const dfgpu_expr *filter, const int32_t *filter_sides, const int32_t *filter_indices, int32_t nfilter_cols,
                                                   int32_t join_type, int32_t null_equals_null, dfgpu_plan **out);
