@@ -341,6 +341,7 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "first_seen_group_order") ctx->first_seen_group_order = value != 0;
     else if (k == "join_rank_index") ctx->join_rank_index = value != 0;
     else if (k == "join_rank_index_unsorted") ctx->join_rank_index_unsorted = value != 0;
+    else if (k == "join_lazy_build_rows") ctx->join_lazy_build_rows = value != 0;
     else if (k == "join_key_packing") ctx->join_key_packing = value != 0;
     else if (k == "group_run_detection") ctx->group_run_detection = value != 0;
     else if (k == "group_dictionary_canon") ctx->group_dictionary_canon = value != 0;
@@ -385,6 +386,7 @@ dfgpu_status dfgpu_ctx_get_option(dfgpu_ctx* ctx, const char* key, int64_t* out)
     else if (k == "first_seen_group_order") *out = ctx->first_seen_group_order;
     else if (k == "join_rank_index") *out = ctx->join_rank_index;
     else if (k == "join_rank_index_unsorted") *out = ctx->join_rank_index_unsorted ? 1 : 0;
+    else if (k == "join_lazy_build_rows") *out = ctx->join_lazy_build_rows ? 1 : 0;
     else if (k == "join_key_packing") *out = ctx->join_key_packing;
     else if (k == "group_run_detection") *out = ctx->group_run_detection;
     else if (k == "group_dictionary_canon") *out = ctx->group_dictionary_canon;

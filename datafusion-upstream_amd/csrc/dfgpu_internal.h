@@ -43,6 +43,7 @@ struct dfgpu_ctx {
   bool force_hash_collisions = false;
   bool first_seen_group_order = true;
   bool join_rank_index = true;
+  bool join_lazy_build_rows = true;         // plan layer: an Inner HashJoinExec over a unique rank-indexed build looks the build rows up when a build-side column is read (dfgpu_join_probe_deferred)
   bool join_rank_index_unsorted = true;     // unique integer keys over a dense domain in ANY order (a repartitioned or filtered primary-key column): bitmap + rank -> build row
   bool join_key_packing = true;
   bool group_run_detection = true;

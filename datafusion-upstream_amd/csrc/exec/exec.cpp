@@ -78,11 +78,32 @@ struct Composed { ArrayRef inner, outer, out; };
 // per column.  Entries pin the arrays their key points at.
 struct TakeMemo { std::map<std::pair<const dfgpu_array*, const dfgpu_array*>, Composed> composed; };
 using MemoPtr = std::shared_ptr<TakeMemo>;
-struct Col {
-  ArrayRef arr, source; std::vector<ArrayRef> chain; MemoPtr memo;
-  int64_t len() const { return arr ? arr.len() : chain.empty() ? 0 : chain.back().len(); }
-};
 static ArrayRef take(const TaskContext& tc, const ArrayRef& v, const ArrayRef& idx) { dfgpu_array* o = nullptr; tc.check(dfgpu_take(tc.ctx, v.a, idx.a, &o)); return ArrayRef::adopt(o); }
+// The innermost stage of a pending gather can be a join's build-row lookup that has not run yet (dfgpu_join_probe_deferred): the chain then indexes the join's matched
+// pairs, and the build rows are computed when a build-side column is finally read -- for the pairs still wanted by then.  TPC-H Q18 joins 600 M lineitems to their orders
+// and keeps a few thousand of them in the next (semi) join: the lookup runs for those, not for 600 M.  Columns of one join output share the object, so a lookup runs once
+// per distinct index array.
+struct LazyLookup {
+  std::shared_ptr<void> keep; dfgpu_join_table* table = nullptr; ArrayRef probe_key, rows; int64_t m = 0;      // rows: the matched probe rows (UInt32), m of them
+  std::mutex mu; std::map<const dfgpu_array*, std::pair<ArrayRef, ArrayRef>> done;                              // pair-index array (pinned) -> build rows; nullptr = every pair
+  ArrayRef resolve(const TaskContext& tc, const ArrayRef& idx) {
+    std::lock_guard<std::mutex> l(mu);
+    auto it = done.find(idx.a); if (it != done.end()) return it->second.second;
+    if (idx) { auto full = done.find(nullptr); if (full != done.end()) { ArrayRef out = take(tc, full->second.second, idx); done[idx.a] = std::make_pair(idx, out); return out; } }      // every pair is known already: a gather, not a second lookup
+    ArrayRef sel = rows;
+    if (idx) {
+      ArrayRef i32 = idx; dfgpu_array_desc d; dfgpu_array_describe(idx.a, &d);
+      if (d.type != DFGPU_UINT32) { dfgpu_array* c = nullptr; tc.check(dfgpu_cast(tc.ctx, idx.a, DFGPU_UINT32, 0, 0, &c)); i32 = ArrayRef::adopt(c); }
+      sel = dfgpu_array_is_identity(rows.a) ? i32 : take(tc, rows, i32);
+    }
+    const dfgpu_array* kp = probe_key.a; dfgpu_array* b = nullptr; tc.check(dfgpu_join_lookup(tc.ctx, table, &kp, 1, sel.a, &b)); ArrayRef out = ArrayRef::adopt(b);
+    done[idx.a] = std::make_pair(idx, out); return out;
+  }
+};
+struct Col {
+  ArrayRef arr, source; std::vector<ArrayRef> chain; MemoPtr memo; std::shared_ptr<LazyLookup> lookup;
+  int64_t len() const { return arr ? arr.len() : !chain.empty() ? chain.back().len() : lookup ? lookup->m : 0; }
+};
 static const ArrayRef& col_indices(const TaskContext& tc, Col& c) {           // the chain as one index array into c.source
   while (c.chain.size() > 1) {
     ArrayRef outer = std::move(c.chain.back()); c.chain.pop_back();
@@ -94,6 +115,7 @@ static const ArrayRef& col_indices(const TaskContext& tc, Col& c) {           //
       inner = it->second.out;
     } else inner = take(tc, inner, outer);
   }
+  if (c.lookup) { ArrayRef b = c.lookup->resolve(tc, c.chain.empty() ? ArrayRef() : c.chain[0]); c.chain.clear(); c.chain.push_back(b); c.lookup.reset(); }
   return c.chain[0];
 }
 static const ArrayRef& col_get(const TaskContext& tc, Col& c) {
@@ -104,7 +126,7 @@ static Col col_take(const Col& c, const ArrayRef& idx, const MemoPtr& memo = nul
   if (dfgpu_array_is_identity(idx.a) && idx.len() == c.len()) return c;          // every row, in order: the column itself
   Col o; o.memo = memo;
   if (c.arr) { o.source = c.arr; o.chain.push_back(idx); return o; }
-  o.source = c.source; o.chain = c.chain; o.chain.push_back(idx);
+  o.source = c.source; o.chain = c.chain; o.lookup = c.lookup; o.chain.push_back(idx);
   return o;
 }
 static Col col_of(ArrayRef a) { Col c; c.arr = std::move(a); return c; }
@@ -655,7 +677,8 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
     // process_probe_batch, hash_join.rs:1238-1343): `batch_size` candidate pairs per emitted batch, index alignment per chunk
     Batch chunk_pb; ArrayRef chunk_b, chunk_p; int64_t chunk_k = -1, chunk_total = 0, chunk_joined = -1;   // 0 WaitBuildSide, 1 probing, 2 final pass, 3 done, 4 swapped semi/anti result pending
     SchemaPtr out_schema;
-    S(const HashJoinExec* o, int p, TaskContext t) : op(o), tc(t), partition(p) {}
+    bool lazy_build_rows = true;
+    S(const HashJoinExec* o, int p, TaskContext t) : op(o), tc(t), partition(p) { int64_t v = 1; if (dfgpu_ctx_get_option(tc.ctx, "join_lazy_build_rows", &v) == DFGPU_OK) lazy_build_rows = v != 0; }
     int64_t last_u32(const ArrayRef& a) {
       int64_t n = a.len(); if (!n) return -1;
       dfgpu_array* s1 = nullptr; tc.check(dfgpu_array_slice(tc.ctx, a.a, n - 1, 1, &s1)); ArrayRef one = ArrayRef::adopt(s1);
@@ -692,13 +715,8 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
       if (last) { chunk_k = -1; chunk_pb = Batch(); chunk_b = ArrayRef(); chunk_p = ArrayRef(); } else chunk_k++;
     }
     ArrayRef filter_idx(const ArrayRef& idx, const ArrayRef& m) { dfgpu_array* o = nullptr; tc.check(dfgpu_filter(tc.ctx, idx.a, m.a, &o)); return ArrayRef::adopt(o); }
-    Batch build_batch(Batch* build, Batch& probe_b, const ArrayRef& bidx, const ArrayRef& pidx) {     // build_batch_from_indices (joins/utils.rs:1180-1230)
-      Batch o; o.schema = out_schema; o.base_rows = pidx.len(); MemoPtr memo = std::make_shared<TakeMemo>();
-      auto lf = op->left->schema();
-      // Inner join on plain columns of one integer / date / decimal type: in every output row the build side's key column holds the probe side's key value, so it is taken
-      // from the probe column through pidx (ascending 32-bit indices; the column itself when every probe row matched once) instead of through bidx (a random 8-byte gather
-      // from the build batch).  TPC-H Q18 joins 600 M lineitems to their orders and then feeds o_orderkey into the next join: that column is l_orderkey, untouched.
-      std::vector<int> alias(lf ? lf->f.size() : 0, -1);
+    std::vector<int> key_aliases(Batch* build, Batch& probe_b) {      // build column -> the probe column that holds the same values in every output row, or -1
+      auto lf = op->left->schema(); std::vector<int> alias(lf ? lf->f.size() : 0, -1);
       if (build && op->join_type == DFGPU_JOIN_INNER && !op->null_equals_null && !op->right_only() && !op->left_only())
         for (size_t k = 0; k < op->on_l.size(); k++) {
           const int bi = op->on_l[k]->column_index(), pi = op->on_r[k]->column_index();
@@ -709,8 +727,18 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
           const bool exact = (bd.type >= DFGPU_INT8 && bd.type <= DFGPU_UINT64) || bd.type == DFGPU_DATE32 || bd.type == DFGPU_DECIMAL128;
           if (exact && bd.type == pd.type && bd.precision == pd.precision && bd.scale == pd.scale) alias[(size_t)bi] = pi;
         }
+      return alias;
+    }
+    Batch build_batch(Batch* build, Batch& probe_b, const ArrayRef& bidx, const ArrayRef& pidx, const std::shared_ptr<LazyLookup>& lazy = nullptr) {     // build_batch_from_indices (joins/utils.rs:1180-1230)
+      Batch o; o.schema = out_schema; o.base_rows = pidx.len(); MemoPtr memo = std::make_shared<TakeMemo>();
+      auto lf = op->left->schema();
+      // Inner join on plain columns of one integer / date / decimal type: in every output row the build side's key column holds the probe side's key value, so it is taken
+      // from the probe column through pidx (ascending 32-bit indices; the column itself when every probe row matched once) instead of through bidx (a random 8-byte gather
+      // from the build batch).  TPC-H Q18 joins 600 M lineitems to their orders and then feeds o_orderkey into the next join: that column is l_orderkey, untouched.
+      std::vector<int> alias = key_aliases(build, probe_b);
       if (!op->right_only()) for (size_t i = 0; i < (lf ? lf->f.size() : 0); i++) {
         if (build && alias[i] >= 0) o.cols.push_back(col_take(probe_b.cols[(size_t)alias[i]], pidx, memo));
+        else if (build && lazy) { Col c; c.source = build->cols[i].arr; c.lookup = lazy; c.memo = memo; o.cols.push_back(std::move(c)); }       // build rows not looked up yet
         else if (build) o.cols.push_back(col_take(build->cols[i], bidx, memo));
         else { dfgpu_array* nn = nullptr; tc.check(dfgpu_array_new_null(tc.ctx, lf->f[i].type, lf->f[i].precision, lf->f[i].scale, o.base_rows, &nn)); o.cols.push_back(col_of(ArrayRef::adopt(nn))); }
       }
@@ -760,7 +788,21 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
           std::vector<ArrayRef> keys; std::vector<const dfgpu_array*> kp;
           for (auto& e : op->on_r) { keys.push_back(into_array(tc, e->eval(tc, pb), pb.base_rows)); kp.push_back(keys.back().a); }
           dfgpu_array *b = nullptr, *p = nullptr;
-          tc.check(dfgpu_join_probe(tc.ctx, bs->table->t, kp.data(), (int32_t)kp.size(), mask.a, &b, &p)); bidx = ArrayRef::adopt(b); pidx = ArrayRef::adopt(p);
+          // an Inner join whose build rows nothing here needs (no filter, no final pass, one piece): the table may leave them for later (LazyLookup)
+          bool defer = !chunked && op->join_type == DFGPU_JOIN_INNER && !op->filter && !need_final && kp.size() == 1 && lazy_build_rows;
+          for (auto& c : bs->batch.cols) defer = defer && (bool)c.arr;
+          if (defer) {
+            tc.check(dfgpu_join_probe_deferred(tc.ctx, bs->table->t, kp.data(), 1, mask.a, &b, &p)); pidx = ArrayRef::adopt(p);
+            if (!b) {
+              auto lz = std::make_shared<LazyLookup>(); lz->keep = bs; lz->table = bs->table->t; lz->probe_key = keys[0]; lz->rows = pidx; lz->m = pidx.len();
+              // Left for later when that can only win: every probe row matched (the lookup is the big one, and a later operator may thin the rows first -- Q18), or no
+              // build column but aliased key columns leaves this join (nobody will ever ask -- Q3's customer side).  Otherwise now, while keys and bitmap are in cache:
+              // deferring the lookup of a 15 % match cost TPC-H Q5 0.3 ms of 7.2.
+              bool wanted = false; { std::vector<int> al = key_aliases(&bs->batch, pb); for (int a : al) wanted |= a < 0; }
+              if (!wanted || (dfgpu_array_is_identity(pidx.a) && pidx.len() == pb.base_rows)) { out = build_batch(&bs->batch, pb, ArrayRef(), pidx, lz); return true; }
+              bidx = lz->resolve(tc, ArrayRef());
+            } else bidx = ArrayRef::adopt(b);
+          } else { tc.check(dfgpu_join_probe(tc.ctx, bs->table->t, kp.data(), (int32_t)kp.size(), mask.a, &b, &p)); bidx = ArrayRef::adopt(b); pidx = ArrayRef::adopt(p); }
           if (!chunked) { apply_filter(pb, bidx, pidx); if (need_final) tc.check(dfgpu_join_mark_visited(tc.ctx, bs->table->t, bidx.a)); }
         }
         if (chunked) {

@@ -713,8 +713,40 @@ void dfgpu_join_table_free(dfgpu_join_table* t) { delete t; }
 int64_t dfgpu_join_table_num_rows(const dfgpu_join_table* t) { return t ? t->n_build : 0; }
 int64_t dfgpu_join_table_memory(const dfgpu_join_table* t) { return t ? t->mem : 0; }
 
+static dfgpu_status join_probe_impl(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* probe_keys, int32_t nkeys,
+                                    const dfgpu_array* opt_mask, dfgpu_array** out_build_idx, dfgpu_array** out_probe_idx, bool may_defer);
 dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* probe_keys, int32_t nkeys,
                               const dfgpu_array* opt_mask, dfgpu_array** out_build_idx, dfgpu_array** out_probe_idx) {
+  return join_probe_impl(ctx, t, probe_keys, nkeys, opt_mask, out_build_idx, out_probe_idx, false);
+}
+/* see include/dfgpu.h */
+dfgpu_status dfgpu_join_probe_deferred(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* probe_keys, int32_t nkeys,
+                                       const dfgpu_array* opt_mask, dfgpu_array** out_build_idx, dfgpu_array** out_probe_idx) {
+  return join_probe_impl(ctx, t, probe_keys, nkeys, opt_mask, out_build_idx, out_probe_idx, true);
+}
+dfgpu_status dfgpu_join_lookup(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* probe_keys, int32_t nkeys, const dfgpu_array* rows, dfgpu_array** out_build_idx) {
+  return guard(ctx, [&] {
+    if (!t || !probe_keys || !out_build_idx) fail(DFGPU_INVALID_ARGUMENT, "join_lookup: null argument");
+    if (!(t->rank_mode && t->unique && !t->rank_runs && t->bitmap) || nkeys != 1 || probe_keys[0]->type != t->keys[0]->type || probe_keys[0]->validity)
+      fail(DFGPU_INVALID_ARGUMENT, "join_lookup: only after dfgpu_join_probe_deferred left the build indices out (a unique rank-indexed build, one integer key column without NULLs)");
+    if (rows && rows->type != DFGPU_UINT32) fail(DFGPU_INVALID_ARGUMENT, "join_lookup: rows must be UInt32");
+    const dfgpu_array* pk = probe_keys[0];
+    const int64_t m = rows ? rows->length : pk->length;
+    ArrayHolder ob(new_fixed(ctx, DFGPU_UINT64, m));
+    if (m) { KernelTimer kt_(ctx, "k_probe_lookup_rank");
+      const bool all = rows == nullptr || (rows->identity && rows->length == pk->length), sel = t->sel_rows != nullptr;
+      const uint32_t* rp = rows ? (const uint32_t*)rows->values->ptr : nullptr;
+#define LR(ALL, SEL) DFGPU_INT_KEY_DISPATCH(pk->type, hipLaunchKernelGGL((k_probe_lookup_rank<T, ALL, SEL>), dim3(grid_for(m, BLOCK * LR_ROWS)), dim3(BLOCK), 0, ctx->stream, (const T*)pk->values->ptr, rp, m, t->key_min, \
+                                                            (const uint64_t*)t->bitmap->ptr, t->rank_prefix ? (const uint32_t*)t->rank_prefix->ptr : nullptr, \
+                                                            t->sel_rows ? (const uint32_t*)t->sel_rows->values->ptr : nullptr, t->rank_identity ? 1 : 0, (uint64_t*)ob.get()->values->ptr))
+      if (all && sel) { LR(true, true); } else if (all) { LR(true, false); } else if (sel) { LR(false, true); } else { LR(false, false); }
+#undef LR
+      KERNEL_CHECK(); }
+    *out_build_idx = ob.release();
+  });
+}
+static dfgpu_status join_probe_impl(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* probe_keys, int32_t nkeys,
+                                    const dfgpu_array* opt_mask, dfgpu_array** out_build_idx, dfgpu_array** out_probe_idx, bool may_defer) {
   return guard(ctx, [&] {
     if (!t || !probe_keys || !out_build_idx || !out_probe_idx) fail(DFGPU_INVALID_ARGUMENT, "join_probe: null argument");
     check_key_types(t, probe_keys, nkeys);
@@ -804,6 +836,11 @@ dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const d
         hipLaunchKernelGGL(k_probe_expand, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, rp, (const uint32_t*)run_of->ptr, (const uint32_t*)cnt->ptr, (const uint64_t*)offs->ptr, m,
                            (const uint32_t*)t->sel_rows->values->ptr, (const uint32_t*)nullptr, (uint64_t*)ob.get()->values->ptr, (uint32_t*)op.get()->values->ptr); }
       KERNEL_CHECK();
+    } else if (t->rank_mode && use_bitmap && may_defer && t->unique && !probe_keys[0]->validity) {
+      // the caller resolves build rows later, for the rows it still holds by then (dfgpu_join_lookup): only the matched probe rows leave
+      *out_build_idx = nullptr; *out_probe_idx = rows.release();
+      check_flags(ctx, "join_probe");
+      return;
     } else if (t->rank_mode && use_bitmap) {
       ob.a = new_fixed(ctx, DFGPU_UINT64, m);
       const dfgpu_array* pk = probe_keys[0];

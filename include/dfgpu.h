@@ -262,6 +262,14 @@ DFGPU_API int64_t dfgpu_join_table_memory(const dfgpu_join_table *t);   /* bytes
 DFGPU_API dfgpu_status dfgpu_join_probe(dfgpu_ctx *ctx, const dfgpu_join_table *t, const dfgpu_array *const *probe_keys,
                                         int32_t nkeys, const dfgpu_array *opt_mask,
                                         dfgpu_array **out_build_idx, dfgpu_array **out_probe_idx);
+/* dfgpu_join_probe whose build indices may be left for later: when the table locates a build row from the key alone (a unique, rank-indexed build: one integer key column, the
+ * probe column of the same type without NULLs) *out_build_idx comes back NULL and only the matched probe rows are returned; dfgpu_join_lookup then gives the build rows for any
+ * subset of them -- `rows` = UInt32 probe rows known to match (NULL = every row of `probe_keys`) -- so a consumer that keeps few of the join's rows (a later semi join, a
+ * selective filter) never pays for the rest.  Any other table answers exactly as dfgpu_join_probe does (*out_build_idx set). */
+DFGPU_API dfgpu_status dfgpu_join_probe_deferred(dfgpu_ctx *ctx, const dfgpu_join_table *table, const dfgpu_array *const *probe_keys, int32_t nkeys,
+                                                 const dfgpu_array *opt_mask, dfgpu_array **out_build_idx, dfgpu_array **out_probe_idx);
+DFGPU_API dfgpu_status dfgpu_join_lookup(dfgpu_ctx *ctx, const dfgpu_join_table *table, const dfgpu_array *const *probe_keys, int32_t nkeys, const dfgpu_array *rows,
+                                         dfgpu_array **out_build_idx);
 /* ≙ visited_left_side.set_bit for every joined build index (hash_join.rs:1274-1278). */
 DFGPU_API dfgpu_status dfgpu_join_mark_visited(dfgpu_ctx *ctx, dfgpu_join_table *t, const dfgpu_array *build_idx);
 /* ≙ adjust_indices_by_join_type over the alignment range [range_start, range_end)

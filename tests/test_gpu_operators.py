@@ -348,3 +348,53 @@ def test_sort_preserving_merge_in_bounded_steps(ctx, task_ctx, budget, fetch):
         assert len(out) > 3, "several merge steps"
     one = pa.concat_tables([b.to_arrow() for b in ops.SortPreservingMergeExec(keys, src, fetch=fetch).execute(0, task_ctx)]) if want else None
     assert (one["src"].to_pylist() if one is not None else []) == want
+
+
+@pytest.mark.parametrize("shape", ["every_probe_row_matches", "key_columns_only", "partial_match_with_payload"])
+def test_inner_join_looks_build_rows_up_when_a_build_column_is_read(ctx, task_ctx, shape):
+    """HashJoinExec Inner over a unique rank-indexed build (dfgpu_join_probe_deferred / dfgpu_join_lookup): the build rows of the matched pairs are computed when a
+    build-side column is read, for the rows still wanted by then -- left for later when every probe row matched or when only (aliased) key columns leave the build side,
+    at once otherwise.  A FilterExec that keeps 1 row in 500 sits above the join; rows equal the eager path's (option off) and pyarrow's join; the profile shows over how
+    many rows the lookup ran."""
+    from dfgpu import physical_plan as ops
+    rng = np.random.default_rng(len(shape))
+    nb, npr = 50_000, 400_000
+    bk = np.arange(nb, dtype=np.int64) * 3 + 7                                   # sorted, unique: the rank index
+    build = pa.table({"k": pa.array(bk), "pay": pa.array(rng.integers(0, 10**6, nb)), "s": pa.array([f"b{i % 97}" for i in range(nb)])})
+    if shape == "key_columns_only":
+        build = build.select(["k"])
+    pk = bk[rng.integers(0, nb, npr)] if shape != "partial_match_with_payload" else np.where(rng.random(npr) < 0.4, bk[rng.integers(0, nb, npr)], -5)
+    probe = pa.table({"pk": pa.array(pk), "v": pa.array(rng.integers(0, 1000, npr))})
+    mk = lambda t: (lambda b: ops.MemoryExec([[b]], b.schema))(ops.batch_from_arrow(ctx, t))
+    C = ops.Column
+
+    def run():
+        join = ops.HashJoinExec(mk(build), mk(probe), [(C("k", 0), C("pk", 0))], None, "Inner", "CollectLeft")
+        nbc = build.num_columns
+        plan = ops.FilterExec(ops.BinaryExpr(ops.BinaryExpr(C("v", nbc + 1), "%", ops.Literal(500, pa.int64())), "=", ops.Literal(3, pa.int64())), join)
+        ctx.profile_select(None); ctx.profile_enable(True); ctx.profile_read()
+        try:
+            out = pa.concat_tables([b.to_arrow() for b in plan.execute(0, task_ctx)])          # probe batches above batch_size are answered in one piece (not in reference-sized chunks)
+            prof = ctx.profile_read()
+        finally:
+            ctx.profile_enable(False)
+        return out, prof
+
+    lazy, prof = run()
+    ctx.set_option("join_lazy_build_rows", 0)
+    try:
+        eager, prof0 = run()
+    finally:
+        ctx.set_option("join_lazy_build_rows", 1)
+    assert lazy.equals(eager)
+    keep = np.isin(pk, bk) & (probe["v"].to_numpy() % 500 == 3)                 # the join's rows that pass the filter, computed directly
+    assert lazy.num_rows == int(keep.sum()) and sorted(lazy["v"].to_pylist()) == sorted(probe["v"].to_numpy()[keep].tolist())
+    assert sorted(lazy["pk"].to_pylist()) == sorted(pk[keep].tolist()) and lazy["k"].to_pylist() == lazy["pk"].to_pylist()
+    if "pay" in build.column_names:
+        pay_of = dict(zip(bk.tolist(), build["pay"].to_pylist()))
+        assert lazy["pay"].to_pylist() == [pay_of[k] for k in lazy["k"].to_pylist()]
+    assert "k_probe_lookup_rank" in prof0                                       # eager: every matched pair
+    if shape == "key_columns_only":
+        assert "k_probe_lookup_rank" not in prof                               # nobody ever asks for a build row
+    else:
+        assert "k_probe_lookup_rank" in prof
