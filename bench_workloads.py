@@ -394,6 +394,7 @@ def run(args, ctx=None, emit=True):
         res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
         member = torch.zeros(nbd * 4 + 2, dtype=torch.bool, device="cuda"); member[bkd] = True; hitd = member[pkd]
         ok = int(res[1][0]) == int(hitd.sum().item()) and wrap64(int(res[0][0])) == wrap64(int(pvd[hitd].sum().item()))
+        per_first = list(STEP_MS[0])
         ctx.set_option("join_rank_index_unsorted", 0)
         try:
             dt0, _, kern0, _ = time_plan(ctx, ops, tc, pland, args.steps, args.warmup)
@@ -401,6 +402,7 @@ def run(args, ctx=None, emit=True):
         finally:
             ctx.set_option("join_rank_index_unsorted", 1)
         ok = ok and int(res0[1][0]) == int(res[1][0]) and wrap64(int(res0[0][0])) == wrap64(int(res[0][0]))
+        STEP_MS[0] = per_first
         report("hash_join_dense_unsorted", dt, nbd + npd, rows, round((nbd * 8 + npd * 16) / (nbd + npd), 2), kern, syncs, {"build_rows": nbd, "probe_rows": npd, "match_fraction": 0.25,
                "hash_table_ms_per_step": round(dt0 * 1e3, 3), "hash_table_kernel_ms_per_step": kern0,
                "result_check": check("hash_join_dense_unsorted", ok, "COUNT(*) and SUM(v) over the join output == a torch membership table over the same keys, and == the same plan through the bitmap + hash table")})
@@ -460,6 +462,7 @@ def run(args, ctx=None, emit=True):
             dt, rows, kern, syncs = time_plan(ctx, ops, tc, plan2, args.steps, args.warmup)
             res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
             ok = int(res[1][0]) == int(hit2.sum().item()) and wrap64(int(res[0][0])) == wrap64(int(pv[hit2].sum().item()))
+            per_first = list(STEP_MS[0])
             ctx.set_option("join_partitioned_hashed", 0)
             try:
                 dt0, _, kern0, _ = time_plan(ctx, ops, tc, plan2, args.steps, args.warmup)
@@ -467,6 +470,7 @@ def run(args, ctx=None, emit=True):
             finally:
                 ctx.set_option("join_partitioned_hashed", 1)
             ok = ok and int(res0[1][0]) == int(res[1][0]) and wrap64(int(res0[0][0])) == wrap64(int(res[0][0]))
+            STEP_MS[0] = per_first
             report("hash_join_two_keys", dt, nb + npr, rows, round((nb * 16 + npr * 24) / (nb + npr), 2), kern, syncs, {"build_rows": nb, "probe_rows": npr, "match_fraction": round(float(hit2.float().mean().item()), 3),
                    "global_table_ms_per_step": round(dt0 * 1e3, 3), "global_table_kernel_ms_per_step": kern0,
                    "result_check": check("hash_join_two_keys", ok, "COUNT(*) and SUM(v) over the join output == the matches by construction (torch), and == the same plan through the global table")})

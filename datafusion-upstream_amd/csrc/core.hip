@@ -648,8 +648,7 @@ dfgpu_status dfgpu_concat(dfgpu_ctx* ctx, const dfgpu_array* const* arrays, int3
       std::vector<Utf8Part> parts; int64_t r = 0;
       for (int i = 0; i < n; i++) { parts.push_back(Utf8Part{arrays[i]->length ? (const int32_t*)arrays[i]->offsets->ptr : nullptr, arrays[i]->values ? (const uint8_t*)arrays[i]->values->ptr : nullptr, arrays[i]->length, r}); r += arrays[i]->length; }
       dparts = alloc_buffer(ctx, parts.size() * sizeof(Utf8Part)); dbases = alloc_buffer(ctx, (size_t)(2 * n + 2) * 4);
-      HIP_CHECK(hipMemcpyAsync(dparts->ptr, parts.data(), parts.size() * sizeof(Utf8Part), hipMemcpyHostToDevice, ctx->stream));
-      HIP_CHECK(hipStreamSynchronize(ctx->stream));          // `parts` is a pageable host vector about to go out of scope
+      HIP_CHECK(hipMemcpyAsync(dparts->ptr, parts.data(), parts.size() * sizeof(Utf8Part), hipMemcpyHostToDevice, ctx->stream));          // pageable source: staged by the runtime before the call returns
       int32_t* first = (int32_t*)dbases->ptr; int32_t* base = first + n;
       hipLaunchKernelGGL(k_concat_utf8_bases, dim3(1), dim3(1), 0, ctx->stream, (const Utf8Part*)dparts->ptr, n, first, base);
       for (int i = 0; i < n; i++) if (arrays[i]->length)
