@@ -171,7 +171,7 @@ def run(args, ctx=None, emit=True):
         if extra:
             line.update(extra)
         if STEP_MS[0]:
-            line["step_ms"] = STEP_MS[0]; STEP_MS[0] = None
+            line["step_ms"] = STEP_MS[0]; line["ms_per_step_median"] = sorted(STEP_MS[0])[len(STEP_MS[0]) // 2]; STEP_MS[0] = None       # ms_per_step is the mean over the timed loop; one slow step of three shows here
         KEEP[0] = False
         live0 = ctx.get_option("live_bytes"); gc.collect()            # device arrays held only by reference cycles of the Python wrappers go back here, not in the middle of a later step
         line["memory_GB"] = {"dfgpu_live_before_gc": round(live0 / 1e9, 2), "dfgpu_live": round(ctx.get_option("live_bytes") / 1e9, 2), "dfgpu_cached": round(ctx.get_option("cached_bytes") / 1e9, 2), "torch_reserved": round(torch.cuda.memory_reserved() / 1e9, 2)}
