@@ -617,7 +617,7 @@ def run(args, ctx=None, emit=True):
                 del kd, kk
             ok = all(bool((owner[oi] == d).all().item()) for d, oi in parts)
             ok = ok and wrap64(sk) == wrap64(int(l_orderkey.sum().item())) and wrap64(sp) == wrap64(int(price[:, 0].sum().item())) and sd == int(sdate.to(torch.int64).sum().item())
-            del keep, owner, parts
+            del keep, owner, parts, b, oi          # `b` too: a partition's batch is a slice of the partition-major output buffers, the last one left bound by the loop held all of them (35 GB)
             report("partition_hash_%d" % nparts, dt, n, rows, 2 * (8 + 16 + 16 + 4), kern, syncs, {"partitions": nparts,
                    "result_check": check("partition_hash_%d" % nparts, ok, "row count and wrapping column sums conserved; every l_orderkey value lives in exactly one output partition")})
             del plan
