@@ -8,7 +8,7 @@ use arrow::ffi::{from_ffi, to_ffi, FFI_ArrowArray, FFI_ArrowSchema};
 use datafusion_common::{DataFusionError, Result};
 
 macro_rules! opaque { ($($n:ident),*) => { $(#[repr(C)] pub struct $n { _p: [u8; 0] })* } }
-opaque!(dfgpu_ctx, dfgpu_array, dfgpu_expr, dfgpu_plan, dfgpu_batch, dfgpu_stream, dfgpu_comm, dfgpu_parquet);
+opaque!(dfgpu_ctx, dfgpu_array, dfgpu_expr, dfgpu_plan, dfgpu_batch, dfgpu_stream, dfgpu_comm, dfgpu_parquet, dfgpu_join_table);
 
 /// dfgpu_comm_vtable (include/dfgpu.h): a transport the host provides instead of RCCL
 #[repr(C)]
@@ -54,6 +54,14 @@ extern "C" {
     pub fn dfgpu_plan_parquet(file: *mut dfgpu_parquet, columns: *const i32, ncols: i32, npartitions: i32, row_groups_per_batch: i32, out: *mut *mut dfgpu_plan) -> i32;
     pub fn dfgpu_plan_csv(bytes: *const u8, len: i64, delimiter: i32, quote: i32, escape: i32, has_header: i32, names: *const *const c_char, types: *const i32, ncols_file: i32, columns: *const i32, ncols: i32, npartitions: i32, batch_bytes: i64, out: *mut *mut dfgpu_plan) -> i32;
     pub fn dfgpu_plan_parquet_prune(parquet_exec: *mut dfgpu_plan, column: i32, min_value: i64, max_value: i64) -> i32;
+    // ---- round 3
+    pub fn dfgpu_list_from_counts(ctx: *mut dfgpu_ctx, counts: *const dfgpu_array, values: *const dfgpu_array, out: *mut *mut dfgpu_array) -> i32;
+    pub fn dfgpu_list_flatten(ctx: *mut dfgpu_ctx, list: *const dfgpu_array, value_type: i32, precision: i32, scale: i32, out_values: *mut *mut dfgpu_array, out_row_of: *mut *mut dfgpu_array) -> i32;
+    pub fn dfgpu_join_probe_deferred(ctx: *mut dfgpu_ctx, table: *const dfgpu_join_table, probe_keys: *const *const dfgpu_array, nkeys: i32, opt_mask: *const dfgpu_array,
+                                     out_build_idx: *mut *mut dfgpu_array, out_probe_idx: *mut *mut dfgpu_array) -> i32;
+    pub fn dfgpu_join_lookup(ctx: *mut dfgpu_ctx, table: *const dfgpu_join_table, probe_keys: *const *const dfgpu_array, nkeys: i32, rows: *const dfgpu_array, out_build_idx: *mut *mut dfgpu_array) -> i32;
+    pub fn dfgpu_plan_sort_merge_join(left: *const dfgpu_plan, right: *const dfgpu_plan, on_l: *const *const dfgpu_expr, on_r: *const *const dfgpu_expr, non: i32, filter: *const dfgpu_expr,
+                                      filter_sides: *const i32, filter_indices: *const i32, nfilter_cols: i32, join_type: i32, null_equals_null: i32, out: *mut *mut dfgpu_plan) -> i32;
     pub fn dfgpu_plan_nested_loop_join(left: *const dfgpu_plan, right: *const dfgpu_plan, filter: *const dfgpu_expr, filter_sides: *const i32, filter_indices: *const i32,
                                        nfilter_cols: i32, join_type: i32, out: *mut *mut dfgpu_plan) -> i32;
     pub fn dfgpu_plan_metrics(p: *const dfgpu_plan, buf: *mut c_char, capacity: i64) -> i32;
