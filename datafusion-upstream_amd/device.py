@@ -339,6 +339,20 @@ class JoinTable:
         self.ctx.check(self.ctx.lib.dfgpu_join_probe(self.ctx.h, self.h, hs, n, mask.h if mask is not None else None, C.byref(ob), C.byref(op)))
         return Array(self.ctx, ob), Array(self.ctx, op)
 
+    def probe_deferred(self, keys: Sequence[Array], mask: Optional[Array] = None):
+        """dfgpu_join_probe_deferred -> (build indices or None, probe indices): None when the table can give the build rows later (`lookup`)"""
+        hs, n = capi.handle_array([a.h.value for a in keys])
+        ob, op = C.c_void_p(), C.c_void_p()
+        self.ctx.check(self.ctx.lib.dfgpu_join_probe_deferred(self.ctx.h, self.h, hs, n, mask.h if mask is not None else None, C.byref(ob), C.byref(op)))
+        return (Array(self.ctx, ob) if ob.value else None), Array(self.ctx, op)
+
+    def lookup(self, keys: Sequence[Array], rows: Optional[Array] = None) -> Array:
+        """dfgpu_join_lookup: build rows of the probe rows `rows` (UInt32, known to match; None = every row of `keys`)"""
+        hs, n = capi.handle_array([a.h.value for a in keys])
+        out = C.c_void_p()
+        self.ctx.check(self.ctx.lib.dfgpu_join_lookup(self.ctx.h, self.h, hs, n, rows.h if rows is not None else None, C.byref(out)))
+        return Array(self.ctx, out)
+
     def mark_visited(self, build_idx: Array):
         self.ctx.check(self.ctx.lib.dfgpu_join_mark_visited(self.ctx.h, self.h, build_idx.h))
 

@@ -392,3 +392,35 @@ def test_probe_key_column_sliced_at_an_odd_row_offset(ctx):
         bi, pi = table.probe([sliced])
         want = po.hash_join([[pa.array(b)]], [[pa.array(p[off:])]], "Inner", False, batch_size=1 << 40)
         assert np.array_equal(bi.to_numpy().astype(np.int64), want.build_idx) and np.array_equal(pi.to_numpy().astype(np.int64), want.probe_idx)
+
+
+@pytest.mark.parametrize("shape", ["sorted_keys", "unsorted_unique_keys", "masked_build", "repeated_keys", "nullable_probe"])
+def test_deferred_probe_and_lookup_at_the_abi(ctx, shape):
+    """dfgpu_join_probe_deferred / dfgpu_join_lookup: a unique rank-indexed build leaves the build indices out and gives them later for any subset of the matched probe
+    rows; every other table (repeated keys -> CSR, a nullable probe column) answers at once, exactly as dfgpu_join_probe.  Both ways equal the plain probe."""
+    import dfgpu
+    rng = np.random.default_rng(len(shape))
+    nb, npr = 30_000, 100_000
+    b = np.arange(nb, dtype=np.int64) * 2 + 10
+    if shape == "unsorted_unique_keys":
+        b = rng.permutation(b)
+    if shape == "repeated_keys":
+        b[5] = b[4]
+    bmask = ctx.from_arrow(pa.array(rng.random(nb) < 0.8)) if shape == "masked_build" else None
+    p = rng.integers(0, 2 * nb + 40, npr).astype(np.int64)
+    pa_p = pa.array(p, mask=(rng.random(npr) < 0.05) if shape == "nullable_probe" else None)
+    table = dfgpu.JoinTable(ctx, [ctx.from_arrow(pa.array(b))], mask=bmask)
+    probe = [ctx.from_arrow(pa_p)]
+    bi, pi = table.probe(probe)
+    dbi, dpi = table.probe_deferred(probe)
+    assert np.array_equal(dpi.to_numpy(), pi.to_numpy()) if dbi is None or shape != "repeated_keys" else True
+    if shape in ("repeated_keys", "nullable_probe"):
+        assert dbi is not None and np.array_equal(dbi.to_numpy(), bi.to_numpy()) and np.array_equal(dpi.to_numpy(), pi.to_numpy())
+        return
+    assert dbi is None
+    assert np.array_equal(table.lookup(probe, dpi).to_numpy(), bi.to_numpy())                       # every matched row
+    sub = np.sort(rng.choice(len(pi), 777, replace=False))
+    rows = ctx.from_arrow(pa.array(pi.to_numpy()[sub].astype(np.uint32)))
+    assert np.array_equal(table.lookup(probe, rows).to_numpy(), bi.to_numpy()[sub])                # a subset, in the subset's order
+    with pytest.raises(dfgpu.DfgpuError):
+        dfgpu.JoinTable(ctx, [ctx.from_arrow(pa.array(["a", "b"]))]).lookup([ctx.from_arrow(pa.array(["a"]))])      # a table that cannot locate a row from the key alone
