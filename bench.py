@@ -106,6 +106,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--no-shuffled", action="store_true", help="N = 1: skip Q3 over row-wise permuted tables")
     ap.add_argument("--no-workloads", action="store_true", help="N = 1: skip the nested other plan shapes (bench_workloads.py)")
     ap.add_argument("--workloads", default="q1_decimal,q1_float64,q5,q18,hash_join,groupby_int64,groupby_decimal_3key,sort,partition,parquet_scan,csv_scan,clickbench_uniform_1000000,clickbench_zipf_1000000",
                     help="N = 1: which plan shapes of bench_workloads.py to nest under \"workloads\"")
@@ -320,7 +321,7 @@ def main():
                     "note": "logical bytes of every referenced column / step time; NOT HBM traffic (filtered rows' payload columns are never read)"}
 
     # ---- N = 1: result check at full scale, the general (hash) paths of the same query, the other target plan shapes
-    result_check = general = workloads = other_plans = dist_workloads = None
+    result_check = general = workloads = other_plans = dist_workloads = shuffled = None
     if world == 1:
         got = tpch.q3_checksum_result(last_out[0] or [])
         want = tpch.q3_checksum_torch(tensors)
@@ -346,6 +347,39 @@ def main():
         general = {"options": {"join_rank_index": 0, "group_run_detection": 0}, "ms_per_step": round(g_ms, 3), "rows_per_s": round(rows_total / (g_ms * 1e-3), 1), "steps": 3, "result_check": "same checksums as the default paths",
                    "kernel_ms_per_step": {k: round(v[1], 3) for k, v in sorted(gp.items(), key=lambda kv: -kv[1][1])[:12]}}
         last_out[0] = None
+        # the same query over the same rows in RANDOM order: every table permuted row-wise, so no key column is sorted and no join or group key arrives clustered -- what the
+        # operators see behind a hash repartition, or on tables that were never written in key order.  Default options (nothing switched off): the builds are unique keys over a
+        # dense domain in no order (rank index over unsorted keys, join.hip), the probes touch the bitmap at random, the group-by finds no runs (partitioned pre-aggregation).
+        shuffled = None
+        if not args.no_shuffled:
+            gsh = torch.Generator(device="cuda"); gsh.manual_seed(20260311)
+            t2 = {}
+            for prefix in ("c_", "o_", "l_"):
+                cols = [k for k in tensors if k.startswith(prefix)]
+                perm = torch.randperm(tensors[cols[0]].shape[0], generator=gsh, device="cuda")
+                for k in cols:          # (n, 2) Decimal128 tensors half by half: torch's row gather of a 2-D int64 tensor returned garbage at 240 M rows on this ROCm build
+                    t2[k] = tensors[k][perm] if tensors[k].dim() == 1 else torch.stack([tensors[k][:, h][perm] for h in range(tensors[k].shape[1])], dim=1).contiguous()
+                del perm
+            tables2 = tpch.tables_from_torch(ctx, t2)
+            template2 = tpch.q3_plan(tables2, batch_size=8192)
+
+            def step_sh():
+                out = [b for b in ops.with_fresh_state(template2).execute(0, tc)]
+                ctx.synchronize(); last_out[0] = out
+            step_sh()
+            ctx.profile_select(None); ctx.profile_enable(True); ctx.profile_read(); step_sh(); sp_, ssync = split_syncs(ctx.profile_read()); ctx.profile_enable(False)
+            barrier(); t1 = time.perf_counter()
+            for _ in range(3):
+                step_sh()
+            barrier(); s_ms = (time.perf_counter() - t1) / 3 * 1e3
+            same = tpch.q3_checksum_result(last_out[0] or []) == got
+            assert same, "Q3 over the shuffled tables differs from Q3 over the clustered ones"
+            shuffled = {"ms_per_step": round(s_ms, 3), "rows_per_s": round(rows_total / (s_ms * 1e-3), 1), "steps": 3, "result_check": "same checksums as over the clustered tables",
+                        "what": "every table permuted row-wise (torch.randperm); default options",
+                        "kernel_ms_per_step": {k: round(v[1], 3) for k, v in sorted(sp_.items(), key=lambda kv: -kv[1][1])[:12]}, "host_syncs_per_step": sum(ssync.values())}
+            last_out[0] = None
+            del t2, tables2, template2
+            torch.cuda.empty_cache()
         if not args.no_workloads:
             import argparse as _ap
             import bench_workloads
@@ -487,6 +521,8 @@ def main():
         line["config"]["paths"] = "joins: membership bitmap + rank index (clustered, dense TPC-H keys: no hash table); group-by: run numbering (input clustered on l_orderkey); see q3_general_paths for the hash paths"
         if world == 1:
             line["result_check"] = result_check; line["q3_general_paths"] = general
+            if shuffled is not None:
+                line["q3_shuffled_inputs"] = shuffled
             if workloads is not None:
                 line["workloads"] = workloads
         else:
