@@ -355,6 +355,7 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     }
     else if (k == "agg_spill_state_bytes") ctx->agg_spill_state_bytes = value;
     else if (k == "sort_estimate_ranges") ctx->sort_estimate_ranges = value != 0;
+    else if (k == "sort_packed_min_rows") ctx->sort_packed_min_rows = value < 2 ? 2 : value;
     else if (k == "sort_spill_bytes") ctx->sort_spill_bytes = value;
     else if (k == "spm_merge_rows") { if (value < 0) fail(DFGPU_INVALID_ARGUMENT, "spm_merge_rows: >= 0"); ctx->spm_merge_rows = value; }
     else if (k == "sort_spill_ranges") { if (value < 1 || value > 4096) fail(DFGPU_INVALID_ARGUMENT, "sort_spill_ranges: 1 .. 4096"); ctx->sort_spill_ranges = value; }
@@ -396,6 +397,7 @@ dfgpu_status dfgpu_ctx_get_option(dfgpu_ctx* ctx, const char* key, int64_t* out)
     else if (k == "memory_limit") *out = ctx->memory_limit;
     else if (k == "agg_spill_state_bytes") *out = ctx->agg_spill_state_bytes;
     else if (k == "sort_estimate_ranges") *out = ctx->sort_estimate_ranges ? 1 : 0;
+    else if (k == "sort_packed_min_rows") *out = ctx->sort_packed_min_rows;
     else if (k == "sort_spill_bytes") *out = ctx->sort_spill_bytes;
     else if (k == "spm_merge_rows") *out = ctx->spm_merge_rows;
     else if (k == "sort_spill_ranges") *out = ctx->sort_spill_ranges;

@@ -372,7 +372,7 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
       W += s.has_null_byte + (lt == DFGPU_BOOL ? 1 : (lt == DFGPU_UTF8 ? s.max_len + 4 : type_width(lt)));
     }
     // ---- packed-key path: large input, fixed-width keys whose value ranges concatenate into 64 bits, no TopK
-    if (n >= (1 << 20) && ctx->sort_packed_keys && !(fetch > 0 && fetch * 16 <= n)) {
+    if (n >= ctx->sort_packed_min_rows && ctx->sort_packed_keys && !(fetch > 0 && fetch * 16 <= n)) {
       bool ok = true; PkCols pc{}; pc.n = k;
       for (int c = 0; c < k && ok; c++) {
         const dfgpu_array* a = cols[c];
