@@ -333,7 +333,7 @@ dfgpu_status dfgpu_ctx_create(int32_t device_id, void* stream, dfgpu_ctx** out) 
 void dfgpu_ctx_destroy(dfgpu_ctx* ctx) { if (ctx) ctx_unref(ctx); }
 const char* dfgpu_last_error(const dfgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 void* dfgpu_ctx_stream(dfgpu_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
-dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx* ctx) { return guard(ctx, [&] { HIP_CHECK(hipSetDevice(ctx->device)); HIP_CHECK(hipStreamSynchronize(ctx->stream)); flush_flags(ctx); }); }
+dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx* ctx) { if (!ctx) return DFGPU_INVALID_ARGUMENT; return guard(ctx, [&] { HIP_CHECK(hipSetDevice(ctx->device)); HIP_CHECK(hipStreamSynchronize(ctx->stream)); flush_flags(ctx); }); }
 dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value) {
   return guard(ctx, [&] {
     std::string k = key ? key : "";
@@ -501,16 +501,19 @@ dfgpu_status dfgpu_profile_read(dfgpu_ctx* ctx, char* buf, int64_t capacity) {
 }
 
 dfgpu_status dfgpu_array_import_host(dfgpu_ctx* ctx, const dfgpu_array_desc* host, dfgpu_array** out) {
-  return guard(ctx, [&] { HIP_CHECK(hipSetDevice(ctx->device)); *out = import_desc(ctx, host, true); });
+  if (!ctx) return DFGPU_INVALID_ARGUMENT;
+  return guard(ctx, [&] { if (!host || !out) fail(DFGPU_INVALID_ARGUMENT, "array_import_host: null argument"); HIP_CHECK(hipSetDevice(ctx->device)); *out = import_desc(ctx, host, true); });
 }
 dfgpu_status dfgpu_array_wrap_device(dfgpu_ctx* ctx, const dfgpu_array_desc* dev, dfgpu_array** out) {
-  return guard(ctx, [&] { *out = import_desc(ctx, dev, false); });
+  if (!ctx) return DFGPU_INVALID_ARGUMENT;
+  return guard(ctx, [&] { if (!dev || !out) fail(DFGPU_INVALID_ARGUMENT, "array_wrap_device: null argument"); *out = import_desc(ctx, dev, false); });
 }
 dfgpu_status dfgpu_array_wrap_device_owned(dfgpu_ctx* ctx, const dfgpu_array_desc* dev, void (*release)(void*), void* cookie, dfgpu_array** out) {
   // the token is created first: if the import fails the callback still fires exactly once (the caller gave the reference away)
   std::shared_ptr<void> owner;
   if (release) owner = std::shared_ptr<void>(cookie ? cookie : (void*)&owner, [release, cookie](void*) { release(cookie); });
-  return guard(ctx, [&] { *out = import_desc(ctx, dev, false, owner); });
+  if (!ctx) return DFGPU_INVALID_ARGUMENT;          // `owner` goes out of scope: the callback fires, as on every other failure
+  return guard(ctx, [&] { if (!dev || !out) fail(DFGPU_INVALID_ARGUMENT, "array_wrap_device_owned: null argument"); *out = import_desc(ctx, dev, false, owner); });
 }
 dfgpu_status dfgpu_array_describe(const dfgpu_array* a, dfgpu_array_desc* o) {
   if (!a || !o) return DFGPU_INVALID_ARGUMENT;
@@ -525,7 +528,9 @@ dfgpu_status dfgpu_array_describe(const dfgpu_array* a, dfgpu_array_desc* o) {
   return DFGPU_OK;
 }
 dfgpu_status dfgpu_array_export_host(dfgpu_ctx* ctx, const dfgpu_array* a, void* values, uint8_t* validity, int32_t* offsets) {
+  if (!ctx) return DFGPU_INVALID_ARGUMENT;
   return guard(ctx, [&] {
+    if (!a) fail(DFGPU_INVALID_ARGUMENT, "array_export_host: null array");
     HIP_CHECK(hipSetDevice(ctx->device));
     materialize_ids(ctx, a);
     flush_flags(ctx);                                   // data never leaves the device past a deferred kernel error
@@ -600,7 +605,9 @@ dfgpu_status dfgpu_array_iota(dfgpu_ctx* ctx, int64_t length, dfgpu_array** out)
   });
 }
 dfgpu_status dfgpu_array_slice(dfgpu_ctx* ctx, const dfgpu_array* a, int64_t offset, int64_t length, dfgpu_array** out) {
+  if (!ctx) return DFGPU_INVALID_ARGUMENT;
   return guard(ctx, [&] {
+    if (!a || !out) fail(DFGPU_INVALID_ARGUMENT, "array_slice: null argument");
     if (offset < 0 || length < 0 || offset + length > a->length) fail(DFGPU_INVALID_ARGUMENT, "slice [%lld, +%lld) outside array of %lld rows", (long long)offset, (long long)length, (long long)a->length);
     int32_t vt0 = a->type == DFGPU_DICTIONARY ? a->key_type : a->type;
     bool bit_aligned_needed = a->validity != nullptr || vt0 == DFGPU_BOOL;

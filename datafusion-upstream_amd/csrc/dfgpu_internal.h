@@ -225,6 +225,7 @@ struct KernelTimer {
 
 template <typename F>
 dfgpu_status guard(dfgpu_ctx* ctx, F&& f) {
+  if (!ctx) return DFGPU_INVALID_ARGUMENT;          // every entry point that takes a ctx: a NULL handle is an argument error, never a crash of the host process
   try { f(); return DFGPU_OK; }
   catch (const Error& e) { if (ctx) ctx->err = e.msg; return e.code; }
   catch (const std::bad_alloc&) { if (ctx) ctx->err = "host allocation failed"; return DFGPU_RESOURCES_EXHAUSTED; }

@@ -90,10 +90,12 @@ int32_t dfgpu_comm_world(const dfgpu_comm* c) { return c ? c->world : 0; }
 dfgpu_status dfgpu_exchange(dfgpu_ctx* ctx, dfgpu_comm* comm, const dfgpu_array* const* keys, int32_t nkeys, const dfgpu_array* const* cols, int32_t ncols,
                             const dfgpu_array* opt_mask, dfgpu_array** out_cols, int64_t* out_counts /* [2 * world]: rows sent to / received from every rank; may be NULL */) {
   return guard(ctx, [&] {
-    if (!comm || !out_cols || ncols < 1) fail(DFGPU_INVALID_ARGUMENT, "exchange: null argument");
+    if (!comm || !out_cols) fail(DFGPU_INVALID_ARGUMENT, "exchange: null argument");
     constexpr int MAXC = 64;
-    const int32_t W = comm->world; if (W > 256) fail(DFGPU_NOT_IMPLEMENTED, "exchange over more than 256 ranks");
-    if (ncols > MAXC) fail(DFGPU_NOT_IMPLEMENTED, "exchange of more than %d columns", MAXC);
+    const int32_t W = comm->world; if (W > 256) fail(DFGPU_NOT_IMPLEMENTED, "exchange over more than 256 ranks");       // the same on every rank of the communicator
+    // A bad column count is this rank's failure alone: like every failure before the collective it travels in the status word (the metadata layout below is
+    // sized by MAXC, not by the local ncols, so the all-gather itself has one length on every rank whatever each rank was handed).
+    const int32_t ncols_arg = ncols; if (ncols < 1 || ncols > MAXC) ncols = 0;
     const bool have = cols != nullptr && keys != nullptr;          // a rank whose input produced no batch still takes part: it learns the column types from the others
     const int64_t n = have ? keys[0]->length : 0;
     // ---- 1. every column grouped by destination rank: fixed-width columns without NULLs in the partition pass itself, every other column (NULLs, Utf8,
@@ -105,6 +107,7 @@ dfgpu_status dfgpu_exchange(dfgpu_ctx* ctx, dfgpu_comm* comm, const dfgpu_array*
     int64_t local_status = DFGPU_OK; std::string local_err;
     auto lane_type = [](const dfgpu_array* a) { return a->type == DFGPU_DICTIONARY ? a->dictionary->type : a->type; };
     try {
+      if (ncols_arg < 1 || ncols_arg > MAXC) fail(ncols_arg < 1 ? DFGPU_INVALID_ARGUMENT : DFGPU_NOT_IMPLEMENTED, "exchange of %d columns (1 .. %d)", ncols_arg, MAXC);
       if (have) {
         std::vector<ArrayHolder> plain((size_t)ncols);             // dictionary columns travel as their values
         std::vector<const dfgpu_array*> src((size_t)ncols);
@@ -151,7 +154,7 @@ dfgpu_status dfgpu_exchange(dfgpu_ctx* ctx, dfgpu_comm* comm, const dfgpu_array*
     } catch (const Error& e) { local_status = e.code ? e.code : DFGPU_INTERNAL; local_err = e.msg; std::fill(send_rows.begin(), send_rows.end(), 0); }
     // ---- 2. what the ranks must agree on, in one small all-gather: the status word, the row-count matrix, the column types, which columns are nullable
     // anywhere, the Utf8 byte counts
-    const int64_t ML = W + 2 + 4 * (int64_t)ncols + (int64_t)ncols * W;
+    const int64_t ML = W + 2 + 4 * (int64_t)MAXC + (int64_t)MAXC * W;
     std::vector<int64_t> mine((size_t)ML, 0), all((size_t)ML * W, 0);
     auto gather = [&](std::vector<int64_t>& m, std::vector<int64_t>& a, int64_t len, const char* what) {
       if (comm->custom) { if (comm->vt.all_gather_host(comm->vt.user, m.data(), len * 8, a.data()) != 0) fail(DFGPU_EXECUTION, "exchange: the transport's all_gather_host failed (%s)", what); return; }
@@ -162,7 +165,7 @@ dfgpu_status dfgpu_exchange(dfgpu_ctx* ctx, dfgpu_comm* comm, const dfgpu_array*
       ctx->count_sync("sync:exchange_counts");
       HIP_CHECK(hipStreamSynchronize(ctx->stream));
     };
-    const size_t O_NCOLS = (size_t)W, O_STATUS = (size_t)W + 1, O_META = (size_t)W + 2, O_UB = O_META + 4 * (size_t)ncols;
+    const size_t O_NCOLS = (size_t)W, O_STATUS = (size_t)W + 1, O_META = (size_t)W + 2, O_UB = O_META + 4 * (size_t)MAXC;
     for (int32_t p = 0; p < W; p++) mine[(size_t)p] = send_rows[(size_t)p];
     mine[O_NCOLS] = have && local_status == DFGPU_OK ? ncols : 0; mine[O_STATUS] = local_status;
     if (have && local_status == DFGPU_OK) for (int32_t c = 0; c < ncols; c++) {
@@ -179,7 +182,9 @@ dfgpu_status dfgpu_exchange(dfgpu_ctx* ctx, dfgpu_comm* comm, const dfgpu_array*
     const int64_t* ref = nullptr;                      // the first rank that holds a schema
     for (int32_t s2 = 0; s2 < W && !ref; s2++) if (all[(size_t)s2 * ML + O_NCOLS] > 0) ref = &all[(size_t)s2 * ML];
     if (!ref) return;                                  // nobody has rows: nothing moves, out_cols stay NULL
-    if (ref[O_NCOLS] != ncols) fail(DFGPU_INVALID_ARGUMENT, "exchange: this rank passes %d columns, another one %lld", ncols, (long long)ref[O_NCOLS]);
+    // every rank reads the same matrix, so every check below gives the same verdict on every rank: all fail together, none enters the data collective alone
+    for (int32_t s2 = 0; s2 < W; s2++) { const int64_t nc2 = all[(size_t)s2 * ML + O_NCOLS]; if (nc2 > 0 && nc2 != ref[O_NCOLS]) fail(DFGPU_INVALID_ARGUMENT, "exchange: rank %d passes %lld columns, another one %lld", s2, (long long)nc2, (long long)ref[O_NCOLS]); }
+    if (ref[O_NCOLS] != ncols) fail(DFGPU_INVALID_ARGUMENT, "exchange: this rank passes %d columns, the ranks with rows %lld", ncols, (long long)ref[O_NCOLS]);      // a rank without rows (cols == NULL) and another count
     std::vector<int64_t> recv_rows((size_t)W, 0); int64_t total = 0, sent = 0;
     for (int32_t s2 = 0; s2 < W; s2++) { recv_rows[(size_t)s2] = all[(size_t)s2 * ML + comm->rank]; total += recv_rows[(size_t)s2]; }
     for (int32_t p = 0; p < W; p++) sent += send_rows[(size_t)p];
@@ -190,10 +195,14 @@ dfgpu_status dfgpu_exchange(dfgpu_ctx* ctx, dfgpu_comm* comm, const dfgpu_array*
     for (int32_t c = 0; c < ncols; c++) {
       const int64_t* f = ref + O_META + 4 * (size_t)c; meta[(size_t)c] = Meta{ (int32_t)f[0], (int32_t)f[1], (int32_t)f[2], false };
       for (int32_t s2 = 0; s2 < W; s2++) { const int64_t* g = &all[(size_t)s2 * ML]; if (g[O_NCOLS] > 0) { if (g[O_META + 4 * (size_t)c] != f[0]) fail(DFGPU_INVALID_ARGUMENT, "exchange: column %d has type %lld on one rank and %lld on another", c, (long long)f[0], (long long)g[O_META + 4 * (size_t)c]); meta[(size_t)c].nullable |= g[O_META + 4 * (size_t)c + 3] != 0; } }
+      if (meta[(size_t)c].type == DFGPU_UTF8) for (int32_t r2 = 0; r2 < W; r2++) {          // Utf8's 32-bit offsets at EVERY receiver, checked by every rank
+        int64_t b2 = 0; for (int32_t s2 = 0; s2 < W; s2++) b2 += all[(size_t)s2 * ML + O_UB + (size_t)c * W + (size_t)r2];
+        if (b2 > 0x7FFFFFF0ll) fail(DFGPU_RESOURCES_EXHAUSTED, "exchange: %lld bytes of column %d arrive at rank %d: beyond Utf8's 32-bit offsets", (long long)b2, c, r2);
+      }
     }
     // ---- 3. the lanes: per column its values (fixed width), or its Boolean bytes, or its Utf8 lengths + value bytes; plus validity bytes where nullable anywhere.
-    // Every receive buffer exists BEFORE the grouped collective starts; a rank that cannot allocate says so in a second status round (only paid when the
-    // ctx runs under a memory limit, where ResourcesExhausted is an expected answer), so that no rank enters the group alone.
+    // Every receive buffer exists BEFORE the grouped collective starts; a rank that cannot allocate says so in a second status round -- always run: an
+    // allocation can fail without a memory limit too, and a per-ctx option may differ between ranks -- so that no rank enters the group alone.
     struct Lane { const uint8_t* sp; uint8_t* rp; std::vector<int64_t> sb, rb; };
     std::vector<Lane> lanes; std::vector<BufferPtr> keep;
     std::vector<BufferPtr> r_vals((size_t)ncols), r_len((size_t)ncols), r_valid((size_t)ncols); std::vector<int64_t> r_bytes((size_t)ncols, 0);
@@ -207,7 +216,6 @@ dfgpu_status dfgpu_exchange(dfgpu_ctx* ctx, dfgpu_comm* comm, const dfgpu_array*
           fixed_lane(g ? ulen[(size_t)c]->ptr : nullptr, r_len[(size_t)c]->ptr, 4);
           Lane l{ g ? (const uint8_t*)g->values->ptr : nullptr, nullptr, std::vector<int64_t>((size_t)W, 0), std::vector<int64_t>((size_t)W, 0) };
           for (int32_t p = 0; p < W; p++) { l.sb[(size_t)p] = ubytes[(size_t)c].empty() ? 0 : ubytes[(size_t)c][(size_t)p]; l.rb[(size_t)p] = all[(size_t)p * ML + O_UB + (size_t)c * W + (size_t)comm->rank]; r_bytes[(size_t)c] += l.rb[(size_t)p]; }
-          if (r_bytes[(size_t)c] > 0x7FFFFFF0ll) fail(DFGPU_RESOURCES_EXHAUSTED, "exchange: %lld bytes of column %d arrive at rank %d: beyond Utf8's 32-bit offsets", (long long)r_bytes[(size_t)c], c, comm->rank);
           r_vals[(size_t)c] = alloc_buffer(ctx, (size_t)r_bytes[(size_t)c] + 8); l.rp = (uint8_t*)r_vals[(size_t)c]->ptr;
           lanes.push_back(std::move(l));
         } else if (m.type == DFGPU_BOOL) {
@@ -228,14 +236,14 @@ dfgpu_status dfgpu_exchange(dfgpu_ctx* ctx, dfgpu_comm* comm, const dfgpu_array*
         fixed_lane(vp, r_valid[(size_t)c]->ptr, 1);
       }
     } catch (const Error& e) { alloc_status = e.code ? e.code : DFGPU_INTERNAL; alloc_err = e.msg; }
-    if (ctx->memory_limit > 0) {
+    {
       std::vector<int64_t> m2(1, alloc_status), a2((size_t)W, 0);
       gather(m2, a2, 1, "allocation status");
       for (int32_t s2 = 0; s2 < W; s2++) if (a2[(size_t)s2] != DFGPU_OK) {
         if (s2 == comm->rank) fail((dfgpu_status)alloc_status, "%s", alloc_err.c_str());
         fail((dfgpu_status)a2[(size_t)s2], "exchange: rank %d could not allocate its receive buffers (status %lld); nothing was exchanged", s2, (long long)a2[(size_t)s2]);
       }
-    } else if (alloc_status != DFGPU_OK) fail((dfgpu_status)alloc_status, "%s", alloc_err.c_str());
+    }
     // ---- 4. one grouped collective over every lane
     { KernelTimer kt_(ctx, "exchange_all_to_all");
       struct Group { bool open = false; ~Group() { if (open) (void)rccl().GroupEnd(); } } group;       // an error between Start and End still closes the group: the communicator stays usable

@@ -675,7 +675,7 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
     const HashJoinExec* op; TaskContext tc; int partition; std::unique_ptr<Stream> probe; std::shared_ptr<BuildSide> bs; Batch swapped; int state = 0;
     // reference-sized probe batches are answered in the reference's output chunks (get_matched_indices_with_limit_offset, joins/utils.rs:284-348;
     // process_probe_batch, hash_join.rs:1238-1343): `batch_size` candidate pairs per emitted batch, index alignment per chunk
-    Batch chunk_pb; ArrayRef chunk_b, chunk_p; int64_t chunk_k = -1, chunk_total = 0, chunk_joined = -1;   // 0 WaitBuildSide, 1 probing, 2 final pass, 3 done, 4 swapped semi/anti result pending
+    Batch chunk_pb; ArrayRef chunk_b, chunk_p; int64_t chunk_k = -1, chunk_total = 0, chunk_joined = -1; std::vector<uint32_t> chunk_last;     // chunk_last: without a JoinFilter, every chunk's last joined probe row (one read-back per probe batch)   // 0 WaitBuildSide, 1 probing, 2 final pass, 3 done, 4 swapped semi/anti result pending
     SchemaPtr out_schema;
     bool lazy_build_rows = true;
     S(const HashJoinExec* o, int p, TaskContext t) : op(o), tc(t), partition(p) { int64_t v = 1; if (dfgpu_ctx_get_option(tc.ctx, "join_lazy_build_rows", &v) == DFGPU_OK) lazy_build_rows = v != 0; }
@@ -683,6 +683,17 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
       int64_t n = a.len(); if (!n) return -1;
       dfgpu_array* s1 = nullptr; tc.check(dfgpu_array_slice(tc.ctx, a.a, n - 1, 1, &s1)); ArrayRef one = ArrayRef::adopt(s1);
       uint32_t v = 0; tc.check(dfgpu_array_export_host(tc.ctx, one.a, &v, nullptr, nullptr)); return (int64_t)v;
+    }
+    // The probe row of the last pair of every `bsz`-pair chunk: the reference resumes the next chunk from an in-memory offset (hash_join.rs:1332-1340); here the
+    // rows are gathered from the pair list at the chunk ends and read back together -- one host read per probe batch, not one per emitted chunk.
+    void chunk_last_rows(const ArrayRef& pidx, int64_t bsz) {
+      const int64_t m = pidx.len(); chunk_last.clear(); if (!m) return;
+      std::vector<uint32_t> pos; for (int64_t e = bsz; ; e += bsz) { pos.push_back((uint32_t)((e < m ? e : m) - 1)); if (e >= m) break; }
+      if (pos.size() == 1) { chunk_last.push_back((uint32_t)last_u32(pidx)); return; }
+      dfgpu_array_desc d{}; d.type = DFGPU_UINT32; d.length = (int64_t)pos.size(); d.values = pos.data();
+      dfgpu_array* a = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &d, &a)); ArrayRef at = ArrayRef::adopt(a);
+      ArrayRef ends = take(tc, pidx, at); chunk_last.resize(pos.size());
+      tc.check(dfgpu_array_export_host(tc.ctx, ends.a, chunk_last.data(), nullptr, nullptr));
     }
     ArrayRef slice_of(const ArrayRef& a, int64_t off, int64_t len) { dfgpu_array* s1 = nullptr; tc.check(dfgpu_array_slice(tc.ctx, a.a, off, len, &s1)); return ArrayRef::adopt(s1); }
     void apply_filter(Batch& pb, ArrayRef& bidx, ArrayRef& pidx) {      // apply_join_filter_to_indices (joins/utils.rs:1143-1176)
@@ -703,7 +714,8 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
       ArrayRef b = slice_of(chunk_b, off < m ? off : m, len), p = slice_of(chunk_p, off < m ? off : m, len);
       apply_filter(chunk_pb, b, p);
       if (need_final && !bs->empty && b.len()) tc.check(dfgpu_join_mark_visited(tc.ctx, bs->table->t, b.a));
-      const int64_t last_joined = last_u32(p);                       // counts as joined after the key comparison and the join filter
+      // counts as joined after the key comparison and the join filter; without a filter the chunk's last pair is known since the probe (chunk_last_rows)
+      const int64_t last_joined = op->filter ? last_u32(p) : (len > 0 ? (int64_t)chunk_last[(size_t)chunk_k] : -1);
       const int64_t r0 = chunk_joined + 1, r1 = last ? chunk_pb.base_rows : (last_joined >= 0 ? last_joined + 1 : 0);
       if (!last && last_joined >= 0) chunk_joined = last_joined;
       const int jt = op->join_type;
@@ -810,7 +822,8 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
           // (chain_traverse!, joins/utils.rs:147-187: next_offset is None only at the last chain element of the last probe row)
           const int64_t bsz = tc.batch_size > 0 ? tc.batch_size : 8192, m = bidx.len();
           chunk_total = m == 0 ? 1 : (m + bsz - 1) / bsz;
-          if (m > 0 && m % bsz == 0 && last_u32(pidx) != pb.base_rows - 1) chunk_total++;
+          chunk_last_rows(pidx, bsz);
+          if (m > 0 && m % bsz == 0 && (int64_t)chunk_last.back() != pb.base_rows - 1) chunk_total++;
           chunk_pb = std::move(pb); chunk_b = bidx; chunk_p = pidx; chunk_k = 0; chunk_joined = -1;
           continue;
         }
@@ -1977,7 +1990,7 @@ dfgpu_status dfgpu_batch_new(const char* const* names, const dfgpu_array* const*
 void dfgpu_batch_free(dfgpu_batch* b) { delete b; }
 int32_t dfgpu_batch_num_columns(const dfgpu_batch* b) { return b ? (int32_t)b->b.cols.size() : 0; }
 const char* dfgpu_batch_column_name(const dfgpu_batch* b, int32_t i) { return (b && i >= 0 && i < (int)b->b.schema->f.size()) ? b->b.schema->f[(size_t)i].name.c_str() : ""; }
-dfgpu_status dfgpu_batch_num_rows(dfgpu_ctx* ctx, dfgpu_batch* b, int64_t* out) { return guard([&] { TaskContext tc{ctx, 8192}; *out = num_rows(tc, b->b); }); }
+dfgpu_status dfgpu_batch_num_rows(dfgpu_ctx* ctx, dfgpu_batch* b, int64_t* out) { return guard([&] { if (!ctx || !b || !out) fail(DFGPU_INVALID_ARGUMENT, "batch_num_rows: null argument"); TaskContext tc{ctx, 8192}; *out = num_rows(tc, b->b); }); }
 // every pending gather of the batch: columns that go through the same index array are gathered together (dfgpu_take_multi)
 static void materialize_all(const TaskContext& tc, Batch& b) {
   if (b.selection) b = materialize(tc, b);
@@ -1998,13 +2011,14 @@ dfgpu_status dfgpu_batch_materialize(dfgpu_ctx* ctx, dfgpu_batch* b) {
 }
 dfgpu_status dfgpu_batch_column(dfgpu_ctx* ctx, dfgpu_batch* b, int32_t i, dfgpu_array** out) {
   return guard([&] {
+    if (!ctx || !b || !out) fail(DFGPU_INVALID_ARGUMENT, "batch_column: null argument");
     TaskContext tc{ctx, 8192};
     if (b->b.selection) b->b = materialize(tc, b->b);
     const ArrayRef& a = b->b.column(tc, i); dfgpu_array_retain(a.a); *out = a.a;
   });
 }
 
-dfgpu_status dfgpu_expr_column(const char* name, int32_t index, dfgpu_expr** out) { return guard([&] { *out = new dfgpu_expr{std::make_shared<ColumnExpr>(name ? name : "", index)}; }); }
+dfgpu_status dfgpu_expr_column(const char* name, int32_t index, dfgpu_expr** out) { return guard([&] { if (!out) fail(DFGPU_INVALID_ARGUMENT, "expr_column: null argument"); *out = new dfgpu_expr{std::make_shared<ColumnExpr>(name ? name : "", index)}; }); }
 dfgpu_status dfgpu_expr_literal(const dfgpu_array* s, dfgpu_expr** out) {
   return guard([&] { if (!s || dfgpu_array_length(s) != 1) fail(DFGPU_INVALID_ARGUMENT, "literal must be a length-1 array"); *out = new dfgpu_expr{std::make_shared<LiteralExpr>(ArrayRef::share(s))}; });
 }
@@ -2021,6 +2035,7 @@ void dfgpu_expr_free(dfgpu_expr* e) { delete e; }
 
 dfgpu_status dfgpu_plan_memory(const dfgpu_batch* const* batches, const int32_t* sizes, int32_t nparts, dfgpu_plan** out) {
   return guard([&] {
+    if (!out || nparts < 0 || (nparts > 0 && (!sizes || !batches))) fail(DFGPU_INVALID_ARGUMENT, "plan_memory: null argument");
     auto m = std::make_shared<MemoryExec>(); int k = 0;
     for (int p = 0; p < nparts; p++) { m->parts.emplace_back(); for (int i = 0; i < sizes[p]; i++) { const dfgpu_batch* b = batches[k++]; if (!b) fail(DFGPU_INVALID_ARGUMENT, "null batch"); if (!m->sch) m->sch = b->b.schema; m->parts.back().push_back(b->b); } }
     if (!m->sch) m->sch = std::make_shared<Schema>();
@@ -2085,6 +2100,7 @@ dfgpu_status dfgpu_plan_repartition(const dfgpu_plan* input, const dfgpu_expr* c
 dfgpu_status dfgpu_plan_hash_join(const dfgpu_plan* left, const dfgpu_plan* right, const dfgpu_expr* const* on_left, const dfgpu_expr* const* on_right, int32_t non,
                                   const dfgpu_expr* filter, const int32_t* fs, const int32_t* fi, int32_t nf, int32_t join_type, int32_t mode, int32_t nen, dfgpu_plan** out) {
   return guard([&] {
+    if (!left || !right || !out) fail(DFGPU_INVALID_ARGUMENT, "plan_hash_join: null argument");
     if (non < 1) fail(DFGPU_EXECUTION, "Plan error: On constraints in HashJoinExec should be non-empty");       // hash_join.rs:303-305
     if (join_type < 0 || join_type > DFGPU_JOIN_RIGHT_ANTI) fail(DFGPU_INVALID_ARGUMENT, "unknown join type %d", join_type);
     auto j = std::make_shared<HashJoinExec>(); j->left = pl(left); j->right = pl(right);
@@ -2097,6 +2113,7 @@ dfgpu_status dfgpu_plan_hash_join(const dfgpu_plan* left, const dfgpu_plan* righ
 dfgpu_status dfgpu_plan_sort_merge_join(const dfgpu_plan* left, const dfgpu_plan* right, const dfgpu_expr* const* on_left, const dfgpu_expr* const* on_right, int32_t non, const dfgpu_expr* filter,
                                         const int32_t* fs, const int32_t* fi, int32_t nf, int32_t join_type, int32_t null_equals_null, dfgpu_plan** out) {
   return guard([&] {
+    if (!left || !right || !out) fail(DFGPU_INVALID_ARGUMENT, "plan_sort_merge_join: null argument");
     if (non < 1) fail(DFGPU_EXECUTION, "Plan error: On constraints in SortMergeJoinExec should be non-empty");       // sort_merge_join.rs:116-120
     if (join_type == DFGPU_JOIN_RIGHT_SEMI) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: SortMergeJoinExec does not support JoinType::RightSemi");       // :107-111
     if (join_type < 0 || join_type > DFGPU_JOIN_RIGHT_ANTI) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: SortMergeJoinExec join type %d on the device", join_type);

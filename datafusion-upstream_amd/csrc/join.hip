@@ -333,17 +333,25 @@ __global__ void __launch_bounds__(BLOCK) k_popc_words(const uint64_t* words, int
 constexpr int LR_ROWS = 4;
 template <typename T, bool ALL, bool SEL>
 __global__ void __launch_bounds__(BLOCK) k_probe_lookup_rank(const T* pkeys, const uint32_t* rows, int64_t m, int64_t kmin, const uint64_t* bitmap,
-                                                             const uint32_t* prefix, const uint32_t* sel_rows, int identity, uint64_t* out_build) {
+                                                             const uint32_t* prefix, const uint32_t* sel_rows, int identity, uint64_t* out_build,
+                                                             const uint64_t* rows_valid = nullptr, int64_t n_probe = 0) {
   const int64_t base = (int64_t)blockIdx.x * BLOCK * LR_ROWS + threadIdx.x;
   int64_t ic[LR_ROWS]; uint64_t d[LR_ROWS], r[LR_ROWS];
 #pragma unroll
   for (int q = 0; q < LR_ROWS; q++) { int64_t i = base + (int64_t)q * BLOCK; ic[q] = i < m ? i : m - 1; }
+  bool live[LR_ROWS];
+#pragma unroll
+  for (int q = 0; q < LR_ROWS; q++) live[q] = rows_valid == nullptr || valid_at(rows_valid, ic[q]);
   if constexpr (!ALL) {
 #pragma unroll
     for (int q = 0; q < LR_ROWS; q++) ic[q] = rows[ic[q]];
   }
+  if (rows_valid) {       // a NULL entry of `rows` (an unmatched row of an outer join above) names no probe row: read row 0, give back key_min's slot, the entry stays NULL
 #pragma unroll
-  for (int q = 0; q < LR_ROWS; q++) d[q] = (uint64_t)((int64_t)pkeys[ic[q]] - kmin);      // pass 1 proved d < range and the bit set
+    for (int q = 0; q < LR_ROWS; q++) if (!live[q] || ic[q] >= n_probe) ic[q] = 0;
+  }
+#pragma unroll
+  for (int q = 0; q < LR_ROWS; q++) d[q] = live[q] ? (uint64_t)((int64_t)pkeys[ic[q]] - kmin) : 0;      // pass 1 proved d < range and the bit set
   if (identity) {
 #pragma unroll
     for (int q = 0; q < LR_ROWS; q++) r[q] = d[q];
@@ -733,15 +741,18 @@ dfgpu_status dfgpu_join_lookup(dfgpu_ctx* ctx, const dfgpu_join_table* t, const 
     const dfgpu_array* pk = probe_keys[0];
     const int64_t m = rows ? rows->length : pk->length;
     ArrayHolder ob(new_fixed(ctx, DFGPU_UINT64, m));
+    // NULL entries of `rows` (the NULL side of an outer join's indices above a deferred join) stay NULL in the answer: take() through it then yields NULL rows
+    const uint64_t* rv = rows && rows->validity ? (const uint64_t*)rows->validity->ptr : nullptr;
     if (m) { KernelTimer kt_(ctx, "k_probe_lookup_rank");
-      const bool all = rows == nullptr || (rows->identity && rows->length == pk->length), sel = t->sel_rows != nullptr;
+      const bool all = !rv && (rows == nullptr || (rows->identity && rows->length == pk->length)), sel = t->sel_rows != nullptr;
       const uint32_t* rp = rows ? (const uint32_t*)rows->values->ptr : nullptr;
 #define LR(ALL, SEL) DFGPU_INT_KEY_DISPATCH(pk->type, hipLaunchKernelGGL((k_probe_lookup_rank<T, ALL, SEL>), dim3(grid_for(m, BLOCK * LR_ROWS)), dim3(BLOCK), 0, ctx->stream, (const T*)pk->values->ptr, rp, m, t->key_min, \
                                                             (const uint64_t*)t->bitmap->ptr, t->rank_prefix ? (const uint32_t*)t->rank_prefix->ptr : nullptr, \
-                                                            t->sel_rows ? (const uint32_t*)t->sel_rows->values->ptr : nullptr, t->rank_identity ? 1 : 0, (uint64_t*)ob.get()->values->ptr))
+                                                            t->sel_rows ? (const uint32_t*)t->sel_rows->values->ptr : nullptr, t->rank_identity ? 1 : 0, (uint64_t*)ob.get()->values->ptr, rv, pk->length))
       if (all && sel) { LR(true, true); } else if (all) { LR(true, false); } else if (sel) { LR(false, true); } else { LR(false, false); }
 #undef LR
       KERNEL_CHECK(); }
+    if (rv) { ob.get()->validity = rows->validity; ob.get()->null_count = rows->null_count; }
     *out_build_idx = ob.release();
   });
 }

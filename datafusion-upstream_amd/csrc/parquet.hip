@@ -171,7 +171,10 @@ struct dfgpu_parquet {
   std::vector<Leaf> leaves; std::vector<RowGroup> rgs; int64_t num_rows = 0; std::string created_by;
   bool utf8_dictionary = true;
   bool registered = false;                            // open_file without device staging: the mapping is page-locked, so column chunks cross PCIe by DMA from where they lie
-  ~dfgpu_parquet() { if (registered) (void)hipHostUnregister(map); if (map) munmap(map, map_len); }
+  hipEvent_t last_copy = nullptr;                     // recorded on the copy stream behind the last staged chunk of every read: DMA out of the mapping is over once it has fired
+  std::mutex copy_mu;
+  // the mapping must outlive every copy that reads it: wait for the last one before the pages are unlocked and unmapped (not left to hipHostUnregister's own waiting)
+  ~dfgpu_parquet() { if (last_copy) { (void)hipEventSynchronize(last_copy); (void)hipEventDestroy(last_copy); } if (registered) (void)hipHostUnregister(map); if (map) munmap(map, map_len); }
 };
 
 namespace dfgpu {
@@ -1092,7 +1095,8 @@ dfgpu_status dfgpu_parquet_read(dfgpu_ctx* ctx, dfgpu_parquet* f, int32_t first_
     // the stream-ordered cache of `stream`, so the copies start behind everything `stream` has been given so far; an error on the way waits for the copies before the buffers go back.
     struct CopyDrain { dfgpu_ctx* c; bool armed = true; ~CopyDrain() { if (armed && c->copy_stream) (void)hipStreamSynchronize(c->copy_stream); } } drain{ctx};
     if (!f->dev) {
-      if (!ctx->copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+      { static std::mutex create_mu; std::lock_guard<std::mutex> l(create_mu);       // plan partitions read concurrently on one ctx: one of them creates the stream
+        if (!ctx->copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)); }
       hipEvent_t e0; HIP_CHECK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
       hipError_t e1 = hipEventRecord(e0, ctx->stream), e2 = e1 == hipSuccess ? hipStreamWaitEvent(ctx->copy_stream, e0, 0) : e1; (void)hipEventDestroy(e0); HIP_CHECK(e2);
     }
@@ -1138,6 +1142,11 @@ dfgpu_status dfgpu_parquet_read(dfgpu_ctx* ctx, dfgpu_parquet* f, int32_t first_
     for (int32_t i : order) {
       if (!compressed && reads[(size_t)i].copied) HIP_CHECK(hipStreamWaitEvent(ctx->stream, reads[(size_t)i].copied, 0));
       res[(size_t)i].a = decode_column(ctx, f, reads[(size_t)i]);
+    }
+    if (!f->dev && ctx->copy_stream) {         // the handle's own marker behind this read's copies (closing the file waits for it)
+      std::lock_guard<std::mutex> l(f->copy_mu);
+      if (!f->last_copy) HIP_CHECK(hipEventCreateWithFlags(&f->last_copy, hipEventDisableTiming));
+      HIP_CHECK(hipEventRecord(f->last_copy, ctx->copy_stream));
     }
     drain.armed = false;                       // every copy is ordered before a kernel of `stream` from here on
     // the staged / decompressed bytes (reads[].keep) outlive the kernels: frees are stream ordered through the caching allocator

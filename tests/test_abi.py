@@ -75,3 +75,34 @@ def test_headers_are_plain_c_and_bind_from_a_c_program(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "jit selftest 0" in out.stdout
+
+
+def _null_probe(extra=()):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "null_probe.py"), *extra], capture_output=True, text=True, timeout=600)
+    lines = [l.split() for l in r.stdout.splitlines() if l.strip()]
+    assert r.returncode == 0, "crashed inside %s (exit %d)\n%s" % (lines[-1][0] if lines else "?", r.returncode, r.stderr[-1500:])
+    return lines
+
+
+def test_every_entry_point_refuses_null_handles():
+    """A C-ABI entry point handed NULL for its handles answers DFGPU_INVALID_ARGUMENT; it never dereferences them (round 3 found dfgpu_array_slice crashing the
+    host process that way).  Every function include/*.h declares is called with NULL pointers and zero scalars, in a child process, without a device."""
+    lines = _null_probe()
+    assert len(lines) >= 150
+    for name, kind, value in lines:
+        if kind == "status" and name != "dfgpu_jit_selftest":           # takes no handle: NULL arch / log are its defaults
+            assert value == "5", f"{name}(NULL, ...) returned status {value}, expected DFGPU_INVALID_ARGUMENT"
+
+
+@pytest.mark.gpu
+def test_every_entry_point_refuses_null_handles_beside_a_live_context():
+    """The same with a real context wherever a dfgpu_ctx* is taken: every other handle NULL.  No crash; an error status except where NULL is a documented
+    argument (clearing the row selection, synchronising, reading options ...)."""
+    lines = _null_probe(["--ctx"])
+    ok_with_null = {"dfgpu_jit_selftest", "dfgpu_ctx_synchronize", "dfgpu_ctx_set_row_selection", "dfgpu_profile_enable", "dfgpu_profile_select", "dfgpu_ctx_trim"}
+    for name, kind, value in lines:
+        if kind == "status" and name not in ok_with_null:
+            assert value != "0", f"{name}(ctx, NULL, ...) returned DFGPU_OK"

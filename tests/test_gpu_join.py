@@ -424,3 +424,58 @@ def test_deferred_probe_and_lookup_at_the_abi(ctx, shape):
     assert np.array_equal(table.lookup(probe, rows).to_numpy(), bi.to_numpy()[sub])                # a subset, in the subset's order
     with pytest.raises(dfgpu.DfgpuError):
         dfgpu.JoinTable(ctx, [ctx.from_arrow(pa.array(["a", "b"]))]).lookup([ctx.from_arrow(pa.array(["a"]))])      # a table that cannot locate a row from the key alone
+
+
+def test_lookup_keeps_the_nulls_of_its_row_list(ctx):
+    """dfgpu_join_lookup over a `rows` array with NULL entries (the NULL side of an outer join's indices above a deferred Inner join): the answer is NULL there and
+    the build row everywhere else; a NULL entry's value (anything, even beyond the probe column) is never used as a row."""
+    import dfgpu
+    rng = np.random.default_rng(11)
+    nb, npr = 20_000, 70_000
+    b = np.arange(nb, dtype=np.int64) * 2 + 10
+    p = b[rng.integers(0, nb, npr)]
+    table = dfgpu.JoinTable(ctx, [ctx.from_arrow(pa.array(b))])
+    probe = [ctx.from_arrow(pa.array(p))]
+    bi, pi = table.probe(probe)
+    dbi, dpi = table.probe_deferred(probe)
+    assert dbi is None
+    want = bi.to_numpy()
+    pick = rng.integers(0, npr, 5000)
+    null = rng.random(5000) < 0.3
+    vals = pick.astype(np.uint32)
+    vals[null] = 0xFFFFFFF0                                   # garbage under the NULLs
+    got = table.lookup(probe, ctx.from_arrow(pa.array(vals, mask=null))).to_arrow()
+    assert got.null_count == int(null.sum())
+    assert got.to_pylist() == [None if nl else int(want[r]) for r, nl in zip(pick, null)]
+
+
+@pytest.mark.parametrize("jt", ["Inner", "Right", "Left"])
+def test_chunked_probe_reads_back_once_per_probe_batch(ctx, jt):
+    """A reference-sized probe batch whose rows each match many build rows comes out in `batch_size`-pair chunks (process_probe_batch, hash_join.rs:1238-1343); the
+    probe row each chunk ends on is read back once for the whole probe batch (the reference resumes from an in-memory offset, :1332-1340), not once per chunk.
+    Pairs, their order and the batch boundaries equal the oracle's at the same batch_size."""
+    from dfgpu import physical_plan as ops
+    rng = np.random.default_rng(21)
+    nkeys, per, npr, bsz = 40, 150, 6000, 1024
+    bk = np.repeat(np.arange(nkeys, dtype=np.int64), per); rng.shuffle(bk)
+    pk = rng.integers(0, nkeys + 8, npr).astype(np.int64)                     # a few probe keys without a match
+    lb = ops.batch_from_arrow(ctx, pa.table({"k": pa.array(bk), "b": pa.array(np.arange(len(bk), dtype=np.int64))}))
+    rb = ops.batch_from_arrow(ctx, pa.table({"k": pa.array(pk), "p": pa.array(np.arange(npr, dtype=np.int64))}))
+    tc = ops.TaskContext(ctx, batch_size=bsz)
+    join = ops.HashJoinExec(ops.MemoryExec([[lb]], lb.schema), ops.MemoryExec([[rb]], rb.schema), [(ops.Column("k", 0), ops.Column("k", 0))], None, jt, "CollectLeft")
+    ctx.profile_select(None); ctx.profile_enable(True); ctx.profile_read()
+    try:
+        out = [b for b in join.execute(0, tc)]
+        ctx.synchronize()
+        prof = ctx.profile_read()
+    finally:
+        ctx.profile_enable(False)
+    want = po.hash_join([[pa.array(bk)]], [[pa.array(pk)]], jt, False, batch_size=bsz)
+    got_b = np.concatenate([np.asarray(b.columns[1].to_arrow().fill_null(-1)) for b in out])
+    got_p = np.concatenate([np.asarray(b.columns[3].to_arrow().fill_null(-1)) for b in out])
+    assert np.array_equal(got_b, want.build_idx) and np.array_equal(got_p, want.probe_idx)
+    assert [b.num_rows for b in out] == np.diff(want.batch_offsets).tolist()    # the reference's batch boundaries
+    pairs = int((pk < nkeys).sum()) * per
+    assert len(out) >= pairs // bsz                                            # hundreds of chunks ...
+    syncs = sum(v[0] for k, v in prof.items() if k.startswith("sync:"))
+    assert syncs <= 12, (syncs, {k: v[0] for k, v in prof.items() if k.startswith("sync:")})       # ... and a handful of read-backs (build, probe, the chunk ends), not one per chunk

@@ -81,6 +81,30 @@ def _worker(rank, world, port, q, scenario):
                 except capi.DfgpuError as e:
                     out["first"] = str(e)
             out["got"] = run()
+        elif scenario in ("column_count_mismatch", "memory_limit_on_one_rank"):
+            try:
+                if rank == 1 and scenario == "column_count_mismatch":          # one rank hands over one column fewer: the metadata round still has one length everywhere
+                    comm.exchange([arrays[0]], arrays[:-1], t.num_columns - 1)
+                elif scenario == "memory_limit_on_one_rank":
+                    # a per-ctx option that differs between ranks: only rank 1 runs under a limit, raised round by round, so that its allocation failure moves from
+                    # the partition pass (status word of the first round) through the receive buffers (second status round) to none at all
+                    base, rounds = ctx.get_option("live_bytes"), []
+                    for k in range(48):
+                        if rank == 1:
+                            ctx.set_option("memory_limit", base + 4096 + k * 16384)
+                        try:
+                            run(); rounds.append("ok")
+                        except capi.DfgpuError as e:
+                            rounds.append(str(e))
+                        finally:
+                            ctx.set_option("memory_limit", 0)
+                    out["rounds"] = rounds
+                else:
+                    run()
+                out["first"] = "no error"
+            except capi.DfgpuError as e:
+                out["first"] = str(e)
+            out["got"] = run()
         q.put((rank, out))
         dist.barrier()
         dist.destroy_process_group()
@@ -93,7 +117,7 @@ def _launch(world, scenario):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 28100 + (os.getpid() % 800) + world + {"lanes": 0, "transport_error": 10, "rank_fails_alone": 20}[scenario]
+    port = 28100 + (os.getpid() % 800) + world + {"lanes": 0, "transport_error": 10, "rank_fails_alone": 20, "column_count_mismatch": 30, "memory_limit_on_one_rank": 40}[scenario]
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, scenario)) for r in range(world)]
     for p in procs:
         p.start()
@@ -139,4 +163,30 @@ def test_a_rank_that_fails_alone_fails_every_rank_and_nothing_hangs():
     assert "differs in length" in res[1]["first"], res[1]["first"]
     for r in (0, 2):
         assert "rank 1 failed before the collective" in res[r]["first"], res[r]["first"]
+    _check_exchange(res, 3)
+
+
+def test_a_rank_with_another_column_count_fails_every_rank():
+    """The metadata all-gather is sized by the column limit, not by the local column count, so ranks that were handed different counts still run one
+    well-formed collective, read the same matrix and fail together."""
+    res = _launch(3, "column_count_mismatch")
+    for r in range(3):
+        assert "columns" in res[r]["first"] and "no error" not in res[r]["first"], res[r]["first"]
+    _check_exchange(res, 3)
+
+
+def test_a_memory_limit_on_one_rank_fails_every_rank():
+    """One rank runs under a memory limit its peers do not have; the limit is raised round by round so the rank fails first in its partition pass, then while
+    allocating its receive buffers, then not at all.  In every round either every rank gets an error or none does (the status rounds do not depend on a
+    per-ctx option), nobody waits in the data collective, and the communicator works afterwards."""
+    res = _launch(3, "memory_limit_on_one_rank")
+    rounds = [res[r]["rounds"] for r in range(3)]
+    assert len(rounds[0]) == len(rounds[1]) == len(rounds[2]) == 48
+    for k in range(48):
+        oks = [rounds[r][k] == "ok" for r in range(3)]
+        assert all(oks) or not any(oks), (k, [rounds[r][k] for r in range(3)])
+        if not oks[0]:
+            assert "rank 1" in rounds[0][k] and "rank 1" in rounds[2][k], rounds[0][k]
+    assert rounds[0][0] != "ok" and rounds[0][-1] == "ok"
+    assert any("could not allocate its receive buffers" in x for x in rounds[0]), "the sweep never failed inside the receive-buffer allocation: " + repr(sorted(set(rounds[0])))
     _check_exchange(res, 3)

@@ -398,3 +398,45 @@ def test_inner_join_looks_build_rows_up_when_a_build_column_is_read(ctx, task_ct
         assert "k_probe_lookup_rank" not in prof                               # nobody ever asks for a build row
     else:
         assert "k_probe_lookup_rank" in prof
+
+
+@pytest.mark.parametrize("above", ["hash_right", "hash_full", "smj_left", "smj_full"])
+def test_lazy_build_columns_through_a_nullable_index(ctx, task_ctx, above):
+    """A deferred Inner HashJoinExec output (build rows not looked up yet) that becomes the NULL-able side of an outer join above it: the outer join takes the lazy
+    columns through indices with a validity buffer, and the unmatched rows must come out NULL in them -- the lookup has to keep the index array's NULLs.
+    Rows equal the eager path's (join_lazy_build_rows = 0) and pyarrow's joins."""
+    from dfgpu import physical_plan as ops
+    rng = np.random.default_rng(5)
+    nb, npr, nx = 20_000, 60_000, 30_000
+    bk = np.arange(nb, dtype=np.int64) * 3 + 7
+    build = pa.table({"k": pa.array(bk), "pay": pa.array(rng.integers(0, 10**6, nb)), "s": pa.array([f"b{i % 97}" for i in range(nb)])})
+    pk = np.sort(bk[rng.integers(0, nb, npr)])                                   # every probe row matches: the lookup is left for later
+    probe = pa.table({"pk": pa.array(pk), "v": pa.array(np.arange(npr, dtype=np.int64))})
+    xk = np.sort(rng.integers(0, 3 * nb + 200, nx).astype(np.int64))             # about a third of these find a pk
+    x = pa.table({"xk": pa.array(xk), "w": pa.array(rng.integers(0, 99, nx))})
+    mk = lambda t: (lambda b: ops.MemoryExec([[b]], b.schema))(ops.batch_from_arrow(ctx, t))
+    C = ops.Column
+
+    def run():
+        j1 = ops.HashJoinExec(mk(build), mk(probe), [(C("k", 0), C("pk", 0))], None, "Inner", "CollectLeft")          # k, pay, s, pk, v
+        if above.startswith("hash"):
+            plan = ops.HashJoinExec(j1, mk(x), [(C("pk", 3), C("xk", 0))], None, "Right" if above == "hash_right" else "Full", "CollectLeft")
+        else:
+            plan = ops.SortMergeJoinExec(mk(x), j1, [(C("xk", 0), C("pk", 3))], "Left" if above == "smj_left" else "Full")
+        return pa.concat_tables([b.to_arrow() for b in plan.execute(0, task_ctx)])
+
+    lazy = run()
+    ctx.set_option("join_lazy_build_rows", 0)
+    try:
+        eager = run()
+    finally:
+        ctx.set_option("join_lazy_build_rows", 1)
+    assert lazy.equals(eager)
+    j1_arrow = probe.join(build, keys="pk", right_keys="k", join_type="inner", coalesce_keys=False)
+    want = x.join(j1_arrow, keys="xk", right_keys="pk", join_type="left outer" if above in ("hash_right", "smj_left") else "full outer", coalesce_keys=False)
+    cols = ["xk", "w", "pk", "v", "k", "pay", "s"]
+    key = lambda r: tuple((v is None, v) for v in r)
+    rows = lambda t: sorted(zip(*[t[c].to_pylist() for c in cols]), key=key)
+    assert lazy.num_rows == want.num_rows and rows(lazy) == rows(want)
+    unmatched = ~np.isin(xk, pk)
+    assert unmatched.any() and lazy["pay"].null_count == int(unmatched.sum()) == lazy["s"].null_count == lazy["k"].null_count
