@@ -165,6 +165,7 @@ def parse_args():
                     help="N = 1: which plan shapes of bench_workloads.py to nest under \"workloads\"")
     ap.add_argument("--collective-deadline", type=float, default=180.0, help="N > 1: seconds without progress (no exchange started, no step finished) after which a rank reports where it stands and exits with code 3 instead of hanging the job")
     ap.add_argument("--native-exchange", action="store_true", help="N > 1 workloads: ShuffleExec through the C entry point dfgpu_exchange (RCCL inside libdfgpu.so) instead of torch.distributed collectives")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="ctx option set before the run (dfgpu_ctx_set_option), e.g. --option mailbox_readback=0 for an A/B run")
     ap.add_argument("--launch-check", action="store_true", help="only rendezvous the ranks (gloo, CPU) and report ranks_seen: rehearses the launcher without a GPU")
     ap.add_argument("--detail", default="", help="where the full result object goes (default: bench_detail.json next to bench.py); it is also written to stderr")
     ap.add_argument("--plan", choices=["colocated", "broadcast", "shuffle"], default="shuffle",
@@ -252,6 +253,8 @@ def main():
 
     # one ctx on torch's current stream: dfgpu kernels, torch ops and RCCL collectives are stream ordered
     ctx = dfgpu.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    for kv in args.option:
+        k_, v_ = kv.split("=", 1); ctx.set_option(k_, int(v_))
     tc = ops.TaskContext(ctx, batch_size=8192)
     tensors = tpch.gen_device_tensors(args.sf, rank=rank, world=world)
     tables = tpch.tables_from_torch(ctx, tensors)

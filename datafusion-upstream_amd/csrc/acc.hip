@@ -1055,7 +1055,7 @@ dfgpu_status dfgpu_acc_evaluate(dfgpu_ctx* ctx, dfgpu_acc* a, dfgpu_array** out)
              hipLaunchKernelGGL(k_avg_dec, grid, block, 0, ctx->stream, (const uint64_t*)a->vals->ptr, (const uint64_t*)a->counts->ptr, (const uint8_t*)a->seen->ptr, a->n, factor, a->out_precision, (uint64_t*)h.get()->values->ptr, ctx->d_flags); }
       hipLaunchKernelGGL(k_seen_to_bits, grid, block, 0, ctx->stream, (const uint8_t*)a->seen->ptr, a->n, (uint64_t*)h.get()->validity->ptr);
       KERNEL_CHECK();
-      uint32_t f = 0; HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 63, ctx->d_flags, 4, hipMemcpyDeviceToHost, ctx->stream)); HIP_CHECK(hipStreamSynchronize(ctx->stream)); f = *(uint32_t*)(ctx->h_pinned + 63);
+      uint32_t f = 0; fetch_to_pinned(ctx, 63, ctx->d_flags, 4); f = *(uint32_t*)(ctx->h_pinned + 63);
       if (f) { HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, 4, ctx->stream)); fail(DFGPU_EXECUTION, "Arithmetic Overflow in AvgAccumulator"); }
     }
     h.get()->null_count = -1;

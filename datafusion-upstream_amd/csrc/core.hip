@@ -101,8 +101,7 @@ void check_flags(dfgpu_ctx* ctx, const char* what) {
   if (ctx->defer_flag_checks > 0) { if (!ctx->flags_pending) ctx->flags_what = what; else if (ctx->flags_what.find(what) == std::string::npos) ctx->flags_what += std::string(", ") + what; ctx->flags_pending = true; return; }
   uint32_t f = 0;
   ctx->count_sync((std::string("sync:flags:") + what).c_str());
-  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 63, ctx->d_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  fetch_to_pinned(ctx, 63, ctx->d_flags, 4);
   f = *(uint32_t*)(ctx->h_pinned + 63);
   if (!f) return;
   HIP_CHECK(hipMemsetAsync(ctx->d_flags, 0, 4, ctx->stream));
@@ -112,19 +111,57 @@ void check_flags(dfgpu_ctx* ctx, const char* what) {
   if (f & DFGPU_FLAG_OOB) fail(DFGPU_EXECUTION, "Arrow error: index out of bounds (%s)", what);
   fail(DFGPU_INTERNAL, "kernel raised flag %u (%s)", f, what);
 }
+__global__ void __launch_bounds__(512) k_post_words(const uint32_t* src, int nwords, uint32_t* h_dst, unsigned long long* h_seq, unsigned long long seq) {
+  const int i = threadIdx.x;
+  if (i < nwords) __hip_atomic_store(h_dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __syncthreads();
+  if (i == 0) __hip_atomic_store(h_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void fetch_to_pinned(dfgpu_ctx* ctx, int h_word, const void* d_src, size_t bytes) {
+  if (bytes == 0 || (bytes & 3) || h_word < 0 || (size_t)h_word * 8 + bytes > (size_t)dfgpu_ctx::MAIL_WORDS * 8) fail(DFGPU_INTERNAL, "fetch_to_pinned: %zu bytes at word %d", bytes, h_word);
+  if (!ctx->mailbox_readback) {
+    HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + h_word, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return;
+  }
+  const unsigned long long seq = ++ctx->mail_seq;
+  unsigned long long* h_seq = (unsigned long long*)(ctx->h_pinned + dfgpu_ctx::MAIL_SEQ);
+  hipLaunchKernelGGL(k_post_words, dim3(1), dim3(bytes <= 512 ? 128 : 512), 0, ctx->stream, (const uint32_t*)d_src, (int)(bytes / 4), (uint32_t*)(ctx->h_pinned + h_word), h_seq, seq);
+  KERNEL_CHECK();
+  // poll; every few thousand spins ask the stream: an error there must not leave the host spinning, and a drained stream means the words are in memory
+  for (uint64_t spins = 1; __atomic_load_n(h_seq, __ATOMIC_ACQUIRE) < seq; spins++) {
+    if ((spins & 0xFFF) == 0) {
+      hipError_t q = hipStreamQuery(ctx->stream);
+      if (q == hipSuccess) { HIP_CHECK(hipStreamSynchronize(ctx->stream)); break; }
+      if (q != hipErrorNotReady) HIP_CHECK(q);
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+void fetch_to_host(dfgpu_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
+  if (!bytes) return;
+  if (ctx->mailbox_readback && bytes <= (size_t)dfgpu_ctx::MAIL_WORDS * 8 && !(bytes & 3)) { fetch_to_pinned(ctx, 0, d_src, bytes); memcpy(dst, ctx->h_pinned, bytes); return; }
+  HIP_CHECK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+}
 uint64_t read_scratch(dfgpu_ctx* ctx, int slot) {
   ctx->count_sync((std::string("sync:count") + std::to_string(slot)).c_str());
-  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + slot, ctx->d_scratch64 + slot, 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  fetch_to_pinned(ctx, slot, ctx->d_scratch64 + slot, 8);
   return ctx->h_pinned[slot];
 }
-// several consecutive slots with ONE copy and one wait; returns a pointer to the pinned copies (valid until the next read-back)
+// several consecutive slots with ONE read-back; returns a pointer to the pinned copies (valid until the next read-back)
 const uint64_t* read_scratch_range(dfgpu_ctx* ctx, int first, int count) {
   ctx->count_sync((std::string("sync:count") + std::to_string(first) + ".." + std::to_string(first + count - 1)).c_str());
-  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + first, ctx->d_scratch64 + first, (size_t)count * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  fetch_to_pinned(ctx, first, ctx->d_scratch64 + first, (size_t)count * 8);
   return ctx->h_pinned + first;
 }
+static std::mutex g_stats_mu;
+std::shared_ptr<const OrderStats> order_stats_get(const dfgpu_array* a) { std::lock_guard<std::mutex> l(g_stats_mu); return a->order_stats; }
+void order_stats_set(const dfgpu_array* a, const OrderStats& st) { auto p = std::make_shared<const OrderStats>(st); std::lock_guard<std::mutex> l(g_stats_mu); const_cast<dfgpu_array*>(a)->order_stats = p; }
 void zero_scratch(dfgpu_ctx* ctx) { HIP_CHECK(hipMemsetAsync(ctx->d_scratch64, 0, 64 * 8, ctx->stream)); }
 
 ColView make_view(const dfgpu_array* a) {
@@ -323,7 +360,7 @@ dfgpu_status dfgpu_ctx_create(int32_t device_id, void* stream, dfgpu_ctx** out) 
     c->alloc_mu = new std::mutex(); c->free_blocks = new std::vector<std::pair<size_t, void*>>();
     HIP_CHECK(hipMalloc((void**)&c->d_flags, 256)); HIP_CHECK(hipMemset(c->d_flags, 0, 256));
     HIP_CHECK(hipMalloc((void**)&c->d_scratch64, 64 * 8)); HIP_CHECK(hipMemset(c->d_scratch64, 0, 64 * 8));
-    HIP_CHECK(hipHostMalloc((void**)&c->h_pinned, 64 * 8, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void**)&c->h_pinned, dfgpu_ctx::PINNED_WORDS * 8, hipHostMallocCoherent | hipHostMallocMapped)); memset(c->h_pinned, 0, dfgpu_ctx::PINNED_WORDS * 8);
   });
   if (st != DFGPU_OK) { fprintf(stderr, "dfgpu_ctx_create: %s\n", c->err.c_str()); delete c; return st; }
   { std::lock_guard<std::mutex> l(g_mu); g_ctx.emplace_back(c, new CtxRefs()); }
@@ -349,6 +386,7 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "fused_aggregate_min_rows") ctx->fused_aggregate_min_rows = value;
     else if (k == "sort_packed_keys") ctx->sort_packed_keys = value != 0;
     else if (k == "memory_limit") ctx->memory_limit = value;
+    else if (k == "mailbox_readback") ctx->mailbox_readback = value != 0;
     else if (k == "trim_cache") {        // give the freed blocks the ctx keeps for reuse back to the driver (≙ MemoryPool::shrink): after the stream has drained, so no kernel still reads them
       HIP_CHECK(hipStreamSynchronize(ctx->stream));
       std::lock_guard<std::mutex> l(*ctx->alloc_mu); for (auto& x : *ctx->free_blocks) (void)hipFree(x.second); ctx->free_blocks->clear(); ctx->cached_bytes = 0;
@@ -395,6 +433,7 @@ dfgpu_status dfgpu_ctx_get_option(dfgpu_ctx* ctx, const char* key, int64_t* out)
     else if (k == "fused_aggregate_min_rows") *out = ctx->fused_aggregate_min_rows;
     else if (k == "sort_packed_keys") *out = ctx->sort_packed_keys;
     else if (k == "memory_limit") *out = ctx->memory_limit;
+    else if (k == "mailbox_readback") *out = ctx->mailbox_readback ? 1 : 0;
     else if (k == "agg_spill_state_bytes") *out = ctx->agg_spill_state_bytes;
     else if (k == "sort_estimate_ranges") *out = ctx->sort_estimate_ranges ? 1 : 0;
     else if (k == "sort_packed_min_rows") *out = ctx->sort_packed_min_rows;

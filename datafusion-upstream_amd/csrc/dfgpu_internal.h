@@ -69,7 +69,12 @@ struct dfgpu_ctx {
   int defer_flag_checks = 0; bool flags_pending = false; std::string flags_what;
   uint32_t* d_flags = nullptr;      // device word for kernel error flags
   uint64_t* d_scratch64 = nullptr;  // 64 x u64 device scratch for counters / totals
-  uint64_t* h_pinned = nullptr;     // 64 x u64 pinned host mirror
+  uint64_t* h_pinned = nullptr;     // 64 x u64 pinned host mirror (+ the mailbox's sequence word, a cache line of its own, at [MAIL_SEQ])
+  // Host read-backs: a one-workgroup kernel posts the words to the pinned mirror and then a sequence number (system-scope release); the host polls the
+  // sequence word.  The answer arrives a microsecond or two after the producing kernel retires -- no blit dispatch, no completion-signal wake-up of a stream
+  // synchronisation (~20 us of idle device per read-back in the SF12.5 trace, profiles/r04_a_gaps_q3_sf12.5.txt).  Option "mailbox_readback" = 0: copy + hipStreamSynchronize.
+  static constexpr int MAIL_SEQ = 384, MAIL_WORDS = 256, PINNED_WORDS = 512;       // words [0, 64): the scratch mirror; [0, MAIL_WORDS): the landing area of fetch_to_host
+  bool mailbox_readback = true; uint64_t mail_seq = 0;
   int num_cus = 256;
   // optional per-kernel timing with HIP events on ctx->stream (bench.py roofline leg)
   // stream-ordered caching allocator: freed blocks are reused by later work on the same stream without going
@@ -108,7 +113,12 @@ BufferPtr borrow_buffer(const void* ptr, size_t bytes);
 
 }  // namespace dfgpu
 
-namespace dfgpu { struct DeferredIds; }
+namespace dfgpu { struct DeferredIds;
+// Order statistics of an integer column without NULLs (arrays are immutable, so they are a memo like null_count): known once a pass has looked (k_check_increasing), or derived --
+// a gather of a sorted column through strictly ascending indices is sorted and lies inside the source's bounds (exact = false: lo / hi bound the values, not necessarily tight).
+// The join build's rank index asks for them; a base-table key column answers from the memo, its filtered / joined descendants from the derivation.
+struct OrderStats { bool sorted = false, repeats = false, exact = false; int64_t lo = 0, hi = 0; };
+}
 struct dfgpu_array {
   std::atomic<int64_t> refs{1};
   dfgpu_ctx* ctx = nullptr;
@@ -127,6 +137,7 @@ struct dfgpu_array {
   // an index array known to be 0, 1, .., length - 1 (a compaction that kept every row, the probe indices of a join whose probe rows
   // all matched once): gathering through it is the identity
   bool identity = false;
+  std::shared_ptr<const dfgpu::OrderStats> order_stats;      // read / written through order_stats_get / order_stats_set (a lock: plan partitions share arrays)
 };
 
 namespace dfgpu {
@@ -165,6 +176,14 @@ void flush_flags(dfgpu_ctx* ctx);                          // the deferred check
 uint64_t read_scratch(dfgpu_ctx* ctx, int slot);          // sync + D2H of d_scratch64[slot]
 const uint64_t* read_scratch_range(dfgpu_ctx* ctx, int first, int count);      // the same for `count` consecutive slots: one copy, one wait
 void zero_scratch(dfgpu_ctx* ctx);
+std::shared_ptr<const OrderStats> order_stats_get(const dfgpu_array* a);
+void order_stats_set(const dfgpu_array* a, const OrderStats& st);
+std::shared_ptr<const OrderStats> order_stats_measure(dfgpu_ctx* ctx, const dfgpu_array* a);      // join.hip: one streaming pass + one read-back; nullptr for columns that are not plain integers without NULLs
+void order_stats_through_take(dfgpu_ctx* ctx, const dfgpu_array* values, const dfgpu_array* indices, dfgpu_array* out);      // select.hip
+// `bytes` (a multiple of 4, <= 512) of device memory to ctx->h_pinned + h_word (64-bit words), then wait until they are there: the one way the host reads a device word back
+void fetch_to_pinned(dfgpu_ctx* ctx, int h_word, const void* d_src, size_t bytes);
+// `bytes` of device memory into host memory `dst`, waited for: through the mailbox up to 2 KB (a multiple of 4), by copy + stream synchronisation beyond
+void fetch_to_host(dfgpu_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 
 // Device view of a column passed to kernels by value.
 struct ColView {
@@ -224,8 +243,8 @@ struct KernelTimer {
 };
 
 template <typename F>
-dfgpu_status guard(dfgpu_ctx* ctx, F&& f) {
-  if (!ctx) return DFGPU_INVALID_ARGUMENT;          // every entry point that takes a ctx: a NULL handle is an argument error, never a crash of the host process
+dfgpu_status guard(dfgpu_ctx* ctx, F&& f, bool ctx_optional = false) {
+  if (!ctx && !ctx_optional) return DFGPU_INVALID_ARGUMENT;          // every entry point that needs its ctx: a NULL handle is an argument error, never a crash of the host process
   try { f(); return DFGPU_OK; }
   catch (const Error& e) { if (ctx) ctx->err = e.msg; return e.code; }
   catch (const std::bad_alloc&) { if (ctx) ctx->err = "host allocation failed"; return DFGPU_RESOURCES_EXHAUSTED; }

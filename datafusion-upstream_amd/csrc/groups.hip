@@ -603,9 +603,7 @@ static dfgpu_status groups_intern_impl(dfgpu_ctx* ctx, dfgpu_groups* g, const df
 #undef PFIND
         }
         KERNEL_CHECK();
-        HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 0, ctx->d_scratch64, 32, hipMemcpyDeviceToHost, ctx->stream));
-        ctx->count_sync("sync:group_table");
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->count_sync("sync:group_table"); fetch_to_pinned(ctx, 0, ctx->d_scratch64, 32);
         if (ctx->h_pinned[3]) { banned = true; break; }
         if (ctx->h_pinned[1] == 0) break;
         if (g->pcap >= (1ull << 31)) fail(DFGPU_RESOURCES_EXHAUSTED, "group table would exceed 2^31 slots");
@@ -715,9 +713,7 @@ static dfgpu_status groups_intern_impl(dfgpu_ctx* ctx, dfgpu_groups* g, const df
         else hipLaunchKernelGGL(k_dense_first, dim3(fgrid), block, 0, ctx->stream, dc, n, mk, (const uint32_t*)g->dense_map->ptr, (uint32_t*)first->ptr, (int)dsize);
         KERNEL_CHECK();
         std::vector<uint32_t> fh((size_t)dsize);
-        HIP_CHECK(hipMemcpyAsync(fh.data(), first->ptr, (size_t)dsize * 4, hipMemcpyDeviceToHost, ctx->stream));
-        ctx->count_sync("sync:dense_groups");
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->count_sync("sync:dense_groups"); fetch_to_host(ctx, fh.data(), first->ptr, (size_t)dsize * 4);
         std::vector<std::pair<uint32_t, uint32_t>> fresh;             // (first row, composite) of the composites met for the first time
         for (int64_t comp = 0; comp < dsize; comp++) if (fh[(size_t)comp] != G_NONE) fresh.emplace_back(fh[(size_t)comp], (uint32_t)comp);
         std::sort(fresh.begin(), fresh.end());                        // first-seen order

@@ -484,8 +484,7 @@ static void build_hash_table(dfgpu_ctx* ctx, dfgpu_join_table* t, bool with_bitm
     DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_minmax<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 2)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, rs, n,
                                                           (long long*)(ctx->d_scratch64 + 4), (long long*)(ctx->d_scratch64 + 5)));
     KERNEL_CHECK();
-    HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 4, ctx->d_scratch64 + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    fetch_to_pinned(ctx, 4, ctx->d_scratch64 + 4, 16);
     long long lo = (long long)ctx->h_pinned[4], hi = (long long)ctx->h_pinned[5];
     if (lo <= hi) {
       uint64_t range = (uint64_t)hi - (uint64_t)lo + 1;
@@ -517,6 +516,17 @@ static void build_hash_table(dfgpu_ctx* ctx, dfgpu_join_table* t, bool with_bitm
   }
 }
 
+std::shared_ptr<const OrderStats> order_stats_measure(dfgpu_ctx* ctx, const dfgpu_array* a) {
+  if (!a || a->type == DFGPU_DICTIONARY || !int_key_type(a->type) || a->validity || a->length < 1) return nullptr;
+  const int64_t n = a->length; const void* kv = a->values->ptr;
+  zero_scratch(ctx);
+  DFGPU_INT_KEY_DISPATCH(a->type, hipLaunchKernelGGL((k_check_increasing<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 8)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, n, (unsigned long long*)ctx->d_scratch64));
+  KERNEL_CHECK();
+  ctx->count_sync("sync:rank_index_check"); fetch_to_pinned(ctx, 0, ctx->d_scratch64, 32);
+  OrderStats st; st.sorted = ctx->h_pinned[0] == 0; st.repeats = ctx->h_pinned[3] != 0; st.exact = true; st.lo = (int64_t)ctx->h_pinned[1]; st.hi = (int64_t)ctx->h_pinned[2];       // sign/zero-extended by the kernel
+  order_stats_set(a, st);
+  return order_stats_get(a);
+}
 // Rank index: taken when the single integer key column is strictly increasing (checked on the device, one streaming pass)
 // and its domain is dense enough for a bitmap.  Returns false (nothing built) otherwise.
 static bool build_rank_index(dfgpu_ctx* ctx, dfgpu_join_table* t) {
@@ -526,18 +536,18 @@ static bool build_rank_index(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   if (key0->type == DFGPU_DICTIONARY || !int_key_type(key0->type) || key0->validity) return false;
   const void* kv = key0->values->ptr;
   KernelTimer kt_(ctx, "join_build_rank");
-  zero_scratch(ctx);
-  DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_check_increasing<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 8)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, n, (unsigned long long*)ctx->d_scratch64));
-  KERNEL_CHECK();
-  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 0, ctx->d_scratch64, 32, hipMemcpyDeviceToHost, ctx->stream));
-  ctx->count_sync("sync:rank_index_check");
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  if (ctx->h_pinned[0] != 0) return false;
-  const bool runs = ctx->h_pinned[3] != 0;                 // sorted with repeats
+  // the column's order statistics: its memo (a base-table key column after its first build), a derivation (a sorted column gathered through ascending row numbers: bounds
+  // of the source, which may be wide), or the pass itself
+  auto st = order_stats_get(key0);
+  if (!st) st = order_stats_measure(ctx, key0);
+  auto dense = [&](const OrderStats& s2) { const uint64_t r = (uint64_t)s2.hi - (uint64_t)s2.lo + 1; return r != 0 && r <= (1ull << 32) && r <= (uint64_t)n * 4096 + 65536; };
+  if (st && st->sorted && !st->exact && !dense(*st)) st = order_stats_measure(ctx, key0);      // the inherited bounds are too wide for a bitmap: the exact ones may not be
+  if (!st || !st->sorted) return false;
+  const bool runs = st->repeats;                           // sorted with repeats (an inherited "repeats" may overstate: the run path answers unique keys too)
   if (runs && (t->build_mask || n > 0xFFFFFFF0ll)) return false;
-  long long lo = (long long)ctx->h_pinned[1], hi = (long long)ctx->h_pinned[2];       // sign/zero-extended by the kernel
+  long long lo = (long long)st->lo, hi = (long long)st->hi;
   uint64_t range = (uint64_t)hi - (uint64_t)lo + 1;
-  if (range == 0 || range > (1ull << 32) || range > (uint64_t)n * 4096 + 65536) return false;
+  if (!dense(*st)) return false;
   const uint64_t* mk = t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr;
   int64_t nw = (int64_t)((range + 63) / 64);
   t->key_min = lo; t->range = range;
@@ -598,9 +608,7 @@ static bool build_rank_index_unsorted(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_minmax_masked<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 4)), dim3(BLOCK), 0, ctx->stream, (const T*)key0->values->ptr,
                                                         (const uint64_t*)nullptr, mk, n, (long long*)(ctx->d_scratch64 + 4), (long long*)(ctx->d_scratch64 + 5)));
   KERNEL_CHECK();
-  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 4, ctx->d_scratch64 + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
-  ctx->count_sync("sync:rank_index_range");
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->count_sync("sync:rank_index_range"); fetch_to_pinned(ctx, 4, ctx->d_scratch64 + 4, 16);
   const long long lo = (long long)ctx->h_pinned[4], hi = (long long)ctx->h_pinned[5];
   t->have_minmax = true; t->sel_min = lo; t->sel_max = hi;
   if (lo > hi) return false;                               // no selected row
@@ -646,9 +654,7 @@ static bool pj_domain_is_sparse(dfgpu_ctx* ctx, dfgpu_join_table* t) {
                                                         key0->validity ? (const uint64_t*)key0->validity->ptr : nullptr, t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr, n,
                                                         (long long*)(ctx->d_scratch64 + 4), (long long*)(ctx->d_scratch64 + 5)));
   KERNEL_CHECK();
-  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 4, ctx->d_scratch64 + 4, 16, hipMemcpyDeviceToHost, ctx->stream));
-  ctx->count_sync("sync:pj_key_range");
-  HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  ctx->count_sync("sync:pj_key_range"); fetch_to_pinned(ctx, 4, ctx->d_scratch64 + 4, 16);
   long long lo = (long long)ctx->h_pinned[4], hi = (long long)ctx->h_pinned[5];
   if (lo > hi) return false;
   uint64_t range = (uint64_t)hi - (uint64_t)lo + 1;
@@ -684,9 +690,7 @@ dfgpu_status dfgpu_join_build(dfgpu_ctx* ctx, const dfgpu_array* const* keys, in
       PackCols pc = pack_cols(t.get(), keys);
       hipLaunchKernelGGL(k_cols_minmax, dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 4)), dim3(BLOCK), 0, ctx->stream, pc, n, (long long*)(ctx->d_scratch64 + 16));
       KERNEL_CHECK();
-      HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 16, ctx->d_scratch64 + 16, init.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-      ctx->count_sync("sync:key_packing_ranges");
-      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      ctx->count_sync("sync:key_packing_ranges"); fetch_to_pinned(ctx, 16, ctx->d_scratch64 + 16, init.size() * 8);
       unsigned __int128 prod = 1; bool any_valid = true, nullable = false;
       for (int c = nkeys - 1; c >= 0; c--) {
         long long lo = (long long)ctx->h_pinned[16 + 2 * c], hi = (long long)ctx->h_pinned[16 + 2 * c + 1];

@@ -454,9 +454,7 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
       switch (ktype) { case DFGPU_INT64: PA_SAMPLE(int64_t); break; case DFGPU_UINT64: PA_SAMPLE(uint64_t); break; case DFGPU_UINT32: PA_SAMPLE(uint32_t); break; default: PA_SAMPLE(int32_t); break; }
 #undef PA_SAMPLE
       KERNEL_CHECK(); }
-    HIP_CHECK(hipMemcpyAsync(ctx->h_pinned, ctx->d_scratch64, 24, hipMemcpyDeviceToHost, ctx->stream));
-    ctx->count_sync("sync:pa_sample");
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->count_sync("sync:pa_sample"); fetch_to_pinned(ctx, 0, ctx->d_scratch64, 24);
     if (verdict_only) {
       ctx->pa_sample_key = ident; ctx->pa_sample_n = n; ctx->pa_sample_mask = (const void*)mk; for (int q = 0; q < 3; q++) ctx->pa_sample[q] = ctx->h_pinned[q];
       ctx->pa_pack = packed; ctx->pa_pack_n = packed_keys ? nkeys : 0;

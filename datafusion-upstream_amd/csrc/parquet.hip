@@ -797,8 +797,7 @@ static StrOut finish_strings(dfgpu_ctx* ctx, int64_t n, BufferPtr offsets, Buffe
   StrOut o; o.offsets = offsets;
   uint64_t* d_total = ctx->d_scratch64 + 40;
   exclusive_scan_u32_inplace32(ctx, (uint32_t*)offsets->ptr, n, d_total);
-  HIP_CHECK(hipMemcpyAsync(ctx->h_pinned + 40, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_CHECK(hipStreamSynchronize(ctx->stream)); ctx->count_sync("parquet string bytes");
+  fetch_to_pinned(ctx, 40, d_total, 8); ctx->count_sync("parquet string bytes");
   uint64_t total = ctx->h_pinned[40];
   if (total > 0x7FFFFFFFull) fail(DFGPU_EXECUTION, "Parquet error: a Utf8 column of one read holds %llu bytes, more than int32 offsets address -- read fewer row groups per call", (unsigned long long)total);
   hipLaunchKernelGGL(k_pq_set_i32, dim3(1), dim3(1), 0, ctx->stream, (int32_t*)offsets->ptr + n, (int32_t)total);
@@ -1016,7 +1015,7 @@ dfgpu_status dfgpu_parquet_open(dfgpu_ctx* ctx, const uint8_t* file_bytes, int64
     if (!file_bytes || !out) fail(DFGPU_INVALID_ARGUMENT, "parquet_open: null argument");
     std::unique_ptr<dfgpu_parquet> f(new dfgpu_parquet()); f->host = file_bytes; f->len = len; f->dev = device_bytes;
     parse_footer(f.get()); *out = f.release();
-  });
+  }, true);          // ctx may be NULL: the footer alone is read (metadata)
 }
 dfgpu_status dfgpu_parquet_open_file(dfgpu_ctx* ctx, const char* path, int32_t stage_on_device, dfgpu_parquet** out) {
   return guard(ctx, [&] {
@@ -1040,7 +1039,7 @@ dfgpu_status dfgpu_parquet_open_file(dfgpu_ctx* ctx, const char* path, int32_t s
       if (hipHostRegister(m, (size_t)st.st_size, hipHostRegisterDefault) == hipSuccess) f->registered = true; else (void)hipGetLastError();
     }
     *out = f.release();
-  });
+  }, true);          // ctx may be NULL: metadata only, read through the host mapping
 }
 void dfgpu_parquet_close(dfgpu_parquet* f) { delete f; }
 dfgpu_status dfgpu_parquet_set_option(dfgpu_parquet* f, const char* key, int64_t value) {

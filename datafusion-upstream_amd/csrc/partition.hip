@@ -38,9 +38,7 @@ extern "C" dfgpu_status dfgpu_hash_partition(dfgpu_ctx* ctx, const dfgpu_array* 
       RpCols cols{}; cols.n = 0; cols.rowid_dst = (uint32_t*)idx.get()->values->ptr;
       RpResult r = rp_partition(ctx, RpHashKeySet{ ks, nullptr, ctx->force_hash_collisions ? 1 : 0 }, n, (uint32_t)num_partitions, cols, true, ctx->d_scratch64 + 9, "rp_hist", "rp_scan", "rp_scatter");
       std::vector<uint32_t> st((size_t)num_partitions + 1);
-      HIP_CHECK(hipMemcpyAsync(st.data(), r.starts->ptr, st.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-      ctx->count_sync("sync:partition_counts");
-      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      ctx->count_sync("sync:partition_counts"); fetch_to_host(ctx, st.data(), r.starts->ptr, st.size() * 4);
       for (int32_t p2 = 0; p2 < num_partitions; p2++) counts_host[p2] = (int64_t)st[(size_t)p2 + 1] - (int64_t)st[(size_t)p2];
       *out_indices = idx.release();
       return;
@@ -55,8 +53,7 @@ extern "C" dfgpu_status dfgpu_hash_partition(dfgpu_ctx* ctx, const dfgpu_array* 
       int bits = 1; while ((1 << bits) < num_partitions) bits++;
       if (num_partitions > 1) radix_sort_pairs_u32(ctx, (uint32_t*)dest->ptr, (uint32_t*)idx.get()->values->ptr, n, bits);
     }
-    HIP_CHECK(hipMemcpyAsync(counts_host, counts->ptr, (size_t)num_partitions * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    fetch_to_host(ctx, counts_host, counts->ptr, (size_t)num_partitions * 8);
     *out_indices = idx.release();
   });
 }
@@ -94,9 +91,7 @@ extern "C" dfgpu_status dfgpu_partition_columns(dfgpu_ctx* ctx, const dfgpu_arra
         r = rp_partition(ctx, RpHashKeySet{ ks, mask ? (const uint64_t*)mask->ptr : nullptr, ctx->force_hash_collisions ? 1 : 0 }, n, (uint32_t)num_partitions, rc, true, ctx->d_scratch64 + 9, "rp_hist", "rp_scan", "rp_scatter");
         if (direct.size() <= c0 + RP_MAX_COLS) break;
       }
-      HIP_CHECK(hipMemcpyAsync(st.data(), r.starts->ptr, st.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-      ctx->count_sync("sync:partition_counts");
-      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      ctx->count_sync("sync:partition_counts"); fetch_to_host(ctx, st.data(), r.starts->ptr, st.size() * 4);
     }
     const int64_t moved = st[(size_t)num_partitions];
     for (int32_t p2 = 0; p2 < num_partitions; p2++) counts_host[p2] = (int64_t)st[(size_t)p2 + 1] - (int64_t)st[(size_t)p2];

@@ -208,6 +208,7 @@ dfgpu_array* mask_to_indices_impl(dfgpu_ctx* ctx, const uint64_t* bits, int64_t 
   ArrayHolder h(new_fixed(ctx, DFGPU_UINT32, total));
   if (total) hipLaunchKernelGGL(k_sel_write, dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream, bits, n, (const uint32_t*)counts->ptr, (uint32_t*)h.get()->values->ptr);
   h.get()->identity = total == n;                        // every row selected: the selection vector is 0 .. n-1
+  { OrderStats st; st.sorted = true; st.repeats = false; st.exact = false; st.lo = 0; st.hi = n - 1; order_stats_set(h.get(), st); }      // set bits in row order: strictly ascending
   KERNEL_CHECK();
   return h.release();
 }
@@ -269,6 +270,21 @@ __global__ void __launch_bounds__(BLOCK) k_rows_gather(RowCols rc, const uint8_t
 }
 }  // namespace dfgpu
 
+namespace dfgpu {
+// take(sorted column, strictly ascending indices) is sorted (strictly, if the source is) and lies inside the source's bounds; take(ascending indices, ascending indices) is
+// ascending.  The source's own statistics are measured here -- once, they stay with the array -- when it is a plain integer column at most 16x the result (a base-table key
+// column behind a filter or a join): the alternative is the same pass over every result that reaches a join build.
+void order_stats_through_take(dfgpu_ctx* ctx, const dfgpu_array* values, const dfgpu_array* indices, dfgpu_array* out) {
+  if (!out || out == values || out->validity || indices->validity || !out->length) return;
+  auto is = order_stats_get(indices);
+  if (!is || !is->sorted || is->repeats) return;
+  auto vs = order_stats_get(values);
+  if (!vs && values->length >= (1 << 16) && values->length <= out->length * 16) vs = order_stats_measure(ctx, values);
+  if (!vs || !vs->sorted) return;
+  OrderStats st = *vs; st.exact = false; order_stats_set(out, st);
+}
+}  // namespace dfgpu
+
 using namespace dfgpu;
 extern "C" {
 
@@ -279,6 +295,7 @@ dfgpu_status dfgpu_take(dfgpu_ctx* ctx, const dfgpu_array* values, const dfgpu_a
     if (!w) fail(DFGPU_INVALID_ARGUMENT, "take: indices must be 32/64-bit integers");
     if (indices->identity && indices->length == values->length) { dfgpu_array_retain(const_cast<dfgpu_array*>(values)); *out = const_cast<dfgpu_array*>(values); return; }      // arrays are immutable: share
     *out = take_impl(ctx, values, indices->values->ptr, w, indices->validity ? (const uint64_t*)indices->validity->ptr : nullptr, indices->length);
+    order_stats_through_take(ctx, values, indices, *out);
     check_flags(ctx, "take");
   });
 }

