@@ -131,6 +131,7 @@ PROTOTYPES = {
     "dfgpu_join_probe": (C.c_int32, [_P, _P, _PP, C.c_int32, _P, _PP, _PP]),
     "dfgpu_join_probe_deferred": (C.c_int32, [_P, _P, _PP, C.c_int32, _P, _PP, _PP]),
     "dfgpu_join_lookup": (C.c_int32, [_P, _P, _PP, C.c_int32, _P, _PP]),
+    "dfgpu_join_probe_selection": (C.c_int32, [_P, _P, _PP, C.c_int32, _P, _PP]),
     "dfgpu_join_mark_visited": (C.c_int32, [_P, _P, _P]),
     "dfgpu_join_adjust_indices": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int32, _PP, _PP]),
     "dfgpu_join_final_indices": (C.c_int32, [_P, _P, C.c_int32, _PP]),

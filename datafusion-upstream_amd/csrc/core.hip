@@ -379,6 +379,9 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "join_rank_index") ctx->join_rank_index = value != 0;
     else if (k == "join_rank_index_unsorted") ctx->join_rank_index_unsorted = value != 0;
     else if (k == "join_lazy_build_rows") ctx->join_lazy_build_rows = value != 0;
+    else if (k == "join_selection_output") ctx->join_selection_output = value != 0;
+    else if (k == "join_bitmap_partitioned") ctx->join_bitmap_partitioned = value != 0;
+    else if (k == "join_bitmap_partitioned_min_rows") ctx->join_bitmap_partitioned_min_rows = value;
     else if (k == "join_key_packing") ctx->join_key_packing = value != 0;
     else if (k == "group_run_detection") ctx->group_run_detection = value != 0;
     else if (k == "group_dictionary_canon") ctx->group_dictionary_canon = value != 0;
@@ -426,6 +429,9 @@ dfgpu_status dfgpu_ctx_get_option(dfgpu_ctx* ctx, const char* key, int64_t* out)
     else if (k == "join_rank_index") *out = ctx->join_rank_index;
     else if (k == "join_rank_index_unsorted") *out = ctx->join_rank_index_unsorted ? 1 : 0;
     else if (k == "join_lazy_build_rows") *out = ctx->join_lazy_build_rows ? 1 : 0;
+    else if (k == "join_selection_output") *out = ctx->join_selection_output ? 1 : 0;
+    else if (k == "join_bitmap_partitioned") *out = ctx->join_bitmap_partitioned ? 1 : 0;
+    else if (k == "join_bitmap_partitioned_min_rows") *out = ctx->join_bitmap_partitioned_min_rows;
     else if (k == "join_key_packing") *out = ctx->join_key_packing;
     else if (k == "group_run_detection") *out = ctx->group_run_detection;
     else if (k == "group_dictionary_canon") *out = ctx->group_dictionary_canon;

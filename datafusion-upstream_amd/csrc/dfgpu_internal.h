@@ -44,6 +44,7 @@ struct dfgpu_ctx {
   bool first_seen_group_order = true;
   bool join_rank_index = true;
   bool join_lazy_build_rows = true;         // plan layer: an Inner HashJoinExec over a unique rank-indexed build looks the build rows up when a build-side column is read (dfgpu_join_probe_deferred)
+  bool join_selection_output = true;        // plan layer: such a join whose build side contributes key columns only answers with the probe batch under a selection (dfgpu_join_probe_selection)
   bool join_rank_index_unsorted = true;     // unique integer keys over a dense domain in ANY order (a repartitioned or filtered primary-key column): bitmap + rank -> build row
   bool join_key_packing = true;
   bool group_run_detection = true;
@@ -52,6 +53,7 @@ struct dfgpu_ctx {
   // radix-partitioned hash join (pjoin.hip): on/off, smallest build / probe batch that takes it, build rows per partition (<= 14000)
   uint64_t join_partitioned_hash_mask = ~0ull;       // tests: AND-ed onto the key hashes of the hashed mode, so that different keys collide
   bool join_partitioned_hashed = true;       // builds the integer mode of the partitioned join does not take (several key columns that do not pack, Utf8 / dictionary keys, null_equals_null) go through it on 64-bit key hashes
+  bool join_bitmap_partitioned = true; int64_t join_bitmap_partitioned_min_rows = 1 << 24;      // membership-bitmap probes of unclustered keys go through a key-range partition (pjoin.hip bp_probe)
   bool join_partitioned = true; int64_t join_partitioned_min_build = 1 << 20, join_partitioned_min_probe = 1 << 22, join_partition_rows = 14000;
   int64_t fused_aggregate_min_rows = 1 << 20;
   bool sort_packed_keys = true;     // large sorts over fixed-width keys: range-packed u64 keys + stable one-pass partition per digit (sort.hip)
@@ -218,6 +220,8 @@ void exclusive_scan_u32_inplace32(dfgpu_ctx* ctx, uint32_t* data, int64_t n, uin
 // select.hip helpers reused by other ops
 dfgpu_array* take_impl(dfgpu_ctx* ctx, const dfgpu_array* values, const void* idx, int idx_width, const uint64_t* idx_validity, int64_t n_out);
 dfgpu_array* mask_to_indices_impl(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n);
+dfgpu_array* mask_to_indices_checked(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n, int check_slot, uint64_t* check_value);
+dfgpu_array* mask_to_indices_uncounted(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n);      // n entries, the first popcount(bits) written; no read-back (internal rank -> row tables)
 int64_t count_set_bits(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n);
 inline const uint64_t* row_selection_words(dfgpu_ctx* ctx, int64_t n) { return ctx->row_selection && ctx->row_selection_len == n ? (const uint64_t*)ctx->row_selection->ptr : nullptr; }
 

@@ -677,8 +677,9 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
     // process_probe_batch, hash_join.rs:1238-1343): `batch_size` candidate pairs per emitted batch, index alignment per chunk
     Batch chunk_pb; ArrayRef chunk_b, chunk_p; int64_t chunk_k = -1, chunk_total = 0, chunk_joined = -1; std::vector<uint32_t> chunk_last;     // chunk_last: without a JoinFilter, every chunk's last joined probe row (one read-back per probe batch)   // 0 WaitBuildSide, 1 probing, 2 final pass, 3 done, 4 swapped semi/anti result pending
     SchemaPtr out_schema;
-    bool lazy_build_rows = true;
-    S(const HashJoinExec* o, int p, TaskContext t) : op(o), tc(t), partition(p) { int64_t v = 1; if (dfgpu_ctx_get_option(tc.ctx, "join_lazy_build_rows", &v) == DFGPU_OK) lazy_build_rows = v != 0; }
+    bool lazy_build_rows = true, selection_output = true;
+    S(const HashJoinExec* o, int p, TaskContext t) : op(o), tc(t), partition(p) { int64_t v = 1; if (dfgpu_ctx_get_option(tc.ctx, "join_lazy_build_rows", &v) == DFGPU_OK) lazy_build_rows = v != 0;
+      v = 1; if (dfgpu_ctx_get_option(tc.ctx, "join_selection_output", &v) == DFGPU_OK) selection_output = v != 0; }
     int64_t last_u32(const ArrayRef& a) {
       int64_t n = a.len(); if (!n) return -1;
       dfgpu_array* s1 = nullptr; tc.check(dfgpu_array_slice(tc.ctx, a.a, n - 1, 1, &s1)); ArrayRef one = ArrayRef::adopt(s1);
@@ -802,6 +803,23 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
           dfgpu_array *b = nullptr, *p = nullptr;
           // an Inner join whose build rows nothing here needs (no filter, no final pass, one piece): the table may leave them for later (LazyLookup)
           bool defer = !chunked && op->join_type == DFGPU_JOIN_INNER && !op->filter && !need_final && kp.size() == 1 && lazy_build_rows;
+          // An Inner join over a unique build of which nothing but (aliased) key columns leaves the build side: its output is the probe batch under the selection
+          // "row is selected and finds its key" -- the probe's match bits.  No index vector, no gather, no row count on the host: the consumer fuses the selection
+          // (the next join's build or probe, a repartition, an aggregate) or compacts it when it must.  TPC-H Q3: customer x orders hands the orders table itself,
+          // under a selection, to the build of the join with lineitem.
+          if (defer && selection_output) {
+            std::vector<int> al = key_aliases(&bs->batch, pb); bool all = !al.empty(); for (int a : al) all = all && a >= 0;
+            if (all) {
+              dfgpu_array* s = nullptr; dfgpu_status st = dfgpu_join_probe_selection(tc.ctx, bs->table->t, kp.data(), 1, mask.a, &s);
+              if (st == DFGPU_OK) {
+                Batch o; o.schema = out_schema; o.base_rows = pb.base_rows; o.selection = ArrayRef::adopt(s);
+                for (int a : al) o.cols.push_back(pb.cols[(size_t)a]);
+                for (auto& c : pb.cols) o.cols.push_back(c);
+                out = std::move(o); return true;
+              }
+              if (st != DFGPU_NOT_IMPLEMENTED) tc.check(st);
+            }
+          }
           for (auto& c : bs->batch.cols) defer = defer && (bool)c.arr;
           if (defer) {
             tc.check(dfgpu_join_probe_deferred(tc.ctx, bs->table->t, kp.data(), 1, mask.a, &b, &p)); pidx = ArrayRef::adopt(p);

@@ -532,8 +532,9 @@ static bool groups_intern_runs(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_arra
     case DFGPU_UINT8: RUNS(uint8_t); break; case DFGPU_UINT16: RUNS(uint16_t); break; case DFGPU_UINT32: RUNS(uint32_t); break; default: RUNS(uint64_t); break; }
 #undef RUNS
   KERNEL_CHECK();
-  if (read_scratch(ctx, 2) != 0) return false;
-  ArrayHolder firsts(mask_to_indices_impl(ctx, (const uint64_t*)heads->ptr, n));
+  // "not clustered" and the number of runs in ONE read-back (counting the heads of an unclustered batch is the price of the lost bet: two small kernels)
+  ArrayHolder firsts(mask_to_indices_checked(ctx, (const uint64_t*)heads->ptr, n, 2, nullptr));
+  if (!firsts.get()) return false;
   int64_t n_new = firsts.get()->length;
   if (g->n_groups + n_new >= (int64_t)G_NEW) fail(DFGPU_RESOURCES_EXHAUSTED, "more than 2^31 groups");
   int64_t nw = (n + 63) / 64;

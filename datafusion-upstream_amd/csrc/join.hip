@@ -572,7 +572,9 @@ static bool build_rank_index(dfgpu_ctx* ctx, dfgpu_join_table* t) {
     exclusive_scan_u32_inplace32(ctx, (uint32_t*)t->rank_prefix->ptr, nw, nullptr);
     KERNEL_CHECK();
     t->mem += nw * 4;
-    if (mk) { t->sel_rows = mask_to_indices_impl(ctx, mk, n); t->mem += t->sel_rows->length * 4; }          // masked build: rank -> build row; runs: rank -> first row of the run
+    // masked build: rank -> build row; runs: rank -> first row of the run.  A plain masked build only ever reads entries below the number of set bits (a rank), so the table
+    // is written without the host learning that number (one read-back less per build); the run path walks to sel_rows[r + 1] and needs the exact length.
+    if (mk) { t->sel_rows = runs ? mask_to_indices_impl(ctx, mk, n) : mask_to_indices_uncounted(ctx, mk, n); t->mem += t->sel_rows->length * 4; }
   }
   return true;
 }
@@ -713,8 +715,7 @@ dfgpu_status dfgpu_join_build(dfgpu_ctx* ctx, const dfgpu_array* const* keys, in
       for (int c = 0; c < nkeys; c++) { t->keys.push_back(const_cast<dfgpu_array*>(keys[c])); dfgpu_array_retain(t->keys.back()); }
     }
     t->build_mask = effective_mask(ctx, opt_mask, n);
-    t->visited = alloc_buffer(ctx, bitmap_bytes(n), true);
-    t->mem = (int64_t)bitmap_bytes(n);
+    t->mem = (int64_t)bitmap_bytes(n);               // the visited bitmap: accounted here, allocated and cleared when a join type that marks rows first does (an Inner join never)
     // order of preference: rank index (clustered keys: no table at all), radix-partitioned LDS tables (large builds on unsorted keys
     // whose domain is too sparse for the membership bitmap in front of the general table), general open-addressing table
     if (!build_rank_index(ctx, t.get()) && !build_rank_index_unsorted(ctx, t.get()) && !((pj_domain_is_sparse(ctx, t.get()) || pj_hashed_candidate(ctx, t.get())) && pj_build(ctx, t.get()))) build_hash_table(ctx, t.get(), true);
@@ -726,15 +727,19 @@ int64_t dfgpu_join_table_num_rows(const dfgpu_join_table* t) { return t ? t->n_b
 int64_t dfgpu_join_table_memory(const dfgpu_join_table* t) { return t ? t->mem : 0; }
 
 static dfgpu_status join_probe_impl(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* probe_keys, int32_t nkeys,
-                                    const dfgpu_array* opt_mask, dfgpu_array** out_build_idx, dfgpu_array** out_probe_idx, bool may_defer);
+                                    const dfgpu_array* opt_mask, dfgpu_array** out_build_idx, dfgpu_array** out_probe_idx, bool may_defer, dfgpu_array** out_selection);
 dfgpu_status dfgpu_join_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* probe_keys, int32_t nkeys,
                               const dfgpu_array* opt_mask, dfgpu_array** out_build_idx, dfgpu_array** out_probe_idx) {
-  return join_probe_impl(ctx, t, probe_keys, nkeys, opt_mask, out_build_idx, out_probe_idx, false);
+  return join_probe_impl(ctx, t, probe_keys, nkeys, opt_mask, out_build_idx, out_probe_idx, false, nullptr);
 }
 /* see include/dfgpu.h */
 dfgpu_status dfgpu_join_probe_deferred(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* probe_keys, int32_t nkeys,
                                        const dfgpu_array* opt_mask, dfgpu_array** out_build_idx, dfgpu_array** out_probe_idx) {
-  return join_probe_impl(ctx, t, probe_keys, nkeys, opt_mask, out_build_idx, out_probe_idx, true);
+  return join_probe_impl(ctx, t, probe_keys, nkeys, opt_mask, out_build_idx, out_probe_idx, true, nullptr);
+}
+dfgpu_status dfgpu_join_probe_selection(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* probe_keys, int32_t nkeys, const dfgpu_array* opt_mask, dfgpu_array** out_selection) {
+  if (!out_selection) return DFGPU_INVALID_ARGUMENT;
+  return join_probe_impl(ctx, t, probe_keys, nkeys, opt_mask, nullptr, nullptr, false, out_selection);
 }
 dfgpu_status dfgpu_join_lookup(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* probe_keys, int32_t nkeys, const dfgpu_array* rows, dfgpu_array** out_build_idx) {
   return guard(ctx, [&] {
@@ -761,10 +766,13 @@ dfgpu_status dfgpu_join_lookup(dfgpu_ctx* ctx, const dfgpu_join_table* t, const 
   });
 }
 static dfgpu_status join_probe_impl(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* probe_keys, int32_t nkeys,
-                                    const dfgpu_array* opt_mask, dfgpu_array** out_build_idx, dfgpu_array** out_probe_idx, bool may_defer) {
+                                    const dfgpu_array* opt_mask, dfgpu_array** out_build_idx, dfgpu_array** out_probe_idx, bool may_defer, dfgpu_array** out_selection) {
   return guard(ctx, [&] {
-    if (!t || !probe_keys || !out_build_idx || !out_probe_idx) fail(DFGPU_INVALID_ARGUMENT, "join_probe: null argument");
+    if (!t || !probe_keys || (!out_selection && (!out_build_idx || !out_probe_idx))) fail(DFGPU_INVALID_ARGUMENT, "join_probe: null argument");
     check_key_types(t, probe_keys, nkeys);
+    // the selection form (dfgpu_join_probe_selection): only for the tables whose probe would be deferred -- decided before any pass runs
+    if (out_selection && !(t->rank_mode && t->unique && !t->rank_runs && t->bitmap && !t->pack_n && nkeys == 1 && probe_keys[0]->type == t->keys[0]->type && !probe_keys[0]->validity))
+      fail(DFGPU_NOT_IMPLEMENTED, "join_probe_selection: only a unique rank-indexed build probed by one integer key column of the build's type without NULLs");
     ArrayHolder packed_probe; const dfgpu_array* pk1 = nullptr;
     if (t->pack_n) {
       for (int c = 0; c < nkeys; c++) if (probe_keys[c]->type == DFGPU_DICTIONARY || probe_keys[c]->length != probe_keys[0]->length) fail(DFGPU_NOT_IMPLEMENTED, "probe of a packed multi-key table with dictionary-encoded keys");
@@ -777,7 +785,7 @@ static dfgpu_status join_probe_impl(dfgpu_ctx* ctx, const dfgpu_join_table* t, c
     int64_t nw = (n + 63) / 64;
     const uint64_t* mk = mask ? (const uint64_t*)mask->ptr : nullptr;
     int nen = t->null_equals_null ? 1 : 0, fz = ctx->force_hash_collisions ? 1 : 0;
-    if (pj_probe_eligible(ctx, t, probe_keys, nkeys, n)) {        // large batch against a partitioned build: partition by partition out of LDS
+    if (!out_selection && pj_probe_eligible(ctx, t, probe_keys, nkeys, n)) {        // large batch against a partitioned build: partition by partition out of LDS
       pj_probe(ctx, t, probe_keys, nkeys, mk, out_build_idx, out_probe_idx);
       check_flags(ctx, "join_probe");
       return;
@@ -798,7 +806,9 @@ static dfgpu_status join_probe_impl(dfgpu_ctx* ctx, const dfgpu_join_table* t, c
       }
       use_bitmap = t->bitmap && pk->type == t->keys[0]->type;      // same physical integer type, no dictionary
       if (!use_bitmap && !t->slots) build_hash_table(ctx, const_cast<dfgpu_join_table*>(t), false);   // rank index cannot serve this probe column
-      if (use_bitmap) {
+      if (use_bitmap && bp_probe(ctx, t, pk, mk, n, (uint64_t*)match_bits->ptr)) {
+        // unclustered keys: probed partition by partition of the key range (pjoin.hip)
+      } else if (use_bitmap) {
         KernelTimer kt_(ctx, "k_probe_match_bitmap");
         int64_t rows_per_block = (int64_t)BLOCK * PM_ROWS;
         const uint64_t* kvp = pk->validity ? (const uint64_t*)pk->validity->ptr : nullptr;
@@ -828,6 +838,12 @@ static dfgpu_status join_probe_impl(dfgpu_ctx* ctx, const dfgpu_join_table* t, c
       KERNEL_CHECK();
     }
     (void)nw;
+    if (out_selection) {            // the match bits ARE the answer: a Boolean column over the probe rows (bits of a partial last word beyond n are zero)
+      ArrayHolder sel(new_array(ctx, DFGPU_BOOL, n)); sel.get()->values = match_bits; sel.get()->null_count = 0;
+      check_flags(ctx, "join_probe");
+      *out_selection = sel.release();
+      return;
+    }
     ArrayHolder rows(mask_to_indices_impl(ctx, (const uint64_t*)match_bits->ptr, n));      // matched probe rows, ascending
     int64_t m = rows.get()->length;
     const uint32_t* rp = (const uint32_t*)rows.get()->values->ptr;
@@ -909,6 +925,7 @@ dfgpu_status dfgpu_join_mark_visited(dfgpu_ctx* ctx, dfgpu_join_table* t, const 
   return guard(ctx, [&] {
     if (!t || !build_idx || build_idx->type != DFGPU_UINT64) fail(DFGPU_INVALID_ARGUMENT, "mark_visited: UINT64 build indices expected");
     int64_t n = build_idx->length; if (!n) return;
+    if (!t->visited) t->visited = alloc_buffer(ctx, bitmap_bytes(t->n_build), true);
     hipLaunchKernelGGL(k_mark_bits_u64idx, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)build_idx->values->ptr,
                        build_idx->validity ? (const uint64_t*)build_idx->validity->ptr : nullptr, n, (uint64_t*)t->visited->ptr, t->n_build, ctx->d_flags);
     KERNEL_CHECK();
@@ -923,6 +940,7 @@ dfgpu_status dfgpu_join_final_indices(dfgpu_ctx* ctx, const dfgpu_join_table* t,
     if (!semi && join_type != DFGPU_JOIN_LEFT && join_type != DFGPU_JOIN_FULL && join_type != DFGPU_JOIN_LEFT_ANTI)
       fail(DFGPU_INVALID_ARGUMENT, "join type %d produces no final build-side batch (need_produce_result_in_final)", join_type);
     int64_t n = t->n_build, nw = (n + 63) / 64;
+    if (!t->visited) const_cast<dfgpu_join_table*>(t)->visited = alloc_buffer(ctx, bitmap_bytes(n), true);      // nothing was ever marked
     BufferPtr sel = alloc_buffer(ctx, bitmap_bytes(n), true);
     if (nw) hipLaunchKernelGGL(k_combine_words, dim3(grid_for(nw, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)t->visited->ptr, semi ? 0ull : ~0ull,
                                t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr, (uint64_t*)sel->ptr, nw);

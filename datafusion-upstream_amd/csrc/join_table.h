@@ -57,6 +57,7 @@ namespace dfgpu {
 // pjoin.hip
 bool pj_build(dfgpu_ctx* ctx, dfgpu_join_table* t);      // false = shape not taken (nothing kept)
 bool pj_probe_eligible(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* probe_keys, int32_t nkeys, int64_t n);
+bool bp_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* probe_key, const uint64_t* mask, int64_t n, uint64_t* match_bits);      // membership bitmap probed by key range (unclustered probe keys)
 void pj_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* const* probe_keys, int32_t nkeys, const uint64_t* mask, dfgpu_array** out_build, dfgpu_array** out_probe);
 bool pj_hashed_candidate(dfgpu_ctx* ctx, const dfgpu_join_table* t);      // a build the integer mode does not take, large enough for the partitioned path
 }  // namespace dfgpu

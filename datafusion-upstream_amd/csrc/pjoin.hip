@@ -683,4 +683,81 @@ void pj_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* cons
   *out_build = ob.release(); *out_probe = op.release();
 }
 
+// ---------------------------------------------------------------- membership bitmap, probed by key range
+// A dense key domain gives the build a membership bitmap (join.hip); keys that arrive in key order walk it like a stream.  Keys in NO order (a probe side behind a hash
+// repartition, a table never written in key order) each touch a line of their own: 280 M probes into a 75 MB bitmap moved 36 GB of lines for 2.3 GB of keys (TPC-H Q3 at
+// SF100 over shuffled tables, 6.8 ms).  Such a batch is first split by key RANGE -- record = (key - key_min) << 32 | probe row, partition = the bits above a 2^21-key slice,
+// one pass of radix_partition.h -- so that the records of a partition test a 256 KB slice of the bitmap that its XCD's L2 holds; a match sets its row's bit with an atomic OR
+// (the records of a partition are in no particular row order).  The sample below decides: unclustered keys, and few enough matches that their atomics stay small.
+template <typename T> struct RpHashKeyRange {
+  const T* keys; const uint64_t* valid; const uint64_t* mask; int64_t kmin; uint64_t range; int shift;
+  __device__ inline bool operator()(int64_t i, uint32_t, uint32_t* pid, uint64_t* key) const {
+    const uint64_t d = (uint64_t)((int64_t)keys[i] - kmin);
+    const bool ok = d < range && (!mask || bit_get(mask, i)) && (!valid || bit_get(valid, i));
+    *pid = ok ? (uint32_t)(d >> shift) : 0u; *key = (d << 32) | (uint64_t)(uint32_t)i; return ok;
+  }
+};
+// 2048 evenly spread rows i: [0] += rows whose successor's key lies in the same 4 KB of bitmap (clustered input: nearly all), [1] += selected rows, [2] += selected rows that match
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_bp_sample(const T* keys, const uint64_t* valid, const uint64_t* mask, int64_t n, int64_t kmin, uint64_t range, const uint64_t* bitmap, unsigned long long* out) {
+  constexpr int S = 2048;
+  uint32_t near = 0, sel = 0, hit = 0;
+  for (int s0 = threadIdx.x; s0 < S; s0 += BLOCK) {
+    const int64_t i = (int64_t)((unsigned __int128)(uint64_t)s0 * (uint64_t)(n - 1) / S);
+    const uint64_t d = (uint64_t)((int64_t)keys[i] - kmin), d1 = (uint64_t)((int64_t)keys[i + 1] - kmin);
+    near += (d >> 15) == (d1 >> 15);
+    const bool ok = d < range && (!mask || bit_get(mask, i)) && (!valid || bit_get(valid, i));
+    sel += ok; hit += ok && ((bitmap[d >> 6] >> (d & 63)) & 1ull);
+  }
+  near = wave_sum(near); sel = wave_sum(sel); hit = wave_sum(hit);
+  if (lane_id() == 0) { atomicAdd(&out[0], (unsigned long long)near); atomicAdd(&out[1], (unsigned long long)sel); atomicAdd(&out[2], (unsigned long long)hit); }
+}
+constexpr int BP_ROWS = 4;
+__global__ void __launch_bounds__(BLOCK) k_bp_probe(const uint64_t* recs, const unsigned long long* d_total, const uint64_t* bitmap, unsigned long long* match_bits) {
+  const int64_t total = (int64_t)*d_total, base = (int64_t)blockIdx.x * BLOCK * BP_ROWS + threadIdx.x;
+  if (base - threadIdx.x >= total) return;
+  uint64_t r[BP_ROWS], w[BP_ROWS];
+#pragma unroll
+  for (int q = 0; q < BP_ROWS; q++) { const int64_t i = base + (int64_t)q * BLOCK; r[q] = recs[i < total ? i : total - 1]; }
+#pragma unroll
+  for (int q = 0; q < BP_ROWS; q++) w[q] = bitmap[r[q] >> 38];                 // d >> 6, d = r >> 32
+#pragma unroll
+  for (int q = 0; q < BP_ROWS; q++) {
+    const int64_t i = base + (int64_t)q * BLOCK; const uint32_t d = (uint32_t)(r[q] >> 32), row = (uint32_t)r[q];
+    if (i < total && ((w[q] >> (d & 63)) & 1ull)) atomicOr(&match_bits[row >> 6], 1ull << (row & 63));
+  }
+}
+template <typename T>
+static bool bp_probe_typed(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* pk, const uint64_t* mask, int64_t n, uint64_t* match_bits) {
+  const T* keys = (const T*)pk->values->ptr; const uint64_t* valid = pk->validity ? (const uint64_t*)pk->validity->ptr : nullptr;
+  HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 10, 0, 32, ctx->stream));
+  hipLaunchKernelGGL((k_bp_sample<T>), dim3(1), dim3(BLOCK), 0, ctx->stream, keys, valid, mask, n, t->key_min, t->range, (const uint64_t*)t->bitmap->ptr, (unsigned long long*)(ctx->d_scratch64 + 10));
+  KERNEL_CHECK();
+  const uint64_t* sm = read_scratch_range(ctx, 10, 3);
+  const uint64_t near = sm[0], sel = sm[1], hit = sm[2];
+  if (near * 2 >= 2048 || hit * 4 > sel) return false;                       // clustered keys stream the bitmap as it is; many matches would pay an atomic each
+  int shift = 21; while ((t->range >> shift) >= RP_MAX_P) shift++;            // 2^21 keys = 256 KB of bitmap per partition
+  const uint32_t P = (uint32_t)(((t->range - 1) >> shift) + 1);
+  if (P < 8) return false;
+  BufferPtr recs = alloc_buffer(ctx, (size_t)n * 8);
+  RpCols cols{}; cols.n = 1; cols.c[0] = RpCol{ nullptr, recs->ptr, 8, RP_HASHKEY, 0 };
+  rp_partition(ctx, RpHashKeyRange<T>{ keys, valid, mask, t->key_min, t->range, shift }, n, P, cols, false, ctx->d_scratch64 + 13, "bp_hist", "bp_scan", "bp_scatter", false);
+  KernelTimer kt_(ctx, "bp_probe");
+  HIP_CHECK(hipMemsetAsync(match_bits, 0, bitmap_bytes(n), ctx->stream));
+  hipLaunchKernelGGL(k_bp_probe, dim3(grid_for(n, BLOCK * BP_ROWS)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)recs->ptr, (const unsigned long long*)(ctx->d_scratch64 + 13),
+                     (const uint64_t*)t->bitmap->ptr, (unsigned long long*)match_bits);
+  KERNEL_CHECK();
+  return true;
+}
+// true = match_bits holds the answer of pass 1 (join.hip); false = not taken (clustered keys, a small batch or bitmap, many matches): the streaming probe runs
+bool bp_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* pk, const uint64_t* mask, int64_t n, uint64_t* match_bits) {
+  if (!ctx->join_partitioned || !ctx->join_bitmap_partitioned || n < ctx->join_bitmap_partitioned_min_rows || n > 0xFFFFFFF0ll || !t->bitmap || t->range > (1ull << 32) || bitmap_bytes((int64_t)t->range) < ((size_t)8 << 20)) return false;          // a bitmap of a few MB is (mostly) L2-resident as it is
+  switch (pk->type) {
+    case DFGPU_INT64: return bp_probe_typed<int64_t>(ctx, t, pk, mask, n, match_bits);
+    case DFGPU_INT32: case DFGPU_DATE32: return bp_probe_typed<int32_t>(ctx, t, pk, mask, n, match_bits);
+    case DFGPU_UINT32: return bp_probe_typed<uint32_t>(ctx, t, pk, mask, n, match_bits);
+    default: return false;
+  }
+}
+
 }  // namespace dfgpu

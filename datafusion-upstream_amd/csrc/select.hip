@@ -197,14 +197,23 @@ __global__ void __launch_bounds__(BLOCK) k_sel_write(const uint64_t* bits, int64
     }
   }
 }
-dfgpu_array* mask_to_indices_impl(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n) {
+dfgpu_array* mask_to_indices_impl(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n) { return mask_to_indices_checked(ctx, bits, n, -1, nullptr); }
+// check_slot >= 0: scratch word `check_slot` (< 60; written by a kernel the caller has enqueued) comes back in the same read-back as the count; a non-zero value means the caller's
+// precondition failed -- nothing is written and nullptr is returned (*check_value tells why).  One host round trip for "is the input what I hoped" + "how many".
+dfgpu_array* mask_to_indices_checked(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n, int check_slot, uint64_t* check_value) {
   int64_t nw = (n + 63) / 64, nb = (nw + SEL_WORDS - 1) / SEL_WORDS;
-  if (n == 0) return new_fixed(ctx, DFGPU_UINT32, 0);
+  if (n == 0) { if (check_slot >= 0) { uint64_t v = read_scratch(ctx, check_slot); if (check_value) *check_value = v; if (v) return nullptr; } return new_fixed(ctx, DFGPU_UINT32, 0); }
   BufferPtr counts = alloc_buffer(ctx, (size_t)nb * 4);
   KernelTimer kt_(ctx, "k_sel_count+scan+write");
   hipLaunchKernelGGL(k_sel_count, dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream, bits, n, (uint32_t*)counts->ptr);
   exclusive_scan_u32_inplace32(ctx, (uint32_t*)counts->ptr, nb, ctx->d_scratch64 + 60);
-  int64_t total = (int64_t)read_scratch(ctx, 60);
+  int64_t total;
+  if (check_slot >= 0 && check_slot < 60) {
+    const uint64_t* w = read_scratch_range(ctx, check_slot, 61 - check_slot);
+    if (check_value) *check_value = w[0];
+    if (w[0]) return nullptr;
+    total = (int64_t)w[60 - check_slot];
+  } else total = (int64_t)read_scratch(ctx, 60);
   ArrayHolder h(new_fixed(ctx, DFGPU_UINT32, total));
   if (total) hipLaunchKernelGGL(k_sel_write, dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream, bits, n, (const uint32_t*)counts->ptr, (uint32_t*)h.get()->values->ptr);
   h.get()->identity = total == n;                        // every row selected: the selection vector is 0 .. n-1
@@ -213,6 +222,21 @@ dfgpu_array* mask_to_indices_impl(dfgpu_ctx* ctx, const uint64_t* bits, int64_t 
   return h.release();
 }
 
+
+// The same vector for a consumer that only reads entries below the count it has on the device already (a rank): the array is n entries long, the first popcount(bits) are
+// written, and nothing is read back.  Not an Arrow array to hand out -- its length is an upper bound.
+dfgpu_array* mask_to_indices_uncounted(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n) {
+  int64_t nw = (n + 63) / 64, nb = (nw + SEL_WORDS - 1) / SEL_WORDS;
+  ArrayHolder h(new_fixed(ctx, DFGPU_UINT32, n));
+  if (n == 0) return h.release();
+  BufferPtr counts = alloc_buffer(ctx, (size_t)nb * 4);
+  KernelTimer kt_(ctx, "k_sel_count+scan+write");
+  hipLaunchKernelGGL(k_sel_count, dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream, bits, n, (uint32_t*)counts->ptr);
+  exclusive_scan_u32_inplace32(ctx, (uint32_t*)counts->ptr, nb, nullptr);
+  hipLaunchKernelGGL(k_sel_write, dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream, bits, n, (const uint32_t*)counts->ptr, (uint32_t*)h.get()->values->ptr);
+  KERNEL_CHECK();
+  return h.release();
+}
 
 // ---------------------------------------------------------------- several columns through ONE index array
 // A gather of n random rows costs one 64-byte sector per row and column whatever the column's width (~53 G sectors/s on MI355X beyond

@@ -346,6 +346,16 @@ class JoinTable:
         self.ctx.check(self.ctx.lib.dfgpu_join_probe_deferred(self.ctx.h, self.h, hs, n, mask.h if mask is not None else None, C.byref(ob), C.byref(op)))
         return (Array(self.ctx, ob) if ob.value else None), Array(self.ctx, op)
 
+    def probe_selection(self, keys: Sequence[Array], mask: Optional[Array] = None) -> Optional[Array]:
+        """dfgpu_join_probe_selection -> Boolean column over the probe rows (selected and matching), or None when the table does not answer that way"""
+        hs, n = capi.handle_array([a.h.value for a in keys])
+        out = C.c_void_p()
+        st = self.ctx.lib.dfgpu_join_probe_selection(self.ctx.h, self.h, hs, n, mask.h if mask is not None else None, C.byref(out))
+        if st == 4:
+            return None
+        self.ctx.check(st)
+        return Array(self.ctx, out)
+
     def lookup(self, keys: Sequence[Array], rows: Optional[Array] = None) -> Array:
         """dfgpu_join_lookup: build rows of the probe rows `rows` (UInt32, known to match; None = every row of `keys`)"""
         hs, n = capi.handle_array([a.h.value for a in keys])

@@ -268,6 +268,12 @@ DFGPU_API dfgpu_status dfgpu_join_probe(dfgpu_ctx *ctx, const dfgpu_join_table *
  * selective filter) never pays for the rest.  Any other table answers exactly as dfgpu_join_probe does (*out_build_idx set). */
 DFGPU_API dfgpu_status dfgpu_join_probe_deferred(dfgpu_ctx *ctx, const dfgpu_join_table *table, const dfgpu_array *const *probe_keys, int32_t nkeys,
                                                  const dfgpu_array *opt_mask, dfgpu_array **out_build_idx, dfgpu_array **out_probe_idx);
+/* The probe of an Inner join whose build rows nobody asks for, as a SELECTION over the probe batch: *out_selection = Boolean column, bit i = probe row i is selected by
+ * opt_mask and finds its key in the build.  Only for a table dfgpu_join_probe_deferred would defer (unique keys: a set bit is exactly one output row, in probe order);
+ * any other table answers DFGPU_NOT_IMPLEMENTED before doing any work and the caller probes the ordinary way.  The join's output is then the probe batch under that
+ * selection -- no index vector is built and nothing is read back (≙ build_batch_from_indices with probe indices = the set bits, joins/utils.rs:1180-1230). */
+DFGPU_API dfgpu_status dfgpu_join_probe_selection(dfgpu_ctx *ctx, const dfgpu_join_table *table, const dfgpu_array *const *probe_keys, int32_t nkeys,
+                                                  const dfgpu_array *opt_mask, dfgpu_array **out_selection);
 DFGPU_API dfgpu_status dfgpu_join_lookup(dfgpu_ctx *ctx, const dfgpu_join_table *table, const dfgpu_array *const *probe_keys, int32_t nkeys, const dfgpu_array *rows,
                                          dfgpu_array **out_build_idx);
 /* ≙ visited_left_side.set_bit for every joined build index (hash_join.rs:1274-1278). */

@@ -59,6 +59,7 @@ extern "C" {
     pub fn dfgpu_list_flatten(ctx: *mut dfgpu_ctx, list: *const dfgpu_array, value_type: i32, precision: i32, scale: i32, out_values: *mut *mut dfgpu_array, out_row_of: *mut *mut dfgpu_array) -> i32;
     pub fn dfgpu_join_probe_deferred(ctx: *mut dfgpu_ctx, table: *const dfgpu_join_table, probe_keys: *const *const dfgpu_array, nkeys: i32, opt_mask: *const dfgpu_array,
                                      out_build_idx: *mut *mut dfgpu_array, out_probe_idx: *mut *mut dfgpu_array) -> i32;
+    pub fn dfgpu_join_probe_selection(ctx: *mut dfgpu_ctx, table: *const dfgpu_join_table, probe_keys: *const *const dfgpu_array, nkeys: i32, opt_mask: *const dfgpu_array, out_selection: *mut *mut dfgpu_array) -> i32;
     pub fn dfgpu_join_lookup(ctx: *mut dfgpu_ctx, table: *const dfgpu_join_table, probe_keys: *const *const dfgpu_array, nkeys: i32, rows: *const dfgpu_array, out_build_idx: *mut *mut dfgpu_array) -> i32;
     pub fn dfgpu_plan_sort_merge_join(left: *const dfgpu_plan, right: *const dfgpu_plan, on_l: *const *const dfgpu_expr, on_r: *const *const dfgpu_expr, non: i32, filter: *const dfgpu_expr,
                                       filter_sides: *const i32, filter_indices: *const i32, nfilter_cols: i32, join_type: i32, null_equals_null: i32, out: *mut *mut dfgpu_plan) -> i32;

@@ -483,3 +483,62 @@ def test_chunked_probe_reads_back_once_per_probe_batch(ctx, jt):
         assert syncs <= 12, (syncs, by_cause)       # ... and a handful of read-backs (build, probe, the chunk ends), not one per chunk
     else:                   # Left marks the visited build rows of every chunk (one flag check per emitted batch), Right counts the unmatched probe rows of every chunk's row range
         assert syncs <= len(out) + 12, (syncs, by_cause)
+
+
+@pytest.mark.parametrize("shape", ["unclustered", "unclustered_masked_nullable", "clustered", "many_matches"])
+def test_bitmap_probe_by_key_range_of_unclustered_keys(ctx, shape):
+    """Probe keys in no order against a build whose membership bitmap is larger than an L2 (pjoin.hip bp_probe): the batch is split by key range and every partition tests its
+    slice of the bitmap; clustered keys and batches with many matches keep the streaming probe (the sample decides).  Pairs equal the oracle's, in order, either way."""
+    import dfgpu
+    rng = np.random.default_rng(len(shape))
+    nb, step, npr = 4_300_000, 16, 3_000_000
+    b = np.arange(nb, dtype=np.int64) * step + 5                                  # sorted unique keys over a 68.8 M domain: 8.6 MB of bitmap
+    if shape == "many_matches":
+        p = b[rng.integers(0, nb, npr)]
+    else:
+        p = rng.integers(0, nb * step + 100, npr).astype(np.int64)
+    if shape == "clustered":
+        p = np.sort(p)
+    mask = valid = None
+    if shape == "unclustered_masked_nullable":
+        mask = rng.random(npr) < 0.6; valid = rng.random(npr) < 0.9
+    table = dfgpu.JoinTable(ctx, [ctx.from_arrow(pa.array(b))])
+    pa_p = pa.array(p, mask=None if valid is None else ~valid)
+    ctx.set_option("join_bitmap_partitioned_min_rows", 1 << 20)
+    ctx.profile_select(None); ctx.profile_enable(True); ctx.profile_read()
+    try:
+        bi, pi = table.probe([ctx.from_arrow(pa_p)], mask=None if mask is None else ctx.from_arrow(pa.array(mask)))
+        prof = ctx.profile_read()
+    finally:
+        ctx.profile_enable(False); ctx.set_option("join_bitmap_partitioned_min_rows", 1 << 24)
+    assert ("bp_probe" in prof) == shape.startswith("unclustered"), sorted(prof)
+    ok = np.ones(npr, bool) if mask is None else (mask & valid)
+    pos = np.searchsorted(b, p); pos[pos >= nb] = nb - 1
+    hit = ok & (b[pos] == p)
+    assert np.array_equal(pi.to_numpy().astype(np.int64), np.nonzero(hit)[0]) and np.array_equal(bi.to_numpy().astype(np.int64), pos[hit])
+
+
+@pytest.mark.parametrize("shape", ["sorted_keys", "masked_build", "repeated_keys", "nullable_probe", "masked_probe"])
+def test_probe_selection_is_the_match_bitmap_of_the_plain_probe(ctx, shape):
+    """dfgpu_join_probe_selection: for a unique rank-indexed build the Inner join's probe side as a Boolean column (selected AND matching), nothing read back; any other table
+    (repeated keys, a nullable probe column) declines before doing work.  Its set bits are the probe indices of dfgpu_join_probe."""
+    import dfgpu
+    rng = np.random.default_rng(len(shape) + 40)
+    nb, npr = 30_000, 100_003
+    b = np.arange(nb, dtype=np.int64) * 3 + 10
+    if shape == "repeated_keys":
+        b[7] = b[6]
+    bmask = ctx.from_arrow(pa.array(rng.random(nb) < 0.7)) if shape == "masked_build" else None
+    p = rng.integers(0, 3 * nb + 40, npr).astype(np.int64)
+    pa_p = pa.array(p, mask=(rng.random(npr) < 0.05) if shape == "nullable_probe" else None)
+    pmask = ctx.from_arrow(pa.array(rng.random(npr) < 0.5)) if shape == "masked_probe" else None
+    table = dfgpu.JoinTable(ctx, [ctx.from_arrow(pa.array(b))], mask=bmask)
+    probe = [ctx.from_arrow(pa_p)]
+    sel = table.probe_selection(probe, mask=pmask)
+    if shape in ("repeated_keys", "nullable_probe"):
+        assert sel is None
+        return
+    bi, pi = table.probe(probe, mask=pmask)
+    got = sel.to_arrow()
+    assert got.null_count == 0 and len(got) == npr
+    assert np.array_equal(np.nonzero(np.asarray(got))[0], pi.to_numpy().astype(np.int64))

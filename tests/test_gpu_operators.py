@@ -440,3 +440,54 @@ def test_lazy_build_columns_through_a_nullable_index(ctx, task_ctx, above):
     assert lazy.num_rows == want.num_rows and rows(lazy) == rows(want)
     unmatched = ~np.isin(xk, pk)
     assert unmatched.any() and lazy["pay"].null_count == int(unmatched.sum()) == lazy["s"].null_count == lazy["k"].null_count
+
+
+@pytest.mark.parametrize("build_filter", [False, True])
+def test_inner_join_of_key_columns_answers_with_a_selection_over_the_probe_batch(ctx, task_ctx, build_filter):
+    """HashJoinExec Inner over a unique sorted build that contributes only its key column (dfgpu_join_probe_selection): the output is the probe batch under the match bits
+    -- no index vector, no count read back -- and the next join builds straight from the probe side's base columns under that selection (TPC-H Q3: customer x orders ->
+    build of the join with lineitem).  Rows equal the path with the option off and pyarrow's joins; the profile shows no compaction for the first join."""
+    from dfgpu import physical_plan as ops
+    rng = np.random.default_rng(17 + build_filter)
+    nc, no, nl = 30_000, 200_000, 600_000
+    cust = pa.table({"c_key": pa.array(np.arange(1, nc + 1, dtype=np.int64)), "seg": pa.array(rng.integers(0, 5, nc).astype(np.int32))})
+    okey = (np.arange(no, dtype=np.int64) // 8) * 32 + np.arange(no, dtype=np.int64) % 8 + 1                 # sorted, sparse: TPC-H's order keys
+    orders = pa.table({"o_key": pa.array(okey), "o_cust": pa.array(rng.integers(1, nc + nc // 2, no).astype(np.int64)), "o_date": pa.array(rng.integers(8000, 9000, no).astype(np.int32))})
+    lkey = np.sort(okey[rng.integers(0, no, nl)])
+    line = pa.table({"l_key": pa.array(lkey), "l_val": pa.array(rng.integers(0, 1000, nl).astype(np.int64))})
+    mk = lambda t: (lambda b: ops.MemoryExec([[b]], b.schema))(ops.batch_from_arrow(ctx, t))
+    C, L, B = ops.Column, ops.Literal, ops.BinaryExpr
+
+    def run():
+        c = mk(cust)
+        if build_filter:
+            c = ops.CoalesceBatchesExec(ops.FilterExec(B(C("seg", 1), "=", L(2, pa.int32())), c), 8192)
+        c = ops.ProjectionExec([(C("c_key", 0), "c_key")], c)
+        o = ops.CoalesceBatchesExec(ops.FilterExec(B(C("o_date", 2), "<", L(8600, pa.int32())), mk(orders)), 8192)
+        j1 = ops.CoalesceBatchesExec(ops.HashJoinExec(c, o, [(C("c_key", 0), C("o_cust", 1))], None, "Inner", "CollectLeft"), 8192)       # c_key, o_key, o_cust, o_date
+        p1 = ops.ProjectionExec([(C("o_key", 1), "o_key"), (C("o_date", 3), "o_date")], j1)
+        j2 = ops.HashJoinExec(p1, mk(line), [(C("o_key", 0), C("l_key", 0))], None, "Inner", "CollectLeft")                                   # o_key, o_date, l_key, l_val
+        ctx.profile_select(None); ctx.profile_enable(True); ctx.profile_read()
+        try:
+            out = pa.concat_tables([b.to_arrow() for b in j2.execute(0, task_ctx)])
+            prof = ctx.profile_read()
+        finally:
+            ctx.profile_enable(False)
+        return out, prof
+
+    sel, prof = run()
+    ctx.set_option("join_selection_output", 0)
+    try:
+        plain, prof0 = run()
+    finally:
+        ctx.set_option("join_selection_output", 1)
+    assert sel.equals(plain)
+    keep_c = cust.filter(pc.equal(cust["seg"], 2)) if build_filter else cust
+    j1a = orders.filter(pc.less(orders["o_date"], 8600)).join(keep_c.select(["c_key"]), keys="o_cust", right_keys="c_key", join_type="inner")
+    want = line.join(j1a.select(["o_key", "o_date"]), keys="l_key", right_keys="o_key", join_type="inner", coalesce_keys=False)
+    assert sel.num_rows == want.num_rows and sel.num_rows > 1000
+    rows = lambda t: sorted(zip(t["o_key"].to_pylist(), t["o_date"].to_pylist(), t["l_key"].to_pylist(), t["l_val"].to_pylist()))
+    assert rows(sel) == rows(want)
+    assert sel["l_key"].to_pylist() == sorted(sel["l_key"].to_pylist())             # probe order kept
+    syncs = lambda p: sum(v[0] for k, v in p.items() if k.startswith("sync:"))
+    assert syncs(prof) < syncs(prof0), (prof, prof0)                                 # the first join's count is gone, and the second build's
