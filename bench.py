@@ -476,7 +476,7 @@ def main():
             del template, tables, tensors
             torch.cuda.empty_cache()
             res = bench_workloads.run(_ap.Namespace(sf=args.sf, steps=3, warmup=2, only=args.workloads), ctx=ctx, emit=False)
-            workloads = {r["workload"]: {k: r[k] for k in ("input_rows", "result_rows", "ms_per_step", "rows_per_s", "algorithmic_GBps", "frac_of_hbm_peak", "algorithmic_bytes_per_row", "roofline", "host_syncs_per_step", "result_check", "step_ms", "memory_GB") if k in r}
+            workloads = {r["workload"]: {k: r[k] for k in ("input_rows", "result_rows", "ms_per_step", "rows_per_s", "algorithmic_GBps", "frac_of_hbm_peak", "algorithmic_bytes_per_row", "roofline", "host_syncs_per_step", "host_syncs_by_cause", "result_check", "step_ms", "memory_GB") if k in r}
                          | {"kernel_ms_per_step": dict(list(r["kernel_ms_per_step"].items())[:8])} | {k: r[k] for k in r if k in ("cardinality", "build_rows", "probe_rows", "rows_per_build_key", "partitions", "exchange", "file_bytes", "decoded_bytes", "decoded_GBps", "file_GBps", "from_host_image_ms", "from_host_image_decoded_GBps", "row_groups",
                                                                                                                                                     "ms_per_step_median", "from_host_image_reads_ms", "host_image", "match_fraction", "global_table_ms_per_step", "hash_table_ms_per_step")} for r in res}
     else:

@@ -51,6 +51,7 @@ def wrap_dict(ctx, capi, keys, dictionary, key_type):
 
 KEEP = [False]             # True only while the last timed step runs: that step's output is what the result check reads
 STEP_MS = [None]           # wall time of every timed step of the most recent workload (reported next to the mean)
+SYNC_CAUSES = [None]       # the last measured workload's host read-backs by cause (from the bracketed step)
 LAST_OUT = [None]          # batches of the most recent plan step: what the result checks read (outside the timed region)
 
 
@@ -128,6 +129,7 @@ def time_plan(ctx, ops, tc, template, steps, warmup):
     STEP_MS[0] = per
     kern = {k: round(v[1], 3) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1][1]) if not k.startswith("sync:")}
     syncs = sum(v[0] for k, v in breakdown.items() if k.startswith("sync:"))
+    SYNC_CAUSES[0] = {k[5:]: v[0] for k, v in breakdown.items() if k.startswith("sync:")}
     return dt, rows, kern, syncs
 
 
@@ -170,6 +172,8 @@ def run(args, ctx=None, emit=True):
                 "algorithmic_bytes_per_row": bytes_per_row, "kernel_ms_per_step": kern, "host_syncs_per_step": syncs}
         if extra:
             line.update(extra)
+        if SYNC_CAUSES[0] is not None:
+            line["host_syncs_by_cause"] = SYNC_CAUSES[0]; SYNC_CAUSES[0] = None
         if STEP_MS[0]:
             line["step_ms"] = STEP_MS[0]; line["ms_per_step_median"] = sorted(STEP_MS[0])[len(STEP_MS[0]) // 2]; STEP_MS[0] = None       # ms_per_step is the mean over the timed loop; one slow step of three shows here
         KEEP[0] = False

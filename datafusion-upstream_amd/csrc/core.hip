@@ -280,6 +280,7 @@ static dfgpu_array* import_desc(dfgpu_ctx* ctx, const dfgpu_array_desc* d, bool 
   ArrayHolder h(new_array(ctx, d->type, d->length, d->precision, d->scale));
   dfgpu_array* a = h.get();
   a->null_count = d->validity ? d->null_count : 0; a->key_type = d->key_type;
+  a->base_column = true;          // handed in by the caller (a table column, a scan's output): it outlives the operators that read it, so statistics memoised on it pay off
   int64_t n = d->length;
   size_t vbytes;
   int32_t vt = d->type == DFGPU_DICTIONARY ? d->key_type : d->type;
@@ -380,6 +381,7 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "join_rank_index_unsorted") ctx->join_rank_index_unsorted = value != 0;
     else if (k == "join_lazy_build_rows") ctx->join_lazy_build_rows = value != 0;
     else if (k == "join_selection_output") ctx->join_selection_output = value != 0;
+    else if (k == "agg_order_inverse_map") ctx->agg_order_inverse_map = value != 0;
     else if (k == "join_bitmap_partitioned") ctx->join_bitmap_partitioned = value != 0;
     else if (k == "join_bitmap_partitioned_min_rows") ctx->join_bitmap_partitioned_min_rows = value;
     else if (k == "join_key_packing") ctx->join_key_packing = value != 0;
@@ -430,6 +432,7 @@ dfgpu_status dfgpu_ctx_get_option(dfgpu_ctx* ctx, const char* key, int64_t* out)
     else if (k == "join_rank_index_unsorted") *out = ctx->join_rank_index_unsorted ? 1 : 0;
     else if (k == "join_lazy_build_rows") *out = ctx->join_lazy_build_rows ? 1 : 0;
     else if (k == "join_selection_output") *out = ctx->join_selection_output ? 1 : 0;
+    else if (k == "agg_order_inverse_map") *out = ctx->agg_order_inverse_map ? 1 : 0;
     else if (k == "join_bitmap_partitioned") *out = ctx->join_bitmap_partitioned ? 1 : 0;
     else if (k == "join_bitmap_partitioned_min_rows") *out = ctx->join_bitmap_partitioned_min_rows;
     else if (k == "join_key_packing") *out = ctx->join_key_packing;

@@ -58,6 +58,7 @@ struct dfgpu_ctx {
   int64_t fused_aggregate_min_rows = 1 << 20;
   bool sort_packed_keys = true;     // large sorts over fixed-width keys: range-packed u64 keys + stable one-pass partition per digit (sort.hip)
   bool agg_partitioned = true, agg_partitioned_force = false; int64_t agg_partitioned_min_rows = 1 << 22;      // partitioned pre-aggregation (pagg.hip)
+  bool agg_order_inverse_map = true;   // pre-aggregation with millions of partial rows: first-seen order through an inverse map over the input rows (pagg.hip) instead of a stable sort
   int64_t agg_pack_estimate_min_rows = 1 << 22;   // packed group keys: batches of at least this many rows take their value ranges from a sample (checked row by row while packing)
   bool pa_last_distinct = false;    // the last dfgpu_agg_preaggregate call emitted every key once
   const void* pa_sample_key = nullptr; const void* pa_sample_mask = nullptr; int64_t pa_sample_n = 0; uint64_t pa_sample[3] = {0, 0, 0};   // sample of a verdict-only dfgpu_agg_preaggregate call
@@ -139,6 +140,7 @@ struct dfgpu_array {
   // an index array known to be 0, 1, .., length - 1 (a compaction that kept every row, the probe indices of a join whose probe rows
   // all matched once): gathering through it is the identity
   bool identity = false;
+  bool base_column = false;     // imported / wrapped by the caller rather than computed by an operator
   std::shared_ptr<const dfgpu::OrderStats> order_stats;      // read / written through order_stats_get / order_stats_set (a lock: plan partitions share arrays)
 };
 
@@ -221,7 +223,7 @@ void exclusive_scan_u32_inplace32(dfgpu_ctx* ctx, uint32_t* data, int64_t n, uin
 dfgpu_array* take_impl(dfgpu_ctx* ctx, const dfgpu_array* values, const void* idx, int idx_width, const uint64_t* idx_validity, int64_t n_out);
 dfgpu_array* mask_to_indices_impl(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n);
 dfgpu_array* mask_to_indices_checked(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n, int check_slot, uint64_t* check_value);
-dfgpu_array* mask_to_indices_uncounted(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n);      // n entries, the first popcount(bits) written; no read-back (internal rank -> row tables)
+dfgpu_array* mask_to_indices_uncounted(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n, uint64_t* d_count = nullptr);      // d_count: device word that receives the number of entries written      // n entries, the first popcount(bits) written; no read-back (internal rank -> row tables)
 int64_t count_set_bits(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n);
 inline const uint64_t* row_selection_words(dfgpu_ctx* ctx, int64_t n) { return ctx->row_selection && ctx->row_selection_len == n ? (const uint64_t*)ctx->row_selection->ptr : nullptr; }
 

@@ -205,7 +205,7 @@ dfgpu_status dfgpu_exchange(dfgpu_ctx* ctx, dfgpu_comm* comm, const dfgpu_array*
     // allocation can fail without a memory limit too, and a per-ctx option may differ between ranks -- so that no rank enters the group alone.
     struct Lane { const uint8_t* sp; uint8_t* rp; std::vector<int64_t> sb, rb; };
     std::vector<Lane> lanes; std::vector<BufferPtr> keep;
-    std::vector<BufferPtr> r_vals((size_t)ncols), r_len((size_t)ncols), r_valid((size_t)ncols); std::vector<int64_t> r_bytes((size_t)ncols, 0);
+    std::vector<BufferPtr> r_vals((size_t)ncols), r_len((size_t)ncols), r_valid((size_t)ncols), o_bits((size_t)ncols), o_vbits((size_t)ncols); std::vector<int64_t> r_bytes((size_t)ncols, 0);      // o_bits / o_vbits: the Boolean values / validity bitmaps of the output arrays (every allocation of the call happens before the status round)
     BufferPtr ones; int64_t alloc_status = DFGPU_OK; std::string alloc_err;
     auto fixed_lane = [&](const void* sp, void* rp, int64_t w) { Lane l{ (const uint8_t*)sp, (uint8_t*)rp, std::vector<int64_t>((size_t)W), std::vector<int64_t>((size_t)W) }; for (int32_t p = 0; p < W; p++) { l.sb[(size_t)p] = send_rows[(size_t)p] * w; l.rb[(size_t)p] = recv_rows[(size_t)p] * w; } lanes.push_back(std::move(l)); };
     try {
@@ -219,7 +219,7 @@ dfgpu_status dfgpu_exchange(dfgpu_ctx* ctx, dfgpu_comm* comm, const dfgpu_array*
           r_vals[(size_t)c] = alloc_buffer(ctx, (size_t)r_bytes[(size_t)c] + 8); l.rp = (uint8_t*)r_vals[(size_t)c]->ptr;
           lanes.push_back(std::move(l));
         } else if (m.type == DFGPU_BOOL) {
-          r_vals[(size_t)c] = alloc_buffer(ctx, (size_t)total + 1);
+          r_vals[(size_t)c] = alloc_buffer(ctx, (size_t)total + 1); o_bits[(size_t)c] = alloc_buffer(ctx, bitmap_bytes(total), true);
           fixed_lane(g ? bbytes[(size_t)c]->ptr : nullptr, r_vals[(size_t)c]->ptr, 1);
         } else {
           const int64_t w = type_width(m.type);
@@ -227,7 +227,7 @@ dfgpu_status dfgpu_exchange(dfgpu_ctx* ctx, dfgpu_comm* comm, const dfgpu_array*
           fixed_lane(g ? g->values->ptr : nullptr, r_vals[(size_t)c]->ptr, w);
         }
         if (!m.nullable) continue;
-        r_valid[(size_t)c] = alloc_buffer(ctx, (size_t)total + 1);
+        r_valid[(size_t)c] = alloc_buffer(ctx, (size_t)total + 1); o_vbits[(size_t)c] = alloc_buffer(ctx, bitmap_bytes(total), true);
         const void* vp = vbytes[(size_t)c] ? vbytes[(size_t)c]->ptr : nullptr;
         if (!vp && sent) {          // nullable on another rank only: this rank's rows are all valid
           if (!ones) { ones = alloc_buffer(ctx, (size_t)sent); HIP_CHECK(hipMemsetAsync(ones->ptr, 1, (size_t)sent, ctx->stream)); }
@@ -266,17 +266,17 @@ dfgpu_status dfgpu_exchange(dfgpu_ctx* ctx, dfgpu_comm* comm, const dfgpu_array*
       const Meta& m = meta[(size_t)c];
       ArrayHolder o(new_array(ctx, m.type, total, m.precision, m.scale));
       if (m.type == DFGPU_UTF8) {
-        o.get()->offsets = alloc_buffer(ctx, (size_t)(total + 1) * 4); o.get()->values = r_vals[(size_t)c]; o.get()->values_bytes = r_bytes[(size_t)c];
+        o.get()->values = r_vals[(size_t)c]; o.get()->values_bytes = r_bytes[(size_t)c];
         HIP_CHECK(hipMemsetAsync((uint8_t*)r_len[(size_t)c]->ptr + (size_t)total * 4, 0, 4, ctx->stream));
         exclusive_scan_u32_inplace32(ctx, (uint32_t*)r_len[(size_t)c]->ptr, total + 1, nullptr);
         o.get()->offsets = r_len[(size_t)c];
       } else if (m.type == DFGPU_BOOL) {
-        o.get()->values = alloc_buffer(ctx, bitmap_bytes(total), true);
+        o.get()->values = o_bits[(size_t)c];
         if (total) hipLaunchKernelGGL(k_bytes_to_bits, dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint8_t*)r_vals[(size_t)c]->ptr, total, (uint64_t*)o.get()->values->ptr);
       } else o.get()->values = r_vals[(size_t)c];
       o.get()->null_count = 0;
       if (m.nullable) {
-        o.get()->validity = alloc_buffer(ctx, bitmap_bytes(total), true); o.get()->null_count = -1;
+        o.get()->validity = o_vbits[(size_t)c]; o.get()->null_count = -1;
         if (total) hipLaunchKernelGGL(k_bytes_to_bits, dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint8_t*)r_valid[(size_t)c]->ptr, total, (uint64_t*)o.get()->validity->ptr);
       }
       KERNEL_CHECK();

@@ -324,6 +324,25 @@ __global__ void __launch_bounds__(BLOCK) k_key_setbits_masked(const T* keys, con
   int64_t nxt = __shfl_down(w, 1, 64);
   if (on && (lane == WAVE - 1 || nxt != w)) atomicOr((unsigned long long*)&bitmap[w], (unsigned long long)b);
 }
+// The same over a LIST of rows whose length is a device word (mask_to_indices_uncounted): a selection that keeps one row in ten of a 150 M-row column would spend the
+// kernel above on 150 M lanes for 15 M bits (SF100 Q3's join of lineitem with the orders the first join selected: 0.68 ms); here the 15 M selected rows fill the lanes.
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_key_setbits_rows(const T* keys, const uint32_t* rows, const unsigned long long* d_count, int64_t kmin, uint64_t* bitmap) {
+  const int64_t m = (int64_t)*d_count; const int lane = lane_id();
+  for (int64_t j0 = (int64_t)blockIdx.x * BLOCK; j0 < m; j0 += (int64_t)gridDim.x * BLOCK) {
+    const int64_t j = j0 + threadIdx.x; const bool on = j < m;
+    uint64_t d = on ? (uint64_t)((int64_t)keys[rows[j]] - kmin) : 0;
+    int64_t w = on ? (int64_t)(d >> 6) : -1 - lane;
+    uint64_t b = on ? 1ull << (d & 63) : 0ull;
+#pragma unroll
+    for (int s2 = 1; s2 < WAVE; s2 <<= 1) {
+      uint64_t ob = __shfl_up(b, s2, 64); int64_t ow = __shfl_up(w, s2, 64);
+      if (lane >= s2 && ow == w) b |= ob;
+    }
+    int64_t nxt = __shfl_down(w, 1, 64);
+    if (on && (lane == WAVE - 1 || nxt != w)) atomicOr((unsigned long long*)&bitmap[w], (unsigned long long)b);
+  }
+}
 __global__ void __launch_bounds__(BLOCK) k_popc_words(const uint64_t* words, int64_t nw, uint32_t* out) {
   int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i < nw) out[i] = (uint32_t)__popcll(words[i]);
@@ -565,16 +584,22 @@ static bool build_rank_index(dfgpu_ctx* ctx, dfgpu_join_table* t) {
     HIP_CHECK(hipMemsetAsync(t->bitmap->ptr, t->rank_identity ? 0xFF : 0, bitmap_bytes((int64_t)range), ctx->stream));   // bits >= range are never read as set: probes test d < range
   }
   if (!t->rank_identity) {
-    DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_setbits_masked<T>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, mk, n, (int64_t)lo, (uint64_t*)t->bitmap->ptr));
+    // masked build: rank -> build row; runs: rank -> first row of the run.  A plain masked build only ever reads entries below the number of set bits (a rank), so the table
+    // is written without the host learning that number (one read-back less per build; the count stays in a device word); the run path walks to sel_rows[r + 1] and needs the exact length.
+    if (mk && !runs && n <= 0xFFFFFFF0ll) {
+      t->sel_rows = mask_to_indices_uncounted(ctx, mk, n, ctx->d_scratch64 + 15); t->mem += t->sel_rows->length * 4;
+      DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_setbits_rows<T>), dim3(grid_for(n, BLOCK, ctx->num_cus * 16)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, (const uint32_t*)t->sel_rows->values->ptr,
+                                                            (const unsigned long long*)(ctx->d_scratch64 + 15), (int64_t)lo, (uint64_t*)t->bitmap->ptr));
+    } else {
+      DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_setbits_masked<T>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const T*)kv, mk, n, (int64_t)lo, (uint64_t*)t->bitmap->ptr));
+      if (mk) { t->sel_rows = mask_to_indices_impl(ctx, mk, n); t->mem += t->sel_rows->length * 4; }
+    }
     KERNEL_CHECK();
     t->rank_prefix = alloc_buffer(ctx, (size_t)nw * 4);
     hipLaunchKernelGGL(k_popc_words, dim3(grid_for(nw, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)t->bitmap->ptr, nw, (uint32_t*)t->rank_prefix->ptr);
     exclusive_scan_u32_inplace32(ctx, (uint32_t*)t->rank_prefix->ptr, nw, nullptr);
     KERNEL_CHECK();
     t->mem += nw * 4;
-    // masked build: rank -> build row; runs: rank -> first row of the run.  A plain masked build only ever reads entries below the number of set bits (a rank), so the table
-    // is written without the host learning that number (one read-back less per build); the run path walks to sel_rows[r + 1] and needs the exact length.
-    if (mk) { t->sel_rows = runs ? mask_to_indices_impl(ctx, mk, n) : mask_to_indices_uncounted(ctx, mk, n); t->mem += t->sel_rows->length * 4; }
   }
   return true;
 }

@@ -25,9 +25,12 @@ constexpr uint64_t PA_EMPTY = ~0ull;
 constexpr int PA_NT = 1024;
 constexpr int PA_MAX_AGGS = 6;
 enum { PA_SUM_I64 = 0, PA_SUM_F64 = 1, PA_MIN_I64 = 2, PA_MAX_I64 = 3, PA_MIN_U64 = 4, PA_MAX_U64 = 5, PA_MIN_F64 = 6, PA_MAX_F64 = 7, PA_NONE = 8,
-       PA_SUM_I128_LO = 9, PA_SUM_I128_HI = 10, PA_SUM_I128_SX = 11 };      // SX: the high word is the sign extension of the low one (Decimal128 of precision <= 18 moves 8 bytes per row through the partition)      // Decimal128 SUM / AVG: two neighbouring cells, the low add's returned value gives the carry (exact mod 2^128, as acc.hip does in HBM)
+       PA_SUM_I128_LO = 9, PA_SUM_I128_HI = 10, PA_SUM_I128_SX = 11,
+       PA_COUNT_FLAG = 12 };      // COUNT_FLAG: the cell counts the rows whose flag bit is set (the non-NULL values of a nullable argument): a wrapping Int64 sum of the bit      // SX: the high word is the sign extension of the low one (Decimal128 of precision <= 18 moves 8 bytes per row through the partition)      // Decimal128 SUM / AVG: two neighbouring cells, the low add's returned value gives the carry (exact mod 2^128, as acc.hip does in HBM)
 
-struct PaPlan { int32_t n_acc; int32_t op[PA_MAX_AGGS]; const uint64_t* val[PA_MAX_AGGS]; int32_t vstride[PA_MAX_AGGS]; uint64_t* out[PA_MAX_AGGS]; int32_t has_i128; };      // val[a][i * vstride[a]]: a Decimal128 column is two cells of stride 2
+// Nullable arguments: the validity bits of the (at most 8) nullable value columns travel through the partition as ONE byte per row (vflag; bit b = value column b is valid in
+// that row).  flag_bit[a] >= 0: cell a takes its row's value only where that bit is set (a NULL adds the operation's identity, i.e. nothing); a COUNT_FLAG cell sums the bit.
+struct PaPlan { int32_t n_acc; int32_t op[PA_MAX_AGGS]; const uint64_t* val[PA_MAX_AGGS]; int32_t vstride[PA_MAX_AGGS]; uint64_t* out[PA_MAX_AGGS]; int32_t has_i128; const uint8_t* vflag; int32_t flag_bit[PA_MAX_AGGS]; };      // val[a][i * vstride[a]]: a Decimal128 column is two cells of stride 2
 
 __device__ inline uint64_t pa_identity(int op) {
   switch (op) {
@@ -38,7 +41,7 @@ __device__ inline uint64_t pa_identity(int op) {
 }
 __device__ inline void pa_apply(int op, unsigned long long* cell, uint64_t v) {
   switch (op) {
-    case PA_SUM_I64: atomicAdd(cell, (unsigned long long)v); break;                                   // wrapping, sum.rs:137
+    case PA_SUM_I64: case PA_COUNT_FLAG: atomicAdd(cell, (unsigned long long)v); break;                                   // wrapping, sum.rs:137
     case PA_SUM_F64: atomicAdd((double*)cell, __longlong_as_double((long long)v)); break;
     case PA_MIN_I64: atomicMin((long long*)cell, (long long)v); break; case PA_MAX_I64: atomicMax((long long*)cell, (long long)v); break;
     case PA_MIN_U64: atomicMin(cell, (unsigned long long)v); break; case PA_MAX_U64: atomicMax(cell, (unsigned long long)v); break;
@@ -49,7 +52,7 @@ __device__ inline void pa_apply(int op, unsigned long long* cell, uint64_t v) {
 }
 __device__ inline uint64_t pa_combine(int op, uint64_t a, uint64_t b) {          // what pa_apply's atomic does, on two values
   switch (op) {
-    case PA_SUM_I64: return a + b;
+    case PA_SUM_I64: case PA_COUNT_FLAG: return a + b;
     case PA_SUM_F64: return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
     case PA_MIN_I64: return (long long)a < (long long)b ? a : b; case PA_MAX_I64: return (long long)a > (long long)b ? a : b;
     case PA_MIN_U64: return a < b ? a : b; case PA_MAX_U64: return a > b ? a : b;
@@ -145,9 +148,21 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
   // the next chunk's row (key, row number, value cells) is loaded while the current one goes through the table
   uint64_t kn = 0, vn[PA_MAX_AGGS]; uint32_t rn = 0;
   const int na = plan_arg.n_acc;
-  { const uint32_t i = q0 + threadIdx.x, ic = i < q1 ? i : q1 - 1; kn = pkey[ic]; rn = prow[ic];
+  const uint8_t* vflag = plan_arg.vflag;
+  // a row's cells as the table takes them: the value, or -- for a cell bound to a flag bit -- the operation's identity where the bit is clear (a NULL argument), the bit itself for a COUNT_FLAG cell
+  auto load_cells = [&](uint32_t ic, uint64_t* v) {
 #pragma unroll
-    for (int a = 0; a < PA_MAX_AGGS; a++) vn[a] = a < na ? plan_arg.val[a][I128 ? (size_t)ic * plan_arg.vstride[a] : (size_t)ic] : 0; }
+    for (int a = 0; a < PA_MAX_AGGS; a++) v[a] = a < na && plan_arg.val[a] ? plan_arg.val[a][I128 ? (size_t)ic * plan_arg.vstride[a] : (size_t)ic] : 0;
+    if (vflag) {
+      const uint32_t f = vflag[ic];
+#pragma unroll
+      for (int a = 0; a < PA_MAX_AGGS; a++) if (a < na && plan_arg.flag_bit[a] >= 0) {
+        const bool set = (f >> plan_arg.flag_bit[a]) & 1u; const int op = plan_arg.op[a];
+        v[a] = op == PA_COUNT_FLAG ? (uint64_t)set : set ? v[a] : (op == PA_SUM_I128_LO || op == PA_SUM_I128_HI || op == PA_SUM_I128_SX) ? 0ull : pa_identity(op);
+      }
+    }
+  };
+  { const uint32_t i = q0 + threadIdx.x, ic = i < q1 ? i : q1 - 1; kn = pkey[ic]; rn = prow[ic]; load_cells(ic, vn); }
   for (uint32_t i0 = q0; i0 < q1; i0 += PA_NT) {
     if (nfilled + PA_NT > C - C / 8) { __syncthreads(); flush(); reset(); if (threadIdx.x == 0) atomicAdd(cursor + 2, 1ull); __syncthreads(); }      // nfilled is only written between barriers: uniform
     const uint32_t i = i0 + threadIdx.x; const bool on = i < q1;
@@ -155,9 +170,7 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
     if (P1 && on && (i & 3u) == 0 && pa_fine_pid(k, P1, P2) != p) *misplaced = 1u;     // the partition bounds came from a binary search that relies on the order the two passes leave: every 4th row re-hashed as an assertion
 #pragma unroll
     for (int a = 0; a < PA_MAX_AGGS; a++) v[a] = vn[a];
-    { const uint32_t i2 = i + PA_NT, ic = i2 < q1 ? i2 : q1 - 1; kn = pkey[ic]; rn = prow[ic];
-#pragma unroll
-      for (int a = 0; a < PA_MAX_AGGS; a++) vn[a] = a < na ? plan_arg.val[a][I128 ? (size_t)ic * plan_arg.vstride[a] : (size_t)ic] : 0; }
+    { const uint32_t i2 = i + PA_NT, ic = i2 < q1 ? i2 : q1 - 1; kn = pkey[ic]; rn = prow[ic]; load_cells(ic, vn); }
     // Skewed keys: when at least 16 lanes of a wave carry the key of its first active lane, those lanes are combined in registers (shuffles) and the leader
     // alone touches the table: one LDS atomic per state instead of one per row on a slot every wave of the workgroup is hammering.
     uint32_t cntv = 1; uint32_t rowv = row; bool mine = on;
@@ -274,7 +287,34 @@ __global__ void __launch_bounds__(BLOCK) k_pa_rank_perm(const uint32_t* __restri
   perm[r] = (uint32_t)i;
 }
 
-// many partial rows: (first row << jb | partial row) words through LSD passes of the stable partition, 8 bytes moving per row and pass
+// Many partial rows (millions): the inverse map.  inv[first row of partial row j] = j is one random 4-byte store per partial row into an n-entry array; the permutation in
+// first-seen order is then the non-empty entries of inv in array order -- two streaming passes (count, write) instead of four passes of a stable sort over (first row, j) words
+// (20 M partial rows of 100 M input rows: 1.3 ms of sort passes).  First rows are distinct (a row belongs to one partial row), so the stores never collide.
+constexpr int INV_PER = 16;             // consecutive entries per lane
+__global__ void __launch_bounds__(BLOCK) k_pa_inv(const uint32_t* __restrict__ first, int64_t m, uint32_t* __restrict__ inv) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < m) inv[first[i]] = (uint32_t)i;
+}
+template <bool WRITE>
+__global__ void __launch_bounds__(BLOCK) k_pa_inv_compact(const uint32_t* __restrict__ inv, int64_t n, uint32_t* __restrict__ counts, uint32_t* __restrict__ perm) {
+  const int64_t base = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * INV_PER;
+  uint32_t v[INV_PER]; uint32_t c = 0;
+  if (base + INV_PER <= n) {
+#pragma unroll
+    for (int q = 0; q < INV_PER / 4; q++) { const uint4 x = ((const uint4*)(inv + base))[q]; v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w; }
+  } else {
+#pragma unroll
+    for (int q = 0; q < INV_PER; q++) v[q] = base + q < n ? inv[base + q] : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int q = 0; q < INV_PER; q++) c += v[q] != 0xFFFFFFFFu;
+  __shared__ uint32_t lds[BLOCK / WAVE];
+  uint32_t tot; uint32_t ex = block_exclusive_sum<uint32_t>(c, lds, &tot);
+  if (!WRITE) { if (threadIdx.x == 0) counts[blockIdx.x] = tot; return; }
+  uint32_t o = counts[blockIdx.x] + ex;
+#pragma unroll
+  for (int q = 0; q < INV_PER; q++) if (v[q] != 0xFFFFFFFFu) perm[o++] = v[q];
+}
+// many partial rows, general form: (first row << jb | partial row) words through LSD passes of the stable partition, 8 bytes moving per row and pass
 __global__ void __launch_bounds__(BLOCK) k_pa_order_words(const uint32_t* __restrict__ first, int64_t m, int jb, uint64_t* __restrict__ words) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < m) words[i] = ((uint64_t)first[i] << jb) | (uint64_t)i;
 }
@@ -341,6 +381,21 @@ __global__ void __launch_bounds__(BLOCK) k_pa_unpack(const uint64_t* packed, int
   if (valid) { const uint64_t b = ballot64(i < m && ok); if (lane_id() == 0 && i < ((m + 63) / 64) * 64) valid[i >> 6] = b; }
 }
 
+struct PaFlagCols { int32_t n; const uint64_t* valid[8]; };
+__global__ void __launch_bounds__(BLOCK) k_pa_flags(PaFlagCols fc, int64_t n, uint8_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i >= n) return;
+  uint32_t f = 0;
+#pragma unroll
+  for (int b = 0; b < 8; b++) if (b < fc.n) f |= (uint32_t)bit_get(fc.valid[b], i) << b;
+  out[i] = (uint8_t)f;
+}
+// validity bitmap of a state column: a group whose nullable argument held no value has a NULL state
+__global__ void __launch_bounds__(BLOCK) k_pa_state_valid(const uint64_t* __restrict__ nvalid, int64_t m, uint64_t* __restrict__ valid) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const uint64_t b = ballot64(i < m && nvalid[i] != 0);
+  if (lane_id() == 0 && i < ((m + 63) / 64) * 64) valid[i >> 6] = b;
+}
+
 static bool pa_key_type_ok(int32_t t) { return t == DFGPU_INT64 || t == DFGPU_UINT64 || t == DFGPU_INT32 || t == DFGPU_UINT32 || t == DFGPU_DATE32; }
 
 }  // namespace dfgpu
@@ -368,10 +423,22 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     if (n < ctx->agg_partitioned_min_rows || n > 0xFFFF0000ll) skip("batch below agg_partitioned_min_rows");
     if (n_aggs > 16) skip("at most 16 aggregates");
     // accumulator plan: one 8-byte LDS cell per SUM / MIN / MAX; COUNT and AVG counts come from the row count (value columns carry no NULLs)
-    PaPlan plan{}; int cell_of[16]; const dfgpu_array* cell_src[PA_MAX_AGGS]; int cell_word[PA_MAX_AGGS];      // cell c reads word cell_word[c] of its source's rows
+    // A nullable argument (accumulate.rs:126-233: NULL values take no part; a group that saw none has a NULL state): its validity travels as one bit of a per-row flag byte,
+    // its cells skip the NULL rows, and one COUNT_FLAG cell per nullable column counts the values seen -- COUNT(x), AVG's count and the validity of SUM / MIN / MAX states.
+    PaPlan plan{}; int cell_of[16], nvalid_of[16]; const dfgpu_array* cell_src[PA_MAX_AGGS]; int cell_word[PA_MAX_AGGS];      // cell c reads word cell_word[c] of its source's rows
+    for (int c = 0; c < PA_MAX_AGGS; c++) { plan.flag_bit[c] = -1; cell_src[c] = nullptr; }
+    const dfgpu_array* flag_src[8]; int n_flags = 0;
+    auto flag_of = [&](const dfgpu_array* v) { for (int b = 0; b < n_flags; b++) if (flag_src[b] == v) return b; if (n_flags == 8) skip("at most 8 nullable value columns"); flag_src[n_flags] = v; return n_flags++; };
+    auto count_cell = [&](const dfgpu_array* v) {           // the COUNT_FLAG cell of a nullable column (one per column)
+      const int b = flag_of(v);
+      for (int j = 0; j < plan.n_acc; j++) if (plan.op[j] == PA_COUNT_FLAG && plan.flag_bit[j] == b) return j;
+      if (plan.n_acc + 1 > PA_MAX_AGGS) skip("at most 6 accumulator cells (a nullable argument takes one more for its count)");
+      const int c = plan.n_acc++; plan.op[c] = PA_COUNT_FLAG; plan.flag_bit[c] = b; cell_src[c] = nullptr; cell_word[c] = 0; return c;
+    };
     for (int i = 0; i < n_aggs; i++) {
-      const dfgpu_array* v = values[i]; cell_of[i] = -1;
-      if (v && (v->validity || v->length != n || v->type == DFGPU_DICTIONARY)) skip("value columns without NULLs");
+      const dfgpu_array* v = values[i]; cell_of[i] = -1; nvalid_of[i] = -1;
+      if (v && (v->length != n || v->type == DFGPU_DICTIONARY)) skip("value columns of the batch's length, not dictionary-encoded");
+      if (v && v->validity) nvalid_of[i] = count_cell(v);
       if (kinds[i] == DFGPU_AGG_COUNT) continue;
       if (!v) skip("aggregate without an argument");
       int op = PA_NONE;
@@ -389,14 +456,15 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
         const int need = d128 ? 2 : 1;
         if (plan.n_acc + need > PA_MAX_AGGS) skip("at most 6 accumulator cells (a Decimal128 sum takes two)");
         c = plan.n_acc; plan.n_acc += need; plan.op[c] = op; cell_src[c] = v; cell_word[c] = 0;
+        const int fbit = v->validity ? flag_of(v) : -1; plan.flag_bit[c] = fbit;
         if (d128) { const bool fits64 = v->precision > 0 && v->precision <= 18;      // |unscaled value| < 10^18 < 2^63: the high word carries no information
-          plan.op[c + 1] = fits64 ? PA_SUM_I128_SX : PA_SUM_I128_HI; cell_src[c + 1] = v; cell_word[c + 1] = fits64 ? 0 : 1; plan.has_i128 = 1; }
+          plan.op[c + 1] = fits64 ? PA_SUM_I128_SX : PA_SUM_I128_HI; cell_src[c + 1] = v; cell_word[c + 1] = fits64 ? 0 : 1; plan.flag_bit[c + 1] = fbit; plan.has_i128 = 1; }
       }
       cell_of[i] = c;
     }
     // the distinct value columns the partition moves (a Decimal128 column once, 16 bytes wide)
     const dfgpu_array* srcs[PA_MAX_AGGS]; int n_src = 0, src_of[PA_MAX_AGGS];
-    for (int c = 0; c < plan.n_acc; c++) { int j = -1; for (int q = 0; q < n_src; q++) if (srcs[q] == cell_src[c]) j = q; if (j < 0) { j = n_src; srcs[n_src++] = cell_src[c]; } src_of[c] = j; }
+    for (int c = 0; c < plan.n_acc; c++) { src_of[c] = -1; if (!cell_src[c]) continue; int j = -1; for (int q = 0; q < n_src; q++) if (srcs[q] == cell_src[c]) j = q; if (j < 0) { j = n_src; srcs[n_src++] = cell_src[c]; } src_of[c] = j; }
     const uint64_t* mk = nullptr; BufferPtr mask = effective_mask(ctx, opt_mask, n); if (mask) mk = (const uint64_t*)mask->ptr;
     // ---- sample: clustered? how many groups?  (a verdict-only call leaves its sample for the call that follows on the same column)
     const int64_t s = n < (1 << 19) ? n : (1 << 19), stride = n / s; const uint64_t cap = 1ull << 21;
@@ -483,12 +551,22 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     else { if (P > n / 2048 + 1) P = n / 2048 + 1; if (P > ctx->num_cus) P = std::min<int64_t>(2048, (P + ctx->num_cus - 1) / ctx->num_cus * ctx->num_cus); P1 = P; }
     // ---- partition (key, row, value cells)
     BufferPtr pkey = alloc_buffer(ctx, (size_t)n * 8), prow = alloc_buffer(ctx, (size_t)n * 4); std::vector<BufferPtr> pval((size_t)n_src);
-    RpCols cols{}; cols.n = 1 + n_src; cols.rowid_dst = (uint32_t*)prow->ptr;
+    // the flag byte of every row: bit b = nullable value column b holds a value there
+    BufferPtr flags_in, pflag;
+    if (n_flags) {
+      flags_in = alloc_buffer(ctx, (size_t)n + 64); pflag = alloc_buffer(ctx, (size_t)n + 64);
+      PaFlagCols fc{}; fc.n = n_flags; for (int b = 0; b < n_flags; b++) fc.valid[b] = (const uint64_t*)flag_src[b]->validity->ptr;
+      hipLaunchKernelGGL(k_pa_flags, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, fc, n, (uint8_t*)flags_in->ptr);
+      KERNEL_CHECK();
+    }
+    RpCols cols{}; cols.n = 1 + n_src + (n_flags ? 1 : 0); cols.rowid_dst = (uint32_t*)prow->ptr;
+    if (n_flags) cols.c[1 + n_src] = RpCol{ flags_in->ptr, pflag->ptr, 1, RP_RAW, 0 };
     cols.c[0] = RpCol{ kptr, pkey->ptr, 8, RP_HASHKEY, ktype };
     auto lo16 = [&](int j) { return srcs[j]->type == DFGPU_DECIMAL128 && srcs[j]->precision > 0 && srcs[j]->precision <= 18; };
     auto src_width = [&](int j) { return srcs[j]->type == DFGPU_DECIMAL128 && !lo16(j) ? 16 : 8; };
     for (int j = 0; j < n_src; j++) { pval[(size_t)j] = alloc_buffer(ctx, (size_t)n * (size_t)src_width(j)); cols.c[1 + j] = RpCol{ srcs[j]->values->ptr, pval[(size_t)j]->ptr, 8 * (src_width(j) / 8), lo16(j) ? RP_LO16 : RP_RAW, 0 }; }
-    auto bind_cells = [&]() { for (int c = 0; c < plan.n_acc; c++) { const int j = src_of[c]; plan.vstride[c] = src_width(j) / 8; plan.val[c] = (const uint64_t*)pval[(size_t)j]->ptr + cell_word[c]; } };
+    auto bind_cells = [&]() { plan.vflag = n_flags ? (const uint8_t*)pflag->ptr : nullptr;
+      for (int c = 0; c < plan.n_acc; c++) { const int j = src_of[c]; if (j < 0) { plan.vstride[c] = 1; plan.val[c] = nullptr; continue; } plan.vstride[c] = src_width(j) / 8; plan.val[c] = (const uint64_t*)pval[(size_t)j]->ptr + cell_word[c]; } };
     bind_cells();
     RpResult r;
 #define PA_PART(T) r = rp_partition(ctx, RpHashInt<T>{ (const T*)kptr, nullptr, mk }, n, (uint32_t)P1, cols, false, ctx->d_scratch64 + 9, "pa_hist", "pa_scan", "pa_scatter")
@@ -498,11 +576,14 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     if (two_level) {
       const int64_t m1 = mk ? (int64_t)read_scratch(ctx, 9) : n;          // rows the selection kept
       BufferPtr pkey2 = alloc_buffer(ctx, (size_t)n * 8), prow2 = alloc_buffer(ctx, (size_t)n * 4); std::vector<BufferPtr> pval2((size_t)n_src);
-      RpCols c2{}; c2.n = 2 + n_src;
+      BufferPtr pflag2; if (n_flags) pflag2 = alloc_buffer(ctx, (size_t)n + 64);
+      RpCols c2{}; c2.n = 2 + n_src + (n_flags ? 1 : 0);
+      if (n_flags) c2.c[2 + n_src] = RpCol{ pflag->ptr, pflag2->ptr, 1, RP_RAW, 0 };
       c2.c[0] = RpCol{ pkey->ptr, pkey2->ptr, 8, RP_RAW, 0 }; c2.c[1] = RpCol{ prow->ptr, prow2->ptr, 4, RP_RAW, 0 };
       for (int j = 0; j < n_src; j++) { pval2[(size_t)j] = alloc_buffer(ctx, (size_t)n * (size_t)src_width(j)); c2.c[2 + j] = RpCol{ pval[(size_t)j]->ptr, pval2[(size_t)j]->ptr, src_width(j), RP_RAW, 0 }; }
       (void)rp_partition(ctx, RpHashU64Low{ (const uint64_t*)pkey->ptr }, m1, (uint32_t)P2, c2, true, ctx->d_scratch64 + 10, "pa_hist2", "pa_scan2", "pa_scatter2", true, true);
       pkey = pkey2; prow = prow2; for (int j = 0; j < n_src; j++) pval[(size_t)j] = pval2[(size_t)j];
+      if (n_flags) pflag = pflag2;
       bind_cells();
       HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 11, 0, 8, ctx->stream));
       r.starts = alloc_buffer(ctx, (size_t)(P + 1) * 4); r.P = (uint32_t)P;
@@ -541,7 +622,7 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     // every key left in exactly one partial row unless a hot partition was cut into slices or a table overflowed mid-partition: the plan layer then
     // needs no hash table to number the groups of a first batch (option "agg_preaggregate_distinct", read only)
     ctx->pa_last_distinct = n_slices == 1 && !is_dict && early == 0;          // dictionary codes: two codes may carry one value
-    pkey.reset(); prow.reset(); pval.clear();
+    pkey.reset(); prow.reset(); pval.clear(); pflag.reset(); flags_in.reset();
     // ---- partial rows in first-seen order of their groups
     BufferPtr perm = alloc_buffer(ctx, (size_t)(m + 1) * 4);
     { KernelTimer kt_(ctx, "pa_order");
@@ -552,6 +633,16 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
         hipLaunchKernelGGL(k_pa_popc, dim3(grid_for(nw, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)bits->ptr, nw, (uint32_t*)pref->ptr);
         exclusive_scan_u32_inplace32(ctx, (uint32_t*)pref->ptr, nw, nullptr);
         hipLaunchKernelGGL(k_pa_rank_perm, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)ofirst->ptr, m, (const uint64_t*)bits->ptr, (const uint32_t*)pref->ptr, (uint32_t*)perm->ptr);
+        KERNEL_CHECK();
+      } else if (ctx->first_seen_group_order && m > (4 << 20) && ctx->agg_order_inverse_map) {
+        BufferPtr inv = alloc_buffer(ctx, (size_t)n * 4 + 64);
+        HIP_CHECK(hipMemsetAsync(inv->ptr, 0xFF, (size_t)n * 4, ctx->stream));
+        hipLaunchKernelGGL(k_pa_inv, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)ofirst->ptr, m, (uint32_t*)inv->ptr);
+        const int64_t nblk = grid_for(n, BLOCK * INV_PER);
+        BufferPtr cnts = alloc_buffer(ctx, (size_t)(nblk + 1) * 4);
+        hipLaunchKernelGGL((k_pa_inv_compact<false>), dim3((unsigned)nblk), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)inv->ptr, n, (uint32_t*)cnts->ptr, (uint32_t*)nullptr);
+        exclusive_scan_u32_inplace32(ctx, (uint32_t*)cnts->ptr, nblk, nullptr);
+        hipLaunchKernelGGL((k_pa_inv_compact<true>), dim3((unsigned)nblk), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)inv->ptr, n, (uint32_t*)cnts->ptr, (uint32_t*)perm->ptr);
         KERNEL_CHECK();
       } else if (ctx->first_seen_group_order && m > (4 << 20)) {
         int jb = 1; while (((uint64_t)(m - 1) >> jb) != 0) jb++;
@@ -575,11 +666,15 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     KernelTimer kt_(ctx, "pa_emit");
     const uint32_t* pp = (const uint32_t*)perm->ptr; dim3 grid(grid_for(m, BLOCK));
     ArrayHolder ok(new_fixed(ctx, ktype, m));
-    PaEmit em{}; auto add = [&](int word, void* dst, int narrow, int dstride = 1, int doff = 0) { em.word[em.n] = word; em.dst[em.n] = dst; em.narrow[em.n] = narrow; em.dstride[em.n] = dstride; em.doff[em.n] = doff; em.n++; };
+    PaEmit em{}; auto add = [&](int word, void* dst, int narrow, int dstride = 1, int doff = 0) { if (em.n >= 2 + 2 * PA_MAX_AGGS) fail(DFGPU_NOT_IMPLEMENTED, "agg_preaggregate: more output columns than one emit pass writes"); em.word[em.n] = word; em.dst[em.n] = dst; em.narrow[em.n] = narrow; em.dstride[em.n] = dstride; em.doff[em.n] = doff; em.n++; };
     add(0, ok.get()->values->ptr, (ktype == DFGPU_INT64 || ktype == DFGPU_UINT64) ? 0 : 1);
     std::vector<ArrayHolder> st((size_t)n_aggs * 2);
+    // the values-seen count of every nullable column, once (UInt64 words): COUNT(x) / AVG counts copy it, state validities derive from it
+    std::vector<BufferPtr> nval_buf((size_t)PA_MAX_AGGS);
+    for (int c = 0; c < plan.n_acc; c++) if (plan.op[c] == PA_COUNT_FLAG) { nval_buf[(size_t)c] = alloc_buffer(ctx, (size_t)(m + 1) * 8); add(2 + c, nval_buf[(size_t)c]->ptr, 0); }
+    std::vector<std::pair<dfgpu_array*, int>> need_valid;          // (state array, its COUNT_FLAG cell)
     for (int i = 0; i < n_aggs; i++) {
-      auto counts_as = [&](int32_t type) { dfgpu_array* a = new_fixed(ctx, type, m); add(1, a->values->ptr, 0); return a; };
+      auto counts_as = [&](int32_t type) { dfgpu_array* a = new_fixed(ctx, type, m); add(nvalid_of[i] >= 0 ? 2 + nvalid_of[i] : 1, a->values->ptr, 0); return a; };
       auto cell_as = [&](int32_t type) { dfgpu_array* a = new_fixed(ctx, type, m); add(2 + cell_of[i], a->values->ptr, 0); return a; };
       // Decimal128 sums: state type Decimal128(min(38, p + 10), s) (sum.rs:75-86, average.rs:96-110); the two cells interleave into 16-byte values
       auto dec_as = [&]() { const dfgpu_array* v = values[i]; dfgpu_array* a = new_fixed(ctx, DFGPU_DECIMAL128, m, std::min(38, v->precision + 10), v->scale); add(2 + cell_of[i], a->values->ptr, 0, 2, 0); add(3 + cell_of[i], a->values->ptr, 0, 2, 1); return a; };
@@ -588,10 +683,16 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
       else if (kinds[i] == DFGPU_AGG_AVG) { st[(size_t)2 * i].a = counts_as(DFGPU_UINT64); st[(size_t)2 * i + 1].a = d128 ? dec_as() : cell_as(DFGPU_FLOAT64); }   // average.rs:392-430: (counts, sums)
       else if (d128) st[(size_t)2 * i].a = dec_as();
       else st[(size_t)2 * i].a = cell_as(values[i]->type);          // SUM / MIN / MAX of an 8-byte type: state type == input type (sum.rs:75-86, min_max.rs:102-139)
+      if (nvalid_of[i] >= 0 && kinds[i] != DFGPU_AGG_COUNT) need_valid.emplace_back(st[(size_t)2 * i + (kinds[i] == DFGPU_AGG_AVG ? 1 : 0)].get(), nvalid_of[i]);
       if (em.n > 2 + 2 * PA_MAX_AGGS) fail(DFGPU_NOT_IMPLEMENTED, "agg_preaggregate: more output columns than one emit pass writes");
     }
     if (m) { if (rs == 4) hipLaunchKernelGGL(k_pa_emit<4>, grid, dim3(BLOCK), 0, ctx->stream, em, (const uint64_t*)orec->ptr, pp, m); else hipLaunchKernelGGL(k_pa_emit<8>, grid, dim3(BLOCK), 0, ctx->stream, em, (const uint64_t*)orec->ptr, pp, m); }
     KERNEL_CHECK();
+    for (auto& nv : need_valid) {          // NullState::build (accumulate.rs:328-356): the state of a group that saw no value is NULL
+      nv.first->validity = alloc_buffer(ctx, bitmap_bytes(m) + 8); nv.first->null_count = -1;
+      if (m) hipLaunchKernelGGL(k_pa_state_valid, dim3(grid_for(((m + 63) / 64) * 64, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)nval_buf[(size_t)nv.second]->ptr, m, (uint64_t*)nv.first->validity->ptr);
+      KERNEL_CHECK();
+    }
     if (is_dict) {           // DictionaryArray::try_new(codes, the input's dictionary)
       dfgpu_array* d = nullptr; dfgpu_status st2 = dfgpu_array_make_dictionary(ctx, ok.get(), key->dictionary, &d);
       if (st2 != DFGPU_OK) fail(st2, "%s", ctx->err.c_str());

@@ -702,8 +702,9 @@ template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_bp_sample(const T* keys, const uint64_t* valid, const uint64_t* mask, int64_t n, int64_t kmin, uint64_t range, const uint64_t* bitmap, unsigned long long* out) {
   constexpr int S = 2048;
   uint32_t near = 0, sel = 0, hit = 0;
+  const int64_t step = (n - 1) / S;                     // n >= 2^20: step >= 512
   for (int s0 = threadIdx.x; s0 < S; s0 += BLOCK) {
-    const int64_t i = (int64_t)((unsigned __int128)(uint64_t)s0 * (uint64_t)(n - 1) / S);
+    const int64_t i = (int64_t)s0 * step;
     const uint64_t d = (uint64_t)((int64_t)keys[i] - kmin), d1 = (uint64_t)((int64_t)keys[i + 1] - kmin);
     near += (d >> 15) == (d1 >> 15);
     const bool ok = d < range && (!mask || bit_get(mask, i)) && (!valid || bit_get(valid, i));
@@ -730,6 +731,10 @@ __global__ void __launch_bounds__(BLOCK) k_bp_probe(const uint64_t* recs, const 
 template <typename T>
 static bool bp_probe_typed(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* pk, const uint64_t* mask, int64_t n, uint64_t* match_bits) {
   const T* keys = (const T*)pk->values->ptr; const uint64_t* valid = pk->validity ? (const uint64_t*)pk->validity->ptr : nullptr;
+  // a column known to be sorted streams the bitmap: no sample, no read-back.  A table column is looked at once (the statistics stay with it); a computed column is sampled.
+  auto st = order_stats_get(pk);
+  if (!st && pk->base_column && !valid) st = order_stats_measure(ctx, pk);
+  if (st && st->sorted) return false;
   HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 10, 0, 32, ctx->stream));
   hipLaunchKernelGGL((k_bp_sample<T>), dim3(1), dim3(BLOCK), 0, ctx->stream, keys, valid, mask, n, t->key_min, t->range, (const uint64_t*)t->bitmap->ptr, (unsigned long long*)(ctx->d_scratch64 + 10));
   KERNEL_CHECK();

@@ -225,14 +225,14 @@ dfgpu_array* mask_to_indices_checked(dfgpu_ctx* ctx, const uint64_t* bits, int64
 
 // The same vector for a consumer that only reads entries below the count it has on the device already (a rank): the array is n entries long, the first popcount(bits) are
 // written, and nothing is read back.  Not an Arrow array to hand out -- its length is an upper bound.
-dfgpu_array* mask_to_indices_uncounted(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n) {
+dfgpu_array* mask_to_indices_uncounted(dfgpu_ctx* ctx, const uint64_t* bits, int64_t n, uint64_t* d_count) {
   int64_t nw = (n + 63) / 64, nb = (nw + SEL_WORDS - 1) / SEL_WORDS;
   ArrayHolder h(new_fixed(ctx, DFGPU_UINT32, n));
-  if (n == 0) return h.release();
+  if (n == 0) { if (d_count) HIP_CHECK(hipMemsetAsync(d_count, 0, 8, ctx->stream)); return h.release(); }
   BufferPtr counts = alloc_buffer(ctx, (size_t)nb * 4);
   KernelTimer kt_(ctx, "k_sel_count+scan+write");
   hipLaunchKernelGGL(k_sel_count, dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream, bits, n, (uint32_t*)counts->ptr);
-  exclusive_scan_u32_inplace32(ctx, (uint32_t*)counts->ptr, nb, nullptr);
+  exclusive_scan_u32_inplace32(ctx, (uint32_t*)counts->ptr, nb, d_count);
   hipLaunchKernelGGL(k_sel_write, dim3((unsigned)nb), dim3(BLOCK), 0, ctx->stream, bits, n, (const uint32_t*)counts->ptr, (uint32_t*)h.get()->values->ptr);
   KERNEL_CHECK();
   return h.release();

@@ -366,7 +366,8 @@ DFGPU_API dfgpu_status dfgpu_acc_merge_batch(dfgpu_ctx *ctx, dfgpu_acc *a, const
  * Taken for one 4- / 8-byte integer key column (or dictionary codes of that width), or for 1..4 integer / Date32 key columns with or without NULLs
  * whose value ranges multiply to < 2^62 (they travel as ONE packed 64-bit key, NULL = a value of its own, and are unpacked again: out_keys[0 ..
  * nkeys)); SUM / MIN / MAX over Int64 / UInt64, SUM / AVG over Float64 and over Decimal128 (exact 128-bit sums; state Decimal128(min(38, p + 10), s)),
- * COUNT, value columns without NULLs, no per-aggregate filter, a batch of >= option "agg_partitioned_min_rows" rows whose keys are neither clustered
+ * COUNT; value columns may hold NULLs (a NULL takes no part, a group without a value has a NULL state, COUNT(x) / AVG count the values: accumulate.rs:126-233) -- up to 8
+ * nullable columns, each costs one of the 6 accumulator cells; no per-aggregate filter, a batch of >= option "agg_partitioned_min_rows" rows whose keys are neither clustered
  * nor few (a sample decides); any other shape returns DFGPU_NOT_IMPLEMENTED and the caller updates the accumulators the ordinary way.
  * values[i] may be NULL for COUNT(*).  opt_mask: BOOL selection, unselected rows do not take part.
  * out_keys == NULL asks for the verdict only (DFGPU_OK = a following call with the same key column and selection will be taken, as far as the

@@ -341,3 +341,26 @@ def test_packed_key_ranges_from_a_sample(ctx, outlier):
     assert ("sync:pa_pack_outside" in ran) == outlier, ran
     wk, want = run_oracle_multi([pa.array(a), pa.array(b)], aggs)
     compare_multi(gk, got, wk, want)
+
+
+@pytest.mark.parametrize("two_level", [False, True], ids=["one-pass", "two-level"])
+def test_nullable_aggregate_arguments(ctx, two_level):
+    """Value columns with NULLs (accumulate.rs:126-233: a NULL takes no part; NullState::build, :328-356: a group that saw no value has a NULL state): SUM / MIN / MAX / AVG skip
+    the NULL rows, COUNT(x) counts the values, a group whose argument is NULL in every row comes out NULL (COUNT 0).  The validity bits travel through the partition as one byte per
+    row.  Keys, first-seen order and every state equal the oracle's row-by-row accumulation."""
+    rng = np.random.default_rng(7 + two_level)
+    n, card = (9_000_000, 2_600_000) if two_level else (600_000, 50_000)
+    kv = rng.integers(0, card, n).astype(np.int64) * 7919 - 11
+    key = pa.array(kv)
+    all_null = (kv % 5) == 0                                  # every row of these groups carries a NULL in vi
+    vi = pa.array(rng.integers(-10**9, 10**9, n).astype(np.int64), mask=all_null | (rng.random(n) < 0.3))
+    vf = pa.array(rng.random(n) * 1000 - 300, mask=rng.random(n) < 0.2)
+    vu = pa.array(rng.integers(0, 10**6, n).astype(np.int64))               # a column without NULLs beside them
+    aggs = [("SUM", vi), ("COUNT", vi), ("MIN", vi), ("AVG", vf), ("COUNT", None), ("SUM", vu)]
+    with forced(ctx, force=0 if two_level else 1) as f:
+        gk, got, m = run_device(ctx, key, aggs)
+        ran = f.kernels()
+    assert "pa_aggregate" in ran and (("pa_scatter2" in ran) == two_level)
+    wk, want = run_oracle(key, aggs)
+    compare(gk, got, wk, want)
+    assert got[0].null_count > 0 and got[0].null_count == want[0].null_count and got[2].null_count == want[2].null_count
