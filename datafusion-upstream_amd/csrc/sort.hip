@@ -93,6 +93,68 @@ __global__ void __launch_bounds__(BLOCK) k_rs_scatter(D dg, const uint32_t* keys
   }
 }
 
+// Small inputs (a query's result rows): a pass is launch latency, not bandwidth -- three launches (histogram, scan, scatter) of a few microseconds each, 18 for six varying
+// key bytes.  Here a pass is ONE launch: every workgroup turns the raw [digit][workgroup] counts into its own start positions (thread t owns digit t: it adds up its digit's
+// counts over the workgroups in front -- at most a few hundred words -- and a 256-wide scan over the digit totals gives the digit's base), and while it scatters it counts the
+// NEXT pass's histogram: an element's output position tells which workgroup will read it there, its next digit is one byte away.  Same stable ranking as k_rs_scatter.
+__global__ void __launch_bounds__(BLOCK) k_rs_plane_pass(const uint8_t* plane, const uint8_t* next_plane, const uint32_t* vals, int64_t n, int64_t chunk, int nb,
+                                                         const uint32_t* counts /*[256][nb] raw*/, uint32_t* next_counts /*[256][nb] zeroed, or null*/, uint32_t* out_vals) {
+  constexpr int NW = BLOCK / WAVE;
+  __shared__ uint32_t running[256];
+  __shared__ uint32_t cnt[RS_ITEMS][NW][256];
+  __shared__ uint32_t scan_lds[NW];
+  {
+    uint32_t before = 0, tot = 0;
+    for (int b = 0; b < nb; b++) { const uint32_t c = counts[(int64_t)threadIdx.x * nb + b]; before += b < (int)blockIdx.x ? c : 0u; tot += c; }
+    uint32_t all; const uint32_t base = block_exclusive_sum<uint32_t>(tot, scan_lds, &all);
+    running[threadIdx.x] = base + before;
+  }
+#pragma unroll
+  for (int q = 0; q < RS_ITEMS; q++)
+#pragma unroll
+    for (int w = 0; w < NW; w++) cnt[q][w][threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  const int wave = threadIdx.x >> 6;
+  for (int64_t t0 = lo; t0 < hi; t0 += (int64_t)BLOCK * RS_ITEMS) {
+    uint32_t val[RS_ITEMS], d[RS_ITEMS], rank[RS_ITEMS]; bool active[RS_ITEMS];
+#pragma unroll
+    for (int q = 0; q < RS_ITEMS; q++) { const int64_t i = t0 + (int64_t)q * BLOCK + threadIdx.x; active[q] = i < hi; val[q] = vals[active[q] ? i : hi - 1]; }
+#pragma unroll
+    for (int q = 0; q < RS_ITEMS; q++) d[q] = plane[val[q]];
+#pragma unroll
+    for (int q = 0; q < RS_ITEMS; q++) {
+      uint64_t peers = ballot64(active[q]);
+#pragma unroll
+      for (int b = 0; b < 8; b++) { const uint64_t m = ballot64((d[q] >> b) & 1u); peers &= ((d[q] >> b) & 1u) ? m : ~m; }
+      rank[q] = __popcll(peers & lanemask_lt());
+      if (active[q] && rank[q] == 0) cnt[q][wave][d[q]] = __popcll(peers);
+    }
+    __syncthreads();
+    {
+      uint32_t run = running[threadIdx.x];
+#pragma unroll
+      for (int q = 0; q < RS_ITEMS; q++)
+#pragma unroll
+        for (int w = 0; w < NW; w++) { const uint32_t c = cnt[q][w][threadIdx.x]; cnt[q][w][threadIdx.x] = run; run += c; }
+      running[threadIdx.x] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RS_ITEMS; q++) if (active[q]) {
+      const uint32_t pos = cnt[q][wave][d[q]] + rank[q];
+      out_vals[pos] = val[q];
+      if (next_counts) atomicAdd(&next_counts[(int64_t)next_plane[val[q]] * nb + (int64_t)(pos / chunk)], 1u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RS_ITEMS; q++)
+#pragma unroll
+      for (int w = 0; w < NW; w++) cnt[q][w][threadIdx.x] = 0;
+    __syncthreads();
+  }
+}
+
 struct RadixPlan { int nb; int64_t chunk; };
 static RadixPlan plan_for(int64_t n) {
   int64_t nb = (n + 4095) / 4096; if (nb < 1) nb = 1; if (nb > RS_MAX_BLOCKS) nb = RS_MAX_BLOCKS;
@@ -543,6 +605,23 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
             std::swap(k0, k1); std::swap(v0, v1);
           }
           first = false;
+        }
+      } else if (p.nb <= 512 && ctx->sort_fused_small_passes) {
+        // one launch per varying plane (k_rs_plane_pass): the first pass's histogram is counted on its own, every later one by the pass before it
+        std::vector<int> vp; for (int b = W - 1; b >= 0; b--) if (h[(size_t)b]) vp.push_back(b);       // least significant plane first
+        if (!vp.empty()) {
+          KernelTimer kt_(ctx, "radix_pass");
+          const size_t hw = (size_t)256 * p.nb;
+          BufferPtr hists = alloc_buffer(ctx, hw * 4 * vp.size(), true);
+          auto plane_of = [&](size_t j) { return (const uint8_t*)planes->ptr + (int64_t)vp[j] * n; };
+          hipLaunchKernelGGL((k_rs_hist<DigitPlane>), dim3(p.nb), dim3(BLOCK), 0, ctx->stream, DigitPlane{ plane_of(0) }, (const uint32_t*)nullptr, (const uint32_t*)v0, n, p.chunk, p.nb, (uint32_t*)hists->ptr);
+          for (size_t j = 0; j < vp.size(); j++) {
+            const bool more = j + 1 < vp.size();
+            hipLaunchKernelGGL(k_rs_plane_pass, dim3(p.nb), dim3(BLOCK), 0, ctx->stream, plane_of(j), more ? plane_of(j + 1) : (const uint8_t*)nullptr, (const uint32_t*)v0, n, p.chunk, p.nb,
+                               (const uint32_t*)hists->ptr + hw * j, more ? (uint32_t*)hists->ptr + hw * (j + 1) : (uint32_t*)nullptr, v1);
+            std::swap(v0, v1);
+          }
+          KERNEL_CHECK();
         }
       } else
       for (int b = W - 1; b >= 0; b--) {        // least significant plane first

@@ -40,7 +40,8 @@ def run_device(ctx, key, aggs, mask=None):
     """aggs: list of (kind name, pyarrow values or None).  -> (emitted keys, [evaluated arrays]) after preaggregate + intern + merge"""
     import dfgpu
     kd = ctx.from_arrow(key)
-    vals = [ctx.from_arrow(v) if v is not None else None for _, v in aggs]
+    dev = {}                                                 # one device column per distinct argument (SUM(x), COUNT(x) and MIN(x) read the same column, as in a plan)
+    vals = [dev.setdefault(id(v), ctx.from_arrow(v)) if v is not None else None for _, v in aggs]
     pk, states = dfgpu.agg_preaggregate(ctx, kd, [KIND[k] for k, _ in aggs], vals, mask=ctx.from_arrow(pa.array(mask)) if mask is not None else None)
     gv = dfgpu.GroupValues(ctx, 1)
     gids = gv.intern([pk])
@@ -219,7 +220,8 @@ def test_first_batch_keeps_its_keys_out_of_the_hash_table_until_a_second_batch_a
 def run_device_multi(ctx, keys, aggs, mask=None):
     import dfgpu
     kd = [ctx.from_arrow(k) for k in keys]
-    vals = [ctx.from_arrow(v) if v is not None else None for _, v in aggs]
+    dev = {}                                                 # one device column per distinct argument (SUM(x), COUNT(x) and MIN(x) read the same column, as in a plan)
+    vals = [dev.setdefault(id(v), ctx.from_arrow(v)) if v is not None else None for _, v in aggs]
     pk, states = dfgpu.agg_preaggregate(ctx, kd, [KIND[k] for k, _ in aggs], vals, mask=ctx.from_arrow(pa.array(mask)) if mask is not None else None)
     gv = dfgpu.GroupValues(ctx, len(keys))
     gids = gv.intern(pk)

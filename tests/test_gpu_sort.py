@@ -231,3 +231,28 @@ def test_packed_sort_key_ranges_from_a_sample(ctx, shape):
     assert np.array_equal(got, po.lexsort_to_indices(cols, [True, False], [True, False]))
     assert ("sort_key_sample" in ks) == (shape != "estimate_off")
     assert ("sort_key_ranges" in ks) == (shape != "ranges_hold")
+
+
+@pytest.mark.parametrize("n", [1, 255, 4097, 300_001, 900_000])
+def test_small_input_passes_in_one_launch_each_give_the_same_stable_order(ctx, n):
+    """Below 2^20 rows every varying key byte is ONE launch (k_rs_plane_pass: offsets derived inside the scatter, the next pass's histogram counted by it) instead of
+    histogram + scan + scatter.  Many equal keys (ties keep input order), a Decimal128 + Date32 + nullable Int32 key set (Q3's result shape plus NULLs): the indices equal the
+    three-launch path's and numpy's stable lexsort."""
+    import decimal
+    rng = np.random.default_rng(n)
+    rev = rng.integers(0, 50, n).astype(np.int64) * 10007                       # few distinct values: long runs of ties
+    date = rng.integers(9000, 9040, n).astype(np.int32)
+    prio = rng.integers(-3, 3, n).astype(np.int32); pmask = rng.random(n) < 0.1
+    cols = [ctx.from_arrow(pa.array([decimal.Decimal(int(v)).scaleb(-4) for v in rev], type=pa.decimal128(38, 4))), ctx.from_arrow(pa.array(date, type=pa.int32()).cast(pa.date32())),
+            ctx.from_arrow(pa.array(prio, mask=pmask))]
+    desc, nf = [True, False, False], [True, False, True]
+    got = ctx.sort_to_indices(cols, desc, nf).to_numpy()
+    ctx.set_option("sort_fused_small_passes", 0)
+    try:
+        plain = ctx.sort_to_indices(cols, desc, nf).to_numpy()
+    finally:
+        ctx.set_option("sort_fused_small_passes", 1)
+    assert np.array_equal(got, plain)
+    pkey = np.where(pmask, np.int64(-(1 << 40)), prio.astype(np.int64))         # NULLs first in an ascending column
+    want = np.lexsort((np.arange(n), pkey, date, -rev))                         # last key is the primary one; row number breaks ties = stable
+    assert np.array_equal(got.astype(np.int64), want)
