@@ -630,10 +630,13 @@ struct BuildSide { Batch batch; std::shared_ptr<JoinTableRef> table; std::vector
 struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
   PlanPtr left, right; std::vector<ExprPtr> on_l, on_r; ExprPtr filter; std::vector<int> f_side, f_index;
   int join_type, mode; bool null_equals_null; bool swap_small_right = true;
+  // set by the operator above when it fuses a selection into its own pass (another join's build or probe, a hash repartition): only then may this join answer with the probe
+  // batch under a selection (dfgpu_join_probe_selection) instead of index vectors -- an aggregate or a sort above would have to compact it first and gains nothing
+  mutable bool selection_consumer = false;
   mutable std::mutex mu; mutable std::shared_ptr<BuildSide> shared;     // CollectLeft: OnceAsync (joins/utils.rs:736-776)
   PlanPtr fresh() const override {
     auto j = std::make_shared<HashJoinExec>(); j->left = left->fresh(); j->right = right->fresh(); j->on_l = on_l; j->on_r = on_r; j->filter = filter; j->f_side = f_side; j->f_index = f_index;
-    j->join_type = join_type; j->mode = mode; j->null_equals_null = null_equals_null; j->swap_small_right = swap_small_right; return j;
+    j->join_type = join_type; j->mode = mode; j->null_equals_null = null_equals_null; j->swap_small_right = swap_small_right; j->selection_consumer = selection_consumer; return j;
   }
   std::vector<std::shared_ptr<const Plan>> children() const override { return {left, right}; }
   const char* name() const override { return "HashJoinExec"; }
@@ -2112,8 +2115,19 @@ dfgpu_status dfgpu_plan_projection(const dfgpu_expr* const* exprs, const char* c
 }
 dfgpu_status dfgpu_plan_coalesce_batches(const dfgpu_plan* input, int64_t target, dfgpu_plan** out) { return guard([&] { auto c = std::make_shared<CoalesceBatchesExec>(); c->input = pl(input); c->target = target; *out = new dfgpu_plan{c}; }); }
 dfgpu_status dfgpu_plan_coalesce_partitions(const dfgpu_plan* input, dfgpu_plan** out) { return guard([&] { auto c = std::make_shared<CoalescePartitionsExec>(); c->input = pl(input); *out = new dfgpu_plan{c}; }); }
+// the nearest HashJoinExec below `p` through operators that pass a selection on untouched (CoalesceBatchesExec, a ProjectionExec of plain columns) learns that its
+// consumer fuses selections
+static void mark_selection_consumer(const PlanPtr& p) {
+  const Plan* q = p.get();
+  while (q) {
+    if (auto* hj = dynamic_cast<const HashJoinExec*>(q)) { hj->selection_consumer = true; return; }
+    if (auto* cb = dynamic_cast<const CoalesceBatchesExec*>(q)) q = cb->input.get();
+    else if (auto* pr = dynamic_cast<const ProjectionExec*>(q)) { if (!pr->only_columns()) return; q = pr->input.get(); }
+    else return;
+  }
+}
 dfgpu_status dfgpu_plan_repartition(const dfgpu_plan* input, const dfgpu_expr* const* exprs, int32_t nexprs, int32_t n, dfgpu_plan** out) {
-  return guard([&] { if (n < 1) fail(DFGPU_INVALID_ARGUMENT, "repartition: partition count must be positive"); auto r = std::make_shared<RepartitionExec>(); r->input = pl(input); r->n = n; for (int i = 0; i < nexprs; i++) r->exprs.push_back(ex(exprs[i])); *out = new dfgpu_plan{r}; });
+  return guard([&] { if (n < 1) fail(DFGPU_INVALID_ARGUMENT, "repartition: partition count must be positive"); auto r = std::make_shared<RepartitionExec>(); r->input = pl(input); r->n = n; if (nexprs > 0) mark_selection_consumer(r->input); for (int i = 0; i < nexprs; i++) r->exprs.push_back(ex(exprs[i])); *out = new dfgpu_plan{r}; });
 }
 dfgpu_status dfgpu_plan_hash_join(const dfgpu_plan* left, const dfgpu_plan* right, const dfgpu_expr* const* on_left, const dfgpu_expr* const* on_right, int32_t non,
                                   const dfgpu_expr* filter, const int32_t* fs, const int32_t* fi, int32_t nf, int32_t join_type, int32_t mode, int32_t nen, dfgpu_plan** out) {
@@ -2125,6 +2139,7 @@ dfgpu_status dfgpu_plan_hash_join(const dfgpu_plan* left, const dfgpu_plan* righ
     for (int i = 0; i < non; i++) { j->on_l.push_back(ex(on_left[i])); j->on_r.push_back(ex(on_right[i])); }
     if (filter) { j->filter = ex(filter); for (int i = 0; i < nf; i++) { j->f_side.push_back(fs[i]); j->f_index.push_back(fi[i]); } }
     j->join_type = join_type; j->mode = mode; j->null_equals_null = nen != 0;
+    mark_selection_consumer(j->left); mark_selection_consumer(j->right);
     *out = new dfgpu_plan{j};
   });
 }

@@ -272,20 +272,27 @@ __global__ void __launch_bounds__(BLOCK) k_check_increasing(const T* keys, int64
 }
 // ---- rank index over UNSORTED unique keys (a key column after a hash repartition, a filtered dimension table in arrival order): the membership bitmap still ranks the
 // keys; one more array, rank -> build row, takes the place of the sort order.  Setting the bits finds repeated keys (the bit is already there).
+// rows != null: the selected rows as a list whose length is the device word *d_count (mask_to_indices_uncounted) -- a selection that keeps one row in ten costs a tenth of the lanes
 template <typename T>
-__global__ void __launch_bounds__(BLOCK) k_key_setbits_unique(const T* keys, const uint64_t* mask, int64_t n, int64_t kmin, uint64_t* bitmap, unsigned long long* dup) {
-  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n || (mask && !bit_get(mask, i))) return;
-  const uint64_t d = (uint64_t)((int64_t)keys[i] - kmin), bit = 1ull << (d & 63);
-  const unsigned long long old = atomicOr((unsigned long long*)&bitmap[d >> 6], (unsigned long long)bit);
-  if (old & bit) *dup = 1ull;
+__global__ void __launch_bounds__(BLOCK) k_key_setbits_unique(const T* keys, const uint64_t* mask, const uint32_t* rows, const unsigned long long* d_count, int64_t n, int64_t kmin, uint64_t* bitmap, unsigned long long* dup) {
+  const int64_t m = rows ? (int64_t)*d_count : n;
+  for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < m; j += (int64_t)gridDim.x * BLOCK) {
+    const int64_t i = rows ? (int64_t)rows[j] : j;
+    if (!rows && mask && !bit_get(mask, i)) continue;
+    const uint64_t d = (uint64_t)((int64_t)keys[i] - kmin), bit = 1ull << (d & 63);
+    const unsigned long long old = atomicOr((unsigned long long*)&bitmap[d >> 6], (unsigned long long)bit);
+    if (old & bit) *dup = 1ull;
+  }
 }
 template <typename T>
-__global__ void __launch_bounds__(BLOCK) k_rank_rows(const T* keys, const uint64_t* mask, int64_t n, int64_t kmin, const uint64_t* bitmap, const uint32_t* prefix, uint32_t* row_of_rank) {
-  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n || (mask && !bit_get(mask, i))) return;
-  const uint64_t d = (uint64_t)((int64_t)keys[i] - kmin);
-  row_of_rank[prefix[d >> 6] + (uint32_t)__popcll(bitmap[d >> 6] & ((1ull << (d & 63)) - 1ull))] = (uint32_t)i;
+__global__ void __launch_bounds__(BLOCK) k_rank_rows(const T* keys, const uint64_t* mask, const uint32_t* rows, const unsigned long long* d_count, int64_t n, int64_t kmin, const uint64_t* bitmap, const uint32_t* prefix, uint32_t* row_of_rank) {
+  const int64_t m = rows ? (int64_t)*d_count : n;
+  for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < m; j += (int64_t)gridDim.x * BLOCK) {
+    const int64_t i = rows ? (int64_t)rows[j] : j;
+    if (!rows && mask && !bit_get(mask, i)) continue;
+    const uint64_t d = (uint64_t)((int64_t)keys[i] - kmin);
+    row_of_rank[prefix[d >> 6] + (uint32_t)__popcll(bitmap[d >> 6] & ((1ull << (d & 63)) - 1ull))] = (uint32_t)i;
+  }
 }
 // heads bit i = row i starts a run of equal keys
 template <typename T>
@@ -607,8 +614,12 @@ static bool build_rank_index(dfgpu_ctx* ctx, dfgpu_join_table* t) {
 // The partitioned join (pjoin.hip) is for key domains the membership bitmap cannot prefilter: min / max of the selected build keys in one
 // streaming pass.  true = range beyond 256 x rows (or beyond 2^32): a bitmap over it would be mostly empty lines.
 template <typename T>
-__global__ void __launch_bounds__(BLOCK) k_key_minmax_masked(const T* keys, const uint64_t* valid, const uint64_t* mask, int64_t n, long long* mn, long long* mx) {
+__global__ void __launch_bounds__(BLOCK) k_key_minmax_masked(const T* keys, const uint64_t* valid, const uint64_t* mask, int64_t n, long long* mn, long long* mx, const uint32_t* rows = nullptr, const unsigned long long* d_count = nullptr) {
   long long lo = INT64_MAX, hi = INT64_MIN;
+  if (rows) {            // the selected rows as a list (length on the device)
+    const int64_t m = (int64_t)*d_count;
+    for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < m; j += (int64_t)gridDim.x * BLOCK) { const int64_t i = rows[j]; if (valid_at(valid, i)) { long long v = (long long)keys[i]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; } }
+  } else
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
     if (row_selected(mask, i) && valid_at(valid, i)) { long long v = (long long)keys[i]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
 #pragma unroll
@@ -630,10 +641,15 @@ static bool build_rank_index_unsorted(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   if (key0->type == DFGPU_DICTIONARY || !int_key_type(key0->type) || key0->validity) return false;
   KernelTimer kt_(ctx, "join_build_rank");
   const uint64_t* mk = t->build_mask ? (const uint64_t*)t->build_mask->ptr : nullptr;
+  // a masked build (a FilterExec or a join's selection fused into it) first turns the mask into the list of its rows -- the count stays on the device -- and every pass below
+  // walks that list: the work follows the selected rows, not the column (TPC-H Q3 behind a shuffle: 15 M of 150 M orders)
+  ArrayHolder list; const uint32_t* rl = nullptr; const unsigned long long* dcount = (const unsigned long long*)(ctx->d_scratch64 + 15);
+  if (mk) { list.a = mask_to_indices_uncounted(ctx, mk, n, ctx->d_scratch64 + 15); rl = (const uint32_t*)list.get()->values->ptr; }
+  const int lgrid = grid_for(n, BLOCK, ctx->num_cus * 16);
   long long init[2] = { INT64_MAX, INT64_MIN };
   HIP_CHECK(hipMemcpyAsync(ctx->d_scratch64 + 4, init, 16, hipMemcpyHostToDevice, ctx->stream));
   DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_minmax_masked<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 4)), dim3(BLOCK), 0, ctx->stream, (const T*)key0->values->ptr,
-                                                        (const uint64_t*)nullptr, mk, n, (long long*)(ctx->d_scratch64 + 4), (long long*)(ctx->d_scratch64 + 5)));
+                                                        (const uint64_t*)nullptr, mk, n, (long long*)(ctx->d_scratch64 + 4), (long long*)(ctx->d_scratch64 + 5), rl, dcount));
   KERNEL_CHECK();
   ctx->count_sync("sync:rank_index_range"); fetch_to_pinned(ctx, 4, ctx->d_scratch64 + 4, 16);
   const long long lo = (long long)ctx->h_pinned[4], hi = (long long)ctx->h_pinned[5];
@@ -645,7 +661,7 @@ static bool build_rank_index_unsorted(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   BufferPtr bitmap = alloc_buffer(ctx, bitmap_bytes((int64_t)range));
   HIP_CHECK(hipMemsetAsync(bitmap->ptr, 0, bitmap_bytes((int64_t)range), ctx->stream));
   HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 6, 0, 8, ctx->stream));
-  DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_setbits_unique<T>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const T*)key0->values->ptr, mk, n, (int64_t)lo, (uint64_t*)bitmap->ptr,
+  DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_setbits_unique<T>), dim3(lgrid), dim3(BLOCK), 0, ctx->stream, (const T*)key0->values->ptr, mk, rl, dcount, n, (int64_t)lo, (uint64_t*)bitmap->ptr,
                                                         (unsigned long long*)(ctx->d_scratch64 + 6)));
   BufferPtr prefix = alloc_buffer(ctx, (size_t)nw * 4);
   hipLaunchKernelGGL(k_popc_words, dim3(grid_for(nw, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)bitmap->ptr, nw, (uint32_t*)prefix->ptr);
@@ -656,7 +672,7 @@ static bool build_rank_index_unsorted(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   if (hsc[0] != 0) return false;                           // a key repeats: the hash paths keep their CSR
   const int64_t nsel = (int64_t)hsc[1];
   ArrayHolder rows(new_fixed(ctx, DFGPU_UINT32, nsel));
-  DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_rank_rows<T>), dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const T*)key0->values->ptr, mk, n, (int64_t)lo, (const uint64_t*)bitmap->ptr,
+  DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_rank_rows<T>), dim3(lgrid), dim3(BLOCK), 0, ctx->stream, (const T*)key0->values->ptr, mk, rl, dcount, n, (int64_t)lo, (const uint64_t*)bitmap->ptr,
                                                         (const uint32_t*)prefix->ptr, (uint32_t*)rows.get()->values->ptr));
   KERNEL_CHECK();
   t->key_min = lo; t->range = range; t->rank_mode = true; t->unique = true; t->rank_runs = false; t->rank_identity = false;

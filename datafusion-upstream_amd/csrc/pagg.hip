@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(PA_NT) k_pa_items(const uint32_t* pstart, uint
 }
 // two-level partition: fine partition = (low hash bits -> P2) * P1 + (high hash bits -> P1)
 __device__ inline uint32_t pa_fine_pid(uint64_t k, uint32_t P1, uint32_t P2) { uint64_t h = mix64(k); return (uint32_t)(((h & 0xFFFFFFFFull) * (uint64_t)P2) >> 32) * P1 + rp_pid(h, P1); }
-template <bool I128>          // I128: the plan holds Decimal128 cell pairs / strided value columns; the plain instantiation is the round-2 kernel (the extra branches cost it 6 %)
+template <bool I128, bool FLAGS>          // I128: the plan holds Decimal128 cell pairs / strided value columns; FLAGS: some argument is nullable (flag byte per row).  The plain instantiation is the round-2 kernel (the I128 branches cost it 6 %, the flag tests 15 %)
 __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, const uint32_t* prow, PaPlan plan_arg, const uint32_t* pstart, const uint32_t* item_start, uint32_t P, int cbits, uint32_t slice,
                                                       uint64_t* orec /* records of `rs` words: key, count, accumulator cells */, int rs, uint32_t* ofirst, unsigned long long* cursor /*[0] rows written, [2] tables flushed before their partition ended*/,
                                                       uint32_t P1, uint32_t P2, uint32_t* misplaced /* two-level partition (P1 != 0): set when a row sits in a partition its key does not hash to */) {
@@ -152,8 +152,8 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
   // a row's cells as the table takes them: the value, or -- for a cell bound to a flag bit -- the operation's identity where the bit is clear (a NULL argument), the bit itself for a COUNT_FLAG cell
   auto load_cells = [&](uint32_t ic, uint64_t* v) {
 #pragma unroll
-    for (int a = 0; a < PA_MAX_AGGS; a++) v[a] = a < na && plan_arg.val[a] ? plan_arg.val[a][I128 ? (size_t)ic * plan_arg.vstride[a] : (size_t)ic] : 0;
-    if (vflag) {
+    for (int a = 0; a < PA_MAX_AGGS; a++) v[a] = a < na && (!FLAGS || plan_arg.val[a]) ? plan_arg.val[a][I128 ? (size_t)ic * plan_arg.vstride[a] : (size_t)ic] : 0;
+    if constexpr (FLAGS) {
       const uint32_t f = vflag[ic];
 #pragma unroll
       for (int a = 0; a < PA_MAX_AGGS; a++) if (a < na && plan_arg.flag_bit[a] >= 0) {
@@ -602,19 +602,20 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     int64_t slice = (n / P + 1) * 3 / 2; if (slice < 65536) slice = 65536;          // uniform keys never split (a partition is within a percent of the average) if (slice > 0x7FFFFFFF) slice = 0x7FFFFFFF;
     const int64_t n_slices = max_len ? (max_len + slice - 1) / slice : 1;
     { KernelTimer kt_(ctx, "pa_aggregate");
-      HIP_CHECK(hipFuncSetAttribute(plan.has_i128 ? (const void*)k_pa_aggregate<true> : (const void*)k_pa_aggregate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));      // per device: set on every call, no process-wide flag
       BufferPtr items; unsigned grid = (unsigned)P;
       if (n_slices > 1) {            // sum over partitions of ceil(len / slice) <= P + n / slice
         items = alloc_buffer(ctx, (size_t)(P + 1) * 4);
         hipLaunchKernelGGL(k_pa_items, dim3(1), dim3(PA_NT), 0, ctx->stream, (const uint32_t*)r.starts->ptr, (uint32_t)P, (uint32_t)slice, (uint32_t*)items->ptr);
         grid = (unsigned)(P + n / slice + 1);
       }
-      if (plan.has_i128) hipLaunchKernelGGL(k_pa_aggregate<true>, dim3(grid), dim3(PA_NT), (((size_t)1 << cbits) + 1) * cell_bytes, ctx->stream, (const uint64_t*)pkey->ptr, (const uint32_t*)prow->ptr, plan, (const uint32_t*)r.starts->ptr,
-                         items ? (const uint32_t*)items->ptr : nullptr, (uint32_t)P, cbits, (uint32_t)slice, (uint64_t*)orec->ptr, rs, (uint32_t*)ofirst->ptr, (unsigned long long*)(ctx->d_scratch64 + 12),
-                         two_level ? (uint32_t)P1 : 0u, (uint32_t)P2, (uint32_t*)(ctx->d_scratch64 + 11));
-      else hipLaunchKernelGGL(k_pa_aggregate<false>, dim3(grid), dim3(PA_NT), (((size_t)1 << cbits) + 1) * cell_bytes, ctx->stream, (const uint64_t*)pkey->ptr, (const uint32_t*)prow->ptr, plan, (const uint32_t*)r.starts->ptr,
-                         items ? (const uint32_t*)items->ptr : nullptr, (uint32_t)P, cbits, (uint32_t)slice, (uint64_t*)orec->ptr, rs, (uint32_t*)ofirst->ptr, (unsigned long long*)(ctx->d_scratch64 + 12),
-                         two_level ? (uint32_t)P1 : 0u, (uint32_t)P2, (uint32_t*)(ctx->d_scratch64 + 11));
+      const size_t lds = (((size_t)1 << cbits) + 1) * cell_bytes;
+#define PA_AGG(I, F) do { HIP_CHECK(hipFuncSetAttribute((const void*)k_pa_aggregate<I, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));      /* per device: set on every call, no process-wide flag */ \
+        hipLaunchKernelGGL((k_pa_aggregate<I, F>), dim3(grid), dim3(PA_NT), lds, ctx->stream, (const uint64_t*)pkey->ptr, (const uint32_t*)prow->ptr, plan, (const uint32_t*)r.starts->ptr, \
+                           items ? (const uint32_t*)items->ptr : nullptr, (uint32_t)P, cbits, (uint32_t)slice, (uint64_t*)orec->ptr, rs, (uint32_t*)ofirst->ptr, (unsigned long long*)(ctx->d_scratch64 + 12), \
+                           two_level ? (uint32_t)P1 : 0u, (uint32_t)P2, (uint32_t*)(ctx->d_scratch64 + 11)); } while (0)
+      if (n_flags) { if (plan.has_i128) PA_AGG(true, true); else PA_AGG(false, true); }
+      else { if (plan.has_i128) PA_AGG(true, false); else PA_AGG(false, false); }
+#undef PA_AGG
       KERNEL_CHECK(); }
     const uint64_t* back = read_scratch_range(ctx, 11, 4);          // [0] rows out of order, [1] partial rows written, [3] tables flushed early: one read-back
     const int64_t m = (int64_t)back[1]; const uint64_t early = back[3];

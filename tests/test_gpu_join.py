@@ -504,13 +504,13 @@ def test_bitmap_probe_by_key_range_of_unclustered_keys(ctx, shape):
         mask = rng.random(npr) < 0.6; valid = rng.random(npr) < 0.9
     table = dfgpu.JoinTable(ctx, [ctx.from_arrow(pa.array(b))])
     pa_p = pa.array(p, mask=None if valid is None else ~valid)
-    ctx.set_option("join_bitmap_partitioned_min_rows", 1 << 20)
+    ctx.set_option("join_bitmap_partitioned", 1); ctx.set_option("join_bitmap_partitioned_min_rows", 1 << 20)       # off by default (measured slower than the random probes at SF100)
     ctx.profile_select(None); ctx.profile_enable(True); ctx.profile_read()
     try:
         bi, pi = table.probe([ctx.from_arrow(pa_p)], mask=None if mask is None else ctx.from_arrow(pa.array(mask)))
         prof = ctx.profile_read()
     finally:
-        ctx.profile_enable(False); ctx.set_option("join_bitmap_partitioned_min_rows", 1 << 24)
+        ctx.profile_enable(False); ctx.set_option("join_bitmap_partitioned_min_rows", 1 << 24); ctx.set_option("join_bitmap_partitioned", 0)
     assert ("bp_probe" in prof) == shape.startswith("unclustered"), sorted(prof)
     ok = np.ones(npr, bool) if mask is None else (mask & valid)
     pos = np.searchsorted(b, p); pos[pos >= nb] = nb - 1

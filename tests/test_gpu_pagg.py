@@ -70,7 +70,8 @@ def compare(got_keys, got, want_keys, want):
     for g, w in zip(got, want):
         assert g.type == w.type and len(g) == len(w)
         if pa.types.is_floating(g.type):
-            a, b = g.to_numpy(zero_copy_only=False), w.to_numpy(zero_copy_only=False)
+            assert g.is_null().equals(w.is_null())       # a group that saw no value is NULL on both sides
+            a, b = g.fill_null(0.0).to_numpy(zero_copy_only=False), w.fill_null(0.0).to_numpy(zero_copy_only=False)
             assert np.allclose(a, b, rtol=FLOAT_RTOL, atol=0.0)
         else:
             assert g.equals(w)
