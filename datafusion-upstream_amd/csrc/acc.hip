@@ -301,10 +301,13 @@ __global__ void __launch_bounds__(BLOCK) k_acc_add_plain(int kind, const T* valu
   int64_t base = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * (WAVE * ADD_ROWS);
   if (base >= n) return;                                             // wave-uniform
   uint32_t gs[ADD_ROWS]; T xs[ADD_ROWS];
+  uint64_t hw[ADD_ROWS], hnext[ADD_ROWS];        // RUNS: the slab's head bits; bit 0 = the row after the slab starts a run (or there is none)
 #pragma unroll
   for (int r = 0; r < ADD_ROWS; r++) {
     int64_t i = base + r * WAVE + lane, ic = i < n ? i : n - 1;
-    if constexpr (RUNS) { int64_t w = ic >> 6; gs[r] = ri.base + ri.prefix[w] + (uint32_t)__popcll(ri.heads[w] & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull))) - 1u; }      // base is a multiple of 64: bit = lane
+    hw[r] = 0; hnext[r] = 1;
+    if constexpr (RUNS) { int64_t w = ic >> 6; hw[r] = ri.heads[w]; const int64_t nx = base + (int64_t)(r + 1) * WAVE; hnext[r] = nx < n ? ri.heads[nx >> 6] & 1ull : 1ull;
+      gs[r] = ri.base + ri.prefix[w] + (uint32_t)__popcll(hw[r] & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull))) - 1u; }      // base is a multiple of 64: bit = lane
     else gs[r] = gids[ic];
     if constexpr (HAS_VALUES) xs[r] = values[ic]; else xs[r] = (T)0;
     if (i >= n) gs[r] = GID_NONE;
@@ -329,7 +332,25 @@ __global__ void __launch_bounds__(BLOCK) k_acc_add_plain(int kind, const T* valu
     }
     uint32_t gn = __shfl_down(g, 1, 64); int an = __shfl_down((int)act, 1, 64);
     bool tail = act && (lane == 63 || !an || gn != g);
-    if (tail) {
+    // RUNS: a piece that begins on a head bit and ends where the run ends IS the run -- no other lane, wave or earlier batch ever touches its group (a run that starts in
+    // this batch is a new group), so its state is stored, not added with atomics.  TPC-H Q18's first aggregate: 150 M runs of ~4 rows, one in sixteen crosses a slab.
+    bool whole = false;
+    if constexpr (RUNS) {
+      const int64_t i = base + r * WAVE + lane;
+      const uint64_t le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+      const bool from_head = (hw[r] & le & hm) != 0 && ((hw[r] >> (63 - __clzll((long long)(hm & le)))) & 1ull);       // the piece's first lane carries a head bit
+      const bool to_end = i + 1 >= n || (lane == 63 ? (hnext[r] & 1ull) : ((hw[r] >> (lane + 1)) & 1ull));
+      whole = tail && from_head && to_end;
+    }
+    if (whole) {
+      if (kind == DFGPU_AGG_COUNT) counts[g] = (uint64_t)c;
+      else {
+        seen[g] = 1;
+        if (kind == DFGPU_AGG_AVG) counts[g] = (uint64_t)c;
+        if constexpr (CLS == CLS_I128) { uint64_t* o = (uint64_t*)vals + 2 * (int64_t)g; o[0] = (uint64_t)x; o[1] = (uint64_t)((unsigned __int128)x >> 64); }
+        else ((T*)vals)[g] = x;
+      }
+    } else if (tail) {
       if (kind == DFGPU_AGG_COUNT) atomicAdd((unsigned long long*)&counts[g], (unsigned long long)c);
       else {
         seen[g] = 1;
@@ -1021,7 +1042,11 @@ dfgpu_status dfgpu_acc_merge_batch(dfgpu_ctx* ctx, dfgpu_acc* a, const dfgpu_arr
     return guard(ctx, [&] {
       if (nst != 2 || st[0]->type != DFGPU_UINT64) fail(DFGPU_INVALID_ARGUMENT, "AVG merge expects (UInt64 counts, sums)");
       acc_resize(a, total);
-      launch_update(a, DFGPU_AGG_SUM, CLS_U64, st[0], gids, filt, total, a->counts->ptr);
+      // the counts are summed without touching the null state (accumulate_indices, average.rs:489-497); only a non-NULL partial sum marks its group as seen (:499-507) -- a
+      // partial state of count 0 and a NULL sum (a group whose argument was NULL in every row) must leave the group NULL
+      { BufferPtr seen = a->seen; a->seen = alloc_buffer(ctx, (size_t)a->cap + 64);
+        struct Restore { dfgpu_acc* a; BufferPtr s; ~Restore() { a->seen = s; } } restore{a, seen};
+        launch_update(a, DFGPU_AGG_SUM, CLS_U64, st[0], gids, filt, total, a->counts->ptr); }
       launch_update(a, DFGPU_AGG_SUM, a->cls, st[1], gids, filt, total, a->vals->ptr);
       check_flags(ctx, "acc_merge_batch");
     });

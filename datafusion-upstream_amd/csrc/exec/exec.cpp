@@ -810,7 +810,7 @@ struct HashJoinExec : Plan {      // joins/hash_join.rs:283-330
           // "row is selected and finds its key" -- the probe's match bits.  No index vector, no gather, no row count on the host: the consumer fuses the selection
           // (the next join's build or probe, a repartition, an aggregate) or compacts it when it must.  TPC-H Q3: customer x orders hands the orders table itself,
           // under a selection, to the build of the join with lineitem.
-          if (defer && selection_output) {
+          if (defer && selection_output && op->selection_consumer) {
             std::vector<int> al = key_aliases(&bs->batch, pb); bool all = !al.empty(); for (int a : al) all = all && a >= 0;
             if (all) {
               dfgpu_array* s = nullptr; dfgpu_status st = dfgpu_join_probe_selection(tc.ctx, bs->table->t, kp.data(), 1, mask.a, &s);

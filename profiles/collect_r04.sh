@@ -4,7 +4,7 @@
 #   gb      bench_workloads.py groupby_int64 + clickbench shapes         hj      bench_workloads.py hash_join (sparse keys)
 # Run on the GPU box from the repo root:  bash profiles/collect_r04.sh <tag> [passes...]   (default: all).  Writes gpurun_out/prof_r04_<tag>/, reduced to what travels back.
 set -o pipefail
-R=$GRAFT_REPO_ROOT; T=${1:-x}; shift; PASSES=${@:-q3 q3s gb hj}
+R=$GRAFT_REPO_ROOT; T=${1:-x}; shift; PASSES=${@:-q3 q3s gb hj shares}
 O=$R/gpurun_out/prof_r04_$T; rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 run3() {   # name, program and its arguments: kernel stats, FETCH_SIZE, WRITE_SIZE
@@ -21,5 +21,7 @@ for p in $PASSES; do case $p in
   q3s) run3 q3s $R/profiles/q3_shuffled_run.py --sf 100 --steps 5 --warmup 2 ;;
   gb)  run3 gb $R/bench_workloads.py --only groupby_int64,clickbench_uniform_1000000,clickbench_zipf_1000000 --sf 100 ;;
   hj)  run3 hj $R/bench_workloads.py --only hash_join_plain --sf 100 ;;
+  shares)   # one rank's share of the Q3 step at 8 / 4 / 2 GPUs when nothing has to move: clustered, general paths, shuffled
+    for sf in 12.5 25 50; do python3 $R/bench.py --sf $sf --steps 20 --warmup 5 --no-workloads --no-cpu-baseline --detail $O/share_sf$sf.json 2> /dev/null | tail -1 > $O/share_sf$sf.line.json; echo "share sf $sf rc=$?"; done ;;
 esac; done
-cd $O; ls -la; tail -2 *_stats.log | cut -c1-400
+cd $O; ls -la; tail -q -n 2 *_stats.log 2>/dev/null | cut -c1-400; cat share_sf*.line.json 2>/dev/null | cut -c1-700

@@ -617,3 +617,15 @@ def test_primitive_key_table_matches_the_oracle(ctx, scenario):
     check(mk(rng.integers(0, 500000, 100000) * 13))
     for a, w in zip(gv.emit(), og.emit()):
         assert a.to_arrow().equals(w)
+
+
+def test_avg_merge_of_a_partial_state_without_values_stays_null(ctx):
+    """AVG's merge_batch (average.rs:472-509) adds the partial counts without touching the null state; only a non-NULL partial sum marks its group as seen.  A Partial stage emits
+    (count 0, NULL sum) for a group whose argument was NULL in every row: merged alone the group stays NULL, merged with a real partial state it is that state's average."""
+    import dfgpu
+    acc = dfgpu.GroupsAccumulator(ctx, dfgpu.capi.AGG_AVG, dfgpu.capi.FLOAT64)
+    counts = ctx.from_arrow(pa.array([0, 2, 0, 3], type=pa.uint64()))
+    sums = ctx.from_arrow(pa.array([None, 5.0, None, 9.0], type=pa.float64()))
+    gids = ctx.from_arrow(pa.array([0, 1, 2, 2], type=pa.uint32()))
+    acc.merge_batch([counts, sums], gids, None, 3)
+    assert acc.evaluate().to_arrow().to_pylist() == [None, 2.5, 3.0]
