@@ -35,7 +35,7 @@ struct PaPlan { int32_t n_acc; int32_t op[PA_MAX_AGGS]; const uint64_t* val[PA_M
 __device__ inline uint64_t pa_identity(int op) {
   switch (op) {
     case PA_MIN_I64: return (uint64_t)INT64_MAX; case PA_MAX_I64: return (uint64_t)INT64_MIN; case PA_MIN_U64: return ~0ull; case PA_MAX_U64: return 0ull;
-    case PA_MIN_F64: return 0x7FF0000000000000ull /* +inf */; case PA_MAX_F64: return 0xFFF0000000000000ull /* -inf */;
+    case PA_MIN_F64: return 0x7FEFFFFFFFFFFFFFull /* f64::MAX */; case PA_MAX_F64: return 0xFFEFFFFFFFFFFFFFull /* f64::MIN */;      // the reference's starting values (min_max.rs:102-139): `cur < new` never lets +-inf beyond them or a NaN in
     default: return 0ull;
   }
 }
@@ -45,7 +45,7 @@ __device__ inline void pa_apply(int op, unsigned long long* cell, uint64_t v) {
     case PA_SUM_F64: atomicAdd((double*)cell, __longlong_as_double((long long)v)); break;
     case PA_MIN_I64: atomicMin((long long*)cell, (long long)v); break; case PA_MAX_I64: atomicMax((long long*)cell, (long long)v); break;
     case PA_MIN_U64: atomicMin(cell, (unsigned long long)v); break; case PA_MAX_U64: atomicMax(cell, (unsigned long long)v); break;
-    case PA_MIN_F64: { double d = __longlong_as_double((long long)v); if (d == d) atomicMin((double*)cell, d); break; }     // NaN inputs: handled by the caller's eligibility (MIN/MAX over Float64 keep the general path when NaNs matter)
+    case PA_MIN_F64: { double d = __longlong_as_double((long long)v); if (d == d) atomicMin((double*)cell, d); break; }     // `if *cur > new` (min_max.rs:124-139) is false for a NaN: NaN inputs never enter, whatever the order
     case PA_MAX_F64: { double d = __longlong_as_double((long long)v); if (d == d) atomicMax((double*)cell, d); break; }
     default: break;
   }
@@ -56,6 +56,8 @@ __device__ inline uint64_t pa_combine(int op, uint64_t a, uint64_t b) {         
     case PA_SUM_F64: return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
     case PA_MIN_I64: return (long long)a < (long long)b ? a : b; case PA_MAX_I64: return (long long)a > (long long)b ? a : b;
     case PA_MIN_U64: return a < b ? a : b; case PA_MAX_U64: return a > b ? a : b;
+    case PA_MIN_F64: { const double x = __longlong_as_double((long long)a), y = __longlong_as_double((long long)b); return y == y && (x != x || y < x) ? b : a; }      // a NaN never wins
+    case PA_MAX_F64: { const double x = __longlong_as_double((long long)a), y = __longlong_as_double((long long)b); return y == y && (x != x || y > x) ? b : a; }
     default: return a;
   }
 }
@@ -447,8 +449,8 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
       switch (kinds[i]) {
         case DFGPU_AGG_SUM: op = d128 ? PA_SUM_I128_LO : f64 ? PA_SUM_F64 : PA_SUM_I64; break;
         case DFGPU_AGG_AVG: if (!f64 && !d128) skip("AVG over Float64 / Decimal128"); op = d128 ? PA_SUM_I128_LO : PA_SUM_F64; break;
-        case DFGPU_AGG_MIN: if (f64 || d128) skip("MIN over Float64 (NaN order) / Decimal128"); op = i64 ? PA_MIN_I64 : PA_MIN_U64; break;
-        case DFGPU_AGG_MAX: if (f64 || d128) skip("MAX over Float64 (NaN order) / Decimal128"); op = i64 ? PA_MAX_I64 : PA_MAX_U64; break;
+        case DFGPU_AGG_MIN: if (d128) skip("MIN over Decimal128"); op = f64 ? PA_MIN_F64 : i64 ? PA_MIN_I64 : PA_MIN_U64; break;
+        case DFGPU_AGG_MAX: if (d128) skip("MAX over Decimal128"); op = f64 ? PA_MAX_F64 : i64 ? PA_MAX_I64 : PA_MAX_U64; break;
         default: skip("SUM / AVG / COUNT / MIN / MAX");
       }
       int c = -1; for (int j = 0; j < plan.n_acc; j++) if (plan.op[j] == op && cell_src[j] == v) c = j;          // SUM(x) and AVG(x) share a cell

@@ -367,3 +367,28 @@ def test_nullable_aggregate_arguments(ctx, two_level):
     wk, want = run_oracle(key, aggs)
     compare(gk, got, wk, want)
     assert got[0].null_count > 0 and got[0].null_count == want[0].null_count and got[2].null_count == want[2].null_count
+
+
+def test_float_min_max_with_nans_and_infinities(ctx):
+    """MIN / MAX over Float64 through the partitioned path: the reference's closures (`if *cur > new`, starting at f64::MAX / f64::MIN, min_max.rs:102-139) never take a NaN and
+    never move past their starting value, so the result does not depend on the order rows are met in -- NaN inputs are ignored, a group of NaNs only keeps the starting value, an
+    infinity beyond the starting value never enters.  Nullable too."""
+    rng = np.random.default_rng(31)
+    n, card = 500_000, 40_000
+    kv = rng.integers(0, card, n).astype(np.int64) * 31 + 3
+    x = rng.normal(size=n) * 1e6
+    x[rng.random(n) < 0.02] = np.nan
+    x[rng.random(n) < 0.01] = np.inf
+    x[rng.random(n) < 0.01] = -np.inf
+    x[(kv % 11) == 0] = np.nan                                  # whole groups of NaNs
+    vf = pa.array(x, mask=rng.random(n) < 0.1)
+    aggs = [("MIN", vf), ("MAX", vf), ("COUNT", vf), ("SUM", pa.array(rng.integers(0, 100, n).astype(np.int64)))]
+    with forced(ctx) as f:
+        gk, got, m = run_device(ctx, pa.array(kv), aggs)
+        assert "pa_aggregate" in f.kernels()
+    wk, want = run_oracle(pa.array(kv), aggs)
+    assert gk.equals(wk)
+    for g, w in zip(got, want):
+        assert g.type == w.type and g.is_null().equals(w.is_null())
+        a, b = g.fill_null(0).to_numpy(zero_copy_only=False), w.fill_null(0).to_numpy(zero_copy_only=False)
+        assert np.array_equal(a, b)                               # MIN / MAX pick one of the inputs (or the starting value): exact
