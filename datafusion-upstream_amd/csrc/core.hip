@@ -339,6 +339,39 @@ __global__ void __launch_bounds__(BLOCK) k_list_row_of(const int32_t* offsets, i
   while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if ((int64_t)offsets[mid] <= at) lo = mid; else hi = mid - 1; }
   row_of[e] = (uint32_t)lo;
 }
+// ---- lists of STRINGS (the List<Utf8> state of COUNT(DISTINCT) over a Utf8 argument, count_distinct/bytes.rs:47-75): a row of the list column holds its strings back to back,
+// each as a 4-byte little-endian length followed by its bytes -- still one Utf8-layout column, moved by everything that moves strings.
+__global__ void __launch_bounds__(BLOCK) k_slist_sizes(const int32_t* voff, int64_t nv, uint32_t* enc) {        // enc[j] = 4 + length of value j; enc[nv] = 0
+  const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (j > nv) return;
+  enc[j] = j == nv ? 0u : 4u + (uint32_t)(voff[j + 1] - voff[j]);
+}
+__global__ void __launch_bounds__(BLOCK) k_slist_offsets(const uint32_t* cpre /*[n + 1] first value of every row*/, const uint32_t* epos /*[nv + 1]*/, int64_t n, int32_t* out_off) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i <= n) out_off[i] = (int32_t)epos[cpre[i]];
+}
+__global__ void __launch_bounds__(BLOCK) k_slist_encode(const int32_t* voff, const uint8_t* vbytes, int64_t nv, const uint32_t* epos, uint8_t* out) {
+  const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (j >= nv) return;
+  const uint32_t len = (uint32_t)(voff[j + 1] - voff[j]); uint8_t* o = out + epos[j]; const uint8_t* src = vbytes + voff[j];
+  o[0] = (uint8_t)len; o[1] = (uint8_t)(len >> 8); o[2] = (uint8_t)(len >> 16); o[3] = (uint8_t)(len >> 24);
+  for (uint32_t b = 0; b < len; b++) o[4 + b] = src[b];
+}
+// a row's strings: pass 0 counts them (cnt[i]), pass 1 writes, for value vstart[i] + k, its length, the byte it starts at inside the list's values and its row
+__global__ void __launch_bounds__(BLOCK) k_slist_walk(const int32_t* loff, const uint8_t* lbytes, int64_t n, const uint32_t* vstart, uint32_t* cnt, uint32_t* lens, uint32_t* spos, uint32_t* row_of, uint32_t* flags) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i >= n) return;
+  int64_t at = loff[i]; const int64_t end = loff[i + 1]; uint32_t k = 0;
+  while (at < end) {
+    if (at + 4 > end) { atomicOr(flags, DFGPU_FLAG_OOB); break; }
+    const uint32_t len = (uint32_t)lbytes[at] | ((uint32_t)lbytes[at + 1] << 8) | ((uint32_t)lbytes[at + 2] << 16) | ((uint32_t)lbytes[at + 3] << 24);
+    if (at + 4 + (int64_t)len > end) { atomicOr(flags, DFGPU_FLAG_OOB); break; }
+    if (lens) { const uint32_t v = vstart[i] + k; lens[v] = len; spos[v] = (uint32_t)(at + 4); row_of[v] = (uint32_t)i; }
+    k++; at += 4 + (int64_t)len;
+  }
+  if (cnt) cnt[i] = k;
+}
+__global__ void __launch_bounds__(BLOCK) k_slist_copy(const uint8_t* lbytes, const uint32_t* spos, const int32_t* voff, int64_t nv, uint8_t* out) {
+  const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (j >= nv) return;
+  const uint32_t len = (uint32_t)(voff[j + 1] - voff[j]); const uint8_t* src = lbytes + spos[j]; uint8_t* o = out + voff[j];
+  for (uint32_t b = 0; b < len; b++) o[b] = src[b];
+}
 }  // namespace dfgpu
 
 extern "C" {
@@ -733,7 +766,29 @@ dfgpu_status dfgpu_list_from_counts(dfgpu_ctx* ctx, const dfgpu_array* counts, c
   return guard(ctx, [&] {
     if (!counts || !values || !out) fail(DFGPU_INVALID_ARGUMENT, "list_from_counts: null argument");
     if (counts->type != DFGPU_INT64) fail(DFGPU_INVALID_ARGUMENT, "list_from_counts: counts must be Int64");
-    if (values->type == DFGPU_UTF8 || values->type == DFGPU_DICTIONARY || values->type == DFGPU_BOOL) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: lists of type %d values on the device (fixed-width values only)", values->type);
+    if (values->type == DFGPU_UTF8) {            // a list of strings: every string as (u32 length, bytes)
+      if (values->validity) fail(DFGPU_INVALID_ARGUMENT, "list_from_counts: the values of a list carry no NULLs");
+      const int64_t n = counts->length, nv = values->length;
+      BufferPtr enc = alloc_buffer(ctx, (size_t)(nv + 1) * 4 + 16), cpre = alloc_buffer(ctx, (size_t)(n + 1) * 4 + 16);
+      hipLaunchKernelGGL(k_slist_sizes, dim3(grid_for(nv + 1, BLOCK)), dim3(BLOCK), 0, ctx->stream, nv ? (const int32_t*)values->offsets->ptr : (const int32_t*)nullptr, nv, (uint32_t*)enc->ptr);
+      exclusive_scan_u32_inplace32(ctx, (uint32_t*)enc->ptr, nv + 1, ctx->d_scratch64 + 13);
+      hipLaunchKernelGGL(k_list_lens, dim3(grid_for(n + 1, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const int64_t*)counts->values->ptr, n, 1u, (uint32_t*)cpre->ptr, ctx->d_flags);
+      exclusive_scan_u32_inplace32(ctx, (uint32_t*)cpre->ptr, n + 1, ctx->d_scratch64 + 14);
+      KERNEL_CHECK();
+      const uint64_t* tot = read_scratch_range(ctx, 13, 2);
+      const int64_t ebytes = (int64_t)tot[0], nvals = (int64_t)tot[1];
+      if (nvals != nv) fail(DFGPU_INVALID_ARGUMENT, "list_from_counts: the counts add up to %lld values, the values hold %lld", (long long)nvals, (long long)nv);
+      if (ebytes > 0x7FFFFFF0ll) fail(DFGPU_NOT_IMPLEMENTED, "list_from_counts: %lld bytes of list values exceed 32-bit offsets", (long long)ebytes);
+      ArrayHolder h(new_array(ctx, DFGPU_UTF8, n)); dfgpu_array* o = h.get();
+      o->offsets = alloc_buffer(ctx, (size_t)(n + 1) * 4 + 16); o->values = alloc_buffer(ctx, (size_t)ebytes + 16); o->values_bytes = ebytes; o->null_count = 0;
+      hipLaunchKernelGGL(k_slist_offsets, dim3(grid_for(n + 1, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)cpre->ptr, (const uint32_t*)enc->ptr, n, (int32_t*)o->offsets->ptr);
+      if (nv) hipLaunchKernelGGL(k_slist_encode, dim3(grid_for(nv, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const int32_t*)values->offsets->ptr, (const uint8_t*)values->values->ptr, nv, (const uint32_t*)enc->ptr, (uint8_t*)o->values->ptr);
+      KERNEL_CHECK();
+      check_flags(ctx, "list_from_counts");
+      *out = h.release();
+      return;
+    }
+    if (values->type == DFGPU_DICTIONARY || values->type == DFGPU_BOOL) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: lists of type %d values on the device (fixed-width values only)", values->type);
     const int w = type_width(values->type); const int64_t n = counts->length, bytes = values->length * w;
     if (bytes > 0x7FFFFFF0ll) fail(DFGPU_NOT_IMPLEMENTED, "list_from_counts: %lld bytes of values exceed 32-bit offsets", (long long)bytes);
     ArrayHolder h(new_array(ctx, DFGPU_UTF8, n)); dfgpu_array* o = h.get();
@@ -750,7 +805,36 @@ dfgpu_status dfgpu_list_flatten(dfgpu_ctx* ctx, const dfgpu_array* list, int32_t
   return guard(ctx, [&] {
     if (!list || !out_values || !out_row_of) fail(DFGPU_INVALID_ARGUMENT, "list_flatten: null argument");
     if (list->type != DFGPU_UTF8) fail(DFGPU_INVALID_ARGUMENT, "list_flatten: a list column travels in the Utf8 layout, got type %d", list->type);
-    if (value_type == DFGPU_UTF8 || value_type == DFGPU_DICTIONARY || value_type == DFGPU_BOOL || value_type < DFGPU_INT8) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: lists of type %d values on the device", value_type);
+    if (value_type == DFGPU_UTF8) {             // the strings of every row back out of their (length, bytes) form
+      const int64_t n = list->length;
+      ArrayHolder v(new_array(ctx, DFGPU_UTF8, 0)), r(new_fixed(ctx, DFGPU_UINT32, 0));
+      if (n) {
+        const int32_t* lo = (const int32_t*)list->offsets->ptr; const uint8_t* lb = list->values ? (const uint8_t*)list->values->ptr : nullptr;
+        BufferPtr cnt = alloc_buffer(ctx, (size_t)(n + 1) * 4 + 16);
+        HIP_CHECK(hipMemsetAsync(cnt->ptr, 0, (size_t)(n + 1) * 4, ctx->stream));
+        hipLaunchKernelGGL(k_slist_walk, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, lo, lb, n, (const uint32_t*)nullptr, (uint32_t*)cnt->ptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, ctx->d_flags);
+        exclusive_scan_u32_inplace32(ctx, (uint32_t*)cnt->ptr, n + 1, ctx->d_scratch64 + 13);
+        KERNEL_CHECK();
+        const int64_t nv = (int64_t)read_scratch(ctx, 13);
+        check_flags(ctx, "list_flatten (a list row is not a sequence of (length, bytes) strings)");
+        if (nv > 0xFFFFFFF0ll) fail(DFGPU_NOT_IMPLEMENTED, "list_flatten: %lld values", (long long)nv);
+        r.a = (dfgpu_array_release(r.release()), new_fixed(ctx, DFGPU_UINT32, nv));
+        dfgpu_array* o = v.get(); o->length = nv; o->null_count = 0;
+        o->offsets = alloc_buffer(ctx, (size_t)(nv + 1) * 4 + 16);
+        BufferPtr spos = alloc_buffer(ctx, (size_t)(nv + 1) * 4 + 16);
+        HIP_CHECK(hipMemsetAsync(o->offsets->ptr, 0, (size_t)(nv + 1) * 4, ctx->stream));
+        hipLaunchKernelGGL(k_slist_walk, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, lo, lb, n, (const uint32_t*)cnt->ptr, (uint32_t*)nullptr, (uint32_t*)o->offsets->ptr, (uint32_t*)spos->ptr, (uint32_t*)r.get()->values->ptr, ctx->d_flags);
+        exclusive_scan_u32_inplace32(ctx, (uint32_t*)o->offsets->ptr, nv + 1, ctx->d_scratch64 + 13);
+        KERNEL_CHECK();
+        const int64_t vb = (int64_t)read_scratch(ctx, 13);
+        o->values = alloc_buffer(ctx, (size_t)vb + 16); o->values_bytes = vb;
+        if (nv) hipLaunchKernelGGL(k_slist_copy, dim3(grid_for(nv, BLOCK)), dim3(BLOCK), 0, ctx->stream, lb, (const uint32_t*)spos->ptr, (const int32_t*)o->offsets->ptr, nv, (uint8_t*)o->values->ptr);
+        KERNEL_CHECK();
+      } else { v.get()->offsets = alloc_buffer(ctx, 16, true); v.get()->values = alloc_buffer(ctx, 16); v.get()->null_count = 0; }
+      *out_values = v.release(); *out_row_of = r.release();
+      return;
+    }
+    if (value_type == DFGPU_DICTIONARY || value_type == DFGPU_BOOL || value_type < DFGPU_INT8) fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: lists of type %d values on the device", value_type);
     const int w = type_width(value_type); const int64_t n = list->length;
     int32_t ends[2] = {0, 0};
     if (n) { HIP_CHECK(hipMemcpyAsync(&ends[0], list->offsets->ptr, 4, hipMemcpyDeviceToHost, ctx->stream)); HIP_CHECK(hipMemcpyAsync(&ends[1], (const int32_t*)list->offsets->ptr + n, 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -1217,7 +1217,7 @@ struct StringMinMax {
 };
 // COUNT(DISTINCT x) (physical-expr/src/aggregate/count_distinct/: a set of values per group): the (group id, value) pairs are interned in a GroupValues of their own;
 // every NEW pair adds one to its group's count.  Partial emits the reference's state -- one List of distinct values per group -- in the Utf8 layout (state()), Final /
-// FinalPartitioned merge such lists (merge()); fixed-width argument types (Utf8 arguments: Single / SinglePartitioned only).
+// FinalPartitioned merge such lists (merge()); fixed-width arguments as packed values, Utf8 arguments as (length, bytes) strings (count_distinct/bytes.rs:47-75).
 struct CountDistinct {
   GroupsRef pairs; AccRef cnt;
   void init(const TaskContext& tc) { tc.check(dfgpu_groups_new(tc.ctx, 2, &pairs.g)); tc.check(dfgpu_acc_new(tc.ctx, DFGPU_AGG_COUNT, DFGPU_INT64, 0, 0, &cnt.a)); }
@@ -2178,8 +2178,8 @@ dfgpu_status dfgpu_plan_aggregate(int32_t mode, const dfgpu_expr* const* gexprs,
       AggExpr x; x.kind = kinds[i]; if (args && args[i]) x.arg = args[i]->e; if (filters && filters[i]) x.filter = filters[i]->e; x.name = names[i] ? names[i] : "";
       x.type = types[3 * i]; x.precision = types[3 * i + 1]; x.scale = types[3 * i + 2];
       if (x.kind < DFGPU_AGG_SUM || x.kind > DFGPU_AGG_COUNT_DISTINCT) fail(DFGPU_NOT_IMPLEMENTED, "aggregate kind %d has no GroupsAccumulator on device", x.kind);
-      if (x.kind == DFGPU_AGG_COUNT_DISTINCT && mode != 3 && mode != 4 && (x.type == DFGPU_UTF8 || x.type == DFGPU_DICTIONARY || x.type == DFGPU_BOOL))
-        fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: COUNT(DISTINCT) over a type %d argument in AggregateMode %d on the device (its Partial state is a List per group, carried for fixed-width values); Single / SinglePartitioned are", x.type, mode);
+      if (x.kind == DFGPU_AGG_COUNT_DISTINCT && mode != 3 && mode != 4 && (x.type == DFGPU_DICTIONARY || x.type == DFGPU_BOOL))
+        fail(DFGPU_NOT_IMPLEMENTED, "This feature is not implemented: COUNT(DISTINCT) over a type %d argument in AggregateMode %d on the device (its Partial state is a List per group, carried for fixed-width and Utf8 values); Single / SinglePartitioned are", x.type, mode);
       if (!x.arg && x.kind != DFGPU_AGG_COUNT && mode != 1 && mode != 2) fail(DFGPU_INVALID_ARGUMENT, "aggregate %s needs an argument", x.name.c_str());
       a->aggs.push_back(std::move(x));
     }

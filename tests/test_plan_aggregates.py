@@ -79,9 +79,7 @@ def test_device_equals_models_on_random_batches(ctx, mode):
         batches.append(pa.table({"k": pa.array(rng.integers(0, 40, n).astype(np.int64), mask=rng.random(n) < 0.05),
                                  "s": pa.array(words[rng.integers(0, 60, n)], mask=rng.random(n) < 0.3),
                                  "v": pa.array(rng.integers(0, 25, n).astype(np.int64), mask=rng.random(n) < 0.2)}))
-    aggs = [("MIN", "s", capi.UTF8), ("MAX", "s", capi.UTF8), ("COUNT", "v", capi.INT64), ("COUNT DISTINCT", "v", capi.INT64)]
-    if mode == "Single":
-        aggs += [("COUNT DISTINCT", "s", capi.UTF8)]
+    aggs = [("MIN", "s", capi.UTF8), ("MAX", "s", capi.UTF8), ("COUNT", "v", capi.INT64), ("COUNT DISTINCT", "v", capi.INT64), ("COUNT DISTINCT", "s", capi.UTF8)]
     out = agg_plan(ctx, batches, ["k"], aggs, mode)
     allt = pa.concat_tables(batches)
     og = po.Groups([pa.int64()]); gids = og.intern([allt["k"].combine_chunks()]); total = len(og)
@@ -90,18 +88,57 @@ def test_device_equals_models_on_random_batches(ctx, mode):
     assert out.column(1).combine_chunks().equals(po.string_min_max(s, gids, total, False))
     assert out.column(2).combine_chunks().equals(po.string_min_max(s, gids, total, True))
     assert out.column(4).combine_chunks().equals(po.count_distinct(v, gids, total))        # PartialFinal: through the List state of the Partial stage
-    if mode == "Single":
-        assert out.column(5).combine_chunks().equals(po.count_distinct(s, gids, total))
+    assert out.column(5).combine_chunks().equals(po.count_distinct(s, gids, total))        # PartialFinal: a List of strings per group ((length, bytes) in the Utf8 layout)
+
+
+def string_lists_of(col: pa.Array):
+    """a list-of-strings column as it travels on the device (every string as u32 length + bytes inside a Utf8-layout row) -> Python lists of str"""
+    col = col.combine_chunks() if isinstance(col, pa.ChunkedArray) else col
+    off = np.frombuffer(col.buffers()[1], dtype=np.int32)[col.offset: col.offset + len(col) + 1]
+    data = bytes(col.buffers()[2]) if col.buffers()[2] is not None else b""
+    out = []
+    for i in range(len(col)):
+        at, row = int(off[i]), []
+        while at < off[i + 1]:
+            ln = int.from_bytes(data[at:at + 4], "little"); row.append(data[at + 4:at + 4 + ln].decode()); at += 4 + ln
+        assert at == off[i + 1]
+        out.append(row)
+    return out
 
 
 @pytest.mark.gpu
-def test_device_refuses_count_distinct_over_strings_in_partial_mode(ctx):
-    import dfgpu
-    from dfgpu import capi
-    t = pa.table({"k": pa.array([1, 2], type=pa.int64()), "v": pa.array(["a", "a"])})
-    with pytest.raises(dfgpu.DfgpuError) as e:
-        agg_plan(ctx, [t], ["k"], [("COUNT DISTINCT", "v", capi.UTF8)], "PartialFinal")
-    assert e.value.kind == "NotImplemented"
+@pytest.mark.parametrize("parts", [1, 3])
+def test_count_distinct_over_strings_partial_state_and_final(ctx, parts):
+    """COUNT(DISTINCT s) over a Utf8 argument in Partial -> RepartitionExec -> FinalPartitioned (count_distinct/bytes.rs:47-75: the state is one List of the group's distinct
+    strings; merge_batch inserts every string of every incoming list): the Partial stage's lists hold each group's distinct strings in first-seen order -- empty strings,
+    multi-byte characters and strings that look like length prefixes included, NULLs excluded --, the counts equal the Single mode's, the model's and pyarrow's."""
+    from dfgpu import capi, physical_plan as ops
+    rng = np.random.default_rng(40 + parts)
+    n = 20_000
+    words = np.array(["", "a", "\x05\x00\x00\x00x", "é" * 3, "long-" * 40] + [f"w{v:03d}" for v in range(45)], dtype=object)
+    k = rng.integers(0, 200, n).astype(np.int64)
+    t = pa.table({"k": pa.array(k, mask=rng.random(n) < 0.02), "s": pa.array(words[rng.integers(0, len(words), n)].tolist(), type=pa.utf8(), mask=rng.random(n) < 0.25)})
+    batches = [t.slice(o, 4096) for o in range(0, n, 4096)]
+    C, F = ops.Column, ops.Field
+    bs = [[ops.batch_from_arrow(ctx, b) for b in batches[p::parts]] for p in range(parts)]
+    src = ops.MemoryExec(bs, bs[0][0].schema)
+    aggs = lambda: [ops.AggregateFunctionExpr("COUNT DISTINCT", C("s", 1), "cs", input_field=F("s", capi.UTF8)), ops.AggregateFunctionExpr("COUNT", C("s", 1), "n", input_field=F("s", capi.UTF8))]
+    tc = ops.TaskContext(ctx, 8192)
+    st = pa.concat_tables([b.to_arrow() for b in ops.AggregateExec("Partial", [(C("k", 0), "k")], aggs(), src).execute(0, tc)])
+    seen = pa.concat_tables(batches[0::parts])
+    og = po.Groups([pa.int64()]); gids = og.intern([seen["k"].combine_chunks()])
+    want = [[] for _ in range(len(og))]
+    for g, x in zip(np.asarray(gids).tolist(), seen["s"].to_pylist()):
+        if x is not None and x not in want[g]:
+            want[g].append(x)
+    assert st.column(0).combine_chunks().equals(og.emit()[0]) and string_lists_of(st.column(1)) == want
+    plan = ops.AggregateExec("FinalPartitioned", [(C("k", 0), "k")], aggs(),
+                             ops.CoalesceBatchesExec(ops.RepartitionExec(ops.AggregateExec("Partial", [(C("k", 0), "k")], aggs(), src), ops.Partitioning.Hash([C("k", 0)], 4)), 8192))
+    out = pa.concat_tables([b.to_arrow() for p in range(4) for b in plan.execute(p, tc)]).sort_by([("k", "ascending")])
+    single = pa.concat_tables([b.to_arrow() for b in ops.AggregateExec("Single", [(C("k", 0), "k")], aggs(), ops.MemoryExec([[x for p in bs for x in p]], bs[0][0].schema)).execute(0, tc)]).sort_by([("k", "ascending")])
+    assert out.equals(single)
+    ref = t.group_by("k", use_threads=False).aggregate([("s", "count_distinct"), ("s", "count")]).sort_by([("k", "ascending")])
+    assert out["cs"].to_pylist() == ref["s_count_distinct"].to_pylist() and out["n"].to_pylist() == ref["s_count"].to_pylist()
 
 
 def lists_of(col: pa.Array, dtype):
