@@ -142,6 +142,7 @@ PROTOTYPES = {
     "dfgpu_groups_len": (C.c_int64, [_P]),
     "dfgpu_groups_size": (C.c_int64, [_P]),
     "dfgpu_groups_emit": (C.c_int32, [_P, _P, _PP]),
+    "dfgpu_groups_emit_deferred": (C.c_int32, [_P, _P, _PP, _PP]),
     "dfgpu_acc_new": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _PP]),
     "dfgpu_acc_free": (None, [_P]),
     "dfgpu_acc_update_batch": (C.c_int32, [_P, _P, _P, _P, _P, C.c_int64]),

@@ -301,13 +301,10 @@ __global__ void __launch_bounds__(BLOCK) k_acc_add_plain(int kind, const T* valu
   int64_t base = ((int64_t)blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)) * (WAVE * ADD_ROWS);
   if (base >= n) return;                                             // wave-uniform
   uint32_t gs[ADD_ROWS]; T xs[ADD_ROWS];
-  uint64_t hw[ADD_ROWS], hnext[ADD_ROWS];        // RUNS: the slab's head bits; bit 0 = the row after the slab starts a run (or there is none)
 #pragma unroll
   for (int r = 0; r < ADD_ROWS; r++) {
     int64_t i = base + r * WAVE + lane, ic = i < n ? i : n - 1;
-    hw[r] = 0; hnext[r] = 1;
-    if constexpr (RUNS) { int64_t w = ic >> 6; hw[r] = ri.heads[w]; const int64_t nx = base + (int64_t)(r + 1) * WAVE; hnext[r] = nx < n ? ri.heads[nx >> 6] & 1ull : 1ull;
-      gs[r] = ri.base + ri.prefix[w] + (uint32_t)__popcll(hw[r] & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull))) - 1u; }      // base is a multiple of 64: bit = lane
+    if constexpr (RUNS) { int64_t w = ic >> 6; gs[r] = ri.base + ri.prefix[w] + (uint32_t)__popcll(ri.heads[w] & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull))) - 1u; }      // base is a multiple of 64: bit = lane
     else gs[r] = gids[ic];
     if constexpr (HAS_VALUES) xs[r] = values[ic]; else xs[r] = (T)0;
     if (i >= n) gs[r] = GID_NONE;
@@ -332,25 +329,9 @@ __global__ void __launch_bounds__(BLOCK) k_acc_add_plain(int kind, const T* valu
     }
     uint32_t gn = __shfl_down(g, 1, 64); int an = __shfl_down((int)act, 1, 64);
     bool tail = act && (lane == 63 || !an || gn != g);
-    // RUNS: a piece that begins on a head bit and ends where the run ends IS the run -- no other lane, wave or earlier batch ever touches its group (a run that starts in
-    // this batch is a new group), so its state is stored, not added with atomics.  TPC-H Q18's first aggregate: 150 M runs of ~4 rows, one in sixteen crosses a slab.
-    bool whole = false;
-    if constexpr (RUNS) {
-      const int64_t i = base + r * WAVE + lane;
-      const uint64_t le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-      const bool from_head = (hw[r] & le & hm) != 0 && ((hw[r] >> (63 - __clzll((long long)(hm & le)))) & 1ull);       // the piece's first lane carries a head bit
-      const bool to_end = i + 1 >= n || (lane == 63 ? (hnext[r] & 1ull) : ((hw[r] >> (lane + 1)) & 1ull));
-      whole = tail && from_head && to_end;
-    }
-    if (whole) {
-      if (kind == DFGPU_AGG_COUNT) counts[g] = (uint64_t)c;
-      else {
-        seen[g] = 1;
-        if (kind == DFGPU_AGG_AVG) counts[g] = (uint64_t)c;
-        if constexpr (CLS == CLS_I128) { uint64_t* o = (uint64_t*)vals + 2 * (int64_t)g; o[0] = (uint64_t)x; o[1] = (uint64_t)((unsigned __int128)x >> 64); }
-        else ((T*)vals)[g] = x;
-      }
-    } else if (tail) {
+    // (measured: storing whole runs -- a piece that starts on a head bit and ends where its run ends -- without atomics made TPC-H Q18's 150 M runs slower, 2.8 -> 3.1 ms:
+    // the L2 atomics were not the bound, the extra head-bit loads and three partial-line stores per group cost more)
+    if (tail) {
       if (kind == DFGPU_AGG_COUNT) atomicAdd((unsigned long long*)&counts[g], (unsigned long long)c);
       else {
         seen[g] = 1;

@@ -419,6 +419,7 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "join_bitmap_partitioned_min_rows") ctx->join_bitmap_partitioned_min_rows = value;
     else if (k == "join_key_packing") ctx->join_key_packing = value != 0;
     else if (k == "group_run_detection") ctx->group_run_detection = value != 0;
+    else if (k == "group_lazy_keys") ctx->group_lazy_keys = value != 0;
     else if (k == "group_dictionary_canon") ctx->group_dictionary_canon = value != 0;
     else if (k == "join_swap_small_semi") ctx->join_swap_small_semi = value != 0;
     else if (k == "fused_aggregate_min_rows") ctx->fused_aggregate_min_rows = value;

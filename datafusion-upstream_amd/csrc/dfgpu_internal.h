@@ -48,6 +48,7 @@ struct dfgpu_ctx {
   bool join_rank_index_unsorted = true;     // unique integer keys over a dense domain in ANY order (a repartitioned or filtered primary-key column): bitmap + rank -> build row
   bool join_key_packing = true;
   bool group_run_detection = true;
+  bool group_lazy_keys = true;              // run-mode GroupValues: the first batch's group keys stay (key columns, first rows) until somebody needs them stored (groups.hip)
   bool group_dictionary_canon = true;
   bool join_swap_small_semi = true;
   // radix-partitioned hash join (pjoin.hip): on/off, smallest build / probe batch that takes it, build rows per partition (<= 14000)

@@ -1543,7 +1543,14 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
     if (total > 0) {              // emit(EmitTo::All) (row_hash.rs:626-662)
       Batch o; o.base_rows = total; std::vector<dfgpu_array*> keys(gexprs.size(), nullptr);
       if (grouped && pending) o.cols.push_back(col_of(pending));          // one key column, already in first-seen order
-      else { if (grouped) tc.check(dfgpu_groups_emit(tc.ctx, groups.g, keys.data())); for (auto k : keys) o.cols.push_back(col_of(ArrayRef::adopt(k))); }
+      else if (grouped) {
+        // keys still "column c at the first row of the run" (one clustered batch): they leave as pending gathers, so that a HAVING above reads the keys of the groups it keeps only
+        std::vector<dfgpu_array*> src(gexprs.size(), nullptr); dfgpu_array* rows = nullptr;
+        dfgpu_status st = dfgpu_groups_emit_deferred(tc.ctx, groups.g, src.data(), &rows);
+        if (st == DFGPU_OK) { ArrayRef r = ArrayRef::adopt(rows); MemoPtr memo = std::make_shared<TakeMemo>();
+          for (auto sp : src) { Col c; c.source = ArrayRef::adopt(sp); c.chain.push_back(r); c.memo = memo; o.cols.push_back(std::move(c)); } }
+        else { if (st != DFGPU_NOT_IMPLEMENTED) tc.check(st); tc.check(dfgpu_groups_emit(tc.ctx, groups.g, keys.data())); for (auto k : keys) o.cols.push_back(col_of(ArrayRef::adopt(k))); }
+      }
       dfgpu_array_desc ed{}; ed.type = DFGPU_UINT32; ed.values = &ed; dfgpu_array* e = nullptr; tc.check(dfgpu_array_import_host(tc.ctx, &ed, &e)); ArrayRef empty_ids = ArrayRef::adopt(e);
       for (size_t i = 0; i < aggs.size(); i++) {
         if (is_string_minmax(i)) { o.cols.push_back(col_of(smm[i].emit(tc, total))); continue; }          // state and final value are the same column

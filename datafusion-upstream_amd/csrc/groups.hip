@@ -49,7 +49,11 @@ struct dfgpu_groups {
   // 16 bytes {key, group id, first row}: find-or-insert touches one sector per row (the general table needs the slot, its first-row
   // word and the representative key behind a matching tag: three), and no stored-key column is consulted.
   BufferPtr pslots; uint64_t pcap = 0; bool prim_mode = false, prim_banned = false;
-  ~dfgpu_groups() { for (auto* a : keys) if (a) dfgpu_array_release(a); for (auto* a : canon_keys) if (a) dfgpu_array_release(a); for (auto& c : canon) if (c.dict) dfgpu_array_release(c.dict); }
+  // run mode, first batch: the stored keys are take(lazy_src[c], lazy_rows) -- the batch's key columns at the first row of every run -- and are not gathered until somebody
+  // needs them here (a second batch, emit).  dfgpu_groups_emit_deferred hands (columns, rows) to a caller that gathers lazily itself: TPC-H Q18's HAVING keeps a few thousand
+  // of 150 M groups, and only their keys are ever read.
+  std::vector<dfgpu_array*> lazy_src; dfgpu_array* lazy_rows = nullptr;
+  ~dfgpu_groups() { for (auto* a : lazy_src) if (a) dfgpu_array_release(a); if (lazy_rows) dfgpu_array_release(lazy_rows); for (auto* a : keys) if (a) dfgpu_array_release(a); for (auto* a : canon_keys) if (a) dfgpu_array_release(a); for (auto& c : canon) if (c.dict) dfgpu_array_release(c.dict); }
 };
 
 namespace dfgpu {
@@ -504,6 +508,13 @@ static void groups_append_keys(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_arra
            dfgpu_array_release(g->keys[c]); g->keys[c] = cat; }
   }
 }
+static void groups_resolve_keys(dfgpu_ctx* ctx, dfgpu_groups* g) {        // the pending gather of a first run-mode batch's keys, now
+  if (!g->lazy_rows) return;
+  std::vector<dfgpu_array*> src; src.swap(g->lazy_src); dfgpu_array* rows = g->lazy_rows; g->lazy_rows = nullptr;
+  struct Drop { std::vector<dfgpu_array*>& s; dfgpu_array* r; ~Drop() { for (auto* a : s) if (a) dfgpu_array_release(a); dfgpu_array_release(r); } } drop{src, rows};
+  std::vector<const dfgpu_array*> cs(src.begin(), src.end());
+  groups_append_keys(ctx, g, cs.data(), g->nkeys, rows, rows->length);
+}
 static void groups_reserve_ghash(dfgpu_ctx* ctx, dfgpu_groups* g, int64_t need, int64_t keep) {
   if (need <= g->ghash_cap) return;
   int64_t nc = g->ghash_cap ? g->ghash_cap : 1024; while (nc < need) nc *= 2;
@@ -545,7 +556,10 @@ static bool groups_intern_runs(dfgpu_ctx* ctx, dfgpu_groups* g, const dfgpu_arra
     auto d = std::make_shared<DeferredIds>(); d->kind = 1; d->heads = heads; d->prefix = prefix; d->base = (uint32_t)g->n_groups; ids->deferred_ids = d;
   } else hipLaunchKernelGGL(k_run_ids, grid, block, 0, ctx->stream, (const uint64_t*)heads->ptr, (const uint32_t*)prefix->ptr, n, (uint32_t)g->n_groups, (uint32_t*)ids->values->ptr);
   KERNEL_CHECK();
-  if (n_new) groups_append_keys(ctx, g, cols, nkeys, firsts.get(), n_new);
+  if (n_new && g->n_groups == 0 && ctx->group_lazy_keys && n_new >= (1 << 16)) {        // first batch: the gather waits (groups_resolve_keys)
+    for (int c = 0; c < nkeys; c++) { g->lazy_src.push_back(const_cast<dfgpu_array*>(cols[c])); dfgpu_array_retain(g->lazy_src.back()); }
+    g->lazy_rows = firsts.release();
+  } else if (n_new) groups_append_keys(ctx, g, cols, nkeys, firsts.get(), n_new);
   g->n_groups += n_new; g->run_mode = true;
   return true;
 }
@@ -561,6 +575,7 @@ static dfgpu_status groups_intern_impl(dfgpu_ctx* ctx, dfgpu_groups* g, const df
   return guard(ctx, [&] {
     if (!g || !cols || !out_group_ids) fail(DFGPU_INVALID_ARGUMENT, "groups_intern: null argument");
     if (nkeys != g->nkeys) fail(DFGPU_INVALID_ARGUMENT, "groups_intern: %d key columns given, %d expected", nkeys, g->nkeys);
+    groups_resolve_keys(ctx, g);
     KeySet bk = make_keyset(cols, nkeys);
     int64_t n = cols[0]->length;
     if (n >= (int64_t)G_NEW) fail(DFGPU_NOT_IMPLEMENTED, "intern batches above 2^31 rows; split the batch");
@@ -861,7 +876,18 @@ dfgpu_status dfgpu_groups_emit(dfgpu_ctx* ctx, dfgpu_groups* g, dfgpu_array** ou
   return guard(ctx, [&] {
     if (!g || !out_cols) fail(DFGPU_INVALID_ARGUMENT, "groups_emit: null argument");
     if (g->n_groups == 0) fail(DFGPU_INVALID_ARGUMENT, "groups_emit: no groups interned yet (key types unknown)");
+    groups_resolve_keys(ctx, g);
     for (int c = 0; c < g->nkeys; c++) { dfgpu_array_retain(g->keys[c]); out_cols[c] = g->keys[c]; }
+  });
+}
+/* see include/dfgpu.h */
+dfgpu_status dfgpu_groups_emit_deferred(dfgpu_ctx* ctx, dfgpu_groups* g, dfgpu_array** out_sources, dfgpu_array** out_rows) {
+  return guard(ctx, [&] {
+    if (!g || !out_sources || !out_rows) fail(DFGPU_INVALID_ARGUMENT, "groups_emit_deferred: null argument");
+    if (!g->lazy_rows) fail(DFGPU_NOT_IMPLEMENTED, "groups_emit_deferred: the keys are stored (no gather is pending)");
+    for (auto* a : g->lazy_src) if (a->type == DFGPU_DICTIONARY) fail(DFGPU_NOT_IMPLEMENTED, "groups_emit_deferred: dictionary key columns are emitted as values");
+    for (int c = 0; c < g->nkeys; c++) { dfgpu_array_retain(g->lazy_src[(size_t)c]); out_sources[c] = g->lazy_src[(size_t)c]; }
+    dfgpu_array_retain(g->lazy_rows); *out_rows = g->lazy_rows;
   });
 }
 
@@ -870,6 +896,7 @@ dfgpu_status dfgpu_groups_emit_first(dfgpu_ctx* ctx, dfgpu_groups* g, int64_t n,
   return guard(ctx, [&] {
     if (!g || !out_cols || n < 0) fail(DFGPU_INVALID_ARGUMENT, "groups_emit_first: bad argument");
     if (g->n_groups == 0) fail(DFGPU_INVALID_ARGUMENT, "groups_emit_first: no groups interned yet (key types unknown)");
+    groups_resolve_keys(ctx, g);
     const int64_t total = g->n_groups, k = n < total ? n : total; const int32_t nkeys = g->nkeys;
     std::vector<ArrayHolder> first((size_t)nkeys), rest((size_t)nkeys);
     for (int c = 0; c < nkeys; c++) {

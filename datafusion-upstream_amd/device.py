@@ -438,6 +438,15 @@ class GroupValues:
         self.ctx.check(self.ctx.lib.dfgpu_groups_emit(self.ctx.h, self.h, outs))
         return [Array(self.ctx, C.c_void_p(outs[i])) for i in range(self.nkeys)]
 
+    def emit_deferred(self):
+        """dfgpu_groups_emit_deferred -> (key columns, first rows) while the keys of a first clustered batch are not gathered yet, else None"""
+        out = (C.c_void_p * self.nkeys)(); rows = C.c_void_p()
+        st = self.ctx.lib.dfgpu_groups_emit_deferred(self.ctx.h, self.h, out, C.byref(rows))
+        if st == 4:
+            return None
+        self.ctx.check(st)
+        return [Array(self.ctx, C.c_void_p(out[i])) for i in range(self.nkeys)], Array(self.ctx, rows)
+
 
 class GroupsAccumulator:
     """≙ trait GroupsAccumulator (expr/src/groups_accumulator.rs:78-164)."""

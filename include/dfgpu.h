@@ -185,7 +185,9 @@ DFGPU_API dfgpu_status dfgpu_concat(dfgpu_ctx *ctx, const dfgpu_array *const *ar
 /* Lists of fixed-width values (the List<T> state column of COUNT(DISTINCT), physical-expr/src/aggregate/count_distinct/native.rs:state()) travel in the Utf8 layout:
  * offsets are BYTE offsets into the packed values, so every operation that moves a Utf8 column (take, filter, concat, slice, partition, exchange, Arrow export) moves a
  * list column; an Arrow ListArray is the same buffers with the offsets divided by the value width.  dfgpu_list_from_counts: row i gets the next counts[i] (Int64) values;
- * dfgpu_list_flatten: the values of all rows back to back (typed value_type) and, per value, the row it belongs to (UInt32) -- what merging such a state needs. */
+ * dfgpu_list_flatten: the values of all rows back to back (typed value_type) and, per value, the row it belongs to (UInt32) -- what merging such a state needs.
+ * Lists of STRINGS (values / value_type Utf8: COUNT(DISTINCT) over a Utf8 argument, count_distinct/bytes.rs:47-75): a row holds its strings back to back, each as a 4-byte
+ * little-endian length followed by its bytes; flatten gives the strings back as a Utf8 array.  List values carry no NULLs. */
 DFGPU_API dfgpu_status dfgpu_list_from_counts(dfgpu_ctx *ctx, const dfgpu_array *counts, const dfgpu_array *values, dfgpu_array **out);
 DFGPU_API dfgpu_status dfgpu_list_flatten(dfgpu_ctx *ctx, const dfgpu_array *list, int32_t value_type, int32_t precision, int32_t scale, dfgpu_array **out_values, dfgpu_array **out_row_of);
 /* fixed-width column of `length` zeros, no validity (e.g. the single group id of an AggregateExec without GROUP BY) */
@@ -314,6 +316,11 @@ DFGPU_API int64_t dfgpu_groups_len(const dfgpu_groups *g);                   /* 
 DFGPU_API int64_t dfgpu_groups_size(const dfgpu_groups *g);                  /* GroupValues::size (bytes) */
 /* ≙ GroupValues::emit(EmitTo::All) (primitive.rs:163-209): key columns in group id order. */
 DFGPU_API dfgpu_status dfgpu_groups_emit(dfgpu_ctx *ctx, dfgpu_groups *g, dfgpu_array **out_cols /* nkeys */);
+/* GroupValues::emit(EmitTo::All) for a caller that gathers lazily: when the stored keys are still "key column c at row out_rows[g]" -- the first batch of a clustered input,
+ * whose groups are run numbers -- the columns (retained) and the UInt32 first rows come back instead of gathered key columns: group g's key c is out_sources[c][out_rows[g]].
+ * DFGPU_NOT_IMPLEMENTED when the keys are stored already (then dfgpu_groups_emit).  The table keeps its state; a later call that needs stored keys gathers them.
+ * (TPC-H Q18: HAVING keeps a few thousand of 150 M groups; only their keys are ever read.) */
+DFGPU_API dfgpu_status dfgpu_groups_emit_deferred(dfgpu_ctx *ctx, dfgpu_groups *g, dfgpu_array **out_sources, dfgpu_array **out_rows);
 /* ≙ GroupValues::emit(EmitTo::First(n)) (expr/src/groups_accumulator.rs:25-57, group_values/row.rs:176-212, primitive.rs:151-190): the keys of the first n groups
  * leave, the remaining groups are renumbered from 0 (group id g becomes g - n); ids handed out earlier refer to the old numbering.  n >= len emits everything. */
 DFGPU_API dfgpu_status dfgpu_groups_emit_first(dfgpu_ctx *ctx, dfgpu_groups *g, int64_t n, dfgpu_array **out_cols /* nkeys */);

@@ -629,3 +629,35 @@ def test_avg_merge_of_a_partial_state_without_values_stays_null(ctx):
     gids = ctx.from_arrow(pa.array([0, 1, 2, 2], type=pa.uint32()))
     acc.merge_batch([counts, sums], gids, None, 3)
     assert acc.evaluate().to_arrow().to_pylist() == [None, 2.5, 3.0]
+
+
+def test_run_mode_group_keys_stay_ungathered_until_needed(ctx):
+    """A clustered first batch numbers its groups by runs; the stored keys are then "key column c at the first row of run g" and are not gathered (dfgpu_groups_emit_deferred
+    hands out the columns and the first rows).  emit(), a second batch (whose first run may continue the last group), EmitTo::First all see gathered keys; with the option off
+    the keys are gathered at once.  Same ids, same keys either way."""
+    import dfgpu
+    n = 400_000
+    k0 = np.repeat(np.arange(n // 4, dtype=np.int64) * 3 + 1, 4)                  # 100 000 runs of 4
+    k1 = (k0 % 7).astype(np.int32)                                                # constant within a run
+    cols = lambda a, b: [ctx.from_arrow(pa.array(a)), ctx.from_arrow(pa.array(b))]
+    gv = dfgpu.GroupValues(ctx, 2)
+    ids = gv.intern(cols(k0, k1)).to_numpy()
+    assert np.array_equal(ids, np.arange(n) // 4)
+    d = gv.emit_deferred()
+    assert d is not None
+    src, rows = d
+    assert np.array_equal(rows.to_numpy(), np.arange(0, n, 4)) and np.array_equal(src[0].to_numpy(), k0) and np.array_equal(src[1].to_numpy(), k1)
+    # a second batch: its first run continues group 99 999, then new keys
+    k0b = np.concatenate([np.full(3, k0[-1]), np.repeat(np.arange(5, dtype=np.int64) * 3 + k0[-1] + 3, 2)]); k1b = (k0b % 7).astype(np.int32)
+    ids2 = gv.intern(cols(k0b, k1b)).to_numpy()
+    assert ids2.tolist() == [n // 4 - 1] * 3 + [n // 4 + i // 2 for i in range(10)]
+    assert gv.emit_deferred() is None                                            # gathered by now
+    e = gv.emit()
+    want0 = np.concatenate([k0[::4], k0b[3::2]])
+    assert np.array_equal(e[0].to_numpy(), want0) and np.array_equal(e[1].to_numpy(), (want0 % 7).astype(np.int32))
+    ctx.set_option("group_lazy_keys", 0)
+    try:
+        gv2 = dfgpu.GroupValues(ctx, 2); gv2.intern(cols(k0, k1))
+        assert gv2.emit_deferred() is None and np.array_equal(gv2.emit()[0].to_numpy(), k0[::4])
+    finally:
+        ctx.set_option("group_lazy_keys", 1)

@@ -491,3 +491,44 @@ def test_inner_join_of_key_columns_answers_with_a_selection_over_the_probe_batch
     assert sel["l_key"].to_pylist() == sorted(sel["l_key"].to_pylist())             # probe order kept
     syncs = lambda p: sum(v[0] for k, v in p.items() if k.startswith("sync:"))
     assert syncs(prof) < syncs(prof0), (prof, prof0)                                 # the first join's count is gone, and the second build's
+
+
+def test_having_over_a_clustered_group_by_reads_the_keys_of_the_groups_it_keeps(ctx, task_ctx):
+    """AggregateExec(Single) over a clustered key -> FilterExec (HAVING) -> ProjectionExec: the group keys leave the aggregate as pending gathers (key column at the first row of
+    each run), so only the kept groups' keys are gathered (TPC-H Q18).  Rows equal the path that stores the keys at once and pyarrow's group_by + filter."""
+    from dfgpu import physical_plan as ops
+    rng = np.random.default_rng(8)
+    ng = 120_000
+    reps = rng.integers(1, 8, ng)
+    k = np.repeat(np.arange(ng, dtype=np.int64) * 5 + 2, reps)
+    q = rng.integers(1, 51, len(k)).astype(np.int64)
+    t = pa.table({"k": pa.array(k), "q": pa.array(q)})
+    C, L, B = ops.Column, ops.Literal, ops.BinaryExpr
+
+    def run():
+        b = ops.batch_from_arrow(ctx, t)
+        agg = ops.AggregateExec("Single", [(C("k", 0), "k")], [ops.AggregateFunctionExpr("SUM", C("q", 1), "s", input_field=ops.Field("q", dfgpu_capi().INT64))], ops.MemoryExec([[b]], b.schema))
+        having = ops.CoalesceBatchesExec(ops.FilterExec(B(C("s", 1), ">", L(250, pa.int64())), agg), 8192)
+        plan = ops.ProjectionExec([(C("k", 0), "k"), (C("s", 1), "s")], having)
+        ctx.profile_select(None); ctx.profile_enable(True); ctx.profile_read()
+        try:
+            out = pa.concat_tables([x.to_arrow() for x in plan.execute(0, task_ctx)]); prof = ctx.profile_read()
+        finally:
+            ctx.profile_enable(False)
+        return out, prof
+
+    lazy, prof = run()
+    ctx.set_option("group_lazy_keys", 0)
+    try:
+        eager, prof0 = run()
+    finally:
+        ctx.set_option("group_lazy_keys", 1)
+    assert lazy.equals(eager)
+    ref = t.group_by("k", use_threads=False).aggregate([("q", "sum")])
+    ref = ref.filter(pc.greater(ref["q_sum"], 250))
+    assert lazy.num_rows == ref.num_rows and lazy.num_rows > 10 and lazy["k"].to_pylist() == ref["k"].to_pylist() and lazy["s"].to_pylist() == ref["q_sum"].to_pylist()
+
+
+def dfgpu_capi():
+    from dfgpu import capi
+    return capi
