@@ -600,16 +600,13 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 12, 0, 24, ctx->stream));
     hipLaunchKernelGGL(k_pa_max_len, dim3((unsigned)((P + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)r.starts->ptr, (uint32_t)P, (unsigned long long*)(ctx->d_scratch64 + 13));
     KERNEL_CHECK();
-    const int64_t max_len = (int64_t)read_scratch(ctx, 13);
     int64_t slice = (n / P + 1) * 3 / 2; if (slice < 65536) slice = 65536;          // uniform keys never split (a partition is within a percent of the average) if (slice > 0x7FFFFFFF) slice = 0x7FFFFFFF;
-    const int64_t n_slices = max_len ? (max_len + slice - 1) / slice : 1;
+    // whether any partition is longer than a slice (skewed keys) is the device's to know: the (partition, slice) work list is always built, the longest partition comes back
+    // with the aggregate's own read-back below (one host round trip less per call)
     { KernelTimer kt_(ctx, "pa_aggregate");
-      BufferPtr items; unsigned grid = (unsigned)P;
-      if (n_slices > 1) {            // sum over partitions of ceil(len / slice) <= P + n / slice
-        items = alloc_buffer(ctx, (size_t)(P + 1) * 4);
-        hipLaunchKernelGGL(k_pa_items, dim3(1), dim3(PA_NT), 0, ctx->stream, (const uint32_t*)r.starts->ptr, (uint32_t)P, (uint32_t)slice, (uint32_t*)items->ptr);
-        grid = (unsigned)(P + n / slice + 1);
-      }
+      BufferPtr items = alloc_buffer(ctx, (size_t)(P + 1) * 4);            // sum over partitions of ceil(len / slice) <= P + n / slice
+      hipLaunchKernelGGL(k_pa_items, dim3(1), dim3(PA_NT), 0, ctx->stream, (const uint32_t*)r.starts->ptr, (uint32_t)P, (uint32_t)slice, (uint32_t*)items->ptr);
+      const unsigned grid = (unsigned)(P + n / slice + 1);
       const size_t lds = (((size_t)1 << cbits) + 1) * cell_bytes;
 #define PA_AGG(I, F) do { HIP_CHECK(hipFuncSetAttribute((const void*)k_pa_aggregate<I, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));      /* per device: set on every call, no process-wide flag */ \
         hipLaunchKernelGGL((k_pa_aggregate<I, F>), dim3(grid), dim3(PA_NT), lds, ctx->stream, (const uint64_t*)pkey->ptr, (const uint32_t*)prow->ptr, plan, (const uint32_t*)r.starts->ptr, \
@@ -619,8 +616,8 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
       else { if (plan.has_i128) PA_AGG(true, false); else PA_AGG(false, false); }
 #undef PA_AGG
       KERNEL_CHECK(); }
-    const uint64_t* back = read_scratch_range(ctx, 11, 4);          // [0] rows out of order, [1] partial rows written, [3] tables flushed early: one read-back
-    const int64_t m = (int64_t)back[1]; const uint64_t early = back[3];
+    const uint64_t* back = read_scratch_range(ctx, 11, 4);          // [0] rows out of order, [1] partial rows written, [2] longest partition, [3] tables flushed early: one read-back
+    const int64_t m = (int64_t)back[1]; const uint64_t early = back[3]; const int64_t n_slices = back[2] ? ((int64_t)back[2] + slice - 1) / slice : 1;
     if (two_level && (uint32_t)back[0] != 0) fail(DFGPU_INTERNAL, "agg_preaggregate: the two-level partition left rows out of partition order");
     // every key left in exactly one partial row unless a hot partition was cut into slices or a table overflowed mid-partition: the plan layer then
     // needs no hash table to number the groups of a first batch (option "agg_preaggregate_distinct", read only)
