@@ -768,7 +768,7 @@ dfgpu_status dfgpu_list_from_counts(dfgpu_ctx* ctx, const dfgpu_array* counts, c
     if (!counts || !values || !out) fail(DFGPU_INVALID_ARGUMENT, "list_from_counts: null argument");
     if (counts->type != DFGPU_INT64) fail(DFGPU_INVALID_ARGUMENT, "list_from_counts: counts must be Int64");
     if (values->type == DFGPU_UTF8) {            // a list of strings: every string as (u32 length, bytes)
-      if (values->validity) fail(DFGPU_INVALID_ARGUMENT, "list_from_counts: the values of a list carry no NULLs");
+      // (a validity buffer on `values` is not consulted: the values of a list are the non-NULL ones by construction -- COUNT(DISTINCT) interns its pairs under an IS NOT NULL mask)
       const int64_t n = counts->length, nv = values->length;
       BufferPtr enc = alloc_buffer(ctx, (size_t)(nv + 1) * 4 + 16), cpre = alloc_buffer(ctx, (size_t)(n + 1) * 4 + 16);
       hipLaunchKernelGGL(k_slist_sizes, dim3(grid_for(nv + 1, BLOCK)), dim3(BLOCK), 0, ctx->stream, nv ? (const int32_t*)values->offsets->ptr : (const int32_t*)nullptr, nv, (uint32_t*)enc->ptr);

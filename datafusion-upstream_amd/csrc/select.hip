@@ -296,14 +296,15 @@ __global__ void __launch_bounds__(BLOCK) k_rows_gather(RowCols rc, const uint8_t
 
 namespace dfgpu {
 // take(sorted column, strictly ascending indices) is sorted (strictly, if the source is) and lies inside the source's bounds; take(ascending indices, ascending indices) is
-// ascending.  The source's own statistics are measured here -- once, they stay with the array -- when it is a plain integer column at most 16x the result (a base-table key
-// column behind a filter or a join): the alternative is the same pass over every result that reaches a join build.
+// ascending.  The source's own statistics are measured here -- once, they stay with the array -- when it is a caller's plain integer column at most 16x the result (a base-table
+// key column behind a filter or a join): the alternative is the same pass over every result that reaches a join build.  A column an operator computed is never measured here
+// (it dies with the step; measuring it would be a pass and a read-back per step).
 void order_stats_through_take(dfgpu_ctx* ctx, const dfgpu_array* values, const dfgpu_array* indices, dfgpu_array* out) {
   if (!out || out == values || out->validity || indices->validity || !out->length) return;
   auto is = order_stats_get(indices);
   if (!is || !is->sorted || is->repeats) return;
   auto vs = order_stats_get(values);
-  if (!vs && values->length >= (1 << 16) && values->length <= out->length * 16) vs = order_stats_measure(ctx, values);
+  if (!vs && values->base_column && values->length >= (1 << 16) && values->length <= out->length * 16) vs = order_stats_measure(ctx, values);      // a caller's column only: the memo outlives this step
   if (!vs || !vs->sorted) return;
   OrderStats st = *vs; st.exact = false; order_stats_set(out, st);
 }
