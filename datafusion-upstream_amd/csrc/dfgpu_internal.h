@@ -89,7 +89,7 @@ struct dfgpu_ctx {
   std::vector<std::pair<size_t, void*>>* free_blocks = nullptr;   // (class bytes, ptr)
   size_t cached_bytes = 0, live_bytes = 0;
   int64_t sort_packed_min_rows = 1 << 20;                      // smallest input the packed-key sort takes (below: byte planes of the encoded keys)
-  bool sort_fused_small_passes = true;                         // inputs below 2^20 rows: one launch per varying key byte (offsets derived in the scatter, the next histogram counted by it)
+  bool sort_fused_small_passes = true;                         // inputs below 2^20 rows: the per-pass scan is folded into the scatter (two launches per varying key byte instead of three)
   bool sort_estimate_ranges = true;                            // packed-key sort of >= 2^22 rows: value ranges from a sample, checked while encoding
   int64_t spm_merge_rows = (int64_t)1 << 25;                   // SortPreservingMergeExec: rows loaded over all inputs per merge step
   int64_t sort_spill_bytes = 0, sort_spill_ranges = 16;        // SortExec: bytes of input batches kept on the device before they are sorted and spilled to host memory as a run (0 = never); key ranges a run is cut into
