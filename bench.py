@@ -384,10 +384,11 @@ def main():
                            "k_compare_scalar_fast": (tables["orders"].num_rows + line_rows) / 2,
                            "k_compare": (tables["customer"].num_rows + tables["orders"].num_rows + line_rows) / 3}.get(name, None)
         bpr = KERNEL_BYTES_PER_ROW.get(name)
+        tpath = None
         if bpr is not None and rows_per_launch is not None:
             achieved = bpr * rows_per_launch / (avg_ms * 1e-3) / 1e9
             traffic = None
-            tpath = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json")) if os.path.exists(q)), None)
+            tpath = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json")) if os.path.exists(q)), None)
             if tpath:
                 traffic = json.load(open(tpath)).get(name)
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -402,7 +403,7 @@ def main():
             if roofline.get("achieved"):
                 roofline["frac_of_measured_copy"] = round(roofline["achieved"] / copy_gbs, 4)
         roofline["host_syncs_per_step"] = host_syncs       # stream synchronisations by cause (counts the host must read back)
-        roofline["traffic_source"] = "profiles/traffic_r03.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel, gfx950 x2 FETCH correction; a tracked file, not measured in this run)"
+        roofline["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel, gfx950 x2 FETCH correction; a tracked file, not measured in this run)" % (os.path.relpath(tpath, ROOT) if tpath else None)
         if roofline.get("achieved") and rank == 0:
             assert roofline["achieved"] <= roofline["measured_copy_GBps"] * 1.25, "kernel bandwidth above the box's copy ceiling: wrong byte count"
     # Not a bandwidth: SURVEY 8(d)'s 39.4 B per input row counts every referenced column in full, while the plan (late materialisation, fused
