@@ -109,6 +109,15 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
  * "agg_partitioned" (1/0), "agg_partitioned_min_rows", "agg_partitioned_force" (1 = skip the sample's verdict; tests) == let the plan layer's
  * AggregateExec pre-aggregate large batches of high-cardinality unclustered keys partition by partition out of LDS (dfgpu_agg_preaggregate);
  * "agg_preaggregate_distinct" (read only) == 1 when the last dfgpu_agg_preaggregate call on this ctx emitted every key in exactly one partial row;
+ * "mailbox_readback" (1/0) == the host reads device words (counts, ranges, error flags) through a pinned mailbox -- a one-workgroup kernel posts them with a sequence number, the host
+ * polls -- instead of a device-to-host copy followed by a stream synchronisation (same values; the switch exists for A/B runs);
+ * "join_selection_output" (1/0) == let the plan layer's HashJoinExec answer an Inner join whose build side contributes key columns only with the probe batch under a selection
+ * (dfgpu_join_probe_selection) when the operator above fuses selections (rows and row order identical); "join_lazy_build_rows" (1/0) == build rows of a deferred probe looked up on demand;
+ * "join_bitmap_partitioned" (0/1, default 0), "join_bitmap_partitioned_min_rows" == probe a membership bitmap larger than an L2 by key range when a sample finds the probe keys
+ * unclustered (pairs identical; measured slower than the plain probe on MI355X, kept for A/B);
+ * "group_lazy_keys" (1/0) == a run-numbered first batch keeps its group keys as (key columns, first rows) until somebody needs them stored (dfgpu_groups_emit_deferred);
+ * "agg_order_inverse_map" (1/0) == first-seen order of millions of pre-aggregated partial rows through an inverse map over the input rows instead of sort passes (same order);
+ * "sort_fused_small_passes" (1/0) == sorts below 2^20 rows fold every pass's offset scan into its scatter (identical indices);
  * "sort_packed_keys" (1/0) == let sort_to_indices sort large inputs over fixed-width keys through range-packed 64-bit keys (identical indices);
  * "sort_estimate_ranges" (1/0) == from 2^22 rows on, take those ranges from a sample and check them while packing (a miss repeats the step with exact ranges; identical indices);
  * "memory_limit" (bytes, 0 = none) == live device memory this ctx may hold; an allocation beyond it fails with DFGPU_RESOURCES_EXHAUSTED and the
