@@ -480,6 +480,13 @@ __global__ void k_fill64(uint64_t* p, int64_t from, int64_t to, uint64_t v, int 
 
 static int imin(int a, int b) { return a < b ? a : b; }
 
+// the three state arrays of the new groups cleared in ONE launch (a query's result-sized accumulators: three hipMemsetAsync calls were three dispatches of ~5 us each)
+__global__ void __launch_bounds__(BLOCK) k_acc_clear(uint64_t* vals, int64_t vwords, uint64_t* counts, int64_t cwords, uint8_t* seen, int64_t sbytes) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < vwords + cwords + sbytes; i += (int64_t)gridDim.x * BLOCK) {
+    if (i < vwords) vals[i] = 0; else if (i < vwords + cwords) counts[i - vwords] = 0; else seen[i - vwords - cwords] = 0;
+  }
+}
+
 static void acc_resize(dfgpu_acc* a, int64_t total) {
   dfgpu_ctx* ctx = a->ctx;
   if (total <= a->n) return;
@@ -492,6 +499,15 @@ static void acc_resize(dfgpu_acc* a, int64_t total) {
     a->vals = nv; a->counts = ncnt; a->seen = ns; a->cap = nc;
   }
   int64_t add = total - a->n;
+  const bool minmax = a->kind == DFGPU_AGG_MIN || a->kind == DFGPU_AGG_MAX;
+  if (!minmax && add <= ((int64_t)1 << 22)) {         // small: one launch for all three arrays
+    const int64_t vw = add * (a->width / 8), cw = add, sb = add;
+    hipLaunchKernelGGL(k_acc_clear, dim3(grid_for(vw + cw + sb, BLOCK, ctx->num_cus * 8)), dim3(BLOCK), 0, ctx->stream, (uint64_t*)((char*)a->vals->ptr + a->n * a->width), vw,
+                       (uint64_t*)((char*)a->counts->ptr + a->n * 8), cw, (uint8_t*)a->seen->ptr + a->n, sb);
+    KERNEL_CHECK();
+    a->n = total;
+    return;
+  }
   HIP_CHECK(hipMemsetAsync((char*)a->counts->ptr + a->n * 8, 0, (size_t)add * 8, ctx->stream));
   HIP_CHECK(hipMemsetAsync((char*)a->seen->ptr + a->n, 0, (size_t)add, ctx->stream));
   if (a->kind == DFGPU_AGG_MIN || a->kind == DFGPU_AGG_MAX) {
