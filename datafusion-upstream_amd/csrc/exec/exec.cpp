@@ -133,7 +133,26 @@ static Col col_of(ArrayRef a) { Col c; c.arr = std::move(a); return c; }
 
 struct Batch {
   SchemaPtr schema; std::vector<Col> cols; ArrayRef selection; int64_t base_rows = 0;
-  const ArrayRef& column(const TaskContext& tc, int i) { return col_get(tc, cols.at((size_t)i)); }
+  // A pending gather of a result-sized batch (<= 2^20 rows) takes its siblings along: every other column of the batch that waits behind the SAME index arrays is gathered in the
+  // same launch (dfgpu_take_multi) -- at that size a launch costs more than the bytes it moves, and a query's last operators read 3-5 columns through each row list.
+  const ArrayRef& column(const TaskContext& tc, int i) {
+    Col& c = cols.at((size_t)i);
+    if (!c.arr && c.source && !c.chain.empty() && base_rows <= ((int64_t)1 << 20) && base_rows > 0) {
+      std::vector<size_t> sib;
+      for (size_t k = 0; k < cols.size(); k++) { const Col& o = cols[k]; if (k == (size_t)i || o.arr || !o.source || o.lookup.get() != c.lookup.get() || o.chain.size() != c.chain.size()) continue;
+        bool same = true; for (size_t q = 0; q < c.chain.size(); q++) same = same && o.chain[q].a == c.chain[q].a; if (same) sib.push_back(k); }
+      if (!sib.empty()) {
+        const ArrayRef idx = col_indices(tc, c);               // composes the chain / resolves a deferred lookup once
+        std::vector<const dfgpu_array*> vals{ c.source.a }; for (size_t k : sib) vals.push_back(cols[k].source.a);
+        std::vector<dfgpu_array*> outs(vals.size(), nullptr);
+        tc.check(dfgpu_take_multi(tc.ctx, vals.data(), (int32_t)vals.size(), idx.a, outs.data()));
+        auto settle = [](Col& x, dfgpu_array* a) { x.arr = ArrayRef::adopt(a); x.source = ArrayRef(); x.chain.clear(); x.memo.reset(); x.lookup.reset(); };
+        settle(c, outs[0]); for (size_t u = 0; u < sib.size(); u++) settle(cols[sib[u]], outs[u + 1]);
+        return c.arr;
+      }
+    }
+    return col_get(tc, c);
+  }
 };
 static ArrayRef mask_indices(const TaskContext& tc, const ArrayRef& mask) { dfgpu_array* o = nullptr; tc.check(dfgpu_mask_to_indices(tc.ctx, mask.a, &o)); return ArrayRef::adopt(o); }
 // ≙ filter_record_batch (filter.rs:325), lazily per column

@@ -242,6 +242,31 @@ dfgpu_array* mask_to_indices_uncounted(dfgpu_ctx* ctx, const uint64_t* bits, int
 // A gather of n random rows costs one 64-byte sector per row and column whatever the column's width (~53 G sectors/s on MI355X beyond
 // L2).  Fixed-width columns without NULLs that go through the same indices are therefore interleaved into row-major records first (one
 // streaming pass), gathered as records -- one sector per row for up to 64 bytes of columns -- and split back while they are written.
+// Several fixed-width columns without NULLs through one index array in ONE launch, column by column (no record packing): for result-sized gathers, where a launch costs
+// more than the bytes it moves (a query's last operators take 3-5 columns through each row list).
+struct TakeCols { int32_t n; const void* src[8]; void* dst[8]; int32_t width[8]; };
+template <typename IT>
+__global__ void __launch_bounds__(BLOCK) k_take_multi_plain(TakeCols tc, const IT* idx, int64_t m, int64_t n_src, uint32_t* flags) {
+  const int64_t base = (int64_t)blockIdx.x * BLOCK * TAKE_ROWS + threadIdx.x;
+  int64_t j[TAKE_ROWS]; bool oob = false;
+#pragma unroll
+  for (int q = 0; q < TAKE_ROWS; q++) { const int64_t i = base + (int64_t)q * BLOCK; j[q] = (int64_t)idx[i < m ? i : m - 1]; const bool bad = j[q] < 0 || j[q] >= n_src; oob |= bad && i < m; if (bad) j[q] = 0; }
+  for (int c = 0; c < 8; c++) {
+    if (c >= tc.n) break;
+#pragma unroll
+    for (int q = 0; q < TAKE_ROWS; q++) {
+      const int64_t i = base + (int64_t)q * BLOCK; if (i >= m) continue;
+      switch (tc.width[c]) {
+        case 1: ((uint8_t*)tc.dst[c])[i] = ((const uint8_t*)tc.src[c])[j[q]]; break;
+        case 2: ((uint16_t*)tc.dst[c])[i] = ((const uint16_t*)tc.src[c])[j[q]]; break;
+        case 4: ((uint32_t*)tc.dst[c])[i] = ((const uint32_t*)tc.src[c])[j[q]]; break;
+        case 8: ((uint64_t*)tc.dst[c])[i] = ((const uint64_t*)tc.src[c])[j[q]]; break;
+        default: ((uint4*)tc.dst[c])[i] = ((const uint4*)tc.src[c])[j[q]]; break;
+      }
+    }
+  }
+  if (oob) atomicOr(flags, DFGPU_FLAG_OOB);
+}
 struct RowCols { int32_t n; int32_t row_bytes; const void* src[16]; void* dst[16]; int32_t width[16]; int32_t off[16]; };
 __global__ void __launch_bounds__(BLOCK) k_rows_pack(RowCols rc, int64_t n, uint8_t* rows) {
   int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -358,6 +383,26 @@ dfgpu_status dfgpu_take_multi(dfgpu_ctx* ctx, const dfgpu_array* const* values, 
           else { if (nq == 1) RG(uint64_t, 1); else if (nq == 2) RG(uint64_t, 2); else if (nq == 3) RG(uint64_t, 3); else RG(uint64_t, 4); }
 #undef RG
           KERNEL_CHECK(); }
+      }
+    }
+    // the columns no record path took, if they are plain (fixed width, no NULLs, one source length): one launch for up to 8 of them
+    if (!indices->validity && !indices->identity && m > 0) {
+      std::vector<int> plain; int64_t ns = -1;
+      for (int32_t c = 0; c < n; c++) {
+        const dfgpu_array* a = values[c];
+        if (res[(size_t)c].a || !a || a->type == DFGPU_DICTIONARY || a->type == DFGPU_UTF8 || a->type == DFGPU_BOOL || a->validity || !type_width(a->type) || a->length == 0) continue;
+        if (ns < 0) ns = a->length;
+        if (a->length == ns) plain.push_back(c);
+      }
+      for (size_t p0 = 0; p0 < plain.size(); p0 += 8) {
+        const size_t cnt = std::min<size_t>(8, plain.size() - p0); if (cnt < 2) break;          // a single left-over column takes the ordinary kernel below
+        TakeCols tcs{}; tcs.n = (int32_t)cnt;
+        for (size_t u = 0; u < cnt; u++) { const dfgpu_array* a = values[plain[p0 + u]]; res[(size_t)plain[p0 + u]].a = new_fixed(ctx, a->type, m, a->precision, a->scale);
+          tcs.src[u] = a->values->ptr; tcs.dst[u] = res[(size_t)plain[p0 + u]].get()->values->ptr; tcs.width[u] = type_width(a->type); }
+        KernelTimer kt_(ctx, "k_take_fixed");
+        if (iw == 4) hipLaunchKernelGGL((k_take_multi_plain<uint32_t>), dim3(grid_for(m, BLOCK * TAKE_ROWS)), dim3(BLOCK), 0, ctx->stream, tcs, (const uint32_t*)indices->values->ptr, m, ns, ctx->d_flags);
+        else hipLaunchKernelGGL((k_take_multi_plain<uint64_t>), dim3(grid_for(m, BLOCK * TAKE_ROWS)), dim3(BLOCK), 0, ctx->stream, tcs, (const uint64_t*)indices->values->ptr, m, ns, ctx->d_flags);
+        KERNEL_CHECK();
       }
     }
     for (int32_t c = 0; c < n; c++) {
