@@ -481,9 +481,11 @@ def run(args, ctx=None, emit=True):
             del bk1, pk0, pk1, hit2, left2, right2, j2k, plan2
         del bk, pk, pv, left, right, plan
         torch.cuda.empty_cache()
-    if not want or "groupby_int64" in want:
+    if not want or "groupby_int64" in want or any(w.startswith("groupby_int64_unclustered_") for w in want):
         ng = int(1_000_000 * args.sf)
         for total in (10**6, 2 * 10**7):
+            if want and "groupby_int64" not in want and f"groupby_int64_unclustered_{total}" not in want:          # one cardinality alone (profiling passes)
+                continue
             keys = torch.randint(0, total, (ng,), generator=g, device="cuda", dtype=torch.int64) * 7919
             val = torch.randint(0, 10**6, (ng,), generator=g, device="cuda", dtype=torch.int64)
             torch.cuda.synchronize()
