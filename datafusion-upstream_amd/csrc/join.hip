@@ -154,10 +154,9 @@ __device__ inline uint64_t spread32(uint64_t x) {      // bit i -> bit 2i
 template <typename T, bool HAS_MASK, bool HAS_VALID, bool FULL>
 __device__ inline void probe_match_chunk(const T* keys, const uint64_t* key_valid, const uint64_t* mask, int64_t n, int64_t kmin, uint64_t range,
                                          const uint64_t* bitmap, uint64_t* match_bits, int64_t base, int lane) {
-  uint64_t d0 = (uint64_t)((int64_t)keys[base] - kmin);
-  d0 = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)d0) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(d0 >> 32)) << 32);
-  int64_t w0i = d0 < range ? (int64_t)(d0 >> 6) : 0;
-  uint64_t win = (uint64_t)(w0i + lane) * 64 < range ? bitmap[w0i + lane] : 0ull;
+  // Every load of the chunk that does not depend on another is issued before the first wait: the four 16-byte key loads and the four selection words (round 4: the kernel
+  // used to load keys[base] on its own, wait, and only then issue the rest -- two memory round trips per wave in a row -- and fetched every selection word inside the loop
+  // behind the previous iteration's store).  The window's first key is lane 0's first key.
   T k[PM_ROWS / 2][2];
 #pragma unroll
   for (int r = 0; r < PM_ROWS / 2; r++) {                      // lane l owns rows base + 128 r + 2l, +1
@@ -165,10 +164,17 @@ __device__ inline void probe_match_chunk(const T* keys, const uint64_t* key_vali
     if (FULL || j + 1 < n) { struct alignas(2 * sizeof(T)) P { T a, b; }; P p = *(const P*)(keys + j); k[r][0] = p.a; k[r][1] = p.b; }
     else { k[r][0] = j < n ? keys[j] : (T)0; k[r][1] = 0; }
   }
+  uint64_t mws[PM_ROWS / 2];
+#pragma unroll
+  for (int r = 0; r < PM_ROWS / 2; r++) { int64_t j = base + r * 2 * WAVE + 2 * lane; mws[r] = (HAS_MASK && (FULL || j < n)) ? mask[j >> 6] >> (j & 63) : 3ull; }
+  uint64_t d0 = (uint64_t)((int64_t)k[0][0] - kmin);           // lane 0: row `base` (the caller guarantees base < n)
+  d0 = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)d0) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(d0 >> 32)) << 32);
+  int64_t w0i = d0 < range ? (int64_t)(d0 >> 6) : 0;
+  uint64_t win = (uint64_t)(w0i + lane) * 64 < range ? bitmap[w0i + lane] : 0ull;
 #pragma unroll
   for (int r = 0; r < PM_ROWS / 2; r++) {
     int64_t j = base + r * 2 * WAVE + 2 * lane;
-    uint64_t mw = (HAS_MASK && (FULL || j < n)) ? mask[j >> 6] >> (j & 63) : 3ull;
+    const uint64_t mw = mws[r];
     bool h[2];
 #pragma unroll
     for (int e = 0; e < 2; e++) {
