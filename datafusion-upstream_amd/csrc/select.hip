@@ -365,7 +365,7 @@ dfgpu_status dfgpu_take_multi(dfgpu_ctx* ctx, const dfgpu_array* const* values, 
         if (n_src < 0) n_src = a->length;
         if (a->length == n_src && rec.size() < 16) rec.push_back(c);
       }
-    if (rec.size() >= 2 && n_src >= (1 << 20)) {
+    if (rec.size() >= 2 && n_src >= (1 << 20) && m * 4 >= n_src) {        // packing is a pass over the WHOLE source: only when the gather reads a good part of it (a result-sized gather out of a base table takes the plain multi-column kernel below)
       RowCols rc{}; int off = 0;
       std::sort(rec.begin(), rec.end(), [&](int x, int y) { return type_width(values[x]->type) > type_width(values[y]->type); });      // widest first: every field aligned to its width
       std::vector<int> use;
