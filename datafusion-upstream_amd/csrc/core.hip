@@ -130,9 +130,10 @@ void fetch_to_pinned(dfgpu_ctx* ctx, int h_word, const void* d_src, size_t bytes
   hipLaunchKernelGGL(k_post_words, dim3(1), dim3(bytes <= 512 ? 128 : 512), 0, ctx->stream, (const uint32_t*)d_src, (int)(bytes / 4), (uint32_t*)(ctx->h_pinned + h_word), h_seq, seq);
   KERNEL_CHECK();
   // poll; every few thousand spins ask the stream: an error there must not leave the host spinning, and a drained stream means the words are in memory
+  bool asked = false;
   for (uint64_t spins = 1; __atomic_load_n(h_seq, __ATOMIC_ACQUIRE) < seq; spins++) {
     if ((spins & 0xFFF) == 0) {
-      hipError_t q = hipStreamQuery(ctx->stream);
+      hipError_t q = hipStreamQuery(ctx->stream); asked = true;
       if (q == hipSuccess) { HIP_CHECK(hipStreamSynchronize(ctx->stream)); break; }
       if (q != hipErrorNotReady) HIP_CHECK(q);
     }
@@ -140,6 +141,7 @@ void fetch_to_pinned(dfgpu_ctx* ctx, int h_word, const void* d_src, size_t bytes
     __builtin_ia32_pause();
 #endif
   }
+  if (asked) (void)hipGetLastError();          // "not ready" is an answer, not an error: it must not be what the next KERNEL_CHECK finds
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
 }
 void fetch_to_host(dfgpu_ctx* ctx, void* dst, const void* d_src, size_t bytes) {

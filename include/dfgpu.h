@@ -162,7 +162,8 @@ DFGPU_API dfgpu_status dfgpu_profile_read(dfgpu_ctx *ctx, char *buf, int64_t cap
 /* ------------------------------------------------------------------ arrays */
 /* Copy a host column to HBM (PCIe).  ≙ a RecordBatch column entering the GPU operator. */
 DFGPU_API dfgpu_status dfgpu_array_import_host(dfgpu_ctx *ctx, const dfgpu_array_desc *host, dfgpu_array **out);
-/* Wrap device memory owned by the caller (zero copy; caller keeps it alive until release). */
+/* Wrap device memory owned by the caller (zero copy; caller keeps it alive until release).  The wrapped memory must not change while the array (or any array derived from it) lives: arrays are immutable, and
+ * statistics measured on one (null count, sortedness of a key column) are kept with it. */
 DFGPU_API dfgpu_status dfgpu_array_wrap_device(dfgpu_ctx *ctx, const dfgpu_array_desc *dev, dfgpu_array **out);
 /* The same with ownership handed over (the Arrow C Data Interface's release callback, ArrowArray::release): the library calls release(cookie)
  * exactly once, when the last array, slice or plan node that refers to the memory is gone -- also when this call fails.  What a Rust shim

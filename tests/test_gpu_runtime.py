@@ -104,3 +104,34 @@ def test_memory_limit_raises_resources_exhausted_and_leaves_the_ctx_usable(ctx):
     gc.collect()
     from dfgpu import physical_plan as ops2
     assert sum(b.num_rows for b in ops2.with_fresh_state(plan).execute(0, tc)) == 100
+
+
+def test_read_backs_through_the_mailbox_and_through_a_copy_agree(ctx):
+    """Host read-backs (counts, key ranges, error flags) go through a pinned mailbox -- a posting kernel + a polled sequence word -- or, with option mailbox_readback = 0, through a
+    device-to-host copy and a stream synchronisation.  The same join, group-by and sort answer the same either way, a kernel error flag (a take out of bounds) is reported on
+    both, and a long kernel in front of the read-back (the host asks the stream while it polls) leaves no stale 'not ready' behind."""
+    import dfgpu
+    rng = np.random.default_rng(12)
+    nb, npr = 200_000, 3_000_000
+    b = rng.permutation(nb * 3)[:nb].astype(np.int64)
+    p = rng.integers(0, nb * 3, npr).astype(np.int64)
+    v = rng.integers(0, 1000, npr).astype(np.int64)
+    out = {}
+    for mode in (1, 0):
+        ctx.set_option("mailbox_readback", mode)
+        try:
+            table = dfgpu.JoinTable(ctx, [ctx.from_arrow(pa.array(b))])
+            bi, pi = table.probe([ctx.from_arrow(pa.array(p))])
+            gv = dfgpu.GroupValues(ctx, 1)
+            keys = ctx.take(ctx.from_arrow(pa.array(p)), pi)
+            ids = gv.intern([keys])
+            acc = dfgpu.GroupsAccumulator(ctx, dfgpu.capi.AGG_SUM, dfgpu.capi.INT64)
+            acc.update_batch(ctx.take(ctx.from_arrow(pa.array(v)), pi), ids, None, len(gv))
+            order = ctx.sort_to_indices([acc.evaluate(), gv.emit()[0]], [True, False], [True, False]).to_numpy()
+            out[mode] = (bi.to_numpy(), pi.to_numpy(), ids.to_numpy(), acc.evaluate().to_numpy(), order)
+            with pytest.raises(dfgpu.DfgpuError):
+                ctx.take(ctx.from_arrow(pa.array(v)), ctx.from_arrow(pa.array([5, npr + 7], type=pa.uint32()))).to_numpy()
+        finally:
+            ctx.set_option("mailbox_readback", 1)
+    for x, y in zip(out[1], out[0]):
+        assert np.array_equal(x, y)
