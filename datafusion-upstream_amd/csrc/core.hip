@@ -406,7 +406,15 @@ dfgpu_status dfgpu_ctx_create(int32_t device_id, void* stream, dfgpu_ctx** out) 
 void dfgpu_ctx_destroy(dfgpu_ctx* ctx) { if (ctx) ctx_unref(ctx); }
 const char* dfgpu_last_error(const dfgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 void* dfgpu_ctx_stream(dfgpu_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
-dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx* ctx) { if (!ctx) return DFGPU_INVALID_ARGUMENT; return guard(ctx, [&] { HIP_CHECK(hipSetDevice(ctx->device)); HIP_CHECK(hipStreamSynchronize(ctx->stream)); flush_flags(ctx); }); }
+dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx* ctx) {
+  if (!ctx) return DFGPU_INVALID_ARGUMENT;
+  return guard(ctx, [&] {
+    HIP_CHECK(hipSetDevice(ctx->device));
+    // a pending flag check is itself a read-back behind everything enqueued: taken first, the stream synchronisation that follows finds the stream drained (no second wake-up)
+    try { flush_flags(ctx); } catch (...) { (void)hipStreamSynchronize(ctx->stream); throw; }
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  });
+}
 dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value) {
   return guard(ctx, [&] {
     std::string k = key ? key : "";
