@@ -130,6 +130,23 @@ __global__ void __launch_bounds__(BLOCK) k_dict_predicate(const void* keys, int 
   uint64_t mv = ballot64(v), mo = ballot64(ok);
   if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) { out_bits[i >> 6] = mv; if (out_valid) out_valid[i >> 6] = mo; }
 }
+// the same for Int32 codes without NULLs on either side: eight rows per lane, the eight code loads issued before the first dictionary-bit load waits (one row per lane ran at
+// 0.9 TB/s of codes: 0.44 ms per 100 M rows, profiles/r04_l_kernel_stats_cbu_sf100.csv)
+__global__ void __launch_bounds__(BLOCK) k_dict_predicate_i32(const int32_t* __restrict__ keys, int64_t n, const uint64_t* __restrict__ dict_bits, int64_t dict_len, uint64_t* __restrict__ out_bits) {
+  const int lane = lane_id();
+  const int64_t nchunks = (n + 511) >> 9, wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * BLOCK) >> 6, nw = (n + 63) >> 6;
+  for (int64_t ch = wave; ch < nchunks; ch += nwaves) {
+    const int64_t base = ch << 9;
+    int32_t c[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) { const int64_t i = base + q * 64 + lane; c[q] = i < n ? keys[i] : -1; }
+    bool v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = c[q] >= 0 && c[q] < dict_len && bit_get(dict_bits, c[q]);
+#pragma unroll
+    for (int q = 0; q < 8; q++) { const uint64_t m = ballot64(v[q]); if (lane == q && (base >> 6) + q < nw) out_bits[(base >> 6) + q] = m; }
+  }
+}
 static int swap_cmp(int op) { switch (op) { case DFGPU_OP_LT: return DFGPU_OP_GT; case DFGPU_OP_LTEQ: return DFGPU_OP_GTEQ; case DFGPU_OP_GT: return DFGPU_OP_LT; case DFGPU_OP_GTEQ: return DFGPU_OP_LTEQ; default: return op; } }
 
 // ---------------------------------------------------------------- Kleene AND / OR on bitmap words
@@ -372,6 +389,10 @@ dfgpu_status dfgpu_binary(dfgpu_ctx* ctx, int32_t op, const dfgpu_array* l, int3
           bool nv = dcol->validity || dres->validity;
           ArrayHolder hd(new_fixed(ctx, DFGPU_BOOL, n, 0, 0, nv));
           KernelTimer kt_(ctx, "k_dict_predicate");
+          if (!nv && dcol->key_type == DFGPU_INT32) {
+            hipLaunchKernelGGL(k_dict_predicate_i32, dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 16)), block, 0, ctx->stream, (const int32_t*)dcol->values->ptr, n, (const uint64_t*)dres->values->ptr, dres->length, (uint64_t*)hd.get()->values->ptr);
+            KERNEL_CHECK(); *out = hd.release(); return;
+          }
           hipLaunchKernelGGL(k_dict_predicate, grid, block, 0, ctx->stream, dcol->values->ptr, dcol->key_type, dcol->validity ? (const uint64_t*)dcol->validity->ptr : nullptr, n,
                              (const uint64_t*)dres->values->ptr, dres->validity ? (const uint64_t*)dres->validity->ptr : nullptr, dres->length,
                              (uint64_t*)hd.get()->values->ptr, nv ? (uint64_t*)hd.get()->validity->ptr : nullptr);
