@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--only", default="")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="ctx option set before the run (dfgpu_ctx_set_option), for A/B runs of one workload")
     args = ap.parse_args()
     run(args)
 
@@ -154,6 +155,8 @@ def run(args, ctx=None, emit=True):
     if ctx is None:
         torch.cuda.set_device(0)
         ctx = dfgpu.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        for kv in getattr(args, "option", []) or []:
+            k, v = kv.split("=", 1); ctx.set_option(k, int(v))
     tc = ops.TaskContext(ctx, batch_size=8192)
     C, L, B, F = ops.Column, ops.Literal, ops.BinaryExpr, ops.Field
     g = torch.Generator(device="cuda"); g.manual_seed(20241024)

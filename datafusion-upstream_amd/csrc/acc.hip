@@ -31,6 +31,9 @@ struct dfgpu_acc {
   int cls = 0; int width = 8;
   int64_t n = 0, cap = 0;
   BufferPtr vals, counts, seen;     // vals: width B/group; counts: 8 B/group (AVG u64, COUNT i64); seen: 1 B/group
+  // states adopted from a fully pre-aggregated first batch (acc_adopt_identity) and not copied yet: the accumulator holds n groups whose values (SUM / MIN / MAX) or counts
+  // (COUNT) are the adopted array's buffer, every group seen.  Evaluating it hands that buffer out again; the first update / merge copies it into vals / counts / seen
+  bool lazy = false; BufferPtr lazy_vals, lazy_counts;
 };
 
 namespace dfgpu {
@@ -487,8 +490,20 @@ __global__ void __launch_bounds__(BLOCK) k_acc_clear(uint64_t* vals, int64_t vwo
   }
 }
 
+static void acc_materialize(dfgpu_acc* a) {
+  if (!a->lazy) return;
+  dfgpu_ctx* ctx = a->ctx; const int64_t total = a->n;
+  a->vals = alloc_buffer(ctx, (size_t)total * a->width); a->counts = alloc_buffer(ctx, (size_t)total * 8); a->seen = alloc_buffer(ctx, (size_t)total); a->cap = total;
+  if (a->lazy_vals) HIP_CHECK(hipMemcpyAsync(a->vals->ptr, a->lazy_vals->ptr, (size_t)total * a->width, hipMemcpyDeviceToDevice, ctx->stream));
+  else HIP_CHECK(hipMemsetAsync(a->vals->ptr, 0, (size_t)total * a->width, ctx->stream));
+  if (a->lazy_counts) HIP_CHECK(hipMemcpyAsync(a->counts->ptr, a->lazy_counts->ptr, (size_t)total * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  else HIP_CHECK(hipMemsetAsync(a->counts->ptr, 0, (size_t)total * 8, ctx->stream));
+  HIP_CHECK(hipMemsetAsync(a->seen->ptr, 1, (size_t)total, ctx->stream));
+  a->lazy = false; a->lazy_vals.reset(); a->lazy_counts.reset();
+}
 static void acc_resize(dfgpu_acc* a, int64_t total) {
   dfgpu_ctx* ctx = a->ctx;
+  acc_materialize(a);                     // every update / merge path comes through here before it touches the state arrays
   if (total <= a->n) return;
   if (total > a->cap) {
     int64_t nc = a->cap ? a->cap : 1024; while (nc < total) nc *= 2;
@@ -1015,12 +1030,10 @@ static bool acc_adopt_identity(dfgpu_ctx* ctx, dfgpu_acc* a, const dfgpu_array* 
   if (a->kind == DFGPU_AGG_COUNT && st[0]->type != DFGPU_INT64) return false;
   if (a->kind == DFGPU_AGG_AVG && st[0]->type != DFGPU_UINT64) return false;
   if (vals && (vals->type != a->state_type || type_width(vals->type) != a->width)) return false;
-  a->vals = alloc_buffer(ctx, (size_t)total * a->width); a->counts = alloc_buffer(ctx, (size_t)total * 8); a->seen = alloc_buffer(ctx, (size_t)total); a->cap = total;
-  if (vals) HIP_CHECK(hipMemcpyAsync(a->vals->ptr, vals->values->ptr, (size_t)total * a->width, hipMemcpyDeviceToDevice, ctx->stream));
-  else HIP_CHECK(hipMemsetAsync(a->vals->ptr, 0, (size_t)total * a->width, ctx->stream));
-  if (a->kind == DFGPU_AGG_COUNT || a->kind == DFGPU_AGG_AVG) HIP_CHECK(hipMemcpyAsync(a->counts->ptr, st[0]->values->ptr, (size_t)total * 8, hipMemcpyDeviceToDevice, ctx->stream));
-  else HIP_CHECK(hipMemsetAsync(a->counts->ptr, 0, (size_t)total * 8, ctx->stream));
-  HIP_CHECK(hipMemsetAsync(a->seen->ptr, 1, (size_t)total, ctx->stream));
+  // nothing is copied here: 20 M groups x (SUM, COUNT) were 0.35 ms of copies and fills per step, written only to be copied out again by the evaluation that follows a
+  // single-batch aggregation (profiles/r04_n_timeline_gb20.txt)
+  a->lazy = true; a->lazy_vals = vals ? vals->values : BufferPtr(); a->lazy_counts = a->kind == DFGPU_AGG_COUNT ? st[0]->values : BufferPtr();
+  a->vals.reset(); a->counts.reset(); a->seen.reset(); a->cap = 0;
   a->n = total;
   return true;
 }
@@ -1053,6 +1066,13 @@ dfgpu_status dfgpu_acc_merge_batch(dfgpu_ctx* ctx, dfgpu_acc* a, const dfgpu_arr
 }
 
 static dfgpu_array* emit_values(dfgpu_ctx* ctx, dfgpu_acc* a, int32_t type, int32_t p, int32_t s, const void* src, bool with_seen) {
+  if (a->lazy) {            // adopted states, every group seen: the adopted buffer is the result (or its narrowed copy)
+    const BufferPtr& buf = a->kind == DFGPU_AGG_COUNT ? a->lazy_counts : a->lazy_vals;
+    if (type_width(type) == a->width || a->cls == CLS_I128 || a->kind == DFGPU_AGG_COUNT) { ArrayHolder h(new_array(ctx, type, a->n, p, s)); h.get()->values = buf; h.get()->null_count = 0; return h.release(); }
+    ArrayHolder h(new_fixed(ctx, type, a->n, p, s, false));
+    hipLaunchKernelGGL(k_narrow, dim3(grid_for(a->n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)buf->ptr, a->n, type, h.get()->values->ptr); KERNEL_CHECK();
+    return h.release();
+  }
   ArrayHolder h(new_fixed(ctx, type, a->n, p, s, with_seen));
   if (a->n) {
     if (type_width(type) == a->width || a->cls == CLS_I128) HIP_CHECK(hipMemcpyAsync(h.get()->values->ptr, src, (size_t)a->n * type_width(type), hipMemcpyDeviceToDevice, ctx->stream));
@@ -1109,7 +1129,7 @@ dfgpu_status dfgpu_acc_emit_first(dfgpu_ctx* ctx, dfgpu_acc* a, int64_t n, int32
     if (as_state) { o0.a = slice(s0.get(), 0, k); if (ns > 1) o1.a = slice(s1.get(), 0, k); } else o0.a = slice(ev.get(), 0, k);
     // the groups that stay are renumbered from 0 (EmitTo::take_needed): their states are merged into the emptied accumulator under ids 0 .. total - k - 1
     const int kind = a->kind; const int32_t it = a->in_type, ip = a->in_precision, is = a->in_scale;
-    a->n = 0; a->cap = 0; a->vals.reset(); a->counts.reset(); a->seen.reset();
+    a->n = 0; a->cap = 0; a->vals.reset(); a->counts.reset(); a->seen.reset(); a->lazy = false; a->lazy_vals.reset(); a->lazy_counts.reset();
     (void)kind; (void)it; (void)ip; (void)is;
     if (k < total) {
       ArrayHolder r0(slice(s0.get(), k, total - k)), r1; if (ns > 1) r1.a = slice(s1.get(), k, total - k);

@@ -130,21 +130,26 @@ __global__ void __launch_bounds__(BLOCK) k_dict_predicate(const void* keys, int 
   uint64_t mv = ballot64(v), mo = ballot64(ok);
   if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) { out_bits[i >> 6] = mv; if (out_valid) out_valid[i >> 6] = mo; }
 }
-// the same for Int32 codes without NULLs on either side: eight rows per lane, the eight code loads issued before the first dictionary-bit load waits (one row per lane ran at
-// 0.9 TB/s of codes: 0.44 ms per 100 M rows, profiles/r04_l_kernel_stats_cbu_sf100.csv)
-__global__ void __launch_bounds__(BLOCK) k_dict_predicate_i32(const int32_t* __restrict__ keys, int64_t n, const uint64_t* __restrict__ dict_bits, int64_t dict_len, uint64_t* __restrict__ out_bits) {
+// the same for Int32 codes without NULLs on either side.  One row per lane with the dictionary bits read from global memory ran at 0.44 ms per 100 M rows over a dictionary of
+// 1 M entries, and eight rows per lane did not change it (0.47 ms, profiles/r04_n_timeline_cbu.txt): the time is the 100 M random 8-byte reads of a 125 KB bitmap that no L1
+// holds, not the 400 MB of codes.  Here every workgroup first copies the bitmap into LDS (up to 144 KB = 1.18 M entries) and the rows read their bit from there.
+__global__ void __launch_bounds__(1024) k_dict_predicate_i32(const int32_t* __restrict__ keys, int64_t n, const uint64_t* __restrict__ dict_bits, int64_t dict_len, uint64_t* __restrict__ out_bits) {
+  extern __shared__ uint32_t dp_bits[];
+  const int64_t dwords = (dict_len + 63) >> 6;
+  for (int64_t x = threadIdx.x; x < dwords; x += 1024) { const uint64_t v = dict_bits[x]; dp_bits[2 * x] = (uint32_t)v; dp_bits[2 * x + 1] = (uint32_t)(v >> 32); }
+  __syncthreads();
   const int lane = lane_id();
-  const int64_t nchunks = (n + 511) >> 9, wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * BLOCK) >> 6, nw = (n + 63) >> 6;
+  const int64_t nchunks = (n + 511) >> 9, wave = ((int64_t)blockIdx.x * 1024 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 1024) >> 6, nw = (n + 63) >> 6;
   for (int64_t ch = wave; ch < nchunks; ch += nwaves) {
     const int64_t base = ch << 9;
     int32_t c[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) { const int64_t i = base + q * 64 + lane; c[q] = i < n ? keys[i] : -1; }
-    bool v[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) v[q] = c[q] >= 0 && c[q] < dict_len && bit_get(dict_bits, c[q]);
-#pragma unroll
-    for (int q = 0; q < 8; q++) { const uint64_t m = ballot64(v[q]); if (lane == q && (base >> 6) + q < nw) out_bits[(base >> 6) + q] = m; }
+    for (int q = 0; q < 8; q++) {
+      const bool v = c[q] >= 0 && c[q] < dict_len && ((dp_bits[c[q] >> 5] >> (c[q] & 31)) & 1u);
+      const uint64_t m = ballot64(v); if (lane == 0 && (base >> 6) + q < nw) out_bits[(base >> 6) + q] = m;
+    }
   }
 }
 static int swap_cmp(int op) { switch (op) { case DFGPU_OP_LT: return DFGPU_OP_GT; case DFGPU_OP_LTEQ: return DFGPU_OP_GTEQ; case DFGPU_OP_GT: return DFGPU_OP_LT; case DFGPU_OP_GTEQ: return DFGPU_OP_LTEQ; default: return op; } }
@@ -389,8 +394,11 @@ dfgpu_status dfgpu_binary(dfgpu_ctx* ctx, int32_t op, const dfgpu_array* l, int3
           bool nv = dcol->validity || dres->validity;
           ArrayHolder hd(new_fixed(ctx, DFGPU_BOOL, n, 0, 0, nv));
           KernelTimer kt_(ctx, "k_dict_predicate");
-          if (!nv && dcol->key_type == DFGPU_INT32) {
-            hipLaunchKernelGGL(k_dict_predicate_i32, dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 16)), block, 0, ctx->stream, (const int32_t*)dcol->values->ptr, n, (const uint64_t*)dres->values->ptr, dres->length, (uint64_t*)hd.get()->values->ptr);
+          const size_t dp_lds = (size_t)((dres->length + 63) / 64) * 8;
+          if (!nv && dcol->key_type == DFGPU_INT32 && dp_lds <= 144 * 1024 && n >= (1 << 16)) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_dict_predicate_i32, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            const int per_cu = dp_lds <= 32 * 1024 ? 2 : 1;       // a large bitmap leaves room for one workgroup of 16 waves per CU
+            hipLaunchKernelGGL(k_dict_predicate_i32, dim3(grid_for(n, 1024 * 8, ctx->num_cus * per_cu)), dim3(1024), dp_lds, ctx->stream, (const int32_t*)dcol->values->ptr, n, (const uint64_t*)dres->values->ptr, dres->length, (uint64_t*)hd.get()->values->ptr);
             KERNEL_CHECK(); *out = hd.release(); return;
           }
           hipLaunchKernelGGL(k_dict_predicate, grid, block, 0, ctx->stream, dcol->values->ptr, dcol->key_type, dcol->validity ? (const uint64_t*)dcol->validity->ptr : nullptr, n,

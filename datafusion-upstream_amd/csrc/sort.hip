@@ -406,7 +406,179 @@ __global__ void __launch_bounds__(BLOCK) k_pk_encode(PkCols pc, int64_t n, uint6
     key |= off << k.shift;
   }
   if (outside && out) atomicOr(outside, 1u);
-  if (ib) keys[i] = (key << ib) | (uint64_t)i; else { keys[i] = key; idx[i] = (uint32_t)i; }
+  if (ib) keys[i] = (key << ib) | (uint64_t)i; else { keys[i] = key; if (idx) idx[i] = (uint32_t)i; }
+}
+// ---- one-sweep LSD passes over the words of word mode
+// The three launches of a pass (per-tile histogram, scan of the [digit][tile] matrix, scatter) read the words twice.  The DEVICE-WIDE digit histogram of every pass does not
+// depend on the order of the words, so all of them are counted while the words are encoded (k_pk_encode_hist: one LDS table per pass, merged with one global atomic per
+// used counter and workgroup), and a pass is ONE launch: a workgroup takes the next tile (a ticket: tiles start in order, so every tile a workgroup waits for is resident),
+// ranks its rows as the LDS-free scatter of radix_partition.h does, publishes the tile's digit counts, and finds the rows of its digit in the tiles before it by walking
+// back over their published words -- (count | AGG) until one carries (inclusive prefix | PREFIX) -- the chained scan with decoupled look-back of Merrill & Garland; thread d
+// walks for digit d, OS_LOOK words in flight per step (a word read at agent scope comes from beyond the XCD's L2: ~1-2 us each).
+constexpr int OS_NT = 512, OS_NW = OS_NT / WAVE, OS_LOOK = 8;
+constexpr uint32_t OS_AGG = 1u << 30, OS_PREFIX = 2u << 30, OS_VAL = (1u << 30) - 1u;
+struct OsLayout { int32_t npass; int32_t shift[8]; uint32_t mask[8]; };
+__global__ void __launch_bounds__(BLOCK) k_pk_encode_hist(PkCols pc, int64_t n, uint64_t* keys, int ib, uint32_t* outside, OsLayout L, uint32_t* hists /*[npass][256]*/) {
+  __shared__ uint32_t h[8 * 256];
+  for (int x = threadIdx.x; x < 8 * 256; x += BLOCK) h[x] = 0;
+  __syncthreads();
+  const int lane = lane_id(); bool out = false;
+  for (int64_t b0 = (int64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63); b0 < n; b0 += (int64_t)gridDim.x * BLOCK) {
+    const int64_t i = b0 + lane; const bool on = i < n;
+    uint64_t key = 0;
+    if (on) for (int c = 0; c < MAX_KEYS; c++) {
+      if (c >= pc.n) break;
+      const PkCol& k = pc.c[c]; uint64_t off;
+      if (!valid_at(k.valid, i)) off = k.nulls_first ? 0 : k.span + 1;
+      else { uint64_t hh, l; pk_order_bits(k.v, k.type, i, &hh, &l); uint64_t d = l - k.lo_bits;
+        if (outside) { const uint64_t dh = hh - k.hi_bits - (l < k.lo_bits ? 1ull : 0ull); out |= dh != 0 || d >= k.span; }
+        off = 1 + (k.desc ? k.span - 1 - d : d); }
+      key |= off << k.shift;
+    }
+    const uint64_t word = (key << ib) | (uint64_t)i;
+    if (on) keys[i] = word;
+    const uint64_t onm = ballot64(on); const int src = __ffsll((unsigned long long)onm) - 1;
+    for (int p = 0; p < L.npass; p++) {
+      const uint32_t d = (uint32_t)(word >> L.shift[p]) & L.mask[p], d0 = __shfl(d, src, 64);
+      if (ballot64(on && d != d0) == 0) { if (lane == src) atomicAdd(&h[p * 256 + d0], (uint32_t)__popcll(onm)); }       // a constant digit (the top bits of a narrow range) is one add per wave
+      else if (on) atomicAdd(&h[p * 256 + d], 1u);
+    }
+  }
+  if (outside && out) atomicOr(outside, 1u);
+  __syncthreads();
+  for (int x = threadIdx.x; x < L.npass * 256; x += BLOCK) if (h[x]) atomicAdd(&hists[x], h[x]);
+}
+// hists[p][256] -> gbase[p][256] = first output slot of digit d in pass p (one workgroup per pass)
+__global__ void __launch_bounds__(256) k_os_bases(const uint32_t* hists, uint32_t* gbase) {
+  __shared__ uint32_t wsum[4];
+  const uint32_t v = hists[blockIdx.x * 256 + threadIdx.x], inc = wave_inclusive_sum(v);
+  if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  uint32_t run = inc - v; for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wsum[w];
+  gbase[blockIdx.x * 256 + threadIdx.x] = run;
+}
+template <int R>          // rows per lane: a tile is R x 512 rows
+__global__ void __launch_bounds__(OS_NT) k_os_pass(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int64_t n, int shift, uint32_t mask, const uint32_t* __restrict__ gbase,
+                                                   uint32_t* status /*[ntiles][256]*/, uint32_t* ticket) {
+  __shared__ uint16_t wcnt[R * OS_NW * 256];          // rows of digit d in (slab q, wave w), then their exclusive prefix in (slab, wave) order
+  __shared__ uint32_t tbase[256]; __shared__ uint32_t tile_sh;
+  if (threadIdx.x == 0) tile_sh = atomicAdd(ticket, 1u);
+  for (int x = threadIdx.x; x < R * OS_NW * 128; x += OS_NT) ((uint32_t*)wcnt)[x] = 0;
+  __syncthreads();
+  const int64_t t = tile_sh, base = t * (int64_t)(R * OS_NT); const int wave = threadIdx.x >> 6;
+  uint64_t w[R]; uint32_t d[R], rk[R]; bool on[R];
+#pragma unroll
+  for (int q = 0; q < R; q++) { const int64_t i = base + (int64_t)q * OS_NT + threadIdx.x; on[q] = i < n; w[q] = on[q] ? in[i] : 0ull; }
+#pragma unroll
+  for (int q = 0; q < R; q++) {
+    d[q] = (uint32_t)(w[q] >> shift) & mask;
+    uint64_t peers = ballot64(on[q]);
+    for (uint32_t b = 1; b <= mask; b <<= 1) { const uint64_t mb = ballot64((d[q] & b) != 0); peers &= (d[q] & b) ? mb : ~mb; }
+    rk[q] = (uint32_t)__popcll(peers & lanemask_lt());
+    if (on[q] && rk[q] == 0) wcnt[((size_t)q * OS_NW + wave) * 256 + d[q]] = (uint16_t)__popcll(peers);
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    uint32_t run = 0;
+#pragma unroll 8
+    for (int x = 0; x < R * OS_NW; x++) { const uint16_t c = wcnt[(size_t)x * 256 + threadIdx.x]; wcnt[(size_t)x * 256 + threadIdx.x] = (uint16_t)run; run += c; }
+    uint32_t* const mine = status + t * 256 + threadIdx.x;
+    uint32_t excl = 0;
+    if (t == 0) __hip_atomic_store(mine, run | OS_PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else {
+      __hip_atomic_store(mine, run | OS_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int64_t tt = t - 1; bool done = false;
+      while (!done) {
+        uint32_t sv[OS_LOOK];
+#pragma unroll
+        for (int k = 0; k < OS_LOOK; k++) sv[k] = tt - k >= 0 ? __hip_atomic_load(status + (tt - k) * 256 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : OS_PREFIX;
+        int used = 0;
+#pragma unroll
+        for (int k = 0; k < OS_LOOK; k++) if (!done && used == k) {
+          if ((sv[k] >> 30) != 0) { excl += sv[k] & OS_VAL; used = k + 1; done = (sv[k] >> 30) == 2u; }          // a word not yet published: poll again from that tile on
+        }
+        tt -= used;
+      }
+      __hip_atomic_store(mine, (excl + run) | OS_PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    tbase[threadIdx.x] = gbase[threadIdx.x] + excl;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < R; q++) if (on[q]) out[(int64_t)(tbase[d[q]] + (uint32_t)wcnt[((size_t)q * OS_NW + wave) * 256 + d[q]] + rk[q])] = w[q];
+}
+// ---- TopK over the words of word mode (SortExec with fetch over a large input whose keys pack; topk/mod.rs keeps a heap of k rows, here:) radix SELECT on the word --
+// every word is distinct (its low bits are the row number), so the k smallest words are exactly the rows a stable sort puts first.  A pass counts one 8-bit digit over the
+// words that share the digits chosen so far; the host picks the digit holding the k-th word; when few candidates are left, the words up to the chosen prefix are
+// compacted (k + at most 4096 of them) and sorted on their own: by counting, for every word, the words below it (one launch) when they fit, by the LSD passes otherwise.
+__global__ void __launch_bounds__(BLOCK) k_ws_hist(const uint64_t* __restrict__ words, int64_t n, int shift, uint32_t mask, int has_prefix, int pshift, uint64_t prefix, uint32_t* hist) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0; __syncthreads();
+  const int lane = lane_id();
+  for (int64_t b0 = ((int64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63)) * 4; b0 < n; b0 += (int64_t)gridDim.x * BLOCK * 4) {
+    uint64_t w[4]; bool on[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int64_t i = b0 + q * 64 + lane; on[q] = i < n; w[q] = on[q] ? words[i] : 0ull; }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const bool c = on[q] && (!has_prefix || (w[q] >> pshift) == prefix);
+      const uint64_t cm = ballot64(c); if (!cm) continue;
+      const int src = __ffsll((unsigned long long)cm) - 1; const uint32_t d = (uint32_t)(w[q] >> shift) & mask, d0 = __shfl(d, src, 64);
+      if (ballot64(c && d != d0) == 0) { if (lane == src) atomicAdd(&h[d0], (uint32_t)__popcll(cm)); }
+      else if (c) atomicAdd(&h[d], 1u);
+    }
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void __launch_bounds__(BLOCK) k_ws_collect(const uint64_t* __restrict__ words, int64_t n, int pshift, uint64_t prefix, uint64_t* __restrict__ out, unsigned long long* counter, uint64_t cap) {
+  const int lane = lane_id();
+  for (int64_t b0 = (int64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63); b0 < n; b0 += (int64_t)gridDim.x * BLOCK) {
+    const int64_t i = b0 + lane; const uint64_t w = i < n ? words[i] : ~0ull;
+    const bool sel = i < n && (w >> pshift) <= prefix;
+    const uint64_t sm = ballot64(sel); if (!sm) continue;
+    const int src = __ffsll((unsigned long long)sm) - 1;
+    unsigned long long pos = 0; if (lane == src) pos = atomicAdd(counter, (unsigned long long)__popcll(sm));
+    pos = __shfl(pos, src, 64) + (unsigned long long)__popcll(sm & lanemask_lt());
+    if (sel && pos < cap) out[pos] = w;
+  }
+}
+// m distinct words (m <= 16384): out[#words below w] = w.  Every thread keeps one word and walks all of them through LDS (broadcast reads): m^2 compares, one launch
+__global__ void __launch_bounds__(BLOCK) k_ws_rank_sort(const uint64_t* __restrict__ in, int m, uint64_t* __restrict__ out) {
+  __shared__ uint64_t tile[1024];
+  const int i = blockIdx.x * BLOCK + threadIdx.x; const uint64_t w = i < m ? in[i] : ~0ull;
+  uint32_t below = 0;
+  for (int t0 = 0; t0 < m; t0 += 1024) {
+    __syncthreads();
+    for (int x = threadIdx.x; x < 1024; x += BLOCK) tile[x] = t0 + x < m ? in[t0 + x] : ~0ull;
+    __syncthreads();
+#pragma unroll 8
+    for (int x = 0; x < 1024; x++) below += tile[x] < w ? 1u : 0u;
+  }
+  if (i < m) out[below] = w;
+}
+// the same select when key and row number do not share a word (keys may repeat): the rows up to the chosen prefix are marked in a bitmap, listed in row order, their
+// keys gathered; (key, position in the list) then orders them as the stable sort does
+__global__ void __launch_bounds__(BLOCK) k_ws_mark(const uint64_t* __restrict__ keys, int64_t n, int pshift, uint64_t prefix, uint64_t* __restrict__ bits) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const uint64_t m = ballot64(i < n && (keys[i] >> pshift) <= prefix);
+  if (lane_id() == 0 && (i >> 6) < ((n + 63) >> 6)) bits[i >> 6] = m;
+}
+__global__ void __launch_bounds__(BLOCK) k_ws_gather(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ rows, int64_t m, uint64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i < m) out[i] = keys[rows[i]];
+}
+__global__ void __launch_bounds__(BLOCK) k_ws_rank_sort_pairs(const uint64_t* __restrict__ in, const uint32_t* __restrict__ vals, int m, uint64_t* __restrict__ out, uint32_t* __restrict__ out_vals) {
+  __shared__ uint64_t tile[1024];
+  const int i = blockIdx.x * BLOCK + threadIdx.x; const uint64_t w = i < m ? in[i] : ~0ull;
+  uint32_t below = 0;
+  for (int t0 = 0; t0 < m; t0 += 1024) {
+    __syncthreads();
+    for (int x = threadIdx.x; x < 1024; x += BLOCK) tile[x] = t0 + x < m ? in[t0 + x] : ~0ull;
+    __syncthreads();
+#pragma unroll 8
+    for (int x = 0; x < 1024; x++) below += (tile[x] < w || (tile[x] == w && t0 + x < i)) ? 1u : 0u;
+  }
+  if (i < m) { out[below] = w; out_vals[below] = vals[i]; }
 }
 // word mode, after the last pass: row numbers out of the low bits; every key column that asked for it (sorted_dst) is rebuilt from its bits of the sorted word --
 // offset -> order pattern (minimum + distance, 128-bit) -> value -- with sequential reads and writes instead of a gather through the permutation
@@ -456,8 +628,10 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
       s.has_null_byte = (s.v.validity || s.v.key_validity) ? 1 : 0; s.descending = descending && descending[c]; s.nulls_first = nulls_first ? nulls_first[c] : 1;
       W += s.has_null_byte + (lt == DFGPU_BOOL ? 1 : (lt == DFGPU_UTF8 ? s.max_len + 4 : type_width(lt)));
     }
-    // ---- packed-key path: large input, fixed-width keys whose value ranges concatenate into 64 bits, no TopK
-    if (n >= ctx->sort_packed_min_rows && ctx->sort_packed_keys && !(fetch > 0 && fetch * 16 <= n)) {
+    // ---- packed-key path: large input, fixed-width keys whose value ranges concatenate into 64 bits; with a fetch of at most n / 16 rows only from sort_topk_words_min_rows
+    // rows on and only when key and row number share one word (the select over the words; below, the byte-plane select that follows is the cheaper one)
+    const bool topk = fetch > 0 && fetch * 16 <= n;
+    if (n >= ctx->sort_packed_min_rows && ctx->sort_packed_keys && (!topk || n >= ctx->sort_topk_words_min_rows)) {
       bool ok = true; PkCols pc{}; pc.n = k;
       for (int c = 0; c < k && ok; c++) {
         const dfgpu_array* a = cols[c];
@@ -502,21 +676,80 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
           const bool word = total_bits + ib <= 64;
           for (int c = 0; c < k; c++) { pc.c[c].bits = bits_of[c]; pc.c[c].sorted_dst = nullptr; }
           BufferPtr k0 = alloc_buffer(ctx, (size_t)n * 8), k1 = alloc_buffer(ctx, (size_t)n * 8), v1 = word ? BufferPtr() : alloc_buffer(ctx, (size_t)n * 4);
-          ArrayHolder idx(new_fixed(ctx, DFGPU_UINT32, word && fetch >= 0 && fetch < n ? fetch : n));
+          ArrayHolder idx(new_fixed(ctx, DFGPU_UINT32, (word || topk) && fetch >= 0 && fetch < n ? fetch : n));
+          const int npass = (total_bits + 7) / 8, dbits = (total_bits + npass - 1) / npass;          // up to 8-bit digits, evened out over the passes (9-bit digits double the count table of the stable scatter: 4 passes of 9 measured 6.6 ms against 4.5 ms for 5 of 8 on 100 M rows)
+          // one-sweep passes: word mode, inputs large enough that a pass is bandwidth and not launches, row counts a 30-bit status value holds
+          const int os_r = ctx->sort_onesweep_rows == 16 ? 16 : 8;
+          const bool onesweep = word && !topk && ctx->sort_onesweep_rows > 0 && npass <= 8 && n >= ((int64_t)1 << 20) && n < ((int64_t)1 << 30);
+          const int64_t os_tiles = (n + (int64_t)os_r * OS_NT - 1) / ((int64_t)os_r * OS_NT);
+          BufferPtr os_buf; OsLayout L{}; uint32_t *os_hist = nullptr, *os_base = nullptr, *os_ticket = nullptr, *os_status = nullptr;
+          if (onesweep) {
+            L.npass = npass; for (int p = 0; p < npass; p++) { const int sh = p * dbits, bits = total_bits - sh < dbits ? total_bits - sh : dbits; L.shift[p] = sh + ib; L.mask[p] = (1u << bits) - 1u; }
+            const size_t head = (size_t)(8 * 256 * 2 + 64) * 4;
+            os_buf = alloc_buffer(ctx, head + (size_t)npass * (size_t)os_tiles * 256 * 4);
+            os_hist = (uint32_t*)os_buf->ptr; os_base = os_hist + 8 * 256; os_ticket = os_base + 8 * 256; os_status = os_ticket + 64;
+            HIP_CHECK(hipMemsetAsync(os_buf->ptr, 0, head + (size_t)npass * (size_t)os_tiles * 256 * 4, ctx->stream));
+          }
           { KernelTimer kt_(ctx, "sort_key_encode");
             if (sampled) HIP_CHECK(hipMemsetAsync(ctx->d_scratch64 + 14, 0, 8, ctx->stream));
-            hipLaunchKernelGGL(k_pk_encode, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, pc, n, (uint64_t*)k0->ptr, word ? (uint32_t*)nullptr : (uint32_t*)idx.get()->values->ptr, word ? ib : 0,
-                               sampled ? (uint32_t*)(ctx->d_scratch64 + 14) : (uint32_t*)nullptr); KERNEL_CHECK(); }
+            if (onesweep) hipLaunchKernelGGL(k_pk_encode_hist, dim3(grid_for(n, BLOCK, ctx->num_cus * 8)), dim3(BLOCK), 0, ctx->stream, pc, n, (uint64_t*)k0->ptr, ib, sampled ? (uint32_t*)(ctx->d_scratch64 + 14) : (uint32_t*)nullptr, L, os_hist);
+            else hipLaunchKernelGGL(k_pk_encode, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, pc, n, (uint64_t*)k0->ptr, word || topk ? (uint32_t*)nullptr : (uint32_t*)idx.get()->values->ptr, word ? ib : 0,
+                               sampled ? (uint32_t*)(ctx->d_scratch64 + 14) : (uint32_t*)nullptr);
+            KERNEL_CHECK(); }
           if (sampled) { const uint64_t miss = read_scratch(ctx, 14); ctx->count_sync("sync:sort_key_outside"); if (miss) continue; }       // some value lies outside the sampled ranges: exact pass
           uint64_t* ka = (uint64_t*)k0->ptr; uint64_t* kb = (uint64_t*)k1->ptr; uint32_t* va = (uint32_t*)idx.get()->values->ptr; uint32_t* vb = word ? nullptr : (uint32_t*)v1->ptr;
-          const int npass = (total_bits + 7) / 8, dbits = (total_bits + npass - 1) / npass;          // up to 8-bit digits, evened out over the passes (9-bit digits double the count table of the stable scatter: 4 passes of 9 measured 6.6 ms against 4.5 ms for 5 of 8 on 100 M rows)
-          for (int shift = 0; shift < total_bits; shift += dbits) {
+          int64_t ns = n;                                // rows the passes sort
+          bool sorted_already = false; ArrayHolder rows;
+          if (topk) {
+            KernelTimer kt_(ctx, "sort_topk_words");
+            BufferPtr hist = alloc_buffer(ctx, 256 * 4 + 8);
+            int sh = total_bits + (word ? ib : 0), pshift = 0, has_prefix = 0; uint64_t prefix = 0; int64_t remaining = fetch, ncand = n;
+            const int grid = grid_for(n, BLOCK * 4, ctx->num_cus * 8);
+            while (sh > 0) {
+              const int bits = sh < 8 ? sh : 8; sh -= bits;
+              HIP_CHECK(hipMemsetAsync(hist->ptr, 0, 256 * 4, ctx->stream));
+              hipLaunchKernelGGL(k_ws_hist, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)ka, n, sh, (1u << bits) - 1u, has_prefix, pshift, prefix, (uint32_t*)hist->ptr); KERNEL_CHECK();
+              uint32_t hh[256]; ctx->count_sync("sync:topk_histogram"); fetch_to_host(ctx, hh, hist->ptr, sizeof hh);
+              int64_t cum = 0; int d = 0;
+              for (; d < (1 << bits) - 1; d++) { if (cum + (int64_t)hh[d] >= remaining) break; cum += hh[d]; }
+              remaining -= cum; ncand = hh[d]; prefix = (prefix << bits) | (uint64_t)d; pshift = sh; has_prefix = 1;
+              if (ncand <= remaining + 4096) break;
+            }
+            ns = fetch - remaining + ncand;              // rows up to the chosen prefix: the fetch first of the sorted order are among them
+            if (word) {
+              unsigned long long* counter = (unsigned long long*)((uint32_t*)hist->ptr + 256);
+              HIP_CHECK(hipMemsetAsync(counter, 0, 8, ctx->stream));
+              hipLaunchKernelGGL(k_ws_collect, dim3(grid_for(n, BLOCK, ctx->num_cus * 16)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)ka, n, pshift, prefix, kb, counter, (uint64_t)ns); KERNEL_CHECK();
+              std::swap(ka, kb);
+              if (ns <= 16384) { hipLaunchKernelGGL(k_ws_rank_sort, dim3(grid_for(ns, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)ka, (int)ns, kb); KERNEL_CHECK(); std::swap(ka, kb); sorted_already = true; }
+            } else {
+              BufferPtr bm = alloc_buffer(ctx, (size_t)((n + 63) / 64) * 8);
+              hipLaunchKernelGGL(k_ws_mark, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)ka, n, pshift, prefix, (uint64_t*)bm->ptr); KERNEL_CHECK();
+              rows.a = mask_to_indices_uncounted(ctx, (const uint64_t*)bm->ptr, n);          // ascending rows; the first ns entries are written (ns is known from the histograms)
+              hipLaunchKernelGGL(k_ws_gather, dim3(grid_for(ns, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)ka, (const uint32_t*)rows.get()->values->ptr, ns, kb); KERNEL_CHECK();
+              std::swap(ka, kb); va = (uint32_t*)rows.get()->values->ptr;
+              if (ns <= 16384) { hipLaunchKernelGGL(k_ws_rank_sort_pairs, dim3(grid_for(ns, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)ka, (const uint32_t*)va, (int)ns, kb, vb); KERNEL_CHECK();
+                std::swap(ka, kb); std::swap(va, vb); sorted_already = true; }
+            }
+          }
+          if (sorted_already) {}
+          else if (onesweep) {
+            KernelTimer kt_(ctx, "sort_pass_onesweep");
+            hipLaunchKernelGGL(k_os_bases, dim3(npass), dim3(256), 0, ctx->stream, (const uint32_t*)os_hist, os_base);
+            for (int p = 0; p < npass; p++) {
+              if (os_r == 16) hipLaunchKernelGGL((k_os_pass<16>), dim3((unsigned)os_tiles), dim3(OS_NT), 0, ctx->stream, (const uint64_t*)ka, kb, n, L.shift[p], L.mask[p], (const uint32_t*)(os_base + p * 256), os_status + (size_t)p * os_tiles * 256, os_ticket + p);
+              else hipLaunchKernelGGL((k_os_pass<8>), dim3((unsigned)os_tiles), dim3(OS_NT), 0, ctx->stream, (const uint64_t*)ka, kb, n, L.shift[p], L.mask[p], (const uint32_t*)(os_base + p * 256), os_status + (size_t)p * os_tiles * 256, os_ticket + p);
+              std::swap(ka, kb);
+            }
+            KERNEL_CHECK();
+          }
+          else for (int shift = 0; shift < total_bits; shift += dbits) {
             const int bits = total_bits - shift < dbits ? total_bits - shift : dbits; const bool last = shift + dbits >= total_bits;
             RpCols rc{};
             if (word) { rc.n = 1; rc.c[0] = RpCol{ nullptr, kb, 8, RP_HASHKEY, 0 }; }       // the whole record is the word the digit is read from
             else { rc.n = last ? 1 : 2; rc.c[0] = RpCol{ va, vb, 4, RP_RAW, 0 };
               if (!last) rc.c[1] = RpCol{ nullptr, kb, 8, RP_HASHKEY, 0 }; }                // the last pass only needs the row ids
-            (void)rp_partition(ctx, RpHashDigit{ ka, shift + (word ? ib : 0), (1u << bits) - 1u }, n, 1u << bits, rc, true, ctx->d_scratch64 + 9, "sort_pass_hist", "sort_pass_scan", "sort_pass_scatter", false);
+            (void)rp_partition(ctx, RpHashDigit{ ka, shift + (word ? ib : 0), (1u << bits) - 1u }, ns, 1u << bits, rc, true, ctx->d_scratch64 + 9, "sort_pass_hist", "sort_pass_scan", "sort_pass_scatter", false);
             std::swap(ka, kb); std::swap(va, vb);
           }
           if (word) {
@@ -530,6 +763,7 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
             *out = idx.release();
             return;
           }
+          if (topk) { HIP_CHECK(hipMemcpyAsync(idx.get()->values->ptr, va, (size_t)fetch * 4, hipMemcpyDeviceToDevice, ctx->stream)); *out = idx.release(); return; }     // the first fetch of the ns sorted rows
           if (va != (uint32_t*)idx.get()->values->ptr) HIP_CHECK(hipMemcpyAsync(idx.get()->values->ptr, va, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
           if (fetch >= 0 && fetch < n) { dfgpu_array* s2 = nullptr; dfgpu_status st = dfgpu_array_slice(ctx, idx.get(), 0, fetch, &s2); if (st != DFGPU_OK) fail(st, "%s", ctx->err.c_str()); *out = s2; }
           else *out = idx.release();

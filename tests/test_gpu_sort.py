@@ -256,3 +256,82 @@ def test_small_input_passes_in_one_launch_each_give_the_same_stable_order(ctx, n
     pkey = np.where(pmask, np.int64(-(1 << 40)), prio.astype(np.int64))         # NULLs first in an ascending column
     want = np.lexsort((np.arange(n), pkey, date, -rev))                         # last key is the primary one; row number breaks ties = stable
     assert np.array_equal(got.astype(np.int64), want)
+
+
+@pytest.mark.parametrize("rows_per_lane", [8, 16])
+@pytest.mark.parametrize("shape", ["decimal_desc_date_nullable", "one_narrow_key", "skewed"])
+def test_one_sweep_passes_equal_the_three_launch_passes(ctx, shape, rows_per_lane):
+    """Word-mode sorts of 2^20 .. 2^30 rows run every LSD pass as one launch (k_os_pass: tiles by ticket, digit counts published per tile, look-back over the tiles in
+    front) over histograms counted while the words are encoded.  The indices must be the three-launch passes' and numpy's stable lexsort: a ragged last tile, NULLs in both
+    columns, a key of few bits (one short pass), and a skewed key whose top digits are constant over most waves (the one-add-per-wave branch of the histogram)."""
+    rng = np.random.default_rng(29)
+    n = (1 << 21) + 777 if shape != "one_narrow_key" else (1 << 20) + 1
+    if shape == "decimal_desc_date_nullable":
+        import decimal
+        price = rng.integers(90000, 10494951, n); pm = rng.random(n) < 0.02
+        date = rng.integers(8035, 10560, n).astype(np.int32); dm = rng.random(n) < 0.02
+        cols = [pa.array([None if m else decimal.Decimal(int(v)).scaleb(-2) for v, m in zip(price, pm)], type=pa.decimal128(15, 2)), pa.array(date, mask=dm).cast(pa.date32())]
+        desc, nf = [True, False], [True, False]
+        pk = np.where(pm, np.int64(1 << 40), price); dk = np.where(dm, np.int64(1 << 40), date.astype(np.int64))
+        want = np.lexsort((np.arange(n), dk, -pk))
+    elif shape == "one_narrow_key":
+        a = rng.integers(0, 11, n).astype(np.int32)
+        cols = [pa.array(a)]; desc, nf = [False], [True]
+        want = np.lexsort((np.arange(n), a))
+    else:
+        a = np.where(rng.random(n) < 0.999, 5, rng.integers(0, 1 << 30, n)).astype(np.int64); b = (rng.zipf(1.5, n) % 1000).astype(np.int32)
+        cols = [pa.array(a), pa.array(b)]; desc, nf = [False, True], [True, True]
+        want = np.lexsort((np.arange(n), -b.astype(np.int64), a))
+    dcols = [ctx.from_arrow(c) for c in cols]
+    ctx.profile_select(None); ctx.profile_enable(True); ctx.profile_read()
+    try:
+        ctx.set_option("sort_onesweep_rows", rows_per_lane)
+        got = ctx.sort_to_indices(dcols, desc, nf).to_numpy()
+        ks = set(ctx.profile_read())
+        ctx.set_option("sort_onesweep_rows", 0)
+        plain = ctx.sort_to_indices(dcols, desc, nf).to_numpy()
+        kp = set(ctx.profile_read())
+    finally:
+        ctx.profile_enable(False); ctx.set_option("sort_onesweep_rows", 8)
+    assert "sort_pass_onesweep" in ks and "sort_pass_scatter" not in ks and "sort_pass_scatter" in kp and "sort_pass_onesweep" not in kp
+    assert np.array_equal(got, plain)
+    assert np.array_equal(got.astype(np.int64), want)
+
+
+@pytest.mark.parametrize("fetch", [1, 10, 5000, 60_000])
+@pytest.mark.parametrize("shape", ["sum_desc_key", "many_ties", "nullable_float", "wide_keys_not_a_word"])
+def test_topk_over_packed_words_equals_sort_then_slice(ctx, shape, fetch):
+    """SortExec with fetch <= n / 16 over a large input whose keys pack with the row number into one word: radix select on the words (k_ws_hist per digit, the host picks the
+    digit of the fetch-th word), the words up to the chosen prefix compacted and sorted on their own (by counting the words below each when they are at most 16384, by the
+    LSD passes otherwise).  Result = the first `fetch` indices of the stable full sort; ties (equal keys) in row order; the option moves the threshold down to the test's size."""
+    rng = np.random.default_rng(31 + fetch)
+    n = (1 << 20) + 4099
+    if shape == "sum_desc_key":
+        a = rng.integers(0, 1 << 20, n).astype(np.int64); b = rng.integers(0, 1 << 18, n).astype(np.int64)              # 21 + 19 key bits + 21 row bits: one word
+        cols = [pa.array(a), pa.array(b)]; desc, nf = [True, False], [True, False]
+        want = np.lexsort((np.arange(n), b, -a))
+    elif shape == "many_ties":
+        a = rng.integers(0, 4, n).astype(np.int32)
+        cols = [pa.array(a)]; desc, nf = [False], [True]
+        want = np.lexsort((np.arange(n), a))
+    elif shape == "wide_keys_not_a_word":             # 31 + 26 key bits + 21 row bits: keys and row numbers move apart, equal keys (about 20 rows each) keep row order
+        a = rng.integers(0, 1 << 30, 1000)[rng.integers(0, 1000, n)].astype(np.int64); b = rng.integers(0, 1 << 25, 50)[rng.integers(0, 50, n)].astype(np.int64)
+        cols = [pa.array(a), pa.array(b)]; desc, nf = [True, False], [True, False]
+        want = np.lexsort((np.arange(n), b, -a))
+    else:
+        a = (rng.random(n) * 1000).astype(np.float32); am = rng.random(n) < 0.3
+        cols = [pa.array(a, mask=am)]; desc, nf = [True], [False]
+        bits = a.view(np.int32).astype(np.int64)                        # positive floats: the bit pattern orders like the value
+        want = np.lexsort((np.arange(n), np.where(am, np.int64(-1), bits) * -1))      # DESC, NULLs last
+    dcols = [ctx.from_arrow(c) for c in cols]
+    ctx.profile_select(None); ctx.profile_enable(True); ctx.profile_read()
+    try:
+        ctx.set_option("sort_topk_words_min_rows", 1 << 20)
+        got = ctx.sort_to_indices(dcols, desc, nf, fetch=fetch).to_numpy()
+        ks = set(ctx.profile_read())
+    finally:
+        ctx.profile_enable(False); ctx.set_option("sort_topk_words_min_rows", 1 << 23)
+    assert "sort_topk_words" in ks
+    full = ctx.sort_to_indices(dcols, desc, nf).to_numpy()
+    assert np.array_equal(got, full[:fetch])
+    assert np.array_equal(got.astype(np.int64), want[:fetch])
