@@ -680,7 +680,7 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
           const int npass = (total_bits + 7) / 8, dbits = (total_bits + npass - 1) / npass;          // up to 8-bit digits, evened out over the passes (9-bit digits double the count table of the stable scatter: 4 passes of 9 measured 6.6 ms against 4.5 ms for 5 of 8 on 100 M rows)
           // one-sweep passes: word mode, inputs large enough that a pass is bandwidth and not launches, row counts a 30-bit status value holds
           const int os_r = ctx->sort_onesweep_rows == 16 ? 16 : 8;
-          const bool onesweep = word && !topk && ctx->sort_onesweep_rows > 0 && npass <= 8 && n >= ((int64_t)1 << 20) && n < ((int64_t)1 << 30);
+          const bool onesweep = word && !topk && ctx->sort_onesweep_rows > 0 && npass <= 8 && n >= ctx->sort_onesweep_min_rows && n < ((int64_t)1 << 30);
           const int64_t os_tiles = (n + (int64_t)os_r * OS_NT - 1) / ((int64_t)os_r * OS_NT);
           BufferPtr os_buf; OsLayout L{}; uint32_t *os_hist = nullptr, *os_base = nullptr, *os_ticket = nullptr, *os_status = nullptr;
           if (onesweep) {
@@ -743,13 +743,17 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
             }
             KERNEL_CHECK();
           }
-          else for (int shift = 0; shift < total_bits; shift += dbits) {
-            const int bits = total_bits - shift < dbits ? total_bits - shift : dbits; const bool last = shift + dbits >= total_bits;
+          // the words a select compacted arrive in no order: their passes also sort the row-number bits (ties = row order); everywhere else the input order breaks ties
+          const int sort_bits = topk && word ? total_bits + ib : total_bits, base_shift = word && !topk ? ib : 0;
+          const int npass_l = (sort_bits + 7) / 8, dbits_l = (sort_bits + npass_l - 1) / npass_l;
+          if (sorted_already || onesweep) {}
+          else for (int shift = 0; shift < sort_bits; shift += dbits_l) {
+            const int bits = sort_bits - shift < dbits_l ? sort_bits - shift : dbits_l; const bool last = shift + dbits_l >= sort_bits;
             RpCols rc{};
             if (word) { rc.n = 1; rc.c[0] = RpCol{ nullptr, kb, 8, RP_HASHKEY, 0 }; }       // the whole record is the word the digit is read from
             else { rc.n = last ? 1 : 2; rc.c[0] = RpCol{ va, vb, 4, RP_RAW, 0 };
               if (!last) rc.c[1] = RpCol{ nullptr, kb, 8, RP_HASHKEY, 0 }; }                // the last pass only needs the row ids
-            (void)rp_partition(ctx, RpHashDigit{ ka, shift + (word ? ib : 0), (1u << bits) - 1u }, ns, 1u << bits, rc, true, ctx->d_scratch64 + 9, "sort_pass_hist", "sort_pass_scan", "sort_pass_scatter", false);
+            (void)rp_partition(ctx, RpHashDigit{ ka, shift + base_shift, (1u << bits) - 1u }, ns, 1u << bits, rc, true, ctx->d_scratch64 + 9, "sort_pass_hist", "sort_pass_scan", "sort_pass_scatter", false);
             std::swap(ka, kb); std::swap(va, vb);
           }
           if (word) {
