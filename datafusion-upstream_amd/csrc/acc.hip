@@ -636,7 +636,8 @@ int64_t dfgpu_acc_size(const dfgpu_acc* a) { return a ? a->cap * (a->width + 9) 
 dfgpu_status dfgpu_acc_update_batch(dfgpu_ctx* ctx, dfgpu_acc* a, const dfgpu_array* values, const dfgpu_array* gids, const dfgpu_array* filt, int64_t total) {
   return guard(ctx, [&] {
     if (!a || !gids) fail(DFGPU_INVALID_ARGUMENT, "acc_update_batch: null argument");
-    if (gids->length == 0) { acc_resize(a, total); return; }     // self.values.resize(total_num_groups, ..) with nothing to accumulate
+    if (gids->length == 0) { if (a->lazy && total <= a->n) return;          // nothing to grow and nothing to add: adopted states stay adopted
+      acc_resize(a, total); return; }     // self.values.resize(total_num_groups, ..) with nothing to accumulate
     if (a->kind != DFGPU_AGG_COUNT) {
       if (!values) fail(DFGPU_INVALID_ARGUMENT, "acc_update_batch: values required");
       int32_t lt = logical_type(values);

@@ -109,6 +109,7 @@ void check_flags(dfgpu_ctx* ctx, const char* what) {
   if (f & DFGPU_FLAG_OVERFLOW) fail(DFGPU_EXECUTION, "Arrow error: Arithmetic overflow (%s)", what);
   if (f & DFGPU_FLAG_CAST) fail(DFGPU_EXECUTION, "Arrow error: Cast error: value out of range (%s)", what);
   if (f & DFGPU_FLAG_OOB) fail(DFGPU_EXECUTION, "Arrow error: index out of bounds (%s)", what);
+  if (f & DFGPU_FLAG_STALLED) fail(DFGPU_INTERNAL, "a workgroup gave up waiting for the tile counts of the workgroups in front of it; the result of that sort is not valid (%s; option sort_onesweep_rows=0 selects the three-launch passes)", what);
   fail(DFGPU_INTERNAL, "kernel raised flag %u (%s)", f, what);
 }
 __global__ void __launch_bounds__(512) k_post_words(const uint32_t* src, int nwords, uint32_t* h_dst, unsigned long long* h_seq, unsigned long long seq) {
@@ -443,6 +444,7 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "agg_spill_state_bytes") ctx->agg_spill_state_bytes = value;
     else if (k == "sort_estimate_ranges") ctx->sort_estimate_ranges = value != 0;
     else if (k == "sort_topk_words_min_rows") ctx->sort_topk_words_min_rows = value < 2 ? 2 : value;
+    else if (k == "sort_onesweep_fused_finish") ctx->sort_onesweep_fused_finish = value != 0;
     else if (k == "sort_onesweep_min_rows") ctx->sort_onesweep_min_rows = value < 2 ? 2 : value;
     else if (k == "sort_onesweep_rows") ctx->sort_onesweep_rows = value == 16 ? 16 : value > 0 ? 8 : 0;
     else if (k == "sort_fused_small_passes") ctx->sort_fused_small_passes = value != 0;

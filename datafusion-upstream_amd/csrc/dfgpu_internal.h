@@ -31,7 +31,7 @@ struct Error : std::exception {
 }  // namespace dfgpu
 
 // Device error flags raised by kernels (checked by the op that launched them).
-enum : uint32_t { DFGPU_FLAG_DIV_ZERO = 1, DFGPU_FLAG_OVERFLOW = 2, DFGPU_FLAG_CAST = 4, DFGPU_FLAG_OOB = 8, DFGPU_FLAG_TABLE_FULL = 16 };
+enum : uint32_t { DFGPU_FLAG_DIV_ZERO = 1, DFGPU_FLAG_OVERFLOW = 2, DFGPU_FLAG_CAST = 4, DFGPU_FLAG_OOB = 8, DFGPU_FLAG_TABLE_FULL = 16, DFGPU_FLAG_STALLED = 32 };      // STALLED: a workgroup gave up waiting for a word another workgroup publishes (one-sweep sort passes)
 
 namespace dfgpu { struct Buffer; }
 struct dfgpu_ctx {
@@ -91,7 +91,8 @@ struct dfgpu_ctx {
   int64_t sort_packed_min_rows = 1 << 20;                      // smallest input the packed-key sort takes (below: byte planes of the encoded keys)
   int64_t sort_topk_words_min_rows = 1 << 23;                  // SortExec with fetch <= n / 16: from this many rows on (keys packing into a word with the row number) the radix select runs on the packed words; below, on byte planes
   int64_t sort_onesweep_min_rows = 1 << 20;
-  int sort_onesweep_rows = 8;                                  // word-mode sorts of 2^20 .. 2^30 rows: one launch per pass (look-back over published tile counts, sort.hip); rows per lane of a tile (8 or 16), 0 = the three-launch passes
+  bool sort_onesweep_fused_finish = true;                      // the last one-sweep pass writes row numbers and rebuilt key columns instead of the words (no k_pk_finish pass)
+  int sort_onesweep_rows = 16;                                  // word-mode sorts of 2^20 .. 2^30 rows: one launch per pass (look-back over published tile counts, sort.hip); rows per lane of a tile (8 or 16), 0 = the three-launch passes
   bool sort_fused_small_passes = true;                         // inputs below 2^20 rows: the per-pass scan is folded into the scatter (two launches per varying key byte instead of three)
   bool sort_estimate_ranges = true;                            // packed-key sort of >= 2^22 rows: value ranges from a sample, checked while encoding
   int64_t spm_merge_rows = (int64_t)1 << 25;                   // SortPreservingMergeExec: rows loaded over all inputs per merge step

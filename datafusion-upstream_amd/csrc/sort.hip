@@ -408,6 +408,33 @@ __global__ void __launch_bounds__(BLOCK) k_pk_encode(PkCols pc, int64_t n, uint6
   if (outside && out) atomicOr(outside, 1u);
   if (ib) keys[i] = (key << ib) | (uint64_t)i; else { keys[i] = key; if (idx) idx[i] = (uint32_t)i; }
 }
+// word mode, after the last pass: row numbers out of the low bits; every key column that asked for it (sorted_dst) is rebuilt from its bits of the sorted word --
+// offset -> order pattern (minimum + distance, 128-bit) -> value -- with sequential reads and writes instead of a gather through the permutation
+__device__ inline void pk_finish_row(const PkCols& pc, uint64_t w, int64_t i, int ib, uint32_t* __restrict__ idx) {
+  idx[i] = (uint32_t)(w & ((1ull << ib) - 1ull)); const uint64_t key = w >> ib;
+  for (int c = 0; c < MAX_KEYS; c++) {
+    if (c >= pc.n) break;
+    const PkCol& k = pc.c[c]; if (!k.sorted_dst) continue;
+    const uint64_t off = (key >> k.shift) & (k.bits >= 64 ? ~0ull : (1ull << k.bits) - 1ull);
+    uint64_t d = off - 1; if (k.desc) d = k.span - 1 - d;
+    const uint64_t lo = k.lo_bits + d, hi = k.hi_bits + (lo < k.lo_bits ? 1ull : 0ull);
+    switch (k.type) {
+      case DFGPU_INT8: ((int8_t*)k.sorted_dst)[i] = (int8_t)(int64_t)(lo ^ 0x8000000000000000ull); break;
+      case DFGPU_INT16: ((int16_t*)k.sorted_dst)[i] = (int16_t)(int64_t)(lo ^ 0x8000000000000000ull); break;
+      case DFGPU_INT32: case DFGPU_DATE32: ((int32_t*)k.sorted_dst)[i] = (int32_t)(int64_t)(lo ^ 0x8000000000000000ull); break;
+      case DFGPU_INT64: ((uint64_t*)k.sorted_dst)[i] = lo ^ 0x8000000000000000ull; break;
+      case DFGPU_UINT8: ((uint8_t*)k.sorted_dst)[i] = (uint8_t)lo; break; case DFGPU_UINT16: ((uint16_t*)k.sorted_dst)[i] = (uint16_t)lo; break;
+      case DFGPU_UINT32: ((uint32_t*)k.sorted_dst)[i] = (uint32_t)lo; break; case DFGPU_UINT64: ((uint64_t*)k.sorted_dst)[i] = lo; break;
+      case DFGPU_FLOAT32: { uint32_t b = (uint32_t)lo; b ^= (b >> 31) ? 0x80000000u : 0xFFFFFFFFu; ((uint32_t*)k.sorted_dst)[i] = b; break; }
+      case DFGPU_FLOAT64: { uint64_t b = lo; b ^= (b >> 63) ? 0x8000000000000000ull : ~0ull; ((uint64_t*)k.sorted_dst)[i] = b; break; }
+      default: { uint64_t* o = (uint64_t*)k.sorted_dst + 2 * i; o[0] = lo; o[1] = hi ^ 0x8000000000000000ull; break; }      // DECIMAL128
+    }
+  }
+}
+__global__ void __launch_bounds__(BLOCK) k_pk_finish(PkCols pc, const uint64_t* __restrict__ words, int64_t m, int ib, uint32_t* __restrict__ idx) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i >= m) return;
+  pk_finish_row(pc, words[i], i, ib, idx);
+}
 // ---- one-sweep LSD passes over the words of word mode
 // The three launches of a pass (per-tile histogram, scan of the [digit][tile] matrix, scatter) read the words twice.  The DEVICE-WIDE digit histogram of every pass does not
 // depend on the order of the words, so all of them are counted while the words are encoded (k_pk_encode_hist: one LDS table per pass, merged with one global atomic per
@@ -457,9 +484,10 @@ __global__ void __launch_bounds__(256) k_os_bases(const uint32_t* hists, uint32_
   uint32_t run = inc - v; for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wsum[w];
   gbase[blockIdx.x * 256 + threadIdx.x] = run;
 }
-template <int R>          // rows per lane: a tile is R x 512 rows
+struct OsFinish { PkCols pc; int32_t ib; uint32_t* idx; int64_t m; };       // the last pass of a sort: instead of the word, its slot receives the row number and the key columns rebuilt from the word (k_pk_finish's work without writing and reading the words once more)
+template <int R, bool FINISH>          // R rows per lane: a tile is R x 512 rows
 __global__ void __launch_bounds__(OS_NT) k_os_pass(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int64_t n, int shift, uint32_t mask, const uint32_t* __restrict__ gbase,
-                                                   uint32_t* status /*[ntiles][256]*/, uint32_t* ticket) {
+                                                   uint32_t* status /*[ntiles][256]*/, uint32_t* ticket, OsFinish fin, uint32_t* flags) {
   __shared__ uint16_t wcnt[R * OS_NW * 256];          // rows of digit d in (slab q, wave w), then their exclusive prefix in (slab, wave) order
   __shared__ uint32_t tbase[256]; __shared__ uint32_t tile_sh;
   if (threadIdx.x == 0) tile_sh = atomicAdd(ticket, 1u);
@@ -487,7 +515,7 @@ __global__ void __launch_bounds__(OS_NT) k_os_pass(const uint64_t* __restrict__ 
     if (t == 0) __hip_atomic_store(mine, run | OS_PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else {
       __hip_atomic_store(mine, run | OS_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int64_t tt = t - 1; bool done = false;
+      int64_t tt = t - 1; bool done = false; uint32_t idle = 0;
       while (!done) {
         uint32_t sv[OS_LOOK];
 #pragma unroll
@@ -498,6 +526,9 @@ __global__ void __launch_bounds__(OS_NT) k_os_pass(const uint64_t* __restrict__ 
           if ((sv[k] >> 30) != 0) { excl += sv[k] & OS_VAL; used = k + 1; done = (sv[k] >> 30) == 2u; }          // a word not yet published: poll again from that tile on
         }
         tt -= used;
+        // Every tile in front holds an earlier ticket, so its workgroup is running and publishes without waiting for anyone: the wait ends.  Should that ever fail
+        // (2^21 polls without progress: seconds), the pass gives up with a flag the host turns into an error instead of keeping the device busy for good
+        if (used == 0) { __builtin_amdgcn_s_sleep(2); if (++idle > (1u << 21)) { atomicOr(flags, DFGPU_FLAG_STALLED); done = true; } } else idle = 0;
       }
       __hip_atomic_store(mine, (excl + run) | OS_PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -505,7 +536,10 @@ __global__ void __launch_bounds__(OS_NT) k_os_pass(const uint64_t* __restrict__ 
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < R; q++) if (on[q]) out[(int64_t)(tbase[d[q]] + (uint32_t)wcnt[((size_t)q * OS_NW + wave) * 256 + d[q]] + rk[q])] = w[q];
+  for (int q = 0; q < R; q++) if (on[q]) {
+    const int64_t pos = (int64_t)(tbase[d[q]] + (uint32_t)wcnt[((size_t)q * OS_NW + wave) * 256 + d[q]] + rk[q]);
+    if (FINISH) { if (pos < fin.m) pk_finish_row(fin.pc, w[q], pos, fin.ib, fin.idx); } else out[pos] = w[q];
+  }
 }
 // ---- TopK over the words of word mode (SortExec with fetch over a large input whose keys pack; topk/mod.rs keeps a heap of k rows, here:) radix SELECT on the word --
 // every word is distinct (its low bits are the row number), so the k smallest words are exactly the rows a stable sort puts first.  A pass counts one 8-bit digit over the
@@ -580,30 +614,6 @@ __global__ void __launch_bounds__(BLOCK) k_ws_rank_sort_pairs(const uint64_t* __
   }
   if (i < m) { out[below] = w; out_vals[below] = vals[i]; }
 }
-// word mode, after the last pass: row numbers out of the low bits; every key column that asked for it (sorted_dst) is rebuilt from its bits of the sorted word --
-// offset -> order pattern (minimum + distance, 128-bit) -> value -- with sequential reads and writes instead of a gather through the permutation
-__global__ void __launch_bounds__(BLOCK) k_pk_finish(PkCols pc, const uint64_t* __restrict__ words, int64_t m, int ib, uint32_t* __restrict__ idx) {
-  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i >= m) return;
-  const uint64_t w = words[i]; idx[i] = (uint32_t)(w & ((1ull << ib) - 1ull)); const uint64_t key = w >> ib;
-  for (int c = 0; c < MAX_KEYS; c++) {
-    if (c >= pc.n) break;
-    const PkCol& k = pc.c[c]; if (!k.sorted_dst) continue;
-    const uint64_t off = (key >> k.shift) & (k.bits >= 64 ? ~0ull : (1ull << k.bits) - 1ull);
-    uint64_t d = off - 1; if (k.desc) d = k.span - 1 - d;
-    const uint64_t lo = k.lo_bits + d, hi = k.hi_bits + (lo < k.lo_bits ? 1ull : 0ull);
-    switch (k.type) {
-      case DFGPU_INT8: ((int8_t*)k.sorted_dst)[i] = (int8_t)(int64_t)(lo ^ 0x8000000000000000ull); break;
-      case DFGPU_INT16: ((int16_t*)k.sorted_dst)[i] = (int16_t)(int64_t)(lo ^ 0x8000000000000000ull); break;
-      case DFGPU_INT32: case DFGPU_DATE32: ((int32_t*)k.sorted_dst)[i] = (int32_t)(int64_t)(lo ^ 0x8000000000000000ull); break;
-      case DFGPU_INT64: ((uint64_t*)k.sorted_dst)[i] = lo ^ 0x8000000000000000ull; break;
-      case DFGPU_UINT8: ((uint8_t*)k.sorted_dst)[i] = (uint8_t)lo; break; case DFGPU_UINT16: ((uint16_t*)k.sorted_dst)[i] = (uint16_t)lo; break;
-      case DFGPU_UINT32: ((uint32_t*)k.sorted_dst)[i] = (uint32_t)lo; break; case DFGPU_UINT64: ((uint64_t*)k.sorted_dst)[i] = lo; break;
-      case DFGPU_FLOAT32: { uint32_t b = (uint32_t)lo; b ^= (b >> 31) ? 0x80000000u : 0xFFFFFFFFu; ((uint32_t*)k.sorted_dst)[i] = b; break; }
-      case DFGPU_FLOAT64: { uint64_t b = lo; b ^= (b >> 63) ? 0x8000000000000000ull : ~0ull; ((uint64_t*)k.sorted_dst)[i] = b; break; }
-      default: { uint64_t* o = (uint64_t*)k.sorted_dst + 2 * i; o[0] = lo; o[1] = hi ^ 0x8000000000000000ull; break; }      // DECIMAL128
-    }
-  }
-}
 }  // namespace dfgpu
 
 using namespace dfgpu;
@@ -642,7 +652,7 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
       // The value ranges cost a pass over the key columns (0.64 ms for a Decimal128 + Date32 pair over 100 M rows).  A large input takes them from a sample first (every
       // n / 2^19-th row), widened by 1/32 of the span on either side (the extremes of a sample lie inside the extremes of the rows); the encode pass checks every value
       // against them and only a miss costs the exact pass.  The packed keys, and with them the indices, do not depend on which ranges were used as long as they hold every value.
-      const bool estimate = ok && ctx->sort_estimate_ranges && n >= ((int64_t)1 << 22);
+      const bool estimate = ok && ctx->sort_estimate_ranges && n >= ((int64_t)1 << 22) && !topk;      // a TopK asks for the extremes, which a sample misses more often than not (SUM per group over 20 M groups: the sampled maximum plus 1/32 of the span was too low, the sample pass and one encode pass wasted)
       for (int attempt = estimate ? 0 : 1; ok && attempt < 2; attempt++) {
         const bool sampled = attempt == 0;
         const int nblk = (int)std::min<int64_t>(ctx->num_cus * 4, std::max<int64_t>(1, n / (sampled ? std::max<int64_t>(2, n >> 19) : 1) / BLOCK + 1)), nb = 1;
@@ -679,7 +689,7 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
           ArrayHolder idx(new_fixed(ctx, DFGPU_UINT32, (word || topk) && fetch >= 0 && fetch < n ? fetch : n));
           const int npass = (total_bits + 7) / 8, dbits = (total_bits + npass - 1) / npass;          // up to 8-bit digits, evened out over the passes (9-bit digits double the count table of the stable scatter: 4 passes of 9 measured 6.6 ms against 4.5 ms for 5 of 8 on 100 M rows)
           // one-sweep passes: word mode, inputs large enough that a pass is bandwidth and not launches, row counts a 30-bit status value holds
-          const int os_r = ctx->sort_onesweep_rows == 16 ? 16 : 8;
+          const int os_r = ctx->sort_onesweep_rows == 16 && n >= ((int64_t)1 << 21) ? 16 : 8;          // 8192-row tiles from 2 M rows on (256 tiles: one per CU); below, the 4096-row tile fills the chip better
           const bool onesweep = word && !topk && ctx->sort_onesweep_rows > 0 && npass <= 8 && n >= ctx->sort_onesweep_min_rows && n < ((int64_t)1 << 30);
           const int64_t os_tiles = (n + (int64_t)os_r * OS_NT - 1) / ((int64_t)os_r * OS_NT);
           BufferPtr os_buf; OsLayout L{}; uint32_t *os_hist = nullptr, *os_base = nullptr, *os_ticket = nullptr, *os_status = nullptr;
@@ -698,6 +708,7 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
             KERNEL_CHECK(); }
           if (sampled) { const uint64_t miss = read_scratch(ctx, 14); ctx->count_sync("sync:sort_key_outside"); if (miss) continue; }       // some value lies outside the sampled ranges: exact pass
           uint64_t* ka = (uint64_t*)k0->ptr; uint64_t* kb = (uint64_t*)k1->ptr; uint32_t* va = (uint32_t*)idx.get()->values->ptr; uint32_t* vb = word ? nullptr : (uint32_t*)v1->ptr;
+          bool fuse_finish = false; std::vector<ArrayHolder> sk_fused((size_t)k);
           int64_t ns = n;                                // rows the passes sort
           bool sorted_already = false; ArrayHolder rows;
           if (topk) {
@@ -736,12 +747,22 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
           else if (onesweep) {
             KernelTimer kt_(ctx, "sort_pass_onesweep");
             hipLaunchKernelGGL(k_os_bases, dim3(npass), dim3(256), 0, ctx->stream, (const uint32_t*)os_hist, os_base);
+            // the last pass writes the result itself (row numbers + rebuilt key columns) when every key column can be rebuilt or none is asked for
+            fuse_finish = ctx->sort_onesweep_fused_finish;
+            const int64_t m = idx.get()->length;
+            if (fuse_finish && out_sorted) for (int c = 0; c < k; c++) if (!pc.c[c].valid) {
+              sk_fused[(size_t)c].a = new_fixed(ctx, cols[c]->type, m, cols[c]->precision, cols[c]->scale); pc.c[c].sorted_dst = sk_fused[(size_t)c].get()->values->ptr; }
             for (int p = 0; p < npass; p++) {
-              if (os_r == 16) hipLaunchKernelGGL((k_os_pass<16>), dim3((unsigned)os_tiles), dim3(OS_NT), 0, ctx->stream, (const uint64_t*)ka, kb, n, L.shift[p], L.mask[p], (const uint32_t*)(os_base + p * 256), os_status + (size_t)p * os_tiles * 256, os_ticket + p);
-              else hipLaunchKernelGGL((k_os_pass<8>), dim3((unsigned)os_tiles), dim3(OS_NT), 0, ctx->stream, (const uint64_t*)ka, kb, n, L.shift[p], L.mask[p], (const uint32_t*)(os_base + p * 256), os_status + (size_t)p * os_tiles * 256, os_ticket + p);
+              const bool fin = fuse_finish && p == npass - 1;
+              OsFinish of{}; if (fin) { of.pc = pc; of.ib = ib; of.idx = (uint32_t*)idx.get()->values->ptr; of.m = m; }
+              const uint32_t* gb = os_base + p * 256; uint32_t* stp = os_status + (size_t)p * os_tiles * 256;
+#define OS_LAUNCH(R_, F_) hipLaunchKernelGGL((k_os_pass<R_, F_>), dim3((unsigned)os_tiles), dim3(OS_NT), 0, ctx->stream, (const uint64_t*)ka, kb, n, L.shift[p], L.mask[p], gb, stp, os_ticket + p, of, ctx->d_flags)
+              if (os_r == 16) { if (fin) OS_LAUNCH(16, true); else OS_LAUNCH(16, false); } else { if (fin) OS_LAUNCH(8, true); else OS_LAUNCH(8, false); }
+#undef OS_LAUNCH
               std::swap(ka, kb);
             }
             KERNEL_CHECK();
+            { const int saved = ctx->defer_flag_checks; ctx->defer_flag_checks = 1; check_flags(ctx, "sort_onesweep"); ctx->defer_flag_checks = saved; }      // read with the next flag read-back (ctx_synchronize at the latest), no round trip of its own
           }
           // the words a select compacted arrive in no order: their passes also sort the row-number bits (ties = row order); everywhere else the input order breaks ties
           const int sort_bits = topk && word ? total_bits + ib : total_bits, base_shift = word && !topk ? ib : 0;
@@ -758,6 +779,7 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
           }
           if (word) {
             const int64_t m = idx.get()->length;
+            if (fuse_finish) { if (out_sorted) for (int c = 0; c < k; c++) out_sorted[c] = sk_fused[(size_t)c].release(); *out = idx.release(); return; }
             std::vector<ArrayHolder> sk((size_t)k);
             if (out_sorted) for (int c = 0; c < k; c++) if (!pc.c[c].valid) {          // a key column without NULLs comes back in sorted order for the price of its sequential write
               sk[(size_t)c].a = new_fixed(ctx, cols[c]->type, m, cols[c]->precision, cols[c]->scale); pc.c[c].sorted_dst = sk[(size_t)c].get()->values->ptr; }

@@ -292,10 +292,23 @@ def test_one_sweep_passes_equal_the_three_launch_passes(ctx, shape, rows_per_lan
         plain = ctx.sort_to_indices(dcols, desc, nf).to_numpy()
         kp = set(ctx.profile_read())
     finally:
-        ctx.profile_enable(False); ctx.set_option("sort_onesweep_rows", 8)
+        ctx.profile_enable(False); ctx.set_option("sort_onesweep_rows", 16)
     assert "sort_pass_onesweep" in ks and "sort_pass_scatter" not in ks and "sort_pass_scatter" in kp and "sort_pass_onesweep" not in kp
     assert np.array_equal(got, plain)
     assert np.array_equal(got.astype(np.int64), want)
+    # the last pass writing row numbers and rebuilt key columns itself == the separate finishing pass, with and without a fetch
+    for fetch in (None, 700_001):
+        a_idx, a_keys = ctx.sort_to_indices_keys(dcols, desc, nf, fetch=fetch)
+        ctx.set_option("sort_onesweep_fused_finish", 0)
+        try:
+            b_idx, b_keys = ctx.sort_to_indices_keys(dcols, desc, nf, fetch=fetch)
+        finally:
+            ctx.set_option("sort_onesweep_fused_finish", 1)
+        assert np.array_equal(a_idx.to_numpy(), b_idx.to_numpy()) and np.array_equal(a_idx.to_numpy(), got[:fetch] if fetch else got)
+        for x, y in zip(a_keys, b_keys):
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert x.to_arrow().equals(y.to_arrow())
 
 
 @pytest.mark.parametrize("fetch", [1, 10, 5000, 60_000])
