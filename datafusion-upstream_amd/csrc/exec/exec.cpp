@@ -1293,7 +1293,10 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
   std::vector<ExprPtr> null_exprs; std::vector<std::vector<uint8_t>> sets;
   // InputOrderMode (physical-plan/src/ordering.rs:33-44): 0 Linear, 1 PartiallySorted(order_indices: the group keys, in order, that the input is sorted on), 2 Sorted -> GroupOrdering (aggregates/order/mod.rs)
   int order_mode = 0; std::vector<int> order_indices;
-  PlanPtr fresh() const override { auto a = std::make_shared<AggregateExec>(); a->mode = mode; a->gexprs = gexprs; a->gnames = gnames; a->aggs = aggs; a->input = input->fresh(); a->null_exprs = null_exprs; a->sets = sets; a->order_mode = order_mode; a->order_indices = order_indices; return a; }
+  // set while the plan is built (dfgpu_plan_sort): the consumer is a SortExec over all group columns (through operators that keep rows as they are), so the order in
+  // which the groups leave cannot show in the result -- the pre-aggregation skips restoring first-seen order (DFGPU_PREAGG_ANY_ORDER)
+  mutable bool any_group_order = false;
+  PlanPtr fresh() const override { auto a = std::make_shared<AggregateExec>(); a->any_group_order = any_group_order; a->mode = mode; a->gexprs = gexprs; a->gnames = gnames; a->aggs = aggs; a->input = input->fresh(); a->null_exprs = null_exprs; a->sets = sets; a->order_mode = order_mode; a->order_indices = order_indices; return a; }
   std::vector<std::shared_ptr<const Plan>> children() const override { return {input}; }
   const char* name() const override { return "AggregateExec"; }
   bool merging() const { return mode == 1 || mode == 2; }
@@ -1368,14 +1371,14 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
       vp.push_back(vals[i].a); kinds.push_back(aggs[i].kind);
     }
     std::vector<dfgpu_array*> st(aggs.size() * 2 + 2, nullptr); dfgpu_array* pk[4] = { nullptr, nullptr, nullptr, nullptr };
-    dfgpu_status rc = dfgpu_agg_preaggregate(tc.ctx, keyv.data(), nk, kinds.data(), vp.data(), (int32_t)aggs.size(), mask.a, pk, st.data());
+    dfgpu_status rc = dfgpu_agg_preaggregate_flags(tc.ctx, keyv.data(), nk, kinds.data(), vp.data(), (int32_t)aggs.size(), mask.a, any_group_order ? DFGPU_PREAGG_ANY_ORDER : 0, pk, st.data());
     if (rc == DFGPU_NOT_IMPLEMENTED) return false;
     tc.check(rc);
     std::vector<ArrayRef> pkeyv; for (int32_t c = 0; c < nk; c++) pkeyv.push_back(ArrayRef::adopt(pk[c]));
     const ArrayRef& pkeys = pkeyv[0]; std::vector<ArrayRef> states; for (auto* x : st) states.push_back(ArrayRef::adopt(x));
     // A FIRST batch whose partial rows hold every key once (in first-seen order) needs no hash table to number its groups: ids are 0, 1, ..; the keys wait
     // in `pending` and are interned only if another batch follows (merge_partial with pending == nullptr), else they are emitted as they are.
-    int64_t distinct = 0, fs = 1; dfgpu_ctx_get_option(tc.ctx, "agg_preaggregate_distinct", &distinct); dfgpu_ctx_get_option(tc.ctx, "first_seen_group_order", &fs); distinct = distinct && fs;
+    int64_t distinct = 0, fs = 1; dfgpu_ctx_get_option(tc.ctx, "agg_preaggregate_distinct", &distinct); dfgpu_ctx_get_option(tc.ctx, "first_seen_group_order", &fs); distinct = distinct && (fs || any_group_order);
     if (nk == 1 && pending && distinct && dfgpu_groups_len(groups.g) == 0 && !*pending) { *pending = pkeys; merge_partial(tc, {}, states, pkeys.len(), groups, accs); return true; }
     merge_partial(tc, pkeyv, states, 0, groups, accs);
     return true;
@@ -2232,11 +2235,33 @@ dfgpu_status dfgpu_plan_aggregate_grouping_sets(dfgpu_plan* aggregate, const dfg
     for (int s2 = 0; s2 < nsets; s2++) a->sets.emplace_back(groups + (size_t)s2 * (size_t)nkeys, groups + (size_t)(s2 + 1) * (size_t)nkeys);
   });
 }
+// A SortExec whose keys hold every group column of the AggregateExec below it (reached through CoalesceBatchesExec, FilterExec and ProjectionExecs of plain columns, which
+// keep or drop rows and rename columns but never reorder them): group key tuples are distinct, so the sort keys order the rows totally and the order in which the
+// aggregation emits its groups cannot show.  The aggregation is told (any_group_order).
+static void mark_any_group_order(const SortExec& s) {
+  std::set<int> cols; for (auto& e : s.exprs) { const int ci = e->column_index(); if (ci >= 0) cols.insert(ci); }
+  const Plan* q = s.input.get();
+  while (q) {
+    if (auto* a = dynamic_cast<const AggregateExec*>(q)) {
+      if (a->mode == 0 || !a->sets.empty() || a->order_mode != 0 || a->gexprs.empty()) return;          // partial states, grouping sets, ordered streaming: left alone
+      for (size_t g = 0; g < a->gexprs.size(); g++) if (!cols.count((int)g)) return;
+      a->any_group_order = true; return;
+    }
+    if (auto* cb = dynamic_cast<const CoalesceBatchesExec*>(q)) q = cb->input.get();
+    else if (auto* f = dynamic_cast<const FilterExec*>(q)) q = f->input.get();
+    else if (auto* pr = dynamic_cast<const ProjectionExec*>(q)) {
+      if (!pr->only_columns()) return;
+      std::set<int> below; for (int ci : cols) { if (ci >= (int)pr->exprs.size()) return; below.insert(pr->exprs[(size_t)ci]->column_index()); }
+      cols = below; q = pr->input.get();
+    } else return;
+  }
+}
 dfgpu_status dfgpu_plan_sort(const dfgpu_expr* const* exprs, const uint8_t* desc, const uint8_t* nf, int32_t n, int64_t fetch, int32_t preserve, const dfgpu_plan* input, dfgpu_plan** out) {
   return guard([&] {
     if (n < 1) fail(DFGPU_INVALID_ARGUMENT, "Sort requires at least one column");
     auto s = std::make_shared<SortExec>(); s->input = pl(input); s->fetch = fetch; s->preserve = preserve != 0;
     for (int i = 0; i < n; i++) { s->exprs.push_back(ex(exprs[i])); s->desc.push_back(desc ? desc[i] : 0); s->nulls_first.push_back(nf ? nf[i] : 1); }
+    mark_any_group_order(*s);
     *out = new dfgpu_plan{s};
   });
 }

@@ -328,7 +328,7 @@ struct PaEmit { int32_t n; int32_t word[2 + 2 * PA_MAX_AGGS]; void* dst[2 + 2 * 
 template <int RS>
 __global__ void __launch_bounds__(BLOCK) k_pa_emit(PaEmit e, const uint64_t* __restrict__ recs, const uint32_t* __restrict__ perm, int64_t m) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; if (i >= m) return;
-  const uint32_t j = perm[i]; uint64_t v[RS];
+  const uint32_t j = perm ? perm[i] : (uint32_t)i; uint64_t v[RS];
   const ulonglong2* r = (const ulonglong2*)(recs + (size_t)j * RS);
 #pragma unroll
   for (int q = 0; q < RS / 2; q++) { const ulonglong2 t = r[q]; v[2 * q] = t.x; v[2 * q + 1] = t.y; }
@@ -405,7 +405,12 @@ static bool pa_key_type_ok(int32_t t) { return t == DFGPU_INT64 || t == DFGPU_UI
 using namespace dfgpu;
 extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array* const* keys, int32_t nkeys, const int32_t* kinds, const dfgpu_array* const* values, int32_t n_aggs,
                                                const dfgpu_array* opt_mask, dfgpu_array** out_keys, dfgpu_array** out_states) {
+  return dfgpu_agg_preaggregate_flags(ctx, keys, nkeys, kinds, values, n_aggs, opt_mask, 0, out_keys, out_states);
+}
+extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu_array* const* keys, int32_t nkeys, const int32_t* kinds, const dfgpu_array* const* values, int32_t n_aggs,
+                                                     const dfgpu_array* opt_mask, int32_t flags, dfgpu_array** out_keys, dfgpu_array** out_states) {
   return guard(ctx, [&] {
+    const bool first_seen = ctx->first_seen_group_order && !(flags & DFGPU_PREAGG_ANY_ORDER);
     const bool verdict_only = out_keys == nullptr;         // would this batch be taken?  (key column + selection only; see include/dfgpu.h)
     if (!keys || (!verdict_only && n_aggs && (!kinds || !values || !out_states))) fail(DFGPU_INVALID_ARGUMENT, "agg_preaggregate: null argument");
     if (verdict_only) n_aggs = 0;
@@ -625,8 +630,8 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
     pkey.reset(); prow.reset(); pval.clear(); pflag.reset(); flags_in.reset();
     // ---- partial rows in first-seen order of their groups
     BufferPtr perm = alloc_buffer(ctx, (size_t)(m + 1) * 4);
-    { KernelTimer kt_(ctx, "pa_order");
-      if (ctx->first_seen_group_order && m >= 32768 && m <= (4 << 20)) {       // beyond a few million rows the random atomics and rank look-ups lose to the sort (20 M: 1.44 ms against 1.28)
+    if (first_seen) { KernelTimer kt_(ctx, "pa_order");
+      if (first_seen && m >= 32768 && m <= (4 << 20)) {       // beyond a few million rows the random atomics and rank look-ups lose to the sort (20 M: 1.44 ms against 1.28)
         const int64_t nw = (n + 63) / 64;
         BufferPtr bits = alloc_buffer(ctx, (size_t)nw * 8, true), pref = alloc_buffer(ctx, (size_t)(nw + 1) * 4);
         hipLaunchKernelGGL(k_pa_mark, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)ofirst->ptr, m, (unsigned long long*)bits->ptr);
@@ -634,7 +639,7 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
         exclusive_scan_u32_inplace32(ctx, (uint32_t*)pref->ptr, nw, nullptr);
         hipLaunchKernelGGL(k_pa_rank_perm, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)ofirst->ptr, m, (const uint64_t*)bits->ptr, (const uint32_t*)pref->ptr, (uint32_t*)perm->ptr);
         KERNEL_CHECK();
-      } else if (ctx->first_seen_group_order && m > (4 << 20) && ctx->agg_order_inverse_map) {
+      } else if (first_seen && m > (4 << 20) && ctx->agg_order_inverse_map) {
         BufferPtr inv = alloc_buffer(ctx, (size_t)n * 4 + 64);
         HIP_CHECK(hipMemsetAsync(inv->ptr, 0xFF, (size_t)n * 4, ctx->stream));
         hipLaunchKernelGGL(k_pa_inv, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)ofirst->ptr, m, (uint32_t*)inv->ptr);
@@ -644,7 +649,7 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
         exclusive_scan_u32_inplace32(ctx, (uint32_t*)cnts->ptr, nblk, nullptr);
         hipLaunchKernelGGL((k_pa_inv_compact<true>), dim3((unsigned)nblk), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)inv->ptr, n, (uint32_t*)cnts->ptr, (uint32_t*)perm->ptr);
         KERNEL_CHECK();
-      } else if (ctx->first_seen_group_order && m > (4 << 20)) {
+      } else if (first_seen && m > (4 << 20)) {
         int jb = 1; while (((uint64_t)(m - 1) >> jb) != 0) jb++;
         int fb = 1; while (((uint64_t)(n - 1) >> fb) != 0) fb++;
         BufferPtr w0 = alloc_buffer(ctx, (size_t)m * 8), w1 = alloc_buffer(ctx, (size_t)m * 8);
@@ -659,12 +664,12 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array
         }
         hipLaunchKernelGGL(k_pa_perm_of_words, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint64_t*)wa, m, jb, (uint32_t*)perm->ptr);
         KERNEL_CHECK();
-      } else {
+      } else if (first_seen) {
         launch_iota_u32(ctx, (uint32_t*)perm->ptr, m, 0);
-        if (ctx->first_seen_group_order) radix_sort_pairs_u32(ctx, (uint32_t*)ofirst->ptr, (uint32_t*)perm->ptr, m, 32);
+        radix_sort_pairs_u32(ctx, (uint32_t*)ofirst->ptr, (uint32_t*)perm->ptr, m, 32);
       } }
     KernelTimer kt_(ctx, "pa_emit");
-    const uint32_t* pp = (const uint32_t*)perm->ptr; dim3 grid(grid_for(m, BLOCK));
+    const uint32_t* pp = first_seen ? (const uint32_t*)perm->ptr : nullptr; dim3 grid(grid_for(m, BLOCK));          // any order: the records leave as the partitions wrote them
     ArrayHolder ok(new_fixed(ctx, ktype, m));
     PaEmit em{}; auto add = [&](int word, void* dst, int narrow, int dstride = 1, int doff = 0) { if (em.n >= 2 + 2 * PA_MAX_AGGS) fail(DFGPU_NOT_IMPLEMENTED, "agg_preaggregate: more output columns than one emit pass writes"); em.word[em.n] = word; em.dst[em.n] = dst; em.narrow[em.n] = narrow; em.dstride[em.n] = dstride; em.doff[em.n] = doff; em.n++; };
     add(0, ok.get()->values->ptr, (ktype == DFGPU_INT64 || ktype == DFGPU_UINT64) ? 0 : 1);

@@ -391,6 +391,13 @@ DFGPU_API dfgpu_status dfgpu_acc_merge_batch(dfgpu_ctx *ctx, dfgpu_acc *a, const
  * key decides; kinds / values are ignored): the plan layer asks before it evaluates computed aggregate arguments. */
 DFGPU_API dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx *ctx, const dfgpu_array *const *keys, int32_t nkeys, const int32_t *kinds, const dfgpu_array *const *values, int32_t n_aggs,
                                               const dfgpu_array *opt_mask, dfgpu_array **out_keys, dfgpu_array **out_states);
+/* The same with flags.  DFGPU_PREAGG_ANY_ORDER: the caller does not depend on the order of the partial rows (the reference's hash aggregation promises none:
+ * AggregateExec::output_ordering is None for unordered input, aggregates/mod.rs:560-600; its stream happens to emit groups in first-seen order) -- the rows leave in
+ * partition order and the pass that restores first-seen order (a third of the call at 20 M groups) is skipped.  The plan layer sets it for an AggregateExec whose
+ * consumer is a SortExec over all of its group columns, where the order of the input rows cannot show in the output. */
+#define DFGPU_PREAGG_ANY_ORDER 1
+DFGPU_API dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx *ctx, const dfgpu_array *const *keys, int32_t nkeys, const int32_t *kinds, const dfgpu_array *const *values, int32_t n_aggs,
+                                                    const dfgpu_array *opt_mask, int32_t flags, dfgpu_array **out_keys, dfgpu_array **out_states);
 /* ≙ evaluate(EmitTo::All) / state(EmitTo::All) (:106-134).  out_states holds up to 2 arrays. */
 DFGPU_API dfgpu_status dfgpu_acc_evaluate(dfgpu_ctx *ctx, dfgpu_acc *a, dfgpu_array **out);
 DFGPU_API dfgpu_status dfgpu_acc_state(dfgpu_ctx *ctx, dfgpu_acc *a, dfgpu_array **out_states, int32_t *n_states);

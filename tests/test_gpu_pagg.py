@@ -392,3 +392,70 @@ def test_float_min_max_with_nans_and_infinities(ctx):
         assert g.type == w.type and g.is_null().equals(w.is_null())
         a, b = g.fill_null(0).to_numpy(zero_copy_only=False), w.fill_null(0).to_numpy(zero_copy_only=False)
         assert np.array_equal(a, b)                               # MIN / MAX pick one of the inputs (or the starting value): exact
+
+
+# ---------------------------------------------------------------------------------------------- round 4: partial rows in any order under a sort over the group columns
+def test_any_order_flag_returns_the_same_partial_rows(ctx):
+    """DFGPU_PREAGG_ANY_ORDER: the partial rows are the ordered call's rows in another order (partition order), nothing else changes; the ordering pass does not run."""
+    import dfgpu
+    n, card = 600_000, 90_000
+    rng = np.random.default_rng(41)
+    key = ctx.from_arrow(pa.array(rng.integers(0, card, n).astype(np.int64) * 7919 - 3))
+    v = ctx.from_arrow(pa.array(rng.integers(-10**6, 10**6, n).astype(np.int64)))
+    kinds = [KIND["SUM"], KIND["COUNT"], KIND["MIN"]]
+    out = {}
+    for any_order in (False, True):
+        with forced(ctx, force=0) as f:
+            pk, states = dfgpu.agg_preaggregate(ctx, key, kinds, [v, None, v], any_order=any_order)
+            ran = f.kernels()
+        assert ("pa_order" in ran) == (not any_order) and "pa_aggregate" in ran
+        out[any_order] = (pk.to_numpy(), [s[0].to_numpy() for s in states])
+    (k0, s0), (k1, s1) = out[False], out[True]
+    assert len(k0) == len(k1) == len(np.unique(k0)) and not np.array_equal(k0, k1)
+    o0, o1 = np.argsort(k0, kind="stable"), np.argsort(k1, kind="stable")
+    assert np.array_equal(k0[o0], k1[o1])
+    for a, b in zip(s0, s1):
+        assert np.array_equal(a[o0], b[o1])
+
+
+@pytest.mark.parametrize("shape", ["sort_over_all_group_columns", "having_and_projection_between", "sort_misses_a_group_column", "sort_on_an_aggregate_only"])
+def test_sort_over_the_group_columns_lets_the_aggregation_emit_in_any_order(ctx, shape):
+    """dfgpu_plan_sort marks the AggregateExec below it (through FilterExec / CoalesceBatchesExec / column-only ProjectionExec) when the sort keys hold every group column:
+    the sorted result is the same rows in the same order as with the ordinary path, and the ordering pass of the pre-aggregation runs only when the sort could show the
+    order of its input (a group column missing from the keys: ties keep input order, which must then be the first-seen order)."""
+    from dfgpu import capi, physical_plan as ops
+    import pyarrow as pa
+    n = 500_000
+    rng = np.random.default_rng(43)
+    k1 = rng.integers(0, 300, n).astype(np.int64) * 1009; k2 = rng.integers(0, 200, n).astype(np.int32); v = rng.integers(0, 5, n).astype(np.int64)
+    batch = ops.batch_from_arrow(ctx, pa.table({"k1": pa.array(k1), "k2": pa.array(k2), "v": pa.array(v)}))
+    C, F, B, L = ops.Column, ops.Field, ops.BinaryExpr, ops.Literal
+    tc = ops.TaskContext(ctx, batch_size=8192)
+
+    def build():
+        agg = ops.AggregateExec("Single", [(C("k1", 0), "k1"), (C("k2", 1), "k2")], [ops.AggregateFunctionExpr("SUM", C("v", 2), "s", input_field=F("v", capi.INT64)), ops.AggregateFunctionExpr("COUNT", None, "c")],
+                                ops.MemoryExec([[batch]], batch.schema))
+        S = ops.PhysicalSortExpr
+        if shape == "sort_over_all_group_columns":
+            return ops.SortExec([S(C("s", 2), True, True), S(C("k2", 1), False, False), S(C("k1", 0), True, False)], agg), True
+        if shape == "having_and_projection_between":
+            having = ops.CoalesceBatchesExec(ops.FilterExec(B(C("c", 3), ">", L(5, pa.int64())), agg), 8192)
+            proj = ops.ProjectionExec([(C("c", 3), "c"), (C("k2", 1), "b"), (C("k1", 0), "a"), (C("s", 2), "s")], having)
+            return ops.SortExec([S(C("c", 0), True, True), S(C("a", 2), False, False), S(C("b", 1), False, False)], proj, fetch=1000), True
+        if shape == "sort_misses_a_group_column":
+            return ops.SortExec([S(C("c", 3), True, True), S(C("k1", 0), False, False)], agg), False
+        return ops.SortExec([S(C("s", 2), True, True)], agg), False
+
+    res = []
+    for on in (1, 0):
+        with forced(ctx, force=0) as fz:
+            ctx.set_option("agg_partitioned", on)
+            plan, marked = build()
+            cols = [[c.to_arrow() for c in b.materialize().columns] for b in plan.execute(0, tc)]
+            ran = fz.kernels()
+        assert ("pa_aggregate" in ran) == bool(on)
+        if on:
+            assert ("pa_order" in ran) == (not marked), (shape, sorted(ran))
+        res.append([pa.concat_arrays([c[i] for c in cols]) for i in range(len(cols[0]))])
+    for a, b in zip(*res):
+        assert a.equals(b)
