@@ -91,7 +91,6 @@ struct dfgpu_ctx {
   int64_t sort_packed_min_rows = 1 << 20;                      // smallest input the packed-key sort takes (below: byte planes of the encoded keys)
   int64_t sort_topk_words_min_rows = 1 << 23;                  // SortExec with fetch <= n / 16: from this many rows on (keys packing into a word with the row number) the radix select runs on the packed words; below, on byte planes
   int64_t sort_onesweep_min_rows = 1 << 20;
-  bool sort_onesweep_wide_status = false;                      // one wave publishes / walks the tile counts with 16-byte accesses (experiment; see sort.hip)
   bool sort_onesweep_fused_finish = true;                      // the last one-sweep pass writes row numbers and rebuilt key columns instead of the words (no k_pk_finish pass)
   int sort_onesweep_rows = 16;                                  // word-mode sorts of 2^20 .. 2^30 rows: one launch per pass (look-back over published tile counts, sort.hip); rows per lane of a tile (8 or 16), 0 = the three-launch passes
   bool sort_fused_small_passes = true;                         // inputs below 2^20 rows: the per-pass scan is folded into the scatter (two launches per varying key byte instead of three)

@@ -149,6 +149,7 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
   __syncthreads();
   // the next chunk's row (key, row number, value cells) is loaded while the current one goes through the table
   uint64_t kn = 0, vn[PA_MAX_AGGS]; uint32_t rn = 0;
+  uint64_t hk = PA_EMPTY;                  // the wave's hot key (wave-uniform)
   const int na = plan_arg.n_acc;
   const uint8_t* vflag = plan_arg.vflag;
   // a row's cells as the table takes them: the value, or -- for a cell bound to a flag bit -- the operation's identity where the bit is clear (a NULL argument), the bit itself for a COUNT_FLAG cell
@@ -175,14 +176,22 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
     { const uint32_t i2 = i + PA_NT, ic = i2 < q1 ? i2 : q1 - 1; kn = pkey[ic]; rn = prow[ic]; load_cells(ic, vn); }
     // Skewed keys: when at least 16 lanes of a wave carry the key of its first active lane, those lanes are combined in registers (shuffles) and the leader
     // alone touches the table: one LDS atomic per state instead of one per row on a slot every wave of the workgroup is hammering.
+    // The key tried is the wave's hot key `hk` -- the last key that was worth combining -- and only when fewer than 12 lanes carry it the key of the first active lane
+    // (which then becomes `hk` if more lanes carry it): a key holding a fifth to a half of its partition's rows (most partitions of Zipf-distributed keys have one) sits
+    // in the first lane only that often, but once found it is tried every time.
     uint32_t cntv = 1; uint32_t rowv = row; bool mine = on;
     {
       const uint64_t act = ballot64(on);
-      const int lead = act ? __ffsll((long long)act) - 1 : 0;
-      const uint32_t k0lo = (uint32_t)__shfl((int)(uint32_t)k, lead, 64), k0hi = (uint32_t)__shfl((int)(uint32_t)(k >> 32), lead, 64);
-      const bool member = on && (uint32_t)k == k0lo && (uint32_t)(k >> 32) == k0hi;
-      const uint64_t mem = ballot64(member);
-      if (__popcll(mem) >= 16 && !I128) {
+      bool member = on && k == hk; uint64_t mem = ballot64(member);
+      if (__popcll(mem) < 12) {
+        const int l0 = act ? __ffsll((long long)act) - 1 : 0;
+        const uint32_t k0lo = (uint32_t)__shfl((int)(uint32_t)k, l0, 64), k0hi = (uint32_t)__shfl((int)(uint32_t)(k >> 32), l0, 64);
+        const uint64_t k0 = ((uint64_t)k0hi << 32) | k0lo;
+        const bool member0 = on && k == k0; const uint64_t mem0 = ballot64(member0);
+        if (__popcll(mem0) > __popcll(mem)) { member = member0; mem = mem0; hk = k0; }
+      }
+      const int lead = mem ? __ffsll((long long)mem) - 1 : 0;
+      if (__popcll(mem) >= 12 && !I128) {
         uint32_t r = member ? row : 0xFFFFFFFFu;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)r, d, 64); r = o < r ? o : r; }

@@ -441,7 +441,9 @@ __global__ void __launch_bounds__(BLOCK) k_pk_finish(PkCols pc, const uint64_t* 
 // used counter and workgroup), and a pass is ONE launch: a workgroup takes the next tile (a ticket: tiles start in order, so every tile a workgroup waits for is resident),
 // ranks its rows as the LDS-free scatter of radix_partition.h does, publishes the tile's digit counts, and finds the rows of its digit in the tiles before it by walking
 // back over their published words -- (count | AGG) until one carries (inclusive prefix | PREFIX) -- the chained scan with decoupled look-back of Merrill & Garland; thread d
-// walks for digit d, OS_LOOK words in flight per step (a word read at agent scope comes from beyond the XCD's L2: ~1-2 us each).
+// walks for digit d, OS_LOOK words in flight per step (a word read at agent scope comes from beyond the XCD's L2: ~1-2 us each).  A wait that makes no progress for
+// ~2^21 polls raises DFGPU_FLAG_STALLED and ends (the host reports an error) instead of keeping the device busy: a variant that published and walked the rows 16 bytes
+// per lane through one wave (inline global_load/store_dwordx4 sc0 sc1) ended exactly there on its first test and was removed (round 4, call q).
 constexpr int OS_NT = 512, OS_NW = OS_NT / WAVE, OS_LOOK = 8;
 constexpr uint32_t OS_AGG = 1u << 30, OS_PREFIX = 2u << 30, OS_VAL = (1u << 30) - 1u;
 struct OsLayout { int32_t npass; int32_t shift[8]; uint32_t mask[8]; };
@@ -464,11 +466,12 @@ __global__ void __launch_bounds__(BLOCK) k_pk_encode_hist(PkCols pc, int64_t n, 
     }
     const uint64_t word = (key << ib) | (uint64_t)i;
     if (on) keys[i] = word;
-    const uint64_t onm = ballot64(on); const int src = __ffsll((unsigned long long)onm) - 1;
+    const bool full = ballot64(on) == ~0ull;
     for (int p = 0; p < L.npass; p++) {
-      const uint32_t d = (uint32_t)(word >> L.shift[p]) & L.mask[p], d0 = __shfl(d, src, 64);
-      if (ballot64(on && d != d0) == 0) { if (lane == src) atomicAdd(&h[p * 256 + d0], (uint32_t)__popcll(onm)); }       // a constant digit (the top bits of a narrow range) is one add per wave
-      else if (on) atomicAdd(&h[p * 256 + d], 1u);
+      const uint32_t d = (uint32_t)(word >> L.shift[p]) & L.mask[p];
+      if (full) { const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+        if (ballot64(d != d0) == 0) { if (lane == 0) atomicAdd(&h[p * 256 + d0], 64u); continue; } }       // a constant digit (the top bits of a narrow range) is one add per wave
+      if (on) atomicAdd(&h[p * 256 + d], 1u);
     }
   }
   if (outside && out) atomicOr(outside, 1u);
@@ -484,16 +487,8 @@ __global__ void __launch_bounds__(256) k_os_bases(const uint32_t* hists, uint32_
   uint32_t run = inc - v; for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wsum[w];
   gbase[blockIdx.x * 256 + threadIdx.x] = run;
 }
-// 16-byte agent-coherent accesses for the status rows (a workgroup's 256 words as 64 x 16 B: one sc1 store of a dword is one fabric write, 6x the time per byte of a dwordx4;
-// /opt/skills/guides/MI355X_MICROARCH.md, stores of each flavour).  The four loads are in flight together; every 32-bit word carries its own flag, so no ordering between them matters.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ inline void os_store4(uint32_t* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory"); }
-__device__ inline void os_load4x4(const uint32_t* p0, const uint32_t* p1, const uint32_t* p2, const uint32_t* p3, u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
-  asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\tglobal_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
-               : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
-}
 struct OsFinish { PkCols pc; int32_t ib; uint32_t* idx; int64_t m; };       // the last pass of a sort: instead of the word, its slot receives the row number and the key columns rebuilt from the word (k_pk_finish's work without writing and reading the words once more)
-template <int R, bool FINISH, bool WIDE>          // R rows per lane: a tile is R x 512 rows; WIDE: one wave publishes and walks the status rows 16 bytes per lane
+template <int R, bool FINISH>          // R rows per lane: a tile is R x 512 rows
 __global__ void __launch_bounds__(OS_NT) k_os_pass(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int64_t n, int shift, uint32_t mask, const uint32_t* __restrict__ gbase,
                                                    uint32_t* status /*[ntiles][256]*/, uint32_t* ticket, OsFinish fin, uint32_t* flags) {
   __shared__ uint16_t wcnt[R * OS_NW * 256];          // rows of digit d in (slab q, wave w), then their exclusive prefix in (slab, wave) order
@@ -514,50 +509,6 @@ __global__ void __launch_bounds__(OS_NT) k_os_pass(const uint64_t* __restrict__ 
     if (on[q] && rk[q] == 0) wcnt[((size_t)q * OS_NW + wave) * 256 + d[q]] = (uint16_t)__popcll(peers);
   }
   __syncthreads();
-  if (WIDE) {
-    if (threadIdx.x < 256) {
-      uint32_t run = 0;
-#pragma unroll 8
-      for (int x = 0; x < R * OS_NW; x++) { const uint16_t c = wcnt[(size_t)x * 256 + threadIdx.x]; wcnt[(size_t)x * 256 + threadIdx.x] = (uint16_t)run; run += c; }
-      tbase[threadIdx.x] = run;
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {          // lane l: digits 4 l .. 4 l + 3
-      const u32x4 run = ((const u32x4*)tbase)[threadIdx.x];
-      uint32_t* const mine = status + t * 256 + 4 * threadIdx.x;
-      u32x4 excl = { 0u, 0u, 0u, 0u };
-      if (t == 0) os_store4(mine, run | OS_PREFIX);
-      else {
-        os_store4(mine, run | OS_AGG);
-        int64_t tt = t - 1; uint32_t pend = 0xFu, idle = 0;
-        while (pend) {
-          u32x4 v[4];
-          const uint32_t* r0 = status + (tt > 0 ? tt : 0) * 256 + 4 * threadIdx.x; const uint32_t* r1 = status + (tt > 1 ? tt - 1 : 0) * 256 + 4 * threadIdx.x;
-          const uint32_t* r2 = status + (tt > 2 ? tt - 2 : 0) * 256 + 4 * threadIdx.x; const uint32_t* r3 = status + (tt > 3 ? tt - 3 : 0) * 256 + 4 * threadIdx.x;
-          os_load4x4(r0, r1, r2, r3, v[0], v[1], v[2], v[3]);
-          int used = 0;
-#pragma unroll
-          for (int k = 0; k < 4; k++) if (pend && used == k) {
-            u32x4 sv = v[k]; if (tt - k < 0) sv = (u32x4){ OS_PREFIX, OS_PREFIX, OS_PREFIX, OS_PREFIX };          // in front of tile 0: nothing
-            const u32x4 fl = sv >> 30;
-            const bool ready = (!(pend & 1u) || fl.x) && (!(pend & 2u) || fl.y) && (!(pend & 4u) || fl.z) && (!(pend & 8u) || fl.w);      // a row is taken whole: its words are published by one instruction
-            if (ready) {
-              if (pend & 1u) { excl.x += sv.x & OS_VAL; if (fl.x == 2u) pend &= ~1u; }
-              if (pend & 2u) { excl.y += sv.y & OS_VAL; if (fl.y == 2u) pend &= ~2u; }
-              if (pend & 4u) { excl.z += sv.z & OS_VAL; if (fl.z == 2u) pend &= ~4u; }
-              if (pend & 8u) { excl.w += sv.w & OS_VAL; if (fl.w == 2u) pend &= ~8u; }
-              used = k + 1;
-            }
-          }
-          tt -= used;
-          if (used == 0) { __builtin_amdgcn_s_sleep(2); if (++idle > (1u << 21)) { atomicOr(flags, DFGPU_FLAG_STALLED); pend = 0; } } else idle = 0;
-        }
-        os_store4(mine, (excl + run) | OS_PREFIX);
-      }
-      const u32x4 gb = ((const u32x4*)gbase)[threadIdx.x];
-      ((u32x4*)tbase)[threadIdx.x] = gb + excl;
-    }
-  } else
   if (threadIdx.x < 256) {
     uint32_t run = 0;
 #pragma unroll 8
@@ -808,8 +759,7 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
               const bool fin = fuse_finish && p == npass - 1;
               OsFinish of{}; if (fin) { of.pc = pc; of.ib = ib; of.idx = (uint32_t*)idx.get()->values->ptr; of.m = m; }
               const uint32_t* gb = os_base + p * 256; uint32_t* stp = os_status + (size_t)p * os_tiles * 256;
-#define OS_LAUNCH(R_, F_) if (ctx->sort_onesweep_wide_status) hipLaunchKernelGGL((k_os_pass<R_, F_, true>), dim3((unsigned)os_tiles), dim3(OS_NT), 0, ctx->stream, (const uint64_t*)ka, kb, n, L.shift[p], L.mask[p], gb, stp, os_ticket + p, of, ctx->d_flags); \
-              else hipLaunchKernelGGL((k_os_pass<R_, F_, false>), dim3((unsigned)os_tiles), dim3(OS_NT), 0, ctx->stream, (const uint64_t*)ka, kb, n, L.shift[p], L.mask[p], gb, stp, os_ticket + p, of, ctx->d_flags)
+#define OS_LAUNCH(R_, F_) hipLaunchKernelGGL((k_os_pass<R_, F_>), dim3((unsigned)os_tiles), dim3(OS_NT), 0, ctx->stream, (const uint64_t*)ka, kb, n, L.shift[p], L.mask[p], gb, stp, os_ticket + p, of, ctx->d_flags)
               if (os_r == 16) { if (fin) OS_LAUNCH(16, true); else OS_LAUNCH(16, false); } else { if (fin) OS_LAUNCH(8, true); else OS_LAUNCH(8, false); }
 #undef OS_LAUNCH
               std::swap(ka, kb);

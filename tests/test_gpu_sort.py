@@ -258,10 +258,9 @@ def test_small_input_passes_in_one_launch_each_give_the_same_stable_order(ctx, n
     assert np.array_equal(got.astype(np.int64), want)
 
 
-@pytest.mark.parametrize("wide_status", [0, 1])
 @pytest.mark.parametrize("rows_per_lane", [8, 16])
 @pytest.mark.parametrize("shape", ["decimal_desc_date_nullable", "one_narrow_key", "skewed"])
-def test_one_sweep_passes_equal_the_three_launch_passes(ctx, shape, rows_per_lane, wide_status):
+def test_one_sweep_passes_equal_the_three_launch_passes(ctx, shape, rows_per_lane):
     """Word-mode sorts of 2^20 .. 2^30 rows run every LSD pass as one launch (k_os_pass: tiles by ticket, digit counts published per tile, look-back over the tiles in
     front) over histograms counted while the words are encoded.  The indices must be the three-launch passes' and numpy's stable lexsort: a ragged last tile, NULLs in both
     columns, a key of few bits (one short pass), and a skewed key whose top digits are constant over most waves (the one-add-per-wave branch of the histogram)."""
@@ -286,14 +285,14 @@ def test_one_sweep_passes_equal_the_three_launch_passes(ctx, shape, rows_per_lan
     dcols = [ctx.from_arrow(c) for c in cols]
     ctx.profile_select(None); ctx.profile_enable(True); ctx.profile_read()
     try:
-        ctx.set_option("sort_onesweep_rows", rows_per_lane); ctx.set_option("sort_onesweep_wide_status", wide_status)
+        ctx.set_option("sort_onesweep_rows", rows_per_lane)
         got = ctx.sort_to_indices(dcols, desc, nf).to_numpy()
         ks = set(ctx.profile_read())
         ctx.set_option("sort_onesweep_rows", 0)
         plain = ctx.sort_to_indices(dcols, desc, nf).to_numpy()
         kp = set(ctx.profile_read())
     finally:
-        ctx.profile_enable(False); ctx.set_option("sort_onesweep_rows", 16); ctx.set_option("sort_onesweep_wide_status", 0)
+        ctx.profile_enable(False); ctx.set_option("sort_onesweep_rows", 16)
     assert "sort_pass_onesweep" in ks and "sort_pass_scatter" not in ks and "sort_pass_scatter" in kp and "sort_pass_onesweep" not in kp
     assert np.array_equal(got, plain)
     assert np.array_equal(got.astype(np.int64), want)
