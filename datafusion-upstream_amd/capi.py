@@ -86,7 +86,7 @@ PROTOTYPES = {
     "dfgpu_span_elapsed_ns": (C.c_int32, [_P, C.c_int64, C.POINTER(C.c_int64)]),
 
     "dfgpu_agg_preaggregate": (C.c_int32, [_P, C.POINTER(_P), C.c_int32, C.POINTER(C.c_int32), C.POINTER(_P), C.c_int32, _P, C.POINTER(_P), C.POINTER(_P)]),
-    "dfgpu_agg_preaggregate_flags": (C.c_int32, [_P, C.POINTER(_P), C.c_int32, C.POINTER(C.c_int32), C.POINTER(_P), C.c_int32, _P, C.c_int32, C.POINTER(_P), C.POINTER(_P)]),
+    "dfgpu_agg_preaggregate_flags": (C.c_int32, [_P, C.POINTER(_P), C.c_int32, C.POINTER(C.c_int32), C.POINTER(_P), C.POINTER(C.c_int32), C.c_int32, _P, C.c_int32, C.POINTER(_P), C.POINTER(_P)]),
     "dfgpu_ctx_get_option": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     "dfgpu_ctx_stream": (_P, [_P]),
     "dfgpu_version": (C.c_char_p, []),

@@ -1355,7 +1355,7 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
   }
   // dfgpu_agg_preaggregate over one batch, then intern + merge_batch of its partial rows.  false = shape not taken, nothing accumulated.
   template <typename Ensure>
-  bool preaggregate(const TaskContext& tc, Batch& b, const std::vector<bool>& deferred, Ensure&& ensure, const std::vector<const dfgpu_array*>& keyv, const ArrayRef& mask, GroupsRef& groups, std::vector<AccRef>& accs, ArrayRef* pending) const {
+  bool preaggregate(const TaskContext& tc, const ProjectionExec* pj, Batch& raw, Batch& b, const std::vector<bool>& deferred, Ensure&& ensure, const std::vector<const dfgpu_array*>& keyv, const ArrayRef& mask, GroupsRef& groups, std::vector<AccRef>& accs, ArrayRef* pending) const {
     const int32_t nk = (int32_t)keyv.size();
     std::vector<ArrayRef> vals(aggs.size()); std::vector<const dfgpu_array*> vp; std::vector<int32_t> kinds;
     for (auto& a : aggs) if (a.filter) return false;
@@ -1363,15 +1363,42 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
     dfgpu_status v0 = dfgpu_agg_preaggregate(tc.ctx, keyv.data(), nk, nullptr, nullptr, 0, mask.a, nullptr, nullptr);
     if (v0 == DFGPU_NOT_IMPLEMENTED) return false;
     tc.check(v0);
+    // An argument that is CAST(<stored integer column> AS DOUBLE) -- written as such, or a column of the projection below that was left unevaluated -- goes down as the
+    // integer column with the cast named beside it (value_casts): the partition converts it while it moves it, the cast pass does not run.
+    auto cast_of_column = [&](const Expr* e, Batch** src) -> int {          // -> column index in *src, or -1
+      const auto* u = dynamic_cast<const UnaryExpr*>(e);
+      if (!u || u->kind != 4 || u->a0 != DFGPU_FLOAT64) return -1;
+      const int ci = u->e->column_index(); if (ci < 0 || ci >= (int)(*src)->cols.size()) return -1;
+      if (*src == &b && ci < (int)deferred.size() && deferred[(size_t)ci]) return -1;
+      return ci;
+    };
+    std::vector<int32_t> casts(aggs.size(), 0); bool any_cast = false;
     for (size_t i = 0; i < aggs.size(); i++) {
       if (aggs[i].arg) {
-        std::set<int> need; aggs[i].arg->columns(need); for (int ci : need) ensure(ci);
-        vals[i] = into_array(tc, aggs[i].arg->eval(tc, b), b.base_rows);
+        Batch* src = &b; int ci = cast_of_column(aggs[i].arg.get(), &src);
+        if (ci < 0 && pj) {          // Column(j) of the projection whose expression j is the cast, still unevaluated
+          const int j = aggs[i].arg->column_index();
+          if (j >= 0 && j < (int)deferred.size() && deferred[(size_t)j] && j < (int)pj->exprs.size()) { src = &raw; ci = cast_of_column(pj->exprs[(size_t)j].get(), &src); }
+        }
+        if (ci >= 0) {
+          ArrayRef col = src->column(tc, ci); dfgpu_array_desc d; dfgpu_array_describe(col.a, &d);
+          const bool is_int = d.type == DFGPU_INT8 || d.type == DFGPU_INT16 || d.type == DFGPU_INT32 || d.type == DFGPU_INT64 || d.type == DFGPU_UINT8 || d.type == DFGPU_UINT16 || d.type == DFGPU_UINT32 || d.type == DFGPU_UINT64;
+          if (is_int && (aggs[i].kind == DFGPU_AGG_SUM || aggs[i].kind == DFGPU_AGG_AVG || aggs[i].kind == DFGPU_AGG_MIN || aggs[i].kind == DFGPU_AGG_MAX || aggs[i].kind == DFGPU_AGG_COUNT)) { vals[i] = col; casts[i] = DFGPU_FLOAT64; any_cast = true; }
+        }
+        if (!casts[i]) {
+          std::set<int> need; aggs[i].arg->columns(need); for (int ci2 : need) ensure(ci2);
+          vals[i] = into_array(tc, aggs[i].arg->eval(tc, b), b.base_rows);
+        }
       }
       vp.push_back(vals[i].a); kinds.push_back(aggs[i].kind);
     }
     std::vector<dfgpu_array*> st(aggs.size() * 2 + 2, nullptr); dfgpu_array* pk[4] = { nullptr, nullptr, nullptr, nullptr };
-    dfgpu_status rc = dfgpu_agg_preaggregate_flags(tc.ctx, keyv.data(), nk, kinds.data(), vp.data(), (int32_t)aggs.size(), mask.a, any_group_order ? DFGPU_PREAGG_ANY_ORDER : 0, pk, st.data());
+    dfgpu_status rc = dfgpu_agg_preaggregate_flags(tc.ctx, keyv.data(), nk, kinds.data(), vp.data(), any_cast ? casts.data() : nullptr, (int32_t)aggs.size(), mask.a, any_group_order ? DFGPU_PREAGG_ANY_ORDER : 0, pk, st.data());
+    if (rc == DFGPU_NOT_IMPLEMENTED && any_cast) {          // declined with the casts (a shape limit): the arguments as arrays, as before
+      vp.clear();
+      for (size_t i = 0; i < aggs.size(); i++) { if (casts[i]) { std::set<int> need; aggs[i].arg->columns(need); for (int ci2 : need) ensure(ci2); vals[i] = into_array(tc, aggs[i].arg->eval(tc, b), b.base_rows); } vp.push_back(vals[i].a); }
+      rc = dfgpu_agg_preaggregate_flags(tc.ctx, keyv.data(), nk, kinds.data(), vp.data(), nullptr, (int32_t)aggs.size(), mask.a, any_group_order ? DFGPU_PREAGG_ANY_ORDER : 0, pk, st.data());
+    }
     if (rc == DFGPU_NOT_IMPLEMENTED) return false;
     tc.check(rc);
     std::vector<ArrayRef> pkeyv; for (int32_t c = 0; c < nk; c++) pkeyv.push_back(ArrayRef::adopt(pk[c]));
@@ -1513,7 +1540,7 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
         }
         // A large batch of high-cardinality keys is first reduced to one row per group partition by partition out of LDS (the Partial stage
         // of a two-phase plan, applied inside the operator): its partial rows are then interned and MERGED like the Final stage does.
-        if (!specials && !merging() && gp.size() >= 1 && gp.size() <= 4 && b.base_rows >= preagg_min_rows && preaggregate(tc, b, deferred, ensure, gp, mask, groups, accs, S.spill ? nullptr : &pending)) return;
+        if (!specials && !merging() && gp.size() >= 1 && gp.size() <= 4 && b.base_rows >= preagg_min_rows && preaggregate(tc, pj, raw, b, deferred, ensure, gp, mask, groups, accs, S.spill ? nullptr : &pending)) return;
         dfgpu_array* ids = nullptr; tc.check(specials || order_mode == 1 ? dfgpu_groups_intern(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids) : dfgpu_groups_intern_deferred(tc.ctx, groups.g, gp.data(), (int32_t)gp.size(), mask.a, &ids)); gids = ArrayRef::adopt(ids);      // deferred ids: only the accumulators read them
         total = dfgpu_groups_len(groups.g);
         if (order_mode == 1 && !specials) note_sort_prefix(S, gp, gids, mask);

@@ -546,8 +546,9 @@ dfgpu_status dfgpu_cast(dfgpu_ctx* ctx, const dfgpu_array* a, int32_t to, int32_
     if (to == DFGPU_DECIMAL128 && (p < 1 || p > 38 || s < 0 || s > p)) fail(DFGPU_INVALID_ARGUMENT, "cast: bad Decimal128(%d, %d)", p, s);
     ColView v = make_view(a);
     ArrayHolder h(new_fixed(ctx, to, a->length, to == DFGPU_DECIMAL128 ? p : 0, to == DFGPU_DECIMAL128 ? s : 0));
-    if (a->length) hipLaunchKernelGGL(k_cast, dim3(grid_for(a->length, BLOCK)), dim3(BLOCK), 0, ctx->stream, v, a->length, to, p, s, h.get()->values->ptr, ctx->d_flags, row_selection_words(ctx, a->length));
-    KERNEL_CHECK();
+    { KernelTimer kt_(ctx, "k_cast");
+      if (a->length) hipLaunchKernelGGL(k_cast, dim3(grid_for(a->length, BLOCK)), dim3(BLOCK), 0, ctx->stream, v, a->length, to, p, s, h.get()->values->ptr, ctx->d_flags, row_selection_words(ctx, a->length));
+      KERNEL_CHECK(); }
     if (a->type != DFGPU_DICTIONARY) { h.get()->validity = a->validity; h.get()->null_count = a->null_count; }
     else if (may_have_nulls(a)) { h.get()->validity = alloc_buffer(ctx, bitmap_bytes(a->length), true); hipLaunchKernelGGL(k_is_null, dim3(grid_for(a->length, BLOCK)), dim3(BLOCK), 0, ctx->stream, v, a->length, 1, (uint64_t*)h.get()->validity->ptr); h.get()->null_count = -1; }
     check_flags(ctx, "cast");

@@ -43,10 +43,14 @@ __device__ inline void pa_apply(int op, unsigned long long* cell, uint64_t v) {
   switch (op) {
     case PA_SUM_I64: case PA_COUNT_FLAG: atomicAdd(cell, (unsigned long long)v); break;                                   // wrapping, sum.rs:137
     case PA_SUM_F64: atomicAdd((double*)cell, __longlong_as_double((long long)v)); break;
-    case PA_MIN_I64: atomicMin((long long*)cell, (long long)v); break; case PA_MAX_I64: atomicMax((long long*)cell, (long long)v); break;
-    case PA_MIN_U64: atomicMin(cell, (unsigned long long)v); break; case PA_MAX_U64: atomicMax(cell, (unsigned long long)v); break;
-    case PA_MIN_F64: { double d = __longlong_as_double((long long)v); if (d == d) atomicMin((double*)cell, d); break; }     // `if *cur > new` (min_max.rs:124-139) is false for a NaN: NaN inputs never enter, whatever the order
-    case PA_MAX_F64: { double d = __longlong_as_double((long long)v); if (d == d) atomicMax((double*)cell, d); break; }
+    // MIN / MAX: a cell only ever moves one way, so a value that does not improve on a plain (possibly stale) read of it cannot improve on the cell: no atomic.  After a
+    // group's first few rows that is nearly every row (the expected number of new maxima among n values is ln n), and on a hot slot it takes the read-modify-write queue away
+    case PA_MIN_I64: if ((long long)v < *(volatile long long*)cell) atomicMin((long long*)cell, (long long)v); break;
+    case PA_MAX_I64: if ((long long)v > *(volatile long long*)cell) atomicMax((long long*)cell, (long long)v); break;
+    case PA_MIN_U64: if (v < *(volatile unsigned long long*)cell) atomicMin(cell, (unsigned long long)v); break;
+    case PA_MAX_U64: if (v > *(volatile unsigned long long*)cell) atomicMax(cell, (unsigned long long)v); break;
+    case PA_MIN_F64: { double d = __longlong_as_double((long long)v); if (d == d && d < *(volatile double*)cell) atomicMin((double*)cell, d); break; }     // `if *cur > new` (min_max.rs:124-139) is false for a NaN: NaN inputs never enter, whatever the order
+    case PA_MAX_F64: { double d = __longlong_as_double((long long)v); if (d == d && d > *(volatile double*)cell) atomicMax((double*)cell, d); break; }
     default: break;
   }
 }
@@ -149,7 +153,6 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
   __syncthreads();
   // the next chunk's row (key, row number, value cells) is loaded while the current one goes through the table
   uint64_t kn = 0, vn[PA_MAX_AGGS]; uint32_t rn = 0;
-  uint64_t hk = PA_EMPTY;                  // the wave's hot key (wave-uniform)
   const int na = plan_arg.n_acc;
   const uint8_t* vflag = plan_arg.vflag;
   // a row's cells as the table takes them: the value, or -- for a cell bound to a flag bit -- the operation's identity where the bit is clear (a NULL argument), the bit itself for a COUNT_FLAG cell
@@ -175,23 +178,17 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
     for (int a = 0; a < PA_MAX_AGGS; a++) v[a] = vn[a];
     { const uint32_t i2 = i + PA_NT, ic = i2 < q1 ? i2 : q1 - 1; kn = pkey[ic]; rn = prow[ic]; load_cells(ic, vn); }
     // Skewed keys: when at least 16 lanes of a wave carry the key of its first active lane, those lanes are combined in registers (shuffles) and the leader
-    // alone touches the table: one LDS atomic per state instead of one per row on a slot every wave of the workgroup is hammering.
-    // The key tried is the wave's hot key `hk` -- the last key that was worth combining -- and only when fewer than 12 lanes carry it the key of the first active lane
-    // (which then becomes `hk` if more lanes carry it): a key holding a fifth to a half of its partition's rows (most partitions of Zipf-distributed keys have one) sits
-    // in the first lane only that often, but once found it is tried every time.
+    // alone touches the table: one LDS atomic per state instead of one per row on a slot every wave of the workgroup is hammering.  (Trying the last combined key
+    // first -- a key with a fifth to a half of its partition's rows sits in the first lane only that often -- was measured on the Zipf ClickBench shape and changed
+    // nothing: 2.34 -> 2.49 ms, round 4 call r; the partitions there hold several warm keys each, not one.)
     uint32_t cntv = 1; uint32_t rowv = row; bool mine = on;
     {
       const uint64_t act = ballot64(on);
-      bool member = on && k == hk; uint64_t mem = ballot64(member);
-      if (__popcll(mem) < 12) {
-        const int l0 = act ? __ffsll((long long)act) - 1 : 0;
-        const uint32_t k0lo = (uint32_t)__shfl((int)(uint32_t)k, l0, 64), k0hi = (uint32_t)__shfl((int)(uint32_t)(k >> 32), l0, 64);
-        const uint64_t k0 = ((uint64_t)k0hi << 32) | k0lo;
-        const bool member0 = on && k == k0; const uint64_t mem0 = ballot64(member0);
-        if (__popcll(mem0) > __popcll(mem)) { member = member0; mem = mem0; hk = k0; }
-      }
-      const int lead = mem ? __ffsll((long long)mem) - 1 : 0;
-      if (__popcll(mem) >= 12 && !I128) {
+      const int lead = act ? __ffsll((long long)act) - 1 : 0;
+      const uint32_t k0lo = (uint32_t)__shfl((int)(uint32_t)k, lead, 64), k0hi = (uint32_t)__shfl((int)(uint32_t)(k >> 32), lead, 64);
+      const bool member = on && (uint32_t)k == k0lo && (uint32_t)(k >> 32) == k0hi;
+      const uint64_t mem = ballot64(member);
+      if (__popcll(mem) >= 16 && !I128) {
         uint32_t r = member ? row : 0xFFFFFFFFu;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)r, d, 64); r = o < r ? o : r; }
@@ -414,9 +411,9 @@ static bool pa_key_type_ok(int32_t t) { return t == DFGPU_INT64 || t == DFGPU_UI
 using namespace dfgpu;
 extern "C" dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx* ctx, const dfgpu_array* const* keys, int32_t nkeys, const int32_t* kinds, const dfgpu_array* const* values, int32_t n_aggs,
                                                const dfgpu_array* opt_mask, dfgpu_array** out_keys, dfgpu_array** out_states) {
-  return dfgpu_agg_preaggregate_flags(ctx, keys, nkeys, kinds, values, n_aggs, opt_mask, 0, out_keys, out_states);
+  return dfgpu_agg_preaggregate_flags(ctx, keys, nkeys, kinds, values, nullptr, n_aggs, opt_mask, 0, out_keys, out_states);
 }
-extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu_array* const* keys, int32_t nkeys, const int32_t* kinds, const dfgpu_array* const* values, int32_t n_aggs,
+extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu_array* const* keys, int32_t nkeys, const int32_t* kinds, const dfgpu_array* const* values, const int32_t* value_casts, int32_t n_aggs,
                                                      const dfgpu_array* opt_mask, int32_t flags, dfgpu_array** out_keys, dfgpu_array** out_states) {
   return guard(ctx, [&] {
     const bool first_seen = ctx->first_seen_group_order && !(flags & DFGPU_PREAGG_ANY_ORDER);
@@ -441,7 +438,11 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu
     // accumulator plan: one 8-byte LDS cell per SUM / MIN / MAX; COUNT and AVG counts come from the row count (value columns carry no NULLs)
     // A nullable argument (accumulate.rs:126-233: NULL values take no part; a group that saw none has a NULL state): its validity travels as one bit of a per-row flag byte,
     // its cells skip the NULL rows, and one COUNT_FLAG cell per nullable column counts the values seen -- COUNT(x), AVG's count and the validity of SUM / MIN / MAX states.
-    PaPlan plan{}; int cell_of[16], nvalid_of[16]; const dfgpu_array* cell_src[PA_MAX_AGGS]; int cell_word[PA_MAX_AGGS];      // cell c reads word cell_word[c] of its source's rows
+    PaPlan plan{}; int cell_of[16], nvalid_of[16]; const dfgpu_array* cell_src[PA_MAX_AGGS]; int cell_word[PA_MAX_AGGS]; bool cell_cast[PA_MAX_AGGS] = {};      // cell c reads word cell_word[c] of its source's rows (cell_cast: of their doubles)
+    // value_casts[i] == DFGPU_FLOAT64 over an integer column: the argument is CAST(column AS DOUBLE) (what AVG / SUM over an integer column are planned as); the column is
+    // converted while the partition moves it -- the cast's own pass (400 MB read, 800 MB written per 100 M Int32 rows: 0.40 ms) does not run
+    auto cast_f64 = [&](int i) { return value_casts && value_casts[i] == DFGPU_FLOAT64 && values[i] && plain_int(values[i]->type) && values[i]->type != DFGPU_DATE32; };
+    for (int i = 0; i < n_aggs; i++) if (value_casts && value_casts[i] != 0 && !cast_f64(i)) skip("an argument cast other than integer -> Float64");
     for (int c = 0; c < PA_MAX_AGGS; c++) { plan.flag_bit[c] = -1; cell_src[c] = nullptr; }
     const dfgpu_array* flag_src[8]; int n_flags = 0;
     auto flag_of = [&](const dfgpu_array* v) { for (int b = 0; b < n_flags; b++) if (flag_src[b] == v) return b; if (n_flags == 8) skip("at most 8 nullable value columns"); flag_src[n_flags] = v; return n_flags++; };
@@ -458,7 +459,8 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu
       if (kinds[i] == DFGPU_AGG_COUNT) continue;
       if (!v) skip("aggregate without an argument");
       int op = PA_NONE;
-      const bool i64 = v->type == DFGPU_INT64, u64 = v->type == DFGPU_UINT64, f64 = v->type == DFGPU_FLOAT64, d128 = v->type == DFGPU_DECIMAL128;
+      const bool asf = cast_f64(i);
+      const bool i64 = !asf && v->type == DFGPU_INT64, u64 = !asf && v->type == DFGPU_UINT64, f64 = asf || v->type == DFGPU_FLOAT64, d128 = v->type == DFGPU_DECIMAL128;
       if (!i64 && !u64 && !f64 && !d128) skip("Int64 / UInt64 / Float64 / Decimal128 aggregate arguments");
       switch (kinds[i]) {
         case DFGPU_AGG_SUM: op = d128 ? PA_SUM_I128_LO : f64 ? PA_SUM_F64 : PA_SUM_I64; break;
@@ -467,11 +469,11 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu
         case DFGPU_AGG_MAX: if (d128) skip("MAX over Decimal128"); op = f64 ? PA_MAX_F64 : i64 ? PA_MAX_I64 : PA_MAX_U64; break;
         default: skip("SUM / AVG / COUNT / MIN / MAX");
       }
-      int c = -1; for (int j = 0; j < plan.n_acc; j++) if (plan.op[j] == op && cell_src[j] == v) c = j;          // SUM(x) and AVG(x) share a cell
+      int c = -1; for (int j = 0; j < plan.n_acc; j++) if (plan.op[j] == op && cell_src[j] == v && cell_cast[j] == asf) c = j;          // SUM(x) and AVG(x) share a cell
       if (c < 0) {
         const int need = d128 ? 2 : 1;
         if (plan.n_acc + need > PA_MAX_AGGS) skip("at most 6 accumulator cells (a Decimal128 sum takes two)");
-        c = plan.n_acc; plan.n_acc += need; plan.op[c] = op; cell_src[c] = v; cell_word[c] = 0;
+        c = plan.n_acc; plan.n_acc += need; plan.op[c] = op; cell_src[c] = v; cell_word[c] = 0; cell_cast[c] = asf;
         const int fbit = v->validity ? flag_of(v) : -1; plan.flag_bit[c] = fbit;
         if (d128) { const bool fits64 = v->precision > 0 && v->precision <= 18;      // |unscaled value| < 10^18 < 2^63: the high word carries no information
           plan.op[c + 1] = fits64 ? PA_SUM_I128_SX : PA_SUM_I128_HI; cell_src[c + 1] = v; cell_word[c + 1] = fits64 ? 0 : 1; plan.flag_bit[c + 1] = fbit; plan.has_i128 = 1; }
@@ -479,8 +481,8 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu
       cell_of[i] = c;
     }
     // the distinct value columns the partition moves (a Decimal128 column once, 16 bytes wide)
-    const dfgpu_array* srcs[PA_MAX_AGGS]; int n_src = 0, src_of[PA_MAX_AGGS];
-    for (int c = 0; c < plan.n_acc; c++) { src_of[c] = -1; if (!cell_src[c]) continue; int j = -1; for (int q = 0; q < n_src; q++) if (srcs[q] == cell_src[c]) j = q; if (j < 0) { j = n_src; srcs[n_src++] = cell_src[c]; } src_of[c] = j; }
+    const dfgpu_array* srcs[PA_MAX_AGGS]; bool src_cast[PA_MAX_AGGS] = {}; int n_src = 0, src_of[PA_MAX_AGGS];
+    for (int c = 0; c < plan.n_acc; c++) { src_of[c] = -1; if (!cell_src[c]) continue; int j = -1; for (int q = 0; q < n_src; q++) if (srcs[q] == cell_src[c] && src_cast[q] == cell_cast[c]) j = q; if (j < 0) { j = n_src; src_cast[n_src] = cell_cast[c]; srcs[n_src++] = cell_src[c]; } src_of[c] = j; }
     const uint64_t* mk = nullptr; BufferPtr mask = effective_mask(ctx, opt_mask, n); if (mask) mk = (const uint64_t*)mask->ptr;
     // ---- sample: clustered? how many groups?  (a verdict-only call leaves its sample for the call that follows on the same column)
     const int64_t s = n < (1 << 19) ? n : (1 << 19), stride = n / s; const uint64_t cap = 1ull << 21;
@@ -580,7 +582,7 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu
     cols.c[0] = RpCol{ kptr, pkey->ptr, 8, RP_HASHKEY, ktype };
     auto lo16 = [&](int j) { return srcs[j]->type == DFGPU_DECIMAL128 && srcs[j]->precision > 0 && srcs[j]->precision <= 18; };
     auto src_width = [&](int j) { return srcs[j]->type == DFGPU_DECIMAL128 && !lo16(j) ? 16 : 8; };
-    for (int j = 0; j < n_src; j++) { pval[(size_t)j] = alloc_buffer(ctx, (size_t)n * (size_t)src_width(j)); cols.c[1 + j] = RpCol{ srcs[j]->values->ptr, pval[(size_t)j]->ptr, 8 * (src_width(j) / 8), lo16(j) ? RP_LO16 : RP_RAW, 0 }; }
+    for (int j = 0; j < n_src; j++) { pval[(size_t)j] = alloc_buffer(ctx, (size_t)n * (size_t)src_width(j)); cols.c[1 + j] = src_cast[j] ? RpCol{ srcs[j]->values->ptr, pval[(size_t)j]->ptr, 8, RP_CASTF64, srcs[j]->type } : RpCol{ srcs[j]->values->ptr, pval[(size_t)j]->ptr, 8 * (src_width(j) / 8), lo16(j) ? RP_LO16 : RP_RAW, 0 }; }
     auto bind_cells = [&]() { plan.vflag = n_flags ? (const uint8_t*)pflag->ptr : nullptr;
       for (int c = 0; c < plan.n_acc; c++) { const int j = src_of[c]; if (j < 0) { plan.vstride[c] = 1; plan.val[c] = nullptr; continue; } plan.vstride[c] = src_width(j) / 8; plan.val[c] = (const uint64_t*)pval[(size_t)j]->ptr + cell_word[c]; } };
     bind_cells();
@@ -696,7 +698,7 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu
       if (kinds[i] == DFGPU_AGG_COUNT) st[(size_t)2 * i].a = counts_as(DFGPU_INT64);                                                       // count.rs: Int64 state
       else if (kinds[i] == DFGPU_AGG_AVG) { st[(size_t)2 * i].a = counts_as(DFGPU_UINT64); st[(size_t)2 * i + 1].a = d128 ? dec_as() : cell_as(DFGPU_FLOAT64); }   // average.rs:392-430: (counts, sums)
       else if (d128) st[(size_t)2 * i].a = dec_as();
-      else st[(size_t)2 * i].a = cell_as(values[i]->type);          // SUM / MIN / MAX of an 8-byte type: state type == input type (sum.rs:75-86, min_max.rs:102-139)
+      else st[(size_t)2 * i].a = cell_as(cast_f64(i) ? DFGPU_FLOAT64 : values[i]->type);          // SUM / MIN / MAX of an 8-byte type: state type == input type (sum.rs:75-86, min_max.rs:102-139)
       if (nvalid_of[i] >= 0 && kinds[i] != DFGPU_AGG_COUNT) need_valid.emplace_back(st[(size_t)2 * i + (kinds[i] == DFGPU_AGG_AVG ? 1 : 0)].get(), nvalid_of[i]);
       if (em.n > 2 + 2 * PA_MAX_AGGS) fail(DFGPU_NOT_IMPLEMENTED, "agg_preaggregate: more output columns than one emit pass writes");
     }

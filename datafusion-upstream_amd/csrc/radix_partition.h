@@ -59,7 +59,7 @@ struct RpHashDigit {      // partition = one digit of a 64-bit word (the LSD pas
 };
 
 // columns moved by the scatter
-enum { RP_RAW = 0, RP_KEY64 = 2, RP_HASHKEY = 3, RP_LO16 = 4 };      // LO16: src holds 16-byte elements (Decimal128), the low 8 bytes move (width 8 on the destination side)
+enum { RP_RAW = 0, RP_KEY64 = 2, RP_HASHKEY = 3, RP_LO16 = 4, RP_CASTF64 = 5 };      // LO16: src holds 16-byte elements (Decimal128), the low 8 bytes move (width 8 on the destination side); CASTF64: src integer column of `type`, dst the double of every value (a CAST(.. AS DOUBLE) argument converted while it moves)
 struct RpCol { const void* src; void* dst; int32_t width; int32_t kind; int32_t type; };   // RAW: width bytes per row (1, 2, 4, 8, 16); KEY64: src integer column of `type`, dst u64; HASHKEY: dst u64 = the 64-bit key the hasher produced for the row
 // rowid_dst (optional): the original row number of every moved row (rides along with the first column's round).
 // pack12_dst (optional; column 0 must be 8 bytes wide): column 0 and the row number leave as ONE array of 12-byte records
@@ -173,6 +173,16 @@ __global__ void __launch_bounds__(NT) k_rp_scatter(H hs, int64_t n, uint32_t P, 
 #define RP_GATHER(EXPR) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) { const int64_t i = i0 + (int64_t)q * QS; stage[spos[q]] = (uint64_t)(EXPR); } }
       if (col.kind == RP_HASHKEY) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) stage[spos[q]] = hk[q]; }
       else if (LO16 && col.kind == RP_LO16) RP_GATHER(((const uint64_t*)col.src)[2 * i])
+      else if (LO16 && col.kind == RP_CASTF64) switch (col.type) {            // arrow-cast: integer -> Float64 is `as f64`
+        case DFGPU_INT8: RP_GATHER(__double_as_longlong((double)((const int8_t*)col.src)[i])) break;
+        case DFGPU_INT16: RP_GATHER(__double_as_longlong((double)((const int16_t*)col.src)[i])) break;
+        case DFGPU_INT32: RP_GATHER(__double_as_longlong((double)((const int32_t*)col.src)[i])) break;
+        case DFGPU_UINT8: RP_GATHER(__double_as_longlong((double)((const uint8_t*)col.src)[i])) break;
+        case DFGPU_UINT16: RP_GATHER(__double_as_longlong((double)((const uint16_t*)col.src)[i])) break;
+        case DFGPU_UINT32: RP_GATHER(__double_as_longlong((double)((const uint32_t*)col.src)[i])) break;
+        case DFGPU_UINT64: RP_GATHER(__double_as_longlong((double)((const uint64_t*)col.src)[i])) break;
+        default: RP_GATHER(__double_as_longlong((double)((const int64_t*)col.src)[i])) break;
+      }
       else if (col.kind == RP_KEY64) switch (col.type) {            // widened exactly as key_at() does
         case DFGPU_INT8: RP_GATHER((int64_t)((const int8_t*)col.src)[i]) break;
         case DFGPU_INT16: RP_GATHER((int64_t)((const int16_t*)col.src)[i]) break;
@@ -296,7 +306,7 @@ static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const 
   // the LDS-free scatter: always for <= 16 partitions; up to 256 when a row is one column (a sort pass: 3.0 against 3.2 ms per 100 M rows) or holds a 16-byte column (the staged
   // scatter moves those as two halves: 600 M rows x 44 B into 64 / 128 / 256: 16.9 / 18.0 / 22.5 ms against 22.8 / 23.9 / 25.9); rows of several narrow columns (the aggregation's
   // (key, row, value): 2.7 against 1.4 ms) stay with the staged one
-  bool wide16 = false, lo16 = false; for (int c = 0; c < cols.n; c++) { wide16 |= cols.c[c].width == 16; lo16 |= cols.c[c].kind == RP_LO16; }
+  bool wide16 = false, lo16 = false; for (int c = 0; c < cols.n; c++) { wide16 |= cols.c[c].width == 16; lo16 |= cols.c[c].kind == RP_LO16 || cols.c[c].kind == RP_CASTF64; }      // lo16: the instantiation with the extra column kinds
   const bool direct = stable && !cols.pack12_dst && !lo16 && (P <= 16 || (P <= 256 && !wide_rows && (cols.n <= 1 || wide16)));
   const bool small_wg = stable && P > 16 && !wide_rows && !direct;    // wide_rows: several columns move per row (the aggregation's second level: 20 B) -- there the 4096-row tile's longer runs win (1.65 -> 1.44 ms),
                                                            // while the sort's single 8-byte column is faster with more workgroups per CU (3.2 against 3.7 ms)                  // stable with many partitions: 256-thread workgroups (the count table is 64 P bytes) keep several on a CU;

@@ -466,12 +466,11 @@ __global__ void __launch_bounds__(BLOCK) k_pk_encode_hist(PkCols pc, int64_t n, 
     }
     const uint64_t word = (key << ib) | (uint64_t)i;
     if (on) keys[i] = word;
-    const bool full = ballot64(on) == ~0ull;
+    const uint64_t onm = ballot64(on); const int src = __ffsll((unsigned long long)onm) - 1;
     for (int p = 0; p < L.npass; p++) {
-      const uint32_t d = (uint32_t)(word >> L.shift[p]) & L.mask[p];
-      if (full) { const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
-        if (ballot64(d != d0) == 0) { if (lane == 0) atomicAdd(&h[p * 256 + d0], 64u); continue; } }       // a constant digit (the top bits of a narrow range) is one add per wave
-      if (on) atomicAdd(&h[p * 256 + d], 1u);
+      const uint32_t d = (uint32_t)(word >> L.shift[p]) & L.mask[p], d0 = __shfl(d, src, 64);
+      if (ballot64(on && d != d0) == 0) { if (lane == src) atomicAdd(&h[p * 256 + d0], (uint32_t)__popcll(onm)); }       // a constant digit (the top bits of a narrow range) is one add per wave
+      else if (on) atomicAdd(&h[p * 256 + d], 1u);
     }
   }
   if (outside && out) atomicOr(outside, 1u);

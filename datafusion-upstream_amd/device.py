@@ -378,9 +378,9 @@ def join_adjust_indices(ctx: Context, build_idx: Array, probe_idx: Array, range_
     return Array(ctx, ob), Array(ctx, op)
 
 
-def agg_preaggregate(ctx: Context, key, kinds: Sequence[int], values: Sequence[Optional[Array]], mask: Optional[Array] = None, any_order: bool = False):
+def agg_preaggregate(ctx: Context, key, kinds: Sequence[int], values: Sequence[Optional[Array]], mask: Optional[Array] = None, any_order: bool = False, casts: Optional[Sequence[int]] = None):
     """dfgpu_agg_preaggregate(_flags): one batch -> (group keys in first-seen order, [state arrays per aggregate]).  `key`: one Array (-> one key Array back) or a
-    sequence of 1..4 Arrays (-> a list of key Arrays back).  any_order (DFGPU_PREAGG_ANY_ORDER): the rows may come back in any order.  Raises
+    sequence of 1..4 Arrays (-> a list of key Arrays back).  any_order (DFGPU_PREAGG_ANY_ORDER): the rows may come back in any order.  casts[i] = capi.FLOAT64: aggregate i's argument is CAST(values[i] AS DOUBLE).  Raises
     DfgpuError(NOT_IMPLEMENTED) for shapes it does not take."""
     n = len(kinds)
     keys = [key] if isinstance(key, Array) else list(key)
@@ -389,7 +389,8 @@ def agg_preaggregate(ctx: Context, key, kinds: Sequence[int], values: Sequence[O
     vh = (C.c_void_p * max(1, n))(*[(v.h if v is not None else None) for v in values])
     ok = (C.c_void_p * 4)()
     os_ = (C.c_void_p * (2 * max(1, n)))()
-    ctx.check(ctx.lib.dfgpu_agg_preaggregate_flags(ctx.h, kh, len(keys), kk, vh, n, mask.h if mask is not None else None, 1 if any_order else 0, ok, os_))
+    cc = (C.c_int32 * max(1, n))(*[int(c) for c in casts]) if casts is not None else None
+    ctx.check(ctx.lib.dfgpu_agg_preaggregate_flags(ctx.h, kh, len(keys), kk, vh, cc, n, mask.h if mask is not None else None, 1 if any_order else 0, ok, os_))
     states = [[Array(ctx, C.c_void_p(os_[2 * i + j])) for j in range(2) if os_[2 * i + j]] for i in range(n)]
     out_keys = [Array(ctx, C.c_void_p(ok[c])) for c in range(len(keys))]
     return (out_keys[0] if isinstance(key, Array) else out_keys), states

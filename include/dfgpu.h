@@ -396,8 +396,12 @@ DFGPU_API dfgpu_status dfgpu_agg_preaggregate(dfgpu_ctx *ctx, const dfgpu_array 
  * partition order and the pass that restores first-seen order (a third of the call at 20 M groups) is skipped.  The plan layer sets it for an AggregateExec whose
  * consumer is a SortExec over all of its group columns, where the order of the input rows cannot show in the output. */
 #define DFGPU_PREAGG_ANY_ORDER 1
-DFGPU_API dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx *ctx, const dfgpu_array *const *keys, int32_t nkeys, const int32_t *kinds, const dfgpu_array *const *values, int32_t n_aggs,
-                                                    const dfgpu_array *opt_mask, int32_t flags, dfgpu_array **out_keys, dfgpu_array **out_states);
+/* value_casts (optional, one entry per aggregate): DFGPU_FLOAT64 = the aggregate's argument is CAST(values[i] AS DOUBLE) of the integer column values[i] (Int8 .. UInt64),
+ * which is how SUM / AVG over an integer column reach the operator after type coercion (AVG: physical-expr/src/aggregate/average.rs:96-110 takes Float64 / Decimal128
+ * only); the column is converted while it is partitioned (arrow-cast's `as f64`) instead of by a cast pass of its own, the states are those of the Float64 argument.
+ * 0 = the argument is values[i] itself; any other value declines (DFGPU_NOT_IMPLEMENTED). */
+DFGPU_API dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx *ctx, const dfgpu_array *const *keys, int32_t nkeys, const int32_t *kinds, const dfgpu_array *const *values, const int32_t *value_casts,
+                                                    int32_t n_aggs, const dfgpu_array *opt_mask, int32_t flags, dfgpu_array **out_keys, dfgpu_array **out_states);
 /* ≙ evaluate(EmitTo::All) / state(EmitTo::All) (:106-134).  out_states holds up to 2 arrays. */
 DFGPU_API dfgpu_status dfgpu_acc_evaluate(dfgpu_ctx *ctx, dfgpu_acc *a, dfgpu_array **out);
 DFGPU_API dfgpu_status dfgpu_acc_state(dfgpu_ctx *ctx, dfgpu_acc *a, dfgpu_array **out_states, int32_t *n_states);

@@ -459,3 +459,65 @@ def test_sort_over_the_group_columns_lets_the_aggregation_emit_in_any_order(ctx,
         res.append([pa.concat_arrays([c[i] for c in cols]) for i in range(len(cols[0]))])
     for a, b in zip(*res):
         assert a.equals(b)
+
+
+@pytest.mark.parametrize("dt,nullable", [(np.int32, False), (np.int64, True), (np.uint16, False)], ids=["int32", "int64-nullable", "uint16"])
+def test_integer_argument_cast_to_float64_while_it_is_partitioned(ctx, dt, nullable):
+    """value_casts = FLOAT64: AVG / SUM / MIN / MAX(CAST(x AS DOUBLE)) over an integer column handed over uncast == the same call over the cast column, state by state
+    (the sums add the same doubles in the same order inside a partition, so they are compared exactly), NULLs of the column included."""
+    import dfgpu
+    from dfgpu import capi
+    n, card = 500_000, 40_000
+    rng = np.random.default_rng(47)
+    key = ctx.from_arrow(pa.array(rng.integers(0, card, n).astype(np.int64) * 31 + 5))
+    info = np.iinfo(dt)
+    x = rng.integers(max(info.min, -10**12), min(info.max, 10**12), n).astype(dt)
+    xa = pa.array(x, mask=(rng.random(n) < 0.1) if nullable else None)
+    xi = ctx.from_arrow(xa); xf = ctx.from_arrow(xa.cast(pa.float64()))
+    kinds = [KIND["AVG"], KIND["SUM"], KIND["MIN"], KIND["MAX"], KIND["COUNT"]]
+    with forced(ctx, force=0) as f:
+        pk0, st0 = dfgpu.agg_preaggregate(ctx, key, kinds, [xf] * 5)
+        f.kernels()
+        pk1, st1 = dfgpu.agg_preaggregate(ctx, key, kinds, [xi] * 5, casts=[capi.FLOAT64] * 5)
+        assert "pa_aggregate" in f.kernels()
+    assert pk0.to_arrow().equals(pk1.to_arrow())
+    for a, b in zip(st0, st1):
+        assert len(a) == len(b)
+        for u, v in zip(a, b):
+            assert u.to_arrow().equals(v.to_arrow())
+    with forced(ctx, force=0):
+        with pytest.raises(dfgpu.DfgpuError) as e:
+            dfgpu.agg_preaggregate(ctx, key, [KIND["SUM"]], [xf], casts=[capi.FLOAT64])          # a cast of a column that is no integer column: declined
+        assert e.value.kind == "NotImplemented"
+
+
+def test_aggregate_exec_hands_cast_arguments_down_uncast(ctx):
+    """AVG(CAST(len AS DOUBLE)) planned as a ProjectionExec computing the cast below AggregateExec (the ClickBench shape): the pre-aggregation takes the Int32 column with the
+    cast named beside it -- no k_cast pass over the batch -- and the result equals the ordinary path's."""
+    from dfgpu import capi, physical_plan as ops
+    n = 400_000
+    rng = np.random.default_rng(53)
+    k = rng.integers(0, 50_000, n).astype(np.int64) * 7 + 1; ln = rng.integers(0, 500, n).astype(np.int32); w = rng.integers(0, 10**6, n).astype(np.int64)
+    batch = ops.batch_from_arrow(ctx, pa.table({"k": pa.array(k), "len": pa.array(ln, mask=rng.random(n) < 0.05), "w": pa.array(w)}))
+    C, F = ops.Column, ops.Field
+    tc = ops.TaskContext(ctx, batch_size=8192)
+    res = []
+    for on in (1, 0):
+        with forced(ctx, force=0) as fz:
+            ctx.set_option("agg_partitioned", on)
+            proj = ops.ProjectionExec([(C("k", 0), "k"), (ops.CastExpr(C("len", 1), capi.FLOAT64), "lenf"), (C("w", 2), "w")], ops.MemoryExec([[batch]], batch.schema))
+            aggs = [ops.AggregateFunctionExpr("AVG", C("lenf", 1), "a", input_field=F("x", capi.FLOAT64)), ops.AggregateFunctionExpr("COUNT", None, "c"),
+                    ops.AggregateFunctionExpr("MAX", C("w", 2), "m", input_field=F("x", capi.INT64)), ops.AggregateFunctionExpr("SUM", C("lenf", 1), "s", input_field=F("x", capi.FLOAT64))]
+            plan = ops.AggregateExec("Single", [(C("k", 0), "k")], aggs, proj)
+            cols = [[c.to_arrow() for c in b.materialize().columns] for b in plan.execute(0, tc)]
+            ran = fz.kernels()
+        assert ("pa_aggregate" in ran) == bool(on)
+        if on:
+            assert "k_cast" not in ran, sorted(ran)
+        res.append([pa.concat_arrays([c[i] for c in cols]) for i in range(5)])
+    a, b = res
+    assert a[0].equals(b[0]) and a[2].equals(b[2]) and a[3].equals(b[3])
+    for i in (1, 4):
+        x, y = a[i], b[i]
+        assert x.is_null().equals(y.is_null())
+        assert np.allclose(x.fill_null(0).to_numpy(), y.fill_null(0).to_numpy(), rtol=FLOAT_RTOL, atol=0.0)
