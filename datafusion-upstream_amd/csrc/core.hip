@@ -445,6 +445,7 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "sort_estimate_ranges") ctx->sort_estimate_ranges = value != 0;
     else if (k == "sort_topk_words_min_rows") ctx->sort_topk_words_min_rows = value < 2 ? 2 : value;
     else if (k == "sort_onesweep_fused_finish") ctx->sort_onesweep_fused_finish = value != 0;
+    else if (k == "sort_one_block_max_rows") ctx->sort_one_block_max_rows = value < 0 ? 0 : value;
     else if (k == "sort_onesweep_min_rows") ctx->sort_onesweep_min_rows = value < 2 ? 2 : value;
     else if (k == "sort_onesweep_rows") ctx->sort_onesweep_rows = value == 16 ? 16 : value > 0 ? 8 : 0;
     else if (k == "sort_fused_small_passes") ctx->sort_fused_small_passes = value != 0;

@@ -486,8 +486,11 @@ struct ProjectionExec : Plan {    // projection.rs:52-62, batch_project :295-317
   Batch project(const TaskContext& tc, Batch b, std::vector<bool>* defer = nullptr) const {
     // A dense selection (>= 1/4 of the rows, e.g. TPC-H Q1's 98 %) is carried: expressions run over the full columns with the
     // selection set as the context's row selection so that dropped rows cannot raise; a sparse one is compacted first.
+    // (A consumer that takes the computed columns unevaluated -- `defer`: AggregateExec -- evaluates them, if at all, under the selection as the row selection
+    // (evaluate_deferred) and reads keys and arguments through the selection as a mask: nothing is evaluated here, so the selection is carried whatever its density and
+    // the count -- a pass over the bitmap and a host round trip per batch -- is not taken.)
     RowSel rowsel;
-    if (b.selection && !only_columns()) {
+    if (b.selection && !only_columns() && !defer) {
       int64_t kept = 0; tc.check(dfgpu_mask_count(tc.ctx, b.selection.a, &kept));
       if (kept * 4 >= b.base_rows) { tc.check(dfgpu_ctx_set_row_selection(tc.ctx, b.selection.a)); rowsel.c = tc.ctx; }
       else { std::set<int> need; for (auto& e : exprs) e->columns(need); b = materialize_subset(tc, b, need); if (defer) defer->assign(exprs.size(), false); defer = nullptr; }

@@ -223,6 +223,60 @@ void radix_sort_pairs_u32(dfgpu_ctx* ctx, uint32_t* keys, uint32_t* vals, int64_
   }
 }
 
+// Inputs one workgroup holds (<= 8192 rows: a TopK's candidates, a small result): EVERY varying plane's pass inside one launch.  The row ids live in LDS (two buffers of
+// 32 KB), a pass is the stable counting sort of radix_partition.h's STABLE ranking -- a wave owns 512 consecutive elements, ballots rank a row inside its slab, a running
+// count per (wave, digit) across the wave's slabs, a prefix over the waves and a 256-wide scan over the digits -- and costs four barriers instead of two launches
+// (a Utf8 tie-break key has ~45 varying planes: 90 launches of 3-4 us each for 4 K candidate rows).
+constexpr int OB_NT = 1024, OB_R = 8, OB_NW = OB_NT / WAVE, OB_MAX = OB_NT * OB_R;
+__global__ void __launch_bounds__(OB_NT) k_rs_one_block(const uint8_t* __restrict__ planes, int n, int W, const uint32_t* __restrict__ varies, const uint32_t* __restrict__ in_vals, uint32_t* __restrict__ out_vals) {
+  __shared__ uint32_t va[OB_MAX], vb[OB_MAX];
+  __shared__ uint16_t wcnt[OB_NW * 256];
+  __shared__ uint32_t cnt[256], wsum[4];
+  uint32_t* cur = va; uint32_t* nxt = vb;
+  for (int e = threadIdx.x; e < n; e += OB_NT) cur[e] = in_vals[e];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  for (int b = W - 1; b >= 0; b--) {          // least significant plane first
+    if (!varies[b]) continue;
+    const uint8_t* plane = planes + (int64_t)b * n;
+    __syncthreads();                          // the previous pass's scatter (or the load above) is complete; wcnt is free
+    for (int x = threadIdx.x; x < OB_NW * 128; x += OB_NT) ((uint32_t*)wcnt)[x] = 0;
+    __syncthreads();
+    uint32_t v[OB_R], d[OB_R], rk[OB_R]; bool on[OB_R];
+#pragma unroll
+    for (int q = 0; q < OB_R; q++) { const int e = wave * (OB_R * WAVE) + q * WAVE + lane; on[q] = e < n; v[q] = on[q] ? cur[e] : 0u; }
+#pragma unroll
+    for (int q = 0; q < OB_R; q++) d[q] = on[q] ? (uint32_t)plane[v[q]] : 0u;
+#pragma unroll
+    for (int q = 0; q < OB_R; q++) {
+      uint64_t peers = ballot64(on[q]);
+#pragma unroll
+      for (int bit = 0; bit < 8; bit++) { const uint64_t mb = ballot64((d[q] >> bit) & 1u); peers &= ((d[q] >> bit) & 1u) ? mb : ~mb; }
+      const uint32_t below = (uint32_t)__popcll(peers & lanemask_lt());
+      uint32_t seen = 0;
+      if (on[q] && below == 0) { uint16_t* wc = wcnt + wave * 256 + d[q]; seen = *wc; *wc = (uint16_t)(seen + (uint32_t)__popcll(peers)); }
+      seen = __shfl(seen, peers ? __ffsll((unsigned long long)peers) - 1 : 0, 64);
+      rk[q] = seen + below;
+    }
+    __syncthreads();
+    uint32_t c = 0, inc = 0;
+    if (threadIdx.x < 256) {
+      uint32_t run = 0;
+#pragma unroll
+      for (int w = 0; w < OB_NW; w++) { const uint32_t x = wcnt[w * 256 + threadIdx.x]; wcnt[w * 256 + threadIdx.x] = (uint16_t)run; run += x; }
+      c = run; inc = wave_inclusive_sum(c);
+      if (lane == 63) wsum[wave] = inc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) { uint32_t run = inc - c; for (int w = 0; w < wave; w++) run += wsum[w]; cnt[threadIdx.x] = run; }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < OB_R; q++) if (on[q]) nxt[cnt[d[q]] + (uint32_t)wcnt[wave * 256 + d[q]] + rk[q]] = v[q];
+    uint32_t* t = cur; cur = nxt; nxt = t;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n; e += OB_NT) out_vals[e] = cur[e];
+}
+
 // ---------------------------------------------------------------- order-preserving key encoding
 struct SortCol { ColView v; int32_t byte_off; int32_t has_null_byte; int32_t descending; int32_t nulls_first; int32_t max_len; };   // max_len: Utf8 only
 struct SortCols { int32_t n; SortCol c[MAX_KEYS]; };
@@ -870,6 +924,10 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
           }
           first = false;
         }
+      } else if (n <= ctx->sort_one_block_max_rows && n <= OB_MAX) {
+        KernelTimer kt_(ctx, "radix_pass_one_block");
+        hipLaunchKernelGGL(k_rs_one_block, dim3(1), dim3(OB_NT), 0, ctx->stream, (const uint8_t*)planes->ptr, (int)n, W, (const uint32_t*)varies->ptr, (const uint32_t*)v0, v1);
+        KERNEL_CHECK(); std::swap(v0, v1);
       } else if (p.nb <= 512 && ctx->sort_fused_small_passes) {
         // two launches per varying plane: the histogram, then k_rs_plane_pass (scan folded into the scatter)
         KernelTimer kt_(ctx, "radix_pass");

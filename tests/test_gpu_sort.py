@@ -348,3 +348,29 @@ def test_topk_over_packed_words_equals_sort_then_slice(ctx, shape, fetch):
     full = ctx.sort_to_indices(dcols, desc, nf).to_numpy()
     assert np.array_equal(got, full[:fetch])
     assert np.array_equal(got.astype(np.int64), want[:fetch])
+
+
+@pytest.mark.parametrize("n", [2, 63, 255, 4097, 8192, 8193])
+def test_sorts_of_one_workgroup_run_every_pass_in_one_launch(ctx, n):
+    """Up to 8192 rows every varying key byte's pass runs inside ONE launch of one workgroup (k_rs_one_block: row ids in LDS, four barriers per pass): the indices are the
+    two-launches-per-pass path's (option sort_one_block_max_rows = 0) and numpy's stable lexsort, for a Utf8 tie-break key with dozens of varying bytes behind a Float64 key with
+    many ties, NULLs in both, DESC / NULLS LAST on the first; 8193 rows take the other path."""
+    rng = np.random.default_rng(100 + n)
+    avg = np.round(rng.random(n) * 3, 1); am = rng.random(n) < 0.1
+    urls = np.array([f"https://site{int(k)}.example/{int(k) * 7919 % 1000}" for k in rng.integers(0, max(2, n // 3), n)], dtype=object); um = rng.random(n) < 0.05
+    cols = [ctx.from_arrow(pa.array(avg, mask=am)), ctx.from_arrow(pa.array(urls, mask=um, type=pa.utf8()))]
+    desc, nf = [True, False], [False, True]
+    ctx.profile_select(None); ctx.profile_enable(True); ctx.profile_read()
+    try:
+        got = ctx.sort_to_indices(cols, desc, nf).to_numpy()
+        ks = set(ctx.profile_read())
+        ctx.set_option("sort_one_block_max_rows", 0)
+        plain = ctx.sort_to_indices(cols, desc, nf).to_numpy()
+        kp = set(ctx.profile_read())
+    finally:
+        ctx.profile_enable(False); ctx.set_option("sort_one_block_max_rows", 8192)
+    assert ("radix_pass_one_block" in ks) == (n <= 8192) and "radix_pass_one_block" not in kp
+    assert np.array_equal(got, plain)
+    ukey = np.array([("" if m else u) for u, m in zip(urls, um)], dtype=object)
+    order = sorted(range(n), key=lambda i: ((1 if am[i] else 0), -avg[i] if not am[i] else 0.0, (0 if um[i] else 1), ukey[i].encode(), i))
+    assert np.array_equal(got.astype(np.int64), np.array(order, dtype=np.int64))
