@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
       }
     }
   };
-  { const uint32_t i = q0 + threadIdx.x, ic = i < q1 ? i : q1 - 1; kn = pkey[ic]; rn = prow[ic]; load_cells(ic, vn); }
+  { const uint32_t i = q0 + threadIdx.x, ic = i < q1 ? i : q1 - 1; kn = pkey[ic]; rn = prow ? prow[ic] : 0u; load_cells(ic, vn); }
   for (uint32_t i0 = q0; i0 < q1; i0 += PA_NT) {
     if (nfilled + PA_NT > C - C / 8) { __syncthreads(); flush(); reset(); if (threadIdx.x == 0) atomicAdd(cursor + 2, 1ull); __syncthreads(); }      // nfilled is only written between barriers: uniform
     const uint32_t i = i0 + threadIdx.x; const bool on = i < q1;
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
     if (P1 && on && (i & 3u) == 0 && pa_fine_pid(k, P1, P2) != p) *misplaced = 1u;     // the partition bounds came from a binary search that relies on the order the two passes leave: every 4th row re-hashed as an assertion
 #pragma unroll
     for (int a = 0; a < PA_MAX_AGGS; a++) v[a] = vn[a];
-    { const uint32_t i2 = i + PA_NT, ic = i2 < q1 ? i2 : q1 - 1; kn = pkey[ic]; rn = prow[ic]; load_cells(ic, vn); }
+    { const uint32_t i2 = i + PA_NT, ic = i2 < q1 ? i2 : q1 - 1; kn = pkey[ic]; rn = prow ? prow[ic] : 0u; load_cells(ic, vn); }
     // Skewed keys: when at least 16 lanes of a wave carry the key of its first active lane, those lanes are combined in registers (shuffles) and the leader
     // alone touches the table: one LDS atomic per state instead of one per row on a slot every wave of the workgroup is hammering.  (Trying the last combined key
     // first -- a key with a fifth to a half of its partition's rows sits in the first lane only that often -- was measured on the Zipf ClickBench shape and changed
@@ -568,7 +568,9 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu
     if (two_level) { P2 = P > 2048 * 128 ? 256 : 128; P1 = (P + P2 - 1) / P2; if (P1 < 16) P1 = 16; if (P1 > 2048) P1 = 2048; P = P1 * P2; }
     else { if (P > n / 2048 + 1) P = n / 2048 + 1; if (P > ctx->num_cus) P = std::min<int64_t>(2048, (P + ctx->num_cus - 1) / ctx->num_cus * ctx->num_cus); P1 = P; }
     // ---- partition (key, row, value cells)
-    BufferPtr pkey = alloc_buffer(ctx, (size_t)n * 8), prow = alloc_buffer(ctx, (size_t)n * 4); std::vector<BufferPtr> pval((size_t)n_src);
+    // the row number travels with a row only to find every group's first row (first-seen order): with DFGPU_PREAGG_ANY_ORDER it stays behind -- 4 of the 20..28 bytes a row
+    // costs each partition level and the aggregation's read
+    BufferPtr pkey = alloc_buffer(ctx, (size_t)n * 8), prow = first_seen ? alloc_buffer(ctx, (size_t)n * 4) : BufferPtr(); std::vector<BufferPtr> pval((size_t)n_src);
     // the flag byte of every row: bit b = nullable value column b holds a value there
     BufferPtr flags_in, pflag;
     if (n_flags) {
@@ -577,7 +579,7 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu
       hipLaunchKernelGGL(k_pa_flags, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, fc, n, (uint8_t*)flags_in->ptr);
       KERNEL_CHECK();
     }
-    RpCols cols{}; cols.n = 1 + n_src + (n_flags ? 1 : 0); cols.rowid_dst = (uint32_t*)prow->ptr;
+    RpCols cols{}; cols.n = 1 + n_src + (n_flags ? 1 : 0); cols.rowid_dst = prow ? (uint32_t*)prow->ptr : nullptr;
     if (n_flags) cols.c[1 + n_src] = RpCol{ flags_in->ptr, pflag->ptr, 1, RP_RAW, 0 };
     cols.c[0] = RpCol{ kptr, pkey->ptr, 8, RP_HASHKEY, ktype };
     auto lo16 = [&](int j) { return srcs[j]->type == DFGPU_DECIMAL128 && srcs[j]->precision > 0 && srcs[j]->precision <= 18; };
@@ -593,12 +595,13 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu
     packed.reset();
     if (two_level) {
       const int64_t m1 = mk ? (int64_t)read_scratch(ctx, 9) : n;          // rows the selection kept
-      BufferPtr pkey2 = alloc_buffer(ctx, (size_t)n * 8), prow2 = alloc_buffer(ctx, (size_t)n * 4); std::vector<BufferPtr> pval2((size_t)n_src);
+      BufferPtr pkey2 = alloc_buffer(ctx, (size_t)n * 8), prow2 = prow ? alloc_buffer(ctx, (size_t)n * 4) : BufferPtr(); std::vector<BufferPtr> pval2((size_t)n_src);
       BufferPtr pflag2; if (n_flags) pflag2 = alloc_buffer(ctx, (size_t)n + 64);
-      RpCols c2{}; c2.n = 2 + n_src + (n_flags ? 1 : 0);
-      if (n_flags) c2.c[2 + n_src] = RpCol{ pflag->ptr, pflag2->ptr, 1, RP_RAW, 0 };
-      c2.c[0] = RpCol{ pkey->ptr, pkey2->ptr, 8, RP_RAW, 0 }; c2.c[1] = RpCol{ prow->ptr, prow2->ptr, 4, RP_RAW, 0 };
-      for (int j = 0; j < n_src; j++) { pval2[(size_t)j] = alloc_buffer(ctx, (size_t)n * (size_t)src_width(j)); c2.c[2 + j] = RpCol{ pval[(size_t)j]->ptr, pval2[(size_t)j]->ptr, src_width(j), RP_RAW, 0 }; }
+      const int c0 = prow ? 2 : 1;          // columns in front of the value columns: key (, row number)
+      RpCols c2{}; c2.n = c0 + n_src + (n_flags ? 1 : 0);
+      if (n_flags) c2.c[c0 + n_src] = RpCol{ pflag->ptr, pflag2->ptr, 1, RP_RAW, 0 };
+      c2.c[0] = RpCol{ pkey->ptr, pkey2->ptr, 8, RP_RAW, 0 }; if (prow) c2.c[1] = RpCol{ prow->ptr, prow2->ptr, 4, RP_RAW, 0 };
+      for (int j = 0; j < n_src; j++) { pval2[(size_t)j] = alloc_buffer(ctx, (size_t)n * (size_t)src_width(j)); c2.c[c0 + j] = RpCol{ pval[(size_t)j]->ptr, pval2[(size_t)j]->ptr, src_width(j), RP_RAW, 0 }; }
       (void)rp_partition(ctx, RpHashU64Low{ (const uint64_t*)pkey->ptr }, m1, (uint32_t)P2, c2, true, ctx->d_scratch64 + 10, "pa_hist2", "pa_scan2", "pa_scatter2", true, true);
       pkey = pkey2; prow = prow2; for (int j = 0; j < n_src; j++) pval[(size_t)j] = pval2[(size_t)j];
       if (n_flags) pflag = pflag2;
@@ -625,7 +628,7 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu
       const unsigned grid = (unsigned)(P + n / slice + 1);
       const size_t lds = (((size_t)1 << cbits) + 1) * cell_bytes;
 #define PA_AGG(I, F) do { HIP_CHECK(hipFuncSetAttribute((const void*)k_pa_aggregate<I, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));      /* per device: set on every call, no process-wide flag */ \
-        hipLaunchKernelGGL((k_pa_aggregate<I, F>), dim3(grid), dim3(PA_NT), lds, ctx->stream, (const uint64_t*)pkey->ptr, (const uint32_t*)prow->ptr, plan, (const uint32_t*)r.starts->ptr, \
+        hipLaunchKernelGGL((k_pa_aggregate<I, F>), dim3(grid), dim3(PA_NT), lds, ctx->stream, (const uint64_t*)pkey->ptr, prow ? (const uint32_t*)prow->ptr : (const uint32_t*)nullptr, plan, (const uint32_t*)r.starts->ptr, \
                            items ? (const uint32_t*)items->ptr : nullptr, (uint32_t)P, cbits, (uint32_t)slice, (uint64_t*)orec->ptr, rs, (uint32_t*)ofirst->ptr, (unsigned long long*)(ctx->d_scratch64 + 12), \
                            two_level ? (uint32_t)P1 : 0u, (uint32_t)P2, (uint32_t*)(ctx->d_scratch64 + 11)); } while (0)
       if (n_flags) { if (plan.has_i128) PA_AGG(true, true); else PA_AGG(false, true); }

@@ -2,6 +2,7 @@
 # The rocprofv3 passes behind profiles/r04_<tag>_*: kernel stats and the two PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, nothing else traced with them) for
 #   q3      bench.py's Q3 step at SF100 (clustered tables)               q3s     the same query over row-wise permuted tables (profiles/q3_shuffled_run.py)
 #   gb      bench_workloads.py groupby_int64 (20 M groups) and the two clickbench shapes, one process each         hj      bench_workloads.py hash_join (sparse keys)
+#   sort    bench_workloads.py sort (two keys, three columns out)
 # Run on the GPU box from the repo root:  bash profiles/collect_r04.sh <tag> [passes...]   (default: all).  Writes gpurun_out/prof_r04_<tag>/, reduced to what travels back.
 set -o pipefail
 R=$GRAFT_REPO_ROOT; T=${1:-x}; shift; PASSES=${@:-q3 q3s gb hj shares}
@@ -23,6 +24,7 @@ for p in $PASSES; do case $p in
        run3 cbu $R/bench_workloads.py --only clickbench_uniform_1000000 --sf 100
        run3 cbz $R/bench_workloads.py --only clickbench_zipf_1000000 --sf 100 ;;
   hj)  run3 hj $R/bench_workloads.py --only hash_join_plain --sf 100 ;;
+  sort) run3 sort $R/bench_workloads.py --only sort --sf 100 ;;
   shares)   # one rank's share of the Q3 step at 8 / 4 / 2 GPUs when nothing has to move: clustered, general paths, shuffled
     for sf in 12.5 25 50; do python3 $R/bench.py --sf $sf --steps 20 --warmup 5 --no-workloads --no-cpu-baseline --detail $O/share_sf$sf.json 2> /dev/null | tail -1 > $O/share_sf$sf.line.json; echo "share sf $sf rc=$?"; done ;;
 esac; done
