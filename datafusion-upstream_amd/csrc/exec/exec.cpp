@@ -2268,23 +2268,31 @@ dfgpu_status dfgpu_plan_aggregate_grouping_sets(dfgpu_plan* aggregate, const dfg
 // A SortExec whose keys hold every group column of the AggregateExec below it (reached through CoalesceBatchesExec, FilterExec and ProjectionExecs of plain columns, which
 // keep or drop rows and rename columns but never reorder them): group key tuples are distinct, so the sort keys order the rows totally and the order in which the
 // aggregation emits its groups cannot show.  The aggregation is told (any_group_order).
-static void mark_any_group_order(const SortExec& s) {
+static const AggregateExec* any_group_order_target(const SortExec& s) {
   std::set<int> cols; for (auto& e : s.exprs) { const int ci = e->column_index(); if (ci >= 0) cols.insert(ci); }
   const Plan* q = s.input.get();
   while (q) {
     if (auto* a = dynamic_cast<const AggregateExec*>(q)) {
-      if (a->mode == 0 || !a->sets.empty() || a->order_mode != 0 || a->gexprs.empty()) return;          // partial states, grouping sets, ordered streaming: left alone
-      for (size_t g = 0; g < a->gexprs.size(); g++) if (!cols.count((int)g)) return;
-      a->any_group_order = true; return;
+      if (a->mode == 0 || !a->sets.empty() || a->order_mode != 0 || a->gexprs.empty()) return nullptr;          // partial states, grouping sets, ordered streaming: left alone
+      for (size_t g = 0; g < a->gexprs.size(); g++) if (!cols.count((int)g)) return nullptr;
+      return a;
     }
     if (auto* cb = dynamic_cast<const CoalesceBatchesExec*>(q)) q = cb->input.get();
     else if (auto* f = dynamic_cast<const FilterExec*>(q)) q = f->input.get();
     else if (auto* pr = dynamic_cast<const ProjectionExec*>(q)) {
-      if (!pr->only_columns()) return;
-      std::set<int> below; for (int ci : cols) { if (ci >= (int)pr->exprs.size()) return; below.insert(pr->exprs[(size_t)ci]->column_index()); }
+      if (!pr->only_columns()) return nullptr;
+      std::set<int> below; for (int ci : cols) { if (ci >= (int)pr->exprs.size()) return nullptr; below.insert(pr->exprs[(size_t)ci]->column_index()); }
       cols = below; q = pr->input.get();
-    } else return;
+    } else return nullptr;
   }
+  return nullptr;
+}
+// The mark goes on the sort's OWN copy of its input (fresh(): the same plan with new operator state): the caller's handle on the aggregation, executed on its own, keeps
+// emitting in first-seen order.
+static void mark_any_group_order(SortExec& s) {
+  if (!any_group_order_target(s)) return;
+  s.input = s.input->fresh();
+  if (auto* a = any_group_order_target(s)) a->any_group_order = true;
 }
 dfgpu_status dfgpu_plan_sort(const dfgpu_expr* const* exprs, const uint8_t* desc, const uint8_t* nf, int32_t n, int64_t fetch, int32_t preserve, const dfgpu_plan* input, dfgpu_plan** out) {
   return guard([&] {

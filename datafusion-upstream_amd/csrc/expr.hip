@@ -133,7 +133,8 @@ __global__ void __launch_bounds__(BLOCK) k_dict_predicate(const void* keys, int 
 // the same for Int32 codes without NULLs on either side.  One row per lane with the dictionary bits read from global memory ran at 0.44 ms per 100 M rows over a dictionary of
 // 1 M entries, and eight rows per lane did not change it (0.47 ms, profiles/r04_n_timeline_cbu.txt): the time is the 100 M random 8-byte reads of a 125 KB bitmap that no L1
 // holds, not the 400 MB of codes.  Here every workgroup first copies the bitmap into LDS (up to 144 KB = 1.18 M entries) and the rows read their bit from there.
-__global__ void __launch_bounds__(1024) k_dict_predicate_i32(const int32_t* __restrict__ keys, int64_t n, const uint64_t* __restrict__ dict_bits, int64_t dict_len, uint64_t* __restrict__ out_bits) {
+template <typename KT>
+__global__ void __launch_bounds__(1024) k_dict_predicate_i32(const KT* __restrict__ keys, int64_t n, const uint64_t* __restrict__ dict_bits, int64_t dict_len, uint64_t* __restrict__ out_bits) {
   extern __shared__ uint32_t dp_bits[];
   const int64_t dwords = (dict_len + 63) >> 6;
   for (int64_t x = threadIdx.x; x < dwords; x += 1024) { const uint64_t v = dict_bits[x]; dp_bits[2 * x] = (uint32_t)v; dp_bits[2 * x + 1] = (uint32_t)(v >> 32); }
@@ -144,7 +145,7 @@ __global__ void __launch_bounds__(1024) k_dict_predicate_i32(const int32_t* __re
     const int64_t base = ch << 9;
     int32_t c[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) { const int64_t i = base + q * 64 + lane; c[q] = i < n ? keys[i] : -1; }
+    for (int q = 0; q < 8; q++) { const int64_t i = base + q * 64 + lane; c[q] = i < n ? (int32_t)keys[i] : -1; }
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       const bool v = c[q] >= 0 && c[q] < dict_len && ((dp_bits[c[q] >> 5] >> (c[q] & 31)) & 1u);
@@ -395,10 +396,13 @@ dfgpu_status dfgpu_binary(dfgpu_ctx* ctx, int32_t op, const dfgpu_array* l, int3
           ArrayHolder hd(new_fixed(ctx, DFGPU_BOOL, n, 0, 0, nv));
           KernelTimer kt_(ctx, "k_dict_predicate");
           const size_t dp_lds = (size_t)((dres->length + 63) / 64) * 8;
-          if (!nv && dcol->key_type == DFGPU_INT32 && dp_lds <= 144 * 1024 && n >= (1 << 16)) {
-            HIP_CHECK(hipFuncSetAttribute((const void*)k_dict_predicate_i32, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+          const int32_t kt = dcol->key_type;
+          if (!nv && (kt == DFGPU_INT32 || kt == DFGPU_INT16 || kt == DFGPU_INT8 || kt == DFGPU_UINT8 || kt == DFGPU_UINT16) && dp_lds <= 144 * 1024 && n >= (1 << 16)) {
             const int per_cu = dp_lds <= 32 * 1024 ? 2 : 1;       // a large bitmap leaves room for one workgroup of 16 waves per CU
-            hipLaunchKernelGGL(k_dict_predicate_i32, dim3(grid_for(n, 1024 * 8, ctx->num_cus * per_cu)), dim3(1024), dp_lds, ctx->stream, (const int32_t*)dcol->values->ptr, n, (const uint64_t*)dres->values->ptr, dres->length, (uint64_t*)hd.get()->values->ptr);
+#define DP_LAUNCH(KT) do { HIP_CHECK(hipFuncSetAttribute((const void*)k_dict_predicate_i32<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)); \
+            hipLaunchKernelGGL((k_dict_predicate_i32<KT>), dim3(grid_for(n, 1024 * 8, ctx->num_cus * per_cu)), dim3(1024), dp_lds, ctx->stream, (const KT*)dcol->values->ptr, n, (const uint64_t*)dres->values->ptr, dres->length, (uint64_t*)hd.get()->values->ptr); } while (0)
+            switch (kt) { case DFGPU_INT8: DP_LAUNCH(int8_t); break; case DFGPU_INT16: DP_LAUNCH(int16_t); break; case DFGPU_UINT8: DP_LAUNCH(uint8_t); break; case DFGPU_UINT16: DP_LAUNCH(uint16_t); break; default: DP_LAUNCH(int32_t); break; }
+#undef DP_LAUNCH
             KERNEL_CHECK(); *out = hd.release(); return;
           }
           hipLaunchKernelGGL(k_dict_predicate, grid, block, 0, ctx->stream, dcol->values->ptr, dcol->key_type, dcol->validity ? (const uint64_t*)dcol->validity->ptr : nullptr, n,

@@ -1,4 +1,9 @@
 #!/bin/bash
-# round 4, call v: kernel stats + PMC passes of the group-by shapes, the sort and the sparse-key hash join
+# round 4, call v: device tests; kernel stats + PMC passes of the group-by shapes, the sort and the sparse-key hash join
+set -o pipefail
 cd "$GRAFT_REPO_ROOT"
-bash profiles/collect_r04.sh ${1:-v} gb sort hj
+O=gpurun_out; T=${1:-v}
+timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $O/r04_${T}_pytest.log 2>&1; rc=$?; echo "pytest rc $rc" | tee -a $O/r04_${T}_pytest.log
+tail -3 $O/r04_${T}_pytest.log
+[ $rc -ne 0 ] && exit $rc
+bash profiles/collect_r04.sh $T gb sort hj

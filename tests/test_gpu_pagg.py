@@ -521,3 +521,31 @@ def test_aggregate_exec_hands_cast_arguments_down_uncast(ctx):
         x, y = a[i], b[i]
         assert x.is_null().equals(y.is_null())
         assert np.allclose(x.fill_null(0).to_numpy(), y.fill_null(0).to_numpy(), rtol=FLOAT_RTOL, atol=0.0)
+
+
+def test_the_mark_stays_on_the_sorts_own_copy_of_the_aggregation(ctx):
+    """dfgpu_plan_sort marks its own copy of the plan below it: the caller's AggregateExec, executed by itself after a SortExec was built over it, still emits its groups in
+    first-seen order (== the ordinary path), and the sort over it skips the ordering pass."""
+    from dfgpu import capi, physical_plan as ops
+    n = 300_000
+    rng = np.random.default_rng(59)
+    k = rng.integers(0, 40_000, n).astype(np.int64) * 13; v = rng.integers(-100, 100, n).astype(np.int64)
+    batch = ops.batch_from_arrow(ctx, pa.table({"k": pa.array(k), "v": pa.array(v)}))
+    C, F = ops.Column, ops.Field
+    tc = ops.TaskContext(ctx, batch_size=8192)
+    mk = lambda: ops.AggregateExec("Single", [(C("k", 0), "k")], [ops.AggregateFunctionExpr("SUM", C("v", 1), "s", input_field=F("v", capi.INT64))], ops.MemoryExec([[batch]], batch.schema))
+    with forced(ctx, force=0) as fz:
+        agg = mk()
+        srt = ops.SortExec([ops.PhysicalSortExpr(C("s", 1), True, True), ops.PhysicalSortExpr(C("k", 0), False, False)], agg)
+        sorted_cols = [[c.to_arrow() for c in b.materialize().columns] for b in srt.execute(0, tc)]
+        ran = fz.kernels()
+        assert "pa_aggregate" in ran and "pa_order" not in ran
+        alone = [[c.to_arrow() for c in b.materialize().columns] for b in agg.execute(0, tc)]
+        assert "pa_order" in fz.kernels()
+        ctx.set_option("agg_partitioned", 0)
+        plain = [[c.to_arrow() for c in b.materialize().columns] for b in mk().execute(0, tc)]
+    cat = lambda cols, i: pa.concat_arrays([c[i] for c in cols])
+    assert cat(alone, 0).equals(cat(plain, 0)) and cat(alone, 1).equals(cat(plain, 1))
+    ks, ss = cat(sorted_cols, 0).to_numpy(), cat(sorted_cols, 1).to_numpy()
+    order = np.lexsort((cat(plain, 0).to_numpy(), -cat(plain, 1).to_numpy()))
+    assert np.array_equal(ks, cat(plain, 0).to_numpy()[order]) and np.array_equal(ss, cat(plain, 1).to_numpy()[order])
