@@ -158,6 +158,7 @@ PROTOTYPES = {
     "dfgpu_cross_join_indices": (C.c_int32, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _PP, _PP]),
     "dfgpu_sort_to_indices": (C.c_int32, [_P, _PP, C.c_char_p, C.c_char_p, C.c_int32, C.c_int64, _PP]),
     "dfgpu_sort_to_indices_keys": (C.c_int32, [_P, _PP, C.c_char_p, C.c_char_p, C.c_int32, C.c_int64, _PP, _PP]),
+    "dfgpu_sort_take": (C.c_int32, [_P, _PP, C.c_char_p, C.c_char_p, C.c_int32, C.c_int64, _PP, C.c_int32, _PP, _PP, _PP]),
     "dfgpu_hash_partition": (C.c_int32, [_P, _PP, C.c_int32, C.c_int32, _PP, C.POINTER(C.c_int64)]),
     "dfgpu_comm_unique_id": (C.c_int32, [C.c_char_p]),
     "dfgpu_comm_create_rccl": (C.c_int32, [_P, C.c_char_p, C.c_int32, C.c_int32, _PP]),

@@ -1794,13 +1794,21 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
 // sort_batch (sorts/sort.rs:584-609): lexsort_to_indices over the evaluated keys, then take() of every column.  A sort column that is a plain input column may
 // come back from the sort already in order (dfgpu_sort_to_indices_keys rebuilds it from the sorted packed keys): that column skips the gather.
 static Batch sorted_batch(const TaskContext& tc, Batch& b, const std::vector<ExprPtr>& exprs, const std::vector<const dfgpu_array*>& kp, const std::vector<uint8_t>& desc, const std::vector<uint8_t>& nulls_first, int64_t fetch) {
-  dfgpu_array* idx = nullptr; std::vector<dfgpu_array*> sk(kp.size(), nullptr);
-  tc.check(dfgpu_sort_to_indices_keys(tc.ctx, kp.data(), desc.data(), nulls_first.data(), (int32_t)kp.size(), fetch, &idx, sk.data()));
+  // the batch's stored columns that are not sort keys go down as payload (dfgpu_sort_take): a large sort's last pass gathers up to four of them while it writes the result
+  std::vector<const dfgpu_array*> pay; std::vector<size_t> pay_col;
+  for (size_t ci = 0; ci < b.cols.size(); ci++) {
+    bool is_key = false; for (auto& e : exprs) is_key |= e->column_index() == (int)ci;
+    if (!is_key && b.cols[ci].arr) { pay.push_back(b.cols[ci].arr.a); pay_col.push_back(ci); }
+  }
+  dfgpu_array* idx = nullptr; std::vector<dfgpu_array*> sk(kp.size(), nullptr), po(pay.size() + 1, nullptr);
+  tc.check(dfgpu_sort_take(tc.ctx, kp.data(), desc.data(), nulls_first.data(), (int32_t)kp.size(), fetch, pay.empty() ? nullptr : pay.data(), (int32_t)pay.size(), &idx, sk.data(), po.data()));
   ArrayRef ix = ArrayRef::adopt(idx); std::vector<ArrayRef> sorted; for (auto* a : sk) sorted.push_back(a ? ArrayRef::adopt(a) : ArrayRef());
+  std::vector<ArrayRef> taken(b.cols.size()); for (size_t j = 0; j < pay.size(); j++) if (po[j]) taken[pay_col[j]] = ArrayRef::adopt(po[j]);
   Batch o; o.schema = b.schema; o.base_rows = ix.len();
   MemoPtr memo = std::make_shared<TakeMemo>();
   for (size_t ci = 0; ci < b.cols.size(); ci++) {
     ArrayRef ready; for (size_t e = 0; e < exprs.size() && !ready; e++) if (sorted[e] && exprs[e]->column_index() == (int)ci) ready = sorted[e];
+    if (!ready && taken[ci]) ready = taken[ci];
     o.cols.push_back(ready ? col_of(ready) : col_take(b.cols[ci], ix, memo));
   }
   return o;

@@ -540,7 +540,8 @@ __global__ void __launch_bounds__(256) k_os_bases(const uint32_t* hists, uint32_
   uint32_t run = inc - v; for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wsum[w];
   gbase[blockIdx.x * 256 + threadIdx.x] = run;
 }
-struct OsFinish { PkCols pc; int32_t ib; uint32_t* idx; int64_t m; };       // the last pass of a sort: instead of the word, its slot receives the row number and the key columns rebuilt from the word (k_pk_finish's work without writing and reading the words once more)
+struct OsPayload { int32_t n; const void* src[4]; void* dst[4]; int32_t width[4]; };          // columns that ride behind the sort (sort_batch's take()): gathered by the last pass
+struct OsFinish { PkCols pc; int32_t ib; uint32_t* idx; int64_t m; OsPayload pay; };       // the last pass of a sort: instead of the word, its slot receives the row number and the key columns rebuilt from the word (k_pk_finish's work without writing and reading the words once more)
 template <int R, bool FINISH>          // R rows per lane: a tile is R x 512 rows
 __global__ void __launch_bounds__(OS_NT) k_os_pass(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, int64_t n, int shift, uint32_t mask, const uint32_t* __restrict__ gbase,
                                                    uint32_t* status /*[ntiles][256]*/, uint32_t* ticket, OsFinish fin, uint32_t* flags) {
@@ -594,7 +595,14 @@ __global__ void __launch_bounds__(OS_NT) k_os_pass(const uint64_t* __restrict__ 
 #pragma unroll
   for (int q = 0; q < R; q++) if (on[q]) {
     const int64_t pos = (int64_t)(tbase[d[q]] + (uint32_t)wcnt[((size_t)q * OS_NW + wave) * 256 + d[q]] + rk[q]);
-    if (FINISH) { if (pos < fin.m) pk_finish_row(fin.pc, w[q], pos, fin.ib, fin.idx); } else out[pos] = w[q];
+    if (FINISH) { if (pos < fin.m) { pk_finish_row(fin.pc, w[q], pos, fin.ib, fin.idx);
+        // the row's other columns: one random sector each, R rows of them in flight per lane while the pass streams -- the gather a separate take() would make afterwards
+        const uint64_t row = w[q] & ((1ull << fin.ib) - 1ull);
+        for (int c = 0; c < 4; c++) { if (c >= fin.pay.n) break;
+          if (fin.pay.width[c] == 8) ((uint64_t*)fin.pay.dst[c])[pos] = ((const uint64_t*)fin.pay.src[c])[row];
+          else if (fin.pay.width[c] == 4) ((uint32_t*)fin.pay.dst[c])[pos] = ((const uint32_t*)fin.pay.src[c])[row];
+          else ((ulonglong2*)fin.pay.dst[c])[pos] = ((const ulonglong2*)fin.pay.src[c])[row]; } } }
+    else out[pos] = w[q];
   }
 }
 // ---- TopK over the words of word mode (SortExec with fetch over a large input whose keys pack; topk/mod.rs keeps a heap of k rows, here:) radix SELECT on the word --
@@ -673,7 +681,8 @@ __global__ void __launch_bounds__(BLOCK) k_ws_rank_sort_pairs(const uint64_t* __
 }  // namespace dfgpu
 
 using namespace dfgpu;
-static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint8_t* descending, const uint8_t* nulls_first, int32_t k, int64_t fetch, dfgpu_array** out, dfgpu_array** out_sorted) {
+static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint8_t* descending, const uint8_t* nulls_first, int32_t k, int64_t fetch, dfgpu_array** out, dfgpu_array** out_sorted,
+                      const dfgpu_array* const* payload = nullptr, int32_t n_payload = 0, dfgpu_array** out_payload = nullptr) {
   {
     if (!cols || k < 1 || !out) fail(DFGPU_INVALID_ARGUMENT, "Sort requires at least one column");
     if (k > MAX_KEYS) fail(DFGPU_NOT_IMPLEMENTED, "more than %d sort columns", MAX_KEYS);
@@ -764,7 +773,7 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
             KERNEL_CHECK(); }
           if (sampled) { const uint64_t miss = read_scratch(ctx, 14); ctx->count_sync("sync:sort_key_outside"); if (miss) continue; }       // some value lies outside the sampled ranges: exact pass
           uint64_t* ka = (uint64_t*)k0->ptr; uint64_t* kb = (uint64_t*)k1->ptr; uint32_t* va = (uint32_t*)idx.get()->values->ptr; uint32_t* vb = word ? nullptr : (uint32_t*)v1->ptr;
-          bool fuse_finish = false; std::vector<ArrayHolder> sk_fused((size_t)k);
+          bool fuse_finish = false; std::vector<ArrayHolder> sk_fused((size_t)k), pay_out((size_t)(n_payload > 0 ? n_payload : 0));
           int64_t ns = n;                                // rows the passes sort
           bool sorted_already = false; ArrayHolder rows;
           if (topk) {
@@ -810,7 +819,14 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
               sk_fused[(size_t)c].a = new_fixed(ctx, cols[c]->type, m, cols[c]->precision, cols[c]->scale); pc.c[c].sorted_dst = sk_fused[(size_t)c].get()->values->ptr; }
             for (int p = 0; p < npass; p++) {
               const bool fin = fuse_finish && p == npass - 1;
-              OsFinish of{}; if (fin) { of.pc = pc; of.ib = ib; of.idx = (uint32_t*)idx.get()->values->ptr; of.m = m; }
+              OsFinish of{}; if (fin) { of.pc = pc; of.ib = ib; of.idx = (uint32_t*)idx.get()->values->ptr; of.m = m;
+                // payload columns: fixed-width (4 / 8 / 16 bytes), no NULLs, at most four; the others are left to the caller's take()
+                for (int c = 0; c < n_payload && out_payload && ctx->sort_payload_in_last_pass && of.pay.n < 4; c++) {
+                  const dfgpu_array* a = payload[c]; if (!a || a->validity || a->type == DFGPU_DICTIONARY || a->type == DFGPU_UTF8 || a->type == DFGPU_BOOL || a->length != n) continue;
+                  const int wdt = type_width(a->type); if (wdt != 4 && wdt != 8 && wdt != 16) continue;
+                  pay_out[(size_t)c].a = new_fixed(ctx, a->type, m, a->precision, a->scale);
+                  of.pay.src[of.pay.n] = a->values->ptr; of.pay.dst[of.pay.n] = pay_out[(size_t)c].get()->values->ptr; of.pay.width[of.pay.n] = wdt; of.pay.n++;
+                } }
               const uint32_t* gb = os_base + p * 256; uint32_t* stp = os_status + (size_t)p * os_tiles * 256;
 #define OS_LAUNCH(R_, F_) hipLaunchKernelGGL((k_os_pass<R_, F_>), dim3((unsigned)os_tiles), dim3(OS_NT), 0, ctx->stream, (const uint64_t*)ka, kb, n, L.shift[p], L.mask[p], gb, stp, os_ticket + p, of, ctx->d_flags)
               if (os_r == 16) { if (fin) OS_LAUNCH(16, true); else OS_LAUNCH(16, false); } else { if (fin) OS_LAUNCH(8, true); else OS_LAUNCH(8, false); }
@@ -835,7 +851,9 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
           }
           if (word) {
             const int64_t m = idx.get()->length;
-            if (fuse_finish) { if (out_sorted) for (int c = 0; c < k; c++) out_sorted[c] = sk_fused[(size_t)c].release(); *out = idx.release(); return; }
+            if (fuse_finish) { if (out_sorted) for (int c = 0; c < k; c++) out_sorted[c] = sk_fused[(size_t)c].release();
+              if (out_payload) for (int c = 0; c < n_payload; c++) out_payload[c] = pay_out[(size_t)c].release();
+              *out = idx.release(); return; }
             std::vector<ArrayHolder> sk((size_t)k);
             if (out_sorted) for (int c = 0; c < k; c++) if (!pc.c[c].valid) {          // a key column without NULLs comes back in sorted order for the price of its sequential write
               sk[(size_t)c].a = new_fixed(ctx, cols[c]->type, m, cols[c]->precision, cols[c]->scale); pc.c[c].sorted_dst = sk[(size_t)c].get()->values->ptr; }
@@ -953,6 +971,15 @@ static void sort_impl(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint
 }
 extern "C" dfgpu_status dfgpu_sort_to_indices(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint8_t* descending, const uint8_t* nulls_first, int32_t k, int64_t fetch, dfgpu_array** out) {
   return guard(ctx, [&] { sort_impl(ctx, cols, descending, nulls_first, k, fetch, out, nullptr); });
+}
+extern "C" dfgpu_status dfgpu_sort_take(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint8_t* descending, const uint8_t* nulls_first, int32_t k, int64_t fetch, const dfgpu_array* const* payload, int32_t n_payload,
+                                        dfgpu_array** out, dfgpu_array** out_sorted, dfgpu_array** out_payload) {
+  return guard(ctx, [&] {
+    if (!out_sorted || (n_payload > 0 && (!payload || !out_payload)) || n_payload < 0) fail(DFGPU_INVALID_ARGUMENT, "sort_take: null argument");
+    for (int32_t c = 0; c < k; c++) out_sorted[c] = nullptr;
+    for (int32_t c = 0; c < n_payload; c++) out_payload[c] = nullptr;
+    sort_impl(ctx, cols, descending, nulls_first, k, fetch, out, out_sorted, payload, n_payload, out_payload);
+  });
 }
 extern "C" dfgpu_status dfgpu_sort_to_indices_keys(dfgpu_ctx* ctx, const dfgpu_array* const* cols, const uint8_t* descending, const uint8_t* nulls_first, int32_t k, int64_t fetch, dfgpu_array** out,
                                                    dfgpu_array** out_sorted) {

@@ -240,6 +240,15 @@ class Context:
                                                        -1 if fetch is None else int(fetch), C.byref(out), sk))
         return self._wrap(out), [self._wrap(C.c_void_p(sk[i])) if sk[i] else None for i in range(n)]
 
+    def sort_take(self, cols: Sequence["Array"], descending: Sequence[bool], nulls_first: Sequence[bool], payload: Sequence["Array"], fetch: Optional[int] = None):
+        """dfgpu_sort_take: (indices, [sorted key columns or None], [payload columns in sorted order or None])."""
+        hs, n = capi.handle_array([a.h.value for a in cols])
+        ps, m = capi.handle_array([a.h.value for a in payload])
+        out = C.c_void_p(); sk = (C.c_void_p * n)(); op = (C.c_void_p * max(1, m))()
+        self.check(self.lib.dfgpu_sort_take(self.h, hs, bytes(int(bool(x)) for x in descending), bytes(int(bool(x)) for x in nulls_first), n,
+                                            -1 if fetch is None else int(fetch), ps, m, C.byref(out), sk, op))
+        return self._wrap(out), [self._wrap(C.c_void_p(sk[i])) if sk[i] else None for i in range(n)], [self._wrap(C.c_void_p(op[i])) if op[i] else None for i in range(m)]
+
     def hash_partition(self, keys: Sequence["Array"], num_partitions: int):
         hs, n = capi.handle_array([a.h.value for a in keys])
         out = C.c_void_p()

@@ -420,6 +420,12 @@ DFGPU_API dfgpu_status dfgpu_sort_to_indices(dfgpu_ctx *ctx, const dfgpu_array *
  * packed keys -- fixed-width key columns without NULLs on the packed-key path -- else NULL; sort_batch's take() (sorts/sort.rs:598-603) of such a column is then free. */
 DFGPU_API dfgpu_status dfgpu_sort_to_indices_keys(dfgpu_ctx *ctx, const dfgpu_array *const *cols, const uint8_t *descending, const uint8_t *nulls_first, int32_t k, int64_t fetch,
                                                   dfgpu_array **out, dfgpu_array **out_sorted);
+/* sort_batch in one call (sorts/sort.rs:584-609: lexsort_to_indices, then take() of every column): dfgpu_sort_to_indices_keys plus the batch's other columns.
+ * out_payload[c] (n_payload entries) = take(payload[c], *out) when the sort's last pass could gather it while it writes the result -- a fixed-width column of 4 / 8 / 16
+ * bytes without NULLs, at most four of them, on the one-launch-per-pass path (keys and row number in one word, 2^20 rows or more) -- else NULL and the caller takes the
+ * column through *out as before.  The gather is the same random sector per row, issued with 16 rows per lane in flight while the pass streams its words. */
+DFGPU_API dfgpu_status dfgpu_sort_take(dfgpu_ctx *ctx, const dfgpu_array *const *cols, const uint8_t *descending, const uint8_t *nulls_first, int32_t k, int64_t fetch,
+                                       const dfgpu_array *const *payload, int32_t n_payload, dfgpu_array **out, dfgpu_array **out_sorted, dfgpu_array **out_payload);
 
 /* ------------------------------------------------------------------ a14: RepartitionExec */
 /* ≙ BatchPartitioner::partition_iter, Hash(exprs, n) (repartition/mod.rs:148-221): destination =

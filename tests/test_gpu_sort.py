@@ -374,3 +374,52 @@ def test_sorts_of_one_workgroup_run_every_pass_in_one_launch(ctx, n):
     ukey = np.array([("" if m else u) for u, m in zip(urls, um)], dtype=object)
     order = sorted(range(n), key=lambda i: ((1 if am[i] else 0), -avg[i] if not am[i] else 0.0, (0 if um[i] else 1), ukey[i].encode(), i))
     assert np.array_equal(got.astype(np.int64), np.array(order, dtype=np.int64))
+
+
+@pytest.mark.parametrize("fetch", [None, 900_000])
+def test_sort_take_gathers_payload_columns_in_the_last_pass(ctx, fetch):
+    """dfgpu_sort_take: fixed-width payload columns without NULLs (8, 4 and 16 bytes wide) come back in sorted order out of the sort's last pass; a nullable column, a Utf8 column
+    and a fifth eligible column come back as None (the caller takes them); every returned column == take(column, indices), with the option off nothing is returned, and
+    SortExec's output is the same either way."""
+    import decimal
+    from dfgpu import physical_plan as ops
+    rng = np.random.default_rng(61)
+    n = (1 << 20) + 555
+    k1 = rng.integers(0, 5000, n).astype(np.int32); k2 = rng.integers(-2**27, 2**27, n).astype(np.int64)          # 13 + 29 key bits + 21 row bits: one word
+    p8 = rng.integers(0, 2**60, n).astype(np.int64); p4 = rng.integers(0, 2**30, n).astype(np.int32)
+    p16 = pa.array([decimal.Decimal(int(v)).scaleb(-2) for v in rng.integers(-10**9, 10**9, 2000)], type=pa.decimal128(20, 2)).take(pa.array(rng.integers(0, 2000, n)))
+    pn = pa.array(rng.integers(0, 100, n).astype(np.int64), mask=rng.random(n) < 0.2)
+    ps = pa.array(np.array(["a", "bb", "ccc"], dtype=object)[rng.integers(0, 3, n)], type=pa.utf8())
+    f1 = rng.random(n); f2 = rng.random(n).astype(np.float32)
+    keys = [ctx.from_arrow(pa.array(k1)), ctx.from_arrow(pa.array(k2))]
+    pay_arrow = [pa.array(p8), pa.array(p4), p16, pn, ps, pa.array(f1), pa.array(f2)]
+    pay = [ctx.from_arrow(a) for a in pay_arrow]
+    desc, nf = [True, False], [True, True]
+    idx, sk, got = ctx.sort_take(keys, desc, nf, pay, fetch=fetch)
+    order = idx.to_numpy()
+    want_order = np.lexsort((np.arange(n), k2, -k1.astype(np.int64)))[:fetch]
+    assert np.array_equal(order.astype(np.int64), want_order)
+    returned = [g is not None for g in got]
+    assert returned == [True, True, True, False, False, True, False]          # the first four eligible columns; NULLs, strings and the fifth are the caller's
+    for a, g in zip(pay_arrow, got):
+        if g is not None:
+            assert g.to_arrow().equals(a.take(pa.array(order)))
+    ctx.set_option("sort_payload_in_last_pass", 0)
+    try:
+        idx0, _, got0 = ctx.sort_take(keys, desc, nf, pay, fetch=fetch)
+    finally:
+        ctx.set_option("sort_payload_in_last_pass", 1)
+    assert np.array_equal(idx0.to_numpy(), order) and all(g is None for g in got0)
+    # through SortExec: the same batch either way
+    t = pa.table({"k1": pa.array(k1), "k2": pa.array(k2), "p8": pa.array(p8), "pn": pn, "p16": p16, "ps": ps})
+    batch = ops.batch_from_arrow(ctx, t)
+    tc = ops.TaskContext(ctx, batch_size=8192)
+    mk = lambda: ops.SortExec([ops.PhysicalSortExpr(ops.Column("k1", 0), True, True), ops.PhysicalSortExpr(ops.Column("k2", 1), False, True)], ops.MemoryExec([[batch]], batch.schema), fetch=fetch)
+    outs = []
+    for on in (1, 0):
+        ctx.set_option("sort_payload_in_last_pass", on)
+        try:
+            outs.append(pa.Table.from_batches([b.to_arrow() for b in mk().execute(0, tc)]))
+        finally:
+            ctx.set_option("sort_payload_in_last_pass", 1)
+    assert outs[0].equals(outs[1]) and outs[0].equals(t.take(pa.array(want_order)))
