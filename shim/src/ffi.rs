@@ -49,6 +49,12 @@ extern "C" {
     pub fn dfgpu_parquet_read(ctx: *mut dfgpu_ctx, file: *mut dfgpu_parquet, first_row_group: i32, num_row_groups: i32, columns: *const i32, ncols: i32, out: *mut *mut dfgpu_array) -> i32;
     // ---- include/dfgpu_exec.h
     pub fn dfgpu_sort_to_indices_keys(ctx: *mut dfgpu_ctx, cols: *const *const dfgpu_array, descending: *const u8, nulls_first: *const u8, k: i32, fetch: i64, out: *mut *mut dfgpu_array, out_sorted: *mut *mut dfgpu_array) -> i32;
+    /// sort_batch in one call: the batch's other columns go down as payload; entries of out_payload the sort's last pass could not gather stay null (dfgpu_take them).
+    pub fn dfgpu_sort_take(ctx: *mut dfgpu_ctx, cols: *const *const dfgpu_array, descending: *const u8, nulls_first: *const u8, k: i32, fetch: i64, payload: *const *const dfgpu_array, n_payload: i32,
+                           out: *mut *mut dfgpu_array, out_sorted: *mut *mut dfgpu_array, out_payload: *mut *mut dfgpu_array) -> i32;
+    /// Partial stage inside the operator; flags: 1 = DFGPU_PREAGG_ANY_ORDER (set below a SortExec over all group columns); value_casts[i] = DFGPU_FLOAT64: argument i is CAST(values[i] AS DOUBLE).
+    pub fn dfgpu_agg_preaggregate_flags(ctx: *mut dfgpu_ctx, keys: *const *const dfgpu_array, nkeys: i32, kinds: *const i32, values: *const *const dfgpu_array, value_casts: *const i32, n_aggs: i32,
+                                        opt_mask: *const dfgpu_array, flags: i32, out_keys: *mut *mut dfgpu_array, out_states: *mut *mut dfgpu_array) -> i32;
     pub fn dfgpu_csv_read(ctx: *mut dfgpu_ctx, bytes: *const u8, len: i64, bytes_on_device: i32, delimiter: i32, quote: i32, escape: i32, has_header: i32, ncols_file: i32, columns: *const i32, types: *const i32, ncols: i32, out: *mut *mut dfgpu_array, out_rows: *mut i64) -> i32;
     pub fn dfgpu_plan_aggregate_input_order(aggregate: *mut dfgpu_plan, input_order_mode: i32, order_indices: *const i32, n: i32) -> i32;
     pub fn dfgpu_plan_parquet(file: *mut dfgpu_parquet, columns: *const i32, ncols: i32, npartitions: i32, row_groups_per_batch: i32, out: *mut *mut dfgpu_plan) -> i32;
