@@ -1385,7 +1385,7 @@ struct AggregateExec : Plan {     // aggregates/mod.rs:242-269; GroupedHashAggre
         }
         if (ci >= 0) {
           ArrayRef col = src->column(tc, ci); dfgpu_array_desc d; dfgpu_array_describe(col.a, &d);
-          const bool is_int = d.type == DFGPU_INT8 || d.type == DFGPU_INT16 || d.type == DFGPU_INT32 || d.type == DFGPU_INT64 || d.type == DFGPU_UINT8 || d.type == DFGPU_UINT16 || d.type == DFGPU_UINT32 || d.type == DFGPU_UINT64;
+          const bool is_int = d.type == DFGPU_INT32 || d.type == DFGPU_INT64;
           if (is_int && (aggs[i].kind == DFGPU_AGG_SUM || aggs[i].kind == DFGPU_AGG_AVG || aggs[i].kind == DFGPU_AGG_MIN || aggs[i].kind == DFGPU_AGG_MAX || aggs[i].kind == DFGPU_AGG_COUNT)) { vals[i] = col; casts[i] = DFGPU_FLOAT64; any_cast = true; }
         }
         if (!casts[i]) {

@@ -173,15 +173,9 @@ __global__ void __launch_bounds__(NT) k_rp_scatter(H hs, int64_t n, uint32_t P, 
 #define RP_GATHER(EXPR) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) { const int64_t i = i0 + (int64_t)q * QS; stage[spos[q]] = (uint64_t)(EXPR); } }
       if (col.kind == RP_HASHKEY) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) stage[spos[q]] = hk[q]; }
       else if (LO16 && col.kind == RP_LO16) RP_GATHER(((const uint64_t*)col.src)[2 * i])
-      else if (LO16 && col.kind == RP_CASTF64) switch (col.type) {            // arrow-cast: integer -> Float64 is `as f64`
-        case DFGPU_INT8: RP_GATHER(__double_as_longlong((double)((const int8_t*)col.src)[i])) break;
-        case DFGPU_INT16: RP_GATHER(__double_as_longlong((double)((const int16_t*)col.src)[i])) break;
-        case DFGPU_INT32: RP_GATHER(__double_as_longlong((double)((const int32_t*)col.src)[i])) break;
-        case DFGPU_UINT8: RP_GATHER(__double_as_longlong((double)((const uint8_t*)col.src)[i])) break;
-        case DFGPU_UINT16: RP_GATHER(__double_as_longlong((double)((const uint16_t*)col.src)[i])) break;
-        case DFGPU_UINT32: RP_GATHER(__double_as_longlong((double)((const uint32_t*)col.src)[i])) break;
-        case DFGPU_UINT64: RP_GATHER(__double_as_longlong((double)((const uint64_t*)col.src)[i])) break;
-        default: RP_GATHER(__double_as_longlong((double)((const int64_t*)col.src)[i])) break;
+      else if (LO16 && col.kind == RP_CASTF64) {            // arrow-cast: integer -> Float64 is `as f64`; Int32 and Int64 sources (two load shapes: every further one is another unrolled gather in this instantiation's column loop)
+        if (col.type == DFGPU_INT32) RP_GATHER(__double_as_longlong((double)((const int32_t*)col.src)[i]))
+        else RP_GATHER(__double_as_longlong((double)((const int64_t*)col.src)[i]))
       }
       else if (col.kind == RP_KEY64) switch (col.type) {            // widened exactly as key_at() does
         case DFGPU_INT8: RP_GATHER((int64_t)((const int8_t*)col.src)[i]) break;

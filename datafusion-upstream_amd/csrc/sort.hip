@@ -506,25 +506,35 @@ __global__ void __launch_bounds__(BLOCK) k_pk_encode_hist(PkCols pc, int64_t n, 
   for (int x = threadIdx.x; x < 8 * 256; x += BLOCK) h[x] = 0;
   __syncthreads();
   const int lane = lane_id(); bool out = false;
-  for (int64_t b0 = (int64_t)blockIdx.x * BLOCK + (threadIdx.x & ~63); b0 < n; b0 += (int64_t)gridDim.x * BLOCK) {
-    const int64_t i = b0 + lane; const bool on = i < n;
-    uint64_t key = 0;
-    if (on) for (int c = 0; c < MAX_KEYS; c++) {
-      if (c >= pc.n) break;
-      const PkCol& k = pc.c[c]; uint64_t off;
-      if (!valid_at(k.valid, i)) off = k.nulls_first ? 0 : k.span + 1;
-      else { uint64_t hh, l; pk_order_bits(k.v, k.type, i, &hh, &l); uint64_t d = l - k.lo_bits;
-        if (outside) { const uint64_t dh = hh - k.hi_bits - (l < k.lo_bits ? 1ull : 0ull); out |= dh != 0 || d >= k.span; }
-        off = 1 + (k.desc ? k.span - 1 - d : d); }
-      key |= off << k.shift;
+  constexpr int U = 2;          // rows per lane and round: both rows' column loads are in flight before the first histogram add
+  const int64_t nwaves = (int64_t)gridDim.x * (BLOCK / WAVE);
+  for (int64_t c0 = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6; c0 * (WAVE * U) < n; c0 += nwaves) {
+    uint64_t word[U]; bool on[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = c0 * (WAVE * U) + u * WAVE + lane; on[u] = i < n;
+      uint64_t key = 0;
+      if (on[u]) for (int c = 0; c < MAX_KEYS; c++) {
+        if (c >= pc.n) break;
+        const PkCol& k = pc.c[c]; uint64_t off;
+        if (!valid_at(k.valid, i)) off = k.nulls_first ? 0 : k.span + 1;
+        else { uint64_t hh, l; pk_order_bits(k.v, k.type, i, &hh, &l); uint64_t d = l - k.lo_bits;
+          if (outside) { const uint64_t dh = hh - k.hi_bits - (l < k.lo_bits ? 1ull : 0ull); out |= dh != 0 || d >= k.span; }
+          off = 1 + (k.desc ? k.span - 1 - d : d); }
+        key |= off << k.shift;
+      }
+      word[u] = (key << ib) | (uint64_t)i;
+      if (on[u]) keys[i] = word[u];
     }
-    const uint64_t word = (key << ib) | (uint64_t)i;
-    if (on) keys[i] = word;
-    const uint64_t onm = ballot64(on); const int src = __ffsll((unsigned long long)onm) - 1;
-    for (int p = 0; p < L.npass; p++) {
-      const uint32_t d = (uint32_t)(word >> L.shift[p]) & L.mask[p], d0 = __shfl(d, src, 64);
-      if (ballot64(on && d != d0) == 0) { if (lane == src) atomicAdd(&h[p * 256 + d0], (uint32_t)__popcll(onm)); }       // a constant digit (the top bits of a narrow range) is one add per wave
-      else if (on) atomicAdd(&h[p * 256 + d], 1u);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint64_t onm = ballot64(on[u]); if (!onm) continue;
+      const int src = __ffsll((unsigned long long)onm) - 1;
+      for (int p = 0; p < L.npass; p++) {
+        const uint32_t d = (uint32_t)(word[u] >> L.shift[p]) & L.mask[p], d0 = __shfl(d, src, 64);
+        if (ballot64(on[u] && d != d0) == 0) { if (lane == src) atomicAdd(&h[p * 256 + d0], (uint32_t)__popcll(onm)); }       // a constant digit (the top bits of a narrow range) is one add per wave
+        else if (on[u]) atomicAdd(&h[p * 256 + d], 1u);
+      }
     }
   }
   if (outside && out) atomicOr(outside, 1u);

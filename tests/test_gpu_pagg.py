@@ -461,7 +461,7 @@ def test_sort_over_the_group_columns_lets_the_aggregation_emit_in_any_order(ctx,
         assert a.equals(b)
 
 
-@pytest.mark.parametrize("dt,nullable", [(np.int32, False), (np.int64, True), (np.uint16, False)], ids=["int32", "int64-nullable", "uint16"])
+@pytest.mark.parametrize("dt,nullable", [(np.int32, False), (np.int64, True), (np.int32, True)], ids=["int32", "int64-nullable", "int32-nullable"])
 def test_integer_argument_cast_to_float64_while_it_is_partitioned(ctx, dt, nullable):
     """value_casts = FLOAT64: AVG / SUM / MIN / MAX(CAST(x AS DOUBLE)) over an integer column handed over uncast == the same call over the cast column, state by state
     (the sums add the same doubles in the same order inside a partition, so they are compared exactly), NULLs of the column included."""
@@ -487,7 +487,10 @@ def test_integer_argument_cast_to_float64_while_it_is_partitioned(ctx, dt, nulla
             assert u.to_arrow().equals(v.to_arrow())
     with forced(ctx, force=0):
         with pytest.raises(dfgpu.DfgpuError) as e:
-            dfgpu.agg_preaggregate(ctx, key, [KIND["SUM"]], [xf], casts=[capi.FLOAT64])          # a cast of a column that is no integer column: declined
+            dfgpu.agg_preaggregate(ctx, key, [KIND["SUM"]], [xf], casts=[capi.FLOAT64])          # a cast of a column that is no Int32 / Int64 column: declined
+        assert e.value.kind == "NotImplemented"
+        with pytest.raises(dfgpu.DfgpuError) as e:
+            dfgpu.agg_preaggregate(ctx, key, [KIND["SUM"]], [ctx.from_arrow(pa.array(rng.integers(0, 100, n).astype(np.uint16)))], casts=[capi.FLOAT64])
         assert e.value.kind == "NotImplemented"
 
 
