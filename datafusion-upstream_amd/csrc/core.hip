@@ -444,6 +444,7 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "agg_spill_state_bytes") ctx->agg_spill_state_bytes = value;
     else if (k == "sort_estimate_ranges") ctx->sort_estimate_ranges = value != 0;
     else if (k == "sort_topk_words_min_rows") ctx->sort_topk_words_min_rows = value < 2 ? 2 : value;
+    else if (k == "partition_two_round_staging") ctx->partition_two_round_staging = value != 0;
     else if (k == "sort_payload_in_last_pass") ctx->sort_payload_in_last_pass = value != 0;
     else if (k == "sort_onesweep_fused_finish") ctx->sort_onesweep_fused_finish = value != 0;
     else if (k == "sort_one_block_max_rows") ctx->sort_one_block_max_rows = value < 0 ? 0 : value;

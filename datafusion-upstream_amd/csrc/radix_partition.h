@@ -87,18 +87,22 @@ __global__ void __launch_bounds__(NT) k_rp_hist(H hs, int64_t n, uint32_t P, int
 }
 
 // LDS of the scatter: cnt[P] u32 | delta[P] u32 | spid[TILE] u16 | slidx[TILE] u16 | stage[TILE] u64 | (STABLE) wcnt[NT / 64][P] u16
-template <int NT> static inline size_t rp_scatter_lds(uint32_t P, bool stable) {
-  return (size_t)P * 8 + (size_t)NT * RP_R * 4 + 8 + (size_t)NT * RP_R * 8 + (stable ? (size_t)(NT / WAVE) * P * 2 : 0);
+template <int NT> static inline size_t rp_scatter_lds(uint32_t P, bool stable, int rounds = 1) {
+  return (size_t)P * 8 + (size_t)NT * RP_R * 4 + 8 + (size_t)NT * RP_R * 8 / (size_t)rounds + (stable ? (size_t)(NT / WAVE) * P * 2 : 0);
 }
 
-template <int NT, bool STABLE, typename H, bool LO16 = false>          // LO16: some column is RP_LO16 (an instantiation of its own: the extra branch in the column loop cost the others 10 %)
+// ROUNDS = 2: a column is staged and written out in two rounds of half a tile each (rows whose staged position lies in the round's half), so the staging buffer is half
+// as large: the 8192-row tile of the many-partition case then needs 74 KB instead of 106 KB of LDS and TWO workgroups fit a CU (one loading while the other writes) --
+// what the partitioned join's own scatter does (pjoin.hip); twice the barriers per column.
+template <int NT, bool STABLE, typename H, bool LO16 = false, int ROUNDS = 1>          // LO16: some column is RP_LO16 (an instantiation of its own: the extra branch in the column loop cost the others 10 %)
 __global__ void __launch_bounds__(NT) k_rp_scatter(H hs, int64_t n, uint32_t P, int64_t ntiles, const uint32_t* goff, RpCols cols) {
   extern __shared__ uint32_t rp_lds[];
   constexpr int TILE = NT * RP_R, NW = NT / WAVE;
   uint32_t* cnt = rp_lds; uint32_t* delta = rp_lds + P; uint16_t* spid = (uint16_t*)(rp_lds + 2 * P);
   uint16_t* slidx = spid + TILE;                                    // tile-local index of the row staged at each position
   uint64_t* stage = (uint64_t*)(((uintptr_t)(slidx + TILE) + 7) & ~(uintptr_t)7);
-  uint16_t* wcnt = (uint16_t*)(stage + TILE);                       // STABLE only: rows of partition p in wave w (running over the wave's slabs while ranking, then exclusive over the waves)
+  constexpr uint32_t HT = TILE / ROUNDS;                            // staged positions per round
+  uint16_t* wcnt = (uint16_t*)(stage + HT);                         // STABLE only: rows of partition p in wave w (running over the wave's slabs while ranking, then exclusive over the waves)
   __shared__ uint32_t wsum[NW]; __shared__ uint32_t moved_sh; __shared__ RpCol scol[RP_MAX_COLS];
 #pragma unroll
   for (int c = 0; c < RP_MAX_COLS; c++) if ((int)threadIdx.x == c) scol[c] = cols.c[c];       // static indexing of the by-value argument; the column loop reads LDS
@@ -167,11 +171,12 @@ __global__ void __launch_bounds__(NT) k_rp_scatter(H hs, int64_t n, uint32_t P, 
   for (int c = 0; c < cols.n; c++) {
     const RpCol col = scol[c];
     const int halves = col.width == 16 ? 2 : 1;
-    for (int hf = 0; hf < halves; hf++) {
-      if (c || hf) __syncthreads();                    // the previous column's write-out has read the staging buffer
+    for (int hf = 0; hf < halves; hf++) for (int r = 0; r < ROUNDS; r++) {
+      if (c || hf || r) __syncthreads();               // the previous column's (round's) write-out has read the staging buffer
+      const uint32_t r0 = (uint32_t)r * HT, r1 = moved < r0 + HT ? moved : r0 + HT;          // staged positions of this round
       // the width switch sits outside the unrolled row loop: one load shape per column, RP_R loads in flight
-#define RP_GATHER(EXPR) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) { const int64_t i = i0 + (int64_t)q * QS; stage[spos[q]] = (uint64_t)(EXPR); } }
-      if (col.kind == RP_HASHKEY) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q]) stage[spos[q]] = hk[q]; }
+#define RP_GATHER(EXPR) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q] && (ROUNDS == 1 || spos[q] - r0 < HT)) { const int64_t i = i0 + (int64_t)q * QS; stage[spos[q] - r0] = (uint64_t)(EXPR); } }
+      if (col.kind == RP_HASHKEY) { _Pragma("unroll") for (int q = 0; q < RP_R; q++) if (on[q] && (ROUNDS == 1 || spos[q] - r0 < HT)) stage[spos[q] - r0] = hk[q]; }
       else if (LO16 && col.kind == RP_LO16) RP_GATHER(((const uint64_t*)col.src)[2 * i])
       else if (LO16 && col.kind == RP_CASTF64) {            // arrow-cast: integer -> Float64 is `as f64`; Int32 and Int64 sources (two load shapes: every further one is another unrolled gather in this instantiation's column loop)
         if (col.type == DFGPU_INT32) RP_GATHER(__double_as_longlong((double)((const int32_t*)col.src)[i]))
@@ -195,14 +200,14 @@ __global__ void __launch_bounds__(NT) k_rp_scatter(H hs, int64_t n, uint32_t P, 
       }
 #undef RP_GATHER
       __syncthreads();
-#define RP_WRITE(T, IDX) for (uint32_t i = threadIdx.x; i < moved; i += NT) { const int64_t pos = (int64_t)(uint32_t)(delta[spid[i]] + i); ((T*)col.dst)[IDX] = (T)stage[i]; }
+#define RP_WRITE(T, IDX) for (uint32_t i = r0 + threadIdx.x; i < r1; i += NT) { const int64_t pos = (int64_t)(uint32_t)(delta[spid[i]] + i); ((T*)col.dst)[IDX] = (T)stage[i - r0]; }
       if (cols.pack12_dst && c == 0) {
         RpRec12* const d12 = cols.pack12_dst;
-        for (uint32_t i = threadIdx.x; i < moved; i += NT) { const int64_t pos = (int64_t)(uint32_t)(delta[spid[i]] + i); const uint64_t v = stage[i]; d12[pos] = RpRec12{ (uint32_t)v, (uint32_t)(v >> 32), (uint32_t)(base + slidx[i]) }; }
+        for (uint32_t i = r0 + threadIdx.x; i < r1; i += NT) { const int64_t pos = (int64_t)(uint32_t)(delta[spid[i]] + i); const uint64_t v = stage[i - r0]; d12[pos] = RpRec12{ (uint32_t)v, (uint32_t)(v >> 32), (uint32_t)(base + slidx[i]) }; }
       } else if (rowid_dst && c == 0 && hf == 0 && col.width == 8) {           // the common (key, row id) pair in one sweep
-        for (uint32_t i = threadIdx.x; i < moved; i += NT) { const int64_t pos = (int64_t)(uint32_t)(delta[spid[i]] + i); ((uint64_t*)col.dst)[pos] = stage[i]; rowid_dst[pos] = (uint32_t)(base + slidx[i]); }
+        for (uint32_t i = r0 + threadIdx.x; i < r1; i += NT) { const int64_t pos = (int64_t)(uint32_t)(delta[spid[i]] + i); ((uint64_t*)col.dst)[pos] = stage[i - r0]; rowid_dst[pos] = (uint32_t)(base + slidx[i]); }
       } else {
-      if (rowid_dst && c == 0 && hf == 0) for (uint32_t i = threadIdx.x; i < moved; i += NT) rowid_dst[(int64_t)(uint32_t)(delta[spid[i]] + i)] = (uint32_t)(base + slidx[i]);
+      if (rowid_dst && c == 0 && hf == 0) for (uint32_t i = r0 + threadIdx.x; i < r1; i += NT) rowid_dst[(int64_t)(uint32_t)(delta[spid[i]] + i)] = (uint32_t)(base + slidx[i]);
       switch (col.width) {
         case 1: RP_WRITE(uint8_t, pos) break;
         case 2: RP_WRITE(uint16_t, pos) break;
@@ -328,7 +333,14 @@ static RpResult rp_partition(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, const 
       hipLaunchKernelGGL((k_rp_scatter<NT_, ST_, H>), dim3(grid), dim3(NT_), rp_scatter_lds<NT_>(P, ST_), ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols); } }
     if (direct && P <= 16) hipLaunchKernelGGL((k_rp_scatter_direct<512, 16, H>), dim3(grid), dim3(512), 0, ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols);
     else if (direct) hipLaunchKernelGGL((k_rp_scatter_direct<512, 256, H>), dim3(grid), dim3(512), 0, ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols);
-    else if (small_wg) RP_LAUNCH(256, true) else if (stable) RP_LAUNCH(512, true) else if (big) RP_LAUNCH(1024, false) else RP_LAUNCH(512, false)
+    else if (small_wg) RP_LAUNCH(256, true) else if (stable) RP_LAUNCH(512, true)
+    else if (big && ctx->partition_two_round_staging) {          // the 8192-row tile staged in two rounds: two workgroups per CU
+      if (lo16) { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_scatter<1024, false, H, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+        hipLaunchKernelGGL((k_rp_scatter<1024, false, H, true, 2>), dim3(grid), dim3(1024), rp_scatter_lds<1024>(P, false, 2), ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols); }
+      else { HIP_CHECK(hipFuncSetAttribute((const void*)k_rp_scatter<1024, false, H, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+        hipLaunchKernelGGL((k_rp_scatter<1024, false, H, false, 2>), dim3(grid), dim3(1024), rp_scatter_lds<1024>(P, false, 2), ctx->stream, hs, n, P, ntiles, (const uint32_t*)counts->ptr, cols); }
+    }
+    else if (big) RP_LAUNCH(1024, false) else RP_LAUNCH(512, false)
 #undef RP_LAUNCH
     KERNEL_CHECK(); }
   return r;

@@ -552,3 +552,40 @@ def test_the_mark_stays_on_the_sorts_own_copy_of_the_aggregation(ctx):
     ks, ss = cat(sorted_cols, 0).to_numpy(), cat(sorted_cols, 1).to_numpy()
     order = np.lexsort((cat(plain, 0).to_numpy(), -cat(plain, 1).to_numpy()))
     assert np.array_equal(ks, cat(plain, 0).to_numpy()[order]) and np.array_equal(ss, cat(plain, 1).to_numpy()[order])
+
+
+def test_many_partition_scatter_staged_in_two_rounds(ctx):
+    """513 .. 2048 partitions: the 8192-row tile's columns are staged in two rounds of half a tile (two workgroups per CU).  Same partial rows, same first-seen order and states
+    as with the whole tile staged at once (option partition_two_round_staging = 0) and as the oracle's row-by-row update; a Decimal128 argument (two 8-byte halves per row), a
+    nullable Int64 one (flag byte column) and an Int32 one cast on the way."""
+    import dfgpu
+    from dfgpu import capi
+    n, card = 3_000_000, 1_500_000
+    rng = np.random.default_rng(67)
+    key = pa.array(rng.integers(0, card, n).astype(np.int64) * 2654435761 + 11)
+    vi = pa.array(rng.integers(-10**6, 10**6, n).astype(np.int64), mask=rng.random(n) < 0.1)
+    vd = dec_array(rng.integers(-10**9, 10**9, n).tolist(), precision=30, scale=2)
+    v32 = pa.array(rng.integers(0, 500, n).astype(np.int32))
+    kd = ctx.from_arrow(key); cols = [ctx.from_arrow(vi), ctx.from_arrow(vd), ctx.from_arrow(v32)]
+    kinds = [KIND["SUM"], KIND["MAX"], KIND["SUM"], KIND["AVG"], KIND["COUNT"]]
+    vals = [cols[0], cols[0], cols[1], cols[2], None]
+    casts = [0, 0, 0, capi.FLOAT64, 0]
+    out = []
+    for on in (1, 0):
+        ctx.set_option("partition_two_round_staging", on)
+        try:
+            with forced(ctx, force=1) as f:
+                pk, states = dfgpu.agg_preaggregate(ctx, kd, kinds, vals, casts=casts)
+                assert "pa_scatter" in f.kernels()
+        finally:
+            ctx.set_option("partition_two_round_staging", 1)
+        out.append((pk.to_arrow(), [[s.to_arrow() for s in st] for st in states]))
+    (k1, s1), (k0, s0) = out
+    assert k1.equals(k0)
+    for a, b in zip(s1, s0):
+        for u, v in zip(a, b):
+            assert u.equals(v)
+    # against the oracle: groups in first-seen order, SUM / MAX / COUNT exact
+    wk, want = run_oracle(key, [("SUM", vi), ("MAX", vi), ("COUNT", None)])
+    assert k1.equals(wk)
+    assert s1[0][0].equals(want[0]) and s1[1][0].equals(want[1]) and s1[4][0].cast(pa.int64()).equals(want[2].cast(pa.int64()))
