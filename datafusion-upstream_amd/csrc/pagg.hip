@@ -559,7 +559,10 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu
     }
     if (verdict_only) return;
     const int cell_bytes = 16 + 8 * plan.n_acc; int cbits = 12; while (cbits > 6 && (((size_t)1 << cbits) + 1) * cell_bytes > 150 * 1024) cbits--;
-    const double per_part = ((double)(1u << cbits)) * 0.55;
+    // groups a partition may hold: 0.55 of the table, and not more than the table takes before the kernel flushes it early (k_pa_aggregate: nfilled + PA_NT > C - C / 8 --
+    // with five or six cells the table has 2048 slots and that bound, 768, is the smaller one: at 0.55 x 2048 every partition was cut and its keys left in two partial rows)
+    const double table = (double)(1u << cbits), room = table - table / 8 - (double)PA_NT;
+    const double per_part = room > 0 && 0.85 * room < 0.55 * table ? 0.85 * room : 0.55 * table;
     const double Dp = D > 4.0 * d ? D : 4.0 * d;          // skewed keys: the uniform model underestimates the tail, stay on the many-partitions side
     int64_t P = (int64_t)(Dp / per_part) + 1; if (P < 64) P = 64;
     // beyond 2048 partitions one pass writes bursts too short to pay (measured: P = 8192 slower than the atomics it replaces): two passes, P1 x P2

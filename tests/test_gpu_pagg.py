@@ -570,6 +570,9 @@ def test_many_partition_scatter_staged_in_two_rounds(ctx):
     kinds = [KIND["SUM"], KIND["MAX"], KIND["SUM"], KIND["AVG"], KIND["COUNT"]]
     vals = [cols[0], cols[0], cols[1], cols[2], None]
     casts = [0, 0, 0, capi.FLOAT64, 0]
+    # six accumulator cells leave 2048 table slots per partition: partitions flush before their end, a key comes back in several partial rows, and where the cuts fall
+    # depends on the order the LDS-atomic ranks gave the rows -- so the comparison is made after intern + merge_batch (what the plan layer does), not on the partial rows
+    in_types = [(capi.INT64, 0, 0), (capi.INT64, 0, 0), (capi.DECIMAL128, 30, 2), (capi.FLOAT64, 0, 0), (capi.INT64, 0, 0)]
     out = []
     for on in (1, 0):
         ctx.set_option("partition_two_round_staging", on)
@@ -579,13 +582,22 @@ def test_many_partition_scatter_staged_in_two_rounds(ctx):
                 assert "pa_scatter" in f.kernels()
         finally:
             ctx.set_option("partition_two_round_staging", 1)
-        out.append((pk.to_arrow(), [[s.to_arrow() for s in st] for st in states]))
-    (k1, s1), (k0, s0) = out
-    assert k1.equals(k0)
-    for a, b in zip(s1, s0):
-        for u, v in zip(a, b):
-            assert u.equals(v)
-    # against the oracle: groups in first-seen order, SUM / MAX / COUNT exact
+        gv = dfgpu.GroupValues(ctx, 1); gids = gv.intern([pk]); res = []
+        for kind, (t, p_, s_), st in zip(kinds, in_types, states):
+            acc = dfgpu.GroupsAccumulator(ctx, kind, t, p_, s_); acc.merge_batch(st, gids, None, len(gv)); res.append(acc.evaluate().to_arrow())
+        out.append((gv.emit()[0].to_arrow(), res))
+    (k1, r1), (k0, r0) = out
+    o1, o0 = np.argsort(k1.to_numpy(), kind="stable"), np.argsort(k0.to_numpy(), kind="stable")          # group order follows the first partial row of a key: compare by key
+    assert np.array_equal(k1.to_numpy()[o1], k0.to_numpy()[o0]) and len(k1) == len(np.unique(k1.to_numpy()))
+    for a, b in zip(r1, r0):
+        x, y = a.take(pa.array(o1)), b.take(pa.array(o0))
+        if pa.types.is_floating(x.type):
+            assert x.is_null().equals(y.is_null()) and np.allclose(x.fill_null(0).to_numpy(), y.fill_null(0).to_numpy(), rtol=FLOAT_RTOL, atol=0.0)
+        else:
+            assert x.equals(y)
+    # against the oracle's row-by-row update: SUM / MAX of the nullable column and COUNT(*) exact
     wk, want = run_oracle(key, [("SUM", vi), ("MAX", vi), ("COUNT", None)])
-    assert k1.equals(wk)
-    assert s1[0][0].equals(want[0]) and s1[1][0].equals(want[1]) and s1[4][0].cast(pa.int64()).equals(want[2].cast(pa.int64()))
+    ow = np.argsort(wk.to_numpy(), kind="stable")
+    assert np.array_equal(k1.to_numpy()[o1], wk.to_numpy()[ow])
+    for got, w in zip((r1[0], r1[1], r1[4]), want):
+        assert got.take(pa.array(o1)).cast(pa.int64()).equals(w.take(pa.array(ow)).cast(pa.int64()))
