@@ -92,7 +92,7 @@ struct dfgpu_ctx {
   int64_t sort_topk_words_min_rows = 1 << 23;                  // SortExec with fetch <= n / 16: from this many rows on (keys packing into a word with the row number) the radix select runs on the packed words; below, on byte planes
   int64_t sort_one_block_max_rows = 8192;                      // byte-plane sorts of at most this many rows (<= 8192): every pass inside one launch of one workgroup; 0 = off
   int64_t sort_onesweep_min_rows = 1 << 20;
-  bool partition_two_round_staging = true;                     // radix partition into 513 .. 2048 partitions: every column staged in two rounds of half a tile (74 KB of LDS: two workgroups per CU)
+  bool partition_two_round_staging = false;                    // radix partition into 513 .. 2048 partitions: every column staged in two rounds of half a tile (74 KB of LDS: two workgroups per CU).  Off: measured slower -- twice the barriers and predicated loads cost more than the second workgroup brings (ClickBench uniform: scatter 1.79 -> 2.44 ms; three-key Decimal128 group-by 1.49 -> 1.99 ms; 1 M Int64 groups 1.26 -> 1.43 ms)
   bool sort_payload_in_last_pass = false;                      // dfgpu_sort_take: the last one-sweep pass gathers the payload columns (else the caller's take() does, afterwards).  Off: measured slower (100 M rows, one 8-byte payload column: passes + gather 6.36 ms inside the last pass against 3.89 + 2.13 ms apart; both sides are bound by memory requests, the random reads in the scatter phase only slow the pass down)
   bool sort_onesweep_fused_finish = true;                      // the last one-sweep pass writes row numbers and rebuilt key columns instead of the words (no k_pk_finish pass)
   int sort_onesweep_rows = 16;                                  // word-mode sorts of 2^20 .. 2^30 rows: one launch per pass (look-back over published tile counts, sort.hip); rows per lane of a tile (8 or 16), 0 = the three-launch passes

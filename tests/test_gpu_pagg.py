@@ -555,8 +555,8 @@ def test_the_mark_stays_on_the_sorts_own_copy_of_the_aggregation(ctx):
 
 
 def test_many_partition_scatter_staged_in_two_rounds(ctx):
-    """513 .. 2048 partitions: the 8192-row tile's columns are staged in two rounds of half a tile (two workgroups per CU).  Same partial rows, same first-seen order and states
-    as with the whole tile staged at once (option partition_two_round_staging = 0) and as the oracle's row-by-row update; a Decimal128 argument (two 8-byte halves per row), a
+    """513 .. 2048 partitions: the 8192-row tile's columns staged in two rounds of half a tile (two workgroups per CU; option partition_two_round_staging, off by default --
+    measured slower) give the same merged groups and states as the whole tile staged at once and as the oracle's row-by-row update; a Decimal128 argument (two 8-byte halves per row), a
     nullable Int64 one (flag byte column) and an Int32 one cast on the way."""
     import dfgpu
     from dfgpu import capi
@@ -581,7 +581,7 @@ def test_many_partition_scatter_staged_in_two_rounds(ctx):
                 pk, states = dfgpu.agg_preaggregate(ctx, kd, kinds, vals, casts=casts)
                 assert "pa_scatter" in f.kernels()
         finally:
-            ctx.set_option("partition_two_round_staging", 1)
+            ctx.set_option("partition_two_round_staging", 0)
         gv = dfgpu.GroupValues(ctx, 1); gids = gv.intern([pk]); res = []
         for kind, (t, p_, s_), st in zip(kinds, in_types, states):
             acc = dfgpu.GroupsAccumulator(ctx, kind, t, p_, s_); acc.merge_batch(st, gids, None, len(gv)); res.append(acc.evaluate().to_arrow())
