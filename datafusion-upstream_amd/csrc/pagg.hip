@@ -168,60 +168,6 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
       }
     }
   };
-  // one row (or one combined group of rows) into the table: find or claim the key's slot, then the count, the first row and the cells; -> the slot was claimed by this call
-  auto insert = [&](uint64_t k, uint32_t cntv, uint32_t rowv, const uint64_t* v) -> bool {
-    uint32_t s = C; bool fresh = false;
-    if (k != PA_EMPTY) {
-      s = pa_slot(k, cbits);
-      for (;;) {
-        unsigned long long old = keys[s];
-        if (old == PA_EMPTY) { old = atomicCAS(&keys[s], (unsigned long long)PA_EMPTY, (unsigned long long)k); if (old == PA_EMPTY) { fresh = true; break; } }
-        if (old == k) break;
-        s = (s + 1) & M;
-      }
-    }
-    if (rowv < first[s]) atomicMin(&first[s], rowv);           // a stale read only costs a redundant atomic
-    atomicAdd(&cnt[s], cntv);
-#pragma unroll
-    for (int a = 0; a < PA_MAX_AGGS; a++) if (a < na) {
-      const int op = plan_arg.op[a];
-      if (!I128) pa_apply(op, &acc[(size_t)a * C1 + s], v[a]);
-      else if (op == PA_SUM_I128_LO && plan_arg.op[a + 1 < PA_MAX_AGGS ? a + 1 : a] == PA_SUM_I128_SX) {            // value = sign-extended 64 bits
-        const int ah = a + 1 < PA_MAX_AGGS ? a + 1 : a;
-        const unsigned long long lo = v[a], old = atomicAdd(&acc[(size_t)a * C1 + s], lo);
-        const unsigned long long hi = (unsigned long long)((long long)lo >> 63) + (unsigned long long)(old + lo < old);
-        if (hi) atomicAdd(&acc[(size_t)ah * C1 + s], hi);
-      } else if (op == PA_SUM_I128_LO) {            // a + 1 is the high word's cell
-        const int ah = a + 1 < PA_MAX_AGGS ? a + 1 : a;      // a LO cell is never the last one (the host lays pairs out); the clamp keeps the unrolled index in range
-        const unsigned long long lo = v[a], old = atomicAdd(&acc[(size_t)a * C1 + s], lo);
-        const unsigned long long hi = v[ah] + (unsigned long long)(old + lo < old);
-        if (hi) atomicAdd(&acc[(size_t)ah * C1 + s], hi);
-      } else if (op != PA_SUM_I128_HI && op != PA_SUM_I128_SX) pa_apply(op, &acc[(size_t)a * C1 + s], v[a]);
-    }
-    return fresh;
-  };
-  // the wave's hot key and every lane's own accumulators for it (see the loop)
-  uint64_t hk = 0; bool has_hk = false; uint64_t pv[PA_MAX_AGGS]; uint32_t pcnt = 0, prowmin = 0xFFFFFFFFu;
-#pragma unroll
-  for (int a = 0; a < PA_MAX_AGGS; a++) pv[a] = a < na ? pa_identity(plan_arg.op[a]) : 0ull;
-  auto flush_private = [&]() {          // wave-uniform: the lanes' accumulators of the hot key -> one table update by lane 0
-    if (!has_hk) return;
-    uint32_t tot = pcnt, r = prowmin;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { tot += (uint32_t)__shfl_xor((int)tot, d, 64); const uint32_t o = (uint32_t)__shfl_xor((int)r, d, 64); r = o < r ? o : r; }
-    if (tot) {
-      uint64_t x[PA_MAX_AGGS];
-#pragma unroll
-      for (int a = 0; a < PA_MAX_AGGS; a++) { x[a] = pv[a]; if (a < na) {
-        const int op = plan_arg.op[a];
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x[a], d, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x[a] >> 32), d, 64); x[a] = pa_combine(op, x[a], ((uint64_t)hi << 32) | lo); } } }
-      if (lane == 0 && insert(hk, tot, r, x)) atomicAdd(&nfilled, 1u);
-    }
-    pcnt = 0; prowmin = 0xFFFFFFFFu;
-#pragma unroll
-    for (int a = 0; a < PA_MAX_AGGS; a++) pv[a] = a < na ? pa_identity(plan_arg.op[a]) : 0ull;
-  };
   { const uint32_t i = q0 + threadIdx.x, ic = i < q1 ? i : q1 - 1; kn = pkey[ic]; rn = prow ? prow[ic] : 0u; load_cells(ic, vn); }
   for (uint32_t i0 = q0; i0 < q1; i0 += PA_NT) {
     if (nfilled + PA_NT > C - C / 8) { __syncthreads(); flush(); reset(); if (threadIdx.x == 0) atomicAdd(cursor + 2, 1ull); __syncthreads(); }      // nfilled is only written between barriers: uniform
@@ -231,36 +177,67 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
 #pragma unroll
     for (int a = 0; a < PA_MAX_AGGS; a++) v[a] = vn[a];
     { const uint32_t i2 = i + PA_NT, ic = i2 < q1 ? i2 : q1 - 1; kn = pkey[ic]; rn = prow ? prow[ic] : 0u; load_cells(ic, vn); }
-    // Skewed keys.  When at least 16 lanes of a wave carry one key (the key of the first active lane that does not carry the wave's current hot key), it becomes the wave's
-    // hot key: from then on every lane that meets it adds the row to accumulators of its OWN (registers: no shuffle, no LDS), and only when another key takes over, or at
-    // the end of the slice, are the lanes' accumulators combined (shuffles) and added to the table by one lane.  A partition dominated by one key -- the hot partitions of
-    // Zipf-distributed keys, cut into slices, and the partition of every key ranked in the first hundreds -- costs a compare and a few adds per row of that key.  (Combining
-    // the leader's lanes by shuffles in every iteration, the round-2 form, made exactly those rows the most expensive ones: 36 ds_bpermute per 64 rows.)
+    // Skewed keys: when at least 16 lanes of a wave carry the key of its first active lane, those lanes are combined in registers (shuffles) and the leader
+    // alone touches the table: one LDS atomic per state instead of one per row on a slot every wave of the workgroup is hammering.  (Trying the last combined key
+    // first -- a key with a fifth to a half of its partition's rows sits in the first lane only that often -- was measured on the Zipf ClickBench shape and changed
+    // nothing: 2.34 -> 2.49 ms, round 4 call r; the partitions there hold several warm keys each, not one.  Keeping the hot key's rows in accumulators of the lanes' own
+    // and combining them once, when another key takes over or the slice ends, was tried as well (call aa): Zipf 2.36 -> 2.16 ms, but every other shape lost 10-30 % to the
+    // longer loop body -- uniform ClickBench 1.07 -> 1.27 ms, 20 M groups 1.64 -> 1.75, three keys + Decimal128 1.04 -> 1.35 -- and it was taken out again.)
     uint32_t cntv = 1; uint32_t rowv = row; bool mine = on;
-    if constexpr (!I128) {
+    {
       const uint64_t act = ballot64(on);
-      bool member = has_hk && on && k == hk;
-      uint64_t mem = ballot64(member);
-      if (__popcll(mem) < 16 && (act & ~mem)) {
-        const int lead = __ffsll((long long)(act & ~mem)) - 1;
-        const uint32_t k0lo = (uint32_t)__shfl((int)(uint32_t)k, lead, 64), k0hi = (uint32_t)__shfl((int)(uint32_t)(k >> 32), lead, 64);
-        const uint64_t k0 = ((uint64_t)k0hi << 32) | k0lo;
-        const bool member0 = on && k == k0;
-        if (__popcll(ballot64(member0)) >= 16) { flush_private(); hk = k0; has_hk = true; member = member0; }
-      }
-      if (member) {
-        pcnt++; prowmin = row < prowmin ? row : prowmin; mine = false;
+      const int lead = act ? __ffsll((long long)act) - 1 : 0;
+      const uint32_t k0lo = (uint32_t)__shfl((int)(uint32_t)k, lead, 64), k0hi = (uint32_t)__shfl((int)(uint32_t)(k >> 32), lead, 64);
+      const bool member = on && (uint32_t)k == k0lo && (uint32_t)(k >> 32) == k0hi;
+      const uint64_t mem = ballot64(member);
+      if (__popcll(mem) >= 16 && !I128) {
+        uint32_t r = member ? row : 0xFFFFFFFFu;
 #pragma unroll
-        for (int a = 0; a < PA_MAX_AGGS; a++) if (a < na) pv[a] = pa_combine(plan_arg.op[a], pv[a], v[a]);
+        for (int d = 32; d > 0; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)r, d, 64); r = o < r ? o : r; }
+#pragma unroll
+        for (int a = 0; a < PA_MAX_AGGS; a++) if (a < na) {
+          const int op = plan_arg.op[a]; uint64_t x = member ? v[a] : pa_identity(op);
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) { uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, d, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), d, 64); x = pa_combine(op, x, ((uint64_t)hi << 32) | lo); }
+          if (lane == lead) v[a] = x;
+        }
+        if (lane == lead) { cntv = (uint32_t)__popcll(mem); rowv = r; } else if (member) mine = false;
       }
     }
-    bool fresh = false;
-    if (mine) fresh = insert(k, cntv, rowv, v);
+    uint32_t s = C; bool fresh = false;
+    if (mine) {
+      if (k != PA_EMPTY) {
+        s = pa_slot(k, cbits);
+        for (;;) {
+          unsigned long long old = keys[s];
+          if (old == PA_EMPTY) { old = atomicCAS(&keys[s], (unsigned long long)PA_EMPTY, (unsigned long long)k); if (old == PA_EMPTY) { fresh = true; break; } }
+          if (old == k) break;
+          s = (s + 1) & M;
+        }
+      }
+      if (rowv < first[s]) atomicMin(&first[s], rowv);           // a stale read only costs a redundant atomic
+      atomicAdd(&cnt[s], cntv);
+#pragma unroll
+      for (int a = 0; a < PA_MAX_AGGS; a++) if (a < na) {
+        const int op = plan_arg.op[a];
+        if (!I128) pa_apply(op, &acc[(size_t)a * C1 + s], v[a]);
+        else if (op == PA_SUM_I128_LO && plan_arg.op[a + 1 < PA_MAX_AGGS ? a + 1 : a] == PA_SUM_I128_SX) {            // value = sign-extended 64 bits
+          const int ah = a + 1 < PA_MAX_AGGS ? a + 1 : a;
+          const unsigned long long lo = v[a], old = atomicAdd(&acc[(size_t)a * C1 + s], lo);
+          const unsigned long long hi = (unsigned long long)((long long)lo >> 63) + (unsigned long long)(old + lo < old);
+          if (hi) atomicAdd(&acc[(size_t)ah * C1 + s], hi);
+        } else if (op == PA_SUM_I128_LO) {            // a + 1 is the high word's cell
+          const int ah = a + 1 < PA_MAX_AGGS ? a + 1 : a;      // a LO cell is never the last one (the host lays pairs out); the clamp keeps the unrolled index in range
+          const unsigned long long lo = v[a], old = atomicAdd(&acc[(size_t)a * C1 + s], lo);
+          const unsigned long long hi = v[ah] + (unsigned long long)(old + lo < old);
+          if (hi) atomicAdd(&acc[(size_t)ah * C1 + s], hi);
+        } else if (op != PA_SUM_I128_HI && op != PA_SUM_I128_SX) pa_apply(op, &acc[(size_t)a * C1 + s], v[a]);
+      }
+    }
     uint64_t fb = ballot64(fresh);
     if (lane == 0 && fb) atomicAdd(&nfilled, (uint32_t)__popcll(fb));
     __syncthreads();
   }
-  if constexpr (!I128) { flush_private(); __syncthreads(); }
   flush();
 }
 
