@@ -120,6 +120,15 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
  * "sort_fused_small_passes" (1/0) == sorts below 2^20 rows fold every pass's offset scan into its scatter (identical indices);
  * "sort_packed_keys" (1/0) == let sort_to_indices sort large inputs over fixed-width keys through range-packed 64-bit keys (identical indices);
  * "sort_estimate_ranges" (1/0) == from 2^22 rows on, take those ranges from a sample and check them while packing (a miss repeats the step with exact ranges; identical indices);
+ * "sort_onesweep_rows" (16 / 8 / 0, default 16), "sort_onesweep_min_rows" (default 2^20), "sort_onesweep_fused_finish" (1/0) == packed-key sorts whose key and row number share
+ * one 64-bit word run every LSD pass as ONE launch (tile offsets by look-back over the digit counts the tiles in front have published; histograms counted while the words are
+ * encoded; tiles of 16 x 512 rows from 2 M rows on, else 8 x 512; 0 = the three-launch passes), the last pass writing row numbers and rebuilt key columns itself (identical indices);
+ * "sort_topk_words_min_rows" (default 2^23) == a sort with fetch <= n / 16 over at least this many rows whose keys pack selects on the packed keys (radix select, then the
+ * few candidates sorted) instead of on byte planes (identical indices); "sort_one_block_max_rows" (default 8192, 0 = off) == byte-plane sorts of at most this many rows run
+ * every pass inside one launch of one workgroup (identical indices); "sort_payload_in_last_pass" (0/1, default 0) == dfgpu_sort_take gathers payload columns in the sort's last
+ * pass (measured slower than the gather afterwards; kept for A/B);
+ * "partition_two_round_staging" (0/1, default 0) == the radix partition into 513 .. 2048 partitions stages every column in two rounds of half a tile, two workgroups per CU
+ * (same rows in the same partitions; measured slower, kept for A/B);
  * "memory_limit" (bytes, 0 = none) == live device memory this ctx may hold; an allocation beyond it fails with DFGPU_RESOURCES_EXHAUSTED and the
  * message of MemoryPool::try_grow (≙ RuntimeConfig::with_memory_limit, execution/src/runtime_env.rs); "live_bytes" / "cached_bytes" (read only);
  * "agg_spill_state_bytes" (0 = never) == the state size (group table + accumulators) above which AggregateExec spills to host memory (non-Partial modes,
