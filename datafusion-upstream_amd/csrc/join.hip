@@ -642,7 +642,15 @@ __global__ void __launch_bounds__(BLOCK) k_key_minmax_masked(const T* keys, cons
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_key_gather_minmax(const T* keys, const uint32_t* rows, const unsigned long long* d_count, T* ckeys, long long* mn, long long* mx) {
   const int64_t m = (int64_t)*d_count; long long lo = INT64_MAX, hi = INT64_MIN;
-  for (int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x; j < m; j += (int64_t)gridDim.x * BLOCK) { const T k = keys[rows[j]]; ckeys[j] = k; const long long v = (long long)k; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+  // four gathers in flight per lane; the grid is at most 4 workgroups per CU because every workgroup that saw a row ends with two atomics on ONE address each (4096 workgroups:
+  // 8192 serialised atomics = 105 us for 1.8 M rows, profiles/r04_shuffled_timeline_sf12.5.txt)
+  for (int64_t j0 = ((int64_t)blockIdx.x * BLOCK) * 4 + threadIdx.x; j0 < m; j0 += (int64_t)gridDim.x * BLOCK * 4) {
+    T k[4]; bool on[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int64_t j = j0 + (int64_t)q * BLOCK; on[q] = j < m; k[q] = on[q] ? keys[rows[j]] : (T)0; }
+#pragma unroll
+    for (int q = 0; q < 4; q++) if (on[q]) { ckeys[j0 + (int64_t)q * BLOCK] = k[q]; const long long v = (long long)k[q]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+  }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { long long a = __shfl_xor(lo, d, 64), b = __shfl_xor(hi, d, 64); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
   __shared__ long long slo[BLOCK / WAVE], shi[BLOCK / WAVE];
@@ -674,7 +682,7 @@ static bool build_rank_index_unsorted(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   BufferPtr ck; const void* ckp = nullptr;
   if (rl) {
     ck = alloc_buffer(ctx, (size_t)n * type_width(key0->type) + 16); ckp = ck->ptr;
-    DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_gather_minmax<T>), dim3(lgrid), dim3(BLOCK), 0, ctx->stream, (const T*)key0->values->ptr, rl, dcount, (T*)ck->ptr,
+    DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_gather_minmax<T>), dim3(grid_for(n, BLOCK * 4, ctx->num_cus * 4)), dim3(BLOCK), 0, ctx->stream, (const T*)key0->values->ptr, rl, dcount, (T*)ck->ptr,
                                                           (long long*)(ctx->d_scratch64 + 4), (long long*)(ctx->d_scratch64 + 5)));
   } else
   DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_minmax_masked<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 4)), dim3(BLOCK), 0, ctx->stream, (const T*)key0->values->ptr,
