@@ -679,27 +679,18 @@ static bool build_rank_index_unsorted(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   HIP_CHECK(hipMemcpyAsync(ctx->d_scratch64 + 4, init, 16, hipMemcpyHostToDevice, ctx->stream));
   // masked: the selected keys are gathered ONCE (with their min / max) into a compact column; setting the bits and ranking the rows then read it in order instead of
   // gathering the same scattered 8 bytes two more times (three random passes over 15 M of 150 M orders cost 0.8 ms, one costs 0.27)
-  const auto st0 = order_stats_get(key0);
-  const bool bounds_known = st0 && st0->lo <= st0->hi && (uint64_t)st0->hi - (uint64_t)st0->lo + 1 <= (uint64_t)n * 256 + 65536;
   BufferPtr ck; const void* ckp = nullptr;
   if (rl) {
     ck = alloc_buffer(ctx, (size_t)n * type_width(key0->type) + 16); ckp = ck->ptr;
     DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_gather_minmax<T>), dim3(grid_for(n, BLOCK * 4, ctx->num_cus * 4)), dim3(BLOCK), 0, ctx->stream, (const T*)key0->values->ptr, rl, dcount, (T*)ck->ptr,
                                                           (long long*)(ctx->d_scratch64 + 4), (long long*)(ctx->d_scratch64 + 5)));
-  } else if (!bounds_known)
+  } else
   DFGPU_INT_KEY_DISPATCH(key0->type, hipLaunchKernelGGL((k_key_minmax_masked<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 4)), dim3(BLOCK), 0, ctx->stream, (const T*)key0->values->ptr,
                                                         (const uint64_t*)nullptr, mk, n, (long long*)(ctx->d_scratch64 + 4), (long long*)(ctx->d_scratch64 + 5), rl, dcount));
   KERNEL_CHECK();
-  // The bitmap's domain: the column's own bounds when its order statistics are on file (build_rank_index measured them, or they were inherited through a gather) -- bounds
-  // of the column hold for every selection of its rows, and a domain somewhat wider than the selected keys' costs bitmap bytes, not a host round trip; else the selected
-  // keys' min / max, read back.
-  long long lo, hi;
-  if (bounds_known) { lo = st0->lo; hi = st0->hi; }
-  else {
-    ctx->count_sync("sync:rank_index_range"); fetch_to_pinned(ctx, 4, ctx->d_scratch64 + 4, 16);
-    lo = (long long)ctx->h_pinned[4]; hi = (long long)ctx->h_pinned[5];
-    t->have_minmax = true; t->sel_min = lo; t->sel_max = hi;
-  }
+  ctx->count_sync("sync:rank_index_range"); fetch_to_pinned(ctx, 4, ctx->d_scratch64 + 4, 16);
+  const long long lo = (long long)ctx->h_pinned[4], hi = (long long)ctx->h_pinned[5];
+  t->have_minmax = true; t->sel_min = lo; t->sel_max = hi;
   if (lo > hi) return false;                               // no selected row
   const uint64_t range = (uint64_t)hi - (uint64_t)lo + 1;
   if (range == 0 || range > (1ull << 32) || range > (uint64_t)n * 256 + 65536) return false;       // sparser domains are the partitioned join's (pj_domain_is_sparse draws the same line)
