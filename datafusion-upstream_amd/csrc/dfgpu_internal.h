@@ -131,6 +131,9 @@ namespace dfgpu { struct DeferredIds;
 // Order statistics of an integer column without NULLs (arrays are immutable, so they are a memo like null_count): known once a pass has looked (k_check_increasing), or derived --
 // a gather of a sorted column through strictly ascending indices is sorted and lies inside the source's bounds (exact = false: lo / hi bound the values, not necessarily tight).
 // The join build's rank index asks for them; a base-table key column answers from the memo, its filtered / joined descendants from the derivation.
+// lo / hi: the first and the last element as measured (order_stats_measure) -- the minimum and maximum of a SORTED column, bounds of everything gathered from it by ascending
+// row numbers; for an unsorted column they bound nothing (using them as the domain of an unsorted rank index was tried in round 4 and faulted: the selected keys' own min / max
+// are read back there)
 struct OrderStats { bool sorted = false, repeats = false, exact = false; int64_t lo = 0, hi = 0; };
 }
 struct dfgpu_array {
