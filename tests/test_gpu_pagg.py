@@ -630,9 +630,7 @@ def test_hot_keys_are_summed_by_a_pass_of_their_own(ctx, first_seen):
         finally:
             ctx.set_option("agg_hot_keys", 1)
         assert "pa_aggregate" in ran and ("pa_hot" in ran) == bool(on)
-        if on:                                                                  # a hot key has no row left in any partition: it comes back exactly once (others may be cut into slices)
-            pkn = pk.to_numpy(); top = keys[mask][:100000]; hot3 = [int(v) for v in np.bincount(((top - 1) // 3).astype(np.int64)).argsort()[-3:] * 3 + 1]
-            assert all(int((pkn == h).sum()) == 1 for h in hot3), hot3
+        assert len(pk) == len(np.unique(pk.to_numpy()))                     # a hot key has no row left in any partition: every key still comes back once
         gv = dfgpu.GroupValues(ctx, 1); gids = gv.intern([pk]); res = []
         for kind, (t, p_, s_), st in zip(kinds, in_types, states):
             acc = dfgpu.GroupsAccumulator(ctx, kind, t, p_, s_); acc.merge_batch(st, gids, None, len(gv)); res.append(acc.evaluate().to_arrow())
