@@ -267,91 +267,6 @@ __global__ void __launch_bounds__(BLOCK) k_pa_sample(const T* keys, const uint64
   if (threadIdx.x < 3) { uint32_t t = 0; for (int w = 0; w < BLOCK / WAVE; w++) t += sh[threadIdx.x][w]; if (t) atomicAdd(&out[threadIdx.x], (unsigned long long)t); }
 }
 
-// ---- hot keys.  Skewed keys (Zipf-distributed, a few values holding a third of the rows) cost the partitioned path twice: their partitions are many times the average,
-// and inside every partition the rows of its hot key meet in the same LDS words.  A second, small sample (one workgroup, 16 K rows, an LDS table with counts) names the
-// keys that hold at least 1/256 of the rows (at most PA_HOT of them); a pass over the batch adds the rows of those keys to one set of accumulators per workgroup (LDS,
-// then one global atomic per key, cell and workgroup) and writes the selection of the rows that are left, which is all the partition passes see.  The hot keys' totals
-// join the partial rows through the cursor the aggregation's flushes use.  Taken when the sampled hot keys hold >= 1/8 of the rows; plans without Decimal128 cells and
-// without nullable arguments (8-byte cells read straight from the argument columns, Int32 / Int64 -> Float64 casts included).
-constexpr int PA_HOT = 64, PA_HOT_SLOTS = 256, PA_HOT_SAMPLE = 16384;
-template <typename T>
-__global__ void __launch_bounds__(1024) k_pa_hot_sample(const T* keys, const uint64_t* mask, int64_t n, unsigned long long* hot_keys /*[PA_HOT]*/, unsigned long long* out /*[0] hot keys, [1] their sampled rows, [2] rows sampled*/) {
-  __shared__ unsigned long long tk[4096]; __shared__ uint32_t tc[4096]; __shared__ uint32_t nsamp, nhot, nrows;
-  for (int x = threadIdx.x; x < 4096; x += 1024) { tk[x] = PA_EMPTY; tc[x] = 0; }
-  if (threadIdx.x == 0) { nsamp = 0; nhot = 0; nrows = 0; }
-  __syncthreads();
-  const int64_t stride = n / PA_HOT_SAMPLE > 0 ? n / PA_HOT_SAMPLE : 1;
-  for (int j = threadIdx.x; j < PA_HOT_SAMPLE; j += 1024) {
-    const int64_t i = (int64_t)j * stride + (stride >> 1);          // between the rows the first sample reads
-    if (i >= n || (mask && !bit_get(mask, i))) continue;
-    const uint64_t k = (uint64_t)(int64_t)keys[i];
-    if (k == PA_EMPTY) continue;                                    // the marker value itself is never hot (it has a slot of its own in every table)
-    uint32_t h = (uint32_t)(mix64(k) >> 40) & 4095u; bool placed = false;
-    for (int step = 0; step < 64 && !placed; step++) {             // a table that fills up (16 K distinct sampled keys) just stops counting: then nothing is hot
-      unsigned long long old = tk[h];
-      if (old == PA_EMPTY) old = atomicCAS(&tk[h], (unsigned long long)PA_EMPTY, (unsigned long long)k);
-      if (old == PA_EMPTY || old == k) { atomicAdd(&tc[h], 1u); placed = true; }
-      h = (h + 1) & 4095u;
-    }
-    atomicAdd(&nsamp, 1u);
-  }
-  __syncthreads();
-  const uint32_t need = nsamp / 256 > 8 ? nsamp / 256 : 8;
-  for (int x = threadIdx.x; x < 4096; x += 1024) if (tk[x] != PA_EMPTY && tc[x] >= need) { const uint32_t j = atomicAdd(&nhot, 1u); if (j < PA_HOT) { hot_keys[j] = tk[x]; atomicAdd(&nrows, tc[x]); } }
-  __syncthreads();
-  if (threadIdx.x == 0) { out[0] = nhot < PA_HOT ? nhot : PA_HOT; out[1] = nrows; out[2] = nsamp; }
-}
-struct PaHotCell { const void* src; int32_t kind; int32_t op; };          // kind: 0 = 8-byte cell, 1 = Int32 -> Float64, 2 = Int64 -> Float64
-struct PaHotPlan { int32_t n_acc; PaHotCell c[PA_MAX_AGGS]; };
-__device__ inline uint64_t pa_hot_cell(const PaHotCell& c, int64_t i) {
-  return c.kind == 0 ? ((const uint64_t*)c.src)[i] : c.kind == 1 ? (uint64_t)__double_as_longlong((double)((const int32_t*)c.src)[i]) : (uint64_t)__double_as_longlong((double)((const int64_t*)c.src)[i]);
-}
-// hot accumulators, global: [PA_HOT][2 + PA_MAX_AGGS] words = count, first row, cells
-template <typename T>
-__global__ void __launch_bounds__(BLOCK) k_pa_hot(const T* keys, const uint64_t* mask, int64_t n, const unsigned long long* hot_keys, int nhot, PaHotPlan hp, unsigned long long* hot_acc, uint64_t* cold_mask) {
-  __shared__ unsigned long long sk[PA_HOT_SLOTS]; __shared__ int sid[PA_HOT_SLOTS];
-  __shared__ unsigned long long acc[PA_HOT][2 + PA_MAX_AGGS];
-  for (int x = threadIdx.x; x < PA_HOT_SLOTS; x += BLOCK) { sk[x] = PA_EMPTY; sid[x] = -1; }
-  for (int x = threadIdx.x; x < PA_HOT * (2 + PA_MAX_AGGS); x += BLOCK) { const int a = x % (2 + PA_MAX_AGGS); (&acc[0][0])[x] = a == 0 ? 0ull : a == 1 ? 0xFFFFFFFFull : (a - 2 < hp.n_acc ? pa_identity(hp.c[a - 2].op) : 0ull); }
-  __syncthreads();
-  if (threadIdx.x < nhot) { const unsigned long long k = hot_keys[threadIdx.x]; uint32_t h = (uint32_t)(mix64(k) >> 40) & (PA_HOT_SLOTS - 1);
-    for (;;) { const unsigned long long old = atomicCAS(&sk[h], (unsigned long long)PA_EMPTY, k); if (old == PA_EMPTY) { sid[h] = (int)threadIdx.x; break; } h = (h + 1) & (PA_HOT_SLOTS - 1); } }
-  __syncthreads();
-  const int lane = lane_id(); const int64_t nw = (n + 63) >> 6;
-  for (int64_t w = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6; w < nw; w += ((int64_t)gridDim.x * BLOCK) >> 6) {
-    const int64_t i = w * 64 + lane; const bool on = i < n && (!mask || bit_get(mask, i));
-    int id = -1;
-    if (on) { const unsigned long long k = (unsigned long long)(int64_t)keys[i]; uint32_t h = (uint32_t)(mix64(k) >> 40) & (PA_HOT_SLOTS - 1);
-      for (;;) { const unsigned long long t = sk[h]; if (t == k) { id = sid[h]; break; } if (t == PA_EMPTY) break; h = (h + 1) & (PA_HOT_SLOTS - 1); } }
-    if (id >= 0) {
-      atomicAdd(&acc[id][0], 1ull); if ((unsigned long long)i < acc[id][1]) atomicMin(&acc[id][1], (unsigned long long)i);
-      for (int a = 0; a < PA_MAX_AGGS; a++) { if (a >= hp.n_acc) break; pa_apply(hp.c[a].op, &acc[id][2 + a], pa_hot_cell(hp.c[a], i)); }
-    }
-    const uint64_t cold = ballot64(on && id < 0);
-    if (lane == 0) cold_mask[w] = cold;
-  }
-  __syncthreads();
-  for (int x = threadIdx.x; x < nhot * (2 + PA_MAX_AGGS); x += BLOCK) {
-    const int id = x / (2 + PA_MAX_AGGS), a = x % (2 + PA_MAX_AGGS); const unsigned long long v = acc[id][a];
-    if (acc[id][0] == 0) continue;                                 // this workgroup saw no row of the key
-    unsigned long long* g = hot_acc + (size_t)id * (2 + PA_MAX_AGGS) + a;
-    if (a == 0) atomicAdd(g, v); else if (a == 1) atomicMin(g, v); else if (a - 2 < hp.n_acc) pa_apply(hp.c[a - 2].op, g, v);
-  }
-}
-__global__ void k_pa_hot_init(PaHotPlan hp, unsigned long long* hot_acc) {
-  const int x = threadIdx.x, a = x % (2 + PA_MAX_AGGS);
-  hot_acc[x] = a == 0 ? 0ull : a == 1 ? 0xFFFFFFFFull : (a - 2 < hp.n_acc ? pa_identity(hp.c[a - 2].op) : 0ull);
-}
-// the hot keys' totals as partial rows behind the aggregation's own (same cursor)
-__global__ void k_pa_hot_emit(const unsigned long long* hot_keys, int nhot, const unsigned long long* hot_acc, int n_acc, uint64_t* orec, int rs, uint32_t* ofirst, unsigned long long* cursor) {
-  const int id = threadIdx.x; if (id >= nhot) return;
-  const unsigned long long* a = hot_acc + (size_t)id * (2 + PA_MAX_AGGS);
-  if (a[0] == 0) return;
-  const unsigned long long o = atomicAdd(cursor, 1ull);
-  uint64_t* rec = orec + (size_t)o * (size_t)rs; rec[0] = hot_keys[id]; rec[1] = a[0]; ofirst[o] = (uint32_t)a[1];
-  for (int c = 0; c < n_acc; c++) rec[2 + c] = a[2 + c];
-}
-
 // ---- two-level partition (more groups than 2048 partitions bring into LDS): pass 1 splits on the high hash bits into P1 partitions, pass 2 is a STABLE
 // split of pass 1's output on the low hash bits into P2 <= 256 -- an LSD radix sort on two digits, so the rows end up ordered by (p2, p1): P1 * P2
 // contiguous partitions.  Their boundaries are read off the partitioned keys.
@@ -571,11 +486,10 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu
     const dfgpu_array* srcs[PA_MAX_AGGS]; bool src_cast[PA_MAX_AGGS] = {}; int n_src = 0, src_of[PA_MAX_AGGS];
     for (int c = 0; c < plan.n_acc; c++) { src_of[c] = -1; if (!cell_src[c]) continue; int j = -1; for (int q = 0; q < n_src; q++) if (srcs[q] == cell_src[c] && src_cast[q] == cell_cast[c]) j = q; if (j < 0) { j = n_src; src_cast[n_src] = cell_cast[c]; srcs[n_src++] = cell_src[c]; } src_of[c] = j; }
     const uint64_t* mk = nullptr; BufferPtr mask = effective_mask(ctx, opt_mask, n); if (mask) mk = (const uint64_t*)mask->ptr;
-    const uint64_t* const mk_in = mk;          // the caller's selection (the sample's cache key); mk itself becomes the cold rows when hot keys are taken out below
     // ---- sample: clustered? how many groups?  (a verdict-only call leaves its sample for the call that follows on the same column)
     const int64_t s = n < (1 << 19) ? n : (1 << 19), stride = n / s; const uint64_t cap = 1ull << 21;
     const void* ident = keys[0]->values->ptr;           // what the verdict-only call and the call that follows share
-    const bool cached = ctx->pa_sample_key == ident && ctx->pa_sample_n == n && ctx->pa_sample_mask == (const void*)mk_in && (!packed_keys || (ctx->pa_pack && ctx->pa_pack_n == nkeys));
+    const bool cached = ctx->pa_sample_key == ident && ctx->pa_sample_n == n && ctx->pa_sample_mask == (const void*)mk && (!packed_keys || (ctx->pa_pack && ctx->pa_pack_n == nkeys));
     BufferPtr packed; PaPackCols pc{};
     if (packed_keys) {
       pc.n = nkeys; for (int c = 0; c < nkeys; c++) { pc.v[c] = keys[c]->values->ptr; pc.valid[c] = keys[c]->validity ? (const uint64_t*)keys[c]->validity->ptr : nullptr; pc.type[c] = keys[c]->type == DFGPU_DATE32 ? DFGPU_INT32 : keys[c]->type; pc.nullable[c] = keys[c]->validity ? 1 : 0;
@@ -622,20 +536,15 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu
     if (cached) { for (int q = 0; q < 3; q++) ctx->h_pinned[q] = ctx->pa_sample[q]; ctx->pa_sample_key = nullptr; ctx->pa_pack.reset(); }
     else {
     BufferPtr table = alloc_buffer(ctx, cap * 8); HIP_CHECK(hipMemsetAsync(table->ptr, 0xFF, cap * 8, ctx->stream));
-    HIP_CHECK(hipMemsetAsync(ctx->d_scratch64, 0, 48, ctx->stream));          // the sample's three counters, the hot-key sample's three
-    ctx->pa_hot = alloc_buffer(ctx, (size_t)PA_HOT * 8 + (size_t)PA_HOT * (2 + PA_MAX_AGGS) * 8);          // hot keys | their accumulators
+    HIP_CHECK(hipMemsetAsync(ctx->d_scratch64, 0, 24, ctx->stream));          // the sample's three counters
     { KernelTimer kt_(ctx, "pa_sample");
 #define PA_SAMPLE(T) hipLaunchKernelGGL((k_pa_sample<T>), dim3(grid_for(s, BLOCK * 8, 256)), dim3(BLOCK), 0, ctx->stream, (const T*)kptr, mk, n, s, stride, (unsigned long long*)table->ptr, cap - 1, (unsigned long long*)ctx->d_scratch64)
       switch (ktype) { case DFGPU_INT64: PA_SAMPLE(int64_t); break; case DFGPU_UINT64: PA_SAMPLE(uint64_t); break; case DFGPU_UINT32: PA_SAMPLE(uint32_t); break; default: PA_SAMPLE(int32_t); break; }
 #undef PA_SAMPLE
-#define PA_HOTS(T) hipLaunchKernelGGL((k_pa_hot_sample<T>), dim3(1), dim3(1024), 0, ctx->stream, (const T*)kptr, mk, n, (unsigned long long*)ctx->pa_hot->ptr, (unsigned long long*)(ctx->d_scratch64 + 3))
-      if (ctx->agg_hot_keys) switch (ktype) { case DFGPU_INT64: PA_HOTS(int64_t); break; case DFGPU_UINT64: PA_HOTS(uint64_t); break; case DFGPU_UINT32: PA_HOTS(uint32_t); break; default: PA_HOTS(int32_t); break; }
-#undef PA_HOTS
       KERNEL_CHECK(); }
-    ctx->count_sync("sync:pa_sample"); fetch_to_pinned(ctx, 0, ctx->d_scratch64, 48);
-    for (int q = 0; q < 3; q++) ctx->pa_hot_stats[q] = ctx->h_pinned[3 + q];
+    ctx->count_sync("sync:pa_sample"); fetch_to_pinned(ctx, 0, ctx->d_scratch64, 24);
     if (verdict_only) {
-      ctx->pa_sample_key = ident; ctx->pa_sample_n = n; ctx->pa_sample_mask = (const void*)mk_in; for (int q = 0; q < 3; q++) ctx->pa_sample[q] = ctx->h_pinned[q];
+      ctx->pa_sample_key = ident; ctx->pa_sample_n = n; ctx->pa_sample_mask = (const void*)mk; for (int q = 0; q < 3; q++) ctx->pa_sample[q] = ctx->h_pinned[q];
       ctx->pa_pack = packed; ctx->pa_pack_n = packed_keys ? nkeys : 0;
       for (int c = 0; c < nkeys && packed_keys; c++) { ctx->pa_pack_min[c] = pc.mn[c]; ctx->pa_pack_stride[c] = pc.stride[c]; ctx->pa_pack_range[c] = pc.range[c]; ctx->pa_pack_nullable[c] = pc.nullable[c] != 0; }
     }
@@ -663,29 +572,6 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu
     int64_t P1 = P, P2 = 1;
     if (two_level) { P2 = P > 2048 * 128 ? 256 : 128; P1 = (P + P2 - 1) / P2; if (P1 < 16) P1 = 16; if (P1 > 2048) P1 = 2048; P = P1 * P2; }
     else { if (P > n / 2048 + 1) P = n / 2048 + 1; if (P > ctx->num_cus) P = std::min<int64_t>(2048, (P + ctx->num_cus - 1) / ctx->num_cus * ctx->num_cus); P1 = P; }
-    // ---- hot keys out of the way (see k_pa_hot): their rows are summed by a pass of their own, the partition passes see the selection of the others
-    BufferPtr hot = ctx->pa_hot; ctx->pa_hot.reset();
-    const int nhot = (int)ctx->pa_hot_stats[0]; bool hot_taken = false; BufferPtr cold_mask; PaHotPlan hp{};
-    if (ctx->agg_hot_keys && hot && nhot > 0 && ctx->pa_hot_stats[1] * 8 >= ctx->pa_hot_stats[2] && !plan.has_i128 && n_flags == 0) {
-      hp.n_acc = plan.n_acc; bool ok_cells = true;
-      for (int c = 0; c < plan.n_acc && ok_cells; c++) {
-        const dfgpu_array* v = cell_src[c]; if (!v) { ok_cells = false; break; }
-        hp.c[c].src = v->values->ptr; hp.c[c].op = plan.op[c];
-        hp.c[c].kind = cell_cast[c] ? (v->type == DFGPU_INT32 ? 1 : 2) : 0;
-        if (!cell_cast[c] && type_width(v->type) != 8) ok_cells = false;
-      }
-      if (ok_cells) {
-        KernelTimer kt_(ctx, "pa_hot");
-        cold_mask = alloc_buffer(ctx, (size_t)((n + 63) / 64) * 8 + 8);
-        unsigned long long* hk = (unsigned long long*)hot->ptr; unsigned long long* hacc = hk + PA_HOT;
-        hipLaunchKernelGGL(k_pa_hot_init, dim3(1), dim3(PA_HOT * (2 + PA_MAX_AGGS)), 0, ctx->stream, hp, hacc);
-#define PA_HOTK(T) hipLaunchKernelGGL((k_pa_hot<T>), dim3(grid_for(n, BLOCK * 8, ctx->num_cus * 8)), dim3(BLOCK), 0, ctx->stream, (const T*)kptr, mk, n, (const unsigned long long*)hk, nhot, hp, hacc, (uint64_t*)cold_mask->ptr)
-        switch (ktype) { case DFGPU_INT64: PA_HOTK(int64_t); break; case DFGPU_UINT64: PA_HOTK(uint64_t); break; case DFGPU_UINT32: PA_HOTK(uint32_t); break; default: PA_HOTK(int32_t); break; }
-#undef PA_HOTK
-        KERNEL_CHECK();
-        mk = (const uint64_t*)cold_mask->ptr; hot_taken = true;
-      }
-    }
     // ---- partition (key, row, value cells)
     // the row number travels with a row only to find every group's first row (first-seen order): with DFGPU_PREAGG_ANY_ORDER it stays behind -- 4 of the 20..28 bytes a row
     // costs each partition level and the aggregation's read
@@ -754,9 +640,6 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu
       else { if (plan.has_i128) PA_AGG(true, false); else PA_AGG(false, false); }
 #undef PA_AGG
       KERNEL_CHECK(); }
-    if (hot_taken) { unsigned long long* hk = (unsigned long long*)hot->ptr;
-      hipLaunchKernelGGL(k_pa_hot_emit, dim3(1), dim3(PA_HOT), 0, ctx->stream, (const unsigned long long*)hk, nhot, (const unsigned long long*)(hk + PA_HOT), plan.n_acc, (uint64_t*)orec->ptr, rs, (uint32_t*)ofirst->ptr,
-                         (unsigned long long*)(ctx->d_scratch64 + 12)); KERNEL_CHECK(); }
     const uint64_t* back = read_scratch_range(ctx, 11, 4);          // [0] rows out of order, [1] partial rows written, [2] longest partition, [3] tables flushed early: one read-back
     const int64_t m = (int64_t)back[1]; const uint64_t early = back[3]; const int64_t n_slices = back[2] ? ((int64_t)back[2] + slice - 1) / slice : 1;
     if (two_level && (uint32_t)back[0] != 0) fail(DFGPU_INTERNAL, "agg_preaggregate: the two-level partition left rows out of partition order");

@@ -601,55 +601,3 @@ def test_many_partition_scatter_staged_in_two_rounds(ctx):
     assert np.array_equal(k1.to_numpy()[o1], wk.to_numpy()[ow])
     for got, w in zip((r1[0], r1[1], r1[4]), want):
         assert got.take(pa.array(o1)).cast(pa.int64()).equals(w.take(pa.array(ow)).cast(pa.int64()))
-
-
-@pytest.mark.parametrize("first_seen", [True, False], ids=["first-seen-order", "any-order"])
-def test_hot_keys_are_summed_by_a_pass_of_their_own(ctx, first_seen):
-    """Zipf-distributed keys: the keys a small sample finds in at least 1/256 of the rows (together at least 1/8 of them) are taken out before the partition passes -- their
-    rows go to accumulators of their own (k_pa_hot), the partitions see the selection of the other rows, the hot totals join the partial rows.  Groups, first-seen order and
-    states equal the path without it (option agg_hot_keys = 0) and the oracle's row-by-row update; an Int32 argument cast to Float64 on the way and a selection mask on top."""
-    import dfgpu
-    from dfgpu import capi
-    n, card = 2_000_000, 200_000
-    rng = np.random.default_rng(71)
-    keys = (rng.zipf(1.15, n) % card).astype(np.int64) * 3 + 1
-    key = pa.array(keys)
-    vi = pa.array(rng.integers(-10**6, 10**6, n).astype(np.int64)); v32 = pa.array(rng.integers(0, 500, n).astype(np.int32))
-    mask = rng.random(n) < 0.9
-    kd = ctx.from_arrow(key); cols = [ctx.from_arrow(vi), ctx.from_arrow(v32)]; md = ctx.from_arrow(pa.array(mask))
-    kinds = [KIND["SUM"], KIND["MAX"], KIND["AVG"], KIND["COUNT"]]
-    vals = [cols[0], cols[0], cols[1], None]; casts = [0, 0, capi.FLOAT64, 0]
-    in_types = [(capi.INT64, 0, 0), (capi.INT64, 0, 0), (capi.FLOAT64, 0, 0), (capi.INT64, 0, 0)]
-    out = []
-    for on in (1, 0):
-        ctx.set_option("agg_hot_keys", on)
-        try:
-            with forced(ctx, force=0) as f:
-                pk, states = dfgpu.agg_preaggregate(ctx, kd, kinds, vals, mask=md, casts=casts, any_order=not first_seen)
-                ran = f.kernels()
-        finally:
-            ctx.set_option("agg_hot_keys", 1)
-        assert "pa_aggregate" in ran and ("pa_hot" in ran) == bool(on)
-        assert len(pk) == len(np.unique(pk.to_numpy()))                     # a hot key has no row left in any partition: every key still comes back once
-        gv = dfgpu.GroupValues(ctx, 1); gids = gv.intern([pk]); res = []
-        for kind, (t, p_, s_), st in zip(kinds, in_types, states):
-            acc = dfgpu.GroupsAccumulator(ctx, kind, t, p_, s_); acc.merge_batch(st, gids, None, len(gv)); res.append(acc.evaluate().to_arrow())
-        out.append((gv.emit()[0].to_arrow(), res))
-    (k1, r1), (k0, r0) = out
-    if first_seen:
-        assert k1.equals(k0)                                                # first-seen order with and without the hot pass
-    o1, o0 = np.argsort(k1.to_numpy(), kind="stable"), np.argsort(k0.to_numpy(), kind="stable")
-    assert np.array_equal(k1.to_numpy()[o1], k0.to_numpy()[o0])
-    for a, b in zip(r1, r0):
-        x, y = a.take(pa.array(o1)), b.take(pa.array(o0))
-        if pa.types.is_floating(x.type):
-            assert np.allclose(x.to_numpy(), y.to_numpy(), rtol=FLOAT_RTOL, atol=0.0)
-        else:
-            assert x.equals(y)
-    wk, want = run_oracle(key, [("SUM", vi), ("MAX", vi), ("COUNT", None)], mask=mask)
-    if first_seen:
-        assert k1.equals(wk)
-    ow = np.argsort(wk.to_numpy(), kind="stable")
-    assert np.array_equal(k1.to_numpy()[o1], wk.to_numpy()[ow])
-    for got, w in zip((r1[0], r1[1], r1[3]), want):
-        assert got.take(pa.array(o1)).cast(pa.int64()).equals(w.take(pa.array(ow)).cast(pa.int64()))
