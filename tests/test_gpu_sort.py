@@ -423,3 +423,37 @@ def test_sort_take_gathers_payload_columns_in_the_last_pass(ctx, fetch):
         finally:
             ctx.set_option("sort_payload_in_last_pass", 0)
     assert outs[0].equals(outs[1]) and outs[0].equals(t.take(pa.array(want_order)).combine_chunks())
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_one_sweep_passes_over_random_sizes_and_key_widths(ctx, seed):
+    """Random row counts between 2^20 and 2^22.2 (4096- and 8192-row tiles, ragged last tiles, a tile count that is and is not a multiple of 8), one to three key columns of
+    random widths (1 .. 6 passes), random directions and NULL fractions: the one-launch passes give numpy's stable order and the three-launch passes' indices."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1 << 20, int(2 ** 22.2)))
+    k = int(rng.integers(1, 4)); cols, desc, nf, keys_np = [], [], [], []
+    budget = 64 - int(n - 1).bit_length()
+    for c in range(k):
+        bits = int(rng.integers(1, max(2, min(24, budget - 2 * (k - c)))));  budget -= bits + 1
+        v = rng.integers(0, 1 << bits, n).astype(np.int64) - int(rng.integers(0, 1 << bits))
+        m = rng.random(n) < float(rng.choice([0.0, 0.0, 0.05]))
+        d, f = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        cols.append(pa.array(v, mask=m if m.any() else None)); desc.append(d); nf.append(f)
+        sv = -v if d else v
+        nullkey = np.where(m, 0 if f else 2, 1)                       # NULLs first or last whatever the direction
+        keys_np.append((nullkey, np.where(m, 0, sv)))
+    dcols = [ctx.from_arrow(c) for c in cols]
+    ctx.profile_select(None); ctx.profile_enable(True); ctx.profile_read()
+    try:
+        got = ctx.sort_to_indices(dcols, desc, nf).to_numpy()
+        ks = set(ctx.profile_read())
+        ctx.set_option("sort_onesweep_rows", 0)
+        plain = ctx.sort_to_indices(dcols, desc, nf).to_numpy()
+    finally:
+        ctx.profile_enable(False); ctx.set_option("sort_onesweep_rows", 16)
+    assert "sort_pass_onesweep" in ks, (n, k)
+    assert np.array_equal(got, plain)
+    lex = [np.arange(n)]
+    for nullkey, sv in reversed(keys_np):
+        lex += [sv, nullkey]
+    assert np.array_equal(got.astype(np.int64), np.lexsort(tuple(lex)))
