@@ -464,6 +464,7 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "join_partitioned") ctx->join_partitioned = value != 0;
     else if (k == "join_partitioned_min_build") ctx->join_partitioned_min_build = value;
     else if (k == "join_partitioned_min_probe") ctx->join_partitioned_min_probe = value;
+    else if (k == "join_partitioned_big") ctx->join_partitioned_big = value != 0;
     else if (k == "join_partitioned_hashed") ctx->join_partitioned_hashed = value != 0;
     else if (k == "join_partitioned_hash_mask") ctx->join_partitioned_hash_mask = value <= 0 ? ~0ull : (uint64_t)value;
     else if (k == "join_partition_rows") ctx->join_partition_rows = value;

@@ -54,6 +54,7 @@ struct dfgpu_ctx {
   // radix-partitioned hash join (pjoin.hip): on/off, smallest build / probe batch that takes it, build rows per partition (<= 14000)
   uint64_t join_partitioned_hash_mask = ~0ull;       // tests: AND-ed onto the key hashes of the hashed mode, so that different keys collide
   bool join_partitioned_hashed = true;       // builds the integer mode of the partitioned join does not take (several key columns that do not pack, Utf8 / dictionary keys, null_equals_null) go through it on 64-bit key hashes
+  bool join_partitioned_big = true;                            // builds beyond 2048 x join_partition_rows rows: up to 4096 partitions (else they decline to the global table)
   // membership-bitmap probes of unclustered keys through a key-range partition (pjoin.hip bp_probe).  OFF: measured slower than the random probes it replaces (TPC-H Q3 over
   // shuffled tables at SF100: partition 6.9 ms + probe 2.0 ms against 6.8 ms of random probes -- the LDS-staged scatter moves ~120 G rows/s whatever the row width)
   bool join_bitmap_partitioned = false; int64_t join_bitmap_partitioned_min_rows = 1 << 24;

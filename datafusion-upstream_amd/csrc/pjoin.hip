@@ -38,6 +38,7 @@ constexpr uint32_t PJ_MAX_PART_ROWS = PJ_IDX_MASK - 1;      // keeps (tag, idx) 
 constexpr int PJ_MAX_SBITS = 15;                      // 32 K slots x 4 B = 128 KB (one workgroup per CU); 14 = two per CU
 constexpr int PJ_NT = 1024, PJ_R = 8, PJ_TILE = PJ_NT * PJ_R, PJ_G = 16, PJ_NW = PJ_NT / WAVE;
 constexpr uint32_t PJ_MAX_P = 2048;                   // two partitions per thread in the offset loops
+constexpr uint32_t PJ_MAX_P_BIG = 4096;               // builds beyond 2048 x 14 000 rows: the same kernels with four partitions per thread (template MP); 57 M rows at 14 000 per partition
 constexpr int PJ_CHS = 14;                            // restore chunk = 2^14 probe rows = two tiles
 static_assert(PJ_TILE == 1 << 13 && PJ_CHS >= 13, "k_pj_join turns a chunk into its first tile by a shift");
 constexpr int PJ_U = 4;                               // probe records per lane in flight
@@ -98,28 +99,31 @@ __global__ void __launch_bounds__(PJ_NT) k_pj_chunk_prefix(uint32_t* tot /*[nchu
   if (p < P) for (int64_t c = c0; c < c1; c++) { const uint32_t v = tot[c * P + p]; tot[c * P + p] = run; run += v; }
 }
 // pstart[p] = exclusive scan of ptot (P <= 2048, one workgroup), pstart[P] = rows moved (also -> *d_total)
+template <int MP>
 __global__ void __launch_bounds__(PJ_NT) k_pj_pstart(const uint32_t* ptot, uint32_t P, uint32_t* pstart, uint64_t* d_total) {
   __shared__ uint32_t wsum[PJ_NW];
-  const uint32_t a = threadIdx.x * 2 < P ? ptot[threadIdx.x * 2] : 0, b = threadIdx.x * 2 + 1 < P ? ptot[threadIdx.x * 2 + 1] : 0, s = a + b;
+  constexpr int PER = MP / PJ_NT; uint32_t v[PER]; uint32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < PER; j++) { const uint32_t p = threadIdx.x * PER + j; v[j] = p < P ? ptot[p] : 0; s += v[j]; }
   const uint32_t inc = wave_inclusive_sum(s);
   if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
   __syncthreads();
   uint32_t run = inc - s, tot = 0; for (int w = 0; w < PJ_NW; w++) { if (w < (int)(threadIdx.x >> 6)) run += wsum[w]; tot += wsum[w]; }
-  if (threadIdx.x * 2 < P) pstart[threadIdx.x * 2] = run;
-  if (threadIdx.x * 2 + 1 < P) pstart[threadIdx.x * 2 + 1] = run + a;
+#pragma unroll
+  for (int j = 0; j < PER; j++) { const uint32_t p = threadIdx.x * PER + j; if (p < P) pstart[p] = run; run += v[j]; }
   if (threadIdx.x == 0) { pstart[P] = tot; if (d_total) *d_total = tot; }
 }
 // LDS-staged scatter of (key, row) records; staging in two rounds of half the sorted tile: 8 P + 6 TILE bytes of LDS, two workgroups per CU.
 // blockIdx -> tile: XCD x (= blockIdx & 7 under round-robin placement; speed only) works on a contiguous range of tiles, so the tiles in flight on one
 // XCD are neighbours and their runs of a partition complete each other's cache lines inside that XCD's L2.
-template <typename H>
+template <typename H, int MP = (int)PJ_MAX_P>
 __global__ void __launch_bounds__(PJ_NT, 8) k_pj_scatter(H hs, int64_t n, uint32_t P, int64_t ntiles, const uint32_t* pre, const uint32_t* cpre, const uint32_t* pstart, RpRec12* out) {
   extern __shared__ uint32_t pj_lds[];
   constexpr int PIECE = PJ_TILE / 2;
   uint32_t* cnt = pj_lds; uint32_t* delta = pj_lds + P; uint16_t* spid = (uint16_t*)(pj_lds + 2 * P); uint16_t* slidx = spid + PIECE;
   uint64_t* skey = (uint64_t*)(((uintptr_t)(slidx + PIECE) + 7) & ~(uintptr_t)7);
   __shared__ uint32_t wsum[PJ_NW]; __shared__ uint32_t moved_sh;
-  constexpr int PER = (int)PJ_MAX_P / PJ_NT;
+  constexpr int PER = MP / PJ_NT;
   const int64_t per = (ntiles + 7) / 8, t = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (t >= ntiles || (int64_t)(blockIdx.x >> 3) >= per) return;
   const int64_t base = t * (int64_t)PJ_TILE, chunk = t / PJ_G;
@@ -370,17 +374,17 @@ __global__ void __launch_bounds__(PJ_NT) k_pj_transpose(const uint32_t* hstart, 
 // the 2048 run lengths; every probe row has at most one hit, so its rank among the chunk's hits = set bits below it in a bitmap of the chunk's rows.  The
 // hits leave through an LDS window of WIN ranks (a chunk usually fits one window: its hits then stay in registers between the two passes).
 constexpr int PJ_K6 = 6, PJ_WIN = PJ_NT * PJ_K6;      // tried: 512 threads x 8 hits (32 KB window, three workgroups per CU instead of two): 0.393 against 0.396 ms -- not the limiter
-template <bool GROUPS>
+template <bool GROUPS, int MP = (int)PJ_MAX_P>
 __global__ void __launch_bounds__(PJ_NT) k_pj_restore(const uint64_t* hits, const uint32_t* pstart, const uint32_t* hT, const uint16_t* lT, int P, int NC, const uint32_t* coff,
                                                      uint32_t* out_probe, uint64_t* out_build, uint32_t* out_ref) {
   constexpr int NWORDS = 1 << (PJ_CHS - 5);
-  __shared__ uint32_t bits[NWORDS]; __shared__ uint32_t pref[NWORDS]; __shared__ uint32_t rsrc[PJ_MAX_P]; __shared__ uint32_t roff[PJ_MAX_P + 1]; __shared__ uint32_t wsum[PJ_NW]; __shared__ uint64_t stage[PJ_WIN];
+  __shared__ uint32_t bits[NWORDS]; __shared__ uint32_t pref[NWORDS]; __shared__ uint32_t rsrc[MP]; __shared__ uint32_t roff[MP + 1]; __shared__ uint32_t wsum[PJ_NW]; __shared__ uint64_t stage[PJ_WIN];
   const int64_t per = (NC + 7) / 8, cc = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (cc >= NC || (int64_t)(blockIdx.x >> 3) >= per) return;
   const int c = (int)cc; const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int x = threadIdx.x; x < NWORDS; x += PJ_NT) bits[x] = 0;
   uint32_t tot;
-  { constexpr int PER = (int)PJ_MAX_P / PJ_NT; uint32_t len[PER]; uint32_t s = 0;
+  { constexpr int PER = MP / PJ_NT; uint32_t len[PER]; uint32_t s = 0;
 #pragma unroll
     for (int j = 0; j < PER; j++) { const int p = threadIdx.x * PER + j; len[j] = 0; if (p < P) { len[j] = lT[(size_t)c * P + p]; rsrc[p] = pstart[p] + hT[(size_t)c * P + p]; } s += len[j]; }
     const uint32_t inc = wave_inclusive_sum(s);
@@ -493,13 +497,17 @@ static PjOffsets pj_partition_t(dfgpu_ctx* ctx, H hs, int64_t n, uint32_t P, RpR
     KERNEL_CHECK(); }
   { KernelTimer kt_(ctx, ts);
     hipLaunchKernelGGL(k_pj_chunk_prefix, dim3((P + 63) / 64), dim3(PJ_NT), 0, ctx->stream, (uint32_t*)o.cpre->ptr, o.nchunks, P, (uint32_t*)ptot->ptr);
-    hipLaunchKernelGGL(k_pj_pstart, dim3(1), dim3(PJ_NT), 0, ctx->stream, (const uint32_t*)ptot->ptr, P, (uint32_t*)o.pstart->ptr, d_total);
+    if (P > PJ_MAX_P) hipLaunchKernelGGL((k_pj_pstart<(int)PJ_MAX_P_BIG>), dim3(1), dim3(PJ_NT), 0, ctx->stream, (const uint32_t*)ptot->ptr, P, (uint32_t*)o.pstart->ptr, d_total);
+    else hipLaunchKernelGGL((k_pj_pstart<(int)PJ_MAX_P>), dim3(1), dim3(PJ_NT), 0, ctx->stream, (const uint32_t*)ptot->ptr, P, (uint32_t*)o.pstart->ptr, d_total);
     KERNEL_CHECK(); }
   if (n) { KernelTimer kt_(ctx, tw);
     const size_t lds = (size_t)P * 8 + (size_t)PJ_TILE / 2 * 12 + 16;
-    pj_set_lds((const void*)k_pj_scatter<H>, lds);
+    if (P > PJ_MAX_P) { pj_set_lds((const void*)k_pj_scatter<H, (int)PJ_MAX_P_BIG>, lds);
+      hipLaunchKernelGGL((k_pj_scatter<H, (int)PJ_MAX_P_BIG>), dim3((unsigned)(((o.ntiles + 7) / 8) * 8)), dim3(PJ_NT), lds, ctx->stream, hs, n, P, o.ntiles, (const uint32_t*)o.pre->ptr, (const uint32_t*)o.cpre->ptr,
+                         (const uint32_t*)o.pstart->ptr, recs); }
+    else { pj_set_lds((const void*)k_pj_scatter<H>, lds);
     hipLaunchKernelGGL((k_pj_scatter<H>), dim3((unsigned)(((o.ntiles + 7) / 8) * 8)), dim3(PJ_NT), lds, ctx->stream, hs, n, P, o.ntiles, (const uint32_t*)o.pre->ptr, (const uint32_t*)o.cpre->ptr,
-                       (const uint32_t*)o.pstart->ptr, recs);
+                       (const uint32_t*)o.pstart->ptr, recs); }
     KERNEL_CHECK(); }
   return o;
 }
@@ -549,7 +557,10 @@ bool pj_build(dfgpu_ctx* ctx, dfgpu_join_table* t) {
   int64_t cap = ctx->join_partition_rows; if (cap < 16) cap = 16; if (cap > 14000) cap = 14000;
   const int64_t per = std::min<int64_t>(cap, 7300);      // <= 8192 keys: a 64 KB table at load <= 1/2, two workgroups per CU
   int64_t P64 = (n + per - 1) / per; if (P64 < 1) P64 = 1;
-  if (P64 > PJ_MAX_P) { if ((n + PJ_MAX_P - 1) / PJ_MAX_P > cap) return false; P64 = PJ_MAX_P; }       // up to `cap` rows per partition: 128 KB tables, one workgroup per CU
+  if (P64 > PJ_MAX_P) {       // up to `cap` rows per partition: 128 KB tables, one workgroup per CU; beyond 2048 x cap rows up to 4096 partitions (the MP = 4096 instantiations)
+    if ((n + PJ_MAX_P - 1) / PJ_MAX_P <= cap) P64 = PJ_MAX_P;
+    else { P64 = (n + cap - 1) / cap; P64 = (P64 + 255) / 256 * 256; if (P64 > PJ_MAX_P_BIG || !ctx->join_partitioned_big) return false; }
+  }
   else if (P64 > 2 * ctx->num_cus) P64 = std::min<int64_t>(PJ_MAX_P, (P64 + 2 * ctx->num_cus - 1) / (2 * ctx->num_cus) * (2 * ctx->num_cus));      // whole rounds of two workgroups per CU
   auto part = std::make_unique<PartitionedBuild>();
   part->P = (uint32_t)P64;
@@ -653,7 +664,9 @@ void pj_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* cons
   const unsigned rgrid = (unsigned)(((NC + 7) / 8) * 8);
   if (!part.dups) {
     ArrayHolder ob(new_fixed(ctx, DFGPU_UINT64, m)), op(new_fixed(ctx, DFGPU_UINT32, m));
-    if (m) hipLaunchKernelGGL((k_pj_restore<false>), dim3(rgrid), dim3(PJ_NT), 0, ctx->stream, (const uint64_t*)hits->ptr, (const uint32_t*)off.pstart->ptr, (const uint32_t*)hT->ptr, (const uint16_t*)lT->ptr, (int)P, NC,
+    if (m && P > PJ_MAX_P) hipLaunchKernelGGL((k_pj_restore<false, (int)PJ_MAX_P_BIG>), dim3(rgrid), dim3(PJ_NT), 0, ctx->stream, (const uint64_t*)hits->ptr, (const uint32_t*)off.pstart->ptr, (const uint32_t*)hT->ptr, (const uint16_t*)lT->ptr, (int)P, NC,
+                                  (const uint32_t*)coff->ptr, (uint32_t*)op.get()->values->ptr, (uint64_t*)ob.get()->values->ptr, (uint32_t*)nullptr);
+    else if (m) hipLaunchKernelGGL((k_pj_restore<false>), dim3(rgrid), dim3(PJ_NT), 0, ctx->stream, (const uint64_t*)hits->ptr, (const uint32_t*)off.pstart->ptr, (const uint32_t*)hT->ptr, (const uint16_t*)lT->ptr, (int)P, NC,
                                   (const uint32_t*)coff->ptr, (uint32_t*)op.get()->values->ptr, (uint64_t*)ob.get()->values->ptr, (uint32_t*)nullptr);
     KERNEL_CHECK();
     kt_.reset();
@@ -666,7 +679,9 @@ void pj_probe(dfgpu_ctx* ctx, const dfgpu_join_table* t, const dfgpu_array* cons
   BufferPtr rows = alloc_buffer(ctx, (size_t)(m + 1) * 4), ref = alloc_buffer(ctx, (size_t)(m + 1) * 4), cnt = alloc_buffer(ctx, (size_t)(m + 1) * 4), offs = alloc_buffer(ctx, (size_t)(m + 1) * 8);
   int64_t total = 0;
   if (m) {
-    hipLaunchKernelGGL((k_pj_restore<true>), dim3(rgrid), dim3(PJ_NT), 0, ctx->stream, (const uint64_t*)hits->ptr, (const uint32_t*)off.pstart->ptr, (const uint32_t*)hT->ptr, (const uint16_t*)lT->ptr, (int)P, NC,
+    if (P > PJ_MAX_P) hipLaunchKernelGGL((k_pj_restore<true, (int)PJ_MAX_P_BIG>), dim3(rgrid), dim3(PJ_NT), 0, ctx->stream, (const uint64_t*)hits->ptr, (const uint32_t*)off.pstart->ptr, (const uint32_t*)hT->ptr, (const uint16_t*)lT->ptr, (int)P, NC,
+                       (const uint32_t*)coff->ptr, (uint32_t*)rows->ptr, (uint64_t*)nullptr, (uint32_t*)ref->ptr);
+    else hipLaunchKernelGGL((k_pj_restore<true>), dim3(rgrid), dim3(PJ_NT), 0, ctx->stream, (const uint64_t*)hits->ptr, (const uint32_t*)off.pstart->ptr, (const uint32_t*)hT->ptr, (const uint16_t*)lT->ptr, (int)P, NC,
                        (const uint32_t*)coff->ptr, (uint32_t*)rows->ptr, (uint64_t*)nullptr, (uint32_t*)ref->ptr);
     hipLaunchKernelGGL(k_pj_group_counts, dim3(grid_for(m, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const uint32_t*)ref->ptr, m, (const uint32_t*)part.grp_cnt->ptr, (uint32_t*)cnt->ptr);
     KERNEL_CHECK();

@@ -75,7 +75,8 @@ def check(ctx, b, p, bmask=None, pmask=None, bnull=None, pnull=None, typ=None):
 
 
 SHAPES = [(50000, 200000, 0.2, 12800), (50000, 200000, 0.2, 64), (20000, 70001, 1.0, 100), (3000, 100000, 0.0, 16), (1, 5000, 0.5, 12800), (2, 5000, 0.5, 12800),
-          (4097, 4096, 0.3, 33), (130000, 400000, 0.25, 64), (60000, 1, 1.0, 500), (60000, 0, 0.0, 500)]
+          (4097, 4096, 0.3, 33), (130000, 400000, 0.25, 64), (60000, 1, 1.0, 500), (60000, 0, 0.0, 500),
+          (250000, 600000, 0.3, 64), (150000, 300001, 0.5, 40)]          # the last two: more than 2048 partitions (3907 -> 4096, 3750 -> 3840: the four-partitions-per-thread instantiations)
 
 
 @pytest.mark.parametrize("nb,npr,frac,per", SHAPES, ids=[f"{s[0]}x{s[1]}-m{s[2]}-r{s[3]}" for s in SHAPES])
@@ -142,8 +143,8 @@ def test_repeated_build_keys_take_the_partitioned_path(ctx):
         assert "pj_build_check" in ran and "pj_build_groups" in ran and "pj_join" in ran and "k_probe_match_hash" not in ran, ran
 
 
-@pytest.mark.parametrize("nb,npr,distinct,per", [(60000, 200000, 9000, 128), (40000, 100000, 39000, 64), (50000, 150000, 500, 12800), (3000, 50000, 1, 12800), (200000, 300000, 40000, 256)],
-                         ids=["fk7", "few-dups", "100-per-key", "one-key", "fk5-2048-partitions"])
+@pytest.mark.parametrize("nb,npr,distinct,per", [(60000, 200000, 9000, 128), (40000, 100000, 39000, 64), (50000, 150000, 500, 12800), (3000, 50000, 1, 12800), (200000, 300000, 40000, 256), (300000, 400000, 60000, 90)],
+                         ids=["fk7", "few-dups", "100-per-key", "one-key", "fk5-2048-partitions", "fk5-3584-partitions"])
 def test_foreign_key_builds(ctx, nb, npr, distinct, per):
     """a build side whose keys repeat (a foreign key): every match emits its key's rows in build input order; masks and NULLs on both sides"""
     keys = unique_keys(distinct)
@@ -346,3 +347,26 @@ def test_rank_index_over_unsorted_unique_keys(ctx, shape):
             assert "k_join_build" in set(ctx.profile_read())
         finally:
             ctx.profile_enable(False); ctx.set_option("join_rank_index_unsorted", 1)
+
+
+def test_builds_beyond_2048_partitions_take_up_to_4096(ctx):
+    """A build of more than 2048 x join_partition_rows rows used to decline to the global table; it now takes up to 4096 partitions (k_pj_scatter / k_pj_restore / k_pj_pstart
+    with four partitions per thread).  Same pairs as the global table (option join_partitioned_big = 0: declined), and a build that needs more than 4096 still declines."""
+    import dfgpu
+    b = unique_keys(260000); p = probe_keys(b, 500000, 0.4)
+    out = []
+    for big in (1, 0):
+        with forced(ctx, 64) as f:
+            ctx.set_option("join_partitioned_big", big)
+            try:
+                t = dfgpu.JoinTable(ctx, [ctx.from_arrow(pa.array(b))])
+                bi, pi = t.probe([ctx.from_arrow(pa.array(p))])
+                out.append((bi.to_numpy(), pi.to_numpy()))
+                assert ("pj_join" in f.kernels()) == bool(big)
+            finally:
+                ctx.set_option("join_partitioned_big", 1)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    b2 = unique_keys(300000); p2 = probe_keys(b2, 100000, 0.5)
+    with forced(ctx, 64) as f:                       # 300 000 / 64 = 4688 partitions: beyond 4096
+        check(ctx, b2, p2)
+        assert "pj_join" not in f.kernels()
