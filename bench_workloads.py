@@ -415,6 +415,28 @@ def run(args, ctx=None, emit=True):
                "result_check": check("hash_join_dense_unsorted", ok, "COUNT(*) and SUM(v) over the join output == a torch membership table over the same keys, and == the same plan through the bitmap + hash table")})
         del bkd, pkd, pvd, leftd, rightd, jd, pland, member, hitd
         torch.cuda.empty_cache()
+    # on request only (--only hash_join_big_build): a build side beyond 2048 x 14 000 rows (40 M x 150 M at sf 100) -- the partitioned join with up to 4096 partitions against the
+    # global table it used to decline to (--option join_partitioned_big=0)
+    if want and "hash_join_big_build" in want:
+        nbb, npb = int(400_000 * args.sf), int(1_500_000 * args.sf)
+        bkb = torch.randint(0, 2**62, (nbb,), generator=g, device="cuda", dtype=torch.int64)
+        pkb = torch.cat([bkb[torch.randint(0, nbb, (npb // 5,), generator=g, device="cuda")], torch.randint(0, 2**62, (npb - npb // 5,), generator=g, device="cuda", dtype=torch.int64)])
+        pkb = pkb[torch.randperm(npb, generator=g, device="cuda")]
+        pvb = torch.randint(0, 10**6, (npb,), generator=g, device="cuda", dtype=torch.int64)
+        torch.cuda.synchronize()
+        leftb = ops.RecordBatch.from_arrays(ctx, ["k"], [ctx.wrap_tensor(bkb, capi.INT64)])
+        rightb = ops.RecordBatch.from_arrays(ctx, ["k", "v"], [ctx.wrap_tensor(pkb, capi.INT64), ctx.wrap_tensor(pvb, capi.INT64)])
+        jb = ops.HashJoinExec(ops.MemoryExec([[leftb]], leftb.schema), ops.MemoryExec([[rightb]], rightb.schema), [(C("k", 0), C("k", 0))], None, "Inner", "CollectLeft")
+        planb = ops.AggregateExec("Single", [], [ops.AggregateFunctionExpr("SUM", C("v", 2), "s", input_field=F("v", capi.INT64)), ops.AggregateFunctionExpr("COUNT", None, "c")], jb)
+        dt, rows, kern, syncs = time_plan(ctx, ops, tc, planb, args.steps, args.warmup)
+        res = result_columns(LAST_OUT[0]); LAST_OUT[0] = None
+        sb = torch.sort(bkb).values; pos = torch.searchsorted(sb, pkb).clamp_(max=nbb - 1); hit = sb[pos] == pkb
+        ok = int(res[1][0]) == int(hit.sum().item()) and wrap64(int(res[0][0])) == wrap64(int(pvb[hit].sum().item()))
+        del sb, pos, hit
+        report("hash_join_big_build", dt, nbb + npb, rows, round((nbb * 8 + npb * 16) / (nbb + npb), 2), kern, syncs, {"build_rows": nbb, "probe_rows": npb, "match_fraction": 0.2,
+               "result_check": check("hash_join_big_build", ok, "COUNT(*) and SUM(v) over the join output == torch sort + searchsorted over the same keys")})
+        del bkb, pkb, pvb, leftb, rightb, jb, planb
+        torch.cuda.empty_cache()
     if not want or "hash_join" in want or "hash_join_plain" in want or "hash_join_fk5" in want or "hash_join_two_keys" in want:          # hash_join = every variant; _plain / _fk5 / _two_keys = one of them (profiling passes)
         do_plain, do_fk5 = (not want or "hash_join" in want or "hash_join_plain" in want), (not want or "hash_join" in want or "hash_join_fk5" in want)
         do_two = not want or "hash_join" in want or "hash_join_two_keys" in want
