@@ -104,6 +104,7 @@ DFGPU_API dfgpu_status dfgpu_ctx_synchronize(dfgpu_ctx *ctx);
  * "join_partitioned" (1/0), "join_partitioned_min_build" / "join_partitioned_min_probe" (rows), "join_partition_rows" (build rows per partition, <= 14000) ==
  * radix-partitioned hash join (csrc/pjoin.hip): large builds on unsorted integer keys with a sparse domain are split by key hash so that
  * every partition's table sits in LDS; probe batches of >= min_probe rows are partitioned the same way.  Pairs and their order are identical;
+ * "join_partitioned_big" (1/0) == builds of more than 2048 x join_partition_rows rows take up to 4096 partitions instead of declining to the global table (pairs identical);
  * "join_partitioned_hashed" (1/0) == large builds on key columns that mode does not take (several columns that do not pack, Utf8 / dictionary keys, null_equals_null) go through
  * the same path on 64-bit key hashes, every emitted pair verified in the columns; "join_partitioned_hash_mask" (0 = all bits; tests) == bits of the hash that are kept;
  * "agg_partitioned" (1/0), "agg_partitioned_min_rows", "agg_partitioned_force" (1 = skip the sample's verdict; tests) == let the plan layer's
