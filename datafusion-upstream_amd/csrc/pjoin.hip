@@ -6,7 +6,8 @@
 // Why: the global open-addressing table of join.hip costs every probe row a random 64-B sector out of a table far larger than L2
 // (150 M probes of a 15 M-row build: ~53 G sectors/s on MI355X whatever the table's size beyond L2, i.e. >= 2.8 ms).  Here both sides are
 // split by hash bits into P <= 2048 partitions so that one partition's table -- 16 K four-byte slots (tag : 17 | partition-local index : 14)
-// -- sits in 64 KB of LDS, two workgroups per CU.
+// -- sits in 64 KB of LDS, two workgroups per CU.  Builds beyond 2048 x 14 000 rows take up to 4096 partitions (round 4: the offset loops of the scatter, the restore and
+// the partition starts instantiated with four partitions per thread; 40 M x 150 M rows: 4.7 ms against 8.1 ms through the global table); beyond 4096 x 14 000 they decline.
 //
 // Round 3 pipeline (profiles/experiments/pjoin2_microbench.hip holds the measurements that chose it; 15 M x 150 M rows, 20 % match):
 //   partition   k_pj_hist     per chunk of 16 tiles (8192 rows each): LDS histogram in u16 counters with the next tile's keys in flight; writes
