@@ -106,10 +106,10 @@ def test_partitioned_equals_general_path(ctx):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
-def test_partitioned_nulls_and_fused_selections(ctx):
-    nb, npr = 30000, 120000
+@pytest.mark.parametrize("nb,npr,per", [(30000, 120000, 200), (240000, 300000, 64)], ids=["150-partitions", "3840-partitions"])
+def test_partitioned_nulls_and_fused_selections(ctx, nb, npr, per):
     b = unique_keys(nb); p = probe_keys(b, npr, 0.5)
-    with forced(ctx, 200) as f:
+    with forced(ctx, per) as f:
         m = check(ctx, b, p, bmask=RNG.random(nb) < 0.7, pmask=RNG.random(npr) < 0.6, bnull=RNG.random(nb) < 0.1, pnull=RNG.random(npr) < 0.1)
         assert m > 1000 and "pj_join" in f.kernels()
 
