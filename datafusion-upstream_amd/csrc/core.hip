@@ -425,7 +425,6 @@ dfgpu_status dfgpu_ctx_set_option(dfgpu_ctx* ctx, const char* key, int64_t value
     else if (k == "join_rank_index_unsorted") ctx->join_rank_index_unsorted = value != 0;
     else if (k == "join_lazy_build_rows") ctx->join_lazy_build_rows = value != 0;
     else if (k == "join_selection_output") ctx->join_selection_output = value != 0;
-    else if (k == "agg_combine_min_lanes") ctx->agg_combine_min_lanes = value < 2 ? 2 : value > 65 ? 65 : (int)value;
     else if (k == "agg_order_inverse_map") ctx->agg_order_inverse_map = value != 0;
     else if (k == "join_bitmap_partitioned") ctx->join_bitmap_partitioned = value != 0;
     else if (k == "join_bitmap_partitioned_min_rows") ctx->join_bitmap_partitioned_min_rows = value;

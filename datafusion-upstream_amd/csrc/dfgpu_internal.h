@@ -65,7 +65,6 @@ struct dfgpu_ctx {
   bool agg_order_inverse_map = true;   // pre-aggregation with millions of partial rows: first-seen order through an inverse map over the input rows (pagg.hip) instead of a stable sort
   int64_t agg_pack_estimate_min_rows = 1 << 22;   // packed group keys: batches of at least this many rows take their value ranges from a sample (checked row by row while packing)
   bool pa_last_distinct = false;    // the last dfgpu_agg_preaggregate call emitted every key once
-  int agg_combine_min_lanes = 16;                              // pre-aggregation: a key that this many lanes of a wave carry is combined in registers before it touches the LDS table
   const void* pa_sample_key = nullptr; const void* pa_sample_mask = nullptr; int64_t pa_sample_n = 0; uint64_t pa_sample[3] = {0, 0, 0};   // sample of a verdict-only dfgpu_agg_preaggregate call
   // 2..4 key columns packed into one u64 by that verdict-only call (kept for the call that follows on the same columns): key = sum((v - min + nullable) * stride), 0 in a nullable column's digit = NULL
   std::shared_ptr<dfgpu::Buffer> pa_pack; int pa_pack_n = 0; int64_t pa_pack_min[4] = {0, 0, 0, 0}; uint64_t pa_pack_stride[4] = {0, 0, 0, 0}, pa_pack_range[4] = {0, 0, 0, 0}; bool pa_pack_nullable[4] = {false, false, false, false};

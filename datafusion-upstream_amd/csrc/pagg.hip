@@ -104,37 +104,10 @@ __global__ void __launch_bounds__(PA_NT) k_pa_items(const uint32_t* pstart, uint
 }
 // two-level partition: fine partition = (low hash bits -> P2) * P1 + (high hash bits -> P1)
 __device__ inline uint32_t pa_fine_pid(uint64_t k, uint32_t P1, uint32_t P2) { uint64_t h = mix64(k); return (uint32_t)(((h & 0xFFFFFFFFull) * (uint64_t)P2) >> 32) * P1 + rp_pid(h, P1); }
-// wave reduction by DPP moves (no LDS crossbar): quad swaps, half-row and row mirrors, then the row broadcasts of gfx9 -- lane 63 ends up holding the combination of all 64
-// lanes.  `id` is what a lane outside a step's row mask contributes (the operation's identity).
-template <int CTRL, int ROWS>
-__device__ inline uint64_t pa_dpp64(uint64_t id, uint64_t x) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)id, (int)(uint32_t)x, CTRL, ROWS, 0xF, false);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(id >> 32), (int)(uint32_t)(x >> 32), CTRL, ROWS, 0xF, false);
-  return ((uint64_t)hi << 32) | lo;
-}
-__device__ inline uint64_t pa_readlane64(uint64_t x, int lane) {
-  return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), lane) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, lane);
-}
-__device__ inline uint64_t pa_wave_combine(int op, uint64_t x) {          // -> the combination over the wave (every lane passes its value, or the identity)
-  const uint64_t id = pa_identity(op);
-  x = pa_combine(op, x, pa_dpp64<0xB1, 0xF>(id, x));          // quad_perm [1,0,3,2]
-  x = pa_combine(op, x, pa_dpp64<0x4E, 0xF>(id, x));          // quad_perm [2,3,0,1]
-  x = pa_combine(op, x, pa_dpp64<0x141, 0xF>(id, x));         // row_half_mirror
-  x = pa_combine(op, x, pa_dpp64<0x140, 0xF>(id, x));         // row_mirror: every lane holds its row of 16
-  x = pa_combine(op, x, pa_dpp64<0x142, 0xA>(id, x));         // row_bcast15 into rows 1 and 3
-  x = pa_combine(op, x, pa_dpp64<0x143, 0xC>(id, x));         // row_bcast31 into rows 2 and 3
-  return pa_readlane64(x, 63);
-}
-__device__ inline uint32_t pa_wave_min_u32(uint32_t x) {
-#define PA_MIN_STEP(CTRL, ROWS) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, CTRL, ROWS, 0xF, false); x = o < x ? o : x; }
-  PA_MIN_STEP(0xB1, 0xF) PA_MIN_STEP(0x4E, 0xF) PA_MIN_STEP(0x141, 0xF) PA_MIN_STEP(0x140, 0xF) PA_MIN_STEP(0x142, 0xA) PA_MIN_STEP(0x143, 0xC)
-#undef PA_MIN_STEP
-  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
-}
 template <bool I128, bool FLAGS>          // I128: the plan holds Decimal128 cell pairs / strided value columns; FLAGS: some argument is nullable (flag byte per row).  The plain instantiation is the round-2 kernel (the I128 branches cost it 6 %, the flag tests 15 %)
 __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, const uint32_t* prow, PaPlan plan_arg, const uint32_t* pstart, const uint32_t* item_start, uint32_t P, int cbits, uint32_t slice,
                                                       uint64_t* orec /* records of `rs` words: key, count, accumulator cells */, int rs, uint32_t* ofirst, unsigned long long* cursor /*[0] rows written, [2] tables flushed before their partition ended*/,
-                                                      uint32_t P1, uint32_t P2, uint32_t* misplaced /* two-level partition (P1 != 0): set when a row sits in a partition its key does not hash to */, int comb_min) {
+                                                      uint32_t P1, uint32_t P2, uint32_t* misplaced /* two-level partition (P1 != 0): set when a row sits in a partition its key does not hash to */) {
   extern __shared__ unsigned long long pa_lds[];
   const uint32_t C = 1u << cbits, M = C - 1, C1 = C + 1;
   unsigned long long* keys = pa_lds; unsigned long long* acc = pa_lds + C1;
@@ -211,24 +184,21 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
     // and combining them once, when another key takes over or the slice ends, was tried as well (call aa): Zipf 2.36 -> 2.16 ms, but every other shape lost 10-30 % to the
     // longer loop body -- uniform ClickBench 1.07 -> 1.27 ms, 20 M groups 1.64 -> 1.75, three keys + Decimal128 1.04 -> 1.35 -- and it was taken out again.)
     uint32_t cntv = 1; uint32_t rowv = row; bool mine = on;
-    if constexpr (!I128) {
-      // up to three candidate keys per round: the key of the first active lane not dealt with yet; a key that at least `comb_min` lanes carry is combined in registers
-      // (DPP reductions, ~6 moves per word) and its first lane alone touches the table
-      const uint64_t act = ballot64(on); uint64_t handled = 0;
-#pragma unroll 1
-      for (int attempt = 0; attempt < 3; attempt++) {
-        const uint64_t rem = act & ~handled; if (!rem) break;
-        const int lead = __ffsll((long long)rem) - 1;
-        const uint64_t k0 = pa_readlane64(k, lead);
-        const bool member = on && !((handled >> lane) & 1ull) && k == k0;
-        const uint64_t mem = ballot64(member);
-        handled |= mem;
-        if (__popcll(mem) < comb_min) continue;
-        const uint32_t r = pa_wave_min_u32(member ? row : 0xFFFFFFFFu);
+    {
+      const uint64_t act = ballot64(on);
+      const int lead = act ? __ffsll((long long)act) - 1 : 0;
+      const uint32_t k0lo = (uint32_t)__shfl((int)(uint32_t)k, lead, 64), k0hi = (uint32_t)__shfl((int)(uint32_t)(k >> 32), lead, 64);
+      const bool member = on && (uint32_t)k == k0lo && (uint32_t)(k >> 32) == k0hi;
+      const uint64_t mem = ballot64(member);
+      if (__popcll(mem) >= 16 && !I128) {
+        uint32_t r = member ? row : 0xFFFFFFFFu;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)r, d, 64); r = o < r ? o : r; }
 #pragma unroll
         for (int a = 0; a < PA_MAX_AGGS; a++) if (a < na) {
-          const int op = plan_arg.op[a];
-          const uint64_t x = pa_wave_combine(op, member ? v[a] : pa_identity(op));
+          const int op = plan_arg.op[a]; uint64_t x = member ? v[a] : pa_identity(op);
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) { uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, d, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), d, 64); x = pa_combine(op, x, ((uint64_t)hi << 32) | lo); }
           if (lane == lead) v[a] = x;
         }
         if (lane == lead) { cntv = (uint32_t)__popcll(mem); rowv = r; } else if (member) mine = false;
@@ -665,7 +635,7 @@ extern "C" dfgpu_status dfgpu_agg_preaggregate_flags(dfgpu_ctx* ctx, const dfgpu
 #define PA_AGG(I, F) do { HIP_CHECK(hipFuncSetAttribute((const void*)k_pa_aggregate<I, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));      /* per device: set on every call, no process-wide flag */ \
         hipLaunchKernelGGL((k_pa_aggregate<I, F>), dim3(grid), dim3(PA_NT), lds, ctx->stream, (const uint64_t*)pkey->ptr, prow ? (const uint32_t*)prow->ptr : (const uint32_t*)nullptr, plan, (const uint32_t*)r.starts->ptr, \
                            items ? (const uint32_t*)items->ptr : nullptr, (uint32_t)P, cbits, (uint32_t)slice, (uint64_t*)orec->ptr, rs, (uint32_t*)ofirst->ptr, (unsigned long long*)(ctx->d_scratch64 + 12), \
-                           two_level ? (uint32_t)P1 : 0u, (uint32_t)P2, (uint32_t*)(ctx->d_scratch64 + 11), ctx->agg_combine_min_lanes); } while (0)
+                           two_level ? (uint32_t)P1 : 0u, (uint32_t)P2, (uint32_t*)(ctx->d_scratch64 + 11)); } while (0)
       if (n_flags) { if (plan.has_i128) PA_AGG(true, true); else PA_AGG(false, true); }
       else { if (plan.has_i128) PA_AGG(true, false); else PA_AGG(false, false); }
 #undef PA_AGG
