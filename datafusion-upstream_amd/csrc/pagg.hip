@@ -182,7 +182,8 @@ __global__ void __launch_bounds__(PA_NT) k_pa_aggregate(const uint64_t* pkey, co
     // first -- a key with a fifth to a half of its partition's rows sits in the first lane only that often -- was measured on the Zipf ClickBench shape and changed
     // nothing: 2.34 -> 2.49 ms, round 4 call r; the partitions there hold several warm keys each, not one.  Keeping the hot key's rows in accumulators of the lanes' own
     // and combining them once, when another key takes over or the slice ends, was tried as well (call aa): Zipf 2.36 -> 2.16 ms, but every other shape lost 10-30 % to the
-    // longer loop body -- uniform ClickBench 1.07 -> 1.27 ms, 20 M groups 1.64 -> 1.75, three keys + Decimal128 1.04 -> 1.35 -- and it was taken out again.)
+    // longer loop body -- uniform ClickBench 1.07 -> 1.27 ms, 20 M groups 1.64 -> 1.75, three keys + Decimal128 1.04 -> 1.35 -- and it was taken out again.  Nor did trying up to three candidate keys per round with DPP reductions in place of the shuffles (call ai): Zipf 2.36 -> 3.04 ms at the same threshold
+    // of 16 lanes, 3.5 / 3.8 ms at 8 / 4; uniform 1.07 -> 1.2 ms.)
     uint32_t cntv = 1; uint32_t rowv = row; bool mine = on;
     {
       const uint64_t act = ballot64(on);
